@@ -1,0 +1,357 @@
+"""CPU oracle: NumPy restatement of the TensorFlow/Keras ops on the DeepLabV3+ hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product package imports this module; only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may.
+
+PARITY UNPINNED: the reference's arithmetic lives in ``tensorflow==2.11.0``
+(/root/reference/requirements.txt:9), which is not installed and cannot be installed here, and the
+reference holds no golden vectors.  The TF semantics below are restated from the
+published TF/Keras behaviour and triangulated against an independent implementation (torch CPU
+ops) in ``tests/test_oracle_ops.py``.
+
+Every op is a forward/backward pair on NHWC arrays.  dtype follows the inputs (float64 is the
+authoritative precision, float32 is used for the timed CPU baseline).
+
+Reference call sites restated here:
+  * Conv2D / DepthwiseConv2D wrappers      deeplabv3p/models/layers.py:14-31
+  * SAME / explicit padding                deeplabv3p/models/layers.py:85-96, deeplabv3p_xception.py:25-54
+  * BatchNormalization                     deeplabv3p/models/layers.py:63-70
+  * tf.image.resize(bilinear)              deeplabv3p/models/layers.py:48-60
+  * AveragePooling2D(pool=(h,w))           deeplabv3p/models/layers.py:132
+  * ReLU / ReLU6 / hard-swish              deeplabv3p_mobilenetv2.py:52,61  deeplabv3p_mobilenetv3.py:98-103
+  * softmax + sparse CE with ignore index  deeplabv3p/model.py:86, deeplabv3p/loss.py:121-156
+  * SGD momentum                           common/model_utils.py:124
+"""
+import math
+import numpy as np
+
+# --------------------------------------------------------------------------------------
+# padding
+# --------------------------------------------------------------------------------------
+
+def same_pad_1d(in_size, k, stride, rate):
+    """TF 'SAME' padding for one spatial dim -> (out_size, pad_begin, pad_end).
+
+    out = ceil(in/stride); pad_total = max((out-1)*stride + k_eff - in, 0); the odd unit goes to the
+    END (bottom/right).  k_eff = k + (k-1)(rate-1).
+    """
+    k_eff = k + (k - 1) * (rate - 1)
+    out = -(-in_size // stride)
+    pad_total = max((out - 1) * stride + k_eff - in_size, 0)
+    beg = pad_total // 2
+    return out, beg, pad_total - beg
+
+
+def valid_out_1d(in_size_padded, k, stride, rate):
+    k_eff = k + (k - 1) * (rate - 1)
+    return (in_size_padded - k_eff) // stride + 1
+
+
+def resolve_padding(H, W, k, stride, rate, padding):
+    """padding: 'same' | 'valid' | (pt, pb, pl, pr) explicit (ZeroPadding2D + VALID).
+    returns Ho, Wo, (pt, pb, pl, pr)"""
+    if padding == 'same':
+        Ho, pt, pb = same_pad_1d(H, k, stride, rate)
+        Wo, pl, pr = same_pad_1d(W, k, stride, rate)
+        return Ho, Wo, (pt, pb, pl, pr)
+    if padding == 'valid':
+        padding = (0, 0, 0, 0)
+    pt, pb, pl, pr = padding
+    return (valid_out_1d(H + pt + pb, k, stride, rate),
+            valid_out_1d(W + pl + pr, k, stride, rate), (pt, pb, pl, pr))
+
+
+def _pad_nhwc(x, pads):
+    pt, pb, pl, pr = pads
+    if pt == pb == pl == pr == 0:
+        return x
+    return np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+
+
+def _tap_slice(Ho, Wo, ky, kx, stride, rate):
+    ys = slice(ky * rate, ky * rate + (Ho - 1) * stride + 1, stride)
+    xs = slice(kx * rate, kx * rate + (Wo - 1) * stride + 1, stride)
+    return ys, xs
+
+# --------------------------------------------------------------------------------------
+# convolutions (weights in Keras layout: dense HWIO (kh,kw,Cin,Cout); depthwise (kh,kw,C))
+# --------------------------------------------------------------------------------------
+
+def conv2d_fwd(x, w, stride=1, rate=1, padding='same', bias=None):
+    N, H, W, Cin = x.shape
+    kh, kw, _, Cout = w.shape
+    Ho, Wo, pads = resolve_padding(H, W, kh, stride, rate, padding)
+    if kh == 1 and kw == 1 and stride == 1:
+        y = (x.reshape(-1, Cin) @ w[0, 0]).reshape(N, H, W, Cout)
+    else:
+        xp = _pad_nhwc(x, pads)
+        y = np.zeros((N, Ho, Wo, Cout), dtype=x.dtype)
+        for ky in range(kh):
+            for kx in range(kw):
+                ys, xs = _tap_slice(Ho, Wo, ky, kx, stride, rate)
+                y += (xp[:, ys, xs, :].reshape(-1, Cin) @ w[ky, kx]).reshape(N, Ho, Wo, Cout)
+    if bias is not None:
+        y = y + bias
+    return y
+
+
+def conv2d_bwd(x, w, gy, stride=1, rate=1, padding='same', need_gx=True):
+    """returns (gx, gw, gb)"""
+    N, H, W, Cin = x.shape
+    kh, kw, _, Cout = w.shape
+    Ho, Wo, pads = resolve_padding(H, W, kh, stride, rate, padding)
+    gy2 = gy.reshape(-1, Cout)
+    gb = gy2.sum(0)
+    gw = np.zeros_like(w)
+    if kh == 1 and kw == 1 and stride == 1:
+        gw[0, 0] = x.reshape(-1, Cin).T @ gy2
+        gx = (gy2 @ w[0, 0].T).reshape(x.shape) if need_gx else None
+        return gx, gw, gb
+    xp = _pad_nhwc(x, pads)
+    gxp = np.zeros_like(xp) if need_gx else None
+    for ky in range(kh):
+        for kx in range(kw):
+            ys, xs = _tap_slice(Ho, Wo, ky, kx, stride, rate)
+            gw[ky, kx] = xp[:, ys, xs, :].reshape(-1, Cin).T @ gy2
+            if need_gx:
+                gxp[:, ys, xs, :] += (gy2 @ w[ky, kx].T).reshape(N, Ho, Wo, Cin)
+    gx = None
+    if need_gx:
+        pt, pb, pl, pr = pads
+        gx = gxp[:, pt:pt + H, pl:pl + W, :]
+    return gx, gw, gb
+
+
+def dwconv2d_fwd(x, w, stride=1, rate=1, padding='same'):
+    N, H, W, C = x.shape
+    kh, kw, _ = w.shape
+    Ho, Wo, pads = resolve_padding(H, W, kh, stride, rate, padding)
+    xp = _pad_nhwc(x, pads)
+    y = np.zeros((N, Ho, Wo, C), dtype=x.dtype)
+    for ky in range(kh):
+        for kx in range(kw):
+            ys, xs = _tap_slice(Ho, Wo, ky, kx, stride, rate)
+            y += xp[:, ys, xs, :] * w[ky, kx]
+    return y
+
+
+def dwconv2d_bwd(x, w, gy, stride=1, rate=1, padding='same'):
+    """returns (gx, gw)"""
+    N, H, W, C = x.shape
+    kh, kw, _ = w.shape
+    Ho, Wo, pads = resolve_padding(H, W, kh, stride, rate, padding)
+    xp = _pad_nhwc(x, pads)
+    gxp = np.zeros_like(xp)
+    gw = np.zeros_like(w)
+    for ky in range(kh):
+        for kx in range(kw):
+            ys, xs = _tap_slice(Ho, Wo, ky, kx, stride, rate)
+            gw[ky, kx] = np.einsum('nyxc,nyxc->c', xp[:, ys, xs, :], gy)
+            gxp[:, ys, xs, :] += gy * w[ky, kx]
+    pt, pb, pl, pr = pads
+    return gxp[:, pt:pt + H, pl:pl + W, :], gw
+
+# --------------------------------------------------------------------------------------
+# batch normalisation (Keras BatchNormalization, fused kernel semantics)
+# --------------------------------------------------------------------------------------
+
+def bn_train_fwd(x, gamma, beta, eps):
+    """Training-mode BN over (N,H,W).  Normalises with the BIASED batch variance.
+    returns y, cache, (batch_mean, batch_var_unbiased) for the moving-average update
+    (TF FusedBatchNormV3 feeds the Bessel-corrected variance into the moving average;
+    count-1 is clamped to >= 1)."""
+    C = x.shape[-1]
+    x2 = x.reshape(-1, C)
+    m = x2.shape[0]
+    mean = x2.mean(0)
+    var = ((x2 - mean) ** 2).mean(0)
+    invstd = 1.0 / np.sqrt(var + eps)
+    xhat = (x - mean) * invstd
+    y = xhat * gamma + beta
+    var_unbiased = var * (m / max(m - 1, 1))
+    return y, (xhat, invstd, gamma), (mean, var_unbiased)
+
+
+def bn_train_bwd(gy, cache):
+    """returns gx, ggamma, gbeta"""
+    xhat, invstd, gamma = cache
+    C = gy.shape[-1]
+    g2 = gy.reshape(-1, C)
+    xh2 = xhat.reshape(-1, C)
+    m = g2.shape[0]
+    gbeta = g2.sum(0)
+    ggamma = (g2 * xh2).sum(0)
+    gx = (gamma * invstd) * (gy - gbeta / m - xhat * (ggamma / m))
+    return gx, ggamma, gbeta
+
+
+def bn_infer_fwd(x, gamma, beta, moving_mean, moving_var, eps):
+    scale = gamma / np.sqrt(moving_var + eps)
+    return x * scale + (beta - moving_mean * scale)
+
+
+def bn_moving_update(moving, batch_value, momentum):
+    return moving * momentum + batch_value * (1.0 - momentum)
+
+# --------------------------------------------------------------------------------------
+# activations
+# --------------------------------------------------------------------------------------
+ACT_NONE, ACT_RELU, ACT_RELU6, ACT_HSWISH, ACT_HSIGMOID = 0, 1, 2, 3, 4
+
+
+def act_fwd(x, act):
+    if act == ACT_NONE:
+        return x
+    if act == ACT_RELU:
+        return np.maximum(x, 0)
+    if act == ACT_RELU6:
+        return np.minimum(np.maximum(x, 0), 6)
+    if act == ACT_HSIGMOID:
+        return np.minimum(np.maximum(x + 3, 0), 6) * (1.0 / 6.0)
+    if act == ACT_HSWISH:
+        return x * (np.minimum(np.maximum(x + 3, 0), 6) * (1.0 / 6.0))
+    raise ValueError(act)
+
+
+def act_bwd(x, gy, act):
+    """x = pre-activation input.  Sub-gradient conventions follow TF: ReLU'(0)=0, ReLU6'(6)=0."""
+    if act == ACT_NONE:
+        return gy
+    if act == ACT_RELU:
+        return gy * (x > 0)
+    if act == ACT_RELU6:
+        return gy * ((x > 0) & (x < 6))
+    if act == ACT_HSIGMOID:
+        return gy * (((x + 3) > 0) & ((x + 3) < 6)) * (1.0 / 6.0)
+    if act == ACT_HSWISH:
+        inner = ((x + 3) > 0) & ((x + 3) < 6)
+        hs = np.minimum(np.maximum(x + 3, 0), 6) * (1.0 / 6.0)
+        return gy * (hs + x * inner * (1.0 / 6.0))
+    raise ValueError(act)
+
+# --------------------------------------------------------------------------------------
+# pooling / resize
+# --------------------------------------------------------------------------------------
+
+def global_avgpool_fwd(x):
+    return x.mean(axis=(1, 2), keepdims=True)
+
+
+def global_avgpool_bwd(gy, H, W):
+    return np.broadcast_to(gy / (H * W), (gy.shape[0], H, W, gy.shape[3])).copy()
+
+
+def bilinear_coeffs(in_size, out_size):
+    """tf.image.resize(method='bilinear') in TF2: half_pixel_centers=True, align_corners=False,
+    antialias=False.  Source coordinate arithmetic is done in float32 exactly as TF's
+    compute_interpolation_weights: scale=in/out (float); src=(o+0.5f)*scale-0.5f;
+    lo=max(floor(src),0); hi=min(ceil(src),in-1); lerp=src-floor(src)."""
+    scale = np.float32(in_size) / np.float32(out_size)
+    o = np.arange(out_size, dtype=np.float32)
+    src = (o + np.float32(0.5)) * scale - np.float32(0.5)
+    fl = np.floor(src)
+    lo = np.maximum(fl.astype(np.int64), 0)
+    hi = np.minimum(np.ceil(src).astype(np.int64), in_size - 1)
+    t = (src - fl).astype(np.float32)
+    return lo, hi, t
+
+
+def bilinear_matrix(in_size, out_size, dtype):
+    lo, hi, t = bilinear_coeffs(in_size, out_size)
+    R = np.zeros((out_size, in_size), dtype=dtype)
+    r = np.arange(out_size)
+    np.add.at(R, (r, lo), (1.0 - t.astype(dtype)))
+    np.add.at(R, (r, hi), t.astype(dtype))
+    return R
+
+
+def _apply_axis(R, x, axis):
+    xm = np.moveaxis(x, axis, 0)
+    shp = xm.shape
+    y = (R @ xm.reshape(shp[0], -1)).reshape((R.shape[0],) + shp[1:])
+    return np.moveaxis(y, 0, axis)
+
+
+def resize_bilinear_fwd(x, out_h, out_w):
+    N, H, W, C = x.shape
+    Ry = bilinear_matrix(H, out_h, x.dtype)
+    Rx = bilinear_matrix(W, out_w, x.dtype)
+    return _apply_axis(Rx, _apply_axis(Ry, x, 1), 2)
+
+
+def resize_bilinear_bwd(gy, in_h, in_w):
+    N, Ho, Wo, C = gy.shape
+    Ry = bilinear_matrix(in_h, Ho, gy.dtype)
+    Rx = bilinear_matrix(in_w, Wo, gy.dtype)
+    return _apply_axis(Rx.T, _apply_axis(Ry.T, gy, 1), 2)
+
+# --------------------------------------------------------------------------------------
+# dropout (mask injected so that stochastic runs are reproducible across implementations)
+# --------------------------------------------------------------------------------------
+
+def dropout_fwd(x, keep_mask, rate):
+    return x * keep_mask * (1.0 / (1.0 - rate))
+
+
+def dropout_bwd(gy, keep_mask, rate):
+    return gy * keep_mask * (1.0 / (1.0 - rate))
+
+# --------------------------------------------------------------------------------------
+# softmax + sparse categorical cross-entropy on probabilities (loss.py:121-156)
+# --------------------------------------------------------------------------------------
+CE_EPS = 1e-7
+
+
+def softmax_fwd(z):
+    zmax = z.max(-1, keepdims=True)
+    e = np.exp(z - zmax)
+    return e / e.sum(-1, keepdims=True)
+
+
+def sparse_ce_fwd_bwd(logits, labels, ignore_index=255):
+    """logits (..., C); labels (...) integer-valued float/ints (data.py:116-124).
+    returns (loss_mean, probs, dlogits).
+
+    Keras semantics: mask=(y != ignore) [only if ignore_index is truthy, loss.py:139];
+    one_hot(255) is an all-zero row; categorical_crossentropy renormalises p/sum(p), clips to
+    [1e-7, 1-1e-7] and returns -sum(onehot*log p); Keras reduces with the mean over ALL entries
+    (ignored pixels stay in the denominator)."""
+    C = logits.shape[-1]
+    p = softmax_fwd(logits)
+    lab = labels.astype(np.int64)
+    flat_p = p.reshape(-1, C)
+    flat_l = lab.reshape(-1)
+    M = flat_l.shape[0]
+    in_range = (flat_l >= 0) & (flat_l < C)
+    mask = np.ones(M, dtype=bool)
+    if ignore_index:
+        mask = flat_l != ignore_index
+    active = in_range & mask
+    idx = np.where(active)[0]
+    pt = flat_p[idx, flat_l[idx]]
+    pt_c = np.clip(pt, CE_EPS, 1.0 - CE_EPS)
+    loss = -np.log(pt_c).sum() / M
+    g = np.zeros_like(flat_p)
+    unclipped = (pt > CE_EPS) & (pt < 1.0 - CE_EPS)
+    rows = idx[unclipped]
+    g[rows] = flat_p[rows]
+    g[rows, flat_l[rows]] -= 1.0
+    g /= M
+    return loss, p, g.reshape(logits.shape)
+
+# --------------------------------------------------------------------------------------
+# optimiser: Keras SGD(momentum=0.9, nesterov=False) + l2 regulariser gradient
+# --------------------------------------------------------------------------------------
+L2_FACTOR = 2e-5  # layers.py:12
+
+
+def sgd_momentum_step(w, v, g, lr, momentum, l2=0.0):
+    """v <- momentum*v - lr*(g + 2*l2*w);  w <- w + v      (common/model_utils.py:124)"""
+    g_total = g + (2.0 * l2) * w
+    v_new = momentum * v - lr * g_total
+    return w + v_new, v_new
+
+
+def glorot_uniform(rng, shape, fan_in, fan_out, dtype=np.float64):
+    limit = math.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-limit, limit, size=shape).astype(dtype)
