@@ -1,0 +1,208 @@
+/*
+ * dl3p.h -- C ABI of libdl3p.so: the MI355X (gfx950) native DeepLabV3+ forward/backward hot path.
+ *
+ * The reference (david8862/tf-keras-deeplabv3p-model-set) has no FFI of its own: its boundary is the
+ * Python factory get_deeplabv3p_model() (deeplabv3p/model.py:51) and all arithmetic happens inside
+ * tf.keras layers.  Each entry point below replaces the TensorFlow op that one reference call site
+ * lowers to; the citation names that call site.
+ *
+ * Conventions
+ *   - all tensors are fp32, NHWC, addressed as rows of pixels: element (row m, channel c) lives at
+ *     base[m*ld + c]; `ld` (row stride in floats) lets an op read/write a channel slice of a wider
+ *     concat buffer (layers.py:155,214 Concatenate costs no pass).
+ *   - raw DEVICE pointers; the caller allocates and owns every buffer (torch caching allocator);
+ *     the library keeps no references and allocates nothing.
+ *   - every call is asynchronous and ordered on `stream` (a hipStream_t passed as void*); calls are
+ *     hipGraph-capture safe (no allocation, no synchronisation).
+ *   - returns 0 on success or a negative DL3P_E* code; dl3p_last_error_string() describes the last
+ *     failure of the calling thread.  Nothing throws or exits across this boundary.
+ *   - "prologue": a conv input may be given as the RAW output z of the producing conv together with
+ *     the per-channel affine (in_scale, in_shift) of the BatchNormalization that follows it and an
+ *     activation code; the kernel then consumes act(z*scale+shift) on the fly, so normalised
+ *     activations are never materialised (layers.py:102-108 BN+ReLU between convs).
+ *     in_scale == NULL means identity affine.
+ *   - "stat partials": producers emit per-block partial sums [rows][2][C] (sum, sum of squares) of
+ *     their raw output; dl3p_bn_finalize reduces them.  *rows_out receives the number of rows the
+ *     launch will write (a host-side value, known before the kernel runs).
+ */
+#ifndef DL3P_H_
+#define DL3P_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DL3P_VERSION 100
+
+enum {
+  DL3P_OK = 0,
+  DL3P_EINVAL = -1,    /* bad argument (shape, alignment, null pointer) */
+  DL3P_EUNSUPPORTED = -2,
+  DL3P_ELAUNCH = -3,   /* hipLaunch / runtime error */
+  DL3P_EWORKSPACE = -4 /* workspace too small */
+};
+
+/* activation codes (ReLU: layers.py:98; ReLU6: deeplabv3p_mobilenetv2.py:52;
+ * hard_swish / hard_sigmoid: deeplabv3p_mobilenetv3.py:98-103) */
+enum { DL3P_ACT_NONE = 0, DL3P_ACT_RELU = 1, DL3P_ACT_RELU6 = 2, DL3P_ACT_HSWISH = 3, DL3P_ACT_HSIGMOID = 4 };
+
+#define DL3P_MAX_STAT_ROWS 2048
+
+int dl3p_version(void);
+const char* dl3p_last_error_string(void);
+/* number of compute units / XCDs the library sizes its grids for (256 / 8 on MI355X) */
+int dl3p_device_cus(void);
+
+/* ---------------------------------------------------------------- depthwise convolution
+ * replaces DepthwiseConv2D (DepthwiseConv2dNative [+SpaceToBatchND for dilation]) at
+ * layers.py:100 (SepConv_BN, ASPP rates 6/12/18), deeplabv3p_mobilenetv2.py:56,
+ * deeplabv3p_mobilenetv3.py:173.  w is the Keras depthwise kernel (k,k,C,1) == [k*k][C].
+ * pad_t/pad_l: zeros in front (TF SAME or explicit ZeroPadding2D, layers.py:85-96); the trailing
+ * pad follows from Ho/Wo.  C % 4 == 0, ld % 4 == 0. */
+int dl3p_dwconv2d_fwd(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                      const float* w, float* y, int ldy, float* stat_partials, int* rows_out,
+                      int N, int H, int W, int C, int k, int stride, int rate, int pad_t, int pad_l,
+                      int Ho, int Wo, void* stream);
+/* gx (+)= conv_transpose(dy).  dy is the gradient w.r.t. the raw conv output. */
+int dl3p_dwconv2d_bwd_data(const float* dy, int lddy, const float* w, float* gx, int ldgx, int accumulate,
+                           int N, int H, int W, int C, int k, int stride, int rate, int pad_t, int pad_l,
+                           int Ho, int Wo, void* stream);
+/* gw[k*k][C] = sum over pixels of act(x*scale+shift)[tap] * dy.  workspace: rows*k*k*C floats with
+ * rows <= DL3P_MAX_STAT_ROWS (query with dl3p_dwconv2d_bwd_weight_workspace). */
+size_t dl3p_dwconv2d_bwd_weight_workspace(int N, int Ho, int Wo, int C, int k);
+int dl3p_dwconv2d_bwd_weight(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                             const float* dy, int lddy, float* gw, float* workspace, size_t workspace_bytes,
+                             int N, int H, int W, int C, int k, int stride, int rate, int pad_t, int pad_l,
+                             int Ho, int Wo, void* stream);
+
+/* ---------------------------------------------------------------- pointwise (1x1) convolution
+ * replaces Conv2D(filters,(1,1)) -> Eigen/cuBLAS GEMM at layers.py:105,134,141,157,209,
+ * deeplabv3p_mobilenetv2.py:47,63, deeplabv3p_xception.py:81, model.py:75.
+ * y[M,N] = act(x[M,K]*scale+shift) @ w[K,N] (+ bias[N]);  w is the Keras kernel (1,1,K,N).
+ * MFMA f32 (v_mfma_f32_16x16x4_f32).  K % 4 == 0, N % 4 == 0, ld % 4 == 0. */
+int dl3p_pwconv_fwd(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                    const float* w, const float* bias, float* y, int ldy,
+                    float* stat_partials, int* rows_out, int M, int K, int N, void* stream);
+/* gx[M,K] (+)= dy[M,N] @ w[K,N]^T */
+int dl3p_pwconv_bwd_data(const float* dy, int lddy, const float* w, float* gx, int ldgx, int accumulate,
+                         int M, int K, int N, void* stream);
+/* gw[K,N] = act(x*scale+shift)^T @ dy ; gb[N] = column sums of dy (gb may be NULL). */
+size_t dl3p_pwconv_bwd_weight_workspace(int M, int K, int N);
+int dl3p_pwconv_bwd_weight(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                           const float* dy, int lddy, float* gw, float* gb,
+                           float* workspace, size_t workspace_bytes, int M, int K, int N, void* stream);
+
+/* ---------------------------------------------------------------- dense stem convolution
+ * replaces Conv2D(32,3,strides=2) on the RGB input (deeplabv3p_mobilenetv2.py:101,
+ * deeplabv3p_xception.py:119, deeplabv3p_mobilenetv3.py:345) and the generic small dense conv
+ * (deeplabv3p_xception.py:123 entry_flow_conv1_2).  w is HWIO (k,k,Cin,Cout); Cout % 4 == 0. */
+int dl3p_conv2d_fwd(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                    const float* w, float* y, int ldy, float* stat_partials, int* rows_out,
+                    int N, int H, int W, int Cin, int Cout, int k, int stride, int rate,
+                    int pad_t, int pad_l, int Ho, int Wo, void* stream);
+size_t dl3p_conv2d_bwd_weight_workspace(int N, int Ho, int Wo, int Cin, int Cout, int k);
+int dl3p_conv2d_bwd_weight(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                           const float* dy, int lddy, float* gw, float* workspace, size_t workspace_bytes,
+                           int N, int H, int W, int Cin, int Cout, int k, int stride, int rate,
+                           int pad_t, int pad_l, int Ho, int Wo, void* stream);
+int dl3p_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* gx, int ldgx, int accumulate,
+                         int N, int H, int W, int Cin, int Cout, int k, int stride, int rate,
+                         int pad_t, int pad_l, int Ho, int Wo, void* stream);
+
+/* ---------------------------------------------------------------- batch normalisation
+ * replaces BatchNormalization/FusedBatchNormV3 (layers.py:63-70 CustomBatchNormalization).
+ * Training: biased batch variance normalises; the Bessel-corrected variance feeds the moving
+ * average  moving <- moving*momentum + batch*(1-momentum).
+ * dl3p_bn_finalize: partial rows [rows][2][C] -> scale = gamma*invstd, shift = beta - mean*scale,
+ * save_mean, save_invstd, and (update_moving) the moving statistics.  `count` = elements per
+ * channel that produced the sums (N*H*W, or the global count under SyncBN with rows == 1). */
+int dl3p_bn_reduce_partials(const float* partials, int rows, int C2, double* sums, void* stream);
+int dl3p_bn_finalize(const float* partials, int rows, const double* sums, int C, double count,
+                     const float* gamma, const float* beta, float eps, float momentum,
+                     float* moving_mean, float* moving_var, int update_moving,
+                     float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
+/* inference-mode coefficients from the moving statistics */
+int dl3p_bn_infer_coeffs(const float* gamma, const float* beta, const float* moving_mean,
+                         const float* moving_var, float eps, float* scale, float* shift,
+                         float* save_mean, float* save_invstd, int C, void* stream);
+/* backward, pass 1: with a = act(z*scale+shift), dyy = g * act'(.), accumulate per-channel partial
+ * sums [rows][2][C] of (dyy, dyy*xhat), xhat = (z-mean)*invstd. */
+int dl3p_bn_bwd_reduce(const float* g, int ldg, const float* z, int ldz, const float* scale, const float* shift,
+                       int act, const float* save_mean, const float* save_invstd,
+                       float* partials, int* rows_out, int M, int C, void* stream);
+/* pass 1b: partial rows (or all-reduced sums) -> dgamma, dbeta and the coefficients
+ * coef[3][C] = {gamma*invstd, sum(dyy)/count, sum(dyy*xhat)/count}.  frozen != 0: inference-mode
+ * BN, coef = {scale, 0, 0} and no parameter gradients. */
+int dl3p_bn_bwd_finalize(const float* partials, int rows, const double* sums, int C, double count,
+                         const float* gamma, const float* save_invstd, const float* scale, int frozen,
+                         float* dgamma, float* dbeta, float* coef, void* stream);
+/* pass 2: dz = coef0*(dyy - coef1 - xhat*coef2).  dz may alias g. */
+int dl3p_bn_bwd_apply(const float* g, int ldg, const float* z, int ldz, const float* scale, const float* shift,
+                      int act, const float* save_mean, const float* save_invstd, const float* coef,
+                      float* dz, int lddz, int M, int C, void* stream);
+
+/* ---------------------------------------------------------------- elementwise
+ * y = dropout(act(x*scale+shift)) [+ act2(r*rscale+rshift)]  -- materialises a lazy activation, the
+ * residual Add (deeplabv3p_mobilenetv2.py:70, deeplabv3p_xception.py:86-88) and Dropout(0.5)
+ * (layers.py:161).  dropout_rate == 0 disables dropout; the keep mask is a counter-based hash of
+ * (seed, *step_counter, element index) so backward can regenerate it. */
+int dl3p_affine_act(const float* x, int ldx, const float* scale, const float* shift, int act,
+                    const float* r, int ldr, const float* rscale, const float* rshift, int ract,
+                    float dropout_rate, uint64_t seed, const int64_t* step_counter,
+                    float* y, int ldy, int M, int C, void* stream);
+/* g_x (+)= g_y * dropout_mask/(1-rate)   (plain copy/accumulate when rate == 0) */
+int dl3p_scale_mask_bwd(const float* gy, int ldgy, float dropout_rate, uint64_t seed, const int64_t* step_counter,
+                        float* gx, int ldgx, int accumulate, int M, int C, void* stream);
+/* the keep mask the two kernels above use, as 0/1 floats [M][C] (test hook) */
+int dl3p_dropout_mask(float dropout_rate, uint64_t seed, const int64_t* step_counter, float* mask, int M, int C,
+                      void* stream);
+/* y = x * s[n]  with s (N,1,1,C) broadcast over HW pixels: SE block Multiply
+ * (deeplabv3p_mobilenetv3.py:145); x/s may carry prologues. */
+int dl3p_fill(float* p, float value, size_t n, void* stream);
+int dl3p_increment_counter(int64_t* counter, void* stream);
+
+/* ---------------------------------------------------------------- pooling / resize
+ * AveragePooling2D(pool=(h,w)) == global mean (layers.py:132); y [N][C] (ldy) = out_scale * mean
+ * (out_scale = HW turns it into the pixel sum that the broadcast branch's backward needs) */
+int dl3p_global_avgpool_fwd(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                            float* y, int ldy, float out_scale, int N, int HW, int C, void* stream);
+int dl3p_global_avgpool_bwd(const float* gy, int ldgy, float* gx, int ldgx, int accumulate,
+                            int N, int HW, int C, void* stream);
+/* tf.image.resize(method='bilinear'), half-pixel centres, no antialias (layers.py:48-60):
+ * src=(o+0.5)*in/out-0.5; lo=max(floor(src),0); hi=min(ceil(src),in-1); t=src-floor(src). */
+int dl3p_resize_bilinear_fwd(const float* x, int ldx, float* y, int ldy,
+                             int N, int h, int w, int C, int H, int W, void* stream);
+/* deterministic gather form of the transpose: gx[h,w] (+)= sum over the output pixels that read it */
+int dl3p_resize_bilinear_bwd(const float* gy, int ldgy, float* gx, int ldgx, int accumulate,
+                             int N, int h, int w, int C, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------- head: pred_resize + Softmax + loss
+ * model.py:76-86 (pred_resize, Reshape, Softmax 'pred_mask') fused with
+ * SparseCategoricalCrossEntropy(ignore_index) (loss.py:121-156): logits z [N,h,w,C] (ldz) are
+ * bilinearly upsampled to (H,W), softmax-ed; with labels != NULL the per-pixel loss
+ * -log(clip(p_y,1e-7,1-1e-7))*(y != ignore) is summed into loss_partials[rows] (scaled by
+ * inv_count = 1/(N*H*W) like Keras' mean over all entries) and dlogits_big [N,H,W,C] (ld C)
+ * receives (p - onehot)*mask*inv_count.  logits_big/dlogits_big rows have stride ld_big (>= C; with
+ * ld_big == C rounded up to 4 the rows are written as 16-B vectors and the pad channels as 0);
+ * probs is compact (N,H,W,C) as Keras returns it.  probs/logits_big/dlogits_big may each be NULL. */
+int dl3p_upsample_softmax_ce(const float* z, int ldz, const float* labels, int ignore_index, float inv_count,
+                             float* logits_big, float* probs, float* dlogits_big, int ld_big,
+                             float* loss_partials, int* rows_out,
+                             int N, int h, int w, int C, int H, int W, void* stream);
+/* out[n] (+)= sum over rows of partials[rows][n]   (loss, wgrad slabs) */
+int dl3p_reduce_rows(const float* partials, int rows, size_t n, float* out, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------- optimiser
+ * Keras SGD(momentum, nesterov=False) (common/model_utils.py:124) with the l2(2e-5) regulariser
+ * gradient (layers.py:12-18) folded in:  g' = g*grad_scale + 2*l2*w; v = momentum*v - lr*g'; w += v.
+ * lr is read from device memory (*lr_dev) so that a captured graph follows a schedule. */
+int dl3p_sgd_momentum(float* w, float* v, const float* g, size_t n, const float* lr_dev, float momentum,
+                      float l2, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DL3P_H_ */

@@ -1,0 +1,283 @@
+"""GPU parity of every C-ABI op against the CPU oracle (oracle/np_ops.py, fp64) on identical seeded
+inputs.  Tolerances are fp32-accumulation level (well inside north_star's 1e-3)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_ops as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+
+
+def close(got, want, rtol=2e-4, atol=2e-5, what=''):
+    got = got.detach().cpu().numpy().astype(np.float64) if torch.is_tensor(got) else np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    scale = max(1.0, float(np.abs(want).max()))
+    err = np.abs(got - want).max()
+    assert err <= atol * scale + rtol * scale, '%s: max err %g (scale %g)' % (what, err, scale)
+
+
+def stats_from(partials, rows, C):
+    p = partials[:rows * 2 * C].reshape(rows, 2, C).double().sum(0).cpu().numpy()
+    return p[0], p[1]
+
+
+DW_CASES = [
+    # N, H, W, C, k, stride, rate, padding
+    (2, 33, 33, 320, 3, 1, 18, 'same'),
+    (2, 33, 33, 320, 3, 1, 12, 'same'),
+    (2, 33, 33, 320, 3, 1, 6, 'same'),
+    (2, 33, 33, 64, 3, 1, 2, 'same'),
+    (2, 17, 19, 144, 3, 1, 1, 'same'),
+    (1, 65, 65, 96, 3, 2, 1, 'same'),
+    (2, 16, 20, 24, 3, 2, 1, 'same'),       # even sizes: extra pad bottom/right
+    (2, 33, 33, 128, 3, 2, 1, (1, 1, 1, 1)),  # Xception explicit pad + VALID
+    (1, 16, 24, 40, 5, 1, 2, 'same'),
+    (1, 16, 24, 72, 5, 2, 1, 'same'),
+    (3, 9, 9, 16, 3, 1, 1, 'same'),
+    (1, 5, 5, 2048, 3, 1, 4, 'same'),
+]
+
+
+@pytest.mark.parametrize('case', DW_CASES)
+def test_dwconv_fwd_bwd(ops, case):
+    N, H, W, C, k, s, r, pad = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((N, H, W, C))
+    w = rng.standard_normal((k, k, C)) * 0.3
+    sc = rng.uniform(0.5, 1.5, C)
+    sh = rng.standard_normal(C) * 0.3
+    a = O.act_fwd(x * sc + sh, O.ACT_RELU6)
+    y_ref = O.dwconv2d_fwd(a, w, s, r, pad)
+    part = ops.new_partials(C, DEV)
+    y, rows = ops.dwconv2d_fwd(T(x), T(w), s, r, pad, T(sc), T(sh), ops.ACT_RELU6, partials=part)
+    close(y, y_ref, what='dw fwd')
+    s1, s2 = stats_from(part, rows, C)
+    close(s1, y_ref.reshape(-1, C).sum(0), rtol=1e-4, atol=1e-4 * y_ref.shape[0] * y_ref.shape[1], what='dw stat sum')
+    close(s2, (y_ref ** 2).reshape(-1, C).sum(0), rtol=1e-4, what='dw stat sumsq')
+    gy = rng.standard_normal(y_ref.shape)
+    gx_ref, gw_ref = O.dwconv2d_bwd(a, w, gy, s, r, pad)
+    gx = ops.dwconv2d_bwd_data(T(gy), T(w), (N, H, W, C), s, r, pad)
+    close(gx, gx_ref, what='dw bwd data')
+    base = rng.standard_normal((N, H, W, C))
+    gx2 = ops.dwconv2d_bwd_data(T(gy), T(w), (N, H, W, C), s, r, pad, out=T(base), accumulate=True)
+    close(gx2, gx_ref + base, what='dw bwd data accumulate')
+    gw = ops.dwconv2d_bwd_weight(T(x), T(gy), k, s, r, pad, T(sc), T(sh), ops.ACT_RELU6)
+    close(gw, gw_ref, rtol=3e-4, what='dw bwd weight')
+
+
+PW_CASES = [
+    # M, K, N
+    (2 * 33 * 33, 320, 256), (1000, 24, 144), (777, 144, 24), (4096 + 5, 32, 16), (513, 16, 96),
+    (300, 304, 256), (129 * 7, 256, 24), (64, 1280, 256), (16, 320, 256), (2 * 17 * 17, 960, 160),
+    (1, 8, 4), (130, 576, 96),
+]
+
+
+@pytest.mark.parametrize('case', PW_CASES)
+def test_pwconv_fwd_bwd(ops, case):
+    M, K, Nn = case
+    rng = np.random.default_rng(M * 7 + K * 3 + Nn)
+    x = rng.standard_normal((M, K))
+    w = rng.standard_normal((K, Nn)) / np.sqrt(K)
+    b = rng.standard_normal(Nn)
+    sc = rng.uniform(0.5, 1.5, K)
+    sh = rng.standard_normal(K) * 0.3
+    a = O.act_fwd(x * sc + sh, O.ACT_RELU)
+    y_ref = a @ w
+    part = ops.new_partials(Nn, DEV)
+    y, rows = ops.pwconv_fwd(T(x), T(w), None, T(sc), T(sh), ops.ACT_RELU, partials=part)
+    close(y, y_ref, what='pw fwd')
+    s1, s2 = stats_from(part, rows, Nn)
+    close(s1, y_ref.sum(0), rtol=1e-4, atol=1e-4 * M, what='pw stat sum')
+    close(s2, (y_ref ** 2).sum(0), rtol=1e-4, what='pw stat sumsq')
+    yb = ops.pwconv_fwd(T(x), T(w), T(b))
+    close(yb, x @ w + b, what='pw fwd bias, no prologue')
+    gy = rng.standard_normal((M, Nn))
+    gx = ops.pwconv_bwd_data(T(gy), T(w))
+    close(gx, gy @ w.T, what='pw bwd data')
+    base = rng.standard_normal((M, K))
+    gx2 = ops.pwconv_bwd_data(T(gy), T(w), out=T(base), accumulate=True)
+    close(gx2, gy @ w.T + base, what='pw bwd data accumulate')
+    gw, gb = ops.pwconv_bwd_weight(T(x), T(gy), T(sc), T(sh), ops.ACT_RELU, with_bias=True)
+    close(gw, a.T @ gy, rtol=3e-4, what='pw bwd weight')
+    close(gb, gy.sum(0), rtol=3e-4, what='pw bwd bias')
+
+
+def test_pwconv_concat_slices(ops):
+    """producers write channel slices of a concat buffer, the consumer reads it with the
+    concatenated per-channel prologue (layers.py:155 Concatenate costs no pass)"""
+    rng = np.random.default_rng(5)
+    M = 2 * 9 * 9
+    x = rng.standard_normal((M, 32))
+    w1 = rng.standard_normal((32, 48))
+    w2 = rng.standard_normal((32, 16))
+    cat = torch.zeros((M, 64), device=DEV)
+    ops.pwconv_fwd(T(x), T(w1), out=cat[:, :48])
+    ops.pwconv_fwd(T(x), T(w2), out=cat[:, 48:])
+    ref = np.concatenate([x @ w1, x @ w2], -1)
+    close(cat, ref, what='slice writes')
+    sc = rng.uniform(0.5, 1.5, 64)
+    sh = rng.standard_normal(64)
+    w3 = rng.standard_normal((64, 8))
+    y = ops.pwconv_fwd(cat, T(w3), None, T(sc), T(sh), ops.ACT_RELU)
+    close(y, O.act_fwd(ref * sc + sh, O.ACT_RELU) @ w3, rtol=3e-4, what='concat consumer')
+    g = rng.standard_normal((M, 8))
+    gcat = torch.zeros((M, 64), device=DEV)
+    ops.pwconv_bwd_data(T(g), T(w3), out=gcat)
+    gw1 = ops.pwconv_bwd_weight(T(x), gcat[:, :48])
+    close(gw1, x.T @ (g @ w3.T)[:, :48], rtol=3e-4, what='wgrad from slice')
+
+
+@pytest.mark.parametrize('case', [(2, 33, 33, 3, 32, 3, 2, 'same'), (1, 32, 48, 3, 16, 3, 2, (0, 1, 0, 1)),
+                                  (1, 17, 17, 8, 16, 3, 1, 'same')])
+def test_conv2d_stem(ops, case):
+    N, H, W, Cin, Cout, k, s, pad = case
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-1, 1, (N, H, W, Cin))
+    w = rng.standard_normal((k, k, Cin, Cout)) * 0.2
+    y_ref = O.conv2d_fwd(x, w, s, 1, pad)
+    part = ops.new_partials(Cout, DEV)
+    y, rows = ops.conv2d_fwd(T(x), T(w), s, 1, pad, partials=part)
+    close(y, y_ref, what='conv fwd')
+    s1, s2 = stats_from(part, rows, Cout)
+    close(s1, y_ref.reshape(-1, Cout).sum(0), rtol=1e-4, atol=1e-2, what='conv stat')
+    close(s2, (y_ref ** 2).reshape(-1, Cout).sum(0), rtol=1e-4, what='conv stat sq')
+    gy = rng.standard_normal(y_ref.shape)
+    gx_ref, gw_ref, _ = O.conv2d_bwd(x, w, gy, s, 1, pad)
+    gw = ops.conv2d_bwd_weight(T(x), T(gy), k, s, 1, pad)
+    close(gw, gw_ref, rtol=3e-4, what='conv bwd weight')
+    gx = ops.conv2d_bwd_data(T(gy), T(w), (N, H, W, Cin), s, 1, pad)
+    close(gx, gx_ref, rtol=3e-4, what='conv bwd data')
+
+
+@pytest.mark.parametrize('shape,act', [((2, 9, 9, 32), O.ACT_RELU6), ((3, 1, 1, 256), O.ACT_RELU),
+                                       ((1, 33, 33, 24), O.ACT_NONE), ((2, 8, 8, 64), O.ACT_HSWISH)])
+def test_batchnorm_fwd_bwd(ops, shape, act):
+    rng = np.random.default_rng(3)
+    C = shape[-1]
+    z = rng.standard_normal(shape) * 2 + 0.5
+    gamma = rng.uniform(0.5, 1.5, C)
+    beta = rng.standard_normal(C) * 0.2
+    eps, mom = 1e-3, 0.99
+    y_ref, cache, (bm, bv) = O.bn_train_fwd(z, gamma, beta, eps)
+    bn = ops.BNState(C, DEV, eps, mom)
+    bn.gamma.copy_(T(gamma)); bn.beta.copy_(T(beta))
+    # statistics produced by a producer kernel: identity depthwise conv is the simplest producer
+    part = ops.new_partials(C, DEV)
+    w = np.zeros((3, 3, C)); w[1, 1] = 1
+    zz, rows = ops.dwconv2d_fwd(T(z), T(w), partials=part)
+    M = z.size // C
+    ops.bn_finalize(bn, part, rows, M)
+    close(bn.scale, gamma * cache[1], what='scale')
+    close(bn.shift, beta - z.reshape(-1, C).mean(0) * gamma * cache[1], what='shift', atol=1e-4)
+    close(bn.moving_mean, 0 * mom + bm * (1 - mom), what='moving mean', atol=1e-5)
+    close(bn.moving_var, 1 * mom + bv * (1 - mom), what='moving var', atol=1e-5)
+    a = ops.affine_act(zz, bn.scale, bn.shift, act)
+    close(a, O.act_fwd(y_ref, act), rtol=3e-4, atol=1e-4, what='bn apply + act')
+    g = rng.standard_normal(shape)
+    gy = O.act_bwd(y_ref, g, act)
+    gz_ref, gg_ref, gb_ref = O.bn_train_bwd(gy, cache)
+    dz = ops.bn_backward(bn, T(g), T(z), act, part)
+    close(dz, gz_ref, rtol=5e-4, atol=5e-4, what='bn bwd dz')
+    close(bn.dgamma, gg_ref, rtol=5e-4, atol=5e-4, what='dgamma')
+    close(bn.dbeta, gb_ref, rtol=5e-4, atol=5e-4, what='dbeta')
+    # frozen / inference mode
+    bn.moving_mean.copy_(T(rng.standard_normal(C))); bn.moving_var.copy_(T(rng.uniform(0.5, 2, C)))
+    ops.bn_infer_coeffs(bn)
+    mm, mv = bn.moving_mean.cpu().numpy().astype(np.float64), bn.moving_var.cpu().numpy().astype(np.float64)
+    a2 = ops.affine_act(T(z), bn.scale, bn.shift, act)
+    y2 = O.bn_infer_fwd(z, gamma, beta, mm, mv, eps)
+    close(a2, O.act_fwd(y2, act), rtol=3e-4, atol=1e-4, what='bn infer')
+    dz2 = ops.bn_backward(bn, T(g), T(z), act, part, frozen=True)
+    close(dz2, O.act_bwd(y2, g, act) * (gamma / np.sqrt(mv + eps)), rtol=3e-4, atol=1e-4, what='bn frozen bwd')
+
+
+def test_residual_dropout(ops):
+    rng = np.random.default_rng(8)
+    M, C = 500, 48
+    x = rng.standard_normal((M, C)); r = rng.standard_normal((M, C))
+    sc = rng.uniform(0.5, 1.5, C); sh = rng.standard_normal(C)
+    y = ops.affine_act(T(x), T(sc), T(sh), ops.ACT_NONE, residual=T(r))
+    close(y, x * sc + sh + r, what='residual add')
+    step = torch.tensor([3], dtype=torch.int64, device=DEV)
+    mask = ops.dropout_mask((M, C), 0.5, 1234, step, DEV).cpu().numpy()
+    assert 0.4 < mask.mean() < 0.6
+    y = ops.affine_act(T(x), T(sc), T(sh), ops.ACT_RELU, dropout_rate=0.5, seed=1234, step_counter=step)
+    close(y, O.dropout_fwd(O.act_fwd(x * sc + sh, O.ACT_RELU), mask, 0.5), what='dropout fwd')
+    g = rng.standard_normal((M, C))
+    gx = ops.scale_mask_bwd(T(g), 0.5, 1234, step)
+    close(gx, O.dropout_bwd(g, mask, 0.5), what='dropout bwd')
+    step2 = torch.tensor([4], dtype=torch.int64, device=DEV)
+    mask2 = ops.dropout_mask((M, C), 0.5, 1234, step2, DEV).cpu().numpy()
+    assert (mask != mask2).mean() > 0.3
+
+
+def test_global_avgpool(ops):
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((3, 33, 33, 320))
+    sc = rng.uniform(0.5, 1.5, 320); sh = rng.standard_normal(320)
+    y = ops.global_avgpool_fwd(T(x), T(sc), T(sh), ops.ACT_NONE)
+    close(y, O.global_avgpool_fwd(x * sc + sh), what='gap fwd')
+    ys = ops.global_avgpool_fwd(T(x), out_scale=33 * 33)
+    close(ys, x.sum((1, 2), keepdims=True), rtol=3e-4, what='gap sum')
+    g = rng.standard_normal((3, 1, 1, 320))
+    gx = ops.global_avgpool_bwd(T(g), 33, 33)
+    close(gx, O.global_avgpool_bwd(g, 33, 33), what='gap bwd')
+
+
+@pytest.mark.parametrize('case', [(2, 33, 33, 256, 129, 129), (1, 1, 1, 256, 33, 33), (2, 9, 13, 24, 33, 50),
+                                  (1, 129, 129, 24, 513, 513), (1, 16, 32, 8, 64, 128), (1, 10, 10, 4, 7, 5)])
+def test_resize_bilinear(ops, case):
+    N, h, w, C, H, W = case
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((N, h, w, C))
+    y = ops.resize_bilinear_fwd(T(x), H, W)
+    close(y, O.resize_bilinear_fwd(x, H, W), what='resize fwd')
+    g = rng.standard_normal((N, H, W, C))
+    gx = ops.resize_bilinear_bwd(T(g), h, w)
+    close(gx, O.resize_bilinear_bwd(g, h, w), rtol=3e-4, what='resize bwd')
+
+
+@pytest.mark.parametrize('C,ignore', [(21, 255), (19, 255), (21, 0)])
+def test_head_softmax_ce(ops, C, ignore):
+    rng = np.random.default_rng(C)
+    N, h, w, H, W = 2, 9, 9, 33, 33
+    cp = ((C + 3) // 4) * 4
+    z = np.zeros((N, h, w, cp)); z[..., :C] = rng.standard_normal((N, h, w, C)) * 3
+    lab = rng.integers(0, C, (N, H, W)).astype(np.float64)
+    lab[rng.uniform(size=lab.shape) < 0.1] = 255
+    big = O.resize_bilinear_fwd(z[..., :C], H, W)
+    loss_ref, p_ref, g_ref = O.sparse_ce_fwd_bwd(big, lab, ignore)
+    out = ops.upsample_softmax_ce(T(z), C, H, W, T(lab.reshape(N, H * W, 1)), ignore, want_probs=True,
+                                  want_logits=True, want_grad=True)
+    close(out['logits'][..., :C], big, what='pred_resize logits')
+    close(out['probs'], p_ref, rtol=1e-4, atol=1e-6, what='probs')
+    close(out['loss'], [loss_ref], rtol=1e-4, what='loss')
+    close(out['dlogits'][..., :C], g_ref, rtol=1e-4, atol=1e-9, what='dlogits')
+    assert float(out['dlogits'][..., C:].abs().max()) == 0.0
+
+
+def test_sgd(ops):
+    rng = np.random.default_rng(2)
+    n = 1003
+    w, v, g = rng.standard_normal(n), rng.standard_normal(n), rng.standard_normal(n)
+    wt, vt = T(np.pad(w, (0, 1))), T(np.pad(v, (0, 1)))
+    lr = torch.tensor([0.01], device=DEV)
+    ops.sgd_momentum(wt[:n], vt[:n], T(np.pad(g, (0, 1)))[:n], lr, 0.9, 2e-5)
+    w2, v2 = O.sgd_momentum_step(w, v, g, 0.01, 0.9, 2e-5)
+    close(wt[:n], w2, what='sgd w'); close(vt[:n], v2, what='sgd v')
+
+
+def test_bad_arguments_fail_loudly(ops):
+    x = torch.zeros((1, 4, 4, 6), device=DEV)   # C % 4 != 0
+    with pytest.raises(ops.Dl3pError):
+        ops.dwconv2d_fwd(x, torch.zeros((3, 3, 6), device=DEV))
+    with pytest.raises(ops.Dl3pError):
+        ops.pwconv_fwd(torch.zeros((4, 8)), torch.zeros((8, 8)))   # CPU tensors are refused

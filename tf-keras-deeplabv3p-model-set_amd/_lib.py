@@ -1,0 +1,88 @@
+"""ctypes binding of libdl3p.so.  Signatures are parsed from include/dl3p.h (the single source of
+truth for the C ABI) so the Python side cannot drift from the header.
+
+The product path has NO fallback: if the HIP library is missing, importing ops fails loudly.
+"""
+import ctypes
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(HERE, '..', 'include', 'dl3p.h')
+LIBPATH = os.path.join(HERE, 'libdl3p.so')
+
+_CT = {
+    'const float*': ctypes.c_void_p, 'float*': ctypes.c_void_p,
+    'const double*': ctypes.c_void_p, 'double*': ctypes.c_void_p,
+    'const int64_t*': ctypes.c_void_p, 'int64_t*': ctypes.c_void_p,
+    'void*': ctypes.c_void_p, 'int*': ctypes.POINTER(ctypes.c_int),
+    'int': ctypes.c_int, 'float': ctypes.c_float, 'double': ctypes.c_double,
+    'size_t': ctypes.c_size_t, 'uint64_t': ctypes.c_uint64,
+    'const char*': ctypes.c_char_p, 'void': None,
+}
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype_str, [argtype_str, ...])} for every dl3p_* prototype in the header"""
+    src = open(path).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    src = re.sub(r'^\s*#.*$', '', src, flags=re.M)
+    src = re.sub(r'\benum\s*\{[^}]*\}\s*;', '', src)
+    src = src.replace('extern "C" {', '')
+    protos = {}
+    for m in re.finditer(r'([\w \*]+?)\b(dl3p_\w+)\s*\(([^)]*)\)\s*;', src):
+        ret = ' '.join(m.group(1).split())
+        name = m.group(2)
+        args = []
+        for a in m.group(3).split(','):
+            a = ' '.join(a.split())
+            if a in ('void', ''):
+                continue
+            mm = re.match(r'(.*?)(\w+)$', a)
+            t = mm.group(1).strip().replace(' *', '*')
+            args.append(t)
+        protos[name] = (ret, args)
+    return protos
+
+
+class Dl3pError(RuntimeError):
+    pass
+
+
+class Lib:
+    def __init__(self, path=LIBPATH):
+        if not os.path.exists(path):
+            raise ImportError(
+                'libdl3p.so not found at %s -- build it with `python __graft_entry__.py` '
+                '(there is no CPU fallback for the HIP path)' % path)
+        self.cdll = ctypes.CDLL(path)
+        self.protos = parse_header()
+        for name, (ret, args) in self.protos.items():
+            fn = getattr(self.cdll, name)
+            fn.restype = _CT[ret]
+            fn.argtypes = [_CT[a] for a in args]
+            setattr(self, name[len('dl3p_'):], self._wrap(name, fn, ret))
+
+    def _wrap(self, name, fn, ret):
+        if ret != 'int' or name in ('dl3p_version', 'dl3p_device_cus'):
+            return fn
+        err = self.cdll.dl3p_last_error_string
+        err.restype = ctypes.c_char_p
+
+        def call(*a):
+            rc = fn(*a)
+            if rc != 0:
+                raise Dl3pError('%s failed (%d): %s' % (name, rc, err().decode()))
+            return rc
+        call.raw = fn
+        return call
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = Lib()
+    return _lib

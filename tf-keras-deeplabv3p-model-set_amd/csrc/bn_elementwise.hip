@@ -1,0 +1,569 @@
+// BatchNorm statistics/backward, elementwise materialisation (residual Add, Dropout), global pooling,
+// SGD and small utilities for gfx950.  All HBM-bound streaming kernels: 16-B vector accesses with
+// channel lanes fastest (common.h pick_lanes), persistent workgroups for the reductions so each
+// emits ONE deterministic partial row (no atomics).
+//
+// Reference call sites: CustomBatchNormalization layers.py:63-70; ReLU/Add/Dropout layers.py:98,161,
+// deeplabv3p_mobilenetv2.py:70; AveragePooling2D layers.py:132; SGD common/model_utils.py:124.
+#include "common.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+void dl3p_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* dl3p_last_error_string(void) { return g_err; }
+extern "C" int dl3p_version(void) { return DL3P_VERSION; }
+extern "C" int dl3p_device_cus(void) { return DL3P_NUM_CUS; }
+
+// ------------------------------------------------------------------------------ row reducer
+// out[i] (+)= sum_r partials[r][i]; double accumulation in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ partials, int rows,
+                                                          size_t row_stride, size_t n, float* __restrict__ out,
+                                                          int accumulate) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double acc = 0.0;
+  for (int r = 0; r < rows; ++r) acc += (double)partials[(size_t)r * row_stride + i];
+  out[i] = (float)(accumulate ? acc + (double)out[i] : acc);
+}
+
+int dl3p_reduce_rows_strided_impl(const float* partials, int rows, size_t row_stride, size_t n, float* out,
+                                  int accumulate, hipStream_t st) {
+  if (n == 0) return DL3P_OK;
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partials, rows,
+                     row_stride, n, out, accumulate);
+  DL3P_CHECK_LAUNCH("dl3p_reduce_rows");
+  return DL3P_OK;
+}
+int dl3p_reduce_rows_impl(const float* partials, int rows, size_t n, float* out, int accumulate, hipStream_t st) {
+  return dl3p_reduce_rows_strided_impl(partials, rows, n, n, out, accumulate, st);
+}
+extern "C" int dl3p_reduce_rows(const float* partials, int rows, size_t n, float* out, int accumulate, void* stream) {
+  DL3P_CHECK_ARG(partials && out && rows >= 0, "dl3p_reduce_rows: bad arguments");
+  return dl3p_reduce_rows_impl(partials, rows, n, out, accumulate, (hipStream_t)stream);
+}
+
+// sums[i] = sum_r partials[r][i] in double (SyncBN: these sums are all-reduced across ranks)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int rows, int n,
+                                                              double* __restrict__ sums) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double acc = 0.0;
+  for (int r = 0; r < rows; ++r) acc += (double)partials[(size_t)r * n + i];
+  sums[i] = acc;
+}
+extern "C" int dl3p_bn_reduce_partials(const float* partials, int rows, int C2, double* sums, void* stream) {
+  DL3P_CHECK_ARG(partials && sums && rows > 0 && C2 > 0, "dl3p_bn_reduce_partials: bad arguments");
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((C2 + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, rows,
+                     C2, sums);
+  DL3P_CHECK_LAUNCH("dl3p_bn_reduce_partials");
+  return DL3P_OK;
+}
+
+// ------------------------------------------------------------------------------ BN finalize
+// 32 channels x 8 row lanes per workgroup; double accumulation
+__device__ __forceinline__ void reduce2_rows(const float* partials, int rows, const double* sums, int C, int c, int ry,
+                                             double& a, double& b) {
+  __shared__ double sm[2][8][32];
+  const int cx = threadIdx.x & 31;
+  double s0 = 0.0, s1 = 0.0;
+  if (c < C) {
+    if (sums) {
+      if (ry == 0) { s0 = sums[c]; s1 = sums[C + c]; }
+    } else {
+      for (int r = ry; r < rows; r += 8) {
+        s0 += (double)partials[((size_t)r * 2) * C + c];
+        s1 += (double)partials[((size_t)r * 2 + 1) * C + c];
+      }
+    }
+  }
+  sm[0][ry][cx] = s0;
+  sm[1][ry][cx] = s1;
+  __syncthreads();
+  a = 0.0; b = 0.0;
+  if (ry == 0) {
+    for (int q = 0; q < 8; ++q) { a += sm[0][q][cx]; b += sm[1][q][cx]; }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partials, int rows, const double* sums, int C,
+                                                          double count, const float* gamma, const float* beta,
+                                                          float eps, float momentum, float* moving_mean,
+                                                          float* moving_var, int update_moving, float* scale,
+                                                          float* shift, float* save_mean, float* save_invstd) {
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  double s, ss;
+  reduce2_rows(partials, rows, sums, C, c, ry, s, ss);
+  if (ry == 0 && c < C) {
+    double mean = s / count;
+    double var = ss / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
+    save_mean[c] = (float)mean;
+    save_invstd[c] = invstd;
+    if (update_moving) {
+      double cm1 = count > 1.0 ? count - 1.0 : 1.0;
+      float var_unbiased = (float)(var * (count / cm1));
+      moving_mean[c] = moving_mean[c] * momentum + (float)mean * (1.f - momentum);
+      moving_var[c] = moving_var[c] * momentum + var_unbiased * (1.f - momentum);
+    }
+  }
+}
+
+extern "C" int dl3p_bn_finalize(const float* partials, int rows, const double* sums, int C, double count,
+                                const float* gamma, const float* beta, float eps, float momentum, float* moving_mean,
+                                float* moving_var, int update_moving, float* scale, float* shift, float* save_mean,
+                                float* save_invstd, void* stream) {
+  DL3P_CHECK_ARG((partials && rows > 0) || sums, "dl3p_bn_finalize: need partial rows or sums");
+  DL3P_CHECK_ARG(C > 0 && count > 0 && gamma && beta && scale && shift && save_mean && save_invstd,
+                 "dl3p_bn_finalize: bad arguments");
+  DL3P_CHECK_ARG(!update_moving || (moving_mean && moving_var), "dl3p_bn_finalize: moving stats missing");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, (hipStream_t)stream, partials, rows,
+                     sums, C, count, gamma, beta, eps, momentum, moving_mean, moving_var, update_moving, scale, shift,
+                     save_mean, save_invstd);
+  DL3P_CHECK_LAUNCH("dl3p_bn_finalize");
+  return DL3P_OK;
+}
+
+__global__ void bn_infer_coeffs_kernel(const float* gamma, const float* beta, const float* mm, const float* mv,
+                                       float eps, float* scale, float* shift, float* save_mean, float* save_invstd,
+                                       int C) {
+  int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float invstd = 1.f / sqrtf(mv[c] + eps);
+  float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - mm[c] * sc;
+  if (save_mean) save_mean[c] = mm[c];
+  if (save_invstd) save_invstd[c] = invstd;
+}
+extern "C" int dl3p_bn_infer_coeffs(const float* gamma, const float* beta, const float* moving_mean,
+                                    const float* moving_var, float eps, float* scale, float* shift, float* save_mean,
+                                    float* save_invstd, int C, void* stream) {
+  DL3P_CHECK_ARG(gamma && beta && moving_mean && moving_var && scale && shift && C > 0,
+                 "dl3p_bn_infer_coeffs: bad arguments");
+  hipLaunchKernelGGL(bn_infer_coeffs_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                     moving_mean, moving_var, eps, scale, shift, save_mean, save_invstd, C);
+  DL3P_CHECK_LAUNCH("dl3p_bn_infer_coeffs");
+  return DL3P_OK;
+}
+
+// ------------------------------------------------------------------------------ BN backward
+struct EwParams {
+  const float* a; int lda;      // g (bwd) or x (fwd)
+  const float* z; int ldz;
+  const float* scale; const float* shift; int act;
+  const float* mean; const float* invstd; const float* coef;
+  const float* r; int ldr; const float* rscale; const float* rshift; int ract;
+  float* out; int ldo;
+  float* partials;
+  long long M; int C;
+  int c4s, px, nslab, nbx;
+  float rate; uint64_t seed; const int64_t* step;
+  int accumulate;
+};
+
+__device__ __forceinline__ float4 opt_ld4(const float* p, int c, float4 dflt) { return p ? ld4(p + c) : dflt; }
+
+// pass 1: partial sums of dyy and dyy*xhat
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(EwParams p) {
+  const int b = blockIdx.x;
+  const int slab = b / p.nbx;
+  const int bx = b - slab * p.nbx;
+  const int pl = threadIdx.x / p.c4s;
+  const int cl = threadIdx.x - pl * p.c4s;
+  const bool active = pl < p.px;
+  const int cbase4 = slab * p.c4s;
+  const int c = (cbase4 + cl) * 4;
+  float4 acc[2] = {zero4(), zero4()};
+  if (active) {
+    const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 sc = opt_ld4(p.scale, c, one), sh = opt_ld4(p.shift, c, zero4());
+    const float4 mu = opt_ld4(p.mean, c, zero4()), is = opt_ld4(p.invstd, c, one);
+    const int act = p.act;
+    for (long long m = (long long)bx * p.px + pl; m < p.M; m += (long long)p.nbx * p.px) {
+      float4 g = ld4(p.a + (size_t)m * p.lda + c);
+      float4 z = ld4(p.z + (size_t)m * p.ldz + c);
+      float4 u = fma4(z, sc, sh);
+      float4 d = make_float4(g.x * act_grad(u.x, act), g.y * act_grad(u.y, act), g.z * act_grad(u.z, act),
+                             g.w * act_grad(u.w, act));
+      float4 xh = make_float4((z.x - mu.x) * is.x, (z.y - mu.y) * is.y, (z.z - mu.z) * is.z, (z.w - mu.w) * is.w);
+      acc[0] = add4(acc[0], d);
+      acc[1] = fma4(d, xh, acc[1]);
+    }
+  }
+  block_reduce_store<2>(acc, active, pl, cl, p.c4s, p.px, cbase4, p.C, p.partials + (size_t)bx * 2 * p.C);
+}
+
+static int ew_setup(EwParams& p, long long M, int C, int max_rows) {
+  pick_lanes(C, &p.c4s, &p.px, &p.nslab);
+  long long need = ceil_div_ll(M, p.px);
+  long long target = DL3P_NUM_CUS * 8 / p.nslab;
+  if (target < 1) target = 1;
+  long long nbx = need < target ? need : target;
+  if (nbx < 1) nbx = 1;
+  if (nbx > max_rows) nbx = max_rows;
+  p.nbx = (int)nbx;
+  p.M = M;
+  p.C = C;
+  return p.nbx;
+}
+
+static int check_ew(const char* fn, const void* a, int lda, int C) {
+  DL3P_CHECK_ARG(a != nullptr, "%s: null pointer", fn);
+  DL3P_CHECK_ARG(C > 0 && C % 4 == 0, "%s: C=%d must be a positive multiple of 4", fn, C);
+  DL3P_CHECK_ARG(lda % 4 == 0 && lda >= C && aligned16(a), "%s: bad layout (ld=%d)", fn, lda);
+  return DL3P_OK;
+}
+
+extern "C" int dl3p_bn_bwd_reduce(const float* g, int ldg, const float* z, int ldz, const float* scale,
+                                  const float* shift, int act, const float* save_mean, const float* save_invstd,
+                                  float* partials, int* rows_out, int M, int C, void* stream) {
+  int rc = check_ew("dl3p_bn_bwd_reduce", g, ldg, C);
+  if (rc) return rc;
+  rc = check_ew("dl3p_bn_bwd_reduce", z, ldz, C);
+  if (rc) return rc;
+  DL3P_CHECK_ARG(partials && M > 0, "dl3p_bn_bwd_reduce: bad arguments");
+  EwParams p = {};
+  p.a = g; p.lda = ldg; p.z = z; p.ldz = ldz; p.scale = scale; p.shift = shift; p.act = act;
+  p.mean = save_mean; p.invstd = save_invstd; p.partials = partials;
+  int rows = ew_setup(p, M, C, DL3P_MAX_STAT_ROWS);
+  if (rows_out) *rows_out = rows;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(p.nbx * p.nslab), dim3(256), 0, (hipStream_t)stream, p);
+  DL3P_CHECK_LAUNCH("dl3p_bn_bwd_reduce");
+  return DL3P_OK;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* partials, int rows, const double* sums,
+                                                              int C, double count, const float* gamma,
+                                                              const float* invstd, const float* scale, int frozen,
+                                                              float* dgamma, float* dbeta, float* coef) {
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  double s, sx;
+  reduce2_rows(partials, rows, sums, C, c, ry, s, sx);
+  if (ry == 0 && c < C) {
+    if (frozen) {
+      coef[c] = scale[c];
+      coef[C + c] = 0.f;
+      coef[2 * C + c] = 0.f;
+    } else {
+      if (dgamma) dgamma[c] = (float)sx;
+      if (dbeta) dbeta[c] = (float)s;
+      coef[c] = gamma[c] * invstd[c];
+      coef[C + c] = (float)(s / count);
+      coef[2 * C + c] = (float)(sx / count);
+    }
+  }
+}
+
+extern "C" int dl3p_bn_bwd_finalize(const float* partials, int rows, const double* sums, int C, double count,
+                                    const float* gamma, const float* save_invstd, const float* scale, int frozen,
+                                    float* dgamma, float* dbeta, float* coef, void* stream) {
+  DL3P_CHECK_ARG(frozen || (partials && rows > 0) || sums, "dl3p_bn_bwd_finalize: need partial rows or sums");
+  DL3P_CHECK_ARG(C > 0 && coef && (frozen ? scale != nullptr : (gamma && save_invstd && count > 0)),
+                 "dl3p_bn_bwd_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, (hipStream_t)stream,
+                     frozen ? nullptr : partials, frozen ? 0 : rows, frozen ? nullptr : sums, C, count, gamma,
+                     save_invstd, scale, frozen, dgamma, dbeta, coef);
+  DL3P_CHECK_LAUNCH("dl3p_bn_bwd_finalize");
+  return DL3P_OK;
+}
+
+// pass 2: dz = coef0*(dyy - coef1 - xhat*coef2)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(EwParams p) {
+  const int b = blockIdx.x;
+  const int slab = b / p.nbx;
+  const int bx = b - slab * p.nbx;
+  const int pl = threadIdx.x / p.c4s;
+  const int cl = threadIdx.x - pl * p.c4s;
+  if (pl >= p.px) return;
+  const int c = (slab * p.c4s + cl) * 4;
+  const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+  const float4 sc = opt_ld4(p.scale, c, one), sh = opt_ld4(p.shift, c, zero4());
+  const float4 mu = opt_ld4(p.mean, c, zero4()), is = opt_ld4(p.invstd, c, one);
+  const float4 c0 = p.coef ? ld4(p.coef + c) : one;
+  const float4 c1 = p.coef ? ld4(p.coef + p.C + c) : zero4();
+  const float4 c2 = p.coef ? ld4(p.coef + 2 * p.C + c) : zero4();
+  const int act = p.act;
+  for (long long m = (long long)bx * p.px + pl; m < p.M; m += (long long)p.nbx * p.px) {
+    float4 g = ld4(p.a + (size_t)m * p.lda + c);
+    float4 z = ld4(p.z + (size_t)m * p.ldz + c);
+    float4 u = fma4(z, sc, sh);
+    float4 d = make_float4(g.x * act_grad(u.x, act), g.y * act_grad(u.y, act), g.z * act_grad(u.z, act),
+                           g.w * act_grad(u.w, act));
+    float4 o;
+    o.x = c0.x * (d.x - c1.x - (z.x - mu.x) * is.x * c2.x);
+    o.y = c0.y * (d.y - c1.y - (z.y - mu.y) * is.y * c2.y);
+    o.z = c0.z * (d.z - c1.z - (z.z - mu.z) * is.z * c2.z);
+    o.w = c0.w * (d.w - c1.w - (z.w - mu.w) * is.w * c2.w);
+    st4(p.out + (size_t)m * p.ldo + c, o);
+  }
+}
+
+extern "C" int dl3p_bn_bwd_apply(const float* g, int ldg, const float* z, int ldz, const float* scale,
+                                 const float* shift, int act, const float* save_mean, const float* save_invstd,
+                                 const float* coef, float* dz, int lddz, int M, int C, void* stream) {
+  int rc = check_ew("dl3p_bn_bwd_apply", g, ldg, C);
+  if (rc) return rc;
+  rc = check_ew("dl3p_bn_bwd_apply", z, ldz, C);
+  if (rc) return rc;
+  rc = check_ew("dl3p_bn_bwd_apply", dz, lddz, C);
+  if (rc) return rc;
+  EwParams p = {};
+  p.a = g; p.lda = ldg; p.z = z; p.ldz = ldz; p.scale = scale; p.shift = shift; p.act = act;
+  p.mean = save_mean; p.invstd = save_invstd; p.coef = coef; p.out = dz; p.ldo = lddz;
+  ew_setup(p, M, C, 1 << 20);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(p.nbx * p.nslab), dim3(256), 0, (hipStream_t)stream, p);
+  DL3P_CHECK_LAUNCH("dl3p_bn_bwd_apply");
+  return DL3P_OK;
+}
+
+// ------------------------------------------------------------------------------ materialise / residual / dropout
+__global__ __launch_bounds__(256) void affine_act_kernel(EwParams p) {
+  const int b = blockIdx.x;
+  const int slab = b / p.nbx;
+  const int bx = b - slab * p.nbx;
+  const int pl = threadIdx.x / p.c4s;
+  const int cl = threadIdx.x - pl * p.c4s;
+  if (pl >= p.px) return;
+  const int c = (slab * p.c4s + cl) * 4;
+  const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+  const float4 sc = opt_ld4(p.scale, c, one), sh = opt_ld4(p.shift, c, zero4());
+  const float4 rsc = opt_ld4(p.rscale, c, one), rsh = opt_ld4(p.rshift, c, zero4());
+  const int64_t step = (p.rate > 0.f && p.step) ? *p.step : 0;
+  const float keep_scale = p.rate > 0.f ? 1.f / (1.f - p.rate) : 1.f;
+  for (long long m = (long long)bx * p.px + pl; m < p.M; m += (long long)p.nbx * p.px) {
+    float4 v = act_apply4(fma4(ld4(p.a + (size_t)m * p.lda + c), sc, sh), p.act);
+    if (p.rate > 0.f) {
+      const uint64_t e = (uint64_t)m * p.C + c;
+      v.x = dropout_keep(p.seed, step, e + 0, p.rate) ? v.x * keep_scale : 0.f;
+      v.y = dropout_keep(p.seed, step, e + 1, p.rate) ? v.y * keep_scale : 0.f;
+      v.z = dropout_keep(p.seed, step, e + 2, p.rate) ? v.z * keep_scale : 0.f;
+      v.w = dropout_keep(p.seed, step, e + 3, p.rate) ? v.w * keep_scale : 0.f;
+    }
+    if (p.r) v = add4(v, act_apply4(fma4(ld4(p.r + (size_t)m * p.ldr + c), rsc, rsh), p.ract));
+    st4(p.out + (size_t)m * p.ldo + c, v);
+  }
+}
+
+extern "C" int dl3p_affine_act(const float* x, int ldx, const float* scale, const float* shift, int act,
+                               const float* r, int ldr, const float* rscale, const float* rshift, int ract,
+                               float dropout_rate, uint64_t seed, const int64_t* step_counter, float* y, int ldy,
+                               int M, int C, void* stream) {
+  int rc = check_ew("dl3p_affine_act", x, ldx, C);
+  if (rc) return rc;
+  rc = check_ew("dl3p_affine_act", y, ldy, C);
+  if (rc) return rc;
+  if (r) { rc = check_ew("dl3p_affine_act", r, ldr, C); if (rc) return rc; }
+  DL3P_CHECK_ARG(dropout_rate >= 0.f && dropout_rate < 1.f && M > 0, "dl3p_affine_act: bad arguments");
+  EwParams p = {};
+  p.a = x; p.lda = ldx; p.scale = scale; p.shift = shift; p.act = act;
+  p.r = r; p.ldr = ldr; p.rscale = rscale; p.rshift = rshift; p.ract = ract;
+  p.rate = dropout_rate; p.seed = seed; p.step = step_counter; p.out = y; p.ldo = ldy;
+  ew_setup(p, M, C, 1 << 20);
+  hipLaunchKernelGGL(affine_act_kernel, dim3(p.nbx * p.nslab), dim3(256), 0, (hipStream_t)stream, p);
+  DL3P_CHECK_LAUNCH("dl3p_affine_act");
+  return DL3P_OK;
+}
+
+__global__ __launch_bounds__(256) void scale_mask_bwd_kernel(EwParams p) {
+  const int b = blockIdx.x;
+  const int slab = b / p.nbx;
+  const int bx = b - slab * p.nbx;
+  const int pl = threadIdx.x / p.c4s;
+  const int cl = threadIdx.x - pl * p.c4s;
+  if (pl >= p.px) return;
+  const int c = (slab * p.c4s + cl) * 4;
+  const int64_t step = (p.rate > 0.f && p.step) ? *p.step : 0;
+  const float keep_scale = p.rate > 0.f ? 1.f / (1.f - p.rate) : 1.f;
+  for (long long m = (long long)bx * p.px + pl; m < p.M; m += (long long)p.nbx * p.px) {
+    float4 v = ld4(p.a + (size_t)m * p.lda + c);
+    if (p.rate > 0.f) {
+      const uint64_t e = (uint64_t)m * p.C + c;
+      v.x = dropout_keep(p.seed, step, e + 0, p.rate) ? v.x * keep_scale : 0.f;
+      v.y = dropout_keep(p.seed, step, e + 1, p.rate) ? v.y * keep_scale : 0.f;
+      v.z = dropout_keep(p.seed, step, e + 2, p.rate) ? v.z * keep_scale : 0.f;
+      v.w = dropout_keep(p.seed, step, e + 3, p.rate) ? v.w * keep_scale : 0.f;
+    }
+    float* o = p.out + (size_t)m * p.ldo + c;
+    if (p.accumulate) v = add4(v, ld4(o));
+    st4(o, v);
+  }
+}
+
+extern "C" int dl3p_scale_mask_bwd(const float* gy, int ldgy, float dropout_rate, uint64_t seed,
+                                   const int64_t* step_counter, float* gx, int ldgx, int accumulate, int M, int C,
+                                   void* stream) {
+  int rc = check_ew("dl3p_scale_mask_bwd", gy, ldgy, C);
+  if (rc) return rc;
+  rc = check_ew("dl3p_scale_mask_bwd", gx, ldgx, C);
+  if (rc) return rc;
+  EwParams p = {};
+  p.a = gy; p.lda = ldgy; p.rate = dropout_rate; p.seed = seed; p.step = step_counter;
+  p.out = gx; p.ldo = ldgx; p.accumulate = accumulate;
+  ew_setup(p, M, C, 1 << 20);
+  hipLaunchKernelGGL(scale_mask_bwd_kernel, dim3(p.nbx * p.nslab), dim3(256), 0, (hipStream_t)stream, p);
+  DL3P_CHECK_LAUNCH("dl3p_scale_mask_bwd");
+  return DL3P_OK;
+}
+
+__global__ void dropout_mask_kernel(float rate, uint64_t seed, const int64_t* step, float* mask, size_t n) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  mask[i] = dropout_keep(seed, step ? *step : 0, i, rate) ? 1.f : 0.f;
+}
+extern "C" int dl3p_dropout_mask(float dropout_rate, uint64_t seed, const int64_t* step_counter, float* mask, int M,
+                                 int C, void* stream) {
+  DL3P_CHECK_ARG(mask && M > 0 && C > 0, "dl3p_dropout_mask: bad arguments");
+  size_t n = (size_t)M * C;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     dropout_rate, seed, step_counter, mask, n);
+  DL3P_CHECK_LAUNCH("dl3p_dropout_mask");
+  return DL3P_OK;
+}
+
+__global__ void fill_kernel(float* p, float v, size_t n) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * 256;
+  for (; i < n; i += stride) p[i] = v;
+}
+extern "C" int dl3p_fill(float* p, float value, size_t n, void* stream) {
+  DL3P_CHECK_ARG(p || n == 0, "dl3p_fill: null pointer");
+  if (n == 0) return DL3P_OK;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, value, n);
+  DL3P_CHECK_LAUNCH("dl3p_fill");
+  return DL3P_OK;
+}
+
+__global__ void increment_kernel(int64_t* c) { if (threadIdx.x == 0 && blockIdx.x == 0) *c += 1; }
+extern "C" int dl3p_increment_counter(int64_t* counter, void* stream) {
+  DL3P_CHECK_ARG(counter, "dl3p_increment_counter: null pointer");
+  hipLaunchKernelGGL(increment_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter);
+  DL3P_CHECK_LAUNCH("dl3p_increment_counter");
+  return DL3P_OK;
+}
+
+// ------------------------------------------------------------------------------ global average pooling
+// one workgroup per (image, channel slab): pixel lanes walk HW, then a block reduction
+__global__ __launch_bounds__(256) void gap_fwd_kernel(EwParams p, int HW, float out_scale) {
+  const int n = blockIdx.x / p.nslab;
+  const int slab = blockIdx.x - n * p.nslab;
+  const int pl = threadIdx.x / p.c4s;
+  const int cl = threadIdx.x - pl * p.c4s;
+  const bool active = pl < p.px;
+  const int cbase4 = slab * p.c4s;
+  const int c = (cbase4 + cl) * 4;
+  float4 acc[1] = {zero4()};
+  if (active) {
+    const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 sc = opt_ld4(p.scale, c, one), sh = opt_ld4(p.shift, c, zero4());
+    const float* base = p.a + (size_t)n * HW * p.lda + c;
+    for (int i = pl; i < HW; i += p.px) acc[0] = add4(acc[0], act_apply4(fma4(ld4(base + (size_t)i * p.lda), sc, sh), p.act));
+    const float inv = out_scale / (float)HW;
+    acc[0] = make_float4(acc[0].x * inv, acc[0].y * inv, acc[0].z * inv, acc[0].w * inv);
+  }
+  // out row n: reuse block_reduce_store with C := ldo so that row stride is honoured
+  block_reduce_store<1>(acc, active, pl, cl, p.c4s, p.px, cbase4, p.ldo, p.out + (size_t)n * p.ldo);
+}
+
+extern "C" int dl3p_global_avgpool_fwd(const float* x, int ldx, const float* in_scale, const float* in_shift,
+                                       int in_act, float* y, int ldy, float out_scale, int N, int HW, int C,
+                                       void* stream) {
+  int rc = check_ew("dl3p_global_avgpool_fwd", x, ldx, C);
+  if (rc) return rc;
+  rc = check_ew("dl3p_global_avgpool_fwd", y, ldy, C);
+  if (rc) return rc;
+  DL3P_CHECK_ARG(N > 0 && HW > 0, "dl3p_global_avgpool_fwd: bad dims");
+  EwParams p = {};
+  p.a = x; p.lda = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act; p.out = y; p.ldo = ldy;
+  pick_lanes(C, &p.c4s, &p.px, &p.nslab);
+  p.C = C;
+  hipLaunchKernelGGL(gap_fwd_kernel, dim3(N * p.nslab), dim3(256), 0, (hipStream_t)stream, p, HW, out_scale);
+  DL3P_CHECK_LAUNCH("dl3p_global_avgpool_fwd");
+  return DL3P_OK;
+}
+
+__global__ __launch_bounds__(256) void gap_bwd_kernel(EwParams p, int HW) {
+  const int b = blockIdx.x;
+  const int slab = b / p.nbx;
+  const int bx = b - slab * p.nbx;
+  const int pl = threadIdx.x / p.c4s;
+  const int cl = threadIdx.x - pl * p.c4s;
+  if (pl >= p.px) return;
+  const int c = (slab * p.c4s + cl) * 4;
+  const float inv = 1.f / (float)HW;
+  for (long long m = (long long)bx * p.px + pl; m < p.M; m += (long long)p.nbx * p.px) {
+    const long long n = m / HW;
+    float4 g = ld4(p.a + (size_t)n * p.lda + c);
+    g = make_float4(g.x * inv, g.y * inv, g.z * inv, g.w * inv);
+    float* o = p.out + (size_t)m * p.ldo + c;
+    if (p.accumulate) g = add4(g, ld4(o));
+    st4(o, g);
+  }
+}
+
+extern "C" int dl3p_global_avgpool_bwd(const float* gy, int ldgy, float* gx, int ldgx, int accumulate, int N, int HW,
+                                       int C, void* stream) {
+  int rc = check_ew("dl3p_global_avgpool_bwd", gy, ldgy, C);
+  if (rc) return rc;
+  rc = check_ew("dl3p_global_avgpool_bwd", gx, ldgx, C);
+  if (rc) return rc;
+  EwParams p = {};
+  p.a = gy; p.lda = ldgy; p.out = gx; p.ldo = ldgx; p.accumulate = accumulate;
+  ew_setup(p, (long long)N * HW, C, 1 << 20);
+  hipLaunchKernelGGL(gap_bwd_kernel, dim3(p.nbx * p.nslab), dim3(256), 0, (hipStream_t)stream, p, HW);
+  DL3P_CHECK_LAUNCH("dl3p_global_avgpool_bwd");
+  return DL3P_OK;
+}
+
+// ------------------------------------------------------------------------------ SGD momentum
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, float* __restrict__ v,
+                                                  const float* __restrict__ g, size_t n4, size_t n,
+                                                  const float* lr_dev, float momentum, float l2, float gscale) {
+  const float lr = *lr_dev;
+  const float l2x2 = 2.f * l2;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (; i < n4; i += stride) {
+    float4 ww = ld4(w + i * 4), vv = ld4(v + i * 4), gg = ld4(g + i * 4);
+    vv.x = momentum * vv.x - lr * fmaf(gg.x, gscale, l2x2 * ww.x);
+    vv.y = momentum * vv.y - lr * fmaf(gg.y, gscale, l2x2 * ww.y);
+    vv.z = momentum * vv.z - lr * fmaf(gg.z, gscale, l2x2 * ww.z);
+    vv.w = momentum * vv.w - lr * fmaf(gg.w, gscale, l2x2 * ww.w);
+    st4(v + i * 4, vv);
+    st4(w + i * 4, add4(ww, vv));
+  }
+  // scalar tail
+  if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) {
+    size_t j = n4 * 4 + threadIdx.x;
+    float vv = momentum * v[j] - lr * fmaf(g[j], gscale, l2x2 * w[j]);
+    v[j] = vv;
+    w[j] += vv;
+  }
+}
+
+extern "C" int dl3p_sgd_momentum(float* w, float* v, const float* g, size_t n, const float* lr_dev, float momentum,
+                                 float l2, float grad_scale, void* stream) {
+  DL3P_CHECK_ARG(w && v && g && lr_dev, "dl3p_sgd_momentum: null pointer");
+  DL3P_CHECK_ARG(aligned16(w) && aligned16(v) && aligned16(g), "dl3p_sgd_momentum: buffers must be 16-byte aligned");
+  if (n == 0) return DL3P_OK;
+  size_t n4 = n / 4;
+  size_t blocks = (n4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, v, g, n4, n, lr_dev,
+                     momentum, l2, grad_scale);
+  DL3P_CHECK_LAUNCH("dl3p_sgd_momentum");
+  return DL3P_OK;
+}

@@ -1,0 +1,380 @@
+// Depthwise (atrous) convolution kernels for gfx950: forward, backward-data, backward-weight.
+//
+// Replaces DepthwiseConv2D at /root/reference deeplabv3p/models/layers.py:100 (SepConv_BN; ASPP rates
+// 6/12/18 at layers.py:146-153), deeplabv3p_mobilenetv2.py:56, deeplabv3p_mobilenetv3.py:173.
+//
+// HBM-bound (2.25 flop/B fp32).  Layout: NHWC; a thread owns 4 consecutive channels (16-B vector
+// loads, a wave covers >= 128 B contiguous per pixel) and a strip of TW output pixels; channel
+// lanes are fastest in the block so every global access is coalesced.  Workgroups are persistent
+// (grid-stride) so the fused BatchNorm statistics (sum, sum^2 of the raw output) stay in registers
+// and leave as ONE partial row per workgroup -- no atomics, deterministic.  The XCD-aware split
+// (common.h xcd_range) keeps all taps of one image in one XCD's L2, so a dilated 3x3 (which touches
+// the whole 33x33 map from every tile) reads x from HBM once.
+// The BN+activation of the producing layer is applied on load (prologue): zero padding is in
+// activation space, so out-of-range taps contribute exactly 0.
+#include "common.h"
+
+struct DwParams {
+  const float* x; int ldx;
+  const float* scale; const float* shift; int act;
+  const float* w;
+  float* y; int ldy;
+  const float* dy; int lddy;   // bwd_weight only
+  float* partials;
+  int N, H, W, C, Ho, Wo, stride, rate, pad_t, pad_l;
+  int c4s, px, nslab, nbx, spr;
+  long long total;
+  int flip, accumulate;
+};
+
+// ------------------------------------------------------------------------------ forward, rate 1
+// TW outputs per thread along W; the (TW-1)*S+KS input columns of one tap row are loaded once.
+template <int KS, int TW, int S>
+__global__ __launch_bounds__(256) void dw_fwd_seg(DwParams p) {
+  constexpr int SEG = (TW - 1) * S + KS;
+  const int b = blockIdx.x;
+  const int slab = b / p.nbx;
+  const int bx = b - slab * p.nbx;
+  const int t = threadIdx.x;
+  const int pl = t / p.c4s;
+  const int cl = t - pl * p.c4s;
+  const bool active = pl < p.px;
+  const int cbase4 = slab * p.c4s;
+  const int c = (cbase4 + cl) * 4;
+  float4 s1[2] = {zero4(), zero4()};
+  if (active) {
+    float4 wreg[KS * KS];
+#pragma unroll
+    for (int i = 0; i < KS * KS; ++i) wreg[i] = ld4(p.w + (size_t)(p.flip ? KS * KS - 1 - i : i) * p.C + c);
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero4();
+    if (p.scale) { sc = ld4(p.scale + c); sh = ld4(p.shift + c); }
+    const int act = p.act;
+    XcdRange r = xcd_range(p.total, bx, p.nbx, p.px, pl);
+    for (long long s = r.begin; s < r.end; s += r.step) {
+      const int strip = (int)(s % p.spr);
+      const long long row = s / p.spr;
+      const int oy = (int)(row % p.Ho);
+      const int n = (int)(row / p.Ho);
+      const int ox0 = strip * TW;
+      const int ix0 = ox0 * S - p.pad_l;
+      float4 acc[TW];
+#pragma unroll
+      for (int i = 0; i < TW; ++i) acc[i] = zero4();
+#pragma unroll
+      for (int ky = 0; ky < KS; ++ky) {
+        const int iy = oy * S - p.pad_t + ky;
+        if (iy < 0 || iy >= p.H) continue;
+        const float* xrow = p.x + ((size_t)n * p.H + iy) * p.W * p.ldx + c;
+        float4 seg[SEG];
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) {
+          const int ix = ix0 + i;
+          if (ix >= 0 && ix < p.W) {
+            seg[i] = act_apply4(fma4(ld4(xrow + (size_t)ix * p.ldx), sc, sh), act);
+          } else {
+            seg[i] = zero4();
+          }
+        }
+#pragma unroll
+        for (int tw = 0; tw < TW; ++tw)
+#pragma unroll
+          for (int kx = 0; kx < KS; ++kx) acc[tw] = fma4(seg[tw * S + kx], wreg[ky * KS + kx], acc[tw]);
+      }
+      float* yrow = p.y + (((size_t)n * p.Ho + oy) * p.Wo + ox0) * p.ldy + c;
+#pragma unroll
+      for (int tw = 0; tw < TW; ++tw) {
+        if (ox0 + tw < p.Wo) {
+          float4 v = acc[tw];
+          if (p.accumulate) {
+            float4 o = ld4(yrow + (size_t)tw * p.ldy);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+          }
+          st4(yrow + (size_t)tw * p.ldy, v);
+          s1[0].x += v.x; s1[0].y += v.y; s1[0].z += v.z; s1[0].w += v.w;
+          s1[1] = fma4(v, v, s1[1]);
+        }
+      }
+    }
+  }
+  if (p.partials) block_reduce_store<2>(s1, active, pl, cl, p.c4s, p.px, cbase4, p.C, p.partials + (size_t)bx * 2 * p.C);
+}
+
+// ------------------------------------------------------------------------------ forward, any rate / stride
+// One output pixel per thread; each tap is a predicated 16-B gather served by the XCD's L2.
+template <int KS>
+__global__ __launch_bounds__(256) void dw_fwd_gather(DwParams p) {
+  const int b = blockIdx.x;
+  const int slab = b / p.nbx;
+  const int bx = b - slab * p.nbx;
+  const int t = threadIdx.x;
+  const int pl = t / p.c4s;
+  const int cl = t - pl * p.c4s;
+  const bool active = pl < p.px;
+  const int cbase4 = slab * p.c4s;
+  const int c = (cbase4 + cl) * 4;
+  float4 s1[2] = {zero4(), zero4()};
+  if (active) {
+    float4 wreg[KS * KS];
+#pragma unroll
+    for (int i = 0; i < KS * KS; ++i) wreg[i] = ld4(p.w + (size_t)(p.flip ? KS * KS - 1 - i : i) * p.C + c);
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero4();
+    if (p.scale) { sc = ld4(p.scale + c); sh = ld4(p.shift + c); }
+    const int act = p.act;
+    XcdRange r = xcd_range(p.total, bx, p.nbx, p.px, pl);
+    for (long long s = r.begin; s < r.end; s += r.step) {
+      const int ox = (int)(s % p.Wo);
+      const long long row = s / p.Wo;
+      const int oy = (int)(row % p.Ho);
+      const int n = (int)(row / p.Ho);
+      const float* ximg = p.x + (size_t)n * p.H * p.W * p.ldx + c;
+      float4 v[KS * KS];
+      // issue every valid tap load first (independent, all in flight), then the FMAs
+#pragma unroll
+      for (int ky = 0; ky < KS; ++ky) {
+        const int iy = oy * p.stride - p.pad_t + ky * p.rate;
+        const bool yok = iy >= 0 && iy < p.H;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+          const int ix = ox * p.stride - p.pad_l + kx * p.rate;
+          if (yok && ix >= 0 && ix < p.W) {
+            v[ky * KS + kx] = act_apply4(fma4(ld4(ximg + ((size_t)iy * p.W + ix) * p.ldx), sc, sh), act);
+          } else {
+            v[ky * KS + kx] = zero4();
+          }
+        }
+      }
+      float4 acc = zero4();
+#pragma unroll
+      for (int i = 0; i < KS * KS; ++i) acc = fma4(v[i], wreg[i], acc);
+      float* yp = p.y + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.ldy + c;
+      if (p.accumulate) {
+        float4 o = ld4(yp);
+        acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+      }
+      st4(yp, acc);
+      s1[0].x += acc.x; s1[0].y += acc.y; s1[0].z += acc.z; s1[0].w += acc.w;
+      s1[1] = fma4(acc, acc, s1[1]);
+    }
+  }
+  if (p.partials) block_reduce_store<2>(s1, active, pl, cl, p.c4s, p.px, cbase4, p.C, p.partials + (size_t)bx * 2 * p.C);
+}
+
+// ------------------------------------------------------------------------------ backward data, stride > 1
+// gx[n,iy,ix] = sum_taps w[ky,kx] * dy[n,(iy+pad_t-ky*r)/s,(ix+pad_l-kx*r)/s] where divisible.
+// Here (H,W) are the conv INPUT dims (the output of this kernel) and (Ho,Wo) the dy dims.
+template <int KS>
+__global__ __launch_bounds__(256) void dw_bwd_data_strided(DwParams p) {
+  const int b = blockIdx.x;
+  const int slab = b / p.nbx;
+  const int bx = b - slab * p.nbx;
+  const int t = threadIdx.x;
+  const int pl = t / p.c4s;
+  const int cl = t - pl * p.c4s;
+  if (pl >= p.px) return;
+  const int c = (slab * p.c4s + cl) * 4;
+  float4 wreg[KS * KS];
+#pragma unroll
+  for (int i = 0; i < KS * KS; ++i) wreg[i] = ld4(p.w + (size_t)i * p.C + c);
+  XcdRange r = xcd_range(p.total, bx, p.nbx, p.px, pl);
+  for (long long s = r.begin; s < r.end; s += r.step) {
+    const int ix = (int)(s % p.W);
+    const long long row = s / p.W;
+    const int iy = (int)(row % p.H);
+    const int n = (int)(row / p.H);
+    const float* dimg = p.dy + (size_t)n * p.Ho * p.Wo * p.lddy + c;
+    float4 acc = zero4();
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky) {
+      const int ty = iy + p.pad_t - ky * p.rate;
+      if (ty < 0 || ty % p.stride) continue;
+      const int oy = ty / p.stride;
+      if (oy >= p.Ho) continue;
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+        const int tx = ix + p.pad_l - kx * p.rate;
+        if (tx < 0 || tx % p.stride) continue;
+        const int ox = tx / p.stride;
+        if (ox >= p.Wo) continue;
+        acc = fma4(ld4(dimg + ((size_t)oy * p.Wo + ox) * p.lddy), wreg[ky * KS + kx], acc);
+      }
+    }
+    float* gp = p.y + (((size_t)n * p.H + iy) * p.W + ix) * p.ldy + c;
+    if (p.accumulate) {
+      float4 o = ld4(gp);
+      acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+    }
+    st4(gp, acc);
+  }
+}
+
+// ------------------------------------------------------------------------------ backward weight
+// gw[tap][c] = sum_{n,oy,ox} a[n, oy*s-pad+ky*r, ox*s-pad+kx*r, c] * dy[n,oy,ox,c]; a = act(x*scale+shift).
+// Per-thread tap accumulators over a persistent loop, then one partial row [k*k][C] per workgroup.
+template <int KS>
+__global__ __launch_bounds__(256) void dw_bwd_weight(DwParams p) {
+  const int b = blockIdx.x;
+  const int slab = b / p.nbx;
+  const int bx = b - slab * p.nbx;
+  const int t = threadIdx.x;
+  const int pl = t / p.c4s;
+  const int cl = t - pl * p.c4s;
+  const bool active = pl < p.px;
+  const int cbase4 = slab * p.c4s;
+  const int c = (cbase4 + cl) * 4;
+  float4 wacc[KS * KS];
+#pragma unroll
+  for (int i = 0; i < KS * KS; ++i) wacc[i] = zero4();
+  if (active) {
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero4();
+    if (p.scale) { sc = ld4(p.scale + c); sh = ld4(p.shift + c); }
+    const int act = p.act;
+    XcdRange r = xcd_range(p.total, bx, p.nbx, p.px, pl);
+    for (long long s = r.begin; s < r.end; s += r.step) {
+      const int ox = (int)(s % p.Wo);
+      const long long row = s / p.Wo;
+      const int oy = (int)(row % p.Ho);
+      const int n = (int)(row / p.Ho);
+      const float4 g = ld4(p.dy + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.lddy + c);
+      const float* ximg = p.x + (size_t)n * p.H * p.W * p.ldx + c;
+#pragma unroll
+      for (int ky = 0; ky < KS; ++ky) {
+        const int iy = oy * p.stride - p.pad_t + ky * p.rate;
+        const bool yok = iy >= 0 && iy < p.H;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+          const int ix = ox * p.stride - p.pad_l + kx * p.rate;
+          if (yok && ix >= 0 && ix < p.W) {
+            float4 a = act_apply4(fma4(ld4(ximg + ((size_t)iy * p.W + ix) * p.ldx), sc, sh), act);
+            wacc[ky * KS + kx] = fma4(a, g, wacc[ky * KS + kx]);
+          }
+        }
+      }
+    }
+  }
+  block_reduce_store<KS * KS>(wacc, active, pl, cl, p.c4s, p.px, cbase4, p.C,
+                              p.partials + (size_t)bx * KS * KS * p.C);
+}
+
+// ------------------------------------------------------------------------------ host side
+static int check_dw_common(const char* fn, const void* x, int ldx, int C, int k) {
+  DL3P_CHECK_ARG(C > 0 && C % 4 == 0, "%s: C=%d must be a positive multiple of 4", fn, C);
+  DL3P_CHECK_ARG(ldx % 4 == 0 && ldx >= C, "%s: ld=%d must be a multiple of 4 and >= C", fn, ldx);
+  DL3P_CHECK_ARG(aligned16(x), "%s: tensor pointer must be 16-byte aligned", fn);
+  DL3P_CHECK_ARG(k == 3 || k == 5, "%s: kernel size %d unsupported (3 or 5)", fn, k);
+  return DL3P_OK;
+}
+
+template <int KS>
+static void launch_fwd(const DwParams& p0, hipStream_t st) {
+  DwParams p = p0;
+  const bool seg = p.rate == 1 && (p.stride == 1 || p.stride == 2) && p.Wo >= 4;
+  const int TW = seg ? (p.stride == 1 ? 4 : 2) : 1;
+  p.spr = ceil_div(p.Wo, TW);
+  p.total = (long long)p.N * p.Ho * p.spr;
+  p.nbx = pick_nbx(p.total, p.px, p.nslab);
+  dim3 grid(p.nbx * p.nslab), block(256);
+  if (seg && p.stride == 1) hipLaunchKernelGGL((dw_fwd_seg<KS, 4, 1>), grid, block, 0, st, p);
+  else if (seg) hipLaunchKernelGGL((dw_fwd_seg<KS, 2, 2>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((dw_fwd_gather<KS>), grid, block, 0, st, p);
+}
+
+extern "C" int dl3p_dwconv2d_fwd(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                                 const float* w, float* y, int ldy, float* stat_partials, int* rows_out,
+                                 int N, int H, int W, int C, int k, int stride, int rate, int pad_t, int pad_l,
+                                 int Ho, int Wo, void* stream) {
+  int rc = check_dw_common("dl3p_dwconv2d_fwd", x, ldx, C, k);
+  if (rc) return rc;
+  DL3P_CHECK_ARG(x && w && y, "dl3p_dwconv2d_fwd: null pointer");
+  DL3P_CHECK_ARG(ldy % 4 == 0 && ldy >= C && aligned16(y) && aligned16(w), "dl3p_dwconv2d_fwd: bad y/w layout");
+  DL3P_CHECK_ARG(N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && stride >= 1 && rate >= 1, "dl3p_dwconv2d_fwd: bad dims");
+  DwParams p = {};
+  p.x = x; p.ldx = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act; p.w = w;
+  p.y = y; p.ldy = ldy; p.partials = stat_partials;
+  p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.rate = rate;
+  p.pad_t = pad_t; p.pad_l = pad_l;
+  pick_lanes(C, &p.c4s, &p.px, &p.nslab);
+  // nbx depends on the variant; replicate launch_fwd's choice to report it
+  {
+    const bool seg = rate == 1 && (stride == 1 || stride == 2) && Wo >= 4;
+    const int TW = seg ? (stride == 1 ? 4 : 2) : 1;
+    long long total = (long long)N * Ho * ceil_div(Wo, TW);
+    if (rows_out) *rows_out = pick_nbx(total, p.px, p.nslab);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (k == 3) launch_fwd<3>(p, st); else launch_fwd<5>(p, st);
+  DL3P_CHECK_LAUNCH("dl3p_dwconv2d_fwd");
+  return DL3P_OK;
+}
+
+extern "C" int dl3p_dwconv2d_bwd_data(const float* dy, int lddy, const float* w, float* gx, int ldgx, int accumulate,
+                                      int N, int H, int W, int C, int k, int stride, int rate, int pad_t, int pad_l,
+                                      int Ho, int Wo, void* stream) {
+  int rc = check_dw_common("dl3p_dwconv2d_bwd_data", dy, lddy, C, k);
+  if (rc) return rc;
+  DL3P_CHECK_ARG(dy && w && gx, "dl3p_dwconv2d_bwd_data: null pointer");
+  DL3P_CHECK_ARG(ldgx % 4 == 0 && ldgx >= C && aligned16(gx) && aligned16(w), "dl3p_dwconv2d_bwd_data: bad gx/w layout");
+  hipStream_t st = (hipStream_t)stream;
+  DwParams p = {};
+  p.w = w; p.C = C; p.N = N; p.accumulate = accumulate;
+  pick_lanes(C, &p.c4s, &p.px, &p.nslab);
+  if (stride == 1) {
+    // correlation with the flipped kernel: a forward conv from (Ho,Wo) to (H,W) with
+    // pad' = rate*(k-1) - pad
+    p.x = dy; p.ldx = lddy; p.y = gx; p.ldy = ldgx; p.flip = 1;
+    p.H = Ho; p.W = Wo; p.Ho = H; p.Wo = W; p.stride = 1; p.rate = rate;
+    p.pad_t = rate * (k - 1) - pad_t; p.pad_l = rate * (k - 1) - pad_l;
+    p.act = DL3P_ACT_NONE;
+    if (k == 3) launch_fwd<3>(p, st); else launch_fwd<5>(p, st);
+  } else {
+    p.dy = dy; p.lddy = lddy; p.y = gx; p.ldy = ldgx;
+    p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.rate = rate; p.pad_t = pad_t; p.pad_l = pad_l;
+    p.total = (long long)N * H * W;
+    p.nbx = pick_nbx(p.total, p.px, p.nslab);
+    dim3 grid(p.nbx * p.nslab), block(256);
+    if (k == 3) hipLaunchKernelGGL((dw_bwd_data_strided<3>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((dw_bwd_data_strided<5>), grid, block, 0, st, p);
+  }
+  DL3P_CHECK_LAUNCH("dl3p_dwconv2d_bwd_data");
+  return DL3P_OK;
+}
+
+static int bwdw_rows(int N, int Ho, int Wo, int C) {
+  int c4s, px, nslab;
+  pick_lanes(C, &c4s, &px, &nslab);
+  return pick_nbx((long long)N * Ho * Wo, px, nslab);
+}
+
+extern "C" size_t dl3p_dwconv2d_bwd_weight_workspace(int N, int Ho, int Wo, int C, int k) {
+  if (C <= 0 || C % 4) return 0;
+  return (size_t)bwdw_rows(N, Ho, Wo, C) * k * k * C * sizeof(float);
+}
+
+extern "C" int dl3p_dwconv2d_bwd_weight(const float* x, int ldx, const float* in_scale, const float* in_shift,
+                                        int in_act, const float* dy, int lddy, float* gw, float* workspace,
+                                        size_t workspace_bytes, int N, int H, int W, int C, int k, int stride,
+                                        int rate, int pad_t, int pad_l, int Ho, int Wo, void* stream) {
+  int rc = check_dw_common("dl3p_dwconv2d_bwd_weight", x, ldx, C, k);
+  if (rc) return rc;
+  DL3P_CHECK_ARG(x && dy && gw && workspace, "dl3p_dwconv2d_bwd_weight: null pointer");
+  DL3P_CHECK_ARG(lddy % 4 == 0 && lddy >= C && aligned16(dy) && aligned16(workspace) && aligned16(gw),
+                 "dl3p_dwconv2d_bwd_weight: bad dy/workspace layout");
+  const size_t need = dl3p_dwconv2d_bwd_weight_workspace(N, Ho, Wo, C, k);
+  if (workspace_bytes < need) {
+    dl3p_set_error("dl3p_dwconv2d_bwd_weight: workspace %zu < %zu bytes", workspace_bytes, need);
+    return DL3P_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  DwParams p = {};
+  p.x = x; p.ldx = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act;
+  p.dy = dy; p.lddy = lddy; p.partials = workspace;
+  p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.rate = rate;
+  p.pad_t = pad_t; p.pad_l = pad_l;
+  pick_lanes(C, &p.c4s, &p.px, &p.nslab);
+  p.total = (long long)N * Ho * Wo;
+  p.nbx = pick_nbx(p.total, p.px, p.nslab);
+  dim3 grid(p.nbx * p.nslab), block(256);
+  if (k == 3) hipLaunchKernelGGL((dw_bwd_weight<3>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((dw_bwd_weight<5>), grid, block, 0, st, p);
+  DL3P_CHECK_LAUNCH("dl3p_dwconv2d_bwd_weight");
+  return dl3p_reduce_rows_impl(workspace, p.nbx, (size_t)k * k * C, gw, 0, st);
+}

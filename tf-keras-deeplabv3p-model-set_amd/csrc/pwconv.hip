@@ -1,0 +1,474 @@
+// Pointwise (1x1) convolution = row-major GEMM on the MFMA f32 path (v_mfma_f32_16x16x4_f32) for gfx950.
+//
+// Replaces Conv2D(filters,(1,1)) at /root/reference deeplabv3p/models/layers.py:105,134,141,157,209,
+// deeplabv3p_mobilenetv2.py:47,63, deeplabv3p_xception.py:81, deeplabv3p/model.py:75 (93-98 % of the
+// model's MACs).
+//
+//   fwd    Y[M,N]  = act(X[M,K]*scale+shift) @ W[K,N] (+bias)      + per-channel (sum, sum^2) partials
+//   dgrad  GX[M,K] (+)= DY[M,N] @ W[K,N]^T
+//   wgrad  GW[K,N] = act(X*scale+shift)^T @ DY                      (split over M, slab reduce)
+//
+// fp32 in / fp32 accumulate is exact f32 (bitwise an fmaf chain), which the 1e-3 parity budget needs;
+// it runs at 64 FLOP/clk/SIMD so the kernels are MFMA-issue bound and LDS traffic is negligible
+// (one 16-B fragment read feeds four MFMAs).  Tiling is for 64-wide waves: a workgroup = 4 waves, each
+// wave owns 32 rows x (16*NT) columns as 2 x NT accumulators of 16x16.  The k index inside a
+// 16-deep group is permuted (lane quarter q supplies k = 4q+j at step j) so that every A fragment is ONE
+// ds_read_b128; both operands use the same permutation so the sum is unchanged.
+// Operands are swapped in the MFMA (D = W^T-frag x X-frag) so a lane ends up with 4 CONSECUTIVE output
+// channels of one pixel: the epilogue is a single 16-B store per accumulator and the BN statistics are
+// a 16-lane shuffle reduction.  Workgroups are persistent over M tiles: statistics stay in registers
+// and leave as one partial row per workgroup (deterministic, no atomics); the global->LDS staging of
+// the next tile is issued before the current tile's MFMAs (register double buffering) and applies the
+// producer's BN+activation on the way in, so normalised activations are never materialised in HBM.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define BM 128
+#define BK 32
+#define APITCH 36  // 32 + 4: rows 4 apart land 16 banks apart -> ds_read_b128 conflict-free
+
+struct GemmParams {
+  const float* A; int lda;
+  const float* scale; const float* shift; int act;
+  const float* B; int ldb;
+  const float* bias;
+  float* Y; int ldy;
+  float* partials;
+  int M, K, N;
+  int accumulate;
+  int num_m_tiles;
+};
+
+// B_KN: B is [Kred][Nout] row-major (forward: the Keras kernel as stored);
+// !B_KN: B is [Nout][Kred] row-major (dgrad: the same kernel read as its transpose).
+template <int NT, bool B_KN, bool STATS>
+__global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
+  constexpr int BN = 16 * NT;
+  constexpr int BPITCH = B_KN ? (BN + 4) : APITCH;
+  constexpr int BS_FLOATS = B_KN ? BK * BPITCH : BN * APITCH;
+  constexpr int NB4 = (8 * BN + 255) / 256;  // float4 per thread for the B tile
+  __shared__ __attribute__((aligned(16))) float As[BM * APITCH];
+  __shared__ __attribute__((aligned(16))) float Bs[BS_FLOATS];
+  __shared__ float red[STATS ? 2 * 4 * BN : 1];
+
+  const int t = threadIdx.x;
+  const int l = t & 63;
+  const int w = t >> 6;
+  const int l15 = l & 15;
+  const int q = l >> 4;
+  const int n0 = blockIdx.y * BN;
+  const int nk = (p.K + BK - 1) / BK;
+  const int my_tiles = (p.num_m_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int it_total = my_tiles * nk;
+
+  // staging roles
+  const int ar = t >> 3;         // A row within a 32-row pass
+  const int akq = (t & 7) * 4;   // A k offset within the K tile
+
+  float4 ra[4];
+  float4 rb[NB4];
+  float4 rsc = make_float4(1.f, 1.f, 1.f, 1.f), rsh = zero4();
+  int cur_m0 = 0;
+
+  auto prefetch = [&](int it) {
+    const int kt = it % nk;
+    const int mt = blockIdx.x + (it / nk) * gridDim.x;
+    const int m0 = mt * BM;
+    const int k0 = kt * BK;
+    const bool kok = k0 + akq < p.K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + ar + 32 * i;
+      ra[i] = (kok && m < p.M) ? ld4(p.A + (size_t)m * p.lda + k0 + akq) : zero4();
+    }
+    if (p.scale && kok) { rsc = ld4(p.scale + k0 + akq); rsh = ld4(p.shift + k0 + akq); }
+#pragma unroll
+    for (int i = 0; i < NB4; ++i) {
+      const int idx = t + 256 * i;
+      if (B_KN) {
+        const int kk = idx / (BN / 4), nq = idx - kk * (BN / 4);
+        const int k = k0 + kk, n = n0 + nq * 4;
+        rb[i] = (idx < 8 * BN && k < p.K && n < p.N) ? ld4(p.B + (size_t)k * p.ldb + n) : zero4();
+      } else {
+        const int r = idx >> 3, kq = (idx & 7) * 4;
+        const int n = n0 + r, k = k0 + kq;
+        rb[i] = (idx < 8 * BN && n < p.N && k < p.K) ? ld4(p.B + (size_t)n * p.ldb + k) : zero4();
+      }
+    }
+  };
+
+  auto stage = [&](int it) {
+    const int kt = it % nk;
+    const int mt = blockIdx.x + (it / nk) * gridDim.x;
+    const int m0 = mt * BM;
+    const bool kok = kt * BK + akq < p.K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = ar + 32 * i;
+      float4 v = ra[i];
+      // zero rows/cols stay exactly zero (padding of the M and K tails)
+      if (kok && m0 + r < p.M) v = act_apply4(fma4(v, rsc, rsh), p.act);
+      *reinterpret_cast<float4*>(&As[r * APITCH + akq]) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB4; ++i) {
+      const int idx = t + 256 * i;
+      if (idx < 8 * BN) {
+        if (B_KN) {
+          const int kk = idx / (BN / 4), nq = idx - kk * (BN / 4);
+          *reinterpret_cast<float4*>(&Bs[kk * BPITCH + nq * 4]) = rb[i];
+        } else {
+          const int r = idx >> 3, kq = (idx & 7) * 4;
+          *reinterpret_cast<float4*>(&Bs[r * APITCH + kq]) = rb[i];
+        }
+      }
+    }
+  };
+
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 st_s[STATS ? NT : 1], st_q[STATS ? NT : 1];
+  if (STATS) {
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) { st_s[ni] = (f32x4){0.f, 0.f, 0.f, 0.f}; st_q[ni] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  }
+
+  if (it_total > 0) prefetch(0);
+  for (int it = 0; it < it_total; ++it) {
+    stage(it);
+    __syncthreads();
+    if (it + 1 < it_total) prefetch(it + 1);
+#pragma unroll
+    for (int g = 0; g < BK / 16; ++g) {
+      const int kc = g * 16 + q * 4;
+      float4 a[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+        a[mi] = *reinterpret_cast<const float4*>(&As[(w * 32 + mi * 16 + l15) * APITCH + kc]);
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) {
+        float b[4];
+        if (B_KN) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) b[j] = Bs[(kc + j) * BPITCH + ni * 16 + l15];
+        } else {
+          const float4 bv = *reinterpret_cast<const float4*>(&Bs[(ni * 16 + l15) * APITCH + kc]);
+          b[0] = bv.x; b[1] = bv.y; b[2] = bv.z; b[3] = bv.w;
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[0], a[mi].x, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[1], a[mi].y, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[2], a[mi].z, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[3], a[mi].w, acc[mi][ni], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    if (it % nk == nk - 1) {
+      // epilogue of this M tile: lane holds 4 consecutive output channels (q*4..q*4+3) of pixel l15
+      const int mt = blockIdx.x + (it / nk) * gridDim.x;
+      const int m0 = mt * BM;
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) {
+        const int n = n0 + ni * 16 + q * 4;
+        float4 bias4 = zero4();
+        if (p.bias && n < p.N) bias4 = ld4(p.bias + n);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int m = m0 + w * 32 + mi * 16 + l15;
+          f32x4 v = acc[mi][ni];
+          acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (m < p.M && n < p.N) {
+            float4 o = make_float4(v[0] + bias4.x, v[1] + bias4.y, v[2] + bias4.z, v[3] + bias4.w);
+            float* yp = p.Y + (size_t)m * p.ldy + n;
+            if (p.accumulate) o = add4(o, ld4(yp));
+            st4(yp, o);
+            if (STATS) {
+              st_s[ni] += (f32x4){o.x, o.y, o.z, o.w};
+              st_q[ni] += (f32x4){o.x * o.x, o.y * o.y, o.z * o.z, o.w * o.w};
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if (STATS) {
+    // reduce over the 16 pixel lanes, then over the 4 waves; one partial row per workgroup
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float s = st_s[ni][e], sq = st_q[ni][e];
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+          s += __shfl_xor(s, off);
+          sq += __shfl_xor(sq, off);
+        }
+        if (l15 == 0) {
+          red[(0 * 4 + w) * BN + ni * 16 + q * 4 + e] = s;
+          red[(1 * 4 + w) * BN + ni * 16 + q * 4 + e] = sq;
+        }
+      }
+    }
+    __syncthreads();
+    if (p.partials) {
+      for (int i = t; i < 2 * BN; i += 256) {
+        const int which = i / BN, nn = i - which * BN;
+        if (n0 + nn < p.N) {
+          float s = red[(which * 4 + 0) * BN + nn] + red[(which * 4 + 1) * BN + nn] +
+                    red[(which * 4 + 2) * BN + nn] + red[(which * 4 + 3) * BN + nn];
+          p.partials[((size_t)blockIdx.x * 2 + which) * p.N + n0 + nn] = s;
+        }
+      }
+    }
+  }
+}
+
+// choose the columns-per-workgroup (NT tiles of 16) that wastes the fewest MFMA columns
+static int pick_nt(int N) {
+  const int ntiles = ceil_div(N, 16);
+  static const int cand[] = {8, 6, 5, 4, 3, 2, 1};
+  int best = 1, best_waste = 1 << 30;
+  for (int c : cand) {
+    int waste = ceil_div(ntiles, c) * c - ntiles;
+    if (waste < best_waste) { best = c; best_waste = waste; }
+  }
+  return best;
+}
+
+static void gemm_grid(int M, int N, int nt, int* gx, int* gy, int* num_m_tiles) {
+  const int mt = ceil_div(M, BM);
+  const int nb = ceil_div(N, 16 * nt);
+  int gx_max = (DL3P_NUM_CUS * 2) / nb;          // two workgroups per CU (acc + stats registers)
+  if (gx_max < 8) gx_max = 8;
+  if (gx_max > DL3P_MAX_STAT_ROWS) gx_max = DL3P_MAX_STAT_ROWS;
+  int g = mt;
+  if (mt > gx_max) {
+    const int per = ceil_div(mt, gx_max);
+    g = ceil_div(mt, per);
+  }
+  *gx = g; *gy = nb; *num_m_tiles = mt;
+}
+
+template <bool B_KN, bool STATS>
+static void launch_gemm(const GemmParams& p, int nt, dim3 grid, hipStream_t st) {
+  dim3 block(256);
+  switch (nt) {
+    case 1: hipLaunchKernelGGL((pw_gemm_kernel<1, B_KN, STATS>), grid, block, 0, st, p); break;
+    case 2: hipLaunchKernelGGL((pw_gemm_kernel<2, B_KN, STATS>), grid, block, 0, st, p); break;
+    case 3: hipLaunchKernelGGL((pw_gemm_kernel<3, B_KN, STATS>), grid, block, 0, st, p); break;
+    case 4: hipLaunchKernelGGL((pw_gemm_kernel<4, B_KN, STATS>), grid, block, 0, st, p); break;
+    case 5: hipLaunchKernelGGL((pw_gemm_kernel<5, B_KN, STATS>), grid, block, 0, st, p); break;
+    case 6: hipLaunchKernelGGL((pw_gemm_kernel<6, B_KN, STATS>), grid, block, 0, st, p); break;
+    default: hipLaunchKernelGGL((pw_gemm_kernel<8, B_KN, STATS>), grid, block, 0, st, p); break;
+  }
+}
+
+static int check_mat(const char* fn, const void* ptr, int ld, int cols) {
+  DL3P_CHECK_ARG(ptr != nullptr, "%s: null pointer", fn);
+  DL3P_CHECK_ARG(cols > 0 && cols % 4 == 0, "%s: channel count %d must be a positive multiple of 4", fn, cols);
+  DL3P_CHECK_ARG(ld % 4 == 0 && ld >= cols && aligned16(ptr), "%s: bad layout (ld=%d)", fn, ld);
+  return DL3P_OK;
+}
+
+extern "C" int dl3p_pwconv_fwd(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                               const float* w, const float* bias, float* y, int ldy, float* stat_partials,
+                               int* rows_out, int M, int K, int N, void* stream) {
+  int rc = check_mat("dl3p_pwconv_fwd", x, ldx, K);
+  if (rc) return rc;
+  rc = check_mat("dl3p_pwconv_fwd", y, ldy, N);
+  if (rc) return rc;
+  DL3P_CHECK_ARG(w && aligned16(w) && M > 0, "dl3p_pwconv_fwd: bad arguments");
+  GemmParams p = {};
+  p.A = x; p.lda = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act;
+  p.B = w; p.ldb = N; p.bias = bias; p.Y = y; p.ldy = ldy; p.partials = stat_partials;
+  p.M = M; p.K = K; p.N = N;
+  const int nt = pick_nt(N);
+  int gx, gy;
+  gemm_grid(M, N, nt, &gx, &gy, &p.num_m_tiles);
+  if (rows_out) *rows_out = gx;
+  hipStream_t st = (hipStream_t)stream;
+  if (stat_partials) launch_gemm<true, true>(p, nt, dim3(gx, gy), st);
+  else launch_gemm<true, false>(p, nt, dim3(gx, gy), st);
+  DL3P_CHECK_LAUNCH("dl3p_pwconv_fwd");
+  return DL3P_OK;
+}
+
+extern "C" int dl3p_pwconv_bwd_data(const float* dy, int lddy, const float* w, float* gx, int ldgx, int accumulate,
+                                    int M, int K, int N, void* stream) {
+  int rc = check_mat("dl3p_pwconv_bwd_data", dy, lddy, N);
+  if (rc) return rc;
+  rc = check_mat("dl3p_pwconv_bwd_data", gx, ldgx, K);
+  if (rc) return rc;
+  DL3P_CHECK_ARG(w && aligned16(w) && M > 0, "dl3p_pwconv_bwd_data: bad arguments");
+  GemmParams p = {};
+  p.A = dy; p.lda = lddy; p.act = DL3P_ACT_NONE;
+  p.B = w; p.ldb = N;           // W[K][N]: output column k, reduction n contiguous
+  p.Y = gx; p.ldy = ldgx; p.accumulate = accumulate;
+  p.M = M; p.K = N; p.N = K;    // reduce over N, produce K columns
+  const int nt = pick_nt(K);
+  int gxn, gy;
+  gemm_grid(M, K, nt, &gxn, &gy, &p.num_m_tiles);
+  launch_gemm<false, false>(p, nt, dim3(gxn, gy), (hipStream_t)stream);
+  DL3P_CHECK_LAUNCH("dl3p_pwconv_bwd_data");
+  return DL3P_OK;
+}
+
+// ------------------------------------------------------------------------------ weight gradient
+// One workgroup = one 64(k) x 64(n) tile of GW over one slice of M; slices are summed by
+// dl3p_reduce_rows (fixed order -> deterministic).  Both operands are staged in their natural
+// [m][channel] layout (pitch 68: rows 4 apart land 16 banks apart) and read as ds_read_b32 fragments.
+#define WPITCH 68
+struct WgradParams {
+  const float* X; int ldx; const float* scale; const float* shift; int act;
+  const float* DY; int lddy;
+  float* slabs;
+  int M, K, N;
+  int ktiles, ntiles, mchunk;
+};
+
+__global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradParams p) {
+  __shared__ __attribute__((aligned(16))) float Xs[32 * WPITCH];
+  __shared__ __attribute__((aligned(16))) float Ds[32 * WPITCH];
+  const int t = threadIdx.x, l = t & 63, w = t >> 6, l15 = l & 15, q = l >> 4;
+  const int tile = blockIdx.x;
+  const int kt = tile / p.ntiles, nt = tile - kt * p.ntiles;
+  const int k0 = kt * 64, n0 = nt * 64;
+  const int m_begin = blockIdx.y * p.mchunk;
+  const int m_end = min(p.M, m_begin + p.mchunk);
+  // staging: 32 rows x 64 cols = 512 float4 per operand, 2 per thread
+  const int sr = t >> 4;            // row 0..15 (+16)
+  const int sc4 = (t & 15) * 4;     // col offset
+  const bool xk_ok = k0 + sc4 < p.K;
+  const bool dn_ok = n0 + sc4 < p.N;
+  float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = zero4();
+  if (p.scale && xk_ok) { xsc = ld4(p.scale + k0 + sc4); xsh = ld4(p.shift + k0 + sc4); }
+  float4 rx[2], rd[2];
+  auto prefetch = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + sr + 16 * i;
+      const bool mok = m < m_end;
+      rx[i] = (mok && xk_ok) ? act_apply4(fma4(ld4(p.X + (size_t)m * p.ldx + k0 + sc4), xsc, xsh), p.act) : zero4();
+      rd[i] = (mok && dn_ok) ? ld4(p.DY + (size_t)m * p.lddy + n0 + sc4) : zero4();
+    }
+  };
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (m_begin < m_end) prefetch(m_begin);
+  for (int m0 = m_begin; m0 < m_end; m0 += 32) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<float4*>(&Xs[(sr + 16 * i) * WPITCH + sc4]) = rx[i];
+      *reinterpret_cast<float4*>(&Ds[(sr + 16 * i) * WPITCH + sc4]) = rd[i];
+    }
+    __syncthreads();
+    if (m0 + 32 < m_end) prefetch(m0 + 32);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      float a[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = Xs[(g * 16 + q * 4 + j) * WPITCH + w * 16 + l15];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float b = Ds[(g * 16 + q * 4 + j) * WPITCH + ni * 16 + l15];
+          // D[n][k]: lane ends with 4 consecutive n for k = l15
+          acc[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a[j], acc[ni], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int k = k0 + w * 16 + l15;
+  float* slab = p.slabs + (size_t)blockIdx.y * p.K * p.N;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int n = n0 + ni * 16 + q * 4;
+    if (k < p.K && n < p.N) st4(slab + (size_t)k * p.N + n, make_float4(acc[ni][0], acc[ni][1], acc[ni][2], acc[ni][3]));
+  }
+}
+
+static void wgrad_split(int M, int K, int N, int* ktiles, int* ntiles, int* splits, int* mchunk) {
+  *ktiles = ceil_div(K, 64);
+  *ntiles = ceil_div(N, 64);
+  const int tiles = *ktiles * *ntiles;
+  int s = (DL3P_NUM_CUS * 4) / tiles;
+  if (s < 1) s = 1;
+  int max_s = ceil_div(M, 256);          // at least 256 rows per slice
+  if (s > max_s) s = max_s;
+  if (s > DL3P_MAX_STAT_ROWS) s = DL3P_MAX_STAT_ROWS;
+  int chunk = ceil_div(ceil_div(M, s), 32) * 32;
+  *splits = ceil_div(M, chunk);
+  *mchunk = chunk;
+}
+
+// column sums of dy (bias gradient): one partial row per workgroup
+__global__ __launch_bounds__(256) void colsum_kernel(const float* dy, int lddy, long long M, int C, int c4s, int px,
+                                                     int nbx, float* partials) {
+  const int b = blockIdx.x;
+  const int slab = b / nbx;
+  const int bx = b - slab * nbx;
+  const int pl = threadIdx.x / c4s;
+  const int cl = threadIdx.x - pl * c4s;
+  const bool active = pl < px;
+  const int cbase4 = slab * c4s;
+  const int c = (cbase4 + cl) * 4;
+  float4 acc[1] = {zero4()};
+  if (active)
+    for (long long m = (long long)bx * px + pl; m < M; m += (long long)nbx * px) acc[0] = add4(acc[0], ld4(dy + (size_t)m * lddy + c));
+  block_reduce_store<1>(acc, active, pl, cl, c4s, px, cbase4, C, partials + (size_t)bx * C);
+}
+
+extern "C" size_t dl3p_pwconv_bwd_weight_workspace(int M, int K, int N) {
+  if (M <= 0 || K <= 0 || N <= 0) return 0;
+  int kt, nt, s, mc;
+  wgrad_split(M, K, N, &kt, &nt, &s, &mc);
+  size_t a = (size_t)s * K * N;
+  size_t b = (size_t)512 * N;  // bias column-sum partial rows
+  return (a > b ? a : b) * sizeof(float);
+}
+
+extern "C" int dl3p_pwconv_bwd_weight(const float* x, int ldx, const float* in_scale, const float* in_shift,
+                                      int in_act, const float* dy, int lddy, float* gw, float* gb, float* workspace,
+                                      size_t workspace_bytes, int M, int K, int N, void* stream) {
+  int rc = check_mat("dl3p_pwconv_bwd_weight", x, ldx, K);
+  if (rc) return rc;
+  rc = check_mat("dl3p_pwconv_bwd_weight", dy, lddy, N);
+  if (rc) return rc;
+  DL3P_CHECK_ARG(gw && workspace && aligned16(workspace) && M > 0, "dl3p_pwconv_bwd_weight: bad arguments");
+  const size_t need = dl3p_pwconv_bwd_weight_workspace(M, K, N);
+  if (workspace_bytes < need) {
+    dl3p_set_error("dl3p_pwconv_bwd_weight: workspace %zu < %zu bytes", workspace_bytes, need);
+    return DL3P_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  WgradParams p = {};
+  p.X = x; p.ldx = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act;
+  p.DY = dy; p.lddy = lddy; p.slabs = workspace; p.M = M; p.K = K; p.N = N;
+  int splits;
+  wgrad_split(M, K, N, &p.ktiles, &p.ntiles, &splits, &p.mchunk);
+  hipLaunchKernelGGL(pw_wgrad_kernel, dim3(p.ktiles * p.ntiles, splits), dim3(256), 0, st, p);
+  DL3P_CHECK_LAUNCH("dl3p_pwconv_bwd_weight");
+  rc = dl3p_reduce_rows_impl(workspace, splits, (size_t)K * N, gw, 0, st);
+  if (rc) return rc;
+  if (gb) {
+    int c4s, px, nslab;
+    pick_lanes(N, &c4s, &px, &nslab);
+    long long need_b = ceil_div_ll(M, px);
+    int nbx = (int)(need_b < 512 ? need_b : 512);
+    hipLaunchKernelGGL(colsum_kernel, dim3(nbx * nslab), dim3(256), 0, st, dy, lddy, (long long)M, N, c4s, px, nbx,
+                       workspace);
+    DL3P_CHECK_LAUNCH("dl3p_pwconv_bwd_weight(colsum)");
+    rc = dl3p_reduce_rows_impl(workspace, nbx, (size_t)N, gb, 0, st);
+  }
+  return rc;
+}

@@ -1,0 +1,340 @@
+"""Tensor-level wrappers over the C ABI (include/dl3p.h).
+
+PyTorch is only the allocator / stream provider here: every function takes CUDA(=HIP) float32
+tensors in NHWC memory (a channel slice of a wider buffer is fine: row stride `ld` is taken from the
+tensor's strides), hands raw device pointers to libdl3p.so and returns.  There is no CPU or torch
+fallback: a missing library raises at import, a non-HIP tensor raises here.
+"""
+import ctypes
+import torch
+
+from ._lib import lib, Dl3pError  # noqa: F401
+
+ACT_NONE, ACT_RELU, ACT_RELU6, ACT_HSWISH, ACT_HSIGMOID = 0, 1, 2, 3, 4
+MAX_STAT_ROWS = 2048
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _pl(t):
+    """(device pointer, row stride in floats) of an NHWC / [M,C] tensor or channel-slice view"""
+    if t is None:
+        return None, 0
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise Dl3pError('dl3p ops need float32 tensors on the HIP device (got %s on %s)' % (t.dtype, t.device))
+    if t.stride(-1) != 1:
+        raise Dl3pError('channel dim must be contiguous')
+    ld = t.stride(-2) if t.dim() >= 2 else t.shape[-1]
+    # rows must be evenly spaced: stride of each leading dim == size*stride of the next
+    for d in range(t.dim() - 2):
+        if t.shape[d + 1] > 0 and t.stride(d) != t.stride(d + 1) * t.shape[d + 1]:
+            raise Dl3pError('rows are not evenly strided: %s %s' % (tuple(t.shape), t.stride()))
+    return t.data_ptr(), ld
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def same_pad(in_size, k, stride, rate):
+    """TF SAME: (out, pad_begin) -- the odd unit of padding goes to the end"""
+    k_eff = k + (k - 1) * (rate - 1)
+    out = -(-in_size // stride)
+    total = max((out - 1) * stride + k_eff - in_size, 0)
+    return out, total // 2
+
+
+def conv_geometry(H, W, k, stride, rate, padding):
+    """padding 'same' | 'valid' | (pt, pb, pl, pr) -> Ho, Wo, pad_t, pad_l"""
+    if padding == 'same':
+        Ho, pt = same_pad(H, k, stride, rate)
+        Wo, pl = same_pad(W, k, stride, rate)
+        return Ho, Wo, pt, pl
+    if padding == 'valid':
+        padding = (0, 0, 0, 0)
+    pt, pb, pl, pr = padding
+    k_eff = k + (k - 1) * (rate - 1)
+    return (H + pt + pb - k_eff) // stride + 1, (W + pl + pr - k_eff) // stride + 1, pt, pl
+
+
+def new_partials(C, device, rows=MAX_STAT_ROWS):
+    return torch.empty(rows * 2 * C, dtype=torch.float32, device=device)
+
+
+# ------------------------------------------------------------------------------------- depthwise
+def dwconv2d_fwd(x, w, stride=1, rate=1, padding='same', in_scale=None, in_shift=None, in_act=ACT_NONE,
+                 out=None, partials=None):
+    """x (N,H,W,C); w (k,k,C) or (k,k,C,1) -> y (N,Ho,Wo,C) [, rows]"""
+    N, H, W, C = x.shape
+    k = w.shape[0]
+    Ho, Wo, pt, pl = conv_geometry(H, W, k, stride, rate, padding)
+    y = out if out is not None else torch.empty((N, Ho, Wo, C), dtype=torch.float32, device=x.device)
+    xp, ldx = _pl(x)
+    yp, ldy = _pl(y)
+    rows = ctypes.c_int(0)
+    lib().dwconv2d_fwd(xp, ldx, _p(in_scale), _p(in_shift), in_act, _p(w), yp, ldy, _p(partials), ctypes.byref(rows),
+                       N, H, W, C, k, stride, rate, pt, pl, Ho, Wo, _stream())
+    return (y, rows.value) if partials is not None else y
+
+
+def dwconv2d_bwd_data(dy, w, x_shape, stride=1, rate=1, padding='same', out=None, accumulate=False):
+    N, H, W, C = x_shape
+    k = w.shape[0]
+    Ho, Wo, pt, pl = conv_geometry(H, W, k, stride, rate, padding)
+    gx = out if out is not None else torch.empty(x_shape, dtype=torch.float32, device=dy.device)
+    dp, ldd = _pl(dy)
+    gp, ldg = _pl(gx)
+    lib().dwconv2d_bwd_data(dp, ldd, _p(w), gp, ldg, int(accumulate), N, H, W, C, k, stride, rate, pt, pl, Ho, Wo,
+                            _stream())
+    return gx
+
+
+def dwconv2d_bwd_weight(x, dy, k, stride=1, rate=1, padding='same', in_scale=None, in_shift=None, in_act=ACT_NONE,
+                        workspace=None):
+    N, H, W, C = x.shape
+    Ho, Wo, pt, pl = conv_geometry(H, W, k, stride, rate, padding)
+    need = lib().dwconv2d_bwd_weight_workspace(N, Ho, Wo, C, k)
+    ws = workspace if workspace is not None else torch.empty(need // 4, dtype=torch.float32, device=x.device)
+    gw = torch.empty((k, k, C), dtype=torch.float32, device=x.device)
+    xp, ldx = _pl(x)
+    dp, ldd = _pl(dy)
+    lib().dwconv2d_bwd_weight(xp, ldx, _p(in_scale), _p(in_shift), in_act, dp, ldd, _p(gw), _p(ws), ws.numel() * 4,
+                              N, H, W, C, k, stride, rate, pt, pl, Ho, Wo, _stream())
+    return gw
+
+
+# ------------------------------------------------------------------------------------- pointwise
+def _rows(t):
+    return t.numel() // t.shape[-1]
+
+
+def pwconv_fwd(x, w, bias=None, in_scale=None, in_shift=None, in_act=ACT_NONE, out=None, partials=None):
+    """x (..., K); w (K,N) -> y (..., N)"""
+    K, Nn = w.shape[-2], w.shape[-1]
+    M = _rows(x)
+    y = out if out is not None else torch.empty(tuple(x.shape[:-1]) + (Nn,), dtype=torch.float32, device=x.device)
+    xp, ldx = _pl(x)
+    yp, ldy = _pl(y)
+    rows = ctypes.c_int(0)
+    lib().pwconv_fwd(xp, ldx, _p(in_scale), _p(in_shift), in_act, _p(w), _p(bias), yp, ldy, _p(partials),
+                     ctypes.byref(rows), M, K, Nn, _stream())
+    return (y, rows.value) if partials is not None else y
+
+
+def pwconv_bwd_data(dy, w, out=None, accumulate=False):
+    K, Nn = w.shape[-2], w.shape[-1]
+    M = _rows(dy)
+    gx = out if out is not None else torch.empty(tuple(dy.shape[:-1]) + (K,), dtype=torch.float32, device=dy.device)
+    dp, ldd = _pl(dy)
+    gp, ldg = _pl(gx)
+    lib().pwconv_bwd_data(dp, ldd, _p(w), gp, ldg, int(accumulate), M, K, Nn, _stream())
+    return gx
+
+
+def pwconv_bwd_weight(x, dy, in_scale=None, in_shift=None, in_act=ACT_NONE, with_bias=False, workspace=None):
+    K, Nn = x.shape[-1], dy.shape[-1]
+    M = _rows(x)
+    need = lib().pwconv_bwd_weight_workspace(M, K, Nn)
+    ws = workspace if workspace is not None else torch.empty(need // 4, dtype=torch.float32, device=x.device)
+    gw = torch.empty((K, Nn), dtype=torch.float32, device=x.device)
+    gb = torch.empty((Nn,), dtype=torch.float32, device=x.device) if with_bias else None
+    xp, ldx = _pl(x)
+    dp, ldd = _pl(dy)
+    lib().pwconv_bwd_weight(xp, ldx, _p(in_scale), _p(in_shift), in_act, dp, ldd, _p(gw), _p(gb), _p(ws),
+                            ws.numel() * 4, M, K, Nn, _stream())
+    return (gw, gb) if with_bias else gw
+
+
+# ------------------------------------------------------------------------------------- dense conv
+def conv2d_fwd(x, w, stride=1, rate=1, padding='same', in_scale=None, in_shift=None, in_act=ACT_NONE, out=None,
+               partials=None):
+    N, H, W, Cin = x.shape
+    k, _, _, Cout = w.shape
+    Ho, Wo, pt, pl = conv_geometry(H, W, k, stride, rate, padding)
+    y = out if out is not None else torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+    xp, ldx = _pl(x)
+    yp, ldy = _pl(y)
+    rows = ctypes.c_int(0)
+    lib().conv2d_fwd(xp, ldx, _p(in_scale), _p(in_shift), in_act, _p(w), yp, ldy, _p(partials), ctypes.byref(rows),
+                     N, H, W, Cin, Cout, k, stride, rate, pt, pl, Ho, Wo, _stream())
+    return (y, rows.value) if partials is not None else y
+
+
+def conv2d_bwd_weight(x, dy, k, stride=1, rate=1, padding='same', in_scale=None, in_shift=None, in_act=ACT_NONE):
+    N, H, W, Cin = x.shape
+    Cout = dy.shape[-1]
+    Ho, Wo, pt, pl = conv_geometry(H, W, k, stride, rate, padding)
+    need = lib().conv2d_bwd_weight_workspace(N, Ho, Wo, Cin, Cout, k)
+    ws = torch.empty(need // 4, dtype=torch.float32, device=x.device)
+    gw = torch.empty((k, k, Cin, Cout), dtype=torch.float32, device=x.device)
+    xp, ldx = _pl(x)
+    dp, ldd = _pl(dy)
+    lib().conv2d_bwd_weight(xp, ldx, _p(in_scale), _p(in_shift), in_act, dp, ldd, _p(gw), _p(ws), ws.numel() * 4,
+                            N, H, W, Cin, Cout, k, stride, rate, pt, pl, Ho, Wo, _stream())
+    return gw
+
+
+def conv2d_bwd_data(dy, w, x_shape, stride=1, rate=1, padding='same', out=None, accumulate=False):
+    N, H, W, Cin = x_shape
+    k, _, _, Cout = w.shape
+    Ho, Wo, pt, pl = conv_geometry(H, W, k, stride, rate, padding)
+    gx = out if out is not None else torch.empty(x_shape, dtype=torch.float32, device=dy.device)
+    dp, ldd = _pl(dy)
+    gp, ldg = _pl(gx)
+    lib().conv2d_bwd_data(dp, ldd, _p(w), gp, ldg, int(accumulate), N, H, W, Cin, Cout, k, stride, rate, pt, pl,
+                          Ho, Wo, _stream())
+    return gx
+
+
+# ------------------------------------------------------------------------------------- batch norm
+class BNState:
+    """device-side state of one BatchNormalization layer (all float32 [C])"""
+
+    def __init__(self, C, device, eps=1e-3, momentum=0.99):
+        f = dict(dtype=torch.float32, device=device)
+        self.C, self.eps, self.momentum = C, eps, momentum
+        self.gamma = torch.ones(C, **f)
+        self.beta = torch.zeros(C, **f)
+        self.moving_mean = torch.zeros(C, **f)
+        self.moving_var = torch.ones(C, **f)
+        self.scale = torch.empty(C, **f)
+        self.shift = torch.empty(C, **f)
+        self.mean = torch.empty(C, **f)
+        self.invstd = torch.empty(C, **f)
+        self.coef = torch.empty(3 * C, **f)
+        self.dgamma = torch.empty(C, **f)
+        self.dbeta = torch.empty(C, **f)
+
+
+def bn_finalize(bn, partials, rows, count, update_moving=True, sums=None):
+    lib().bn_finalize(_p(partials), rows, _p(sums), bn.C, float(count), _p(bn.gamma), _p(bn.beta), bn.eps,
+                      bn.momentum, _p(bn.moving_mean), _p(bn.moving_var), int(update_moving), _p(bn.scale),
+                      _p(bn.shift), _p(bn.mean), _p(bn.invstd), _stream())
+
+
+def bn_reduce_partials(partials, rows, C2):
+    sums = torch.empty(C2, dtype=torch.float64, device=partials.device)
+    lib().bn_reduce_partials(_p(partials), rows, C2, _p(sums), _stream())
+    return sums
+
+
+def bn_infer_coeffs(bn):
+    lib().bn_infer_coeffs(_p(bn.gamma), _p(bn.beta), _p(bn.moving_mean), _p(bn.moving_var), bn.eps, _p(bn.scale),
+                          _p(bn.shift), _p(bn.mean), _p(bn.invstd), bn.C, _stream())
+
+
+def bn_backward(bn, g, z, act, partials, frozen=False, out=None, sums=None):
+    """g: gradient w.r.t. act(bn(z)); returns dz (in place in g unless out is given)"""
+    M = _rows(z)
+    gp, ldg = _pl(g)
+    zp, ldz = _pl(z)
+    rows = ctypes.c_int(0)
+    if not frozen and sums is None:
+        lib().bn_bwd_reduce(gp, ldg, zp, ldz, _p(bn.scale), _p(bn.shift), act, _p(bn.mean), _p(bn.invstd),
+                            _p(partials), ctypes.byref(rows), M, bn.C, _stream())
+    lib().bn_bwd_finalize(_p(partials), rows.value, _p(sums), bn.C, float(M), _p(bn.gamma), _p(bn.invstd),
+                          _p(bn.scale), int(frozen), _p(bn.dgamma), _p(bn.dbeta), _p(bn.coef), _stream())
+    dz = out if out is not None else g
+    dp, ldd = _pl(dz)
+    lib().bn_bwd_apply(gp, ldg, zp, ldz, _p(bn.scale), _p(bn.shift), act, _p(bn.mean), _p(bn.invstd), _p(bn.coef),
+                       dp, ldd, M, bn.C, _stream())
+    return dz
+
+
+# ------------------------------------------------------------------------------------- elementwise
+def affine_act(x, scale=None, shift=None, act=ACT_NONE, residual=None, rscale=None, rshift=None, ract=ACT_NONE,
+               dropout_rate=0.0, seed=0, step_counter=None, out=None):
+    C = x.shape[-1]
+    y = out if out is not None else torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    xp, ldx = _pl(x)
+    rp, ldr = _pl(residual)
+    yp, ldy = _pl(y)
+    lib().affine_act(xp, ldx, _p(scale), _p(shift), act, rp, ldr, _p(rscale), _p(rshift), ract, float(dropout_rate),
+                     int(seed), _p(step_counter), yp, ldy, _rows(x), C, _stream())
+    return y
+
+
+def scale_mask_bwd(gy, dropout_rate=0.0, seed=0, step_counter=None, out=None, accumulate=False):
+    C = gy.shape[-1]
+    gx = out if out is not None else torch.empty(gy.shape, dtype=torch.float32, device=gy.device)
+    gp, ldg = _pl(gy)
+    xp, ldx = _pl(gx)
+    lib().scale_mask_bwd(gp, ldg, float(dropout_rate), int(seed), _p(step_counter), xp, ldx, int(accumulate),
+                         _rows(gy), C, _stream())
+    return gx
+
+
+def dropout_mask(shape, rate, seed, step_counter, device):
+    C = shape[-1]
+    m = torch.empty(shape, dtype=torch.float32, device=device)
+    lib().dropout_mask(float(rate), int(seed), _p(step_counter), _p(m), m.numel() // C, C, _stream())
+    return m
+
+
+def global_avgpool_fwd(x, in_scale=None, in_shift=None, in_act=ACT_NONE, out_scale=1.0, out=None):
+    N, H, W, C = x.shape
+    y = out if out is not None else torch.empty((N, 1, 1, C), dtype=torch.float32, device=x.device)
+    xp, ldx = _pl(x)
+    yp, ldy = _pl(y)
+    lib().global_avgpool_fwd(xp, ldx, _p(in_scale), _p(in_shift), in_act, yp, ldy, float(out_scale), N, H * W, C,
+                             _stream())
+    return y
+
+
+def global_avgpool_bwd(gy, H, W, out=None, accumulate=False):
+    N, C = gy.shape[0], gy.shape[-1]
+    gx = out if out is not None else torch.empty((N, H, W, C), dtype=torch.float32, device=gy.device)
+    gp, ldg = _pl(gy)
+    xp, ldx = _pl(gx)
+    lib().global_avgpool_bwd(gp, ldg, xp, ldx, int(accumulate), N, H * W, C, _stream())
+    return gx
+
+
+def resize_bilinear_fwd(x, H, W, out=None):
+    N, h, w, C = x.shape
+    y = out if out is not None else torch.empty((N, H, W, C), dtype=torch.float32, device=x.device)
+    xp, ldx = _pl(x)
+    yp, ldy = _pl(y)
+    lib().resize_bilinear_fwd(xp, ldx, yp, ldy, N, h, w, C, H, W, _stream())
+    return y
+
+
+def resize_bilinear_bwd(gy, h, w, out=None, accumulate=False):
+    N, H, W, C = gy.shape
+    gx = out if out is not None else torch.empty((N, h, w, C), dtype=torch.float32, device=gy.device)
+    gp, ldg = _pl(gy)
+    xp, ldx = _pl(gx)
+    lib().resize_bilinear_bwd(gp, ldg, xp, ldx, int(accumulate), N, h, w, C, H, W, _stream())
+    return gx
+
+
+# ------------------------------------------------------------------------------------- head / loss
+def upsample_softmax_ce(z, C, H, W, labels=None, ignore_index=255, want_probs=False, want_logits=False,
+                        want_grad=False, ld_big=None):
+    """z (N,h,w,Cpad) small logits -> dict(loss, probs (N,H,W,C), logits (N,H,W,ld_big), dlogits)"""
+    N, h, w, _ = z.shape
+    dev = z.device
+    ld_big = ld_big or ((C + 3) // 4) * 4
+    zp, ldz = _pl(z)
+    out = {}
+    probs = torch.empty((N, H, W, C), dtype=torch.float32, device=dev) if want_probs else None
+    logits = torch.zeros((N, H, W, ld_big), dtype=torch.float32, device=dev) if want_logits else None
+    dlog = torch.zeros((N, H, W, ld_big), dtype=torch.float32, device=dev) if want_grad else None
+    partial = torch.zeros(MAX_STAT_ROWS, dtype=torch.float32, device=dev) if labels is not None else None
+    rows = ctypes.c_int(0)
+    inv = 1.0 / float(N * H * W)
+    lib().upsample_softmax_ce(zp, ldz, _p(labels), int(ignore_index or 0), inv, _p(logits), _p(probs), _p(dlog),
+                              ld_big, _p(partial), ctypes.byref(rows), N, h, w, C, H, W, _stream())
+    if labels is not None:
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        lib().reduce_rows(_p(partial), rows.value, 1, _p(loss), 0, _stream())
+        out['loss'] = loss
+    out['probs'], out['logits'], out['dlogits'] = probs, logits, dlog
+    return out
+
+
+def sgd_momentum(w, v, g, lr_dev, momentum=0.9, l2=0.0, grad_scale=1.0):
+    lib().sgd_momentum(_p(w), _p(v), _p(g), w.numel(), _p(lr_dev), float(momentum), float(l2), float(grad_scale),
+                       _stream())
