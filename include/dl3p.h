@@ -198,9 +198,12 @@ int dl3p_reduce_rows(const float* partials, int rows, size_t n, float* out, int 
 /* ---------------------------------------------------------------- optimiser
  * Keras SGD(momentum, nesterov=False) (common/model_utils.py:124) with the l2(2e-5) regulariser
  * gradient (layers.py:12-18) folded in:  g' = g*grad_scale + 2*l2*w; v = momentum*v - lr*g'; w += v.
- * lr is read from device memory (*lr_dev) so that a captured graph follows a schedule. */
+ * lr is read from device memory (*lr_dev) so that a captured graph follows a schedule.
+ * l2_elem / lr_scale_elem (either may be NULL) give per-element l2 factors (conv kernels are
+ * regularised, depthwise kernels and BN parameters are not) and per-element learning-rate
+ * multipliers (0 freezes a weight: model.py:106-110 freeze_level) over ONE flat parameter buffer. */
 int dl3p_sgd_momentum(float* w, float* v, const float* g, size_t n, const float* lr_dev, float momentum,
-                      float l2, float grad_scale, void* stream);
+                      float l2, float grad_scale, const float* l2_elem, const float* lr_scale_elem, void* stream);
 
 #ifdef __cplusplus
 }

@@ -17,11 +17,12 @@ from . import np_ops as O
 
 
 class Var:
-    __slots__ = ('v', 'g')
+    __slots__ = ('v', 'g', 'tag')
 
     def __init__(self, v):
         self.v = v
         self.g = None
+        self.tag = None
 
     def acc(self, g):
         self.g = g if self.g is None else self.g + g
@@ -45,6 +46,11 @@ class Net:
         self.dropout_masks = {}  # layer name -> keep mask (injected); None -> no dropout
         self.taps = {}          # optional named intermediate activations
         self.reg_loss = 0.0
+        # optional {BN layer name: act'(u) array}: ReLU-type activations are not differentiable at 0, so a
+        # float32 implementation and this float64 oracle can disagree on the branch taken by elements
+        # within rounding distance of the kink.  Parity tests inject the branch pattern of the
+        # implementation under test so that the comparison is well-conditioned.
+        self.act_derivs = {}
 
     # ---- parameters -------------------------------------------------------------------
     def param(self, name, shape, init, trainable=True, l2=0.0):
@@ -129,6 +135,7 @@ class Net:
             self.moving_updates[name + '/moving_mean'] = O.bn_moving_update(mm, bm, momentum)
             self.moving_updates[name + '/moving_variance'] = O.bn_moving_update(mv, bv, momentum)
             y = Var(yv)
+            y.tag = name
 
             def bwd():
                 if y.g is None:
@@ -139,6 +146,7 @@ class Net:
                 x.acc(gx)
         else:
             y = Var(O.bn_infer_fwd(x.v, gamma, beta, mm, mv, eps))
+            y.tag = name
             scale = gamma / np.sqrt(mv + eps)
 
             def bwd():
@@ -153,10 +161,14 @@ class Net:
 
     def act(self, x, kind):
         y = Var(O.act_fwd(x.v, kind))
+        deriv = self.act_derivs.get(x.tag) if x.tag is not None else None
 
         def bwd():
             if y.g is not None:
-                x.acc(O.act_bwd(x.v, y.g, kind))
+                if deriv is not None:
+                    x.acc(y.g * deriv)
+                else:
+                    x.acc(O.act_bwd(x.v, y.g, kind))
         self.tape.append(bwd)
         return y
 

@@ -1,0 +1,130 @@
+"""End-to-end GPU parity of the DeepLabV3+ train step / predict against the fp64 CPU oracle on
+identical weights and inputs (north_star tolerance: 1e-3 fp32)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_pkg
+from oracle.np_net import OracleModel
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _data(N, H, W, C, seed=0):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-1, 1, (N, H, W, 3)).astype(np.float32)
+    y = rng.integers(0, C, (N, H * W, 1)).astype(np.float32)
+    y[rng.uniform(size=y.shape) < 0.05] = 255
+    return x, y
+
+
+def _pair(model_type, H, W, C, OS=16, freeze_level=0, training=True):
+    pkg = load_pkg()
+    m = pkg.get_deeplabv3p_model(model_type, C, (H, W), OS, freeze_level=freeze_level, training=training)
+    m.compile(optimizer=pkg.SGD(0.01), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
+    o = OracleModel(model_type, C, (H, W), OS, dtype=np.float64, seed=0, freeze_level=freeze_level)
+    rng = np.random.default_rng(42)
+    for k, v in o.net.params.items():     # non-trivial BN parameters / moving statistics
+        if k.endswith('/gamma'):
+            v[...] = rng.uniform(0.5, 1.5, v.shape)
+        elif k.endswith('/beta') or k.endswith('/moving_mean'):
+            v[...] = rng.standard_normal(v.shape) * 0.1
+        elif k.endswith('/moving_variance'):
+            v[...] = rng.uniform(0.5, 1.5, v.shape)
+        elif k.endswith('/bias'):
+            v[...] = rng.standard_normal(v.shape) * 0.1
+    m.set_weights_by_name(dict(o.net.params))
+    return m, o
+
+
+def _act_derivs(m, ex):
+    """act'(u) of every BN+activation as the HIP kernels evaluate it (same fmaf, same branch)"""
+    ops = load_pkg('ops')
+    out = {}
+    for bn in m.graph.bns:
+        if bn.act == 0:
+            continue
+        z = ex.view(bn.z)
+        sc = ex.gscale[bn.group.id][bn.offset:bn.offset + bn.C]
+        sh = ex.gshift[bn.group.id][bn.offset:bn.offset + bn.C]
+        a = ops.affine_act(z, sc, sh, bn.act).cpu().numpy()
+        if bn.act == ops.ACT_RELU:
+            out[bn.name] = (a > 0).astype(np.float64)
+        elif bn.act == ops.ACT_RELU6:
+            out[bn.name] = ((a > 0) & (a < 6)).astype(np.float64)
+    return out
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(1e-6, np.abs(b).max()))
+
+
+@pytest.mark.parametrize('model_type,H,W', [('mobilenetv2', 65, 65), ('mobilenetv2_lite', 65, 97)])
+def test_predict_matches_oracle(model_type, H, W):
+    m, o = _pair(model_type, H, W, 21, training=False)
+    x, _ = _data(2, H, W, 21)
+    p = m.predict(x)
+    logits_ref, p_ref = o.predict(x)
+    assert p.shape == (2, H, W, 21)
+    assert np.abs(p - p_ref).max() < TOL
+    # logits (pred_resize output) through the head kernel
+    ex = m._executor(2, False)
+    ops = load_pkg('ops')
+    out = ops.upsample_softmax_ce(ex.view(m.head.tensor), 21, H, W, want_logits=True)
+    assert np.abs(out['logits'][..., :21].cpu().numpy() - logits_ref).max() < TOL * max(1.0, np.abs(logits_ref).max())
+
+
+@pytest.mark.parametrize('model_type,H,W,freeze', [('mobilenetv2', 65, 65, 0), ('mobilenetv2_lite', 65, 65, 0),
+                                                   ('mobilenetv2', 65, 65, 1)])
+def test_train_step_matches_oracle(model_type, H, W, freeze):
+    N, C = 2, 21
+    m, o = _pair(model_type, H, W, C, freeze_level=freeze)
+    m.use_graphs = False
+    x, y = _data(N, H, W, C, seed=3)
+    loss = m.train_on_batch(x, y)
+    ex = m._executor(N, True)
+    drop = [op for op in m.graph.ops if op.kind == 'materialize' and op.rate > 0][0]
+    mask = ex.dropout_mask(drop).cpu().numpy()
+    # the ReLU branch pattern of the float32 run is injected into the float64 oracle (see
+    # oracle/np_net.py Net.act_derivs): gradients are then comparable element by element
+    o.net.act_derivs = _act_derivs(m, ex)
+    total, ce, logits = o.loss_and_grads(x, y, {'aspp_dropout': mask})
+    assert abs(loss - ce) < TOL * max(1.0, abs(ce)), (loss, ce)
+    # per-parameter gradients (data term), relative to each tensor's scale
+    st = m._store
+    worst = ('', 0.0)
+    for p in m.graph.all_params():
+        if not p.trainable:
+            continue
+        g = st.get(p, st.G)
+        gref = o.net.grads[p.name]
+        r = _rel(g, gref) if np.abs(gref).max() > 1e-7 else float(np.abs(g).max())
+        if r > worst[1]:
+            worst = (p.name, r)
+    assert worst[1] < 5e-3, worst
+    # SGD update + moving statistics
+    o.sgd_step(0.01, 0.9)
+    w = m.get_weights_by_name()
+    for k, v in w.items():
+        assert np.abs(v - o.net.params[k]).max() < TOL * max(1.0, np.abs(o.net.params[k]).max()), k
+    if freeze:
+        assert all(not p.trainable for p in m.graph.all_params() if p.layer.name.startswith('expanded_conv'))
+
+
+def test_graph_replay_equals_eager():
+    """three steps through hipGraph replay == three eager steps"""
+    N, C, H, W = 2, 21, 65, 65
+    ma, _ = _pair('mobilenetv2', H, W, C)
+    mb, _ = _pair('mobilenetv2', H, W, C)
+    ma.use_graphs, mb.use_graphs = False, True
+    la, lb = [], []
+    for s in range(3):
+        x, y = _data(N, H, W, C, seed=10 + s)
+        la.append(ma.train_on_batch(x, y))
+        lb.append(mb.train_on_batch(x, y))
+    assert mb._executor(N, True).graphed
+    assert np.allclose(la, lb, rtol=1e-5, atol=1e-6), (la, lb)
+    wa, wb = ma.get_weights_by_name(), mb.get_weights_by_name()
+    assert max(float(np.abs(wa[k] - wb[k]).max()) for k in wa) < 1e-5

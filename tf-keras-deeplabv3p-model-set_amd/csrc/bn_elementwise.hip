@@ -530,40 +530,50 @@ extern "C" int dl3p_global_avgpool_bwd(const float* gy, int ldgy, float* gx, int
 // ------------------------------------------------------------------------------ SGD momentum
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, float* __restrict__ v,
                                                   const float* __restrict__ g, size_t n4, size_t n,
-                                                  const float* lr_dev, float momentum, float l2, float gscale) {
+                                                  const float* lr_dev, float momentum, float l2, float gscale,
+                                                  const float* __restrict__ l2e, const float* __restrict__ lre) {
   const float lr = *lr_dev;
-  const float l2x2 = 2.f * l2;
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * 256;
   for (; i < n4; i += stride) {
     float4 ww = ld4(w + i * 4), vv = ld4(v + i * 4), gg = ld4(g + i * 4);
-    vv.x = momentum * vv.x - lr * fmaf(gg.x, gscale, l2x2 * ww.x);
-    vv.y = momentum * vv.y - lr * fmaf(gg.y, gscale, l2x2 * ww.y);
-    vv.z = momentum * vv.z - lr * fmaf(gg.z, gscale, l2x2 * ww.z);
-    vv.w = momentum * vv.w - lr * fmaf(gg.w, gscale, l2x2 * ww.w);
-    st4(v + i * 4, vv);
-    st4(w + i * 4, add4(ww, vv));
+    float4 d = l2e ? ld4(l2e + i * 4) : make_float4(l2, l2, l2, l2);
+    float4 m = lre ? ld4(lre + i * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 nv;
+    nv.x = momentum * vv.x - lr * fmaf(gg.x, gscale, 2.f * d.x * ww.x);
+    nv.y = momentum * vv.y - lr * fmaf(gg.y, gscale, 2.f * d.y * ww.y);
+    nv.z = momentum * vv.z - lr * fmaf(gg.z, gscale, 2.f * d.z * ww.z);
+    nv.w = momentum * vv.w - lr * fmaf(gg.w, gscale, 2.f * d.w * ww.w);
+    nv.x = m.x != 0.f ? nv.x : vv.x; nv.y = m.y != 0.f ? nv.y : vv.y;
+    nv.z = m.z != 0.f ? nv.z : vv.z; nv.w = m.w != 0.f ? nv.w : vv.w;
+    st4(v + i * 4, nv);
+    st4(w + i * 4, make_float4(m.x != 0.f ? ww.x + nv.x : ww.x, m.y != 0.f ? ww.y + nv.y : ww.y,
+                               m.z != 0.f ? ww.z + nv.z : ww.z, m.w != 0.f ? ww.w + nv.w : ww.w));
   }
-  // scalar tail
-  if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) {
+  if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) {   // scalar tail
     size_t j = n4 * 4 + threadIdx.x;
-    float vv = momentum * v[j] - lr * fmaf(g[j], gscale, l2x2 * w[j]);
-    v[j] = vv;
-    w[j] += vv;
+    const float d = l2e ? l2e[j] : l2;
+    if (!lre || lre[j] != 0.f) {
+      float nv = momentum * v[j] - lr * fmaf(g[j], gscale, 2.f * d * w[j]);
+      v[j] = nv;
+      w[j] += nv;
+    }
   }
 }
 
 extern "C" int dl3p_sgd_momentum(float* w, float* v, const float* g, size_t n, const float* lr_dev, float momentum,
-                                 float l2, float grad_scale, void* stream) {
+                                 float l2, float grad_scale, const float* l2_elem, const float* lr_scale_elem,
+                                 void* stream) {
   DL3P_CHECK_ARG(w && v && g && lr_dev, "dl3p_sgd_momentum: null pointer");
-  DL3P_CHECK_ARG(aligned16(w) && aligned16(v) && aligned16(g), "dl3p_sgd_momentum: buffers must be 16-byte aligned");
+  DL3P_CHECK_ARG(aligned16(w) && aligned16(v) && aligned16(g) && aligned16(l2_elem) && aligned16(lr_scale_elem),
+                 "dl3p_sgd_momentum: buffers must be 16-byte aligned");
   if (n == 0) return DL3P_OK;
   size_t n4 = n / 4;
   size_t blocks = (n4 + 255) / 256;
   if (blocks < 1) blocks = 1;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, v, g, n4, n, lr_dev,
-                     momentum, l2, grad_scale);
+                     momentum, l2, grad_scale, l2_elem, lr_scale_elem);
   DL3P_CHECK_LAUNCH("dl3p_sgd_momentum");
   return DL3P_OK;
 }

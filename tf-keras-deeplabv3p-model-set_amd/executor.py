@@ -1,0 +1,522 @@
+"""Executor: binds a static layer graph (graph.py) to device buffers and traces it into launch plans
+(forward, loss+backward, SGD) made of C-ABI calls (include/dl3p.h).
+
+MI355X-first execution model: one process per GPU; every buffer (activations, gradients, the flat
+parameter / gradient / momentum buffers, workspaces) is allocated once -- 288 GB of HBM make
+activation recomputation and buffer juggling unnecessary -- and the traced plan is captured into a
+hipGraph, so a training step is a single graph launch instead of ~900 eager kernel launches (no
+tracing compiler, no per-op Python on the hot path).  Plans are segmented at collectives: under
+data parallelism the gradient all-reduce (and SyncBatchNorm's statistics all-reduce) are RCCL calls
+between graph segments.
+
+PyTorch only provides memory, streams, graphs and torch.distributed here.
+"""
+import ctypes
+import zlib
+import numpy as np
+import torch
+
+from ._lib import lib
+from .graph import ACT_NONE
+
+MAX_ROWS = 2048
+
+
+class ParamStore:
+    """all weights of a model in three flat float32 device buffers (value, gradient, momentum), laid out
+    in Keras weight order with 16-byte aligned offsets.  One SGD launch and one all-reduce cover it."""
+
+    def __init__(self, graph, device):
+        self.graph = graph
+        self.device = device
+        self.params = graph.all_params()
+        self.offset = {}
+        off = 0
+        for p in self.params:
+            self.offset[p] = off
+            off += (p.dev_size + 3) // 4 * 4
+        self.total = off
+        f = dict(dtype=torch.float32, device=device)
+        self.P = torch.zeros(off, **f)
+        self.G = torch.zeros(off, **f)
+        self.V = torch.zeros(off, **f)
+        self.l2 = torch.zeros(off, **f)
+        self.lr_scale = torch.zeros(off, **f)
+        self.upload()
+        self.refresh_masks()
+
+    def view(self, p, buf=None):
+        buf = self.P if buf is None else buf
+        o = self.offset[p]
+        return buf[o:o + p.dev_size].view(p.dev_shape)
+
+    def ptr(self, p, buf=None):
+        buf = self.P if buf is None else buf
+        return buf.data_ptr() + 4 * self.offset[p]
+
+    @staticmethod
+    def _pad(p, value):
+        a = np.asarray(value, dtype=np.float32)
+        if p.dev_shape != p.shape:
+            pad = [(0, d - s) for s, d in zip(p.shape, p.dev_shape)]
+            a = np.pad(a, pad)
+        return a
+
+    def upload(self, only=None):
+        host = np.zeros(self.total, np.float32)
+        for p in self.params:
+            o = self.offset[p]
+            host[o:o + p.dev_size] = self._pad(p, p.value).reshape(-1)
+        self.P.copy_(torch.from_numpy(host))
+
+    def download(self):
+        host = self.P.detach().cpu().numpy()
+        for p in self.params:
+            o = self.offset[p]
+            a = host[o:o + p.dev_size].reshape(p.dev_shape)
+            sl = tuple(slice(0, s) for s in p.shape)
+            p.value = a[sl].copy()
+
+    def get(self, p, buf=None):
+        a = self.view(p, buf).detach().cpu().numpy()
+        return a[tuple(slice(0, s) for s in p.shape)].copy()
+
+    def refresh_masks(self):
+        """per-element l2 factor and learning-rate multiplier (0 = frozen / not a trainable weight)"""
+        l2 = np.zeros(self.total, np.float32)
+        lr = np.zeros(self.total, np.float32)
+        for p in self.params:
+            o = self.offset[p]
+            l2[o:o + p.dev_size] = p.l2
+            lr[o:o + p.dev_size] = 1.0 if p.trainable else 0.0
+        self.l2.copy_(torch.from_numpy(l2))
+        self.lr_scale.copy_(torch.from_numpy(lr))
+
+
+class Plan:
+    """a traced list of C-ABI launches (+ python callbacks at collectives), replayable eagerly or as
+    hipGraph segments"""
+
+    def __init__(self):
+        self.items = []
+        self.segments = None
+
+    def k(self, fn, *args):
+        fn(*args, torch.cuda.current_stream().cuda_stream)
+        self.items.append((fn, args))
+
+    def py(self, fn):
+        fn()
+        self.items.append((None, fn))
+
+    def run(self):
+        if self.segments is not None:
+            for seg in self.segments:
+                if isinstance(seg, torch.cuda.CUDAGraph):
+                    seg.replay()
+                else:
+                    seg()
+            return
+        st = torch.cuda.current_stream().cuda_stream
+        for fn, args in self.items:
+            if fn is None:
+                args()
+            else:
+                fn(*args, st)
+
+    def capture(self):
+        """turn each run of kernel launches into one hipGraph"""
+        segs, cur = [], []
+        for it in self.items:
+            if it[0] is None:
+                if cur:
+                    segs.append(cur)
+                    cur = []
+                segs.append(it[1])
+            else:
+                cur.append(it)
+        if cur:
+            segs.append(cur)
+        out = []
+        for seg in segs:
+            if not isinstance(seg, list):
+                out.append(seg)
+                continue
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                st = torch.cuda.current_stream().cuda_stream
+                for fn, args in seg:
+                    fn(*args, st)
+            out.append(g)
+        self.segments = out
+        return self
+
+    @property
+    def n_launches(self):
+        return sum(1 for it in self.items if it[0] is not None)
+
+
+class Executor:
+    def __init__(self, graph, head, store, batch, training, num_classes, ignore_index=255, dist=None,
+                 seed=1234, momentum=0.9):
+        self.g, self.head, self.store = graph, head, store
+        self.N, self.training, self.C = batch, training, num_classes
+        self.ignore_index = ignore_index
+        self.dist = dist if (dist is not None and dist.world_size > 1) else None
+        self.sync_bn = self.dist is not None and self.dist.sync_bn
+        self.seed, self.momentum = seed, momentum
+        self.dev = store.device
+        self.L = lib()
+        self.f32 = dict(dtype=torch.float32, device=self.dev)
+        self._alloc()
+        # tracing runs every kernel once on zero inputs: keep the weights / optimiser state intact
+        snap_p, snap_v = store.P.clone(), store.V.clone()
+        if training:
+            self.fwd = self._trace_forward()
+            self.bwd = self._trace_backward()
+            self.opt = self._trace_sgd()
+        else:
+            self.fwd = self._trace_forward()
+        torch.cuda.synchronize()
+        store.P.copy_(snap_p)
+        store.V.copy_(snap_v)
+        self.step.zero_()
+        self.graphed = False
+
+    # ---------------------------------------------------------------- buffers
+    def _alloc(self):
+        g, N = self.g, self.N
+        self.buf, self.grad = {}, {}
+        self._mark_requires_grad()
+        for t in g.tensors:
+            self.buf[t.id] = torch.zeros(N * t.H * t.W * t.C, **self.f32)
+            if self.training and t.requires_grad:
+                self.grad[t.id] = torch.zeros(N * t.H * t.W * t.C, **self.f32)
+        self.gscale, self.gshift = {}, {}
+        for grp in g.groups:
+            self.gscale[grp.id] = torch.ones(grp.C, **self.f32)
+            self.gshift[grp.id] = torch.zeros(grp.C, **self.f32)
+        self.bn_aux = {}
+        cmax = 4
+        for bn in g.bns:
+            self.bn_aux[bn] = dict(mean=torch.zeros(bn.C, **self.f32), invstd=torch.ones(bn.C, **self.f32),
+                                   coef=torch.zeros(3 * bn.C, **self.f32),
+                                   sums=torch.zeros(2 * bn.C, dtype=torch.float64, device=self.dev))
+            cmax = max(cmax, bn.C)
+        self.partials = torch.zeros(MAX_ROWS * 2 * cmax, **self.f32)
+        ws = 1 << 20
+        L = self.L
+        for op in g.ops:
+            if op.kind == 'conv_pw':
+                ws = max(ws, L.pwconv_bwd_weight_workspace(N * op.Ho * op.Wo, op.cin, op.cout))
+            elif op.kind == 'conv_dw':
+                ws = max(ws, L.dwconv2d_bwd_weight_workspace(N, op.Ho, op.Wo, op.c, op.k))
+            elif op.kind == 'conv_dense':
+                ws = max(ws, L.conv2d_bwd_weight_workspace(N, op.Ho, op.Wo, op.cin, op.cout, op.k))
+        self.workspace = torch.zeros(ws // 4 + 4, **self.f32) if self.training else None
+        H, W, _ = g.input_shape
+        self.H, self.W = H, W
+        self.cpad = (self.C + 3) // 4 * 4
+        self.labels = torch.zeros(N * H * W, **self.f32)
+        self.loss_partials = torch.zeros(MAX_ROWS, **self.f32)
+        self.loss = torch.zeros(1, **self.f32)
+        self.dlogits_big = torch.zeros(N * H * W * self.cpad, **self.f32) if self.training else None
+        self.probs = None if self.training else torch.zeros(N * H * W * self.C, **self.f32)
+        self.logits_big = None
+        self.step = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.lr = torch.full((1,), 0.01, **self.f32)
+
+    def _mark_requires_grad(self):
+        for t in self.g.tensors:
+            t.requires_grad = False
+        slices = {}
+
+        def rg(v):
+            t = v.tensor
+            return t.requires_grad or t.root.requires_grad
+
+        def setrg(t, val):
+            if val:
+                t.requires_grad = True
+                t.root.requires_grad = True
+        for op in self.g.ops:
+            k = op.kind
+            if k in ('conv_pw', 'conv_dense', 'conv_dw'):
+                setrg(op.out, op.layer.trainable or rg(op.x))
+            elif k == 'bn':
+                setrg(op.z, op.layer.trainable)
+            elif k == 'materialize':
+                setrg(op.out, rg(op.x) or (op.r is not None and rg(op.r)))
+            elif k in ('gap', 'resize', 'broadcast'):
+                setrg(op.out, rg(op.x))
+
+    # ---------------------------------------------------------------- addressing helpers
+    def tptr(self, t, grad=False):
+        store = self.grad if grad else self.buf
+        return store[t.root.id].data_ptr() + 4 * t.c0
+
+    def vargs(self, v):
+        """(ptr, ld, scale_ptr, shift_ptr, act) of a Value as a kernel prologue"""
+        sp = hp = None
+        if v.group is not None:
+            sp = self.gscale[v.group.id].data_ptr() + 4 * v.goff
+            hp = self.gshift[v.group.id].data_ptr() + 4 * v.goff
+        return self.tptr(v.tensor), v.tensor.ld, sp, hp, v.act
+
+    def view(self, t, grad=False):
+        """torch view (N,H,W,C) of a graph tensor (test / debug hook)"""
+        store = self.grad if grad else self.buf
+        root = t.root
+        full = store[root.id].view(self.N, root.H, root.W, root.C)
+        return full[..., t.c0:t.c0 + t.C]
+
+    # ---------------------------------------------------------------- forward
+    def _trace_forward(self):
+        P, L, N, st = Plan(), self.L, self.N, self.store
+        train = self.training
+        if train:
+            P.k(L.increment_counter, self.step.data_ptr())
+        for op in self.g.ops:
+            k = op.kind
+            if k in ('conv_pw', 'conv_dense', 'conv_dw'):
+                xp, ldx, sp, hp, act = self.vargs(op.x)
+                bn = op.bn
+                want_stats = train and bn is not None and bn.layer.trainable
+                part = self.partials.data_ptr() if want_stats else None
+                rows = ctypes.c_int(0)
+                xt = op.x.tensor
+                if k == 'conv_pw':
+                    P.k(L.pwconv_fwd, xp, ldx, sp, hp, act, st.ptr(op.w), st.ptr(op.b) if op.b else None,
+                        self.tptr(op.out), op.out.ld, part, ctypes.byref(rows), N * op.Ho * op.Wo, op.cin, op.cout)
+                elif k == 'conv_dw':
+                    P.k(L.dwconv2d_fwd, xp, ldx, sp, hp, act, st.ptr(op.w), self.tptr(op.out), op.out.ld, part,
+                        ctypes.byref(rows), N, xt.H, xt.W, op.c, op.k, op.stride, op.rate, op.pad_t, op.pad_l,
+                        op.Ho, op.Wo)
+                else:
+                    P.k(L.conv2d_fwd, xp, ldx, sp, hp, act, st.ptr(op.w), self.tptr(op.out), op.out.ld, part,
+                        ctypes.byref(rows), N, xt.H, xt.W, op.cin, op.cout, op.k, op.stride, op.rate, op.pad_t,
+                        op.pad_l, op.Ho, op.Wo)
+                op.rows = rows.value
+            elif k == 'bn':
+                self._bn_forward(P, op)
+            elif k == 'materialize':
+                xp, ldx, sp, hp, act = self.vargs(op.x)
+                rp = ldr = rsp = rhp = None
+                ract = ACT_NONE
+                if op.r is not None:
+                    rp, ldr, rsp, rhp, ract = self.vargs(op.r)
+                rate = op.rate if train else 0.0
+                t = op.out
+                P.k(L.affine_act, xp, ldx, sp, hp, act, rp, ldr or 0, rsp, rhp, ract, float(rate),
+                    self._dropout_seed(op), self.step.data_ptr(), self.tptr(t), t.ld, N * t.H * t.W, t.C)
+            elif k == 'gap':
+                xp, ldx, sp, hp, act = self.vargs(op.x)
+                xt = op.x.tensor
+                P.k(L.global_avgpool_fwd, xp, ldx, sp, hp, act, self.tptr(op.out), op.out.ld, 1.0, N, xt.H * xt.W,
+                    xt.C)
+            elif k in ('resize', 'broadcast'):
+                xt, t = op.x.tensor, op.out
+                P.k(L.resize_bilinear_fwd, self.tptr(xt), xt.ld, self.tptr(t), t.ld, N, xt.H, xt.W, xt.C, t.H, t.W)
+            else:
+                raise NotImplementedError(k)
+        # head: pred_resize + softmax (+ loss and its gradient when training)
+        zt = self.head.tensor
+        rows = ctypes.c_int(0)
+        if train:
+            P.k(L.upsample_softmax_ce, self.tptr(zt), zt.ld, self.labels.data_ptr(), int(self.ignore_index or 0),
+                1.0 / float(N * self.H * self.W), None, None, self.dlogits_big.data_ptr(), self.cpad,
+                self.loss_partials.data_ptr(), ctypes.byref(rows), N, zt.H, zt.W, self.C, self.H, self.W)
+            P.k(L.reduce_rows, self.loss_partials.data_ptr(), rows.value, 1, self.loss.data_ptr(), 0)
+        else:
+            P.k(L.upsample_softmax_ce, self.tptr(zt), zt.ld, None, 0, 1.0, None, self.probs.data_ptr(), None, self.cpad,
+                None, ctypes.byref(rows), N, zt.H, zt.W, self.C, self.H, self.W)
+        return P
+
+    def _dropout_seed(self, op):
+        return (self.seed * 1000003 + zlib.crc32((op.dropout_name or '').encode()) % 65521) & 0x7FFFFFFFFFFFFFFF
+
+    def _bn_forward(self, P, op):
+        bn, L, st, N = op.bn, self.L, self.store, self.N
+        aux = self.bn_aux[bn]
+        lp = {p.key: p for p in bn.layer.params}
+        sp = self.gscale[bn.group.id].data_ptr() + 4 * bn.offset
+        hp = self.gshift[bn.group.id].data_ptr() + 4 * bn.offset
+        z = op.z
+        count = float(N * z.H * z.W)
+        if self.training and bn.layer.trainable:
+            rows = op.producer.rows
+            sums = None
+            if self.sync_bn:
+                P.k(L.bn_reduce_partials, self.partials.data_ptr(), rows, 2 * bn.C, aux['sums'].data_ptr())
+                P.py(lambda s=aux['sums']: self.dist.all_reduce(s))
+                sums, count = aux['sums'].data_ptr(), count * self.dist.world_size
+            P.k(L.bn_finalize, self.partials.data_ptr(), rows, sums, bn.C, count, st.ptr(lp['gamma']),
+                st.ptr(lp['beta']), bn.eps, bn.momentum, st.ptr(lp['moving_mean']), st.ptr(lp['moving_variance']), 1,
+                sp, hp, aux['mean'].data_ptr(), aux['invstd'].data_ptr())
+        else:
+            P.k(L.bn_infer_coeffs, st.ptr(lp['gamma']), st.ptr(lp['beta']), st.ptr(lp['moving_mean']),
+                st.ptr(lp['moving_variance']), bn.eps, sp, hp, aux['mean'].data_ptr(), aux['invstd'].data_ptr(), bn.C)
+
+    # ---------------------------------------------------------------- backward
+    def _acc(self, t):
+        """accumulate flag for a write into grad(t): 0 the first time, 1 afterwards"""
+        key = t.id
+        if key in self._written or (t.base is not None and t.base.id in self._written):
+            return 1
+        self._written.add(key)
+        return 0
+
+    def _gbuf(self, v):
+        # a Concatenate value carries the activation of its branches: each branch's BatchNormalization
+        # backward applies act' to its own channel slice, so the buffer itself takes the plain gradient
+        if v.bn is None and v.group is None and v.act != ACT_NONE:
+            raise NotImplementedError('activation-only lazy value needs materialisation: ' + v.tensor.name)
+        return self.tptr(v.tensor, grad=True), v.tensor.ld
+
+    def _trace_backward(self):
+        P, L, N, st = Plan(), self.L, self.N, self.store
+        self._written = set()
+        G = st.G
+        zt = self.head.tensor
+        # d(loss)/d(pred_resize output) -> d/d(conv_upsample output): transpose of the bilinear upsample
+        if zt.requires_grad:
+            P.k(L.resize_bilinear_bwd, self.dlogits_big.data_ptr(), self.cpad, self.tptr(zt, True), zt.ld,
+                self._acc(zt), N, zt.H, zt.W, zt.C, self.H, self.W)
+        ws, wsb = self.workspace.data_ptr(), self.workspace.numel() * 4
+        for op in reversed(self.g.ops):
+            k = op.kind
+            out = getattr(op, 'out', None)
+            if k == 'bn':
+                if op.z.requires_grad:
+                    self._bn_backward(P, op)
+                continue
+            if out is None or not out.requires_grad:
+                continue
+            if k in ('conv_pw', 'conv_dense', 'conv_dw'):
+                xp, ldx, sp, hp, act = self.vargs(op.x)
+                xt = op.x.tensor
+                dz, lddz = self.tptr(out, True), out.ld
+                need_gx = xt.requires_grad or xt.root.requires_grad
+                if op.layer.trainable:
+                    gw = st.ptr(op.w, G)
+                    if k == 'conv_pw':
+                        P.k(L.pwconv_bwd_weight, xp, ldx, sp, hp, act, dz, lddz, gw, st.ptr(op.b, G) if op.b else None,
+                            ws, wsb, N * op.Ho * op.Wo, op.cin, op.cout)
+                    elif k == 'conv_dw':
+                        P.k(L.dwconv2d_bwd_weight, xp, ldx, sp, hp, act, dz, lddz, gw, ws, wsb, N, xt.H, xt.W, op.c,
+                            op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
+                    else:
+                        P.k(L.conv2d_bwd_weight, xp, ldx, sp, hp, act, dz, lddz, gw, ws, wsb, N, xt.H, xt.W, op.cin,
+                            op.cout, op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
+                if need_gx:
+                    gp, ldg = self._gbuf(op.x)
+                    acc = self._acc(xt)
+                    if k == 'conv_pw':
+                        P.k(L.pwconv_bwd_data, dz, lddz, st.ptr(op.w), gp, ldg, acc, N * op.Ho * op.Wo, op.cin,
+                            op.cout)
+                    elif k == 'conv_dw':
+                        P.k(L.dwconv2d_bwd_data, dz, lddz, st.ptr(op.w), gp, ldg, acc, N, xt.H, xt.W, op.c, op.k,
+                            op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
+                    else:
+                        P.k(L.conv2d_bwd_data, dz, lddz, st.ptr(op.w), gp, ldg, acc, N, xt.H, xt.W, op.cin, op.cout,
+                            op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
+            elif k == 'materialize':
+                gt, ldt = self.tptr(out, True), out.ld
+                M = N * out.H * out.W
+                if op.x.tensor.requires_grad or op.x.tensor.root.requires_grad:
+                    gp, ldg = self._gbuf(op.x)
+                    P.k(L.scale_mask_bwd, gt, ldt, float(op.rate), self._dropout_seed(op), self.step.data_ptr(), gp, ldg,
+                        self._acc(op.x.tensor), M, out.C)
+                if op.r is not None and (op.r.tensor.requires_grad or op.r.tensor.root.requires_grad):
+                    gp, ldg = self._gbuf(op.r)
+                    P.k(L.scale_mask_bwd, gt, ldt, 0.0, 0, None, gp, ldg, self._acc(op.r.tensor), M, out.C)
+            elif k == 'gap':
+                xt = op.x.tensor
+                gp, ldg = self._gbuf(op.x)
+                P.k(L.global_avgpool_bwd, self.tptr(out, True), out.ld, gp, ldg, self._acc(xt), N, xt.H * xt.W, xt.C)
+            elif k == 'broadcast':
+                # gradient w.r.t. the (lazy) 1x1 value = sum over the pixels it was broadcast to
+                xt = op.x.tensor
+                assert self._acc(xt) == 0
+                P.k(L.global_avgpool_fwd, self.tptr(out, True), out.ld, None, None, ACT_NONE, self.tptr(xt, True),
+                    xt.ld, float(out.H * out.W), N, out.H * out.W, out.C)
+            elif k == 'resize':
+                xt = op.x.tensor
+                P.k(L.resize_bilinear_bwd, self.tptr(out, True), out.ld, self.tptr(xt, True), xt.ld, self._acc(xt),
+                    N, xt.H, xt.W, xt.C, out.H, out.W)
+            else:
+                raise NotImplementedError(k)
+        return P
+
+    def _bn_backward(self, P, op):
+        bn, L, st, N = op.bn, self.L, self.store, self.N
+        aux = self.bn_aux[bn]
+        lp = {p.key: p for p in bn.layer.params}
+        z = op.z
+        M = N * z.H * z.W
+        sp = self.gscale[bn.group.id].data_ptr() + 4 * bn.offset
+        hp = self.gshift[bn.group.id].data_ptr() + 4 * bn.offset
+        g, ldg = self.tptr(z, True), z.ld
+        zp, ldz = self.tptr(z), z.ld
+        mean, invstd, coef = aux['mean'].data_ptr(), aux['invstd'].data_ptr(), aux['coef'].data_ptr()
+        frozen = not bn.layer.trainable
+        G = st.G
+        if frozen:
+            P.k(L.bn_bwd_finalize, None, 0, None, bn.C, float(M), st.ptr(lp['gamma']), invstd, sp, 1, None, None, coef)
+        else:
+            rows = ctypes.c_int(0)
+            P.k(L.bn_bwd_reduce, g, ldg, zp, ldz, sp, hp, bn.act, mean, invstd, self.partials.data_ptr(),
+                ctypes.byref(rows), M, bn.C)
+            P.k(L.bn_bwd_finalize, self.partials.data_ptr(), rows.value, None, bn.C, float(M), st.ptr(lp['gamma']),
+                invstd, sp, 0, st.ptr(lp['gamma'], G), st.ptr(lp['beta'], G), coef)
+            if self.sync_bn:
+                # parameter gradients stay local (they are averaged with every other gradient); the
+                # normalisation terms use the global sums
+                P.k(L.bn_reduce_partials, self.partials.data_ptr(), rows.value, 2 * bn.C, aux['sums'].data_ptr())
+                P.py(lambda s=aux['sums']: self.dist.all_reduce(s))
+                P.k(L.bn_bwd_finalize, None, 0, aux['sums'].data_ptr(), bn.C, float(M * self.dist.world_size),
+                    st.ptr(lp['gamma']), invstd, sp, 0, None, None, coef)
+        P.k(L.bn_bwd_apply, g, ldg, zp, ldz, sp, hp, bn.act, mean, invstd, coef, g, ldg, M, bn.C)
+
+    # ---------------------------------------------------------------- optimiser
+    def _trace_sgd(self):
+        P, L, st = Plan(), self.L, self.store
+        scale = 1.0
+        if self.dist is not None:
+            P.py(lambda: self.dist.all_reduce(st.G))
+            scale = 1.0 / self.dist.world_size
+        P.k(L.sgd_momentum, st.P.data_ptr(), st.V.data_ptr(), st.G.data_ptr(), st.total, self.lr.data_ptr(),
+            float(self.momentum), 0.0, scale, st.l2.data_ptr(), st.lr_scale.data_ptr())
+        return P
+
+    # ---------------------------------------------------------------- running
+    def set_inputs(self, x, y=None):
+        inp = self.buf[self.g.input.tensor.id]
+        x = torch.as_tensor(x, dtype=torch.float32)
+        inp.copy_(x.reshape(-1), non_blocking=True)
+        if y is not None:
+            y = torch.as_tensor(y, dtype=torch.float32)
+            self.labels.copy_(y.reshape(-1), non_blocking=True)
+
+    def capture(self):
+        """capture the traced plans into hipGraphs (done once, after a warm-up eager step)"""
+        torch.cuda.synchronize()
+        # the trace already ran every kernel once; undo its side effects on the step counter only
+        for plan in ([self.fwd, self.bwd, self.opt] if self.training else [self.fwd]):
+            plan.capture()
+        self.graphed = True
+
+    def train_step(self):
+        self.fwd.run()
+        self.bwd.run()
+        self.opt.run()
+
+    def forward(self):
+        self.fwd.run()
+
+    def dropout_mask(self, op):
+        t = op.out
+        m = torch.empty(self.N * t.H * t.W * t.C, **self.f32)
+        self.L.dropout_mask(float(op.rate), self._dropout_seed(op), self.step.data_ptr(), m.data_ptr(),
+                            self.N * t.H * t.W, t.C, torch.cuda.current_stream().cuda_stream)
+        return m.view(self.N, t.H, t.W, t.C)

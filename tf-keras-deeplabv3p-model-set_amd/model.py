@@ -1,0 +1,387 @@
+"""create deeplabv3p models -- the drop-in counterpart of the reference's deeplabv3p/model.py:
+`deeplab_model_map` (:23-48) and `get_deeplabv3p_model(model_type, num_classes, model_input_shape,
+output_stride, freeze_level=0, weights_path=None, training=True, use_subpixel=False)` (:51-117), same
+names, argument meaning and error behaviour.  What it returns is not a tf.keras.Model wrapping
+TensorFlow ops but a `DeeplabModel` façade over the MI355X HIP executor, exposing what the reference's
+callers use: compile / fit / fit_generator / train_on_batch / predict / summary / save / load_weights /
+layers[i].trainable (train.py:155-247, eval.py:33-36, deeplab.py:71-113).
+"""
+import os
+import sys
+import time
+from functools import partial
+
+import numpy as np
+
+from .graph import ACT_NONE
+from .mobilenetv2 import Deeplabv3pMobileNetV2, Deeplabv3pLiteMobileNetV2
+
+#
+# A map of model type to construction function for DeepLabv3+ (reference model.py:23-48).  Entries that
+# are out of this build's hot-path scope raise the same ValueError as an unknown key.
+#
+deeplab_model_map = {
+    'mobilenetv2': partial(Deeplabv3pMobileNetV2, alpha=1.0),
+    'mobilenetv2_lite': partial(Deeplabv3pLiteMobileNetV2, alpha=1.0),
+}
+
+
+def _register_optional():
+    try:
+        from .xception import Deeplabv3pXception
+        deeplab_model_map['xception'] = Deeplabv3pXception
+    except ImportError:
+        pass
+    try:
+        from .mobilenetv3 import Deeplabv3pMobileNetV3Large
+        deeplab_model_map['mobilenetv3large'] = partial(Deeplabv3pMobileNetV3Large, alpha=1.0)
+    except ImportError:
+        pass
+
+
+_register_optional()
+
+
+class SGD:
+    """Keras SGD(learning_rate, momentum=0.9, nesterov=False) (common/model_utils.py:124)"""
+
+    def __init__(self, learning_rate=0.01, momentum=0.9, nesterov=False):
+        if nesterov:
+            raise ValueError('nesterov momentum is not on the hot path')
+        self.learning_rate, self.momentum = learning_rate, momentum
+
+    def lr_at(self, step):
+        lr = self.learning_rate
+        return float(lr(step)) if callable(lr) else float(lr)
+
+
+def get_optimizer(optim_type, learning_rate, average_type=None, decay_type=None, decay_steps=100000):
+    """common/model_utils.py:112-130 -- only 'sgd' is on the hot path"""
+    if optim_type.lower() != 'sgd':
+        raise ValueError('Unsupported optimizer type')
+    if average_type:
+        raise ValueError('averaged optimizers are out of scope')
+    lr = learning_rate
+    if decay_type:
+        d = decay_type.lower()
+        if d == 'cosine':          # CosineDecay(alpha=0.2)
+            lr = lambda s: learning_rate * (0.8 * 0.5 * (1 + np.cos(np.pi * min(s, decay_steps) / decay_steps)) + 0.2)
+        elif d == 'exponential':   # ExponentialDecay(decay_rate=0.9)
+            lr = lambda s: learning_rate * 0.9 ** (s / decay_steps)
+        elif d == 'polynomial':    # PolynomialDecay(end=lr/100, power=1)
+            lr = lambda s: (learning_rate - learning_rate / 100) * (1 - min(s, decay_steps) / decay_steps) + learning_rate / 100
+        elif d == 'piecewise_constant':
+            b = [500, int(decay_steps * 0.9), decay_steps]
+            v = [0.001, learning_rate, learning_rate / 10., learning_rate / 100.]
+            lr = lambda s: v[sum(1 for x in b if s > x)]
+        else:
+            raise ValueError('Unsupported lr decay type')
+    return SGD(lr, momentum=0.9)
+
+
+class SparseCategoricalCrossEntropy(object):
+    """deeplabv3p/loss.py:121-156: configuration holder -- the arithmetic is fused into the HIP head kernel"""
+
+    def __init__(self, ignore_index=None, from_logits=False):
+        if from_logits:
+            raise ValueError('the model emits probabilities (Softmax pred_mask); from_logits is not supported')
+        self.ignore_index = ignore_index
+        self.from_logits = from_logits
+        self.__name__ = 'sparse_categorical_crossentropy'
+
+
+class DistContext:
+    """one process per GPU; RCCL (torch.distributed backend 'nccl') over xGMI"""
+
+    def __init__(self, sync_bn=True):
+        import torch.distributed as dist
+        self.dist = dist
+        self.world_size = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.sync_bn = sync_bn
+
+    def all_reduce(self, t):
+        self.dist.all_reduce(t)
+
+    def broadcast(self, t, src=0):
+        self.dist.broadcast(t, src)
+
+
+class DeeplabModel:
+    def __init__(self, graph, head, model_type, num_classes, input_shape, training, backbone_len, seed=0):
+        self.graph, self.head = graph, head
+        self.name = 'deeplabv3p_' + model_type
+        self.model_type, self.num_classes = model_type, num_classes
+        self.input_shape_hw = tuple(input_shape)
+        self.flatten_output = training      # Reshape((H*W, C)) when built for training (model.py:79-80)
+        self.backbone_len = backbone_len
+        self.layers = graph.layers
+        graph.init_weights()
+        self.optimizer = None
+        self.loss = None
+        self.dist = None
+        self.seed = seed
+        self._store = None
+        self._exec = {}
+        self._steps = 0
+        self.use_graphs = True
+        self.stop_training = False
+
+    # ---- Keras surface ------------------------------------------------------------------
+    @property
+    def input_shape(self):
+        return (None,) + self.input_shape_hw + (3,)
+
+    @property
+    def output_shape(self):
+        H, W = self.input_shape_hw
+        return (None, H * W, self.num_classes) if self.flatten_output else (None, H, W, self.num_classes)
+
+    def get_layer(self, name):
+        return self.graph.layer_by_name[name]
+
+    def count_params(self):
+        return sum(p.size for p in self.graph.all_params())
+
+    def summary(self, print_fn=print):
+        print_fn('Model: "%s"' % self.name)
+        print_fn('%-48s %-24s %12s' % ('Layer (type)', 'Output Shape', 'Param #'))
+        print_fn('=' * 86)
+        for l in self.layers:
+            shape = (None,) + tuple(l.output_shape) if l.output_shape else ''
+            print_fn('%-48s %-24s %12d' % ('%s (%s)' % (l.name, l.kind), str(shape), l.count_params()))
+        tr = sum(p.size for p in self.graph.all_params() if p.trainable)
+        tot = self.count_params()
+        print_fn('=' * 86)
+        print_fn('Total params: {:,}'.format(tot))
+        print_fn('Trainable params: {:,}'.format(tr))
+        print_fn('Non-trainable params: {:,}'.format(tot - tr))
+
+    def compile(self, optimizer=None, loss=None, metrics=None, sample_weight_mode=None, distributed=None,
+                sync_bn=True, **kw):
+        """model.compile(optimizer, loss, ...) (train.py:157,224): (re)binds optimiser and loss and drops the
+        traced plans, so `layers[i].trainable` changes take effect like a Keras recompile"""
+        self.optimizer = optimizer or SGD(0.01)
+        self.loss = loss or SparseCategoricalCrossEntropy(ignore_index=255)
+        if sample_weight_mode:
+            raise ValueError('sample weights (adaptive mode) are not on the hot path')
+        if distributed is None:
+            import torch.distributed as dist
+            distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.dist = DistContext(sync_bn) if distributed else None
+        self._exec = {}
+        if self._store is not None:
+            self._store.refresh_masks()
+            self._store.V.zero_()
+        return self
+
+    def _ensure_store(self):
+        import torch
+        if self._store is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError('the DeepLabV3+ HIP path needs an MI355X device; there is no CPU fallback')
+            from .executor import ParamStore
+            self._store = ParamStore(self.graph, torch.device('cuda', torch.cuda.current_device()))
+            if self.dist is not None:
+                self.dist.broadcast(self._store.P, 0)   # identical replicas (MirroredStrategy semantics)
+        return self._store
+
+    def _executor(self, batch, training):
+        key = (batch, training)
+        if key not in self._exec:
+            from .executor import Executor
+            store = self._ensure_store()
+            ignore = self.loss.ignore_index if self.loss is not None else 255
+            mom = self.optimizer.momentum if self.optimizer is not None else 0.9
+            rank = self.dist.rank if self.dist is not None else 0
+            self._exec[key] = Executor(self.graph, self.head, store, batch, training, self.num_classes,
+                                       ignore_index=ignore, dist=self.dist if training else None,
+                                       seed=self.seed + 7919 * rank, momentum=mom)
+        return self._exec[key]
+
+    def train_on_batch(self, x, y, return_tensor=False):
+        """one SGD step on (x (B,H,W,3) float32 in [-1,1], y (B,H*W,1) class ids); returns the data loss"""
+        if self.optimizer is None:
+            raise RuntimeError('You must compile your model before training')
+        ex = self._executor(int(x.shape[0]), True)
+        ex.set_inputs(x, y)
+        ex.lr.fill_(self.optimizer.lr_at(self._steps))
+        if self.use_graphs and not ex.graphed and self._steps_on(ex) >= 1:
+            ex.capture()
+        ex.train_step()
+        ex._steps = self._steps_on(ex) + 1
+        self._steps += 1
+        return ex.loss if return_tensor else float(ex.loss.item())
+
+    @staticmethod
+    def _steps_on(ex):
+        return getattr(ex, '_steps', 0)
+
+    def predict(self, x, verbose=0, batch_size=None):
+        """probabilities (B,H*W,C) for a training-shaped model, (B,H,W,C) otherwise (eval.py:33-36)"""
+        if isinstance(x, (list, tuple)):
+            x = x[0]
+        x = np.asarray(x, dtype=np.float32)
+        B = x.shape[0]
+        ex = self._executor(B, False)
+        ex.set_inputs(x)
+        ex.forward()
+        H, W = self.input_shape_hw
+        p = ex.probs.view(B, H, W, self.num_classes).cpu().numpy()
+        return p.reshape(B, H * W, self.num_classes) if self.flatten_output else p
+
+    def fit(self, x=None, steps_per_epoch=None, epochs=1, initial_epoch=0, verbose=1, callbacks=None,
+            validation_data=None, validation_steps=None, **kw):
+        """Keras-like loop over a Sequence/generator yielding (images, labels) (train.py:177-187)"""
+        gen = x
+        n = steps_per_epoch or len(gen)
+        history = {'loss': []}
+        for cb in callbacks or []:
+            getattr(cb, 'set_model', lambda m: None)(self)
+        for epoch in range(initial_epoch, epochs):
+            t0, losses = time.time(), []
+            it = iter(gen) if not hasattr(gen, '__getitem__') else None
+            for i in range(n):
+                batch = gen[i] if it is None else next(it)
+                losses.append(self.train_on_batch(batch[0], batch[1]))
+                if not np.isfinite(losses[-1]):      # TerminateOnNaN (train.py:64)
+                    self.stop_training = True
+                    break
+            logs = {'loss': float(np.mean(losses))}
+            if validation_data is not None:
+                logs['val_loss'] = self.evaluate(validation_data, validation_steps)
+            history['loss'].append(logs['loss'])
+            if verbose:
+                print('Epoch %d/%d - %.1fs - loss: %.4f%s' % (
+                    epoch + 1, epochs, time.time() - t0, logs['loss'],
+                    (' - val_loss: %.4f' % logs['val_loss']) if 'val_loss' in logs else ''))
+            if hasattr(gen, 'on_epoch_end'):
+                gen.on_epoch_end()
+            for cb in callbacks or []:
+                getattr(cb, 'on_epoch_end', lambda e, l=None: None)(epoch, logs)
+            if self.stop_training:
+                break
+        return history
+
+    fit_generator = fit
+
+    # ---- weights ------------------------------------------------------------------------
+    def _sync_to_host(self):
+        if self._store is not None:
+            self._store.download()
+
+    def get_weights(self):
+        self._sync_to_host()
+        return [p.value for p in self.graph.all_params()]
+
+    def set_weights(self, weights):
+        ps = self.graph.all_params()
+        assert len(weights) == len(ps), (len(weights), len(ps))
+        for p, w in zip(ps, weights):
+            w = np.asarray(w, dtype=np.float32)
+            assert w.shape == p.shape, (p.name, w.shape, p.shape)
+            p.value = w.copy()
+        if self._store is not None:
+            self._store.upload()
+
+    def get_weights_by_name(self):
+        self._sync_to_host()
+        return {p.name: p.value for p in self.graph.all_params()}
+
+    def set_weights_by_name(self, d, strict=True):
+        for p in self.graph.all_params():
+            if p.name in d:
+                w = np.asarray(d[p.name], dtype=np.float32)
+                assert w.shape == p.shape, (p.name, w.shape, p.shape)
+                p.value = w.copy()
+            elif strict:
+                raise KeyError(p.name)
+        if self._store is not None:
+            self._store.upload()
+
+    def save(self, path):
+        """whole-model checkpoint (train.py:247).  Format: .npz keyed by Keras weight name (the reference's
+        HDF5 container is a 'next' row)"""
+        np.savez(path if path.endswith('.npz') else path + '.npz', **self.get_weights_by_name())
+
+    save_weights = save
+
+    def load_weights(self, path, by_name=False, skip_mismatch=False):
+        if not os.path.exists(path) and os.path.exists(path + '.npz'):
+            path = path + '.npz'
+        data = np.load(path)
+        if by_name:
+            self.set_weights_by_name({k: data[k] for k in data.files}, strict=False)
+        else:
+            # topological order == creation order (model.py:103 load_weights(by_name=False))
+            self.set_weights([data[p.name] for p in self.graph.all_params()])
+
+
+def _evaluate(self, gen, steps=None):
+    """mean data loss with inference-mode BN and no dropout"""
+    n = steps or len(gen)
+    tot, cnt = 0.0, 0
+    ignore = self.loss.ignore_index if self.loss is not None else 255
+    for i in range(n):
+        x, y = gen[i][0], gen[i][1]
+        p = self.predict(x)
+        p = p.reshape(-1, self.num_classes)
+        lab = np.asarray(y).reshape(-1).astype(np.int64)
+        ok = (lab >= 0) & (lab < self.num_classes)
+        if ignore:
+            ok &= lab != ignore
+        pt = np.clip(p[np.where(ok)[0], lab[ok]], 1e-7, 1 - 1e-7)
+        tot += float(-np.log(pt).sum())
+        cnt += lab.size
+    return tot / max(cnt, 1)
+
+
+DeeplabModel.evaluate = _evaluate
+
+
+def get_deeplabv3p_model(model_type, num_classes, model_input_shape, output_stride, freeze_level=0,
+                         weights_path=None, training=True, use_subpixel=False, seed=0):
+    # check if model type is valid
+    if model_type not in deeplab_model_map.keys():
+        raise ValueError('This model type is not supported now')
+    if use_subpixel:
+        raise ValueError('Subpixel head is experimental in the reference (README TODO) and not on the hot path')
+
+    model_function = deeplab_model_map[model_type]
+    H, W = model_input_shape
+    # the reference builds a 21-class stub head and cuts it off again at layers[-5] (model.py:59-65);
+    # the builders here stop at that tensor.  weights=None: offline, random init.
+    g, x, backbone_len = model_function(input_shape=(H, W, 3), weights=None, num_classes=21, OS=output_stride,
+                                        seed=seed)
+    print('backbone layers number: {}'.format(backbone_len))
+    base_len = len(g.layers)
+
+    # new head (model.py:75-86): conv_upsample 1x1 (+bias) -> pred_resize -> [Reshape] -> Softmax('pred_mask').
+    # The class dimension is padded to a multiple of 4 on the device (pad weights/bias stay exactly 0).
+    cpad = (num_classes + 3) // 4 * 4
+    x = g.conv2d(x, num_classes, 1, 'conv_upsample', use_bias=True, pad_to=cpad)
+    g.add_layer('pred_resize', 'Lambda', (H, W, num_classes))
+    if training:
+        g.add_layer(None, 'Reshape', (H * W, num_classes))
+    g.add_layer('pred_mask', 'Softmax', (H * W, num_classes) if training else (H, W, num_classes))
+    if x.tensor.C != cpad or not x.is_plain:
+        raise AssertionError('head tensor layout')
+
+    model = DeeplabModel(g, x, model_type, num_classes, (H, W), training, backbone_len, seed=seed)
+
+    if weights_path:
+        model.load_weights(weights_path, by_name=False)
+        print('Load weights {}.'.format(weights_path))
+
+    if freeze_level in [1, 2]:
+        # Freeze the backbone part or freeze all but final feature map & input layers.
+        num = (backbone_len, base_len)[freeze_level - 1]
+        for i in range(num):
+            model.layers[i].trainable = False
+        print('Freeze the first {} layers of total {} layers.'.format(num, len(model.layers)))
+    elif freeze_level == 0:
+        # Unfreeze all layers.
+        for i in range(len(model.layers)):
+            model.layers[i].trainable = True
+        print('Unfreeze all of the layers.')
+    return model

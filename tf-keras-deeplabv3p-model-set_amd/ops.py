@@ -335,6 +335,6 @@ def upsample_softmax_ce(z, C, H, W, labels=None, ignore_index=255, want_probs=Fa
     return out
 
 
-def sgd_momentum(w, v, g, lr_dev, momentum=0.9, l2=0.0, grad_scale=1.0):
+def sgd_momentum(w, v, g, lr_dev, momentum=0.9, l2=0.0, grad_scale=1.0, l2_elem=None, lr_scale_elem=None):
     lib().sgd_momentum(_p(w), _p(v), _p(g), w.numel(), _p(lr_dev), float(momentum), float(l2), float(grad_scale),
-                       _stream())
+                       _p(l2_elem), _p(lr_scale_elem), _stream())
