@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the MobileNetV2-DeepLabV3+ (ASPP 6/12/18 + decoder) training step,
+513x513x3 synthetic batches, 21 classes, OS=16, fp32, per-GPU batch 16 (BASELINE.json configs[1]).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`,
+   one rank per GPU over RCCL; weak scaling: per-GPU batch fixed)
+
+A step = forward + softmax-CE(ignore 255) + L2 + backward + SGD(momentum) over one resident batch,
+replayed as hipGraph segments.  Rank 0 prints ONE JSON line.  Besides the throughput it carries
+  roofline     : the rate-18 atrous depthwise kernel (ASPP aspp3_depthwise) timed live with HIP events
+                 inside the timed steps, priced against its ALGORITHMIC bytes
+  cpu_baseline : the NumPy oracle (a CPU port of the same train step, BASELINE.json configs[0]:
+                 mobilenetv2_lite, batch 2) timed on this box's host cores, rank 0 / N == 1 only.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = 'tf-keras-deeplabv3p-model-set_amd'
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=16, help='per-GPU batch')
+    ap.add_argument('--size', type=int, default=513)
+    ap.add_argument('--model', default='mobilenetv2')
+    ap.add_argument('--classes', type=int, default=21)
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-sync-bn', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-steps', type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """time the CPU port (oracle, float32 NumPy + BLAS) on a bounded sample of the workload"""
+    import numpy as np
+    from oracle.np_net import OracleModel
+    H = W = args.size
+    B, C = 2, args.classes
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count()
+    m = OracleModel('mobilenetv2_lite', C, (H, W), 16, dtype=np.float32, seed=0)
+    rng = np.random.default_rng(1234)
+    x = rng.uniform(-1, 1, (B, H, W, 3)).astype(np.float32)
+    y = rng.integers(0, C, (B, H * W, 1)).astype(np.float32)
+    y[rng.uniform(size=y.shape) < 0.05] = 255
+    mask = (rng.uniform(size=(B, (H + 15) // 16, (W + 15) // 16, 256)) >= 0.5).astype(np.float32)
+    m.train_step(x, y, {'aspp_dropout': mask})          # warm-up
+    t0 = time.time()
+    for _ in range(args.cpu_steps):
+        m.train_step(x, y, {'aspp_dropout': mask})
+    dt = time.time() - t0
+    return {'value': round(B * args.cpu_steps / dt, 3), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': '%d train steps of mobilenetv2_lite %dx%d batch %d fp32 (NumPy oracle, BLAS threads = cores); '
+                      'the tf.keras reference itself is not installable here' % (args.cpu_steps, H, W, B)}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (there is no CPU fallback for the HIP path)')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    pkg = importlib.import_module(PKG)
+    H = W = args.size
+    N, C = args.batch, args.classes
+
+    model = pkg.get_deeplabv3p_model(args.model, C, (H, W), 16, freeze_level=0, training=True)
+    model.compile(optimizer=pkg.SGD(0.01, momentum=0.9), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255),
+                  sync_bn=not args.no_sync_bn)
+    model.use_graphs = not args.no_graph
+
+    # synthetic resident batch: U[-1,1) images, labels in [0,C) with 5 % set to 255
+    gen = torch.Generator(device='cuda')
+    gen.manual_seed(1234 + rank)
+    x = torch.rand((N, H, W, 3), device='cuda', generator=gen) * 2 - 1
+    y = torch.randint(0, C, (N, H * W, 1), device='cuda', generator=gen).float()
+    y[torch.rand(y.shape, device='cuda', generator=gen) < 0.05] = 255.0
+
+    ex = model._executor(N, True)
+    ex.set_inputs(x, y)
+    ex.lr.fill_(0.01)
+
+    # roofline probe: the rate-18 depthwise launch stays outside the graph segments, between two events
+    probe_name = 'aspp3_depthwise' if any(getattr(o, 'name', '') == 'aspp3_depthwise' for o in model.graph.ops) else None
+    probe = ex.install_probe(probe_name) if probe_name else None
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    ex.train_step()                      # first step eager (also the graph-capture warm-up)
+    if model.use_graphs:
+        ex.capture()
+    for _ in range(args.warmup):
+        ex.train_step()
+    if probe:
+        probe.reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ex.train_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    loss = float(ex.loss.item())
+    if world > 1:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        out = {
+            'metric': 'images/sec (513x513, 21-class) MobileNetV2-DeepLabV3+ OS=16 training step',
+            'value': round(N * world * args.steps / dt, 2), 'unit': 'images/sec', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000 * dt / args.steps, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s + ASPP(6/12/18) + decoder, OS=16, %dx%d, %d classes, per-GPU batch %d, '
+                                   'fwd+loss+bwd+SGD(momentum 0.9, l2 2e-5), BN training mode, dropout 0.5'
+                                   % (args.model, H, W, C, N),
+                       'global_batch': N * world,
+                       'parallelism': 'dp%d%s' % (world, '+syncbn' if (world > 1 and not args.no_sync_bn) else ''),
+                       'hip_graph': bool(model.use_graphs), 'final_loss': round(loss, 5),
+                       'launches_per_step': ex.fwd.n_launches + ex.bwd.n_launches + ex.opt.n_launches},
+        }
+        if probe:
+            ms = probe.mean_ms()
+            op = probe.op
+            t = op.out
+            algo = 2.0 * N * t.H * t.W * op.c * 4 + op.k * op.k * op.c * 4     # read x once, write y once, weights
+            ach = algo / (ms * 1e-3) / 1e9
+            out['roofline'] = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                               'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+                               'kernel': probe.kernel_name, 'avg_us': round(ms * 1e3, 3),
+                               'algorithmic_bytes': int(algo),
+                               'shape': 'N=%d %dx%dx%d k=%d rate=%d' % (N, t.H, t.W, op.c, op.k, op.rate)}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -100,10 +100,27 @@ class Plan:
     def __init__(self):
         self.items = []
         self.segments = None
+        self.tags = {}
 
-    def k(self, fn, *args):
+    def k(self, fn, *args, tag=None):
         fn(*args, torch.cuda.current_stream().cuda_stream)
+        if tag is not None:
+            self.tags[tag] = len(self.items)
         self.items.append((fn, args))
+
+    def probe(self, tag, probe):
+        """keep one launch outside the graph segments, bracketed by two events on its stream"""
+        i = self.tags[tag]
+        fn, args = self.items[i]
+
+        def timed():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn(*args, torch.cuda.current_stream().cuda_stream)
+            e1.record()
+            probe.events.append((e0, e1))
+        self.items[i] = (None, timed)
+        self.segments = None
 
     def py(self, fn):
         fn()
@@ -154,6 +171,20 @@ class Plan:
     @property
     def n_launches(self):
         return sum(1 for it in self.items if it[0] is not None)
+
+
+class Probe:
+    def __init__(self, op, kernel_name):
+        self.op, self.kernel_name, self.events = op, kernel_name, []
+
+    def reset(self):
+        torch.cuda.synchronize()
+        self.events = []
+
+    def mean_ms(self):
+        torch.cuda.synchronize()
+        ts = [a.elapsed_time(b) for a, b in self.events]
+        return sum(ts) / max(1, len(ts))
 
 
 class Executor:
@@ -291,7 +322,7 @@ class Executor:
                 elif k == 'conv_dw':
                     P.k(L.dwconv2d_fwd, xp, ldx, sp, hp, act, st.ptr(op.w), self.tptr(op.out), op.out.ld, part,
                         ctypes.byref(rows), N, xt.H, xt.W, op.c, op.k, op.stride, op.rate, op.pad_t, op.pad_l,
-                        op.Ho, op.Wo)
+                        op.Ho, op.Wo, tag=op.name)
                 else:
                     P.k(L.conv2d_fwd, xp, ldx, sp, hp, act, st.ptr(op.w), self.tptr(op.out), op.out.ld, part,
                         ctypes.byref(rows), N, xt.H, xt.W, op.cin, op.cout, op.k, op.stride, op.rate, op.pad_t,
@@ -513,6 +544,15 @@ class Executor:
 
     def forward(self):
         self.fwd.run()
+
+    def install_probe(self, name):
+        """time one forward depthwise launch with HIP events inside the steps (bench.py roofline)"""
+        op = [o for o in self.g.ops if getattr(o, 'name', None) == name and o.kind == 'conv_dw'][0]
+        seg = op.rate == 1 and op.stride in (1, 2) and op.Wo >= 4
+        kname = ('dw_fwd_seg<%d,%d,%d>' % (op.k, 4 if op.stride == 1 else 2, op.stride)) if seg else 'dw_fwd_gather<%d>' % op.k
+        probe = Probe(op, kname)
+        self.fwd.probe(name, probe)
+        return probe
 
     def dropout_mask(self, op):
         t = op.out
