@@ -21,21 +21,46 @@ extern "C" int dl3p_device_cus(void) { return DL3P_NUM_CUS; }
 
 // ------------------------------------------------------------------------------ row reducer
 // out[i] (+)= sum_r partials[r][i]; double accumulation in a fixed order (deterministic)
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ partials, int rows,
-                                                          size_t row_stride, size_t n, float* __restrict__ out,
-                                                          int accumulate) {
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  double acc = 0.0;
-  for (int r = 0; r < rows; ++r) acc += (double)partials[(size_t)r * row_stride + i];
-  out[i] = (float)(accumulate ? acc + (double)out[i] : acc);
+// EL consecutive elements x RL row lanes per workgroup; each thread keeps 4 independent double
+// accumulators so that 4 row loads are in flight, then the row lanes are combined through LDS.
+template <int EL, int RL>
+__global__ __launch_bounds__(EL * RL) void reduce_rows_kernel(const float* __restrict__ partials, int rows,
+                                                              size_t row_stride, size_t n, float* __restrict__ out,
+                                                              int accumulate) {
+  __shared__ double sm[RL][EL];
+  const int ex = threadIdx.x % EL, ry = threadIdx.x / EL;
+  const size_t i = (size_t)blockIdx.x * EL + ex;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (i < n) {
+    int r = ry;
+    for (; r + 3 * RL < rows; r += 4 * RL) {
+      a0 += (double)partials[(size_t)r * row_stride + i];
+      a1 += (double)partials[(size_t)(r + RL) * row_stride + i];
+      a2 += (double)partials[(size_t)(r + 2 * RL) * row_stride + i];
+      a3 += (double)partials[(size_t)(r + 3 * RL) * row_stride + i];
+    }
+    for (; r < rows; r += RL) a0 += (double)partials[(size_t)r * row_stride + i];
+  }
+  sm[ry][ex] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (ry == 0 && i < n) {
+    double acc = 0.0;
+#pragma unroll 8
+    for (int q = 0; q < RL; ++q) acc += sm[q][ex];
+    out[i] = (float)(accumulate ? acc + (double)out[i] : acc);
+  }
 }
 
 int dl3p_reduce_rows_strided_impl(const float* partials, int rows, size_t row_stride, size_t n, float* out,
                                   int accumulate, hipStream_t st) {
   if (n == 0) return DL3P_OK;
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partials, rows,
-                     row_stride, n, out, accumulate);
+  if (n >= 64 * 1024 || rows <= 16) {
+    hipLaunchKernelGGL((reduce_rows_kernel<64, 4>), dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, partials, rows,
+                       row_stride, n, out, accumulate);
+  } else {
+    hipLaunchKernelGGL((reduce_rows_kernel<16, 64>), dim3((unsigned)((n + 15) / 16)), dim3(1024), 0, st, partials,
+                       rows, row_stride, n, out, accumulate);
+  }
   DL3P_CHECK_LAUNCH("dl3p_reduce_rows");
   return DL3P_OK;
 }
@@ -65,38 +90,48 @@ extern "C" int dl3p_bn_reduce_partials(const float* partials, int rows, int C2, 
 }
 
 // ------------------------------------------------------------------------------ BN finalize
-// 32 channels x 8 row lanes per workgroup; double accumulation
+// 16 channels x 64 row lanes per workgroup (1024 threads); double accumulation, 2 rows in flight
+#define FIN_CX 16
+#define FIN_RY 64
 __device__ __forceinline__ void reduce2_rows(const float* partials, int rows, const double* sums, int C, int c, int ry,
                                              double& a, double& b) {
-  __shared__ double sm[2][8][32];
-  const int cx = threadIdx.x & 31;
-  double s0 = 0.0, s1 = 0.0;
+  __shared__ double sm[2][FIN_RY][FIN_CX];
+  const int cx = threadIdx.x % FIN_CX;
+  double s0 = 0.0, s1 = 0.0, t0 = 0.0, t1 = 0.0;
   if (c < C) {
     if (sums) {
       if (ry == 0) { s0 = sums[c]; s1 = sums[C + c]; }
     } else {
-      for (int r = ry; r < rows; r += 8) {
+      int r = ry;
+      for (; r + FIN_RY < rows; r += 2 * FIN_RY) {
+        s0 += (double)partials[((size_t)r * 2) * C + c];
+        s1 += (double)partials[((size_t)r * 2 + 1) * C + c];
+        t0 += (double)partials[((size_t)(r + FIN_RY) * 2) * C + c];
+        t1 += (double)partials[((size_t)(r + FIN_RY) * 2 + 1) * C + c];
+      }
+      if (r < rows) {
         s0 += (double)partials[((size_t)r * 2) * C + c];
         s1 += (double)partials[((size_t)r * 2 + 1) * C + c];
       }
     }
   }
-  sm[0][ry][cx] = s0;
-  sm[1][ry][cx] = s1;
+  sm[0][ry][cx] = s0 + t0;
+  sm[1][ry][cx] = s1 + t1;
   __syncthreads();
   a = 0.0; b = 0.0;
   if (ry == 0) {
-    for (int q = 0; q < 8; ++q) { a += sm[0][q][cx]; b += sm[1][q][cx]; }
+#pragma unroll 8
+    for (int q = 0; q < FIN_RY; ++q) { a += sm[0][q][cx]; b += sm[1][q][cx]; }
   }
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* partials, int rows, const double* sums, int C,
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* partials, int rows, const double* sums, int C,
                                                           double count, const float* gamma, const float* beta,
                                                           float eps, float momentum, float* moving_mean,
                                                           float* moving_var, int update_moving, float* scale,
                                                           float* shift, float* save_mean, float* save_invstd) {
-  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cx;
+  const int cx = threadIdx.x % FIN_CX, ry = threadIdx.x / FIN_CX;
+  const int c = blockIdx.x * FIN_CX + cx;
   double s, ss;
   reduce2_rows(partials, rows, sums, C, c, ry, s, ss);
   if (ry == 0 && c < C) {
@@ -126,7 +161,7 @@ extern "C" int dl3p_bn_finalize(const float* partials, int rows, const double* s
   DL3P_CHECK_ARG(C > 0 && count > 0 && gamma && beta && scale && shift && save_mean && save_invstd,
                  "dl3p_bn_finalize: bad arguments");
   DL3P_CHECK_ARG(!update_moving || (moving_mean && moving_var), "dl3p_bn_finalize: moving stats missing");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, (hipStream_t)stream, partials, rows,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, FIN_CX)), dim3(FIN_CX * FIN_RY), 0, (hipStream_t)stream, partials, rows,
                      sums, C, count, gamma, beta, eps, momentum, moving_mean, moving_var, update_moving, scale, shift,
                      save_mean, save_invstd);
   DL3P_CHECK_LAUNCH("dl3p_bn_finalize");
@@ -242,12 +277,12 @@ extern "C" int dl3p_bn_bwd_reduce(const float* g, int ldg, const float* z, int l
   return DL3P_OK;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* partials, int rows, const double* sums,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* partials, int rows, const double* sums,
                                                               int C, double count, const float* gamma,
                                                               const float* invstd, const float* scale, int frozen,
                                                               float* dgamma, float* dbeta, float* coef) {
-  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cx;
+  const int cx = threadIdx.x % FIN_CX, ry = threadIdx.x / FIN_CX;
+  const int c = blockIdx.x * FIN_CX + cx;
   double s, sx;
   reduce2_rows(partials, rows, sums, C, c, ry, s, sx);
   if (ry == 0 && c < C) {
@@ -271,7 +306,7 @@ extern "C" int dl3p_bn_bwd_finalize(const float* partials, int rows, const doubl
   DL3P_CHECK_ARG(frozen || (partials && rows > 0) || sums, "dl3p_bn_bwd_finalize: need partial rows or sums");
   DL3P_CHECK_ARG(C > 0 && coef && (frozen ? scale != nullptr : (gamma && save_invstd && count > 0)),
                  "dl3p_bn_bwd_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, FIN_CX)), dim3(FIN_CX * FIN_RY), 0, (hipStream_t)stream,
                      frozen ? nullptr : partials, frozen ? 0 : rows, frozen ? nullptr : sums, C, count, gamma,
                      save_invstd, scale, frozen, dgamma, dbeta, coef);
   DL3P_CHECK_LAUNCH("dl3p_bn_bwd_finalize");

@@ -245,7 +245,9 @@ static int pick_nt(int N) {
 static void gemm_grid(int M, int N, int nt, int* gx, int* gy, int* num_m_tiles) {
   const int mt = ceil_div(M, BM);
   const int nb = ceil_div(N, 16 * nt);
-  int gx_max = (DL3P_NUM_CUS * 2) / nb;          // two workgroups per CU (acc + stats registers)
+  // resident workgroups per CU allowed by the accumulator/statistics registers of this NT
+  const int per_cu = nt <= 1 ? 6 : (nt == 2 ? 5 : (nt <= 4 ? 3 : 2));
+  int gx_max = (DL3P_NUM_CUS * per_cu) / nb;
   if (gx_max < 8) gx_max = 8;
   if (gx_max > DL3P_MAX_STAT_ROWS) gx_max = DL3P_MAX_STAT_ROWS;
   int g = mt;
