@@ -33,28 +33,32 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }
 
 // ---------------------------------------------------------------------------------- device
+// Activations are evaluated BRANCH-FREE from wave-uniform constants derived from the activation code:
+//   t = clamp(v + add, lo, hi) * mul;  out = (hswish) ? v * t : t
+// (none: lo=-inf,hi=+inf; relu: 0,+inf; relu6: 0,6; hard-sigmoid / hard-swish: add 3, clamp 0..6, /6).
+// A `switch` here gets loop-unswitched inside the heavily unrolled conv bodies and explodes the code
+// (43k instructions for one depthwise kernel); selects on a uniform value cost a few SALU ops once.
+#define DL3P_INF __builtin_huge_valf()
 __device__ __forceinline__ float act_apply(float v, int act) {
-  switch (act) {
-    case DL3P_ACT_RELU: return fmaxf(v, 0.f);
-    case DL3P_ACT_RELU6: return fminf(fmaxf(v, 0.f), 6.f);
-    case DL3P_ACT_HSWISH: return v * (fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f));
-    case DL3P_ACT_HSIGMOID: return fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);
-    default: return v;
-  }
+  const bool h = act >= DL3P_ACT_HSWISH;
+  const float lo = act == DL3P_ACT_NONE ? -DL3P_INF : 0.f;
+  const float hi = (act == DL3P_ACT_NONE || act == DL3P_ACT_RELU) ? DL3P_INF : 6.f;
+  const float add = h ? 3.f : 0.f;
+  const float mul = h ? (1.f / 6.f) : 1.f;
+  const float t = fminf(fmaxf(v + add, lo), hi) * mul;
+  return act == DL3P_ACT_HSWISH ? v * t : t;
 }
-// derivative of the activation w.r.t. its (pre-activation) input u
+// derivative of the activation w.r.t. its (pre-activation) input u (TF conventions: 0 at the kinks)
 __device__ __forceinline__ float act_grad(float u, int act) {
-  switch (act) {
-    case DL3P_ACT_RELU: return u > 0.f ? 1.f : 0.f;
-    case DL3P_ACT_RELU6: return (u > 0.f && u < 6.f) ? 1.f : 0.f;
-    case DL3P_ACT_HSWISH: {
-      float in = (u + 3.f > 0.f && u + 3.f < 6.f) ? 1.f : 0.f;
-      float hs = fminf(fmaxf(u + 3.f, 0.f), 6.f) * (1.f / 6.f);
-      return hs + u * in * (1.f / 6.f);
-    }
-    case DL3P_ACT_HSIGMOID: return (u + 3.f > 0.f && u + 3.f < 6.f) ? (1.f / 6.f) : 0.f;
-    default: return 1.f;
-  }
+  const bool h = act >= DL3P_ACT_HSWISH;
+  const float lo = act == DL3P_ACT_NONE ? -DL3P_INF : 0.f;
+  const float hi = (act == DL3P_ACT_NONE || act == DL3P_ACT_RELU) ? DL3P_INF : 6.f;
+  const float add = h ? 3.f : 0.f;
+  const float mul = h ? (1.f / 6.f) : 1.f;
+  const float t = u + add;
+  const float in = (t > lo && t < hi) ? mul : 0.f;
+  const float hs = fminf(fmaxf(t, lo), hi) * mul;
+  return act == DL3P_ACT_HSWISH ? hs + u * in : in;
 }
 __device__ __forceinline__ float4 act_apply4(float4 v, int act) {
   return make_float4(act_apply(v.x, act), act_apply(v.y, act), act_apply(v.z, act), act_apply(v.w, act));
@@ -79,18 +83,19 @@ __device__ __forceinline__ bool dropout_keep(uint64_t seed, int64_t step, uint64
 // (each with a private 4 MiB L2).  Giving workgroup b the `b % 8`-th contiguous chunk of the
 // (image,row,col) work range keeps every image's reads inside one L2.  Speed only, never
 // correctness.  Work items [begin,end) of this workgroup's chunk, visited with stride `step`.
-struct XcdRange { long long begin, end, step; };
-__device__ __forceinline__ XcdRange xcd_range(long long total, int bx, int nbx, int lanes, int lane) {
+struct XcdRange { int begin, end, step; };
+__device__ __forceinline__ XcdRange xcd_range(long long total_ll, int bx, int nbx, int lanes, int lane) {
+  const int total = (int)total_ll;  // hosts reject work ranges >= 2^31
   int xcd = bx & (DL3P_NUM_XCDS - 1);
   int j = bx >> 3;
   int nbj = nbx >> 3;
-  long long chunk = (total + DL3P_NUM_XCDS - 1) / DL3P_NUM_XCDS;
-  long long b = chunk * xcd;
-  long long e = b + chunk < total ? b + chunk : total;
+  const int chunk = (total + DL3P_NUM_XCDS - 1) / DL3P_NUM_XCDS;
+  const int b = chunk * xcd;
+  const int e = b + chunk < total ? b + chunk : total;
   XcdRange r;
-  r.begin = b + (long long)j * lanes + lane;
+  r.begin = b + j * lanes + lane;
   r.end = e;
-  r.step = (long long)nbj * lanes;
+  r.step = nbj * lanes;
   return r;
 }
 
@@ -102,7 +107,7 @@ static inline void pick_lanes(int C, int* c4s, int* px, int* nslab) {
   int best = 1, best_used = 0;
   for (int d = 1; d <= c4 && d <= 256; ++d) {
     if (c4 % d) continue;
-    if (d < 8 && c4 >= 8) continue;  // keep >= 128 B contiguous per pixel
+    if (d < 32 && d < c4) continue;  // keep >= 512 B contiguous per pixel (or the whole pixel)
     int used = (256 / d) * d;
     if (used > best_used || (used == best_used && d > best)) { best = d; best_used = used; }
   }

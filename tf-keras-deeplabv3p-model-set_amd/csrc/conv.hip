@@ -32,11 +32,11 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvParams p) {
   float4 st[2] = {zero4(), zero4()};
   if (active) {
     XcdRange r = xcd_range(p.total, bx, p.nbx, p.px, pl);
-    for (long long s = r.begin; s < r.end; s += r.step) {
-      const int ox = (int)(s % p.Wo);
-      const long long row = s / p.Wo;
-      const int oy = (int)(row % p.Ho);
-      const int n = (int)(row / p.Ho);
+    for (int s = r.begin; s < r.end; s += r.step) {
+      const int ox = s % p.Wo;
+      const int row = s / p.Wo;
+      const int oy = row % p.Ho;
+      const int n = row / p.Ho;
       float4 acc = zero4();
       for (int ky = 0; ky < p.k; ++ky) {
         const int iy = oy * p.stride - p.pad_t + ky * p.rate;
@@ -79,11 +79,11 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(ConvParams p) {
   for (int i = 0; i < WCHUNK; ++i) acc[i] = zero4();
   if (active) {
     XcdRange r = xcd_range(p.total, bx, p.nbx, p.px, pl);
-    for (long long s = r.begin; s < r.end; s += r.step) {
-      const int ox = (int)(s % p.Wo);
-      const long long row = s / p.Wo;
-      const int oy = (int)(row % p.Ho);
-      const int n = (int)(row / p.Ho);
+    for (int s = r.begin; s < r.end; s += r.step) {
+      const int ox = s % p.Wo;
+      const int row = s / p.Wo;
+      const int oy = row % p.Ho;
+      const int n = row / p.Ho;
       const float4 g = ld4(p.dy + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.lddy + co);
 #pragma unroll
       for (int i = 0; i < WCHUNK; ++i) {

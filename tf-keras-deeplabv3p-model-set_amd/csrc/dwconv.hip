@@ -22,14 +22,32 @@ struct DwParams {
   const float* dy; int lddy;   // bwd_weight only
   float* partials;
   int N, H, W, C, Ho, Wo, stride, rate, pad_t, pad_l;
-  int c4s, px, nslab, nbx, spr;
+  int c4s, px, nslab, nbx, spr, th, nbands;
   long long total;
   int flip, accumulate;
 };
 
-// ------------------------------------------------------------------------------ forward, rate 1
-// TW outputs per thread along W; the (TW-1)*S+KS input columns of one tap row are loaded once.
-template <int KS, int TW, int S>
+// producer prologue, specialised at compile time: PRO 0 = raw tensor (backward-data), 1 = BatchNorm affine
+// only (no activation follows the producer's BN), 2 = affine + activation
+template <int PRO>
+__device__ __forceinline__ float4 prologue4(float4 v, float4 sc, float4 sh, int act) {
+  if (PRO == 0) return v;
+  v = fma4(v, sc, sh);
+  if (PRO == 2) v = act_apply4(v, act);
+  return v;
+}
+
+// ------------------------------------------------------------------------------ forward, sliding window
+// A thread owns 4 channels x TW output columns and walks a band of `th` output rows, keeping the KS
+// input rows of its window in registers (already normalised + activated).  Each new output row loads
+// only S new input rows and the loads of the next row are issued before the current row's FMAs.
+// Atrous rates are handled on the rate x rate sub-lattices of the image: outputs (py + v*r, px + u*r)
+// only touch inputs of the same residue class, on which the dilated conv IS a dense 3x3 -- so the
+// window walks (u, v) with pixel stride r and every rate gets the same reuse; taps that fall into the
+// zero padding are exec-masked loads that never leave the CU (at rate 18 on a 33x33 map a 2x2 output
+// block issues 4 loads instead of 36).  This replaces TF's SpaceToBatchND->conv->BatchToSpaceND
+// (two extra tensor passes) by index arithmetic.
+template <int KS, int TW, int S, int PRO>
 __global__ __launch_bounds__(256) void dw_fwd_seg(DwParams p) {
   constexpr int SEG = (TW - 1) * S + KS;
   const int b = blockIdx.x;
@@ -49,50 +67,106 @@ __global__ __launch_bounds__(256) void dw_fwd_seg(DwParams p) {
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero4();
     if (p.scale) { sc = ld4(p.scale + c); sh = ld4(p.shift + c); }
     const int act = p.act;
+    const int th = p.th, nbands = p.nbands, rate = p.rate;
     XcdRange r = xcd_range(p.total, bx, p.nbx, p.px, pl);
-    for (long long s = r.begin; s < r.end; s += r.step) {
-      const int strip = (int)(s % p.spr);
-      const long long row = s / p.spr;
-      const int oy = (int)(row % p.Ho);
-      const int n = (int)(row / p.Ho);
-      const int ox0 = strip * TW;
+    for (int s = r.begin; s < r.end; s += r.step) {
+      const int strip = s % p.spr;
+      int t2 = s / p.spr;
+      const int band = t2 % nbands;
+      t2 /= nbands;
+      const int phase = t2 % (rate * rate);      // sub-lattice (py, px); 0 when rate == 1
+      const int n = t2 / (rate * rate);
+      const int py = phase / rate, pxo = phase - py * rate;
+      const int u0 = strip * TW;                 // first sub-lattice column of this strip
+      const int v0 = band * th;
+      const int ox0 = pxo + u0 * rate;
       const int ix0 = ox0 * S - p.pad_l;
-      float4 acc[TW];
+      const float* ximg = p.x + (size_t)n * p.H * p.W * p.ldx + c;
+      int coff[SEG];
+      bool cok[SEG];
 #pragma unroll
-      for (int i = 0; i < TW; ++i) acc[i] = zero4();
-#pragma unroll
-      for (int ky = 0; ky < KS; ++ky) {
-        const int iy = oy * S - p.pad_t + ky;
-        if (iy < 0 || iy >= p.H) continue;
-        const float* xrow = p.x + ((size_t)n * p.H + iy) * p.W * p.ldx + c;
-        float4 seg[SEG];
-#pragma unroll
-        for (int i = 0; i < SEG; ++i) {
-          const int ix = ix0 + i;
-          if (ix >= 0 && ix < p.W) {
-            seg[i] = act_apply4(fma4(ld4(xrow + (size_t)ix * p.ldx), sc, sh), act);
-          } else {
-            seg[i] = zero4();
-          }
-        }
-#pragma unroll
-        for (int tw = 0; tw < TW; ++tw)
-#pragma unroll
-          for (int kx = 0; kx < KS; ++kx) acc[tw] = fma4(seg[tw * S + kx], wreg[ky * KS + kx], acc[tw]);
+      for (int i = 0; i < SEG; ++i) {
+        const int ix = ix0 + i * rate;
+        cok[i] = ix >= 0 && ix < p.W;
+        coff[i] = ix * p.ldx;
       }
-      float* yrow = p.y + (((size_t)n * p.Ho + oy) * p.Wo + ox0) * p.ldy + c;
+      float4 win[KS][SEG];
+      float4 raw[S][SEG];
+      // prime the window with the KS rows of the first output row (exec-masked loads, math afterwards)
+      {
+        const int oy = py + v0 * rate;
 #pragma unroll
-      for (int tw = 0; tw < TW; ++tw) {
-        if (ox0 + tw < p.Wo) {
-          float4 v = acc[tw];
-          if (p.accumulate) {
-            float4 o = ld4(yrow + (size_t)tw * p.ldy);
-            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        for (int ky = 0; ky < KS; ++ky) {
+          const int iy = oy * S - p.pad_t + ky * rate;
+          const bool yok = iy >= 0 && iy < p.H;
+          const float* xrow = ximg + (size_t)iy * p.W * p.ldx;
+#pragma unroll
+          for (int i = 0; i < SEG; ++i) {
+            win[ky][i] = zero4();
+            if (yok && cok[i]) win[ky][i] = ld4(xrow + coff[i]);
           }
-          st4(yrow + (size_t)tw * p.ldy, v);
-          s1[0].x += v.x; s1[0].y += v.y; s1[0].z += v.z; s1[0].w += v.w;
-          s1[1] = fma4(v, v, s1[1]);
         }
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+          const int iy = oy * S - p.pad_t + ky * rate;
+          const bool yok = iy >= 0 && iy < p.H;
+#pragma unroll
+          for (int i = 0; i < SEG; ++i) {
+            const float4 a = prologue4<PRO>(win[ky][i], sc, sh, act);
+            win[ky][i] = (yok && cok[i]) ? a : zero4();
+          }
+        }
+      }
+      for (int v = v0; v < v0 + th; ++v) {
+        const int oy = py + v * rate;
+        if (oy >= p.Ho) break;
+        const bool more = v + 1 < v0 + th && oy + rate < p.Ho;
+        // issue the loads of the S rows that enter the window for the next output row
+        bool nyok[S];
+#pragma unroll
+        for (int q = 0; q < S; ++q) {
+          const int iy = (oy + rate) * S - p.pad_t + (KS - S + q) * rate;
+          nyok[q] = more && iy >= 0 && iy < p.H;
+          const float* xrow = ximg + (size_t)iy * p.W * p.ldx;
+#pragma unroll
+          for (int i = 0; i < SEG; ++i) {
+            raw[q][i] = zero4();
+            if (nyok[q] && cok[i]) raw[q][i] = ld4(xrow + coff[i]);
+          }
+        }
+        float4 acc[TW];
+#pragma unroll
+        for (int i = 0; i < TW; ++i) acc[i] = zero4();
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+          for (int tw = 0; tw < TW; ++tw)
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) acc[tw] = fma4(win[ky][tw * S + kx], wreg[ky * KS + kx], acc[tw]);
+        float* yrow = p.y + (((size_t)n * p.Ho + oy) * p.Wo + ox0) * p.ldy + c;
+#pragma unroll
+        for (int tw = 0; tw < TW; ++tw) {
+          if (ox0 + tw * rate < p.Wo) {
+            float4 vv = acc[tw];
+            float* yp = yrow + (size_t)tw * rate * p.ldy;
+            if (p.accumulate) vv = add4(vv, ld4(yp));
+            st4(yp, vv);
+            s1[0] = add4(s1[0], vv);
+            s1[1] = fma4(vv, vv, s1[1]);
+          }
+        }
+        // slide the window down by S rows
+#pragma unroll
+        for (int ky = 0; ky + S < KS; ++ky)
+#pragma unroll
+          for (int i = 0; i < SEG; ++i) win[ky][i] = win[ky + S][i];
+#pragma unroll
+        for (int q = 0; q < S; ++q)
+#pragma unroll
+          for (int i = 0; i < SEG; ++i) {
+            const float4 a = prologue4<PRO>(raw[q][i], sc, sh, act);
+            win[KS - S + q][i] = (nyok[q] && cok[i]) ? a : zero4();
+          }
       }
     }
   }
@@ -100,9 +174,13 @@ __global__ __launch_bounds__(256) void dw_fwd_seg(DwParams p) {
 }
 
 // ------------------------------------------------------------------------------ forward, any rate / stride
-// One output pixel per thread; each tap is a predicated 16-B gather served by the XCD's L2.
-template <int KS>
+// Per-pixel gather for the geometries the window kernel does not cover (sub-lattice narrower than a
+// strip: the ASPP rates 12/18 on a 33x33 map, where most taps fall into the zero padding).  Two output
+// pixels per thread and iteration: all their in-range taps are exec-masked 16-B loads issued before any
+// arithmetic (taps in the padding issue nothing), served by the XCD's L2.
+template <int KS, int PRO>
 __global__ __launch_bounds__(256) void dw_fwd_gather(DwParams p) {
+  constexpr int TI = 2;
   const int b = blockIdx.x;
   const int slab = b / p.nbx;
   const int bx = b - slab * p.nbx;
@@ -118,42 +196,53 @@ __global__ __launch_bounds__(256) void dw_fwd_gather(DwParams p) {
 #pragma unroll
     for (int i = 0; i < KS * KS; ++i) wreg[i] = ld4(p.w + (size_t)(p.flip ? KS * KS - 1 - i : i) * p.C + c);
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero4();
-    if (p.scale) { sc = ld4(p.scale + c); sh = ld4(p.shift + c); }
+    if (PRO && p.scale) { sc = ld4(p.scale + c); sh = ld4(p.shift + c); }
     const int act = p.act;
     XcdRange r = xcd_range(p.total, bx, p.nbx, p.px, pl);
-    for (long long s = r.begin; s < r.end; s += r.step) {
-      const int ox = (int)(s % p.Wo);
-      const long long row = s / p.Wo;
-      const int oy = (int)(row % p.Ho);
-      const int n = (int)(row / p.Ho);
-      const float* ximg = p.x + (size_t)n * p.H * p.W * p.ldx + c;
-      float4 v[KS * KS];
-      // issue every valid tap load first (independent, all in flight), then the FMAs
+    for (int s0 = r.begin; s0 < r.end; s0 += TI * r.step) {
+      float4 v[TI][KS * KS];
+      bool ok[TI][KS * KS];
+      float* yp[TI];
+      bool live[TI];
 #pragma unroll
-      for (int ky = 0; ky < KS; ++ky) {
-        const int iy = oy * p.stride - p.pad_t + ky * p.rate;
-        const bool yok = iy >= 0 && iy < p.H;
+      for (int ti = 0; ti < TI; ++ti) {
+        const int s = s0 + ti * r.step;
+        live[ti] = s < r.end;
+        const int ox = s % p.Wo;
+        const int row = s / p.Wo;
+        const int oy = row % p.Ho;
+        const int n = row / p.Ho;
+        const float* ximg = p.x + (size_t)n * p.H * p.W * p.ldx + c;
+        yp[ti] = p.y + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.ldy + c;
 #pragma unroll
-        for (int kx = 0; kx < KS; ++kx) {
-          const int ix = ox * p.stride - p.pad_l + kx * p.rate;
-          if (yok && ix >= 0 && ix < p.W) {
-            v[ky * KS + kx] = act_apply4(fma4(ld4(ximg + ((size_t)iy * p.W + ix) * p.ldx), sc, sh), act);
-          } else {
-            v[ky * KS + kx] = zero4();
+        for (int ky = 0; ky < KS; ++ky) {
+          const int iy = oy * p.stride - p.pad_t + ky * p.rate;
+          const bool yok = live[ti] && iy >= 0 && iy < p.H;
+#pragma unroll
+          for (int kx = 0; kx < KS; ++kx) {
+            const int ix = ox * p.stride - p.pad_l + kx * p.rate;
+            const bool o = yok && ix >= 0 && ix < p.W;
+            ok[ti][ky * KS + kx] = o;
+            v[ti][ky * KS + kx] = zero4();
+            if (o) v[ti][ky * KS + kx] = ld4(ximg + ((size_t)iy * p.W + ix) * p.ldx);
           }
         }
       }
-      float4 acc = zero4();
 #pragma unroll
-      for (int i = 0; i < KS * KS; ++i) acc = fma4(v[i], wreg[i], acc);
-      float* yp = p.y + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.ldy + c;
-      if (p.accumulate) {
-        float4 o = ld4(yp);
-        acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+      for (int ti = 0; ti < TI; ++ti) {
+        float4 acc = zero4();
+#pragma unroll
+        for (int i = 0; i < KS * KS; ++i) {
+          const float4 a = prologue4<PRO>(v[ti][i], sc, sh, act);
+          acc = fma4(ok[ti][i] ? a : zero4(), wreg[i], acc);
+        }
+        if (live[ti]) {
+          if (p.accumulate) acc = add4(acc, ld4(yp[ti]));
+          st4(yp[ti], acc);
+          s1[0] = add4(s1[0], acc);
+          s1[1] = fma4(acc, acc, s1[1]);
+        }
       }
-      st4(yp, acc);
-      s1[0].x += acc.x; s1[0].y += acc.y; s1[0].z += acc.z; s1[0].w += acc.w;
-      s1[1] = fma4(acc, acc, s1[1]);
     }
   }
   if (p.partials) block_reduce_store<2>(s1, active, pl, cl, p.c4s, p.px, cbase4, p.C, p.partials + (size_t)bx * 2 * p.C);
@@ -176,11 +265,11 @@ __global__ __launch_bounds__(256) void dw_bwd_data_strided(DwParams p) {
 #pragma unroll
   for (int i = 0; i < KS * KS; ++i) wreg[i] = ld4(p.w + (size_t)i * p.C + c);
   XcdRange r = xcd_range(p.total, bx, p.nbx, p.px, pl);
-  for (long long s = r.begin; s < r.end; s += r.step) {
-    const int ix = (int)(s % p.W);
-    const long long row = s / p.W;
-    const int iy = (int)(row % p.H);
-    const int n = (int)(row / p.H);
+  for (int s = r.begin; s < r.end; s += r.step) {
+    const int ix = s % p.W;
+    const int row = s / p.W;
+    const int iy = row % p.H;
+    const int n = row / p.H;
     const float* dimg = p.dy + (size_t)n * p.Ho * p.Wo * p.lddy + c;
     float4 acc = zero4();
 #pragma unroll
@@ -229,25 +318,32 @@ __global__ __launch_bounds__(256) void dw_bwd_weight(DwParams p) {
     if (p.scale) { sc = ld4(p.scale + c); sh = ld4(p.shift + c); }
     const int act = p.act;
     XcdRange r = xcd_range(p.total, bx, p.nbx, p.px, pl);
-    for (long long s = r.begin; s < r.end; s += r.step) {
-      const int ox = (int)(s % p.Wo);
-      const long long row = s / p.Wo;
-      const int oy = (int)(row % p.Ho);
-      const int n = (int)(row / p.Ho);
+    for (int s = r.begin; s < r.end; s += r.step) {
+      const int ox = s % p.Wo;
+      const int row = s / p.Wo;
+      const int oy = row % p.Ho;
+      const int n = row / p.Ho;
       const float4 g = ld4(p.dy + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.lddy + c);
       const float* ximg = p.x + (size_t)n * p.H * p.W * p.ldx + c;
+      float4 v[KS * KS];
+      bool ok[KS * KS];
 #pragma unroll
       for (int ky = 0; ky < KS; ++ky) {
         const int iy = oy * p.stride - p.pad_t + ky * p.rate;
         const bool yok = iy >= 0 && iy < p.H;
+        const int iyc = min(max(iy, 0), p.H - 1);
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx) {
           const int ix = ox * p.stride - p.pad_l + kx * p.rate;
-          if (yok && ix >= 0 && ix < p.W) {
-            float4 a = act_apply4(fma4(ld4(ximg + ((size_t)iy * p.W + ix) * p.ldx), sc, sh), act);
-            wacc[ky * KS + kx] = fma4(a, g, wacc[ky * KS + kx]);
-          }
+          ok[ky * KS + kx] = yok && ix >= 0 && ix < p.W;
+          const int ixc = min(max(ix, 0), p.W - 1);
+          v[ky * KS + kx] = ld4(ximg + ((size_t)iyc * p.W + ixc) * p.ldx);
         }
+      }
+#pragma unroll
+      for (int i = 0; i < KS * KS; ++i) {
+        const float4 a = act_apply4(fma4(v[i], sc, sh), act);
+        if (ok[i]) wacc[i] = fma4(a, g, wacc[i]);
       }
     }
   }
@@ -264,18 +360,56 @@ static int check_dw_common(const char* fn, const void* x, int ldx, int C, int k)
   return DL3P_OK;
 }
 
+// rows per band: as tall as possible (less halo re-reading) while every CU still gets a few workgroups
+static int pick_band(long long items_per_row_band, int rows, int px, int nslab) {
+  const long long want = (long long)DL3P_NUM_CUS * 8;          // workgroup-iterations wanted overall
+  int th = 16;
+  while (th > 1 && (items_per_row_band * ceil_div(rows, th) / px) * nslab < want) th >>= 1;
+  return th;
+}
+
+// variant + work decomposition of a forward depthwise launch
+//   kind 1: window kernel TW=4, stride 1 (any rate, on the rate x rate sub-lattices)
+//   kind 2: window kernel TW=2, stride 2, rate 1
+//   kind 0: per-pixel gather (stride > 1 with rate > 1, or maps narrower than a strip)
+static int fwd_plan(DwParams& p) {
+  int kind = 0;
+  if (p.stride == 1 && ceil_div(p.Wo, p.rate) >= 4) kind = 1;
+  else if (p.stride == 2 && p.rate == 1 && p.Wo >= 4) kind = 2;
+  if (kind == 0) {
+    p.spr = p.Wo; p.th = 1; p.nbands = p.Ho;
+    p.total = (long long)p.N * p.Ho * p.Wo;
+  } else {
+    const int TW = kind == 1 ? 4 : 2;
+    const int r = p.rate;
+    const int uw = ceil_div(p.Wo, r), uh = ceil_div(p.Ho, r);      // sub-lattice size
+    p.spr = ceil_div(uw, TW);
+    p.th = pick_band((long long)p.N * r * r * p.spr, uh, p.px, p.nslab);
+    if (p.th > uh) p.th = uh;
+    p.nbands = ceil_div(uh, p.th);
+    p.total = (long long)p.N * r * r * p.nbands * p.spr;
+  }
+  p.nbx = pick_nbx(p.total, p.px, p.nslab);
+  return kind;
+}
+
+template <int KS, int PRO>
+static void launch_fwd_pro(const DwParams& p, int kind, dim3 grid, hipStream_t st) {
+  dim3 block(256);
+  if (kind == 1) hipLaunchKernelGGL((dw_fwd_seg<KS, 4, 1, PRO>), grid, block, 0, st, p);
+  else if (kind == 2) hipLaunchKernelGGL((dw_fwd_seg<KS, 2, 2, PRO>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((dw_fwd_gather<KS, PRO>), grid, block, 0, st, p);
+}
+
 template <int KS>
 static void launch_fwd(const DwParams& p0, hipStream_t st) {
   DwParams p = p0;
-  const bool seg = p.rate == 1 && (p.stride == 1 || p.stride == 2) && p.Wo >= 4;
-  const int TW = seg ? (p.stride == 1 ? 4 : 2) : 1;
-  p.spr = ceil_div(p.Wo, TW);
-  p.total = (long long)p.N * p.Ho * p.spr;
-  p.nbx = pick_nbx(p.total, p.px, p.nslab);
-  dim3 grid(p.nbx * p.nslab), block(256);
-  if (seg && p.stride == 1) hipLaunchKernelGGL((dw_fwd_seg<KS, 4, 1>), grid, block, 0, st, p);
-  else if (seg) hipLaunchKernelGGL((dw_fwd_seg<KS, 2, 2>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL((dw_fwd_gather<KS>), grid, block, 0, st, p);
+  const int kind = fwd_plan(p);
+  dim3 grid(p.nbx * p.nslab);
+  const int pro = (p.act != DL3P_ACT_NONE) ? 2 : (p.scale ? 1 : 0);
+  if (pro == 2) launch_fwd_pro<KS, 2>(p, kind, grid, st);
+  else if (pro == 1) launch_fwd_pro<KS, 1>(p, kind, grid, st);
+  else launch_fwd_pro<KS, 0>(p, kind, grid, st);
 }
 
 extern "C" int dl3p_dwconv2d_fwd(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
@@ -293,12 +427,10 @@ extern "C" int dl3p_dwconv2d_fwd(const float* x, int ldx, const float* in_scale,
   p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.rate = rate;
   p.pad_t = pad_t; p.pad_l = pad_l;
   pick_lanes(C, &p.c4s, &p.px, &p.nslab);
-  // nbx depends on the variant; replicate launch_fwd's choice to report it
   {
-    const bool seg = rate == 1 && (stride == 1 || stride == 2) && Wo >= 4;
-    const int TW = seg ? (stride == 1 ? 4 : 2) : 1;
-    long long total = (long long)N * Ho * ceil_div(Wo, TW);
-    if (rows_out) *rows_out = pick_nbx(total, p.px, p.nslab);
+    DwParams q = p;
+    fwd_plan(q);
+    if (rows_out) *rows_out = q.nbx;
   }
   hipStream_t st = (hipStream_t)stream;
   if (k == 3) launch_fwd<3>(p, st); else launch_fwd<5>(p, st);

@@ -40,11 +40,11 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(ResizeParams p) {
   const int c = (slab * p.c4s + cl) * 4;
   const float sy = (float)p.h / (float)p.H, sx = (float)p.w / (float)p.W;
   XcdRange r = xcd_range(p.total, bx, p.nbx, p.px, pl);
-  for (long long s = r.begin; s < r.end; s += r.step) {
-    const int ox = (int)(s % p.W);
-    const long long row = s / p.W;
-    const int oy = (int)(row % p.H);
-    const int n = (int)(row / p.H);
+  for (int s = r.begin; s < r.end; s += r.step) {
+    const int ox = s % p.W;
+    const int row = s / p.W;
+    const int oy = row % p.H;
+    const int n = row / p.H;
     const Lerp ly = lerp_coeff(oy, sy, p.h), lx = lerp_coeff(ox, sx, p.w);
     const float* img = p.x + (size_t)n * p.h * p.w * p.ldx + c;
     const float4 tl = ld4(img + ((size_t)ly.lo * p.w + lx.lo) * p.ldx);
@@ -80,11 +80,11 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeParams p) {
   const float sy = (float)p.h / (float)p.H, sx = (float)p.w / (float)p.W;
   const float isy = (float)p.H / (float)p.h, isx = (float)p.W / (float)p.w;
   XcdRange r = xcd_range(p.total, bx, p.nbx, p.px, pl);
-  for (long long s = r.begin; s < r.end; s += r.step) {
-    const int ix = (int)(s % p.w);
-    const long long row = s / p.w;
-    const int iy = (int)(row % p.h);
-    const int n = (int)(row / p.h);
+  for (int s = r.begin; s < r.end; s += r.step) {
+    const int ix = s % p.w;
+    const int row = s / p.w;
+    const int iy = row % p.h;
+    const int n = row / p.h;
     int y0, y1, x0, x1;
     touch_range(iy, isy, p.H, y0, y1);
     touch_range(ix, isx, p.W, x0, x1);
@@ -169,10 +169,10 @@ __global__ __launch_bounds__(256) void head_kernel(HeadParams p) {
   const float sy = (float)p.h / (float)p.H, sx = (float)p.w / (float)p.W;
   float loss = 0.f;
   for (long long s = (long long)blockIdx.x * 256 + threadIdx.x; s < p.total; s += (long long)gridDim.x * 256) {
-    const int ox = (int)(s % p.W);
-    const long long row = s / p.W;
-    const int oy = (int)(row % p.H);
-    const int n = (int)(row / p.H);
+    const int ox = s % p.W;
+    const int row = s / p.W;
+    const int oy = row % p.H;
+    const int n = row / p.H;
     const Lerp ly = lerp_coeff(oy, sy, p.h), lx = lerp_coeff(ox, sx, p.w);
     const float* img = p.z + (size_t)n * p.h * p.w * p.ldz;
     const float* ptl = img + ((size_t)ly.lo * p.w + lx.lo) * p.ldz;
