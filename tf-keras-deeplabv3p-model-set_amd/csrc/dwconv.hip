@@ -173,6 +173,129 @@ __global__ __launch_bounds__(256) void dw_fwd_seg(DwParams p) {
   if (p.partials) block_reduce_store<2>(s1, active, pl, cl, p.c4s, p.px, cbase4, p.C, p.partials + (size_t)bx * 2 * p.C);
 }
 
+// ------------------------------------------------------------------------------ backward weight, sliding window
+// Same window walk as the forward kernel (the activated input rows live in registers); every output
+// row adds win[ky][tw+kx] * dy[tw] into the k*k per-thread tap accumulators.  One partial row
+// [k*k][C] per workgroup, summed in a fixed order afterwards.
+template <int KS, int TW, int S, int PRO>
+__global__ __launch_bounds__(256) void dw_bwd_weight_seg(DwParams p) {
+  constexpr int SEG = (TW - 1) * S + KS;
+  const int b = blockIdx.x;
+  const int slab = b / p.nbx;
+  const int bx = b - slab * p.nbx;
+  const int t = threadIdx.x;
+  const int pl = t / p.c4s;
+  const int cl = t - pl * p.c4s;
+  const bool active = pl < p.px;
+  const int cbase4 = slab * p.c4s;
+  const int c = (cbase4 + cl) * 4;
+  float4 wacc[KS * KS];
+#pragma unroll
+  for (int i = 0; i < KS * KS; ++i) wacc[i] = zero4();
+  if (active) {
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero4();
+    if (p.scale) { sc = ld4(p.scale + c); sh = ld4(p.shift + c); }
+    const int act = p.act;
+    const int th = p.th, nbands = p.nbands, rate = p.rate;
+    XcdRange r = xcd_range(p.total, bx, p.nbx, p.px, pl);
+    for (int s = r.begin; s < r.end; s += r.step) {
+      const int strip = s % p.spr;
+      int t2 = s / p.spr;
+      const int band = t2 % nbands;
+      t2 /= nbands;
+      const int phase = t2 % (rate * rate);      // sub-lattice (py, px); 0 when rate == 1
+      const int n = t2 / (rate * rate);
+      const int py = phase / rate, pxo = phase - py * rate;
+      const int u0 = strip * TW;                 // first sub-lattice column of this strip
+      const int v0 = band * th;
+      const int ox0 = pxo + u0 * rate;
+      const int ix0 = ox0 * S - p.pad_l;
+      const float* ximg = p.x + (size_t)n * p.H * p.W * p.ldx + c;
+      int coff[SEG];
+      bool cok[SEG];
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) {
+        const int ix = ix0 + i * rate;
+        cok[i] = ix >= 0 && ix < p.W;
+        coff[i] = ix * p.ldx;
+      }
+      float4 win[KS][SEG];
+      float4 raw[S][SEG];
+      // prime the window with the KS rows of the first output row (exec-masked loads, math afterwards)
+      {
+        const int oy = py + v0 * rate;
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+          const int iy = oy * S - p.pad_t + ky * rate;
+          const bool yok = iy >= 0 && iy < p.H;
+          const float* xrow = ximg + (size_t)iy * p.W * p.ldx;
+#pragma unroll
+          for (int i = 0; i < SEG; ++i) {
+            win[ky][i] = zero4();
+            if (yok && cok[i]) win[ky][i] = ld4(xrow + coff[i]);
+          }
+        }
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+          const int iy = oy * S - p.pad_t + ky * rate;
+          const bool yok = iy >= 0 && iy < p.H;
+#pragma unroll
+          for (int i = 0; i < SEG; ++i) {
+            const float4 a = prologue4<PRO>(win[ky][i], sc, sh, act);
+            win[ky][i] = (yok && cok[i]) ? a : zero4();
+          }
+        }
+      }
+      for (int v = v0; v < v0 + th; ++v) {
+        const int oy = py + v * rate;
+        if (oy >= p.Ho) break;
+        const bool more = v + 1 < v0 + th && oy + rate < p.Ho;
+        // issue the loads of the S rows that enter the window for the next output row
+        bool nyok[S];
+#pragma unroll
+        for (int q = 0; q < S; ++q) {
+          const int iy = (oy + rate) * S - p.pad_t + (KS - S + q) * rate;
+          nyok[q] = more && iy >= 0 && iy < p.H;
+          const float* xrow = ximg + (size_t)iy * p.W * p.ldx;
+#pragma unroll
+          for (int i = 0; i < SEG; ++i) {
+            raw[q][i] = zero4();
+            if (nyok[q] && cok[i]) raw[q][i] = ld4(xrow + coff[i]);
+          }
+        }
+        // gradient of the raw conv output for this row's strip
+        float4 dyv[TW];
+        const float* drow = p.dy + (((size_t)n * p.Ho + oy) * p.Wo + ox0) * p.lddy + c;
+#pragma unroll
+        for (int tw = 0; tw < TW; ++tw) {
+          dyv[tw] = zero4();
+          if (ox0 + tw * rate < p.Wo) dyv[tw] = ld4(drow + (size_t)tw * rate * p.lddy);
+        }
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+            for (int tw = 0; tw < TW; ++tw) wacc[ky * KS + kx] = fma4(win[ky][tw * S + kx], dyv[tw], wacc[ky * KS + kx]);
+        // slide the window down by S rows
+#pragma unroll
+        for (int ky = 0; ky + S < KS; ++ky)
+#pragma unroll
+          for (int i = 0; i < SEG; ++i) win[ky][i] = win[ky + S][i];
+#pragma unroll
+        for (int q = 0; q < S; ++q)
+#pragma unroll
+          for (int i = 0; i < SEG; ++i) {
+            const float4 a = prologue4<PRO>(raw[q][i], sc, sh, act);
+            win[KS - S + q][i] = (nyok[q] && cok[i]) ? a : zero4();
+          }
+      }
+    }
+  }
+  block_reduce_store<KS * KS>(wacc, active, pl, cl, p.c4s, p.px, cbase4, p.C,
+                              p.partials + (size_t)bx * KS * KS * p.C);
+}
+
 // ------------------------------------------------------------------------------ forward, any rate / stride
 // Per-pixel gather for the geometries the window kernel does not cover (sub-lattice narrower than a
 // strip: the ASPP rates 12/18 on a 33x33 map, where most taps fall into the zero padding).  Two output
@@ -299,7 +422,7 @@ __global__ __launch_bounds__(256) void dw_bwd_data_strided(DwParams p) {
 // ------------------------------------------------------------------------------ backward weight
 // gw[tap][c] = sum_{n,oy,ox} a[n, oy*s-pad+ky*r, ox*s-pad+kx*r, c] * dy[n,oy,ox,c]; a = act(x*scale+shift).
 // Per-thread tap accumulators over a persistent loop, then one partial row [k*k][C] per workgroup.
-template <int KS>
+template <int KS, int PRO>
 __global__ __launch_bounds__(256) void dw_bwd_weight(DwParams p) {
   const int b = blockIdx.x;
   const int slab = b / p.nbx;
@@ -331,18 +454,18 @@ __global__ __launch_bounds__(256) void dw_bwd_weight(DwParams p) {
       for (int ky = 0; ky < KS; ++ky) {
         const int iy = oy * p.stride - p.pad_t + ky * p.rate;
         const bool yok = iy >= 0 && iy < p.H;
-        const int iyc = min(max(iy, 0), p.H - 1);
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx) {
           const int ix = ox * p.stride - p.pad_l + kx * p.rate;
-          ok[ky * KS + kx] = yok && ix >= 0 && ix < p.W;
-          const int ixc = min(max(ix, 0), p.W - 1);
-          v[ky * KS + kx] = ld4(ximg + ((size_t)iyc * p.W + ixc) * p.ldx);
+          const bool o = yok && ix >= 0 && ix < p.W;
+          ok[ky * KS + kx] = o;
+          v[ky * KS + kx] = zero4();
+          if (o) v[ky * KS + kx] = ld4(ximg + ((size_t)iy * p.W + ix) * p.ldx);
         }
       }
 #pragma unroll
       for (int i = 0; i < KS * KS; ++i) {
-        const float4 a = act_apply4(fma4(v[i], sc, sh), act);
+        const float4 a = prologue4<PRO>(v[i], sc, sh, act);
         if (ok[i]) wacc[i] = fma4(a, g, wacc[i]);
       }
     }
@@ -470,15 +593,18 @@ extern "C" int dl3p_dwconv2d_bwd_data(const float* dy, int lddy, const float* w,
   return DL3P_OK;
 }
 
-static int bwdw_rows(int N, int Ho, int Wo, int C) {
-  int c4s, px, nslab;
-  pick_lanes(C, &c4s, &px, &nslab);
-  return pick_nbx((long long)N * Ho * Wo, px, nslab);
+template <int KS, int PRO>
+static void launch_bwdw(const DwParams& p, int kind, dim3 grid, hipStream_t st) {
+  dim3 block(256);
+  if (kind == 1) hipLaunchKernelGGL((dw_bwd_weight_seg<KS, 4, 1, PRO>), grid, block, 0, st, p);
+  else if (kind == 2) hipLaunchKernelGGL((dw_bwd_weight_seg<KS, 2, 2, PRO>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((dw_bwd_weight<KS, PRO>), grid, block, 0, st, p);
 }
 
 extern "C" size_t dl3p_dwconv2d_bwd_weight_workspace(int N, int Ho, int Wo, int C, int k) {
   if (C <= 0 || C % 4) return 0;
-  return (size_t)bwdw_rows(N, Ho, Wo, C) * k * k * C * sizeof(float);
+  (void)N; (void)Ho; (void)Wo;
+  return (size_t)DL3P_MAX_STAT_ROWS * k * k * C * sizeof(float);   // one partial row per workgroup, at most
 }
 
 extern "C" int dl3p_dwconv2d_bwd_weight(const float* x, int ldx, const float* in_scale, const float* in_shift,
@@ -502,11 +628,14 @@ extern "C" int dl3p_dwconv2d_bwd_weight(const float* x, int ldx, const float* in
   p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.rate = rate;
   p.pad_t = pad_t; p.pad_l = pad_l;
   pick_lanes(C, &p.c4s, &p.px, &p.nslab);
-  p.total = (long long)N * Ho * Wo;
-  p.nbx = pick_nbx(p.total, p.px, p.nslab);
-  dim3 grid(p.nbx * p.nslab), block(256);
-  if (k == 3) hipLaunchKernelGGL((dw_bwd_weight<3>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL((dw_bwd_weight<5>), grid, block, 0, st, p);
+  const int kind = fwd_plan(p);
+  dim3 grid(p.nbx * p.nslab);
+  const int pro = (in_act != DL3P_ACT_NONE) ? 2 : (in_scale ? 1 : 0);
+  if (k == 3) {
+    if (pro == 2) launch_bwdw<3, 2>(p, kind, grid, st); else if (pro == 1) launch_bwdw<3, 1>(p, kind, grid, st); else launch_bwdw<3, 0>(p, kind, grid, st);
+  } else {
+    if (pro == 2) launch_bwdw<5, 2>(p, kind, grid, st); else if (pro == 1) launch_bwdw<5, 1>(p, kind, grid, st); else launch_bwdw<5, 0>(p, kind, grid, st);
+  }
   DL3P_CHECK_LAUNCH("dl3p_dwconv2d_bwd_weight");
   return dl3p_reduce_rows_impl(workspace, p.nbx, (size_t)k * k * C, gw, 0, st);
 }
