@@ -24,7 +24,6 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define BM 128
 #define BK 32
 #define APITCH 36  // 32 + 4: rows 4 apart land 16 banks apart -> ds_read_b128 conflict-free
 
@@ -42,8 +41,9 @@ struct GemmParams {
 
 // B_KN: B is [Kred][Nout] row-major (forward: the Keras kernel as stored);
 // !B_KN: B is [Nout][Kred] row-major (dgrad: the same kernel read as its transpose).
-template <int NT, bool B_KN, bool STATS>
+template <int NT, bool B_KN, bool STATS, int MI>
 __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
+  constexpr int BM = 64 * MI;   // 4 waves x MI tiles of 16 rows
   constexpr int BN = 16 * NT;
   constexpr int BPITCH = B_KN ? (BN + 4) : APITCH;
   constexpr int BS_FLOATS = B_KN ? BK * BPITCH : BN * APITCH;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
   const int ar = t >> 3;         // A row within a 32-row pass
   const int akq = (t & 7) * 4;   // A k offset within the K tile
 
-  float4 ra[4];
+  float4 ra[2 * MI];
   float4 rb[NB4];
   float4 rsc = make_float4(1.f, 1.f, 1.f, 1.f), rsh = zero4();
   int cur_m0 = 0;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
     const int k0 = kt * BK;
     const bool kok = k0 + akq < p.K;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 2 * MI; ++i) {
       const int m = m0 + ar + 32 * i;
       ra[i] = (kok && m < p.M) ? ld4(p.A + (size_t)m * p.lda + k0 + akq) : zero4();
     }
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
     const int m0 = mt * BM;
     const bool kok = kt * BK + akq < p.K;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 2 * MI; ++i) {
       const int r = ar + 32 * i;
       float4 v = ra[i];
       // zero rows/cols stay exactly zero (padding of the M and K tails)
@@ -126,9 +126,9 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
     }
   };
 
-  f32x4 acc[2][NT];
+  f32x4 acc[MI][NT];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 st_s[STATS ? NT : 1], st_q[STATS ? NT : 1];
@@ -145,10 +145,10 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int g = 0; g < BK / 16; ++g) {
       const int kc = g * 16 + q * 4;
-      float4 a[2];
+      float4 a[MI];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-        a[mi] = *reinterpret_cast<const float4*>(&As[(w * 32 + mi * 16 + l15) * APITCH + kc]);
+      for (int mi = 0; mi < MI; ++mi)
+        a[mi] = *reinterpret_cast<const float4*>(&As[(w * 16 * MI + mi * 16 + l15) * APITCH + kc]);
 #pragma unroll
       for (int ni = 0; ni < NT; ++ni) {
         float b[4];
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
           b[0] = bv.x; b[1] = bv.y; b[2] = bv.z; b[3] = bv.w;
         }
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[0], a[mi].x, acc[mi][ni], 0, 0, 0);
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[1], a[mi].y, acc[mi][ni], 0, 0, 0);
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[2], a[mi].z, acc[mi][ni], 0, 0, 0);
@@ -179,8 +179,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
         float4 bias4 = zero4();
         if (p.bias && n < p.N) bias4 = ld4(p.bias + n);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-          const int m = m0 + w * 32 + mi * 16 + l15;
+        for (int mi = 0; mi < MI; ++mi) {
+          const int m = m0 + w * 16 * MI + mi * 16 + l15;
           f32x4 v = acc[mi][ni];
           acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
           if (m < p.M && n < p.N) {
@@ -234,19 +234,27 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
 static int pick_nt(int N) {
   const int ntiles = ceil_div(N, 16);
   static const int cand[] = {8, 6, 5, 4, 3, 2, 1};
-  int best = 1, best_waste = 1 << 30;
+  int best = 1;
+  float best_cost = 1e30f;
   for (int c : cand) {
-    int waste = ceil_div(ntiles, c) * c - ntiles;
-    if (waste < best_waste) { best = c; best_waste = waste; }
+    // MFMA columns actually computed, plus the A-tile re-reads/staging that every column block repeats
+    const float cost = (float)(ceil_div(ntiles, c) * c) * (1.f + 1.5f / (float)c);
+    if (cost < best_cost) { best = c; best_cost = cost; }
   }
   return best;
 }
 
-static void gemm_grid(int M, int N, int nt, int* gx, int* gy, int* num_m_tiles) {
-  const int mt = ceil_div(M, BM);
+// grid: persistent workgroups over M tiles.  Small maps (M = N*33*33) give only ~137 tiles of 128 rows,
+// which quantises badly over 256 CUs; 64-row tiles (MI = 1) are used whenever 128-row tiles would leave
+// the chip under two rounds of work.
+static void gemm_grid(int M, int N, int nt, int* gx, int* gy, int* num_m_tiles, int* mi_out) {
   const int nb = ceil_div(N, 16 * nt);
-  // resident workgroups per CU allowed by the accumulator/statistics registers of this NT
-  const int per_cu = nt <= 1 ? 6 : (nt == 2 ? 5 : (nt <= 4 ? 3 : 2));
+  int mi = 2;
+  if ((long long)ceil_div(M, 128) * nb < 4LL * DL3P_NUM_CUS) mi = 1;
+  const int bm = 64 * mi;
+  const int mt = ceil_div(M, bm);
+  int per_cu = nt <= 1 ? 6 : (nt == 2 ? 5 : (nt <= 4 ? 3 : 2));
+  if (mi == 1 && per_cu < 3) per_cu = 3;
   int gx_max = (DL3P_NUM_CUS * per_cu) / nb;
   if (gx_max < 8) gx_max = 8;
   if (gx_max > DL3P_MAX_STAT_ROWS) gx_max = DL3P_MAX_STAT_ROWS;
@@ -255,21 +263,27 @@ static void gemm_grid(int M, int N, int nt, int* gx, int* gy, int* num_m_tiles) 
     const int per = ceil_div(mt, gx_max);
     g = ceil_div(mt, per);
   }
-  *gx = g; *gy = nb; *num_m_tiles = mt;
+  *gx = g; *gy = nb; *num_m_tiles = mt; *mi_out = mi;
+}
+
+template <bool B_KN, bool STATS, int MI>
+static void launch_gemm_mi(const GemmParams& p, int nt, dim3 grid, hipStream_t st) {
+  dim3 block(256);
+  switch (nt) {
+    case 1: hipLaunchKernelGGL((pw_gemm_kernel<1, B_KN, STATS, MI>), grid, block, 0, st, p); break;
+    case 2: hipLaunchKernelGGL((pw_gemm_kernel<2, B_KN, STATS, MI>), grid, block, 0, st, p); break;
+    case 3: hipLaunchKernelGGL((pw_gemm_kernel<3, B_KN, STATS, MI>), grid, block, 0, st, p); break;
+    case 4: hipLaunchKernelGGL((pw_gemm_kernel<4, B_KN, STATS, MI>), grid, block, 0, st, p); break;
+    case 5: hipLaunchKernelGGL((pw_gemm_kernel<5, B_KN, STATS, MI>), grid, block, 0, st, p); break;
+    case 6: hipLaunchKernelGGL((pw_gemm_kernel<6, B_KN, STATS, MI>), grid, block, 0, st, p); break;
+    default: hipLaunchKernelGGL((pw_gemm_kernel<8, B_KN, STATS, MI>), grid, block, 0, st, p); break;
+  }
 }
 
 template <bool B_KN, bool STATS>
-static void launch_gemm(const GemmParams& p, int nt, dim3 grid, hipStream_t st) {
-  dim3 block(256);
-  switch (nt) {
-    case 1: hipLaunchKernelGGL((pw_gemm_kernel<1, B_KN, STATS>), grid, block, 0, st, p); break;
-    case 2: hipLaunchKernelGGL((pw_gemm_kernel<2, B_KN, STATS>), grid, block, 0, st, p); break;
-    case 3: hipLaunchKernelGGL((pw_gemm_kernel<3, B_KN, STATS>), grid, block, 0, st, p); break;
-    case 4: hipLaunchKernelGGL((pw_gemm_kernel<4, B_KN, STATS>), grid, block, 0, st, p); break;
-    case 5: hipLaunchKernelGGL((pw_gemm_kernel<5, B_KN, STATS>), grid, block, 0, st, p); break;
-    case 6: hipLaunchKernelGGL((pw_gemm_kernel<6, B_KN, STATS>), grid, block, 0, st, p); break;
-    default: hipLaunchKernelGGL((pw_gemm_kernel<8, B_KN, STATS>), grid, block, 0, st, p); break;
-  }
+static void launch_gemm(const GemmParams& p, int nt, int mi, dim3 grid, hipStream_t st) {
+  if (mi == 1) launch_gemm_mi<B_KN, STATS, 1>(p, nt, grid, st);
+  else launch_gemm_mi<B_KN, STATS, 2>(p, nt, grid, st);
 }
 
 static int check_mat(const char* fn, const void* ptr, int ld, int cols) {
@@ -292,12 +306,12 @@ extern "C" int dl3p_pwconv_fwd(const float* x, int ldx, const float* in_scale, c
   p.B = w; p.ldb = N; p.bias = bias; p.Y = y; p.ldy = ldy; p.partials = stat_partials;
   p.M = M; p.K = K; p.N = N;
   const int nt = pick_nt(N);
-  int gx, gy;
-  gemm_grid(M, N, nt, &gx, &gy, &p.num_m_tiles);
+  int gx, gy, mi;
+  gemm_grid(M, N, nt, &gx, &gy, &p.num_m_tiles, &mi);
   if (rows_out) *rows_out = gx;
   hipStream_t st = (hipStream_t)stream;
-  if (stat_partials) launch_gemm<true, true>(p, nt, dim3(gx, gy), st);
-  else launch_gemm<true, false>(p, nt, dim3(gx, gy), st);
+  if (stat_partials) launch_gemm<true, true>(p, nt, mi, dim3(gx, gy), st);
+  else launch_gemm<true, false>(p, nt, mi, dim3(gx, gy), st);
   DL3P_CHECK_LAUNCH("dl3p_pwconv_fwd");
   return DL3P_OK;
 }
@@ -315,9 +329,9 @@ extern "C" int dl3p_pwconv_bwd_data(const float* dy, int lddy, const float* w, f
   p.Y = gx; p.ldy = ldgx; p.accumulate = accumulate;
   p.M = M; p.K = N; p.N = K;    // reduce over N, produce K columns
   const int nt = pick_nt(K);
-  int gxn, gy;
-  gemm_grid(M, K, nt, &gxn, &gy, &p.num_m_tiles);
-  launch_gemm<false, false>(p, nt, dim3(gxn, gy), (hipStream_t)stream);
+  int gxn, gy, mi;
+  gemm_grid(M, K, nt, &gxn, &gy, &p.num_m_tiles, &mi);
+  launch_gemm<false, false>(p, nt, mi, dim3(gxn, gy), (hipStream_t)stream);
   DL3P_CHECK_LAUNCH("dl3p_pwconv_bwd_data");
   return DL3P_OK;
 }
