@@ -1,0 +1,123 @@
+"""Known answers the reference does pin (README.md:312-317 FLOPs/params table) for BOTH
+the oracle graphs and the product graphs, the get_deeplabv3p_model() surface, and the C ABI."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import load_pkg, ROOT
+
+# trainable / non-trainable parameter counts with 21 classes
+KNOWN = {'mobilenetv2_lite': (2113557, 33088, 54), 'mobilenetv2': (2719813, 38784, 65),
+         'xception': (41055413, 202800, 146), 'mobilenetv3large': (3514453, 28752, 59)}
+
+
+@pytest.mark.parametrize('mt', ['mobilenetv2_lite', 'mobilenetv2', 'mobilenetv3large'])
+def test_oracle_param_counts(mt):
+    from oracle.np_net import OracleModel
+    m = OracleModel(mt, 21, (33, 33), 16)
+    tr, ntr, nbn = KNOWN[mt]
+    assert m.net.n_params(True) == tr
+    assert m.net.n_params(False) == ntr
+    assert sum(1 for n in m.net.order if n.endswith('/gamma')) == nbn
+
+
+def _product_models():
+    return sorted(load_pkg().deeplab_model_map.keys())
+
+
+@pytest.mark.parametrize('mt', ['mobilenetv2_lite', 'mobilenetv2', 'xception', 'mobilenetv3large'])
+def test_product_param_counts_and_names_match_oracle(mt):
+    pkg = load_pkg()
+    if mt not in pkg.deeplab_model_map:
+        pytest.skip(mt + ' not built yet')
+    m = pkg.get_deeplabv3p_model(mt, 21, (513, 513), 16)
+    tr, ntr, nbn = KNOWN[mt]
+    ps = m.graph.all_params()
+    assert sum(p.size for p in ps if p.weight_trainable) == tr
+    assert sum(p.size for p in ps if not p.weight_trainable) == ntr
+    assert sum(1 for l in m.layers if l.kind == 'BatchNormalization') == nbn
+    if mt == 'xception':
+        return   # the oracle Xception takes ~20 s to initialise; names are covered by the GPU parity test
+    from oracle.np_net import OracleModel
+    o = OracleModel(mt, 21, (33, 33), 16)
+    assert [p.name for p in ps] == o.net.order            # same Keras weight order
+    for p in ps:
+        assert p.shape == o.net.params[p.name].shape, p.name
+    # 19 classes: subtract 2*257
+    m19 = pkg.get_deeplabv3p_model(mt, 19, (513, 513), 16)
+    assert m19.count_params() == tr + ntr - 514
+
+
+def test_factory_surface():
+    pkg = load_pkg()
+    with pytest.raises(ValueError, match='This model type is not supported now'):
+        pkg.get_deeplabv3p_model('resnet101', 21, (513, 513), 16)
+    with pytest.raises(ValueError):
+        pkg.get_deeplabv3p_model('mobilenetv2', 21, (513, 513), 7)
+    m = pkg.get_deeplabv3p_model('mobilenetv2', 21, (513, 513), 16, training=True)
+    assert m.output_shape == (None, 513 * 513, 21) and m.input_shape == (None, 513, 513, 3)
+    assert m.layers[-1].name == 'pred_mask' and m.get_layer('conv_upsample').count_params() == 256 * 21 + 21
+    mi = pkg.get_deeplabv3p_model('mobilenetv2', 21, (513, 513), 16, training=False)
+    assert mi.output_shape == (None, 513, 513, 21)
+    # freeze levels (model.py:106-115)
+    m1 = pkg.get_deeplabv3p_model('mobilenetv2_lite', 21, (513, 513), 16, freeze_level=1)
+    assert not m1.get_layer('expanded_conv_16_project').trainable and m1.get_layer('aspp0').trainable
+    m2 = pkg.get_deeplabv3p_model('mobilenetv2_lite', 21, (513, 513), 16, freeze_level=2)
+    assert not m2.get_layer('concat_projection').trainable and m2.get_layer('conv_upsample').trainable
+    lines = []
+    m.summary(print_fn=lines.append)
+    assert any('Total params: 2,758,597' in l for l in lines)
+    # the reference's import path works
+    import deeplabv3p.model as shim
+    assert shim.get_deeplabv3p_model is pkg.get_deeplabv3p_model
+
+
+def test_no_cpu_fallback():
+    """the product path must fail loudly without the HIP device"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    pkg = load_pkg()
+    m = pkg.get_deeplabv3p_model('mobilenetv2_lite', 21, (65, 65), 16)
+    m.compile()
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m.train_on_batch(np.zeros((1, 65, 65, 3), np.float32), np.zeros((1, 65 * 65, 1), np.float32))
+    ops = load_pkg('ops')
+    with pytest.raises(ops.Dl3pError):
+        ops.pwconv_fwd(torch.zeros((4, 8)), torch.zeros((8, 8)))
+
+
+def test_weights_roundtrip(tmp_path):
+    pkg = load_pkg()
+    a = pkg.get_deeplabv3p_model('mobilenetv2_lite', 21, (65, 65), 16, seed=1)
+    b = pkg.get_deeplabv3p_model('mobilenetv2_lite', 21, (65, 65), 16, seed=2)
+    path = str(tmp_path / 'w.npz')
+    a.save(path)
+    b.load_weights(path)
+    for x, y in zip(a.get_weights(), b.get_weights()):
+        np.testing.assert_array_equal(x, y)
+    c = pkg.get_deeplabv3p_model('mobilenetv2_lite', 21, (65, 65), 16, weights_path=path, seed=3)
+    np.testing.assert_array_equal(c.get_weights()[0], a.get_weights()[0])
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """libdl3p.so loads and exports exactly what include/dl3p.h declares (no compute without a GPU)"""
+    libm = load_pkg('_lib')
+    protos = libm.parse_header()
+    assert len(protos) >= 30
+    assert os.path.exists(libm.LIBPATH), 'build libdl3p.so first: python __graft_entry__.py'
+    cdll = ctypes.CDLL(libm.LIBPATH)
+    for name in protos:
+        assert hasattr(cdll, name), name
+    out = subprocess.run(['nm', '-D', '--defined-only', libm.LIBPATH], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if ' T dl3p_' in l}
+    assert exported == set(protos), (exported ^ set(protos))
+    L = libm.lib()
+    assert L.version() == 100 and L.device_cus() == 256
+    # argument validation happens before any launch -> callable without a device
+    with pytest.raises(libm.Dl3pError, match='multiple of 4'):
+        L.dwconv2d_fwd(16, 6, None, None, 0, 16, 16, 6, None, ctypes.byref(ctypes.c_int()), 1, 4, 4, 6, 3, 1, 1, 1, 1,
+                       4, 4, None)
