@@ -51,6 +51,11 @@ class Net:
         # within rounding distance of the kink.  Parity tests inject the branch pattern of the
         # implementation under test so that the comparison is well-conditioned.
         self.act_derivs = {}
+        # optional SyncBatchNorm: (all_reduce_sum(ndarray) -> ndarray, world_size).  Statistics are
+        # summed over ranks in forward (sum x, sum x^2, count) and backward (sum dy, sum dy*xhat); the
+        # parameter gradients stay local and are averaged with all other gradients (README.md:38,
+        # layers.py:63-70; the protocol the HIP executor implements with RCCL).
+        self.sync = None
 
     # ---- parameters -------------------------------------------------------------------
     def param(self, name, shape, init, trainable=True, l2=0.0):
@@ -130,6 +135,8 @@ class Net:
         beta = self.param(name + '/beta', (c,), np.zeros)
         mm = self.param(name + '/moving_mean', (c,), np.zeros, trainable=False)
         mv = self.param(name + '/moving_variance', (c,), np.ones, trainable=False)
+        if self.training and self.layer_is_trainable(name) and self.sync is not None:
+            return self._sync_bn(x, name, gamma, beta, mm, mv, eps, momentum)
         if self.training and self.layer_is_trainable(name):
             yv, cache, (bm, bv) = O.bn_train_fwd(x.v, gamma, beta, eps)
             self.moving_updates[name + '/moving_mean'] = O.bn_moving_update(mm, bm, momentum)
@@ -156,6 +163,34 @@ class Net:
                 self.acc_grad(name + '/gamma', (y.g * xh).reshape(-1, c).sum(0))
                 self.acc_grad(name + '/beta', y.g.reshape(-1, c).sum(0))
                 x.acc(y.g * scale)
+        self.tape.append(bwd)
+        return y
+
+    def _sync_bn(self, x, name, gamma, beta, mm, mv, eps, momentum):
+        allreduce, world = self.sync
+        c = x.v.shape[-1]
+        x2 = x.v.reshape(-1, c)
+        m_local = x2.shape[0]
+        sums = allreduce(np.concatenate([x2.sum(0), (x2 ** 2).sum(0)]))
+        m = m_local * world
+        mean = sums[:c] / m
+        var = np.maximum(sums[c:] / m - mean ** 2, 0.0)
+        invstd = 1.0 / np.sqrt(var + eps)
+        xhat = (x.v - mean) * invstd
+        y = Var(xhat * gamma + beta)
+        y.tag = name
+        self.moving_updates[name + '/moving_mean'] = O.bn_moving_update(mm, mean, momentum)
+        self.moving_updates[name + '/moving_variance'] = O.bn_moving_update(mv, var * (m / max(m - 1, 1)), momentum)
+
+        def bwd():
+            if y.g is None:
+                return
+            g2 = y.g.reshape(-1, c)
+            sdy, sdyx = g2.sum(0), (g2 * xhat.reshape(-1, c)).sum(0)
+            self.acc_grad(name + '/gamma', sdyx)
+            self.acc_grad(name + '/beta', sdy)
+            tot = allreduce(np.concatenate([sdy, sdyx]))
+            x.acc((gamma * invstd) * (y.g - tot[:c] / m - xhat * (tot[c:] / m)))
         self.tape.append(bwd)
         return y
 
