@@ -78,9 +78,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (there is no CPU fallback for the HIP path)')
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get('DL3P_FORCE_DIST'):
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     pkg = importlib.import_module(PKG)
     H = W = args.size
@@ -104,7 +107,8 @@ def main():
 
     # roofline probe: the rate-18 depthwise launch stays outside the graph segments, between two events
     probe_name = 'aspp3_depthwise' if any(getattr(o, 'name', '') == 'aspp3_depthwise' for o in model.graph.ops) else None
-    probe = ex.install_probe(probe_name) if probe_name else None
+    # (N == 1 only: with collectives captured into the graph the forward must stay one segment)
+    probe = ex.install_probe(probe_name) if (probe_name and world == 1) else None
 
     def barrier():
         if world > 1:
@@ -158,7 +162,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

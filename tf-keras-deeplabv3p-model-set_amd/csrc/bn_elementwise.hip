@@ -72,18 +72,34 @@ extern "C" int dl3p_reduce_rows(const float* partials, int rows, size_t n, float
   return dl3p_reduce_rows_impl(partials, rows, n, out, accumulate, (hipStream_t)stream);
 }
 
-// sums[i] = sum_r partials[r][i] in double (SyncBN: these sums are all-reduced across ranks)
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int rows, int n,
-                                                              double* __restrict__ sums) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  double acc = 0.0;
-  for (int r = 0; r < rows; ++r) acc += (double)partials[(size_t)r * n + i];
-  sums[i] = acc;
+// sums[i] = sum_r partials[r][i] in double (SyncBN: these sums are all-reduced across ranks).
+// 16 elements x 64 row lanes per workgroup, two rows in flight per thread.
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partials, int rows, int n,
+                                                               double* __restrict__ sums) {
+  __shared__ double sm[64][16];
+  const int ex = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + ex;
+  double a0 = 0.0, a1 = 0.0;
+  if (i < n) {
+    int r = ry;
+    for (; r + 64 < rows; r += 128) {
+      a0 += (double)partials[(size_t)r * n + i];
+      a1 += (double)partials[(size_t)(r + 64) * n + i];
+    }
+    if (r < rows) a0 += (double)partials[(size_t)r * n + i];
+  }
+  sm[ry][ex] = a0 + a1;
+  __syncthreads();
+  if (ry == 0 && i < n) {
+    double acc = 0.0;
+#pragma unroll 8
+    for (int q = 0; q < 64; ++q) acc += sm[q][ex];
+    sums[i] = acc;
+  }
 }
 extern "C" int dl3p_bn_reduce_partials(const float* partials, int rows, int C2, double* sums, void* stream) {
   DL3P_CHECK_ARG(partials && sums && rows > 0 && C2 > 0, "dl3p_bn_reduce_partials: bad arguments");
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((C2 + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, rows,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((C2 + 15) / 16), dim3(1024), 0, (hipStream_t)stream, partials, rows,
                      C2, sums);
   DL3P_CHECK_LAUNCH("dl3p_bn_reduce_partials");
   return DL3P_OK;

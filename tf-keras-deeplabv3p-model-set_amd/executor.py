@@ -12,6 +12,7 @@ between graph segments.
 PyTorch only provides memory, streams, graphs and torch.distributed here.
 """
 import ctypes
+import os
 import zlib
 import numpy as np
 import torch
@@ -119,6 +120,7 @@ class Plan:
             fn(*args, torch.cuda.current_stream().cuda_stream)
             e1.record()
             probe.events.append((e0, e1))
+        timed.no_capture = True
         self.items[i] = (None, timed)
         self.segments = None
 
@@ -141,8 +143,30 @@ class Plan:
             else:
                 fn(*args, st)
 
-    def capture(self):
-        """turn each run of kernel launches into one hipGraph"""
+    def capture(self, collectives_in_graph=True):
+        """turn the plan into hipGraphs.  With collectives_in_graph the RCCL calls (SyncBatchNorm
+        statistics, gradient buckets on the side stream) are captured INTO the graph, so a whole
+        forward / backward is one graph launch and the ~130 tiny all-reduces of a step cost GPU time
+        only (no host round trip each).  If the runtime refuses to capture them, fall back to one graph
+        per run of kernels with the collectives issued eagerly in between."""
+        has_py = any(it[0] is None for it in self.items)
+        if has_py and collectives_in_graph and not any(getattr(it[1], 'no_capture', False) for it in self.items if it[0] is None):
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                    st = torch.cuda.current_stream().cuda_stream
+                    for fn, args in self.items:
+                        if fn is None:
+                            args()
+                        else:
+                            fn(*args, st)
+                self.segments = [g]
+                self.single_graph = True
+                return self
+            except Exception as e:   # noqa: BLE001 - any capture failure -> segmented replay
+                import warnings
+                warnings.warn('collectives could not be captured into the hipGraph (%s); using segments' % (e,))
+                torch.cuda.synchronize()
         segs, cur = [], []
         for it in self.items:
             if it[0] is None:
@@ -160,7 +184,8 @@ class Plan:
                 out.append(seg)
                 continue
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: RCCL's watchdog thread may touch the runtime while this thread captures
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
                 st = torch.cuda.current_stream().cuda_stream
                 for fn, args in seg:
                     fn(*args, st)
@@ -193,7 +218,9 @@ class Executor:
         self.g, self.head, self.store = graph, head, store
         self.N, self.training, self.C = batch, training, num_classes
         self.ignore_index = ignore_index
-        self.dist = dist if (dist is not None and dist.world_size > 1) else None
+        # DL3P_FORCE_DIST=1 exercises the collective path on a single rank (plumbing test)
+        force = bool(os.environ.get('DL3P_FORCE_DIST'))
+        self.dist = dist if (dist is not None and (dist.world_size > 1 or force)) else None
         self.sync_bn = self.dist is not None and self.dist.sync_bn
         self.seed, self.momentum = seed, momentum
         self.dev = store.device
@@ -414,8 +441,14 @@ class Executor:
             P.k(L.resize_bilinear_bwd, self.dlogits_big.data_ptr(), self.cpad, self.tptr(zt, True), zt.ld,
                 self._acc(zt), N, zt.H, zt.W, zt.C, self.H, self.W)
         ws, wsb = self.workspace.data_ptr(), self.workspace.numel() * 4
+        # data parallel: the flat gradient buffer is produced back to front; each finished bucket is
+        # all-reduced on the side stream while the remaining backward kernels run
+        bucket_edges = self._bucket_edges() if self.dist is not None else {}
         for op in reversed(self.g.ops):
             k = op.kind
+            if op in bucket_edges:
+                lo, hi = bucket_edges[op]
+                P.py(lambda lo=lo, hi=hi: self.dist.all_reduce_async(G[lo:hi]))
             out = getattr(op, 'out', None)
             if k == 'bn':
                 if op.z.requires_grad:
@@ -477,7 +510,30 @@ class Executor:
                     N, xt.H, xt.W, xt.C, out.H, out.W)
             else:
                 raise NotImplementedError(k)
+        if self.dist is not None:
+            P.py(lambda hi=self._first_bucket_hi: self.dist.all_reduce_async(G[0:hi]))
         return P
+
+    def _bucket_edges(self):
+        """{op: (lo, hi)}: when backward reaches `op` (going back to front), the gradients of every
+        parameter created after it are final -> all-reduce that slice of the flat buffer"""
+        st = self.store
+        layer_lo = {}
+        for p in st.params:
+            layer_lo.setdefault(p.layer, st.offset[p])
+        ops = [o for o in self.g.ops if getattr(o, 'layer', None) in layer_lo]
+        n = max(1, self.dist.n_buckets)
+        target = st.total / n
+        edges, hi = {}, st.total
+        for op in reversed(ops):
+            lo = layer_lo[op.layer]
+            # `op` itself is still to be processed: the finished range is everything above the end of its layer
+            done_lo = lo + sum((p.dev_size + 3) // 4 * 4 for p in op.layer.params)
+            if hi - done_lo >= target and len(edges) < n - 1:
+                edges[op] = (done_lo, hi)
+                hi = done_lo
+        self._first_bucket_hi = hi
+        return edges
 
     def _bn_backward(self, P, op):
         bn, L, st, N = op.bn, self.L, self.store, self.N
@@ -514,7 +570,7 @@ class Executor:
         P, L, st = Plan(), self.L, self.store
         scale = 1.0
         if self.dist is not None:
-            P.py(lambda: self.dist.all_reduce(st.G))
+            P.py(self.dist.wait_all)          # gradient buckets were all-reduced beside backward
             scale = 1.0 / self.dist.world_size
         P.k(L.sgd_momentum, st.P.data_ptr(), st.V.data_ptr(), st.G.data_ptr(), st.total, self.lr.data_ptr(),
             float(self.momentum), 0.0, scale, st.l2.data_ptr(), st.lr_scale.data_ptr())

@@ -91,20 +91,43 @@ class SparseCategoricalCrossEntropy(object):
 
 
 class DistContext:
-    """one process per GPU; RCCL (torch.distributed backend 'nccl') over xGMI"""
+    """one process per GPU; collectives are RCCL (torch.distributed backend 'nccl') over xGMI.
+    Gradient buckets are all-reduced on a side HIP stream so that they overlap the rest of backward."""
 
-    def __init__(self, sync_bn=True):
+    def __init__(self, sync_bn=True, n_buckets=4):
         import torch.distributed as dist
         self.dist = dist
         self.world_size = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.sync_bn = sync_bn
+        self.n_buckets = n_buckets
+        self._comm_stream = None
+        self._pending = []
 
     def all_reduce(self, t):
+        """blocking (stream-ordered) sum all-reduce: SyncBatchNorm statistics"""
         self.dist.all_reduce(t)
 
     def broadcast(self, t, src=0):
         self.dist.broadcast(t, src)
+
+    def all_reduce_async(self, t):
+        """sum all-reduce of a gradient bucket, ordered after everything already queued on the
+        compute stream but running beside what is queued later"""
+        import torch
+        if not t.is_cuda:
+            self.dist.all_reduce(t)
+            return
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream()
+        self._comm_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._comm_stream):
+            self.dist.all_reduce(t)
+
+    def wait_all(self):
+        import torch
+        if self._comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
 
 
 class DeeplabModel:
@@ -167,7 +190,8 @@ class DeeplabModel:
             raise ValueError('sample weights (adaptive mode) are not on the hot path')
         if distributed is None:
             import torch.distributed as dist
-            distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            distributed = dist.is_available() and dist.is_initialized() and (
+                dist.get_world_size() > 1 or bool(os.environ.get('DL3P_FORCE_DIST')))
         self.dist = DistContext(sync_bn) if distributed else None
         self._exec = {}
         if self._store is not None:
