@@ -1,0 +1,32 @@
+#!/bin/bash
+# run on the GPU box from the repo root: bench line + rocprofv3 kernel stats + HBM counters (separate passes)
+set -x
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+R=${1:-r01}
+O=gpurun_out/profiles_$R
+mkdir -p $O
+python3 bench.py > $O/bench_$R.log 2>&1
+grep '"metric"' $O/bench_$R.log > $O/bench_$R.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/kt.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $O/pmc_write.log 2>&1
+cp $O/kt/*/*kernel_stats.csv $O/${R}_kernel_stats.csv
+python3 scripts/prof_summary.py $O/kt 14 40 > $O/${R}_kernel_summary.txt
+python3 - <<PY
+import csv, glob
+out = open('$O/${R}_hbm_counters_dw.csv', 'w')
+out.write('counter,kernel,grid,calls,mean_value_KB\n')
+for tag in ('pmc_fetch', 'pmc_write'):
+    f = glob.glob('$O/%s/**/*counter_collection.csv' % tag, recursive=True)
+    if not f: continue
+    agg = {}
+    for r in csv.DictReader(open(f[0])):
+        if 'dw_' not in r['Kernel_Name']: continue
+        k = (r['Counter_Name'], r['Kernel_Name'][:60], r['Grid_Size'])
+        agg.setdefault(k, []).append(float(r['Counter_Value']))
+    for (c, kn, g), v in sorted(agg.items()):
+        out.write('%s,"%s",%s,%d,%.1f\n' % (c, kn, g, len(v), sum(v) / len(v)))
+out.close()
+PY
+rm -rf $O/kt $O/pmc_fetch $O/pmc_write
+ls -la $O
