@@ -205,6 +205,14 @@ int dl3p_reduce_rows(const float* partials, int rows, size_t n, float* out, int 
 int dl3p_sgd_momentum(float* w, float* v, const float* g, size_t n, const float* lr_dev, float momentum,
                       float l2, float grad_scale, const float* l2_elem, const float* lr_scale_elem, void* stream);
 
+/* ---------------------------------------------------------------- measurement hook
+ * dl3p_probe_arm(i): the NEXT depthwise-forward launch of the calling thread is issued with a pair of HIP
+ * events (hipExtLaunchKernelGGL start/stop events on the launch stream) stored in slot i (0 <= i < 4096);
+ * dl3p_probe_read(i, &ms) waits for slot i's stop event and returns the kernel's duration in ms.
+ * Used by bench.py to time the rate-18 atrous kernel inside the timed steps (roofline). */
+int dl3p_probe_arm(int slot);
+int dl3p_probe_read(int slot, float* ms);
+
 #ifdef __cplusplus
 }
 #endif

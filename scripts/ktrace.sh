@@ -1,0 +1,18 @@
+#!/bin/bash
+# usage: ktrace.sh <kernel substring> -- <python args> : mean kernel duration (us) from rocprofv3 kernel trace
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+K="$1"; shift 2
+rm -rf gpurun_out/kt_tmp
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/kt_tmp -- python3 "$@" > /dev/null 2>&1
+python3 - "$K" <<'PY'
+import csv, glob, sys, collections
+k = sys.argv[1]
+f = glob.glob('gpurun_out/kt_tmp/**/*kernel_trace.csv', recursive=True)[0]
+d = collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    if k in r['Kernel_Name']:
+        d[r['Kernel_Name'][:50]].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+for n, v in d.items():
+    v2 = sorted(v[len(v)//4:])
+    print('%-50s n=%d mean %.2f us  median %.2f  min %.2f' % (n, len(v), sum(v2)/len(v2), v2[len(v2)//2], v2[0]))
+PY

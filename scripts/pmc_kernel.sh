@@ -1,0 +1,18 @@
+#!/bin/bash
+# usage: pmc_kernel.sh "<counters>" <kernel substring> -- <python args>
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+C="$1"; K="$2"; shift 3
+rm -rf gpurun_out/pmc_tmp
+rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/pmc_tmp -- python3 "$@" > /dev/null 2>&1
+python3 - "$K" <<'PY'
+import csv, glob, sys, collections
+k = sys.argv[1]
+f = glob.glob('gpurun_out/pmc_tmp/**/*counter_collection.csv', recursive=True)[0]
+agg = collections.defaultdict(list); dur = []
+for r in csv.DictReader(open(f)):
+    if k in r['Kernel_Name']:
+        agg[r['Counter_Name']].append(float(r['Counter_Value']))
+for c, v in agg.items():
+    v = v[len(v)//2:]
+    print('%-28s mean %.4g (n=%d)' % (c, sum(v)/len(v), len(v)))
+PY

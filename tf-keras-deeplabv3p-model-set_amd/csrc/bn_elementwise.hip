@@ -19,6 +19,31 @@ extern "C" const char* dl3p_last_error_string(void) { return g_err; }
 extern "C" int dl3p_version(void) { return DL3P_VERSION; }
 extern "C" int dl3p_device_cus(void) { return DL3P_NUM_CUS; }
 
+// ------------------------------------------------------------------------------ measurement hook
+thread_local hipEvent_t dl3p_probe_start = nullptr, dl3p_probe_stop = nullptr;
+#define DL3P_PROBE_SLOTS 4096
+static hipEvent_t g_probe_ev[DL3P_PROBE_SLOTS][2];
+extern "C" int dl3p_probe_arm(int slot) {
+  DL3P_CHECK_ARG(slot >= 0 && slot < DL3P_PROBE_SLOTS, "dl3p_probe_arm: slot %d out of range", slot);
+  for (int i = 0; i < 2; ++i)
+    if (!g_probe_ev[slot][i] && hipEventCreate(&g_probe_ev[slot][i]) != hipSuccess) {
+      dl3p_set_error("dl3p_probe_arm: hipEventCreate failed");
+      return DL3P_ELAUNCH;
+    }
+  dl3p_probe_start = g_probe_ev[slot][0];
+  dl3p_probe_stop = g_probe_ev[slot][1];
+  return DL3P_OK;
+}
+extern "C" int dl3p_probe_read(int slot, float* ms) {
+  DL3P_CHECK_ARG(slot >= 0 && slot < DL3P_PROBE_SLOTS && ms && g_probe_ev[slot][0], "dl3p_probe_read: slot %d not armed", slot);
+  if (hipEventSynchronize(g_probe_ev[slot][1]) != hipSuccess ||
+      hipEventElapsedTime(ms, g_probe_ev[slot][0], g_probe_ev[slot][1]) != hipSuccess) {
+    dl3p_set_error("dl3p_probe_read: event query failed (was a depthwise forward launched after arming?)");
+    return DL3P_ELAUNCH;
+  }
+  return DL3P_OK;
+}
+
 // ------------------------------------------------------------------------------ row reducer
 // out[i] (+)= sum_r partials[r][i]; double accumulation in a fixed order (deterministic)
 // EL consecutive elements x RL row lanes per workgroup; each thread keeps 4 independent double

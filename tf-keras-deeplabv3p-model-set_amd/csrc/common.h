@@ -1,6 +1,7 @@
 // Shared device/host helpers for libdl3p (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -118,10 +119,10 @@ static inline void pick_lanes(int C, int* c4s, int* px, int* nslab) {
 
 // workgroups per channel slab (a multiple of 8 = one share per XCD), ~8 workgroups per CU overall,
 // never more than DL3P_MAX_STAT_ROWS (each workgroup emits one partial row)
-static inline int pick_nbx(long long total, int px, int nslab) {
+static inline int pick_nbx(long long total, int px, int nslab, int per_cu = 8) {
   long long chunk = ceil_div_ll(total, DL3P_NUM_XCDS);
   long long need = ceil_div_ll(chunk, px);
-  long long target = (DL3P_NUM_CUS * 8 / nslab) / DL3P_NUM_XCDS;
+  long long target = (DL3P_NUM_CUS * per_cu / nslab) / DL3P_NUM_XCDS;
   if (target < 1) target = 1;
   long long nbj = need < target ? need : target;
   if (nbj < 1) nbj = 1;
@@ -154,3 +155,17 @@ __device__ __forceinline__ void block_reduce_store(const float4 (&vals)[NV], boo
 int dl3p_reduce_rows_impl(const float* partials, int rows, size_t n, float* out, int accumulate, hipStream_t st);
 int dl3p_reduce_rows_strided_impl(const float* partials, int rows, size_t row_stride, size_t n, float* out,
                                   int accumulate, hipStream_t st);
+
+// ---------------------------------------------------------------------------------- timed launches
+// dl3p_probe_arm() leaves a (start, stop) event pair for the next launch that goes through dl3p_launch
+extern thread_local hipEvent_t dl3p_probe_start, dl3p_probe_stop;
+template <typename K, typename... A>
+static inline void dl3p_launch(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t st, A... args) {
+  if (dl3p_probe_start) {
+    hipExtLaunchKernelGGL(kernel, grid, block, shmem, st, dl3p_probe_start, dl3p_probe_stop, 0, args...);
+    dl3p_probe_start = nullptr;
+    dl3p_probe_stop = nullptr;
+  } else {
+    hipLaunchKernelGGL(kernel, grid, block, shmem, st, args...);
+  }
+}

@@ -13,6 +13,7 @@
 // The BN+activation of the producing layer is applied on load (prologue): zero padding is in
 // activation space, so out-of-range taps contribute exactly 0.
 #include "common.h"
+#include <stdlib.h>
 
 struct DwParams {
   const float* x; int ldx;
@@ -22,7 +23,7 @@ struct DwParams {
   const float* dy; int lddy;   // bwd_weight only
   float* partials;
   int N, H, W, C, Ho, Wo, stride, rate, pad_t, pad_l;
-  int c4s, px, nslab, nbx, spr, th, nbands;
+  int c4s, px, nslab, nbx, spr, th, nbands, ks;
   long long total;
   int flip, accumulate;
 };
@@ -371,6 +372,128 @@ __global__ __launch_bounds__(256) void dw_fwd_gather(DwParams p) {
   if (p.partials) block_reduce_store<2>(s1, active, pl, cl, p.c4s, p.px, cbase4, p.C, p.partials + (size_t)bx * 2 * p.C);
 }
 
+// ------------------------------------------------------------------------------ forward, largest atrous rate
+// When 2*rate >= max(H, W) (ASPP rate 18 on the 33x33 map of a 513x513 input at OS16) every residue class
+// (py, px) of the rate x rate sub-lattice holds at most 2 x 2 pixels, and on a sub-lattice the atrous 3x3 is
+// a dense 3x3 with padding 1: the <= 4 outputs of a class depend on exactly its <= 4 inputs.  One thread
+// owns one class (x 4 channels): 4 loads feed 4 outputs, i.e. every input element crosses the CU's load
+// path ONCE (the per-pixel gather fetches it 3.6 times through L1 misses and is bound by the ~24 GB/s/CU load
+// path, not by HBM).  Two classes per thread are in flight (8 loads issued before any arithmetic); all tap
+// indices are compile-time, so the 9 weights live in registers.  HBM-bound: reads x once, writes y once.
+#ifndef DL3P_LAT2_PER_CU
+#define DL3P_LAT2_PER_CU 2
+#endif
+struct Lat2Item { unsigned pix[2][2]; bool rv[2], cv[2]; };
+
+__device__ __forceinline__ void lat2_decode(int s, int end, int rate, int H, int W, Lat2Item& it) {
+  const bool live = s < end;
+  const int pxo = s % rate;
+  const int t2 = s / rate;
+  const int py = t2 % rate;
+  const int n = t2 / rate;
+  it.rv[0] = live; it.rv[1] = live && py + rate < H;
+  it.cv[0] = live; it.cv[1] = live && pxo + rate < W;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+      it.pix[a][b] = ((unsigned)n * H + (unsigned)(py + a * rate)) * W + (unsigned)(pxo + b * rate);
+}
+
+template <int PRO>
+__global__ __launch_bounds__(256) void dw_fwd_lattice2(DwParams p) {
+  constexpr int TI = 1;   // residue classes per pipeline stage (2 was slower: fewer, longer stages overlap worse)
+  const int b = blockIdx.x;
+  const int slab = b / p.nbx;
+  const int bx = b - slab * p.nbx;
+  const int t = threadIdx.x;
+  const int pl = t / p.c4s;
+  const int cl = t - pl * p.c4s;
+  const bool active = pl < p.px;
+  const int cbase4 = slab * p.c4s;
+  const int c = (cbase4 + cl) * 4;
+  float4 s1[2] = {zero4(), zero4()};
+  if (active) {
+    const int rate = p.rate, H = p.H, W = p.W;
+    const unsigned ldx = (unsigned)p.ldx, ldy = (unsigned)p.ldy;
+    const float* xb = p.x + c;
+    float* yb = p.y + c;
+    XcdRange r = xcd_range(p.total, bx, p.nbx, p.px, pl);
+    // software pipeline: the loads of the NEXT stage are issued before the current stage is computed and
+    // stored, so reads and writes of different waves/iterations overlap instead of running in two phases
+    Lat2Item cur[TI], nxt[TI];
+    float4 in[TI][2][2], inn[TI][2][2];
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) {
+      lat2_decode(r.begin + ti * r.step, r.end, rate, H, W, cur[ti]);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+          in[ti][a][bb] = zero4();
+          if (cur[ti].rv[a] && cur[ti].cv[bb]) in[ti][a][bb] = ld4(xb + cur[ti].pix[a][bb] * ldx);
+        }
+    }
+    float4 wreg[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wreg[i] = ld4(p.w + (size_t)(p.flip ? 8 - i : i) * p.C + c);
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero4();
+    if (PRO && p.scale) { sc = ld4(p.scale + c); sh = ld4(p.shift + c); }
+    const int act = p.act;
+    for (int s = r.begin; s < r.end; s += TI * r.step) {
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti) {
+        lat2_decode(s + (TI + ti) * r.step, r.end, rate, H, W, nxt[ti]);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb) {
+            inn[ti][a][bb] = zero4();
+            if (nxt[ti].rv[a] && nxt[ti].cv[bb]) inn[ti][a][bb] = ld4(xb + nxt[ti].pix[a][bb] * ldx);
+          }
+      }
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti) {
+        float4 av[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb) {
+            const float4 v = prologue4<PRO>(in[ti][a][bb], sc, sh, act);
+            av[a][bb] = (cur[ti].rv[a] && cur[ti].cv[bb]) ? v : zero4();     // zero padding is in activation space
+          }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb) {
+            // output (a,bb) of the class: tap (ky,kx) = (a'-a+1, b'-bb+1) reads input (a',b')
+            float4 acc = zero4();
+#pragma unroll
+            for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+              for (int b2 = 0; b2 < 2; ++b2) acc = fma4(av[a2][b2], wreg[(a2 - a + 1) * 3 + (b2 - bb + 1)], acc);
+            if (cur[ti].rv[a] && cur[ti].cv[bb]) {
+              float* yp = yb + cur[ti].pix[a][bb] * ldy;
+              if (p.accumulate) acc = add4(acc, ld4(yp));
+              st4(yp, acc);
+              s1[0] = add4(s1[0], acc);
+              s1[1] = fma4(acc, acc, s1[1]);
+            }
+          }
+      }
+#pragma unroll
+      for (int ti = 0; ti < TI; ++ti) {
+        cur[ti] = nxt[ti];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb) in[ti][a][bb] = inn[ti][a][bb];
+      }
+    }
+  }
+  if (p.partials) block_reduce_store<2>(s1, active, pl, cl, p.c4s, p.px, cbase4, p.C, p.partials + (size_t)bx * 2 * p.C);
+}
+
 // ------------------------------------------------------------------------------ backward data, stride > 1
 // gx[n,iy,ix] = sum_taps w[ky,kx] * dy[n,(iy+pad_t-ky*r)/s,(ix+pad_l-kx*r)/s] where divisible.
 // Here (H,W) are the conv INPUT dims (the output of this kernel) and (Ho,Wo) the dy dims.
@@ -499,7 +622,13 @@ static int fwd_plan(DwParams& p) {
   int kind = 0;
   if (p.stride == 1 && ceil_div(p.Wo, p.rate) >= 4) kind = 1;
   else if (p.stride == 2 && p.rate == 1 && p.Wo >= 4) kind = 2;
-  if (kind == 0) {
+  if (kind == 0 && p.ks == 3 && p.stride == 1 && p.pad_t == p.rate && p.pad_l == p.rate && p.Ho == p.H && p.Wo == p.W &&
+      2 * p.rate >= p.H && 2 * p.rate >= p.W && p.rate < p.H && p.rate < p.W &&
+      (long long)p.N * p.H * p.W * (p.ldx > p.ldy ? p.ldx : p.ldy) < (1LL << 31)) kind = 3;
+  if (kind == 3) {
+    p.spr = p.rate; p.th = 1; p.nbands = p.rate;
+    p.total = (long long)p.N * p.rate * p.rate;      // one work item per residue class (py, px)
+  } else if (kind == 0) {
     p.spr = p.Wo; p.th = 1; p.nbands = p.Ho;
     p.total = (long long)p.N * p.Ho * p.Wo;
   } else {
@@ -512,21 +641,24 @@ static int fwd_plan(DwParams& p) {
     p.nbands = ceil_div(uh, p.th);
     p.total = (long long)p.N * r * r * p.nbands * p.spr;
   }
-  p.nbx = pick_nbx(p.total, p.px, p.nslab);
+  static const int lat2_per_cu = getenv("DL3P_LAT2_PER_CU") ? atoi(getenv("DL3P_LAT2_PER_CU")) : DL3P_LAT2_PER_CU;
+  p.nbx = pick_nbx(p.total, p.px, p.nslab, kind == 3 ? lat2_per_cu : 8);
   return kind;
 }
 
 template <int KS, int PRO>
 static void launch_fwd_pro(const DwParams& p, int kind, dim3 grid, hipStream_t st) {
   dim3 block(256);
-  if (kind == 1) hipLaunchKernelGGL((dw_fwd_seg<KS, 4, 1, PRO>), grid, block, 0, st, p);
-  else if (kind == 2) hipLaunchKernelGGL((dw_fwd_seg<KS, 2, 2, PRO>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL((dw_fwd_gather<KS, PRO>), grid, block, 0, st, p);
+  if (kind == 1) dl3p_launch(dw_fwd_seg<KS, 4, 1, PRO>, grid, block, 0, st, p);
+  else if (kind == 2) dl3p_launch(dw_fwd_seg<KS, 2, 2, PRO>, grid, block, 0, st, p);
+  else if (kind == 3) dl3p_launch(dw_fwd_lattice2<PRO>, grid, block, 0, st, p);
+  else dl3p_launch(dw_fwd_gather<KS, PRO>, grid, block, 0, st, p);
 }
 
 template <int KS>
 static void launch_fwd(const DwParams& p0, hipStream_t st) {
   DwParams p = p0;
+  p.ks = KS;
   const int kind = fwd_plan(p);
   dim3 grid(p.nbx * p.nslab);
   const int pro = (p.act != DL3P_ACT_NONE) ? 2 : (p.scale ? 1 : 0);
@@ -552,6 +684,7 @@ extern "C" int dl3p_dwconv2d_fwd(const float* x, int ldx, const float* in_scale,
   pick_lanes(C, &p.c4s, &p.px, &p.nslab);
   {
     DwParams q = p;
+    q.ks = k;
     fwd_plan(q);
     if (rows_out) *rows_out = q.nbx;
   }
@@ -598,7 +731,7 @@ static void launch_bwdw(const DwParams& p, int kind, dim3 grid, hipStream_t st) 
   dim3 block(256);
   if (kind == 1) hipLaunchKernelGGL((dw_bwd_weight_seg<KS, 4, 1, PRO>), grid, block, 0, st, p);
   else if (kind == 2) hipLaunchKernelGGL((dw_bwd_weight_seg<KS, 2, 2, PRO>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL((dw_bwd_weight<KS, PRO>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((dw_bwd_weight<KS, PRO>), grid, block, 0, st, p);   // kind 0 (ks == 0 there: no kind 3)
 }
 
 extern "C" size_t dl3p_dwconv2d_bwd_weight_workspace(int N, int Ho, int Wo, int C, int k) {

@@ -51,6 +51,7 @@ def ASPP_block(g, x, OS):
     else:
         raise ValueError('invalid output stride', OS)
     H, W, _ = x.shape
+    x_in = x
     # Concatenate([b4, b0, b1, b2, b3]) (layers.py:155): the five branches write their raw outputs
     # into channel slices of one buffer; their BNs own slices of one coefficient group
     base, slices, group = g.concat_buffer(H, W, [256] * 5, 'aspp_concat')
@@ -61,11 +62,28 @@ def ASPP_block(g, x, OS):
     for i, r in enumerate(atrous_rates):
         SepConv_BN(g, x, 256, 'aspp%d' % (i + 1), rate=r, depth_activation=True, epsilon=1e-5,
                    out=slices[2 + i][0], out_group=group, out_goff=slices[2 + i][1])
+    _atrous_first(g, x_in)
     x = g.concat_value(base, group, ACT_RELU)
     x = g.conv2d(x, 256, 1, 'concat_projection')
     x = g.batchnorm(x, 'concat_projection_BN', eps=1e-5)
     x = g.relu(x)
     return g.dropout(x, 0.5)
+
+
+def _atrous_first(g, x_in):
+    """Execution order only (layers and weights keep the reference's order): run the three atrous
+    depthwise convs -- largest rate first -- directly after the op that produced the ASPP input, while
+    that tensor is still resident in the Infinity Cache, then the pooling / 1x1 branches."""
+    names = ['aspp3_depthwise', 'aspp2_depthwise', 'aspp1_depthwise']
+    moved = []
+    for n in names:
+        for op in g.ops:
+            if getattr(op, 'name', None) in (n, n + '_BN') and op.kind in ('conv_dw', 'bn'):
+                moved.append(op)
+    first = min(i for i, op in enumerate(g.ops) if getattr(op, 'x', None) is not None and op.x.tensor is x_in.tensor
+                and op.kind in ('gap', 'conv_pw', 'conv_dw'))
+    rest = [op for op in g.ops if op not in moved]
+    g.ops[:] = rest[:first] + moved + rest[first:]
 
 
 def ASPP_Lite_block(g, x):
