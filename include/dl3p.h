@@ -112,6 +112,14 @@ int dl3p_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* gx, i
                          int N, int H, int W, int Cin, int Cout, int k, int stride, int rate,
                          int pad_t, int pad_l, int Ho, int Wo, void* stream);
 
+/* im2col for the small dense convs: col[m][(ky*k+kx)*Cin+ci] = act(x*scale+shift) at the tap (zero in the
+ * padding), rows padded with zeros to Kp = ld_col >= k*k*Cin (multiple of 4).  The conv is then
+ * dl3p_pwconv_* on col with the HWIO kernel read as [k*k*Cin (padded to Kp)][Cout] -- the stem runs on the
+ * same MFMA GEMM (and its BN-statistics epilogue) as the pointwise convs. */
+int dl3p_im2col(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                float* col, int ld_col, int N, int H, int W, int Cin, int k, int stride, int rate,
+                int pad_t, int pad_l, int Ho, int Wo, void* stream);
+
 /* ---------------------------------------------------------------- batch normalisation
  * replaces BatchNormalization/FusedBatchNormV3 (layers.py:63-70 CustomBatchNormalization).
  * Training: biased batch variance normalises; the Bessel-corrected variance feeds the moving

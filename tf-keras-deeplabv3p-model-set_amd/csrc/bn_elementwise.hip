@@ -545,7 +545,17 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(EwParams p, int HW, float 
     const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
     const float4 sc = opt_ld4(p.scale, c, one), sh = opt_ld4(p.shift, c, zero4());
     const float* base = p.a + (size_t)n * HW * p.lda + c;
-    for (int i = pl; i < HW; i += p.px) acc[0] = add4(acc[0], act_apply4(fma4(ld4(base + (size_t)i * p.lda), sc, sh), p.act));
+    // 4 independent accumulators: 4 row loads in flight per thread
+    float4 a1 = zero4(), a2 = zero4(), a3 = zero4();
+    int i = pl;
+    for (; i + 3 * p.px < HW; i += 4 * p.px) {
+      acc[0] = add4(acc[0], act_apply4(fma4(ld4(base + (size_t)i * p.lda), sc, sh), p.act));
+      a1 = add4(a1, act_apply4(fma4(ld4(base + (size_t)(i + p.px) * p.lda), sc, sh), p.act));
+      a2 = add4(a2, act_apply4(fma4(ld4(base + (size_t)(i + 2 * p.px) * p.lda), sc, sh), p.act));
+      a3 = add4(a3, act_apply4(fma4(ld4(base + (size_t)(i + 3 * p.px) * p.lda), sc, sh), p.act));
+    }
+    for (; i < HW; i += p.px) acc[0] = add4(acc[0], act_apply4(fma4(ld4(base + (size_t)i * p.lda), sc, sh), p.act));
+    acc[0] = add4(add4(acc[0], a1), add4(a2, a3));
     const float inv = out_scale / (float)HW;
     acc[0] = make_float4(acc[0].x * inv, acc[0].y * inv, acc[0].z * inv, acc[0].w * inv);
   }
@@ -563,7 +573,13 @@ extern "C" int dl3p_global_avgpool_fwd(const float* x, int ldx, const float* in_
   DL3P_CHECK_ARG(N > 0 && HW > 0, "dl3p_global_avgpool_fwd: bad dims");
   EwParams p = {};
   p.a = x; p.lda = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act; p.out = y; p.ldo = ldy;
-  pick_lanes(C, &p.c4s, &p.px, &p.nslab);
+  // narrow channel slabs (<= 16 lanes = 256 B per pixel) -> many workgroups with 16+ pixel lanes each
+  {
+    const int c4 = C / 4;
+    int d = 1;
+    for (int k = 1; k <= 16 && k <= c4; ++k) if (c4 % k == 0) d = k;
+    p.c4s = d; p.px = 256 / d; p.nslab = c4 / d;
+  }
   p.C = C;
   hipLaunchKernelGGL(gap_fwd_kernel, dim3(N * p.nslab), dim3(256), 0, (hipStream_t)stream, p, HW, out_scale);
   DL3P_CHECK_LAUNCH("dl3p_global_avgpool_fwd");

@@ -238,3 +238,55 @@ extern "C" int dl3p_conv2d_bwd_data(const float* dy, int lddy, const float* w, f
   DL3P_CHECK_LAUNCH("dl3p_conv2d_bwd_data");
   return DL3P_OK;
 }
+
+// ------------------------------------------------------------------------------ im2col
+// one thread per (output pixel, group of 4 consecutive k): gathers 4 taps, writes one 16-B vector
+__global__ __launch_bounds__(256) void im2col_kernel(ConvParams p, int kp) {
+  const int k4n = kp / 4;
+  const long long total = (long long)p.N * p.Ho * p.Wo * k4n;
+  const int kk = p.k * p.k * p.Cin;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int k4 = (int)(i % k4n);
+    long long m = i / k4n;
+    const int ox = (int)(m % p.Wo);
+    long long row = m / p.Wo;
+    const int oy = (int)(row % p.Ho);
+    const int n = (int)(row / p.Ho);
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = k4 * 4 + j;
+      float a = 0.f;
+      if (e < kk) {
+        const int tap = e / p.Cin, ci = e - tap * p.Cin;
+        const int ky = tap / p.k, kx = tap - ky * p.k;
+        const int iy = oy * p.stride - p.pad_t + ky * p.rate;
+        const int ix = ox * p.stride - p.pad_l + kx * p.rate;
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+          a = p.x[(((size_t)n * p.H + iy) * p.W + ix) * p.ldx + ci];
+          if (p.scale) a = fmaf(a, p.scale[ci], p.shift[ci]);
+          a = act_apply(a, p.act);
+        }
+      }
+      v[j] = a;
+    }
+    st4(p.y + (size_t)m * p.ldy + k4 * 4, make_float4(v[0], v[1], v[2], v[3]));
+  }
+}
+
+extern "C" int dl3p_im2col(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                           float* col, int ld_col, int N, int H, int W, int Cin, int k, int stride, int rate,
+                           int pad_t, int pad_l, int Ho, int Wo, void* stream) {
+  DL3P_CHECK_ARG(x && col && aligned16(col) && ld_col % 4 == 0 && ld_col >= k * k * Cin && ldx >= Cin,
+                 "dl3p_im2col: bad layout (ld_col=%d)", ld_col);
+  ConvParams p = {};
+  p.x = x; p.ldx = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act; p.y = col; p.ldy = ld_col;
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.k = k; p.stride = stride; p.rate = rate;
+  p.pad_t = pad_t; p.pad_l = pad_l;
+  long long total = (long long)N * Ho * Wo * (ld_col / 4);
+  long long blocks = ceil_div_ll(total, 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, ld_col);
+  DL3P_CHECK_LAUNCH("dl3p_im2col");
+  return DL3P_OK;
+}

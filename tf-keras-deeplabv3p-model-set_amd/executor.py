@@ -58,6 +58,9 @@ class ParamStore:
     @staticmethod
     def _pad(p, value):
         a = np.asarray(value, dtype=np.float32)
+        if len(p.dev_shape) != len(p.shape):      # dense conv kernel (k,k,cin,cout) -> [k*k*cin (padded)][cout]
+            a = a.reshape(-1, p.shape[-1])
+            return np.pad(a, [(0, p.dev_shape[0] - a.shape[0]), (0, p.dev_shape[1] - a.shape[1])])
         if p.dev_shape != p.shape:
             pad = [(0, d - s) for s, d in zip(p.shape, p.dev_shape)]
             a = np.pad(a, pad)
@@ -74,13 +77,17 @@ class ParamStore:
         host = self.P.detach().cpu().numpy()
         for p in self.params:
             o = self.offset[p]
-            a = host[o:o + p.dev_size].reshape(p.dev_shape)
-            sl = tuple(slice(0, s) for s in p.shape)
-            p.value = a[sl].copy()
+            p.value = self._unpad(p, host[o:o + p.dev_size].reshape(p.dev_shape))
+
+    @staticmethod
+    def _unpad(p, a):
+        if len(p.dev_shape) != len(p.shape):
+            rows = int(np.prod(p.shape[:-1]))
+            return a[:rows, :p.shape[-1]].reshape(p.shape).copy()
+        return a[tuple(slice(0, s) for s in p.shape)].copy()
 
     def get(self, p, buf=None):
-        a = self.view(p, buf).detach().cpu().numpy()
-        return a[tuple(slice(0, s) for s in p.shape)].copy()
+        return self._unpad(p, self.view(p, buf).detach().cpu().numpy())
 
     def refresh_masks(self):
         """per-element l2 factor and learning-rate multiplier (0 = frozen / not a trainable weight)"""
@@ -275,7 +282,7 @@ class Executor:
             elif op.kind == 'conv_dw':
                 ws = max(ws, L.dwconv2d_bwd_weight_workspace(N, op.Ho, op.Wo, op.c, op.k))
             elif op.kind == 'conv_dense':
-                ws = max(ws, L.conv2d_bwd_weight_workspace(N, op.Ho, op.Wo, op.cin, op.cout, op.k))
+                ws = max(ws, L.pwconv_bwd_weight_workspace(N * op.Ho * op.Wo, op.kp, op.cout))
         self.workspace = torch.zeros(ws // 4 + 4, **self.f32) if self.training else None
         H, W, _ = g.input_shape
         self.H, self.W = H, W
@@ -356,9 +363,12 @@ class Executor:
                         ctypes.byref(rows), N, xt.H, xt.W, op.c, op.k, op.stride, op.rate, op.pad_t, op.pad_l,
                         op.Ho, op.Wo, tag=op.name)
                 else:
-                    P.k(L.conv2d_fwd, xp, ldx, sp, hp, act, st.ptr(op.w), self.tptr(op.out), op.out.ld, part,
-                        ctypes.byref(rows), N, xt.H, xt.W, op.cin, op.cout, op.k, op.stride, op.rate, op.pad_t,
-                        op.pad_l, op.Ho, op.Wo)
+                    # small dense conv (RGB stem): im2col once (kept for the weight gradient), then the MFMA GEMM
+                    P.k(L.im2col, xp, ldx, sp, hp, act, self.tptr(op.col), op.col.ld, N, xt.H, xt.W, op.cin, op.k,
+                        op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
+                    P.k(L.pwconv_fwd, self.tptr(op.col), op.col.ld, None, None, ACT_NONE, st.ptr(op.w),
+                        st.ptr(op.b) if op.b else None, self.tptr(op.out), op.out.ld, part, ctypes.byref(rows),
+                        N * op.Ho * op.Wo, op.kp, op.cout)
                 op.rows = rows.value
             elif k == 'bn':
                 self._bn_forward(P, op)
@@ -475,8 +485,8 @@ class Executor:
                         P.k(L.dwconv2d_bwd_weight, xp, ldx, sp, hp, act, dz, lddz, gw, ws, wsb, N, xt.H, xt.W, op.c,
                             op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
                     else:
-                        P.k(L.conv2d_bwd_weight, xp, ldx, sp, hp, act, dz, lddz, gw, ws, wsb, N, xt.H, xt.W, op.cin,
-                            op.cout, op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
+                        P.k(L.pwconv_bwd_weight, self.tptr(op.col), op.col.ld, None, None, ACT_NONE, dz, lddz, gw,
+                            st.ptr(op.b, G) if op.b else None, ws, wsb, N * op.Ho * op.Wo, op.kp, op.cout)
                 if need_gx:
                     gp, ldg = self._gbuf(op.x)
                     acc = self._acc(xt)

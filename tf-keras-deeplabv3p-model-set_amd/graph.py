@@ -225,9 +225,12 @@ class GraphBuilder:
         Ho, Wo, pt, pl = conv_geometry(H, W, k, stride, rate, padding)
         layer = self.add_layer(name, 'Conv2D', (Ho, Wo, filters))
         cdev = pad_to or filters
+        # dense (k > 1) kernels are stored as the im2col GEMM operand [k*k*cin padded to a multiple of 4][cout]
+        kp = (k * k * cin + 3) // 4 * 4
+        dev_shape = (k, k, cin, cdev) if k == 1 else (kp, cdev)
         wp = layer.add_param('kernel', (k, k, cin, filters),
                              lambda s: glorot_uniform(self.rng, s, k * k * cin, k * k * filters), l2=L2_FACTOR,
-                             dev_shape=(k, k, cin, cdev))
+                             dev_shape=dev_shape)
         bp = None
         if use_bias:
             bp = layer.add_param('bias', (filters,), lambda s: np.zeros(s, np.float32), l2=L2_FACTOR,
@@ -238,8 +241,9 @@ class GraphBuilder:
         kind = 'conv_pw' if (k == 1 and stride == 1) else 'conv_dense'
         if k == 1 and stride > 1:
             kind = 'conv_pw_strided'
+        col = self.new_tensor(Ho, Wo, kp, name + '_im2col') if kind == 'conv_dense' else None
         self.ops.append(Op(kind, name=name, layer=layer, x=x, w=wp, b=bp, out=out, k=k, stride=stride, rate=rate,
-                           pad_t=pt, pad_l=pl, Ho=Ho, Wo=Wo, cin=cin, cout=cdev, bn=None))
+                           pad_t=pt, pad_l=pl, Ho=Ho, Wo=Wo, cin=cin, cout=cdev, bn=None, col=col, kp=kp))
         return Value(out)
 
     def dwconv2d(self, x, k, name, stride=1, rate=1, padding='same', out=None):
