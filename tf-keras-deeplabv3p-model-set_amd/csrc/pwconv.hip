@@ -51,6 +51,13 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) float As[BM * APITCH];
   __shared__ __attribute__((aligned(16))) float Bs[BS_FLOATS];
   __shared__ float red[STATS ? 2 * 4 * BN : 1];
+  // epilogue transpose buffer (wave-private slices): accumulators go out as whole 256-B row segments
+  constexpr int TPP = NT < 4 ? NT : 4;            // 16-column tiles per epilogue pass
+  constexpr int NPASS = (NT + TPP - 1) / TPP;
+  constexpr int CH = 16 * TPP;
+  constexpr int EPITCH = CH + 4;
+  constexpr int RW = 16 * MI;                      // rows per wave
+  __shared__ __attribute__((aligned(16))) float Es[4 * RW * EPITCH];
 
   const int t = threadIdx.x;
   const int l = t & 63;
@@ -131,10 +138,10 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  f32x4 st_s[STATS ? NT : 1], st_q[STATS ? NT : 1];
+  float4 st_s[STATS ? NPASS : 1], st_q[STATS ? NPASS : 1];   // per lane: 4 columns of each epilogue pass
   if (STATS) {
 #pragma unroll
-    for (int ni = 0; ni < NT; ++ni) { st_s[ni] = (f32x4){0.f, 0.f, 0.f, 0.f}; st_q[ni] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int i = 0; i < NPASS; ++i) { st_s[i] = zero4(); st_q[i] = zero4(); }
   }
 
   if (it_total > 0) prefetch(0);
@@ -170,27 +177,45 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
     }
     __syncthreads();
     if (it % nk == nk - 1) {
-      // epilogue of this M tile: lane holds 4 consecutive output channels (q*4..q*4+3) of pixel l15
+      // epilogue of this M tile.  After the MFMAs a lane holds 4 consecutive channels of pixel l15 per
+      // accumulator; stored directly that is 16 rows x 64 B per store instruction (half cache lines,
+      // measured: 13.6k cycles per tile, and the next tile's staging waits behind those stores).  The tile
+      // is therefore transposed through a wave-private LDS slice and leaves as 4 rows x 256 B per
+      // instruction; bias / accumulate / BN statistics are applied on the way out.
       const int mt = blockIdx.x + (it / nk) * gridDim.x;
       const int m0 = mt * BM;
+      float* es = Es + w * RW * EPITCH;
+      const int rr = l >> 4, cq = l & 15;
 #pragma unroll
-      for (int ni = 0; ni < NT; ++ni) {
-        const int n = n0 + ni * 16 + q * 4;
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int ni0 = ps * TPP;
+#pragma unroll
+        for (int nl = 0; nl < TPP; ++nl) {
+          if (ni0 + nl < NT) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+              const f32x4 v = acc[mi][ni0 + nl];
+              acc[mi][ni0 + nl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+              *reinterpret_cast<float4*>(&es[(mi * 16 + l15) * EPITCH + nl * 16 + q * 4]) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+          }
+        }
+        const int n = n0 + ni0 * 16 + cq * 4;
+        const bool col_ok = (ni0 * 16 + cq * 4 < BN) && (cq * 4 < CH) && n < p.N && (ni0 + cq / 4 < NT);
         float4 bias4 = zero4();
-        if (p.bias && n < p.N) bias4 = ld4(p.bias + n);
+        if (p.bias && col_ok) bias4 = ld4(p.bias + n);
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          const int m = m0 + w * 16 * MI + mi * 16 + l15;
-          f32x4 v = acc[mi][ni];
-          acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (m < p.M && n < p.N) {
-            float4 o = make_float4(v[0] + bias4.x, v[1] + bias4.y, v[2] + bias4.z, v[3] + bias4.w);
+        for (int r0 = 0; r0 < RW; r0 += 4) {
+          const int row = r0 + rr;
+          const int m = m0 + w * RW + row;
+          if (col_ok && m < p.M) {
+            float4 o = add4(*reinterpret_cast<const float4*>(&es[row * EPITCH + cq * 4]), bias4);
             float* yp = p.Y + (size_t)m * p.ldy + n;
             if (p.accumulate) o = add4(o, ld4(yp));
             st4(yp, o);
             if (STATS) {
-              st_s[ni] += (f32x4){o.x, o.y, o.z, o.w};
-              st_q[ni] += (f32x4){o.x * o.x, o.y * o.y, o.z * o.z, o.w * o.w};
+              st_s[ps] = add4(st_s[ps], o);
+              st_q[ps] = fma4(o, o, st_q[ps]);
             }
           }
         }
@@ -199,20 +224,21 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
   }
 
   if (STATS) {
-    // reduce over the 16 pixel lanes, then over the 4 waves; one partial row per workgroup
+    // reduce over the 4 row groups of the wave, then over the 4 waves; one partial row per workgroup
+    const int rr = l >> 4, cq = l & 15;
 #pragma unroll
-    for (int ni = 0; ni < NT; ++ni) {
+    for (int ps = 0; ps < NPASS; ++ps) {
+      float sv[4] = {st_s[ps].x, st_s[ps].y, st_s[ps].z, st_s[ps].w};
+      float qv[4] = {st_q[ps].x, st_q[ps].y, st_q[ps].z, st_q[ps].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float s = st_s[ni][e], sq = st_q[ni][e];
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) {
-          s += __shfl_xor(s, off);
-          sq += __shfl_xor(sq, off);
-        }
-        if (l15 == 0) {
-          red[(0 * 4 + w) * BN + ni * 16 + q * 4 + e] = s;
-          red[(1 * 4 + w) * BN + ni * 16 + q * 4 + e] = sq;
+        float s1 = sv[e], s2 = qv[e];
+        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        const int col = ps * CH + cq * 4 + e;
+        if (rr == 0 && cq * 4 < CH && col < BN) {
+          red[(0 * 4 + w) * BN + col] = s1;
+          red[(1 * 4 + w) * BN + col] = s2;
         }
       }
     }
