@@ -120,6 +120,11 @@ int dl3p_im2col(const float* x, int ldx, const float* in_scale, const float* in_
                 float* col, int ld_col, int N, int H, int W, int Cin, int k, int stride, int rate,
                 int pad_t, int pad_l, int Ho, int Wo, void* stream);
 
+/* transpose of dl3p_im2col in gather form (deterministic): gx[n,iy,ix,ci] (+)= sum over the taps that read
+ * it of gcol[m][tap*Cin+ci].  Cin % 4 == 0. */
+int dl3p_col2im(const float* gcol, int ld_col, float* gx, int ldgx, int accumulate, int N, int H, int W, int Cin,
+                int k, int stride, int rate, int pad_t, int pad_l, int Ho, int Wo, void* stream);
+
 /* ---------------------------------------------------------------- batch normalisation
  * replaces BatchNormalization/FusedBatchNormV3 (layers.py:63-70 CustomBatchNormalization).
  * Training: biased batch variance normalises; the Bessel-corrected variance feeds the moving
@@ -147,10 +152,12 @@ int dl3p_bn_bwd_reduce(const float* g, int ldg, const float* z, int ldz, const f
 int dl3p_bn_bwd_finalize(const float* partials, int rows, const double* sums, int C, double count,
                          const float* gamma, const float* save_invstd, const float* scale, int frozen,
                          float* dgamma, float* dbeta, float* coef, void* stream);
-/* pass 2: dz = coef0*(dyy - coef1 - xhat*coef2).  dz may alias g. */
+/* pass 2: dz (+)= coef0*(dyy - coef1 - xhat*coef2).  dz may alias g (when not accumulating).  With every
+ * per-channel pointer NULL this is the backward of a bare activation: dz (+)= g * act'(z)  (the ReLU in
+ * front of a SepConv_BN applied to a residual sum, layers.py:98). */
 int dl3p_bn_bwd_apply(const float* g, int ldg, const float* z, int ldz, const float* scale, const float* shift,
                       int act, const float* save_mean, const float* save_invstd, const float* coef,
-                      float* dz, int lddz, int M, int C, void* stream);
+                      float* dz, int lddz, int accumulate, int M, int C, void* stream);
 
 /* ---------------------------------------------------------------- elementwise
  * y = dropout(act(x*scale+shift)) [+ act2(r*rscale+rshift)]  -- materialises a lazy activation, the

@@ -51,6 +51,10 @@ class Net:
         # within rounding distance of the kink.  Parity tests inject the branch pattern of the
         # implementation under test so that the comparison is well-conditioned.
         self.act_derivs = {}
+        # ... and, in creation order, the derivative arrays of bare activations applied to tensors that are
+        # not BatchNormalization outputs (residual sums, SE-block convs)
+        self.act_derivs_seq = []
+        self._seq_pos = 0
         # optional SyncBatchNorm: (all_reduce_sum(ndarray) -> ndarray, world_size).  Statistics are
         # summed over ranks in forward (sum x, sum x^2, count) and backward (sum dy, sum dy*xhat); the
         # parameter gradients stay local and are averaged with all other gradients (README.md:38,
@@ -80,6 +84,7 @@ class Net:
         self.training = training
         self.taps = {}
         self.reg_loss = 0.0
+        self._seq_pos = 0
 
     def backward(self):
         for f in reversed(self.tape):
@@ -196,7 +201,13 @@ class Net:
 
     def act(self, x, kind):
         y = Var(O.act_fwd(x.v, kind))
-        deriv = self.act_derivs.get(x.tag) if x.tag is not None else None
+        y.tag = ('act',)
+        deriv = None
+        if isinstance(x.tag, str):
+            deriv = self.act_derivs.get(x.tag)
+        elif x.tag is None and self.act_derivs_seq:
+            deriv = self.act_derivs_seq[self._seq_pos]
+            self._seq_pos += 1
 
         def bwd():
             if y.g is not None:

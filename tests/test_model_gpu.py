@@ -56,12 +56,37 @@ def _act_derivs(m, ex):
     return out
 
 
+def _act_derivs_seq(m, ex, named_out):
+    """the same for bare activations of materialised tensors, in creation order"""
+    ops = load_pkg('ops')
+    seq = []
+    for (t, act, vt) in m.graph.act_views.values():
+        prod = m.graph.producer_of(t)
+        named = prod is not None and prod.kind == 'materialize' and prod.r is None and prod.x.bn is not None
+        z = ex.view(t)
+        a = ops.affine_act(z, None, None, act).cpu().numpy()
+        zz = z.cpu().numpy()
+        if act == ops.ACT_RELU:
+            d = (a > 0).astype(np.float64)
+        elif act == ops.ACT_RELU6:
+            d = ((a > 0) & (a < 6)).astype(np.float64)
+        elif act == ops.ACT_HSIGMOID:
+            d = (((zz + 3) > 0) & ((zz + 3) < 6)).astype(np.float64) / 6.0
+        else:
+            raise NotImplementedError(act)
+        if named:     # a materialised BatchNormalization output: the oracle knows it by the BN layer's name
+            named_out[prod.x.bn.name] = d
+        else:
+            seq.append(d)
+    return seq
+
+
 def _rel(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / max(1e-6, np.abs(b).max()))
 
 
-@pytest.mark.parametrize('model_type,H,W', [('mobilenetv2', 65, 65), ('mobilenetv2_lite', 65, 97)])
+@pytest.mark.parametrize('model_type,H,W', [('mobilenetv2', 65, 65), ('mobilenetv2_lite', 65, 97), ('xception', 65, 65)])
 def test_predict_matches_oracle(model_type, H, W):
     m, o = _pair(model_type, H, W, 21, training=False)
     x, _ = _data(2, H, W, 21)
@@ -77,7 +102,7 @@ def test_predict_matches_oracle(model_type, H, W):
 
 
 @pytest.mark.parametrize('model_type,H,W,freeze', [('mobilenetv2', 65, 65, 0), ('mobilenetv2_lite', 65, 65, 0),
-                                                   ('mobilenetv2', 65, 65, 1)])
+                                                   ('mobilenetv2', 65, 65, 1), ('xception', 65, 65, 0)])
 def test_train_step_matches_oracle(model_type, H, W, freeze):
     N, C = 2, 21
     m, o = _pair(model_type, H, W, C, freeze_level=freeze)
@@ -90,6 +115,7 @@ def test_train_step_matches_oracle(model_type, H, W, freeze):
     # the ReLU branch pattern of the float32 run is injected into the float64 oracle (see
     # oracle/np_net.py Net.act_derivs): gradients are then comparable element by element
     o.net.act_derivs = _act_derivs(m, ex)
+    o.net.act_derivs_seq = _act_derivs_seq(m, ex, o.net.act_derivs)
     total, ce, logits = o.loss_and_grads(x, y, {'aspp_dropout': mask})
     assert abs(loss - ce) < TOL * max(1.0, abs(ce)), (loss, ce)
     # per-parameter gradients (data term), relative to each tensor's scale
@@ -111,6 +137,11 @@ def test_train_step_matches_oracle(model_type, H, W, freeze):
         assert np.abs(v - o.net.params[k]).max() < TOL * max(1.0, np.abs(o.net.params[k]).max()), k
     if freeze:
         assert all(not p.trainable for p in m.graph.all_params() if p.layer.name.startswith('expanded_conv'))
+
+
+def _skip_if_missing(model_type):
+    if model_type not in load_pkg().deeplab_model_map:
+        pytest.skip(model_type + ' not built')
 
 
 def test_graph_replay_equals_eager():

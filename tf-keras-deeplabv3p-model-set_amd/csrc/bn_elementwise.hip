@@ -381,13 +381,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(EwParams p) {
     o.y = c0.y * (d.y - c1.y - (z.y - mu.y) * is.y * c2.y);
     o.z = c0.z * (d.z - c1.z - (z.z - mu.z) * is.z * c2.z);
     o.w = c0.w * (d.w - c1.w - (z.w - mu.w) * is.w * c2.w);
-    st4(p.out + (size_t)m * p.ldo + c, o);
+    float* op = p.out + (size_t)m * p.ldo + c;
+    if (p.accumulate) o = add4(o, ld4(op));
+    st4(op, o);
   }
 }
 
 extern "C" int dl3p_bn_bwd_apply(const float* g, int ldg, const float* z, int ldz, const float* scale,
                                  const float* shift, int act, const float* save_mean, const float* save_invstd,
-                                 const float* coef, float* dz, int lddz, int M, int C, void* stream) {
+                                 const float* coef, float* dz, int lddz, int accumulate, int M, int C,
+                                 void* stream) {
   int rc = check_ew("dl3p_bn_bwd_apply", g, ldg, C);
   if (rc) return rc;
   rc = check_ew("dl3p_bn_bwd_apply", z, ldz, C);
@@ -396,7 +399,7 @@ extern "C" int dl3p_bn_bwd_apply(const float* g, int ldg, const float* z, int ld
   if (rc) return rc;
   EwParams p = {};
   p.a = g; p.lda = ldg; p.z = z; p.ldz = ldz; p.scale = scale; p.shift = shift; p.act = act;
-  p.mean = save_mean; p.invstd = save_invstd; p.coef = coef; p.out = dz; p.ldo = lddz;
+  p.mean = save_mean; p.invstd = save_invstd; p.coef = coef; p.out = dz; p.ldo = lddz; p.accumulate = accumulate;
   ew_setup(p, M, C, 1 << 20);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(p.nbx * p.nslab), dim3(256), 0, (hipStream_t)stream, p);
   DL3P_CHECK_LAUNCH("dl3p_bn_bwd_apply");

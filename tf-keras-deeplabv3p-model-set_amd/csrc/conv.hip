@@ -290,3 +290,51 @@ extern "C" int dl3p_im2col(const float* x, int ldx, const float* in_scale, const
   DL3P_CHECK_LAUNCH("dl3p_im2col");
   return DL3P_OK;
 }
+
+// ------------------------------------------------------------------------------ col2im (gather form)
+__global__ __launch_bounds__(256) void col2im_kernel(ConvParams p, int kp) {
+  const int c4n = p.Cin / 4;
+  const long long total = (long long)p.N * p.H * p.W * c4n;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c4 = (int)(i % c4n);
+    long long pix = i / c4n;
+    const int ix = (int)(pix % p.W);
+    pix /= p.W;
+    const int iy = (int)(pix % p.H);
+    const int n = (int)(pix / p.H);
+    float4 acc = zero4();
+    for (int ky = 0; ky < p.k; ++ky) {
+      const int ty = iy + p.pad_t - ky * p.rate;
+      if (ty < 0 || ty % p.stride) continue;
+      const int oy = ty / p.stride;
+      if (oy >= p.Ho) continue;
+      for (int kx = 0; kx < p.k; ++kx) {
+        const int tx = ix + p.pad_l - kx * p.rate;
+        if (tx < 0 || tx % p.stride) continue;
+        const int ox = tx / p.stride;
+        if (ox >= p.Wo) continue;
+        const size_t m = ((size_t)n * p.Ho + oy) * p.Wo + ox;
+        acc = add4(acc, ld4(p.dy + m * kp + (size_t)(ky * p.k + kx) * p.Cin + c4 * 4));
+      }
+    }
+    float* o = p.y + (((size_t)n * p.H + iy) * p.W + ix) * p.ldy + c4 * 4;
+    if (p.accumulate) acc = add4(acc, ld4(o));
+    st4(o, acc);
+  }
+}
+
+extern "C" int dl3p_col2im(const float* gcol, int ld_col, float* gx, int ldgx, int accumulate, int N, int H, int W,
+                           int Cin, int k, int stride, int rate, int pad_t, int pad_l, int Ho, int Wo, void* stream) {
+  DL3P_CHECK_ARG(gcol && gx && aligned16(gcol) && aligned16(gx) && Cin % 4 == 0 && ld_col % 4 == 0 &&
+                 ld_col >= k * k * Cin && ldgx % 4 == 0 && ldgx >= Cin, "dl3p_col2im: bad layout");
+  ConvParams p = {};
+  p.dy = gcol; p.y = gx; p.ldy = ldgx; p.accumulate = accumulate;
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.k = k; p.stride = stride; p.rate = rate;
+  p.pad_t = pad_t; p.pad_l = pad_l;
+  long long total = (long long)N * H * W * (Cin / 4);
+  long long blocks = ceil_div_ll(total, 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(col2im_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, ld_col);
+  DL3P_CHECK_LAUNCH("dl3p_col2im");
+  return DL3P_OK;
+}

@@ -259,7 +259,8 @@ class Executor:
         self.buf, self.grad = {}, {}
         self._mark_requires_grad()
         for t in g.tensors:
-            self.buf[t.id] = torch.zeros(N * t.H * t.W * t.C, **self.f32)
+            if not getattr(t, 'grad_only', False):
+                self.buf[t.id] = torch.zeros(N * t.H * t.W * t.C, **self.f32)
             if self.training and t.requires_grad:
                 self.grad[t.id] = torch.zeros(N * t.H * t.W * t.C, **self.f32)
         self.gscale, self.gshift = {}, {}
@@ -313,12 +314,16 @@ class Executor:
             k = op.kind
             if k in ('conv_pw', 'conv_dense', 'conv_dw'):
                 setrg(op.out, op.layer.trainable or rg(op.x))
+                if k == 'conv_dense':
+                    setrg(op.col, rg(op.x))
             elif k == 'bn':
                 setrg(op.z, op.layer.trainable)
             elif k == 'materialize':
                 setrg(op.out, rg(op.x) or (op.r is not None and rg(op.r)))
             elif k in ('gap', 'resize', 'broadcast'):
                 setrg(op.out, rg(op.x))
+        for (t, act, vt) in self.g.act_views.values():
+            setrg(vt, t.requires_grad or t.root.requires_grad)
 
     # ---------------------------------------------------------------- addressing helpers
     def tptr(self, t, grad=False):
@@ -440,15 +445,33 @@ class Executor:
         return 0
 
     def _gbuf(self, v):
+        """(ptr, ld, key tensor) of the buffer that collects d/d(value v)"""
+        vt = getattr(v, 'view_grad', None)
+        if vt is not None:
+            # bare activation of a materialised tensor: consumers write d/d(act(T)) here; folded into T's
+            # gradient (g * act'(T)) when backward reaches T's producer
+            self._pending_views.setdefault(v.tensor.id, []).append((v.tensor, v.act, vt))
+            return self.tptr(vt, grad=True), vt.ld, vt
         # a Concatenate value carries the activation of its branches: each branch's BatchNormalization
         # backward applies act' to its own channel slice, so the buffer itself takes the plain gradient
         if v.bn is None and v.group is None and v.act != ACT_NONE:
-            raise NotImplementedError('activation-only lazy value needs materialisation: ' + v.tensor.name)
-        return self.tptr(v.tensor, grad=True), v.tensor.ld
+            raise NotImplementedError('activation-only lazy value without a view buffer: ' + v.tensor.name)
+        return self.tptr(v.tensor, grad=True), v.tensor.ld, v.tensor
+
+    def _flush_views(self, P, t):
+        """T.grad (+)= view.grad * act'(T) for every bare-activation view of T"""
+        done = set()
+        for (tt, act, vt) in self._pending_views.pop(t.id, []):
+            if vt.id in done:
+                continue
+            done.add(vt.id)
+            P.k(self.L.bn_bwd_apply, self.tptr(vt, True), vt.ld, self.tptr(tt), tt.ld, None, None, act, None, None, None,
+                self.tptr(tt, True), tt.ld, self._acc(tt), self.N * tt.H * tt.W, tt.C)
 
     def _trace_backward(self):
         P, L, N, st = Plan(), self.L, self.N, self.store
         self._written = set()
+        self._pending_views = {}
         G = st.G
         zt = self.head.tensor
         # d(loss)/d(pred_resize output) -> d/d(conv_upsample output): transpose of the bilinear upsample
@@ -465,6 +488,8 @@ class Executor:
                 lo, hi = bucket_edges[op]
                 P.py(lambda lo=lo, hi=hi: self.dist.all_reduce_async(G[lo:hi]))
             out = getattr(op, 'out', None)
+            if out is not None and out.id in self._pending_views:
+                self._flush_views(P, out)
             if k == 'bn':
                 if op.z.requires_grad:
                     self._bn_backward(P, op)
@@ -488,8 +513,8 @@ class Executor:
                         P.k(L.pwconv_bwd_weight, self.tptr(op.col), op.col.ld, None, None, ACT_NONE, dz, lddz, gw,
                             st.ptr(op.b, G) if op.b else None, ws, wsb, N * op.Ho * op.Wo, op.kp, op.cout)
                 if need_gx:
-                    gp, ldg = self._gbuf(op.x)
-                    acc = self._acc(xt)
+                    gp, ldg, keyt = self._gbuf(op.x)
+                    acc = self._acc(keyt)
                     if k == 'conv_pw':
                         P.k(L.pwconv_bwd_data, dz, lddz, st.ptr(op.w), gp, ldg, acc, N * op.Ho * op.Wo, op.cin,
                             op.cout)
@@ -497,22 +522,25 @@ class Executor:
                         P.k(L.dwconv2d_bwd_data, dz, lddz, st.ptr(op.w), gp, ldg, acc, N, xt.H, xt.W, op.c, op.k,
                             op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
                     else:
-                        P.k(L.conv2d_bwd_data, dz, lddz, st.ptr(op.w), gp, ldg, acc, N, xt.H, xt.W, op.cin, op.cout,
-                            op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
+                        # d/d(im2col matrix) by the GEMM, then the transposed gather back onto the input pixels
+                        P.k(L.pwconv_bwd_data, dz, lddz, st.ptr(op.w), self.tptr(op.col, True), op.col.ld, 0,
+                            N * op.Ho * op.Wo, op.kp, op.cout)
+                        P.k(L.col2im, self.tptr(op.col, True), op.col.ld, gp, ldg, acc, N, xt.H, xt.W, op.cin, op.k,
+                            op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
             elif k == 'materialize':
                 gt, ldt = self.tptr(out, True), out.ld
                 M = N * out.H * out.W
                 if op.x.tensor.requires_grad or op.x.tensor.root.requires_grad:
-                    gp, ldg = self._gbuf(op.x)
+                    gp, ldg, keyt = self._gbuf(op.x)
                     P.k(L.scale_mask_bwd, gt, ldt, float(op.rate), self._dropout_seed(op), self.step.data_ptr(), gp, ldg,
-                        self._acc(op.x.tensor), M, out.C)
+                        self._acc(keyt), M, out.C)
                 if op.r is not None and (op.r.tensor.requires_grad or op.r.tensor.root.requires_grad):
-                    gp, ldg = self._gbuf(op.r)
-                    P.k(L.scale_mask_bwd, gt, ldt, 0.0, 0, None, gp, ldg, self._acc(op.r.tensor), M, out.C)
+                    gp, ldg, keyt = self._gbuf(op.r)
+                    P.k(L.scale_mask_bwd, gt, ldt, 0.0, 0, None, gp, ldg, self._acc(keyt), M, out.C)
             elif k == 'gap':
                 xt = op.x.tensor
-                gp, ldg = self._gbuf(op.x)
-                P.k(L.global_avgpool_bwd, self.tptr(out, True), out.ld, gp, ldg, self._acc(xt), N, xt.H * xt.W, xt.C)
+                gp, ldg, keyt = self._gbuf(op.x)
+                P.k(L.global_avgpool_bwd, self.tptr(out, True), out.ld, gp, ldg, self._acc(keyt), N, xt.H * xt.W, xt.C)
             elif k == 'broadcast':
                 # gradient w.r.t. the (lazy) 1x1 value = sum over the pixels it was broadcast to
                 xt = op.x.tensor
@@ -578,7 +606,7 @@ class Executor:
                 P.py(lambda s=aux['sums']: self.dist.all_reduce(s))
                 P.k(L.bn_bwd_finalize, None, 0, aux['sums'].data_ptr(), bn.C, float(M * self.dist.world_size),
                     st.ptr(lp['gamma']), invstd, sp, 0, None, None, coef)
-        P.k(L.bn_bwd_apply, g, ldg, zp, ldz, sp, hp, bn.act, mean, invstd, coef, g, ldg, M, bn.C)
+        P.k(L.bn_bwd_apply, g, ldg, zp, ldz, sp, hp, bn.act, mean, invstd, coef, g, ldg, 0, M, bn.C)
 
     # ---------------------------------------------------------------- optimiser
     def _trace_sgd(self):

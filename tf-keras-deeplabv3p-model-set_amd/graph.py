@@ -180,6 +180,7 @@ class GraphBuilder:
         self.tensors = []
         self.groups = []
         self.dropout_count = 0
+        self.act_views = {}
         inp = self.new_tensor(H, W, C, 'image_input')
         self.add_layer('image_input', 'InputLayer', (H, W, C))
         self.input = Value(inp)
@@ -238,9 +239,9 @@ class GraphBuilder:
         if out is None:
             out = self.new_tensor(Ho, Wo, cdev, name)
         assert (out.H, out.W, out.C) == (Ho, Wo, cdev), (name, (out.H, out.W, out.C), (Ho, Wo, cdev))
+        # 1x1 stride 1 is a plain GEMM; everything else (3x3 stem, Xception's stride-2 1x1 shortcuts) goes through
+        # im2col + the same GEMM
         kind = 'conv_pw' if (k == 1 and stride == 1) else 'conv_dense'
-        if k == 1 and stride > 1:
-            kind = 'conv_pw_strided'
         col = self.new_tensor(Ho, Wo, kp, name + '_im2col') if kind == 'conv_dense' else None
         self.ops.append(Op(kind, name=name, layer=layer, x=x, w=wp, b=bp, out=out, k=k, stride=stride, rate=rate,
                            pad_t=pt, pad_l=pl, Ho=Ho, Wo=Wo, cin=cin, cout=cdev, bn=None, col=col, kp=kp))
@@ -296,11 +297,25 @@ class GraphBuilder:
         self.add_layer(name, kind, v.shape)
         if act == ACT_NONE:
             return v
+        if v.act == act and act in (ACT_RELU, ACT_RELU6):
+            return v                      # idempotent (ReLU in front of a SepConv_BN whose input is already ReLU-ed)
         assert v.act == ACT_NONE, 'stacked activations need a materialised tensor'
         if v.bn is not None:
             assert v.bn.act in (ACT_NONE, act), 'one activation per BatchNormalization (materialise otherwise)'
             v.bn.act = act
-        return Value(v.tensor, v.group, v.goff, act, v.bn)
+            return Value(v.tensor, v.group, v.goff, act, v.bn)
+        out = Value(v.tensor, v.group, v.goff, act, None)
+        if v.group is None:
+            # bare activation of a materialised tensor (Xception: ReLU in front of a SepConv_BN applied to a
+            # residual sum; SE block activations).  Its consumers write d/d(act(T)) into a view buffer that
+            # backward folds into T's gradient as g * act'(T).
+            key = (v.tensor.id, act)
+            if key not in self.act_views:
+                vt = self.new_tensor(v.tensor.H, v.tensor.W, v.tensor.C, 'actview%d_%s' % (act, v.tensor.name))
+                vt.grad_only = True
+                self.act_views[key] = (v.tensor, act, vt)
+            out.view_grad = self.act_views[key][2]
+        return out
 
     def relu(self, v, name=None):
         return self.activation(v, ACT_RELU, name)

@@ -239,7 +239,7 @@ def bn_backward(bn, g, z, act, partials, frozen=False, out=None, sums=None):
     dz = out if out is not None else g
     dp, ldd = _pl(dz)
     lib().bn_bwd_apply(gp, ldg, zp, ldz, _p(bn.scale), _p(bn.shift), act, _p(bn.mean), _p(bn.invstd), _p(bn.coef),
-                       dp, ldd, M, bn.C, _stream())
+                       dp, ldd, 0, M, bn.C, _stream())
     return dz
 
 
@@ -338,3 +338,34 @@ def upsample_softmax_ce(z, C, H, W, labels=None, ignore_index=255, want_probs=Fa
 def sgd_momentum(w, v, g, lr_dev, momentum=0.9, l2=0.0, grad_scale=1.0, l2_elem=None, lr_scale_elem=None):
     lib().sgd_momentum(_p(w), _p(v), _p(g), w.numel(), _p(lr_dev), float(momentum), float(l2), float(grad_scale),
                        _p(l2_elem), _p(lr_scale_elem), _stream())
+
+
+def act_bwd(g, z, act, out, accumulate=False):
+    """out (+)= g * act'(z): backward of a bare activation on a materialised tensor"""
+    gp, ldg = _pl(g)
+    zp, ldz = _pl(z)
+    op, ldo = _pl(out)
+    lib().bn_bwd_apply(gp, ldg, zp, ldz, None, None, act, None, None, None, op, ldo, int(accumulate), _rows(z),
+                       z.shape[-1], _stream())
+    return out
+
+
+def im2col(x, k, stride=1, rate=1, padding='same', in_scale=None, in_shift=None, in_act=ACT_NONE):
+    N, H, W, Cin = x.shape
+    Ho, Wo, pt, pl = conv_geometry(H, W, k, stride, rate, padding)
+    kp = (k * k * Cin + 3) // 4 * 4
+    col = torch.empty((N, Ho, Wo, kp), dtype=torch.float32, device=x.device)
+    xp, ldx = _pl(x)
+    lib().im2col(xp, ldx, _p(in_scale), _p(in_shift), in_act, _p(col), kp, N, H, W, Cin, k, stride, rate, pt, pl, Ho, Wo,
+                 _stream())
+    return col
+
+
+def col2im(gcol, x_shape, k, stride=1, rate=1, padding='same', out=None, accumulate=False):
+    N, H, W, Cin = x_shape
+    Ho, Wo, pt, pl = conv_geometry(H, W, k, stride, rate, padding)
+    gx = out if out is not None else torch.empty(x_shape, dtype=torch.float32, device=gcol.device)
+    gp, ldg = _pl(gx)
+    lib().col2im(_p(gcol), gcol.shape[-1], gp, ldg, int(accumulate), N, H, W, Cin, k, stride, rate, pt, pl, Ho, Wo,
+                 _stream())
+    return gx
