@@ -176,6 +176,13 @@ int dl3p_dropout_mask(float dropout_rate, uint64_t seed, const int64_t* step_cou
                       void* stream);
 /* y = x * s[n]  with s (N,1,1,C) broadcast over HW pixels: SE block Multiply
  * (deeplabv3p_mobilenetv3.py:145); x/s may carry prologues. */
+int dl3p_scale_bcast_fwd(const float* x, int ldx, const float* scale, const float* shift, int act,
+                         const float* s, int lds, int s_act, float* y, int ldy, int N, int HW, int C, void* stream);
+/* backward of the above: gx (+)= gy * act_s(s)[n]   (gradient w.r.t. act(x*scale+shift));
+ * gs[n][c] = sum over the image's pixels of gy * act(x*scale+shift)  (gradient w.r.t. act_s(s)) */
+int dl3p_scale_bcast_bwd(const float* gy, int ldgy, const float* x, int ldx, const float* scale, const float* shift,
+                         int act, const float* s, int lds, int s_act, float* gx, int ldgx, int accumulate_gx,
+                         float* gs, int ldgs, int N, int HW, int C, void* stream);
 int dl3p_fill(float* p, float value, size_t n, void* stream);
 int dl3p_increment_counter(int64_t* counter, void* stream);
 

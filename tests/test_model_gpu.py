@@ -53,6 +53,12 @@ def _act_derivs(m, ex):
             out[bn.name] = (a > 0).astype(np.float64)
         elif bn.act == ops.ACT_RELU6:
             out[bn.name] = ((a > 0) & (a < 6)).astype(np.float64)
+        elif bn.act == ops.ACT_HSWISH:
+            u = ops.affine_act(z, sc, sh, ops.ACT_NONE).cpu().numpy().astype(np.float64)
+            inner = ((u + 3) > 0) & ((u + 3) < 6)
+            out[bn.name] = np.minimum(np.maximum(u + 3, 0), 6) / 6.0 + u * inner / 6.0
+        else:
+            raise NotImplementedError(bn.act)
     return out
 
 
@@ -86,7 +92,8 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / max(1e-6, np.abs(b).max()))
 
 
-@pytest.mark.parametrize('model_type,H,W', [('mobilenetv2', 65, 65), ('mobilenetv2_lite', 65, 97), ('xception', 65, 65)])
+@pytest.mark.parametrize('model_type,H,W', [('mobilenetv2', 65, 65), ('mobilenetv2_lite', 65, 97), ('xception', 65, 65),
+                                            ('mobilenetv3large', 65, 65), ('mobilenetv3large', 64, 96)])
 def test_predict_matches_oracle(model_type, H, W):
     m, o = _pair(model_type, H, W, 21, training=False)
     x, _ = _data(2, H, W, 21)
@@ -102,7 +109,8 @@ def test_predict_matches_oracle(model_type, H, W):
 
 
 @pytest.mark.parametrize('model_type,H,W,freeze', [('mobilenetv2', 65, 65, 0), ('mobilenetv2_lite', 65, 65, 0),
-                                                   ('mobilenetv2', 65, 65, 1), ('xception', 65, 65, 0)])
+                                                   ('mobilenetv2', 65, 65, 1), ('xception', 65, 65, 0),
+                                                   ('mobilenetv3large', 65, 65, 0), ('mobilenetv3large', 64, 96, 0)])
 def test_train_step_matches_oracle(model_type, H, W, freeze):
     N, C = 2, 21
     m, o = _pair(model_type, H, W, C, freeze_level=freeze)

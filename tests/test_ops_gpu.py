@@ -264,6 +264,43 @@ def test_head_softmax_ce(ops, C, ignore):
     assert float(out['dlogits'][..., C:].abs().max()) == 0.0
 
 
+def test_se_multiply_and_bare_activation(ops):
+    rng = np.random.default_rng(21)
+    N, H, W, C = 3, 7, 9, 24
+    x = rng.standard_normal((N, H, W, C)); s = rng.standard_normal((N, 1, 1, C)) * 2
+    sc = rng.uniform(0.5, 1.5, C); sh = rng.standard_normal(C) * 0.3
+    a = O.act_fwd(x * sc + sh, O.ACT_HSWISH)
+    sv = O.act_fwd(s, O.ACT_HSIGMOID)
+    y = ops.scale_bcast_fwd(T(x), T(s), T(sc), T(sh), ops.ACT_HSWISH, ops.ACT_HSIGMOID)
+    close(y, a * sv, what='se multiply')
+    gy = rng.standard_normal((N, H, W, C))
+    gx, gs = ops.scale_bcast_bwd(T(gy), T(x), T(s), T(sc), T(sh), ops.ACT_HSWISH, ops.ACT_HSIGMOID)
+    close(gx, gy * sv, what='se bwd x')
+    close(gs, (gy * a).sum((1, 2), keepdims=True), rtol=3e-4, what='se bwd s')
+    base = rng.standard_normal(s.shape)
+    out = ops.act_bwd(T(gs.cpu().numpy()), T(s), ops.ACT_HSIGMOID, T(base), accumulate=True)
+    close(out, base + O.act_bwd(s, gs.cpu().numpy().astype(np.float64), O.ACT_HSIGMOID), rtol=3e-4, what='bare act bwd')
+
+
+@pytest.mark.parametrize('case', [(2, 17, 17, 8, 3, 1, 'same'), (1, 16, 20, 16, 1, 2, (0, 0, 0, 0)), (2, 9, 9, 4, 3, 2, (1, 1, 1, 1))])
+def test_im2col_col2im(ops, case):
+    N, H, W, Cin, k, s, pad = case
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((N, H, W, Cin))
+    w = rng.standard_normal((k, k, Cin, 12)) * 0.2
+    col = ops.im2col(T(x), k, s, 1, pad)
+    y = col.reshape(-1, col.shape[-1]).double().cpu().numpy()[:, :k * k * Cin] @ w.reshape(-1, 12)
+    y_ref = O.conv2d_fwd(x, w, s, 1, pad)
+    close(y.reshape(y_ref.shape), y_ref, what='im2col @ w == conv')
+    gy = rng.standard_normal(y_ref.shape)
+    gx_ref, _, _ = O.conv2d_bwd(x, w, gy, s, 1, pad)
+    kp = col.shape[-1]
+    gcol = np.zeros((gy.reshape(-1, 12).shape[0], kp))
+    gcol[:, :k * k * Cin] = gy.reshape(-1, 12) @ w.reshape(-1, 12).T
+    gx = ops.col2im(T(gcol.reshape(col.shape)), (N, H, W, Cin), k, s, 1, pad)
+    close(gx, gx_ref, rtol=3e-4, what='col2im')
+
+
 def test_sgd(ops):
     rng = np.random.default_rng(2)
     n = 1003

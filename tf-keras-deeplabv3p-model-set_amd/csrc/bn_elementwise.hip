@@ -622,6 +622,100 @@ extern "C" int dl3p_global_avgpool_bwd(const float* gy, int ldgy, float* gx, int
   return DL3P_OK;
 }
 
+// ------------------------------------------------------------------------------ SE-block multiply
+// y[n,p,c] = act(x*scale+shift) * act_s(s[n,c])  (deeplabv3p_mobilenetv3.py:145 Multiply); one workgroup per
+// (image, channel slab) like the pooling kernel, so the backward's per-image reduction needs no atomics
+__global__ __launch_bounds__(256) void scale_bcast_fwd_kernel(EwParams p, int HW, const float* s, int lds, int s_act) {
+  const int n = blockIdx.x / p.nslab;
+  const int slab = blockIdx.x - n * p.nslab;
+  const int pl = threadIdx.x / p.c4s;
+  const int cl = threadIdx.x - pl * p.c4s;
+  if (pl >= p.px) return;
+  const int c = (slab * p.c4s + cl) * 4;
+  const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+  const float4 sc = opt_ld4(p.scale, c, one), sh = opt_ld4(p.shift, c, zero4());
+  const float4 sv = act_apply4(ld4(s + (size_t)n * lds + c), s_act);
+  const float* base = p.a + (size_t)n * HW * p.lda + c;
+  float* ob = p.out + (size_t)n * HW * p.ldo + c;
+  for (int i = pl; i < HW; i += p.px)
+    st4(ob + (size_t)i * p.ldo, mul4(act_apply4(fma4(ld4(base + (size_t)i * p.lda), sc, sh), p.act), sv));
+}
+
+__global__ __launch_bounds__(256) void scale_bcast_bwd_kernel(EwParams p, int HW, const float* s, int lds, int s_act,
+                                                              const float* gy, int ldgy, float* gs, int ldgs) {
+  const int n = blockIdx.x / p.nslab;
+  const int slab = blockIdx.x - n * p.nslab;
+  const int pl = threadIdx.x / p.c4s;
+  const int cl = threadIdx.x - pl * p.c4s;
+  const bool active = pl < p.px;
+  const int cbase4 = slab * p.c4s;
+  const int c = (cbase4 + cl) * 4;
+  float4 acc[1] = {zero4()};
+  if (active) {
+    const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 sc = opt_ld4(p.scale, c, one), sh = opt_ld4(p.shift, c, zero4());
+    const float4 sv = act_apply4(ld4(s + (size_t)n * lds + c), s_act);
+    const float* xb = p.a + (size_t)n * HW * p.lda + c;
+    const float* gb = gy + (size_t)n * HW * ldgy + c;
+    float* ob = p.out + (size_t)n * HW * p.ldo + c;
+    for (int i = pl; i < HW; i += p.px) {
+      const float4 g = ld4(gb + (size_t)i * ldgy);
+      const float4 a = act_apply4(fma4(ld4(xb + (size_t)i * p.lda), sc, sh), p.act);
+      acc[0] = fma4(g, a, acc[0]);
+      float4 o = mul4(g, sv);
+      if (p.accumulate) o = add4(o, ld4(ob + (size_t)i * p.ldo));
+      st4(ob + (size_t)i * p.ldo, o);
+    }
+  }
+  block_reduce_store<1>(acc, active, pl, cl, p.c4s, p.px, cbase4, ldgs, gs + (size_t)n * ldgs);
+}
+
+static void se_lanes(EwParams& p, int C) {
+  const int c4 = C / 4;
+  int d = 1;
+  for (int k = 1; k <= 16 && k <= c4; ++k) if (c4 % k == 0) d = k;
+  p.c4s = d; p.px = 256 / d; p.nslab = c4 / d; p.C = C;
+}
+
+extern "C" int dl3p_scale_bcast_fwd(const float* x, int ldx, const float* scale, const float* shift, int act,
+                                    const float* s, int lds, int s_act, float* y, int ldy, int N, int HW, int C,
+                                    void* stream) {
+  int rc = check_ew("dl3p_scale_bcast_fwd", x, ldx, C);
+  if (rc) return rc;
+  rc = check_ew("dl3p_scale_bcast_fwd", y, ldy, C);
+  if (rc) return rc;
+  rc = check_ew("dl3p_scale_bcast_fwd", s, lds, C);
+  if (rc) return rc;
+  EwParams p = {};
+  p.a = x; p.lda = ldx; p.scale = scale; p.shift = shift; p.act = act; p.out = y; p.ldo = ldy;
+  se_lanes(p, C);
+  hipLaunchKernelGGL(scale_bcast_fwd_kernel, dim3(N * p.nslab), dim3(256), 0, (hipStream_t)stream, p, HW, s, lds, s_act);
+  DL3P_CHECK_LAUNCH("dl3p_scale_bcast_fwd");
+  return DL3P_OK;
+}
+
+extern "C" int dl3p_scale_bcast_bwd(const float* gy, int ldgy, const float* x, int ldx, const float* scale,
+                                    const float* shift, int act, const float* s, int lds, int s_act, float* gx,
+                                    int ldgx, int accumulate_gx, float* gs, int ldgs, int N, int HW, int C,
+                                    void* stream) {
+  int rc = check_ew("dl3p_scale_bcast_bwd", gy, ldgy, C);
+  if (rc) return rc;
+  rc = check_ew("dl3p_scale_bcast_bwd", x, ldx, C);
+  if (rc) return rc;
+  rc = check_ew("dl3p_scale_bcast_bwd", gx, ldgx, C);
+  if (rc) return rc;
+  rc = check_ew("dl3p_scale_bcast_bwd", gs, ldgs, C);
+  if (rc) return rc;
+  EwParams p = {};
+  p.a = x; p.lda = ldx; p.scale = scale; p.shift = shift; p.act = act; p.out = gx; p.ldo = ldgx;
+  p.accumulate = accumulate_gx;
+  se_lanes(p, C);
+  hipLaunchKernelGGL(scale_bcast_bwd_kernel, dim3(N * p.nslab), dim3(256), 0, (hipStream_t)stream, p, HW, s, lds,
+                     s_act, gy, ldgy, gs, ldgs);
+  DL3P_CHECK_LAUNCH("dl3p_scale_bcast_bwd");
+  return DL3P_OK;
+}
+
 // ------------------------------------------------------------------------------ SGD momentum
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, float* __restrict__ v,
                                                   const float* __restrict__ g, size_t n4, size_t n,

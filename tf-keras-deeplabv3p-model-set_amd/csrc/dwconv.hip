@@ -23,7 +23,7 @@ struct DwParams {
   const float* dy; int lddy;   // bwd_weight only
   float* partials;
   int N, H, W, C, Ho, Wo, stride, rate, pad_t, pad_l;
-  int c4s, px, nslab, nbx, spr, th, nbands, ks;
+  int c4s, px, nslab, nbx, spr, th, nbands, ks, ks5;
   long long total;
   int flip, accumulate;
 };
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_seg(DwParams p) {
 // arithmetic (taps in the padding issue nothing), served by the XCD's L2.
 template <int KS, int PRO>
 __global__ __launch_bounds__(256) void dw_fwd_gather(DwParams p) {
-  constexpr int TI = 2;
+  constexpr int TI = KS == 3 ? 2 : 1;   // 5x5: 25 taps per pixel already fill the registers
   const int b = blockIdx.x;
   const int slab = b / p.nbx;
   const int bx = b - slab * p.nbx;
@@ -620,7 +620,9 @@ static int pick_band(long long items_per_row_band, int rows, int px, int nslab) 
 //   kind 0: per-pixel gather (stride > 1 with rate > 1, or maps narrower than a strip)
 static int fwd_plan(DwParams& p) {
   int kind = 0;
-  if (p.stride == 1 && ceil_div(p.Wo, p.rate) >= 4) kind = 1;
+  // (5x5 kernels use the per-pixel gather: a 5-row window plus 25 weights does not fit the register file)
+  if (p.ks5) kind = 0;
+  else if (p.stride == 1 && ceil_div(p.Wo, p.rate) >= 4) kind = 1;
   else if (p.stride == 2 && p.rate == 1 && p.Wo >= 4) kind = 2;
   if (kind == 0 && p.ks == 3 && p.stride == 1 && p.pad_t == p.rate && p.pad_l == p.rate && p.Ho == p.H && p.Wo == p.W &&
       2 * p.rate >= p.H && 2 * p.rate >= p.W && p.rate < p.H && p.rate < p.W &&
@@ -659,6 +661,7 @@ template <int KS>
 static void launch_fwd(const DwParams& p0, hipStream_t st) {
   DwParams p = p0;
   p.ks = KS;
+  p.ks5 = KS == 5;
   const int kind = fwd_plan(p);
   dim3 grid(p.nbx * p.nslab);
   const int pro = (p.act != DL3P_ACT_NONE) ? 2 : (p.scale ? 1 : 0);
@@ -685,6 +688,7 @@ extern "C" int dl3p_dwconv2d_fwd(const float* x, int ldx, const float* in_scale,
   {
     DwParams q = p;
     q.ks = k;
+    q.ks5 = k == 5;
     fwd_plan(q);
     if (rows_out) *rows_out = q.nbx;
   }
@@ -761,6 +765,7 @@ extern "C" int dl3p_dwconv2d_bwd_weight(const float* x, int ldx, const float* in
   p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.rate = rate;
   p.pad_t = pad_t; p.pad_l = pad_l;
   pick_lanes(C, &p.c4s, &p.px, &p.nslab);
+  p.ks5 = k == 5;
   const int kind = fwd_plan(p);
   dim3 grid(p.nbx * p.nslab);
   const int pro = (in_act != DL3P_ACT_NONE) ? 2 : (in_scale ? 1 : 0);

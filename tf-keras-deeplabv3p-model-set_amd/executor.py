@@ -322,6 +322,8 @@ class Executor:
                 setrg(op.out, rg(op.x) or (op.r is not None and rg(op.r)))
             elif k in ('gap', 'resize', 'broadcast'):
                 setrg(op.out, rg(op.x))
+            elif k == 'se_mul':
+                setrg(op.out, rg(op.x) or rg(op.s))
         for (t, act, vt) in self.g.act_views.values():
             setrg(vt, t.requires_grad or t.root.requires_grad)
 
@@ -392,6 +394,11 @@ class Executor:
                 xt = op.x.tensor
                 P.k(L.global_avgpool_fwd, xp, ldx, sp, hp, act, self.tptr(op.out), op.out.ld, 1.0, N, xt.H * xt.W,
                     xt.C)
+            elif k == 'se_mul':
+                xp, ldx, sp, hp, act = self.vargs(op.x)
+                s_ptr, lds, _, _, sact = self.vargs(op.s)
+                t = op.out
+                P.k(L.scale_bcast_fwd, xp, ldx, sp, hp, act, s_ptr, lds, sact, self.tptr(t), t.ld, N, t.H * t.W, t.C)
             elif k in ('resize', 'broadcast'):
                 xt, t = op.x.tensor, op.out
                 P.k(L.resize_bilinear_fwd, self.tptr(xt), xt.ld, self.tptr(t), t.ld, N, xt.H, xt.W, xt.C, t.H, t.W)
@@ -537,6 +544,14 @@ class Executor:
                 if op.r is not None and (op.r.tensor.requires_grad or op.r.tensor.root.requires_grad):
                     gp, ldg, keyt = self._gbuf(op.r)
                     P.k(L.scale_mask_bwd, gt, ldt, 0.0, 0, None, gp, ldg, self._acc(keyt), M, out.C)
+            elif k == 'se_mul':
+                xp, ldx, sp, hp, act = self.vargs(op.x)
+                s_ptr, lds, _, _, sact = self.vargs(op.s)
+                gp, ldg, keyx = self._gbuf(op.x)
+                gsp, ldgs, keys = self._gbuf(op.s)
+                assert self._acc(keys) == 0, 'SE scale gradient has a single producer'
+                P.k(L.scale_bcast_bwd, self.tptr(out, True), out.ld, xp, ldx, sp, hp, act, s_ptr, lds, sact, gp, ldg,
+                    self._acc(keyx), gsp, ldgs, N, out.H * out.W, out.C)
             elif k == 'gap':
                 xt = op.x.tensor
                 gp, ldg, keyt = self._gbuf(op.x)

@@ -345,6 +345,14 @@ class GraphBuilder:
         self.add_layer(name, 'Dropout', v.shape)
         return self.materialize(v, dropout=rate, name=name)
 
+    def se_multiply(self, x, s, name=None):
+        """Multiply([x, s]) with s (1,1,C) broadcast over the pixels (reference deeplabv3p_mobilenetv3.py:145)"""
+        H, W, C = x.shape
+        self.add_layer(name, 'Multiply', (H, W, C))
+        out = self.new_tensor(H, W, C, name or ('semul_' + x.tensor.name))
+        self.ops.append(Op('se_mul', name=out.name, x=x, s=s, out=out))
+        return Value(out)
+
     def global_avgpool(self, v, name=None, kind='AveragePooling2D'):
         H, W, C = v.shape
         self.add_layer(name, kind, (1, 1, C))

@@ -369,3 +369,26 @@ def col2im(gcol, x_shape, k, stride=1, rate=1, padding='same', out=None, accumul
     lib().col2im(_p(gcol), gcol.shape[-1], gp, ldg, int(accumulate), N, H, W, Cin, k, stride, rate, pt, pl, Ho, Wo,
                  _stream())
     return gx
+
+
+def scale_bcast_fwd(x, s, scale=None, shift=None, act=ACT_NONE, s_act=ACT_NONE, out=None):
+    """y = act(x*scale+shift) * s_act(s)[n]  with s (N,1,1,C): the SE-block Multiply"""
+    N, H, W, C = x.shape
+    y = out if out is not None else torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    xp, ldx = _pl(x)
+    sp, lds = _pl(s)
+    yp, ldy = _pl(y)
+    lib().scale_bcast_fwd(xp, ldx, _p(scale), _p(shift), act, sp, lds, s_act, yp, ldy, N, H * W, C, _stream())
+    return y
+
+
+def scale_bcast_bwd(gy, x, s, scale=None, shift=None, act=ACT_NONE, s_act=ACT_NONE):
+    N, H, W, C = x.shape
+    gx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    gs = torch.empty((N, 1, 1, C), dtype=torch.float32, device=x.device)
+    gp, ldg = _pl(gy)
+    xp, ldx = _pl(x)
+    sp, lds = _pl(s)
+    lib().scale_bcast_bwd(gp, ldg, xp, ldx, _p(scale), _p(shift), act, sp, lds, s_act, _p(gx), C, 0, _p(gs), C, N, H * W, C,
+                          _stream())
+    return gx, gs
