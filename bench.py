@@ -35,6 +35,7 @@ def parse():
     ap.add_argument('--size', type=int, default=513)
     ap.add_argument('--model', default='mobilenetv2')
     ap.add_argument('--classes', type=int, default=21)
+    ap.add_argument('--os', type=int, default=16, help='output stride')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-sync-bn', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -89,7 +90,7 @@ def main():
     H = W = args.size
     N, C = args.batch, args.classes
 
-    model = pkg.get_deeplabv3p_model(args.model, C, (H, W), 16, freeze_level=0, training=True)
+    model = pkg.get_deeplabv3p_model(args.model, C, (H, W), args.os, freeze_level=0, training=True)
     model.compile(optimizer=pkg.SGD(0.01, momentum=0.9), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255),
                   sync_bn=not args.no_sync_bn)
     model.use_graphs = not args.no_graph

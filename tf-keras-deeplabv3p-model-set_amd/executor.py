@@ -570,6 +570,8 @@ class Executor:
                 raise NotImplementedError(k)
         if self.dist is not None:
             P.py(lambda hi=self._first_bucket_hi: self.dist.all_reduce_async(G[0:hi]))
+            # join the side stream inside this plan: a captured graph may not end with forked work in flight
+            P.py(self.dist.wait_all)
         return P
 
     def _bucket_edges(self):
@@ -628,7 +630,6 @@ class Executor:
         P, L, st = Plan(), self.L, self.store
         scale = 1.0
         if self.dist is not None:
-            P.py(self.dist.wait_all)          # gradient buckets were all-reduced beside backward
             scale = 1.0 / self.dist.world_size
         P.k(L.sgd_momentum, st.P.data_ptr(), st.V.data_ptr(), st.G.data_ptr(), st.total, self.lr.data_ptr(),
             float(self.momentum), 0.0, scale, st.l2.data_ptr(), st.lr_scale.data_ptr())
