@@ -69,6 +69,20 @@ def cpu_baseline(args):
                       'the tf.keras reference itself is not installable here' % (args.cpu_steps, H, W, B)}
 
 
+def measured_traffic(kernel_name):
+    """HBM bytes per launch of the roofline kernel from the newest committed PMC pass (profiles/*_roofline_traffic.json,
+    written by scripts/collect_profiles.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied)"""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_roofline_traffic.json')), reverse=True):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get('kernel') and d['kernel'] in (kernel_name or ''):
+            return int(d['traffic_bytes']), os.path.basename(f)
+    return None, None
+
+
 def main():
     args = parse()
     import numpy as np
@@ -155,8 +169,10 @@ def main():
             t = op.out
             algo = 2.0 * N * t.H * t.W * op.c * 4 + op.k * op.k * op.c * 4     # read x once, write y once, weights
             ach = algo / (ms * 1e-3) / 1e9
+            traffic, src = (measured_traffic(probe.kernel_name) if (args.size, N, args.model) == (513, 16, 'mobilenetv2')
+                            else (None, None))
             out['roofline'] = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                               'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+                               'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': src,
                                'kernel': probe.kernel_name, 'avg_us': round(ms * 1e3, 3),
                                'algorithmic_bytes': int(algo),
                                'shape': 'N=%d %dx%dx%d k=%d rate=%d' % (N, t.H, t.W, op.c, op.k, op.rate)}
