@@ -228,7 +228,7 @@ int dl3p_sgd_momentum(float* w, float* v, const float* g, size_t n, const float*
                       float l2, float grad_scale, const float* l2_elem, const float* lr_scale_elem, void* stream);
 
 /* ---------------------------------------------------------------- measurement hook
- * dl3p_probe_arm(i): the NEXT depthwise-forward launch of the calling thread is issued with a pair of HIP
+ * dl3p_probe_arm(i): the NEXT depthwise-forward or pointwise-GEMM kernel launch of the calling thread is issued with a pair of HIP
  * events (hipExtLaunchKernelGGL start/stop events on the launch stream) stored in slot i (0 <= i < 4096);
  * dl3p_probe_read(i, &ms) waits for slot i's stop event and returns the kernel's duration in ms.
  * Used by bench.py to time the rate-18 atrous kernel inside the timed steps (roofline). */

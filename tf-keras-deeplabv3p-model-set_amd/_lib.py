@@ -75,6 +75,7 @@ class Lib:
                 raise Dl3pError('%s failed (%d): %s' % (name, rc, err().decode()))
             return rc
         call.raw = fn
+        call.__name__ = name
         return call
 
 

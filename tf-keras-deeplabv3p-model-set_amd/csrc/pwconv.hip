@@ -21,6 +21,7 @@
 // the next tile is issued before the current tile's MFMAs (register double buffering) and applies the
 // producer's BN+activation on the way in, so normalised activations are never materialised in HBM.
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -37,6 +38,10 @@ struct GemmParams {
   int M, K, N;
   int accumulate;
   int num_m_tiles;
+  int stagger;
+#ifdef DL3P_STAMP
+  long long* stamp;   // dev instrument: per-wave cycle counts of the loop phases (scripts/micro/stamp_gemm.py)
+#endif
 };
 
 // B_KN: B is [Kred][Nout] row-major (forward: the Keras kernel as stored);
@@ -69,16 +74,80 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
   const int my_tiles = (p.num_m_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int it_total = my_tiles * nk;
 
-  // staging roles
+  // staging roles.  Every global load of the K loop is UNCONDITIONAL on a clamped 32-bit byte offset
+  // (rows >= M re-read row M-1, columns >= K re-read the last float4) and invalid lanes are zeroed by a
+  // select when the tile is written to LDS: no exec-masked branch per load (13 of them per K-step
+  // before), one v_add per address.  Hosts reject operands of 4 GiB or more.
   const int ar = t >> 3;         // A row within a 32-row pass
   const int akq = (t & 7) * 4;   // A k offset within the K tile
+  const char* Ab = reinterpret_cast<const char*>(p.A);
+  const char* Bb = reinterpret_cast<const char*>(p.B);
 
   float4 ra[2 * MI];
   float4 rb[NB4];
   float4 rsc = make_float4(1.f, 1.f, 1.f, 1.f), rsh = zero4();
-  int cur_m0 = 0;
+  uint32_t a_row[2 * MI];        // byte offset of this thread's A rows in the current M tile
+  uint32_t b_off[NB4];           // byte offset of this thread's B float4s at k0 = 0
+  bool b_nok[NB4];               // column (B_KN) / row (!B_KN) of the B tile inside the matrix
+  int pf_m0 = -1;
+#pragma unroll
+  for (int i = 0; i < NB4; ++i) {
+    const int idx = min(t + 256 * i, 8 * BN - 1);
+    if (B_KN) {
+      const int kk = idx / (BN / 4), nq = idx - kk * (BN / 4);
+      const int n = n0 + nq * 4;
+      b_nok[i] = (t + 256 * i < 8 * BN) && n < p.N;
+      b_off[i] = (uint32_t)(min(n, p.N - 4)) * 4u;    // + k * ldb * 4 per K-step
+    } else {
+      const int r = idx >> 3;
+      const int n = n0 + r;
+      b_nok[i] = (t + 256 * i < 8 * BN) && n < p.N;
+      b_off[i] = (uint32_t)min(n, p.N - 1) * (uint32_t)p.ldb * 4u;   // + k * 4 per K-step
+    }
+  }
 
   auto prefetch = [&](int it) {
+    const int kt = it % nk;
+    const int mt = blockIdx.x + (it / nk) * gridDim.x;
+    const int m0 = mt * BM;
+    const int k0 = kt * BK;
+    if (m0 != pf_m0) {
+      pf_m0 = m0;
+#pragma unroll
+      for (int i = 0; i < 2 * MI; ++i) a_row[i] = (uint32_t)min(m0 + ar + 32 * i, p.M - 1) * (uint32_t)p.lda * 4u;
+    }
+    const uint32_t kb = (uint32_t)min(k0 + akq, p.K - 4) * 4u;
+#pragma unroll
+    for (int i = 0; i < 2 * MI; ++i) ra[i] = *reinterpret_cast<const float4*>(Ab + (a_row[i] + kb));
+    if (p.scale) {
+      rsc = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.scale) + kb);
+      rsh = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.shift) + kb);
+    }
+#pragma unroll
+    for (int i = 0; i < NB4; ++i) {
+      const int idx = min(t + 256 * i, 8 * BN - 1);
+      if (B_KN) {
+        const int kk = idx / (BN / 4);
+        rb[i] = *reinterpret_cast<const float4*>(Bb + (b_off[i] + (uint32_t)min(k0 + kk, p.K - 1) * (uint32_t)p.ldb * 4u));
+      } else {
+        const int kq = (idx & 7) * 4;
+        rb[i] = *reinterpret_cast<const float4*>(Bb + (b_off[i] + (uint32_t)min(k0 + kq, p.K - 4) * 4u));
+      }
+    }
+  };
+
+  // producer's BatchNormalization + activation on the way into LDS.  relu / relu6 / none are one
+  // fma + one v_med3 per element; the hard-swish family takes the general form (wave-uniform branch).
+  const float act_lo = p.act == DL3P_ACT_NONE ? -DL3P_INF : 0.f;
+  const float act_hi = (p.act == DL3P_ACT_NONE || p.act == DL3P_ACT_RELU) ? DL3P_INF : 6.f;
+  auto prologue4 = [&](float4 v) {
+    v = fma4(v, rsc, rsh);
+    if (p.act >= DL3P_ACT_HSWISH) return act_apply4(v, p.act);
+    return make_float4(__builtin_amdgcn_fmed3f(v.x, act_lo, act_hi), __builtin_amdgcn_fmed3f(v.y, act_lo, act_hi),
+                       __builtin_amdgcn_fmed3f(v.z, act_lo, act_hi), __builtin_amdgcn_fmed3f(v.w, act_lo, act_hi));
+  };
+
+  auto stage = [&](int it) {
     const int kt = it % nk;
     const int mt = blockIdx.x + (it / nk) * gridDim.x;
     const int m0 = mt * BM;
@@ -86,37 +155,11 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
     const bool kok = k0 + akq < p.K;
 #pragma unroll
     for (int i = 0; i < 2 * MI; ++i) {
-      const int m = m0 + ar + 32 * i;
-      ra[i] = (kok && m < p.M) ? ld4(p.A + (size_t)m * p.lda + k0 + akq) : zero4();
-    }
-    if (p.scale && kok) { rsc = ld4(p.scale + k0 + akq); rsh = ld4(p.shift + k0 + akq); }
-#pragma unroll
-    for (int i = 0; i < NB4; ++i) {
-      const int idx = t + 256 * i;
-      if (B_KN) {
-        const int kk = idx / (BN / 4), nq = idx - kk * (BN / 4);
-        const int k = k0 + kk, n = n0 + nq * 4;
-        rb[i] = (idx < 8 * BN && k < p.K && n < p.N) ? ld4(p.B + (size_t)k * p.ldb + n) : zero4();
-      } else {
-        const int r = idx >> 3, kq = (idx & 7) * 4;
-        const int n = n0 + r, k = k0 + kq;
-        rb[i] = (idx < 8 * BN && n < p.N && k < p.K) ? ld4(p.B + (size_t)n * p.ldb + k) : zero4();
-      }
-    }
-  };
-
-  auto stage = [&](int it) {
-    const int kt = it % nk;
-    const int mt = blockIdx.x + (it / nk) * gridDim.x;
-    const int m0 = mt * BM;
-    const bool kok = kt * BK + akq < p.K;
-#pragma unroll
-    for (int i = 0; i < 2 * MI; ++i) {
       const int r = ar + 32 * i;
-      float4 v = ra[i];
       // zero rows/cols stay exactly zero (padding of the M and K tails)
-      if (kok && m0 + r < p.M) v = act_apply4(fma4(v, rsc, rsh), p.act);
-      *reinterpret_cast<float4*>(&As[r * APITCH + akq]) = v;
+      const float4 v = prologue4(ra[i]);
+      const bool ok = kok && m0 + r < p.M;
+      *reinterpret_cast<float4*>(&As[r * APITCH + akq]) = ok ? v : zero4();
     }
 #pragma unroll
     for (int i = 0; i < NB4; ++i) {
@@ -124,10 +167,10 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
       if (idx < 8 * BN) {
         if (B_KN) {
           const int kk = idx / (BN / 4), nq = idx - kk * (BN / 4);
-          *reinterpret_cast<float4*>(&Bs[kk * BPITCH + nq * 4]) = rb[i];
+          *reinterpret_cast<float4*>(&Bs[kk * BPITCH + nq * 4]) = (b_nok[i] && k0 + kk < p.K) ? rb[i] : zero4();
         } else {
           const int r = idx >> 3, kq = (idx & 7) * 4;
-          *reinterpret_cast<float4*>(&Bs[r * APITCH + kq]) = rb[i];
+          *reinterpret_cast<float4*>(&Bs[r * APITCH + kq]) = (b_nok[i] && k0 + kq < p.K) ? rb[i] : zero4();
         }
       }
     }
@@ -144,10 +187,21 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
     for (int i = 0; i < NPASS; ++i) { st_s[i] = zero4(); st_q[i] = zero4(); }
   }
 
+#ifdef DL3P_STAMP
+  long long tacc[5] = {0, 0, 0, 0, 0};
+  long long t0 = __builtin_amdgcn_s_memtime(), t1;
+#define STAMP(i) { t1 = __builtin_amdgcn_s_memtime(); tacc[i] += t1 - t0; t0 = t1; }
+#else
+#define STAMP(i) {}
+#endif
+  if (p.stagger > 0 && (int)(blockIdx.x + gridDim.x * blockIdx.y) >= 256)
+    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(16);
   if (it_total > 0) prefetch(0);
   for (int it = 0; it < it_total; ++it) {
     stage(it);
+    STAMP(0)
     __syncthreads();
+    STAMP(1)
     if (it + 1 < it_total) prefetch(it + 1);
 #pragma unroll
     for (int g = 0; g < BK / 16; ++g) {
@@ -175,7 +229,9 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
         }
       }
     }
+    STAMP(2)
     __syncthreads();
+    STAMP(3)
     if (it % nk == nk - 1) {
       // epilogue of this M tile.  After the MFMAs a lane holds 4 consecutive channels of pixel l15 per
       // accumulator; stored directly that is 16 rows x 64 B per store instruction (half cache lines,
@@ -202,27 +258,44 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
         }
         const int n = n0 + ni0 * 16 + cq * 4;
         const bool col_ok = (ni0 * 16 + cq * 4 < BN) && (cq * 4 < CH) && n < p.N && (ni0 + cq / 4 < NT);
-        float4 bias4 = zero4();
-        if (p.bias && col_ok) bias4 = ld4(p.bias + n);
+        const int row_lim = p.M - (m0 + w * RW);     // valid rows of this wave's slice (wave-uniform)
+        if (col_ok) {
+          float4 bias4 = zero4();
+          if (p.bias) bias4 = ld4(p.bias + n);
+          char* yb = reinterpret_cast<char*>(p.Y) + ((uint32_t)(m0 + w * RW + rr) * (uint32_t)p.ldy + (uint32_t)n) * 4u;
+          const uint32_t ystep = (uint32_t)p.ldy * 16u;   // 4 rows
+          auto rows = [&](auto full) {
 #pragma unroll
-        for (int r0 = 0; r0 < RW; r0 += 4) {
-          const int row = r0 + rr;
-          const int m = m0 + w * RW + row;
-          if (col_ok && m < p.M) {
-            float4 o = add4(*reinterpret_cast<const float4*>(&es[row * EPITCH + cq * 4]), bias4);
-            float* yp = p.Y + (size_t)m * p.ldy + n;
-            if (p.accumulate) o = add4(o, ld4(yp));
-            st4(yp, o);
-            if (STATS) {
-              st_s[ps] = add4(st_s[ps], o);
-              st_q[ps] = fma4(o, o, st_q[ps]);
+            for (int r0 = 0; r0 < RW; r0 += 4) {
+              const int row = r0 + rr;
+              if (decltype(full)::value || row < row_lim) {
+                float4 o = add4(*reinterpret_cast<const float4*>(&es[row * EPITCH + cq * 4]), bias4);
+                float* yp = reinterpret_cast<float*>(yb + (r0 / 4) * ystep);
+                if (p.accumulate) o = add4(o, ld4(yp));
+                st4(yp, o);
+                if (STATS) {
+                  st_s[ps] = add4(st_s[ps], o);
+                  st_q[ps] = fma4(o, o, st_q[ps]);
+                }
+              }
             }
-          }
+          };
+          if (row_lim >= RW) rows(std::true_type{});
+          else rows(std::false_type{});
         }
       }
+      STAMP(4)
     }
   }
 
+#ifdef DL3P_STAMP
+  STAMP(4)   // epilogues (the last one; earlier ones are counted with the next stage's wait)
+  if (p.stamp && l == 0) {
+    long long* o = p.stamp + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + w) * 8;
+    for (int i = 0; i < 5; ++i) o[i] = tacc[i];
+    o[5] = it_total;
+  }
+#endif
   if (STATS) {
     // reduce over the 4 row groups of the wave, then over the 4 waves; one partial row per workgroup
     const int rr = l >> 4, cq = l & 15;
@@ -256,13 +329,315 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------ ping-pong variant
+// Two of the workgroups above fused into one 512-thread workgroup: waves 0-3 ("half 0") and waves 4-7
+// ("half 1") each own a stream of M tiles with private LDS tiles, and alternate roles every barrier:
+// while one half issues its K-step's MFMAs the other half (its waves sit on the same four SIMDs) does
+// the non-matrix work of its next K-step -- waiting for the prefetched global loads, the BN+activation
+// prologue, the LDS writes, and the epilogue of a finished tile.  Two independent co-resident workgroups
+// run the same program in lockstep (both stage, then both contend for the matrix pipe: measured 6.8k
+// cycles per 4.1k-cycle MFMA block plus 2.5k of staging per K-step); the barrier-enforced anti-phase
+// keeps the matrix pipe fed from one half at a time (MI355X_MICROARCH.md, "Two waves per SIMD").
+template <int NT, bool B_KN, bool STATS, int MI>
+__global__ __launch_bounds__(512) void pw_gemm_pp_kernel(GemmParams p) {
+  constexpr int BM = 64 * MI;
+  constexpr int BN = 16 * NT;
+  constexpr int BPITCH = B_KN ? (BN + 4) : APITCH;
+  constexpr int AS_FLOATS = BM * APITCH;
+  constexpr int BS_FLOATS = B_KN ? BK * BPITCH : BN * APITCH;
+  constexpr int NB4 = (8 * BN + 255) / 256;
+  constexpr int TPP = NT < 4 ? NT : 4;
+  constexpr int NPASS = (NT + TPP - 1) / TPP;
+  constexpr int CH = 16 * TPP;
+  constexpr int EPITCH = CH + 4;
+  constexpr int RW = 16 * MI;
+  constexpr int ES_FLOATS = 4 * RW * EPITCH;
+  constexpr int RED_FLOATS = STATS ? 2 * 4 * BN : 0;
+  constexpr int HALF_FLOATS = AS_FLOATS + BS_FLOATS + ES_FLOATS + RED_FLOATS;
+  extern __shared__ __attribute__((aligned(16))) float pp_lds[];   // ONE LDS object (both halves)
+  const int half = threadIdx.x >> 8;
+  float* As = pp_lds + half * HALF_FLOATS;
+  float* Bs = As + AS_FLOATS;
+  float* Es = Bs + BS_FLOATS;
+  float* red = Es + ES_FLOATS;
+
+  const int t = threadIdx.x & 255;
+  const int l = t & 63;
+  const int w = t >> 6;
+  const int l15 = l & 15;
+  const int q = l >> 4;
+  const int n0 = blockIdx.y * BN;
+  const int nk = (p.K + BK - 1) / BK;
+  const int vb = blockIdx.x * 2 + half;          // virtual workgroup id: one per half
+  const int vgrid = gridDim.x * 2;
+  const int T = ((p.num_m_tiles - vb + vgrid - 1) / vgrid) * nk;              // my K-steps
+  const int T0 = ((p.num_m_tiles - (vb - half) + vgrid - 1) / vgrid) * nk;    // half 0's (>= half 1's)
+
+  const int ar = t >> 3;
+  const int akq = (t & 7) * 4;
+
+  float4 ra[2 * MI];
+  float4 rb[NB4];
+  float4 rsc = make_float4(1.f, 1.f, 1.f, 1.f), rsh = zero4();
+
+  auto prefetch = [&](int it) {
+    const int kt = it % nk;
+    const int mt = vb + (it / nk) * vgrid;
+    const int m0 = mt * BM;
+    const int k0 = kt * BK;
+    const bool kok = k0 + akq < p.K;
+#pragma unroll
+    for (int i = 0; i < 2 * MI; ++i) {
+      const int m = m0 + ar + 32 * i;
+      ra[i] = (kok && m < p.M) ? ld4(p.A + (size_t)m * p.lda + k0 + akq) : zero4();
+    }
+    if (p.scale && kok) { rsc = ld4(p.scale + k0 + akq); rsh = ld4(p.shift + k0 + akq); }
+#pragma unroll
+    for (int i = 0; i < NB4; ++i) {
+      const int idx = t + 256 * i;
+      if (B_KN) {
+        const int kk = idx / (BN / 4), nq = idx - kk * (BN / 4);
+        const int k = k0 + kk, n = n0 + nq * 4;
+        rb[i] = (idx < 8 * BN && k < p.K && n < p.N) ? ld4(p.B + (size_t)k * p.ldb + n) : zero4();
+      } else {
+        const int r = idx >> 3, kq = (idx & 7) * 4;
+        const int n = n0 + r, k = k0 + kq;
+        rb[i] = (idx < 8 * BN && n < p.N && k < p.K) ? ld4(p.B + (size_t)n * p.ldb + k) : zero4();
+      }
+    }
+  };
+
+  auto stage = [&](int it) {
+    const int kt = it % nk;
+    const int mt = vb + (it / nk) * vgrid;
+    const int m0 = mt * BM;
+    const bool kok = kt * BK + akq < p.K;
+#pragma unroll
+    for (int i = 0; i < 2 * MI; ++i) {
+      const int r = ar + 32 * i;
+      float4 v = ra[i];
+      if (kok && m0 + r < p.M) v = act_apply4(fma4(v, rsc, rsh), p.act);
+      *reinterpret_cast<float4*>(&As[r * APITCH + akq]) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB4; ++i) {
+      const int idx = t + 256 * i;
+      if (idx < 8 * BN) {
+        if (B_KN) {
+          const int kk = idx / (BN / 4), nq = idx - kk * (BN / 4);
+          *reinterpret_cast<float4*>(&Bs[kk * BPITCH + nq * 4]) = rb[i];
+        } else {
+          const int r = idx >> 3, kq = (idx & 7) * 4;
+          *reinterpret_cast<float4*>(&Bs[r * APITCH + kq]) = rb[i];
+        }
+      }
+    }
+  };
+
+  f32x4 acc[MI][NT];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 st_s[STATS ? NPASS : 1], st_q[STATS ? NPASS : 1];
+  if (STATS) {
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) { st_s[i] = zero4(); st_q[i] = zero4(); }
+  }
+
+  auto mfma_step = [&]() {
+#pragma unroll
+    for (int g = 0; g < BK / 16; ++g) {
+      const int kc = g * 16 + q * 4;
+      float4 a[MI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        a[mi] = *reinterpret_cast<const float4*>(&As[(w * 16 * MI + mi * 16 + l15) * APITCH + kc]);
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) {
+        float b[4];
+        if (B_KN) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) b[j] = Bs[(kc + j) * BPITCH + ni * 16 + l15];
+        } else {
+          const float4 bv = *reinterpret_cast<const float4*>(&Bs[(ni * 16 + l15) * APITCH + kc]);
+          b[0] = bv.x; b[1] = bv.y; b[2] = bv.z; b[3] = bv.w;
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[0], a[mi].x, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[1], a[mi].y, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[2], a[mi].z, acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[3], a[mi].w, acc[mi][ni], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  // epilogue of the M tile that K-step `it` completed (same LDS transpose as pw_gemm_kernel)
+  auto epilogue = [&](int it) {
+    const int mt = vb + (it / nk) * vgrid;
+    const int m0 = mt * BM;
+    float* es = Es + w * RW * EPITCH;
+    const int rr = l >> 4, cq = l & 15;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int ni0 = ps * TPP;
+#pragma unroll
+      for (int nl = 0; nl < TPP; ++nl) {
+        if (ni0 + nl < NT) {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            const f32x4 v = acc[mi][ni0 + nl];
+            acc[mi][ni0 + nl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<float4*>(&es[(mi * 16 + l15) * EPITCH + nl * 16 + q * 4]) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      }
+      const int n = n0 + ni0 * 16 + cq * 4;
+      const bool col_ok = (ni0 * 16 + cq * 4 < BN) && (cq * 4 < CH) && n < p.N && (ni0 + cq / 4 < NT);
+      float4 bias4 = zero4();
+      if (p.bias && col_ok) bias4 = ld4(p.bias + n);
+#pragma unroll
+      for (int r0 = 0; r0 < RW; r0 += 4) {
+        const int row = r0 + rr;
+        const int m = m0 + w * RW + row;
+        if (col_ok && m < p.M) {
+          float4 o = add4(*reinterpret_cast<const float4*>(&es[row * EPITCH + cq * 4]), bias4);
+          float* yp = p.Y + (size_t)m * p.ldy + n;
+          if (p.accumulate) o = add4(o, ld4(yp));
+          st4(yp, o);
+          if (STATS) {
+            st_s[ps] = add4(st_s[ps], o);
+            st_q[ps] = fma4(o, o, st_q[ps]);
+          }
+        }
+      }
+    }
+  };
+
+#ifdef DL3P_STAMP
+  long long tacc[5] = {0, 0, 0, 0, 0};
+  long long t0 = __builtin_amdgcn_s_memtime(), t1;
+#endif
+  // phase -1: half 0 stages its first K-step, half 1 only issues its first loads
+  if (T > 0) {
+    prefetch(0);
+    if (half == 0) stage(0);
+  }
+  __syncthreads();
+  STAMP(4)
+  for (int i = 0; i < T0; ++i) {
+    // phase A: half 0 multiplies K-step i | half 1 finishes K-step i-1's tile and stages K-step i
+    if (half == 0) {
+      if (i + 1 < T) prefetch(i + 1);
+      mfma_step();
+      STAMP(0)
+    } else {
+      if (i > 0 && i - 1 < T && (i - 1) % nk == nk - 1) epilogue(i - 1);
+      if (i < T) stage(i);
+      STAMP(2)
+    }
+    __syncthreads();
+    if (half == 0) STAMP(1) else STAMP(3)
+    // phase B: roles swapped
+    if (half == 0) {
+      if (i % nk == nk - 1) epilogue(i);
+      if (i + 1 < T) stage(i + 1);
+      STAMP(2)
+    } else if (i < T) {
+      if (i + 1 < T) prefetch(i + 1);
+      mfma_step();
+      STAMP(0)
+    }
+    __syncthreads();
+    if (half == 0) STAMP(3) else STAMP(1)
+  }
+#ifdef DL3P_STAMP
+  if (p.stamp && l == 0) {
+    long long* o = p.stamp + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (threadIdx.x >> 6)) * 8;
+    for (int i = 0; i < 5; ++i) o[i] = tacc[i];
+    o[5] = T;
+  }
+#endif
+  if (half == 1 && T > 0 && T == T0) epilogue(T - 1);
+
+  if (STATS) {
+    const int rr = l >> 4, cq = l & 15;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      float sv[4] = {st_s[ps].x, st_s[ps].y, st_s[ps].z, st_s[ps].w};
+      float qv[4] = {st_q[ps].x, st_q[ps].y, st_q[ps].z, st_q[ps].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float s1 = sv[e], s2 = qv[e];
+        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        const int col = ps * CH + cq * 4 + e;
+        if (rr == 0 && cq * 4 < CH && col < BN) {
+          red[(0 * 4 + w) * BN + col] = s1;
+          red[(1 * 4 + w) * BN + col] = s2;
+        }
+      }
+    }
+    __syncthreads();
+    if (p.partials) {
+      for (int i = t; i < 2 * BN; i += 256) {
+        const int which = i / BN, nn = i - which * BN;
+        if (n0 + nn < p.N) {
+          float s = red[(which * 4 + 0) * BN + nn] + red[(which * 4 + 1) * BN + nn] +
+                    red[(which * 4 + 2) * BN + nn] + red[(which * 4 + 3) * BN + nn];
+          p.partials[((size_t)vb * 2 + which) * p.N + n0 + nn] = s;
+        }
+      }
+    }
+  }
+}
+
+template <int NT, bool B_KN, bool STATS, int MI>
+static constexpr size_t pp_lds_bytes() {
+  constexpr int BM = 64 * MI, BN = 16 * NT;
+  constexpr int BPITCH = B_KN ? (BN + 4) : APITCH;
+  constexpr int TPP = NT < 4 ? NT : 4;
+  constexpr int CH = 16 * TPP;
+  return 2 * sizeof(float) * (size_t)(BM * APITCH + (B_KN ? BK * BPITCH : BN * APITCH) + 4 * 16 * MI * (CH + 4) +
+                                      (STATS ? 2 * 4 * BN : 0));
+}
+
+template <int NT, bool B_KN, bool STATS, int MI>
+static void launch_pp_one(const GemmParams& p, dim3 grid, hipStream_t st) {
+  constexpr size_t lds = pp_lds_bytes<NT, B_KN, STATS, MI>();
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)pw_gemm_pp_kernel<NT, B_KN, STATS, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dl3p_launch(pw_gemm_pp_kernel<NT, B_KN, STATS, MI>, grid, dim3(512), lds, st, p);
+}
+
+template <bool B_KN, bool STATS, int MI>
+static void launch_pp_mi(const GemmParams& p, int nt, dim3 grid, hipStream_t st) {
+  switch (nt) {
+    case 1: launch_pp_one<1, B_KN, STATS, MI>(p, grid, st); break;
+    case 2: launch_pp_one<2, B_KN, STATS, MI>(p, grid, st); break;
+    case 3: launch_pp_one<3, B_KN, STATS, MI>(p, grid, st); break;
+    case 4: launch_pp_one<4, B_KN, STATS, MI>(p, grid, st); break;
+    case 5: launch_pp_one<5, B_KN, STATS, MI>(p, grid, st); break;
+    case 6: launch_pp_one<6, B_KN, STATS, MI>(p, grid, st); break;
+    default: launch_pp_one<8, B_KN, STATS, MI>(p, grid, st); break;
+  }
+}
+
+static int gemm_use_pp();
 // choose the columns-per-workgroup (NT tiles of 16) that wastes the fewest MFMA columns
 static int pick_nt(int N) {
   const int ntiles = ceil_div(N, 16);
   static const int cand[] = {8, 6, 5, 4, 3, 2, 1};
   int best = 1;
   float best_cost = 1e30f;
+  static const int nt_max = getenv("DL3P_GEMM_NT_MAX") ? atoi(getenv("DL3P_GEMM_NT_MAX")) : 8;
   for (int c : cand) {
+    if (c > nt_max) continue;
     // MFMA columns actually computed, plus the A-tile re-reads/staging that every column block repeats
     const float cost = (float)(ceil_div(ntiles, c) * c) * (1.f + 1.5f / (float)c);
     if (cost < best_cost) { best = c; best_cost = cost; }
@@ -277,10 +652,14 @@ static void gemm_grid(int M, int N, int nt, int* gx, int* gy, int* num_m_tiles, 
   const int nb = ceil_div(N, 16 * nt);
   int mi = 2;
   if ((long long)ceil_div(M, 128) * nb < 4LL * DL3P_NUM_CUS) mi = 1;
-  const int bm = 64 * mi;
-  const int mt = ceil_div(M, bm);
   int per_cu = nt <= 1 ? 6 : (nt == 2 ? 5 : (nt <= 4 ? 3 : 2));
   if (mi == 1 && per_cu < 3) per_cu = 3;
+  static const int e_mi = getenv("DL3P_GEMM_MI") ? atoi(getenv("DL3P_GEMM_MI")) : 0;
+  static const int e_pc = getenv("DL3P_GEMM_PER_CU") ? atoi(getenv("DL3P_GEMM_PER_CU")) : 0;
+  if (e_mi) mi = e_mi;
+  if (e_pc) per_cu = e_pc;
+  const int bm = 64 * mi;
+  const int mt = ceil_div(M, bm);
   int gx_max = (DL3P_NUM_CUS * per_cu) / nb;
   if (gx_max < 8) gx_max = 8;
   if (gx_max > DL3P_MAX_STAT_ROWS) gx_max = DL3P_MAX_STAT_ROWS;
@@ -289,6 +668,7 @@ static void gemm_grid(int M, int N, int nt, int* gx, int* gy, int* num_m_tiles, 
     const int per = ceil_div(mt, gx_max);
     g = ceil_div(mt, per);
   }
+  if (gemm_use_pp()) g = (g + 1) & ~1;   // two virtual workgroups per 512-thread workgroup
   *gx = g; *gy = nb; *num_m_tiles = mt; *mi_out = mi;
 }
 
@@ -296,18 +676,35 @@ template <bool B_KN, bool STATS, int MI>
 static void launch_gemm_mi(const GemmParams& p, int nt, dim3 grid, hipStream_t st) {
   dim3 block(256);
   switch (nt) {
-    case 1: hipLaunchKernelGGL((pw_gemm_kernel<1, B_KN, STATS, MI>), grid, block, 0, st, p); break;
-    case 2: hipLaunchKernelGGL((pw_gemm_kernel<2, B_KN, STATS, MI>), grid, block, 0, st, p); break;
-    case 3: hipLaunchKernelGGL((pw_gemm_kernel<3, B_KN, STATS, MI>), grid, block, 0, st, p); break;
-    case 4: hipLaunchKernelGGL((pw_gemm_kernel<4, B_KN, STATS, MI>), grid, block, 0, st, p); break;
-    case 5: hipLaunchKernelGGL((pw_gemm_kernel<5, B_KN, STATS, MI>), grid, block, 0, st, p); break;
-    case 6: hipLaunchKernelGGL((pw_gemm_kernel<6, B_KN, STATS, MI>), grid, block, 0, st, p); break;
-    default: hipLaunchKernelGGL((pw_gemm_kernel<8, B_KN, STATS, MI>), grid, block, 0, st, p); break;
+    case 1: dl3p_launch(pw_gemm_kernel<1, B_KN, STATS, MI>, grid, block, 0, st, p); break;
+    case 2: dl3p_launch(pw_gemm_kernel<2, B_KN, STATS, MI>, grid, block, 0, st, p); break;
+    case 3: dl3p_launch(pw_gemm_kernel<3, B_KN, STATS, MI>, grid, block, 0, st, p); break;
+    case 4: dl3p_launch(pw_gemm_kernel<4, B_KN, STATS, MI>, grid, block, 0, st, p); break;
+    case 5: dl3p_launch(pw_gemm_kernel<5, B_KN, STATS, MI>, grid, block, 0, st, p); break;
+    case 6: dl3p_launch(pw_gemm_kernel<6, B_KN, STATS, MI>, grid, block, 0, st, p); break;
+    default: dl3p_launch(pw_gemm_kernel<8, B_KN, STATS, MI>, grid, block, 0, st, p); break;
   }
 }
 
+static int gemm_use_pp() {
+  static const int v = getenv("DL3P_GEMM_PP") ? atoi(getenv("DL3P_GEMM_PP")) : 0;
+  return v;
+}
+
 template <bool B_KN, bool STATS>
-static void launch_gemm(const GemmParams& p, int nt, int mi, dim3 grid, hipStream_t st) {
+static void launch_gemm(const GemmParams& p_in, int nt, int mi, dim3 grid, hipStream_t st) {
+  GemmParams p = p_in;
+#ifdef DL3P_STAMP
+  const char* sp = getenv("DL3P_STAMP_PTR");
+  p.stamp = sp ? (long long*)strtoull(sp, nullptr, 10) : nullptr;
+#endif
+  { const char* e = getenv("DL3P_GEMM_STAGGER"); p.stagger = e ? atoi(e) : 0; }
+  if (gemm_use_pp()) {
+    dim3 g2((grid.x + 1) / 2, grid.y);
+    if (mi == 1) launch_pp_mi<B_KN, STATS, 1>(p, nt, g2, st);
+    else launch_pp_mi<B_KN, STATS, 2>(p, nt, g2, st);
+    return;
+  }
   if (mi == 1) launch_gemm_mi<B_KN, STATS, 1>(p, nt, grid, st);
   else launch_gemm_mi<B_KN, STATS, 2>(p, nt, grid, st);
 }
@@ -327,6 +724,8 @@ extern "C" int dl3p_pwconv_fwd(const float* x, int ldx, const float* in_scale, c
   rc = check_mat("dl3p_pwconv_fwd", y, ldy, N);
   if (rc) return rc;
   DL3P_CHECK_ARG(w && aligned16(w) && M > 0, "dl3p_pwconv_fwd: bad arguments");
+  DL3P_CHECK_ARG((unsigned long long)M * (unsigned long long)(ldx > ldy ? ldx : ldy) * 4ull < (1ull << 32),
+                 "dl3p_pwconv_fwd: operands of 4 GiB or more are not supported (M=%d)", M);
   GemmParams p = {};
   p.A = x; p.lda = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act;
   p.B = w; p.ldb = N; p.bias = bias; p.Y = y; p.ldy = ldy; p.partials = stat_partials;
@@ -349,6 +748,8 @@ extern "C" int dl3p_pwconv_bwd_data(const float* dy, int lddy, const float* w, f
   rc = check_mat("dl3p_pwconv_bwd_data", gx, ldgx, K);
   if (rc) return rc;
   DL3P_CHECK_ARG(w && aligned16(w) && M > 0, "dl3p_pwconv_bwd_data: bad arguments");
+  DL3P_CHECK_ARG((unsigned long long)M * (unsigned long long)(lddy > ldgx ? lddy : ldgx) * 4ull < (1ull << 32),
+                 "dl3p_pwconv_bwd_data: operands of 4 GiB or more are not supported (M=%d)", M);
   GemmParams p = {};
   p.A = dy; p.lda = lddy; p.act = DL3P_ACT_NONE;
   p.B = w; p.ldb = N;           // W[K][N]: output column k, reduction n contiguous
@@ -498,7 +899,7 @@ extern "C" int dl3p_pwconv_bwd_weight(const float* x, int ldx, const float* in_s
   p.DY = dy; p.lddy = lddy; p.slabs = workspace; p.M = M; p.K = K; p.N = N;
   int splits;
   wgrad_split(M, K, N, &p.ktiles, &p.ntiles, &splits, &p.mchunk);
-  hipLaunchKernelGGL(pw_wgrad_kernel, dim3(p.ktiles * p.ntiles, splits), dim3(256), 0, st, p);
+  dl3p_launch(pw_wgrad_kernel, dim3(p.ktiles * p.ntiles, splits), dim3(256), 0, st, p);
   DL3P_CHECK_LAUNCH("dl3p_pwconv_bwd_weight");
   rc = dl3p_reduce_rows_impl(workspace, splits, (size_t)K * N, gw, 0, st);
   if (rc) return rc;

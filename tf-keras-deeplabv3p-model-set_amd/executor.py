@@ -101,12 +101,23 @@ class ParamStore:
         self.lr_scale.copy_(torch.from_numpy(lr))
 
 
+def _op_label(op):
+    n = getattr(op, 'name', None)
+    if n is None and getattr(op, 'bn', None) is not None and op.kind == 'bn':
+        n = op.bn.layer.name
+    if n is None and getattr(op, 'out', None) is not None:
+        n = op.out.name
+    return '%s:%s' % (op.kind, n)
+
+
 class Plan:
     """a traced list of C-ABI launches (+ python callbacks at collectives), replayable eagerly or as
     hipGraph segments"""
 
     def __init__(self):
         self.items = []
+        self.labels = []          # (entry point, graph op) per item, for scripts/step_table.py
+        self.ctx = ''
         self.segments = None
         self.tags = {}
 
@@ -115,6 +126,7 @@ class Plan:
         if tag is not None:
             self.tags[tag] = len(self.items)
         self.items.append((fn, args))
+        self.labels.append((getattr(fn, '__name__', str(fn)), self.ctx))
 
     def probe(self, tag, probe):
         """keep one launch outside the graph segments and issue it with the library's HIP event pair
@@ -134,6 +146,7 @@ class Plan:
     def py(self, fn):
         fn()
         self.items.append((None, fn))
+        self.labels.append(('py', self.ctx))
 
     def run(self):
         if self.segments is not None:
@@ -355,6 +368,7 @@ class Executor:
             P.k(L.increment_counter, self.step.data_ptr())
         for op in self.g.ops:
             k = op.kind
+            P.ctx = _op_label(op)
             if k in ('conv_pw', 'conv_dense', 'conv_dw'):
                 xp, ldx, sp, hp, act = self.vargs(op.x)
                 bn = op.bn
@@ -405,6 +419,7 @@ class Executor:
             else:
                 raise NotImplementedError(k)
         # head: pred_resize + softmax (+ loss and its gradient when training)
+        P.ctx = 'head'
         zt = self.head.tensor
         rows = ctypes.c_int(0)
         if train:
@@ -491,6 +506,7 @@ class Executor:
         bucket_edges = self._bucket_edges() if self.dist is not None else {}
         for op in reversed(self.g.ops):
             k = op.kind
+            P.ctx = _op_label(op)
             if op in bucket_edges:
                 lo, hi = bucket_edges[op]
                 P.py(lambda lo=lo, hi=hi: self.dist.all_reduce_async(G[lo:hi]))
