@@ -41,6 +41,16 @@ for M, K, N in shapes:
     if which in ('all', 'dgrad'):
         t = probe(lambda: ops.pwconv_bwd_data(dy, w, out=gx)); tot['dgrad'] += t
         line += ' dgrad %6.1f (%3.0f%%)' % (t, 100 * fl / t)
+    if which == 'wgrad_ev':      # whole entry point (kernel + slab reduce) by events over back-to-back calls
+        f = lambda: ops.pwconv_bwd_weight(x, dy, sc, sh, ops.ACT_RELU6, workspace=ws)
+        for _ in range(3): f()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): f()
+        e1.record(); torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e3 / 20; tot['wgrad'] += t
+        line += ' wgrad(total) %6.1f (%3.0f%%)' % (t, 100 * fl / t)
     if which in ('all', 'wgrad'):
         t = probe(lambda: ops.pwconv_bwd_weight(x, dy, sc, sh, ops.ACT_RELU6, workspace=ws)); tot['wgrad'] += t
         line += ' wgrad %6.1f (%3.0f%%)' % (t, 100 * fl / t)

@@ -840,6 +840,204 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------ weight gradient, small K x N
+// High-resolution layers have tiny kernels (16x96, 24x144, 32x192 ...) and millions of rows: the weight
+// gradient is a pure stream over X and DY.  Here every WAVE owns the whole K x N gradient (KT x NTN
+// accumulators) and walks its own 16-row tiles of M: it loads 16 whole rows of X and DY (contiguous
+// 16-B lanes), writes them to a wave-private LDS slice, reads them back as MFMA fragments and multiplies.
+// No workgroup barrier in the loop -- the 16 waves of a CU drift apart and cover each other's latencies --
+// every input byte is read exactly once, and the next tile's loads are in flight during the MFMAs.
+// The four waves of a workgroup are summed through LDS at the end (fixed order), one slab per workgroup.
+template <int KT, int NTN>
+__global__ __launch_bounds__(256, 2) void pw_wgrad_small_kernel(WgradParams p) {
+  constexpr int KP = 16 * KT, NP = 16 * NTN;
+  constexpr int XP = KP + 4, DP = NP + 4;          // pitches: rows 4 apart land 16 banks apart
+  constexpr int WAVE_FLOATS = 16 * (XP + DP);
+  extern __shared__ __attribute__((aligned(16))) float ws_lds[];
+  // layout: [scale KP][shift KP][4 waves x WAVE_FLOATS]; the end-of-kernel reduction reuses it from 0
+  float* sc_s = ws_lds;
+  float* sh_s = ws_lds + KP;
+  const int t = threadIdx.x, l = t & 63, w = t >> 6, l15 = l & 15, q = l >> 4;
+  float* Xs = ws_lds + 2 * KP + w * WAVE_FLOATS;
+  float* Ds = Xs + 16 * XP;
+  for (int i = t; i < KP; i += 256) {
+    sc_s[i] = (p.scale && i < p.K) ? p.scale[i] : 1.f;
+    sh_s[i] = (p.scale && i < p.K) ? p.shift[i] : 0.f;
+  }
+  // columns K..KP-1 / N..NP-1 of the wave's slices are never loaded: zero them once
+  for (int i = l; i < 16 * XP; i += 64) Xs[i] = 0.f;
+  for (int i = l; i < 16 * DP; i += 64) Ds[i] = 0.f;
+  __syncthreads();
+
+  const int k4 = p.K >> 2, n4 = p.N >> 2;          // float4 per row
+  const int nx = 4 * p.K, nd = 4 * p.N;            // float4 per 16-row tile
+  // per-lane constants of the i-th load of a tile: row within the tile, LDS offset, global offset
+  int xrow[KT], drow[NTN];
+  uint32_t xg[KT], dg[NTN];
+  int xl[KT], dl[NTN];
+#pragma unroll
+  for (int i = 0; i < KT; ++i) {
+    const int f = min(l + 64 * i, nx - 1);
+    const int r = f / k4, c = f - r * k4;
+    xrow[i] = (l + 64 * i < nx) ? r : 16;          // 16 = never valid
+    xl[i] = r * XP + c * 4;
+    xg[i] = ((uint32_t)r * (uint32_t)p.ldx + (uint32_t)c * 4u) * 4u;
+  }
+#pragma unroll
+  for (int i = 0; i < NTN; ++i) {
+    const int f = min(l + 64 * i, nd - 1);
+    const int r = f / n4, c = f - r * n4;
+    drow[i] = (l + 64 * i < nd) ? r : 16;
+    dl[i] = r * DP + c * 4;
+    dg[i] = ((uint32_t)r * (uint32_t)p.lddy + (uint32_t)c * 4u) * 4u;
+  }
+  const float act_lo = p.act == DL3P_ACT_NONE ? -DL3P_INF : 0.f;
+  const float act_hi = (p.act == DL3P_ACT_NONE || p.act == DL3P_ACT_RELU) ? DL3P_INF : 6.f;
+
+  f32x4 acc[KT][NTN];
+#pragma unroll
+  for (int a = 0; a < KT; ++a)
+#pragma unroll
+    for (int b = 0; b < NTN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int ntiles = (p.M + 15) >> 4;
+  const int nwaves = gridDim.x * 4;
+  const int gw = blockIdx.x * 4 + w;
+  const char* Xb = reinterpret_cast<const char*>(p.X);
+  const char* Db = reinterpret_cast<const char*>(p.DY);
+  float4 rx[KT], rd[NTN];
+  // (a macro, not a lambda: hipcc keeps a by-reference captured float4[] in scratch here)
+#define WS_PREFETCH(tile_)                                                                          \
+  {                                                                                                 \
+    const int pm0 = (tile_) << 4;                                                                   \
+    /* rows past M: the tile is loaded shifted up so every row is in bounds; see `back` below */    \
+    const int pback = max(0, pm0 + 16 - p.M);                                                       \
+    const uint32_t xb0 = (uint32_t)(pm0 - pback) * (uint32_t)p.ldx * 4u;                            \
+    const uint32_t db0 = (uint32_t)(pm0 - pback) * (uint32_t)p.lddy * 4u;                           \
+    _Pragma("unroll") for (int i = 0; i < KT; ++i) rx[i] = *reinterpret_cast<const float4*>(Xb + (xb0 + xg[i]));   \
+    _Pragma("unroll") for (int i = 0; i < NTN; ++i) rd[i] = *reinterpret_cast<const float4*>(Db + (db0 + dg[i]));  \
+  }
+  WS_PREFETCH(min(gw, ntiles - 1))
+  for (int tile = gw; tile < ntiles; tile += nwaves) {
+    const int m0 = tile << 4;
+    const int back = max(0, m0 + 16 - p.M);        // the tile was loaded shifted up by `back` rows
+    // stage: rows [0, back) of the shifted tile belong to the previous tile -> zero (X only: 0 * dy = 0)
+#pragma unroll
+    for (int i = 0; i < KT; ++i) {
+      if (xrow[i] < 16) {
+        const float4 s4 = *reinterpret_cast<const float4*>(&sc_s[xl[i] - xrow[i] * XP]);
+        const float4 h4 = *reinterpret_cast<const float4*>(&sh_s[xl[i] - xrow[i] * XP]);
+        float4 v = fma4(rx[i], s4, h4);
+        if (p.act >= DL3P_ACT_HSWISH) v = act_apply4(v, p.act);
+        else v = make_float4(__builtin_amdgcn_fmed3f(v.x, act_lo, act_hi), __builtin_amdgcn_fmed3f(v.y, act_lo, act_hi),
+                             __builtin_amdgcn_fmed3f(v.z, act_lo, act_hi), __builtin_amdgcn_fmed3f(v.w, act_lo, act_hi));
+        *reinterpret_cast<float4*>(&Xs[xl[i]]) = xrow[i] >= back ? v : zero4();
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NTN; ++i)
+      if (drow[i] < 16) *reinterpret_cast<float4*>(&Ds[dl[i]]) = make_float4(rd[i].x, rd[i].y, rd[i].z, rd[i].w);
+    WS_PREFETCH(min(tile + nwaves, ntiles - 1))   // unconditional (the last one is a harmless re-read)
+    // fragments: reduction index m = 4q + j; lane l15 = channel within the 16-wide tile
+    float b[NTN][4];
+#pragma unroll
+    for (int nt = 0; nt < NTN; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[nt][j] = Ds[(4 * q + j) * DP + nt * 16 + l15];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      float a[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = Xs[(4 * q + j) * XP + kt * 16 + l15];
+#pragma unroll
+      for (int nt = 0; nt < NTN; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[kt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt][j], a[j], acc[kt][nt], 0, 0, 0);
+    }
+  }
+  // sum the four waves (fixed order 0+1+2+3) and write this workgroup's slab
+  __syncthreads();
+  float4* red = reinterpret_cast<float4*>(ws_lds);
+  if (w > 0) {
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int nt = 0; nt < NTN; ++nt)
+        red[((w - 1) * KT * NTN + kt * NTN + nt) * 64 + l] =
+            make_float4(acc[kt][nt][0], acc[kt][nt][1], acc[kt][nt][2], acc[kt][nt][3]);
+  }
+  __syncthreads();
+  if (w == 0) {
+    float* slab = p.slabs + (size_t)blockIdx.x * p.K * p.N;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int nt = 0; nt < NTN; ++nt) {
+        float4 v = make_float4(acc[kt][nt][0], acc[kt][nt][1], acc[kt][nt][2], acc[kt][nt][3]);
+#pragma unroll
+        for (int ww = 0; ww < 3; ++ww) v = add4(v, red[(ww * KT * NTN + kt * NTN + nt) * 64 + l]);
+        const int k = kt * 16 + l15, n = nt * 16 + q * 4;
+        if (k < p.K && n < p.N) st4(slab + (size_t)k * p.N + n, v);
+      }
+  }
+}
+
+template <int KT, int NTN>
+static constexpr size_t wgrad_small_lds() {
+  constexpr size_t stage = sizeof(float) * (size_t)(2 * 16 * KT + 4 * 16 * (16 * KT + 4 + 16 * NTN + 4));
+  constexpr size_t red = 16 * (size_t)(3 * KT * NTN * 64);
+  return stage > red ? stage : red;
+}
+
+// workgroups for the small-K.N kernel (all resident at once)
+static int wgrad_small_grid(int M, int KT, int NTN) {
+  const int tiles = ceil_div(M, 16);
+  // measured (kernel + slab reduce): two workgroups per CU stream as fast as four and halve the slabs;
+  // below two row tiles per wave the per-wave prologue / reduction dominates
+  const int occ = 2, tpw = 2;
+  (void)KT; (void)NTN;
+  int g = tiles / (4 * tpw);
+  if (g > DL3P_NUM_CUS * occ) g = DL3P_NUM_CUS * occ;
+  if (g > DL3P_MAX_STAT_ROWS) g = DL3P_MAX_STAT_ROWS;
+  if (g < 1) g = 1;
+  return g;
+}
+
+template <int KT, int NTN>
+static void launch_wgrad_small(const WgradParams& p, int grid, hipStream_t st) {
+  constexpr size_t lds = wgrad_small_lds<KT, NTN>();
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)pw_wgrad_small_kernel<KT, NTN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dl3p_launch(pw_wgrad_small_kernel<KT, NTN>, dim3(grid), dim3(256), lds, st, p);
+}
+
+// the (KT, NTN) instantiations: kernels of the 513x513 MobileNetV2 / V3 / Xception graphs at OS 2-8
+struct SmallShape { int kt, ntn; };
+static bool wgrad_small_pick(int K, int N, SmallShape* out) {
+  static const SmallShape list[] = {{1, 2}, {2, 1}, {2, 2}, {1, 6}, {2, 3}, {2, 4}, {4, 2}, {6, 2}, {2, 6}, {2, 9}, {9, 2},
+                                    {2, 12}, {12, 2}, {4, 4}};
+  static const int off = getenv("DL3P_WGRAD_SMALL") ? atoi(getenv("DL3P_WGRAD_SMALL")) == 0 : 0;
+  if (off) return false;
+  const int kt = ceil_div(K, 16), ntn = ceil_div(N, 16);
+  int best = -1, best_tiles = 1 << 30;
+  for (int i = 0; i < (int)(sizeof(list) / sizeof(list[0])); ++i)
+    if (list[i].kt >= kt && list[i].ntn >= ntn && list[i].kt * list[i].ntn < best_tiles) { best = i; best_tiles = list[i].kt * list[i].ntn; }
+  if (best < 0 || best_tiles > 2 * kt * ntn) return false;   // too much padding: use the tiled kernel
+  *out = list[best];
+  return true;
+}
+
+static void launch_wgrad_small_any(const WgradParams& p, SmallShape sh, int grid, hipStream_t st) {
+#define DL3P_WS(a, b) if (sh.kt == a && sh.ntn == b) { launch_wgrad_small<a, b>(p, grid, st); return; }
+  DL3P_WS(1, 2) DL3P_WS(2, 1) DL3P_WS(2, 2) DL3P_WS(1, 6) DL3P_WS(2, 3) DL3P_WS(2, 4) DL3P_WS(4, 2) DL3P_WS(6, 2)
+  DL3P_WS(2, 6) DL3P_WS(2, 9) DL3P_WS(9, 2) DL3P_WS(2, 12) DL3P_WS(12, 2) DL3P_WS(4, 4)
+#undef DL3P_WS
+}
+
 static void wgrad_split(int M, int K, int N, int* ktiles, int* ntiles, int* splits, int* mchunk) {
   *ktiles = ceil_div(K, 64);
   *ntiles = ceil_div(N, 64);
@@ -876,6 +1074,8 @@ extern "C" size_t dl3p_pwconv_bwd_weight_workspace(int M, int K, int N) {
   int kt, nt, s, mc;
   wgrad_split(M, K, N, &kt, &nt, &s, &mc);
   size_t a = (size_t)s * K * N;
+  SmallShape sh;
+  if (wgrad_small_pick(K, N, &sh)) a = (size_t)wgrad_small_grid(M, sh.kt, sh.ntn) * K * N;
   size_t b = (size_t)512 * N;  // bias column-sum partial rows
   return (a > b ? a : b) * sizeof(float);
 }
@@ -898,8 +1098,14 @@ extern "C" int dl3p_pwconv_bwd_weight(const float* x, int ldx, const float* in_s
   p.X = x; p.ldx = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act;
   p.DY = dy; p.lddy = lddy; p.slabs = workspace; p.M = M; p.K = K; p.N = N;
   int splits;
-  wgrad_split(M, K, N, &p.ktiles, &p.ntiles, &splits, &p.mchunk);
-  dl3p_launch(pw_wgrad_kernel, dim3(p.ktiles * p.ntiles, splits), dim3(256), 0, st, p);
+  SmallShape sh;
+  if (M >= 16 && wgrad_small_pick(K, N, &sh) && (unsigned long long)M * (unsigned long long)(ldx > lddy ? ldx : lddy) * 4ull < (1ull << 32)) {
+    splits = wgrad_small_grid(M, sh.kt, sh.ntn);
+    launch_wgrad_small_any(p, sh, splits, st);
+  } else {
+    wgrad_split(M, K, N, &p.ktiles, &p.ntiles, &splits, &p.mchunk);
+    dl3p_launch(pw_wgrad_kernel, dim3(p.ktiles * p.ntiles, splits), dim3(256), 0, st, p);
+  }
   DL3P_CHECK_LAUNCH("dl3p_pwconv_bwd_weight");
   rc = dl3p_reduce_rows_impl(workspace, splits, (size_t)K * N, gw, 0, st);
   if (rc) return rc;
