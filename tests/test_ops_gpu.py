@@ -77,6 +77,8 @@ PW_CASES = [
     (2 * 33 * 33, 320, 256), (1000, 24, 144), (777, 144, 24), (4096 + 5, 32, 16), (513, 16, 96),
     (300, 304, 256), (129 * 7, 256, 24), (64, 1280, 256), (16, 320, 256), (2 * 17 * 17, 960, 160),
     (1, 8, 4), (130, 576, 96),
+    # small K x N: the wave-independent streaming kernels (ragged last row tile, padded K / N tiles)
+    (70001, 32, 32), (5003, 96, 24), (3001, 32, 192), (2005, 192, 32), (4007, 24, 48), (2 * 129 * 129, 144, 32),
 ]
 
 

@@ -39,6 +39,7 @@ struct GemmParams {
   int accumulate;
   int num_m_tiles;
   int stagger;
+  int b_kn;            // pw_small_kernel: B stored [K][N] (forward) or [N][K] (data gradient)
 #ifdef DL3P_STAMP
   long long* stamp;   // dev instrument: per-wave cycle counts of the loop phases (scripts/micro/stamp_gemm.py)
 #endif
@@ -628,6 +629,208 @@ static void launch_pp_mi(const GemmParams& p, int nt, dim3 grid, hipStream_t st)
   }
 }
 
+// ------------------------------------------------------------------------------ forward / dgrad, small K x N
+// Same idea as pw_wgrad_small_kernel for Y = act(X*scale+shift) @ W when the whole kernel matrix is a few
+// KB (the 129x129 / 257x257 layers): W sits in LDS for the life of the workgroup, every wave walks its own
+// 16-row tiles of M with no workgroup barrier, A fragments come straight from global memory (lane
+// (row l15, quarter q) loads the float4 X[row][16 kt + 4q ..]: the k-permutation of the big kernel makes
+// that exactly its MFMA operand), the 16 x N result is transposed through a wave-private LDS slice and
+// leaves as whole rows; BN statistics are kept per lane in that row-major form and reduced once at the end.
+template <int KT, int NTN, bool STATS>
+__global__ __launch_bounds__(256, 2) void pw_small_kernel(GemmParams p) {
+  constexpr int KP = 16 * KT, NP = 16 * NTN;
+  constexpr int BP = NP + 4, TP = NP + 4;
+  extern __shared__ __attribute__((aligned(16))) float sm_lds[];
+  float* Bs = sm_lds;                         // [KP][BP], zero padded
+  float* sc_s = Bs + KP * BP;
+  float* sh_s = sc_s + KP;
+  float* Tall = sh_s + KP;                    // 4 wave slices of [16][TP]
+  const int t = threadIdx.x, l = t & 63, w = t >> 6, l15 = l & 15, q = l >> 4;
+  float* Ts = Tall + w * 16 * TP;
+  if (p.b_kn) {
+    for (int idx = t; idx < KP * NP; idx += 256) {
+      const int k = idx / NP, n = idx - k * NP;
+      Bs[k * BP + n] = (k < p.K && n < p.N) ? p.B[(size_t)k * p.ldb + n] : 0.f;
+    }
+  } else {
+    for (int idx = t; idx < KP * NP; idx += 256) {
+      const int n = idx / KP, k = idx - n * KP;
+      Bs[k * BP + n] = (k < p.K && n < p.N) ? p.B[(size_t)n * p.ldb + k] : 0.f;
+    }
+  }
+  for (int i = t; i < KP; i += 256) {
+    sc_s[i] = (p.scale && i < p.K) ? p.scale[i] : 1.f;
+    sh_s[i] = (p.scale && i < p.K) ? p.shift[i] : 0.f;
+  }
+  __syncthreads();
+
+  // A fragment loads: clamped 32-bit byte offsets, invalid lanes zeroed by select
+  uint32_t a_k[KT];
+  bool a_kok[KT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    const int k = kt * 16 + 4 * q;
+    a_kok[kt] = k < p.K;
+    a_k[kt] = (uint32_t)min(k, p.K - 4) * 4u;
+  }
+  // row-major output mapping of a 16 x N tile: float4 f = l + 64 i  ->  (row f / (N/4), column group f % (N/4))
+  const int n4 = p.N >> 2, nf = 4 * p.N;
+  int yrow[NTN], yl[NTN];
+  uint32_t yg[NTN];
+#pragma unroll
+  for (int i = 0; i < NTN; ++i) {
+    const int f = min(l + 64 * i, nf - 1);
+    const int r = f / n4, c = f - r * n4;
+    yrow[i] = (l + 64 * i < nf) ? r : (1 << 20);
+    yl[i] = r * TP + c * 4;
+    yg[i] = ((uint32_t)r * (uint32_t)p.ldy + (uint32_t)c * 4u) * 4u;
+  }
+  const float act_lo = p.act == DL3P_ACT_NONE ? -DL3P_INF : 0.f;
+  const float act_hi = (p.act == DL3P_ACT_NONE || p.act == DL3P_ACT_RELU) ? DL3P_INF : 6.f;
+
+  f32x4 acc[NTN];
+#pragma unroll
+  for (int b = 0; b < NTN; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 st_s[STATS ? NTN : 1], st_q[STATS ? NTN : 1];
+  if (STATS) {
+#pragma unroll
+    for (int i = 0; i < NTN; ++i) { st_s[i] = zero4(); st_q[i] = zero4(); }
+  }
+
+  const int ntiles = (p.M + 15) >> 4;
+  const int nwaves = gridDim.x * 4;
+  const int gw = blockIdx.x * 4 + w;
+  const char* Ab = reinterpret_cast<const char*>(p.A);
+  char* Yb = reinterpret_cast<char*>(p.Y);
+  float4 ra[KT];
+#define SM_PREFETCH(tile_)                                                                                   \
+  {                                                                                                          \
+    const uint32_t arow = (uint32_t)min(((tile_) << 4) + l15, p.M - 1) * (uint32_t)p.lda * 4u;              \
+    _Pragma("unroll") for (int kt = 0; kt < KT; ++kt) ra[kt] = *reinterpret_cast<const float4*>(Ab + (arow + a_k[kt])); \
+  }
+  SM_PREFETCH(min(gw, ntiles - 1))
+  for (int tile = gw; tile < ntiles; tile += nwaves) {
+    const int m0 = tile << 4;
+    const bool row_ok = m0 + l15 < p.M;
+    float4 a[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      const float4 s4 = *reinterpret_cast<const float4*>(&sc_s[kt * 16 + 4 * q]);
+      const float4 h4 = *reinterpret_cast<const float4*>(&sh_s[kt * 16 + 4 * q]);
+      float4 v = fma4(ra[kt], s4, h4);
+      if (p.act >= DL3P_ACT_HSWISH) v = act_apply4(v, p.act);
+      else v = make_float4(__builtin_amdgcn_fmed3f(v.x, act_lo, act_hi), __builtin_amdgcn_fmed3f(v.y, act_lo, act_hi),
+                           __builtin_amdgcn_fmed3f(v.z, act_lo, act_hi), __builtin_amdgcn_fmed3f(v.w, act_lo, act_hi));
+      a[kt] = (row_ok && a_kok[kt]) ? v : zero4();
+    }
+    SM_PREFETCH(min(tile + nwaves, ntiles - 1))
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      const float av[4] = {a[kt].x, a[kt].y, a[kt].z, a[kt].w};
+#pragma unroll
+      for (int nt = 0; nt < NTN; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Bs[(kt * 16 + 4 * q + j) * BP + nt * 16 + l15], av[j], acc[nt], 0, 0, 0);
+    }
+    // lane holds 4 consecutive channels (nt*16 + 4q ..) of pixel l15 -> wave-private transpose -> whole rows
+#pragma unroll
+    for (int nt = 0; nt < NTN; ++nt) {
+      *reinterpret_cast<float4*>(&Ts[l15 * TP + nt * 16 + 4 * q]) = make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]);
+      acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const uint32_t ybase = (uint32_t)m0 * (uint32_t)p.ldy * 4u;
+    const int rows_here = p.M - m0;
+#pragma unroll
+    for (int i = 0; i < NTN; ++i) {
+      if (yrow[i] < rows_here) {
+        float4 o = *reinterpret_cast<const float4*>(&Ts[yl[i]]);
+        if (p.bias) o = add4(o, ld4(p.bias + (yl[i] - yrow[i] * TP)));
+        float* yp = reinterpret_cast<float*>(Yb + (ybase + yg[i]));
+        if (p.accumulate) o = add4(o, ld4(yp));
+        st4(yp, o);
+        if (STATS) {
+          st_s[i] = add4(st_s[i], o);
+          st_q[i] = fma4(o, o, st_q[i]);
+        }
+      }
+    }
+  }
+#undef SM_PREFETCH
+  if (STATS) {
+    // per-lane sums are indexed by (row r, column group c) of the tile pattern: dump them and add the
+    // 16 rows x 4 waves of every column group in a fixed order; one partial row per workgroup
+    float4* S = reinterpret_cast<float4*>(Tall);
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NTN; ++i)
+        if (l + 64 * i < nf) S[w * 4 * NP + l + 64 * i] = which ? st_q[i] : st_s[i];
+      __syncthreads();
+      if (p.partials && t < n4) {
+        float4 s = zero4();
+        for (int ww = 0; ww < 4; ++ww)
+          for (int r = 0; r < 16; ++r) s = add4(s, S[ww * 4 * NP + r * n4 + t]);
+        st4(p.partials + ((size_t)blockIdx.x * 2 + which) * p.N + 4 * t, s);
+      }
+    }
+  }
+}
+
+template <int KT, int NTN>
+static constexpr size_t pw_small_lds() {
+  return sizeof(float) * (size_t)(16 * KT * (16 * NTN + 4) + 2 * 16 * KT + 4 * 16 * (16 * NTN + 4));
+}
+
+template <int KT, int NTN, bool STATS>
+static void launch_pw_small(const GemmParams& p, int grid, hipStream_t st) {
+  constexpr size_t lds = pw_small_lds<KT, NTN>();
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)pw_small_kernel<KT, NTN, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dl3p_launch(pw_small_kernel<KT, NTN, STATS>, dim3(grid), dim3(256), lds, st, p);
+}
+
+struct SmallShape { int kt, ntn; };
+// (reduction tiles, output tiles) instantiated for the forward / data-gradient small kernel
+static bool pw_small_pick(int K, int N, SmallShape* out) {
+  // measured against the tiled kernel (scripts/gemm_sweep.py): these shapes win 5-25 % at M >= 2^17 rows;
+  // 2x2 (32x32), 2x16 / 16x2 and the 67600-row layers lose and stay on the tiled kernel
+  static const SmallShape list[] = {{1, 2}, {2, 1}, {6, 1}, {1, 6}, {2, 3}, {3, 2}, {6, 2}, {2, 6}, {2, 9}, {9, 2}};
+  static const int off = getenv("DL3P_PW_SMALL") ? atoi(getenv("DL3P_PW_SMALL")) == 0 : 0;
+  if (off) return false;
+  const int kt = ceil_div(K, 16), ntn = ceil_div(N, 16);
+  int best = -1, best_tiles = 1 << 30;
+  for (int i = 0; i < (int)(sizeof(list) / sizeof(list[0])); ++i)
+    if (list[i].kt >= kt && list[i].ntn >= ntn && list[i].kt * list[i].ntn < best_tiles) { best = i; best_tiles = list[i].kt * list[i].ntn; }
+  if (best < 0 || best_tiles > 2 * kt * ntn) return false;
+  *out = list[best];
+  return true;
+}
+
+static int pw_small_min_rows() {
+  static const int v = getenv("DL3P_PW_SMALL_MIN_ROWS") ? atoi(getenv("DL3P_PW_SMALL_MIN_ROWS")) : (1 << 17);
+  return v;
+}
+
+static int pw_small_grid(int M) {
+  int g = ceil_div(M, 16) / (4 * 2);          // >= 2 row tiles per wave
+  if (g > DL3P_NUM_CUS * 2) g = DL3P_NUM_CUS * 2;   // two resident workgroups per CU
+  if (g < 1) g = 1;
+  return g;
+}
+
+template <bool STATS>
+static void launch_pw_small_any(const GemmParams& p, SmallShape sh, int grid, hipStream_t st) {
+#define DL3P_PS(a, b) if (sh.kt == a && sh.ntn == b) { launch_pw_small<a, b, STATS>(p, grid, st); return; }
+  DL3P_PS(1, 2) DL3P_PS(2, 1) DL3P_PS(6, 1) DL3P_PS(1, 6) DL3P_PS(2, 3) DL3P_PS(3, 2) DL3P_PS(6, 2) DL3P_PS(2, 6)
+  DL3P_PS(2, 9) DL3P_PS(9, 2)
+#undef DL3P_PS
+}
+
 static int gemm_use_pp();
 // choose the columns-per-workgroup (NT tiles of 16) that wastes the fewest MFMA columns
 static int pick_nt(int N) {
@@ -730,11 +933,21 @@ extern "C" int dl3p_pwconv_fwd(const float* x, int ldx, const float* in_scale, c
   p.A = x; p.lda = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act;
   p.B = w; p.ldb = N; p.bias = bias; p.Y = y; p.ldy = ldy; p.partials = stat_partials;
   p.M = M; p.K = K; p.N = N;
+  hipStream_t st = (hipStream_t)stream;
+  SmallShape sh;
+  if (M >= pw_small_min_rows() && pw_small_pick(K, N, &sh)) {
+    p.b_kn = 1;
+    const int g = pw_small_grid(M);
+    if (rows_out) *rows_out = g;
+    if (stat_partials) launch_pw_small_any<true>(p, sh, g, st);
+    else launch_pw_small_any<false>(p, sh, g, st);
+    DL3P_CHECK_LAUNCH("dl3p_pwconv_fwd");
+    return DL3P_OK;
+  }
   const int nt = pick_nt(N);
   int gx, gy, mi;
   gemm_grid(M, N, nt, &gx, &gy, &p.num_m_tiles, &mi);
   if (rows_out) *rows_out = gx;
-  hipStream_t st = (hipStream_t)stream;
   if (stat_partials) launch_gemm<true, true>(p, nt, mi, dim3(gx, gy), st);
   else launch_gemm<true, false>(p, nt, mi, dim3(gx, gy), st);
   DL3P_CHECK_LAUNCH("dl3p_pwconv_fwd");
@@ -755,6 +968,13 @@ extern "C" int dl3p_pwconv_bwd_data(const float* dy, int lddy, const float* w, f
   p.B = w; p.ldb = N;           // W[K][N]: output column k, reduction n contiguous
   p.Y = gx; p.ldy = ldgx; p.accumulate = accumulate;
   p.M = M; p.K = N; p.N = K;    // reduce over N, produce K columns
+  SmallShape sh;
+  if (M >= pw_small_min_rows() && pw_small_pick(N, K, &sh)) {
+    p.b_kn = 0;
+    launch_pw_small_any<false>(p, sh, pw_small_grid(M), (hipStream_t)stream);
+    DL3P_CHECK_LAUNCH("dl3p_pwconv_bwd_data");
+    return DL3P_OK;
+  }
   const int nt = pick_nt(K);
   int gxn, gy, mi;
   gemm_grid(M, K, nt, &gxn, &gy, &p.num_m_tiles, &mi);
@@ -1016,7 +1236,6 @@ static void launch_wgrad_small(const WgradParams& p, int grid, hipStream_t st) {
 }
 
 // the (KT, NTN) instantiations: kernels of the 513x513 MobileNetV2 / V3 / Xception graphs at OS 2-8
-struct SmallShape { int kt, ntn; };
 static bool wgrad_small_pick(int K, int N, SmallShape* out) {
   static const SmallShape list[] = {{1, 2}, {2, 1}, {2, 2}, {1, 6}, {2, 3}, {2, 4}, {4, 2}, {6, 2}, {2, 6}, {2, 9}, {9, 2},
                                     {2, 12}, {12, 2}, {4, 4}};
