@@ -102,7 +102,7 @@ def parse(d):
         i += 1                                              # the marker
         t = sum(us(r) for r in ks)
         tot += t
-        out.append((pname, ep, ctx, t, [r['Kernel_Name'].split('(')[0][:48] for r in ks]))
+        out.append((pname, ep, ctx, t, ['%s %.1f' % (r['Kernel_Name'].split('(')[0][:40], us(r)) for r in ks]))
     shapes = json.load(open(os.path.join(ROOT, 'gpurun_out', 'st_shapes.json')))
     HBM, MFMA = 6.3e6, 157e6          # achievable bytes/us (guide: ~6.3 TB/s), fp32 MFMA flop/us
 

@@ -542,6 +542,73 @@ __global__ __launch_bounds__(256) void dw_bwd_data_strided(DwParams p) {
   }
 }
 
+// stride-2 backward data (rate 1), by 2x2 quads of input pixels.  With u = iy + pad_t, only taps ky of u's
+// parity reach input row iy (oy = (u - ky) / 2), so the quad rows u in {2a, 2a+1}, columns v in {2b, 2b+1}
+// read the same (J+1)^2 dy pixels (rows a-j, columns b-i, J = (KS-1)/2): all loads are issued first on
+// clamped addresses (no branch, no % or / per tap), 9 (25) FMAs per quad, 4 stores.
+template <int KS>
+__global__ __launch_bounds__(256) void dw_bwd_data_s2(DwParams p) {
+  constexpr int J = (KS - 1) / 2;
+  const int b = blockIdx.x;
+  const int slab = b / p.nbx;
+  const int bx = b - slab * p.nbx;
+  const int t = threadIdx.x;
+  const int pl = t / p.c4s;
+  const int cl = t - pl * p.c4s;
+  if (pl >= p.px) return;
+  const int c = (slab * p.c4s + cl) * 4;
+  float4 wreg[KS * KS];
+#pragma unroll
+  for (int i = 0; i < KS * KS; ++i) wreg[i] = ld4(p.w + (size_t)i * p.C + c);
+  const int QA = p.th, QB = p.spr;          // quads per image column / row (host)
+  XcdRange r = xcd_range(p.total, bx, p.nbx, p.px, pl);
+  for (int s = r.begin; s < r.end; s += r.step) {
+    const int qb = s % QB;
+    const int row = s / QB;
+    const int qa = row % QA;
+    const int n = row / QA;
+    const float* dimg = p.dy + (size_t)n * p.Ho * p.Wo * p.lddy + c;
+    float4 d[J + 1][J + 1];
+#pragma unroll
+    for (int j = 0; j <= J; ++j) {
+      const int oy = qa - j;
+      const bool yok = oy >= 0 && oy < p.Ho;
+      const int oyc = min(max(oy, 0), p.Ho - 1);
+#pragma unroll
+      for (int i = 0; i <= J; ++i) {
+        const int ox = qb - i;
+        const bool ok = yok && ox >= 0 && ox < p.Wo;
+        const int oxc = min(max(ox, 0), p.Wo - 1);
+        const float4 v = ld4(dimg + ((size_t)oyc * p.Wo + oxc) * p.lddy);
+        d[j][i] = ok ? v : zero4();
+      }
+    }
+#pragma unroll
+    for (int du = 0; du < 2; ++du) {
+      const int iy = 2 * qa + du - p.pad_t;
+#pragma unroll
+      for (int dv = 0; dv < 2; ++dv) {
+        const int ix = 2 * qb + dv - p.pad_l;
+        float4 acc = zero4();
+#pragma unroll
+        for (int j = 0; j <= J; ++j) {
+          if (du + 2 * j >= KS) continue;
+#pragma unroll
+          for (int i = 0; i <= J; ++i) {
+            if (dv + 2 * i >= KS) continue;
+            acc = fma4(d[j][i], wreg[(du + 2 * j) * KS + dv + 2 * i], acc);
+          }
+        }
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+          float* gp = p.y + (((size_t)n * p.H + iy) * p.W + ix) * p.ldy + c;
+          if (p.accumulate) acc = add4(acc, ld4(gp));
+          st4(gp, acc);
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------ backward weight
 // gw[tap][c] = sum_{n,oy,ox} a[n, oy*s-pad+ky*r, ox*s-pad+kx*r, c] * dy[n,oy,ox,c]; a = act(x*scale+shift).
 // Per-thread tap accumulators over a persistent loop, then one partial row [k*k][C] per workgroup.
@@ -720,11 +787,21 @@ extern "C" int dl3p_dwconv2d_bwd_data(const float* dy, int lddy, const float* w,
   } else {
     p.dy = dy; p.lddy = lddy; p.y = gx; p.ldy = ldgx;
     p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.rate = rate; p.pad_t = pad_t; p.pad_l = pad_l;
-    p.total = (long long)N * H * W;
-    p.nbx = pick_nbx(p.total, p.px, p.nslab);
-    dim3 grid(p.nbx * p.nslab), block(256);
-    if (k == 3) hipLaunchKernelGGL((dw_bwd_data_strided<3>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((dw_bwd_data_strided<5>), grid, block, 0, st, p);
+    if (stride == 2 && rate == 1) {
+      p.th = ((H - 1 + pad_t) >> 1) + 1;     // quads per column
+      p.spr = ((W - 1 + pad_l) >> 1) + 1;    // quads per row
+      p.total = (long long)N * p.th * p.spr;
+      p.nbx = pick_nbx(p.total, p.px, p.nslab);
+      dim3 grid(p.nbx * p.nslab), block(256);
+      if (k == 3) hipLaunchKernelGGL((dw_bwd_data_s2<3>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((dw_bwd_data_s2<5>), grid, block, 0, st, p);
+    } else {
+      p.total = (long long)N * H * W;
+      p.nbx = pick_nbx(p.total, p.px, p.nslab);
+      dim3 grid(p.nbx * p.nslab), block(256);
+      if (k == 3) hipLaunchKernelGGL((dw_bwd_data_strided<3>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((dw_bwd_data_strided<5>), grid, block, 0, st, p);
+    }
   }
   DL3P_CHECK_LAUNCH("dl3p_dwconv2d_bwd_data");
   return DL3P_OK;
