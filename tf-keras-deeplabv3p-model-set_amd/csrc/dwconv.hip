@@ -685,7 +685,7 @@ static int pick_band(long long items_per_row_band, int rows, int px, int nslab) 
 //   kind 1: window kernel TW=4, stride 1 (any rate, on the rate x rate sub-lattices)
 //   kind 2: window kernel TW=2, stride 2, rate 1
 //   kind 0: per-pixel gather (stride > 1 with rate > 1, or maps narrower than a strip)
-static int fwd_plan(DwParams& p) {
+static int fwd_plan(DwParams& p, int per_cu = 8) {
   int kind = 0;
   // (5x5 kernels use the per-pixel gather: a 5-row window plus 25 weights does not fit the register file)
   if (p.ks5) kind = 0;
@@ -711,7 +711,7 @@ static int fwd_plan(DwParams& p) {
     p.total = (long long)p.N * r * r * p.nbands * p.spr;
   }
   static const int lat2_per_cu = getenv("DL3P_LAT2_PER_CU") ? atoi(getenv("DL3P_LAT2_PER_CU")) : DL3P_LAT2_PER_CU;
-  p.nbx = pick_nbx(p.total, p.px, p.nslab, kind == 3 ? lat2_per_cu : 8);
+  p.nbx = pick_nbx(p.total, p.px, p.nslab, kind == 3 ? lat2_per_cu : per_cu);
   return kind;
 }
 
@@ -729,7 +729,8 @@ static void launch_fwd(const DwParams& p0, hipStream_t st) {
   DwParams p = p0;
   p.ks = KS;
   p.ks5 = KS == 5;
-  const int kind = fwd_plan(p);
+  static const int dwf_per_cu = getenv("DL3P_DWF_PER_CU") ? atoi(getenv("DL3P_DWF_PER_CU")) : 8;
+  const int kind = fwd_plan(p, dwf_per_cu);
   dim3 grid(p.nbx * p.nslab);
   const int pro = (p.act != DL3P_ACT_NONE) ? 2 : (p.scale ? 1 : 0);
   if (pro == 2) launch_fwd_pro<KS, 2>(p, kind, grid, st);
@@ -843,7 +844,8 @@ extern "C" int dl3p_dwconv2d_bwd_weight(const float* x, int ldx, const float* in
   p.pad_t = pad_t; p.pad_l = pad_l;
   pick_lanes(C, &p.c4s, &p.px, &p.nslab);
   p.ks5 = k == 5;
-  const int kind = fwd_plan(p);
+  static const int dww_per_cu = getenv("DL3P_DWW_PER_CU") ? atoi(getenv("DL3P_DWW_PER_CU")) : 2;   // fewer slabs: the slab reduce costs as much as the kernel at 8
+  const int kind = fwd_plan(p, dww_per_cu);
   dim3 grid(p.nbx * p.nslab);
   const int pro = (in_act != DL3P_ACT_NONE) ? 2 : (in_scale ? 1 : 0);
   if (k == 3) {
