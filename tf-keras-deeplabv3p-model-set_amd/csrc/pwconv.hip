@@ -47,23 +47,35 @@ struct GemmParams {
 
 // B_KN: B is [Kred][Nout] row-major (forward: the Keras kernel as stored);
 // !B_KN: B is [Nout][Kred] row-major (dgrad: the same kernel read as its transpose).
-template <int NT, bool B_KN, bool STATS, int MI>
+template <int NT, bool B_KN, bool STATS, int MI, int BKT>
 __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
+  constexpr int AP = BKT + 4;   // A pitch: rows 4 apart land 16 banks apart -> ds_read_b128 conflict-free
+  constexpr int KQ = BKT / 4;   // float4 per K-tile row
+  constexpr int RP = 256 / KQ;  // A rows staged per pass of the 256 threads
+  constexpr int NA = (64 * MI) / RP;
   constexpr int BM = 64 * MI;   // 4 waves x MI tiles of 16 rows
   constexpr int BN = 16 * NT;
-  constexpr int BPITCH = B_KN ? (BN + 4) : APITCH;
-  constexpr int BS_FLOATS = B_KN ? BK * BPITCH : BN * APITCH;
-  constexpr int NB4 = (8 * BN + 255) / 256;  // float4 per thread for the B tile
-  __shared__ __attribute__((aligned(16))) float As[BM * APITCH];
-  __shared__ __attribute__((aligned(16))) float Bs[BS_FLOATS];
-  __shared__ float red[STATS ? 2 * 4 * BN : 1];
+  constexpr int BPITCH = B_KN ? (BN + 4) : AP;
+  constexpr int BS_FLOATS = B_KN ? BKT * BPITCH : BN * AP;
+  constexpr int NB4 = (KQ * BN + 255) / 256;  // float4 per thread for the B tile
   // epilogue transpose buffer (wave-private slices): accumulators go out as whole 256-B row segments
   constexpr int TPP = NT < 4 ? NT : 4;            // 16-column tiles per epilogue pass
   constexpr int NPASS = (NT + TPP - 1) / TPP;
   constexpr int CH = 16 * TPP;
   constexpr int EPITCH = CH + 4;
   constexpr int RW = 16 * MI;                      // rows per wave
-  __shared__ __attribute__((aligned(16))) float Es[4 * RW * EPITCH];
+  // one dynamic LDS object.  BKT = 64: the epilogue buffer overlays the operand tiles (one extra barrier per
+  // M tile) so that two workgroups still fit a CU
+  constexpr int AS_FLOATS = BM * AP;
+  constexpr int ES_FLOATS = 4 * RW * EPITCH;
+  constexpr int OPER_FLOATS = AS_FLOATS + BS_FLOATS;
+  constexpr bool OVERLAY = BKT > 32;
+  constexpr int RED_OFF = OVERLAY ? (OPER_FLOATS > ES_FLOATS ? OPER_FLOATS : ES_FLOATS) : OPER_FLOATS + ES_FLOATS;
+  extern __shared__ __attribute__((aligned(16))) float g_lds[];
+  float* As = g_lds;
+  float* Bs = g_lds + AS_FLOATS;
+  float* Es = OVERLAY ? g_lds : g_lds + OPER_FLOATS;
+  float* red = g_lds + RED_OFF;
 
   const int t = threadIdx.x;
   const int l = t & 63;
@@ -71,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
   const int l15 = l & 15;
   const int q = l >> 4;
   const int n0 = blockIdx.y * BN;
-  const int nk = (p.K + BK - 1) / BK;
+  const int nk = (p.K + BKT - 1) / BKT;
   const int my_tiles = (p.num_m_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int it_total = my_tiles * nk;
 
@@ -79,30 +91,30 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
   // (rows >= M re-read row M-1, columns >= K re-read the last float4) and invalid lanes are zeroed by a
   // select when the tile is written to LDS: no exec-masked branch per load (13 of them per K-step
   // before), one v_add per address.  Hosts reject operands of 4 GiB or more.
-  const int ar = t >> 3;         // A row within a 32-row pass
-  const int akq = (t & 7) * 4;   // A k offset within the K tile
+  const int ar = t / KQ;         // A row within a pass of RP rows
+  const int akq = (t % KQ) * 4;  // A k offset within the K tile
   const char* Ab = reinterpret_cast<const char*>(p.A);
   const char* Bb = reinterpret_cast<const char*>(p.B);
 
-  float4 ra[2 * MI];
+  float4 ra[NA];
   float4 rb[NB4];
   float4 rsc = make_float4(1.f, 1.f, 1.f, 1.f), rsh = zero4();
-  uint32_t a_row[2 * MI];        // byte offset of this thread's A rows in the current M tile
+  uint32_t a_row[NA];        // byte offset of this thread's A rows in the current M tile
   uint32_t b_off[NB4];           // byte offset of this thread's B float4s at k0 = 0
   bool b_nok[NB4];               // column (B_KN) / row (!B_KN) of the B tile inside the matrix
   int pf_m0 = -1;
 #pragma unroll
   for (int i = 0; i < NB4; ++i) {
-    const int idx = min(t + 256 * i, 8 * BN - 1);
+    const int idx = min(t + 256 * i, KQ * BN - 1);
     if (B_KN) {
       const int kk = idx / (BN / 4), nq = idx - kk * (BN / 4);
       const int n = n0 + nq * 4;
-      b_nok[i] = (t + 256 * i < 8 * BN) && n < p.N;
+      b_nok[i] = (t + 256 * i < KQ * BN) && n < p.N;
       b_off[i] = (uint32_t)(min(n, p.N - 4)) * 4u;    // + k * ldb * 4 per K-step
     } else {
-      const int r = idx >> 3;
+      const int r = idx / KQ;
       const int n = n0 + r;
-      b_nok[i] = (t + 256 * i < 8 * BN) && n < p.N;
+      b_nok[i] = (t + 256 * i < KQ * BN) && n < p.N;
       b_off[i] = (uint32_t)min(n, p.N - 1) * (uint32_t)p.ldb * 4u;   // + k * 4 per K-step
     }
   }
@@ -111,27 +123,27 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
     const int kt = it % nk;
     const int mt = blockIdx.x + (it / nk) * gridDim.x;
     const int m0 = mt * BM;
-    const int k0 = kt * BK;
+    const int k0 = kt * BKT;
     if (m0 != pf_m0) {
       pf_m0 = m0;
 #pragma unroll
-      for (int i = 0; i < 2 * MI; ++i) a_row[i] = (uint32_t)min(m0 + ar + 32 * i, p.M - 1) * (uint32_t)p.lda * 4u;
+      for (int i = 0; i < NA; ++i) a_row[i] = (uint32_t)min(m0 + ar + RP * i, p.M - 1) * (uint32_t)p.lda * 4u;
     }
     const uint32_t kb = (uint32_t)min(k0 + akq, p.K - 4) * 4u;
 #pragma unroll
-    for (int i = 0; i < 2 * MI; ++i) ra[i] = *reinterpret_cast<const float4*>(Ab + (a_row[i] + kb));
+    for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4*>(Ab + (a_row[i] + kb));
     if (p.scale) {
       rsc = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.scale) + kb);
       rsh = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.shift) + kb);
     }
 #pragma unroll
     for (int i = 0; i < NB4; ++i) {
-      const int idx = min(t + 256 * i, 8 * BN - 1);
+      const int idx = min(t + 256 * i, KQ * BN - 1);
       if (B_KN) {
         const int kk = idx / (BN / 4);
         rb[i] = *reinterpret_cast<const float4*>(Bb + (b_off[i] + (uint32_t)min(k0 + kk, p.K - 1) * (uint32_t)p.ldb * 4u));
       } else {
-        const int kq = (idx & 7) * 4;
+        const int kq = (idx % KQ) * 4;
         rb[i] = *reinterpret_cast<const float4*>(Bb + (b_off[i] + (uint32_t)min(k0 + kq, p.K - 4) * 4u));
       }
     }
@@ -152,26 +164,26 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
     const int kt = it % nk;
     const int mt = blockIdx.x + (it / nk) * gridDim.x;
     const int m0 = mt * BM;
-    const int k0 = kt * BK;
+    const int k0 = kt * BKT;
     const bool kok = k0 + akq < p.K;
 #pragma unroll
-    for (int i = 0; i < 2 * MI; ++i) {
-      const int r = ar + 32 * i;
+    for (int i = 0; i < NA; ++i) {
+      const int r = ar + RP * i;
       // zero rows/cols stay exactly zero (padding of the M and K tails)
       const float4 v = prologue4(ra[i]);
       const bool ok = kok && m0 + r < p.M;
-      *reinterpret_cast<float4*>(&As[r * APITCH + akq]) = ok ? v : zero4();
+      *reinterpret_cast<float4*>(&As[r * AP + akq]) = ok ? v : zero4();
     }
 #pragma unroll
     for (int i = 0; i < NB4; ++i) {
       const int idx = t + 256 * i;
-      if (idx < 8 * BN) {
+      if (idx < KQ * BN) {
         if (B_KN) {
           const int kk = idx / (BN / 4), nq = idx - kk * (BN / 4);
           *reinterpret_cast<float4*>(&Bs[kk * BPITCH + nq * 4]) = (b_nok[i] && k0 + kk < p.K) ? rb[i] : zero4();
         } else {
-          const int r = idx >> 3, kq = (idx & 7) * 4;
-          *reinterpret_cast<float4*>(&Bs[r * APITCH + kq]) = (b_nok[i] && k0 + kq < p.K) ? rb[i] : zero4();
+          const int r = idx / KQ, kq = (idx % KQ) * 4;
+          *reinterpret_cast<float4*>(&Bs[r * AP + kq]) = (b_nok[i] && k0 + kq < p.K) ? rb[i] : zero4();
         }
       }
     }
@@ -195,22 +207,29 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
 #else
 #define STAMP(i) {}
 #endif
-  if (p.stagger > 0 && (int)(blockIdx.x + gridDim.x * blockIdx.y) >= 256)
-    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+  // ablation modes of the instrumented build (scripts/micro/build_stamp.sh, DL3P_GEMM_STAGGER): 100 = no staging
+  // after the first K-step, 101 = also no epilogue, 102 = no global prefetch.  Measured on 266256x304x256:
+  // 497 us -> 447 (102) -> 386 (100) -> 355 (101): the MFMA loop alone runs at 94 % of the clock- and
+  // tile-quantisation-adjusted peak; staging costs 22 %, the epilogue 6 %.
+#ifdef DL3P_STAMP
+  const int dbg = p.stagger;
+#else
+  constexpr int dbg = 0;
+#endif
   if (it_total > 0) prefetch(0);
   for (int it = 0; it < it_total; ++it) {
-    stage(it);
+    if (dbg < 100 || dbg == 102 || it == 0) stage(it);
     STAMP(0)
     __syncthreads();
     STAMP(1)
-    if (it + 1 < it_total) prefetch(it + 1);
+    if (it + 1 < it_total && dbg < 100) prefetch(it + 1);
 #pragma unroll
-    for (int g = 0; g < BK / 16; ++g) {
+    for (int g = 0; g < BKT / 16; ++g) {
       const int kc = g * 16 + q * 4;
       float4 a[MI];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
-        a[mi] = *reinterpret_cast<const float4*>(&As[(w * 16 * MI + mi * 16 + l15) * APITCH + kc]);
+        a[mi] = *reinterpret_cast<const float4*>(&As[(w * 16 * MI + mi * 16 + l15) * AP + kc]);
 #pragma unroll
       for (int ni = 0; ni < NT; ++ni) {
         float b[4];
@@ -218,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) b[j] = Bs[(kc + j) * BPITCH + ni * 16 + l15];
         } else {
-          const float4 bv = *reinterpret_cast<const float4*>(&Bs[(ni * 16 + l15) * APITCH + kc]);
+          const float4 bv = *reinterpret_cast<const float4*>(&Bs[(ni * 16 + l15) * AP + kc]);
           b[0] = bv.x; b[1] = bv.y; b[2] = bv.z; b[3] = bv.w;
         }
 #pragma unroll
@@ -233,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
     STAMP(2)
     __syncthreads();
     STAMP(3)
-    if (it % nk == nk - 1) {
+    if (it % nk == nk - 1 && dbg != 101) {
       // epilogue of this M tile.  After the MFMAs a lane holds 4 consecutive channels of pixel l15 per
       // accumulator; stored directly that is 16 rows x 64 B per store instruction (half cache lines,
       // measured: 13.6k cycles per tile, and the next tile's staging waits behind those stores).  The tile
@@ -285,6 +304,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
           else rows(std::false_type{});
         }
       }
+      if (OVERLAY) __syncthreads();   // the next stage() overwrites the epilogue buffer
       STAMP(4)
     }
   }
@@ -875,17 +895,34 @@ static void gemm_grid(int M, int N, int nt, int* gx, int* gy, int* num_m_tiles, 
   *gx = g; *gy = nb; *num_m_tiles = mt; *mi_out = mi;
 }
 
-template <bool B_KN, bool STATS, int MI>
+template <int NT, bool B_KN, bool STATS, int MI, int BKT>
+static void launch_gemm_one(const GemmParams& p, dim3 grid, hipStream_t st) {
+  constexpr int BM = 64 * MI, BN = 16 * NT, AP = BKT + 4;
+  constexpr int BS = B_KN ? BKT * (BN + 4) : BN * AP;
+  constexpr int TPP = NT < 4 ? NT : 4;
+  constexpr int ES = 4 * 16 * MI * (16 * TPP + 4);
+  constexpr int OPER = BM * AP + BS;
+  constexpr int RED = STATS ? 2 * 4 * BN : 0;
+  constexpr size_t lds = sizeof(float) * (size_t)((BKT > 32 ? (OPER > ES ? OPER : ES) : OPER + ES) + RED);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)pw_gemm_kernel<NT, B_KN, STATS, MI, BKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dl3p_launch(pw_gemm_kernel<NT, B_KN, STATS, MI, BKT>, grid, dim3(256), lds, st, p);
+}
+
+template <bool B_KN, bool STATS, int MI, int BKT>
 static void launch_gemm_mi(const GemmParams& p, int nt, dim3 grid, hipStream_t st) {
-  dim3 block(256);
   switch (nt) {
-    case 1: dl3p_launch(pw_gemm_kernel<1, B_KN, STATS, MI>, grid, block, 0, st, p); break;
-    case 2: dl3p_launch(pw_gemm_kernel<2, B_KN, STATS, MI>, grid, block, 0, st, p); break;
-    case 3: dl3p_launch(pw_gemm_kernel<3, B_KN, STATS, MI>, grid, block, 0, st, p); break;
-    case 4: dl3p_launch(pw_gemm_kernel<4, B_KN, STATS, MI>, grid, block, 0, st, p); break;
-    case 5: dl3p_launch(pw_gemm_kernel<5, B_KN, STATS, MI>, grid, block, 0, st, p); break;
-    case 6: dl3p_launch(pw_gemm_kernel<6, B_KN, STATS, MI>, grid, block, 0, st, p); break;
-    default: dl3p_launch(pw_gemm_kernel<8, B_KN, STATS, MI>, grid, block, 0, st, p); break;
+    case 1: launch_gemm_one<1, B_KN, STATS, MI, BKT>(p, grid, st); break;
+    case 2: launch_gemm_one<2, B_KN, STATS, MI, BKT>(p, grid, st); break;
+    case 3: launch_gemm_one<3, B_KN, STATS, MI, BKT>(p, grid, st); break;
+    case 4: launch_gemm_one<4, B_KN, STATS, MI, BKT>(p, grid, st); break;
+    case 5: launch_gemm_one<5, B_KN, STATS, MI, BKT>(p, grid, st); break;
+    case 6: launch_gemm_one<6, B_KN, STATS, MI, BKT>(p, grid, st); break;
+    default: launch_gemm_one<8, B_KN, STATS, MI, BKT>(p, grid, st); break;
   }
 }
 
@@ -908,8 +945,12 @@ static void launch_gemm(const GemmParams& p_in, int nt, int mi, dim3 grid, hipSt
     else launch_pp_mi<B_KN, STATS, 2>(p, nt, g2, st);
     return;
   }
-  if (mi == 1) launch_gemm_mi<B_KN, STATS, 1>(p, nt, grid, st);
-  else launch_gemm_mi<B_KN, STATS, 2>(p, nt, grid, st);
+  // K tile 64 deep (half the barriers and staging passes per MFMA) was measured neutral on the decoder layers:
+  // the loop is bound by matrix-pipe sharing between the two resident workgroups, not by barrier count
+  static const int bk64_min_k = getenv("DL3P_GEMM_BK64_MIN_K") ? atoi(getenv("DL3P_GEMM_BK64_MIN_K")) : (1 << 30);   // measured neutral (+-2 %): off
+  if (mi == 1) launch_gemm_mi<B_KN, STATS, 1, 32>(p, nt, grid, st);
+  else if (p.K >= bk64_min_k && nt >= 4) launch_gemm_mi<B_KN, STATS, 2, 64>(p, nt, grid, st);
+  else launch_gemm_mi<B_KN, STATS, 2, 32>(p, nt, grid, st);
 }
 
 static int check_mat(const char* fn, const void* ptr, int ld, int cols) {
