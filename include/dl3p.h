@@ -214,6 +214,14 @@ int dl3p_upsample_softmax_ce(const float* z, int ldz, const float* labels, int i
                              float* logits_big, float* probs, float* dlogits_big, int ld_big,
                              float* loss_partials, int* rows_out,
                              int N, int h, int w, int C, int H, int W, void* stream);
+/* Training head in one launch: the same forward + loss as dl3p_upsample_softmax_ce AND the transposed
+ * pred_resize of the gradient (what dl3p_resize_bilinear_bwd(dlogits_big) returns), gz [N,h,w,C] (ldgz),
+ * without ever writing the (N,H,W,C) gradient.  Available for upsampling factors up to ~4.2
+ * (dl3p_head_train_supported() == 1); loss_partials[rows] as above. */
+int dl3p_head_train_supported(int h, int w, int C, int H, int W);
+int dl3p_head_train(const float* z, int ldz, const float* labels, int ignore_index, float inv_count,
+                    float* gz, int ldgz, int accumulate, float* loss_partials, int* rows_out,
+                    int N, int h, int w, int C, int H, int W, void* stream);
 /* out[n] (+)= sum over rows of partials[rows][n]   (loss, wgrad slabs) */
 int dl3p_reduce_rows(const float* partials, int rows, size_t n, float* out, int accumulate, void* stream);
 

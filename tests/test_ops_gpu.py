@@ -266,6 +266,31 @@ def test_head_softmax_ce(ops, C, ignore):
     assert float(out['dlogits'][..., C:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('case', [(2, 9, 9, 33, 33, 21, 255), (1, 33, 33, 129, 129, 19, 255), (2, 17, 23, 65, 89, 21, 0),
+                                  (1, 129, 129, 513, 513, 21, 255)])
+def test_head_train_fused(ops, case):
+    """fused training head == softmax-CE head followed by the transposed pred_resize, and == the oracle"""
+    N, h, w, H, W, C, ignore = case
+    assert ops.head_train_supported(h, w, C, H, W)
+    rng = np.random.default_rng(C + h)
+    cp = ((C + 3) // 4) * 4
+    z = np.zeros((N, h, w, cp)); z[..., :C] = rng.standard_normal((N, h, w, C)) * 3
+    lab = rng.integers(0, C, (N, H, W)).astype(np.float64)
+    lab[rng.uniform(size=lab.shape) < 0.1] = 255
+    labels = T(lab.reshape(N, H * W, 1))
+    loss, gz = ops.head_train(T(z), C, H, W, labels, ignore)
+    two = ops.upsample_softmax_ce(T(z), C, H, W, labels, ignore, want_grad=True)
+    gz2 = ops.resize_bilinear_bwd(two['dlogits'], h, w)
+    assert torch.equal(gz, gz2), float((gz - gz2).abs().max())          # same summation order -> same bits
+    close(loss, two['loss'].cpu().numpy(), rtol=1e-5, what='fused loss vs two-kernel loss')
+    if H * W <= 129 * 129:
+        big = O.resize_bilinear_fwd(z[..., :C], H, W)
+        loss_ref, _, g_ref = O.sparse_ce_fwd_bwd(big, lab, ignore)
+        close(loss, [loss_ref], rtol=1e-4, what='fused loss')
+        close(gz[..., :C], O.resize_bilinear_bwd(g_ref, h, w), rtol=1e-4, atol=1e-9, what='fused d loss / d z')
+    assert not ops.head_train_supported(33, 33, 21, 513, 513)
+
+
 def test_se_multiply_and_bare_activation(ops):
     rng = np.random.default_rng(21)
     N, H, W, C = 3, 7, 9, 24

@@ -11,6 +11,8 @@
 // operator in gather form (each input pixel sums the output pixels that read it) -> no atomics.
 #include "common.h"
 
+// exp of the max-shifted logits is the hardware v_exp_f32 (1 ulp on the [-87, 0] arguments a softmax sees); the
+// full-range expf costs ~25 instructions x 21 classes per pixel and made the head kernels VALU-bound
 struct Lerp { int lo, hi; float t; };
 __device__ __forceinline__ Lerp lerp_coeff(int o, float scale, int in_size) {
   const float src = ((float)o + 0.5f) * scale - 0.5f;
@@ -69,6 +71,7 @@ __device__ __forceinline__ void touch_range(int i, float inv_scale, int out_size
   o1 = min((int)ceilf(b) + 1, out_size - 1);
 }
 
+#define RB_MAXW 12
 __global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeParams p) {
   const int b = blockIdx.x;
   const int slab = b / p.nbx;
@@ -95,18 +98,46 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeParams p) {
     if (ix == p.w - 1) x1 = p.W - 1;
     float4 acc = zero4();
     const float* gimg = p.x + (size_t)n * p.H * p.W * p.ldx + c;
-    for (int oy = y0; oy <= y1; ++oy) {
-      const Lerp ly = lerp_coeff(oy, sy, p.h);
-      const float wy = (ly.lo == iy ? 1.f - ly.t : 0.f) + (ly.hi == iy ? ly.t : 0.f);
-      if (wy == 0.f) continue;
-      for (int ox = x0; ox <= x1; ++ox) {
+    if (x1 - x0 < RB_MAXW) {
+      // column weights once per pixel (not once per row): the window is at most RB_MAXW wide for scales <= ~4
+      float wxs[RB_MAXW];
+#pragma unroll
+      for (int j = 0; j < RB_MAXW; ++j) {
+        const int ox = min(x0 + j, p.W - 1);
         const Lerp lx = lerp_coeff(ox, sx, p.w);
         const float wx = (lx.lo == ix ? 1.f - lx.t : 0.f) + (lx.hi == ix ? lx.t : 0.f);
-        if (wx == 0.f) continue;
-        const float wgt = wy * wx;
-        const float4 g = ld4(gimg + ((size_t)oy * p.W + ox) * p.ldx);
-        acc.x = fmaf(g.x, wgt, acc.x); acc.y = fmaf(g.y, wgt, acc.y);
-        acc.z = fmaf(g.z, wgt, acc.z); acc.w = fmaf(g.w, wgt, acc.w);
+        wxs[j] = (x0 + j <= x1) ? wx : 0.f;
+      }
+      for (int oy = y0; oy <= y1; ++oy) {
+        const Lerp ly = lerp_coeff(oy, sy, p.h);
+        const float wy = (ly.lo == iy ? 1.f - ly.t : 0.f) + (ly.hi == iy ? ly.t : 0.f);
+        if (wy == 0.f) continue;
+        // all loads of the row first (columns past x1 re-read the last one with weight 0: fma(g, 0, acc) == acc)
+        const float* grow = gimg + (size_t)oy * p.W * p.ldx;
+        float4 g[RB_MAXW];
+#pragma unroll
+        for (int j = 0; j < RB_MAXW; ++j) g[j] = ld4(grow + (size_t)min(x0 + j, x1) * p.ldx);
+#pragma unroll
+        for (int j = 0; j < RB_MAXW; ++j) {
+          const float wgt = wy * wxs[j];
+          acc.x = fmaf(g[j].x, wgt, acc.x); acc.y = fmaf(g[j].y, wgt, acc.y);
+          acc.z = fmaf(g[j].z, wgt, acc.z); acc.w = fmaf(g[j].w, wgt, acc.w);
+        }
+      }
+    } else {
+      for (int oy = y0; oy <= y1; ++oy) {
+        const Lerp ly = lerp_coeff(oy, sy, p.h);
+        const float wy = (ly.lo == iy ? 1.f - ly.t : 0.f) + (ly.hi == iy ? ly.t : 0.f);
+        if (wy == 0.f) continue;
+        for (int ox = x0; ox <= x1; ++ox) {
+          const Lerp lx = lerp_coeff(ox, sx, p.w);
+          const float wx = (lx.lo == ix ? 1.f - lx.t : 0.f) + (lx.hi == ix ? lx.t : 0.f);
+          if (wx == 0.f) continue;
+          const float wgt = wy * wx;
+          const float4 g = ld4(gimg + ((size_t)oy * p.W + ox) * p.ldx);
+          acc.x = fmaf(g.x, wgt, acc.x); acc.y = fmaf(g.y, wgt, acc.y);
+          acc.z = fmaf(g.z, wgt, acc.z); acc.w = fmaf(g.w, wgt, acc.w);
+        }
       }
     }
     float* o = p.y + (((size_t)n * p.h + iy) * p.w + ix) * p.ldy + c;
@@ -166,9 +197,18 @@ struct HeadParams {
 template <int CP>  // padded channel count held in registers (multiple of 4, >= C)
 __global__ __launch_bounds__(256) void head_kernel(HeadParams p) {
   __shared__ float wsum[4];
+  // a wave's 64 pixels are 64*CP contiguous floats of the padded (N,H,W,CP) tensors: rows written by the
+  // pixel's thread go through a wave-private LDS slice and leave as 1 KB-contiguous store instructions
+  __shared__ __attribute__((aligned(16))) float tr_s[4][64 * (CP + 4)];
+  float* trw = tr_s[threadIdx.x >> 6];
+  const int lane = threadIdx.x & 63;
   const float sy = (float)p.h / (float)p.H, sx = (float)p.w / (float)p.W;
   float loss = 0.f;
-  for (long long s = (long long)blockIdx.x * 256 + threadIdx.x; s < p.total; s += (long long)gridDim.x * 256) {
+  // whole waves stay in the loop (lanes past the end recompute the last pixel and store nothing): the
+  // coalesced gradient store below needs every lane of the wave
+  for (long long sw = (long long)blockIdx.x * 256 + threadIdx.x; sw - lane < p.total; sw += (long long)gridDim.x * 256) {
+    const bool live = sw < p.total;
+    const long long s = live ? sw : p.total - 1;
     const int ox = s % p.W;
     const int row = s / p.W;
     const int oy = row % p.H;
@@ -194,14 +234,14 @@ __global__ __launch_bounds__(256) void head_kernel(HeadParams p) {
     float sum = 0.f;
 #pragma unroll
     for (int c = 0; c < CP; ++c) {
-      e[c] = c < p.C ? expf(v[c] - mx) : 0.f;
+      e[c] = c < p.C ? __expf(v[c] - mx) : 0.f;
       sum += e[c];
     }
     const float inv = 1.f / sum;
     const size_t obase = (size_t)s * p.C;
     const size_t bbase = (size_t)s * p.ld_big;
     const bool vec = p.ld_big == CP;   // padded rows: 16-B stores, pad channels written as 0
-    if (p.logits_big) {
+    if (p.logits_big && live) {
       if (vec) {
 #pragma unroll
         for (int c4 = 0; c4 < CP / 4; ++c4)
@@ -212,7 +252,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadParams p) {
         for (int c = 0; c < CP; ++c) if (c < p.C) p.logits_big[bbase + c] = v[c];
       }
     }
-    if (p.probs) {
+    if (p.probs && live) {
 #pragma unroll
       for (int c = 0; c < CP; ++c) if (c < p.C) p.probs[obase + c] = e[c] * inv;
     }
@@ -224,7 +264,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadParams p) {
 #pragma unroll
       for (int c = 0; c < CP; ++c) if (c == lab) pt = e[c] * inv;
       const bool unclipped = pt > 1e-7f && pt < 1.f - 1e-7f;
-      if (valid) loss += -logf(fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f));
+      if (valid && live) loss += -logf(fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f));
       if (p.dlogits) {
         const float gs = (valid && unclipped) ? p.inv_count : 0.f;
         float d[CP];
@@ -233,10 +273,21 @@ __global__ __launch_bounds__(256) void head_kernel(HeadParams p) {
         if (vec) {
 #pragma unroll
           for (int c4 = 0; c4 < CP / 4; ++c4)
-            st4(p.dlogits + bbase + c4 * 4, make_float4(d[c4 * 4], d[c4 * 4 + 1], d[c4 * 4 + 2], d[c4 * 4 + 3]));
+            *reinterpret_cast<float4*>(&trw[lane * (CP + 4) + c4 * 4]) = make_float4(d[c4 * 4], d[c4 * 4 + 1], d[c4 * 4 + 2], d[c4 * 4 + 3]);
+          // other lanes' rows are read next: keep the compiler (single-thread view) from hoisting those reads
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const long long s0 = sw - lane;                     // first pixel of this wave's group
+          const int npx = (int)(p.total - s0 < 64 ? p.total - s0 : 64);
+#pragma unroll
+          for (int k = 0; k < CP / 4; ++k) {
+            const int f = lane + 64 * k;
+            const int r = f / (CP / 4), cc = f - r * (CP / 4);
+            if (r < npx) st4(p.dlogits + (size_t)s0 * CP + (size_t)f * 4, *reinterpret_cast<const float4*>(&trw[r * (CP + 4) + cc * 4]));
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... and the next pixel's writes from passing them
         } else {
 #pragma unroll
-          for (int c = 0; c < CP; ++c) if (c < p.C) p.dlogits[bbase + c] = d[c];
+          for (int c = 0; c < CP; ++c) if (c < p.C && live) p.dlogits[bbase + c] = d[c];
         }
       }
     }
@@ -275,5 +326,232 @@ extern "C" int dl3p_upsample_softmax_ce(const float* z, int ldz, const float* la
   else if (cp <= 24) hipLaunchKernelGGL((head_kernel<24>), dim3((unsigned)blocks), dim3(256), 0, st, p);
   else hipLaunchKernelGGL((head_kernel<32>), dim3((unsigned)blocks), dim3(256), 0, st, p);
   DL3P_CHECK_LAUNCH("dl3p_upsample_softmax_ce");
+  return DL3P_OK;
+}
+
+// ------------------------------------------------------------------------------ fused training head
+// pred_resize + Softmax + loss + the transposed resize of the gradient in ONE kernel: the (N,H,W,C) gradient
+// (404 MB at batch 16, written by head_kernel and read back by resize_bwd_kernel) never exists.  A workgroup
+// owns a tile of TH x TW logit pixels: it stages their neighbourhood of z in LDS, evaluates softmax / loss /
+// gradient for every full-resolution pixel that reads the tile (halo pixels are evaluated by both neighbours:
+// 2x the minimum work, all of it out of LDS), keeps that gradient tile in LDS and gathers it back onto the
+// logit pixels with the bilinear weights, in the same (oy, ox) order as resize_bwd_kernel -> same bits.
+struct HeadTrainParams {
+  const float* z; int ldz; const float* labels; int ignore_index; float inv_count;
+  float* gz; int ldgz; int accumulate; float* loss_partials;
+  int N, h, w, C, H, W, tiles_y, tiles_x;
+  long long tiles;
+};
+
+template <int CP, int TH, int TW, int EH, int EW>
+__global__ __launch_bounds__(512) void head_train_kernel(HeadTrainParams p) {
+  constexpr int NTHR = 512;
+  constexpr int ZH = TH + 4, ZW = TW + 4;                // z tile with a 2-pixel halo
+  constexpr int C4 = CP / 4;
+  extern __shared__ __attribute__((aligned(16))) float ht_lds[];
+  float* zt = ht_lds;                                    // [ZH*ZW][CP]
+  float* dt = ht_lds + ZH * ZW * CP;                     // [EH*EW][CP]
+  float* wy_s = dt + EH * EW * CP;                       // [TH][EH] row weights of the transposed resize
+  float* wx_s = wy_s + TH * EH;                          // [TW][EW]
+  int* rng_s = reinterpret_cast<int*>(wx_s + TW * EW);   // [TH][2] + [TW][2]: first / last non-zero weight
+  __shared__ float wsum[8];
+  const int t = threadIdx.x;
+  const float sy = (float)p.h / (float)p.H, sx = (float)p.w / (float)p.W;
+  const float isy = (float)p.H / (float)p.h, isx = (float)p.W / (float)p.w;
+  float loss = 0.f;
+  for (long long tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
+    const int tx = (int)(tile % p.tiles_x);
+    const int trow = (int)(tile / p.tiles_x);
+    const int ty = trow % p.tiles_y;
+    const int n = trow / p.tiles_y;
+    const int iy0 = ty * TH, ix0 = tx * TW;
+    const int iy1 = min(iy0 + TH, p.h) - 1, ix1 = min(ix0 + TW, p.w) - 1;
+    int Y0, Y1, X0, X1, tmp;
+    touch_range(iy0, isy, p.H, Y0, tmp);
+    touch_range(iy1, isy, p.H, tmp, Y1);
+    touch_range(ix0, isx, p.W, X0, tmp);
+    touch_range(ix1, isx, p.W, tmp, X1);
+    if (iy0 == 0) Y0 = 0;
+    if (iy1 == p.h - 1) Y1 = p.H - 1;
+    if (ix0 == 0) X0 = 0;
+    if (ix1 == p.w - 1) X1 = p.W - 1;
+    const int eh = Y1 - Y0 + 1, ew = X1 - X0 + 1;        // <= EH, EW (host check)
+    const int zy0 = iy0 - 2, zx0 = ix0 - 2;
+    __syncthreads();                                     // previous tile's gather is done with dt / zt
+    // 1. z neighbourhood -> LDS (rows / columns outside the map are clamped copies; never read with weight)
+    const float* zimg = p.z + (size_t)n * p.h * p.w * p.ldz;
+    for (int i = t; i < ZH * ZW * C4; i += NTHR) {
+      const int c4 = i % C4, px = i / C4;
+      const int zy = min(max(zy0 + px / ZW, 0), p.h - 1), zx = min(max(zx0 + px % ZW, 0), p.w - 1);
+      *reinterpret_cast<float4*>(&zt[px * CP + c4 * 4]) = ld4(zimg + ((size_t)zy * p.w + zx) * p.ldz + c4 * 4);
+    }
+    // weights of the transposed resize for this tile (one table entry per thread)
+    for (int i = t; i < TH * EH + TW * EW; i += NTHR) {
+      if (i < TH * EH) {
+        const int r = i / EH, oy = Y0 + i - r * EH;
+        float wgt = 0.f;
+        if (oy <= Y1 && iy0 + r <= iy1) {
+          const Lerp ly = lerp_coeff(oy, sy, p.h);
+          wgt = (ly.lo == iy0 + r ? 1.f - ly.t : 0.f) + (ly.hi == iy0 + r ? ly.t : 0.f);
+        }
+        wy_s[i] = wgt;
+      } else {
+        const int j = i - TH * EH;
+        const int r = j / EW, ox = X0 + j - r * EW;
+        float wgt = 0.f;
+        if (ox <= X1 && ix0 + r <= ix1) {
+          const Lerp lx = lerp_coeff(ox, sx, p.w);
+          wgt = (lx.lo == ix0 + r ? 1.f - lx.t : 0.f) + (lx.hi == ix0 + r ? lx.t : 0.f);
+        }
+        wx_s[j] = wgt;
+      }
+    }
+    __syncthreads();
+    if (t < TH + TW) {
+      const float* tab = t < TH ? wy_s + t * EH : wx_s + (t - TH) * EW;
+      const int len = t < TH ? EH : EW;
+      int first = len, last = -1;
+      for (int i = 0; i < len; ++i)
+        if (tab[i] != 0.f) { if (first == len) first = i; last = i; }
+      rng_s[2 * t] = first;
+      rng_s[2 * t + 1] = last;
+    }
+    // 2. every full-resolution pixel of the extent: logits, softmax, loss (owner tile only), gradient -> LDS
+    for (int e = t; e < eh * ew; e += NTHR) {
+      const int ey = e / ew, ex = e - ey * ew;
+      const int oy = Y0 + ey, ox = X0 + ex;
+      const Lerp ly = lerp_coeff(oy, sy, p.h), lx = lerp_coeff(ox, sx, p.w);
+      const float* ptl = zt + ((ly.lo - zy0) * ZW + (lx.lo - zx0)) * CP;
+      const float* ptr = zt + ((ly.lo - zy0) * ZW + (lx.hi - zx0)) * CP;
+      const float* pbl = zt + ((ly.hi - zy0) * ZW + (lx.lo - zx0)) * CP;
+      const float* pbr = zt + ((ly.hi - zy0) * ZW + (lx.hi - zx0)) * CP;
+      float v[CP];
+#pragma unroll
+      for (int c4 = 0; c4 < C4; ++c4) {
+        const float4 tl = *reinterpret_cast<const float4*>(ptl + c4 * 4), tr = *reinterpret_cast<const float4*>(ptr + c4 * 4);
+        const float4 bl = *reinterpret_cast<const float4*>(pbl + c4 * 4), br = *reinterpret_cast<const float4*>(pbr + c4 * 4);
+#define LERP2(f, i) { float top = tl.f + (tr.f - tl.f) * lx.t; float bot = bl.f + (br.f - bl.f) * lx.t; v[c4 * 4 + i] = top + (bot - top) * ly.t; }
+        LERP2(x, 0) LERP2(y, 1) LERP2(z, 2) LERP2(w, 3)
+#undef LERP2
+      }
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int c = 0; c < CP; ++c) if (c < p.C) mx = fmaxf(mx, v[c]);
+      float sum = 0.f;
+#pragma unroll
+      for (int c = 0; c < CP; ++c) {
+        v[c] = c < p.C ? __expf(v[c] - mx) : 0.f;
+        sum += v[c];
+      }
+      const float inv = 1.f / sum;
+      const int lab = (int)p.labels[((size_t)n * p.H + oy) * p.W + ox];
+      const bool masked = p.ignore_index != 0 && lab == p.ignore_index;
+      const bool valid = !masked && lab >= 0 && lab < p.C;
+      float pt = 0.f;
+#pragma unroll
+      for (int c = 0; c < CP; ++c) if (c == lab) pt = v[c] * inv;
+      const bool unclipped = pt > 1e-7f && pt < 1.f - 1e-7f;
+      const bool owner = ly.lo >= iy0 && ly.lo <= iy1 && lx.lo >= ix0 && lx.lo <= ix1;
+      if (valid && owner) loss += -logf(fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f));
+      const float gs = (valid && unclipped) ? p.inv_count : 0.f;
+#pragma unroll
+      for (int c4 = 0; c4 < C4; ++c4) {
+        float d[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int c = c4 * 4 + i;
+          d[i] = c < p.C ? gs * (v[c] * inv - (c == lab ? 1.f : 0.f)) : 0.f;
+        }
+        *reinterpret_cast<float4*>(&dt[e * CP + c4 * 4]) = make_float4(d[0], d[1], d[2], d[3]);
+      }
+    }
+    __syncthreads();
+    // 3. transposed resize: logit pixel (iy, ix) gathers the gradient of every pixel that read it
+    if (t < TH * TW * C4) {
+      const int c4 = t % C4, lp = t / C4;
+      const int iy = iy0 + lp / TW, ix = ix0 + lp % TW;
+      if (iy <= iy1 && ix <= ix1) {
+        const int ry = lp / TW, rx = lp % TW;
+        const int ey0 = rng_s[2 * ry], ey1 = rng_s[2 * ry + 1];
+        const int ex0 = rng_s[2 * (TH + rx)], ex1 = rng_s[2 * (TH + rx) + 1];
+        float4 acc = zero4();
+        for (int ey = ey0; ey <= ey1; ++ey) {
+          const float wy = wy_s[ry * EH + ey];
+          if (wy == 0.f) continue;
+          for (int ex = ex0; ex <= ex1; ++ex) {
+            const float wx = wx_s[rx * EW + ex];
+            if (wx == 0.f) continue;
+            const float wgt = wy * wx;
+            const float4 g = *reinterpret_cast<const float4*>(&dt[(ey * ew + ex) * CP + c4 * 4]);
+            acc.x = fmaf(g.x, wgt, acc.x); acc.y = fmaf(g.y, wgt, acc.y);
+            acc.z = fmaf(g.z, wgt, acc.z); acc.w = fmaf(g.w, wgt, acc.w);
+          }
+        }
+        float* o = p.gz + (((size_t)n * p.h + iy) * p.w + ix) * p.ldgz + c4 * 4;
+        if (p.accumulate) acc = add4(acc, ld4(o));
+        st4(o, acc);
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) loss += __shfl_xor(loss, off);
+  if ((t & 63) == 0) wsum[t >> 6] = loss;
+  __syncthreads();
+  if (t == 0) p.loss_partials[blockIdx.x] = (((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) + ((wsum[4] + wsum[5]) + (wsum[6] + wsum[7]))) * p.inv_count;
+}
+
+// the fused head handles upsampling factors up to ~4.2 (logits at OS 4); others use the two-kernel path
+#define HT_TH 4
+#define HT_TW 8
+#define HT_EH 26
+#define HT_EW 42
+static bool head_train_fits(int h, int w, int H, int W) {
+  if (h < 1 || w < 1 || H < h || W < w) return false;
+  const float isy = (float)H / (float)h, isx = (float)W / (float)w;
+  // extent of a tile: touch_range(first).o0 .. touch_range(last).o1
+  const float eh = ((float)HT_TH + 1.f) * isy + 5.f, ew = ((float)HT_TW + 1.f) * isx + 5.f;
+  return eh <= (float)HT_EH && ew <= (float)HT_EW;
+}
+
+extern "C" int dl3p_head_train_supported(int h, int w, int C, int H, int W) {
+  return (C > 0 && C <= 32 && head_train_fits(h, w, H, W)) ? 1 : 0;
+}
+
+template <int CP>
+static void launch_head_train(const HeadTrainParams& p, unsigned grid, hipStream_t st) {
+  constexpr size_t lds = sizeof(float) * ((size_t)CP * ((HT_TH + 4) * (HT_TW + 4) + HT_EH * HT_EW) + HT_TH * HT_EH + HT_TW * HT_EW +
+                                          2 * (HT_TH + HT_TW));
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)head_train_kernel<CP, HT_TH, HT_TW, HT_EH, HT_EW>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((head_train_kernel<CP, HT_TH, HT_TW, HT_EH, HT_EW>), dim3(grid), dim3(512), lds, st, p);
+}
+
+extern "C" int dl3p_head_train(const float* z, int ldz, const float* labels, int ignore_index, float inv_count,
+                               float* gz, int ldgz, int accumulate, float* loss_partials, int* rows_out,
+                               int N, int h, int w, int C, int H, int W, void* stream) {
+  DL3P_CHECK_ARG(z && labels && gz && loss_partials && aligned16(z) && aligned16(gz) && ldz % 4 == 0 && ldgz % 4 == 0,
+                 "dl3p_head_train: null / misaligned pointer");
+  DL3P_CHECK_ARG(dl3p_head_train_supported(h, w, C, H, W), "dl3p_head_train: upsampling %dx%d -> %dx%d not supported "
+                 "(use dl3p_upsample_softmax_ce + dl3p_resize_bilinear_bwd)", h, w, H, W);
+  const int cp = ((C + 3) / 4) * 4;
+  const int cpv = cp <= 20 ? 20 : (cp <= 24 ? 24 : 32);
+  DL3P_CHECK_ARG(ldz >= cpv && ldgz >= cpv, "dl3p_head_train: ld=%d/%d must be >= %d for C=%d", ldz, ldgz, cpv, C);
+  HeadTrainParams p = {};
+  p.z = z; p.ldz = ldz; p.labels = labels; p.ignore_index = ignore_index; p.inv_count = inv_count;
+  p.gz = gz; p.ldgz = ldgz; p.accumulate = accumulate; p.loss_partials = loss_partials;
+  p.N = N; p.h = h; p.w = w; p.C = C; p.H = H; p.W = W;
+  p.tiles_y = ceil_div(h, HT_TH); p.tiles_x = ceil_div(w, HT_TW);
+  p.tiles = (long long)N * p.tiles_y * p.tiles_x;
+  long long blocks = p.tiles < DL3P_MAX_STAT_ROWS ? p.tiles : DL3P_MAX_STAT_ROWS;
+  if (rows_out) *rows_out = (int)blocks;
+  hipStream_t st = (hipStream_t)stream;
+  if (cpv == 20) launch_head_train<20>(p, (unsigned)blocks, st);
+  else if (cpv == 24) launch_head_train<24>(p, (unsigned)blocks, st);
+  else launch_head_train<32>(p, (unsigned)blocks, st);
+  DL3P_CHECK_LAUNCH("dl3p_head_train");
   return DL3P_OK;
 }

@@ -304,7 +304,13 @@ class Executor:
         self.labels = torch.zeros(N * H * W, **self.f32)
         self.loss_partials = torch.zeros(MAX_ROWS, **self.f32)
         self.loss = torch.zeros(1, **self.f32)
-        self.dlogits_big = torch.zeros(N * H * W * self.cpad, **self.f32) if self.training else None
+        # dl3p_head_train (loss + gradient resize in one launch, no (N,H,W,C) gradient in HBM) is bit-identical to the
+        # two-kernel path but measured slower on MI355X (506 us vs 141 + 165 us at batch 16): opt-in, for memory
+        zt = self.head.tensor
+        self.fused_head = bool(self.training and os.environ.get('DL3P_FUSED_HEAD', '0') != '0' and zt is not None and
+                               zt.requires_grad and L.head_train_supported(zt.H, zt.W, self.C, H, W))
+        self.dlogits_big = (torch.zeros(N * H * W * self.cpad, **self.f32)
+                            if (self.training and not self.fused_head) else None)
         self.probs = None if self.training else torch.zeros(N * H * W * self.C, **self.f32)
         self.logits_big = None
         self.step = torch.zeros(1, dtype=torch.int64, device=self.dev)
@@ -422,7 +428,13 @@ class Executor:
         P.ctx = 'head'
         zt = self.head.tensor
         rows = ctypes.c_int(0)
-        if train:
+        if train and self.fused_head:
+            # loss + d loss / d (conv_upsample output) in one launch; the full-resolution gradient is never written
+            P.k(L.head_train, self.tptr(zt), zt.ld, self.labels.data_ptr(), int(self.ignore_index or 0),
+                1.0 / float(N * self.H * self.W), self.tptr(zt, True), zt.ld, 0, self.loss_partials.data_ptr(),
+                ctypes.byref(rows), N, zt.H, zt.W, self.C, self.H, self.W)
+            P.k(L.reduce_rows, self.loss_partials.data_ptr(), rows.value, 1, self.loss.data_ptr(), 0)
+        elif train:
             P.k(L.upsample_softmax_ce, self.tptr(zt), zt.ld, self.labels.data_ptr(), int(self.ignore_index or 0),
                 1.0 / float(N * self.H * self.W), None, None, self.dlogits_big.data_ptr(), self.cpad,
                 self.loss_partials.data_ptr(), ctypes.byref(rows), N, zt.H, zt.W, self.C, self.H, self.W)
@@ -497,7 +509,9 @@ class Executor:
         G = st.G
         zt = self.head.tensor
         # d(loss)/d(pred_resize output) -> d/d(conv_upsample output): transpose of the bilinear upsample
-        if zt.requires_grad:
+        if zt.requires_grad and self.fused_head:
+            self._acc(zt)        # the forward plan's head_train launch already wrote grad(zt)
+        elif zt.requires_grad:
             P.k(L.resize_bilinear_bwd, self.dlogits_big.data_ptr(), self.cpad, self.tptr(zt, True), zt.ld,
                 self._acc(zt), N, zt.H, zt.W, zt.C, self.H, self.W)
         ws, wsb = self.workspace.data_ptr(), self.workspace.numel() * 4

@@ -335,6 +335,25 @@ def upsample_softmax_ce(z, C, H, W, labels=None, ignore_index=255, want_probs=Fa
     return out
 
 
+def head_train_supported(h, w, C, H, W):
+    return bool(lib().head_train_supported(h, w, C, H, W))
+
+
+def head_train(z, C, H, W, labels, ignore_index=255):
+    """fused training head: z (N,h,w,Cpad) -> (loss [1], d loss / d z (N,h,w,Cpad)) without the (N,H,W,C) gradient"""
+    N, h, w, cp = z.shape
+    dev = z.device
+    zp, ldz = _pl(z)
+    gz = torch.zeros((N, h, w, cp), dtype=torch.float32, device=dev)
+    partial = torch.zeros(MAX_STAT_ROWS, dtype=torch.float32, device=dev)
+    rows = ctypes.c_int(0)
+    lib().head_train(zp, ldz, _p(labels), int(ignore_index or 0), 1.0 / float(N * H * W), _p(gz), cp, 0, _p(partial),
+                     ctypes.byref(rows), N, h, w, C, H, W, _stream())
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    lib().reduce_rows(_p(partial), rows.value, 1, _p(loss), 0, _stream())
+    return loss, gz
+
+
 def sgd_momentum(w, v, g, lr_dev, momentum=0.9, l2=0.0, grad_scale=1.0, l2_elem=None, lr_scale_elem=None):
     lib().sgd_momentum(_p(w), _p(v), _p(g), w.numel(), _p(lr_dev), float(momentum), float(l2), float(grad_scale),
                        _p(l2_elem), _p(lr_scale_elem), _stream())
