@@ -1037,67 +1037,116 @@ struct WgradParams {
   int ktiles, ntiles, mchunk;
 };
 
+// Tile = (64 KW) x (16 NW) of GW: wave w owns k rows [16 KW w, 16 KW (w+1)) and all NW column tiles.  Larger
+// tiles re-read X (N / TN times) and DY (K / TK times) less often -- at 64 x 64 the 304 x 256 decoder layer
+// pulls 2.7 GB through L2 for 0.6 GB of operands.  Loads are unconditional on clamped offsets, zeroed by select.
+template <int KW, int NW>
 __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradParams p) {
-  __shared__ __attribute__((aligned(16))) float Xs[32 * WPITCH];
-  __shared__ __attribute__((aligned(16))) float Ds[32 * WPITCH];
+  constexpr int TK = 64 * KW, TN = 16 * NW;
+  constexpr int XP = TK + 4, DP = TN + 4;      // pitches: rows 4 apart land 16 banks apart
+  constexpr int XQ = TK / 4, DQ = TN / 4;      // float4 per staged row
+  constexpr int NX = (32 * XQ) / 256, ND = (32 * DQ + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float Xs[32 * XP];
+  __shared__ __attribute__((aligned(16))) float Ds[32 * DP];
   const int t = threadIdx.x, l = t & 63, w = t >> 6, l15 = l & 15, q = l >> 4;
   const int tile = blockIdx.x;
   const int kt = tile / p.ntiles, nt = tile - kt * p.ntiles;
-  const int k0 = kt * 64, n0 = nt * 64;
+  const int k0 = kt * TK, n0 = nt * TN;
   const int m_begin = blockIdx.y * p.mchunk;
   const int m_end = min(p.M, m_begin + p.mchunk);
-  // staging: 32 rows x 64 cols = 512 float4 per operand, 2 per thread
-  const int sr = t >> 4;            // row 0..15 (+16)
-  const int sc4 = (t & 15) * 4;     // col offset
-  const bool xk_ok = k0 + sc4 < p.K;
-  const bool dn_ok = n0 + sc4 < p.N;
-  float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = zero4();
-  if (p.scale && xk_ok) { xsc = ld4(p.scale + k0 + sc4); xsh = ld4(p.shift + k0 + sc4); }
-  float4 rx[2], rd[2];
-  auto prefetch = [&](int m0) {
+  // per-thread staging constants
+  int xr[NX], dr[ND];
+  uint32_t xo[NX], dof[ND];
+  bool xok[NX], dok[ND];
+  float4 xsc[NX], xsh[NX];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = m0 + sr + 16 * i;
-      const bool mok = m < m_end;
-      rx[i] = (mok && xk_ok) ? act_apply4(fma4(ld4(p.X + (size_t)m * p.ldx + k0 + sc4), xsc, xsh), p.act) : zero4();
-      rd[i] = (mok && dn_ok) ? ld4(p.DY + (size_t)m * p.lddy + n0 + sc4) : zero4();
-    }
-  };
-  f32x4 acc[4];
+  for (int i = 0; i < NX; ++i) {
+    const int idx = t + 256 * i;
+    xr[i] = idx / XQ;
+    const int c = k0 + (idx - xr[i] * XQ) * 4;
+    xok[i] = c < p.K;
+    xo[i] = (uint32_t)min(c, p.K - 4) * 4u;
+    xsc[i] = make_float4(1.f, 1.f, 1.f, 1.f); xsh[i] = zero4();
+    if (p.scale) { xsc[i] = ld4(p.scale + min(c, p.K - 4)); xsh[i] = ld4(p.shift + min(c, p.K - 4)); }
+  }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (m_begin < m_end) prefetch(m_begin);
+  for (int i = 0; i < ND; ++i) {
+    const int idx = min(t + 256 * i, 32 * DQ - 1);
+    dr[i] = idx / DQ;
+    const int c = n0 + (idx - dr[i] * DQ) * 4;
+    dok[i] = (t + 256 * i < 32 * DQ) && c < p.N;
+    dof[i] = (uint32_t)min(c, p.N - 4) * 4u;
+  }
+  const float act_lo = p.act == DL3P_ACT_NONE ? -DL3P_INF : 0.f;
+  const float act_hi = (p.act == DL3P_ACT_NONE || p.act == DL3P_ACT_RELU) ? DL3P_INF : 6.f;
+  const char* Xb = reinterpret_cast<const char*>(p.X);
+  const char* Db = reinterpret_cast<const char*>(p.DY);
+  float4 rx[NX], rd[ND];
+#define WT_PREFETCH(m0_)                                                                                              \
+  {                                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < NX; ++i)                                                                    \
+      rx[i] = *reinterpret_cast<const float4*>(Xb + ((uint32_t)min((m0_) + xr[i], m_end - 1) * (uint32_t)p.ldx * 4u + xo[i]));   \
+    _Pragma("unroll") for (int i = 0; i < ND; ++i)                                                                    \
+      rd[i] = *reinterpret_cast<const float4*>(Db + ((uint32_t)min((m0_) + dr[i], m_end - 1) * (uint32_t)p.lddy * 4u + dof[i])); \
+  }
+  f32x4 acc[KW][NW];
+#pragma unroll
+  for (int a = 0; a < KW; ++a)
+#pragma unroll
+    for (int b = 0; b < NW; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (m_begin < m_end) WT_PREFETCH(m_begin)
   for (int m0 = m_begin; m0 < m_end; m0 += 32) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<float4*>(&Xs[(sr + 16 * i) * WPITCH + sc4]) = rx[i];
-      *reinterpret_cast<float4*>(&Ds[(sr + 16 * i) * WPITCH + sc4]) = rd[i];
+    for (int i = 0; i < NX; ++i) {
+      float4 v = fma4(rx[i], xsc[i], xsh[i]);
+      if (p.act >= DL3P_ACT_HSWISH) v = act_apply4(v, p.act);
+      else v = make_float4(__builtin_amdgcn_fmed3f(v.x, act_lo, act_hi), __builtin_amdgcn_fmed3f(v.y, act_lo, act_hi),
+                           __builtin_amdgcn_fmed3f(v.z, act_lo, act_hi), __builtin_amdgcn_fmed3f(v.w, act_lo, act_hi));
+      const bool ok = xok[i] && m0 + xr[i] < m_end;
+      *reinterpret_cast<float4*>(&Xs[xr[i] * XP + (t + 256 * i - xr[i] * XQ) * 4]) = ok ? v : zero4();
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int idx = t + 256 * i;
+      if (idx < 32 * DQ) {
+        const bool ok = dok[i] && m0 + dr[i] < m_end;
+        *reinterpret_cast<float4*>(&Ds[dr[i] * DP + (idx - dr[i] * DQ) * 4]) = ok ? make_float4(rd[i].x, rd[i].y, rd[i].z, rd[i].w) : zero4();
+      }
     }
     __syncthreads();
-    if (m0 + 32 < m_end) prefetch(m0 + 32);
+    if (m0 + 32 < m_end) WT_PREFETCH(m0 + 32)
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-      float a[4];
+      float a[KW][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) a[j] = Xs[(g * 16 + q * 4 + j) * WPITCH + w * 16 + l15];
+      for (int kw = 0; kw < KW; ++kw)
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
+        for (int j = 0; j < 4; ++j) a[kw][j] = Xs[(g * 16 + q * 4 + j) * XP + (w * KW + kw) * 16 + l15];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float b = Ds[(g * 16 + q * 4 + j) * WPITCH + ni * 16 + l15];
-          // D[n][k]: lane ends with 4 consecutive n for k = l15
-          acc[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a[j], acc[ni], 0, 0, 0);
-        }
+      for (int ni = 0; ni < NW; ++ni) {
+        float b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = Ds[(g * 16 + q * 4 + j) * DP + ni * 16 + l15];
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)   // D[n][k]: lane ends with 4 consecutive n for k = l15
+            acc[kw][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[kw][j], acc[kw][ni], 0, 0, 0);
       }
     }
     __syncthreads();
   }
-  const int k = k0 + w * 16 + l15;
+#undef WT_PREFETCH
   float* slab = p.slabs + (size_t)blockIdx.y * p.K * p.N;
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
-    const int n = n0 + ni * 16 + q * 4;
-    if (k < p.K && n < p.N) st4(slab + (size_t)k * p.N + n, make_float4(acc[ni][0], acc[ni][1], acc[ni][2], acc[ni][3]));
+  for (int kw = 0; kw < KW; ++kw) {
+    const int k = k0 + (w * KW + kw) * 16 + l15;
+#pragma unroll
+    for (int ni = 0; ni < NW; ++ni) {
+      const int n = n0 + ni * 16 + q * 4;
+      if (k < p.K && n < p.N)
+        st4(slab + (size_t)k * p.N + n, make_float4(acc[kw][ni][0], acc[kw][ni][1], acc[kw][ni][2], acc[kw][ni][3]));
+    }
   }
 }
 
@@ -1298,11 +1347,31 @@ static void launch_wgrad_small_any(const WgradParams& p, SmallShape sh, int grid
 #undef DL3P_WS
 }
 
+// tile shape (KW, NW) -> (64 KW) x (16 NW): fewest padded MFMA columns, weighted by the operand re-reads
+static void wgrad_pick_tile(int M, int K, int N, int* kw, int* nw) {
+  static const int cand[4][2] = {{1, 4}, {2, 4}, {1, 8}, {2, 8}};
+  static const int force = getenv("DL3P_WGRAD_TILE") ? atoi(getenv("DL3P_WGRAD_TILE")) : -1;
+  // measured: larger tiles pay only when M is large (decoder layers: 64 x 128 is 8-10 % faster than 64 x 64);
+  // on the 17424-row layers they cut the number of workgroups too far
+  if (force < 0 && M < 65536) { *kw = 1; *nw = 4; return; }
+  float best = 1e30f;
+  for (int i = 0; i < 4; ++i) {
+    if (force >= 0 && i != force) continue;
+    const int tk = 64 * cand[i][0], tn = 16 * cand[i][1];
+    const float area = (float)(ceil_div(K, tk) * tk) * (float)(ceil_div(N, tn) * tn);
+    const float cost = area * (1.f + 0.5f * (64.f / tk + 64.f / tn));
+    if (cost < best) { best = cost; *kw = cand[i][0]; *nw = cand[i][1]; }
+  }
+}
+
 static void wgrad_split(int M, int K, int N, int* ktiles, int* ntiles, int* splits, int* mchunk) {
-  *ktiles = ceil_div(K, 64);
-  *ntiles = ceil_div(N, 64);
+  int kw, nw;
+  wgrad_pick_tile(M, K, N, &kw, &nw);
+  *ktiles = ceil_div(K, 64 * kw);
+  *ntiles = ceil_div(N, 16 * nw);
   const int tiles = *ktiles * *ntiles;
-  int s = (DL3P_NUM_CUS * 4) / tiles;
+  static const int per_cu = getenv("DL3P_WGRAD_PER_CU") ? atoi(getenv("DL3P_WGRAD_PER_CU")) : 4;
+  int s = (DL3P_NUM_CUS * per_cu) / tiles;
   if (s < 1) s = 1;
   int max_s = ceil_div(M, 256);          // at least 256 rows per slice
   if (s > max_s) s = max_s;
@@ -1310,6 +1379,16 @@ static void wgrad_split(int M, int K, int N, int* ktiles, int* ntiles, int* spli
   int chunk = ceil_div(ceil_div(M, s), 32) * 32;
   *splits = ceil_div(M, chunk);
   *mchunk = chunk;
+}
+
+static void launch_wgrad_tiled(const WgradParams& p, int splits, hipStream_t st) {
+  int kw, nw;
+  wgrad_pick_tile(p.M, p.K, p.N, &kw, &nw);
+  const dim3 grid(p.ktiles * p.ntiles, splits), block(256);
+  if (kw == 1 && nw == 4) dl3p_launch(pw_wgrad_kernel<1, 4>, grid, block, 0, st, p);
+  else if (kw == 2 && nw == 4) dl3p_launch(pw_wgrad_kernel<2, 4>, grid, block, 0, st, p);
+  else if (kw == 1 && nw == 8) dl3p_launch(pw_wgrad_kernel<1, 8>, grid, block, 0, st, p);
+  else dl3p_launch(pw_wgrad_kernel<2, 8>, grid, block, 0, st, p);
 }
 
 // column sums of dy (bias gradient): one partial row per workgroup
@@ -1364,7 +1443,7 @@ extern "C" int dl3p_pwconv_bwd_weight(const float* x, int ldx, const float* in_s
     launch_wgrad_small_any(p, sh, splits, st);
   } else {
     wgrad_split(M, K, N, &p.ktiles, &p.ntiles, &splits, &p.mchunk);
-    dl3p_launch(pw_wgrad_kernel, dim3(p.ktiles * p.ntiles, splits), dim3(256), 0, st, p);
+    launch_wgrad_tiled(p, splits, st);
   }
   DL3P_CHECK_LAUNCH("dl3p_pwconv_bwd_weight");
   rc = dl3p_reduce_rows_impl(workspace, splits, (size_t)K * N, gw, 0, st);
