@@ -282,7 +282,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(EwParams p) {
 static int ew_setup(EwParams& p, long long M, int C, int max_rows) {
   pick_lanes(C, &p.c4s, &p.px, &p.nslab);
   long long need = ceil_div_ll(M, p.px);
-  long long target = DL3P_NUM_CUS * 8 / p.nslab;
+  static const int ew_per_cu = getenv("DL3P_EW_PER_CU") ? atoi(getenv("DL3P_EW_PER_CU")) : 4;   // 8 -> 4: fewer partial rows for the finalize kernels, same streaming rate
+  long long target = DL3P_NUM_CUS * ew_per_cu / p.nslab;
   if (target < 1) target = 1;
   long long nbx = need < target ? need : target;
   if (nbx < 1) nbx = 1;
