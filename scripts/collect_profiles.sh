@@ -10,6 +10,7 @@ grep '"metric"' $O/bench_$R.log > $O/bench_$R.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $O/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_F32 --kernel-trace --output-format csv -d $O/pmc_mfma -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $O/pmc_mfma.log 2>&1
 cp $O/kt/*/*kernel_stats.csv $O/${R}_kernel_stats.csv
 python3 scripts/prof_summary.py $O/kt 14 40 > $O/${R}_kernel_summary.txt
 python3 - <<PY
@@ -42,5 +43,27 @@ if 'FETCH_SIZE' in t and 'WRITE_SIZE' in t:
                'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, eager launches; FETCH_SIZE doubled (gfx950)'},
               open('$O/${R}_roofline_traffic.json', 'w'))
 PY
-rm -rf $O/kt $O/pmc_fetch $O/pmc_write
+python3 - <<PY
+# MFMA utilisation of the pointwise GEMM kernels: busy cycles of the matrix pipe / busy CU cycles (x4: 4 SIMDs per CU
+# are counted in SQ_VALU_MFMA_BUSY_CYCLES), and MFMA instructions issued per launch
+import csv, glob, collections
+f = glob.glob('$O/pmc_mfma/**/*counter_collection.csv', recursive=True)
+out = open('$O/${R}_mfma_counters_gemm.csv', 'w')
+out.write('kernel,grid,calls,mfma_busy_cycles,busy_cu_cycles,mfma_insts_f32,mfma_busy_over_busy_cu\n')
+if f:
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f[0])):
+        kn = r['Kernel_Name']
+        if 'pw_' not in kn: continue
+        agg[(kn[:70], r['Grid_Size'])][r['Counter_Name']].append(float(r['Counter_Value']))
+    rows = []
+    for (kn, g), c in agg.items():
+        m = c.get('SQ_VALU_MFMA_BUSY_CYCLES', [0]); b = c.get('SQ_BUSY_CU_CYCLES', [0]); i = c.get('SQ_INSTS_VALU_MFMA_F32', [0])
+        mm, bb, ii = sum(m) / len(m), sum(b) / len(b), sum(i) / len(i)
+        rows.append((mm, '"%s",%s,%d,%.0f,%.0f,%.0f,%.3f\n' % (kn, g, len(m), mm, bb, ii, mm / bb / 4 if bb else 0)))
+    for _, line in sorted(rows, reverse=True)[:40]:
+        out.write(line)
+out.close()
+PY
+rm -rf $O/kt $O/pmc_fetch $O/pmc_write $O/pmc_mfma
 ls -la $O
