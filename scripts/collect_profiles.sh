@@ -49,7 +49,7 @@ python3 - <<PY
 import csv, glob, collections
 f = glob.glob('$O/pmc_mfma/**/*counter_collection.csv', recursive=True)
 out = open('$O/${R}_mfma_counters_gemm.csv', 'w')
-out.write('kernel,grid,calls,mfma_busy_cycles,busy_cu_cycles,mfma_insts_f32,mfma_busy_over_busy_cu\n')
+out.write('kernel,grid,calls,mfma_busy_cycles,busy_cu_cycles,mfma_insts_f32,mfma_pipe_utilisation\n')
 if f:
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f[0])):
