@@ -350,304 +350,10 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
   }
 }
 
-// ------------------------------------------------------------------------------ ping-pong variant
-// Two of the workgroups above fused into one 512-thread workgroup: waves 0-3 ("half 0") and waves 4-7
-// ("half 1") each own a stream of M tiles with private LDS tiles, and alternate roles every barrier:
-// while one half issues its K-step's MFMAs the other half (its waves sit on the same four SIMDs) does
-// the non-matrix work of its next K-step -- waiting for the prefetched global loads, the BN+activation
-// prologue, the LDS writes, and the epilogue of a finished tile.  Two independent co-resident workgroups
-// run the same program in lockstep (both stage, then both contend for the matrix pipe: measured 6.8k
-// cycles per 4.1k-cycle MFMA block plus 2.5k of staging per K-step); the barrier-enforced anti-phase
-// keeps the matrix pipe fed from one half at a time (MI355X_MICROARCH.md, "Two waves per SIMD").
-template <int NT, bool B_KN, bool STATS, int MI>
-__global__ __launch_bounds__(512) void pw_gemm_pp_kernel(GemmParams p) {
-  constexpr int BM = 64 * MI;
-  constexpr int BN = 16 * NT;
-  constexpr int BPITCH = B_KN ? (BN + 4) : APITCH;
-  constexpr int AS_FLOATS = BM * APITCH;
-  constexpr int BS_FLOATS = B_KN ? BK * BPITCH : BN * APITCH;
-  constexpr int NB4 = (8 * BN + 255) / 256;
-  constexpr int TPP = NT < 4 ? NT : 4;
-  constexpr int NPASS = (NT + TPP - 1) / TPP;
-  constexpr int CH = 16 * TPP;
-  constexpr int EPITCH = CH + 4;
-  constexpr int RW = 16 * MI;
-  constexpr int ES_FLOATS = 4 * RW * EPITCH;
-  constexpr int RED_FLOATS = STATS ? 2 * 4 * BN : 0;
-  constexpr int HALF_FLOATS = AS_FLOATS + BS_FLOATS + ES_FLOATS + RED_FLOATS;
-  extern __shared__ __attribute__((aligned(16))) float pp_lds[];   // ONE LDS object (both halves)
-  const int half = threadIdx.x >> 8;
-  float* As = pp_lds + half * HALF_FLOATS;
-  float* Bs = As + AS_FLOATS;
-  float* Es = Bs + BS_FLOATS;
-  float* red = Es + ES_FLOATS;
-
-  const int t = threadIdx.x & 255;
-  const int l = t & 63;
-  const int w = t >> 6;
-  const int l15 = l & 15;
-  const int q = l >> 4;
-  const int n0 = blockIdx.y * BN;
-  const int nk = (p.K + BK - 1) / BK;
-  const int vb = blockIdx.x * 2 + half;          // virtual workgroup id: one per half
-  const int vgrid = gridDim.x * 2;
-  const int T = ((p.num_m_tiles - vb + vgrid - 1) / vgrid) * nk;              // my K-steps
-  const int T0 = ((p.num_m_tiles - (vb - half) + vgrid - 1) / vgrid) * nk;    // half 0's (>= half 1's)
-
-  const int ar = t >> 3;
-  const int akq = (t & 7) * 4;
-
-  float4 ra[2 * MI];
-  float4 rb[NB4];
-  float4 rsc = make_float4(1.f, 1.f, 1.f, 1.f), rsh = zero4();
-
-  auto prefetch = [&](int it) {
-    const int kt = it % nk;
-    const int mt = vb + (it / nk) * vgrid;
-    const int m0 = mt * BM;
-    const int k0 = kt * BK;
-    const bool kok = k0 + akq < p.K;
-#pragma unroll
-    for (int i = 0; i < 2 * MI; ++i) {
-      const int m = m0 + ar + 32 * i;
-      ra[i] = (kok && m < p.M) ? ld4(p.A + (size_t)m * p.lda + k0 + akq) : zero4();
-    }
-    if (p.scale && kok) { rsc = ld4(p.scale + k0 + akq); rsh = ld4(p.shift + k0 + akq); }
-#pragma unroll
-    for (int i = 0; i < NB4; ++i) {
-      const int idx = t + 256 * i;
-      if (B_KN) {
-        const int kk = idx / (BN / 4), nq = idx - kk * (BN / 4);
-        const int k = k0 + kk, n = n0 + nq * 4;
-        rb[i] = (idx < 8 * BN && k < p.K && n < p.N) ? ld4(p.B + (size_t)k * p.ldb + n) : zero4();
-      } else {
-        const int r = idx >> 3, kq = (idx & 7) * 4;
-        const int n = n0 + r, k = k0 + kq;
-        rb[i] = (idx < 8 * BN && n < p.N && k < p.K) ? ld4(p.B + (size_t)n * p.ldb + k) : zero4();
-      }
-    }
-  };
-
-  auto stage = [&](int it) {
-    const int kt = it % nk;
-    const int mt = vb + (it / nk) * vgrid;
-    const int m0 = mt * BM;
-    const bool kok = kt * BK + akq < p.K;
-#pragma unroll
-    for (int i = 0; i < 2 * MI; ++i) {
-      const int r = ar + 32 * i;
-      float4 v = ra[i];
-      if (kok && m0 + r < p.M) v = act_apply4(fma4(v, rsc, rsh), p.act);
-      *reinterpret_cast<float4*>(&As[r * APITCH + akq]) = v;
-    }
-#pragma unroll
-    for (int i = 0; i < NB4; ++i) {
-      const int idx = t + 256 * i;
-      if (idx < 8 * BN) {
-        if (B_KN) {
-          const int kk = idx / (BN / 4), nq = idx - kk * (BN / 4);
-          *reinterpret_cast<float4*>(&Bs[kk * BPITCH + nq * 4]) = rb[i];
-        } else {
-          const int r = idx >> 3, kq = (idx & 7) * 4;
-          *reinterpret_cast<float4*>(&Bs[r * APITCH + kq]) = rb[i];
-        }
-      }
-    }
-  };
-
-  f32x4 acc[MI][NT];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float4 st_s[STATS ? NPASS : 1], st_q[STATS ? NPASS : 1];
-  if (STATS) {
-#pragma unroll
-    for (int i = 0; i < NPASS; ++i) { st_s[i] = zero4(); st_q[i] = zero4(); }
-  }
-
-  auto mfma_step = [&]() {
-#pragma unroll
-    for (int g = 0; g < BK / 16; ++g) {
-      const int kc = g * 16 + q * 4;
-      float4 a[MI];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-        a[mi] = *reinterpret_cast<const float4*>(&As[(w * 16 * MI + mi * 16 + l15) * APITCH + kc]);
-#pragma unroll
-      for (int ni = 0; ni < NT; ++ni) {
-        float b[4];
-        if (B_KN) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) b[j] = Bs[(kc + j) * BPITCH + ni * 16 + l15];
-        } else {
-          const float4 bv = *reinterpret_cast<const float4*>(&Bs[(ni * 16 + l15) * APITCH + kc]);
-          b[0] = bv.x; b[1] = bv.y; b[2] = bv.z; b[3] = bv.w;
-        }
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[0], a[mi].x, acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[1], a[mi].y, acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[2], a[mi].z, acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[3], a[mi].w, acc[mi][ni], 0, 0, 0);
-        }
-      }
-    }
-  };
-
-  // epilogue of the M tile that K-step `it` completed (same LDS transpose as pw_gemm_kernel)
-  auto epilogue = [&](int it) {
-    const int mt = vb + (it / nk) * vgrid;
-    const int m0 = mt * BM;
-    float* es = Es + w * RW * EPITCH;
-    const int rr = l >> 4, cq = l & 15;
-#pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-      const int ni0 = ps * TPP;
-#pragma unroll
-      for (int nl = 0; nl < TPP; ++nl) {
-        if (ni0 + nl < NT) {
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) {
-            const f32x4 v = acc[mi][ni0 + nl];
-            acc[mi][ni0 + nl] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<float4*>(&es[(mi * 16 + l15) * EPITCH + nl * 16 + q * 4]) = make_float4(v[0], v[1], v[2], v[3]);
-          }
-        }
-      }
-      const int n = n0 + ni0 * 16 + cq * 4;
-      const bool col_ok = (ni0 * 16 + cq * 4 < BN) && (cq * 4 < CH) && n < p.N && (ni0 + cq / 4 < NT);
-      float4 bias4 = zero4();
-      if (p.bias && col_ok) bias4 = ld4(p.bias + n);
-#pragma unroll
-      for (int r0 = 0; r0 < RW; r0 += 4) {
-        const int row = r0 + rr;
-        const int m = m0 + w * RW + row;
-        if (col_ok && m < p.M) {
-          float4 o = add4(*reinterpret_cast<const float4*>(&es[row * EPITCH + cq * 4]), bias4);
-          float* yp = p.Y + (size_t)m * p.ldy + n;
-          if (p.accumulate) o = add4(o, ld4(yp));
-          st4(yp, o);
-          if (STATS) {
-            st_s[ps] = add4(st_s[ps], o);
-            st_q[ps] = fma4(o, o, st_q[ps]);
-          }
-        }
-      }
-    }
-  };
-
-#ifdef DL3P_STAMP
-  long long tacc[5] = {0, 0, 0, 0, 0};
-  long long t0 = __builtin_amdgcn_s_memtime(), t1;
-#endif
-  // phase -1: half 0 stages its first K-step, half 1 only issues its first loads
-  if (T > 0) {
-    prefetch(0);
-    if (half == 0) stage(0);
-  }
-  __syncthreads();
-  STAMP(4)
-  for (int i = 0; i < T0; ++i) {
-    // phase A: half 0 multiplies K-step i | half 1 finishes K-step i-1's tile and stages K-step i
-    if (half == 0) {
-      if (i + 1 < T) prefetch(i + 1);
-      mfma_step();
-      STAMP(0)
-    } else {
-      if (i > 0 && i - 1 < T && (i - 1) % nk == nk - 1) epilogue(i - 1);
-      if (i < T) stage(i);
-      STAMP(2)
-    }
-    __syncthreads();
-    if (half == 0) STAMP(1) else STAMP(3)
-    // phase B: roles swapped
-    if (half == 0) {
-      if (i % nk == nk - 1) epilogue(i);
-      if (i + 1 < T) stage(i + 1);
-      STAMP(2)
-    } else if (i < T) {
-      if (i + 1 < T) prefetch(i + 1);
-      mfma_step();
-      STAMP(0)
-    }
-    __syncthreads();
-    if (half == 0) STAMP(3) else STAMP(1)
-  }
-#ifdef DL3P_STAMP
-  if (p.stamp && l == 0) {
-    long long* o = p.stamp + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (threadIdx.x >> 6)) * 8;
-    for (int i = 0; i < 5; ++i) o[i] = tacc[i];
-    o[5] = T;
-  }
-#endif
-  if (half == 1 && T > 0 && T == T0) epilogue(T - 1);
-
-  if (STATS) {
-    const int rr = l >> 4, cq = l & 15;
-#pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-      float sv[4] = {st_s[ps].x, st_s[ps].y, st_s[ps].z, st_s[ps].w};
-      float qv[4] = {st_q[ps].x, st_q[ps].y, st_q[ps].z, st_q[ps].w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float s1 = sv[e], s2 = qv[e];
-        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
-        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-        const int col = ps * CH + cq * 4 + e;
-        if (rr == 0 && cq * 4 < CH && col < BN) {
-          red[(0 * 4 + w) * BN + col] = s1;
-          red[(1 * 4 + w) * BN + col] = s2;
-        }
-      }
-    }
-    __syncthreads();
-    if (p.partials) {
-      for (int i = t; i < 2 * BN; i += 256) {
-        const int which = i / BN, nn = i - which * BN;
-        if (n0 + nn < p.N) {
-          float s = red[(which * 4 + 0) * BN + nn] + red[(which * 4 + 1) * BN + nn] +
-                    red[(which * 4 + 2) * BN + nn] + red[(which * 4 + 3) * BN + nn];
-          p.partials[((size_t)vb * 2 + which) * p.N + n0 + nn] = s;
-        }
-      }
-    }
-  }
-}
-
-template <int NT, bool B_KN, bool STATS, int MI>
-static constexpr size_t pp_lds_bytes() {
-  constexpr int BM = 64 * MI, BN = 16 * NT;
-  constexpr int BPITCH = B_KN ? (BN + 4) : APITCH;
-  constexpr int TPP = NT < 4 ? NT : 4;
-  constexpr int CH = 16 * TPP;
-  return 2 * sizeof(float) * (size_t)(BM * APITCH + (B_KN ? BK * BPITCH : BN * APITCH) + 4 * 16 * MI * (CH + 4) +
-                                      (STATS ? 2 * 4 * BN : 0));
-}
-
-template <int NT, bool B_KN, bool STATS, int MI>
-static void launch_pp_one(const GemmParams& p, dim3 grid, hipStream_t st) {
-  constexpr size_t lds = pp_lds_bytes<NT, B_KN, STATS, MI>();
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)pw_gemm_pp_kernel<NT, B_KN, STATS, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  dl3p_launch(pw_gemm_pp_kernel<NT, B_KN, STATS, MI>, grid, dim3(512), lds, st, p);
-}
-
-template <bool B_KN, bool STATS, int MI>
-static void launch_pp_mi(const GemmParams& p, int nt, dim3 grid, hipStream_t st) {
-  switch (nt) {
-    case 1: launch_pp_one<1, B_KN, STATS, MI>(p, grid, st); break;
-    case 2: launch_pp_one<2, B_KN, STATS, MI>(p, grid, st); break;
-    case 3: launch_pp_one<3, B_KN, STATS, MI>(p, grid, st); break;
-    case 4: launch_pp_one<4, B_KN, STATS, MI>(p, grid, st); break;
-    case 5: launch_pp_one<5, B_KN, STATS, MI>(p, grid, st); break;
-    case 6: launch_pp_one<6, B_KN, STATS, MI>(p, grid, st); break;
-    default: launch_pp_one<8, B_KN, STATS, MI>(p, grid, st); break;
-  }
-}
+// (A barrier-enforced ping-pong of two half-workgroups -- 512 threads, waves 0-3 multiply while waves 4-7 stage and
+// vice versa -- was built and measured twice this round: 510 us and 624 us against 471 us for two free-running
+// workgroups per CU on 266256x304x256.  One wave per SIMD cannot keep the matrix pipe issuing back to back through
+// its own LDS-read latencies; the free-running pair fills those bubbles.  Removed.)
 
 // ------------------------------------------------------------------------------ forward / dgrad, small K x N
 // Same idea as pw_wgrad_small_kernel for Y = act(X*scale+shift) @ W when the whole kernel matrix is a few
@@ -851,7 +557,6 @@ static void launch_pw_small_any(const GemmParams& p, SmallShape sh, int grid, hi
 #undef DL3P_PS
 }
 
-static int gemm_use_pp();
 // choose the columns-per-workgroup (NT tiles of 16) that wastes the fewest MFMA columns
 static int pick_nt(int N) {
   const int ntiles = ceil_div(N, 16);
@@ -891,7 +596,6 @@ static void gemm_grid(int M, int N, int nt, int* gx, int* gy, int* num_m_tiles, 
     const int per = ceil_div(mt, gx_max);
     g = ceil_div(mt, per);
   }
-  if (gemm_use_pp()) g = (g + 1) & ~1;   // two virtual workgroups per 512-thread workgroup
   *gx = g; *gy = nb; *num_m_tiles = mt; *mi_out = mi;
 }
 
@@ -926,11 +630,6 @@ static void launch_gemm_mi(const GemmParams& p, int nt, dim3 grid, hipStream_t s
   }
 }
 
-static int gemm_use_pp() {
-  static const int v = getenv("DL3P_GEMM_PP") ? atoi(getenv("DL3P_GEMM_PP")) : 0;
-  return v;
-}
-
 template <bool B_KN, bool STATS>
 static void launch_gemm(const GemmParams& p_in, int nt, int mi, dim3 grid, hipStream_t st) {
   GemmParams p = p_in;
@@ -939,12 +638,6 @@ static void launch_gemm(const GemmParams& p_in, int nt, int mi, dim3 grid, hipSt
   p.stamp = sp ? (long long*)strtoull(sp, nullptr, 10) : nullptr;
 #endif
   { const char* e = getenv("DL3P_GEMM_STAGGER"); p.stagger = e ? atoi(e) : 0; }
-  if (gemm_use_pp()) {
-    dim3 g2((grid.x + 1) / 2, grid.y);
-    if (mi == 1) launch_pp_mi<B_KN, STATS, 1>(p, nt, g2, st);
-    else launch_pp_mi<B_KN, STATS, 2>(p, nt, g2, st);
-    return;
-  }
   // K tile 64 deep (half the barriers and staging passes per MFMA) was measured neutral on the decoder layers:
   // the loop is bound by matrix-pipe sharing between the two resident workgroups, not by barrier count
   static const int bk64_min_k = getenv("DL3P_GEMM_BK64_MIN_K") ? atoi(getenv("DL3P_GEMM_BK64_MIN_K")) : (1 << 30);   // measured neutral (+-2 %): off
