@@ -160,19 +160,25 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
                        __builtin_amdgcn_fmed3f(v.z, act_lo, act_hi), __builtin_amdgcn_fmed3f(v.w, act_lo, act_hi));
   };
 
+  const bool has_pro = p.scale != nullptr || p.act != DL3P_ACT_NONE;   // data gradient / im2col input: raw operand
+  const bool n_edge = n0 + BN > p.N;
   auto stage = [&](int it) {
     const int kt = it % nk;
     const int mt = blockIdx.x + (it / nk) * gridDim.x;
     const int m0 = mt * BM;
     const int k0 = kt * BKT;
+    // interior K-steps (the common case, wave-uniform) skip the zero-fill selects of the M / K / N tails
+    const bool a_edge = m0 + BM > p.M || k0 + BKT > p.K;
+    const bool b_edge = n_edge || k0 + BKT > p.K;
     const bool kok = k0 + akq < p.K;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int r = ar + RP * i;
+      float4 v = ra[i];
+      if (has_pro) v = prologue4(v);
       // zero rows/cols stay exactly zero (padding of the M and K tails)
-      const float4 v = prologue4(ra[i]);
-      const bool ok = kok && m0 + r < p.M;
-      *reinterpret_cast<float4*>(&As[r * AP + akq]) = ok ? v : zero4();
+      if (a_edge) v = (kok && m0 + r < p.M) ? v : zero4();
+      *reinterpret_cast<float4*>(&As[r * AP + akq]) = v;
     }
 #pragma unroll
     for (int i = 0; i < NB4; ++i) {
@@ -180,10 +186,14 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
       if (idx < KQ * BN) {
         if (B_KN) {
           const int kk = idx / (BN / 4), nq = idx - kk * (BN / 4);
-          *reinterpret_cast<float4*>(&Bs[kk * BPITCH + nq * 4]) = (b_nok[i] && k0 + kk < p.K) ? rb[i] : zero4();
+          float4 v = make_float4(rb[i].x, rb[i].y, rb[i].z, rb[i].w);
+          if (b_edge) v = (b_nok[i] && k0 + kk < p.K) ? v : zero4();
+          *reinterpret_cast<float4*>(&Bs[kk * BPITCH + nq * 4]) = v;
         } else {
           const int r = idx / KQ, kq = (idx % KQ) * 4;
-          *reinterpret_cast<float4*>(&Bs[r * AP + kq]) = (b_nok[i] && k0 + kq < p.K) ? rb[i] : zero4();
+          float4 v = make_float4(rb[i].x, rb[i].y, rb[i].z, rb[i].w);
+          if (b_edge) v = (b_nok[i] && k0 + kq < p.K) ? v : zero4();
+          *reinterpret_cast<float4*>(&Bs[r * AP + kq]) = v;
         }
       }
     }
