@@ -648,11 +648,9 @@ static void launch_gemm(const GemmParams& p_in, int nt, int mi, dim3 grid, hipSt
   p.stamp = sp ? (long long*)strtoull(sp, nullptr, 10) : nullptr;
 #endif
   { const char* e = getenv("DL3P_GEMM_STAGGER"); p.stagger = e ? atoi(e) : 0; }
-  // K tile 64 deep (half the barriers and staging passes per MFMA) was measured neutral on the decoder layers:
-  // the loop is bound by matrix-pipe sharing between the two resident workgroups, not by barrier count
-  static const int bk64_min_k = getenv("DL3P_GEMM_BK64_MIN_K") ? atoi(getenv("DL3P_GEMM_BK64_MIN_K")) : (1 << 30);   // measured neutral (+-2 %): off
+  // (BKT = 64 -- half the barriers and staging passes per MFMA -- was measured neutral on the decoder layers and is
+  // not instantiated: the loop is bound by matrix-pipe sharing between the two resident workgroups)
   if (mi == 1) launch_gemm_mi<B_KN, STATS, 1, 32>(p, nt, grid, st);
-  else if (p.K >= bk64_min_k && nt >= 4) launch_gemm_mi<B_KN, STATS, 2, 64>(p, nt, grid, st);
   else launch_gemm_mi<B_KN, STATS, 2, 32>(p, nt, grid, st);
 }
 
