@@ -518,10 +518,21 @@ class Executor:
         # data parallel: the flat gradient buffer is produced back to front; each finished bucket is
         # all-reduced on the side stream while the remaining backward kernels run
         bucket_edges = self._bucket_edges() if self.dist is not None else {}
+        # SyncBatchNorm: a layer's weight gradient feeds nothing in the backward chain, so it is held back and
+        # issued while the NEXT BatchNorm's statistics all-reduce is on the wire (hides the collective's latency)
+        self._deferred = []
+        defer = self.sync_bn
+
+        def wgrad(fn, *args):
+            if defer:
+                self._deferred.append((fn, args, P.ctx))
+            else:
+                P.k(fn, *args)
         for op in reversed(self.g.ops):
             k = op.kind
             P.ctx = _op_label(op)
             if op in bucket_edges:
+                self._flush_deferred(P)        # every gradient of the finished bucket must have been produced
                 lo, hi = bucket_edges[op]
                 P.py(lambda lo=lo, hi=hi: self.dist.all_reduce_async(G[lo:hi]))
             out = getattr(op, 'out', None)
@@ -541,14 +552,14 @@ class Executor:
                 if op.layer.trainable:
                     gw = st.ptr(op.w, G)
                     if k == 'conv_pw':
-                        P.k(L.pwconv_bwd_weight, xp, ldx, sp, hp, act, dz, lddz, gw, st.ptr(op.b, G) if op.b else None,
-                            ws, wsb, N * op.Ho * op.Wo, op.cin, op.cout)
+                        wgrad(L.pwconv_bwd_weight, xp, ldx, sp, hp, act, dz, lddz, gw, st.ptr(op.b, G) if op.b else None,
+                              ws, wsb, N * op.Ho * op.Wo, op.cin, op.cout)
                     elif k == 'conv_dw':
-                        P.k(L.dwconv2d_bwd_weight, xp, ldx, sp, hp, act, dz, lddz, gw, ws, wsb, N, xt.H, xt.W, op.c,
-                            op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
+                        wgrad(L.dwconv2d_bwd_weight, xp, ldx, sp, hp, act, dz, lddz, gw, ws, wsb, N, xt.H, xt.W, op.c,
+                              op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
                     else:
-                        P.k(L.pwconv_bwd_weight, self.tptr(op.col), op.col.ld, None, None, ACT_NONE, dz, lddz, gw,
-                            st.ptr(op.b, G) if op.b else None, ws, wsb, N * op.Ho * op.Wo, op.kp, op.cout)
+                        wgrad(L.pwconv_bwd_weight, self.tptr(op.col), op.col.ld, None, None, ACT_NONE, dz, lddz, gw,
+                              st.ptr(op.b, G) if op.b else None, ws, wsb, N * op.Ho * op.Wo, op.kp, op.cout)
                 if need_gx:
                     gp, ldg, keyt = self._gbuf(op.x)
                     acc = self._acc(keyt)
@@ -598,11 +609,20 @@ class Executor:
                     N, xt.H, xt.W, xt.C, out.H, out.W)
             else:
                 raise NotImplementedError(k)
+        self._flush_deferred(P)
         if self.dist is not None:
             P.py(lambda hi=self._first_bucket_hi: self.dist.all_reduce_async(G[0:hi]))
             # join the side stream inside this plan: a captured graph may not end with forked work in flight
             P.py(self.dist.wait_all)
         return P
+
+    def _flush_deferred(self, P):
+        ctx = P.ctx
+        for fn, args, c in self._deferred:
+            P.ctx = c
+            P.k(fn, *args)
+        self._deferred = []
+        P.ctx = ctx
 
     def _bucket_edges(self):
         """{op: (lo, hi)}: when backward reaches `op` (going back to front), the gradients of every
@@ -648,9 +668,12 @@ class Executor:
                 invstd, sp, 0, st.ptr(lp['gamma'], G), st.ptr(lp['beta'], G), coef)
             if self.sync_bn:
                 # parameter gradients stay local (they are averaged with every other gradient); the
-                # normalisation terms use the global sums
+                # normalisation terms use the global sums.  The all-reduce runs beside the deferred weight
+                # gradient(s) of the layer(s) processed before this one.
                 P.k(L.bn_reduce_partials, self.partials.data_ptr(), rows.value, 2 * bn.C, aux['sums'].data_ptr())
-                P.py(lambda s=aux['sums']: self.dist.all_reduce(s))
+                P.py(lambda s=aux['sums']: self.dist.bn_all_reduce_begin(s))
+                self._flush_deferred(P)
+                P.py(self.dist.bn_all_reduce_end)
                 P.k(L.bn_bwd_finalize, None, 0, aux['sums'].data_ptr(), bn.C, float(M * self.dist.world_size),
                     st.ptr(lp['gamma']), invstd, sp, 0, None, None, coef)
         P.k(L.bn_bwd_apply, g, ldg, zp, ldz, sp, hp, bn.act, mean, invstd, coef, g, ldg, 0, M, bn.C)

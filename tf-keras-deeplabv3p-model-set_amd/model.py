@@ -101,15 +101,28 @@ class DistContext:
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.sync_bn = sync_bn
         self.n_buckets = n_buckets
-        self._comm_stream = None
-        self._pending = []
+        self._streams = {}
+        self._bn_pg = None
 
     def all_reduce(self, t):
-        """blocking (stream-ordered) sum all-reduce: SyncBatchNorm statistics"""
-        self.dist.all_reduce(t)
+        """blocking (stream-ordered) sum all-reduce: SyncBatchNorm statistics of the forward pass"""
+        self.dist.all_reduce(t, group=self._bn_group())
+
+    def _bn_group(self):
+        # SyncBatchNorm gets its own communicator (own RCCL stream): a statistics all-reduce never queues behind
+        # a gradient bucket that is still on the wire
+        if self._bn_pg is None and self.dist.is_initialized() and self.dist.get_backend() == 'nccl':
+            self._bn_pg = self.dist.new_group(backend='nccl')
+        return self._bn_pg
 
     def broadcast(self, t, src=0):
         self.dist.broadcast(t, src)
+
+    def _side(self, which):
+        import torch
+        if self._streams.get(which) is None:
+            self._streams[which] = torch.cuda.Stream()
+        return self._streams[which]
 
     def all_reduce_async(self, t):
         """sum all-reduce of a gradient bucket, ordered after everything already queued on the
@@ -118,16 +131,33 @@ class DistContext:
         if not t.is_cuda:
             self.dist.all_reduce(t)
             return
-        if self._comm_stream is None:
-            self._comm_stream = torch.cuda.Stream()
-        self._comm_stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self._comm_stream):
+        side = self._side('grad')
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
             self.dist.all_reduce(t)
 
     def wait_all(self):
         import torch
-        if self._comm_stream is not None:
-            torch.cuda.current_stream().wait_stream(self._comm_stream)
+        if self._streams.get('grad') is not None:
+            torch.cuda.current_stream().wait_stream(self._streams['grad'])
+
+    def bn_all_reduce_begin(self, t):
+        """SyncBatchNorm backward sums: start the all-reduce beside the compute stream (the deferred weight
+        gradient of the previous layer runs meanwhile) ..."""
+        import torch
+        if not t.is_cuda:
+            self.dist.all_reduce(t)
+            return
+        side = self._side('bn')
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.dist.all_reduce(t, group=self._bn_group())
+
+    def bn_all_reduce_end(self):
+        """... and make the compute stream wait for it"""
+        import torch
+        if self._streams.get('bn') is not None:
+            torch.cuda.current_stream().wait_stream(self._streams['bn'])
 
 
 class DeeplabModel:
