@@ -673,9 +673,13 @@ static int check_dw_common(const char* fn, const void* x, int ldx, int C, int k)
   return DL3P_OK;
 }
 
-// rows per band: as tall as possible (less halo re-reading) while every CU still gets a few workgroups
+// rows per band: as tall as possible (less halo re-reading: at th = 1 every input row is fetched 3x from L2 and the
+// 33x33 layers were L2-bound) while every CU still gets 1-2 workgroup-iterations (measured optimum 256-512)
 static int pick_band(long long items_per_row_band, int rows, int px, int nslab) {
-  const long long want = (long long)DL3P_NUM_CUS * 8;          // workgroup-iterations wanted overall
+  static const int want_env = getenv("DL3P_DW_WANT") ? atoi(getenv("DL3P_DW_WANT")) : DL3P_NUM_CUS * 3 / 2;
+  const long long want = want_env;                               // workgroup-iterations wanted overall
+  static const int force = getenv("DL3P_DW_BAND") ? atoi(getenv("DL3P_DW_BAND")) : 0;
+  if (force && rows <= 40) return force;
   int th = 16;
   while (th > 1 && (items_per_row_band * ceil_div(rows, th) / px) * nslab < want) th >>= 1;
   return th;
