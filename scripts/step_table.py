@@ -20,7 +20,8 @@ sys.path.insert(0, ROOT)
 PKG = 'tf-keras-deeplabv3p-model-set_amd'
 
 
-def run(model_type='mobilenetv2', N=16, size=513, C=21):
+def run(model_type='mobilenetv2', N=None, size=513, C=21):
+    N = N or (4 if model_type == 'xception' else 16)
     import torch
     pkg = importlib.import_module(PKG)
     lib = importlib.import_module(PKG + '._lib').lib()

@@ -169,3 +169,14 @@ def test_graph_replay_equals_eager():
     assert np.allclose(la, lb, rtol=1e-5, atol=1e-6), (la, lb)
     wa, wb = ma.get_weights_by_name(), mb.get_weights_by_name()
     assert max(float(np.abs(wa[k] - wb[k]).max()) for k in wa) < 1e-5
+
+
+def test_graft_entry_smoke_in_fresh_process():
+    """build() then smoke() in a fresh interpreter, the order the driver uses: libdl3p.so must bind to the HIP
+    runtime torch brings (loading it before torch left two HSA runtimes in the process and no visible device)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, '__graft_entry__.py'), 'smoke'], capture_output=True, text=True,
+                       cwd=root, timeout=600)
+    assert r.returncode == 0 and 'smoke ok' in r.stdout, (r.stdout[-500:], r.stderr[-1500:])

@@ -55,6 +55,10 @@ class Lib:
             raise ImportError(
                 'libdl3p.so not found at %s -- build it with `python __graft_entry__.py` '
                 '(there is no CPU fallback for the HIP path)' % path)
+        # torch ships its own HIP / HSA runtime; it has to be the one already in the process when libdl3p.so is
+        # loaded (the loader then binds libdl3p's libamdhip64 dependency to it).  Loaded the other way round the
+        # process ends up with two HSA runtimes and the second one sees no device.
+        import torch  # noqa: F401
         self.cdll = ctypes.CDLL(path)
         self.protos = parse_header()
         for name, (ret, args) in self.protos.items():
