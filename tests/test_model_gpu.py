@@ -1,5 +1,7 @@
 """End-to-end GPU parity of the DeepLabV3+ train step / predict against the fp64 CPU oracle on
 identical weights and inputs (north_star tolerance: 1e-3 fp32)."""
+import os
+
 import numpy as np
 import pytest
 import torch
