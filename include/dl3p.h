@@ -86,6 +86,13 @@ int dl3p_dwconv2d_bwd_weight(const float* x, int ldx, const float* in_scale, con
 int dl3p_pwconv_fwd(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
                     const float* w, const float* bias, float* y, int ldy,
                     float* stat_partials, int* rows_out, int M, int K, int N, void* stream);
+/* The same with the kernel transposed, wt[N][K] (B fragments become one 16-B LDS read): the host keeps the
+ * transposed copies of all pointwise kernels next to the flat parameter buffer and refreshes them after every
+ * optimiser step with dl3p_transpose_batch (table: device int[n][4] rows of (float offset, K, N, 0)). */
+int dl3p_pwconv_fwd_wt(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                       const float* wt, const float* bias, float* y, int ldy, float* stat_partials, int* rows_out,
+                       int M, int K, int N, void* stream);
+int dl3p_transpose_batch(const float* src, float* dst, const int* table, int n_matrices, void* stream);
 /* gx[M,K] (+)= dy[M,N] @ w[K,N]^T */
 int dl3p_pwconv_bwd_data(const float* dy, int lddy, const float* w, float* gx, int ldgx, int accumulate,
                          int M, int K, int N, void* stream);

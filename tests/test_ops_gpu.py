@@ -112,6 +112,33 @@ def test_pwconv_fwd_bwd(ops, case):
     close(gb, gy.sum(0), rtol=3e-4, what='pw bwd bias')
 
 
+def test_pwconv_fwd_transposed_kernel(ops):
+    """dl3p_transpose_batch + dl3p_pwconv_fwd_wt == dl3p_pwconv_fwd (tiled and small-K.N kernels)"""
+    rng = np.random.default_rng(3)
+    mats = [(320, 256), (24, 144), (28, 32), (960, 160)]
+    offs, off = [], 0
+    for K, Nn in mats:
+        offs.append(off)
+        off += K * Nn
+    flat = torch.tensor(rng.standard_normal(off), dtype=torch.float32, device=DEV)
+    flat_t = torch.zeros_like(flat)
+    table = torch.tensor([[o, K, Nn, 0] for o, (K, Nn) in zip(offs, mats)], dtype=torch.int32, device=DEV)
+    ops.transpose_batch(flat, flat_t, table)
+    for o, (K, Nn) in zip(offs, mats):
+        w = flat[o:o + K * Nn].view(K, Nn)
+        wt = flat_t[o:o + K * Nn].view(Nn, K)
+        assert torch.equal(wt, w.t().contiguous())
+        for M in (777, 3000):
+            x = torch.tensor(rng.standard_normal((M, K)), dtype=torch.float32, device=DEV)
+            sc = torch.tensor(rng.uniform(0.5, 1.5, K), dtype=torch.float32, device=DEV)
+            sh = torch.tensor(rng.standard_normal(K) * 0.3, dtype=torch.float32, device=DEV)
+            p1, p2 = ops.new_partials(Nn, DEV), ops.new_partials(Nn, DEV)
+            y1, r1 = ops.pwconv_fwd(x, w, None, sc, sh, ops.ACT_RELU6, partials=p1)
+            y2, r2 = ops.pwconv_fwd_wt(x, wt, None, sc, sh, ops.ACT_RELU6, partials=p2)
+            assert torch.equal(y1, y2) and r1 == r2       # same products in the same order
+            assert torch.equal(p1[:r1 * 2 * Nn], p2[:r2 * 2 * Nn])
+
+
 def test_pwconv_concat_slices(ops):
     """producers write channel slices of a concat buffer, the consumer reads it with the
     concatenated per-channel prologue (layers.py:155 Concatenate costs no pass)"""

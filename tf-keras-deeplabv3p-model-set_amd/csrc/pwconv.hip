@@ -661,38 +661,90 @@ static int check_mat(const char* fn, const void* ptr, int ld, int cols) {
   return DL3P_OK;
 }
 
-extern "C" int dl3p_pwconv_fwd(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
-                               const float* w, const float* bias, float* y, int ldy, float* stat_partials,
-                               int* rows_out, int M, int K, int N, void* stream) {
-  int rc = check_mat("dl3p_pwconv_fwd", x, ldx, K);
+static int pwconv_fwd_impl(const char* fn, const float* x, int ldx, const float* in_scale, const float* in_shift,
+                           int in_act, const float* w, bool w_kn, const float* bias, float* y, int ldy,
+                           float* stat_partials, int* rows_out, int M, int K, int N, void* stream) {
+  int rc = check_mat(fn, x, ldx, K);
   if (rc) return rc;
-  rc = check_mat("dl3p_pwconv_fwd", y, ldy, N);
+  rc = check_mat(fn, y, ldy, N);
   if (rc) return rc;
-  DL3P_CHECK_ARG(w && aligned16(w) && M > 0, "dl3p_pwconv_fwd: bad arguments");
+  DL3P_CHECK_ARG(w && aligned16(w) && M > 0, "%s: bad arguments", fn);
   DL3P_CHECK_ARG((unsigned long long)M * (unsigned long long)(ldx > ldy ? ldx : ldy) * 4ull < (1ull << 32),
-                 "dl3p_pwconv_fwd: operands of 4 GiB or more are not supported (M=%d)", M);
+                 "%s: operands of 4 GiB or more are not supported (M=%d)", fn, M);
   GemmParams p = {};
   p.A = x; p.lda = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act;
-  p.B = w; p.ldb = N; p.bias = bias; p.Y = y; p.ldy = ldy; p.partials = stat_partials;
+  p.B = w; p.ldb = w_kn ? N : K; p.bias = bias; p.Y = y; p.ldy = ldy; p.partials = stat_partials;
   p.M = M; p.K = K; p.N = N;
   hipStream_t st = (hipStream_t)stream;
   SmallShape sh;
   if (M >= pw_small_min_rows() && pw_small_pick(K, N, &sh)) {
-    p.b_kn = 1;
+    p.b_kn = w_kn ? 1 : 0;
     const int g = pw_small_grid(M);
     if (rows_out) *rows_out = g;
     if (stat_partials) launch_pw_small_any<true>(p, sh, g, st);
     else launch_pw_small_any<false>(p, sh, g, st);
-    DL3P_CHECK_LAUNCH("dl3p_pwconv_fwd");
+    DL3P_CHECK_LAUNCH(fn);
     return DL3P_OK;
   }
   const int nt = pick_nt(N);
   int gx, gy, mi;
   gemm_grid(M, N, nt, &gx, &gy, &p.num_m_tiles, &mi);
   if (rows_out) *rows_out = gx;
-  if (stat_partials) launch_gemm<true, true>(p, nt, mi, dim3(gx, gy), st);
-  else launch_gemm<true, false>(p, nt, mi, dim3(gx, gy), st);
-  DL3P_CHECK_LAUNCH("dl3p_pwconv_fwd");
+  if (w_kn) {
+    if (stat_partials) launch_gemm<true, true>(p, nt, mi, dim3(gx, gy), st);
+    else launch_gemm<true, false>(p, nt, mi, dim3(gx, gy), st);
+  } else {
+    if (stat_partials) launch_gemm<false, true>(p, nt, mi, dim3(gx, gy), st);
+    else launch_gemm<false, false>(p, nt, mi, dim3(gx, gy), st);
+  }
+  DL3P_CHECK_LAUNCH(fn);
+  return DL3P_OK;
+}
+
+extern "C" int dl3p_pwconv_fwd(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                               const float* w, const float* bias, float* y, int ldy, float* stat_partials,
+                               int* rows_out, int M, int K, int N, void* stream) {
+  return pwconv_fwd_impl("dl3p_pwconv_fwd", x, ldx, in_scale, in_shift, in_act, w, true, bias, y, ldy, stat_partials,
+                         rows_out, M, K, N, stream);
+}
+
+// the same product with the kernel handed over transposed, wt[N][K]: the B tile then sits in LDS as [n][k] and its
+// MFMA fragments are one ds_read_b128 instead of four ds_read_b32 (the layout the data-gradient GEMM gets for free)
+extern "C" int dl3p_pwconv_fwd_wt(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                                  const float* wt, const float* bias, float* y, int ldy, float* stat_partials,
+                                  int* rows_out, int M, int K, int N, void* stream) {
+  return pwconv_fwd_impl("dl3p_pwconv_fwd_wt", x, ldx, in_scale, in_shift, in_act, wt, false, bias, y, ldy,
+                         stat_partials, rows_out, M, K, N, stream);
+}
+
+// dst[off + n*K + k] = src[off + k*N + n] for every (off, K, N) row of `table` (device, int[n][4]): the transposed
+// copies of all pointwise kernels in the flat parameter buffer, refreshed once per optimiser step
+__global__ __launch_bounds__(256) void transpose_batch_kernel(const float* src, float* dst, const int* table) {
+  __shared__ float tile[32][33];
+  const int off = table[blockIdx.x * 4], K = table[blockIdx.x * 4 + 1], N = table[blockIdx.x * 4 + 2];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int tk = (K + 31) / 32, tn = (N + 31) / 32;
+  for (int tl = blockIdx.y; tl < tk * tn; tl += gridDim.y) {
+    const int k0 = (tl / tn) * 32, n0 = (tl % tn) * 32;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + ty + 8 * i, n = n0 + tx;
+      tile[ty + 8 * i][tx] = (k < K && n < N) ? src[off + (size_t)k * N + n] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = n0 + ty + 8 * i, k = k0 + tx;
+      if (k < K && n < N) dst[off + (size_t)n * K + k] = tile[tx][ty + 8 * i];
+    }
+  }
+}
+
+extern "C" int dl3p_transpose_batch(const float* src, float* dst, const int* table, int n_matrices, void* stream) {
+  DL3P_CHECK_ARG(src && dst && table && n_matrices > 0, "dl3p_transpose_batch: bad arguments");
+  hipLaunchKernelGGL(transpose_batch_kernel, dim3(n_matrices, 16), dim3(256), 0, (hipStream_t)stream, src, dst, table);
+  DL3P_CHECK_LAUNCH("dl3p_transpose_batch");
   return DL3P_OK;
 }
 

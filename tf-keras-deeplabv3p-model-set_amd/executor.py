@@ -43,8 +43,19 @@ class ParamStore:
         self.V = torch.zeros(off, **f)
         self.l2 = torch.zeros(off, **f)
         self.lr_scale = torch.zeros(off, **f)
+        # transposed copies [N][K] of the pointwise / im2col'd kernels (same offsets as in P): the forward GEMM reads
+        # its B fragments from them as 16-B vectors; refreshed after every optimiser step (dl3p_transpose_batch)
+        self.Pt = torch.zeros(off, **f)
+        rows = [[self.offset[op.w], op.cin if op.kind == 'conv_pw' else op.kp, op.cout, 0]
+                for op in graph.ops if op.kind in ('conv_pw', 'conv_dense')]
+        self.tr_table = torch.tensor(rows, dtype=torch.int32, device=device) if rows else None
         self.upload()
         self.refresh_masks()
+
+    def transpose(self):
+        if self.tr_table is not None:
+            lib().transpose_batch(self.P.data_ptr(), self.Pt.data_ptr(), self.tr_table.data_ptr(),
+                                  int(self.tr_table.shape[0]), torch.cuda.current_stream().cuda_stream)
 
     def view(self, p, buf=None):
         buf = self.P if buf is None else buf
@@ -72,6 +83,7 @@ class ParamStore:
             o = self.offset[p]
             host[o:o + p.dev_size] = self._pad(p, p.value).reshape(-1)
         self.P.copy_(torch.from_numpy(host))
+        self.transpose()
 
     def download(self):
         host = self.P.detach().cpu().numpy()
@@ -263,6 +275,7 @@ class Executor:
         torch.cuda.synchronize()
         store.P.copy_(snap_p)
         store.V.copy_(snap_v)
+        store.transpose()
         self.step.zero_()
         self.graphed = False
 
@@ -383,7 +396,7 @@ class Executor:
                 rows = ctypes.c_int(0)
                 xt = op.x.tensor
                 if k == 'conv_pw':
-                    P.k(L.pwconv_fwd, xp, ldx, sp, hp, act, st.ptr(op.w), st.ptr(op.b) if op.b else None,
+                    P.k(L.pwconv_fwd_wt, xp, ldx, sp, hp, act, st.ptr(op.w, st.Pt), st.ptr(op.b) if op.b else None,
                         self.tptr(op.out), op.out.ld, part, ctypes.byref(rows), N * op.Ho * op.Wo, op.cin, op.cout)
                 elif k == 'conv_dw':
                     P.k(L.dwconv2d_fwd, xp, ldx, sp, hp, act, st.ptr(op.w), self.tptr(op.out), op.out.ld, part,
@@ -393,7 +406,7 @@ class Executor:
                     # small dense conv (RGB stem): im2col once (kept for the weight gradient), then the MFMA GEMM
                     P.k(L.im2col, xp, ldx, sp, hp, act, self.tptr(op.col), op.col.ld, N, xt.H, xt.W, op.cin, op.k,
                         op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
-                    P.k(L.pwconv_fwd, self.tptr(op.col), op.col.ld, None, None, ACT_NONE, st.ptr(op.w),
+                    P.k(L.pwconv_fwd_wt, self.tptr(op.col), op.col.ld, None, None, ACT_NONE, st.ptr(op.w, st.Pt),
                         st.ptr(op.b) if op.b else None, self.tptr(op.out), op.out.ld, part, ctypes.byref(rows),
                         N * op.Ho * op.Wo, op.kp, op.cout)
                 op.rows = rows.value
@@ -686,6 +699,8 @@ class Executor:
             scale = 1.0 / self.dist.world_size
         P.k(L.sgd_momentum, st.P.data_ptr(), st.V.data_ptr(), st.G.data_ptr(), st.total, self.lr.data_ptr(),
             float(self.momentum), 0.0, scale, st.l2.data_ptr(), st.lr_scale.data_ptr())
+        if st.tr_table is not None:        # the forward GEMMs read the transposed kernel copies
+            P.k(L.transpose_batch, st.P.data_ptr(), st.Pt.data_ptr(), st.tr_table.data_ptr(), int(st.tr_table.shape[0]))
         return P
 
     # ---------------------------------------------------------------- running

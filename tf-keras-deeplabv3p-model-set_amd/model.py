@@ -238,6 +238,7 @@ class DeeplabModel:
             self._store = ParamStore(self.graph, torch.device('cuda', torch.cuda.current_device()))
             if self.dist is not None:
                 self.dist.broadcast(self._store.P, 0)   # identical replicas (MirroredStrategy semantics)
+                self._store.transpose()
         return self._store
 
     def _executor(self, batch, training):

@@ -123,6 +123,23 @@ def pwconv_fwd(x, w, bias=None, in_scale=None, in_shift=None, in_act=ACT_NONE, o
     return (y, rows.value) if partials is not None else y
 
 
+def pwconv_fwd_wt(x, wt, bias=None, in_scale=None, in_shift=None, in_act=ACT_NONE, out=None, partials=None):
+    """pwconv_fwd with the kernel given transposed, wt (N, K)"""
+    M, K = _rows(x), x.shape[-1]
+    N = wt.shape[0]
+    y = out if out is not None else torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+    xp, ldx = _pl(x)
+    yp, ldy = _pl(y)
+    rows = ctypes.c_int(0)
+    lib().pwconv_fwd_wt(xp, ldx, _p(in_scale), _p(in_shift), in_act, _p(wt), _p(bias), yp, ldy, _p(partials),
+                        ctypes.byref(rows), M, K, N, _stream())
+    return (y, rows.value) if partials is not None else y
+
+
+def transpose_batch(src, dst, table):
+    lib().transpose_batch(_p(src), _p(dst), _p(table), int(table.shape[0]), _stream())
+
+
 def pwconv_bwd_data(dy, w, out=None, accumulate=False):
     K, Nn = w.shape[-2], w.shape[-1]
     M = _rows(dy)
