@@ -9,8 +9,7 @@ libm = importlib.import_module('tf-keras-deeplabv3p-model-set_amd._lib')
 libm._lib = libm.Lib(os.path.join(ROOT, 'scripts/micro/libdl3p_stamp.so'))
 ops = importlib.import_module('tf-keras-deeplabv3p-model-set_amd.ops')
 shapes = [(266256, 304, 256), (1056784, 16, 96), (266256, 144, 24), (17424, 960, 160), (17424, 160, 960)]
-PP = os.environ.get('DL3P_GEMM_PP', '0') != '0'
-dbg = torch.zeros(8192 * 8 * 8, dtype=torch.int64, device='cuda')
+dbg = torch.zeros(8192 * 4 * 8, dtype=torch.int64, device='cuda')
 os.environ['DL3P_STAMP_PTR'] = str(dbg.data_ptr())
 for M, K, N in shapes:
     x = torch.randn((M, K), device='cuda'); w = torch.randn((K, N), device='cuda') * 0.05
@@ -28,7 +27,6 @@ for M, K, N in shapes:
         its = d[:, 5].mean()
         ph = d[:, :5].mean(0)
         tot = ph.sum()
-        fmt = ('mfma %6.0f  bar-after-mfma %6.0f  stage+epi %6.0f  bar-after-stage %6.0f  pre %6.0f' if PP else
-               'stage %6.0f  bar1 %6.0f  mfma %6.0f  bar2 %6.0f  epi %6.0f')
+        fmt = 'stage %6.0f  bar1 %6.0f  mfma %6.0f  bar2 %6.0f  epi %6.0f'
         print(('M=%7d K=%4d N=%4d %-5s waves %5d  k-steps/wave %5.1f  total %8.0f cyc | per k-step: ' + fmt)
               % (M, K, N, name, len(d), its, tot, *(ph / its)), flush=True)
