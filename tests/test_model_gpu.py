@@ -110,12 +110,14 @@ def test_predict_matches_oracle(model_type, H, W):
     assert np.abs(out['logits'][..., :21].cpu().numpy() - logits_ref).max() < TOL * max(1.0, np.abs(logits_ref).max())
 
 
-@pytest.mark.parametrize('model_type,H,W,freeze', [('mobilenetv2', 65, 65, 0), ('mobilenetv2_lite', 65, 65, 0),
-                                                   ('mobilenetv2', 65, 65, 1), ('xception', 65, 65, 0),
-                                                   ('mobilenetv3large', 65, 65, 0), ('mobilenetv3large', 64, 96, 0)])
-def test_train_step_matches_oracle(model_type, H, W, freeze):
+@pytest.mark.parametrize('model_type,H,W,freeze,OS', [('mobilenetv2', 65, 65, 0, 16), ('mobilenetv2_lite', 65, 65, 0, 16),
+                                                      ('mobilenetv2', 65, 65, 1, 16), ('xception', 65, 65, 0, 16),
+                                                      ('mobilenetv3large', 65, 65, 0, 16), ('mobilenetv3large', 64, 96, 0, 16),
+                                                      # output stride 8 (BASELINE configs[3]): denser atrous grid, ASPP rates 12/24/36
+                                                      ('mobilenetv2', 65, 65, 0, 8), ('xception', 97, 97, 0, 8)])
+def test_train_step_matches_oracle(model_type, H, W, freeze, OS):
     N, C = 2, 21
-    m, o = _pair(model_type, H, W, C, freeze_level=freeze)
+    m, o = _pair(model_type, H, W, C, OS=OS, freeze_level=freeze)
     m.use_graphs = False
     x, y = _data(N, H, W, C, seed=3)
     loss = m.train_on_batch(x, y)
