@@ -26,7 +26,8 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
         dist.destroy_process_group()
 else:
     out = {}
-    for tag, env in (('single', {}), ('forced_dist', {'DL3P_FORCE_DIST': '1'})):
+    for tag, env in (('single', {}), ('forced_dist', {'DL3P_FORCE_DIST': '1'}),
+                     ('forced_dist_segmented', {'DL3P_FORCE_DIST': '1', 'DL3P_COLLECTIVES_IN_GRAPH': '0'})):
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, __file__, 'child'], env=e, capture_output=True, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith('LOSSES')]
@@ -34,5 +35,5 @@ else:
             print(tag, 'FAILED', r.stderr[-2000:]); sys.exit(1)
         out[tag] = json.loads(line[0][7:])
         print(tag, out[tag])
-    assert out['single'] == out['forced_dist'], 'trajectories differ'
+    assert out['single'] == out['forced_dist'] == out['forced_dist_segmented'], 'trajectories differ'
     print('OK identical')

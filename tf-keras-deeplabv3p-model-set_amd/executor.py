@@ -716,8 +716,9 @@ class Executor:
         """capture the traced plans into hipGraphs (done once, after a warm-up eager step)"""
         torch.cuda.synchronize()
         # the trace already ran every kernel once; undo its side effects on the step counter only
+        in_graph = os.environ.get('DL3P_COLLECTIVES_IN_GRAPH', '1') != '0'     # 0: force the segmented fallback
         for plan in ([self.fwd, self.bwd, self.opt] if self.training else [self.fwd]):
-            plan.capture()
+            plan.capture(collectives_in_graph=in_graph)
         self.graphed = True
 
     def train_step(self):
