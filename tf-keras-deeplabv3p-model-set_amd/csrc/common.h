@@ -69,6 +69,11 @@ __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
 }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// streaming store (global_store ... nt): the line is not kept in L2 for this kernel's benefit
+__device__ __forceinline__ void st4_nt(float* p, float4 v) {
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store((f4v){v.x, v.y, v.z, v.w}, reinterpret_cast<f4v*>(p));
+}
 
 // counter-based keep mask for Dropout: one 64-bit mix per element (splitmix64 finaliser)
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, int64_t step, uint64_t idx, float rate) {

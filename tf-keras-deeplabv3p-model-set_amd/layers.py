@@ -72,9 +72,17 @@ def ASPP_block(g, x, OS):
 
 def _atrous_first(g, x_in):
     """Execution order only (layers and weights keep the reference's order): run the three atrous
-    depthwise convs -- largest rate first -- directly after the op that produced the ASPP input, while
-    that tensor is still resident in the Infinity Cache, then the pooling / 1x1 branches."""
+    depthwise convs directly after the op that produced the ASPP input, while that tensor is still
+    resident in the Infinity Cache, then the pooling / 1x1 branches.  Rate 6, 12, then 18 (measured:
+    the rate-18 kernel takes 9.6 us behind the two other readers of x, 11.1 us straight behind the
+    projection GEMM whose 22 MB of output is still being written back)."""
+    import os
+    order = int(os.environ.get('DL3P_ASPP_ORDER', '2'))
+    if order == 3:
+        return
     names = ['aspp3_depthwise', 'aspp2_depthwise', 'aspp1_depthwise']
+    if order in (2, 4):
+        names = names[::-1]
     moved = []
     for n in names:
         for op in g.ops:
@@ -83,6 +91,13 @@ def _atrous_first(g, x_in):
     first = min(i for i, op in enumerate(g.ops) if getattr(op, 'x', None) is not None and op.x.tensor is x_in.tensor
                 and op.kind in ('gap', 'conv_pw', 'conv_dw'))
     rest = [op for op in g.ops if op not in moved]
+    if order in (1, 4):      # pooling branch (gap, 1x1 conv, BN, broadcast) first, then the atrous convs
+        pool = [op for op in rest[first:] if getattr(op, 'name', '') in ('image_pooling', 'image_pooling_BN', 'aspp_resize')
+                or op.kind == 'gap']
+        rest2 = [op for op in rest if op not in pool]
+        first2 = first
+        g.ops[:] = rest2[:first2] + pool + moved + rest2[first2:]
+        return
     g.ops[:] = rest[:first] + moved + rest[first:]
 
 
