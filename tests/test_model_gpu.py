@@ -184,3 +184,46 @@ def test_graft_entry_smoke_in_fresh_process():
     r = subprocess.run([sys.executable, os.path.join(root, '__graft_entry__.py'), 'smoke'], capture_output=True, text=True,
                        cwd=root, timeout=600)
     assert r.returncode == 0 and 'smoke ok' in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_full_size_properties():
+    """BASELINE.json configs[1] at full size (MobileNetV2 + ASPP, 513x513, 21 classes, batch 16), where the fp64
+    oracle would take minutes: size-independent properties instead.
+      * training is bitwise deterministic: two models stepped from the same weights on the same batches agree bit
+        for bit (loss and every weight), eagerly and through hipGraph replay
+      * predict is equivariant under a permutation of the batch (inference BN is per pixel) and its outputs are
+        probability vectors
+      * the loss of the first step on random weights is close to log(21)"""
+    pkg = load_pkg()
+    N, C, H, W = 16, 21, 513, 513
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, (N, H, W, 3)).astype(np.float32)
+    y = rng.integers(0, C, (N, H * W, 1)).astype(np.float32)
+    y[rng.uniform(size=y.shape) < 0.05] = 255
+
+    def run(use_graphs):
+        m = pkg.get_deeplabv3p_model('mobilenetv2', C, (H, W), 16, training=True)
+        m.compile(optimizer=pkg.SGD(0.01, momentum=0.9), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
+        m.use_graphs = use_graphs
+        losses = [m.train_on_batch(x, y) for _ in range(3)]
+        return m, losses
+    ma, la = run(False)
+    wa = ma.get_weights_by_name()
+    del ma
+    torch.cuda.empty_cache()
+    mb, lb = run(True)
+    wb = mb.get_weights_by_name()
+    assert la == lb, (la, lb)                                       # bit-identical losses
+    assert all(np.array_equal(wa[k], wb[k]) for k in wa)            # and weights
+    assert abs(la[0] - np.log(C)) < 0.5, la
+    del mb
+    torch.cuda.empty_cache()
+    mi = pkg.get_deeplabv3p_model('mobilenetv2', C, (H, W), 16, training=False)
+    mi.set_weights_by_name(wa)
+    xs = x[:4]
+    p = mi.predict(xs)
+    assert p.shape == (4, H, W, C)
+    assert np.abs(p.sum(-1) - 1.0).max() < 1e-5 and p.min() >= 0.0
+    perm = np.array([2, 0, 3, 1])
+    pp = mi.predict(xs[perm])
+    assert np.array_equal(pp, p[perm])
