@@ -39,7 +39,7 @@ def parse():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-sync-bn', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--cpu-steps', type=int, default=4)
     return ap.parse_args()
 
 
