@@ -1,0 +1,24 @@
+"""images/s of train_on_batch when every batch arrives as host numpy arrays (the reference's fit_generator boundary):
+PCIe copy of 16 x 513 x 513 x 3 floats + labels per step included -- reported in DESIGN.md, never as bench `value`"""
+import importlib, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+pkg = importlib.import_module('tf-keras-deeplabv3p-model-set_amd')
+N, C, H, W = 16, 21, 513, 513
+m = pkg.get_deeplabv3p_model('mobilenetv2', C, (H, W), 16, training=True)
+m.compile(optimizer=pkg.SGD(0.01, momentum=0.9), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
+rng = np.random.default_rng(0)
+batches = [(rng.uniform(-1, 1, (N, H, W, 3)).astype(np.float32), rng.integers(0, C, (N, H * W, 1)).astype(np.float32))
+           for _ in range(3)]
+for i in range(4):
+    m.train_on_batch(*batches[i % 3])
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+K = 20
+for i in range(K):
+    m.train_on_batch(*batches[i % 3])
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print('train_on_batch with host numpy batches: %.1f images/s (%.2f ms/step)' % (N * K / dt, 1e3 * dt / K))
