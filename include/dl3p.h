@@ -70,6 +70,14 @@ int dl3p_dwconv2d_fwd(const float* x, int ldx, const float* in_scale, const floa
 int dl3p_dwconv2d_bwd_data(const float* dy, int lddy, const float* w, float* gx, int ldgx, int accumulate,
                            int N, int H, int W, int C, int k, int stride, int rate, int pad_t, int pad_l,
                            int Ho, int Wo, void* stream);
+/* The same for a layer whose input is act(BN(z)) with a trainable BN: also returns the partial rows
+ * (sum g', sum g'*xhat) of that BN's backward pass (what dl3p_bn_bwd_reduce(gx, z, ...) computes), folded into the
+ * store loop where the kernel decomposition allows it.  gx must be complete after this call (last writer). */
+int dl3p_dwconv2d_bwd_data_bn(const float* dy, int lddy, const float* w, float* gx, int ldgx, int accumulate,
+                              int N, int H, int W, int C, int k, int stride, int rate, int pad_t, int pad_l,
+                              int Ho, int Wo, const float* z, int ldz, const float* scale, const float* shift, int act,
+                              const float* save_mean, const float* save_invstd, float* partials, int* rows_out,
+                              void* stream);
 /* gw[k*k][C] = sum over pixels of act(x*scale+shift)[tap] * dy.  workspace: rows*k*k*C floats with
  * rows <= DL3P_MAX_STAT_ROWS (query with dl3p_dwconv2d_bwd_weight_workspace). */
 size_t dl3p_dwconv2d_bwd_weight_workspace(int N, int Ho, int Wo, int C, int k);
@@ -96,6 +104,14 @@ int dl3p_transpose_batch(const float* src, float* dst, const int* table, int n_m
 /* gx[M,K] (+)= dy[M,N] @ w[K,N]^T */
 int dl3p_pwconv_bwd_data(const float* dy, int lddy, const float* w, float* gx, int ldgx, int accumulate,
                          int M, int K, int N, void* stream);
+/* The same for a layer whose input is act(BN(z)) with a trainable BN: additionally emits, from the finished gradient
+ * in the GEMM epilogue, the partial rows (sum g', sum g'*xhat) that dl3p_bn_bwd_reduce(gx, z, ...) would produce in
+ * a separate pass over gx and z (feed them to dl3p_bn_bwd_finalize).  gx must be complete after this call (last
+ * writer). */
+int dl3p_pwconv_bwd_data_bn(const float* dy, int lddy, const float* w, float* gx, int ldgx, int accumulate,
+                            int M, int K, int N, const float* z, int ldz, const float* scale, const float* shift,
+                            int act, const float* save_mean, const float* save_invstd, float* partials, int* rows_out,
+                            void* stream);
 /* gw[K,N] = act(x*scale+shift)^T @ dy ; gb[N] = column sums of dy (gb may be NULL). */
 size_t dl3p_pwconv_bwd_weight_workspace(int M, int K, int N);
 int dl3p_pwconv_bwd_weight(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,

@@ -1,5 +1,7 @@
 """GPU parity of every C-ABI op against the CPU oracle (oracle/np_ops.py, fp64) on identical seeded
 inputs.  Tolerances are fp32-accumulation level (well inside north_star's 1e-3)."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -137,6 +139,67 @@ def test_pwconv_fwd_transposed_kernel(ops):
             y2, r2 = ops.pwconv_fwd_wt(x, wt, None, sc, sh, ops.ACT_RELU6, partials=p2)
             assert torch.equal(y1, y2) and r1 == r2       # same products in the same order
             assert torch.equal(p1[:r1 * 2 * Nn], p2[:r2 * 2 * Nn])
+
+
+@pytest.mark.parametrize('case', [(2 * 33 * 33, 96, 576, 2), (1000, 24, 144, 1), (3001, 256, 256, 2), (777, 160, 960, 0)])
+def test_pwconv_bwd_data_fused_bn_stats(ops, case):
+    """dl3p_pwconv_bwd_data_bn == dl3p_pwconv_bwd_data followed by dl3p_bn_bwd_reduce on its result"""
+    M, K, Nn, act = case
+    rng = np.random.default_rng(K + Nn)
+    dy = T(rng.standard_normal((M, Nn)))
+    w = T(rng.standard_normal((K, Nn)) / np.sqrt(Nn))
+    z = T(rng.standard_normal((M, K)) * 2)
+    sc = T(rng.uniform(0.5, 1.5, K)); sh = T(rng.standard_normal(K) * 0.5)
+    mu = T(rng.standard_normal(K) * 0.2); inv = T(rng.uniform(0.5, 2.0, K))
+    base = T(rng.standard_normal((M, K)))
+    for accumulate in (False, True):
+        ref = ops.pwconv_bwd_data(dy, w, out=base.clone() if accumulate else None, accumulate=accumulate)
+        p_ref = ops.new_partials(K, DEV)
+        rows_ref = ctypes.c_int(0)
+        ops.lib().bn_bwd_reduce(ref.data_ptr(), K, z.data_ptr(), K, sc.data_ptr(), sh.data_ptr(), act, mu.data_ptr(),
+                                inv.data_ptr(), p_ref.data_ptr(), ctypes.byref(rows_ref), M, K,
+                                torch.cuda.current_stream().cuda_stream)
+        part = ops.new_partials(K, DEV)
+        gx, rows = ops.pwconv_bwd_data_bn(dy, w, z, sc, sh, act, mu, inv, part, out=base.clone() if accumulate else None,
+                                          accumulate=accumulate)
+        assert torch.equal(gx, ref)
+        s_ref = p_ref[:rows_ref.value * 2 * K].view(rows_ref.value, 2, K).double().sum(0).cpu().numpy()
+        s_fus = part[:rows * 2 * K].view(rows, 2, K).double().sum(0).cpu().numpy()
+        scale = np.abs(s_ref).max(1, keepdims=True) + 1e-6
+        assert (np.abs(s_fus - s_ref) / scale).max() < 2e-5, (np.abs(s_fus - s_ref) / scale).max()
+
+
+@pytest.mark.parametrize('case', [(2, 33, 33, 96, 3, 1, 1, 'same', 2), (1, 65, 65, 144, 3, 2, 1, 'same', 2),
+                                  (2, 16, 20, 24, 3, 2, 1, 'same', 1), (2, 33, 33, 64, 3, 1, 2, 'same', 2),
+                                  (2, 33, 33, 320, 3, 1, 18, 'same', 2), (1, 16, 24, 40, 5, 1, 1, 'same', 2)])
+def test_dwconv_bwd_data_fused_bn_stats(ops, case):
+    """dl3p_dwconv2d_bwd_data_bn == dl3p_dwconv2d_bwd_data followed by dl3p_bn_bwd_reduce (fused window / quad kernels and
+    the two-launch fallback of the other decompositions)"""
+    N, H, W, C, k, stride, rate, pad, act = case
+    rng = np.random.default_rng(C + H)
+    Ho, Wo, _, _ = ops.conv_geometry(H, W, k, stride, rate, pad)
+    dy = T(rng.standard_normal((N, Ho, Wo, C)))
+    w = T(rng.standard_normal((k, k, C)) * 0.3)
+    z = T(rng.standard_normal((N, H, W, C)) * 2)
+    sc = T(rng.uniform(0.5, 1.5, C)); sh = T(rng.standard_normal(C) * 0.5)
+    mu = T(rng.standard_normal(C) * 0.2); inv = T(rng.uniform(0.5, 2.0, C))
+    base = T(rng.standard_normal((N, H, W, C)))
+    st = torch.cuda.current_stream().cuda_stream
+    for accumulate in (False, True):
+        ref = ops.dwconv2d_bwd_data(dy, w, (N, H, W, C), stride, rate, pad, out=base.clone() if accumulate else None,
+                                    accumulate=accumulate)
+        p_ref = ops.new_partials(C, DEV)
+        rows_ref = ctypes.c_int(0)
+        ops.lib().bn_bwd_reduce(ref.data_ptr(), C, z.data_ptr(), C, sc.data_ptr(), sh.data_ptr(), act, mu.data_ptr(),
+                                inv.data_ptr(), p_ref.data_ptr(), ctypes.byref(rows_ref), N * H * W, C, st)
+        part = ops.new_partials(C, DEV)
+        gx, rows = ops.dwconv2d_bwd_data_bn(dy, w, (N, H, W, C), z, sc, sh, act, mu, inv, part, stride, rate, pad,
+                                            out=base.clone() if accumulate else None, accumulate=accumulate)
+        assert torch.equal(gx, ref)
+        s_ref = p_ref[:rows_ref.value * 2 * C].view(rows_ref.value, 2, C).double().sum(0).cpu().numpy()
+        s_fus = part[:rows * 2 * C].view(rows, 2, C).double().sum(0).cpu().numpy()
+        scale = np.abs(s_ref).max(1, keepdims=True) + 1e-6
+        assert (np.abs(s_fus - s_ref) / scale).max() < 2e-5, (np.abs(s_fus - s_ref) / scale).max()
 
 
 def test_pwconv_concat_slices(ops):

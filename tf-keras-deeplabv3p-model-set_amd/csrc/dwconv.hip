@@ -27,7 +27,22 @@ struct DwParams {
   long long total;
   int flip, accumulate;
   int nt;              // streaming stores for the output (forward role only)
+  // fused BatchNorm-backward statistics (data-gradient role, output = gradient of act(BN(z))): partial rows hold
+  // (sum g', sum g' * xhat) as dl3p_bn_bwd_reduce would compute them from the finished gradient
+  const float* bb_z; int bb_ldz;
+  const float* bb_scale; const float* bb_shift; const float* bb_mean; const float* bb_invstd; int bb_act;
 };
+
+// g' = g * act'(z*scale+shift), xhat = (z - mean) * invstd  ->  s[0] += g', s[1] += g' * xhat
+__device__ __forceinline__ void bnb_accumulate(float4 (&s1)[2], float4 g, float4 zv, float4 bsc, float4 bsh, float4 bmu,
+                                               float4 bis, int act) {
+  const float4 u = fma4(zv, bsc, bsh);
+  const float4 d = make_float4(g.x * act_grad(u.x, act), g.y * act_grad(u.y, act), g.z * act_grad(u.z, act),
+                               g.w * act_grad(u.w, act));
+  const float4 xh = make_float4((zv.x - bmu.x) * bis.x, (zv.y - bmu.y) * bis.y, (zv.z - bmu.z) * bis.z, (zv.w - bmu.w) * bis.w);
+  s1[0] = add4(s1[0], d);
+  s1[1] = fma4(d, xh, s1[1]);
+}
 
 // producer prologue, specialised at compile time: PRO 0 = raw tensor (backward-data), 1 = BatchNorm affine
 // only (no activation follows the producer's BN), 2 = affine + activation
@@ -49,7 +64,7 @@ __device__ __forceinline__ float4 prologue4(float4 v, float4 sc, float4 sh, int 
 // zero padding are exec-masked loads that never leave the CU (at rate 18 on a 33x33 map a 2x2 output
 // block issues 4 loads instead of 36).  This replaces TF's SpaceToBatchND->conv->BatchToSpaceND
 // (two extra tensor passes) by index arithmetic.
-template <int KS, int TW, int S, int PRO>
+template <int KS, int TW, int S, int PRO, bool BNB = false>
 __global__ __launch_bounds__(256) void dw_fwd_seg(DwParams p) {
   constexpr int SEG = (TW - 1) * S + KS;
   const int b = blockIdx.x;
@@ -68,6 +83,8 @@ __global__ __launch_bounds__(256) void dw_fwd_seg(DwParams p) {
     for (int i = 0; i < KS * KS; ++i) wreg[i] = ld4(p.w + (size_t)(p.flip ? KS * KS - 1 - i : i) * p.C + c);
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero4();
     if (p.scale) { sc = ld4(p.scale + c); sh = ld4(p.shift + c); }
+    float4 bsc = zero4(), bsh = zero4(), bmu = zero4(), bis = zero4();
+    if (BNB) { bsc = ld4(p.bb_scale + c); bsh = ld4(p.bb_shift + c); bmu = ld4(p.bb_mean + c); bis = ld4(p.bb_invstd + c); }
     const int act = p.act;
     const int th = p.th, nbands = p.nbands, rate = p.rate;
     XcdRange r = xcd_range(p.total, bx, p.nbx, p.px, pl);
@@ -146,6 +163,12 @@ __global__ __launch_bounds__(256) void dw_fwd_seg(DwParams p) {
 #pragma unroll
             for (int kx = 0; kx < KS; ++kx) acc[tw] = fma4(win[ky][tw * S + kx], wreg[ky * KS + kx], acc[tw]);
         float* yrow = p.y + (((size_t)n * p.Ho + oy) * p.Wo + ox0) * p.ldy + c;
+        float4 zv[TW];
+        if (BNB) {      // z at the output pixels, requested before the stores
+          const float* zrow = p.bb_z + (((size_t)n * p.Ho + oy) * p.Wo + ox0) * p.bb_ldz + c;
+#pragma unroll
+          for (int tw = 0; tw < TW; ++tw) zv[tw] = ld4(zrow + (size_t)min(tw * rate, p.Wo - 1 - ox0) * p.bb_ldz);
+        }
 #pragma unroll
         for (int tw = 0; tw < TW; ++tw) {
           if (ox0 + tw * rate < p.Wo) {
@@ -153,8 +176,12 @@ __global__ __launch_bounds__(256) void dw_fwd_seg(DwParams p) {
             float* yp = yrow + (size_t)tw * rate * p.ldy;
             if (p.accumulate) vv = add4(vv, ld4(yp));
             if (p.nt) st4_nt(yp, vv); else st4(yp, vv);
-            s1[0] = add4(s1[0], vv);
-            s1[1] = fma4(vv, vv, s1[1]);
+            if (BNB) {
+              bnb_accumulate(s1, vv, zv[tw], bsc, bsh, bmu, bis, p.bb_act);
+            } else {
+              s1[0] = add4(s1[0], vv);
+              s1[1] = fma4(vv, vv, s1[1]);
+            }
           }
         }
         // slide the window down by S rows
@@ -551,7 +578,7 @@ __global__ __launch_bounds__(256) void dw_bwd_data_strided(DwParams p) {
 // parity reach input row iy (oy = (u - ky) / 2), so the quad rows u in {2a, 2a+1}, columns v in {2b, 2b+1}
 // read the same (J+1)^2 dy pixels (rows a-j, columns b-i, J = (KS-1)/2): all loads are issued first on
 // clamped addresses (no branch, no % or / per tap), 9 (25) FMAs per quad, 4 stores.
-template <int KS>
+template <int KS, bool BNB = false>
 __global__ __launch_bounds__(256) void dw_bwd_data_s2(DwParams p) {
   constexpr int J = (KS - 1) / 2;
   const int b = blockIdx.x;
@@ -560,8 +587,13 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2(DwParams p) {
   const int t = threadIdx.x;
   const int pl = t / p.c4s;
   const int cl = t - pl * p.c4s;
-  if (pl >= p.px) return;
-  const int c = (slab * p.c4s + cl) * 4;
+  const bool active = pl < p.px;
+  const int cbase4 = slab * p.c4s;
+  const int c = (cbase4 + cl) * 4;
+  float4 s1[2] = {zero4(), zero4()};
+  if (active) {
+  float4 bsc = zero4(), bsh = zero4(), bmu = zero4(), bis = zero4();
+  if (BNB) { bsc = ld4(p.bb_scale + c); bsh = ld4(p.bb_shift + c); bmu = ld4(p.bb_mean + c); bis = ld4(p.bb_invstd + c); }
   float4 wreg[KS * KS];
 #pragma unroll
   for (int i = 0; i < KS * KS; ++i) wreg[i] = ld4(p.w + (size_t)i * p.C + c);
@@ -605,13 +637,17 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2(DwParams p) {
           }
         }
         if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-          float* gp = p.y + (((size_t)n * p.H + iy) * p.W + ix) * p.ldy + c;
+          const size_t pix = ((size_t)n * p.H + iy) * p.W + ix;
+          float* gp = p.y + pix * p.ldy + c;
           if (p.accumulate) acc = add4(acc, ld4(gp));
           st4(gp, acc);
+          if (BNB) bnb_accumulate(s1, acc, ld4(p.bb_z + pix * p.bb_ldz + c), bsc, bsh, bmu, bis, p.bb_act);
         }
       }
     }
   }
+  }
+  if (BNB) block_reduce_store<2>(s1, active, pl, cl, p.c4s, p.px, cbase4, p.C, p.partials + (size_t)bx * 2 * p.C);
 }
 
 // ------------------------------------------------------------------------------ backward weight
@@ -819,6 +855,62 @@ extern "C" int dl3p_dwconv2d_bwd_data(const float* dy, int lddy, const float* w,
   }
   DL3P_CHECK_LAUNCH("dl3p_dwconv2d_bwd_data");
   return DL3P_OK;
+}
+
+// bwd-data of a layer whose input is act(BN(z)) + the BN-backward partial sums of that BN.  The stride-1 window
+// kernel and the stride-2 quad kernel fold the sums into their store loop (one extra read of z at the output pixel);
+// other decompositions (gather, residue-class kernel, 5x5) run the plain data gradient followed by the reduce pass.
+extern "C" int dl3p_bn_bwd_reduce(const float* g, int ldg, const float* z, int ldz, const float* scale, const float* shift,
+                                  int act, const float* save_mean, const float* save_invstd, float* partials,
+                                  int* rows_out, int M, int C, void* stream);
+extern "C" int dl3p_dwconv2d_bwd_data_bn(const float* dy, int lddy, const float* w, float* gx, int ldgx, int accumulate,
+                                         int N, int H, int W, int C, int k, int stride, int rate, int pad_t, int pad_l,
+                                         int Ho, int Wo, const float* z, int ldz, const float* scale, const float* shift,
+                                         int act, const float* save_mean, const float* save_invstd, float* partials,
+                                         int* rows_out, void* stream) {
+  int rc = check_dw_common("dl3p_dwconv2d_bwd_data_bn", dy, lddy, C, k);
+  if (rc) return rc;
+  DL3P_CHECK_ARG(dy && w && gx && z && scale && shift && save_mean && save_invstd && partials && rows_out,
+                 "dl3p_dwconv2d_bwd_data_bn: null pointer");
+  DL3P_CHECK_ARG(ldgx % 4 == 0 && ldgx >= C && ldz % 4 == 0 && ldz >= C && aligned16(gx) && aligned16(w) && aligned16(z),
+                 "dl3p_dwconv2d_bwd_data_bn: bad gx/z/w layout");
+  hipStream_t st = (hipStream_t)stream;
+  DwParams p = {};
+  p.w = w; p.C = C; p.N = N; p.accumulate = accumulate; p.partials = partials;
+  p.bb_z = z; p.bb_ldz = ldz; p.bb_scale = scale; p.bb_shift = shift; p.bb_mean = save_mean; p.bb_invstd = save_invstd;
+  p.bb_act = act;
+  pick_lanes(C, &p.c4s, &p.px, &p.nslab);
+  bool fused = false;
+  if (stride == 1 && k == 3) {
+    p.x = dy; p.ldx = lddy; p.y = gx; p.ldy = ldgx; p.flip = 1;
+    p.H = Ho; p.W = Wo; p.Ho = H; p.Wo = W; p.stride = 1; p.rate = rate;
+    p.pad_t = rate * (k - 1) - pad_t; p.pad_l = rate * (k - 1) - pad_l;
+    p.act = DL3P_ACT_NONE; p.ks = 3; p.ks5 = 0;
+    static const int dwf_per_cu = getenv("DL3P_DWF_PER_CU") ? atoi(getenv("DL3P_DWF_PER_CU")) : 8;
+    const int kind = fwd_plan(p, dwf_per_cu);
+    if (kind == 1) {
+      dl3p_launch(dw_fwd_seg<3, 4, 1, 0, true>, dim3(p.nbx * p.nslab), dim3(256), 0, st, p);
+      fused = true;
+    }
+  } else if (stride == 2 && rate == 1 && k == 3) {
+    p.dy = dy; p.lddy = lddy; p.y = gx; p.ldy = ldgx;
+    p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.rate = rate; p.pad_t = pad_t; p.pad_l = pad_l;
+    p.th = ((H - 1 + pad_t) >> 1) + 1;
+    p.spr = ((W - 1 + pad_l) >> 1) + 1;
+    p.total = (long long)N * p.th * p.spr;
+    p.nbx = pick_nbx(p.total, p.px, p.nslab);
+    hipLaunchKernelGGL((dw_bwd_data_s2<3, true>), dim3(p.nbx * p.nslab), dim3(256), 0, st, p);
+    fused = true;
+  }
+  if (fused) {
+    *rows_out = p.nbx;
+    DL3P_CHECK_LAUNCH("dl3p_dwconv2d_bwd_data_bn");
+    return DL3P_OK;
+  }
+  rc = dl3p_dwconv2d_bwd_data(dy, lddy, w, gx, ldgx, accumulate, N, H, W, C, k, stride, rate, pad_t, pad_l, Ho, Wo, stream);
+  if (rc) return rc;
+  return dl3p_bn_bwd_reduce(gx, ldgx, z, ldz, scale, shift, act, save_mean, save_invstd, partials, rows_out, N * H * W, C,
+                            stream);
 }
 
 template <int KS, int PRO>

@@ -40,6 +40,11 @@ struct GemmParams {
   int num_m_tiles;
   int stagger;
   int b_kn;            // pw_small_kernel: B stored [K][N] (forward) or [N][K] (data gradient)
+  // fused BatchNorm-backward statistics (data gradient writing the gradient of a BN+activation output): with bb_z
+  // set, the per-channel partials are (sum g', sum g' * xhat), g' = y * act'(z*scale+shift), xhat = (z-mean)*invstd,
+  // i.e. exactly what dl3p_bn_bwd_reduce would compute from the finished gradient y in a separate pass
+  const float* bb_z; int bb_ldz;
+  const float* bb_scale; const float* bb_shift; const float* bb_mean; const float* bb_invstd; int bb_act;
 #ifdef DL3P_STAMP
   long long* stamp;   // dev instrument: per-wave cycle counts of the loop phases (scripts/micro/stamp_gemm.py)
 #endif
@@ -47,7 +52,7 @@ struct GemmParams {
 
 // B_KN: B is [Kred][Nout] row-major (forward: the Keras kernel as stored);
 // !B_KN: B is [Nout][Kred] row-major (dgrad: the same kernel read as its transpose).
-template <int NT, bool B_KN, bool STATS, int MI, int BKT>
+template <int NT, bool B_KN, bool STATS, int MI, int BKT, bool BNB = false>
 __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
   constexpr int AP = BKT + 4;   // A pitch: rows 4 apart land 16 banks apart -> ds_read_b128 conflict-free
   constexpr int KQ = BKT / 4;   // float4 per K-tile row
@@ -294,6 +299,19 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
           if (p.bias) bias4 = ld4(p.bias + n);
           char* yb = reinterpret_cast<char*>(p.Y) + ((uint32_t)(m0 + w * RW + rr) * (uint32_t)p.ldy + (uint32_t)n) * 4u;
           const uint32_t ystep = (uint32_t)p.ldy * 16u;   // 4 rows
+          // fused BN-backward statistics: per-channel constants of this lane's 4 columns
+          constexpr bool bnb = STATS && BNB;    // (a template flag: the z prefetch registers must not burden the forward)
+          float4 bsc = zero4(), bsh = zero4(), bmu = zero4(), bis = zero4();
+          float4 zpre[RW / 4];          // all z rows of the pass are requested before the first one is used
+          if (bnb) {
+            bsc = ld4(p.bb_scale + n); bsh = ld4(p.bb_shift + n); bmu = ld4(p.bb_mean + n); bis = ld4(p.bb_invstd + n);
+            const char* zbase = reinterpret_cast<const char*>(p.bb_z) + (uint32_t)n * 4u;
+#pragma unroll
+            for (int i = 0; i < RW / 4; ++i) {
+              const int mrow = min(m0 + w * RW + 4 * i + rr, p.M - 1);       // rows past M re-read the last one (unused)
+              zpre[i] = *reinterpret_cast<const float4*>(zbase + (uint32_t)mrow * (uint32_t)p.bb_ldz * 4u);
+            }
+          }
           auto rows = [&](auto full) {
 #pragma unroll
             for (int r0 = 0; r0 < RW; r0 += 4) {
@@ -304,8 +322,19 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
                 if (p.accumulate) o = add4(o, ld4(yp));
                 st4(yp, o);
                 if (STATS) {
-                  st_s[ps] = add4(st_s[ps], o);
-                  st_q[ps] = fma4(o, o, st_q[ps]);
+                  if (bnb) {
+                    const float4 zv = zpre[r0 / 4];
+                    const float4 u = fma4(zv, bsc, bsh);
+                    const float4 d = make_float4(o.x * act_grad(u.x, p.bb_act), o.y * act_grad(u.y, p.bb_act),
+                                                 o.z * act_grad(u.z, p.bb_act), o.w * act_grad(u.w, p.bb_act));
+                    const float4 xh = make_float4((zv.x - bmu.x) * bis.x, (zv.y - bmu.y) * bis.y, (zv.z - bmu.z) * bis.z,
+                                                  (zv.w - bmu.w) * bis.w);
+                    st_s[ps] = add4(st_s[ps], d);
+                    st_q[ps] = fma4(d, xh, st_q[ps]);
+                  } else {
+                    st_s[ps] = add4(st_s[ps], o);
+                    st_q[ps] = fma4(o, o, st_q[ps]);
+                  }
                 }
               }
             }
@@ -609,7 +638,7 @@ static void gemm_grid(int M, int N, int nt, int* gx, int* gy, int* num_m_tiles, 
   *gx = g; *gy = nb; *num_m_tiles = mt; *mi_out = mi;
 }
 
-template <int NT, bool B_KN, bool STATS, int MI, int BKT>
+template <int NT, bool B_KN, bool STATS, int MI, int BKT, bool BNB = false>
 static void launch_gemm_one(const GemmParams& p, dim3 grid, hipStream_t st) {
   constexpr int BM = 64 * MI, BN = 16 * NT, AP = BKT + 4;
   constexpr int BS = B_KN ? BKT * (BN + 4) : BN * AP;
@@ -621,26 +650,26 @@ static void launch_gemm_one(const GemmParams& p, dim3 grid, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)pw_gemm_kernel<NT, B_KN, STATS, MI, BKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)pw_gemm_kernel<NT, B_KN, STATS, MI, BKT, BNB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  dl3p_launch(pw_gemm_kernel<NT, B_KN, STATS, MI, BKT>, grid, dim3(256), lds, st, p);
+  dl3p_launch(pw_gemm_kernel<NT, B_KN, STATS, MI, BKT, BNB>, grid, dim3(256), lds, st, p);
 }
 
-template <bool B_KN, bool STATS, int MI, int BKT>
+template <bool B_KN, bool STATS, int MI, int BKT, bool BNB = false>
 static void launch_gemm_mi(const GemmParams& p, int nt, dim3 grid, hipStream_t st) {
   switch (nt) {
-    case 1: launch_gemm_one<1, B_KN, STATS, MI, BKT>(p, grid, st); break;
-    case 2: launch_gemm_one<2, B_KN, STATS, MI, BKT>(p, grid, st); break;
-    case 3: launch_gemm_one<3, B_KN, STATS, MI, BKT>(p, grid, st); break;
-    case 4: launch_gemm_one<4, B_KN, STATS, MI, BKT>(p, grid, st); break;
-    case 5: launch_gemm_one<5, B_KN, STATS, MI, BKT>(p, grid, st); break;
-    case 6: launch_gemm_one<6, B_KN, STATS, MI, BKT>(p, grid, st); break;
-    default: launch_gemm_one<8, B_KN, STATS, MI, BKT>(p, grid, st); break;
+    case 1: launch_gemm_one<1, B_KN, STATS, MI, BKT, BNB>(p, grid, st); break;
+    case 2: launch_gemm_one<2, B_KN, STATS, MI, BKT, BNB>(p, grid, st); break;
+    case 3: launch_gemm_one<3, B_KN, STATS, MI, BKT, BNB>(p, grid, st); break;
+    case 4: launch_gemm_one<4, B_KN, STATS, MI, BKT, BNB>(p, grid, st); break;
+    case 5: launch_gemm_one<5, B_KN, STATS, MI, BKT, BNB>(p, grid, st); break;
+    case 6: launch_gemm_one<6, B_KN, STATS, MI, BKT, BNB>(p, grid, st); break;
+    default: launch_gemm_one<8, B_KN, STATS, MI, BKT, BNB>(p, grid, st); break;
   }
 }
 
-template <bool B_KN, bool STATS>
+template <bool B_KN, bool STATS, bool BNB = false>
 static void launch_gemm(const GemmParams& p_in, int nt, int mi, dim3 grid, hipStream_t st) {
   GemmParams p = p_in;
 #ifdef DL3P_STAMP
@@ -650,8 +679,8 @@ static void launch_gemm(const GemmParams& p_in, int nt, int mi, dim3 grid, hipSt
   { const char* e = getenv("DL3P_GEMM_STAGGER"); p.stagger = e ? atoi(e) : 0; }
   // (BKT = 64 -- half the barriers and staging passes per MFMA -- was measured neutral on the decoder layers and is
   // not instantiated: the loop is bound by matrix-pipe sharing between the two resident workgroups)
-  if (mi == 1) launch_gemm_mi<B_KN, STATS, 1, 32>(p, nt, grid, st);
-  else launch_gemm_mi<B_KN, STATS, 2, 32>(p, nt, grid, st);
+  if (mi == 1) launch_gemm_mi<B_KN, STATS, 1, 32, BNB>(p, nt, grid, st);
+  else launch_gemm_mi<B_KN, STATS, 2, 32, BNB>(p, nt, grid, st);
 }
 
 static int check_mat(const char* fn, const void* ptr, int ld, int cols) {
@@ -774,6 +803,39 @@ extern "C" int dl3p_pwconv_bwd_data(const float* dy, int lddy, const float* w, f
   gemm_grid(M, K, nt, &gxn, &gy, &p.num_m_tiles, &mi);
   launch_gemm<false, false>(p, nt, mi, dim3(gxn, gy), (hipStream_t)stream);
   DL3P_CHECK_LAUNCH("dl3p_pwconv_bwd_data");
+  return DL3P_OK;
+}
+
+// data gradient of a layer whose input is act(BN(z)): writes gx and, from the finished gradient in the epilogue, the
+// BatchNorm-backward partial sums of that BN (the separate dl3p_bn_bwd_reduce pass over gx and z disappears)
+extern "C" int dl3p_pwconv_bwd_data_bn(const float* dy, int lddy, const float* w, float* gx, int ldgx, int accumulate,
+                                       int M, int K, int N, const float* z, int ldz, const float* scale,
+                                       const float* shift, int act, const float* save_mean, const float* save_invstd,
+                                       float* partials, int* rows_out, void* stream) {
+  int rc = check_mat("dl3p_pwconv_bwd_data_bn", dy, lddy, N);
+  if (rc) return rc;
+  rc = check_mat("dl3p_pwconv_bwd_data_bn", gx, ldgx, K);
+  if (rc) return rc;
+  rc = check_mat("dl3p_pwconv_bwd_data_bn", z, ldz, K);
+  if (rc) return rc;
+  DL3P_CHECK_ARG(w && aligned16(w) && M > 0 && scale && shift && save_mean && save_invstd && partials && rows_out,
+                 "dl3p_pwconv_bwd_data_bn: bad arguments");
+  DL3P_CHECK_ARG((unsigned long long)M * (unsigned long long)(lddy > ldgx ? (lddy > ldz ? lddy : ldz) : (ldgx > ldz ? ldgx : ldz)) * 4ull < (1ull << 32),
+                 "dl3p_pwconv_bwd_data_bn: operands of 4 GiB or more are not supported (M=%d)", M);
+  GemmParams p = {};
+  p.A = dy; p.lda = lddy; p.act = DL3P_ACT_NONE;
+  p.B = w; p.ldb = N;
+  p.Y = gx; p.ldy = ldgx; p.accumulate = accumulate;
+  p.M = M; p.K = N; p.N = K;    // reduce over N, produce K columns
+  p.partials = partials;
+  p.bb_z = z; p.bb_ldz = ldz; p.bb_scale = scale; p.bb_shift = shift; p.bb_mean = save_mean; p.bb_invstd = save_invstd;
+  p.bb_act = act;
+  const int nt = pick_nt(K);
+  int gxn, gy, mi;
+  gemm_grid(M, K, nt, &gxn, &gy, &p.num_m_tiles, &mi);
+  *rows_out = gxn;
+  launch_gemm<false, true, true>(p, nt, mi, dim3(gxn, gy), (hipStream_t)stream);
+  DL3P_CHECK_LAUNCH("dl3p_pwconv_bwd_data_bn");
   return DL3P_OK;
 }
 

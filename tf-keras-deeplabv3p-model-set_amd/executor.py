@@ -535,6 +535,8 @@ class Executor:
         # issued while the NEXT BatchNorm's statistics all-reduce is on the wire (hides the collective's latency)
         self._deferred = []
         defer = self.sync_bn
+        fuse = self._bn_fusion_map()
+        bn_done = set()
 
         def wgrad(fn, *args):
             if defer:
@@ -552,7 +554,7 @@ class Executor:
             if out is not None and out.id in self._pending_views:
                 self._flush_views(P, out)
             if k == 'bn':
-                if op.z.requires_grad:
+                if op.z.requires_grad and op not in bn_done:
                     self._bn_backward(P, op)
                 continue
             if out is None or not out.requires_grad:
@@ -576,9 +578,39 @@ class Executor:
                 if need_gx:
                     gp, ldg, keyt = self._gbuf(op.x)
                     acc = self._acc(keyt)
-                    if k == 'conv_pw':
+                    if k == 'conv_pw' and op in fuse and fuse[op].z.requires_grad:
+                        bn_op = fuse[op]
+                        bn = bn_op.bn
+                        aux = self.bn_aux[bn]
+                        rows = ctypes.c_int(0)
+                        P.k(L.pwconv_bwd_data_bn, dz, lddz, st.ptr(op.w), gp, ldg, acc, N * op.Ho * op.Wo, op.cin,
+                            op.cout, self.tptr(bn_op.z), bn_op.z.ld,
+                            self.gscale[bn.group.id].data_ptr() + 4 * bn.offset,
+                            self.gshift[bn.group.id].data_ptr() + 4 * bn.offset, bn.act, aux['mean'].data_ptr(),
+                            aux['invstd'].data_ptr(), self.partials.data_ptr(), ctypes.byref(rows))
+                        ctx = P.ctx
+                        P.ctx = _op_label(bn_op)
+                        self._bn_backward(P, bn_op, fused_rows=rows.value)
+                        P.ctx = ctx
+                        bn_done.add(bn_op)
+                    elif k == 'conv_pw':
                         P.k(L.pwconv_bwd_data, dz, lddz, st.ptr(op.w), gp, ldg, acc, N * op.Ho * op.Wo, op.cin,
                             op.cout)
+                    elif k == 'conv_dw' and op in fuse and fuse[op].z.requires_grad:
+                        bn_op = fuse[op]
+                        bn = bn_op.bn
+                        aux = self.bn_aux[bn]
+                        rows = ctypes.c_int(0)
+                        P.k(L.dwconv2d_bwd_data_bn, dz, lddz, st.ptr(op.w), gp, ldg, acc, N, xt.H, xt.W, op.c, op.k,
+                            op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo, self.tptr(bn_op.z), bn_op.z.ld,
+                            self.gscale[bn.group.id].data_ptr() + 4 * bn.offset,
+                            self.gshift[bn.group.id].data_ptr() + 4 * bn.offset, bn.act, aux['mean'].data_ptr(),
+                            aux['invstd'].data_ptr(), self.partials.data_ptr(), ctypes.byref(rows))
+                        ctx = P.ctx
+                        P.ctx = _op_label(bn_op)
+                        self._bn_backward(P, bn_op, fused_rows=rows.value)
+                        P.ctx = ctx
+                        bn_done.add(bn_op)
                     elif k == 'conv_dw':
                         P.k(L.dwconv2d_bwd_data, dz, lddz, st.ptr(op.w), gp, ldg, acc, N, xt.H, xt.W, op.c, op.k,
                             op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
@@ -629,6 +661,29 @@ class Executor:
             P.py(self.dist.wait_all)
         return P
 
+    def _bn_fusion_map(self):
+        """{consumer conv op: 'bn' op} for every trainable BatchNorm whose output value has exactly ONE consumer and that
+        consumer is a pointwise or depthwise conv: its data-gradient kernel is then the only (= last) writer of the gradient
+        of the BN output and emits the BN-backward partial sums itself (dl3p_pwconv_bwd_data_bn / dl3p_dwconv2d_bwd_data_bn); the BN's
+        finalize + apply are issued right behind it and the separate reduce pass over (g, z) disappears."""
+        if os.environ.get('DL3P_FUSE_BN_BWD', '1') == '0':
+            return {}
+        cons = {}
+        for op in self.g.ops:
+            for slot in ('x', 'r', 's'):
+                v = getattr(op, slot, None)
+                if v is not None and getattr(v, 'bn', None) is not None:
+                    cons.setdefault(v.bn, []).append((op, slot, v))
+        bn_ops = {op.bn: op for op in self.g.ops if op.kind == 'bn'}
+        fuse = {}
+        for bn, lst in cons.items():
+            if len(lst) != 1 or bn not in bn_ops or not bn.layer.trainable:
+                continue
+            op, slot, v = lst[0]
+            if slot == 'x' and op.kind in ('conv_pw', 'conv_dw') and getattr(v, 'view_grad', None) is None and v.tensor is bn.z:
+                fuse[op] = bn_ops[bn]
+        return fuse
+
     def _flush_deferred(self, P):
         ctx = P.ctx
         for fn, args, c in self._deferred:
@@ -658,7 +713,7 @@ class Executor:
         self._first_bucket_hi = hi
         return edges
 
-    def _bn_backward(self, P, op):
+    def _bn_backward(self, P, op, fused_rows=None):
         bn, L, st, N = op.bn, self.L, self.store, self.N
         aux = self.bn_aux[bn]
         lp = {p.key: p for p in bn.layer.params}
@@ -674,9 +729,10 @@ class Executor:
         if frozen:
             P.k(L.bn_bwd_finalize, None, 0, None, bn.C, float(M), st.ptr(lp['gamma']), invstd, sp, 1, None, None, coef)
         else:
-            rows = ctypes.c_int(0)
-            P.k(L.bn_bwd_reduce, g, ldg, zp, ldz, sp, hp, bn.act, mean, invstd, self.partials.data_ptr(),
-                ctypes.byref(rows), M, bn.C)
+            rows = ctypes.c_int(fused_rows or 0)
+            if fused_rows is None:      # (otherwise the producer of g already left the partial sums in self.partials)
+                P.k(L.bn_bwd_reduce, g, ldg, zp, ldz, sp, hp, bn.act, mean, invstd, self.partials.data_ptr(),
+                    ctypes.byref(rows), M, bn.C)
             P.k(L.bn_bwd_finalize, self.partials.data_ptr(), rows.value, None, bn.C, float(M), st.ptr(lp['gamma']),
                 invstd, sp, 0, st.ptr(lp['gamma'], G), st.ptr(lp['beta'], G), coef)
             if self.sync_bn:

@@ -91,6 +91,23 @@ def dwconv2d_bwd_data(dy, w, x_shape, stride=1, rate=1, padding='same', out=None
     return gx
 
 
+def dwconv2d_bwd_data_bn(dy, w, x_shape, z, scale, shift, act, mean, invstd, partials, stride=1, rate=1, padding='same',
+                          out=None, accumulate=False):
+    """dwconv2d_bwd_data + the BatchNorm-backward partial sums of act(BN(z)) of the finished gradient; -> (gx, rows)"""
+    N, H, W, C = x_shape
+    k = w.shape[0]
+    Ho, Wo, pt, pl = conv_geometry(H, W, k, stride, rate, padding)
+    gx = out if out is not None else torch.empty((N, H, W, C), dtype=torch.float32, device=dy.device)
+    dp, lddy = _pl(dy)
+    gp, ldg = _pl(gx)
+    zp, ldz = _pl(z)
+    rows = ctypes.c_int(0)
+    lib().dwconv2d_bwd_data_bn(dp, lddy, _p(w), gp, ldg, int(accumulate), N, H, W, C, k, stride, rate, pt, pl, Ho, Wo,
+                               zp, ldz, _p(scale), _p(shift), act, _p(mean), _p(invstd), _p(partials),
+                               ctypes.byref(rows), _stream())
+    return gx, rows.value
+
+
 def dwconv2d_bwd_weight(x, dy, k, stride=1, rate=1, padding='same', in_scale=None, in_shift=None, in_act=ACT_NONE,
                         workspace=None):
     N, H, W, C = x.shape
@@ -148,6 +165,20 @@ def pwconv_bwd_data(dy, w, out=None, accumulate=False):
     gp, ldg = _pl(gx)
     lib().pwconv_bwd_data(dp, ldd, _p(w), gp, ldg, int(accumulate), M, K, Nn, _stream())
     return gx
+
+
+def pwconv_bwd_data_bn(dy, w, z, scale, shift, act, mean, invstd, partials, out=None, accumulate=False):
+    """pwconv_bwd_data + the BatchNorm-backward partial sums of act(BN(z)) from the finished gradient; -> (gx, rows)"""
+    M, N = _rows(dy), dy.shape[-1]
+    K = w.shape[0]
+    gx = out if out is not None else torch.empty(dy.shape[:-1] + (K,), dtype=torch.float32, device=dy.device)
+    dp, lddy = _pl(dy)
+    gp, ldg = _pl(gx)
+    zp, ldz = _pl(z)
+    rows = ctypes.c_int(0)
+    lib().pwconv_bwd_data_bn(dp, lddy, _p(w), gp, ldg, int(accumulate), M, K, N, zp, ldz, _p(scale), _p(shift), act,
+                             _p(mean), _p(invstd), _p(partials), ctypes.byref(rows), _stream())
+    return gx, rows.value
 
 
 def pwconv_bwd_weight(x, dy, in_scale=None, in_shift=None, in_act=ACT_NONE, with_bias=False, workspace=None):
