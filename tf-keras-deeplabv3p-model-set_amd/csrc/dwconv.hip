@@ -140,6 +140,12 @@ __global__ __launch_bounds__(256) void dw_fwd_seg(DwParams p) {
         const int oy = py + v * rate;
         if (oy >= p.Ho) break;
         const bool more = v + 1 < v0 + th && oy + rate < p.Ho;
+        float4 zv[TW];
+        if (BNB) {      // z at this row's output pixels: in flight during the FMAs below
+          const float* zrow = p.bb_z + (((size_t)n * p.Ho + oy) * p.Wo + ox0) * p.bb_ldz + c;
+#pragma unroll
+          for (int tw = 0; tw < TW; ++tw) zv[tw] = ld4(zrow + (size_t)min(tw * rate, p.Wo - 1 - ox0) * p.bb_ldz);
+        }
         // issue the loads of the S rows that enter the window for the next output row
         bool nyok[S];
 #pragma unroll
@@ -163,12 +169,6 @@ __global__ __launch_bounds__(256) void dw_fwd_seg(DwParams p) {
 #pragma unroll
             for (int kx = 0; kx < KS; ++kx) acc[tw] = fma4(win[ky][tw * S + kx], wreg[ky * KS + kx], acc[tw]);
         float* yrow = p.y + (((size_t)n * p.Ho + oy) * p.Wo + ox0) * p.ldy + c;
-        float4 zv[TW];
-        if (BNB) {      // z at the output pixels, requested before the stores
-          const float* zrow = p.bb_z + (((size_t)n * p.Ho + oy) * p.Wo + ox0) * p.bb_ldz + c;
-#pragma unroll
-          for (int tw = 0; tw < TW; ++tw) zv[tw] = ld4(zrow + (size_t)min(tw * rate, p.Wo - 1 - ox0) * p.bb_ldz);
-        }
 #pragma unroll
         for (int tw = 0; tw < TW; ++tw) {
           if (ox0 + tw * rate < p.Wo) {
