@@ -77,10 +77,24 @@ __global__ __launch_bounds__(256) void dw_fwd_seg(DwParams p) {
   const int cbase4 = slab * p.c4s;
   const int c = (cbase4 + cl) * 4;
   float4 s1[2] = {zero4(), zero4()};
+  // 5x5: the 25 weight vectors of a thread's channels live in LDS ([tap][channel lane], one ds_read_b128 per tap and
+  // row) -- in registers they cost 100 VGPRs on top of the 5-row window and halve the occupancy
+  constexpr bool WLDS = KS == 5;
+  extern __shared__ __attribute__((aligned(16))) float4 dw_w_lds[];
+  if (WLDS) {
+    for (int i = t; i < KS * KS * p.c4s; i += 256) {
+      const int tap = i / p.c4s, lane = i - tap * p.c4s;
+      dw_w_lds[i] = ld4(p.w + (size_t)(p.flip ? KS * KS - 1 - tap : tap) * p.C + (cbase4 + lane) * 4);
+    }
+    __syncthreads();
+  }
   if (active) {
-    float4 wreg[KS * KS];
+    float4 wreg[WLDS ? 1 : KS * KS];
+    if (!WLDS) {
 #pragma unroll
-    for (int i = 0; i < KS * KS; ++i) wreg[i] = ld4(p.w + (size_t)(p.flip ? KS * KS - 1 - i : i) * p.C + c);
+      for (int i = 0; i < KS * KS; ++i) wreg[i] = ld4(p.w + (size_t)(p.flip ? KS * KS - 1 - i : i) * p.C + c);
+    }
+    auto wtap = [&](int i) { return WLDS ? dw_w_lds[i * p.c4s + cl] : wreg[WLDS ? 0 : i]; };
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero4();
     if (p.scale) { sc = ld4(p.scale + c); sh = ld4(p.shift + c); }
     float4 bsc = zero4(), bsh = zero4(), bmu = zero4(), bis = zero4();
@@ -165,9 +179,11 @@ __global__ __launch_bounds__(256) void dw_fwd_seg(DwParams p) {
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
-          for (int tw = 0; tw < TW; ++tw)
+          for (int kx = 0; kx < KS; ++kx) {
+            const float4 wv = wtap(ky * KS + kx);
 #pragma unroll
-            for (int kx = 0; kx < KS; ++kx) acc[tw] = fma4(win[ky][tw * S + kx], wreg[ky * KS + kx], acc[tw]);
+            for (int tw = 0; tw < TW; ++tw) acc[tw] = fma4(win[ky][tw * S + kx], wv, acc[tw]);
+          }
         float* yrow = p.y + (((size_t)n * p.Ho + oy) * p.Wo + ox0) * p.ldy + c;
 #pragma unroll
         for (int tw = 0; tw < TW; ++tw) {
@@ -730,10 +746,11 @@ static int pick_band(long long items_per_row_band, int rows, int px, int nslab) 
 //   kind 1: window kernel TW=4, stride 1 (any rate, on the rate x rate sub-lattices)
 //   kind 2: window kernel TW=2, stride 2, rate 1
 //   kind 0: per-pixel gather (stride > 1 with rate > 1, or maps narrower than a strip)
-static int fwd_plan(DwParams& p, int per_cu = 8) {
+static int fwd_plan(DwParams& p, int per_cu = 8, bool window5 = false) {
   int kind = 0;
-  // (5x5 kernels use the per-pixel gather: a 5-row window plus 25 weights does not fit the register file)
-  if (p.ks5) kind = 0;
+  // 5x5: window kernels with LDS weights in the forward / data-gradient role (strips of 2 at stride 1, 1 at stride 2);
+  // the weight gradient keeps the per-pixel gather (25 tap accumulators + a 5-row window do not fit)
+  if (p.ks5 && !window5) kind = 0;
   else if (p.stride == 1 && ceil_div(p.Wo, p.rate) >= 4) kind = 1;
   else if (p.stride == 2 && p.rate == 1 && p.Wo >= 4) kind = 2;
   if (kind == 0 && p.ks == 3 && p.stride == 1 && p.pad_t == p.rate && p.pad_l == p.rate && p.Ho == p.H && p.Wo == p.W &&
@@ -746,7 +763,7 @@ static int fwd_plan(DwParams& p, int per_cu = 8) {
     p.spr = p.Wo; p.th = 1; p.nbands = p.Ho;
     p.total = (long long)p.N * p.Ho * p.Wo;
   } else {
-    const int TW = kind == 1 ? 4 : 2;
+    const int TW = p.ks5 ? (kind == 1 ? 2 : 1) : (kind == 1 ? 4 : 2);
     const int r = p.rate;
     const int uw = ceil_div(p.Wo, r), uh = ceil_div(p.Ho, r);      // sub-lattice size
     p.spr = ceil_div(uw, TW);
@@ -763,19 +780,39 @@ static int fwd_plan(DwParams& p, int per_cu = 8) {
 template <int KS, int PRO>
 static void launch_fwd_pro(const DwParams& p, int kind, dim3 grid, hipStream_t st) {
   dim3 block(256);
-  if (kind == 1) dl3p_launch(dw_fwd_seg<KS, 4, 1, PRO>, grid, block, 0, st, p);
-  else if (kind == 2) dl3p_launch(dw_fwd_seg<KS, 2, 2, PRO>, grid, block, 0, st, p);
+  if (KS == 5) {
+    // 5x5: narrower strips (window = 5 rows) and the weights in LDS (25 x c4s float4)
+    const size_t lds = (size_t)25 * p.c4s * sizeof(float4);
+    if (kind == 1) dl3p_launch(dw_fwd_seg<5, 2, 1, PRO>, grid, block, lds, st, p);
+    else if (kind == 2) dl3p_launch(dw_fwd_seg<5, 1, 2, PRO>, grid, block, lds, st, p);
+    else dl3p_launch(dw_fwd_gather<5, PRO>, grid, block, 0, st, p);
+    return;
+  }
+  if (kind == 1) dl3p_launch(dw_fwd_seg<3, 4, 1, PRO>, grid, block, 0, st, p);
+  else if (kind == 2) dl3p_launch(dw_fwd_seg<3, 2, 2, PRO>, grid, block, 0, st, p);
   else if (kind == 3) dl3p_launch(dw_fwd_lattice2<PRO>, grid, block, 0, st, p);
-  else dl3p_launch(dw_fwd_gather<KS, PRO>, grid, block, 0, st, p);
+  else dl3p_launch(dw_fwd_gather<3, PRO>, grid, block, 0, st, p);
+}
+
+// lanes + work decomposition of a forward-role launch (also what dl3p_dwconv2d_fwd reports as partial rows)
+static int plan_forward(DwParams& p, int KS) {
+  p.ks = KS;
+  p.ks5 = KS == 5;
+  static const int dwf_per_cu = getenv("DL3P_DWF_PER_CU") ? atoi(getenv("DL3P_DWF_PER_CU")) : 8;
+  if (KS == 5) {          // keep the LDS weight tile small: at most 64 channel lanes per workgroup
+    const int c4 = p.C / 4;
+    int best = 1;
+    for (int d = 1; d <= c4 && d <= 64; ++d)
+      if (c4 % d == 0 && (256 / d) * d >= (256 / best) * best) best = d;
+    p.c4s = best; p.px = 256 / best; p.nslab = c4 / best;
+  }
+  return fwd_plan(p, dwf_per_cu, true);
 }
 
 template <int KS>
 static void launch_fwd(const DwParams& p0, hipStream_t st) {
   DwParams p = p0;
-  p.ks = KS;
-  p.ks5 = KS == 5;
-  static const int dwf_per_cu = getenv("DL3P_DWF_PER_CU") ? atoi(getenv("DL3P_DWF_PER_CU")) : 8;
-  const int kind = fwd_plan(p, dwf_per_cu);
+  const int kind = plan_forward(p, KS);
   // streaming stores for forward outputs (bit 0 window kernels, bit 1 gather): -0.09 ms per step, and the rate-18
   // lattice kernel (always streaming) keeps its input in L2: 9.6 -> 8.8 us in-step
   static const int nt_mask = getenv("DL3P_DW_NT") ? atoi(getenv("DL3P_DW_NT")) : 3;
@@ -804,9 +841,7 @@ extern "C" int dl3p_dwconv2d_fwd(const float* x, int ldx, const float* in_scale,
   pick_lanes(C, &p.c4s, &p.px, &p.nslab);
   {
     DwParams q = p;
-    q.ks = k;
-    q.ks5 = k == 5;
-    fwd_plan(q);
+    plan_forward(q, k);
     if (rows_out) *rows_out = q.nbx;
   }
   hipStream_t st = (hipStream_t)stream;
