@@ -772,7 +772,7 @@ __global__ __launch_bounds__(256) void transpose_batch_kernel(const float* src, 
 
 extern "C" int dl3p_transpose_batch(const float* src, float* dst, const int* table, int n_matrices, void* stream) {
   DL3P_CHECK_ARG(src && dst && table && n_matrices > 0, "dl3p_transpose_batch: bad arguments");
-  hipLaunchKernelGGL(transpose_batch_kernel, dim3(n_matrices, 16), dim3(256), 0, (hipStream_t)stream, src, dst, table);
+  hipLaunchKernelGGL(transpose_batch_kernel, dim3(n_matrices, 96), dim3(256), 0, (hipStream_t)stream, src, dst, table);
   DL3P_CHECK_LAUNCH("dl3p_transpose_batch");
   return DL3P_OK;
 }
