@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void dw_fwd_gather(DwParams p) {
 // path, not by HBM).  Two classes per thread are in flight (8 loads issued before any arithmetic); all tap
 // indices are compile-time, so the 9 weights live in registers.  HBM-bound: reads x once, writes y once.
 #ifndef DL3P_LAT2_PER_CU
-#define DL3P_LAT2_PER_CU 2
+#define DL3P_LAT2_PER_CU 3
 #endif
 struct Lat2Item { unsigned pix[2][2]; bool rv[2], cv[2]; };
 
