@@ -474,8 +474,8 @@ __global__ __launch_bounds__(256) void dw_fwd_lattice2(DwParams p) {
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
-          in[ti][a][bb] = zero4();
-          if (cur[ti].rv[a] && cur[ti].cv[bb]) in[ti][a][bb] = ld4(xb + cur[ti].pix[a][bb] * ldx);
+          // unconditional load (pixel 0 for pixels outside the map; masked to zero below): no branch per load
+          in[ti][a][bb] = ld4(xb + ((cur[ti].rv[a] && cur[ti].cv[bb]) ? cur[ti].pix[a][bb] : 0u) * ldx);
         }
     }
     float4 wreg[9];
@@ -495,8 +495,7 @@ __global__ __launch_bounds__(256) void dw_fwd_lattice2(DwParams p) {
         for (int a = 0; a < 2; ++a)
 #pragma unroll
           for (int bb = 0; bb < 2; ++bb) {
-            inn[ti][a][bb] = zero4();
-            if (nxt[ti].rv[a] && nxt[ti].cv[bb]) inn[ti][a][bb] = ld4(xb + nxt[ti].pix[a][bb] * ldx);
+            inn[ti][a][bb] = ld4(xb + ((nxt[ti].rv[a] && nxt[ti].cv[bb]) ? nxt[ti].pix[a][bb] : 0u) * ldx);
           }
       }
 #pragma unroll
