@@ -227,3 +227,66 @@ def test_full_size_properties():
     perm = np.array([2, 0, 3, 1])
     pp = mi.predict(xs[perm])
     assert np.array_equal(pp, p[perm])
+
+
+def test_train_py_flow(tmp_path):
+    """the calls train.py makes, in its order (train.py:155-247): build with freeze_level 1, compile, fit_generator with
+    a Sequence-like generator + callback, unfreeze every layer, compile again, continue, save, load into a fresh
+    inference model, predict / evaluate"""
+    pkg = load_pkg()
+    C, H, W, B = 21, 65, 65, 2
+
+    class Gen:
+        def __init__(self, n):
+            self.n, self.epochs_seen = n, 0
+        def __len__(self):
+            return self.n
+        def __getitem__(self, i):
+            return _data(B, H, W, C, seed=100 + i)
+        def on_epoch_end(self):
+            self.epochs_seen += 1
+
+    class Cb:
+        def __init__(self):
+            self.logs = []
+        def set_model(self, m):
+            self.model = m
+        def on_epoch_end(self, epoch, logs=None):
+            self.logs.append((epoch, dict(logs)))
+
+    gen, cb = Gen(3), Cb()
+    m = pkg.get_deeplabv3p_model('mobilenetv2', C, (H, W), 16, freeze_level=1)
+    opt = pkg.get_optimizer('sgd', 0.02, decay_type=None)
+    m.compile(optimizer=opt, loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
+    lines = []
+    m.summary(print_fn=lines.append)
+    assert any('Total params' in l for l in lines)
+    w0 = m.get_weights_by_name()
+    h1 = m.fit_generator(gen, steps_per_epoch=len(gen), epochs=2, initial_epoch=0, callbacks=[cb], verbose=0,
+                         validation_data=gen, validation_steps=1)
+    assert len(h1['loss']) == 2 and gen.epochs_seen == 2 and [e for e, _ in cb.logs] == [0, 1]
+    assert 'val_loss' in cb.logs[0][1] and np.isfinite(cb.logs[0][1]['val_loss'])
+    w1 = m.get_weights_by_name()
+    backbone = [l.name for l in m.layers[:m.backbone_len]]
+    frozen_same = all(np.array_equal(w0[k], w1[k]) for k in w0
+                      if k.split('/')[0] in backbone and not k.endswith(('moving_mean', 'moving_variance')))
+    assert frozen_same, 'freeze_level=1 must leave the backbone weights untouched'
+    assert any(not np.array_equal(w0[k], w1[k]) for k in w0 if k.startswith('conv_upsample'))
+    # train.py:222-229: unfreeze, recompile, continue from the reached epoch
+    for i in range(len(m.layers)):
+        m.layers[i].trainable = True
+    m.compile(optimizer=opt, loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
+    h2 = m.fit_generator(gen, steps_per_epoch=len(gen), epochs=3, initial_epoch=2, callbacks=[cb], verbose=0)
+    assert len(h2['loss']) == 1 and np.isfinite(h2['loss'][0])
+    w2 = m.get_weights_by_name()
+    assert any(not np.array_equal(w1[k], w2[k]) for k in w1 if k.startswith('expanded_conv_3_expand/'))
+    path = str(tmp_path / 'trained_final')
+    m.save(path)
+    mi = pkg.get_deeplabv3p_model('mobilenetv2', C, (H, W), 16, training=False)
+    mi.load_weights(path, by_name=False)
+    x, y = _data(B, H, W, C, seed=7)
+    p = mi.predict(x)
+    assert p.shape == (B, H, W, C) and np.abs(p.sum(-1) - 1).max() < 1e-5
+    mi.compile(optimizer=None, loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
+    ev = mi.evaluate(Gen(1), 1)
+    assert np.isfinite(ev) and ev > 0
