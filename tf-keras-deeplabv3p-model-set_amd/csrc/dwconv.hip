@@ -950,9 +950,13 @@ extern "C" int dl3p_dwconv2d_bwd_data_bn(const float* dy, int lddy, const float*
 template <int KS, int PRO>
 static void launch_bwdw(const DwParams& p, int kind, dim3 grid, hipStream_t st) {
   dim3 block(256);
-  if (kind == 1) hipLaunchKernelGGL((dw_bwd_weight_seg<KS, 4, 1, PRO>), grid, block, 0, st, p);
-  else if (kind == 2) hipLaunchKernelGGL((dw_bwd_weight_seg<KS, 2, 2, PRO>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL((dw_bwd_weight<KS, PRO>), grid, block, 0, st, p);   // kind 0 (ks == 0 there: no kind 3)
+  if (KS == 5) {     // 25 tap accumulators + a 5-row window do not fit the register file: per-pixel gather only
+    hipLaunchKernelGGL((dw_bwd_weight<5, PRO>), grid, block, 0, st, p);
+    return;
+  }
+  if (kind == 1) hipLaunchKernelGGL((dw_bwd_weight_seg<3, 4, 1, PRO>), grid, block, 0, st, p);
+  else if (kind == 2) hipLaunchKernelGGL((dw_bwd_weight_seg<3, 2, 2, PRO>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((dw_bwd_weight<3, PRO>), grid, block, 0, st, p);   // kind 0 (ks == 0 there: no kind 3)
 }
 
 extern "C" size_t dl3p_dwconv2d_bwd_weight_workspace(int N, int Ho, int Wo, int C, int k) {
