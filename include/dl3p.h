@@ -205,15 +205,23 @@ int dl3p_scale_bcast_fwd(const float* x, int ldx, const float* scale, const floa
  * gs[n][c] = sum over the image's pixels of gy * act(x*scale+shift)  (gradient w.r.t. act_s(s)) */
 int dl3p_scale_bcast_bwd(const float* gy, int ldgy, const float* x, int ldx, const float* scale, const float* shift,
                          int act, const float* s, int lds, int s_act, float* gx, int ldgx, int accumulate_gx,
-                         float* gs, int ldgs, int N, int HW, int C, void* stream);
+                         float* gs, int ldgs, int N, int HW, int C, float* workspace, size_t workspace_bytes,
+                         void* stream);
 int dl3p_fill(float* p, float value, size_t n, void* stream);
 int dl3p_increment_counter(int64_t* counter, void* stream);
 
 /* ---------------------------------------------------------------- pooling / resize
- * AveragePooling2D(pool=(h,w)) == global mean (layers.py:132); y [N][C] (ldy) = out_scale * mean
+ * Per-image reductions (dl3p_global_avgpool_fwd, dl3p_scale_bcast_bwd) split each image into pixel chunks when
+ * given a workspace of dl3p_pool_workspace() bytes: partial rows + tickets, summed in chunk order by the
+ * workgroup that draws the last ticket (deterministic).  The workspace must be ZERO before its first use and is
+ * left ready for the next call; it may be shared by calls on one stream, not by concurrent streams.  With
+ * workspace == NULL (or too small) one workgroup reduces a whole (image, channel slab). */
+size_t dl3p_pool_workspace(int N, int HW, int C);
+/* AveragePooling2D(pool=(h,w)) == global mean (layers.py:132); y [N][C] (ldy) = out_scale * mean
  * (out_scale = HW turns it into the pixel sum that the broadcast branch's backward needs) */
 int dl3p_global_avgpool_fwd(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
-                            float* y, int ldy, float out_scale, int N, int HW, int C, void* stream);
+                            float* y, int ldy, float out_scale, int N, int HW, int C, float* workspace,
+                            size_t workspace_bytes, void* stream);
 int dl3p_global_avgpool_bwd(const float* gy, int ldgy, float* gx, int ldgx, int accumulate,
                             int N, int HW, int C, void* stream);
 /* tf.image.resize(method='bilinear'), half-pixel centres, no antialias (layers.py:48-60):

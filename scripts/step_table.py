@@ -107,15 +107,22 @@ def parse(d):
     shapes = json.load(open(os.path.join(ROOT, 'gpurun_out', 'st_shapes.json')))
     HBM, MFMA = 6.3e6, 157e6          # achievable bytes/us (guide: ~6.3 TB/s), fp32 MFMA flop/us
 
+    pw, dw, bn = ('M', 'K', 'N'), ('Min', 'M', 'C'), ('M', 'C')
+    NEED = dict(pwconv_fwd=pw, pwconv_fwd_wt=pw, pwconv_bwd_data=pw, pwconv_bwd_data_bn=pw, pwconv_bwd_weight=pw,
+                dwconv2d_fwd=dw, dwconv2d_bwd_data=dw, dwconv2d_bwd_data_bn=dw, dwconv2d_bwd_weight=dw,
+                bn_bwd_reduce=bn, bn_bwd_apply=bn)
+
     def floor_us(ep, ctx):
         sh = shapes.get(ctx)
         if not sh:
             return None
         ep = ep.replace('dl3p_', '')
-        if ep in ('pwconv_fwd', 'pwconv_bwd_data', 'pwconv_bwd_weight'):
+        if not all(k in sh for k in NEED.get(ep, ())):
+            return None
+        if ep in ('pwconv_fwd', 'pwconv_fwd_wt', 'pwconv_bwd_data', 'pwconv_bwd_data_bn', 'pwconv_bwd_weight'):
             by = 4.0 * sh['M'] * (sh['K'] + sh['N'])
             return max(by / HBM, 2.0 * sh['M'] * sh['K'] * sh['N'] / MFMA)
-        if ep in ('dwconv2d_fwd', 'dwconv2d_bwd_data', 'dwconv2d_bwd_weight'):
+        if ep in ('dwconv2d_fwd', 'dwconv2d_bwd_data', 'dwconv2d_bwd_data_bn', 'dwconv2d_bwd_weight'):
             return 4.0 * (sh['Min'] + sh['M']) * sh['C'] / HBM
         if ep == 'bn_bwd_reduce':
             return 8.0 * sh['M'] * sh['C'] / HBM

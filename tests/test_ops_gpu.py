@@ -324,6 +324,45 @@ def test_global_avgpool(ops):
     close(gx, O.global_avgpool_bwd(g, 33, 33), what='gap bwd')
 
 
+@pytest.mark.parametrize('shape', [(4, 65, 65, 120), (16, 33, 33, 960), (3, 33, 33, 672), (2, 65, 65, 72), (1, 5, 3, 8)])
+def test_chunked_per_image_reductions(ops, shape):
+    """pooling and the SE backward split images into pixel chunks (tickets + partial rows in a workspace): same
+    numbers as the one-workgroup-per-image path, bit-identical from call to call, tickets left at zero"""
+    L = ops.lib()
+    N, H, W, C = shape
+    rng = np.random.default_rng(C)
+    x = rng.standard_normal(shape); s = rng.standard_normal((N, 1, 1, C)) * 2
+    sc = rng.uniform(0.5, 1.5, C); sh = rng.standard_normal(C) * 0.3
+    gy = rng.standard_normal(shape)
+    xt, st, sct, sht, gyt = T(x), T(s), T(sc), T(sh), T(gy)
+    nbytes = L.pool_workspace(N, H * W, C)
+    ws = torch.zeros(nbytes // 4, dtype=torch.float32, device=DEV)
+    ys, gss = [], []
+    for _ in range(3):                                   # the same workspace, call after call
+        y = torch.empty((N, 1, 1, C), dtype=torch.float32, device=DEV)
+        L.global_avgpool_fwd(xt.data_ptr(), C, sct.data_ptr(), sht.data_ptr(), ops.ACT_HSWISH, y.data_ptr(), C, 1.0, N,
+                             H * W, C, ws.data_ptr(), nbytes, ops._stream())
+        gx = torch.empty(shape, dtype=torch.float32, device=DEV)
+        gs = torch.empty((N, 1, 1, C), dtype=torch.float32, device=DEV)
+        L.scale_bcast_bwd(gyt.data_ptr(), C, xt.data_ptr(), C, sct.data_ptr(), sht.data_ptr(), ops.ACT_HSWISH,
+                          st.data_ptr(), C, ops.ACT_HSIGMOID, gx.data_ptr(), C, 0, gs.data_ptr(), C, N, H * W, C,
+                          ws.data_ptr(), nbytes, ops._stream())
+        ys.append(y.cpu().numpy()); gss.append(gs.cpu().numpy())
+    assert all(np.array_equal(ys[0], v) for v in ys[1:]) and all(np.array_equal(gss[0], v) for v in gss[1:])
+    tickets = ws[:N * 64].view(torch.int32)[:N].cpu().numpy()
+    assert (tickets == 0).all()
+    a = O.act_fwd(x * sc + sh, O.ACT_HSWISH)
+    close(ys[0], a.mean((1, 2), keepdims=True), rtol=3e-4, atol=1e-5, what='chunked gap')
+    close(gss[0], (gy * a).sum((1, 2), keepdims=True), rtol=3e-4, atol=1e-4, what='chunked se bwd s')
+    close(gx, gy * O.act_fwd(s, O.ACT_HSIGMOID), what='chunked se bwd x')
+    y1 = ops.global_avgpool_fwd(xt, sct, sht, ops.ACT_HSWISH, chunked=False)
+    _, gs1 = ops.scale_bcast_bwd(gyt, xt, st, sct, sht, ops.ACT_HSWISH, ops.ACT_HSIGMOID, chunked=False)
+    close(ys[0], y1.cpu().numpy(), rtol=1e-5, atol=1e-6, what='chunked vs whole-image gap')
+    close(gss[0], gs1.cpu().numpy(), rtol=1e-4, atol=1e-4, what='chunked vs whole-image se bwd')
+    yf = ops.scale_bcast_fwd(xt, st, sct, sht, ops.ACT_HSWISH, ops.ACT_HSIGMOID)
+    close(yf, a * O.act_fwd(s, O.ACT_HSIGMOID), what='se multiply')
+
+
 @pytest.mark.parametrize('case', [(2, 33, 33, 256, 129, 129), (1, 1, 1, 256, 33, 33), (2, 9, 13, 24, 33, 50),
                                   (1, 129, 129, 24, 513, 513), (1, 16, 32, 8, 64, 128), (1, 10, 10, 4, 7, 5)])
 def test_resize_bilinear(ops, case):

@@ -535,41 +535,127 @@ extern "C" int dl3p_increment_counter(int64_t* counter, void* stream) {
 }
 
 // ------------------------------------------------------------------------------ global average pooling
-// one workgroup per (image, channel slab): pixel lanes walk HW, then a block reduction
-__global__ __launch_bounds__(256) void gap_fwd_kernel(EwParams p, int HW, float out_scale) {
-  const int n = blockIdx.x / p.nslab;
-  const int slab = blockIdx.x - n * p.nslab;
+// Per-image reductions over HW pixels (pooling, SE-block backward).  Workgroups = (image, channel slab, pixel
+// chunk).  With one chunk the workgroup owns the whole image and stores the result; with several, each stores an
+// unscaled partial row into the workspace, takes a ticket, and the workgroup that draws the last ticket of its
+// (image, slab) sums the partial rows in chunk order -- the same order whichever workgroup ends up doing it, so the
+// result is deterministic.  Tickets live at the head of the workspace and are reset to zero by that last workgroup.
+struct PoolPlan { int c4s, px, nslab, nchunk, per; size_t ticket_floats; };
+static PoolPlan pool_plan(int N, int HW, int C, bool chunked) {
+  PoolPlan pl;
+  const int c4 = C / 4;
+  int d = 1;
+  const int dmax = chunked ? 64 : 16;   // chunks supply the parallelism: whole rows per pixel lane when they fit
+  for (int k = 1; k <= dmax && k <= c4; ++k) if (c4 % k == 0) d = k;
+  pl.c4s = d; pl.px = 256 / d; pl.nslab = c4 / d;
+  int nchunk = 1;
+  if (chunked) {
+    static const int want = getenv("DL3P_POOL_WGS") ? atoi(getenv("DL3P_POOL_WGS")) : 512;
+    nchunk = (want + N * pl.nslab - 1) / (N * pl.nslab);
+    const int most = (HW + 4 * pl.px - 1) / (4 * pl.px);          // >= 4 pixels per lane and chunk
+    if (nchunk > most) nchunk = most;
+    if (nchunk > 64) nchunk = 64;
+    if (nchunk < 1) nchunk = 1;
+  }
+  pl.per = (HW + nchunk - 1) / nchunk;
+  pl.nchunk = (HW + pl.per - 1) / pl.per;
+  pl.ticket_floats = (((size_t)N * pl.nslab + 63) / 64) * 64;
+  return pl;
+}
+extern "C" size_t dl3p_pool_workspace(int N, int HW, int C) {
+  if (N <= 0 || HW <= 0 || C <= 0 || C % 4) return 0;
+  const PoolPlan pl = pool_plan(N, HW, C, true);
+  return (pl.ticket_floats + (size_t)N * pl.nchunk * C) * sizeof(float);
+}
+static bool pool_ws_ok(const float* ws, size_t bytes, int N, int HW, int C) {
+  return ws && aligned16(ws) && bytes >= dl3p_pool_workspace(N, HW, C);
+}
+
+// All 256 threads call.  Block-reduces the pixel lanes' partial sums into row `chunk` of the workspace, takes a
+// ticket, and lets the workgroup with the last ticket add the rows up.  The partial rows are written and read with
+// agent-scope atomic accesses (write-through / L2-bypassing on the 8-XCD part), so no __threadfence() is needed: a
+// full fence writes back the whole L2, which is ruinous next to a kernel that is streaming its output through it.
+__device__ __forceinline__ void pool_finish(const float4& val, bool active, int pl, int cl, int px, float* ws,
+                                            size_t ticket_floats, int n, int chunk, int slab, int nslab, int nchunk,
+                                            int c4s, int cbase4, int C, float* out_row, float scale) {
+  __shared__ float4 sm[256];
+  __shared__ int last;
+  if (active) sm[pl * c4s + cl] = val;
+  __syncthreads();
+  float* rows = ws + ticket_floats + (size_t)n * nchunk * C + (size_t)(cbase4 + threadIdx.x) * 4;
+  if ((int)threadIdx.x < c4s) {
+    float4 a = sm[threadIdx.x];
+    for (int q = 1; q < px; ++q) a = add4(a, sm[q * c4s + threadIdx.x]);
+    float* r = rows + (size_t)chunk * C;
+    __hip_atomic_store(r + 0, a.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(r + 1, a.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(r + 2, a.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(r + 3, a.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the stores above have completed ...
+  __syncthreads();                                            // ... for every lane before the ticket is drawn
+  int* tickets = reinterpret_cast<int*>(ws);
+  if (threadIdx.x == 0)
+    last = __hip_atomic_fetch_add(&tickets[n * nslab + slab], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nchunk - 1;
+  __syncthreads();
+  if (!last) return;
+  if ((int)threadIdx.x < c4s) {
+    float4 a = zero4();
+    for (int q = 0; q < nchunk; ++q) {
+      const float* r = rows + (size_t)q * C;
+      a.x += __hip_atomic_load(r + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      a.y += __hip_atomic_load(r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      a.z += __hip_atomic_load(r + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      a.w += __hip_atomic_load(r + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    st4(out_row + (size_t)(cbase4 + threadIdx.x) * 4, make_float4(a.x * scale, a.y * scale, a.z * scale, a.w * scale));
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(&tickets[n * nslab + slab], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void gap_fwd_kernel(EwParams p, int HW, float out_scale, float* ws,
+                                                      size_t ticket_floats, int nchunk, int per) {
+  const int chunk = blockIdx.x % nchunk;
+  const int rest = blockIdx.x / nchunk;
+  const int n = rest / p.nslab;
+  const int slab = rest - n * p.nslab;
   const int pl = threadIdx.x / p.c4s;
   const int cl = threadIdx.x - pl * p.c4s;
   const bool active = pl < p.px;
   const int cbase4 = slab * p.c4s;
   const int c = (cbase4 + cl) * 4;
+  const float inv = out_scale / (float)HW;
   float4 acc[1] = {zero4()};
   if (active) {
     const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
     const float4 sc = opt_ld4(p.scale, c, one), sh = opt_ld4(p.shift, c, zero4());
     const float* base = p.a + (size_t)n * HW * p.lda + c;
+    const int i1 = min(HW, (chunk + 1) * per);
     // 4 independent accumulators: 4 row loads in flight per thread
     float4 a1 = zero4(), a2 = zero4(), a3 = zero4();
-    int i = pl;
-    for (; i + 3 * p.px < HW; i += 4 * p.px) {
+    int i = chunk * per + pl;
+    for (; i + 3 * p.px < i1; i += 4 * p.px) {
       acc[0] = add4(acc[0], act_apply4(fma4(ld4(base + (size_t)i * p.lda), sc, sh), p.act));
       a1 = add4(a1, act_apply4(fma4(ld4(base + (size_t)(i + p.px) * p.lda), sc, sh), p.act));
       a2 = add4(a2, act_apply4(fma4(ld4(base + (size_t)(i + 2 * p.px) * p.lda), sc, sh), p.act));
       a3 = add4(a3, act_apply4(fma4(ld4(base + (size_t)(i + 3 * p.px) * p.lda), sc, sh), p.act));
     }
-    for (; i < HW; i += p.px) acc[0] = add4(acc[0], act_apply4(fma4(ld4(base + (size_t)i * p.lda), sc, sh), p.act));
+    for (; i < i1; i += p.px) acc[0] = add4(acc[0], act_apply4(fma4(ld4(base + (size_t)i * p.lda), sc, sh), p.act));
     acc[0] = add4(add4(acc[0], a1), add4(a2, a3));
-    const float inv = out_scale / (float)HW;
-    acc[0] = make_float4(acc[0].x * inv, acc[0].y * inv, acc[0].z * inv, acc[0].w * inv);
+    if (nchunk == 1) acc[0] = make_float4(acc[0].x * inv, acc[0].y * inv, acc[0].z * inv, acc[0].w * inv);
   }
-  // out row n: reuse block_reduce_store with C := ldo so that row stride is honoured
-  block_reduce_store<1>(acc, active, pl, cl, p.c4s, p.px, cbase4, p.ldo, p.out + (size_t)n * p.ldo);
+  if (nchunk == 1) {
+    // out row n: block_reduce_store with C := ldo so that the row stride is honoured
+    block_reduce_store<1>(acc, active, pl, cl, p.c4s, p.px, cbase4, p.ldo, p.out + (size_t)n * p.ldo);
+    return;
+  }
+  pool_finish(acc[0], active, pl, cl, p.px, ws, ticket_floats, n, chunk, slab, p.nslab, nchunk, p.c4s, cbase4, p.C,
+              p.out + (size_t)n * p.ldo, inv);
 }
 
 extern "C" int dl3p_global_avgpool_fwd(const float* x, int ldx, const float* in_scale, const float* in_shift,
                                        int in_act, float* y, int ldy, float out_scale, int N, int HW, int C,
-                                       void* stream) {
+                                       float* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_ew("dl3p_global_avgpool_fwd", x, ldx, C);
   if (rc) return rc;
   rc = check_ew("dl3p_global_avgpool_fwd", y, ldy, C);
@@ -577,15 +663,10 @@ extern "C" int dl3p_global_avgpool_fwd(const float* x, int ldx, const float* in_
   DL3P_CHECK_ARG(N > 0 && HW > 0, "dl3p_global_avgpool_fwd: bad dims");
   EwParams p = {};
   p.a = x; p.lda = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act; p.out = y; p.ldo = ldy;
-  // narrow channel slabs (<= 16 lanes = 256 B per pixel) -> many workgroups with 16+ pixel lanes each
-  {
-    const int c4 = C / 4;
-    int d = 1;
-    for (int k = 1; k <= 16 && k <= c4; ++k) if (c4 % k == 0) d = k;
-    p.c4s = d; p.px = 256 / d; p.nslab = c4 / d;
-  }
-  p.C = C;
-  hipLaunchKernelGGL(gap_fwd_kernel, dim3(N * p.nslab), dim3(256), 0, (hipStream_t)stream, p, HW, out_scale);
+  const PoolPlan pl = pool_plan(N, HW, C, pool_ws_ok(workspace, workspace_bytes, N, HW, C));
+  p.c4s = pl.c4s; p.px = pl.px; p.nslab = pl.nslab; p.C = C;
+  hipLaunchKernelGGL(gap_fwd_kernel, dim3(N * p.nslab * pl.nchunk), dim3(256), 0, (hipStream_t)stream, p, HW,
+                     out_scale, workspace, pl.ticket_floats, pl.nchunk, pl.per);
   DL3P_CHECK_LAUNCH("dl3p_global_avgpool_fwd");
   return DL3P_OK;
 }
@@ -624,11 +705,14 @@ extern "C" int dl3p_global_avgpool_bwd(const float* gy, int ldgy, float* gx, int
 }
 
 // ------------------------------------------------------------------------------ SE-block multiply
-// y[n,p,c] = act(x*scale+shift) * act_s(s[n,c])  (deeplabv3p_mobilenetv3.py:145 Multiply); one workgroup per
-// (image, channel slab) like the pooling kernel, so the backward's per-image reduction needs no atomics
-__global__ __launch_bounds__(256) void scale_bcast_fwd_kernel(EwParams p, int HW, const float* s, int lds, int s_act) {
-  const int n = blockIdx.x / p.nslab;
-  const int slab = blockIdx.x - n * p.nslab;
+// y[n,p,c] = act(x*scale+shift) * act_s(s[n,c])  (deeplabv3p_mobilenetv3.py:145 Multiply); workgroups = (image,
+// channel slab, pixel chunk) like the pooling kernel, so the backward's per-image reduction needs no float atomics
+__global__ __launch_bounds__(256) void scale_bcast_fwd_kernel(EwParams p, int HW, const float* s, int lds, int s_act,
+                                                              int nchunk, int per) {
+  const int chunk = blockIdx.x % nchunk;
+  const int rest = blockIdx.x / nchunk;
+  const int n = rest / p.nslab;
+  const int slab = rest - n * p.nslab;
   const int pl = threadIdx.x / p.c4s;
   const int cl = threadIdx.x - pl * p.c4s;
   if (pl >= p.px) return;
@@ -638,14 +722,23 @@ __global__ __launch_bounds__(256) void scale_bcast_fwd_kernel(EwParams p, int HW
   const float4 sv = act_apply4(ld4(s + (size_t)n * lds + c), s_act);
   const float* base = p.a + (size_t)n * HW * p.lda + c;
   float* ob = p.out + (size_t)n * HW * p.ldo + c;
-  for (int i = pl; i < HW; i += p.px)
-    st4(ob + (size_t)i * p.ldo, mul4(act_apply4(fma4(ld4(base + (size_t)i * p.lda), sc, sh), p.act), sv));
+  const int i1 = min(HW, (chunk + 1) * per);
+  int i = chunk * per + pl;
+  for (; i + p.px < i1; i += 2 * p.px) {
+    const float4 v0 = ld4(base + (size_t)i * p.lda), v1 = ld4(base + (size_t)(i + p.px) * p.lda);
+    st4(ob + (size_t)i * p.ldo, mul4(act_apply4(fma4(v0, sc, sh), p.act), sv));
+    st4(ob + (size_t)(i + p.px) * p.ldo, mul4(act_apply4(fma4(v1, sc, sh), p.act), sv));
+  }
+  if (i < i1) st4(ob + (size_t)i * p.ldo, mul4(act_apply4(fma4(ld4(base + (size_t)i * p.lda), sc, sh), p.act), sv));
 }
 
 __global__ __launch_bounds__(256) void scale_bcast_bwd_kernel(EwParams p, int HW, const float* s, int lds, int s_act,
-                                                              const float* gy, int ldgy, float* gs, int ldgs) {
-  const int n = blockIdx.x / p.nslab;
-  const int slab = blockIdx.x - n * p.nslab;
+                                                              const float* gy, int ldgy, float* gs, int ldgs,
+                                                              float* ws, size_t ticket_floats, int nchunk, int per) {
+  const int chunk = blockIdx.x % nchunk;
+  const int rest = blockIdx.x / nchunk;
+  const int n = rest / p.nslab;
+  const int slab = rest - n * p.nslab;
   const int pl = threadIdx.x / p.c4s;
   const int cl = threadIdx.x - pl * p.c4s;
   const bool active = pl < p.px;
@@ -659,7 +752,21 @@ __global__ __launch_bounds__(256) void scale_bcast_bwd_kernel(EwParams p, int HW
     const float* xb = p.a + (size_t)n * HW * p.lda + c;
     const float* gb = gy + (size_t)n * HW * ldgy + c;
     float* ob = p.out + (size_t)n * HW * p.ldo + c;
-    for (int i = pl; i < HW; i += p.px) {
+    const int i1 = min(HW, (chunk + 1) * per);
+    float4 a1 = zero4();
+    int i = chunk * per + pl;
+    for (; i + p.px < i1; i += 2 * p.px) {
+      const int j = i + p.px;
+      const float4 g0 = ld4(gb + (size_t)i * ldgy), g1 = ld4(gb + (size_t)j * ldgy);
+      const float4 x0 = ld4(xb + (size_t)i * p.lda), x1 = ld4(xb + (size_t)j * p.lda);
+      float4 o0 = mul4(g0, sv), o1 = mul4(g1, sv);
+      if (p.accumulate) { o0 = add4(o0, ld4(ob + (size_t)i * p.ldo)); o1 = add4(o1, ld4(ob + (size_t)j * p.ldo)); }
+      acc[0] = fma4(g0, act_apply4(fma4(x0, sc, sh), p.act), acc[0]);
+      a1 = fma4(g1, act_apply4(fma4(x1, sc, sh), p.act), a1);
+      st4(ob + (size_t)i * p.ldo, o0);
+      st4(ob + (size_t)j * p.ldo, o1);
+    }
+    if (i < i1) {
       const float4 g = ld4(gb + (size_t)i * ldgy);
       const float4 a = act_apply4(fma4(ld4(xb + (size_t)i * p.lda), sc, sh), p.act);
       acc[0] = fma4(g, a, acc[0]);
@@ -667,15 +774,14 @@ __global__ __launch_bounds__(256) void scale_bcast_bwd_kernel(EwParams p, int HW
       if (p.accumulate) o = add4(o, ld4(ob + (size_t)i * p.ldo));
       st4(ob + (size_t)i * p.ldo, o);
     }
+    acc[0] = add4(acc[0], a1);
   }
-  block_reduce_store<1>(acc, active, pl, cl, p.c4s, p.px, cbase4, ldgs, gs + (size_t)n * ldgs);
-}
-
-static void se_lanes(EwParams& p, int C) {
-  const int c4 = C / 4;
-  int d = 1;
-  for (int k = 1; k <= 16 && k <= c4; ++k) if (c4 % k == 0) d = k;
-  p.c4s = d; p.px = 256 / d; p.nslab = c4 / d; p.C = C;
+  if (nchunk == 1) {
+    block_reduce_store<1>(acc, active, pl, cl, p.c4s, p.px, cbase4, ldgs, gs + (size_t)n * ldgs);
+    return;
+  }
+  pool_finish(acc[0], active, pl, cl, p.px, ws, ticket_floats, n, chunk, slab, p.nslab, nchunk, p.c4s, cbase4, p.C,
+              gs + (size_t)n * ldgs, 1.f);
 }
 
 extern "C" int dl3p_scale_bcast_fwd(const float* x, int ldx, const float* scale, const float* shift, int act,
@@ -687,10 +793,13 @@ extern "C" int dl3p_scale_bcast_fwd(const float* x, int ldx, const float* scale,
   if (rc) return rc;
   rc = check_ew("dl3p_scale_bcast_fwd", s, lds, C);
   if (rc) return rc;
+  DL3P_CHECK_ARG(N > 0 && HW > 0, "dl3p_scale_bcast_fwd: bad dims");
   EwParams p = {};
   p.a = x; p.lda = ldx; p.scale = scale; p.shift = shift; p.act = act; p.out = y; p.ldo = ldy;
-  se_lanes(p, C);
-  hipLaunchKernelGGL(scale_bcast_fwd_kernel, dim3(N * p.nslab), dim3(256), 0, (hipStream_t)stream, p, HW, s, lds, s_act);
+  const PoolPlan pl = pool_plan(N, HW, C, true);
+  p.c4s = pl.c4s; p.px = pl.px; p.nslab = pl.nslab; p.C = C;
+  hipLaunchKernelGGL(scale_bcast_fwd_kernel, dim3(N * p.nslab * pl.nchunk), dim3(256), 0, (hipStream_t)stream, p, HW,
+                     s, lds, s_act, pl.nchunk, pl.per);
   DL3P_CHECK_LAUNCH("dl3p_scale_bcast_fwd");
   return DL3P_OK;
 }
@@ -698,7 +807,7 @@ extern "C" int dl3p_scale_bcast_fwd(const float* x, int ldx, const float* scale,
 extern "C" int dl3p_scale_bcast_bwd(const float* gy, int ldgy, const float* x, int ldx, const float* scale,
                                     const float* shift, int act, const float* s, int lds, int s_act, float* gx,
                                     int ldgx, int accumulate_gx, float* gs, int ldgs, int N, int HW, int C,
-                                    void* stream) {
+                                    float* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_ew("dl3p_scale_bcast_bwd", gy, ldgy, C);
   if (rc) return rc;
   rc = check_ew("dl3p_scale_bcast_bwd", x, ldx, C);
@@ -707,12 +816,14 @@ extern "C" int dl3p_scale_bcast_bwd(const float* gy, int ldgy, const float* x, i
   if (rc) return rc;
   rc = check_ew("dl3p_scale_bcast_bwd", gs, ldgs, C);
   if (rc) return rc;
+  DL3P_CHECK_ARG(N > 0 && HW > 0, "dl3p_scale_bcast_bwd: bad dims");
   EwParams p = {};
   p.a = x; p.lda = ldx; p.scale = scale; p.shift = shift; p.act = act; p.out = gx; p.ldo = ldgx;
   p.accumulate = accumulate_gx;
-  se_lanes(p, C);
-  hipLaunchKernelGGL(scale_bcast_bwd_kernel, dim3(N * p.nslab), dim3(256), 0, (hipStream_t)stream, p, HW, s, lds,
-                     s_act, gy, ldgy, gs, ldgs);
+  const PoolPlan pl = pool_plan(N, HW, C, pool_ws_ok(workspace, workspace_bytes, N, HW, C));
+  p.c4s = pl.c4s; p.px = pl.px; p.nslab = pl.nslab; p.C = C;
+  hipLaunchKernelGGL(scale_bcast_bwd_kernel, dim3(N * p.nslab * pl.nchunk), dim3(256), 0, (hipStream_t)stream, p, HW,
+                     s, lds, s_act, gy, ldgy, gs, ldgs, workspace, pl.ticket_floats, pl.nchunk, pl.per);
   DL3P_CHECK_LAUNCH("dl3p_scale_bcast_bwd");
   return DL3P_OK;
 }

@@ -311,6 +311,15 @@ class Executor:
             elif op.kind == 'conv_dense':
                 ws = max(ws, L.pwconv_bwd_weight_workspace(N * op.Ho * op.Wo, op.kp, op.cout))
         self.workspace = torch.zeros(ws // 4 + 4, **self.f32) if self.training else None
+        # tickets + partial rows of the chunked per-image reductions (pooling, SE backward): zero once, every call
+        # leaves its tickets at zero again; one stream runs all of them
+        pws = 0
+        for op in g.ops:
+            if op.kind in ('gap', 'se_mul', 'broadcast'):
+                t = op.x.tensor if op.kind != 'broadcast' else op.out
+                pws = max(pws, L.pool_workspace(N, t.H * t.W, t.C))
+        self.pool_ws = torch.zeros(pws // 4 + 4, **self.f32)
+        self.pool_wsb = pws
         H, W, _ = g.input_shape
         self.H, self.W = H, W
         self.cpad = (self.C + 3) // 4 * 4
@@ -426,7 +435,7 @@ class Executor:
                 xp, ldx, sp, hp, act = self.vargs(op.x)
                 xt = op.x.tensor
                 P.k(L.global_avgpool_fwd, xp, ldx, sp, hp, act, self.tptr(op.out), op.out.ld, 1.0, N, xt.H * xt.W,
-                    xt.C)
+                    xt.C, self.pool_ws.data_ptr(), self.pool_wsb)
             elif k == 'se_mul':
                 xp, ldx, sp, hp, act = self.vargs(op.x)
                 s_ptr, lds, _, _, sact = self.vargs(op.s)
@@ -637,7 +646,7 @@ class Executor:
                 gsp, ldgs, keys = self._gbuf(op.s)
                 assert self._acc(keys) == 0, 'SE scale gradient has a single producer'
                 P.k(L.scale_bcast_bwd, self.tptr(out, True), out.ld, xp, ldx, sp, hp, act, s_ptr, lds, sact, gp, ldg,
-                    self._acc(keyx), gsp, ldgs, N, out.H * out.W, out.C)
+                    self._acc(keyx), gsp, ldgs, N, out.H * out.W, out.C, self.pool_ws.data_ptr(), self.pool_wsb)
             elif k == 'gap':
                 xt = op.x.tensor
                 gp, ldg, keyt = self._gbuf(op.x)
@@ -647,7 +656,7 @@ class Executor:
                 xt = op.x.tensor
                 assert self._acc(xt) == 0
                 P.k(L.global_avgpool_fwd, self.tptr(out, True), out.ld, None, None, ACT_NONE, self.tptr(xt, True),
-                    xt.ld, float(out.H * out.W), N, out.H * out.W, out.C)
+                    xt.ld, float(out.H * out.W), N, out.H * out.W, out.C, self.pool_ws.data_ptr(), self.pool_wsb)
             elif k == 'resize':
                 xt = op.x.tensor
                 P.k(L.resize_bilinear_bwd, self.tptr(out, True), out.ld, self.tptr(xt, True), xt.ld, self._acc(xt),

@@ -321,13 +321,22 @@ def dropout_mask(shape, rate, seed, step_counter, device):
     return m
 
 
-def global_avgpool_fwd(x, in_scale=None, in_shift=None, in_act=ACT_NONE, out_scale=1.0, out=None):
+def _pool_ws(N, HW, C, device, chunked):
+    """zeroed ticket + partial-row workspace of the chunked per-image reductions (None: one workgroup per image)"""
+    if not chunked:
+        return None, 0
+    nbytes = lib().pool_workspace(N, HW, C)
+    return torch.zeros(nbytes // 4, dtype=torch.float32, device=device), nbytes
+
+
+def global_avgpool_fwd(x, in_scale=None, in_shift=None, in_act=ACT_NONE, out_scale=1.0, out=None, chunked=True):
     N, H, W, C = x.shape
     y = out if out is not None else torch.empty((N, 1, 1, C), dtype=torch.float32, device=x.device)
     xp, ldx = _pl(x)
     yp, ldy = _pl(y)
+    ws, wsb = _pool_ws(N, H * W, C, x.device, chunked)
     lib().global_avgpool_fwd(xp, ldx, _p(in_scale), _p(in_shift), in_act, yp, ldy, float(out_scale), N, H * W, C,
-                             _stream())
+                             _p(ws), wsb, _stream())
     return y
 
 
@@ -449,13 +458,14 @@ def scale_bcast_fwd(x, s, scale=None, shift=None, act=ACT_NONE, s_act=ACT_NONE, 
     return y
 
 
-def scale_bcast_bwd(gy, x, s, scale=None, shift=None, act=ACT_NONE, s_act=ACT_NONE):
+def scale_bcast_bwd(gy, x, s, scale=None, shift=None, act=ACT_NONE, s_act=ACT_NONE, chunked=True):
     N, H, W, C = x.shape
     gx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     gs = torch.empty((N, 1, 1, C), dtype=torch.float32, device=x.device)
     gp, ldg = _pl(gy)
     xp, ldx = _pl(x)
     sp, lds = _pl(s)
+    ws, wsb = _pool_ws(N, H * W, C, x.device, chunked)
     lib().scale_bcast_bwd(gp, ldg, xp, ldx, _p(scale), _p(shift), act, sp, lds, s_act, _p(gx), C, 0, _p(gs), C, N, H * W, C,
-                          _stream())
+                          _p(ws), wsb, _stream())
     return gx, gs
