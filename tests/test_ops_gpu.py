@@ -42,6 +42,10 @@ DW_CASES = [
     (2, 33, 33, 128, 3, 2, 1, (1, 1, 1, 1)),  # Xception explicit pad + VALID
     (1, 16, 24, 40, 5, 1, 2, 'same'),
     (1, 16, 24, 72, 5, 2, 1, 'same'),
+    (2, 33, 33, 160, 5, 1, 2, 'same'),      # MobileNetV3 last blocks at OS16: 5x5 on the 17x17 rate-2 sub-lattices
+    (1, 33, 33, 672, 5, 1, 1, 'same'),      # 4-column strips, 3 channel slabs
+    (1, 65, 47, 120, 5, 1, 1, 'same'),      # 2-column strips (wide map)
+    (1, 7, 6, 24, 5, 1, 1, 'same'),         # map smaller than the window
     (3, 9, 9, 16, 3, 1, 1, 'same'),
     (1, 5, 5, 2048, 3, 1, 4, 'same'),
 ]
@@ -171,7 +175,9 @@ def test_pwconv_bwd_data_fused_bn_stats(ops, case):
 
 @pytest.mark.parametrize('case', [(2, 33, 33, 96, 3, 1, 1, 'same', 2), (1, 65, 65, 144, 3, 2, 1, 'same', 2),
                                   (2, 16, 20, 24, 3, 2, 1, 'same', 1), (2, 33, 33, 64, 3, 1, 2, 'same', 2),
-                                  (2, 33, 33, 320, 3, 1, 18, 'same', 2), (1, 16, 24, 40, 5, 1, 1, 'same', 2)])
+                                  (2, 33, 33, 320, 3, 1, 18, 'same', 2), (1, 16, 24, 40, 5, 1, 1, 'same', 2),
+                                  (2, 33, 33, 160, 5, 1, 2, 'same', 2), (1, 65, 47, 120, 5, 1, 1, 'same', 1),
+                                  (1, 33, 33, 672, 5, 1, 1, 'same', 2)])
 def test_dwconv_bwd_data_fused_bn_stats(ops, case):
     """dl3p_dwconv2d_bwd_data_bn == dl3p_dwconv2d_bwd_data followed by dl3p_bn_bwd_reduce (fused window / quad kernels and
     the two-launch fallback of the other decompositions)"""

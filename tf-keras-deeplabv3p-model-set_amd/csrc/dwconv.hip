@@ -24,6 +24,7 @@ struct DwParams {
   float* partials;
   int N, H, W, C, Ho, Wo, stride, rate, pad_t, pad_l;
   int c4s, px, nslab, nbx, spr, th, nbands, ks, ks5;
+  int uh;              // rows the bands share: band b covers rows [b*uh/nbands, (b+1)*uh/nbands)
   long long total;
   int flip, accumulate;
   int nt;              // streaming stores for the output (forward role only)
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void dw_fwd_seg(DwParams p) {
       const int n = t2 / (rate * rate);
       const int py = phase / rate, pxo = phase - py * rate;
       const int u0 = strip * TW;                 // first sub-lattice column of this strip
-      const int v0 = band * th;
+      const int v0 = band * p.uh / nbands, v1 = (band + 1) * p.uh / nbands;
       const int ox0 = pxo + u0 * rate;
       const int ix0 = ox0 * S - p.pad_l;
       const float* ximg = p.x + (size_t)n * p.H * p.W * p.ldx + c;
@@ -150,10 +151,10 @@ __global__ __launch_bounds__(256) void dw_fwd_seg(DwParams p) {
           }
         }
       }
-      for (int v = v0; v < v0 + th; ++v) {
+      for (int v = v0; v < v1; ++v) {
         const int oy = py + v * rate;
         if (oy >= p.Ho) break;
-        const bool more = v + 1 < v0 + th && oy + rate < p.Ho;
+        const bool more = v + 1 < v1 && oy + rate < p.Ho;
         float4 zv[TW];
         if (BNB) {      // z at this row's output pixels: in flight during the FMAs below
           const float* zrow = p.bb_z + (((size_t)n * p.Ho + oy) * p.Wo + ox0) * p.bb_ldz + c;
@@ -176,6 +177,8 @@ __global__ __launch_bounds__(256) void dw_fwd_seg(DwParams p) {
         float4 acc[TW];
 #pragma unroll
         for (int i = 0; i < TW; ++i) acc[i] = zero4();
+        // keep the LDS weight reads inside the row loop: hoisted, the 25 vectors cost 100 VGPRs (1 wave per SIMD)
+        if (WLDS) asm volatile("" ::: "memory");
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
@@ -218,6 +221,290 @@ __global__ __launch_bounds__(256) void dw_fwd_seg(DwParams p) {
   if (p.partials) block_reduce_store<2>(s1, active, pl, cl, p.c4s, p.px, cbase4, p.C, p.partials + (size_t)bx * 2 * p.C);
 }
 
+// compiler fence that also materialises v: arithmetic producing v stays above, memory accesses do not cross
+__device__ __forceinline__ void pin4(float4& v) {
+  asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w) : : "memory");
+}
+
+// ------------------------------------------------------------------------------ 5x5 stride 1, rolling output rows
+// The 5-row input window of the kernel above costs 5 x (TW+4) vectors of registers at 5x5 (300+ VGPRs with the
+// loads in flight: one wave per SIMD, every load latency exposed).  Here the thread keeps the OUTPUT side instead:
+// five rows of TW accumulators.  An input row (TW+4 vectors, loaded once, prologue applied once) feeds the five
+// output rows it overlaps -- input row j meets output row j-ky with weight row ky -- and output row j-4 is complete
+// after input row j, when the accumulator rows shift up by one (register moves, ~10% of the row's FMAs).
+// Same sub-lattice walk for atrous rates, same strips/bands/partials as dw_fwd_seg<5, TW, 1>.
+template <int TW, int PRO>
+__global__ __launch_bounds__(256, 2) void dw5_rows(DwParams p) {
+  constexpr int KS = 5, SEG = TW + KS - 1;
+  const int b = blockIdx.x;
+  const int slab = b / p.nbx;
+  const int bx = b - slab * p.nbx;
+  const int t = threadIdx.x;
+  const int pl = t / p.c4s;
+  const int cl = t - pl * p.c4s;
+  const bool active = pl < p.px;
+  const int cbase4 = slab * p.c4s;
+  const int c = (cbase4 + cl) * 4;
+  float4 s1[2] = {zero4(), zero4()};
+  extern __shared__ __attribute__((aligned(16))) float4 dw_w_lds[];
+  for (int i = t; i < KS * KS * p.c4s; i += 256) {
+    const int tap = i / p.c4s, lane = i - tap * p.c4s;
+    dw_w_lds[i] = ld4(p.w + (size_t)(p.flip ? KS * KS - 1 - tap : tap) * p.C + (cbase4 + lane) * 4);
+  }
+  __syncthreads();
+  if (active) {
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero4();
+    if (p.scale) { sc = ld4(p.scale + c); sh = ld4(p.shift + c); }
+    const int act = p.act;
+    const int th = p.th, nbands = p.nbands, rate = p.rate;
+    const float4* wl = dw_w_lds + cl;
+    const int c4s = p.c4s;
+    XcdRange r = xcd_range(p.total, bx, p.nbx, p.px, pl);
+    for (int s = r.begin; s < r.end; s += r.step) {
+      const int strip = s % p.spr;
+      int t2 = s / p.spr;
+      const int band = t2 % nbands;
+      t2 /= nbands;
+      const int phase = t2 % (rate * rate);
+      const int n = t2 / (rate * rate);
+      const int py = phase / rate, pxo = phase - py * rate;
+      const int v0 = band * p.uh / nbands, v1 = (band + 1) * p.uh / nbands;
+      const int oy0 = py + v0 * rate;                       // first output row of the band
+      if (oy0 >= p.Ho) continue;
+      int nv = (p.Ho - oy0 + rate - 1) / rate;              // output rows of this band
+      if (nv > v1 - v0) nv = v1 - v0;
+      const int ox0 = pxo + strip * TW * rate;
+      const int ix0 = ox0 - p.pad_l;
+      const float* ximg = p.x + (size_t)n * p.H * p.W * p.ldx + c;
+      int coff[SEG];
+      bool cok[SEG];
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) {
+        const int ix = ix0 + i * rate;
+        cok[i] = ix >= 0 && ix < p.W;
+        coff[i] = ix * p.ldx;
+      }
+      const int iy0 = oy0 - p.pad_t;                        // input row j is iy0 + j * rate
+      const int nj = nv + KS - 1;
+      float4 acc[KS][TW];
+#pragma unroll
+      for (int q = 0; q < KS; ++q)
+#pragma unroll
+        for (int tw = 0; tw < TW; ++tw) acc[q][tw] = zero4();
+      // a = the current input row, prologue applied, zero where it lies in the padding
+      float4 a[SEG];
+      {
+        const bool yok = iy0 >= 0 && iy0 < p.H;
+        const float* xrow = ximg + (size_t)iy0 * p.W * p.ldx;
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) {
+          a[i] = zero4();
+          if (yok && cok[i]) a[i] = ld4(xrow + coff[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) {
+          const float4 v = prologue4<PRO>(a[i], sc, sh, act);
+          a[i] = (yok && cok[i]) ? v : zero4();
+        }
+      }
+      for (int j = 0; j < nj; ++j) {
+        // next input row: in flight during this row's FMAs
+        float4 nxt[SEG];
+        const int iyn = iy0 + (j + 1) * rate;
+        const bool nyok = j + 1 < nj && iyn >= 0 && iyn < p.H;
+        {
+          const float* xrow = ximg + (size_t)iyn * p.W * p.ldx;
+#pragma unroll
+          for (int i = 0; i < SEG; ++i) {
+            nxt[i] = zero4();
+            if (nyok && cok[i]) nxt[i] = ld4(xrow + coff[i]);
+          }
+        }
+        const int vdone = j - (KS - 1);                 // output row completed by this input row
+        const int oyd = oy0 + vdone * rate;
+        // the LDS weight reads stay inside the row loop (hoisted they occupy 100 VGPRs and the accumulators spill)
+        asm volatile("" ::: "memory");
+        // acc[d] belongs to output row j - 4 + d: weight row ky meets output row j - ky
+        // one weight row in use and the next one in flight: left alone, the scheduler issues all 25 LDS reads at the
+        // top of the row (100 VGPRs) and the accumulators spill
+        float4 wrow[2][KS];
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) wrow[0][kx] = wl[kx * c4s];
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+          if (ky + 1 < KS) {
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) wrow[(ky + 1) & 1][kx] = wl[((ky + 1) * KS + kx) * c4s];
+          }
+#pragma unroll
+          for (int kx = 0; kx < KS; ++kx) {
+#pragma unroll
+            for (int tw = 0; tw < TW; ++tw)
+              acc[KS - 1 - ky][tw] = fma4(a[tw + kx], wrow[ky & 1][kx], acc[KS - 1 - ky][tw]);
+          }
+          // pin this weight row's FMAs here (instruction selection otherwise sinks all 25 x TW of them below the
+          // last LDS read, with every weight live)
+#pragma unroll
+          for (int tw = 0; tw < TW; ++tw) pin4(acc[KS - 1 - ky][tw]);
+        }
+        if (vdone >= 0) {
+          float* yrow = p.y + (((size_t)n * p.Ho + oyd) * p.Wo + ox0) * p.ldy + c;
+#pragma unroll
+          for (int tw = 0; tw < TW; ++tw) {
+            if (ox0 + tw * rate < p.Wo) {
+              float4 vv = acc[0][tw];
+              float* yp = yrow + (size_t)tw * rate * p.ldy;
+              if (p.accumulate) vv = add4(vv, ld4(yp));
+              if (p.nt) st4_nt(yp, vv); else st4(yp, vv);
+              s1[0] = add4(s1[0], vv);
+              s1[1] = fma4(vv, vv, s1[1]);
+            }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q + 1 < KS; ++q)
+#pragma unroll
+          for (int tw = 0; tw < TW; ++tw) acc[q][tw] = acc[q + 1][tw];
+#pragma unroll
+        for (int tw = 0; tw < TW; ++tw) acc[KS - 1][tw] = zero4();
+        // the next row's loads have had this row's FMAs to land
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) {
+          const float4 v = prologue4<PRO>(nxt[i], sc, sh, act);
+          a[i] = (nyok && cok[i]) ? v : zero4();
+        }
+      }
+    }
+  }
+  if (p.partials) block_reduce_store<2>(s1, active, pl, cl, p.c4s, p.px, cbase4, p.C, p.partials + (size_t)bx * 2 * p.C);
+}
+
+// ------------------------------------------------------------------------------ 5x5 stride 1 weight gradient, rolling rows
+// The same row walk for gw[ky][kx] += a[oy + ky, ox + kx] * dy[oy, ox]: the 25 tap accumulators stay put, the input row
+// (prologue applied once per element, not once per tap as in the per-pixel gather below: with hard-swish that was
+// 25 x 7 VALU operations per output) meets a rolling window of five dy rows.  One partial row [25][C] per workgroup.
+template <int TW, int PRO>
+__global__ __launch_bounds__(256, 2) void dw5_wgrad_rows(DwParams p) {
+  constexpr int KS = 5, SEG = TW + KS - 1;
+  const int b = blockIdx.x;
+  const int slab = b / p.nbx;
+  const int bx = b - slab * p.nbx;
+  const int t = threadIdx.x;
+  const int pl = t / p.c4s;
+  const int cl = t - pl * p.c4s;
+  const bool active = pl < p.px;
+  const int cbase4 = slab * p.c4s;
+  const int c = (cbase4 + cl) * 4;
+  float4 wacc[KS * KS];
+#pragma unroll
+  for (int i = 0; i < KS * KS; ++i) wacc[i] = zero4();
+  if (active) {
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero4();
+    if (p.scale) { sc = ld4(p.scale + c); sh = ld4(p.shift + c); }
+    const int act = p.act;
+    const int nbands = p.nbands, rate = p.rate;
+    XcdRange r = xcd_range(p.total, bx, p.nbx, p.px, pl);
+    for (int s = r.begin; s < r.end; s += r.step) {
+      const int strip = s % p.spr;
+      int t2 = s / p.spr;
+      const int band = t2 % nbands;
+      t2 /= nbands;
+      const int phase = t2 % (rate * rate);
+      const int n = t2 / (rate * rate);
+      const int py = phase / rate, pxo = phase - py * rate;
+      const int v0 = band * p.uh / nbands, v1 = (band + 1) * p.uh / nbands;
+      const int oy0 = py + v0 * rate;
+      if (oy0 >= p.Ho) continue;
+      int nv = (p.Ho - oy0 + rate - 1) / rate;
+      if (nv > v1 - v0) nv = v1 - v0;
+      const int ox0 = pxo + strip * TW * rate;
+      const int ix0 = ox0 - p.pad_l;
+      const float* ximg = p.x + (size_t)n * p.H * p.W * p.ldx + c;
+      const float* dimg = p.dy + ((size_t)n * p.Ho * p.Wo + ox0) * p.lddy + c;
+      int coff[SEG];
+      bool cok[SEG];
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) {
+        const int ix = ix0 + i * rate;
+        cok[i] = ix >= 0 && ix < p.W;
+        coff[i] = ix * p.ldx;
+      }
+      bool dok[TW];
+#pragma unroll
+      for (int tw = 0; tw < TW; ++tw) dok[tw] = ox0 + tw * rate < p.Wo;
+      const int iy0 = oy0 - p.pad_t;
+      const int nj = nv + KS - 1;
+      // a = current input row (activated, zero in the padding); dyw[d] = dy row j - 4 + d of this strip
+      float4 a[SEG];
+      float4 dyw[KS][TW];
+#pragma unroll
+      for (int d = 0; d < KS; ++d)
+#pragma unroll
+        for (int tw = 0; tw < TW; ++tw) dyw[d][tw] = zero4();
+      {
+        const bool yok = iy0 >= 0 && iy0 < p.H;
+        const float* xrow = ximg + (size_t)iy0 * p.W * p.ldx;
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) {
+          a[i] = zero4();
+          if (yok && cok[i]) a[i] = ld4(xrow + coff[i]);
+        }
+        const float* drow = dimg + (size_t)oy0 * p.Wo * p.lddy;
+#pragma unroll
+        for (int tw = 0; tw < TW; ++tw)
+          if (dok[tw]) dyw[KS - 1][tw] = ld4(drow + (size_t)tw * rate * p.lddy);
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) {
+          const float4 v = prologue4<PRO>(a[i], sc, sh, act);
+          a[i] = (yok && cok[i]) ? v : zero4();
+        }
+      }
+      for (int j = 0; j < nj; ++j) {
+        // next input row and next dy row: in flight during this row's FMAs
+        float4 nxt[SEG], dyn[TW];
+        const int iyn = iy0 + (j + 1) * rate;
+        const bool nyok = j + 1 < nj && iyn >= 0 && iyn < p.H;
+        const bool dyok = j + 1 < nv;
+        {
+          const float* xrow = ximg + (size_t)iyn * p.W * p.ldx;
+#pragma unroll
+          for (int i = 0; i < SEG; ++i) {
+            nxt[i] = zero4();
+            if (nyok && cok[i]) nxt[i] = ld4(xrow + coff[i]);
+          }
+          const float* drow = dimg + (size_t)(oy0 + (j + 1) * rate) * p.Wo * p.lddy;
+#pragma unroll
+          for (int tw = 0; tw < TW; ++tw) {
+            dyn[tw] = zero4();
+            if (dyok && dok[tw]) dyn[tw] = ld4(drow + (size_t)tw * rate * p.lddy);
+          }
+        }
+        // input row j meets output row j - ky (= dyw[4 - ky]) under weight row ky
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+            for (int tw = 0; tw < TW; ++tw)
+              wacc[ky * KS + kx] = fma4(a[tw + kx], dyw[KS - 1 - ky][tw], wacc[ky * KS + kx]);
+#pragma unroll
+        for (int d = 0; d + 1 < KS; ++d)
+#pragma unroll
+          for (int tw = 0; tw < TW; ++tw) dyw[d][tw] = dyw[d + 1][tw];
+#pragma unroll
+        for (int tw = 0; tw < TW; ++tw) dyw[KS - 1][tw] = dyn[tw];
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) {
+          const float4 v = prologue4<PRO>(nxt[i], sc, sh, act);
+          a[i] = (nyok && cok[i]) ? v : zero4();
+        }
+      }
+    }
+  }
+  block_reduce_store<KS * KS>(wacc, active, pl, cl, p.c4s, p.px, cbase4, p.C,
+                              p.partials + (size_t)bx * KS * KS * p.C);
+}
+
 // ------------------------------------------------------------------------------ backward weight, sliding window
 // Same window walk as the forward kernel (the activated input rows live in registers); every output
 // row adds win[ky][tw+kx] * dy[tw] into the k*k per-thread tap accumulators.  One partial row
@@ -252,7 +539,7 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_seg(DwParams p) {
       const int n = t2 / (rate * rate);
       const int py = phase / rate, pxo = phase - py * rate;
       const int u0 = strip * TW;                 // first sub-lattice column of this strip
-      const int v0 = band * th;
+      const int v0 = band * p.uh / nbands, v1 = (band + 1) * p.uh / nbands;
       const int ox0 = pxo + u0 * rate;
       const int ix0 = ox0 * S - p.pad_l;
       const float* ximg = p.x + (size_t)n * p.H * p.W * p.ldx + c;
@@ -291,10 +578,10 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_seg(DwParams p) {
           }
         }
       }
-      for (int v = v0; v < v0 + th; ++v) {
+      for (int v = v0; v < v1; ++v) {
         const int oy = py + v * rate;
         if (oy >= p.Ho) break;
-        const bool more = v + 1 < v0 + th && oy + rate < p.Ho;
+        const bool more = v + 1 < v1 && oy + rate < p.Ho;
         // issue the loads of the S rows that enter the window for the next output row
         bool nyok[S];
 #pragma unroll
@@ -745,7 +1032,17 @@ static int pick_band(long long items_per_row_band, int rows, int px, int nslab) 
 //   kind 1: window kernel TW=4, stride 1 (any rate, on the rate x rate sub-lattices)
 //   kind 2: window kernel TW=2, stride 2, rate 1
 //   kind 0: per-pixel gather (stride > 1 with rate > 1, or maps narrower than a strip)
-static int fwd_plan(DwParams& p, int per_cu = 8, bool window5 = false) {
+// strip width of the 5x5 stride-1 rolling-row kernel: 4 columns per thread on the narrow maps (33 wide and the 17-wide
+// sub-lattices of rate 2: 37 vs 55 us at 33x33x672), 2 on the wide ones (65x65x120: 49 vs 58 us, the bands stay taller).
+// DL3P_DW5_ROWS = 2 | 4 forces one, 0 selects the older register-window kernel (1 wave per SIMD, kept for comparison).
+static int dw5_rows_tw(int uw) {
+  static const int v = getenv("DL3P_DW5_ROWS") ? atoi(getenv("DL3P_DW5_ROWS")) : -1;
+  if (v >= 0) return v;
+  return uw <= 40 ? 4 : 2;
+}
+static int dw5_tw(int uw) { return dw5_rows_tw(uw) == 4 ? 4 : 2; }
+
+static int fwd_plan(DwParams& p, int per_cu = 8, bool window5 = false, int tw5 = 0) {
   int kind = 0;
   // 5x5: window kernels with LDS weights in the forward / data-gradient role (strips of 2 at stride 1, 1 at stride 2);
   // the weight gradient keeps the per-pixel gather (25 tap accumulators + a 5-row window do not fit)
@@ -762,13 +1059,28 @@ static int fwd_plan(DwParams& p, int per_cu = 8, bool window5 = false) {
     p.spr = p.Wo; p.th = 1; p.nbands = p.Ho;
     p.total = (long long)p.N * p.Ho * p.Wo;
   } else {
-    const int TW = p.ks5 ? (kind == 1 ? 2 : 1) : (kind == 1 ? 4 : 2);
     const int r = p.rate;
     const int uw = ceil_div(p.Wo, r), uh = ceil_div(p.Ho, r);      // sub-lattice size
+    const int TW = p.ks5 ? (kind == 1 ? (tw5 ? tw5 : dw5_tw(uw)) : 1) : (kind == 1 ? 4 : 2);
     p.spr = ceil_div(uw, TW);
-    p.th = pick_band((long long)p.N * r * r * p.spr, uh, p.px, p.nslab);
-    if (p.th > uh) p.th = uh;
-    p.nbands = ceil_div(uh, p.th);
+    // bands of equal height (+-1 row) instead of full ones and a remainder: 33 rows as 11+11+11, not 16+16+1
+    static const int balance = getenv("DL3P_DW_BALANCE") ? atoi(getenv("DL3P_DW_BALANCE")) : 2;
+    if (balance == 2) {
+      // the fewest bands (tallest, least halo re-reading) that still give every CU its workgroup-iterations
+      static const int want = getenv("DL3P_DW_WANT") ? atoi(getenv("DL3P_DW_WANT")) : DL3P_NUM_CUS * 3 / 2;
+      static const int maxth = getenv("DL3P_DW_MAXTH") ? atoi(getenv("DL3P_DW_MAXTH")) : 16;
+      const long long per_band = (long long)p.N * r * r * p.spr;
+      int nb = ceil_div(uh, maxth);
+      while (nb < uh && (per_band * nb / p.px) * p.nslab < want) ++nb;
+      p.nbands = nb;
+      p.th = ceil_div(uh, nb);
+      p.uh = uh;
+    } else {
+      p.th = pick_band((long long)p.N * r * r * p.spr, uh, p.px, p.nslab);
+      if (p.th > uh) p.th = uh;
+      p.nbands = ceil_div(uh, p.th);
+      p.uh = balance ? uh : p.nbands * p.th;
+    }
     p.total = (long long)p.N * r * r * p.nbands * p.spr;
   }
   static const int lat2_per_cu = getenv("DL3P_LAT2_PER_CU") ? atoi(getenv("DL3P_LAT2_PER_CU")) : DL3P_LAT2_PER_CU;
@@ -782,7 +1094,10 @@ static void launch_fwd_pro(const DwParams& p, int kind, dim3 grid, hipStream_t s
   if (KS == 5) {
     // 5x5: narrower strips (window = 5 rows) and the weights in LDS (25 x c4s float4)
     const size_t lds = (size_t)25 * p.c4s * sizeof(float4);
-    if (kind == 1) dl3p_launch(dw_fwd_seg<5, 2, 1, PRO>, grid, block, lds, st, p);
+    const int rows_tw = dw5_rows_tw(ceil_div(p.Wo, p.rate));
+    if (kind == 1 && rows_tw == 4) dl3p_launch(dw5_rows<4, PRO>, grid, block, lds, st, p);
+    else if (kind == 1 && rows_tw == 2) dl3p_launch(dw5_rows<2, PRO>, grid, block, lds, st, p);
+    else if (kind == 1) dl3p_launch(dw_fwd_seg<5, 2, 1, PRO>, grid, block, lds, st, p);
     else if (kind == 2) dl3p_launch(dw_fwd_seg<5, 1, 2, PRO>, grid, block, lds, st, p);
     else dl3p_launch(dw_fwd_gather<5, PRO>, grid, block, 0, st, p);
     return;
@@ -893,7 +1208,9 @@ extern "C" int dl3p_dwconv2d_bwd_data(const float* dy, int lddy, const float* w,
 
 // bwd-data of a layer whose input is act(BN(z)) + the BN-backward partial sums of that BN.  The stride-1 window
 // kernel and the stride-2 quad kernel fold the sums into their store loop (one extra read of z at the output pixel);
-// other decompositions (gather, residue-class kernel, 5x5) run the plain data gradient followed by the reduce pass.
+// other decompositions (gather, residue-class kernel, 5x5) run the plain data gradient followed by the reduce pass: the
+// 5x5 rolling-row kernel is VALU-bound and the sums cost it more (65x65x120: +18 us, 4-column strips spill) than the
+// streaming reduce pass does (12 us).
 extern "C" int dl3p_bn_bwd_reduce(const float* g, int ldg, const float* z, int ldz, const float* scale, const float* shift,
                                   int act, const float* save_mean, const float* save_invstd, float* partials,
                                   int* rows_out, int M, int C, void* stream);
@@ -919,9 +1236,8 @@ extern "C" int dl3p_dwconv2d_bwd_data_bn(const float* dy, int lddy, const float*
     p.x = dy; p.ldx = lddy; p.y = gx; p.ldy = ldgx; p.flip = 1;
     p.H = Ho; p.W = Wo; p.Ho = H; p.Wo = W; p.stride = 1; p.rate = rate;
     p.pad_t = rate * (k - 1) - pad_t; p.pad_l = rate * (k - 1) - pad_l;
-    p.act = DL3P_ACT_NONE; p.ks = 3; p.ks5 = 0;
-    static const int dwf_per_cu = getenv("DL3P_DWF_PER_CU") ? atoi(getenv("DL3P_DWF_PER_CU")) : 8;
-    const int kind = fwd_plan(p, dwf_per_cu);
+    p.act = DL3P_ACT_NONE;
+    const int kind = plan_forward(p, k);
     if (kind == 1) {
       dl3p_launch(dw_fwd_seg<3, 4, 1, 0, true>, dim3(p.nbx * p.nslab), dim3(256), 0, st, p);
       fused = true;
@@ -988,10 +1304,24 @@ extern "C" int dl3p_dwconv2d_bwd_weight(const float* x, int ldx, const float* in
   pick_lanes(C, &p.c4s, &p.px, &p.nslab);
   p.ks5 = k == 5;
   static const int dww_per_cu = getenv("DL3P_DWW_PER_CU") ? atoi(getenv("DL3P_DWW_PER_CU")) : 2;   // fewer slabs: the slab reduce costs as much as the kernel at 8
-  const int kind = fwd_plan(p, dww_per_cu);
+  // 5x5 stride 1: rolling-row kernel with strips of DL3P_DW5_WROWS (1 | 2) columns, 0 = per-pixel gather
+  static const int wrows = getenv("DL3P_DW5_WROWS") ? atoi(getenv("DL3P_DW5_WROWS")) : 2;
+  const bool rows5 = k == 5 && stride == 1 && wrows > 0;
+  const int kind = fwd_plan(p, dww_per_cu, rows5, wrows);
   dim3 grid(p.nbx * p.nslab);
   const int pro = (in_act != DL3P_ACT_NONE) ? 2 : (in_scale ? 1 : 0);
-  if (k == 3) {
+  if (rows5 && kind == 1) {
+    dim3 block(256);
+    if (wrows == 1) {
+      if (pro == 2) hipLaunchKernelGGL((dw5_wgrad_rows<1, 2>), grid, block, 0, st, p);
+      else if (pro == 1) hipLaunchKernelGGL((dw5_wgrad_rows<1, 1>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((dw5_wgrad_rows<1, 0>), grid, block, 0, st, p);
+    } else {
+      if (pro == 2) hipLaunchKernelGGL((dw5_wgrad_rows<2, 2>), grid, block, 0, st, p);
+      else if (pro == 1) hipLaunchKernelGGL((dw5_wgrad_rows<2, 1>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((dw5_wgrad_rows<2, 0>), grid, block, 0, st, p);
+    }
+  } else if (k == 3) {
     if (pro == 2) launch_bwdw<3, 2>(p, kind, grid, st); else if (pro == 1) launch_bwdw<3, 1>(p, kind, grid, st); else launch_bwdw<3, 0>(p, kind, grid, st);
   } else {
     if (pro == 2) launch_bwdw<5, 2>(p, kind, grid, st); else if (pro == 1) launch_bwdw<5, 1>(p, kind, grid, st); else launch_bwdw<5, 0>(p, kind, grid, st);
