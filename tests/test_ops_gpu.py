@@ -145,6 +145,40 @@ def test_pwconv_fwd_transposed_kernel(ops):
             assert torch.equal(p1[:r1 * 2 * Nn], p2[:r2 * 2 * Nn])
 
 
+@pytest.mark.parametrize('case', [(16, 960, 240), (16, 240, 960), (17, 72, 24), (1, 24, 72), (40, 160, 256), (64, 672, 168),
+                                  (3, 8, 4)])
+def test_pwconv_few_rows(ops, case):
+    """M <= 64 (convs behind a global pooling: ASPP image pooling, MobileNetV3 squeeze-excite): the row-parallel
+    kernels of pw_tiny.hip in all three roles, with prologue, bias, statistics and accumulation"""
+    M, K, Nn = case
+    rng = np.random.default_rng(M + K + Nn)
+    x = rng.standard_normal((M, K)); w = rng.standard_normal((K, Nn)) / np.sqrt(K); b = rng.standard_normal(Nn)
+    sc = rng.uniform(0.5, 1.5, K); sh = rng.standard_normal(K) * 0.3
+    a = O.act_fwd(x * sc + sh, O.ACT_HSWISH)
+    wt = T(np.ascontiguousarray(w.T))
+    part = ops.new_partials(Nn, DEV)
+    y, rows = ops.pwconv_fwd_wt(T(x), wt, T(b), T(sc), T(sh), ops.ACT_HSWISH, partials=part)
+    y_ref = a @ w + b
+    close(y, y_ref, what='few-row fwd')
+    assert rows == 1
+    s1, s2 = stats_from(part, rows, Nn)
+    close(s1, y_ref.sum(0), rtol=1e-4, atol=1e-4 * M, what='few-row stat sum')
+    close(s2, (y_ref ** 2).sum(0), rtol=1e-4, what='few-row stat sumsq')
+    close(ops.pwconv_fwd_wt(T(x), wt), x @ w, what='few-row fwd, bare')
+    gy = rng.standard_normal((M, Nn)); base = rng.standard_normal((M, K))
+    close(ops.pwconv_bwd_data(T(gy), T(w)), gy @ w.T, what='few-row bwd data')
+    close(ops.pwconv_bwd_data(T(gy), T(w), out=T(base), accumulate=True), gy @ w.T + base, what='few-row bwd data accumulate')
+    gw, gb = ops.pwconv_bwd_weight(T(x), T(gy), T(sc), T(sh), ops.ACT_HSWISH, with_bias=True)
+    close(gw, a.T @ gy, rtol=3e-4, what='few-row bwd weight')
+    close(gb, gy.sum(0), rtol=3e-4, what='few-row bwd bias')
+    # strided rows (a channel slice of a wider buffer) on both sides
+    wide_in = torch.zeros((M, K + 8), device=DEV); wide_in[:, 4:4 + K] = T(x)
+    wide_out = torch.zeros((M, Nn + 12), device=DEV)
+    ops.pwconv_fwd_wt(wide_in[:, 4:4 + K], wt, out=wide_out[:, 8:8 + Nn])
+    close(wide_out[:, 8:8 + Nn], x @ w, what='few-row fwd, strided views')
+    assert float(wide_out[:, :8].abs().max()) == 0 and float(wide_out[:, 8 + Nn:].abs().max()) == 0
+
+
 @pytest.mark.parametrize('case', [(2 * 33 * 33, 96, 576, 2), (1000, 24, 144, 1), (3001, 256, 256, 2), (777, 160, 960, 0)])
 def test_pwconv_bwd_data_fused_bn_stats(ops, case):
     """dl3p_pwconv_bwd_data_bn == dl3p_pwconv_bwd_data followed by dl3p_bn_bwd_reduce on its result"""

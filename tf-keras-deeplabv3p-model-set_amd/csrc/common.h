@@ -157,6 +157,14 @@ __device__ __forceinline__ void block_reduce_store(const float4 (&vals)[NV], boo
   }
 }
 
+// pw_tiny.hip: pointwise convolutions on M <= 64 rows (behind a global pooling)
+bool dl3p_pw_tiny_applies(int M);
+void dl3p_pw_tiny_nt(const float* a, int lda, const float* scale, const float* shift, int act, const float* bt, int ldb,
+                     const float* bias, float* y, int ldy, int accumulate, float* partials, int M, int K, int N,
+                     hipStream_t st);
+void dl3p_pw_tiny_wgrad(const float* x, int ldx, const float* scale, const float* shift, int act, const float* dy,
+                        int lddy, float* gw, float* gb, int M, int K, int N, hipStream_t st);
+
 int dl3p_reduce_rows_impl(const float* partials, int rows, size_t n, float* out, int accumulate, hipStream_t st);
 int dl3p_reduce_rows_strided_impl(const float* partials, int rows, size_t row_stride, size_t n, float* out,
                                   int accumulate, hipStream_t st);

@@ -705,6 +705,12 @@ static int pwconv_fwd_impl(const char* fn, const float* x, int ldx, const float*
   p.B = w; p.ldb = w_kn ? N : K; p.bias = bias; p.Y = y; p.ldy = ldy; p.partials = stat_partials;
   p.M = M; p.K = K; p.N = N;
   hipStream_t st = (hipStream_t)stream;
+  if (!w_kn && dl3p_pw_tiny_applies(M)) {
+    if (rows_out) *rows_out = 1;
+    dl3p_pw_tiny_nt(x, ldx, in_scale, in_shift, in_act, w, K, bias, y, ldy, 0, stat_partials, M, K, N, st);
+    DL3P_CHECK_LAUNCH(fn);
+    return DL3P_OK;
+  }
   SmallShape sh;
   if (M >= pw_small_min_rows() && pw_small_pick(K, N, &sh)) {
     p.b_kn = w_kn ? 1 : 0;
@@ -791,6 +797,12 @@ extern "C" int dl3p_pwconv_bwd_data(const float* dy, int lddy, const float* w, f
   p.B = w; p.ldb = N;           // W[K][N]: output column k, reduction n contiguous
   p.Y = gx; p.ldy = ldgx; p.accumulate = accumulate;
   p.M = M; p.K = N; p.N = K;    // reduce over N, produce K columns
+  if (dl3p_pw_tiny_applies(M)) {
+    dl3p_pw_tiny_nt(dy, lddy, nullptr, nullptr, DL3P_ACT_NONE, w, N, nullptr, gx, ldgx, accumulate, nullptr, M, N, K,
+                    (hipStream_t)stream);
+    DL3P_CHECK_LAUNCH("dl3p_pwconv_bwd_data");
+    return DL3P_OK;
+  }
   SmallShape sh;
   if (M >= pw_small_min_rows() && pw_small_pick(N, K, &sh)) {
     p.b_kn = 0;
@@ -1248,6 +1260,12 @@ extern "C" int dl3p_pwconv_bwd_weight(const float* x, int ldx, const float* in_s
     return DL3P_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (dl3p_pw_tiny_applies(M)) {
+    DL3P_CHECK_ARG(aligned16(gw) && (!gb || aligned16(gb)), "dl3p_pwconv_bwd_weight: gw/gb must be 16-byte aligned");
+    dl3p_pw_tiny_wgrad(x, ldx, in_scale, in_shift, in_act, dy, lddy, gw, gb, M, K, N, st);
+    DL3P_CHECK_LAUNCH("dl3p_pwconv_bwd_weight");
+    return DL3P_OK;
+  }
   WgradParams p = {};
   p.X = x; p.ldx = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act;
   p.DY = dy; p.lddy = lddy; p.slabs = workspace; p.M = M; p.K = K; p.N = N;
