@@ -631,17 +631,21 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(EwParams p, int HW, float 
     const float4 sc = opt_ld4(p.scale, c, one), sh = opt_ld4(p.shift, c, zero4());
     const float* base = p.a + (size_t)n * HW * p.lda + c;
     const int i1 = min(HW, (chunk + 1) * per);
-    // 4 independent accumulators: 4 row loads in flight per thread
-    float4 a1 = zero4(), a2 = zero4(), a3 = zero4();
+    // 8 independent accumulators: 8 row loads in flight per thread
+    float4 ax[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) ax[q] = zero4();
     int i = chunk * per + pl;
-    for (; i + 3 * p.px < i1; i += 4 * p.px) {
-      acc[0] = add4(acc[0], act_apply4(fma4(ld4(base + (size_t)i * p.lda), sc, sh), p.act));
-      a1 = add4(a1, act_apply4(fma4(ld4(base + (size_t)(i + p.px) * p.lda), sc, sh), p.act));
-      a2 = add4(a2, act_apply4(fma4(ld4(base + (size_t)(i + 2 * p.px) * p.lda), sc, sh), p.act));
-      a3 = add4(a3, act_apply4(fma4(ld4(base + (size_t)(i + 3 * p.px) * p.lda), sc, sh), p.act));
+    for (; i + 7 * p.px < i1; i += 8 * p.px) {
+      float4 v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = ld4(base + (size_t)(i + q * p.px) * p.lda);
+      acc[0] = add4(acc[0], act_apply4(fma4(v[0], sc, sh), p.act));
+#pragma unroll
+      for (int q = 1; q < 8; ++q) ax[q - 1] = add4(ax[q - 1], act_apply4(fma4(v[q], sc, sh), p.act));
     }
     for (; i < i1; i += p.px) acc[0] = add4(acc[0], act_apply4(fma4(ld4(base + (size_t)i * p.lda), sc, sh), p.act));
-    acc[0] = add4(add4(acc[0], a1), add4(a2, a3));
+    acc[0] = add4(add4(add4(acc[0], ax[0]), add4(ax[1], ax[2])), add4(add4(ax[3], ax[4]), add4(ax[5], ax[6])));
     if (nchunk == 1) acc[0] = make_float4(acc[0].x * inv, acc[0].y * inv, acc[0].z * inv, acc[0].w * inv);
   }
   if (nchunk == 1) {

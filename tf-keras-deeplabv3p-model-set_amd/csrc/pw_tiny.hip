@@ -23,16 +23,18 @@ struct TinyParams {
 };
 
 constexpr int TM = 16;              // rows per pass
-constexpr int TN = 4;               // output columns per wave
+constexpr int TN = 4;               // output columns per workgroup
 
-// A wave owns TN output columns: lanes stride K in float4 steps, every lane keeps TM x TN partial dot products, and a
-// transpose through LDS hands lane t the 64 partials of output (m = t / TN, column t % TN).
+// A workgroup owns TN output columns: its 256 threads stride K in float4 steps, every thread keeps TM x TN partial dot
+// products, and a transpose through LDS hands thread (wave w, lane t) the partials of threads 64w..64w+63 for output
+// (m = t / TN, column t % TN); wave 0 adds the four wave sums.  Many small workgroups: the weight matrix is the only
+// operand of any size (960 x 240 floats) and every workgroup streams its own 4 rows of it.
 template <bool STATS>
 __global__ __launch_bounds__(256) void pw_tiny_nt_kernel(TinyParams p) {
-  __shared__ float red[4][64][TM * TN + 1];
+  __shared__ float red[256][TM * TN + 1];
+  __shared__ float wsum[4][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int n0 = (blockIdx.x * 4 + wave) * TN;
-  const bool wave_on = n0 < p.N;            // N % 4 == 0: the wave's columns are all in range or all out
+  const int n0 = blockIdx.x * TN;
   float s_sum = 0.f, s_sq = 0.f;
   for (int m0 = 0; m0 < p.M; m0 += TM) {
     float acc[TM][TN];
@@ -40,53 +42,56 @@ __global__ __launch_bounds__(256) void pw_tiny_nt_kernel(TinyParams p) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = 0.f;
-    if (wave_on) {
-      for (int k = lane * 4; k < p.K; k += 256) {
-        float4 b[TN];
+    for (int k = threadIdx.x * 4; k < p.K; k += 1024) {
+      float4 b[TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = ld4(p.B + (size_t)(n0 + j) * p.ldb + k);
-        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero4();
-        if (p.scale) { sc = ld4(p.scale + k); sh = ld4(p.shift + k); }
+      for (int j = 0; j < TN; ++j) b[j] = ld4(p.B + (size_t)(n0 + j) * p.ldb + k);
+      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero4();
+      if (p.scale) { sc = ld4(p.scale + k); sh = ld4(p.shift + k); }
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int m = min(m0 + i, p.M - 1);             // rows past M repeat the last one and are dropped below
-          const float4 a = act_apply4(fma4(ld4(p.A + (size_t)m * p.lda + k), sc, sh), p.act);
+      for (int i = 0; i < TM; ++i) {
+        const int m = min(m0 + i, p.M - 1);             // rows past M repeat the last one and are dropped below
+        const float4 a = act_apply4(fma4(ld4(p.A + (size_t)m * p.lda + k), sc, sh), p.act);
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] += a.x * b[j].x + a.y * b[j].y + a.z * b[j].z + a.w * b[j].w;
-        }
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] += a.x * b[j].x + a.y * b[j].y + a.z * b[j].z + a.w * b[j].w;
       }
     }
-    __syncthreads();                                      // previous pass has read red
+    __syncthreads();                                      // the previous pass has read red / wsum
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) red[wave][lane][i * TN + j] = acc[i][j];
+      for (int j = 0; j < TN; ++j) red[threadIdx.x][i * TN + j] = acc[i][j];
     __syncthreads();
     float v = 0.f;
-    for (int l = 0; l < 64; ++l) v += red[wave][l][lane];
-    const int m = m0 + lane / TN, n = n0 + lane % TN;
-    const bool ok = wave_on && m < p.M;
-    if (ok) {
-      if (p.bias) v += p.bias[n];
-      float* y = p.Y + (size_t)m * p.ldy + n;
-      if (p.accumulate) v += *y;
-      *y = v;
-    }
-    if (STATS) {
-      const float u = ok ? v : 0.f;
-      s_sum += u;
-      s_sq += u * u;
+    for (int l = 0; l < 64; ++l) v += red[wave * 64 + l][lane];
+    wsum[wave][lane] = v;
+    __syncthreads();
+    if (wave == 0) {
+      v = (wsum[0][lane] + wsum[1][lane]) + (wsum[2][lane] + wsum[3][lane]);
+      const int m = m0 + lane / TN, n = n0 + lane % TN;
+      const bool ok = m < p.M;
+      if (ok) {
+        if (p.bias) v += p.bias[n];
+        float* y = p.Y + (size_t)m * p.ldy + n;
+        if (p.accumulate) v += *y;
+        *y = v;
+      }
+      if (STATS) {
+        const float u = ok ? v : 0.f;
+        s_sum += u;
+        s_sq += u * u;
+      }
     }
   }
-  if (STATS) {
+  if (STATS && wave == 0) {
     // lanes with the same column differ in bits 2..5
 #pragma unroll
     for (int d = TN; d < 64; d <<= 1) {
       s_sum += __shfl_xor(s_sum, d);
       s_sq += __shfl_xor(s_sq, d);
     }
-    if (wave_on && lane < TN) {
+    if (lane < TN) {
       p.partials[n0 + lane] = s_sum;
       p.partials[p.N + n0 + lane] = s_sq;
     }
@@ -135,7 +140,7 @@ void dl3p_pw_tiny_nt(const float* a, int lda, const float* scale, const float* s
   TinyParams p = {};
   p.A = a; p.lda = lda; p.scale = scale; p.shift = shift; p.act = act; p.B = bt; p.ldb = ldb; p.bias = bias;
   p.Y = y; p.ldy = ldy; p.partials = partials; p.accumulate = accumulate; p.M = M; p.K = K; p.N = N;
-  const dim3 grid((N / TN + 3) / 4), block(256);
+  const dim3 grid(N / TN), block(256);
   if (partials) dl3p_launch(pw_tiny_nt_kernel<true>, grid, block, 0, st, p);
   else dl3p_launch(pw_tiny_nt_kernel<false>, grid, block, 0, st, p);
 }
