@@ -32,7 +32,8 @@ def parse():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=16, help='per-GPU batch')
-    ap.add_argument('--size', type=int, default=513)
+    ap.add_argument('--size', type=int, default=513, help='input height (and width unless --width is given)')
+    ap.add_argument('--width', type=int, default=0, help='input width for non-square inputs (1024x2048 Cityscapes)')
     ap.add_argument('--model', default='mobilenetv2')
     ap.add_argument('--classes', type=int, default=21)
     ap.add_argument('--os', type=int, default=16, help='output stride')
@@ -101,7 +102,7 @@ def main():
         os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     pkg = importlib.import_module(PKG)
-    H = W = args.size
+    H, W = args.size, (args.width or args.size)
     N, C = args.batch, args.classes
 
     model = pkg.get_deeplabv3p_model(args.model, C, (H, W), args.os, freeze_level=0, training=True)
@@ -155,9 +156,9 @@ def main():
             'value': round(N * world * args.steps / dt, 2), 'unit': 'images/sec', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000 * dt / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': '%s + ASPP(6/12/18) + decoder, OS=16, %dx%d, %d classes, per-GPU batch %d, '
+            'config': {'workload': '%s + ASPP(%s) + decoder, OS=%d, %dx%d, %d classes, per-GPU batch %d, '
                                    'fwd+loss+bwd+SGD(momentum 0.9, l2 2e-5), BN training mode, dropout 0.5'
-                                   % (args.model, H, W, C, N),
+                                   % (args.model, {8: '12/24/36', 16: '6/12/18', 32: '3/6/9'}[args.os], args.os, H, W, C, N),
                        'global_batch': N * world,
                        'parallelism': 'dp%d%s' % (world, '+syncbn' if (world > 1 and not args.no_sync_bn) else ''),
                        'hip_graph': bool(model.use_graphs), 'final_loss': round(loss, 5),
