@@ -667,7 +667,12 @@ extern "C" int dl3p_global_avgpool_fwd(const float* x, int ldx, const float* in_
   DL3P_CHECK_ARG(N > 0 && HW > 0, "dl3p_global_avgpool_fwd: bad dims");
   EwParams p = {};
   p.a = x; p.lda = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act; p.out = y; p.ldo = ldy;
-  const PoolPlan pl = pool_plan(N, HW, C, pool_ws_ok(workspace, workspace_bytes, N, HW, C));
+  // the ticketed finish costs ~5 us of serial latency at the kernel's tail (write-through store, ticket, re-read):
+  // chunk only when (image, slab) workgroups alone leave most of the chip idle (33x33x960: 240 workgroups, 18 us whole
+  // vs 21 us chunked; 33x33x320: 80 workgroups, 12 vs 15 us; 65x65x120: 32 workgroups, 27-52 us whole vs 23 us chunked)
+  bool chunked = pool_ws_ok(workspace, workspace_bytes, N, HW, C);
+  if (chunked && N * pool_plan(N, HW, C, false).nslab >= DL3P_NUM_CUS / 4) chunked = false;
+  const PoolPlan pl = pool_plan(N, HW, C, chunked);
   p.c4s = pl.c4s; p.px = pl.px; p.nslab = pl.nslab; p.C = C;
   hipLaunchKernelGGL(gap_fwd_kernel, dim3(N * p.nslab * pl.nchunk), dim3(256), 0, (hipStream_t)stream, p, HW,
                      out_scale, workspace, pl.ticket_floats, pl.nchunk, pl.per);
