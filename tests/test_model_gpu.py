@@ -290,3 +290,11 @@ def test_train_py_flow(tmp_path):
     mi.compile(optimizer=None, loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
     ev = mi.evaluate(Gen(1), 1)
     assert np.isfinite(ev) and ev > 0
+    # train.py:247 writes 'trained_final.h5': the Keras HDF5 container through the same calls (needs libhdf5)
+    try:
+        load_pkg('h5io').lib()
+    except ImportError:
+        return
+    m.save(path + '.h5')
+    mh = pkg.get_deeplabv3p_model('mobilenetv2', C, (H, W), 16, weights_path=path + '.h5', training=False)
+    assert np.array_equal(mh.predict(x), p)

@@ -354,16 +354,79 @@ class DeeplabModel:
         if self._store is not None:
             self._store.upload()
 
+    def _keras_layers(self):
+        """[(layer name, [(Keras weight name, array), ...]), ...] in topological order, weightless layers included"""
+        self._sync_to_host()
+        return [(l.name, [(p.name + ':0', p.value) for p in l.params]) for l in self.graph.layers]
+
     def save(self, path):
-        """whole-model checkpoint (train.py:247).  Format: .npz keyed by Keras weight name (the reference's
-        HDF5 container is a 'next' row)"""
+        """whole-model checkpoint (train.py:247, deeplab.py:113).  `*.h5`: the Keras HDF5 layout (weights under
+        `model_weights`, see h5io.py; `model_config` records the factory arguments -- it is not a Keras-deserialisable
+        layer config, `keras.Model.load_weights` reads the file, `load_model` does not).  Anything else: `.npz` keyed
+        by Keras weight name."""
+        if path.endswith('.h5') or path.endswith('.hdf5'):
+            import json
+            from . import h5io
+            cfg = json.dumps({'class_name': 'DeeplabV3p', 'config': {
+                'name': self.name, 'factory': {'model_type': self.model_type, 'num_classes': self.num_classes,
+                                               'model_input_shape': list(self.input_shape_hw),
+                                               'output_stride': getattr(self.graph, 'output_stride', None),
+                                               'training': bool(self.flatten_output)}}})
+            h5io.write_keras_h5(path, self._keras_layers(), whole_model=True, model_config=cfg)
+            return
         np.savez(path if path.endswith('.npz') else path + '.npz', **self.get_weights_by_name())
 
-    save_weights = save
+    def save_weights(self, path):
+        """`model.save_weights`: the same tree at the file root"""
+        if path.endswith('.h5') or path.endswith('.hdf5'):
+            from . import h5io
+            h5io.write_keras_h5(path, self._keras_layers(), whole_model=False)
+            return
+        self.save(path)
+
+    def _load_keras_h5(self, path, by_name, skip_mismatch):
+        """Keras `load_weights_from_hdf5_group` (topological: the i-th layer WITH weights of the file feeds the i-th
+        layer with weights of the model, names ignored) / `..._by_name` (layers matched by name, weights by position)"""
+        from . import h5io
+        file_layers, _ = h5io.read_keras_h5(path)
+        mine = [l for l in self.graph.layers if l.params]
+
+        def assign(layer, ws, lname):
+            if len(ws) != len(layer.params):
+                if skip_mismatch:
+                    return
+                raise ValueError('Layer %r expects %d weight(s), but the saved layer %r holds %d'
+                                 % (layer.name, len(layer.params), lname, len(ws)))
+            for p, (wn, w) in zip(layer.params, ws):
+                if tuple(w.shape) != p.shape:
+                    if skip_mismatch:
+                        continue
+                    raise ValueError('Shape mismatch for %s: model %s, file %s %s' % (p.name, p.shape, wn, w.shape))
+                p.value = np.ascontiguousarray(w, dtype=np.float32)
+
+        if by_name:
+            index = {n: ws for n, ws in file_layers if ws}
+            for l in mine:
+                if l.name in index:
+                    assign(l, index[l.name], l.name)
+        else:
+            theirs = [(n, ws) for n, ws in file_layers if ws]
+            if len(theirs) != len(mine):
+                raise ValueError('You are trying to load a weight file containing %d layers into a model with %d layers.'
+                                 % (len(theirs), len(mine)))
+            for l, (n, ws) in zip(mine, theirs):
+                assign(l, ws, n)
+        if self._store is not None:
+            self._store.upload()
 
     def load_weights(self, path, by_name=False, skip_mismatch=False):
+        """model.py:102-104 `model.load_weights(weights_path, by_name=False)`; Keras `.h5` files or `.npz`"""
         if not os.path.exists(path) and os.path.exists(path + '.npz'):
             path = path + '.npz'
+        with open(path, 'rb') as fh:
+            magic = fh.read(8)
+        if magic == b'\x89HDF\r\n\x1a\n':
+            return self._load_keras_h5(path, by_name, skip_mismatch)
         data = np.load(path)
         if by_name:
             self.set_weights_by_name({k: data[k] for k in data.files}, strict=False)
