@@ -245,6 +245,12 @@ int dl3p_upsample_softmax_ce(const float* z, int ldz, const float* labels, int i
                              float* logits_big, float* probs, float* dlogits_big, int ld_big,
                              float* loss_partials, int* rows_out,
                              int N, int h, int w, int C, int H, int W, void* stream);
+/* Evaluation head (eval.py:33-36 argmax of the prediction, :368-373 generate_matrix): pred_mask[N*H*W] (int32) =
+ * argmax over the C classes of the upsampled logits (first index on ties, like np.argmax); for pixels with
+ * 0 <= label < C, confusion[label*C + pred] += 1 (uint64 [C][C], zeroed by the caller, accumulates across calls;
+ * integer atomics, order-independent).  pred_mask, or labels + confusion, may be NULL. */
+int dl3p_argmax_confusion(const float* z, int ldz, const float* labels, int32_t* pred_mask,
+                          unsigned long long* confusion, int N, int h, int w, int C, int H, int W, void* stream);
 /* Training head in one launch: the same forward + loss as dl3p_upsample_softmax_ce AND the transposed
  * pred_resize of the gradient (what dl3p_resize_bilinear_bwd(dlogits_big) returns), gz [N,h,w,C] (ldgz),
  * without ever writing the (N,H,W,C) gradient.  Available for upsampling factors up to ~4.2

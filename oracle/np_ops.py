@@ -355,3 +355,35 @@ def sgd_momentum_step(w, v, g, lr, momentum, l2=0.0):
 def glorot_uniform(rng, shape, fan_in, fan_out, dtype=np.float64):
     limit = math.sqrt(6.0 / (fan_in + fan_out))
     return rng.uniform(-limit, limit, size=shape).astype(dtype)
+
+
+# ---------------------------------------------------------------------------------------- evaluation (eval.py)
+def confusion_matrix(gt_mask, pred_mask, num_classes):
+    """eval.py:368-373 generate_matrix: rows = ground truth, columns = prediction, labels outside [0, C) dropped"""
+    gt = np.asarray(gt_mask).astype(np.int64).ravel()
+    pr = np.asarray(pred_mask).astype(np.int64).ravel()
+    valid = (gt >= 0) & (gt < num_classes)
+    label = num_classes * gt[valid] + pr[valid]
+    return np.bincount(label, minlength=num_classes ** 2).reshape(num_classes, num_classes)
+
+
+def miou_summary(cm):
+    """eval.py:462-497: pixel accuracy, per-class accuracy / IoU / Dice / frequency, mean IoU (NaN -> 0 before the
+    mean, as the reference does), frequency-weighted IoU"""
+    cm = np.asarray(cm, dtype=np.float64)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        pixel_acc = np.diag(cm).sum() / cm.sum()
+        class_acc = np.diag(cm) / cm.sum(axis=1)
+        class_acc[np.isnan(class_acc)] = 0
+        inter = np.diag(cm)
+        union = cm.sum(axis=0) + cm.sum(axis=1) - inter
+        iou = inter / union
+        iou[np.isnan(iou)] = 0
+        freq = cm.sum(axis=1) / cm.sum()
+        freq[np.isnan(freq)] = 0
+        dice = 2 * inter / (union + inter)
+        dice[np.isnan(dice)] = 0
+    return {'PixelAcc': float(pixel_acc), 'ClassAcc': class_acc, 'mClassAcc': float(np.nanmean(class_acc)), 'IoU': iou,
+            'mIoU': float(np.nanmean(iou)), 'Freq': freq, 'FWIoU': float((freq[freq > 0] * iou[freq > 0]).sum()),
+            'Dice': dice}
+

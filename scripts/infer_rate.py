@@ -29,3 +29,25 @@ def rate(tag, reps=30):
 rate('eager ')
 ex.capture()
 rate('graph ')
+
+# evaluation step: forward without the probability tensor + device-side argmax / confusion matrix
+C = 21
+y = torch.randint(0, C, (N, H * W, 1), device='cuda').float()
+ex.set_inputs(x, y)
+cm = torch.zeros(C * C, dtype=torch.int64, device='cuda')
+for _ in range(3):
+    ex.eval_step(cm)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(30):
+    ex.eval_step(cm)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 30
+print('%s eval_step batch %d: %.2f ms (forward + argmax + confusion matrix on the device), %.0f images/s' % (name, N, dt * 1e3, N / dt))
+t0 = time.perf_counter()
+for _ in range(5):
+    p = model.predict(x.cpu().numpy())
+    p.argmax(-1)
+dt = (time.perf_counter() - t0) / 5
+print('%s predict() + host argmax batch %d: %.1f ms, %.0f images/s' % (name, N, dt * 1e3, N / dt))
+

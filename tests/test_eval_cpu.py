@@ -1,0 +1,38 @@
+"""Evaluation row: the oracle's restatement of eval.py's confusion matrix / mIOU
+arithmetic against a brute-force count, and the product's host-side summary against the oracle."""
+import numpy as np
+
+from conftest import load_pkg
+from oracle import np_ops as O
+
+
+def test_confusion_matrix_is_a_pixel_count():
+    rng = np.random.default_rng(0)
+    C = 7
+    gt = rng.integers(0, C, (3, 11, 13))
+    gt[rng.uniform(size=gt.shape) < 0.1] = 255            # ignored label
+    gt[0, 0, 0] = -1
+    pr = rng.integers(0, C, gt.shape)
+    cm = O.confusion_matrix(gt, pr, C)
+    want = np.zeros((C, C), np.int64)
+    for g, p in zip(gt.ravel(), pr.ravel()):
+        if 0 <= g < C:
+            want[g, p] += 1                                 # eval.py:446-453 (the commented-out loop)
+    assert np.array_equal(cm, want) and cm.sum() == ((gt >= 0) & (gt < C)).sum()
+
+
+def test_miou_summary_known_answer_and_host_summary():
+    cm = np.array([[8, 2, 0], [1, 5, 0], [0, 0, 0]])        # class 2 never occurs and is never predicted
+    s = O.miou_summary(cm)
+    iou = np.array([8 / 11, 5 / 8, 0.0])                    # I / (row + col - I); 0/0 -> 0 (eval.py:473)
+    assert np.allclose(s['IoU'], iou) and np.isclose(s['mIoU'], iou.mean())
+    assert np.isclose(s['PixelAcc'], 13 / 16)
+    assert np.allclose(s['ClassAcc'], [0.8, 5 / 6, 0.0]) and np.isclose(s['mClassAcc'], (0.8 + 5 / 6) / 3)
+    assert np.isclose(s['FWIoU'], 10 / 16 * 8 / 11 + 6 / 16 * 5 / 8)
+    assert np.allclose(s['Dice'], [16 / 19, 10 / 13, 0.0])
+    mine = load_pkg().miou_from_confusion(cm, class_names=['a', 'b', 'c'])
+    for k in ('mIoU', 'PixelAcc', 'mClassAcc', 'FWIoU'):
+        assert np.isclose(mine[k], s[k]), k
+    for k in ('IoU', 'ClassAcc', 'Dice', 'Freq'):
+        assert np.allclose(mine[k], s[k]), k
+    assert list(mine['IoU_by_class']) == ['a', 'b', 'c']    # sorted by IoU, descending (eval.py:493)

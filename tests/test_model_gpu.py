@@ -298,3 +298,30 @@ def test_train_py_flow(tmp_path):
     m.save(path + '.h5')
     mh = pkg.get_deeplabv3p_model('mobilenetv2', C, (H, W), 16, weights_path=path + '.h5', training=False)
     assert np.array_equal(mh.predict(x), p)
+
+
+def test_evaluate_miou_matches_oracle_recipe():
+    """model.evaluate_miou (device-side argmax + confusion matrix, eval.py:376-512) == the reference's recipe
+    (argmax of the prediction -> generate_matrix -> IoU summary) run by the oracle on the pred_resize logits.
+    (A random-init inference model has logits ~1e-3 apart: fp32 softmax rounds them all to exactly 1/21, so the
+    comparison goes through the logits; argmax on probabilities of O(1) logits is covered by test_argmax_confusion.)"""
+    from oracle import np_ops as O
+    pkg = load_pkg()
+    ops = load_pkg('ops')
+    C, H, W, B = 21, 65, 65, 2
+    m = pkg.get_deeplabv3p_model('mobilenetv2_lite', C, (H, W), 16, training=False)
+    batches = [_data(B, H, W, C, seed=40 + i) for i in range(3)]
+    res = m.evaluate_miou(batches, class_names=['c%d' % i for i in range(C)])
+    cm = np.zeros((C, C), np.int64)
+    ex = m._executor(B, False)
+    for x, y in batches:
+        ex.set_inputs(x)
+        ex.forward()
+        logits = ops.upsample_softmax_ce(ex.view(m.head.tensor), C, H, W, want_logits=True)['logits'][..., :C]
+        pred = logits.cpu().numpy().argmax(-1)               # eval.py:33-36
+        cm += O.confusion_matrix(np.asarray(y).reshape(B, H, W), pred, C)
+    assert len(np.unique(cm.nonzero()[1])) > 3, 'degenerate prediction: the test would prove nothing'
+    assert np.array_equal(res['confusion_matrix'].astype(np.int64), cm)
+    ref = O.miou_summary(cm)
+    assert abs(res['mIoU'] - ref['mIoU']) < 1e-12 and abs(res['FWIoU'] - ref['FWIoU']) < 1e-12
+    assert len(res['IoU_by_class']) == C and cm.sum() > 0

@@ -514,3 +514,37 @@ def test_bad_arguments_fail_loudly(ops):
         ops.dwconv2d_fwd(x, torch.zeros((3, 3, 6), device=DEV))
     with pytest.raises(ops.Dl3pError):
         ops.pwconv_fwd(torch.zeros((4, 8)), torch.zeros((8, 8)))   # CPU tensors are refused
+
+
+@pytest.mark.parametrize('case', [(2, 9, 9, 21, 33, 33), (1, 17, 33, 19, 65, 129), (3, 5, 7, 4, 20, 28), (1, 33, 33, 32, 129, 129)])
+def test_argmax_confusion(ops, case):
+    """evaluation head: argmax of the upsampled logits + confusion matrix == oracle resize -> np.argmax ->
+    generate_matrix (eval.py:33-36, 368-373); counters accumulate across calls; the mask equals the argmax of predict's
+    probabilities"""
+    N, h, w, C, H, W = case
+    rng = np.random.default_rng(C + H)
+    cp = {21: 24, 19: 20, 4: 20, 32: 32}[C]
+    z = np.zeros((N, h, w, cp))
+    z[..., :C] = rng.standard_normal((N, h, w, C)) * 3
+    z[0, 0, 0, :C] = 1.5                                       # an exact tie: the lowest class index wins
+    lab = rng.integers(0, C, (N, H * W)).astype(np.float64)
+    lab[rng.uniform(size=lab.shape) < 0.07] = 255
+    zt, lt = T(z), T(lab)
+    pred, cm = ops.argmax_confusion(zt, C, H, W, labels=lt, want_mask=True)
+    big = O.resize_bilinear_fwd(z[..., :C], H, W)
+    ref = big.argmax(-1)
+    got = pred.cpu().numpy()
+    # fp32 interpolation vs fp64: allow disagreement only where the two best logits are within rounding distance
+    srt = np.sort(big, -1)
+    close_call = (srt[..., -1] - srt[..., -2]) < 1e-4
+    assert ((got == ref) | close_call).all() and (got != ref).mean() < 1e-3
+    assert got[0, 0, 0] == 0
+    probs = ops.upsample_softmax_ce(zt, C, H, W, want_probs=True)['probs'].cpu().numpy()
+    assert np.array_equal(got, probs.argmax(-1)) or ((got != probs.argmax(-1)) <= close_call).all()
+    want = O.confusion_matrix(lab.reshape(N, H, W), got, C)     # the matrix itself is exact integer counting
+    assert np.array_equal(cm.cpu().numpy(), want)
+    _, cm2 = ops.argmax_confusion(zt, C, H, W, labels=lt, confusion=cm)
+    assert np.array_equal(cm2.cpu().numpy(), 2 * want)
+    only_mask, none = ops.argmax_confusion(zt, C, H, W, want_mask=True)
+    assert none is None and np.array_equal(only_mask.cpu().numpy(), got)
+

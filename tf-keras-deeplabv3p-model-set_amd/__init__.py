@@ -6,7 +6,7 @@ importlib:  importlib.import_module('tf-keras-deeplabv3p-model-set_amd')  -- or 
 (`from deeplabv3p.model import get_deeplabv3p_model`).
 """
 from .model import (get_deeplabv3p_model, deeplab_model_map, DeeplabModel, SGD, get_optimizer,  # noqa: F401
-                    SparseCategoricalCrossEntropy)
+                    SparseCategoricalCrossEntropy, miou_from_confusion)
 
 __all__ = ['get_deeplabv3p_model', 'deeplab_model_map', 'DeeplabModel', 'SGD', 'get_optimizer',
-           'SparseCategoricalCrossEntropy']
+           'SparseCategoricalCrossEntropy', 'miou_from_confusion']

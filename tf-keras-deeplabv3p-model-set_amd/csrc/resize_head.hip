@@ -329,6 +329,92 @@ extern "C" int dl3p_upsample_softmax_ce(const float* z, int ldz, const float* la
   return DL3P_OK;
 }
 
+// ------------------------------------------------------------------------------ evaluation head: argmax + confusion matrix
+// eval.py:33-36 (`np.argmax(prediction, -1)`) and :368-373 (`generate_matrix`): the class of a pixel is the argmax of
+// the upsampled logits (= the argmax of their softmax, except that logits too close for fp32 softmax to tell apart are
+// still told apart here; first index on ties, like np.argmax); pixels whose label lies
+// in [0, C) add 1 to confusion[label][prediction].  Counts are integers: a workgroup-private LDS histogram flushed
+// with 64-bit atomics gives the same matrix in any order.  The (N,H,W,C) probability tensor is never written.
+struct EvalParams {
+  const float* z; int ldz; const float* labels; int* pred; unsigned long long* cm;
+  int N, h, w, C, H, W;
+  long long total;
+};
+
+template <int CP>
+__global__ __launch_bounds__(256) void argmax_confusion_kernel(EvalParams p) {
+  extern __shared__ unsigned int hist[];                 // [C][C], only with labels and C <= 64
+  const bool use_lds = p.labels && p.cm && p.C <= 64;
+  if (use_lds) {
+    for (int i = threadIdx.x; i < p.C * p.C; i += 256) hist[i] = 0u;
+    __syncthreads();
+  }
+  const float sy = (float)p.h / (float)p.H, sx = (float)p.w / (float)p.W;
+  for (long long s = (long long)blockIdx.x * 256 + threadIdx.x; s < p.total; s += (long long)gridDim.x * 256) {
+    const int ox = s % p.W;
+    const int row = s / p.W;
+    const int oy = row % p.H;
+    const int n = row / p.H;
+    const Lerp ly = lerp_coeff(oy, sy, p.h), lx = lerp_coeff(ox, sx, p.w);
+    const float* img = p.z + (size_t)n * p.h * p.w * p.ldz;
+    const float* ptl = img + ((size_t)ly.lo * p.w + lx.lo) * p.ldz;
+    const float* ptr = img + ((size_t)ly.lo * p.w + lx.hi) * p.ldz;
+    const float* pbl = img + ((size_t)ly.hi * p.w + lx.lo) * p.ldz;
+    const float* pbr = img + ((size_t)ly.hi * p.w + lx.hi) * p.ldz;
+    float best = -3.0e38f;
+    int arg = 0;
+#pragma unroll
+    for (int c4 = 0; c4 < CP / 4; ++c4) {
+      const float4 tl = ld4(ptl + c4 * 4), tr = ld4(ptr + c4 * 4), bl = ld4(pbl + c4 * 4), br = ld4(pbr + c4 * 4);
+      // the same arithmetic as head_kernel, so predict() followed by a host argmax gives the same class
+#define LERP2(f, i) { float top = tl.f + (tr.f - tl.f) * lx.t; float bot = bl.f + (br.f - bl.f) * lx.t; \
+                      const float v = top + (bot - top) * ly.t; \
+                      if (c4 * 4 + i < p.C && v > best) { best = v; arg = c4 * 4 + i; } }
+      LERP2(x, 0) LERP2(y, 1) LERP2(z, 2) LERP2(w, 3)
+#undef LERP2
+    }
+    if (p.pred) p.pred[s] = arg;
+    if (p.labels && p.cm) {
+      const int lab = (int)p.labels[s];
+      if (lab >= 0 && lab < p.C) {
+        if (use_lds) atomicAdd(&hist[lab * p.C + arg], 1u);
+        else atomicAdd(&p.cm[(size_t)lab * p.C + arg], 1ull);
+      }
+    }
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < p.C * p.C; i += 256)
+      if (hist[i]) atomicAdd(&p.cm[i], (unsigned long long)hist[i]);
+  }
+}
+
+extern "C" int dl3p_argmax_confusion(const float* z, int ldz, const float* labels, int32_t* pred_mask,
+                                     unsigned long long* confusion, int N, int h, int w, int C, int H, int W,
+                                     void* stream) {
+  DL3P_CHECK_ARG(z && aligned16(z) && ldz % 4 == 0, "dl3p_argmax_confusion: logits must be 16-byte aligned, ld %% 4 == 0");
+  DL3P_CHECK_ARG(C > 0 && C <= 32 && N > 0 && h > 0 && w > 0 && H > 0 && W > 0, "dl3p_argmax_confusion: bad dims (C=%d)", C);
+  DL3P_CHECK_ARG(pred_mask || (labels && confusion), "dl3p_argmax_confusion: nothing to produce");
+  DL3P_CHECK_ARG(!confusion || labels, "dl3p_argmax_confusion: a confusion matrix needs labels");
+  EvalParams p = {};
+  p.z = z; p.ldz = ldz; p.labels = labels; p.pred = pred_mask; p.cm = confusion;
+  p.N = N; p.h = h; p.w = w; p.C = C; p.H = H; p.W = W;
+  p.total = (long long)N * H * W;
+  long long blocks = ceil_div_ll(p.total, 256 * 8);      // 8 pixels per thread: few histogram flushes
+  if (blocks < 1) blocks = 1;
+  if (blocks > 4096) blocks = 4096;
+  const int cp = ((C + 3) / 4) * 4;
+  const int cpv = cp <= 20 ? 20 : (cp <= 24 ? 24 : 32);
+  DL3P_CHECK_ARG(ldz >= cpv, "dl3p_argmax_confusion: ld=%d must be >= %d for C=%d", ldz, cpv, C);
+  const size_t lds = (labels && confusion) ? (size_t)C * C * sizeof(unsigned int) : 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (cp <= 20) hipLaunchKernelGGL((argmax_confusion_kernel<20>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+  else if (cp <= 24) hipLaunchKernelGGL((argmax_confusion_kernel<24>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((argmax_confusion_kernel<32>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+  DL3P_CHECK_LAUNCH("dl3p_argmax_confusion");
+  return DL3P_OK;
+}
+
 // ------------------------------------------------------------------------------ fused training head
 // pred_resize + Softmax + loss + the transposed resize of the gradient in ONE kernel: the (N,H,W,C) gradient
 // (404 MB at batch 16, written by head_kernel and read back by resize_bwd_kernel) never exists.  A workgroup

@@ -794,6 +794,22 @@ class Executor:
     def forward(self):
         self.fwd.run()
 
+    def eval_step(self, confusion, pred=None):
+        """inference forward WITHOUT the probability tensor, then argmax + confusion-matrix accumulation against
+        self.labels on the device (eval.py:33-36, 368-373, 440-443): per batch nothing but the C x C counters changes
+        (predict() writes and downloads N*H*W*C probabilities: 354 MB at batch 16).  confusion: int64 [C*C] tensor."""
+        assert not self.training
+        if getattr(self, '_eval_plan', None) is None:
+            P = Plan()
+            P.items = list(self.fwd.items[:-1])            # the body; the last item is the softmax head
+            P.labels = list(self.fwd.labels[:-1])
+            self._eval_plan = P
+        self._eval_plan.run()
+        zt = self.head.tensor
+        self.L.argmax_confusion(self.tptr(zt), zt.ld, self.labels.data_ptr(), None if pred is None else pred.data_ptr(),
+                                confusion.data_ptr(), self.N, zt.H, zt.W, self.C, self.H, self.W,
+                                torch.cuda.current_stream().cuda_stream)
+
     def install_probe(self, name):
         """time one forward depthwise launch with HIP events inside the steps (bench.py roofline)"""
         op = [o for o in self.g.ops if getattr(o, 'name', None) == name and o.kind == 'conv_dw'][0]

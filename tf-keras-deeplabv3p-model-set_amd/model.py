@@ -457,6 +457,52 @@ def _evaluate(self, gen, steps=None):
 DeeplabModel.evaluate = _evaluate
 
 
+def miou_from_confusion(cm, class_names=None):
+    """eval.py:462-497 on a (C,C) confusion matrix (rows = ground truth): PixelAcc, per-class ClassAcc / IoU / Dice /
+    Freq, mClassAcc, mIoU (NaN -> 0 before the mean, like the reference), FWIoU"""
+    cm = np.asarray(cm, dtype=np.float64)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        inter = np.diag(cm)
+        rows, cols, tot = cm.sum(axis=1), cm.sum(axis=0), cm.sum()
+        pixel_acc = inter.sum() / tot
+        class_acc = np.nan_to_num(inter / rows, nan=0.0)
+        union = rows + cols - inter
+        iou = np.nan_to_num(inter / union, nan=0.0)
+        freq = np.nan_to_num(rows / tot, nan=0.0)
+        dice = np.nan_to_num(2 * inter / (union + inter), nan=0.0)
+    out = {'PixelAcc': float(pixel_acc), 'mClassAcc': float(class_acc.mean()), 'mIoU': float(iou.mean()),
+           'FWIoU': float((freq[freq > 0] * iou[freq > 0]).sum()), 'IoU': iou, 'ClassAcc': class_acc, 'Dice': dice,
+           'Freq': freq, 'confusion_matrix': cm}
+    if class_names is not None:
+        out['IoU_by_class'] = dict(sorted(zip(class_names, iou.tolist()), key=lambda kv: -kv[1]))
+    return out
+
+
+def _evaluate_miou(self, gen, steps=None, class_names=None, verbose=0):
+    """eval.py:376-512 `eval_mIOU` for a generator of (images, labels) batches: inference forward, argmax and the
+    confusion matrix stay on the device (Executor.eval_step); only the C x C counters come back.  -> miou_from_confusion"""
+    import torch
+    n = steps or len(gen)
+    C = self.num_classes
+    cm = torch.zeros(C * C, dtype=torch.int64, device='cuda')
+    for i in range(n):
+        x, y = gen[i][0], gen[i][1]
+        x = np.asarray(x, dtype=np.float32)
+        ex = self._executor(x.shape[0], False)
+        ex.set_inputs(x, np.asarray(y, dtype=np.float32))
+        ex.eval_step(cm)
+    res = miou_from_confusion(cm.view(C, C).cpu().numpy(), class_names)
+    if verbose:
+        print('mIoU=%.3f' % (res['mIoU'] * 100))
+        print('FWIoU=%.3f' % (res['FWIoU'] * 100))
+        print('PixelAcc=%.3f' % (res['PixelAcc'] * 100))
+        print('mClassAcc=%.3f' % (res['mClassAcc'] * 100))
+    return res
+
+
+DeeplabModel.evaluate_miou = _evaluate_miou
+
+
 def get_deeplabv3p_model(model_type, num_classes, model_input_shape, output_stride, freeze_level=0,
                          weights_path=None, training=True, use_subpixel=False, seed=0):
     # check if model type is valid

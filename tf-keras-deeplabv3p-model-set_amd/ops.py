@@ -392,6 +392,19 @@ def upsample_softmax_ce(z, C, H, W, labels=None, ignore_index=255, want_probs=Fa
     return out
 
 
+def argmax_confusion(z, C, H, W, labels=None, confusion=None, want_mask=False):
+    """z (N,h,w,Cpad) small logits -> (pred mask (N,H,W) int32 or None, confusion (C,C) int64 or None); an existing
+    `confusion` tensor is accumulated into (eval.py:443)"""
+    N, h, w, _ = z.shape
+    zp, ldz = _pl(z)
+    pred = torch.empty((N, H, W), dtype=torch.int32, device=z.device) if want_mask else None
+    if labels is not None and confusion is None:
+        confusion = torch.zeros((C, C), dtype=torch.int64, device=z.device)
+    lib().argmax_confusion(zp, ldz, _p(labels), _p(pred), _p(confusion) if labels is not None else None, N, h, w, C, H, W,
+                           _stream())
+    return pred, (confusion if labels is not None else None)
+
+
 def head_train_supported(h, w, C, H, W):
     return bool(lib().head_train_supported(h, w, C, H, W))
 
