@@ -537,7 +537,38 @@ def os_table(OS):
     raise ValueError('invalid output stride', OS)
 
 
-MODEL_TYPES = ('mobilenetv2', 'mobilenetv2_lite', 'xception', 'mobilenetv3large')
+MODEL_TYPES = ('mobilenetv2', 'mobilenetv2_lite', 'xception', 'mobilenetv3large', 'mobilenetv3large_lite',
+               'mobilenetv3small', 'mobilenetv3small_lite')
+
+
+def _mobilenetv3small_body(self, x, OS):
+    """MobileNetV3 stem (deeplabv3p_mobilenetv3.py:343-355) + MobileNetV3Small.stack_fn (:469-499): alpha=1.0, kernel=5,
+    activation=hard_swish, se_ratio=0.25; skip feature = block 0's output"""
+    s16, r16, s32, r32 = os_table(OS)
+    H, W = x.v.shape[1:3]
+    adj_h, adj_w = 1 - H % 2, 1 - W % 2
+    x = self.conv2d(x, 16, 3, 'Conv', stride=2, padding=(1 - adj_h, 1, 1 - adj_w, 1))
+    x = self.bn(x, 'Conv/BatchNorm', 1e-3, 0.999)
+    x = self.act(x, O.ACT_HSWISH)
+    RE, HS = O.ACT_RELU, O.ACT_HSWISH
+    d = lambda v: make_divisible(v, 8)
+    se, k = 0.25, 5
+    x = self.mnv3_block(x, 1, d(16), 3, 2, se, RE, 0, False)
+    skip = x
+    x = self.mnv3_block(x, 72. / 16, d(24), 3, 2, None, RE, 1, False)
+    x = self.mnv3_block(x, 88. / 24, d(24), 3, 1, None, RE, 2, True)
+    x = self.mnv3_block(x, 4, d(40), k, s16, se, HS, 3, False)
+    x = self.mnv3_block(x, 6, d(40), k, 1, se, HS, 4, True, rate=r16)
+    x = self.mnv3_block(x, 6, d(40), k, 1, se, HS, 5, True, rate=r16)
+    x = self.mnv3_block(x, 3, d(48), k, 1, se, HS, 6, False, rate=r16)
+    x = self.mnv3_block(x, 3, d(48), k, 1, se, HS, 7, True, rate=r16)
+    x = self.mnv3_block(x, 6, d(96), k, s32, se, HS, 8, False, rate=r16)
+    x = self.mnv3_block(x, 6, d(96), k, 1, se, HS, 9, True, rate=r32)
+    x = self.mnv3_block(x, 6, d(96), k, 1, se, HS, 10, True, rate=r32)
+    return x, skip
+
+
+Net.mobilenetv3small_body = _mobilenetv3small_body
 
 
 class OracleModel:
@@ -581,13 +612,15 @@ class OracleModel:
             f, skip = net.mobilenetv2_body(xin, self.OS)
         elif self.model_type == 'xception':
             f, skip = net.xception_body(xin, self.OS)
+        elif self.model_type.startswith('mobilenetv3small'):
+            f, skip = net.mobilenetv3small_body(xin, self.OS)
         else:
             f, skip = net.mobilenetv3large_body(xin, self.OS)
         if not hasattr(self, '_backbone_names'):
             self._backbone_names = net.order[n_before:]
             self._backbone_layers = {n.rsplit('/', 1)[0] for n in self._backbone_names}
         net.tap('backbone_out', f)
-        if self.model_type == 'mobilenetv2_lite':
+        if self.model_type.endswith('_lite'):      # Deeplabv3pLite*: ASPP-Lite, no decoder
             y = net.aspp_lite_block(f)
         else:
             y = net.aspp_block(f, self.OS)

@@ -95,7 +95,9 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize('model_type,H,W', [('mobilenetv2', 65, 65), ('mobilenetv2_lite', 65, 97), ('xception', 65, 65),
-                                            ('mobilenetv3large', 65, 65), ('mobilenetv3large', 64, 96)])
+                                            ('mobilenetv3large', 65, 65), ('mobilenetv3large', 64, 96),
+                                            ('mobilenetv3small', 65, 65), ('mobilenetv3small_lite', 64, 96),
+                                            ('mobilenetv3large_lite', 65, 65)])
 def test_predict_matches_oracle(model_type, H, W):
     m, o = _pair(model_type, H, W, 21, training=False)
     x, _ = _data(2, H, W, 21)
@@ -113,6 +115,8 @@ def test_predict_matches_oracle(model_type, H, W):
 @pytest.mark.parametrize('model_type,H,W,freeze,OS', [('mobilenetv2', 65, 65, 0, 16), ('mobilenetv2_lite', 65, 65, 0, 16),
                                                       ('mobilenetv2', 65, 65, 1, 16), ('xception', 65, 65, 0, 16),
                                                       ('mobilenetv3large', 65, 65, 0, 16), ('mobilenetv3large', 64, 96, 0, 16),
+                                                      ('mobilenetv3small', 65, 65, 0, 16), ('mobilenetv3small_lite', 65, 65, 0, 16),
+                                                      ('mobilenetv3large_lite', 65, 65, 0, 16),
                                                       # output stride 8 (BASELINE configs[3]): denser atrous grid, ASPP rates 12/24/36
                                                       ('mobilenetv2', 65, 65, 0, 8), ('xception', 97, 97, 0, 8)])
 def test_train_step_matches_oracle(model_type, H, W, freeze, OS):

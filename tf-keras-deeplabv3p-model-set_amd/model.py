@@ -33,8 +33,12 @@ def _register_optional():
     except ImportError:
         pass
     try:
-        from .mobilenetv3 import Deeplabv3pMobileNetV3Large
+        from .mobilenetv3 import (Deeplabv3pMobileNetV3Large, Deeplabv3pLiteMobileNetV3Large,
+                                  Deeplabv3pMobileNetV3Small, Deeplabv3pLiteMobileNetV3Small)
         deeplab_model_map['mobilenetv3large'] = partial(Deeplabv3pMobileNetV3Large, alpha=1.0)
+        deeplab_model_map['mobilenetv3large_lite'] = partial(Deeplabv3pLiteMobileNetV3Large, alpha=1.0)
+        deeplab_model_map['mobilenetv3small'] = partial(Deeplabv3pMobileNetV3Small, alpha=1.0)
+        deeplab_model_map['mobilenetv3small_lite'] = partial(Deeplabv3pLiteMobileNetV3Small, alpha=1.0)
     except ImportError:
         pass
 
