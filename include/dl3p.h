@@ -245,6 +245,17 @@ int dl3p_upsample_softmax_ce(const float* z, int ldz, const float* labels, int i
                              float* logits_big, float* probs, float* dlogits_big, int ld_big,
                              float* loss_partials, int* rows_out,
                              int N, int h, int w, int C, int H, int W, void* stream);
+/* The same head with the reference's other two losses (train.py:108-137): loss_kind DL3P_LOSS_WEIGHTED_CE =
+ * WeightedSparseCategoricalCrossEntropy (loss.py:159-191: -w[y]*log(p_y), class_weights[C] on the device, no
+ * clipping), DL3P_LOSS_FOCAL = SparseSoftmaxFocalLoss (loss.py:63-118: -alpha*(1-p_y)^gamma*log(p_y), p clipped to
+ * [1e-15, 1-1e-15]); DL3P_LOSS_CE is dl3p_upsample_softmax_ce.  Masking, mean over all N*H*W entries and the
+ * outputs are as above. */
+enum { DL3P_LOSS_CE = 0, DL3P_LOSS_WEIGHTED_CE = 1, DL3P_LOSS_FOCAL = 2 };
+int dl3p_upsample_softmax_loss(const float* z, int ldz, const float* labels, int ignore_index, float inv_count,
+                               int loss_kind, const float* class_weights, float focal_gamma, float focal_alpha,
+                               float* logits_big, float* probs, float* dlogits_big, int ld_big,
+                               float* loss_partials, int* rows_out,
+                               int N, int h, int w, int C, int H, int W, void* stream);
 /* Evaluation head (eval.py:33-36 argmax of the prediction, :368-373 generate_matrix): pred_mask[N*H*W] (int32) =
  * argmax over the C classes of the upsampled logits (first index on ties, like np.argmax); for pixels with
  * 0 <= label < C, confusion[label*C + pred] += 1 (uint64 [C][C], zeroed by the caller, accumulates across calls;

@@ -339,6 +339,67 @@ def sparse_ce_fwd_bwd(logits, labels, ignore_index=255):
     g /= M
     return loss, p, g.reshape(logits.shape)
 
+def _active_rows(logits, labels, ignore_index):
+    C = logits.shape[-1]
+    flat_l = labels.astype(np.int64).reshape(-1)
+    in_range = (flat_l >= 0) & (flat_l < C)
+    mask = np.ones(flat_l.shape[0], dtype=bool)
+    if ignore_index:
+        mask = flat_l != ignore_index
+    return flat_l, np.where(in_range & mask)[0]
+
+
+def weighted_sparse_ce_fwd_bwd(logits, labels, weights, ignore_index=255):
+    """WeightedSparseCategoricalCrossEntropy (loss.py:159-191): -w[y] * log(p_y), no clipping, label mask as in the
+    plain loss, Keras mean over ALL entries.  returns (loss_mean, probs, dlogits)"""
+    C = logits.shape[-1]
+    w = np.asarray(weights, dtype=logits.dtype)
+    assert w.shape == (C,)
+    p = softmax_fwd(logits)
+    flat_p = p.reshape(-1, C)
+    flat_l, idx = _active_rows(logits, labels, ignore_index)
+    M = flat_l.shape[0]
+    wy = w[flat_l[idx]]
+    loss = -(wy * np.log(flat_p[idx, flat_l[idx]])).sum() / M
+    g = np.zeros_like(flat_p)
+    g[idx] = flat_p[idx] * wy[:, None]
+    g[idx, flat_l[idx]] -= wy
+    return loss, p, (g / M).reshape(logits.shape)
+
+
+def sparse_focal_fwd_bwd(logits, labels, gamma=2.0, alpha=0.25, ignore_index=255):
+    """SparseSoftmaxFocalLoss (loss.py:63-118): sum_c alpha * (1 - p_c)^gamma * (-onehot_c * log p_c) with p clipped to
+    [1e-15, 1 - 1e-15] = -alpha (1 - p_y)^gamma log p_y; label mask and Keras mean as above.
+    d/dz_c = alpha * ((1-p_y)^gamma - gamma (1-p_y)^(gamma-1) p_y log p_y) * (p_c - [c == y])"""
+    C = logits.shape[-1]
+    p = softmax_fwd(logits)
+    flat_p = p.reshape(-1, C)
+    flat_l, idx = _active_rows(logits, labels, ignore_index)
+    M = flat_l.shape[0]
+    pt_raw = flat_p[idx, flat_l[idx]]
+    pt = np.clip(pt_raw, 1e-15, 1.0 - 1e-15)
+    om = 1.0 - pt
+    loss = -(alpha * om ** gamma * np.log(pt)).sum() / M
+    f = alpha * (om ** gamma - gamma * om ** (gamma - 1.0) * pt * np.log(pt))
+    f = np.where((pt_raw >= 1e-15) & (pt_raw <= 1.0 - 1e-15), f, 0.0)     # the clip has zero slope outside its range
+    g = np.zeros_like(flat_p)
+    g[idx] = flat_p[idx] * f[:, None]
+    g[idx, flat_l[idx]] -= f
+    return loss, p, (g / M).reshape(logits.shape)
+
+
+def loss_fwd_bwd(logits, labels, spec=None, ignore_index=255):
+    """spec: None / ('ce',) | ('weighted', weights) | ('focal', gamma, alpha)  (train.py:108-137)"""
+    kind = spec[0] if spec else 'ce'
+    if kind == 'ce':
+        return sparse_ce_fwd_bwd(logits, labels, ignore_index)
+    if kind == 'weighted':
+        return weighted_sparse_ce_fwd_bwd(logits, labels, spec[1], ignore_index)
+    if kind == 'focal':
+        return sparse_focal_fwd_bwd(logits, labels, spec[1], spec[2], ignore_index)
+    raise ValueError(kind)
+
+
 # --------------------------------------------------------------------------------------
 # optimiser: Keras SGD(momentum=0.9, nesterov=False) + l2 regulariser gradient
 # --------------------------------------------------------------------------------------

@@ -36,3 +36,27 @@ def test_miou_summary_known_answer_and_host_summary():
     for k in ('IoU', 'ClassAcc', 'Dice', 'Freq'):
         assert np.allclose(mine[k], s[k]), k
     assert list(mine['IoU_by_class']) == ['a', 'b', 'c']    # sorted by IoU, descending (eval.py:493)
+
+
+def test_focal_and_weighted_loss_gradients_are_derivatives():
+    """the oracle's analytic d loss / d logits of the two optional losses (loss.py:63-118, 159-191) against central
+    differences, and their known limits: gamma = 0, alpha = 1 is the plain loss; unit weights are the plain loss"""
+    rng = np.random.default_rng(3)
+    z = rng.standard_normal((2, 5, 4, 6)) * 2
+    lab = rng.integers(0, 6, (2, 5, 4)).astype(np.float64)
+    lab[0, 0, 0] = 255
+    w = rng.uniform(0.3, 2.5, 6)
+    for spec in (('weighted', w), ('focal', 2.0, 0.25), ('focal', 1.0, 0.5), ('focal', 3.5, 1.0)):
+        loss, _, g = O.loss_fwd_bwd(z, lab, spec)
+        num = np.zeros_like(z)
+        eps = 1e-6
+        for i in np.ndindex(z.shape):
+            zp, zm = z.copy(), z.copy()
+            zp[i] += eps; zm[i] -= eps
+            num[i] = (O.loss_fwd_bwd(zp, lab, spec)[0] - O.loss_fwd_bwd(zm, lab, spec)[0]) / (2 * eps)
+        assert np.abs(num - g).max() < 1e-8, spec[0]
+        assert np.abs(g[0, 0, 0]).max() == 0                # ignored pixel
+    ce, _, gce = O.sparse_ce_fwd_bwd(z, lab)
+    l0, _, g0 = O.loss_fwd_bwd(z, lab, ('focal', 0.0, 1.0))
+    l1, _, g1 = O.loss_fwd_bwd(z, lab, ('weighted', np.ones(6)))
+    assert np.isclose(l0, ce) and np.allclose(g0, gce) and np.isclose(l1, ce) and np.allclose(g1, gce)

@@ -329,3 +329,41 @@ def test_evaluate_miou_matches_oracle_recipe():
     ref = O.miou_summary(cm)
     assert abs(res['mIoU'] - ref['mIoU']) < 1e-12 and abs(res['FWIoU'] - ref['FWIoU']) < 1e-12
     assert len(res['IoU_by_class']) == C and cm.sum() > 0
+
+
+@pytest.mark.parametrize('kind', ['weighted', 'focal'])
+def test_train_step_with_optional_losses(kind):
+    """compile(loss=WeightedSparseCategoricalCrossEntropy(...) | SparseSoftmaxFocalLoss(...)) (train.py:108-137): loss
+    value, one SGD step of every weight against the oracle run with the same loss"""
+    pkg = load_pkg()
+    N, C, H, W = 2, 21, 65, 65
+    m, o = _pair('mobilenetv2_lite', H, W, C)
+    rng = np.random.default_rng(1)
+    if kind == 'weighted':
+        wts = rng.uniform(0.3, 2.5, C)
+        loss_obj, spec = pkg.WeightedSparseCategoricalCrossEntropy(wts, ignore_index=255), ('weighted', wts.astype(np.float32))
+    else:
+        loss_obj, spec = pkg.SparseSoftmaxFocalLoss(gamma=2.0, alpha=0.25, ignore_index=255), ('focal', 2.0, 0.25)
+    m.compile(optimizer=pkg.SGD(0.01), loss=loss_obj)
+    m.use_graphs = False
+    x, y = _data(N, H, W, C, seed=5)
+    loss = m.train_on_batch(x, y)
+    ex = m._executor(N, True)
+    drop = [op for op in m.graph.ops if op.kind == 'materialize' and op.rate > 0][0]
+    mask = ex.dropout_mask(drop).cpu().numpy()
+    o.net.act_derivs = _act_derivs(m, ex)
+    o.net.act_derivs_seq = _act_derivs_seq(m, ex, o.net.act_derivs)
+    total, data_loss, _ = o.loss_and_grads(x, y, {'aspp_dropout': mask}, loss=spec)
+    assert abs(loss - data_loss) < TOL * max(1.0, abs(data_loss)), (loss, data_loss)
+    st = m._store
+    worst = 0.0
+    for p in m.graph.all_params():
+        if p.trainable:
+            gref = o.net.grads[p.name]
+            if np.abs(gref).max() > 1e-7:
+                worst = max(worst, _rel(st.get(p, st.G), gref))
+    assert worst < 5e-3, worst
+    o.sgd_step(0.01, 0.9)
+    w = m.get_weights_by_name()
+    assert max(float(np.abs(v - o.net.params[k]).max()) for k, v in w.items()) < TOL
+

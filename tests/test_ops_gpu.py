@@ -435,6 +435,31 @@ def test_head_softmax_ce(ops, C, ignore):
     assert float(out['dlogits'][..., C:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('spec', [('weighted',), ('focal', 2.0, 0.25), ('focal', 1.0, 0.5), ('focal', 3.5, 1.0)])
+def test_head_optional_losses(ops, spec):
+    """the reference's other two training losses in the same head kernel (train.py:108-137): class-weighted CE
+    (loss.py:159-191) and softmax focal loss (loss.py:63-118), value and gradient against the oracle"""
+    rng = np.random.default_rng(11)
+    N, h, w, H, W, C = 2, 9, 9, 33, 33, 21
+    z = np.zeros((N, h, w, 24)); z[..., :C] = rng.standard_normal((N, h, w, C)) * 3
+    z[0, 0, 0, 3] = 60.0                                     # a saturated pixel: p_y -> 1 (label 3) or -> 0 (others)
+    lab = rng.integers(0, C, (N, H, W)).astype(np.float64)
+    lab[rng.uniform(size=lab.shape) < 0.1] = 255
+    lab[0, 0, 0], lab[0, 0, 1] = 3, 5
+    big = O.resize_bilinear_fwd(z[..., :C], H, W)
+    if spec[0] == 'weighted':
+        wts = rng.uniform(0.2, 3.0, C)
+        ospec, dspec = ('weighted', wts), ('weighted', T(wts))
+    else:
+        ospec = dspec = spec
+    loss_ref, _, g_ref = O.loss_fwd_bwd(big, lab, ospec, 255)
+    out = ops.upsample_softmax_ce(T(z), C, H, W, T(lab.reshape(N, H * W, 1)), 255, want_grad=True, loss=dspec)
+    close(out['loss'], [loss_ref], rtol=2e-4, what='%s loss' % spec[0])
+    close(out['dlogits'][..., :C], g_ref, rtol=2e-4, atol=1e-9, what='%s dlogits' % spec[0])
+    assert float(out['dlogits'][..., C:].abs().max()) == 0.0
+    assert np.isfinite(out['dlogits'].cpu().numpy()).all()
+
+
 @pytest.mark.parametrize('case', [(2, 9, 9, 33, 33, 21, 255), (1, 33, 33, 129, 129, 19, 255), (2, 17, 23, 65, 89, 21, 0),
                                   (1, 129, 129, 513, 513, 21, 255)])
 def test_head_train_fused(ops, case):

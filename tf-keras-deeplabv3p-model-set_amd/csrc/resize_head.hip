@@ -189,6 +189,7 @@ extern "C" int dl3p_resize_bilinear_bwd(const float* gy, int ldgy, float* gx, in
 // written when asked for (predict); training never materialises it.
 struct HeadParams {
   const float* z; int ldz; const float* labels; int ignore_index; float inv_count;
+  int loss_kind; const float* class_w; float focal_gamma, focal_alpha;   // DL3P_LOSS_*
   float* logits_big; float* probs; float* dlogits; float* loss_partials;
   int N, h, w, C, H, W, ld_big;
   long long total;
@@ -263,10 +264,32 @@ __global__ __launch_bounds__(256) void head_kernel(HeadParams p) {
       float pt = 0.f;
 #pragma unroll
       for (int c = 0; c < CP; ++c) if (c == lab) pt = e[c] * inv;
-      const bool unclipped = pt > 1e-7f && pt < 1.f - 1e-7f;
-      if (valid && live) loss += -logf(fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f));
+      // per-pixel loss l(p_t) and the factor f with d l / d z_c = f * (p_c - [c == y]):
+      //   cross entropy (loss.py:121-156)   l = -log(clip(p_t, 1e-7, 1 - 1e-7)),  f = 1 inside the clip range, else 0
+      //   class-weighted  (loss.py:159-191) l = -w_y log(p_t)  (no clipping),      f = w_y
+      //   focal           (loss.py:63-118)  l = -alpha (1 - p_t)^gamma log(p_t),   p_t clipped to [1e-15, 1 - 1e-15];
+      //                                     f = alpha ((1 - p_t)^gamma - gamma (1 - p_t)^(gamma - 1) p_t log p_t)
+      float li, f;
+      if (p.loss_kind == DL3P_LOSS_WEIGHTED_CE) {
+        float wy = 0.f;
+        if (valid) wy = p.class_w[lab];
+        li = -wy * logf(pt);
+        f = wy;
+      } else if (p.loss_kind == DL3P_LOSS_FOCAL) {
+        const float pc = fmaxf(pt, 1e-15f);               // 1 - 1e-15 rounds to 1 in fp32: the upper clip is a no-op
+        const float om = 1.f - pc, lp = logf(pc);
+        const float pw1 = om > 0.f ? powf(om, p.focal_gamma - 1.f) : (p.focal_gamma == 1.f ? 1.f : 0.f);
+        const float pw = pw1 * om;
+        li = -p.focal_alpha * pw * lp;
+        f = pt >= 1e-15f ? p.focal_alpha * (pw - p.focal_gamma * pw1 * pc * lp) : 0.f;
+      } else {
+        const bool unclipped = pt > 1e-7f && pt < 1.f - 1e-7f;
+        li = -logf(fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f));
+        f = unclipped ? 1.f : 0.f;
+      }
+      if (valid && live) loss += li;
       if (p.dlogits) {
-        const float gs = (valid && unclipped) ? p.inv_count : 0.f;
+        const float gs = valid ? f * p.inv_count : 0.f;
         float d[CP];
 #pragma unroll
         for (int c = 0; c < CP; ++c) d[c] = c < p.C ? gs * (e[c] * inv - (c == lab ? 1.f : 0.f)) : 0.f;
@@ -305,13 +328,25 @@ extern "C" int dl3p_upsample_softmax_ce(const float* z, int ldz, const float* la
                                         float inv_count, float* logits_big, float* probs, float* dlogits_big,
                                         int ld_big, float* loss_partials, int* rows_out, int N, int h, int w, int C,
                                         int H, int W, void* stream) {
+  return dl3p_upsample_softmax_loss(z, ldz, labels, ignore_index, inv_count, DL3P_LOSS_CE, nullptr, 0.f, 0.f, logits_big,
+                                    probs, dlogits_big, ld_big, loss_partials, rows_out, N, h, w, C, H, W, stream);
+}
+
+extern "C" int dl3p_upsample_softmax_loss(const float* z, int ldz, const float* labels, int ignore_index,
+                                          float inv_count, int loss_kind, const float* class_weights, float focal_gamma,
+                                          float focal_alpha, float* logits_big, float* probs, float* dlogits_big,
+                                          int ld_big, float* loss_partials, int* rows_out, int N, int h, int w, int C,
+                                          int H, int W, void* stream) {
   DL3P_CHECK_ARG(z && aligned16(z) && ldz % 4 == 0, "dl3p_upsample_softmax_ce: logits must be 16-byte aligned, ld %% 4 == 0");
+  DL3P_CHECK_ARG(loss_kind == DL3P_LOSS_CE || loss_kind == DL3P_LOSS_FOCAL || (loss_kind == DL3P_LOSS_WEIGHTED_CE && class_weights),
+                 "dl3p_upsample_softmax_loss: bad loss kind %d (weighted CE needs class_weights[C])", loss_kind);
   DL3P_CHECK_ARG(C > 0 && C <= 32 && ldz >= ((C + 3) / 4) * 4, "dl3p_upsample_softmax_ce: C=%d (ld=%d) unsupported", C, ldz);
   DL3P_CHECK_ARG(!labels || loss_partials, "dl3p_upsample_softmax_ce: loss_partials required with labels");
   DL3P_CHECK_ARG((!logits_big && !dlogits_big) || (ld_big >= C && (ld_big % 4 || (aligned16(logits_big) && aligned16(dlogits_big)))),
                  "dl3p_upsample_softmax_ce: bad ld_big=%d", ld_big);
   HeadParams p = {};
   p.z = z; p.ldz = ldz; p.labels = labels; p.ignore_index = ignore_index; p.inv_count = inv_count;
+  p.loss_kind = loss_kind; p.class_w = class_weights; p.focal_gamma = focal_gamma; p.focal_alpha = focal_alpha;
   p.logits_big = logits_big; p.probs = probs; p.dlogits = dlogits_big; p.loss_partials = labels ? loss_partials : nullptr;
   p.N = N; p.h = h; p.w = w; p.C = C; p.H = H; p.W = W; p.ld_big = ld_big;
   p.total = (long long)N * H * W;

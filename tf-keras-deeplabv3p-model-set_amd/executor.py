@@ -251,10 +251,14 @@ class Probe:
 
 class Executor:
     def __init__(self, graph, head, store, batch, training, num_classes, ignore_index=255, dist=None,
-                 seed=1234, momentum=0.9):
+                 seed=1234, momentum=0.9, loss=('ce',)):
         self.g, self.head, self.store = graph, head, store
         self.N, self.training, self.C = batch, training, num_classes
         self.ignore_index = ignore_index
+        # loss: ('ce',) | ('weighted', weights[C]) | ('focal', gamma, alpha)  (model.loss_spec)
+        self.loss_kind = {'ce': 0, 'weighted': 1, 'focal': 2}[loss[0]]
+        self.loss_gamma, self.loss_alpha = (float(loss[1]), float(loss[2])) if loss[0] == 'focal' else (0.0, 0.0)
+        self._loss_weights_host = np.asarray(loss[1], np.float32) if loss[0] == 'weighted' else None
         # DL3P_FORCE_DIST=1 exercises the collective path on a single rank (plumbing test)
         force = bool(os.environ.get('DL3P_FORCE_DIST'))
         self.dist = dist if (dist is not None and (dist.world_size > 1 or force)) else None
@@ -329,7 +333,11 @@ class Executor:
         # dl3p_head_train (loss + gradient resize in one launch, no (N,H,W,C) gradient in HBM) is bit-identical to the
         # two-kernel path but measured slower on MI355X (506 us vs 141 + 165 us at batch 16): opt-in, for memory
         zt = self.head.tensor
-        self.fused_head = bool(self.training and os.environ.get('DL3P_FUSED_HEAD', '0') != '0' and zt is not None and
+        self.class_weights = None
+        if self._loss_weights_host is not None:
+            assert self._loss_weights_host.shape == (self.C,), 'one class weight per class'
+            self.class_weights = torch.from_numpy(self._loss_weights_host).to(self.dev)
+        self.fused_head = bool(self.training and self.loss_kind == 0 and os.environ.get('DL3P_FUSED_HEAD', '0') != '0' and zt is not None and
                                zt.requires_grad and L.head_train_supported(zt.H, zt.W, self.C, H, W))
         self.dlogits_big = (torch.zeros(N * H * W * self.cpad, **self.f32)
                             if (self.training and not self.fused_head) else None)
@@ -457,8 +465,10 @@ class Executor:
                 ctypes.byref(rows), N, zt.H, zt.W, self.C, self.H, self.W)
             P.k(L.reduce_rows, self.loss_partials.data_ptr(), rows.value, 1, self.loss.data_ptr(), 0)
         elif train:
-            P.k(L.upsample_softmax_ce, self.tptr(zt), zt.ld, self.labels.data_ptr(), int(self.ignore_index or 0),
-                1.0 / float(N * self.H * self.W), None, None, self.dlogits_big.data_ptr(), self.cpad,
+            P.k(L.upsample_softmax_loss, self.tptr(zt), zt.ld, self.labels.data_ptr(), int(self.ignore_index or 0),
+                1.0 / float(N * self.H * self.W), self.loss_kind,
+                None if self.class_weights is None else self.class_weights.data_ptr(), self.loss_gamma, self.loss_alpha,
+                None, None, self.dlogits_big.data_ptr(), self.cpad,
                 self.loss_partials.data_ptr(), ctypes.byref(rows), N, zt.H, zt.W, self.C, self.H, self.W)
             P.k(L.reduce_rows, self.loss_partials.data_ptr(), rows.value, 1, self.loss.data_ptr(), 0)
         else:

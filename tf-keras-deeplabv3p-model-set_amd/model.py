@@ -94,6 +94,39 @@ class SparseCategoricalCrossEntropy(object):
         self.__name__ = 'sparse_categorical_crossentropy'
 
 
+class WeightedSparseCategoricalCrossEntropy(object):
+    """deeplabv3p/loss.py:159-191 (train.py:115, --weighted_type balanced): -w[y] * log(p_y)"""
+
+    def __init__(self, weights, ignore_index=None, from_logits=False):
+        if from_logits:
+            raise ValueError('the model emits probabilities (Softmax pred_mask); from_logits is not supported')
+        self.weights = np.array(weights).astype('float32')
+        self.ignore_index = ignore_index
+        self.from_logits = from_logits
+        self.__name__ = 'weighted_sparse_categorical_crossentropy'
+
+
+class SparseSoftmaxFocalLoss(object):
+    """deeplabv3p/loss.py:63-118 (train.py:131, --loss focal): -alpha * (1 - p_y)^gamma * log(p_y)"""
+
+    def __init__(self, gamma=2.0, alpha=0.25, ignore_index=None, from_logits=False):
+        if from_logits:
+            raise ValueError('the model emits probabilities (Softmax pred_mask); from_logits is not supported')
+        self.gamma, self.alpha = gamma, alpha
+        self.ignore_index = ignore_index
+        self.from_logits = from_logits
+        self.__name__ = 'sparse_softmax_focal_loss'
+
+
+def loss_spec(loss):
+    """-> ('ce',) | ('weighted', weights) | ('focal', gamma, alpha): what the head kernel (and the oracle) need"""
+    if isinstance(loss, WeightedSparseCategoricalCrossEntropy):
+        return ('weighted', loss.weights)
+    if isinstance(loss, SparseSoftmaxFocalLoss):
+        return ('focal', float(loss.gamma), float(loss.alpha))
+    return ('ce',)
+
+
 class DistContext:
     """one process per GPU; collectives are RCCL (torch.distributed backend 'nccl') over xGMI.
     Gradient buckets are all-reduced on a side HIP stream so that they overlap the rest of backward."""
@@ -255,7 +288,7 @@ class DeeplabModel:
             rank = self.dist.rank if self.dist is not None else 0
             self._exec[key] = Executor(self.graph, self.head, store, batch, training, self.num_classes,
                                        ignore_index=ignore, dist=self.dist if training else None,
-                                       seed=self.seed + 7919 * rank, momentum=mom)
+                                       seed=self.seed + 7919 * rank, momentum=mom, loss=loss_spec(self.loss))
         return self._exec[key]
 
     def train_on_batch(self, x, y, return_tensor=False):
