@@ -207,6 +207,9 @@ int dl3p_scale_bcast_bwd(const float* gy, int ldgy, const float* x, int ldx, con
                          int act, const float* s, int lds, int s_act, float* gx, int ldgx, int accumulate_gx,
                          float* gs, int ldgs, int N, int HW, int C, float* workspace, size_t workspace_bytes,
                          void* stream);
+/* dst[i] = (float)src[i] / divide_by - subtract: normalize_image (common/data_utils.py:403-417: /127.5 - 1) and the
+ * label cast (deeplabv3p/data.py:116-124: /1 - 0) for batches that arrive as bytes; bit-identical to NumPy float32 */
+int dl3p_u8_to_float(const unsigned char* src, float* dst, size_t n, float divide_by, float subtract, void* stream);
 int dl3p_fill(float* p, float value, size_t n, void* stream);
 int dl3p_increment_counter(int64_t* counter, void* stream);
 

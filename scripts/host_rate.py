@@ -22,3 +22,17 @@ for i in range(K):
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print('train_on_batch with host numpy batches: %.1f images/s (%.2f ms/step)' % (N * K / dt, 1e3 * dt / K))
+
+# the same with the bytes the generator decoded: uint8 pixels / uint8 labels, normalised on the device
+batches8 = [(rng.integers(0, 256, (N, H, W, 3)).astype(np.uint8), rng.integers(0, C, (N, H * W, 1)).astype(np.uint8))
+            for _ in range(3)]
+for i in range(4):
+    m.train_on_batch(*batches8[i % 3])
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(K):
+    m.train_on_batch(*batches8[i % 3])
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print('train_on_batch with host uint8 batches:  %.1f images/s (%.2f ms/step)' % (N * K / dt, 1e3 * dt / K))
+

@@ -367,3 +367,25 @@ def test_train_step_with_optional_losses(kind):
     w = m.get_weights_by_name()
     assert max(float(np.abs(v - o.net.params[k]).max()) for k, v in w.items()) < TOL
 
+
+def test_uint8_batches_are_normalised_on_the_device():
+    """train_on_batch / predict with uint8 pixels and uint8 labels == the same calls with the host-normalised float32
+    batch (`image / 127.5 - 1`, common/data_utils.py:403-417): bit-identical loss, weights and probabilities"""
+    pkg = load_pkg()
+    N, C, H, W = 2, 21, 65, 65
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 256, (N, H, W, 3)).astype(np.uint8)
+    lab = rng.integers(0, C, (N, H * W, 1)).astype(np.uint8)
+    lab[rng.uniform(size=lab.shape) < 0.05] = 255
+    xf = img.astype(np.float32) / 127.5 - 1.0
+    yf = lab.astype(np.float32)
+    out = []
+    for x, y in ((xf, yf), (img, lab)):
+        m = pkg.get_deeplabv3p_model('mobilenetv2_lite', C, (H, W), 16, training=True, seed=4)
+        m.compile(optimizer=pkg.SGD(0.01), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
+        losses = [m.train_on_batch(x, y) for _ in range(3)]          # eager step, capture, replay
+        out.append((losses, m.get_weights_by_name(), m.predict(x)))
+    assert out[0][0] == out[1][0]
+    assert all(np.array_equal(out[0][1][k], out[1][1][k]) for k in out[0][1])
+    assert np.array_equal(out[0][2], out[1][2])
+

@@ -534,6 +534,31 @@ extern "C" int dl3p_increment_counter(int64_t* counter, void* stream) {
   return DL3P_OK;
 }
 
+// ------------------------------------------------------------------------------ uint8 batches at the boundary
+// common/data_utils.py:403-417 normalize_image (`image.astype(np.float32) / 127.5 - 1.0`) and the label cast of
+// deeplabv3p/data.py:116-124 done on the device: the host hands over the bytes it decoded (a quarter of the PCIe
+// traffic of float32 batches).  True IEEE division, so the result is bit-identical to NumPy's.
+__global__ __launch_bounds__(256) void u8_to_float_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst,
+                                                          size_t n, float div, float sub) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const uchar4 v = *reinterpret_cast<const uchar4*>(src + i);
+    st4(dst + i, make_float4((float)v.x / div - sub, (float)v.y / div - sub, (float)v.z / div - sub, (float)v.w / div - sub));
+  } else {
+    for (size_t j = i; j < n; ++j) dst[j] = (float)src[j] / div - sub;
+  }
+}
+extern "C" int dl3p_u8_to_float(const unsigned char* src, float* dst, size_t n, float divide_by, float subtract,
+                                void* stream) {
+  DL3P_CHECK_ARG(src && dst && ((uintptr_t)src % 4 == 0) && aligned16(dst), "dl3p_u8_to_float: bad pointers");
+  if (n == 0) return DL3P_OK;
+  const size_t blocks = (n / 4 + 256) / 256;
+  hipLaunchKernelGGL(u8_to_float_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, n, divide_by,
+                     subtract);
+  DL3P_CHECK_LAUNCH("dl3p_u8_to_float");
+  return DL3P_OK;
+}
+
 // ------------------------------------------------------------------------------ global average pooling
 // Per-image reductions over HW pixels (pooling, SE-block backward).  Workgroups = (image, channel slab, pixel
 // chunk).  With one chunk the workgroup owns the whole image and stores the result; with several, each stores an

@@ -256,6 +256,7 @@ class Executor:
         self.N, self.training, self.C = batch, training, num_classes
         self.ignore_index = ignore_index
         # loss: ('ce',) | ('weighted', weights[C]) | ('focal', gamma, alpha)  (model.loss_spec)
+        self._u8 = {}
         self.loss_kind = {'ce': 0, 'weighted': 1, 'focal': 2}[loss[0]]
         self.loss_gamma, self.loss_alpha = (float(loss[1]), float(loss[2])) if loss[0] == 'focal' else (0.0, 0.0)
         self._loss_weights_host = np.asarray(loss[1], np.float32) if loss[0] == 'weighted' else None
@@ -779,13 +780,30 @@ class Executor:
         return P
 
     # ---------------------------------------------------------------- running
+    def _upload_u8(self, src, dst, div, sub, slot):
+        """bytes over PCIe, float32 on the device (dl3p_u8_to_float)"""
+        src = torch.as_tensor(src).reshape(-1)
+        stage = self._u8.get(slot)
+        if stage is None or stage.numel() != src.numel():
+            stage = self._u8[slot] = torch.empty(src.numel(), dtype=torch.uint8, device=self.dev)
+        stage.copy_(src, non_blocking=True)
+        self.L.u8_to_float(stage.data_ptr(), dst.data_ptr(), src.numel(), div, sub, torch.cuda.current_stream().cuda_stream)
+
     def set_inputs(self, x, y=None):
+        """x float32 in [-1, 1] -- or uint8 pixels, normalised on the device like normalize_image does on the host
+        (common/data_utils.py:403-417); y float / integer class ids, uint8 accepted the same way"""
         inp = self.buf[self.g.input.tensor.id]
-        x = torch.as_tensor(x, dtype=torch.float32)
-        inp.copy_(x.reshape(-1), non_blocking=True)
+        if getattr(x, 'dtype', None) in (np.uint8, torch.uint8):
+            self._upload_u8(x, inp, 127.5, 1.0, 'x')
+        else:
+            x = torch.as_tensor(x, dtype=torch.float32)
+            inp.copy_(x.reshape(-1), non_blocking=True)
         if y is not None:
-            y = torch.as_tensor(y, dtype=torch.float32)
-            self.labels.copy_(y.reshape(-1), non_blocking=True)
+            if getattr(y, 'dtype', None) in (np.uint8, torch.uint8):
+                self._upload_u8(y, self.labels, 1.0, 0.0, 'y')
+            else:
+                y = torch.as_tensor(y, dtype=torch.float32)
+                self.labels.copy_(y.reshape(-1), non_blocking=True)
 
     def capture(self):
         """capture the traced plans into hipGraphs (done once, after a warm-up eager step)"""

@@ -313,7 +313,9 @@ class DeeplabModel:
         """probabilities (B,H*W,C) for a training-shaped model, (B,H,W,C) otherwise (eval.py:33-36)"""
         if isinstance(x, (list, tuple)):
             x = x[0]
-        x = np.asarray(x, dtype=np.float32)
+        x = np.asarray(x)
+        if x.dtype != np.uint8:                 # uint8 pixels are normalised on the device (Executor.set_inputs)
+            x = x.astype(np.float32, copy=False)
         B = x.shape[0]
         ex = self._executor(B, False)
         ex.set_inputs(x)
@@ -524,9 +526,10 @@ def _evaluate_miou(self, gen, steps=None, class_names=None, verbose=0):
     cm = torch.zeros(C * C, dtype=torch.int64, device='cuda')
     for i in range(n):
         x, y = gen[i][0], gen[i][1]
-        x = np.asarray(x, dtype=np.float32)
+        x, y = np.asarray(x), np.asarray(y)
         ex = self._executor(x.shape[0], False)
-        ex.set_inputs(x, np.asarray(y, dtype=np.float32))
+        ex.set_inputs(x if x.dtype == np.uint8 else x.astype(np.float32, copy=False),
+                      y if y.dtype == np.uint8 else y.astype(np.float32, copy=False))
         ex.eval_step(cm)
     res = miou_from_confusion(cm.view(C, C).cpu().numpy(), class_names)
     if verbose:
