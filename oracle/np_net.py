@@ -94,11 +94,12 @@ class Net:
         self.grads[name] = g if name not in self.grads else self.grads[name] + g
 
     # ---- layers -----------------------------------------------------------------------
-    def conv2d(self, x, filters, k, name, stride=1, rate=1, padding='same', use_bias=False):
-        """DeeplabConv2D (layers.py:14-21): glorot_uniform kernel, zero bias, l2(2e-5) on both."""
+    def conv2d(self, x, filters, k, name, stride=1, rate=1, padding='same', use_bias=False, he_normal=False):
+        """DeeplabConv2D (layers.py:14-21): glorot_uniform kernel (he_normal in ResNet50), zero bias, l2(2e-5) on both."""
         cin = x.v.shape[-1]
-        w = self.param(name + '/kernel', (k, k, cin, filters),
-                       lambda s: O.glorot_uniform(self.rng, s, k * k * cin, k * k * filters), l2=O.L2_FACTOR)
+        init = ((lambda s: O.he_normal(self.rng, s, k * k * cin)) if he_normal else
+                (lambda s: O.glorot_uniform(self.rng, s, k * k * cin, k * k * filters)))
+        w = self.param(name + '/kernel', (k, k, cin, filters), init, l2=O.L2_FACTOR)
         b = self.param(name + '/bias', (filters,), np.zeros, l2=O.L2_FACTOR) if use_bias else None
         y = Var(O.conv2d_fwd(x.v, w, stride, rate, padding, b))
         need_gx = True
@@ -256,6 +257,18 @@ class Net:
             for x, s in zip(xs, sizes):
                 x.acc(y.g[..., o:o + s])
                 o += s
+        self.tape.append(bwd)
+        return y
+
+    def maxpool2d(self, x, k, stride, pad):
+        """ZeroPadding2D(pad) + MaxPooling2D((k,k), strides) (deeplabv3p_resnet50.py:266-267)"""
+        yv, arg = O.maxpool2d_fwd(x.v, k, stride, pad)
+        y = Var(yv)
+        shape = x.v.shape
+
+        def bwd():
+            if y.g is not None:
+                x.acc(O.maxpool2d_bwd(y.g, arg, shape, k, stride, pad))
         self.tape.append(bwd)
         return y
 
@@ -538,7 +551,53 @@ def os_table(OS):
 
 
 MODEL_TYPES = ('mobilenetv2', 'mobilenetv2_lite', 'xception', 'mobilenetv3large', 'mobilenetv3large_lite',
-               'mobilenetv3small', 'mobilenetv3small_lite')
+               'mobilenetv3small', 'mobilenetv3small_lite', 'resnet50')
+
+
+def _resnet50_body(self, x, OS):
+    """deeplabv3p_resnet50.py: identity_block :32-75, conv_block :78-139, body :262-292 (stem conv1_pad + 7x7 s2 valid,
+    pool1_pad + MaxPooling2D(3, 2), stages 2-5 with the output-stride table :208-226); every conv has a bias and is
+    followed by BatchNormalization with the Keras defaults"""
+    s16, r16, s32, r32 = os_table(OS)
+
+    def cbn(x, f, k, cn, bn, stride=1, rate=1, padding='same'):
+        x = self.conv2d(x, f, k, cn, stride=stride, rate=rate, padding=padding, use_bias=True, he_normal=True)
+        return self.bn(x, bn, 1e-3, 0.99)
+
+    def identity(x, filters, stage, block, rate=1):
+        cn, bn = 'res%d%s_branch' % (stage, block), 'bn%d%s_branch' % (stage, block)
+        y = self.relu(cbn(x, filters[0], 1, cn + '2a', bn + '2a'))
+        y = self.relu(cbn(y, filters[1], 3, cn + '2b', bn + '2b', rate=rate))
+        y = cbn(y, filters[2], 1, cn + '2c', bn + '2c')
+        return self.relu(self.add(y, x))
+
+    def conv(x, filters, stage, block, strides=2, rate=1):
+        cn, bn = 'res%d%s_branch' % (stage, block), 'bn%d%s_branch' % (stage, block)
+        y = self.relu(cbn(x, filters[0], 1, cn + '2a', bn + '2a', stride=strides, padding='valid'))
+        y = self.relu(cbn(y, filters[1], 3, cn + '2b', bn + '2b', rate=rate))
+        y = cbn(y, filters[2], 1, cn + '2c', bn + '2c')
+        sc = cbn(x, filters[2], 1, cn + '1', bn + '1', stride=strides, padding='valid')
+        return self.relu(self.add(y, sc))
+
+    x = self.relu(cbn(x, 64, 7, 'conv1', 'bn_conv1', stride=2, padding=(3, 3, 3, 3)))
+    x = self.maxpool2d(x, 3, 2, (1, 1, 1, 1))
+    x = conv(x, [64, 64, 256], 2, 'a', strides=1)
+    x = identity(x, [64, 64, 256], 2, 'b')
+    x = identity(x, [64, 64, 256], 2, 'c')
+    skip = x
+    x = conv(x, [128, 128, 512], 3, 'a')
+    for b in 'bcd':
+        x = identity(x, [128, 128, 512], 3, b)
+    x = conv(x, [256, 256, 1024], 4, 'a', strides=s16)
+    for b in 'bcdef':
+        x = identity(x, [256, 256, 1024], 4, b, rate=r16)
+    x = conv(x, [512, 512, 2048], 5, 'a', strides=s32, rate=r16)
+    for b in 'bc':
+        x = identity(x, [512, 512, 2048], 5, b, rate=r32)
+    return x, skip
+
+
+Net.resnet50_body = _resnet50_body
 
 
 def _mobilenetv3small_body(self, x, OS):
@@ -612,6 +671,8 @@ class OracleModel:
             f, skip = net.mobilenetv2_body(xin, self.OS)
         elif self.model_type == 'xception':
             f, skip = net.xception_body(xin, self.OS)
+        elif self.model_type == 'resnet50':
+            f, skip = net.resnet50_body(xin, self.OS)
         elif self.model_type.startswith('mobilenetv3small'):
             f, skip = net.mobilenetv3small_body(xin, self.OS)
         else:

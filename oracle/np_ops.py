@@ -241,6 +241,31 @@ def global_avgpool_bwd(gy, H, W):
     return np.broadcast_to(gy / (H * W), (gy.shape[0], H, W, gy.shape[3])).copy()
 
 
+def maxpool2d_fwd(x, k, stride, pad):
+    """ZeroPadding2D(pad) + MaxPooling2D((k,k), strides, 'valid') (deeplabv3p_resnet50.py:266-267); pad = (top, bottom,
+    left, right).  returns (y, argmax) with argmax the flat index of the first maximum inside each window"""
+    pt, pb, pl, pr = pad
+    xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+    N, Hp, Wp, C = xp.shape
+    Ho, Wo = (Hp - k) // stride + 1, (Wp - k) // stride + 1
+    win = np.stack([xp[:, ky:ky + (Ho - 1) * stride + 1:stride, kx:kx + (Wo - 1) * stride + 1:stride, :]
+                    for ky in range(k) for kx in range(k)], axis=-1)          # (N,Ho,Wo,C,k*k)
+    arg = win.argmax(-1)                                                      # first maximum in (ky, kx) order
+    return np.take_along_axis(win, arg[..., None], -1)[..., 0], arg
+
+
+def maxpool2d_bwd(gy, arg, x_shape, k, stride, pad):
+    pt, pb, pl, pr = pad
+    N, H, W, C = x_shape
+    gp = np.zeros((N, H + pt + pb, W + pl + pr, C), dtype=gy.dtype)
+    Ho, Wo = gy.shape[1:3]
+    for t in range(k * k):
+        ky, kx = divmod(t, k)
+        sel = np.where(arg == t, gy, 0)
+        gp[:, ky:ky + (Ho - 1) * stride + 1:stride, kx:kx + (Wo - 1) * stride + 1:stride, :] += sel
+    return gp[:, pt:pt + H, pl:pl + W, :]                                     # the padding's share is dropped
+
+
 def bilinear_coeffs(in_size, out_size):
     """tf.image.resize(method='bilinear') in TF2: half_pixel_centers=True, align_corners=False,
     antialias=False.  Source coordinate arithmetic is done in float32 exactly as TF's
@@ -416,6 +441,17 @@ def sgd_momentum_step(w, v, g, lr, momentum, l2=0.0):
 def glorot_uniform(rng, shape, fan_in, fan_out, dtype=np.float64):
     limit = math.sqrt(6.0 / (fan_in + fan_out))
     return rng.uniform(-limit, limit, size=shape).astype(dtype)
+
+
+def he_normal(rng, shape, fan_in, dtype=np.float64):
+    """Keras he_normal = VarianceScaling(2, 'fan_in', 'truncated_normal') (deeplabv3p_resnet50.py: every conv)"""
+    std = math.sqrt(2.0 / fan_in) / 0.87962566103423978
+    out = rng.standard_normal(size=shape)
+    bad = np.abs(out) > 2.0
+    while bad.any():
+        out[bad] = rng.standard_normal(size=int(bad.sum()))
+        bad = np.abs(out) > 2.0
+    return (out * std).astype(dtype)
 
 
 # ---------------------------------------------------------------------------------------- evaluation (eval.py)

@@ -97,7 +97,7 @@ def _rel(a, b):
 @pytest.mark.parametrize('model_type,H,W', [('mobilenetv2', 65, 65), ('mobilenetv2_lite', 65, 97), ('xception', 65, 65),
                                             ('mobilenetv3large', 65, 65), ('mobilenetv3large', 64, 96),
                                             ('mobilenetv3small', 65, 65), ('mobilenetv3small_lite', 64, 96),
-                                            ('mobilenetv3large_lite', 65, 65)])
+                                            ('mobilenetv3large_lite', 65, 65), ('resnet50', 65, 65), ('resnet50', 64, 96)])
 def test_predict_matches_oracle(model_type, H, W):
     m, o = _pair(model_type, H, W, 21, training=False)
     x, _ = _data(2, H, W, 21)
@@ -117,10 +117,14 @@ def test_predict_matches_oracle(model_type, H, W):
                                                       ('mobilenetv3large', 65, 65, 0, 16), ('mobilenetv3large', 64, 96, 0, 16),
                                                       ('mobilenetv3small', 65, 65, 0, 16), ('mobilenetv3small_lite', 65, 65, 0, 16),
                                                       ('mobilenetv3large_lite', 65, 65, 0, 16),
+                                                      ('resnet50', 65, 65, 0, 16), ('resnet50', 65, 65, 0, 8),
                                                       # output stride 8 (BASELINE configs[3]): denser atrous grid, ASPP rates 12/24/36
                                                       ('mobilenetv2', 65, 65, 0, 8), ('xception', 97, 97, 0, 8)])
 def test_train_step_matches_oracle(model_type, H, W, freeze, OS):
-    N, C = 2, 21
+    # batch 4 for ResNet50: with 2 images the image-pooling BatchNorm normalises 2 samples per channel, its input
+    # gradient cancels exactly in exact arithmetic, and fp32 leaves noise of 1e-2 of the backbone gradient (2048
+    # channels feed it); at batch 4 the worst tensor is at 4e-4
+    N, C = (4 if model_type == 'resnet50' else 2), 21
     m, o = _pair(model_type, H, W, C, OS=OS, freeze_level=freeze)
     m.use_graphs = False
     x, y = _data(N, H, W, C, seed=3)

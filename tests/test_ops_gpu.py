@@ -573,3 +573,31 @@ def test_argmax_confusion(ops, case):
     only_mask, none = ops.argmax_confusion(zt, C, H, W, want_mask=True)
     assert none is None and np.array_equal(only_mask.cpu().numpy(), got)
 
+
+@pytest.mark.parametrize('case', [(2, 33, 33, 64, 3, 2, (1, 1, 1, 1)), (1, 16, 22, 8, 3, 2, (1, 1, 1, 1)), (2, 9, 9, 12, 2, 2, (0, 0, 0, 0)),
+                                  (1, 12, 10, 4, 3, 1, (1, 1, 1, 1))])
+def test_maxpool2d(ops, case):
+    """ZeroPadding2D + MaxPooling2D (deeplabv3p_resnet50.py:266-267) with the BN + ReLU prologue, forward and backward"""
+    N, H, W, C, k, s, pad = case
+    rng = np.random.default_rng(H + C)
+    x = rng.standard_normal((N, H, W, C))
+    sc = rng.uniform(0.5, 1.5, C); sh = rng.standard_normal(C) * 0.3
+    a = O.act_fwd(x * sc + sh, O.ACT_RELU)                 # many exact zeros: ties with the zero padding
+    y_ref, arg = O.maxpool2d_fwd(a, k, s, pad)
+    y = ops.maxpool2d_fwd(T(x), k, s, pad, T(sc), T(sh), ops.ACT_RELU)
+    close(y, y_ref, what='maxpool fwd')
+    gy = rng.standard_normal(y_ref.shape)
+    g_ref = O.maxpool2d_bwd(gy, arg, x.shape, k, s, pad)
+    gx = ops.maxpool2d_bwd(T(x), T(gy), k, s, pad, T(sc), T(sh), ops.ACT_RELU)
+    # gradient routed to a zero (ReLU-dead or padding) position is arbitrary among the tied zeros in Keras too and is
+    # killed by the ReLU backward: compare where the activation is alive
+    alive = a > 0
+    assert np.abs(np.where(alive, gx.cpu().numpy() - g_ref, 0)).max() < 1e-6
+    base = rng.standard_normal(x.shape)
+    gx2 = ops.maxpool2d_bwd(T(x), T(gy), k, s, pad, T(sc), T(sh), ops.ACT_RELU, out=T(base), accumulate=True)
+    assert np.abs((gx2 - gx).cpu().numpy() - base).max() < 1e-5
+    raw, arg_raw = O.maxpool2d_fwd(x, k, s, pad)           # no prologue: negative inputs lose against the padded zeros
+    close(ops.maxpool2d_fwd(T(x), k, s, pad), raw, what='maxpool fwd, bare')
+    g_raw = O.maxpool2d_bwd(gy, arg_raw, x.shape, k, s, pad)
+    close(ops.maxpool2d_bwd(T(x), T(gy), k, s, pad), g_raw, what='maxpool bwd, bare (no ties)')
+

@@ -15,11 +15,12 @@ KNOWN = {'mobilenetv2_lite': (2113557, 33088, 54), 'mobilenetv2': (2719813, 3878
          # README.md:317 pins MobileNetV3Small Lite at 1.06 M parameters (its table counts the trainable ones: MobileNetV2
          # Lite 2.11 M = 2113557); the other two rows have no published figure and pin oracle == product only
          'mobilenetv3small_lite': (1057717, 12496, 36), 'mobilenetv3small': (1484165, 16848, 47),
-         'mobilenetv3large_lite': (3036357, 24016, 48)}
+         'mobilenetv3large_lite': (3036357, 24016, 48),
+         'resnet50': (26722693, 70720, 67)}                  # README.md:314: 26.72 M
 
 
 @pytest.mark.parametrize('mt', ['mobilenetv2_lite', 'mobilenetv2', 'mobilenetv3large', 'mobilenetv3small_lite',
-                                'mobilenetv3small', 'mobilenetv3large_lite'])
+                                'mobilenetv3small', 'mobilenetv3large_lite', 'resnet50'])
 def test_oracle_param_counts(mt):
     from oracle.np_net import OracleModel
     m = OracleModel(mt, 21, (33, 33), 16)
@@ -28,6 +29,8 @@ def test_oracle_param_counts(mt):
     assert m.net.n_params(False) == ntr
     if mt == 'mobilenetv3small_lite':
         assert round(tr / 1e6, 2) == 1.06               # README.md:317
+    if mt == 'resnet50':
+        assert round(tr / 1e6, 2) == 26.72              # README.md:314
     assert sum(1 for n in m.net.order if n.endswith('/gamma')) == nbn
 
 
@@ -36,7 +39,7 @@ def _product_models():
 
 
 @pytest.mark.parametrize('mt', ['mobilenetv2_lite', 'mobilenetv2', 'xception', 'mobilenetv3large', 'mobilenetv3small_lite',
-                                'mobilenetv3small', 'mobilenetv3large_lite'])
+                                'mobilenetv3small', 'mobilenetv3large_lite', 'resnet50'])
 def test_product_param_counts_and_names_match_oracle(mt):
     pkg = load_pkg()
     if mt not in pkg.deeplab_model_map:

@@ -370,7 +370,7 @@ class Executor:
                 setrg(op.z, op.layer.trainable)
             elif k == 'materialize':
                 setrg(op.out, rg(op.x) or (op.r is not None and rg(op.r)))
-            elif k in ('gap', 'resize', 'broadcast'):
+            elif k in ('gap', 'resize', 'broadcast', 'maxpool'):
                 setrg(op.out, rg(op.x))
             elif k == 'se_mul':
                 setrg(op.out, rg(op.x) or rg(op.s))
@@ -445,6 +445,11 @@ class Executor:
                 xt = op.x.tensor
                 P.k(L.global_avgpool_fwd, xp, ldx, sp, hp, act, self.tptr(op.out), op.out.ld, 1.0, N, xt.H * xt.W,
                     xt.C, self.pool_ws.data_ptr(), self.pool_wsb)
+            elif k == 'maxpool':
+                xp, ldx, sp, hp, act = self.vargs(op.x)
+                xt, t = op.x.tensor, op.out
+                P.k(L.maxpool2d_fwd, xp, ldx, sp, hp, act, self.tptr(t), t.ld, N, xt.H, xt.W, xt.C, op.k, op.stride,
+                    op.pad_t, op.pad_l, op.Ho, op.Wo)
             elif k == 'se_mul':
                 xp, ldx, sp, hp, act = self.vargs(op.x)
                 s_ptr, lds, _, _, sact = self.vargs(op.s)
@@ -658,6 +663,12 @@ class Executor:
                 assert self._acc(keys) == 0, 'SE scale gradient has a single producer'
                 P.k(L.scale_bcast_bwd, self.tptr(out, True), out.ld, xp, ldx, sp, hp, act, s_ptr, lds, sact, gp, ldg,
                     self._acc(keyx), gsp, ldgs, N, out.H * out.W, out.C, self.pool_ws.data_ptr(), self.pool_wsb)
+            elif k == 'maxpool':
+                xp, ldx, sp, hp, act = self.vargs(op.x)
+                xt = op.x.tensor
+                gp, ldg, keyt = self._gbuf(op.x)
+                P.k(L.maxpool2d_bwd, xp, ldx, sp, hp, act, self.tptr(out, True), out.ld, gp, ldg, self._acc(keyt), N,
+                    xt.H, xt.W, xt.C, op.k, op.stride, op.pad_t, op.pad_l, op.Ho, op.Wo)
             elif k == 'gap':
                 xt = op.x.tensor
                 gp, ldg, keyt = self._gbuf(op.x)

@@ -166,6 +166,18 @@ def glorot_uniform(rng, shape, fan_in, fan_out):
     return rng.uniform(-limit, limit, size=shape).astype(np.float32)
 
 
+def he_normal(rng, shape, fan_in):
+    """Keras `he_normal` = VarianceScaling(2, 'fan_in', 'truncated_normal'): N(0, s) cut at +-2 s with
+    s = sqrt(2 / fan_in) / 0.87962566103423978 (so that the truncated law has variance 2 / fan_in)"""
+    std = math.sqrt(2.0 / fan_in) / 0.87962566103423978
+    out = rng.standard_normal(size=shape)
+    bad = np.abs(out) > 2.0
+    while bad.any():
+        out[bad] = rng.standard_normal(size=int(bad.sum()))
+        bad = np.abs(out) > 2.0
+    return (out * std).astype(np.float32)
+
+
 class GraphBuilder:
     """records layers / ops while the model functions (layers.py, mobilenetv2.py, ...) run"""
 
@@ -193,7 +205,7 @@ class GraphBuilder:
             base = {'ReLU': 're_lu', 'Add': 'add', 'Concatenate': 'concatenate', 'Dropout': 'dropout',
                     'ZeroPadding2D': 'zero_padding2d', 'AveragePooling2D': 'average_pooling2d',
                     'Activation': 'activation', 'Multiply': 'multiply', 'Reshape': 'reshape',
-                    'GlobalAveragePooling2D': 'global_average_pooling2d'}.get(kind, kind.lower())
+                    'GlobalAveragePooling2D': 'global_average_pooling2d', 'MaxPooling2D': 'max_pooling2d'}.get(kind, kind.lower())
             n = sum(1 for l in self.layers if l.kind == kind and l.name.startswith(base))
             name = base if n == 0 else '%s_%d' % (base, n)
         assert name not in self.layer_by_name, 'duplicate layer name ' + name
@@ -218,8 +230,9 @@ class GraphBuilder:
 
     # ---- Keras layers -----------------------------------------------------------------
     def conv2d(self, x, filters, k, name, stride=1, rate=1, padding='same', use_bias=False, out=None,
-               pad_to=None):
-        """DeeplabConv2D (reference layers.py:14-21): glorot_uniform kernel, zero bias, l2(2e-5) on both"""
+               pad_to=None, kernel_initializer='glorot_uniform'):
+        """DeeplabConv2D (reference layers.py:14-21): glorot_uniform kernel (he_normal in the ResNet50 backbone), zero
+        bias, l2(2e-5) on both"""
         H, W, cin = x.shape
         if not isinstance(padding, str):
             self.add_layer(None, 'ZeroPadding2D')
@@ -229,9 +242,11 @@ class GraphBuilder:
         # dense (k > 1) kernels are stored as the im2col GEMM operand [k*k*cin padded to a multiple of 4][cout]
         kp = (k * k * cin + 3) // 4 * 4
         dev_shape = (k, k, cin, cdev) if k == 1 else (kp, cdev)
-        wp = layer.add_param('kernel', (k, k, cin, filters),
-                             lambda s: glorot_uniform(self.rng, s, k * k * cin, k * k * filters), l2=L2_FACTOR,
-                             dev_shape=dev_shape)
+        if kernel_initializer == 'he_normal':
+            init = lambda s: he_normal(self.rng, s, k * k * cin)
+        else:
+            init = lambda s: glorot_uniform(self.rng, s, k * k * cin, k * k * filters)
+        wp = layer.add_param('kernel', (k, k, cin, filters), init, l2=L2_FACTOR, dev_shape=dev_shape)
         bp = None
         if use_bias:
             bp = layer.add_param('bias', (filters,), lambda s: np.zeros(s, np.float32), l2=L2_FACTOR,
@@ -351,6 +366,18 @@ class GraphBuilder:
         self.add_layer(name, 'Multiply', (H, W, C))
         out = self.new_tensor(H, W, C, name or ('semul_' + x.tensor.name))
         self.ops.append(Op('se_mul', name=out.name, x=x, s=s, out=out))
+        return Value(out)
+
+    def maxpool2d(self, v, k, stride, pad, name=None, pad_name=None):
+        """ZeroPadding2D(pad) + MaxPooling2D((k,k), strides) (reference deeplabv3p_resnet50.py:266-267)"""
+        H, W, C = v.shape
+        pt, pb, pl, pr = pad
+        if any(pad):
+            self.add_layer(pad_name, 'ZeroPadding2D')
+        Ho, Wo = (H + pt + pb - k) // stride + 1, (W + pl + pr - k) // stride + 1
+        layer = self.add_layer(name, 'MaxPooling2D', (Ho, Wo, C))
+        out = self.new_tensor(Ho, Wo, C, layer.name)
+        self.ops.append(Op('maxpool', name=layer.name, x=v, out=out, k=k, stride=stride, pad_t=pt, pad_l=pl, Ho=Ho, Wo=Wo))
         return Value(out)
 
     def global_avgpool(self, v, name=None, kind='AveragePooling2D'):

@@ -41,6 +41,11 @@ def _register_optional():
         deeplab_model_map['mobilenetv3small_lite'] = partial(Deeplabv3pLiteMobileNetV3Small, alpha=1.0)
     except ImportError:
         pass
+    try:
+        from .resnet50 import Deeplabv3pResNet50
+        deeplab_model_map['resnet50'] = Deeplabv3pResNet50
+    except ImportError:
+        pass
 
 
 _register_optional()
