@@ -179,9 +179,18 @@ def main():
                                'shape': 'N=%d %dx%dx%d k=%d rate=%d' % (N, t.H, t.W, op.c, op.k, op.rate)}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)
-        print(json.dumps(out), flush=True)
     if torch.distributed.is_initialized():
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        # native libraries (RCCL's version banner) write through C stdio: flush their buffer first so that the JSON
+        # line is the last thing on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':
