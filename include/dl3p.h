@@ -295,6 +295,16 @@ int dl3p_reduce_rows(const float* partials, int rows, size_t n, float* out, int 
 int dl3p_sgd_momentum(float* w, float* v, const float* g, size_t n, const float* lr_dev, float momentum,
                       float l2, float grad_scale, const float* l2_elem, const float* lr_scale_elem, void* stream);
 
+/* Keras Adam(epsilon=1e-7) and RMSprop(rho=0.9, momentum=0, epsilon=1e-7, centered=False) (common/model_utils.py:118-121,
+ * train.py --optimizer) on the same flat buffers and with the same folded regulariser / freeze mask as above:
+ *   adam:    m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2; w -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps), t = *step_counter
+ *   rmsprop: v = rho v + (1-rho) g'^2; w -= lr * g' / sqrt(v + eps) */
+int dl3p_adam_step(float* w, float* m, float* v, const float* g, size_t n, const float* lr_dev,
+                   const int64_t* step_counter, float beta_1, float beta_2, float epsilon, float grad_scale,
+                   const float* l2_elem, const float* lr_scale_elem, void* stream);
+int dl3p_rmsprop_step(float* w, float* v, const float* g, size_t n, const float* lr_dev, float rho, float epsilon,
+                      float grad_scale, const float* l2_elem, const float* lr_scale_elem, void* stream);
+
 /* ---------------------------------------------------------------- measurement hook
  * dl3p_probe_arm(i): the NEXT depthwise-forward or pointwise-GEMM kernel launch of the calling thread is issued with a pair of HIP
  * events (hipExtLaunchKernelGGL start/stop events on the launch stream) stored in slot i (0 <= i < 4096);

@@ -727,8 +727,10 @@ class OracleModel:
         self.last_probs = probs
         return ce + reg, ce, logits.v
 
-    def sgd_step(self, lr=1e-2, momentum=0.9):
+    def sgd_step(self, lr=1e-2, momentum=0.9, optimizer='sgd'):
+        """one optimiser step: 'sgd' (momentum), 'adam', 'rmsprop' (common/model_utils.py:118-124)"""
         net = self.net
+        self.iterations = getattr(self, 'iterations', 0) + 1
         for n in self.trainable_param_names():
             g = net.grads.get(n)
             if g is None:
@@ -736,7 +738,16 @@ class OracleModel:
             v = self.velocity.get(n)
             if v is None:
                 v = np.zeros_like(net.params[n])
-            net.params[n], self.velocity[n] = O.sgd_momentum_step(net.params[n], v, g, lr, momentum, net.l2[n])
+            if optimizer == 'adam':
+                m = getattr(self, 'moment1', None)
+                if m is None:
+                    m = self.moment1 = {}
+                m1 = m.get(n, np.zeros_like(net.params[n]))
+                net.params[n], m[n], self.velocity[n] = O.adam_step(net.params[n], m1, v, g, self.iterations, lr, l2=net.l2[n])
+            elif optimizer == 'rmsprop':
+                net.params[n], self.velocity[n] = O.rmsprop_step(net.params[n], v, g, lr, l2=net.l2[n])
+            else:
+                net.params[n], self.velocity[n] = O.sgd_momentum_step(net.params[n], v, g, lr, momentum, net.l2[n])
         for n, val in net.moving_updates.items():
             net.params[n] = val
 

@@ -443,6 +443,22 @@ def glorot_uniform(rng, shape, fan_in, fan_out, dtype=np.float64):
     return rng.uniform(-limit, limit, size=shape).astype(dtype)
 
 
+def adam_step(w, m, v, g, t, lr, beta_1=0.9, beta_2=0.999, epsilon=1e-7, l2=0.0):
+    """Keras 2.11 Adam (common/model_utils.py:119): t = 1-based iteration; the l2 regulariser gradient 2*l2*w is part of g"""
+    g = g + 2.0 * l2 * w
+    m = beta_1 * m + (1.0 - beta_1) * g
+    v = beta_2 * v + (1.0 - beta_2) * g * g
+    alpha = lr * math.sqrt(1.0 - beta_2 ** t) / (1.0 - beta_1 ** t)
+    return w - alpha * m / (np.sqrt(v) + epsilon), m, v
+
+
+def rmsprop_step(w, v, g, lr, rho=0.9, epsilon=1e-7, l2=0.0):
+    """Keras 2.11 RMSprop(momentum=0, centered=False) (common/model_utils.py:121): w -= lr * g * rsqrt(v + eps)"""
+    g = g + 2.0 * l2 * w
+    v = rho * v + (1.0 - rho) * g * g
+    return w - lr * g / np.sqrt(v + epsilon), v
+
+
 def he_normal(rng, shape, fan_in, dtype=np.float64):
     """Keras he_normal = VarianceScaling(2, 'fan_in', 'truncated_normal') (deeplabv3p_resnet50.py: every conv)"""
     std = math.sqrt(2.0 / fan_in) / 0.87962566103423978

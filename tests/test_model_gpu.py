@@ -393,3 +393,45 @@ def test_uint8_batches_are_normalised_on_the_device():
     assert all(np.array_equal(out[0][1][k], out[1][1][k]) for k in out[0][1])
     assert np.array_equal(out[0][2], out[1][2])
 
+
+@pytest.mark.parametrize('kind', ['adam', 'rmsprop'])
+def test_adam_and_rmsprop_step_matches_oracle(kind):
+    """get_optimizer('adam' | 'rmsprop', ...) (common/model_utils.py:118-121, train.py --optimizer) through a model: the
+    first update against the oracle's Keras 2.11 rules.  The first Adam / RMSprop step moves a weight by ~lr * sign(g)
+    whatever |g| is, so weights whose gradient is rounding noise are left out of the comparison (the kernels' arithmetic
+    over many steps is checked exactly in test_ops_gpu.py::test_adam_rmsprop_kernels)."""
+    pkg = load_pkg()
+    N, C, H, W = 2, 21, 65, 65
+    m, o = _pair('mobilenetv2_lite', H, W, C)
+    lr = 1e-3
+    m.compile(optimizer=pkg.get_optimizer(kind, lr, decay_type=None), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
+    m.use_graphs = False
+    w0 = {k: v.copy() for k, v in m.get_weights_by_name().items()}
+    x, y = _data(N, H, W, C, seed=20)
+    loss = m.train_on_batch(x, y)
+    ex = m._executor(N, True)
+    drop = [op for op in m.graph.ops if op.kind == 'materialize' and op.rate > 0][0]
+    mask = ex.dropout_mask(drop).cpu().numpy()
+    o.net.act_derivs = _act_derivs(m, ex)
+    o.net.act_derivs_seq = _act_derivs_seq(m, ex, o.net.act_derivs)
+    total, ce, _ = o.loss_and_grads(x, y, {'aspp_dropout': mask})
+    assert abs(loss - ce) < TOL * max(1.0, abs(ce)), (loss, ce)
+    grads = {k: v.copy() for k, v in o.net.grads.items()}
+    o.sgd_step(lr, optimizer=kind)
+    w1 = m.get_weights_by_name()
+    checked = 0
+    for k in w1:
+        g = grads.get(k)
+        if g is None or k.endswith(('moving_mean', 'moving_variance')):
+            continue
+        g = g + 2 * o.net.l2[k] * w0[k]
+        # gradient well above fp32 rounding noise.  (Whole tensors can be noise: a BN beta in front of a conv + BN pair
+        # has an exactly zero gradient -- the next BN removes the shift -- and Adam turns the fp32 residue into steps.)
+        solid = np.abs(g) > max(5e-2 * np.abs(g).max(), 1e-5)      # fp32 noise is ~5e-3 of a tensor's largest gradient
+        if solid.any():
+            d_dev, d_ref = (w1[k] - w0[k])[solid], (o.net.params[k] - w0[k])[solid]
+            tol = 2e-2 * max(lr, float(np.abs(d_ref).max()))      # RMSprop's first step is lr / sqrt(1 - rho) = 3.2 lr
+            assert np.abs(d_dev - d_ref).max() < tol, (k, float(np.abs(d_dev - d_ref).max()))
+            assert np.abs(d_ref).max() > 0.5 * lr                   # ~lr per weight, as Adam / RMSprop do at t = 1
+            checked += int(solid.sum())
+    assert checked > 1e5, checked

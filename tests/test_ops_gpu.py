@@ -601,3 +601,37 @@ def test_maxpool2d(ops, case):
     g_raw = O.maxpool2d_bwd(gy, arg_raw, x.shape, k, s, pad)
     close(ops.maxpool2d_bwd(T(x), T(gy), k, s, pad), g_raw, what='maxpool bwd, bare (no ties)')
 
+
+def test_adam_rmsprop_kernels(ops):
+    """dl3p_adam_step / dl3p_rmsprop_step over 6 steps == the oracle's Keras 2.11 rules (bias correction from the device
+    step counter, folded l2 term, frozen elements untouched)"""
+    rng = np.random.default_rng(2)
+    n = 10007
+    L = ops.lib()
+    w0 = rng.standard_normal(n); l2 = np.where(rng.uniform(size=n) < 0.5, 2e-5, 0.0); frozen = rng.uniform(size=n) < 0.1
+    lre = np.where(frozen, 0.0, 1.0)
+    st = ops._stream()
+    for kind in ('adam', 'rmsprop'):
+        w = T(w0); m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)
+        wr, mr, vr = w0.copy(), np.zeros(n), np.zeros(n)
+        lr = torch.tensor([1e-3], dtype=torch.float32, device=DEV)
+        step = torch.zeros(1, dtype=torch.int64, device=DEV)
+        l2t, lret = T(l2), T(lre)
+        for t in range(1, 7):
+            g = rng.standard_normal(n) * 10.0 ** rng.uniform(-6, 0, n)
+            gt = T(g)
+            step += 1
+            if kind == 'adam':
+                L.adam_step(w.data_ptr(), m.data_ptr(), v.data_ptr(), gt.data_ptr(), n, lr.data_ptr(), step.data_ptr(), 0.9, 0.999,
+                            1e-7, 0.5, l2t.data_ptr(), lret.data_ptr(), st)
+                wn, mn, vn = O.adam_step(wr, mr, vr, g * 0.5, t, 1e-3, l2=l2)
+                mr = np.where(frozen, mr, mn)
+            else:
+                L.rmsprop_step(w.data_ptr(), v.data_ptr(), gt.data_ptr(), n, lr.data_ptr(), 0.9, 1e-7, 0.5, l2t.data_ptr(),
+                               lret.data_ptr(), st)
+                wn, vn = O.rmsprop_step(wr, vr, g * 0.5, 1e-3, l2=l2)
+            wr, vr = np.where(frozen, wr, wn), np.where(frozen, vr, vn)
+        assert np.array_equal(w.cpu().numpy()[frozen], w0.astype(np.float32)[frozen])
+        assert np.abs(w.cpu().numpy() - wr).max() < 2e-6, kind
+        close(v, vr, rtol=1e-5, atol=1e-12, what=kind + ' second moment')
+

@@ -5,10 +5,10 @@ importlib:  importlib.import_module('tf-keras-deeplabv3p-model-set_amd')  -- or 
 `deeplabv3p` shim package at the repo root, which mirrors the reference's import paths
 (`from deeplabv3p.model import get_deeplabv3p_model`).
 """
-from .model import (get_deeplabv3p_model, deeplab_model_map, DeeplabModel, SGD, get_optimizer,  # noqa: F401
+from .model import (get_deeplabv3p_model, deeplab_model_map, DeeplabModel, SGD, Adam, RMSprop, get_optimizer,  # noqa: F401
                     SparseCategoricalCrossEntropy, WeightedSparseCategoricalCrossEntropy, SparseSoftmaxFocalLoss,
                     miou_from_confusion)
 
-__all__ = ['get_deeplabv3p_model', 'deeplab_model_map', 'DeeplabModel', 'SGD', 'get_optimizer',
+__all__ = ['get_deeplabv3p_model', 'deeplab_model_map', 'DeeplabModel', 'SGD', 'Adam', 'RMSprop', 'get_optimizer',
            'SparseCategoricalCrossEntropy', 'WeightedSparseCategoricalCrossEntropy', 'SparseSoftmaxFocalLoss',
            'miou_from_confusion']

@@ -912,3 +912,72 @@ extern "C" int dl3p_sgd_momentum(float* w, float* v, const float* g, size_t n, c
   DL3P_CHECK_LAUNCH("dl3p_sgd_momentum");
   return DL3P_OK;
 }
+
+// ------------------------------------------------------------------------------ Adam / RMSprop
+// common/model_utils.py:118-121 (train.py --optimizer adam | rmsprop), the Keras 2.11 update rules on the same flat
+// buffers as SGD: g' = g*grad_scale + 2*l2*w (the regulariser is part of the Keras loss, so it passes through the
+// moments), per-element freeze mask.
+//   Adam(epsilon=1e-7):        m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;
+//                              w -= lr * sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps)        t = step count
+//   RMSprop(rho=.9, eps=1e-7): v = rho v + (1-rho) g'^2;  w -= lr * g' / sqrt(v + eps)            (momentum 0, not centred)
+// The step count is read from the device counter the forward plan increments, so graph replay follows it.
+template <bool ADAM>
+__global__ __launch_bounds__(256) void adaptive_kernel(float* __restrict__ w, float* __restrict__ m1, float* __restrict__ v2,
+                                                       const float* __restrict__ g, size_t n, const float* lr_dev,
+                                                       const int64_t* step, float b1, float b2, float eps, float gscale,
+                                                       const float* __restrict__ l2e, const float* __restrict__ lre) {
+  __shared__ float alpha_s;
+  if (threadIdx.x == 0) {
+    float a = *lr_dev;
+    if (ADAM) {
+      const double t = (double)(step ? *step : 1);
+      a = (float)((double)a * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+    }
+    alpha_s = a;
+  }
+  __syncthreads();
+  const float alpha = alpha_s;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    if (lre && lre[i] == 0.f) continue;
+    const float ww = w[i];
+    const float gg = fmaf(g[i], gscale, 2.f * (l2e ? l2e[i] : 0.f) * ww);
+    if (ADAM) {
+      const float m = b1 * m1[i] + (1.f - b1) * gg;
+      const float v = b2 * v2[i] + (1.f - b2) * gg * gg;
+      m1[i] = m;
+      v2[i] = v;
+      w[i] = ww - alpha * m / (sqrtf(v) + eps);
+    } else {
+      const float v = b2 * v2[i] + (1.f - b2) * gg * gg;
+      v2[i] = v;
+      w[i] = ww - alpha * gg * rsqrtf(v + eps);
+    }
+  }
+}
+
+extern "C" int dl3p_adam_step(float* w, float* m, float* v, const float* g, size_t n, const float* lr_dev,
+                              const int64_t* step_counter, float beta_1, float beta_2, float epsilon, float grad_scale,
+                              const float* l2_elem, const float* lr_scale_elem, void* stream) {
+  DL3P_CHECK_ARG(w && m && v && g && lr_dev && step_counter, "dl3p_adam_step: null pointer");
+  if (n == 0) return DL3P_OK;
+  size_t blocks = (n + 1023) / 1024;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL((adaptive_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, m, v, g, n,
+                     lr_dev, step_counter, beta_1, beta_2, epsilon, grad_scale, l2_elem, lr_scale_elem);
+  DL3P_CHECK_LAUNCH("dl3p_adam_step");
+  return DL3P_OK;
+}
+
+extern "C" int dl3p_rmsprop_step(float* w, float* v, const float* g, size_t n, const float* lr_dev, float rho,
+                                 float epsilon, float grad_scale, const float* l2_elem, const float* lr_scale_elem,
+                                 void* stream) {
+  DL3P_CHECK_ARG(w && v && g && lr_dev, "dl3p_rmsprop_step: null pointer");
+  if (n == 0) return DL3P_OK;
+  size_t blocks = (n + 1023) / 1024;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL((adaptive_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (float*)nullptr,
+                     v, g, n, lr_dev, (const int64_t*)nullptr, 0.f, rho, epsilon, grad_scale, l2_elem, lr_scale_elem);
+  DL3P_CHECK_LAUNCH("dl3p_rmsprop_step");
+  return DL3P_OK;
+}
+

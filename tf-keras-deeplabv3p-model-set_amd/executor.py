@@ -41,6 +41,7 @@ class ParamStore:
         self.P = torch.zeros(off, **f)
         self.G = torch.zeros(off, **f)
         self.V = torch.zeros(off, **f)
+        self.V2 = None                        # second-moment buffer, allocated when Adam asks for it
         self.l2 = torch.zeros(off, **f)
         self.lr_scale = torch.zeros(off, **f)
         # transposed copies [N][K] of the pointwise / im2col'd kernels (same offsets as in P): the forward GEMM reads
@@ -251,7 +252,7 @@ class Probe:
 
 class Executor:
     def __init__(self, graph, head, store, batch, training, num_classes, ignore_index=255, dist=None,
-                 seed=1234, momentum=0.9, loss=('ce',)):
+                 seed=1234, momentum=0.9, loss=('ce',), optimizer=None):
         self.g, self.head, self.store = graph, head, store
         self.N, self.training, self.C = batch, training, num_classes
         self.ignore_index = ignore_index
@@ -264,13 +265,18 @@ class Executor:
         force = bool(os.environ.get('DL3P_FORCE_DIST'))
         self.dist = dist if (dist is not None and (dist.world_size > 1 or force)) else None
         self.sync_bn = self.dist is not None and self.dist.sync_bn
-        self.seed, self.momentum = seed, momentum
+        # optimizer: ('sgd', momentum) | ('adam', beta_1, beta_2, epsilon) | ('rmsprop', rho, epsilon)
+        self.optimizer = optimizer or ('sgd', momentum)
+        self.seed, self.momentum = seed, (self.optimizer[1] if self.optimizer[0] == 'sgd' else 0.0)
+        if self.optimizer[0] == 'adam' and store.V2 is None:
+            store.V2 = torch.zeros_like(store.V)
         self.dev = store.device
         self.L = lib()
         self.f32 = dict(dtype=torch.float32, device=self.dev)
         self._alloc()
         # tracing runs every kernel once on zero inputs: keep the weights / optimiser state intact
         snap_p, snap_v = store.P.clone(), store.V.clone()
+        snap_v2 = store.V2.clone() if store.V2 is not None else None
         if training:
             self.fwd = self._trace_forward()
             self.bwd = self._trace_backward()
@@ -280,6 +286,8 @@ class Executor:
         torch.cuda.synchronize()
         store.P.copy_(snap_p)
         store.V.copy_(snap_v)
+        if snap_v2 is not None:
+            store.V2.copy_(snap_v2)
         store.transpose()
         self.step.zero_()
         self.graphed = False
@@ -784,8 +792,18 @@ class Executor:
         scale = 1.0
         if self.dist is not None:
             scale = 1.0 / self.dist.world_size
-        P.k(L.sgd_momentum, st.P.data_ptr(), st.V.data_ptr(), st.G.data_ptr(), st.total, self.lr.data_ptr(),
-            float(self.momentum), 0.0, scale, st.l2.data_ptr(), st.lr_scale.data_ptr())
+        kind = self.optimizer[0]
+        if kind == 'adam':
+            _, b1, b2, eps = self.optimizer
+            P.k(L.adam_step, st.P.data_ptr(), st.V.data_ptr(), st.V2.data_ptr(), st.G.data_ptr(), st.total,
+                self.lr.data_ptr(), self.step.data_ptr(), b1, b2, eps, scale, st.l2.data_ptr(), st.lr_scale.data_ptr())
+        elif kind == 'rmsprop':
+            _, rho, eps = self.optimizer
+            P.k(L.rmsprop_step, st.P.data_ptr(), st.V.data_ptr(), st.G.data_ptr(), st.total, self.lr.data_ptr(), rho, eps,
+                scale, st.l2.data_ptr(), st.lr_scale.data_ptr())
+        else:
+            P.k(L.sgd_momentum, st.P.data_ptr(), st.V.data_ptr(), st.G.data_ptr(), st.total, self.lr.data_ptr(),
+                float(self.momentum), 0.0, scale, st.l2.data_ptr(), st.lr_scale.data_ptr())
         if st.tr_table is not None:        # the forward GEMMs read the transposed kernel copies
             P.k(L.transpose_batch, st.P.data_ptr(), st.Pt.data_ptr(), st.tr_table.data_ptr(), int(st.tr_table.shape[0]))
         return P

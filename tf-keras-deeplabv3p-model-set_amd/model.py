@@ -63,10 +63,40 @@ class SGD:
         lr = self.learning_rate
         return float(lr(step)) if callable(lr) else float(lr)
 
+    def spec(self):
+        return ('sgd', float(self.momentum))
+
+
+class Adam(SGD):
+    """Keras Adam(learning_rate, epsilon=1e-7, amsgrad=False) (common/model_utils.py:119)"""
+
+    def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, amsgrad=False):
+        if amsgrad:
+            raise ValueError('amsgrad is not built (the reference passes amsgrad=False)')
+        self.learning_rate, self.beta_1, self.beta_2, self.epsilon = learning_rate, beta_1, beta_2, epsilon
+        self.momentum = 0.0
+
+    def spec(self):
+        return ('adam', float(self.beta_1), float(self.beta_2), float(self.epsilon))
+
+
+class RMSprop(SGD):
+    """Keras RMSprop(learning_rate, rho=0.9, momentum=0.0, centered=False) (common/model_utils.py:121)"""
+
+    def __init__(self, learning_rate=0.001, rho=0.9, momentum=0.0, epsilon=1e-7, centered=False):
+        if momentum or centered:
+            raise ValueError('RMSprop momentum / centered are not built (the reference uses momentum=0.0, centered=False)')
+        self.learning_rate, self.rho, self.epsilon = learning_rate, rho, epsilon
+        self.momentum = 0.0
+
+    def spec(self):
+        return ('rmsprop', float(self.rho), float(self.epsilon))
+
 
 def get_optimizer(optim_type, learning_rate, average_type=None, decay_type=None, decay_steps=100000):
-    """common/model_utils.py:112-130 -- only 'sgd' is on the hot path"""
-    if optim_type.lower() != 'sgd':
+    """common/model_utils.py:112-130: 'sgd' (momentum 0.9), 'adam', 'rmsprop' with the four learning-rate schedules"""
+    optim_type = optim_type.lower()
+    if optim_type not in ('sgd', 'adam', 'rmsprop'):
         raise ValueError('Unsupported optimizer type')
     if average_type:
         raise ValueError('averaged optimizers are out of scope')
@@ -85,6 +115,10 @@ def get_optimizer(optim_type, learning_rate, average_type=None, decay_type=None,
             lr = lambda s: v[sum(1 for x in b if s > x)]
         else:
             raise ValueError('Unsupported lr decay type')
+    if optim_type == 'adam':
+        return Adam(lr, epsilon=1e-7)
+    if optim_type == 'rmsprop':
+        return RMSprop(lr, rho=0.9)
     return SGD(lr, momentum=0.9)
 
 
@@ -269,6 +303,8 @@ class DeeplabModel:
         if self._store is not None:
             self._store.refresh_masks()
             self._store.V.zero_()
+            if self._store.V2 is not None:
+                self._store.V2.zero_()
         return self
 
     def _ensure_store(self):
@@ -289,11 +325,11 @@ class DeeplabModel:
             from .executor import Executor
             store = self._ensure_store()
             ignore = self.loss.ignore_index if self.loss is not None else 255
-            mom = self.optimizer.momentum if self.optimizer is not None else 0.9
+            opt = self.optimizer.spec() if self.optimizer is not None else ('sgd', 0.9)
             rank = self.dist.rank if self.dist is not None else 0
             self._exec[key] = Executor(self.graph, self.head, store, batch, training, self.num_classes,
                                        ignore_index=ignore, dist=self.dist if training else None,
-                                       seed=self.seed + 7919 * rank, momentum=mom, loss=loss_spec(self.loss))
+                                       seed=self.seed + 7919 * rank, loss=loss_spec(self.loss), optimizer=opt)
         return self._exec[key]
 
     def train_on_batch(self, x, y, return_tensor=False):
