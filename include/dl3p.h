@@ -260,11 +260,13 @@ int dl3p_upsample_softmax_ce(const float* z, int ldz, const float* labels, int i
 /* The same head with the reference's other two losses (train.py:108-137): loss_kind DL3P_LOSS_WEIGHTED_CE =
  * WeightedSparseCategoricalCrossEntropy (loss.py:159-191: -w[y]*log(p_y), class_weights[C] on the device, no
  * clipping), DL3P_LOSS_FOCAL = SparseSoftmaxFocalLoss (loss.py:63-118: -alpha*(1-p_y)^gamma*log(p_y), p clipped to
- * [1e-15, 1-1e-15]); DL3P_LOSS_CE is dl3p_upsample_softmax_ce.  Masking, mean over all N*H*W entries and the
- * outputs are as above. */
+ * [1e-15, 1-1e-15]); DL3P_LOSS_CE is dl3p_upsample_softmax_ce.  pixel_weights [N*H*W] (or NULL) are Keras sample
+ * weights in 'temporal' mode (train.py:116-120, --weighted_type adaptive): each pixel's loss is multiplied by its
+ * weight before the mean.  Masking, mean over all N*H*W entries and the outputs are as above. */
 enum { DL3P_LOSS_CE = 0, DL3P_LOSS_WEIGHTED_CE = 1, DL3P_LOSS_FOCAL = 2 };
 int dl3p_upsample_softmax_loss(const float* z, int ldz, const float* labels, int ignore_index, float inv_count,
                                int loss_kind, const float* class_weights, float focal_gamma, float focal_alpha,
+                               const float* pixel_weights,
                                float* logits_big, float* probs, float* dlogits_big, int ld_big,
                                float* loss_partials, int* rows_out,
                                int N, int h, int w, int C, int H, int W, void* stream);

@@ -709,7 +709,7 @@ class OracleModel:
         logits = self._forward_graph(x.astype(self.net.dtype), x.shape[1], x.shape[2], training=True)
         return logits
 
-    def loss_and_grads(self, x, labels, dropout_masks=None, ignore_index=255, loss=None):
+    def loss_and_grads(self, x, labels, dropout_masks=None, ignore_index=255, loss=None, sample_weight=None):
         """labels: (N, H*W, 1) float class ids (data.py:39-41).  returns (total_loss, ce_loss, logits);
         gradients (data term only; the l2 term is applied inside sgd_step like Keras adds it to the
         loss) are left in self.net.grads."""
@@ -717,7 +717,8 @@ class OracleModel:
         logits = self.forward_train(x, dropout_masks)
         N, H, W, C = logits.v.shape
         lab = labels.reshape(N, H, W)
-        ce, probs, dlogits = O.loss_fwd_bwd(logits.v, lab, loss, ignore_index)     # loss: see np_ops.loss_fwd_bwd
+        sw = None if sample_weight is None else np.asarray(sample_weight).reshape(N, H, W)
+        ce, probs, dlogits = O.loss_fwd_bwd(logits.v, lab, loss, ignore_index, sw)  # loss: see np_ops.loss_fwd_bwd
         logits.g = dlogits
         net.backward()
         reg = 0.0

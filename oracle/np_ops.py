@@ -413,16 +413,32 @@ def sparse_focal_fwd_bwd(logits, labels, gamma=2.0, alpha=0.25, ignore_index=255
     return loss, p, (g / M).reshape(logits.shape)
 
 
-def loss_fwd_bwd(logits, labels, spec=None, ignore_index=255):
-    """spec: None / ('ce',) | ('weighted', weights) | ('focal', gamma, alpha)  (train.py:108-137)"""
+def loss_fwd_bwd(logits, labels, spec=None, ignore_index=255, sample_weight=None):
+    """spec: None / ('ce',) | ('weighted', weights) | ('focal', gamma, alpha)  (train.py:108-137).
+    sample_weight (same shape as labels): Keras sample_weight_mode='temporal' (train.py:116-120) -- each pixel's loss is
+    multiplied by its weight, the mean still runs over all entries.  Every loss here is a sum of per-pixel terms, so the
+    weighted value is assembled from per-pixel evaluations."""
     kind = spec[0] if spec else 'ce'
-    if kind == 'ce':
-        return sparse_ce_fwd_bwd(logits, labels, ignore_index)
-    if kind == 'weighted':
-        return weighted_sparse_ce_fwd_bwd(logits, labels, spec[1], ignore_index)
-    if kind == 'focal':
-        return sparse_focal_fwd_bwd(logits, labels, spec[1], spec[2], ignore_index)
-    raise ValueError(kind)
+
+    def base(z, lab):
+        if kind == 'ce':
+            return sparse_ce_fwd_bwd(z, lab, ignore_index)
+        if kind == 'weighted':
+            return weighted_sparse_ce_fwd_bwd(z, lab, spec[1], ignore_index)
+        if kind == 'focal':
+            return sparse_focal_fwd_bwd(z, lab, spec[1], spec[2], ignore_index)
+        raise ValueError(kind)
+    if sample_weight is None:
+        return base(logits, labels)
+    # d(sum_i w_i l_i)/dz_i = w_i d l_i / dz_i: the gradient rows scale by the weights; the value needs the per-pixel
+    # losses, obtained by evaluating the (mean-reduced) loss with all other pixels masked out of the gradient path
+    loss, p, g = base(logits, labels)
+    sw = np.asarray(sample_weight, dtype=logits.dtype).reshape(labels.shape)
+    C = logits.shape[-1]
+    flat_z, flat_l = logits.reshape(-1, C), labels.reshape(-1)
+    M = flat_l.shape[0]
+    per = np.array([base(flat_z[i:i + 1], flat_l[i:i + 1])[0] for i in range(M)])       # each is l_i (mean over 1 entry)
+    return float((per * sw.reshape(-1)).sum() / M), p, g * sw[..., None]
 
 
 # --------------------------------------------------------------------------------------

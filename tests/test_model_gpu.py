@@ -435,3 +435,37 @@ def test_adam_and_rmsprop_step_matches_oracle(kind):
             assert np.abs(d_ref).max() > 0.5 * lr                   # ~lr per weight, as Adam / RMSprop do at t = 1
             checked += int(solid.sum())
     assert checked > 1e5, checked
+
+
+def test_fit_with_adaptive_sample_weights():
+    """train.py --weighted_type adaptive: compile(sample_weight_mode='temporal') and a generator that yields
+    (images, labels, {'pred_mask': weights}) (deeplabv3p/data.py:140-152); one step against the oracle"""
+    pkg = load_pkg()
+    N, C, H, W = 2, 21, 65, 65
+    m, o = _pair('mobilenetv2_lite', H, W, C)
+    m.compile(optimizer=pkg.SGD(0.01), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255), sample_weight_mode='temporal')
+    m.use_graphs = False
+    x, y = _data(N, H, W, C, seed=8)
+    sw = np.random.default_rng(8).uniform(0.2, 4.0, (N, H * W)).astype(np.float32)
+
+    class Gen:
+        def __len__(self):
+            return 1
+        def __getitem__(self, i):
+            return x, y, {'pred_mask': sw}
+    hist = m.fit_generator(Gen(), steps_per_epoch=1, epochs=1, verbose=0)
+    ex = m._executor(N, True)
+    drop = [op for op in m.graph.ops if op.kind == 'materialize' and op.rate > 0][0]
+    mask = ex.dropout_mask(drop).cpu().numpy()
+    o.net.act_derivs = _act_derivs(m, ex)
+    o.net.act_derivs_seq = _act_derivs_seq(m, ex, o.net.act_derivs)
+    total, data_loss, _ = o.loss_and_grads(x, y, {'aspp_dropout': mask}, sample_weight=sw)
+    assert abs(hist['loss'][0] - data_loss) < TOL * max(1.0, abs(data_loss)), (hist['loss'][0], data_loss)
+    o.sgd_step(0.01, 0.9)
+    w = m.get_weights_by_name()
+    assert max(float(np.abs(v - o.net.params[k]).max()) for k, v in w.items()) < TOL
+    with pytest.raises(ValueError):
+        m2 = pkg.get_deeplabv3p_model('mobilenetv2_lite', C, (H, W), 16)
+        m2.compile(optimizer=pkg.SGD(0.01), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
+        m2.train_on_batch(x, y, sample_weight=sw)
+

@@ -460,6 +460,28 @@ def test_head_optional_losses(ops, spec):
     assert np.isfinite(out['dlogits'].cpu().numpy()).all()
 
 
+@pytest.mark.parametrize('spec', [('ce',), ('focal', 2.0, 0.25)])
+def test_head_sample_weights(ops, spec):
+    """Keras sample weights in 'temporal' mode (train.py:116-120, deeplabv3p/data.py:140-152): per-pixel weights on the
+    loss and its gradient"""
+    rng = np.random.default_rng(13)
+    N, h, w, H, W, C = 2, 5, 5, 17, 17, 21
+    z = np.zeros((N, h, w, 24)); z[..., :C] = rng.standard_normal((N, h, w, C)) * 2
+    lab = rng.integers(0, C, (N, H, W)).astype(np.float64)
+    lab[rng.uniform(size=lab.shape) < 0.1] = 255
+    sw = rng.uniform(0.3, 3.0, (N, H, W))
+    big = O.resize_bilinear_fwd(z[..., :C], H, W)
+    loss_ref, _, g_ref = O.loss_fwd_bwd(big, lab, spec, 255, sample_weight=sw)
+    out = ops.upsample_softmax_ce(T(z), C, H, W, T(lab.reshape(N, H * W, 1)), 255, want_grad=True, loss=spec,
+                                  pixel_weights=T(sw.reshape(N, H * W)))
+    close(out['loss'], [loss_ref], rtol=2e-4, what='weighted loss')
+    close(out['dlogits'][..., :C], g_ref, rtol=2e-4, atol=1e-9, what='weighted dlogits')
+    ones = ops.upsample_softmax_ce(T(z), C, H, W, T(lab.reshape(N, H * W, 1)), 255, want_grad=True, loss=spec,
+                                   pixel_weights=torch.ones(N * H * W, device=DEV))
+    plain = ops.upsample_softmax_ce(T(z), C, H, W, T(lab.reshape(N, H * W, 1)), 255, want_grad=True, loss=spec)
+    assert torch.equal(ones['dlogits'], plain['dlogits']) and torch.equal(ones['loss'], plain['loss'])
+
+
 @pytest.mark.parametrize('case', [(2, 9, 9, 33, 33, 21, 255), (1, 33, 33, 129, 129, 19, 255), (2, 17, 23, 65, 89, 21, 0),
                                   (1, 129, 129, 513, 513, 21, 255)])
 def test_head_train_fused(ops, case):

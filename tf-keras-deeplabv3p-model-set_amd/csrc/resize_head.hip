@@ -190,6 +190,7 @@ extern "C" int dl3p_resize_bilinear_bwd(const float* gy, int ldgy, float* gx, in
 struct HeadParams {
   const float* z; int ldz; const float* labels; int ignore_index; float inv_count;
   int loss_kind; const float* class_w; float focal_gamma, focal_alpha;   // DL3P_LOSS_*
+  const float* pixel_w;           // Keras sample_weight_mode='temporal': one weight per (image, pixel), or null
   float* logits_big; float* probs; float* dlogits; float* loss_partials;
   int N, h, w, C, H, W, ld_big;
   long long total;
@@ -287,6 +288,11 @@ __global__ __launch_bounds__(256) void head_kernel(HeadParams p) {
         li = -logf(fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f));
         f = unclipped ? 1.f : 0.f;
       }
+      if (p.pixel_w) {            // the weighted per-pixel losses are averaged over ALL entries, like the unweighted ones
+        const float sw = p.pixel_w[s];
+        li *= sw;
+        f *= sw;
+      }
       if (valid && live) loss += li;
       if (p.dlogits) {
         const float gs = valid ? f * p.inv_count : 0.f;
@@ -328,13 +334,15 @@ extern "C" int dl3p_upsample_softmax_ce(const float* z, int ldz, const float* la
                                         float inv_count, float* logits_big, float* probs, float* dlogits_big,
                                         int ld_big, float* loss_partials, int* rows_out, int N, int h, int w, int C,
                                         int H, int W, void* stream) {
-  return dl3p_upsample_softmax_loss(z, ldz, labels, ignore_index, inv_count, DL3P_LOSS_CE, nullptr, 0.f, 0.f, logits_big,
-                                    probs, dlogits_big, ld_big, loss_partials, rows_out, N, h, w, C, H, W, stream);
+  return dl3p_upsample_softmax_loss(z, ldz, labels, ignore_index, inv_count, DL3P_LOSS_CE, nullptr, 0.f, 0.f, nullptr,
+                                    logits_big, probs, dlogits_big, ld_big, loss_partials, rows_out, N, h, w, C, H, W,
+                                    stream);
 }
 
 extern "C" int dl3p_upsample_softmax_loss(const float* z, int ldz, const float* labels, int ignore_index,
                                           float inv_count, int loss_kind, const float* class_weights, float focal_gamma,
-                                          float focal_alpha, float* logits_big, float* probs, float* dlogits_big,
+                                          float focal_alpha, const float* pixel_weights, float* logits_big, float* probs,
+                                          float* dlogits_big,
                                           int ld_big, float* loss_partials, int* rows_out, int N, int h, int w, int C,
                                           int H, int W, void* stream) {
   DL3P_CHECK_ARG(z && aligned16(z) && ldz % 4 == 0, "dl3p_upsample_softmax_ce: logits must be 16-byte aligned, ld %% 4 == 0");
@@ -347,6 +355,7 @@ extern "C" int dl3p_upsample_softmax_loss(const float* z, int ldz, const float* 
   HeadParams p = {};
   p.z = z; p.ldz = ldz; p.labels = labels; p.ignore_index = ignore_index; p.inv_count = inv_count;
   p.loss_kind = loss_kind; p.class_w = class_weights; p.focal_gamma = focal_gamma; p.focal_alpha = focal_alpha;
+  p.pixel_w = pixel_weights;
   p.logits_big = logits_big; p.probs = probs; p.dlogits = dlogits_big; p.loss_partials = labels ? loss_partials : nullptr;
   p.N = N; p.h = h; p.w = w; p.C = C; p.H = H; p.W = W; p.ld_big = ld_big;
   p.total = (long long)N * H * W;

@@ -252,12 +252,13 @@ class Probe:
 
 class Executor:
     def __init__(self, graph, head, store, batch, training, num_classes, ignore_index=255, dist=None,
-                 seed=1234, momentum=0.9, loss=('ce',), optimizer=None):
+                 seed=1234, momentum=0.9, loss=('ce',), optimizer=None, sample_weighted=False):
         self.g, self.head, self.store = graph, head, store
         self.N, self.training, self.C = batch, training, num_classes
         self.ignore_index = ignore_index
         # loss: ('ce',) | ('weighted', weights[C]) | ('focal', gamma, alpha)  (model.loss_spec)
         self._u8 = {}
+        self.sample_weighted = bool(sample_weighted)
         self.loss_kind = {'ce': 0, 'weighted': 1, 'focal': 2}[loss[0]]
         self.loss_gamma, self.loss_alpha = (float(loss[1]), float(loss[2])) if loss[0] == 'focal' else (0.0, 0.0)
         self._loss_weights_host = np.asarray(loss[1], np.float32) if loss[0] == 'weighted' else None
@@ -346,7 +347,9 @@ class Executor:
         if self._loss_weights_host is not None:
             assert self._loss_weights_host.shape == (self.C,), 'one class weight per class'
             self.class_weights = torch.from_numpy(self._loss_weights_host).to(self.dev)
-        self.fused_head = bool(self.training and self.loss_kind == 0 and os.environ.get('DL3P_FUSED_HEAD', '0') != '0' and zt is not None and
+        # Keras sample weights, sample_weight_mode='temporal' (train.py:116-120): ones until set_inputs receives some
+        self.pixel_weights = torch.ones(N * H * W, **self.f32) if (self.training and self.sample_weighted) else None
+        self.fused_head = bool(self.training and self.loss_kind == 0 and not self.sample_weighted and os.environ.get('DL3P_FUSED_HEAD', '0') != '0' and zt is not None and
                                zt.requires_grad and L.head_train_supported(zt.H, zt.W, self.C, H, W))
         self.dlogits_big = (torch.zeros(N * H * W * self.cpad, **self.f32)
                             if (self.training and not self.fused_head) else None)
@@ -482,6 +485,7 @@ class Executor:
             P.k(L.upsample_softmax_loss, self.tptr(zt), zt.ld, self.labels.data_ptr(), int(self.ignore_index or 0),
                 1.0 / float(N * self.H * self.W), self.loss_kind,
                 None if self.class_weights is None else self.class_weights.data_ptr(), self.loss_gamma, self.loss_alpha,
+                None if self.pixel_weights is None else self.pixel_weights.data_ptr(),
                 None, None, self.dlogits_big.data_ptr(), self.cpad,
                 self.loss_partials.data_ptr(), ctypes.byref(rows), N, zt.H, zt.W, self.C, self.H, self.W)
             P.k(L.reduce_rows, self.loss_partials.data_ptr(), rows.value, 1, self.loss.data_ptr(), 0)
@@ -818,7 +822,7 @@ class Executor:
         stage.copy_(src, non_blocking=True)
         self.L.u8_to_float(stage.data_ptr(), dst.data_ptr(), src.numel(), div, sub, torch.cuda.current_stream().cuda_stream)
 
-    def set_inputs(self, x, y=None):
+    def set_inputs(self, x, y=None, sample_weight=None):
         """x float32 in [-1, 1] -- or uint8 pixels, normalised on the device like normalize_image does on the host
         (common/data_utils.py:403-417); y float / integer class ids, uint8 accepted the same way"""
         inp = self.buf[self.g.input.tensor.id]
@@ -833,6 +837,10 @@ class Executor:
             else:
                 y = torch.as_tensor(y, dtype=torch.float32)
                 self.labels.copy_(y.reshape(-1), non_blocking=True)
+        if sample_weight is not None:
+            if self.pixel_weights is None:
+                raise ValueError("sample weights need compile(sample_weight_mode='temporal')")
+            self.pixel_weights.copy_(torch.as_tensor(sample_weight, dtype=torch.float32).reshape(-1), non_blocking=True)
 
     def capture(self):
         """capture the traced plans into hipGraphs (done once, after a warm-up eager step)"""

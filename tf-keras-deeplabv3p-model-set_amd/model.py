@@ -292,8 +292,9 @@ class DeeplabModel:
         traced plans, so `layers[i].trainable` changes take effect like a Keras recompile"""
         self.optimizer = optimizer or SGD(0.01)
         self.loss = loss or SparseCategoricalCrossEntropy(ignore_index=255)
-        if sample_weight_mode:
-            raise ValueError('sample weights (adaptive mode) are not on the hot path')
+        if sample_weight_mode not in (None, 'temporal'):
+            raise ValueError("sample_weight_mode must be None or 'temporal' (train.py:116-120)")
+        self.sample_weight_mode = sample_weight_mode
         if distributed is None:
             import torch.distributed as dist
             distributed = dist.is_available() and dist.is_initialized() and (
@@ -329,15 +330,17 @@ class DeeplabModel:
             rank = self.dist.rank if self.dist is not None else 0
             self._exec[key] = Executor(self.graph, self.head, store, batch, training, self.num_classes,
                                        ignore_index=ignore, dist=self.dist if training else None,
-                                       seed=self.seed + 7919 * rank, loss=loss_spec(self.loss), optimizer=opt)
+                                       seed=self.seed + 7919 * rank, loss=loss_spec(self.loss), optimizer=opt,
+                                       sample_weighted=getattr(self, 'sample_weight_mode', None) == 'temporal')
         return self._exec[key]
 
-    def train_on_batch(self, x, y, return_tensor=False):
-        """one SGD step on (x (B,H,W,3) float32 in [-1,1], y (B,H*W,1) class ids); returns the data loss"""
+    def train_on_batch(self, x, y, sample_weight=None, return_tensor=False):
+        """one optimiser step on (x (B,H,W,3) float32 in [-1,1] or uint8, y (B,H*W,1) class ids[, sample_weight (B,H*W)
+        with compile(sample_weight_mode='temporal')]); returns the data loss"""
         if self.optimizer is None:
             raise RuntimeError('You must compile your model before training')
         ex = self._executor(int(x.shape[0]), True)
-        ex.set_inputs(x, y)
+        ex.set_inputs(x, y, sample_weight)
         ex.lr.fill_(self.optimizer.lr_at(self._steps))
         if self.use_graphs and not ex.graphed and self._steps_on(ex) >= 1:
             ex.capture()
@@ -378,7 +381,11 @@ class DeeplabModel:
             it = iter(gen) if not hasattr(gen, '__getitem__') else None
             for i in range(n):
                 batch = gen[i] if it is None else next(it)
-                losses.append(self.train_on_batch(batch[0], batch[1]))
+                # generators yield (x, y) or, in adaptive weighting mode, (x, y, sample_weight) (deeplabv3p/data.py:149-154)
+                sw = batch[2] if len(batch) > 2 else None
+                if isinstance(sw, dict):
+                    sw = next(iter(sw.values()))          # {'pred_mask': weights}
+                losses.append(self.train_on_batch(batch[0], batch[1], sample_weight=sw))
                 if not np.isfinite(losses[-1]):      # TerminateOnNaN (train.py:64)
                     self.stop_training = True
                     break

@@ -394,7 +394,7 @@ def resize_bilinear_bwd(gy, h, w, out=None, accumulate=False):
 
 # ------------------------------------------------------------------------------------- head / loss
 def upsample_softmax_ce(z, C, H, W, labels=None, ignore_index=255, want_probs=False, want_logits=False,
-                        want_grad=False, ld_big=None, loss=('ce',)):
+                        want_grad=False, ld_big=None, loss=('ce',), pixel_weights=None):
     """z (N,h,w,Cpad) small logits -> dict(loss, probs (N,H,W,C), logits (N,H,W,ld_big), dlogits)"""
     N, h, w, _ = z.shape
     dev = z.device
@@ -411,8 +411,9 @@ def upsample_softmax_ce(z, C, H, W, labels=None, ignore_index=255, want_probs=Fa
     kind = {'ce': 0, 'weighted': 1, 'focal': 2}[loss[0]]
     cw = loss[1] if kind == 1 else None
     gamma, alpha = (float(loss[1]), float(loss[2])) if kind == 2 else (0.0, 0.0)
-    lib().upsample_softmax_loss(zp, ldz, _p(labels), int(ignore_index or 0), inv, kind, _p(cw), gamma, alpha, _p(logits),
-                                _p(probs), _p(dlog), ld_big, _p(partial), ctypes.byref(rows), N, h, w, C, H, W, _stream())
+    lib().upsample_softmax_loss(zp, ldz, _p(labels), int(ignore_index or 0), inv, kind, _p(cw), gamma, alpha,
+                                _p(pixel_weights), _p(logits), _p(probs), _p(dlog), ld_big, _p(partial), ctypes.byref(rows),
+                                N, h, w, C, H, W, _stream())
     if labels is not None:
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         lib().reduce_rows(_p(partial), rows.value, 1, _p(loss), 0, _stream())
