@@ -276,6 +276,11 @@ int dl3p_upsample_softmax_loss(const float* z, int ldz, const float* labels, int
  * integer atomics, order-independent).  pred_mask, or labels + confusion, may be NULL. */
 int dl3p_argmax_confusion(const float* z, int ldz, const float* labels, int32_t* pred_mask,
                           unsigned long long* confusion, int N, int h, int w, int C, int H, int W, void* stream);
+/* Training metrics (deeplabv3p/metrics.py:20-46, train.py:140): per image n and class c,
+ * counts[n][0][c] = |label == c and pred == c|, counts[n][1][c] = |label == c|, counts[n][2][c] = |pred == c| (over all
+ * pixels, ignored labels included), pred = argmax of the upsampled logits.  int32 [N][3][C], zeroed by the caller. */
+int dl3p_class_counts(const float* z, int ldz, const float* labels, int32_t* counts, int N, int h, int w, int C,
+                      int H, int W, void* stream);
 /* Training head in one launch: the same forward + loss as dl3p_upsample_softmax_ce AND the transposed
  * pred_resize of the gradient (what dl3p_resize_bilinear_bwd(dlogits_big) returns), gz [N,h,w,C] (ldgz),
  * without ever writing the (N,H,W,C) gradient.  Available for upsampling factors up to ~4.2

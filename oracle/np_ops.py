@@ -496,6 +496,21 @@ def confusion_matrix(gt_mask, pred_mask, num_classes):
     return np.bincount(label, minlength=num_classes ** 2).reshape(num_classes, num_classes)
 
 
+def jaccard_metric(labels, pred, num_classes):
+    """deeplabv3p/metrics.py:29-46 Jaccard: labels, pred (N, P) integer arrays.  For every class i in [0, C]: per-image
+    IoU over the images that contain the class, averaged; then the mean over the classes that occur at all"""
+    labels = np.asarray(labels).astype(np.int64)
+    pred = np.asarray(pred).astype(np.int64)
+    iou = []
+    for i in range(num_classes + 1):
+        t, q = labels == i, pred == i
+        inter, union = (t & q).sum(1), (t | q).sum(1)
+        legal = t.sum(1) > 0
+        if legal.any():
+            iou.append(float(np.mean(inter[legal] / union[legal])))
+    return float(np.mean(iou)) if iou else float('nan')
+
+
 def miou_summary(cm):
     """eval.py:462-497: pixel accuracy, per-class accuracy / IoU / Dice / frequency, mean IoU (NaN -> 0 before the
     mean, as the reference does), frequency-weighted IoU"""

@@ -60,3 +60,20 @@ def test_focal_and_weighted_loss_gradients_are_derivatives():
     l0, _, g0 = O.loss_fwd_bwd(z, lab, ('focal', 0.0, 1.0))
     l1, _, g1 = O.loss_fwd_bwd(z, lab, ('weighted', np.ones(6)))
     assert np.isclose(l0, ce) and np.allclose(g0, gce) and np.isclose(l1, ce) and np.allclose(g1, gce)
+
+
+def test_jaccard_metric_restatement_and_count_form():
+    """oracle Jaccard (deeplabv3p/metrics.py:29-46) on a hand example, and the product's count-based evaluation of it"""
+    lab = np.array([[0, 0, 1, 1, 255, 2], [0, 0, 0, 0, 0, 0]])
+    pred = np.array([[0, 1, 1, 1, 1, 0], [0, 0, 0, 2, 2, 0]])
+    # class 0: image 0 inter 1 union 3; image 1 inter 4 union 6 -> mean(1/3, 4/6) = 0.5
+    # class 1: only image 0: inter 2, union 4 (the ignored pixel predicted as 1 counts in the union) -> 0.5
+    # class 2: only image 0: inter 0, union 1 (label) -> 0      => mean = 1/3
+    assert np.isclose(O.jaccard_metric(lab, pred, 3), (0.5 + 0.5 + 0.0) / 3)
+    C = 3
+    counts = np.zeros((2, 3, C))
+    for c in range(C):
+        counts[:, 0, c] = ((lab == c) & (pred == c)).sum(1)
+        counts[:, 1, c] = (lab == c).sum(1)
+        counts[:, 2, c] = (pred == c).sum(1)
+    assert np.isclose(load_pkg().jaccard_from_counts(counts), O.jaccard_metric(lab, pred, 3))

@@ -469,3 +469,40 @@ def test_fit_with_adaptive_sample_weights():
         m2.compile(optimizer=pkg.SGD(0.01), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
         m2.train_on_batch(x, y, sample_weight=sw)
 
+
+def test_jaccard_training_metric():
+    """compile(metrics={'pred_mask': Jaccard}) (train.py:140, deeplabv3p/metrics.py:29-46): the per-image class counts
+    come from the device, the metric equals the oracle's restatement on the pred_resize logits' argmax, and fit() logs
+    Jaccard / val_Jaccard like Keras does"""
+    from oracle import np_ops as O
+    pkg = load_pkg()
+    ops = load_pkg('ops')
+    N, C, H, W = 3, 21, 65, 65
+    m = pkg.get_deeplabv3p_model('mobilenetv2_lite', C, (H, W), 16, training=True, seed=2)
+    m.compile(optimizer=pkg.SGD(0.0), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255), metrics={'pred_mask': pkg.Jaccard})
+    m.use_graphs = False
+    x, y = _data(N, H, W, C, seed=31)
+    y = y.copy()
+    y[1, :2000] = 7                                          # some structure: classes present in one image only
+    m.train_on_batch(x, y)
+    ex = m._executor(N, True)
+    logits = ops.upsample_softmax_ce(ex.view(m.head.tensor), C, H, W, want_logits=True)['logits'][..., :C].cpu().numpy()
+    pred = logits.argmax(-1).reshape(N, -1)
+    want = O.jaccard_metric(np.asarray(y).reshape(N, -1), pred, C)
+    assert abs(m.last_metrics['Jaccard'] - want) < 1e-12, (m.last_metrics, want)
+    counts = ex.metric_counts.cpu().numpy()
+    assert counts[:, 2].sum() == N * H * W and (counts[:, 0] <= counts[:, 1]).all()
+
+    class Gen:
+        def __len__(self):
+            return 2
+        def __getitem__(self, i):
+            return x, y
+    hist_logs = []
+
+    class Cb:
+        def on_epoch_end(self, epoch, logs=None):
+            hist_logs.append(dict(logs))
+    m.fit_generator(Gen(), steps_per_epoch=2, epochs=1, validation_data=Gen(), validation_steps=1, callbacks=[Cb()], verbose=0)
+    assert 0.0 <= hist_logs[0]['Jaccard'] <= 1.0 and 0.0 <= hist_logs[0]['val_Jaccard'] <= 1.0
+

@@ -459,6 +459,60 @@ extern "C" int dl3p_argmax_confusion(const float* z, int ldz, const float* label
   return DL3P_OK;
 }
 
+// ------------------------------------------------------------------------------ training metrics: per-image class counts
+// deeplabv3p/metrics.py:29-46 Jaccard (train.py:140 metrics={'pred_mask': Jaccard}) and :20-26
+// sparse_accuracy_ignoring_last_label need, per image n and class c: |label == c & pred == c|, |label == c| and
+// |pred == c| over ALL pixels (a pixel with an ignored label still counts towards the union of its predicted class).
+// counts[n][3][C] (int32, zeroed by the caller): workgroups stay inside one image and keep an LDS histogram.
+__global__ __launch_bounds__(256) void class_counts_kernel(EvalParams p, int* counts, int blocks_per_image) {
+  extern __shared__ unsigned int hist[];                 // [3][C]
+  for (int i = threadIdx.x; i < 3 * p.C; i += 256) hist[i] = 0u;
+  __syncthreads();
+  const int n = blockIdx.x / blocks_per_image, b = blockIdx.x - n * blocks_per_image;
+  const int HW = p.H * p.W;
+  const float sy = (float)p.h / (float)p.H, sx = (float)p.w / (float)p.W;
+  const float* img = p.z + (size_t)n * p.h * p.w * p.ldz;
+  for (int s = b * 256 + threadIdx.x; s < HW; s += blocks_per_image * 256) {
+    const int ox = s % p.W, oy = s / p.W;
+    const Lerp ly = lerp_coeff(oy, sy, p.h), lx = lerp_coeff(ox, sx, p.w);
+    const float* ptl = img + ((size_t)ly.lo * p.w + lx.lo) * p.ldz;
+    const float* ptr = img + ((size_t)ly.lo * p.w + lx.hi) * p.ldz;
+    const float* pbl = img + ((size_t)ly.hi * p.w + lx.lo) * p.ldz;
+    const float* pbr = img + ((size_t)ly.hi * p.w + lx.hi) * p.ldz;
+    float best = -3.0e38f;
+    int arg = 0;
+    for (int c = 0; c < p.C; ++c) {                      // same arithmetic as head_kernel / argmax_confusion_kernel
+      const float top = ptl[c] + (ptr[c] - ptl[c]) * lx.t, bot = pbl[c] + (pbr[c] - pbl[c]) * lx.t;
+      const float v = top + (bot - top) * ly.t;
+      if (v > best) { best = v; arg = c; }
+    }
+    const int lab = (int)p.labels[(size_t)n * HW + s];
+    atomicAdd(&hist[2 * p.C + arg], 1u);
+    if (lab >= 0 && lab < p.C) {
+      atomicAdd(&hist[p.C + lab], 1u);
+      if (lab == arg) atomicAdd(&hist[lab], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * p.C; i += 256)
+    if (hist[i]) atomicAdd(&counts[(size_t)n * 3 * p.C + i], (int)hist[i]);
+}
+
+extern "C" int dl3p_class_counts(const float* z, int ldz, const float* labels, int32_t* counts, int N, int h, int w,
+                                 int C, int H, int W, void* stream) {
+  DL3P_CHECK_ARG(z && labels && counts && ldz >= C, "dl3p_class_counts: bad arguments");
+  DL3P_CHECK_ARG(C > 0 && C <= 1024 && N > 0 && h > 0 && w > 0 && H > 0 && W > 0, "dl3p_class_counts: bad dims");
+  EvalParams p = {};
+  p.z = z; p.ldz = ldz; p.labels = labels; p.N = N; p.h = h; p.w = w; p.C = C; p.H = H; p.W = W;
+  int bpi = (H * W + 256 * 8 - 1) / (256 * 8);
+  if (bpi < 1) bpi = 1;
+  if (bpi > 256) bpi = 256;
+  hipLaunchKernelGGL(class_counts_kernel, dim3((unsigned)(N * bpi)), dim3(256), (size_t)3 * C * sizeof(unsigned int),
+                     (hipStream_t)stream, p, counts, bpi);
+  DL3P_CHECK_LAUNCH("dl3p_class_counts");
+  return DL3P_OK;
+}
+
 // ------------------------------------------------------------------------------ fused training head
 // pred_resize + Softmax + loss + the transposed resize of the gradient in ONE kernel: the (N,H,W,C) gradient
 // (404 MB at batch 16, written by head_kernel and read back by resize_bwd_kernel) never exists.  A workgroup

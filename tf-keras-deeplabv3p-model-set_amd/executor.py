@@ -252,13 +252,14 @@ class Probe:
 
 class Executor:
     def __init__(self, graph, head, store, batch, training, num_classes, ignore_index=255, dist=None,
-                 seed=1234, momentum=0.9, loss=('ce',), optimizer=None, sample_weighted=False):
+                 seed=1234, momentum=0.9, loss=('ce',), optimizer=None, sample_weighted=False, class_counts=False):
         self.g, self.head, self.store = graph, head, store
         self.N, self.training, self.C = batch, training, num_classes
         self.ignore_index = ignore_index
         # loss: ('ce',) | ('weighted', weights[C]) | ('focal', gamma, alpha)  (model.loss_spec)
         self._u8 = {}
         self.sample_weighted = bool(sample_weighted)
+        self.want_class_counts = bool(class_counts)
         self.loss_kind = {'ce': 0, 'weighted': 1, 'focal': 2}[loss[0]]
         self.loss_gamma, self.loss_alpha = (float(loss[1]), float(loss[2])) if loss[0] == 'focal' else (0.0, 0.0)
         self._loss_weights_host = np.asarray(loss[1], np.float32) if loss[0] == 'weighted' else None
@@ -349,6 +350,9 @@ class Executor:
             self.class_weights = torch.from_numpy(self._loss_weights_host).to(self.dev)
         # Keras sample weights, sample_weight_mode='temporal' (train.py:116-120): ones until set_inputs receives some
         self.pixel_weights = torch.ones(N * H * W, **self.f32) if (self.training and self.sample_weighted) else None
+        # per-image class counts for the Jaccard training metric (deeplabv3p/metrics.py:29-46), refreshed every step
+        self.metric_counts = (torch.zeros(N * 3 * self.C, dtype=torch.int32, device=self.dev).view(N, 3, self.C)
+                              if (self.training and self.want_class_counts) else None)
         self.fused_head = bool(self.training and self.loss_kind == 0 and not self.sample_weighted and os.environ.get('DL3P_FUSED_HEAD', '0') != '0' and zt is not None and
                                zt.requires_grad and L.head_train_supported(zt.H, zt.W, self.C, H, W))
         self.dlogits_big = (torch.zeros(N * H * W * self.cpad, **self.f32)
@@ -492,6 +496,10 @@ class Executor:
         else:
             P.k(L.upsample_softmax_ce, self.tptr(zt), zt.ld, None, 0, 1.0, None, self.probs.data_ptr(), None, self.cpad,
                 None, ctypes.byref(rows), N, zt.H, zt.W, self.C, self.H, self.W)
+        if train and self.metric_counts is not None:
+            P.k(L.fill, self.metric_counts.data_ptr(), 0.0, N * 3 * self.C)       # int32 zeros share the bit pattern
+            P.k(L.class_counts, self.tptr(zt), zt.ld, self.labels.data_ptr(), self.metric_counts.data_ptr(), N, zt.H, zt.W,
+                self.C, self.H, self.W)
         return P
 
     def _dropout_seed(self, op):

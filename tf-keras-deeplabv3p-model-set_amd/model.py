@@ -157,6 +157,35 @@ class SparseSoftmaxFocalLoss(object):
         self.__name__ = 'sparse_softmax_focal_loss'
 
 
+def Jaccard(y_true=None, y_pred=None):
+    """deeplabv3p/metrics.py:29-46, train.py:140 `metrics = {'pred_mask': Jaccard}`: a marker for compile(metrics=...);
+    the counts come from dl3p_class_counts on the device and jaccard_from_counts evaluates them"""
+    raise RuntimeError('Jaccard is evaluated on the device: pass it to compile(metrics=...)')
+
+
+def jaccard_from_counts(counts):
+    """counts (N,3,C) = per image [intersection, label pixels, predicted pixels] per class -> metrics.py:29-46"""
+    c = np.asarray(counts, dtype=np.float64)
+    inter, true, pred = c[:, 0], c[:, 1], c[:, 2]
+    union = true + pred - inter
+    legal = true > 0
+    ious = []
+    for i in range(c.shape[2]):
+        if legal[:, i].any():
+            ious.append(float(np.mean(inter[legal[:, i], i] / union[legal[:, i], i])))
+    return float(np.mean(ious)) if ious else float('nan')
+
+
+def _wants_jaccard(metrics):
+    if not metrics:
+        return False
+    items = metrics.values() if isinstance(metrics, dict) else metrics
+    flat = []
+    for it in items:
+        flat += list(it) if isinstance(it, (list, tuple)) else [it]
+    return any(it is Jaccard or getattr(it, '__name__', it) == 'Jaccard' for it in flat)
+
+
 def loss_spec(loss):
     """-> ('ce',) | ('weighted', weights) | ('focal', gamma, alpha): what the head kernel (and the oracle) need"""
     if isinstance(loss, WeightedSparseCategoricalCrossEntropy):
@@ -295,6 +324,8 @@ class DeeplabModel:
         if sample_weight_mode not in (None, 'temporal'):
             raise ValueError("sample_weight_mode must be None or 'temporal' (train.py:116-120)")
         self.sample_weight_mode = sample_weight_mode
+        self.metrics = metrics
+        self._jaccard = _wants_jaccard(metrics)
         if distributed is None:
             import torch.distributed as dist
             distributed = dist.is_available() and dist.is_initialized() and (
@@ -331,7 +362,8 @@ class DeeplabModel:
             self._exec[key] = Executor(self.graph, self.head, store, batch, training, self.num_classes,
                                        ignore_index=ignore, dist=self.dist if training else None,
                                        seed=self.seed + 7919 * rank, loss=loss_spec(self.loss), optimizer=opt,
-                                       sample_weighted=getattr(self, 'sample_weight_mode', None) == 'temporal')
+                                       sample_weighted=getattr(self, 'sample_weight_mode', None) == 'temporal',
+                                       class_counts=getattr(self, '_jaccard', False))
         return self._exec[key]
 
     def train_on_batch(self, x, y, sample_weight=None, return_tensor=False):
@@ -347,7 +379,11 @@ class DeeplabModel:
         ex.train_step()
         ex._steps = self._steps_on(ex) + 1
         self._steps += 1
-        return ex.loss if return_tensor else float(ex.loss.item())
+        if return_tensor:
+            return ex.loss
+        loss = float(ex.loss.item())
+        self.last_metrics = {'Jaccard': jaccard_from_counts(ex.metric_counts.cpu().numpy())} if ex.metric_counts is not None else {}
+        return loss
 
     @staticmethod
     def _steps_on(ex):
@@ -377,7 +413,7 @@ class DeeplabModel:
         for cb in callbacks or []:
             getattr(cb, 'set_model', lambda m: None)(self)
         for epoch in range(initial_epoch, epochs):
-            t0, losses = time.time(), []
+            t0, losses, metric_sums = time.time(), [], {}
             it = iter(gen) if not hasattr(gen, '__getitem__') else None
             for i in range(n):
                 batch = gen[i] if it is None else next(it)
@@ -386,12 +422,18 @@ class DeeplabModel:
                 if isinstance(sw, dict):
                     sw = next(iter(sw.values()))          # {'pred_mask': weights}
                 losses.append(self.train_on_batch(batch[0], batch[1], sample_weight=sw))
+                for mk, mv in getattr(self, 'last_metrics', {}).items():
+                    metric_sums.setdefault(mk, []).append(mv)
                 if not np.isfinite(losses[-1]):      # TerminateOnNaN (train.py:64)
                     self.stop_training = True
                     break
             logs = {'loss': float(np.mean(losses))}
+            for mk, mv in metric_sums.items():             # Keras averages a metric over the epoch's batches
+                logs[mk] = float(np.nanmean(mv))
             if validation_data is not None:
                 logs['val_loss'] = self.evaluate(validation_data, validation_steps)
+                for mk, mv in getattr(self, 'last_val_metrics', {}).items():
+                    logs['val_' + mk] = mv
             history['loss'].append(logs['loss'])
             if verbose:
                 print('Epoch %d/%d - %.1fs - loss: %.4f%s' % (
@@ -525,7 +567,7 @@ class DeeplabModel:
 def _evaluate(self, gen, steps=None):
     """mean data loss with inference-mode BN and no dropout"""
     n = steps or len(gen)
-    tot, cnt = 0.0, 0
+    tot, cnt, jac = 0.0, 0, []
     ignore = self.loss.ignore_index if self.loss is not None else 255
     for i in range(n):
         x, y = gen[i][0], gen[i][1]
@@ -538,6 +580,17 @@ def _evaluate(self, gen, steps=None):
         pt = np.clip(p[np.where(ok)[0], lab[ok]], 1e-7, 1 - 1e-7)
         tot += float(-np.log(pt).sum())
         cnt += lab.size
+        if getattr(self, '_jaccard', False):
+            B = np.asarray(x).shape[0]
+            pr, lb = p.argmax(-1).reshape(B, -1), lab.reshape(B, -1)
+            C = self.num_classes
+            counts = np.zeros((B, 3, C))
+            for c in range(C):
+                counts[:, 0, c] = ((lb == c) & (pr == c)).sum(1)
+                counts[:, 1, c] = (lb == c).sum(1)
+                counts[:, 2, c] = (pr == c).sum(1)
+            jac.append(jaccard_from_counts(counts))
+    self.last_val_metrics = {'Jaccard': float(np.nanmean(jac))} if jac else {}
     return tot / max(cnt, 1)
 
 
