@@ -597,16 +597,27 @@ static void launch_pw_small_any(const GemmParams& p, SmallShape sh, int grid, hi
 }
 
 // choose the columns-per-workgroup (NT tiles of 16) that wastes the fewest MFMA columns
-static int pick_nt(int N) {
+static int pick_nt(int N, int M) {
   const int ntiles = ceil_div(N, 16);
-  static const int cand[] = {8, 6, 5, 4, 3, 2, 1};
+  static const int cand[] = {8, 7, 6, 5, 4, 3, 2, 1};
   int best = 1;
   float best_cost = 1e30f;
   static const int nt_max = getenv("DL3P_GEMM_NT_MAX") ? atoi(getenv("DL3P_GEMM_NT_MAX")) : 8;
+  static const int quant = getenv("DL3P_GEMM_QUANT") ? atoi(getenv("DL3P_GEMM_QUANT")) : 1;
+  // Small grids (Xception at batch 4: M = 4356, N = 728 -> 414 workgroups of 64x128 on 256 CUs): what counts is how
+  // many workgroups the busiest CU has to run, times the cost of one (fixed part ~2 column blocks + nt).  112-column
+  // tiles (nt = 7) exist for this regime only: 483 workgroups of 7/8 the work instead of 414.
+  const long long mt64 = ceil_div(M, 64);
+  const bool small = quant && mt64 * ceil_div(ntiles, 8) <= 6LL * DL3P_NUM_CUS;
   for (int c : cand) {
-    if (c > nt_max) continue;
-    // MFMA columns actually computed, plus the A-tile re-reads/staging that every column block repeats
-    const float cost = (float)(ceil_div(ntiles, c) * c) * (1.f + 1.5f / (float)c);
+    if (c > nt_max || (c == 7 && !small)) continue;
+    float cost;
+    if (small) {
+      cost = (float)ceil_div_ll(mt64 * ceil_div(ntiles, c), DL3P_NUM_CUS) * (2.f + (float)c);
+    } else {
+      // MFMA columns actually computed, plus the A-tile re-reads/staging that every column block repeats
+      cost = (float)(ceil_div(ntiles, c) * c) * (1.f + 1.5f / (float)c);
+    }
     if (cost < best_cost) { best = c; best_cost = cost; }
   }
   return best;
@@ -665,6 +676,7 @@ static void launch_gemm_mi(const GemmParams& p, int nt, dim3 grid, hipStream_t s
     case 4: launch_gemm_one<4, B_KN, STATS, MI, BKT, BNB>(p, grid, st); break;
     case 5: launch_gemm_one<5, B_KN, STATS, MI, BKT, BNB>(p, grid, st); break;
     case 6: launch_gemm_one<6, B_KN, STATS, MI, BKT, BNB>(p, grid, st); break;
+    case 7: launch_gemm_one<7, B_KN, STATS, MI, BKT, BNB>(p, grid, st); break;
     default: launch_gemm_one<8, B_KN, STATS, MI, BKT, BNB>(p, grid, st); break;
   }
 }
@@ -721,7 +733,7 @@ static int pwconv_fwd_impl(const char* fn, const float* x, int ldx, const float*
     DL3P_CHECK_LAUNCH(fn);
     return DL3P_OK;
   }
-  const int nt = pick_nt(N);
+  const int nt = pick_nt(N, M);
   int gx, gy, mi;
   gemm_grid(M, N, nt, &gx, &gy, &p.num_m_tiles, &mi);
   if (rows_out) *rows_out = gx;
@@ -810,7 +822,7 @@ extern "C" int dl3p_pwconv_bwd_data(const float* dy, int lddy, const float* w, f
     DL3P_CHECK_LAUNCH("dl3p_pwconv_bwd_data");
     return DL3P_OK;
   }
-  const int nt = pick_nt(K);
+  const int nt = pick_nt(K, M);
   int gxn, gy, mi;
   gemm_grid(M, K, nt, &gxn, &gy, &p.num_m_tiles, &mi);
   launch_gemm<false, false>(p, nt, mi, dim3(gxn, gy), (hipStream_t)stream);
@@ -842,7 +854,7 @@ extern "C" int dl3p_pwconv_bwd_data_bn(const float* dy, int lddy, const float* w
   p.partials = partials;
   p.bb_z = z; p.bb_ldz = ldz; p.bb_scale = scale; p.bb_shift = shift; p.bb_mean = save_mean; p.bb_invstd = save_invstd;
   p.bb_act = act;
-  const int nt = pick_nt(K);
+  const int nt = pick_nt(K, M);
   int gxn, gy, mi;
   gemm_grid(M, K, nt, &gxn, &gy, &p.num_m_tiles, &mi);
   *rows_out = gxn;
