@@ -415,15 +415,21 @@ class DeeplabModel:
         for epoch in range(initial_epoch, epochs):
             t0, losses, metric_sums = time.time(), [], {}
             it = iter(gen) if not hasattr(gen, '__getitem__') else None
+            fetch = (lambda i: gen[i]) if it is None else (lambda i: next(it))
+            batch = fetch(0) if n > 0 else None
             for i in range(n):
-                batch = gen[i] if it is None else next(it)
                 # generators yield (x, y) or, in adaptive weighting mode, (x, y, sample_weight) (deeplabv3p/data.py:149-154)
                 sw = batch[2] if len(batch) > 2 else None
                 if isinstance(sw, dict):
                     sw = next(iter(sw.values()))          # {'pred_mask': weights}
-                losses.append(self.train_on_batch(batch[0], batch[1], sample_weight=sw))
-                for mk, mv in getattr(self, 'last_metrics', {}).items():
-                    metric_sums.setdefault(mk, []).append(mv)
+                # the step is only enqueued here; the generator prepares the next batch (decode, augment, resize on
+                # the host) while the GPU runs it, and the loss is read back afterwards
+                loss_t = self.train_on_batch(batch[0], batch[1], sample_weight=sw, return_tensor=True)
+                ex = self._executor(int(np.shape(batch[0])[0]), True)
+                batch = fetch(i + 1) if i + 1 < n else None
+                losses.append(float(loss_t.item()))
+                if ex.metric_counts is not None:
+                    metric_sums.setdefault('Jaccard', []).append(jaccard_from_counts(ex.metric_counts.cpu().numpy()))
                 if not np.isfinite(losses[-1]):      # TerminateOnNaN (train.py:64)
                     self.stop_training = True
                     break
