@@ -97,7 +97,10 @@ def _rel(a, b):
 @pytest.mark.parametrize('model_type,H,W', [('mobilenetv2', 65, 65), ('mobilenetv2_lite', 65, 97), ('xception', 65, 65),
                                             ('mobilenetv3large', 65, 65), ('mobilenetv3large', 64, 96),
                                             ('mobilenetv3small', 65, 65), ('mobilenetv3small_lite', 64, 96),
-                                            ('mobilenetv3large_lite', 65, 65), ('resnet50', 65, 65), ('resnet50', 64, 96)])
+                                            ('mobilenetv3large_lite', 65, 65), ('resnet50', 65, 65), ('resnet50', 64, 96),
+                                            # degenerate sizes: OS-16 maps of 3x3 / 2x1 pixels (every atrous tap but the
+                                            # centre in the padding, maps narrower than a window strip)
+                                            ('mobilenetv2', 33, 33), ('mobilenetv3large', 17, 24), ('xception', 33, 40)])
 def test_predict_matches_oracle(model_type, H, W):
     m, o = _pair(model_type, H, W, 21, training=False)
     x, _ = _data(2, H, W, 21)
@@ -118,6 +121,7 @@ def test_predict_matches_oracle(model_type, H, W):
                                                       ('mobilenetv3small', 65, 65, 0, 16), ('mobilenetv3small_lite', 65, 65, 0, 16),
                                                       ('mobilenetv3large_lite', 65, 65, 0, 16),
                                                       ('resnet50', 65, 65, 0, 16), ('resnet50', 65, 65, 0, 8),
+                                                      ('mobilenetv2', 33, 33, 0, 16), ('mobilenetv3large', 33, 40, 0, 16),
                                                       # output stride 8 (BASELINE configs[3]): denser atrous grid, ASPP rates 12/24/36
                                                       ('mobilenetv2', 65, 65, 0, 8), ('xception', 97, 97, 0, 8)])
 def test_train_step_matches_oracle(model_type, H, W, freeze, OS):
