@@ -618,6 +618,13 @@ def test_maxpool2d(ops, case):
     base = rng.standard_normal(x.shape)
     gx2 = ops.maxpool2d_bwd(T(x), T(gy), k, s, pad, T(sc), T(sh), ops.ACT_RELU, out=T(base), accumulate=True)
     assert np.abs((gx2 - gx).cpu().numpy() - base).max() < 1e-5
+    # recorded winners: the forward stores each window's first maximum, the backward reads it back -> same gradient
+    Ho, Wo = y_ref.shape[1:3]
+    rec = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=DEV)
+    y2 = ops.maxpool2d_fwd(T(x), k, s, pad, T(sc), T(sh), ops.ACT_RELU, argmax=rec)
+    assert torch.equal(y2, y)
+    gx3 = ops.maxpool2d_bwd(T(x), T(gy), k, s, pad, T(sc), T(sh), ops.ACT_RELU, argmax=rec)
+    assert torch.equal(gx3, gx)
     raw, arg_raw = O.maxpool2d_fwd(x, k, s, pad)           # no prologue: negative inputs lose against the padded zeros
     close(ops.maxpool2d_fwd(T(x), k, s, pad), raw, what='maxpool fwd, bare')
     g_raw = O.maxpool2d_bwd(gy, arg_raw, x.shape, k, s, pad)

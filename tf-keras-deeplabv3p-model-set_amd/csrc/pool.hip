@@ -10,6 +10,7 @@ struct PoolParams {
   const float* scale; const float* shift; int act;
   float* y; int ldy;              // forward output / backward: gradient w.r.t. the (activated) input
   const float* dy; int lddy;
+  unsigned char* arg;             // [N][Ho][Wo][C] tap index of each window's first maximum (forward writes, backward reads)
   int accumulate;
   int N, H, W, C, k, stride, pad_t, pad_l, Ho, Wo;
   long long total;
@@ -35,12 +36,18 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(PoolParams p) {
     if (p.scale) { sc = ld4(p.scale + c); sh = ld4(p.shift + c); }
     const float* img = p.x + (size_t)n * p.H * p.W * p.ldx;
     float4 m = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+    uchar4 a = make_uchar4(0, 0, 0, 0);
     for (int ky = 0; ky < p.k; ++ky)
       for (int kx = 0; kx < p.k; ++kx) {
         const float4 v = pool_in(p, img, oy * p.stride - p.pad_t + ky, ox * p.stride - p.pad_l + kx, c, sc, sh);
-        m = make_float4(fmaxf(m.x, v.x), fmaxf(m.y, v.y), fmaxf(m.z, v.z), fmaxf(m.w, v.w));
+        const unsigned char t = (unsigned char)(ky * p.k + kx);
+        if (v.x > m.x) { m.x = v.x; a.x = t; }             // strict: the first maximum in (ky, kx) order wins
+        if (v.y > m.y) { m.y = v.y; a.y = t; }
+        if (v.z > m.z) { m.z = v.z; a.z = t; }
+        if (v.w > m.w) { m.w = v.w; a.w = t; }
       }
     st4(p.y + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.ldy + c, m);
+    if (p.arg) *reinterpret_cast<uchar4*>(p.arg + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.C + c) = a;
   }
 }
 
@@ -57,8 +64,28 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolParams p) {
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero4();
     if (p.scale) { sc = ld4(p.scale + c); sh = ld4(p.shift + c); }
     const float* img = p.x + (size_t)n * p.H * p.W * p.ldx;
-    const float4 mine = pool_in(p, img, iy, ix, c, sc, sh);
     float4 g = zero4();
+    if (p.arg) {
+      // the forward pass recorded which tap won each window: 2 small loads per window instead of recomputing it
+      const int oy_hi = (iy + p.pad_t) / p.stride, ox_hi = (ix + p.pad_l) / p.stride;
+      for (int oy = oy_hi; oy >= 0 && oy * p.stride - p.pad_t + p.k > iy; --oy) {
+        if (oy >= p.Ho) continue;
+        for (int ox = ox_hi; ox >= 0 && ox * p.stride - p.pad_l + p.k > ix; --ox) {
+          if (ox >= p.Wo) continue;
+          const unsigned char t = (unsigned char)((iy - (oy * p.stride - p.pad_t)) * p.k + ix - (ox * p.stride - p.pad_l));
+          const size_t o = ((size_t)n * p.Ho + oy) * p.Wo + ox;
+          const uchar4 a = *reinterpret_cast<const uchar4*>(p.arg + o * p.C + c);
+          const float4 d = ld4(p.dy + o * p.lddy + c);
+          g = make_float4(g.x + (a.x == t ? d.x : 0.f), g.y + (a.y == t ? d.y : 0.f), g.z + (a.z == t ? d.z : 0.f),
+                          g.w + (a.w == t ? d.w : 0.f));
+        }
+      }
+      float* o = p.y + (((size_t)n * p.H + iy) * p.W + ix) * p.ldy + c;
+      if (p.accumulate) g = add4(g, ld4(o));
+      st4(o, g);
+      continue;
+    }
+    const float4 mine = pool_in(p, img, iy, ix, c, sc, sh);
     // windows (oy, ox) with oy*stride - pad_t <= iy < oy*stride - pad_t + k
     const int oy_hi = (iy + p.pad_t) / p.stride, ox_hi = (ix + p.pad_l) / p.stride;
     for (int oy = oy_hi; oy >= 0 && oy * p.stride - p.pad_t + p.k > iy; --oy) {
@@ -102,15 +129,16 @@ unsigned grid_for(long long total) {
 }  // namespace
 
 extern "C" int dl3p_maxpool2d_fwd(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
-                                  float* y, int ldy, int N, int H, int W, int C, int k, int stride, int pad_t,
-                                  int pad_l, int Ho, int Wo, void* stream) {
-  DL3P_CHECK_ARG(C > 0 && C % 4 == 0 && N > 0 && k >= 1 && stride >= 1 && Ho > 0 && Wo > 0, "dl3p_maxpool2d_fwd: bad dims");
+                                  float* y, int ldy, uint8_t* argmax, int N, int H, int W, int C, int k, int stride,
+                                  int pad_t, int pad_l, int Ho, int Wo, void* stream) {
+  DL3P_CHECK_ARG(C > 0 && C % 4 == 0 && N > 0 && k >= 1 && k <= 15 && stride >= 1 && Ho > 0 && Wo > 0, "dl3p_maxpool2d_fwd: bad dims");
+  DL3P_CHECK_ARG(!argmax || (uintptr_t)argmax % 4 == 0, "dl3p_maxpool2d_fwd: argmax must be 4-byte aligned");
   int rc = check("dl3p_maxpool2d_fwd", x, ldx, C);
   if (rc) return rc;
   rc = check("dl3p_maxpool2d_fwd", y, ldy, C);
   if (rc) return rc;
   PoolParams p = {};
-  p.x = x; p.ldx = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act; p.y = y; p.ldy = ldy;
+  p.x = x; p.ldx = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act; p.y = y; p.ldy = ldy; p.arg = argmax;
   p.N = N; p.H = H; p.W = W; p.C = C; p.k = k; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l; p.Ho = Ho; p.Wo = Wo;
   p.total = (long long)N * Ho * Wo * (C / 4);
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(p.total)), dim3(256), 0, (hipStream_t)stream, p);
@@ -119,8 +147,9 @@ extern "C" int dl3p_maxpool2d_fwd(const float* x, int ldx, const float* in_scale
 }
 
 extern "C" int dl3p_maxpool2d_bwd(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
-                                  const float* dy, int lddy, float* gx, int ldgx, int accumulate, int N, int H, int W,
-                                  int C, int k, int stride, int pad_t, int pad_l, int Ho, int Wo, void* stream) {
+                                  const float* dy, int lddy, const uint8_t* argmax, float* gx, int ldgx, int accumulate,
+                                  int N, int H, int W, int C, int k, int stride, int pad_t, int pad_l, int Ho, int Wo,
+                                  void* stream) {
   DL3P_CHECK_ARG(C > 0 && C % 4 == 0 && N > 0 && k >= 1 && stride >= 1 && Ho > 0 && Wo > 0, "dl3p_maxpool2d_bwd: bad dims");
   int rc = check("dl3p_maxpool2d_bwd", x, ldx, C);
   if (rc) return rc;
@@ -130,7 +159,7 @@ extern "C" int dl3p_maxpool2d_bwd(const float* x, int ldx, const float* in_scale
   if (rc) return rc;
   PoolParams p = {};
   p.x = x; p.ldx = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act; p.y = gx; p.ldy = ldgx;
-  p.dy = dy; p.lddy = lddy; p.accumulate = accumulate;
+  p.dy = dy; p.lddy = lddy; p.accumulate = accumulate; p.arg = const_cast<uint8_t*>(argmax);
   p.N = N; p.H = H; p.W = W; p.C = C; p.k = k; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l; p.Ho = Ho; p.Wo = Wo;
   p.total = (long long)N * H * W * (C / 4);
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(p.total)), dim3(256), 0, (hipStream_t)stream, p);

@@ -258,6 +258,7 @@ class Executor:
         self.ignore_index = ignore_index
         # loss: ('ce',) | ('weighted', weights[C]) | ('focal', gamma, alpha)  (model.loss_spec)
         self._u8 = {}
+        self._pool_arg = {}
         self.sample_weighted = bool(sample_weighted)
         self.want_class_counts = bool(class_counts)
         self.loss_kind = {'ce': 0, 'weighted': 1, 'focal': 2}[loss[0]]
@@ -463,8 +464,11 @@ class Executor:
             elif k == 'maxpool':
                 xp, ldx, sp, hp, act = self.vargs(op.x)
                 xt, t = op.x.tensor, op.out
-                P.k(L.maxpool2d_fwd, xp, ldx, sp, hp, act, self.tptr(t), t.ld, N, xt.H, xt.W, xt.C, op.k, op.stride,
-                    op.pad_t, op.pad_l, op.Ho, op.Wo)
+                arg = None
+                if train:          # the backward pass reads the winning taps instead of re-evaluating the windows
+                    arg = self._pool_arg[op] = torch.empty(N * op.Ho * op.Wo * xt.C, dtype=torch.uint8, device=self.dev)
+                P.k(L.maxpool2d_fwd, xp, ldx, sp, hp, act, self.tptr(t), t.ld, None if arg is None else arg.data_ptr(), N,
+                    xt.H, xt.W, xt.C, op.k, op.stride, op.pad_t, op.pad_l, op.Ho, op.Wo)
             elif k == 'se_mul':
                 xp, ldx, sp, hp, act = self.vargs(op.x)
                 s_ptr, lds, _, _, sact = self.vargs(op.s)
@@ -687,8 +691,8 @@ class Executor:
                 xp, ldx, sp, hp, act = self.vargs(op.x)
                 xt = op.x.tensor
                 gp, ldg, keyt = self._gbuf(op.x)
-                P.k(L.maxpool2d_bwd, xp, ldx, sp, hp, act, self.tptr(out, True), out.ld, gp, ldg, self._acc(keyt), N,
-                    xt.H, xt.W, xt.C, op.k, op.stride, op.pad_t, op.pad_l, op.Ho, op.Wo)
+                P.k(L.maxpool2d_bwd, xp, ldx, sp, hp, act, self.tptr(out, True), out.ld, self._pool_arg[op].data_ptr(), gp,
+                    ldg, self._acc(keyt), N, xt.H, xt.W, xt.C, op.k, op.stride, op.pad_t, op.pad_l, op.Ho, op.Wo)
             elif k == 'gap':
                 xt = op.x.tensor
                 gp, ldg, keyt = self._gbuf(op.x)

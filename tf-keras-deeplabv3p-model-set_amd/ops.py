@@ -349,7 +349,7 @@ def global_avgpool_bwd(gy, H, W, out=None, accumulate=False):
     return gx
 
 
-def maxpool2d_fwd(x, k, stride, pad, in_scale=None, in_shift=None, in_act=ACT_NONE):
+def maxpool2d_fwd(x, k, stride, pad, in_scale=None, in_shift=None, in_act=ACT_NONE, argmax=None):
     """x (N,H,W,C), explicit zero padding pad = (top, bottom, left, right) then VALID max pooling"""
     N, H, W, C = x.shape
     pt, pb, pl, pr = pad
@@ -357,11 +357,13 @@ def maxpool2d_fwd(x, k, stride, pad, in_scale=None, in_shift=None, in_act=ACT_NO
     y = torch.empty((N, Ho, Wo, C), dtype=torch.float32, device=x.device)
     xp, ldx = _pl(x)
     yp, ldy = _pl(y)
-    lib().maxpool2d_fwd(xp, ldx, _p(in_scale), _p(in_shift), in_act, yp, ldy, N, H, W, C, k, stride, pt, pl, Ho, Wo, _stream())
+    lib().maxpool2d_fwd(xp, ldx, _p(in_scale), _p(in_shift), in_act, yp, ldy, _p(argmax), N, H, W, C, k, stride, pt, pl, Ho, Wo,
+                        _stream())
     return y
 
 
-def maxpool2d_bwd(x, dy, k, stride, pad, in_scale=None, in_shift=None, in_act=ACT_NONE, out=None, accumulate=False):
+def maxpool2d_bwd(x, dy, k, stride, pad, in_scale=None, in_shift=None, in_act=ACT_NONE, out=None, accumulate=False,
+                  argmax=None):
     N, H, W, C = x.shape
     pt, pb, pl, pr = pad
     Ho, Wo = dy.shape[1], dy.shape[2]
@@ -369,8 +371,8 @@ def maxpool2d_bwd(x, dy, k, stride, pad, in_scale=None, in_shift=None, in_act=AC
     xp, ldx = _pl(x)
     dp, ldd = _pl(dy)
     gp, ldg = _pl(gx)
-    lib().maxpool2d_bwd(xp, ldx, _p(in_scale), _p(in_shift), in_act, dp, ldd, gp, ldg, int(accumulate), N, H, W, C, k, stride,
-                        pt, pl, Ho, Wo, _stream())
+    lib().maxpool2d_bwd(xp, ldx, _p(in_scale), _p(in_shift), in_act, dp, ldd, _p(argmax), gp, ldg, int(accumulate), N, H, W, C,
+                        k, stride, pt, pl, Ho, Wo, _stream())
     return gx
 
 
