@@ -510,3 +510,24 @@ def test_jaccard_training_metric():
     m.fit_generator(Gen(), steps_per_epoch=2, epochs=1, validation_data=Gen(), validation_steps=1, callbacks=[Cb()], verbose=0)
     assert 0.0 <= hist_logs[0]['Jaccard'] <= 1.0 and 0.0 <= hist_logs[0]['val_Jaccard'] <= 1.0
 
+
+@pytest.mark.parametrize('kind', ['ce', 'focal'])
+def test_evaluate_loss_matches_oracle(kind):
+    """model.evaluate (validation loss of fit): the compiled loss in inference mode, computed on the device, against the
+    oracle's predict() logits pushed through the same loss"""
+    from oracle import np_ops as O
+    pkg = load_pkg()
+    N, C, H, W = 2, 21, 65, 65
+    m, o = _pair('mobilenetv2_lite', H, W, C, training=False)
+    loss_obj = (pkg.SparseSoftmaxFocalLoss(ignore_index=255) if kind == 'focal'
+                else pkg.SparseCategoricalCrossEntropy(ignore_index=255))
+    m.compile(optimizer=None, loss=loss_obj, metrics={'pred_mask': pkg.Jaccard})
+    batches = [_data(N, H, W, C, seed=60 + i) for i in range(2)]
+    got = m.evaluate(batches)
+    want = []
+    for x, y in batches:
+        logits, _ = o.predict(x)
+        want.append(O.loss_fwd_bwd(logits, np.asarray(y).reshape(N, H, W), ('focal', 2.0, 0.25) if kind == 'focal' else None, 255)[0])
+    assert abs(got - np.mean(want)) < TOL * max(1.0, abs(np.mean(want))), (got, want)
+    assert 0.0 <= m.last_val_metrics['Jaccard'] <= 1.0
+

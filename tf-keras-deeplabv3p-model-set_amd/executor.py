@@ -887,6 +887,31 @@ class Executor:
                                 confusion.data_ptr(), self.N, zt.H, zt.W, self.C, self.H, self.W,
                                 torch.cuda.current_stream().cuda_stream)
 
+    def eval_loss_step(self, counts=None):
+        """validation step on the device: inference forward, the compiled loss against self.labels (no gradient, no
+        probability tensor) and, if asked for, the per-image class counts of the Jaccard metric; -> loss tensor [1]"""
+        assert not self.training
+        if getattr(self, '_eval_plan', None) is None:
+            P = Plan()
+            P.items = list(self.fwd.items[:-1])
+            P.labels = list(self.fwd.labels[:-1])
+            self._eval_plan = P
+        self._eval_plan.run()
+        zt, L = self.head.tensor, self.L
+        st = torch.cuda.current_stream().cuda_stream
+        rows = ctypes.c_int(0)
+        L.upsample_softmax_loss(self.tptr(zt), zt.ld, self.labels.data_ptr(), int(self.ignore_index or 0),
+                                1.0 / float(self.N * self.H * self.W), self.loss_kind,
+                                None if self.class_weights is None else self.class_weights.data_ptr(), self.loss_gamma,
+                                self.loss_alpha, None, None, None, None, self.cpad, self.loss_partials.data_ptr(),
+                                ctypes.byref(rows), self.N, zt.H, zt.W, self.C, self.H, self.W, st)
+        L.reduce_rows(self.loss_partials.data_ptr(), rows.value, 1, self.loss.data_ptr(), 0, st)
+        if counts is not None:
+            L.fill(counts.data_ptr(), 0.0, counts.numel(), st)
+            L.class_counts(self.tptr(zt), zt.ld, self.labels.data_ptr(), counts.data_ptr(), self.N, zt.H, zt.W, self.C,
+                           self.H, self.W, st)
+        return self.loss
+
     def install_probe(self, name):
         """time one forward depthwise launch with HIP events inside the steps (bench.py roofline)"""
         op = [o for o in self.g.ops if getattr(o, 'name', None) == name and o.kind == 'conv_dw'][0]

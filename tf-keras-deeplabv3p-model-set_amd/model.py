@@ -571,31 +571,25 @@ class DeeplabModel:
 
 
 def _evaluate(self, gen, steps=None):
-    """mean data loss with inference-mode BN and no dropout"""
+    """Keras `evaluate` / the validation pass of `fit`: mean of the compiled loss with inference-mode BN and no dropout,
+    evaluated on the device (the probability tensor is neither written nor downloaded); fills last_val_metrics"""
+    import torch
     n = steps or len(gen)
     tot, cnt, jac = 0.0, 0, []
-    ignore = self.loss.ignore_index if self.loss is not None else 255
     for i in range(n):
-        x, y = gen[i][0], gen[i][1]
-        p = self.predict(x)
-        p = p.reshape(-1, self.num_classes)
-        lab = np.asarray(y).reshape(-1).astype(np.int64)
-        ok = (lab >= 0) & (lab < self.num_classes)
-        if ignore:
-            ok &= lab != ignore
-        pt = np.clip(p[np.where(ok)[0], lab[ok]], 1e-7, 1 - 1e-7)
-        tot += float(-np.log(pt).sum())
-        cnt += lab.size
+        x, y = np.asarray(gen[i][0]), np.asarray(gen[i][1])
+        B = x.shape[0]
+        ex = self._executor(B, False)
+        ex.set_inputs(x if x.dtype == np.uint8 else x.astype(np.float32, copy=False),
+                      y if y.dtype == np.uint8 else y.astype(np.float32, copy=False))
+        counts = None
         if getattr(self, '_jaccard', False):
-            B = np.asarray(x).shape[0]
-            pr, lb = p.argmax(-1).reshape(B, -1), lab.reshape(B, -1)
-            C = self.num_classes
-            counts = np.zeros((B, 3, C))
-            for c in range(C):
-                counts[:, 0, c] = ((lb == c) & (pr == c)).sum(1)
-                counts[:, 1, c] = (lb == c).sum(1)
-                counts[:, 2, c] = (pr == c).sum(1)
-            jac.append(jaccard_from_counts(counts))
+            counts = torch.zeros((B, 3, self.num_classes), dtype=torch.int32, device='cuda')
+        loss = float(ex.eval_loss_step(counts).item())
+        tot += loss * B
+        cnt += B
+        if counts is not None:
+            jac.append(jaccard_from_counts(counts.cpu().numpy()))
     self.last_val_metrics = {'Jaccard': float(np.nanmean(jac))} if jac else {}
     return tot / max(cnt, 1)
 
