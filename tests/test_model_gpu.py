@@ -332,6 +332,8 @@ def test_evaluate_miou_matches_oracle_recipe():
         logits = ops.upsample_softmax_ce(ex.view(m.head.tensor), C, H, W, want_logits=True)['logits'][..., :C]
         pred = logits.cpu().numpy().argmax(-1)               # eval.py:33-36
         cm += O.confusion_matrix(np.asarray(y).reshape(B, H, W), pred, C)
+    mask = m.predict_mask(batches[-1][0])
+    assert mask.shape == (B, H, W) and mask.dtype == np.int32 and np.array_equal(mask, pred)
     assert len(np.unique(cm.nonzero()[1])) > 3, 'degenerate prediction: the test would prove nothing'
     assert np.array_equal(res['confusion_matrix'].astype(np.int64), cm)
     ref = O.miou_summary(cm)

@@ -883,9 +883,10 @@ class Executor:
             self._eval_plan = P
         self._eval_plan.run()
         zt = self.head.tensor
-        self.L.argmax_confusion(self.tptr(zt), zt.ld, self.labels.data_ptr(), None if pred is None else pred.data_ptr(),
-                                confusion.data_ptr(), self.N, zt.H, zt.W, self.C, self.H, self.W,
-                                torch.cuda.current_stream().cuda_stream)
+        self.L.argmax_confusion(self.tptr(zt), zt.ld, None if confusion is None else self.labels.data_ptr(),
+                                None if pred is None else pred.data_ptr(),
+                                None if confusion is None else confusion.data_ptr(), self.N, zt.H, zt.W, self.C, self.H,
+                                self.W, torch.cuda.current_stream().cuda_stream)
 
     def eval_loss_step(self, counts=None):
         """validation step on the device: inference forward, the compiled loss against self.labels (no gradient, no
