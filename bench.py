@@ -31,7 +31,10 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=16, help='per-GPU batch')
+    ap.add_argument('--batch', type=int, default=16, help='per-GPU batch (with --scaling strong: the GLOBAL batch)')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
+                    help="weak: per-GPU batch fixed (default, what the driver measures); strong: the reference's semantics, "
+                         "--batch is the global batch split across the ranks (train.py:143-158)")
     ap.add_argument('--size', type=int, default=513, help='input height (and width unless --width is given)')
     ap.add_argument('--width', type=int, default=0, help='input width for non-square inputs (1024x2048 Cityscapes)')
     ap.add_argument('--model', default='mobilenetv2')
@@ -104,6 +107,10 @@ def main():
     pkg = importlib.import_module(PKG)
     H, W = args.size, (args.width or args.size)
     N, C = args.batch, args.classes
+    if args.scaling == 'strong':
+        if args.batch % world:
+            raise SystemExit('--scaling strong: the global batch %d does not divide over %d ranks' % (args.batch, world))
+        N = args.batch // world
 
     model = pkg.get_deeplabv3p_model(args.model, C, (H, W), args.os, freeze_level=0, training=True)
     model.compile(optimizer=pkg.SGD(0.01, momentum=0.9), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255),
@@ -155,7 +162,7 @@ def main():
             'metric': 'images/sec (513x513, 21-class) MobileNetV2-DeepLabV3+ OS=16 training step',
             'value': round(N * world * args.steps / dt, 2), 'unit': 'images/sec', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000 * dt / args.steps, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%s + ASPP(%s) + decoder, OS=%d, %dx%d, %d classes, per-GPU batch %d, '
                                    'fwd+loss+bwd+SGD(momentum 0.9, l2 2e-5), BN training mode, dropout 0.5'
                                    % (args.model, {8: '12/24/36', 16: '6/12/18', 32: '3/6/9'}[args.os], args.os, H, W, C, N),
