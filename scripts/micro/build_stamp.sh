@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/../.."
 P=tf-keras-deeplabv3p-model-set_amd
 mkdir -p /tmp/dl3p_stamp
-for f in bn_elementwise conv dwconv pwconv resize_head; do
+for f in $(cd $P/csrc && ls *.hip | sed 's/\.hip$//'); do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -DDL3P_STAMP -c $P/csrc/$f.hip -o /tmp/dl3p_stamp/$f.o &
 done
 wait

@@ -141,6 +141,9 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
       rsc = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.scale) + kb);
       rsh = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.shift) + kb);
     }
+#ifdef DL3P_STAMP
+    if (p.stagger == 104 && it > 0) return;      // ablation: no B loads after the first K-step
+#endif
 #pragma unroll
     for (int i = 0; i < NB4; ++i) {
       const int idx = min(t + 256 * i, KQ * BN - 1);
@@ -185,6 +188,14 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
       if (a_edge) v = (kok && m0 + r < p.M) ? v : zero4();
       *reinterpret_cast<float4*>(&As[r * AP + akq]) = v;
     }
+#ifdef DL3P_STAMP
+    if ((p.stagger == 103 || p.stagger == 104) && it > 0) return;   // ablation: the B tile of the first K-step stays
+    if (p.stagger == 105 && it > 0) {                               // ... but the loads are still waited for
+#pragma unroll
+      for (int i = 0; i < NB4; ++i) asm volatile("" :: "v"(rb[i].x), "v"(rb[i].y), "v"(rb[i].z), "v"(rb[i].w));
+      return;
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < NB4; ++i) {
       const int idx = t + 256 * i;
@@ -223,7 +234,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
 #define STAMP(i) {}
 #endif
   // ablation modes of the instrumented build (scripts/micro/build_stamp.sh, DL3P_GEMM_STAGGER): 100 = no staging
-  // after the first K-step, 101 = also no epilogue, 102 = no global prefetch.  Measured on 266256x304x256:
+  // after the first K-step, 101 = also no epilogue, 102 = no global prefetch, 103 = no B-tile LDS stores (and no wait for its loads), 104 = no
+  // B-tile loads either, 105 = B loads waited for but not stored.  Measured on 266256x304x256:
   // 497 us -> 447 (102) -> 386 (100) -> 355 (101): the MFMA loop alone runs at 94 % of the clock- and
   // tile-quantisation-adjusted peak; staging costs 22 %, the epilogue 6 %.
 #ifdef DL3P_STAMP
