@@ -24,7 +24,7 @@ if len(sys.argv) > 1:
         e1.record(); torch.cuda.synchronize()
         print('  dgrad M=%d K=%d N=%d: %.1f us' % (M, K, N, e0.elapsed_time(e1) * 100))
 else:
-    for mode in ('0', '103', '104', '105'):
+    for mode in ('0', '103', '104', '105', '108'):
         print('DL3P_GEMM_STAGGER=' + mode, flush=True)
         env = dict(os.environ, DL3P_GEMM_STAGGER=mode)
         subprocess.run([sys.executable, __file__, 'child'], env=env)

@@ -52,6 +52,9 @@ struct GemmParams {
 
 // B_KN: B is [Kred][Nout] row-major (forward: the Keras kernel as stored);
 // !B_KN: B is [Nout][Kred] row-major (dgrad: the same kernel read as its transpose).
+#ifndef DL3P_GEMM_PIN_B
+#define DL3P_GEMM_PIN_B 1      // 0 builds the unpinned loop for A/B runs (scripts/micro/build_variant.sh)
+#endif
 template <int NT, bool B_KN, bool STATS, int MI, int BKT, bool BNB = false>
 __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
   constexpr int AP = BKT + 4;   // A pitch: rows 4 apart land 16 banks apart -> ds_read_b128 conflict-free
@@ -179,10 +182,16 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
     const bool a_edge = m0 + BM > p.M || k0 + BKT > p.K;
     const bool b_edge = n_edge || k0 + BKT > p.K;
     const bool kok = k0 + akq < p.K;
+#ifdef DL3P_STAMP
+    const bool skip_a = p.stagger == 106 && it > 0;     // ablation: A tile not restored (its loads still waited for)
+#else
+    constexpr bool skip_a = false;
+#endif
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int r = ar + RP * i;
       float4 v = ra[i];
+      if (skip_a) { asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); continue; }
       if (has_pro) v = prologue4(v);
       // zero rows/cols stay exactly zero (padding of the M and K tails)
       if (a_edge) v = (kok && m0 + r < p.M) ? v : zero4();
@@ -199,6 +208,20 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int i = 0; i < NB4; ++i) {
       const int idx = t + 256 * i;
+#ifdef DL3P_STAMP
+      // ablation: 107 stores only the first half of the B tile, 108 all but its last float4 per thread
+      if (it > 0 && ((p.stagger == 107 && i >= NB4 / 2) || (p.stagger == 108 && i == NB4 - 1))) {
+        asm volatile("" :: "v"(rb[i].x), "v"(rb[i].y), "v"(rb[i].z), "v"(rb[i].w));
+        continue;
+      }
+#endif
+#if DL3P_GEMM_PIN_B
+      // An empty asm that reads rb[i] right before its LDS store.  Without it clang hoists the B stores' address math
+      // and, in 64 of the 80 instantiations, ends up with an s_waitcnt vmcnt(5)/(6) INSIDE the next K-step's prefetch
+      // burst (right after the barrier): every wave then sits out a full memory latency before its first MFMA.  With
+      // the pin none of the 80 has that wait; the decoder GEMMs run 4-12 % faster ("stage phase").
+      asm volatile("" :: "v"(rb[i].x), "v"(rb[i].y), "v"(rb[i].z), "v"(rb[i].w));
+#endif
       if (idx < KQ * BN) {
         if (B_KN) {
           const int kk = idx / (BN / 4), nq = idx - kk * (BN / 4);
@@ -235,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
 #endif
   // ablation modes of the instrumented build (scripts/micro/build_stamp.sh, DL3P_GEMM_STAGGER): 100 = no staging
   // after the first K-step, 101 = also no epilogue, 102 = no global prefetch, 103 = no B-tile LDS stores (and no wait for its loads), 104 = no
-  // B-tile loads either, 105 = B loads waited for but not stored.  Measured on 266256x304x256:
+  // B-tile loads either, 105 = B loads waited for but not stored, 106 = the same for A.  Measured on 266256x304x256:
   // 497 us -> 447 (102) -> 386 (100) -> 355 (101): the MFMA loop alone runs at 94 % of the clock- and
   // tile-quantisation-adjusted peak; staging costs 22 %, the epilogue 6 %.
 #ifdef DL3P_STAMP
