@@ -10,7 +10,7 @@ if len(sys.argv) > 1:
     libm = importlib.import_module('tf-keras-deeplabv3p-model-set_amd._lib')
     libm._lib = libm.Lib(os.path.join(ROOT, 'scripts/micro/libdl3p_stamp.so'))
     ops = importlib.import_module('tf-keras-deeplabv3p-model-set_amd.ops')
-    for M, K, N in [(266256, 304, 256), (266256, 256, 256), (17424, 960, 160), (17424, 160, 960)]:
+    for M, K, N in [(266256, 304, 256), (266256, 256, 256), (4356, 728, 728), (17424, 960, 160)]:
         dy = torch.randn((M, N), device='cuda'); w = torch.randn((K, N), device='cuda') * 0.05
         gx = torch.empty((M, K), device='cuda')
         f = lambda: ops.pwconv_bwd_data(dy, w, out=gx)
@@ -24,7 +24,7 @@ if len(sys.argv) > 1:
         e1.record(); torch.cuda.synchronize()
         print('  dgrad M=%d K=%d N=%d: %.1f us' % (M, K, N, e0.elapsed_time(e1) * 100))
 else:
-    for mode in ('0', '103', '104', '105', '108'):
+    for mode in ('0', '100', '102', '103', '105', '106'):
         print('DL3P_GEMM_STAGGER=' + mode, flush=True)
         env = dict(os.environ, DL3P_GEMM_STAGGER=mode)
         subprocess.run([sys.executable, __file__, 'child'], env=env)

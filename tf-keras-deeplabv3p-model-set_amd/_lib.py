@@ -89,5 +89,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        _lib = Lib()
+        # DL3P_LIB_OVERRIDE: an A/B build of the same sources (scripts/micro/build_variant.sh), for running the
+        # parity tests against it; never a different implementation
+        _lib = Lib(os.environ['DL3P_LIB_OVERRIDE']) if os.environ.get('DL3P_LIB_OVERRIDE') else Lib()
     return _lib

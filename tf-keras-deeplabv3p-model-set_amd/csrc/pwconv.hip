@@ -263,6 +263,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
   // tile-quantisation-adjusted peak; staging costs 22 %, the epilogue 6 %.
 #ifdef DL3P_STAMP
   const int dbg = p.stagger;
+#elif defined(DL3P_ABLATE)
+  constexpr int dbg = DL3P_ABLATE;   // compile-time ablation of the production kernel: build_variant.sh abl100 -DDL3P_ABLATE=100
 #else
   constexpr int dbg = 0;
 #endif
