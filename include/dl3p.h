@@ -210,6 +210,14 @@ int dl3p_scale_bcast_bwd(const float* gy, int ldgy, const float* x, int ldx, con
 /* dst[i] = (float)src[i] / divide_by - subtract: normalize_image (common/data_utils.py:403-417: /127.5 - 1) and the
  * label cast (deeplabv3p/data.py:116-124: /1 - 0) for batches that arrive as bytes; bit-identical to NumPy float32 */
 int dl3p_u8_to_float(const unsigned char* src, float* dst, size_t n, float divide_by, float subtract, void* stream);
+/* The label tail of SegmentationGenerator.__getitem__ for byte labels (N images of P pixels each):
+ * labels_out = float(label), with label > num_classes-1 replaced by ignore_index (deeplabv3p/data.py:116-121);
+ * weights_out (optional) = the `--weighted_type adaptive` pixel weights (data.py:134-145): sklearn's
+ * compute_class_weight('balanced') over the values present in the image, P / (distinct values * count of the
+ * value) in float64, rounded to float32.  hist: N*256 unsigned workspace (zeroed by the call), NULL iff
+ * weights_out is NULL. */
+int dl3p_label_prepare(const unsigned char* labels, float* labels_out, float* weights_out, uint32_t* hist,
+                       int N, size_t P, int num_classes, int ignore_index, void* stream);
 int dl3p_fill(float* p, float value, size_t n, void* stream);
 int dl3p_increment_counter(int64_t* counter, void* stream);
 

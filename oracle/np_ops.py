@@ -486,6 +486,21 @@ def he_normal(rng, shape, fan_in, dtype=np.float64):
     return (out * std).astype(dtype)
 
 
+# ------------------------------------------------------------------- label tail of the generator (deeplabv3p/data.py)
+def prepare_labels(label, num_classes, ignore_index=255, adaptive=False):
+    """deeplabv3p/data.py:116-145 for one image: label (P,) integers -> (float32 labels with every value above
+    num_classes-1 set to ignore_index, float32 pixel weights or None).  The weights restate sklearn's
+    compute_class_weight('balanced', classes=np.unique(label), y=label): len(y) / (n_distinct * bincount), float64,
+    written into the generator's float32 array (ignore_index counts as a value, as it does there)"""
+    lab = np.asarray(label).astype(np.int32).ravel().copy()
+    lab[lab > num_classes - 1] = ignore_index
+    if not adaptive:
+        return lab.astype(np.float32), None
+    values, inverse, counts = np.unique(lab, return_inverse=True, return_counts=True)
+    recip = lab.size / (len(values) * counts.astype(np.float64))
+    return lab.astype(np.float32), recip[inverse].astype(np.float32)
+
+
 # ---------------------------------------------------------------------------------------- evaluation (eval.py)
 def confusion_matrix(gt_mask, pred_mask, num_classes):
     """eval.py:368-373 generate_matrix: rows = ground truth, columns = prediction, labels outside [0, C) dropped"""

@@ -36,3 +36,42 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print('train_on_batch with host uint8 batches:  %.1f images/s (%.2f ms/step)' % (N * K / dt, 1e3 * dt / K))
 
+
+# --weighted_type adaptive (deeplabv3p/data.py:134-145): the generator's per-image balanced class weights.  Host side as
+# the reference computes them (np.unique + one putmask per class; sklearn's formula inlined) against 'adaptive' on the
+# device (dl3p_label_prepare)
+m2 = pkg.get_deeplabv3p_model('mobilenetv2', C, (H, W), 16, training=True)
+m2.compile(optimizer=pkg.SGD(0.01, momentum=0.9), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255),
+           sample_weight_mode='temporal')
+
+
+def host_weights(lab_u8):
+    out = np.zeros((N, H * W), dtype='float32')
+    for n in range(N):
+        label = lab_u8[n].astype('int32').flatten()
+        label[label > (C - 1)] = 255
+        class_list, counts = np.unique(label, return_counts=True)
+        cw = label.size / (len(class_list) * counts.astype(np.float64))
+        for class_id, w in zip(class_list, cw):
+            np.putmask(out[n], label == class_id, w)
+    return out
+
+
+t0 = time.perf_counter()
+sw = host_weights(batches8[0][1])
+t_host = time.perf_counter() - t0
+for mode in ('host', 'device'):
+    for i in range(3):
+        m2.train_on_batch(*batches8[i % 3], sample_weight='adaptive')
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K):
+        x8, y8 = batches8[i % 3]
+        if mode == 'host':
+            m2.train_on_batch(x8, y8, sample_weight=host_weights(y8))
+        else:
+            m2.train_on_batch(x8, y8, sample_weight='adaptive')
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print('adaptive pixel weights on the %-6s: %.1f images/s (%.2f ms/step; host weights alone %.1f ms per batch)'
+          % (mode, N * K / dt, 1e3 * dt / K, 1e3 * t_host))

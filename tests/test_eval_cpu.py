@@ -77,3 +77,17 @@ def test_jaccard_metric_restatement_and_count_form():
         counts[:, 1, c] = (lab == c).sum(1)
         counts[:, 2, c] = (pred == c).sum(1)
     assert np.isclose(load_pkg().jaccard_from_counts(counts), O.jaccard_metric(lab, pred, 3))
+
+
+def test_prepare_labels_matches_sklearn_golden():
+    """the oracle's restatement of the generator's label tail (deeplabv3p/data.py:116-145) against vectors made with
+    the real sklearn compute_class_weight (tests/golden/make_label_weights.py)"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'label_weights.npz'))
+    C, ign = int(g['num_classes']), int(g['ignore_index'])
+    for i in range(int(g['n'])):
+        lab, w = O.prepare_labels(g['u8_%d' % i], C, ign, adaptive=True)
+        assert lab.dtype == np.float32 and np.array_equal(lab, g['labels_%d' % i])
+        assert w.dtype == np.float32 and np.array_equal(w, g['weights_%d' % i])          # bit-exact
+        lab2, none = O.prepare_labels(g['u8_%d' % i], C, ign)
+        assert none is None and np.array_equal(lab2, lab)

@@ -476,6 +476,45 @@ def test_fit_with_adaptive_sample_weights():
         m2.train_on_batch(x, y, sample_weight=sw)
 
 
+def test_adaptive_weights_from_uint8_labels_on_the_device():
+    """fit(weighted_type='adaptive') with a generator that yields uint8 pixels + uint8 labels and NO weights: the
+    balanced class weights of deeplabv3p/data.py:134-145 and the `label > C-1 -> ignore` of data.py:121 are computed on
+    the device; the step equals one with the oracle's (sklearn-pinned) host-side weights"""
+    from oracle import np_ops as O
+    pkg = load_pkg()
+    N, C, H, W = 2, 21, 65, 65
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (N, H, W, 3)).astype(np.uint8)
+    lab = rng.choice([0, 3, 7, 15, 20, 23, 255], size=(N, H * W, 1), p=[.5, .2, .1, .1, .05, .03, .02]).astype(np.uint8)
+    prepared = [O.prepare_labels(lab[n], C, 255, adaptive=True) for n in range(N)]
+    y_ref = np.stack([p[0] for p in prepared]).reshape(N, H * W, 1)
+    sw_ref = np.stack([p[1] for p in prepared])
+    assert (y_ref == 255).sum() > (lab == 255).sum()          # the 23s became ignore
+    x_ref = img.astype(np.float32) / 127.5 - 1.0
+    runs = []
+    for mode in ('device', 'host'):
+        m = pkg.get_deeplabv3p_model('mobilenetv2_lite', C, (H, W), 16, training=True)
+        m.compile(optimizer=pkg.SGD(0.01), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255), sample_weight_mode='temporal')
+        m.use_graphs = False
+
+        class Gen:
+            def __len__(self):
+                return 1
+            def __getitem__(self, i):
+                return (img, lab) if mode == 'device' else (x_ref, y_ref, {'pred_mask': sw_ref})
+        hist = m.fit_generator(Gen(), steps_per_epoch=1, epochs=1, verbose=0, weighted_type='adaptive')
+        ex = m._executor(N, True)
+        runs.append((hist['loss'][0], ex.labels.cpu().numpy(), ex.pixel_weights.cpu().numpy(), m.get_weights_by_name()))
+    (l0, y0, w0, p0), (l1, y1, w1, p1) = runs
+    assert np.array_equal(y0, y1) and np.array_equal(w0, w1)  # the same bits reach the loss kernel either way
+    assert l0 == l1
+    assert all(np.array_equal(p0[k], p1[k]) for k in p0)
+    m = pkg.get_deeplabv3p_model('mobilenetv2_lite', C, (H, W), 16, training=True)
+    m.compile(optimizer=pkg.SGD(0.01), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255), sample_weight_mode='temporal')
+    with pytest.raises(ValueError):
+        m.train_on_batch(x_ref, y_ref, sample_weight='adaptive')          # float labels: the host already made them
+
+
 def test_jaccard_training_metric():
     """compile(metrics={'pred_mask': Jaccard}) (train.py:140, deeplabv3p/metrics.py:29-46): the per-image class counts
     come from the device, the metric equals the oracle's restatement on the pred_resize logits' argmax, and fit() logs

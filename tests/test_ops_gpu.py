@@ -664,3 +664,34 @@ def test_adam_rmsprop_kernels(ops):
         assert np.abs(w.cpu().numpy() - wr).max() < 2e-6, kind
         close(v, vr, rtol=1e-5, atol=1e-12, what=kind + ' second moment')
 
+
+
+def test_label_prepare_matches_sklearn_golden(ops):
+    """dl3p_label_prepare == the reference generator's label tail (deeplabv3p/data.py:116-145), bit-exact against
+    vectors made with the real sklearn (tests/golden/make_label_weights.py) and against the oracle on a full-size,
+    odd-sized batch (513*513 pixels per image: image bases are only byte aligned)"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'label_weights.npz'))
+    C, ign = int(g['num_classes']), int(g['ignore_index'])
+    for i in range(int(g['n'])):
+        u8 = torch.as_tensor(g['u8_%d' % i]).cuda().view(1, -1)
+        lab, w = ops.label_prepare(u8, C, ign, adaptive=True)
+        assert np.array_equal(lab.cpu().numpy().ravel(), g['labels_%d' % i])
+        assert np.array_equal(w.cpu().numpy().ravel(), g['weights_%d' % i])
+        lab2, none = ops.label_prepare(u8, C, ign)
+        assert none is None and torch.equal(lab2, lab)
+    rng = np.random.default_rng(3)
+    N, P = 5, 513 * 513
+    u8 = rng.integers(0, 30, (N, P)).astype(np.uint8)
+    u8[rng.uniform(size=u8.shape) < 0.03] = 255
+    u8[1] = 4                                                # a single-class image: weight 1 everywhere
+    u8[2, :1000] = 9; u8[2, 1000:] = 255                     # mostly ignored
+    lab, w = ops.label_prepare(torch.as_tensor(u8).cuda(), C, ign, adaptive=True)
+    lab, w = lab.cpu().numpy(), w.cpu().numpy()
+    for n in range(N):
+        lr, wr = O.prepare_labels(u8[n], C, ign, adaptive=True)
+        assert np.array_equal(lab[n], lr) and np.array_equal(w[n], wr), n
+    assert np.all(w[1] == 1.0)
+    src, dst = torch.zeros(4, dtype=torch.uint8, device='cuda'), torch.empty(4, device='cuda')
+    with pytest.raises(RuntimeError):
+        ops.lib().label_prepare(src.data_ptr(), dst.data_ptr(), dst.data_ptr(), None, 1, 4, C, ign, None)   # no workspace

@@ -825,31 +825,55 @@ class Executor:
         return P
 
     # ---------------------------------------------------------------- running
-    def _upload_u8(self, src, dst, div, sub, slot):
-        """bytes over PCIe, float32 on the device (dl3p_u8_to_float)"""
+    def _stage_u8(self, src, slot):
         src = torch.as_tensor(src).reshape(-1)
         stage = self._u8.get(slot)
         if stage is None or stage.numel() != src.numel():
             stage = self._u8[slot] = torch.empty(src.numel(), dtype=torch.uint8, device=self.dev)
         stage.copy_(src, non_blocking=True)
-        self.L.u8_to_float(stage.data_ptr(), dst.data_ptr(), src.numel(), div, sub, torch.cuda.current_stream().cuda_stream)
+        return stage
+
+    def _upload_u8(self, src, dst, div, sub, slot):
+        """bytes over PCIe, float32 on the device (dl3p_u8_to_float)"""
+        stage = self._stage_u8(src, slot)
+        self.L.u8_to_float(stage.data_ptr(), dst.data_ptr(), stage.numel(), div, sub, torch.cuda.current_stream().cuda_stream)
 
     def set_inputs(self, x, y=None, sample_weight=None):
         """x float32 in [-1, 1] -- or uint8 pixels, normalised on the device like normalize_image does on the host
-        (common/data_utils.py:403-417); y float / integer class ids, uint8 accepted the same way"""
+        (common/data_utils.py:403-417); y float / integer class ids -- or uint8, which then also get the generator's
+        `label > num_classes-1 -> ignore_index` (deeplabv3p/data.py:116-121); sample_weight (N, H*W) or 'adaptive':
+        the generator's balanced per-image class weights (data.py:134-145) computed on the device from uint8 labels"""
         inp = self.buf[self.g.input.tensor.id]
         if getattr(x, 'dtype', None) in (np.uint8, torch.uint8):
             self._upload_u8(x, inp, 127.5, 1.0, 'x')
         else:
             x = torch.as_tensor(x, dtype=torch.float32)
             inp.copy_(x.reshape(-1), non_blocking=True)
+        adaptive = isinstance(sample_weight, str)
+        if adaptive:
+            if sample_weight != 'adaptive':
+                raise ValueError("sample_weight must be an array or 'adaptive'")
+            if self.pixel_weights is None:
+                raise ValueError("sample weights need compile(sample_weight_mode='temporal')")
+            if y is None or getattr(y, 'dtype', None) not in (np.uint8, torch.uint8) or self.ignore_index is None:
+                raise ValueError("'adaptive' weights are computed on the device from uint8 labels (and an ignore_index)")
         if y is not None:
             if getattr(y, 'dtype', None) in (np.uint8, torch.uint8):
-                self._upload_u8(y, self.labels, 1.0, 0.0, 'y')
+                if self.ignore_index is not None and 0 <= int(self.ignore_index) <= 255 and self.C <= 256:
+                    stage = self._stage_u8(y, 'y')
+                    if adaptive and 'hist' not in self._u8:
+                        self._u8['hist'] = torch.empty(self.N * 256, dtype=torch.int32, device=self.dev)
+                    self.L.label_prepare(stage.data_ptr(), self.labels.data_ptr(),
+                                         self.pixel_weights.data_ptr() if adaptive else None,
+                                         self._u8['hist'].data_ptr() if adaptive else None,
+                                         self.N, stage.numel() // self.N, self.C, int(self.ignore_index),
+                                         torch.cuda.current_stream().cuda_stream)
+                else:
+                    self._upload_u8(y, self.labels, 1.0, 0.0, 'y')
             else:
                 y = torch.as_tensor(y, dtype=torch.float32)
                 self.labels.copy_(y.reshape(-1), non_blocking=True)
-        if sample_weight is not None:
+        if sample_weight is not None and not adaptive:
             if self.pixel_weights is None:
                 raise ValueError("sample weights need compile(sample_weight_mode='temporal')")
             self.pixel_weights.copy_(torch.as_tensor(sample_weight, dtype=torch.float32).reshape(-1), non_blocking=True)

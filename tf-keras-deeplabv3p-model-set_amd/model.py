@@ -368,7 +368,8 @@ class DeeplabModel:
 
     def train_on_batch(self, x, y, sample_weight=None, return_tensor=False):
         """one optimiser step on (x (B,H,W,3) float32 in [-1,1] or uint8, y (B,H*W,1) class ids[, sample_weight (B,H*W)
-        with compile(sample_weight_mode='temporal')]); returns the data loss"""
+        with compile(sample_weight_mode='temporal'); 'adaptive' = the generator's balanced class weights, computed on
+        the device from uint8 labels]); returns the data loss"""
         if self.optimizer is None:
             raise RuntimeError('You must compile your model before training')
         ex = self._executor(int(x.shape[0]), True)
@@ -420,8 +421,10 @@ class DeeplabModel:
         return pred.view(B, H, W).cpu().numpy()
 
     def fit(self, x=None, steps_per_epoch=None, epochs=1, initial_epoch=0, verbose=1, callbacks=None,
-            validation_data=None, validation_steps=None, **kw):
-        """Keras-like loop over a Sequence/generator yielding (images, labels) (train.py:177-187)"""
+            validation_data=None, validation_steps=None, weighted_type=None, **kw):
+        """Keras-like loop over a Sequence/generator yielding (images, labels) (train.py:177-187).
+        weighted_type='adaptive' (train.py --weighted_type, deeplabv3p/data.py:134-145): a generator that yields uint8
+        labels and no weights gets the balanced per-image class weights computed on the device"""
         gen = x
         n = steps_per_epoch or len(gen)
         history = {'loss': []}
@@ -437,6 +440,8 @@ class DeeplabModel:
                 sw = batch[2] if len(batch) > 2 else None
                 if isinstance(sw, dict):
                     sw = next(iter(sw.values()))          # {'pred_mask': weights}
+                if sw is None and weighted_type == 'adaptive' and getattr(batch[1], 'dtype', None) == np.uint8:
+                    sw = 'adaptive'
                 # the step is only enqueued here; the generator prepares the next batch (decode, augment, resize on
                 # the host) while the GPU runs it, and the loss is read back afterwards
                 loss_t = self.train_on_batch(batch[0], batch[1], sample_weight=sw, return_tensor=True)

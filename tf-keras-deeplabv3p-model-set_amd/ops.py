@@ -437,6 +437,23 @@ def argmax_confusion(z, C, H, W, labels=None, confusion=None, want_mask=False):
     return pred, (confusion if labels is not None else None)
 
 
+def label_prepare(labels_u8, num_classes, ignore_index=255, adaptive=False, labels_out=None, weights_out=None):
+    """uint8 labels (N, P) on the device -> (float32 labels with values above num_classes-1 set to ignore_index,
+    float32 'balanced' pixel weights or None): deeplabv3p/data.py:116-145"""
+    N, P = labels_u8.shape
+    assert labels_u8.dtype == torch.uint8 and labels_u8.is_contiguous()
+    if labels_out is None:
+        labels_out = torch.empty((N, P), dtype=torch.float32, device=labels_u8.device)
+    hist = None
+    if adaptive:
+        if weights_out is None:
+            weights_out = torch.empty((N, P), dtype=torch.float32, device=labels_u8.device)
+        hist = torch.empty(N * 256, dtype=torch.int32, device=labels_u8.device)
+    lib().label_prepare(labels_u8.data_ptr(), labels_out.data_ptr(), _p(weights_out) if adaptive else None, _p(hist), N, P,
+                        num_classes, ignore_index, _stream())
+    return labels_out, (weights_out if adaptive else None)
+
+
 def head_train_supported(h, w, C, H, W):
     return bool(lib().head_train_supported(h, w, C, H, W))
 
