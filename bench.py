@@ -89,6 +89,7 @@ def measured_traffic(kernel_name):
 
 def main():
     args = parse()
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC (what RCCL needs here); before HIP starts
     import numpy as np
     import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
