@@ -515,6 +515,35 @@ def test_adaptive_weights_from_uint8_labels_on_the_device():
         m.train_on_batch(x_ref, y_ref, sample_weight='adaptive')          # float labels: the host already made them
 
 
+def test_eval_callback_saves_the_best_checkpoint(tmp_path):
+    """common/callbacks.py:33-53 EvalCallBack: mIOU evaluation every `eval_epoch_interval` epochs from fit(), best model
+    saved under the reference's file name pattern; the logged mIOU is evaluate_miou's of the weights at that point"""
+    import glob
+    pkg = load_pkg()
+    N, C, H, W = 2, 5, 65, 65
+    x, y = _data(N, H, W, C, seed=21)
+
+    class Gen:
+        def __len__(self):
+            return 2
+        def __getitem__(self, i):
+            return x, y
+    m = pkg.get_deeplabv3p_model('mobilenetv2_lite', C, (H, W), 16, training=True)
+    m.compile(optimizer=pkg.SGD(0.05), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
+    cb = pkg.EvalCallBack(Gen(), log_dir=str(tmp_path), eval_epoch_interval=2, save_eval_checkpoint=True)
+    m.fit_generator(Gen(), steps_per_epoch=2, epochs=4, verbose=0, callbacks=[cb])
+    assert [e for e, _ in cb.history] == [2, 4]
+    want = m.evaluate_miou(Gen())['mIoU']
+    assert abs(cb.history[-1][1] - want) < 1e-12
+    files = sorted(glob.glob(str(tmp_path / 'ep*-mIOU*.h5')))
+    assert files and all('-loss' in f and '-val_Jaccard' in f for f in files)
+    assert abs(cb.best_mIOU - max(v for _, v in cb.history)) < 1e-12
+    m2 = pkg.get_deeplabv3p_model('mobilenetv2_lite', C, (H, W), 16, training=True, weights_path=files[-1])
+    if cb.history[-1][1] >= cb.history[0][1] and len(files) == (2 if cb.history[1][1] > cb.history[0][1] else 1):
+        got = m2.evaluate_miou(Gen())['mIoU']
+        assert abs(got - cb.best_mIOU) < 1e-6, (got, cb.best_mIOU)
+
+
 def test_jaccard_training_metric():
     """compile(metrics={'pred_mask': Jaccard}) (train.py:140, deeplabv3p/metrics.py:29-46): the per-image class counts
     come from the device, the metric equals the oracle's restatement on the pred_resize logits' argmax, and fit() logs

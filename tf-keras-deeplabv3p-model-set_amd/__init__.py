@@ -7,8 +7,8 @@ importlib:  importlib.import_module('tf-keras-deeplabv3p-model-set_amd')  -- or 
 """
 from .model import (get_deeplabv3p_model, deeplab_model_map, DeeplabModel, SGD, Adam, RMSprop, get_optimizer,  # noqa: F401
                     SparseCategoricalCrossEntropy, WeightedSparseCategoricalCrossEntropy, SparseSoftmaxFocalLoss,
-                    miou_from_confusion, Jaccard, jaccard_from_counts)
+                    miou_from_confusion, Jaccard, jaccard_from_counts, EvalCallBack)
 
 __all__ = ['get_deeplabv3p_model', 'deeplab_model_map', 'DeeplabModel', 'SGD', 'Adam', 'RMSprop', 'get_optimizer',
            'SparseCategoricalCrossEntropy', 'WeightedSparseCategoricalCrossEntropy', 'SparseSoftmaxFocalLoss',
-           'miou_from_confusion', 'Jaccard', 'jaccard_from_counts']
+           'miou_from_confusion', 'Jaccard', 'jaccard_from_counts', 'EvalCallBack']

@@ -364,11 +364,14 @@ extern "C" int dl3p_upsample_softmax_loss(const float* z, int ldz, const float* 
   if (rows_out) *rows_out = (int)blocks;
   hipStream_t st = (hipStream_t)stream;
   const int cp = ((C + 3) / 4) * 4;
-  const int cpv = cp <= 20 ? 20 : (cp <= 24 ? 24 : 32);
-  DL3P_CHECK_ARG(ldz >= cpv, "dl3p_upsample_softmax_ce: ld=%d must be >= %d for C=%d", ldz, cpv, C);
-  if (cp <= 20) hipLaunchKernelGGL((head_kernel<20>), dim3((unsigned)blocks), dim3(256), 0, st, p);
-  else if (cp <= 24) hipLaunchKernelGGL((head_kernel<24>), dim3((unsigned)blocks), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((head_kernel<32>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+  // one instantiation per padded class count (a multiple of 4 up to 32): the kernel reads exactly the cp floats a
+  // pixel of the (N,h,w,cp) logits holds, so 2-class models work like 21-class ones
+  switch (cp) {
+#define DL3P_HEAD_CASE(CP) case CP: hipLaunchKernelGGL((head_kernel<CP>), dim3((unsigned)blocks), dim3(256), 0, st, p); break;
+    DL3P_HEAD_CASE(4) DL3P_HEAD_CASE(8) DL3P_HEAD_CASE(12) DL3P_HEAD_CASE(16) DL3P_HEAD_CASE(20) DL3P_HEAD_CASE(24)
+    DL3P_HEAD_CASE(28) DL3P_HEAD_CASE(32)
+#undef DL3P_HEAD_CASE
+  }
   DL3P_CHECK_LAUNCH("dl3p_upsample_softmax_ce");
   return DL3P_OK;
 }
@@ -448,13 +451,15 @@ extern "C" int dl3p_argmax_confusion(const float* z, int ldz, const float* label
   if (blocks < 1) blocks = 1;
   if (blocks > 4096) blocks = 4096;
   const int cp = ((C + 3) / 4) * 4;
-  const int cpv = cp <= 20 ? 20 : (cp <= 24 ? 24 : 32);
-  DL3P_CHECK_ARG(ldz >= cpv, "dl3p_argmax_confusion: ld=%d must be >= %d for C=%d", ldz, cpv, C);
+  DL3P_CHECK_ARG(ldz >= cp, "dl3p_argmax_confusion: ld=%d must be >= %d for C=%d", ldz, cp, C);
   const size_t lds = (labels && confusion) ? (size_t)C * C * sizeof(unsigned int) : 0;
   hipStream_t st = (hipStream_t)stream;
-  if (cp <= 20) hipLaunchKernelGGL((argmax_confusion_kernel<20>), dim3((unsigned)blocks), dim3(256), lds, st, p);
-  else if (cp <= 24) hipLaunchKernelGGL((argmax_confusion_kernel<24>), dim3((unsigned)blocks), dim3(256), lds, st, p);
-  else hipLaunchKernelGGL((argmax_confusion_kernel<32>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+  switch (cp) {
+#define DL3P_AC_CASE(CP) case CP: hipLaunchKernelGGL((argmax_confusion_kernel<CP>), dim3((unsigned)blocks), dim3(256), lds, st, p); break;
+    DL3P_AC_CASE(4) DL3P_AC_CASE(8) DL3P_AC_CASE(12) DL3P_AC_CASE(16) DL3P_AC_CASE(20) DL3P_AC_CASE(24) DL3P_AC_CASE(28)
+    DL3P_AC_CASE(32)
+#undef DL3P_AC_CASE
+  }
   DL3P_CHECK_LAUNCH("dl3p_argmax_confusion");
   return DL3P_OK;
 }
@@ -698,7 +703,8 @@ static bool head_train_fits(int h, int w, int H, int W) {
 }
 
 extern "C" int dl3p_head_train_supported(int h, int w, int C, int H, int W) {
-  return (C > 0 && C <= 32 && head_train_fits(h, w, H, W)) ? 1 : 0;
+  const int cp = ((C + 3) / 4) * 4;      // instantiated for 20 / 24 / 32 padded classes (the (N,h,w,cp) logits' row)
+  return ((cp == 20 || cp == 24 || cp == 32) && head_train_fits(h, w, H, W)) ? 1 : 0;
 }
 
 template <int CP>
@@ -723,7 +729,8 @@ extern "C" int dl3p_head_train(const float* z, int ldz, const float* labels, int
                  "(use dl3p_upsample_softmax_ce + dl3p_resize_bilinear_bwd)", h, w, H, W);
   const int cp = ((C + 3) / 4) * 4;
   const int cpv = cp <= 20 ? 20 : (cp <= 24 ? 24 : 32);
-  DL3P_CHECK_ARG(ldz >= cpv && ldgz >= cpv, "dl3p_head_train: ld=%d/%d must be >= %d for C=%d", ldz, ldgz, cpv, C);
+  DL3P_CHECK_ARG(ldz >= cpv && ldgz >= cpv, "dl3p_head_train: ld=%d/%d must be >= %d for C=%d (use dl3p_upsample_softmax_ce)",
+                 ldz, ldgz, cpv, C);
   HeadTrainParams p = {};
   p.z = z; p.ldz = ldz; p.labels = labels; p.ignore_index = ignore_index; p.inv_count = inv_count;
   p.gz = gz; p.ldgz = ldgz; p.accumulate = accumulate; p.loss_partials = loss_partials;

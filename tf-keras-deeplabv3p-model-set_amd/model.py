@@ -646,8 +646,8 @@ def _evaluate_miou(self, gen, steps=None, class_names=None, verbose=0):
     C = self.num_classes
     cm = torch.zeros(C * C, dtype=torch.int64, device='cuda')
     for i in range(n):
-        x, y = gen[i][0], gen[i][1]
-        x, y = np.asarray(x), np.asarray(y)
+        batch = gen[i]
+        x, y = np.asarray(batch[0]), np.asarray(batch[1])
         ex = self._executor(x.shape[0], False)
         ex.set_inputs(x if x.dtype == np.uint8 else x.astype(np.float32, copy=False),
                       y if y.dtype == np.uint8 else y.astype(np.float32, copy=False))
@@ -710,3 +710,35 @@ def get_deeplabv3p_model(model_type, num_classes, model_input_shape, output_stri
             model.layers[i].trainable = True
         print('Unfreeze all of the layers.')
     return model
+
+
+class EvalCallBack:
+    """common/callbacks.py:33-53: every `eval_epoch_interval` epochs run the mIOU evaluation and, with
+    save_eval_checkpoint, keep the best model under the reference's file name pattern.  The reference re-reads the
+    dataset from disk inside eval_mIOU; here the evaluation batches come from `eval_generator` (images, labels) and the
+    argmax + confusion matrix stay on the device (DeeplabModel.evaluate_miou)."""
+
+    def __init__(self, eval_generator, class_names=None, log_dir='.', eval_epoch_interval=10, save_eval_checkpoint=False,
+                 steps=None):
+        self.eval_generator, self.class_names, self.log_dir = eval_generator, class_names, log_dir
+        self.eval_epoch_interval, self.save_eval_checkpoint, self.steps = eval_epoch_interval, save_eval_checkpoint, steps
+        self.best_mIOU = 0.0
+        self.history = []
+        self.model = None
+
+    def set_model(self, model):
+        self.model = model
+
+    def on_epoch_end(self, epoch, logs=None):
+        if (epoch + 1) % self.eval_epoch_interval:
+            return
+        logs = logs or {}
+        mIOU = float(self.model.evaluate_miou(self.eval_generator, class_names=self.class_names, steps=self.steps)['mIoU'])
+        self.history.append((epoch + 1, mIOU))
+        if self.save_eval_checkpoint and mIOU > self.best_mIOU:
+            self.best_mIOU = mIOU
+            nan = float('nan')
+            name = 'ep{epoch:03d}-loss{loss:.3f}-Jaccard{Jaccard:.3f}-val_loss{val_loss:.3f}-val_Jaccard{val_Jaccard:.3f}-mIOU{mIOU:.3f}.h5'
+            self.model.save(os.path.join(self.log_dir, name.format(
+                epoch=epoch + 1, loss=logs.get('loss', nan), Jaccard=logs.get('Jaccard', nan),
+                val_loss=logs.get('val_loss', nan), val_Jaccard=logs.get('val_Jaccard', nan), mIOU=mIOU)))
