@@ -671,6 +671,9 @@ def get_deeplabv3p_model(model_type, num_classes, model_input_shape, output_stri
         raise ValueError('This model type is not supported now')
     if use_subpixel:
         raise ValueError('Subpixel head is experimental in the reference (README TODO) and not on the hot path')
+    if not 1 <= int(num_classes) <= 32:
+        # the loss / argmax head kernels keep a pixel's class vector in registers (VOC 21, Cityscapes 19)
+        raise ValueError('num_classes must be in [1, 32] (got %r): the HIP head kernels hold one pixel\'s classes in registers' % (num_classes,))
 
     model_function = deeplab_model_map[model_type]
     H, W = model_input_shape
