@@ -544,6 +544,31 @@ def test_eval_callback_saves_the_best_checkpoint(tmp_path):
         assert abs(got - cb.best_mIOU) < 1e-6, (got, cb.best_mIOU)
 
 
+def test_training_learns_a_learnable_task():
+    """end to end through graph replay: labels that are a function of the pixels (brightness bands) are learnt -- the loss
+    falls well below ln(C) and nothing drifts to NaN over a few hundred replayed steps.  (Inference-mode mIOU is not
+    asserted: the backbone's BatchNorm momentum is 0.999, its moving statistics need thousands of steps, as in Keras.)"""
+    pkg = load_pkg()
+    N, C, H, W = 4, 4, 65, 65
+    rng = np.random.default_rng(5)
+    batches = []
+    for _ in range(4):
+        base = rng.uniform(-1, 1, (N, 5, 5, 1))
+        img = np.repeat(np.repeat(base, 13, 1), 13, 2) + rng.normal(0, 0.05, (N, H, W, 1))      # blocky brightness
+        x = np.clip(np.concatenate([img, img * 0.5, -img], -1), -1, 1).astype(np.float32)
+        y = np.clip(((x[..., 0] + 1) * 0.5 * C).astype(np.int64), 0, C - 1).reshape(N, H * W, 1).astype(np.float32)
+        batches.append((x, y))
+    m = pkg.get_deeplabv3p_model('mobilenetv2_lite', C, (H, W), 16, training=True)
+    m.compile(optimizer=pkg.SGD(0.05, momentum=0.9), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
+    first = [m.train_on_batch(*batches[i % 4]) for i in range(4)]
+    for i in range(300):
+        loss = m.train_on_batch(*batches[i % 4])
+        assert np.isfinite(loss), i
+    last = [m.train_on_batch(*batches[i % 4]) for i in range(4)]
+    assert np.mean(first) > 0.9 * np.log(C) and np.mean(last) < 0.5 * np.mean(first), (first, last)
+    assert np.isfinite(m.evaluate_miou(batches)['mIoU'])
+
+
 def test_jaccard_training_metric():
     """compile(metrics={'pred_mask': Jaccard}) (train.py:140, deeplabv3p/metrics.py:29-46): the per-image class counts
     come from the device, the metric equals the oracle's restatement on the pred_resize logits' argmax, and fit() logs
