@@ -55,6 +55,10 @@ int dl3p_version(void);
 const char* dl3p_last_error_string(void);
 /* number of compute units / XCDs the library sizes its grids for (256 / 8 on MI355X) */
 int dl3p_device_cus(void);
+/* dispatch knobs that tests need to move at run time.  "pw_small_min_rows": the row count from which the
+ * wave-independent streaming GEMM kernels replace the tiled kernel for small K x N (production 131072; value < 0
+ * restores it).  Unknown names return DL3P_EINVAL. */
+int dl3p_set_option(const char* name, int value);
 
 /* ---------------------------------------------------------------- depthwise convolution
  * replaces DepthwiseConv2D (DepthwiseConv2dNative [+SpaceToBatchND for dilation]) at
@@ -150,8 +154,9 @@ int dl3p_col2im(const float* gcol, int ld_col, float* gx, int ldgx, int accumula
 
 /* ---------------------------------------------------------------- batch normalisation
  * replaces BatchNormalization/FusedBatchNormV3 (layers.py:63-70 CustomBatchNormalization).
- * Training: biased batch variance normalises; the Bessel-corrected variance feeds the moving
- * average  moving <- moving*momentum + batch*(1-momentum).
+ * Training: the biased batch variance normalises AND feeds the moving average
+ * moving <- moving*momentum + batch*(1-momentum)  (CustomBatchNormalization is Keras SyncBatchNormalization, the
+ * non-fused path: no Bessel correction).
  * dl3p_bn_finalize: partial rows [rows][2][C] -> scale = gamma*invstd, shift = beta - mean*scale,
  * save_mean, save_invstd, and (update_moving) the moving statistics.  `count` = elements per
  * channel that produced the sums (N*H*W, or the global count under SyncBN with rows == 1). */

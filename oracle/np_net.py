@@ -55,6 +55,8 @@ class Net:
         # not BatchNormalization outputs (residual sums, SE-block convs)
         self.act_derivs_seq = []
         self._seq_pos = 0
+        self.flip_count = 0
+        self.flip_total = 0
         # optional SyncBatchNorm: (all_reduce_sum(ndarray) -> ndarray, world_size).  Statistics are
         # summed over ranks in forward (sum x, sum x^2, count) and backward (sum dy, sum dy*xhat); the
         # parameter gradients stay local and are averaged with all other gradients (README.md:38,
@@ -85,6 +87,8 @@ class Net:
         self.taps = {}
         self.reg_loss = 0.0
         self._seq_pos = 0
+        self.flip_count = 0       # activation elements whose injected branch differs from the oracle's own
+        self.flip_total = 0
 
     def backward(self):
         for f in reversed(self.tape):
@@ -186,7 +190,7 @@ class Net:
         y = Var(xhat * gamma + beta)
         y.tag = name
         self.moving_updates[name + '/moving_mean'] = O.bn_moving_update(mm, mean, momentum)
-        self.moving_updates[name + '/moving_variance'] = O.bn_moving_update(mv, var * (m / max(m - 1, 1)), momentum)
+        self.moving_updates[name + '/moving_variance'] = O.bn_moving_update(mv, var, momentum)
 
         def bwd():
             if y.g is None:
@@ -209,6 +213,12 @@ class Net:
         elif x.tag is None and self.act_derivs_seq:
             deriv = self.act_derivs_seq[self._seq_pos]
             self._seq_pos += 1
+
+        if deriv is not None:
+            # how much the injection changes: elements whose branch differs from this oracle's own derivative
+            own = O.act_bwd(x.v, np.ones_like(x.v), kind)
+            self.flip_count += int(np.count_nonzero(np.abs(own - deriv) > 1e-6))
+            self.flip_total += int(own.size)
 
         def bwd():
             if y.g is not None:

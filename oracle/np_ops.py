@@ -152,24 +152,24 @@ def dwconv2d_bwd(x, w, gy, stride=1, rate=1, padding='same'):
     return gxp[:, pt:pt + H, pl:pl + W, :], gw
 
 # --------------------------------------------------------------------------------------
-# batch normalisation (Keras BatchNormalization, fused kernel semantics)
+# batch normalisation (Keras SyncBatchNormalization = non-fused BatchNormalizationBase semantics)
 # --------------------------------------------------------------------------------------
 
 def bn_train_fwd(x, gamma, beta, eps):
     """Training-mode BN over (N,H,W).  Normalises with the BIASED batch variance.
-    returns y, cache, (batch_mean, batch_var_unbiased) for the moving-average update
-    (TF FusedBatchNormV3 feeds the Bessel-corrected variance into the moving average;
-    count-1 is clamped to >= 1)."""
+    returns y, cache, (batch_mean, batch_var) for the moving-average update.  CustomBatchNormalization is
+    tf.keras SyncBatchNormalization under TF >= 2.2 (layers.py:63-70), i.e. the NON-fused BatchNormalizationBase
+    path: `_calculate_mean_and_var` returns E[x^2] - E[x]^2 and that same biased variance feeds the moving
+    average (only the fused FusedBatchNormV3 kernel applies Bessel's correction; SyncBatchNormalization refuses
+    fused=True)."""
     C = x.shape[-1]
     x2 = x.reshape(-1, C)
-    m = x2.shape[0]
     mean = x2.mean(0)
     var = ((x2 - mean) ** 2).mean(0)
     invstd = 1.0 / np.sqrt(var + eps)
     xhat = (x - mean) * invstd
     y = xhat * gamma + beta
-    var_unbiased = var * (m / max(m - 1, 1))
-    return y, (xhat, invstd, gamma), (mean, var_unbiased)
+    return y, (xhat, invstd, gamma), (mean, var)
 
 
 def bn_train_bwd(gy, cache):

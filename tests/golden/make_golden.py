@@ -50,7 +50,7 @@ def ops_fixture():
     gz = rng.standard_normal(z.shape).astype(np.float32)
     y, cache, (bm, bv) = O.bn_train_fwd(z.astype(np.float64), g, b, 1e-3)
     gx, gg, gb = O.bn_train_bwd(O.act_bwd(y, gz.astype(np.float64), O.ACT_RELU6), cache)
-    d.update(bn_z=z, bn_gamma=g, bn_beta=b, bn_g=gz, bn_y=y, bn_mean=bm, bn_var_unbiased=bv, bn_dz=gx, bn_dgamma=gg,
+    d.update(bn_z=z, bn_gamma=g, bn_beta=b, bn_g=gz, bn_y=y, bn_mean=bm, bn_var=bv, bn_dz=gx, bn_dgamma=gg,
              bn_dbeta=gb)
     # bilinear 33 -> 129 and the head (pred_resize + softmax + CE with ignore 255)
     rx = rng.standard_normal((1, 9, 9, 24)).astype(np.float32)

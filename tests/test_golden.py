@@ -81,3 +81,62 @@ def test_hip_model_matches_golden(mt):
     m.set_weights_by_name(dict(o.net.params))
     p = m.predict(d['x'])
     assert np.abs(p[:, ::4, ::4] - d['probs_infer_s4']).max() < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Reference-held pins: the label maps of /root/reference/example/*.png (tests/golden/make_reference_labels.py) with
+# ANALYTIC answers that follow from deeplabv3p/loss.py:121-156 alone (masking, Keras' mean over all entries, the
+# 1e-7 clip) -- not from this repo's oracle.
+def _voc_cases():
+    d = load('voc_example_labels.npz')
+    C = 21
+    for name in sorted(d):
+        lab = d[name].astype(np.float32)
+        valid = float((lab != 255).sum())
+        yield name, lab, C, np.log(C) * valid / lab.size, -np.log(1.0 - 1e-7) * valid / lab.size
+
+
+def test_oracle_ce_on_reference_labels():
+    for name, lab, C, loss_uniform, loss_clipped in _voc_cases():
+        H, W = lab.shape
+        z = np.zeros((1, H, W, C))
+        loss, p, g = O.sparse_ce_fwd_bwd(z, lab[None], 255)
+        assert abs(loss - loss_uniform) < 1e-12, name
+        want = np.full((H, W, C), 1.0 / C)
+        iy, ix = np.nonzero(lab != 255)
+        want[iy, ix, lab[iy, ix].astype(int)] -= 1.0
+        want[lab == 255] = 0.0
+        np.testing.assert_allclose(g[0], want / lab.size, atol=1e-15)
+        onehot = np.zeros((1, H, W, C))
+        onehot[0, iy, ix, lab[iy, ix].astype(int)] = 20.0
+        loss, _, g = O.sparse_ce_fwd_bwd(onehot, lab[None], 255)
+        assert abs(loss - loss_clipped) < 1e-15, name
+        assert not g.any()                      # clipped probabilities have zero gradient (tf.clip_by_value)
+
+
+@pytest.mark.gpu
+def test_hip_head_on_reference_labels(ops):
+    import torch
+    for name, lab, C, loss_uniform, loss_clipped in _voc_cases():
+        H, W = lab.shape
+        labels = torch.from_numpy(lab[None].copy()).cuda()
+        # all-equal small logits, upsampled 4x by the head itself
+        z = torch.full((1, (H + 3) // 4, (W + 3) // 4, 24), 0.25, device='cuda')
+        z[..., C:] = 0
+        out = ops.upsample_softmax_ce(z, C, H, W, labels=labels, want_grad=True)
+        assert abs(float(out['loss'].item()) - loss_uniform) < 2e-6 * loss_uniform, name
+        g = out['dlogits'][0, ..., :C].cpu().numpy()
+        iy, ix = np.nonzero(lab != 255)
+        want = np.full((H, W, C), 1.0 / C)
+        want[iy, ix, lab[iy, ix].astype(int)] -= 1.0
+        want[lab == 255] = 0.0
+        np.testing.assert_allclose(g, want / lab.size, atol=1e-6 / lab.size)
+        # logits = 20 * onehot(label) at full resolution (identity resize): every labelled pixel is clipped
+        zz = torch.zeros((1, H, W, 24), device='cuda')
+        idx = torch.from_numpy(np.where(lab == 255, 0, lab).astype(np.int64)).cuda()
+        zz[0].scatter_(2, idx[..., None], 20.0)
+        out = ops.upsample_softmax_ce(zz, C, H, W, labels=labels, want_grad=True)
+        # in float32 (the reference's dtype) the clip bound 1 - 1e-7 is the float 1 - 2^-23
+        clipped32 = loss_clipped * np.log(np.float64(np.float32(1.0 - 1e-7))) / np.log(1.0 - 1e-7)
+        assert abs(float(out['loss'].item()) - clipped32) < 1e-2 * clipped32, name
+        assert not out['dlogits'].any()

@@ -156,6 +156,24 @@ def test_train_step_matches_oracle(model_type, H, W, freeze, OS):
     # fp32-vs-fp64 rounding accumulates with depth: 65 BatchNorm layers (MobileNet) stay under 5e-3 of the
     # tensor scale, the 146 of Xception (OS-16 maps of 5x5 pixels, 50 samples per channel) under 1e-2
     assert worst[1] < (1e-2 if model_type == 'xception' else 5e-3), worst
+    # What the injection changes: the number of activation elements whose branch differs between
+    # the float32 run and the float64 oracle, and the same comparison WITHOUT the injection.  A kernel bug in an
+    # activation would flip far more than rounding-distance elements; the un-injected error is what a handful of
+    # O(1) flips costs.  Both are recorded (gpurun_out/parity_injection.jsonl) and the flip fraction is bounded.
+    flips, total_elems = o.net.flip_count, o.net.flip_total
+    assert flips <= max(8, 2e-4 * total_elems), (flips, total_elems)
+    grads_inj = {k: v.copy() for k, v in o.net.grads.items()}
+    o.net.act_derivs, o.net.act_derivs_seq = {}, []
+    o.loss_and_grads(x, y, {'aspp_dropout': mask})
+    worst_raw = ('', 0.0)
+    for p in m.graph.all_params():
+        if p.trainable and np.abs(o.net.grads[p.name]).max() > 1e-7:
+            r = _rel(st.get(p, st.G), o.net.grads[p.name])
+            if r > worst_raw[1]:
+                worst_raw = (p.name, r)
+    _record_injection(dict(model=model_type, H=H, W=W, OS=OS, freeze=freeze, flipped=flips, activation_elements=total_elems,
+                           worst_injected=worst, worst_uninjected=worst_raw))
+    o.net.grads = grads_inj
     # SGD update + moving statistics
     o.sgd_step(0.01, 0.9)
     w = m.get_weights_by_name()
@@ -163,6 +181,17 @@ def test_train_step_matches_oracle(model_type, H, W, freeze, OS):
         assert np.abs(v - o.net.params[k]).max() < TOL * max(1.0, np.abs(o.net.params[k]).max()), k
     if freeze:
         assert all(not p.trainable for p in m.graph.all_params() if p.layer.name.startswith('expanded_conv'))
+
+
+def _record_injection(rec):
+    import json
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, 'parity_injection.jsonl'), 'a') as fh:
+            fh.write(json.dumps(rec) + '\n')
+    except OSError:
+        pass
 
 
 def _skip_if_missing(model_type):

@@ -88,11 +88,13 @@ def test_batchnorm_matches_torch():
     xt = nchw(x).requires_grad_(True)
     gt, bt = t(g).requires_grad_(True), t(b).requires_grad_(True)
     rm, rv = torch.zeros(4).double(), torch.ones(4).double()
-    # torch momentum is (1 - keras momentum); torch also feeds the UNBIASED variance into the moving average
+    # torch momentum is (1 - keras momentum); torch feeds the UNBIASED variance into the moving average, Keras'
+    # SyncBatchNormalization (the reference's CustomBatchNormalization) the biased one
     yt = F.batch_norm(xt, rm, rv, gt, bt, training=True, momentum=1 - mom, eps=eps)
     np.testing.assert_allclose(y, nhwc(yt.detach()), atol=1e-10)
     np.testing.assert_allclose(O.bn_moving_update(np.zeros(4), bm, mom), rm.numpy(), atol=1e-12)
-    np.testing.assert_allclose(O.bn_moving_update(np.ones(4), bv, mom), rv.numpy(), atol=1e-12)
+    m = x.size // 4
+    np.testing.assert_allclose(O.bn_moving_update(np.ones(4), bv * m / (m - 1), mom), rv.numpy(), atol=1e-12)
     gy = RNG.standard_normal(y.shape)
     yt.backward(nchw(gy))
     gx, gg, gb = O.bn_train_bwd(gy, cache)

@@ -1,0 +1,238 @@
+"""Parity at the PRODUCTION shapes and with the PRODUCTION dispatch ("what's weak" 2).
+
+The other GPU parity tests run at 65x65 / 97x97 with `pw_small_min_rows` lowered so that small shapes reach the
+streaming GEMM kernels.  The kernels that carry the headline number -- the tiled GEMM over thousands of row tiles,
+`pw_wgrad_kernel` slabs, the depthwise row-band splits at 257x257 / 129x129, the XCD chunking and the rate-18 lattice
+kernel at batch 16 -- run a different dispatch at BASELINE.json configs[1].  Here:
+
+  * whole-model train step + predict of `mobilenetv2` / `mobilenetv2_lite` at 513x513 (batch 2: the fp64 oracle
+    needs about a minute per step on 8 cores) with the production threshold restored,
+  * the ten costliest launches of profiles/r01_step_table_mobilenetv2.txt at their exact configs[1] shapes
+    (batch 16) against float64 NumPy.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_pkg
+from oracle import np_ops as O
+from oracle.np_net import OracleModel
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(autouse=True)
+def production_dispatch():
+    L = load_pkg('_lib').lib()
+    L.set_option(b'pw_small_min_rows', -1)        # production threshold (2^17 rows)
+    yield
+    L.set_option(b'pw_small_min_rows', 64)        # what conftest.py sets for the small-shape tests
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+
+
+def rel(got, want):
+    got = got.detach().cpu().numpy().astype(np.float64) if torch.is_tensor(got) else np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    return float(np.abs(got - want).max() / max(1e-30, np.abs(want).max()))
+
+
+# ------------------------------------------------------------------------------------------- whole model, 513 x 513
+@pytest.mark.parametrize('model_type', ['mobilenetv2', 'mobilenetv2_lite'])
+def test_train_step_513_production_dispatch(model_type):
+    from test_model_gpu import _pair, _data, _act_derivs, _act_derivs_seq, _rel
+    N, C, H, W = 2, 21, 513, 513
+    m, o = _pair(model_type, H, W, C)
+    m.use_graphs = False
+    x, y = _data(N, H, W, C, seed=11)
+    loss = m.train_on_batch(x, y)
+    ex = m._executor(N, True)
+    drop = [op for op in m.graph.ops if op.kind == 'materialize' and op.rate > 0][0]
+    mask = ex.dropout_mask(drop).cpu().numpy()
+    o.net.act_derivs = _act_derivs(m, ex)
+    o.net.act_derivs_seq = _act_derivs_seq(m, ex, o.net.act_derivs)
+    total, ce, logits_ref = o.loss_and_grads(x, y, {'aspp_dropout': mask})
+    assert abs(loss - ce) < 1e-3 * max(1.0, abs(ce)), (loss, ce)
+    # north_star: per-pixel class logits within 1e-3 (training-mode BN, the same dropout mask)
+    ops = load_pkg('ops')
+    out = ops.upsample_softmax_ce(ex.view(m.head.tensor), C, H, W, want_logits=True)
+    lg = out['logits'][..., :C].cpu().numpy()
+    assert np.abs(lg - logits_ref).max() < 1e-3 * max(1.0, np.abs(logits_ref).max())
+    st = m._store
+    worst = ('', 0.0)
+    for p in m.graph.all_params():
+        if not p.trainable:
+            continue
+        g = st.get(p, st.G)
+        gref = o.net.grads[p.name]
+        r = _rel(g, gref) if np.abs(gref).max() > 1e-7 else float(np.abs(g).max())
+        if r > worst[1]:
+            worst = (p.name, r)
+    assert worst[1] < 5e-3, worst
+    o.sgd_step(0.01, 0.9)
+    w = m.get_weights_by_name()
+    for k, v in w.items():
+        assert np.abs(v - o.net.params[k]).max() < 1e-3 * max(1.0, np.abs(o.net.params[k]).max()), k
+    # predict (inference BN from the updated moving statistics) with the same weights
+    pkg = load_pkg()
+    mi = pkg.get_deeplabv3p_model(model_type, C, (H, W), 16, training=False)
+    mi.set_weights_by_name(w)
+    p = mi.predict(x[:1])
+    _, p_ref = o.predict(x[:1])
+    assert np.abs(p - p_ref).max() < 1e-3
+
+
+# ------------------------------------------------------------------------------------------- configs[1] launches
+# (M, K, N) of the pointwise convolutions at batch 16, 513 x 513: decoder_conv0 / decoder_conv1 (129 x 129 maps),
+# expanded_conv_1_expand / expanded_conv_1_project (257 x 257 -> tiled + streaming kernels), feature_projection0,
+# concat_projection (33 x 33, K = 1280) and the 21-class head (N padded to 24)
+PW_PROD = [(16 * 129 * 129, 304, 256), (16 * 129 * 129, 256, 256), (16 * 257 * 257, 16, 96), (16 * 257 * 257, 96, 24),
+           (16 * 129 * 129, 24, 48), (16 * 33 * 33, 1280, 256), (16 * 129 * 129, 256, 24), (16 * 33 * 33, 960, 160)]
+
+
+@pytest.mark.parametrize('case', PW_PROD)
+def test_pointwise_at_config1_shapes(ops, case):
+    M, K, Nn = case
+    rng = np.random.default_rng(M % 1000 + K * 3 + Nn)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((K, Nn)) / np.sqrt(K)).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, K).astype(np.float32)
+    sh = (rng.standard_normal(K) * 0.3).astype(np.float32)
+    a = O.act_fwd(x.astype(np.float64) * sc + sh, O.ACT_RELU6)
+    y_ref = a @ w.astype(np.float64)
+    part = ops.new_partials(Nn, DEV)
+    xt, wt = T(x), T(w)
+    y, rows = ops.pwconv_fwd(xt, wt, None, T(sc), T(sh), ops.ACT_RELU6, partials=part)
+    assert rel(y, y_ref) < 2e-5, 'forward'
+    p = part[:rows * 2 * Nn].reshape(rows, 2, Nn).double().sum(0).cpu().numpy()
+    assert rel(p[0], y_ref.sum(0)) < 1e-4 + 1e-4 * np.sqrt(M) / max(1.0, np.abs(y_ref.sum(0)).max()), 'stat sum'
+    assert rel(p[1], (y_ref ** 2).sum(0)) < 1e-4, 'stat sum of squares'
+    # transposed-kernel forward: the path the executor launches
+    y2, _ = ops.pwconv_fwd_wt(xt, T(np.ascontiguousarray(w.T)), None, T(sc), T(sh), ops.ACT_RELU6,
+                              partials=ops.new_partials(Nn, DEV))
+    assert rel(y2, y_ref) < 2e-5, 'forward (transposed kernel)'
+    del y, y2, xt
+    gy = rng.standard_normal((M, Nn)).astype(np.float32)
+    gyt = T(gy)
+    gx = ops.pwconv_bwd_data(gyt, wt)
+    gx_ref = gy.astype(np.float64) @ w.astype(np.float64).T
+    assert rel(gx, gx_ref) < 2e-5, 'data gradient'
+    # data gradient with the fused BatchNorm-backward sums (what the executor launches behind a BN + activation)
+    z = rng.standard_normal((M, K)).astype(np.float32)
+    mean, invstd = z.mean(0), 1.0 / np.sqrt(z.var(0) + 1e-3)
+    part = ops.new_partials(K, DEV)
+    gx2, rows = ops.pwconv_bwd_data_bn(gyt, wt, T(z), T(sc), T(sh), ops.ACT_RELU6, T(mean), T(invstd), part)
+    assert rel(gx2, gx_ref) < 2e-5, 'data gradient (+BN sums)'
+    u = z.astype(np.float64) * sc + sh
+    d = gx_ref * ((u > 0) & (u < 6))
+    xh = (z.astype(np.float64) - mean) * invstd
+    p = part[:rows * 2 * K].reshape(rows, 2, K).double().sum(0).cpu().numpy()
+    assert np.abs(p[0] - d.sum(0)).max() < 2e-4 * np.abs(d).sum(0).max(), 'BN backward sum'
+    assert np.abs(p[1] - (d * xh).sum(0)).max() < 2e-4 * np.abs(d * xh).sum(0).max(), 'BN backward sum * xhat'
+    del gx, gx2, u, d, xh, z
+    gw, gb = ops.pwconv_bwd_weight(T(x), gyt, T(sc), T(sh), ops.ACT_RELU6, with_bias=True)
+    gw_ref = a.T @ gy.astype(np.float64)
+    # M = 266 256 .. 1 056 784 products per entry: fp32 accumulation in fixed-order slabs
+    assert np.abs(gw.cpu().numpy() - gw_ref).max() < 3e-5 * np.sqrt(M) * max(1.0, float(np.abs(a).max())), 'weight gradient'
+    assert rel(gw, gw_ref) < 5e-3, 'weight gradient (relative to the largest entry)'
+    assert rel(gb, gy.astype(np.float64).sum(0)) < 1e-3, 'bias gradient'
+
+
+# (N, H, W, C, k, stride, rate): decoder_conv0_depthwise, expanded_conv_1_depthwise (257 -> 129, stride 2),
+# expanded_conv_depthwise (257 x 257 x 32), the three ASPP branches (rate 18 = the roofline kernel) and a rate-2 block
+DW_PROD = [(16, 129, 129, 304, 3, 1, 1), (16, 257, 257, 96, 3, 2, 1), (16, 257, 257, 32, 3, 1, 1),
+           (16, 33, 33, 320, 3, 1, 18), (16, 33, 33, 320, 3, 1, 12), (16, 33, 33, 320, 3, 1, 6),
+           (16, 33, 33, 960, 3, 1, 2), (16, 65, 65, 192, 3, 2, 1)]
+
+
+@pytest.mark.parametrize('case', DW_PROD)
+def test_depthwise_at_config1_shapes(ops, case):
+    N, H, W, C, k, s, r = case
+    rng = np.random.default_rng(H * 7 + C + r)
+    x = rng.standard_normal((N, H, W, C)).astype(np.float32)
+    w = (rng.standard_normal((k, k, C)) * 0.3).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, C).astype(np.float32)
+    sh = (rng.standard_normal(C) * 0.3).astype(np.float32)
+    a = O.act_fwd(x.astype(np.float64) * sc + sh, O.ACT_RELU6)
+    y_ref = O.dwconv2d_fwd(a, w.astype(np.float64), s, r, 'same')
+    part = ops.new_partials(C, DEV)
+    y, rows = ops.dwconv2d_fwd(T(x), T(w), s, r, 'same', T(sc), T(sh), ops.ACT_RELU6, partials=part)
+    assert rel(y, y_ref) < 1e-5, 'forward'
+    p = part[:rows * 2 * C].reshape(rows, 2, C).double().sum(0).cpu().numpy()
+    assert np.abs(p[0] - y_ref.reshape(-1, C).sum(0)).max() < 1e-4 * np.abs(y_ref).reshape(-1, C).sum(0).max(), 'stat sum'
+    assert rel(p[1], (y_ref ** 2).reshape(-1, C).sum(0)) < 1e-4, 'stat sum of squares'
+    del y
+    gy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    gx_ref, gw_ref = O.dwconv2d_bwd(a, w.astype(np.float64), gy.astype(np.float64), s, r, 'same')
+    gx = ops.dwconv2d_bwd_data(T(gy), T(w), (N, H, W, C), s, r, 'same')
+    assert rel(gx, gx_ref) < 1e-5, 'data gradient'
+    z = rng.standard_normal((N, H, W, C)).astype(np.float32)
+    mean = z.reshape(-1, C).mean(0)
+    invstd = 1.0 / np.sqrt(z.reshape(-1, C).var(0) + 1e-3)
+    part = ops.new_partials(C, DEV)
+    gx2, rows = ops.dwconv2d_bwd_data_bn(T(gy), T(w), (N, H, W, C), T(z), T(sc), T(sh), ops.ACT_RELU6, T(mean), T(invstd),
+                                         part, s, r, 'same')
+    assert rel(gx2, gx_ref) < 1e-5, 'data gradient (+BN sums)'
+    u = z.astype(np.float64) * sc + sh
+    d = (gx_ref * ((u > 0) & (u < 6))).reshape(-1, C)
+    xh = ((z.astype(np.float64) - mean) * invstd).reshape(-1, C)
+    p = part[:rows * 2 * C].reshape(rows, 2, C).double().sum(0).cpu().numpy()
+    assert np.abs(p[0] - d.sum(0)).max() < 2e-4 * np.abs(d).sum(0).max(), 'BN backward sum'
+    assert np.abs(p[1] - (d * xh).sum(0)).max() < 2e-4 * np.abs(d * xh).sum(0).max(), 'BN backward sum * xhat'
+    del gx, gx2, u, d, xh
+    gw = ops.dwconv2d_bwd_weight(T(x), T(gy), k, s, r, 'same', T(sc), T(sh), ops.ACT_RELU6)
+    M = N * y_ref.shape[1] * y_ref.shape[2]
+    assert np.abs(gw.cpu().numpy() - gw_ref).max() < 3e-5 * np.sqrt(M) * max(1.0, float(np.abs(a).max())), 'weight gradient'
+    assert rel(gw, gw_ref) < 5e-3, 'weight gradient (relative to the largest entry)'
+
+
+def test_head_and_resize_at_config1_shapes(ops):
+    """pred_resize + softmax + CE (129 -> 513, 21 classes, batch 16) and decoder_resize (33 -> 129, 256 ch)"""
+    N, h, w, C, H, W = 16, 129, 129, 21, 513, 513
+    rng = np.random.default_rng(9)
+    z = (rng.standard_normal((N, h, w, 24)) * 2).astype(np.float32)
+    z[..., C:] = 0
+    labels = rng.integers(0, C, (N, H, W)).astype(np.float32)
+    labels[rng.uniform(size=labels.shape) < 0.05] = 255
+    out = ops.upsample_softmax_ce(T(z), C, H, W, labels=T(labels), want_logits=True, want_grad=True)
+    # reference on two images (the fp64 softmax of 16 x 513 x 513 x 21 is 0.7 GB per temporary)
+    for n in (0, 15):
+        lg = O.resize_bilinear_fwd(z[n:n + 1, ..., :C].astype(np.float64), H, W)
+        assert np.abs(out['logits'][n, ..., :C].cpu().numpy() - lg[0]).max() < 1e-5 * np.abs(lg).max()
+        ce, probs, dl = O.sparse_ce_fwd_bwd(lg, labels[n:n + 1], 255)
+        got = out['dlogits'][n, ..., :C].cpu().numpy() * N          # the kernel scales by 1 / (N H W)
+        assert np.abs(got - dl[0]).max() < 1e-5 * np.abs(dl).max() + 1e-9
+    x = rng.standard_normal((N, 33, 33, 256)).astype(np.float32)
+    y = ops.resize_bilinear_fwd(T(x), 129, 129)
+    y_ref = O.resize_bilinear_fwd(x.astype(np.float64), 129, 129)
+    assert rel(y, y_ref) < 1e-5
+    gy = rng.standard_normal((N, 129, 129, 256)).astype(np.float32)
+    gx = ops.resize_bilinear_bwd(T(gy), 33, 33)
+    assert rel(gx, O.resize_bilinear_bwd(gy.astype(np.float64), 33, 33)) < 1e-5
+
+
+def test_bn_backward_at_config1_shape(ops):
+    """the separate reduce / finalize / apply passes on the largest BN of the step (expanded_conv_1_expand_BN,
+    16 x 257 x 257 x 96), channels with |mean| >> sigma included"""
+    M, C = 16 * 257 * 257, 96
+    rng = np.random.default_rng(21)
+    z = rng.standard_normal((M, C)).astype(np.float32)
+    z[:, :8] = z[:, :8] * 0.01 + 30.0            # post-ReLU6-like channels: mean 30, sigma 0.01
+    g = rng.standard_normal((M, C)).astype(np.float32)
+    bn = ops.BNState(C, DEV, eps=1e-3)
+    part = ops.new_partials(C, DEV)
+    # statistics through a producer: identity 1x1 conv would cost a GEMM; use the reduce of (sum, sum^2) kernels
+    zt = T(z)
+    y, rows = ops.pwconv_fwd(zt, T(np.eye(C, dtype=np.float32)), partials=part)
+    ops.bn_finalize(bn, part, rows, float(M))
+    z64 = z.astype(np.float64)
+    mean, var = z64.mean(0), z64.var(0)
+    assert np.abs(bn.mean.cpu().numpy() - mean).max() < 1e-5 * np.abs(mean).max()
+    # E[x^2] - E[x]^2 from float32 partial rows: relative error of the variance grows with (mean/sigma)^2
+    invstd_ref = 1.0 / np.sqrt(var + 1e-3)
+    assert np.abs(bn.invstd.cpu().numpy()[8:] - invstd_ref[8:]).max() < 1e-4 * invstd_ref[8:].max()
+    assert np.abs(bn.invstd.cpu().numpy()[:8] - invstd_ref[:8]).max() < 2e-2 * invstd_ref[:8].max()

@@ -34,6 +34,30 @@ def test_oracle_param_counts(mt):
     assert sum(1 for n in m.net.order if n.endswith('/gamma')) == nbn
 
 
+# README.md:312-317, column FLOPS at 512 x 512, OS 16, 21 classes (TensorFlow's profiler: 2 flops per multiply-add of
+# every convolution plus the elementwise ops, which weigh ~1 % on the large graphs and ~4 % on MobileNetV3Small-Lite)
+README_GFLOPS = {'xception': 102.73, 'resnet50': 73.95, 'mobilenetv3large': 9.52, 'mobilenetv2_lite': 5.24,
+                 'mobilenetv3small_lite': 1.36}
+
+
+@pytest.mark.parametrize('mt', sorted(README_GFLOPS))
+def test_forward_flops_match_readme(mt):
+    """MAC-count known answer: the convolutions of the product graph at the README's geometry, 2 flops per
+    multiply-add, reproduce the published figure from below (the remainder is the elementwise work)"""
+    pkg = load_pkg()
+    m = pkg.get_deeplabv3p_model(mt, 21, (512, 512), 16, training=False)
+    macs = 0
+    for op in m.graph.ops:
+        if op.kind in ('conv_pw', 'conv_dense'):
+            kh, kw, cin, cout = op.w.shape
+            macs += op.Ho * op.Wo * kh * kw * cin * cout
+        elif op.kind == 'conv_dw':
+            macs += op.Ho * op.Wo * op.k * op.k * op.c
+    g = 2.0 * macs / 1e9
+    ref = README_GFLOPS[mt]
+    assert g <= ref and g >= ref * (0.95 if mt == 'mobilenetv3small_lite' else 0.99), (mt, g, ref)
+
+
 def _product_models():
     return sorted(load_pkg().deeplab_model_map.keys())
 

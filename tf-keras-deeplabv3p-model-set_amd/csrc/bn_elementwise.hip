@@ -186,10 +186,9 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* partials
     save_mean[c] = (float)mean;
     save_invstd[c] = invstd;
     if (update_moving) {
-      double cm1 = count > 1.0 ? count - 1.0 : 1.0;
-      float var_unbiased = (float)(var * (count / cm1));
+      // SyncBatchNormalization (non-fused Keras path): the biased batch variance feeds the moving average too
       moving_mean[c] = moving_mean[c] * momentum + (float)mean * (1.f - momentum);
-      moving_var[c] = moving_var[c] * momentum + var_unbiased * (1.f - momentum);
+      moving_var[c] = moving_var[c] * momentum + (float)var * (1.f - momentum);
     }
   }
 }

@@ -22,6 +22,7 @@
 // producer's BN+activation on the way in, so normalised activations are never materialised in HBM.
 #include "common.h"
 #include <type_traits>
+#include <string.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -613,9 +614,23 @@ static bool pw_small_pick(int K, int N, SmallShape* out) {
   return true;
 }
 
+// rows from which the streaming small-K.N kernels take over from the tiled kernel (production: 2^17).  The parity
+// tests lower it through dl3p_set_option so that small test shapes reach those kernels too, and reset it for the
+// tests that check the production dispatch at the production shapes.
+static int g_pw_small_min_rows = -1;
 static int pw_small_min_rows() {
-  static const int v = getenv("DL3P_PW_SMALL_MIN_ROWS") ? atoi(getenv("DL3P_PW_SMALL_MIN_ROWS")) : (1 << 17);
-  return v;
+  if (g_pw_small_min_rows < 0)
+    g_pw_small_min_rows = getenv("DL3P_PW_SMALL_MIN_ROWS") ? atoi(getenv("DL3P_PW_SMALL_MIN_ROWS")) : (1 << 17);
+  return g_pw_small_min_rows;
+}
+extern "C" int dl3p_set_option(const char* name, int value) {
+  DL3P_CHECK_ARG(name != nullptr, "dl3p_set_option: null name");
+  if (!strcmp(name, "pw_small_min_rows")) {
+    g_pw_small_min_rows = value < 0 ? (1 << 17) : value;      // value < 0 restores the production threshold
+    return DL3P_OK;
+  }
+  dl3p_set_error("dl3p_set_option: unknown option '%s'", name);
+  return DL3P_EINVAL;
 }
 
 static int pw_small_grid(int M) {
