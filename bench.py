@@ -87,9 +87,36 @@ def measured_traffic(kernel_name):
     return None, None
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD torch.distributed.run job (this
+    process has not touched the GPU and never will), pass its output through and relay rank 0's JSON line as the last
+    line.  The driver's own `python -m torch.distributed.run ... bench.py --gpus N` sets WORLD_SIZE and never gets here."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = proc.stdout.splitlines()
+    js = [l for l in lines if l.startswith('{') and '"metric"' in l]
+    for l in lines:
+        if not js or l is not js[-1]:
+            print(l)
+    if js:
+        print(js[-1], flush=True)
+    return proc.returncode if proc.returncode else (0 if js else 1)
+
+
 def main():
     args = parse()
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC (what RCCL needs here); before HIP starts
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     import numpy as np
     import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -170,7 +197,8 @@ def main():
                        'global_batch': N * world,
                        'parallelism': 'dp%d%s' % (world, '+syncbn' if (world > 1 and not args.no_sync_bn) else ''),
                        'hip_graph': bool(model.use_graphs), 'final_loss': round(loss, 5),
-                       'launches_per_step': ex.fwd.n_launches + ex.bwd.n_launches + ex.opt.n_launches},
+                       'launches_per_step': ex.fwd.n_launches + ex.bwd.n_launches + ex.opt.n_launches,
+                       'collectives_per_step': sum(getattr(pl, 'n_collectives', 0) for pl in (ex.fwd, ex.bwd, ex.opt))},
         }
         if probe:
             ms = probe.mean_ms()

@@ -103,7 +103,7 @@ def test_model_h5_round_trip_and_topological_load(h5io, tmp_path, model_type):
         p = str(tmp_path / ('m%d.h5' % whole))
         (a.save if whole else a.save_weights)(p)
         layers, attrs = h5io.read_keras_h5(p)
-        assert [n for n, _ in layers] == [l.name for l in a.graph.layers]          # weightless layers listed too
+        assert [n for n, _ in layers] == [l.name for l in a.layers]                # weightless layers listed too, Keras order
         first = next(ws for _, ws in layers if ws)
         assert first[0][0].endswith('kernel:0')                                      # Keras weight names: '<layer>/kernel:0'
         for by_name in (False, True):
@@ -151,3 +151,71 @@ print('H5PY_OK')
 '''
     r = subprocess.run([H5PY_PYTHON, '-c', code, p, str(tmp_path / 'want.npz')], capture_output=True, text=True)
     assert 'H5PY_OK' in r.stdout, r.stderr[-2000:]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Keras layer order of the branched graphs: `model.layers`, and with it the order of the weighted
+# layers in a `.h5` file and the pairing of `load_weights(by_name=False)`, is by DECREASING depth from the output with
+# the depth-first visiting order as tie-break (keras/engine/functional.py `_map_graph_network`), not creation order.
+def _weighted_names(model):
+    return [l.name for l in model.layers if l.params]
+
+
+def test_keras_layer_order_mobilenetv2_aspp_and_decoder():
+    pkg = load_pkg()
+    m = pkg.get_deeplabv3p_model('mobilenetv2', 21, (65, 65), 16)
+    names = _weighted_names(m)
+    i = names.index('aspp1_depthwise')
+    assert names[i - 1] == 'expanded_conv_16_project_BN'
+    # hand-derived from reference layers.py:131-161 (depths counted back from the Concatenate):
+    #   +6 the three depthwise convs, +5 their BNs (and the pooling layer), +4 image_pooling, +3 image_pooling_BN and the
+    #   four 1x1 convs, +2 their BNs; branches in the order of Concatenate([b4, b0, b1, b2, b3])
+    assert names[i:i + 18] == [
+        'aspp1_depthwise', 'aspp2_depthwise', 'aspp3_depthwise',
+        'aspp1_depthwise_BN', 'aspp2_depthwise_BN', 'aspp3_depthwise_BN',
+        'image_pooling',
+        'image_pooling_BN', 'aspp0', 'aspp1_pointwise', 'aspp2_pointwise', 'aspp3_pointwise',
+        'aspp0_BN', 'aspp1_pointwise_BN', 'aspp2_pointwise_BN', 'aspp3_pointwise_BN',
+        'concat_projection', 'concat_projection_BN']
+    # the decoder's skip projection hangs off expanded_conv_2 but sits 3 layers above the decoder Concatenate
+    assert names[i + 18:i + 20] == ['feature_projection0', 'feature_projection0_BN']
+    assert names[i + 20] == 'decoder_conv0_depthwise' and names[-1] == 'conv_upsample'
+    assert m.layers[0].name == 'image_input' and m.layers[-1].name == 'pred_mask'
+    # the first backbone_len layers are exactly the backbone (what freeze_level=1 freezes, model.py:106-110)
+    head = {'image_pooling', 'aspp0', 'aspp1_depthwise', 'feature_projection0', 'decoder_conv0_depthwise', 'conv_upsample'}
+    assert not head & {l.name for l in m.layers[:m.backbone_len]}
+    assert sum(1 for l in m.layers[:m.backbone_len] if l.name.startswith(('expanded_conv', 'Conv'))) == \
+        sum(1 for l in m.layers if l.name.startswith(('expanded_conv', 'Conv')))
+
+
+def test_keras_layer_order_xception_shortcut_interleaves():
+    pkg = load_pkg()
+    m = pkg.get_deeplabv3p_model('xception', 21, (65, 65), 16)
+    names = _weighted_names(m)
+    i = names.index('entry_flow_block1_separable_conv3_depthwise')
+    # add([residual, shortcut]) (deeplabv3p_xception.py:85): the shortcut conv ties with separable_conv3_pointwise at
+    # depth +2 and its BN with separable_conv3_pointwise_BN at +1; the residual branch is visited first
+    assert names[i:i + 6] == ['entry_flow_block1_separable_conv3_depthwise', 'entry_flow_block1_separable_conv3_depthwise_BN',
+                              'entry_flow_block1_separable_conv3_pointwise', 'entry_flow_block1_shortcut',
+                              'entry_flow_block1_separable_conv3_pointwise_BN', 'entry_flow_block1_shortcut_BN']
+
+
+def test_h5_topological_round_trip_of_a_branched_model(tmp_path):
+    """save_weights -> load_weights(by_name=False) of full MobileNetV2 / by-name into a fresh model: same weights; the
+    file lists the layers in Keras order"""
+    pkg = load_pkg()
+    h5io = load_pkg('h5io')
+    try:
+        h5io.lib()
+    except ImportError:
+        pytest.skip('libhdf5 not available')
+    a = pkg.get_deeplabv3p_model('mobilenetv2', 21, (65, 65), 16, seed=1)
+    b = pkg.get_deeplabv3p_model('mobilenetv2', 21, (65, 65), 16, seed=2)
+    path = str(tmp_path / 'w.h5')
+    a.save_weights(path)
+    file_layers, _ = h5io.read_keras_h5(path)
+    assert [n for n, ws in file_layers if ws] == _weighted_names(a)
+    b.load_weights(path, by_name=False)
+    wa, wb = a.get_weights_by_name(), b.get_weights_by_name()
+    assert all(np.array_equal(wa[k], wb[k]) for k in wa)
+    assert [w.shape for w in a.get_weights()] == [p.shape for l in a.layers for p in l.params]

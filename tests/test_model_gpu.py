@@ -317,8 +317,19 @@ def test_train_py_flow(tmp_path):
     for i in range(len(m.layers)):
         m.layers[i].trainable = True
     m.compile(optimizer=opt, loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
+    v_before = m._store.V.clone()
+    assert opt.iterations == 6 and float(v_before.abs().max()) > 0
     h2 = m.fit_generator(gen, steps_per_epoch=len(gen), epochs=3, initial_epoch=2, callbacks=[cb], verbose=0)
     assert len(h2['loss']) == 1 and np.isfinite(h2['loss'][0])
+    # the SAME optimizer object: Keras keeps its iteration count (compile() restarted the schedule)
+    assert opt.iterations == 9
+    # train.py:190-224: the second stage builds a NEW optimizer whose schedule starts at iteration 0 (piecewise_constant:
+    # 0.001 for the first 500 steps) with fresh slots
+    opt2 = pkg.get_optimizer('sgd', 0.02, decay_type='piecewise_constant', decay_steps=1000)
+    m.compile(optimizer=opt2, loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
+    assert float(m._store.V.abs().max()) == 0.0 and int(m._store.step.item()) == 0
+    m.train_on_batch(*gen[0])
+    assert abs(float(m._executor(B, True).lr.item()) - 0.001) < 1e-9 and opt2.iterations == 1
     w2 = m.get_weights_by_name()
     assert any(not np.array_equal(w1[k], w2[k]) for k in w1 if k.startswith('expanded_conv_3_expand/'))
     path = str(tmp_path / 'trained_final')

@@ -31,17 +31,16 @@ class ParamStore:
         self.graph = graph
         self.device = device
         self.params = graph.all_params()
-        self.offset = {}
-        off = 0
-        for p in self.params:
-            self.offset[p] = off
-            off += (p.dev_size + 3) // 4 * 4
+        self.offset, off = param_offsets(self.params)
         self.total = off
         f = dict(dtype=torch.float32, device=device)
         self.P = torch.zeros(off, **f)
         self.G = torch.zeros(off, **f)
         self.V = torch.zeros(off, **f)
         self.V2 = None                        # second-moment buffer, allocated when Adam asks for it
+        # optimiser iteration counter (Adam's bias correction, the dropout stream): one per model, shared by the
+        # executors of every batch size, so a last partial batch continues the count instead of restarting it
+        self.step = torch.zeros(1, dtype=torch.int64, device=device)
         self.l2 = torch.zeros(off, **f)
         self.lr_scale = torch.zeros(off, **f)
         # transposed copies [N][K] of the pointwise / im2col'd kernels (same offsets as in P): the forward GEMM reads
@@ -114,6 +113,46 @@ class ParamStore:
         self.lr_scale.copy_(torch.from_numpy(lr))
 
 
+def param_offsets(params):
+    """flat-buffer offsets (in floats, 16-byte aligned) of the parameters in Keras weight order -> ({param: offset}, total)"""
+    offset, off = {}, 0
+    for p in params:
+        offset[p] = off
+        off += (p.dev_size + 3) // 4 * 4
+    return offset, off
+
+
+def bucket_edges(graph, offset, total, n_buckets):
+    """Gradient buckets of the flat buffer for the data-parallel all-reduce.  -> ({op: (lo, hi)}, first_bucket_hi):
+    when backward (reversed(graph.ops)) is ABOUT TO process `op`, every gradient in [lo, hi) is final and the slice can
+    go on the wire; [0, first_bucket_hi) follows after the last op.
+
+    The flat buffer is in layer-creation order but backward visits the ops in reversed EXECUTION order, and the two
+    differ (layers._atrous_first runs the ASPP depthwise convs first, so their gradients are the LAST of the ASPP
+    block to be written although they sit above image_pooling / aspp0 in the buffer).  A suffix [lo, total) is final
+    only once no op that is still to be processed owns a parameter at or above lo: lo = the highest parameter end
+    among the unprocessed layers (a BatchNormalization fused into its consumer's data-gradient kernel finishes
+    earlier than its own position -- counting it at its position is conservative)."""
+    rng = {}
+    for p, o in offset.items():
+        e = o + (p.dev_size + 3) // 4 * 4
+        lo, hi = rng.get(p.layer, (o, e))
+        rng[p.layer] = (min(lo, o), max(hi, e))
+    ops_r = [o for o in reversed(graph.ops) if getattr(o, 'layer', None) in rng]
+    pending_end = [0] * (len(ops_r) + 1)          # highest parameter end among ops_r[i:]
+    for i in range(len(ops_r) - 1, -1, -1):
+        pending_end[i] = max(pending_end[i + 1], rng[ops_r[i].layer][1])
+    n = max(1, int(n_buckets))
+    target = total / n
+    edges, hi = {}, total
+    for i, op in enumerate(ops_r):
+        done_lo = pending_end[i]
+        if done_lo < hi and hi - done_lo >= target and len(edges) < n - 1:
+            edges[op] = (done_lo, hi)
+            hi = done_lo
+    return edges, hi
+
+
 def _op_label(op):
     n = getattr(op, 'name', None)
     if n is None and getattr(op, 'bn', None) is not None and op.kind == 'bn':
@@ -160,6 +199,11 @@ class Plan:
         fn()
         self.items.append((None, fn))
         self.labels.append(('py', self.ctx))
+
+    def coll(self, fn):
+        """a collective (RCCL all-reduce); counted for the bench line"""
+        self.n_collectives = getattr(self, 'n_collectives', 0) + 1
+        self.py(fn)
 
     def run(self):
         if self.segments is not None:
@@ -278,7 +322,7 @@ class Executor:
         self.f32 = dict(dtype=torch.float32, device=self.dev)
         self._alloc()
         # tracing runs every kernel once on zero inputs: keep the weights / optimiser state intact
-        snap_p, snap_v = store.P.clone(), store.V.clone()
+        snap_p, snap_v, snap_step = store.P.clone(), store.V.clone(), store.step.clone()
         snap_v2 = store.V2.clone() if store.V2 is not None else None
         if training:
             self.fwd = self._trace_forward()
@@ -292,7 +336,7 @@ class Executor:
         if snap_v2 is not None:
             store.V2.copy_(snap_v2)
         store.transpose()
-        self.step.zero_()
+        store.step.copy_(snap_step)
         self.graphed = False
 
     # ---------------------------------------------------------------- buffers
@@ -360,7 +404,7 @@ class Executor:
                             if (self.training and not self.fused_head) else None)
         self.probs = None if self.training else torch.zeros(N * H * W * self.C, **self.f32)
         self.logits_big = None
-        self.step = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.step = self.store.step
         self.lr = torch.full((1,), 0.01, **self.f32)
 
     def _mark_requires_grad(self):
@@ -522,7 +566,7 @@ class Executor:
             sums = None
             if self.sync_bn:
                 P.k(L.bn_reduce_partials, self.partials.data_ptr(), rows, 2 * bn.C, aux['sums'].data_ptr())
-                P.py(lambda s=aux['sums']: self.dist.all_reduce(s))
+                P.coll(lambda s=aux['sums']: self.dist.all_reduce(s))
                 sums, count = aux['sums'].data_ptr(), count * self.dist.world_size
             P.k(L.bn_finalize, self.partials.data_ptr(), rows, sums, bn.C, count, st.ptr(lp['gamma']),
                 st.ptr(lp['beta']), bn.eps, bn.momentum, st.ptr(lp['moving_mean']), st.ptr(lp['moving_variance']), 1,
@@ -598,7 +642,7 @@ class Executor:
             if op in bucket_edges:
                 self._flush_deferred(P)        # every gradient of the finished bucket must have been produced
                 lo, hi = bucket_edges[op]
-                P.py(lambda lo=lo, hi=hi: self.dist.all_reduce_async(G[lo:hi]))
+                P.coll(lambda lo=lo, hi=hi: self.dist.all_reduce_async(G[lo:hi]))
             out = getattr(op, 'out', None)
             if out is not None and out.id in self._pending_views:
                 self._flush_views(P, out)
@@ -711,7 +755,7 @@ class Executor:
                 raise NotImplementedError(k)
         self._flush_deferred(P)
         if self.dist is not None:
-            P.py(lambda hi=self._first_bucket_hi: self.dist.all_reduce_async(G[0:hi]))
+            P.coll(lambda hi=self._first_bucket_hi: self.dist.all_reduce_async(G[0:hi]))
             # join the side stream inside this plan: a captured graph may not end with forked work in flight
             P.py(self.dist.wait_all)
         return P
@@ -748,24 +792,7 @@ class Executor:
         P.ctx = ctx
 
     def _bucket_edges(self):
-        """{op: (lo, hi)}: when backward reaches `op` (going back to front), the gradients of every
-        parameter created after it are final -> all-reduce that slice of the flat buffer"""
-        st = self.store
-        layer_lo = {}
-        for p in st.params:
-            layer_lo.setdefault(p.layer, st.offset[p])
-        ops = [o for o in self.g.ops if getattr(o, 'layer', None) in layer_lo]
-        n = max(1, self.dist.n_buckets)
-        target = st.total / n
-        edges, hi = {}, st.total
-        for op in reversed(ops):
-            lo = layer_lo[op.layer]
-            # `op` itself is still to be processed: the finished range is everything above the end of its layer
-            done_lo = lo + sum((p.dev_size + 3) // 4 * 4 for p in op.layer.params)
-            if hi - done_lo >= target and len(edges) < n - 1:
-                edges[op] = (done_lo, hi)
-                hi = done_lo
-        self._first_bucket_hi = hi
+        edges, self._first_bucket_hi = bucket_edges(self.g, self.store.offset, self.store.total, self.dist.n_buckets)
         return edges
 
     def _bn_backward(self, P, op, fused_rows=None):
@@ -795,7 +822,7 @@ class Executor:
                 # normalisation terms use the global sums.  The all-reduce runs beside the deferred weight
                 # gradient(s) of the layer(s) processed before this one.
                 P.k(L.bn_reduce_partials, self.partials.data_ptr(), rows.value, 2 * bn.C, aux['sums'].data_ptr())
-                P.py(lambda s=aux['sums']: self.dist.bn_all_reduce_begin(s))
+                P.coll(lambda s=aux['sums']: self.dist.bn_all_reduce_begin(s))
                 self._flush_deferred(P)
                 P.py(self.dist.bn_all_reduce_end)
                 P.k(L.bn_bwd_finalize, None, 0, aux['sums'].data_ptr(), bn.C, float(M * self.dist.world_size),

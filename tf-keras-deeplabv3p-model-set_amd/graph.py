@@ -68,6 +68,7 @@ class Layer:
         self.name, self.kind, self.output_shape = name, kind, output_shape
         self.trainable = True
         self.params = []
+        self.inbound = []       # the Keras layers whose outputs this layer is called on (functional-API edges)
 
     def add_param(self, key, shape, init, **kw):
         p = Param(self, key, shape, init, **kw)
@@ -140,8 +141,16 @@ class BNSpec:
 class Value:
     """act(tensor * scale + shift): what a Keras tensor is, lazily"""
 
-    def __init__(self, tensor, group=None, goff=0, act=ACT_NONE, bn=None):
+    def __init__(self, tensor, group=None, goff=0, act=ACT_NONE, bn=None, klayer=None):
         self.tensor, self.group, self.goff, self.act, self.bn = tensor, group, goff, act, bn
+        self.klayer = klayer      # the Keras layer this tensor is the output of
+
+    def from_layer(self, layer):
+        """the same lazy value as the output tensor of another Keras layer (a copy: `self` may have other consumers)"""
+        import copy
+        v = copy.copy(self)
+        v.klayer = layer
+        return v
 
     @property
     def shape(self):
@@ -194,13 +203,12 @@ class GraphBuilder:
         self.dropout_count = 0
         self.act_views = {}
         inp = self.new_tensor(H, W, C, 'image_input')
-        self.add_layer('image_input', 'InputLayer', (H, W, C))
-        self.input = Value(inp)
+        self.input = Value(inp, klayer=self.add_layer('image_input', 'InputLayer', (H, W, C)))
         self.input_shape = (H, W, C)
         self.taps = {}
 
     # ---- bookkeeping ------------------------------------------------------------------
-    def add_layer(self, name, kind, output_shape=None):
+    def add_layer(self, name, kind, output_shape=None, inbound=()):
         if name is None:
             base = {'ReLU': 're_lu', 'Add': 'add', 'Concatenate': 'concatenate', 'Dropout': 'dropout',
                     'ZeroPadding2D': 'zero_padding2d', 'AveragePooling2D': 'average_pooling2d',
@@ -210,6 +218,10 @@ class GraphBuilder:
             name = base if n == 0 else '%s_%d' % (base, n)
         assert name not in self.layer_by_name, 'duplicate layer name ' + name
         layer = Layer(name, kind, output_shape)
+        for v in inbound:
+            src = v.klayer if isinstance(v, Value) else v
+            assert src is not None, 'layer %s: an input tensor has no producing Keras layer' % name
+            layer.inbound.append(src)
         self.layers.append(layer)
         self.layer_by_name[name] = layer
         return layer
@@ -234,10 +246,11 @@ class GraphBuilder:
         """DeeplabConv2D (reference layers.py:14-21): glorot_uniform kernel (he_normal in the ResNet50 backbone), zero
         bias, l2(2e-5) on both"""
         H, W, cin = x.shape
+        src = x
         if not isinstance(padding, str):
-            self.add_layer(None, 'ZeroPadding2D')
+            src = self.add_layer(None, 'ZeroPadding2D', inbound=[x])
         Ho, Wo, pt, pl = conv_geometry(H, W, k, stride, rate, padding)
-        layer = self.add_layer(name, 'Conv2D', (Ho, Wo, filters))
+        layer = self.add_layer(name, 'Conv2D', (Ho, Wo, filters), inbound=[src])
         cdev = pad_to or filters
         # dense (k > 1) kernels are stored as the im2col GEMM operand [k*k*cin padded to a multiple of 4][cout]
         kp = (k * k * cin + 3) // 4 * 4
@@ -260,29 +273,30 @@ class GraphBuilder:
         col = self.new_tensor(Ho, Wo, kp, name + '_im2col') if kind == 'conv_dense' else None
         self.ops.append(Op(kind, name=name, layer=layer, x=x, w=wp, b=bp, out=out, k=k, stride=stride, rate=rate,
                            pad_t=pt, pad_l=pl, Ho=Ho, Wo=Wo, cin=cin, cout=cdev, bn=None, col=col, kp=kp))
-        return Value(out)
+        return Value(out, klayer=layer)
 
     def dwconv2d(self, x, k, name, stride=1, rate=1, padding='same', out=None):
         """DeeplabDepthwiseConv2D (reference layers.py:24-31); its kernel_regularizer never reaches the
         depthwise kernel in Keras -> no l2"""
         H, W, c = x.shape
+        src = x
         if not isinstance(padding, str):
-            self.add_layer(None, 'ZeroPadding2D')
+            src = self.add_layer(None, 'ZeroPadding2D', inbound=[x])
         Ho, Wo, pt, pl = conv_geometry(H, W, k, stride, rate, padding)
-        layer = self.add_layer(name, 'DepthwiseConv2D', (Ho, Wo, c))
+        layer = self.add_layer(name, 'DepthwiseConv2D', (Ho, Wo, c), inbound=[src])
         wp = layer.add_param('depthwise_kernel', (k, k, c, 1),
                              lambda s: glorot_uniform(self.rng, s, k * k * c, k * k * 1), l2=0.0)
         if out is None:
             out = self.new_tensor(Ho, Wo, c, name)
         self.ops.append(Op('conv_dw', name=name, layer=layer, x=x, w=wp, out=out, k=k, stride=stride, rate=rate,
                            pad_t=pt, pad_l=pl, Ho=Ho, Wo=Wo, c=c, bn=None))
-        return Value(out)
+        return Value(out, klayer=layer)
 
     def batchnorm(self, z, name, eps=1e-3, momentum=0.99, group=None, goff=0):
         """CustomBatchNormalization (reference layers.py:63-70)"""
         assert z.is_plain, 'BatchNormalization expects a raw conv output'
         t = z.tensor
-        layer = self.add_layer(name, 'BatchNormalization', (t.H, t.W, t.C))
+        layer = self.add_layer(name, 'BatchNormalization', (t.H, t.W, t.C), inbound=[z])
         c = t.C
         layer.add_param('gamma', (c,), lambda s: np.ones(s, np.float32))
         layer.add_param('beta', (c,), lambda s: np.zeros(s, np.float32))
@@ -300,7 +314,7 @@ class GraphBuilder:
         assert prod is not None and prod.bn is None, name
         prod.bn = bn
         self.ops.append(Op('bn', name=name, layer=layer, bn=bn, z=t, producer=prod))
-        return Value(t, group, goff, ACT_NONE, bn)
+        return Value(t, group, goff, ACT_NONE, bn, klayer=layer)
 
     def producer_of(self, t):
         for op in reversed(self.ops):
@@ -309,17 +323,20 @@ class GraphBuilder:
         return None
 
     def activation(self, v, act, name=None, kind='ReLU'):
-        self.add_layer(name, kind, v.shape)
+        layer = self.add_layer(name, kind, v.shape, inbound=[v])
+        if act == ACT_HSWISH:
+            # hard_swish(x) = Multiply()([Activation(hard_sigmoid)(x), x]) (deeplabv3p_mobilenetv3.py:102-103): two Keras layers
+            layer = self.add_layer(None, 'Multiply', v.shape, inbound=[layer, v])
         if act == ACT_NONE:
-            return v
+            return v.from_layer(layer)
         if v.act == act and act in (ACT_RELU, ACT_RELU6):
-            return v                      # idempotent (ReLU in front of a SepConv_BN whose input is already ReLU-ed)
+            return v.from_layer(layer)    # idempotent (ReLU in front of a SepConv_BN whose input is already ReLU-ed)
         assert v.act == ACT_NONE, 'stacked activations need a materialised tensor'
         if v.bn is not None:
             assert v.bn.act in (ACT_NONE, act), 'one activation per BatchNormalization (materialise otherwise)'
             v.bn.act = act
-            return Value(v.tensor, v.group, v.goff, act, v.bn)
-        out = Value(v.tensor, v.group, v.goff, act, None)
+            return Value(v.tensor, v.group, v.goff, act, v.bn, klayer=layer)
+        out = Value(v.tensor, v.group, v.goff, act, None, klayer=layer)
         if v.group is None:
             # bare activation of a materialised tensor (Xception: ReLU in front of a SepConv_BN applied to a
             # residual sum; SE block activations).  Its consumers write d/d(act(T)) into a view buffer that
@@ -349,57 +366,63 @@ class GraphBuilder:
             self.dropout_count += 1
         self.ops.append(Op('materialize', name=name or out.name, x=v, r=residual, rate=dropout, dropout_name=dname,
                            out=out))
-        return Value(out)
+        return Value(out, klayer=v.klayer)      # not a Keras layer by itself: add() / dropout() name theirs
 
-    def add(self, a, b, name=None):
-        """Add([a, b]) -- `b` is the BN output (lazy), `a` the shortcut"""
-        self.add_layer(name, 'Add', a.shape)
-        return self.materialize(b, residual=a, name=name)
+    def add(self, a, b, name=None, keras_inputs=None):
+        """Add([a, b]) -- `b` is the BN output (lazy), `a` the shortcut; keras_inputs: the list as the reference passes it
+        when that is [b, a] (the order decides ties in Keras' layer ordering)"""
+        layer = self.add_layer(name, 'Add', a.shape, inbound=keras_inputs or [a, b])
+        return self.materialize(b, residual=a, name=name).from_layer(layer)
 
     def dropout(self, v, rate, name=None):
-        self.add_layer(name, 'Dropout', v.shape)
-        return self.materialize(v, dropout=rate, name=name)
+        layer = self.add_layer(name, 'Dropout', v.shape, inbound=[v])
+        return self.materialize(v, dropout=rate, name=name).from_layer(layer)
 
     def se_multiply(self, x, s, name=None):
         """Multiply([x, s]) with s (1,1,C) broadcast over the pixels (reference deeplabv3p_mobilenetv3.py:145)"""
         H, W, C = x.shape
-        self.add_layer(name, 'Multiply', (H, W, C))
+        layer = self.add_layer(name, 'Multiply', (H, W, C), inbound=[x, s])
         out = self.new_tensor(H, W, C, name or ('semul_' + x.tensor.name))
         self.ops.append(Op('se_mul', name=out.name, x=x, s=s, out=out))
-        return Value(out)
+        return Value(out, klayer=layer)
 
     def maxpool2d(self, v, k, stride, pad, name=None, pad_name=None):
         """ZeroPadding2D(pad) + MaxPooling2D((k,k), strides) (reference deeplabv3p_resnet50.py:266-267)"""
         H, W, C = v.shape
         pt, pb, pl, pr = pad
+        src = v
         if any(pad):
-            self.add_layer(pad_name, 'ZeroPadding2D')
+            src = self.add_layer(pad_name, 'ZeroPadding2D', inbound=[v])
         Ho, Wo = (H + pt + pb - k) // stride + 1, (W + pl + pr - k) // stride + 1
-        layer = self.add_layer(name, 'MaxPooling2D', (Ho, Wo, C))
+        layer = self.add_layer(name, 'MaxPooling2D', (Ho, Wo, C), inbound=[src])
         out = self.new_tensor(Ho, Wo, C, layer.name)
         self.ops.append(Op('maxpool', name=layer.name, x=v, out=out, k=k, stride=stride, pad_t=pt, pad_l=pl, Ho=Ho, Wo=Wo))
-        return Value(out)
+        return Value(out, klayer=layer)
 
     def global_avgpool(self, v, name=None, kind='AveragePooling2D'):
         H, W, C = v.shape
-        self.add_layer(name, kind, (1, 1, C))
+        layer = self.add_layer(name, kind, (1, 1, C), inbound=[v])
         out = self.new_tensor(1, 1, C, 'pool_' + v.tensor.name)
         self.ops.append(Op('gap', name=out.name, x=v, out=out))
-        return Value(out)
+        return Value(out, klayer=layer)
+
+    def passthrough(self, v, kind, output_shape=None, name=None):
+        """a Keras layer that moves no data here (Reshape of a pooled vector, pred_resize / Softmax of the head)"""
+        return v.from_layer(self.add_layer(name, kind, output_shape, inbound=[v]))
 
     def resize(self, v, H, W, name, out=None):
         """Lambda(img_resize, bilinear) (reference layers.py:48-60).  From a 1x1 map the bilinear
         resize is a broadcast, which commutes with the lazy BN+activation -> stays lazy."""
         h, w, C = v.shape
-        self.add_layer(name, 'Lambda', (H, W, C))
+        layer = self.add_layer(name, 'Lambda', (H, W, C), inbound=[v])
         if out is None:
             out = self.new_tensor(H, W, C, name)
         if h == 1 and w == 1:
             self.ops.append(Op('broadcast', name=name, x=v, out=out))
-            return Value(out, v.group, v.goff, v.act, v.bn)
+            return Value(out, v.group, v.goff, v.act, v.bn, klayer=layer)
         assert v.is_plain, 'bilinear resize needs a materialised input'
         self.ops.append(Op('resize', name=name, x=v, out=out))
-        return Value(out)
+        return Value(out, klayer=layer)
 
     def concat_buffer(self, H, W, channels, name):
         """allocate the Concatenate target up front: returns (slices, coefficient group)"""
@@ -412,9 +435,47 @@ class GraphBuilder:
             off += c
         return base, slices, group
 
-    def concat_value(self, base, group, act, name=None):
-        self.add_layer(name, 'Concatenate', (base.H, base.W, base.C))
-        return Value(base, group, 0, act, None)
+    def concat_value(self, base, group, act, inputs, name=None):
+        """`inputs`: the branch values in the order of the reference's Concatenate([...]) call"""
+        layer = self.add_layer(name, 'Concatenate', (base.H, base.W, base.C), inbound=inputs)
+        return Value(base, group, 0, act, None, klayer=layer)
+
+    def keras_layer_order(self, output_layer=None):
+        """`model.layers` as Keras builds it for a functional model (keras/engine/functional.py `_map_graph_network`):
+        layers sorted by DECREASING depth -- the length of the longest path from the layer to the output -- and, inside
+        one depth, by the order in which a depth-first walk from the output (inputs of a merge layer in list order) first
+        meets them.  Creation order and this order differ wherever the graph branches: the ASPP branches, the Xception
+        shortcut convs, the decoder's skip projection.  `save_weights` writes and `load_weights(by_name=False)` pairs
+        layers in THIS order (the i-th layer with weights of the file feeds the i-th layer with weights of the model)."""
+        out = output_layer or self.layers[-1]
+        index, depth, post = {}, {}, []
+
+        def walk(root):
+            # iterative DFS: pre-order index at first visit, post-order list for the depth pass
+            stack = [(root, 0)]
+            index[root] = len(index)
+            while stack:
+                layer, i = stack.pop()
+                if i < len(layer.inbound):
+                    stack.append((layer, i + 1))
+                    nxt = layer.inbound[i]
+                    if nxt not in index:
+                        index[nxt] = len(index)
+                        stack.append((nxt, 0))
+                else:
+                    post.append(layer)
+        walk(out)
+        for layer in reversed(post):               # consumers before producers
+            d = depth.setdefault(layer, 0)
+            for src in layer.inbound:
+                depth[src] = max(depth.get(src, 0), d + 1)
+        by_depth = {}
+        for layer, d in depth.items():
+            by_depth.setdefault(d, []).append(layer)
+        order = []
+        for d in sorted(by_depth, reverse=True):
+            order.extend(sorted(by_depth[d], key=lambda l: index[l]))
+        return order
 
     # ---- finishing --------------------------------------------------------------------
     def init_weights(self):

@@ -55,15 +55,15 @@ def ASPP_block(g, x, OS):
     # Concatenate([b4, b0, b1, b2, b3]) (layers.py:155): the five branches write their raw outputs
     # into channel slices of one buffer; their BNs own slices of one coefficient group
     base, slices, group = g.concat_buffer(H, W, [256] * 5, 'aspp_concat')
-    _image_pooling_branch(g, x, slices[0][0], group, slices[0][1])
+    b4 = _image_pooling_branch(g, x, slices[0][0], group, slices[0][1])
     b0 = g.conv2d(x, 256, 1, 'aspp0', out=slices[1][0])
     b0 = g.batchnorm(b0, 'aspp0_BN', eps=1e-5, group=group, goff=slices[1][1])
-    g.relu(b0, 'aspp0_activation')
+    branches = [b4, g.relu(b0, 'aspp0_activation')]
     for i, r in enumerate(atrous_rates):
-        SepConv_BN(g, x, 256, 'aspp%d' % (i + 1), rate=r, depth_activation=True, epsilon=1e-5,
-                   out=slices[2 + i][0], out_group=group, out_goff=slices[2 + i][1])
+        branches.append(SepConv_BN(g, x, 256, 'aspp%d' % (i + 1), rate=r, depth_activation=True, epsilon=1e-5,
+                                   out=slices[2 + i][0], out_group=group, out_goff=slices[2 + i][1]))
     _atrous_first(g, x_in)
-    x = g.concat_value(base, group, ACT_RELU)
+    x = g.concat_value(base, group, ACT_RELU, branches)          # Concatenate()([b4, b0, b1, b2, b3]) (:155)
     x = g.conv2d(x, 256, 1, 'concat_projection')
     x = g.batchnorm(x, 'concat_projection_BN', eps=1e-5)
     x = g.relu(x)
@@ -105,11 +105,11 @@ def ASPP_Lite_block(g, x):
     """global pooling + 1x1 branch only (reference layers.py:166-196)"""
     H, W, _ = x.shape
     base, slices, group = g.concat_buffer(H, W, [256] * 2, 'aspp_concat')
-    _image_pooling_branch(g, x, slices[0][0], group, slices[0][1])
+    b4 = _image_pooling_branch(g, x, slices[0][0], group, slices[0][1])
     b0 = g.conv2d(x, 256, 1, 'aspp0', out=slices[1][0])
     b0 = g.batchnorm(b0, 'aspp0_BN', eps=1e-5, group=group, goff=slices[1][1])
-    g.relu(b0, 'aspp0_activation')
-    x = g.concat_value(base, group, ACT_RELU)
+    b0 = g.relu(b0, 'aspp0_activation')
+    x = g.concat_value(base, group, ACT_RELU, [b4, b0])          # Concatenate()([b4, b0]) (:189)
     x = g.conv2d(x, 256, 1, 'concat_projection')
     x = g.batchnorm(x, 'concat_projection_BN', eps=1e-5)
     x = g.relu(x)
@@ -121,11 +121,11 @@ def Decoder_block(g, x, skip_feature):
     H, W, _ = skip_feature.shape
     base, slices, group = g.concat_buffer(H, W, [x.shape[2], 48], 'decoder_concat')
     # the resized ASPP output is already activated (>= 0): identity coefficients + ReLU is a no-op on it
-    g.resize(x, H, W, 'decoder_resize', out=slices[0][0])
+    xr = g.resize(x, H, W, 'decoder_resize', out=slices[0][0])
     s = g.conv2d(skip_feature, 48, 1, 'feature_projection0', out=slices[1][0])
     s = g.batchnorm(s, 'feature_projection0_BN', eps=1e-5, group=group, goff=slices[1][1])
-    g.relu(s)
-    x = g.concat_value(base, group, ACT_RELU)
+    s = g.relu(s)
+    x = g.concat_value(base, group, ACT_RELU, [xr, s])           # Concatenate()([x, skip_feature]) (:214)
     x = SepConv_BN(g, x, 256, 'decoder_conv0', depth_activation=True, epsilon=1e-5)
     x = SepConv_BN(g, x, 256, 'decoder_conv1', depth_activation=True, epsilon=1e-5)
     return x

@@ -29,7 +29,7 @@ def _act(g, x, activation):
 
 def _se_block(g, inputs, filters, se_ratio, prefix):
     x = g.global_avgpool(inputs, prefix + 'squeeze_excite/AvgPool', kind='GlobalAveragePooling2D')
-    g.add_layer(None, 'Reshape', (1, 1, filters))
+    x = g.passthrough(x, 'Reshape', (1, 1, filters))
     x = g.conv2d(x, _depth(filters * se_ratio), 1, prefix + 'squeeze_excite/Conv', use_bias=True)
     x = g.relu(x, prefix + 'squeeze_excite/Relu')
     x = g.conv2d(x, filters, 1, prefix + 'squeeze_excite/Conv_1', use_bias=True)

@@ -58,6 +58,7 @@ class SGD:
         if nesterov:
             raise ValueError('nesterov momentum is not on the hot path')
         self.learning_rate, self.momentum = learning_rate, momentum
+        self.iterations = 0          # Keras `optimizer.iterations`: a schedule starts at 0 with a NEW optimizer
 
     def lr_at(self, step):
         lr = self.learning_rate
@@ -75,6 +76,7 @@ class Adam(SGD):
             raise ValueError('amsgrad is not built (the reference passes amsgrad=False)')
         self.learning_rate, self.beta_1, self.beta_2, self.epsilon = learning_rate, beta_1, beta_2, epsilon
         self.momentum = 0.0
+        self.iterations = 0
 
     def spec(self):
         return ('adam', float(self.beta_1), float(self.beta_2), float(self.epsilon))
@@ -88,6 +90,7 @@ class RMSprop(SGD):
             raise ValueError('RMSprop momentum / centered are not built (the reference uses momentum=0.0, centered=False)')
         self.learning_rate, self.rho, self.epsilon = learning_rate, rho, epsilon
         self.momentum = 0.0
+        self.iterations = 0
 
     def spec(self):
         return ('rmsprop', float(self.rho), float(self.epsilon))
@@ -273,7 +276,10 @@ class DeeplabModel:
         self.input_shape_hw = tuple(input_shape)
         self.flatten_output = training      # Reshape((H*W, C)) when built for training (model.py:79-80)
         self.backbone_len = backbone_len
-        self.layers = graph.layers
+        # `model.layers` as Keras orders a functional model (by depth from the output, graph.keras_layer_order): what
+        # layers[i].trainable (train.py:222-229, model.py:106-115), get_weights() and topological weight loading index.
+        # The flat device buffers keep creation order (graph.all_params()).
+        self.layers = graph.keras_layer_order(getattr(graph, 'output_layer', None))
         graph.init_weights()
         self.optimizer = None
         self.loss = None
@@ -319,6 +325,10 @@ class DeeplabModel:
                 sync_bn=True, **kw):
         """model.compile(optimizer, loss, ...) (train.py:157,224): (re)binds optimiser and loss and drops the
         traced plans, so `layers[i].trainable` changes take effect like a Keras recompile"""
+        # Keras keeps the slot variables and `iterations` on the optimizer OBJECT: compiling again with the same object
+        # (train.py:224 after unfreezing) continues its schedule and momentum, a new object (train.py:190-224 builds one
+        # for the second stage) starts its schedule at step 0 with fresh slots
+        same_optimizer = optimizer is not None and optimizer is self.optimizer
         self.optimizer = optimizer or SGD(0.01)
         self.loss = loss or SparseCategoricalCrossEntropy(ignore_index=255)
         if sample_weight_mode not in (None, 'temporal'):
@@ -334,9 +344,11 @@ class DeeplabModel:
         self._exec = {}
         if self._store is not None:
             self._store.refresh_masks()
-            self._store.V.zero_()
-            if self._store.V2 is not None:
-                self._store.V2.zero_()
+            if not same_optimizer:
+                self._store.V.zero_()
+                if self._store.V2 is not None:
+                    self._store.V2.zero_()
+                self._store.step.zero_()
         return self
 
     def _ensure_store(self):
@@ -374,12 +386,13 @@ class DeeplabModel:
             raise RuntimeError('You must compile your model before training')
         ex = self._executor(int(x.shape[0]), True)
         ex.set_inputs(x, y, sample_weight)
-        ex.lr.fill_(self.optimizer.lr_at(self._steps))
+        ex.lr.fill_(self.optimizer.lr_at(self.optimizer.iterations))
         if self.use_graphs and not ex.graphed and self._steps_on(ex) >= 1:
             ex.capture()
         ex.train_step()
         ex._steps = self._steps_on(ex) + 1
         self._steps += 1
+        self.optimizer.iterations += 1
         if return_tensor:
             return ex.loss
         loss = float(ex.loss.item())
@@ -480,12 +493,15 @@ class DeeplabModel:
         if self._store is not None:
             self._store.download()
 
+    def _keras_params(self):
+        return [p for l in self.layers for p in l.params]
+
     def get_weights(self):
         self._sync_to_host()
-        return [p.value for p in self.graph.all_params()]
+        return [p.value for p in self._keras_params()]
 
     def set_weights(self, weights):
-        ps = self.graph.all_params()
+        ps = self._keras_params()
         assert len(weights) == len(ps), (len(weights), len(ps))
         for p, w in zip(ps, weights):
             w = np.asarray(w, dtype=np.float32)
@@ -512,7 +528,7 @@ class DeeplabModel:
     def _keras_layers(self):
         """[(layer name, [(Keras weight name, array), ...]), ...] in topological order, weightless layers included"""
         self._sync_to_host()
-        return [(l.name, [(p.name + ':0', p.value) for p in l.params]) for l in self.graph.layers]
+        return [(l.name, [(p.name + ':0', p.value) for p in l.params]) for l in self.layers]
 
     def save(self, path):
         """whole-model checkpoint (train.py:247, deeplab.py:113).  `*.h5`: the Keras HDF5 layout (weights under
@@ -544,7 +560,7 @@ class DeeplabModel:
         layer with weights of the model, names ignored) / `..._by_name` (layers matched by name, weights by position)"""
         from . import h5io
         file_layers, _ = h5io.read_keras_h5(path)
-        mine = [l for l in self.graph.layers if l.params]
+        mine = [l for l in self.layers if l.params]
 
         def assign(layer, ws, lname):
             if len(ws) != len(layer.params):
@@ -586,8 +602,7 @@ class DeeplabModel:
         if by_name:
             self.set_weights_by_name({k: data[k] for k in data.files}, strict=False)
         else:
-            # topological order == creation order (model.py:103 load_weights(by_name=False))
-            self.set_weights([data[p.name] for p in self.graph.all_params()])
+            self.set_weights([data[p.name] for p in self._keras_params()])
 
 
 def _evaluate(self, gen, steps=None):
@@ -682,16 +697,17 @@ def get_deeplabv3p_model(model_type, num_classes, model_input_shape, output_stri
     g, x, backbone_len = model_function(input_shape=(H, W, 3), weights=None, num_classes=21, OS=output_stride,
                                         seed=seed)
     print('backbone layers number: {}'.format(backbone_len))
-    base_len = len(g.layers)
+    base_len = len(g.layers)           # every layer but the new head (= len(base_model.layers), model.py:108)
 
     # new head (model.py:75-86): conv_upsample 1x1 (+bias) -> pred_resize -> [Reshape] -> Softmax('pred_mask').
     # The class dimension is padded to a multiple of 4 on the device (pad weights/bias stay exactly 0).
     cpad = (num_classes + 3) // 4 * 4
     x = g.conv2d(x, num_classes, 1, 'conv_upsample', use_bias=True, pad_to=cpad)
-    g.add_layer('pred_resize', 'Lambda', (H, W, num_classes))
+    out = g.passthrough(x, 'Lambda', (H, W, num_classes), name='pred_resize')
     if training:
-        g.add_layer(None, 'Reshape', (H * W, num_classes))
-    g.add_layer('pred_mask', 'Softmax', (H * W, num_classes) if training else (H, W, num_classes))
+        out = g.passthrough(out, 'Reshape', (H * W, num_classes))
+    out = g.passthrough(out, 'Softmax', (H * W, num_classes) if training else (H, W, num_classes), name='pred_mask')
+    g.output_layer = out.klayer
     if x.tensor.C != cpad or not x.is_plain:
         raise AssertionError('head tensor layout')
 

@@ -20,7 +20,7 @@ def identity_block(g, input_tensor, kernel_size, filters, stage, block, rate=1):
     x = _conv_bn(g, x, f2, kernel_size, cn + '2b', bn + '2b', rate=rate)
     x = g.relu(x)
     x = _conv_bn(g, x, f3, 1, cn + '2c', bn + '2c')
-    x = g.add(input_tensor, x)
+    x = g.add(input_tensor, x, keras_inputs=[x, input_tensor])      # add([x, input_tensor]) (:75)
     return g.relu(x)
 
 
@@ -33,7 +33,7 @@ def conv_block(g, input_tensor, kernel_size, filters, stage, block, strides=2, r
     x = g.relu(x)
     x = _conv_bn(g, x, f3, 1, cn + '2c', bn + '2c')
     shortcut = _conv_bn(g, input_tensor, f3, 1, cn + '1', bn + '1', stride=strides, padding='valid')
-    x = g.add(shortcut, x)
+    x = g.add(shortcut, x, keras_inputs=[x, shortcut])               # add([x, shortcut]) (:140)
     return g.relu(x)
 
 

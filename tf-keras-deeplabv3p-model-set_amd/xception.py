@@ -37,7 +37,7 @@ def _xception_block(g, inputs, depth_list, prefix, skip_connection_type, stride,
         shortcut = g.batchnorm(shortcut, prefix + '_shortcut_BN')
         outputs = g.add(residual, shortcut)
     elif skip_connection_type == 'sum':
-        outputs = g.add(inputs, residual)
+        outputs = g.add(inputs, residual, keras_inputs=[residual, inputs])       # add([residual, inputs]) (:87)
     elif skip_connection_type == 'none':
         outputs = residual
     if return_skip:
