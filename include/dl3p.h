@@ -327,6 +327,74 @@ int dl3p_adam_step(float* w, float* m, float* v, const float* g, size_t n, const
 int dl3p_rmsprop_step(float* w, float* v, const float* g, size_t n, const float* lr_dev, float rho, float epsilon,
                       float grad_scale, const float* l2_elem, const float* lr_scale_elem, void* stream);
 
+/* ---------------------------------------------------------------- mixed precision (bf16 storage, fp32 accumulate)
+ * train.py:37-46 `--mixed_precision` (the reference sets the Keras global policy; BASELINE.json configs[4] asks for bf16
+ * on MobileNetV3-Large 1024x2048).  The *_bf16 entry points are the twins of the calls above for tensors stored as
+ * bfloat16 (`const void*` / `void*` = bf16 device pointers, ld in ELEMENTS); BatchNorm coefficients, statistics partial
+ * rows, biases, loss and every parameter gradient stay fp32.  Rounding points (round to nearest even): a conv output
+ * when it is stored, and act(z*scale+shift) when a consumer's prologue forms it -- each Keras layer output is a bf16
+ * tensor under the mixed policy.  Statistics partial rows are sums of the STORED (rounded) values.  GEMM weights come
+ * from bf16 mirrors of the fp32 master copy: dl3p_f32_to_bf16 (w[K][N], read by the data gradient, and the depthwise
+ * kernels [k*k][C]) and dl3p_transpose_batch_bf16 (wt[N][K], read by the forward).  `*_is_f32` flags let the logits
+ * tensor (conv_upsample output and its gradient) stay fp32, so the softmax / loss head above is used unchanged.
+ * Channel counts and row strides must be multiples of 8 for the GEMMs, of 4 elsewhere. */
+int dl3p_f32_to_bf16(const float* src, void* dst, size_t n, void* stream);
+int dl3p_u8_to_bf16(const unsigned char* src, void* dst, size_t n, float divide_by, float subtract, void* stream);
+int dl3p_transpose_batch_bf16(const float* src, void* dst, const int* table, int n_matrices, void* stream);
+int dl3p_pwconv_fwd_bf16(const void* x, int ldx, int x_is_f32, const float* in_scale, const float* in_shift, int in_act,
+                         const void* wt, const float* bias, void* y, int ldy, int y_is_f32,
+                         float* stat_partials, int* rows_out, int M, int K, int N, void* stream);
+int dl3p_pwconv_bwd_data_bf16(const void* dy, int lddy, int dy_is_f32, const void* w, void* gx, int ldgx, int accumulate,
+                              int M, int K, int N, void* stream);
+size_t dl3p_pwconv_bwd_weight_workspace_bf16(int M, int K, int N);
+int dl3p_pwconv_bwd_weight_bf16(const void* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                                const void* dy, int lddy, int dy_is_f32, float* gw, float* gb,
+                                float* workspace, size_t workspace_bytes, int M, int K, int N, void* stream);
+int dl3p_dwconv2d_fwd_bf16(const void* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                           const void* w, void* y, int ldy, float* stat_partials, int* rows_out,
+                           int N, int H, int W, int C, int k, int stride, int rate, int pad_t, int pad_l,
+                           int Ho, int Wo, void* stream);
+int dl3p_dwconv2d_bwd_data_bf16(const void* dy, int lddy, const void* w, void* gx, int ldgx, int accumulate,
+                                int N, int H, int W, int C, int k, int stride, int rate, int pad_t, int pad_l,
+                                int Ho, int Wo, void* stream);
+size_t dl3p_dwconv2d_bwd_weight_workspace_bf16(int N, int Ho, int Wo, int C, int k);
+int dl3p_dwconv2d_bwd_weight_bf16(const void* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                                  const void* dy, int lddy, float* gw, float* workspace, size_t workspace_bytes,
+                                  int N, int H, int W, int C, int k, int stride, int rate, int pad_t, int pad_l,
+                                  int Ho, int Wo, void* stream);
+int dl3p_im2col_bf16(const void* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                     void* col, int ld_col, int N, int H, int W, int Cin, int k, int stride, int rate,
+                     int pad_t, int pad_l, int Ho, int Wo, void* stream);
+int dl3p_bn_bwd_reduce_bf16(const void* g, int ldg, const void* z, int ldz, const float* scale, const float* shift,
+                            int act, const float* save_mean, const float* save_invstd,
+                            float* partials, int* rows_out, int M, int C, void* stream);
+int dl3p_bn_bwd_apply_bf16(const void* g, int ldg, const void* z, int ldz, const float* scale, const float* shift,
+                           int act, const float* save_mean, const float* save_invstd, const float* coef,
+                           void* dz, int lddz, int accumulate, int M, int C, void* stream);
+int dl3p_affine_act_bf16(const void* x, int ldx, const float* scale, const float* shift, int act,
+                         const void* r, int ldr, const float* rscale, const float* rshift, int ract,
+                         float dropout_rate, uint64_t seed, const int64_t* step_counter,
+                         void* y, int ldy, int M, int C, void* stream);
+int dl3p_scale_mask_bwd_bf16(const void* gy, int ldgy, float dropout_rate, uint64_t seed, const int64_t* step_counter,
+                             void* gx, int ldgx, int accumulate, int M, int C, void* stream);
+/* per-image reductions: two launches (partial rows per pixel chunk in the fp32 workspace, then the chunk sum) */
+size_t dl3p_pool_workspace_bf16(int N, int HW, int C);
+int dl3p_global_avgpool_fwd_bf16(const void* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                                 void* y, int ldy, float out_scale, int N, int HW, int C, float* workspace,
+                                 size_t workspace_bytes, void* stream);
+int dl3p_global_avgpool_bwd_bf16(const void* gy, int ldgy, void* gx, int ldgx, int accumulate,
+                                 int N, int HW, int C, void* stream);
+int dl3p_scale_bcast_fwd_bf16(const void* x, int ldx, const float* scale, const float* shift, int act,
+                              const void* s, int lds, int s_act, void* y, int ldy, int N, int HW, int C, void* stream);
+int dl3p_scale_bcast_bwd_bf16(const void* gy, int ldgy, const void* x, int ldx, const float* scale, const float* shift,
+                              int act, const void* s, int lds, int s_act, void* gx, int ldgx, int accumulate_gx,
+                              void* gs, int ldgs, int N, int HW, int C, float* workspace, size_t workspace_bytes,
+                              void* stream);
+int dl3p_resize_bilinear_fwd_bf16(const void* x, int ldx, void* y, int ldy,
+                                  int N, int h, int w, int C, int H, int W, void* stream);
+int dl3p_resize_bilinear_bwd_bf16(const void* gy, int ldgy, void* gx, int ldgx, int accumulate,
+                                  int N, int h, int w, int C, int H, int W, void* stream);
+
 /* ---------------------------------------------------------------- measurement hook
  * dl3p_probe_arm(i): the NEXT depthwise-forward or pointwise-GEMM kernel launch of the calling thread is issued with a pair of HIP
  * events (hipExtLaunchKernelGGL start/stop events on the launch stream) stored in slot i (0 <= i < 4096);

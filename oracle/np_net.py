@@ -17,7 +17,7 @@ from . import np_ops as O
 
 
 class Var:
-    __slots__ = ('v', 'g', 'tag')
+    __slots__ = ('v', 'g', 'tag', 'raw')
 
     def __init__(self, v):
         self.v = v
@@ -57,6 +57,12 @@ class Net:
         self._seq_pos = 0
         self.flip_count = 0
         self.flip_total = 0
+        # mixed precision (train.py:37-46, bf16 on MI355X): with bf16 = True every layer OUTPUT that the HIP path stores or
+        # forms in a consumer's prologue is rounded to bfloat16 -- conv / depthwise outputs, act(BN(z)) (the BatchNorm output
+        # itself only where no activation follows), Add / Multiply / pooling / resize results, the conv kernels as the
+        # matrix cores read them; statistics, biases, the logits (`keep_f32`) and the whole backward stay in this net's
+        # dtype.  Forward values then follow the device's rounding points; gradients are compared with a tolerance.
+        self.bf16 = False
         # optional SyncBatchNorm: (all_reduce_sum(ndarray) -> ndarray, world_size).  Statistics are
         # summed over ranks in forward (sum x, sum x^2, count) and backward (sum dy, sum dy*xhat); the
         # parameter gradients stay local and are averaged with all other gradients (README.md:38,
@@ -74,6 +80,9 @@ class Net:
 
     def layer_is_trainable(self, layer):
         return self.layer_trainable.get(layer, True)
+
+    def q(self, a):
+        return O.bf16_round(a) if self.bf16 else a
 
     def n_params(self, trainable=True):
         return sum(int(np.prod(self.params[n].shape)) for n in self.order if self.trainable[n] == trainable)
@@ -98,20 +107,22 @@ class Net:
         self.grads[name] = g if name not in self.grads else self.grads[name] + g
 
     # ---- layers -----------------------------------------------------------------------
-    def conv2d(self, x, filters, k, name, stride=1, rate=1, padding='same', use_bias=False, he_normal=False):
+    def conv2d(self, x, filters, k, name, stride=1, rate=1, padding='same', use_bias=False, he_normal=False, keep_f32=False):
         """DeeplabConv2D (layers.py:14-21): glorot_uniform kernel (he_normal in ResNet50), zero bias, l2(2e-5) on both."""
         cin = x.v.shape[-1]
         init = ((lambda s: O.he_normal(self.rng, s, k * k * cin)) if he_normal else
                 (lambda s: O.glorot_uniform(self.rng, s, k * k * cin, k * k * filters)))
         w = self.param(name + '/kernel', (k, k, cin, filters), init, l2=O.L2_FACTOR)
         b = self.param(name + '/bias', (filters,), np.zeros, l2=O.L2_FACTOR) if use_bias else None
-        y = Var(O.conv2d_fwd(x.v, w, stride, rate, padding, b))
+        wq = self.q(w)
+        yv = O.conv2d_fwd(x.v, wq, stride, rate, padding, b)
+        y = Var(yv if keep_f32 else self.q(yv))
         need_gx = True
 
         def bwd():
             if y.g is None:
                 return
-            gx, gw, gb = O.conv2d_bwd(x.v, w, y.g, stride, rate, padding, need_gx)
+            gx, gw, gb = O.conv2d_bwd(x.v, wq, y.g, stride, rate, padding, need_gx)
             self.acc_grad(name + '/kernel', gw)
             if use_bias:
                 self.acc_grad(name + '/bias', gb)
@@ -125,8 +136,8 @@ class Net:
         c = x.v.shape[-1]
         w4 = self.param(name + '/depthwise_kernel', (k, k, c, 1),
                         lambda s: O.glorot_uniform(self.rng, s, k * k * c, k * k * 1), l2=0.0)
-        w = w4[..., 0]
-        y = Var(O.dwconv2d_fwd(x.v, w, stride, rate, padding))
+        w = self.q(w4[..., 0])
+        y = Var(self.q(O.dwconv2d_fwd(x.v, w, stride, rate, padding)))
 
         def bwd():
             if y.g is None:
@@ -151,7 +162,9 @@ class Net:
             yv, cache, (bm, bv) = O.bn_train_fwd(x.v, gamma, beta, eps)
             self.moving_updates[name + '/moving_mean'] = O.bn_moving_update(mm, bm, momentum)
             self.moving_updates[name + '/moving_variance'] = O.bn_moving_update(mv, bv, momentum)
-            y = Var(yv)
+            y = Var(self.q(yv))
+            if self.bf16:
+                y.raw = yv          # an activation that follows rounds act(BN(z)) once, like the kernels' prologue
             y.tag = name
 
             def bwd():
@@ -162,7 +175,10 @@ class Net:
                 self.acc_grad(name + '/beta', gb)
                 x.acc(gx)
         else:
-            y = Var(O.bn_infer_fwd(x.v, gamma, beta, mm, mv, eps))
+            yv = O.bn_infer_fwd(x.v, gamma, beta, mm, mv, eps)
+            y = Var(self.q(yv))
+            if self.bf16:
+                y.raw = yv
             y.tag = name
             scale = gamma / np.sqrt(mv + eps)
 
@@ -205,7 +221,7 @@ class Net:
         return y
 
     def act(self, x, kind):
-        y = Var(O.act_fwd(x.v, kind))
+        y = Var(self.q(O.act_fwd(getattr(x, 'raw', x.v) if self.bf16 else x.v, kind)))
         y.tag = ('act',)
         deriv = None
         if isinstance(x.tag, str):
@@ -236,7 +252,7 @@ class Net:
         return self.act(x, O.ACT_RELU6)
 
     def add(self, a, b):
-        y = Var(a.v + b.v)
+        y = Var(self.q(a.v + b.v))
 
         def bwd():
             if y.g is not None:
@@ -247,7 +263,7 @@ class Net:
 
     def mul_bcast(self, x, s):
         """x (N,H,W,C) * s (N,1,1,C)   (SE block Multiply, deeplabv3p_mobilenetv3.py:145)"""
-        y = Var(x.v * s.v)
+        y = Var(self.q(x.v * s.v))
 
         def bwd():
             if y.g is not None:
@@ -284,7 +300,7 @@ class Net:
 
     def global_avgpool(self, x):
         H, W = x.v.shape[1:3]
-        y = Var(O.global_avgpool_fwd(x.v))
+        y = Var(self.q(O.global_avgpool_fwd(x.v)))
 
         def bwd():
             if y.g is not None:
@@ -292,10 +308,11 @@ class Net:
         self.tape.append(bwd)
         return y
 
-    def resize(self, x, out_h, out_w):
+    def resize(self, x, out_h, out_w, keep_f32=False):
         """img_resize (layers.py:48-60) bilinear"""
         H, W = x.v.shape[1:3]
-        y = Var(O.resize_bilinear_fwd(x.v, out_h, out_w))
+        yv = O.resize_bilinear_fwd(x.v, out_h, out_w)
+        y = Var(yv if keep_f32 else self.q(yv))
 
         def bwd():
             if y.g is not None:
@@ -675,7 +692,7 @@ class OracleModel:
     def _forward_graph(self, x, H, W, training):
         net = self.net
         net.begin(training)
-        xin = Var(x)
+        xin = Var(net.q(x))
         n_before = len(net.order)
         if self.model_type in ('mobilenetv2', 'mobilenetv2_lite'):
             f, skip = net.mobilenetv2_body(xin, self.OS)
@@ -698,9 +715,9 @@ class OracleModel:
             net.tap('aspp_out', y)
             y = net.decoder_block(y, skip)
         net.tap('head_in', y)
-        y = net.conv2d(y, self.num_classes, 1, 'conv_upsample', use_bias=True)
+        y = net.conv2d(y, self.num_classes, 1, 'conv_upsample', use_bias=True, keep_f32=True)   # fp32 logits on the bf16 path
         net.tap('conv_upsample', y)
-        logits = net.resize(y, H, W)            # 'pred_resize' (model.py:76)
+        logits = net.resize(y, H, W, keep_f32=True)            # 'pred_resize' (model.py:76)
         net.tap('pred_resize', logits)
         return logits
 

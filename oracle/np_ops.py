@@ -29,6 +29,15 @@ import numpy as np
 # padding
 # --------------------------------------------------------------------------------------
 
+def bf16_round(x):
+    """round to the nearest bfloat16 (ties to even), returned in x's dtype: the storage rounding of the mixed-precision
+    path (a bf16 tensor holds the top 16 bits of the float32 pattern)"""
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    u = a.view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).view(np.float32)
+    return r.astype(np.asarray(x).dtype if np.asarray(x).dtype.kind == 'f' else np.float32)
+
+
 def same_pad_1d(in_size, k, stride, rate):
     """TF 'SAME' padding for one spatial dim -> (out_size, pad_begin, pad_end).
 

@@ -1,0 +1,247 @@
+"""Mixed-precision path (BASELINE.json configs[4]: MobileNetV3-Large, bf16; reference switch train.py:37-46).
+
+Oracle leg: the fp64 oracle with `net.bf16 = True` rounds to bfloat16 at the storage points of the HIP path (oracle/np_net.py
+Net.bf16, csrc/bf16.h).  Tolerances (DESIGN.md "bf16"): an op reproduces the rounded fp64 result to ONE bf16 ulp per
+stored element (2^-8 relative: fp32 vs fp64 accumulation can land on the other side of a rounding boundary) -- checked as
+|got - want| <= 2^-7 |want| + eps; fp32 outputs (weight gradients, statistics) to 2e-3 of the tensor's scale; through a
+whole model the logits to 3e-2 of their range and every parameter gradient to a cosine similarity > 0.99 with the oracle
+whose BACKWARD runs unrounded."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_pkg
+from oracle import np_ops as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+Q = O.bf16_round
+
+
+def TB(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV).to(torch.bfloat16)
+
+
+def TF(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+
+
+def np64(t):
+    return t.detach().float().cpu().numpy().astype(np.float64)
+
+
+def close_bf16(got, want, what, slack=1.0):
+    got, want = np64(got), np.asarray(want, np.float64)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    # one bf16 ulp of the element + the echo of one-ulp flips among the operands (a sum of K terms moves by ~1e-3 of its scale)
+    tol = slack * (2.0 ** -7) * np.abs(want) + slack * 1e-3 * float(np.abs(want).max()) + 1e-30
+    bad = np.abs(got - want) > tol
+    assert not bad.any(), '%s: %d of %d outside one bf16 ulp, worst %g' % (what, bad.sum(), bad.size, np.abs(got - want).max())
+
+
+def close_f32(got, want, what, rtol=2e-3):
+    got, want = np64(got), np.asarray(want, np.float64)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert np.abs(got - want).max() <= rtol * max(1e-6, float(np.abs(want).max())), (what, np.abs(got - want).max(), np.abs(want).max())
+
+
+PW = [(2 * 33 * 33, 320, 256), (1000, 24, 72), (777, 72, 24), (4101, 16, 64), (513, 304, 256), (300, 960, 160), (131, 184, 80),
+      (64 * 128 + 5, 160, 960), (3, 240, 64), (1, 960, 240), (257, 1280, 256), (5000, 256, 24)]
+
+
+@pytest.mark.parametrize('case', PW)
+def test_pointwise_bf16(ops, case):
+    M, K, Nn = case
+    rng = np.random.default_rng(M + 7 * K + Nn)
+    x = Q(rng.standard_normal((M, K)))
+    w = rng.standard_normal((K, Nn)) / np.sqrt(K)
+    sc = rng.uniform(0.5, 1.5, K).astype(np.float32)
+    sh = (rng.standard_normal(K) * 0.3).astype(np.float32)
+    b = (rng.standard_normal(Nn) * 0.2).astype(np.float32)
+    wq = Q(w)
+    a = Q(O.act_fwd(np.float32(np.float64(x) * sc + sh), O.ACT_HSWISH).astype(np.float64))      # fmaf, then fp32 activation
+    y_ref = a @ wq
+    part = ops.new_partials(Nn, DEV)
+    y, rows = ops.pwconv_fwd_bf16(TB(x), TF(w), None, TF(sc), TF(sh), ops.ACT_HSWISH, partials=part)
+    close_bf16(y, Q(y_ref), 'forward')
+    yq = np64(y)
+    p = part[:rows * 2 * Nn].reshape(rows, 2, Nn).double().sum(0).cpu().numpy()
+    close_f32(p[0], yq.sum(0), 'stat sum (of the stored values)', 1e-4 + 1e-5 * np.sqrt(M))
+    close_f32(p[1], (yq ** 2).sum(0), 'stat sum of squares', 1e-4)
+    # bias, no prologue, fp32 output (the logits layer)
+    y32 = ops.pwconv_fwd_bf16(TB(x), TF(w), TF(b), out_f32=True)
+    close_f32(y32, x @ wq + b, 'forward fp32 out', 1e-5)
+    gy = Q(rng.standard_normal((M, Nn)))
+    gx = ops.pwconv_bwd_data_bf16(TB(gy), TF(w))
+    close_bf16(gx, Q(gy @ wq.T), 'data gradient')
+    base = Q(rng.standard_normal((M, K)))
+    gx2 = ops.pwconv_bwd_data_bf16(TB(gy), TF(w), out=TB(base), accumulate=True)
+    close_bf16(gx2, Q(Q(gy @ wq.T).astype(np.float64) * 0 + gy @ wq.T + base), 'data gradient accumulate', slack=2.0)
+    gx3 = ops.pwconv_bwd_data_bf16(TF(gy), TF(w))            # fp32 gradient in (the logits layer): rounded on the way in
+    close_bf16(gx3, Q(gy @ wq.T), 'data gradient from fp32')
+    gw, gb = ops.pwconv_bwd_weight_bf16(TB(x), TB(gy), TF(sc), TF(sh), ops.ACT_HSWISH, with_bias=True)
+    close_f32(gw, a.T @ gy, 'weight gradient', 2e-5 * np.sqrt(M) + 1e-5)
+    close_f32(gb, gy.sum(0), 'bias gradient', 1e-4)
+
+
+DW = [(2, 33, 33, 160, 3, 1, 18), (2, 33, 33, 160, 3, 1, 6), (1, 65, 47, 72, 3, 2, 1), (2, 16, 20, 24, 3, 2, 1), (1, 16, 24, 40, 5, 1, 2),
+      (1, 16, 24, 72, 5, 2, 1), (2, 33, 33, 960, 5, 1, 2), (1, 7, 6, 24, 5, 1, 1), (1, 64, 96, 16, 3, 1, 1), (3, 9, 9, 12, 3, 1, 1)]
+
+
+@pytest.mark.parametrize('case', DW)
+def test_depthwise_bf16(ops, case):
+    N, H, W, C, k, s, r = case
+    rng = np.random.default_rng(H * 5 + C + k + r)
+    x = Q(rng.standard_normal((N, H, W, C)))
+    w = rng.standard_normal((k, k, C)) * 0.3
+    sc = rng.uniform(0.5, 1.5, C).astype(np.float32)
+    sh = (rng.standard_normal(C) * 0.3).astype(np.float32)
+    wq = Q(w)
+    a = Q(O.act_fwd(np.float32(np.float64(x) * sc + sh), O.ACT_RELU6).astype(np.float64))
+    y_ref = O.dwconv2d_fwd(a, wq, s, r, 'same')
+    part = ops.new_partials(C, DEV)
+    y, rows = ops.dwconv2d_fwd_bf16(TB(x), TF(w), s, r, 'same', TF(sc), TF(sh), ops.ACT_RELU6, partials=part)
+    close_bf16(y, Q(y_ref), 'forward')
+    yq = np64(y).reshape(-1, C)
+    p = part[:rows * 2 * C].reshape(rows, 2, C).double().sum(0).cpu().numpy()
+    close_f32(p[0], yq.sum(0), 'stat sum', 1e-4 + 1e-5 * np.sqrt(yq.shape[0]))
+    close_f32(p[1], (yq ** 2).sum(0), 'stat sum of squares', 1e-4)
+    gy = Q(rng.standard_normal(y_ref.shape))
+    gx_ref, gw_ref = O.dwconv2d_bwd(a, wq, gy, s, r, 'same')
+    gx = ops.dwconv2d_bwd_data_bf16(TB(gy), TF(w), (N, H, W, C), s, r, 'same')
+    close_bf16(gx, Q(gx_ref), 'data gradient')
+    gw = ops.dwconv2d_bwd_weight_bf16(TB(x), TB(gy), k, s, r, 'same', TF(sc), TF(sh), ops.ACT_RELU6)
+    close_f32(gw, gw_ref, 'weight gradient', 1e-4)
+
+
+def test_elementwise_bf16(ops):
+    rng = np.random.default_rng(4)
+    N, H, W, C = 2, 17, 19, 72
+    z = Q(rng.standard_normal((N, H, W, C)) * 2 + 0.3)
+    g = Q(rng.standard_normal((N, H, W, C)))
+    gamma, beta = rng.uniform(0.5, 1.5, C), rng.standard_normal(C) * 0.2
+    y_ref, cache, _ = O.bn_train_fwd(z, gamma, beta, 1e-3)
+    bn = ops.BNState(C, DEV, 1e-3)
+    bn.gamma.copy_(TF(gamma)); bn.beta.copy_(TF(beta))
+    mean, var = z.reshape(-1, C).mean(0), z.reshape(-1, C).var(0)
+    invstd = 1 / np.sqrt(var + 1e-3)
+    bn.mean.copy_(TF(mean)); bn.invstd.copy_(TF(invstd))
+    bn.scale.copy_(TF(gamma * invstd)); bn.shift.copy_(TF(beta - mean * gamma * invstd))
+    dz_ref, gg, gb = O.bn_train_bwd(O.act_bwd(y_ref, g, O.ACT_RELU6), cache)
+    gt = TB(g)
+    ops.bn_backward_bf16(bn, gt, TB(z), ops.ACT_RELU6, ops.new_partials(C, DEV))
+    close_bf16(gt, Q(dz_ref), 'bn backward dz', slack=2.0)
+    close_f32(bn.dgamma, gg, 'dgamma', 1e-4)
+    close_f32(bn.dbeta, gb, 'dbeta', 1e-4)
+    # materialise + residual
+    r = Q(rng.standard_normal((N, H, W, C)))
+    a = Q(O.act_fwd(np.float32(np.float64(z) * np.float32(gamma * invstd) + np.float32(beta - mean * gamma * invstd)), O.ACT_HSWISH).astype(np.float64))
+    y = ops.affine_act_bf16(TB(z), bn.scale, bn.shift, ops.ACT_HSWISH, residual=TB(r))
+    close_bf16(y, Q(a + r), 'affine_act + residual')
+    # pooling / SE multiply
+    pooled = ops.global_avgpool_fwd_bf16(TB(z), bn.scale, bn.shift, ops.ACT_HSWISH)
+    close_bf16(pooled, Q(a.mean(axis=(1, 2), keepdims=True)), 'global pooling')
+    s = Q(rng.standard_normal((N, 1, 1, C)))
+    sv = Q(O.act_fwd(s, O.ACT_HSIGMOID))
+    ym = ops.scale_bcast_fwd_bf16(TB(z), TB(s), bn.scale, bn.shift, ops.ACT_HSWISH, ops.ACT_HSIGMOID)
+    close_bf16(ym, Q(a * sv), 'SE multiply')
+    gx, gs = ops.scale_bcast_bwd_bf16(TB(g), TB(z), TB(s), bn.scale, bn.shift, ops.ACT_HSWISH, ops.ACT_HSIGMOID)
+    close_bf16(gx, Q(g * sv), 'SE multiply: gradient w.r.t. the tensor')
+    close_bf16(gs, Q((g * a).sum(axis=(1, 2), keepdims=True)), 'SE multiply: gradient w.r.t. the scale', slack=2.0)
+    # resize 17x19 -> 65x73 and back
+    yr = ops.resize_bilinear_fwd_bf16(TB(z), 65, 73)
+    close_bf16(yr, Q(O.resize_bilinear_fwd(z, 65, 73)), 'resize')
+    gbig = Q(rng.standard_normal((N, 65, 73, C)))
+    close_bf16(ops.resize_bilinear_bwd_bf16(TB(gbig), H, W), Q(O.resize_bilinear_bwd(gbig, H, W)), 'resize backward', slack=2.0)
+
+
+def _cos(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(a @ b / max(1e-30, np.linalg.norm(a) * np.linalg.norm(b)))
+
+
+@pytest.mark.parametrize('model_type,H,W', [('mobilenetv3large', 64, 96), ('mobilenetv3large', 128, 256), ('mobilenetv3large_lite', 65, 65),
+                                            ('mobilenetv2', 65, 65)])
+def test_train_step_bf16_matches_rounding_oracle(model_type, H, W):
+    from oracle.np_net import OracleModel
+    pkg = load_pkg()
+    mp = pkg.mixed_precision
+    N, C = 2, 19
+    mp.set_policy(mp.Policy('mixed_bfloat16'))
+    try:
+        m = pkg.get_deeplabv3p_model(model_type, C, (H, W), 16, training=True)
+    finally:
+        mp.set_policy(mp.Policy('float32'))
+    assert m.bf16
+    m.compile(optimizer=pkg.SGD(0.01), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
+    o = OracleModel(model_type, C, (H, W), 16, dtype=np.float64, seed=0)
+    o.net.bf16 = True
+    rng = np.random.default_rng(42)
+    for k, v in o.net.params.items():
+        if k.endswith('/gamma'):
+            v[...] = rng.uniform(0.5, 1.5, v.shape)
+        elif k.endswith('/beta') or k.endswith('/bias'):
+            v[...] = rng.standard_normal(v.shape) * 0.1
+    m.set_weights_by_name(dict(o.net.params))
+    m.use_graphs = False
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1, 1, (N, H, W, 3)).astype(np.float32)
+    y = rng.integers(0, C, (N, H * W, 1)).astype(np.float32)
+    y[rng.uniform(size=y.shape) < 0.05] = 255
+    loss = m.train_on_batch(x, y)
+    ex = m._executor(N, True)
+    assert ex.bf16 and ex.buf[m.graph.input.tensor.id].dtype == torch.bfloat16
+    drop = [op for op in m.graph.ops if op.kind == 'materialize' and op.rate > 0][0]
+    mask = ex.dropout_mask(drop).cpu().numpy()
+    total, ce, logits_ref = o.loss_and_grads(x, y, {'aspp_dropout': mask})
+    ops = load_pkg('ops')
+    out = ops.upsample_softmax_ce(ex.view(m.head.tensor), C, H, W, want_logits=True)
+    lg = out['logits'][..., :C].cpu().numpy()
+    rng_l = float(np.abs(logits_ref).max())
+    assert np.abs(lg - logits_ref).max() < 3e-2 * max(1.0, rng_l), (np.abs(lg - logits_ref).max(), rng_l)
+    assert abs(loss - ce) < 1e-2 * max(1.0, abs(ce)), (loss, ce)
+    st = m._store
+    worst = ('', 1.0)
+    for p in m.graph.all_params():
+        if not p.trainable:
+            continue
+        gref = o.net.grads[p.name]
+        if np.abs(gref).max() < 1e-7 or gref.size < 8:
+            continue
+        c = _cos(st.get(p, st.G), gref)
+        if c < worst[1]:
+            worst = (p.name, c)
+    assert worst[1] > 0.99, worst
+    # master weights stay fp32 and move by lr * (g + l2): the update itself is the fp32 optimiser kernel
+    w = m.get_weights_by_name()
+    assert all(v.dtype == np.float32 for v in w.values())
+
+
+def test_bf16_full_size_properties():
+    """BASELINE configs[4] per-GPU shape: MobileNetV3-Large, 1024 x 2048, 19 classes, batch 1, bf16.  Size-independent
+    properties: deterministic replay (eager == hipGraph, bit for bit), loss ~ ln(19) at initialisation, finite weights"""
+    pkg = load_pkg()
+    mp = pkg.mixed_precision
+    N, C, H, W = 1, 19, 1024, 2048
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, (N, H, W, 3)).astype(np.float32)
+    y = rng.integers(0, C, (N, H * W, 1)).astype(np.float32)
+
+    def run(use_graphs):
+        mp.set_policy(mp.Policy('mixed_bfloat16'))
+        try:
+            m = pkg.get_deeplabv3p_model('mobilenetv3large', C, (H, W), 16, training=True)
+        finally:
+            mp.set_policy(mp.Policy('float32'))
+        m.compile(optimizer=pkg.SGD(0.01, momentum=0.9), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
+        m.use_graphs = use_graphs
+        return m, [m.train_on_batch(x, y) for _ in range(3)]
+    ma, la = run(False)
+    wa = ma.get_weights_by_name()
+    del ma
+    torch.cuda.empty_cache()
+    mb, lb = run(True)
+    wb = mb.get_weights_by_name()
+    assert la == lb, (la, lb)
+    assert all(np.array_equal(wa[k], wb[k]) for k in wa)
+    assert abs(la[0] - np.log(C)) < 0.5 and all(np.isfinite(v).all() for v in wa.values())

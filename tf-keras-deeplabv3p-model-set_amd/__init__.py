@@ -9,6 +9,8 @@ from .model import (get_deeplabv3p_model, deeplab_model_map, DeeplabModel, SGD, 
                     SparseCategoricalCrossEntropy, WeightedSparseCategoricalCrossEntropy, SparseSoftmaxFocalLoss,
                     miou_from_confusion, Jaccard, jaccard_from_counts, EvalCallBack)
 
+from . import mixed_precision  # noqa: F401,E402
+
 __all__ = ['get_deeplabv3p_model', 'deeplab_model_map', 'DeeplabModel', 'SGD', 'Adam', 'RMSprop', 'get_optimizer',
            'SparseCategoricalCrossEntropy', 'WeightedSparseCategoricalCrossEntropy', 'SparseSoftmaxFocalLoss',
-           'miou_from_confusion', 'Jaccard', 'jaccard_from_counts', 'EvalCallBack']
+           'miou_from_confusion', 'Jaccard', 'jaccard_from_counts', 'EvalCallBack', 'mixed_precision']

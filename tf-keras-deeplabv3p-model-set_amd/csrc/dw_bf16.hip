@@ -1,0 +1,285 @@
+// Depthwise convolution with bf16 storage (fp32 arithmetic) for the mixed-precision path of BASELINE.json configs[4]
+// (MobileNetV3-Large: 3x3 and 5x5 kernels, stride 1 / 2, atrous rates 2 / 6 / 12 / 18).  Same call sites as
+// dwconv.hip: DepthwiseConv2D at /root/reference deeplabv3p/models/layers.py:100, deeplabv3p_mobilenetv3.py:173.
+//
+// HBM-bound at half the bytes of the fp32 path.  One generic gather formulation per direction: a thread owns V
+// consecutive channels (V = 8: 16-byte lanes) of one pixel and walks the k x k taps; channel lanes are fastest and pixel
+// lanes walk along a row, so the taps of neighbouring pixels are served by L1 / the XCD's L2 (workgroup b takes the
+// b % 8-th contiguous chunk of the pixel range).  The kernel's k*k*V weights sit in registers; 5x5 uses V = 4.
+// The input prologue (lazy BatchNorm + activation) is applied per tap in fp32 and rounded to bf16 (bf16.h).
+#include "bf16.h"
+
+namespace {
+
+struct DwB {
+  const bf16* x; int ldx; const float* scale; const float* shift; int act;
+  const bf16* w;                  // [k*k][C] bf16 mirror of the Keras depthwise kernel
+  const bf16* dy; int lddy;
+  bf16* y; int ldy;
+  float* partials;
+  int N, H, W, C, k, stride, rate, pad_t, pad_l, Ho, Wo;
+  int cs, px, nslab, nbx;
+  long long total;
+  int accumulate;
+};
+
+template <int V, int NV>
+__device__ __forceinline__ void dw_block_reduce(const fvec<V> (&vals)[NV], bool active, int pl, int cl, int cs, int px,
+                                                int cbase, int ldc, float* out_row) {
+  __shared__ float sm[256 * V];
+  for (int v = 0; v < NV; ++v) {
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < V; ++i) sm[(pl * cs + cl) * V + i] = vals[v].v[i];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < cs * V; e += 256) {
+      float a = sm[e];
+      for (int q = 1; q < px; ++q) a += sm[q * cs * V + e];
+      out_row[(size_t)v * ldc + cbase + e] = a;
+    }
+  }
+}
+
+template <int V, int KS>
+__global__ __launch_bounds__(256) void dwb_fwd(DwB p) {
+  const int slab = blockIdx.x / p.nbx, bx = blockIdx.x - slab * p.nbx;
+  const int pl = threadIdx.x / p.cs, cl = threadIdx.x - pl * p.cs;
+  const bool active = pl < p.px;
+  const int cbase = slab * p.cs * V, c = cbase + cl * V;
+  fvec<V> st[2] = {fzero<V>(), fzero<V>()};
+  if (active) {
+    const fvec<V> sc = ldv_f32_or<V>(p.scale, c, 1.f), sh = ldv_f32_or<V>(p.shift, c, 0.f);
+    fvec<V> wv[KS * KS];
+#pragma unroll
+    for (int i = 0; i < KS * KS; ++i) wv[i] = ldv<V>(p.w + (size_t)i * p.C + c);
+    const XcdRange r = xcd_range(p.total, bx, p.nbx, p.px, pl);
+    for (int s = r.begin; s < r.end; s += r.step) {
+      const int ox = s % p.Wo;
+      const int row = s / p.Wo;
+      const int oy = row % p.Ho, n = row / p.Ho;
+      fvec<V> acc = fzero<V>();
+      const bf16* img = p.x + (size_t)n * p.H * p.W * p.ldx + c;
+#pragma unroll
+      for (int ky = 0; ky < KS; ++ky) {
+        const int iy = oy * p.stride - p.pad_t + ky * p.rate;
+        if (iy < 0 || iy >= p.H) continue;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+          const int ix = ox * p.stride - p.pad_l + kx * p.rate;
+          if (ix < 0 || ix >= p.W) continue;
+          const fvec<V> a = prologue_bf16<V>(ldv<V>(img + ((size_t)iy * p.W + ix) * p.ldx), sc, sh, p.act);
+#pragma unroll
+          for (int i = 0; i < V; ++i) acc.v[i] = fmaf(a.v[i], wv[ky * KS + kx].v[i], acc.v[i]);
+        }
+      }
+      stv<V>(p.y + (size_t)s * p.ldy + c, acc);
+      if (p.partials) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          const float q = bf16_round(acc.v[i]);       // statistics of the stored values
+          st[0].v[i] += q;
+          st[1].v[i] = fmaf(q, q, st[1].v[i]);
+        }
+      }
+    }
+  }
+  if (p.partials) dw_block_reduce<V, 2>(st, active, pl, cl, p.cs, p.px, cbase, p.C, p.partials + (size_t)bx * 2 * p.C);
+}
+
+// gx[n,iy,ix,c] (+)= sum over taps of dy[n,oy,ox,c] * w[ky,kx,c] with oy*stride - pad_t + ky*rate == iy (gather form)
+template <int V, int KS>
+__global__ __launch_bounds__(256) void dwb_bwd_data(DwB p) {
+  const int slab = blockIdx.x / p.nbx, bx = blockIdx.x - slab * p.nbx;
+  const int pl = threadIdx.x / p.cs, cl = threadIdx.x - pl * p.cs;
+  if (pl >= p.px) return;
+  const int c = (slab * p.cs + cl) * V;
+  fvec<V> wv[KS * KS];
+#pragma unroll
+  for (int i = 0; i < KS * KS; ++i) wv[i] = ldv<V>(p.w + (size_t)i * p.C + c);
+  const XcdRange r = xcd_range(p.total, bx, p.nbx, p.px, pl);
+  for (int s = r.begin; s < r.end; s += r.step) {
+    const int ix = s % p.W;
+    const int row = s / p.W;
+    const int iy = row % p.H, n = row / p.H;
+    fvec<V> acc = fzero<V>();
+    const bf16* gimg = p.dy + (size_t)n * p.Ho * p.Wo * p.lddy + c;
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky) {
+      const int ty = iy + p.pad_t - ky * p.rate;
+      if (ty < 0 || ty % p.stride) continue;
+      const int oy = ty / p.stride;
+      if (oy >= p.Ho) continue;
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+        const int tx = ix + p.pad_l - kx * p.rate;
+        if (tx < 0 || tx % p.stride) continue;
+        const int ox = tx / p.stride;
+        if (ox >= p.Wo) continue;
+        const fvec<V> g = ldv<V>(gimg + ((size_t)oy * p.Wo + ox) * p.lddy);
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc.v[i] = fmaf(g.v[i], wv[ky * KS + kx].v[i], acc.v[i]);
+      }
+    }
+    bf16* o = p.y + (size_t)s * p.ldy + c;
+    if (p.accumulate) {
+      const fvec<V> old = ldv<V>(o);
+#pragma unroll
+      for (int i = 0; i < V; ++i) acc.v[i] += old.v[i];
+    }
+    stv<V>(o, acc);
+  }
+}
+
+// gw[tap][c] = sum over output pixels of bf16(act(x*scale+shift))[tap] * dy: k*k accumulators of 4 channels per thread,
+// one partial row [k*k][C] per workgroup, summed by the row reducer
+template <int KS>
+__global__ __launch_bounds__(256) void dwb_bwd_weight(DwB p) {
+  const int slab = blockIdx.x / p.nbx, bx = blockIdx.x - slab * p.nbx;
+  const int pl = threadIdx.x / p.cs, cl = threadIdx.x - pl * p.cs;
+  const bool active = pl < p.px;
+  const int cbase = slab * p.cs * 4, c = cbase + cl * 4;
+  fvec<4> acc[KS * KS];
+#pragma unroll
+  for (int i = 0; i < KS * KS; ++i) acc[i] = fzero<4>();
+  if (active) {
+    const fvec<4> sc = ldv_f32_or<4>(p.scale, c, 1.f), sh = ldv_f32_or<4>(p.shift, c, 0.f);
+    const XcdRange r = xcd_range(p.total, bx, p.nbx, p.px, pl);
+    for (int s = r.begin; s < r.end; s += r.step) {
+      const int ox = s % p.Wo;
+      const int row = s / p.Wo;
+      const int oy = row % p.Ho, n = row / p.Ho;
+      const fvec<4> g = ldv<4>(p.dy + (size_t)s * p.lddy + c);
+      const bf16* img = p.x + (size_t)n * p.H * p.W * p.ldx + c;
+#pragma unroll
+      for (int ky = 0; ky < KS; ++ky) {
+        const int iy = oy * p.stride - p.pad_t + ky * p.rate;
+        if (iy < 0 || iy >= p.H) continue;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+          const int ix = ox * p.stride - p.pad_l + kx * p.rate;
+          if (ix < 0 || ix >= p.W) continue;
+          const fvec<4> a = prologue_bf16<4>(ldv<4>(img + ((size_t)iy * p.W + ix) * p.ldx), sc, sh, p.act);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[ky * KS + kx].v[i] = fmaf(a.v[i], g.v[i], acc[ky * KS + kx].v[i]);
+        }
+      }
+    }
+  }
+  dw_block_reduce<4, KS * KS>(acc, active, pl, cl, p.cs, p.px, cbase, p.C, p.partials + (size_t)bx * KS * KS * p.C);
+}
+
+int dw_check(const char* fn, const void* a, int lda, int C, int k, int stride) {
+  DL3P_CHECK_ARG(a != nullptr && ((uintptr_t)a & 7u) == 0, "%s: bad pointer", fn);
+  DL3P_CHECK_ARG(C > 0 && C % 4 == 0 && lda % 4 == 0 && lda >= C, "%s: bad layout (C=%d ld=%d)", fn, C, lda);
+  DL3P_CHECK_ARG((k == 3 || k == 5) && stride >= 1, "%s: kernel size %d unsupported on the bf16 path", fn, k);
+  return DL3P_OK;
+}
+
+void dw_grid(DwB& p, int V, long long total, int per_cu, int max_rows) {
+  const LaneSplit s = lane_split(p.C, V);
+  p.cs = s.cs; p.px = s.px; p.nslab = s.nslab;
+  p.total = total;
+  const long long chunk = ceil_div_ll(total, DL3P_NUM_XCDS);
+  const long long need = ceil_div_ll(chunk, p.px);
+  long long target = (DL3P_NUM_CUS * per_cu / p.nslab) / DL3P_NUM_XCDS;
+  if (target < 1) target = 1;
+  long long nbj = need < target ? need : target;
+  if (nbj < 1) nbj = 1;
+  if (nbj * DL3P_NUM_XCDS > max_rows) nbj = max_rows / DL3P_NUM_XCDS;
+  p.nbx = (int)nbj * DL3P_NUM_XCDS;
+}
+
+inline bool ok8(int C, const void* a, int lda, const void* b, int ldb) {
+  return C % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && aligned16(a) && aligned16(b);
+}
+
+}  // namespace
+
+extern "C" int dl3p_dwconv2d_fwd_bf16(const void* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                                      const void* w, void* y, int ldy, float* stat_partials, int* rows_out, int N, int H,
+                                      int W, int C, int k, int stride, int rate, int pad_t, int pad_l, int Ho, int Wo,
+                                      void* stream) {
+  int rc = dw_check("dl3p_dwconv2d_fwd_bf16", x, ldx, C, k, stride);
+  if (rc) return rc;
+  rc = dw_check("dl3p_dwconv2d_fwd_bf16", y, ldy, C, k, stride);
+  if (rc) return rc;
+  DL3P_CHECK_ARG(w && N > 0 && Ho > 0 && Wo > 0 && (long long)N * Ho * Wo < (1LL << 31), "dl3p_dwconv2d_fwd_bf16: bad arguments");
+  DwB p = {};
+  p.x = (const bf16*)x; p.ldx = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act; p.w = (const bf16*)w;
+  p.y = (bf16*)y; p.ldy = ldy; p.partials = stat_partials;
+  p.N = N; p.H = H; p.W = W; p.C = C; p.k = k; p.stride = stride; p.rate = rate; p.pad_t = pad_t; p.pad_l = pad_l;
+  p.Ho = Ho; p.Wo = Wo;
+  const bool v8 = k == 3 && ok8(C, x, ldx, y, ldy) && aligned16(w);
+  dw_grid(p, v8 ? 8 : 4, (long long)N * Ho * Wo, 8, DL3P_MAX_STAT_ROWS);
+  if (rows_out) *rows_out = p.nbx;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(p.nbx * p.nslab);
+  if (k == 3 && v8) hipLaunchKernelGGL((dwb_fwd<8, 3>), grid, dim3(256), 0, st, p);
+  else if (k == 3) hipLaunchKernelGGL((dwb_fwd<4, 3>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((dwb_fwd<4, 5>), grid, dim3(256), 0, st, p);
+  DL3P_CHECK_LAUNCH("dl3p_dwconv2d_fwd_bf16");
+  return DL3P_OK;
+}
+
+extern "C" int dl3p_dwconv2d_bwd_data_bf16(const void* dy, int lddy, const void* w, void* gx, int ldgx, int accumulate,
+                                           int N, int H, int W, int C, int k, int stride, int rate, int pad_t, int pad_l,
+                                           int Ho, int Wo, void* stream) {
+  int rc = dw_check("dl3p_dwconv2d_bwd_data_bf16", dy, lddy, C, k, stride);
+  if (rc) return rc;
+  rc = dw_check("dl3p_dwconv2d_bwd_data_bf16", gx, ldgx, C, k, stride);
+  if (rc) return rc;
+  DL3P_CHECK_ARG(w && N > 0 && (long long)N * H * W < (1LL << 31), "dl3p_dwconv2d_bwd_data_bf16: bad arguments");
+  DwB p = {};
+  p.dy = (const bf16*)dy; p.lddy = lddy; p.w = (const bf16*)w; p.y = (bf16*)gx; p.ldy = ldgx; p.accumulate = accumulate;
+  p.N = N; p.H = H; p.W = W; p.C = C; p.k = k; p.stride = stride; p.rate = rate; p.pad_t = pad_t; p.pad_l = pad_l;
+  p.Ho = Ho; p.Wo = Wo;
+  const bool v8 = k == 3 && ok8(C, dy, lddy, gx, ldgx) && aligned16(w);
+  dw_grid(p, v8 ? 8 : 4, (long long)N * H * W, 8, 1 << 20);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(p.nbx * p.nslab);
+  if (k == 3 && v8) hipLaunchKernelGGL((dwb_bwd_data<8, 3>), grid, dim3(256), 0, st, p);
+  else if (k == 3) hipLaunchKernelGGL((dwb_bwd_data<4, 3>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((dwb_bwd_data<4, 5>), grid, dim3(256), 0, st, p);
+  DL3P_CHECK_LAUNCH("dl3p_dwconv2d_bwd_data_bf16");
+  return DL3P_OK;
+}
+
+namespace {
+int dww_rows(int N, int Ho, int Wo, int C) {
+  DwB p = {};
+  p.C = C;
+  dw_grid(p, 4, (long long)N * Ho * Wo, 2, 512);
+  return p.nbx;
+}
+}  // namespace
+
+extern "C" size_t dl3p_dwconv2d_bwd_weight_workspace_bf16(int N, int Ho, int Wo, int C, int k) {
+  if (N <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || C % 4) return 0;
+  return (size_t)dww_rows(N, Ho, Wo, C) * k * k * C * sizeof(float);
+}
+
+extern "C" int dl3p_dwconv2d_bwd_weight_bf16(const void* x, int ldx, const float* in_scale, const float* in_shift,
+                                             int in_act, const void* dy, int lddy, float* gw, float* workspace,
+                                             size_t workspace_bytes, int N, int H, int W, int C, int k, int stride,
+                                             int rate, int pad_t, int pad_l, int Ho, int Wo, void* stream) {
+  int rc = dw_check("dl3p_dwconv2d_bwd_weight_bf16", x, ldx, C, k, stride);
+  if (rc) return rc;
+  rc = dw_check("dl3p_dwconv2d_bwd_weight_bf16", dy, lddy, C, k, stride);
+  if (rc) return rc;
+  DL3P_CHECK_ARG(gw && workspace && workspace_bytes >= dl3p_dwconv2d_bwd_weight_workspace_bf16(N, Ho, Wo, C, k) &&
+                 (long long)N * Ho * Wo < (1LL << 31), "dl3p_dwconv2d_bwd_weight_bf16: bad arguments / workspace too small");
+  DwB p = {};
+  p.x = (const bf16*)x; p.ldx = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act;
+  p.dy = (const bf16*)dy; p.lddy = lddy; p.partials = workspace;
+  p.N = N; p.H = H; p.W = W; p.C = C; p.k = k; p.stride = stride; p.rate = rate; p.pad_t = pad_t; p.pad_l = pad_l;
+  p.Ho = Ho; p.Wo = Wo;
+  dw_grid(p, 4, (long long)N * Ho * Wo, 2, 512);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(p.nbx * p.nslab);
+  if (k == 3) hipLaunchKernelGGL((dwb_bwd_weight<3>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((dwb_bwd_weight<5>), grid, dim3(256), 0, st, p);
+  DL3P_CHECK_LAUNCH("dl3p_dwconv2d_bwd_weight_bf16");
+  return dl3p_reduce_rows_impl(workspace, p.nbx, (size_t)k * k * C, gw, 0, st);
+}

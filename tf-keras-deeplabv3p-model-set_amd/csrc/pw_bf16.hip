@@ -1,0 +1,549 @@
+// Pointwise (1x1) convolution on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16) for the mixed-precision path of
+// BASELINE.json configs[4] (MobileNetV3-Large 1024x2048; reference switch train.py:37-46).  Same call sites as
+// pwconv.hip: Conv2D(filters,(1,1)) at /root/reference deeplabv3p/models/layers.py:105,134,141,157,209,
+// deeplabv3p_mobilenetv3.py:131-141,160-196, deeplabv3p/model.py:75.
+//
+//   fwd    Y[M,N]  = bf16(act(X*scale+shift)) @ Wt[N,K]^T (+bias)    (+ per-channel (sum, sum^2) of the STORED values)
+//   dgrad  GX[M,K] (+)= DY[M,N] @ W[K,N]^T                            (the same kernel: B = W, reduce over N)
+//   wgrad  GW[K,N] = bf16(act(X*scale+shift))^T @ DY                  (fp32 out; split over M, slab reduce)
+//
+// bf16 operands, fp32 accumulation.  At 16x the fp32 MFMA rate these layers are HBM-bound (K, N <= 960 against
+// M = 8 192 .. 524 288 rows), so the kernels are laid out to read every activation byte once per column block and
+// in 16-byte lanes: a workgroup owns 128 rows x up to 256 columns, the A tile passes registers -> (BN + activation
+// prologue, rounding) -> LDS once per 32-deep K-step, B comes from the bf16 weight mirror (L2-resident).
+// Operands are swapped in the MFMA (D = Wfrag x Xfrag) so that a lane ends with 4 CONSECUTIVE output channels of one
+// pixel (one 8-byte store per accumulator).  The weight gradient needs both operands transposed (the reduction runs
+// over rows): tiles are staged row-major and read back with ds_read_b64_tr_b16, the hardware transpose read.
+#include "bf16.h"
+#include <string.h>
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LP = 48;      // LDS row pitch in bf16 (96 B): ds_read_b128 of 16 rows x 4 k-groups is conflict-free
+
+struct GemmB {
+  const void* A; int lda;
+  const float* scale; const float* shift; int act;
+  const bf16* B; int ldb;           // [Nout][Kred] row-major
+  const float* bias;
+  void* Y; int ldy;
+  float* partials;
+  int M, K, N;
+  int accumulate;
+  int num_m_tiles;
+};
+
+template <bool F32> struct AType { typedef bf16 type; };
+template <> struct AType<true> { typedef float type; };
+
+// NT: 16-column tiles per workgroup; A_F32 / Y_F32: the logits tensor (conv_upsample output and its gradient) stays
+// fp32 so that the softmax / loss head is the fp32 one
+template <int NT, bool A_F32, bool Y_F32, bool STATS>
+__global__ __launch_bounds__(256, 2) void pwb_gemm(GemmB p) {
+  constexpr int BM = 128, BN = 16 * NT;
+  constexpr int NB = (BN * 4 + 255) / 256;      // 16-B chunks of the B tile per thread
+  typedef typename AType<A_F32>::type TA;
+  typedef typename AType<Y_F32>::type TY;
+  __shared__ __attribute__((aligned(16))) bf16 As[BM * LP];
+  __shared__ __attribute__((aligned(16))) bf16 Bs[BN * LP];
+  __shared__ float red[STATS ? 2 * 4 * BN : 1];
+  const int t = threadIdx.x, l = t & 63, w = t >> 6, r = l & 15, kg = l >> 4;
+  const int n0 = blockIdx.y * BN;
+  const int nk = (p.K + BK - 1) / BK;
+  const int my_tiles = (p.num_m_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int it_total = my_tiles * nk;
+  const TA* Ap = reinterpret_cast<const TA*>(p.A);
+  TY* Yp = reinterpret_cast<TY*>(p.Y);
+  const int ar = t >> 2, ac = (t & 3) * 8;      // A staging role: rows ar, ar + 64; k offset ac
+  const bool has_pro = p.scale != nullptr || p.act != DL3P_ACT_NONE;
+
+  fvec<8> ra[2], sc, sh;
+  bf16x8 rb[NB];
+  bool a_ok[2], b_ok[NB];
+  sc = ldv_f32_or<8>(nullptr, 0, 1.f);
+  sh = fzero<8>();
+
+  auto prefetch = [&](int it) {
+    const int kt = it % nk, mt = blockIdx.x + (it / nk) * gridDim.x;
+    const int m0 = mt * BM, k0 = kt * BK;
+    const int k = k0 + ac;
+    const bool kok = k < p.K;                     // K % 8 == 0: a chunk is inside or outside as a whole
+    const int kc = kok ? k : 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + ar + 64 * i;
+      a_ok[i] = kok && m < p.M;
+      ra[i] = ldv<8>(Ap + (size_t)min(m, p.M - 1) * p.lda + kc);
+    }
+    if (p.scale) {
+      sc = ldv<8>(p.scale + kc);
+      sh = ldv<8>(p.shift + kc);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int idx = t + 256 * i;
+      const int br = idx >> 2, bc = (idx & 3) * 8;
+      const int n = n0 + br, kk = k0 + bc;
+      b_ok[i] = idx < BN * 4 && n < p.N && kk < p.K;
+      rb[i] = *reinterpret_cast<const bf16x8*>(p.B + (size_t)min(n, p.N - 1) * p.ldb + (kk < p.K ? kk : 0));
+    }
+  };
+
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = ra[i].v[e];
+        if (has_pro) x = act_apply(fmaf(x, sc.v[e], sh.v[e]), p.act);
+        v[e] = a_ok[i] ? (bf16)x : (bf16)0.f;
+      }
+      *reinterpret_cast<bf16x8*>(&As[(ar + 64 * i) * LP + ac]) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int idx = t + 256 * i;
+      if (idx < BN * 4) {
+        bf16x8 v = rb[i];
+        if (!b_ok[i]) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+        }
+        *reinterpret_cast<bf16x8*>(&Bs[(idx >> 2) * LP + (idx & 3) * 8]) = v;
+      }
+    }
+  };
+
+  f32x4v acc[2][NT];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+  float st_s[STATS ? NT : 1][4], st_q[STATS ? NT : 1][4];
+  if (STATS) {
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { st_s[ni][j] = 0.f; st_q[ni][j] = 0.f; }
+  }
+
+  if (it_total > 0) prefetch(0);
+  for (int it = 0; it < it_total; ++it) {
+    stage();
+    __syncthreads();
+    if (it + 1 < it_total) prefetch(it + 1);
+    bf16x8 af[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(&As[(w * 32 + mi * 16 + r) * LP + kg * 8]);
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+      const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(&Bs[(ni * 16 + r) * LP + kg * 8]);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr, af[mi], acc[mi][ni], 0, 0, 0);
+    }
+    __syncthreads();
+    if (it % nk == nk - 1) {
+      // epilogue of this M tile: lane (r, kg) holds channels n = n0 + 16 ni + 4 kg + j of pixel m = m0 + 32 w + 16 mi + r
+      const int mt = blockIdx.x + (it / nk) * gridDim.x;
+      const int m0 = mt * BM;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int m = m0 + w * 32 + mi * 16 + r;
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+          const int n = n0 + ni * 16 + kg * 4;
+          f32x4v v = acc[mi][ni];
+          acc[mi][ni] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+          if (m < p.M && n < p.N) {
+            float4 o = make_float4(v[0], v[1], v[2], v[3]);
+            if (p.bias) o = add4(o, ld4(p.bias + n));
+            TY* yp = Yp + (size_t)m * p.ldy + n;
+            if (p.accumulate) o = add4(o, ld4(yp));
+            st4(yp, o);
+            if (STATS) {
+              const float4 q = Y_F32 ? o : bf16_round4(o);      // statistics of the values the consumers will read
+              st_s[ni][0] += q.x; st_s[ni][1] += q.y; st_s[ni][2] += q.z; st_s[ni][3] += q.w;
+              st_q[ni][0] = fmaf(q.x, q.x, st_q[ni][0]); st_q[ni][1] = fmaf(q.y, q.y, st_q[ni][1]);
+              st_q[ni][2] = fmaf(q.z, q.z, st_q[ni][2]); st_q[ni][3] = fmaf(q.w, q.w, st_q[ni][3]);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if (STATS) {
+    // sum over the 16 pixel lanes of a wave, then over the 4 waves; one partial row per workgroup
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float s1 = st_s[ni][j], s2 = st_q[ni][j];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        if (r == 0) {
+          red[(0 * 4 + w) * BN + ni * 16 + kg * 4 + j] = s1;
+          red[(1 * 4 + w) * BN + ni * 16 + kg * 4 + j] = s2;
+        }
+      }
+    __syncthreads();
+    if (p.partials) {
+      for (int i = t; i < 2 * BN; i += 256) {
+        const int which = i / BN, nn = i - which * BN;
+        if (n0 + nn < p.N)
+          p.partials[((size_t)blockIdx.x * 2 + which) * p.N + n0 + nn] =
+              red[(which * 4 + 0) * BN + nn] + red[(which * 4 + 1) * BN + nn] + red[(which * 4 + 2) * BN + nn] + red[(which * 4 + 3) * BN + nn];
+      }
+    }
+  }
+}
+
+// M <= 64 rows (convs behind a global pooling: ASPP image pooling, squeeze-excite): one wave per output column, lanes
+// stride the reduction in 16-byte chunks
+template <bool A_F32, bool Y_F32>
+__global__ __launch_bounds__(64) void pwb_tiny(GemmB p) {
+  typedef typename AType<A_F32>::type TA;
+  typedef typename AType<Y_F32>::type TY;
+  const int n = blockIdx.x, l = threadIdx.x;
+  const TA* Ap = reinterpret_cast<const TA*>(p.A);
+  TY* Yp = reinterpret_cast<TY*>(p.Y);
+  const bool has_pro = p.scale != nullptr || p.act != DL3P_ACT_NONE;
+  float s1 = 0.f, s2 = 0.f;
+  for (int m = 0; m < p.M; ++m) {
+    float acc = 0.f;
+    for (int k = l * 8; k < p.K; k += 512) {
+      fvec<8> a = ldv<8>(Ap + (size_t)m * p.lda + k);
+      const fvec<8> wv = ldv<8>(p.B + (size_t)n * p.ldb + k);
+      if (has_pro) a = prologue_bf16<8>(a, ldv_f32_or<8>(p.scale, k, 1.f), ldv_f32_or<8>(p.shift, k, 0.f), p.act);
+      else if (A_F32) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a.v[e] = bf16_round(a.v[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc = fmaf(a.v[e], wv.v[e], acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (l == 0) {
+      if (p.bias) acc += p.bias[n];
+      TY* yp = Yp + (size_t)m * p.ldy + n;
+      if (p.accumulate) acc += (float)*yp;
+      *yp = (TY)acc;
+      const float q = Y_F32 ? acc : bf16_round(acc);
+      s1 += q; s2 = fmaf(q, q, s2);
+    }
+  }
+  if (p.partials && l == 0) { p.partials[n] = s1; p.partials[p.N + n] = s2; }
+}
+
+// ------------------------------------------------------------------------------ weight gradient
+struct WgradB {
+  const bf16* X; int ldx; const float* scale; const float* shift; int act;
+  const void* DY; int lddy;
+  float* slabs;
+  int M, K, N;
+  int ktiles, ntiles, mrows;      // rows of M per chunk (multiple of 32)
+};
+
+__device__ __forceinline__ bf16x4 tr_read(const bf16* lds_ptr) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)lds_ptr);
+  return *reinterpret_cast<const bf16x4*>(&v);
+}
+
+template <int NW, bool DY_F32>
+__global__ __launch_bounds__(256, 2) void pwb_wgrad(WgradB p) {
+  constexpr int TK = 64, TN = 16 * NW;
+  constexpr int XP = TK + 8, DP = TN + 8;           // pitches (bf16): 8-byte aligned rows for the transposed reads
+  constexpr int ND = (32 * TN / 8 + 255) / 256;     // 16-B chunks of the DY tile per thread
+  typedef typename AType<DY_F32>::type TD;
+  __shared__ __attribute__((aligned(16))) bf16 Xs[32 * XP];
+  __shared__ __attribute__((aligned(16))) bf16 Ds[32 * DP];
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int tile = blockIdx.x, kt = tile / p.ntiles, nt = tile - kt * p.ntiles;
+  const int k0 = kt * TK, n0 = nt * TN;
+  const int mbeg = blockIdx.y * p.mrows, mend = min(p.M, mbeg + p.mrows);
+  const TD* Dp = reinterpret_cast<const TD*>(p.DY);
+  // staging roles: X tile 32 rows x 64 k = 256 chunks, one per thread; the thread's 8 channels are fixed for the kernel
+  const int xm = t >> 3, xk = k0 + (t & 7) * 8;
+  const bool xk_ok = xk < p.K;
+  const fvec<8> sc = ldv_f32_or<8>(xk_ok ? p.scale : nullptr, xk, 1.f), sh = ldv_f32_or<8>(xk_ok ? p.shift : nullptr, xk, 0.f);
+  const bool has_pro = p.scale != nullptr || p.act != DL3P_ACT_NONE;
+  f32x4v acc[NW];
+#pragma unroll
+  for (int ni = 0; ni < NW; ++ni) acc[ni] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+  // transposed-read addresses: lane (g = l >> 4, i = l & 15 = 4q + pp) supplies row 8g + q (+4), columns 4pp..4pp+3
+  const int g = l >> 4, q = (l & 15) >> 2, pp = l & 3;
+  fvec<8> rx;
+  fvec<8> rd[ND];
+  bool x_ok, d_ok[ND];
+  auto prefetch = [&](int m0) {
+    const int m = m0 + xm;
+    x_ok = xk_ok && m < mend;
+    rx = ldv<8>(p.X + (size_t)min(m, p.M - 1) * p.ldx + (xk_ok ? xk : 0));
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int idx = t + 256 * i;
+      const int dm = idx / (TN / 8), dc = (idx - dm * (TN / 8)) * 8;
+      const int mm = m0 + dm, n = n0 + dc;
+      d_ok[i] = idx < 32 * TN / 8 && mm < mend && n < p.N;
+      rd[i] = ldv<8>(Dp + (size_t)min(mm, p.M - 1) * p.lddy + (n < p.N ? n : 0));
+    }
+  };
+  if (mbeg < mend) prefetch(mbeg);
+  for (int m0 = mbeg; m0 < mend; m0 += 32) {
+    {
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = rx.v[e];
+        if (has_pro) x = act_apply(fmaf(x, sc.v[e], sh.v[e]), p.act);
+        v[e] = x_ok ? (bf16)x : (bf16)0.f;
+      }
+      *reinterpret_cast<bf16x8*>(&Xs[xm * XP + (t & 7) * 8]) = v;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const int idx = t + 256 * i;
+        if (idx < 32 * TN / 8) {
+          const int dm = idx / (TN / 8), dc = (idx - dm * (TN / 8)) * 8;
+          bf16x8 dv;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dv[e] = d_ok[i] ? (bf16)rd[i].v[e] : (bf16)0.f;
+          *reinterpret_cast<bf16x8*>(&Ds[dm * DP + dc]) = dv;
+        }
+      }
+    }
+    __syncthreads();
+    if (m0 + 32 < mend) prefetch(m0 + 32);
+    // A operand (16 k rows x 32 m) of this wave, B operands (32 m x 16 n) per column tile; EXEC is full here
+    const bf16x4 a0 = tr_read(&Xs[(8 * g + q) * XP + w * 16 + 4 * pp]);
+    const bf16x4 a1 = tr_read(&Xs[(8 * g + 4 + q) * XP + w * 16 + 4 * pp]);
+    const bf16x8 af = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+    for (int ni = 0; ni < NW; ++ni) {
+      const bf16x4 b0 = tr_read(&Ds[(8 * g + q) * DP + ni * 16 + 4 * pp]);
+      const bf16x4 b1 = tr_read(&Ds[(8 * g + 4 + q) * DP + ni * 16 + 4 * pp]);
+      const bf16x8 bfr = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[ni], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // D[row = 4 (l >> 4) + j -> k][col = l & 15 -> n]
+  float* slab = p.slabs + (size_t)blockIdx.y * p.K * p.N;
+#pragma unroll
+  for (int ni = 0; ni < NW; ++ni) {
+    const int n = n0 + ni * 16 + (l & 15);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + w * 16 + 4 * g + j;
+      if (k < p.K && n < p.N) slab[(size_t)k * p.N + n] = acc[ni][j];
+    }
+  }
+}
+
+// tiny M: gw[k][n] = sum_m a[m][k] dy[m][n], gb[n] = sum_m dy[m][n]; one thread per (k, n)
+template <bool DY_F32>
+__global__ __launch_bounds__(256) void pwb_tiny_wgrad(WgradB p, float* gw, float* gb) {
+  typedef typename AType<DY_F32>::type TD;
+  const TD* Dp = reinterpret_cast<const TD*>(p.DY);
+  const long long total = (long long)p.K * p.N;
+  const bool has_pro = p.scale != nullptr || p.act != DL3P_ACT_NONE;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int k = (int)(i / p.N), n = (int)(i - (long long)k * p.N);
+    float acc = 0.f, bsum = 0.f;
+    for (int m = 0; m < p.M; ++m) {
+      float a = (float)p.X[(size_t)m * p.ldx + k];
+      if (has_pro) a = bf16_round(act_apply(fmaf(a, p.scale ? p.scale[k] : 1.f, p.scale ? p.shift[k] : 0.f), p.act));
+      const float d = bf16_round((float)Dp[(size_t)m * p.lddy + n]);
+      acc = fmaf(a, d, acc);
+      bsum += d;
+    }
+    gw[i] = acc;
+    if (gb && k == 0) gb[n] = bsum;
+  }
+}
+
+// column sums of DY (bias gradient): partial rows, then the row reducer
+template <bool DY_F32>
+__global__ __launch_bounds__(256) void pwb_colsum(const void* dy, int lddy, int M, int N, float* partial) {
+  typedef typename AType<DY_F32>::type TD;
+  const TD* Dp = reinterpret_cast<const TD*>(dy);
+  const int nl = N < 256 ? N : 256;             // column lanes
+  const int rl = 256 / nl;                      // row lanes
+  const int c = threadIdx.x % nl, rr = threadIdx.x / nl;
+  __shared__ float sm[256];
+  for (int c0 = 0; c0 < N; c0 += nl) {
+    float a = 0.f;
+    if (rr < rl && c0 + c < N)
+      for (long long m = (long long)blockIdx.x * rl + rr; m < M; m += (long long)gridDim.x * rl)
+        a += bf16_round((float)Dp[(size_t)m * lddy + c0 + c]);
+    __syncthreads();
+    sm[threadIdx.x] = (rr < rl) ? a : 0.f;
+    __syncthreads();
+    if (rr == 0 && c0 + c < N) {
+      float s = 0.f;
+      for (int q = 0; q < rl; ++q) s += sm[q * nl + c];
+      partial[(size_t)blockIdx.x * N + c0 + c] = s;
+    }
+  }
+}
+
+int check_mat_b(const char* fn, const void* ptr, int ld, int cols, bool f32) {
+  DL3P_CHECK_ARG(ptr != nullptr, "%s: null pointer", fn);
+  DL3P_CHECK_ARG(cols > 0 && cols % 8 == 0, "%s: channel count %d must be a positive multiple of 8 (bf16 path)", fn, cols);
+  DL3P_CHECK_ARG(ld % 8 == 0 && ld >= cols && aligned16(ptr), "%s: bad layout (ld=%d)", fn, ld);
+  (void)f32;
+  return DL3P_OK;
+}
+
+int pick_nt_b(int N, bool stats) {
+  const int cap = stats ? 8 : 16;
+  int nt = 2;
+  while (nt < cap && 16 * nt < N) nt *= 2;
+  return nt;
+}
+
+template <bool A_F32, bool Y_F32, bool STATS>
+void launch_gemm_b(const GemmB& p, int nt, dim3 grid, hipStream_t st) {
+  switch (nt) {
+    case 2: hipLaunchKernelGGL((pwb_gemm<2, A_F32, Y_F32, STATS>), grid, dim3(256), 0, st, p); break;
+    case 4: hipLaunchKernelGGL((pwb_gemm<4, A_F32, Y_F32, STATS>), grid, dim3(256), 0, st, p); break;
+    case 8: hipLaunchKernelGGL((pwb_gemm<8, A_F32, Y_F32, STATS>), grid, dim3(256), 0, st, p); break;
+    default:
+      if constexpr (!STATS) hipLaunchKernelGGL((pwb_gemm<16, A_F32, Y_F32, false>), grid, dim3(256), 0, st, p);
+      break;
+  }
+}
+
+int gemm_b(const char* fn, GemmB p, bool a_f32, bool y_f32, int* rows_out, hipStream_t st) {
+  DL3P_CHECK_ARG(!(a_f32 && y_f32), "%s: fp32 in and out is the fp32 library's job", fn);
+  if (p.M <= 64) {
+    if (rows_out) *rows_out = 1;
+    if (a_f32) hipLaunchKernelGGL((pwb_tiny<true, false>), dim3(p.N), dim3(64), 0, st, p);
+    else if (y_f32) hipLaunchKernelGGL((pwb_tiny<false, true>), dim3(p.N), dim3(64), 0, st, p);
+    else hipLaunchKernelGGL((pwb_tiny<false, false>), dim3(p.N), dim3(64), 0, st, p);
+    DL3P_CHECK_LAUNCH(fn);
+    return DL3P_OK;
+  }
+  const bool stats = p.partials != nullptr;
+  const int nt = pick_nt_b(p.N, stats);
+  const int gy = ceil_div(p.N, 16 * nt);
+  p.num_m_tiles = ceil_div(p.M, 128);
+  int gx_max = (DL3P_NUM_CUS * 4) / gy;
+  if (gx_max < 8) gx_max = 8;
+  if (gx_max > DL3P_MAX_STAT_ROWS) gx_max = DL3P_MAX_STAT_ROWS;
+  int gx = p.num_m_tiles;
+  if (gx > gx_max) gx = ceil_div(p.num_m_tiles, ceil_div(p.num_m_tiles, gx_max));
+  if (rows_out) *rows_out = gx;
+  const dim3 grid(gx, gy);
+  if (a_f32) launch_gemm_b<true, false, false>(p, nt, grid, st);
+  else if (y_f32) launch_gemm_b<false, true, false>(p, nt, grid, st);
+  else if (stats) launch_gemm_b<false, false, true>(p, nt, grid, st);
+  else launch_gemm_b<false, false, false>(p, nt, grid, st);
+  DL3P_CHECK_LAUNCH(fn);
+  return DL3P_OK;
+}
+
+struct WgradPlan { int nw, ktiles, ntiles, mchunks, mrows; };
+WgradPlan wgrad_plan_b(int M, int K, int N) {
+  WgradPlan pl;
+  pl.nw = N > 64 ? 8 : 4;
+  pl.ktiles = ceil_div(K, 64);
+  pl.ntiles = ceil_div(N, 16 * pl.nw);
+  const int tiles = pl.ktiles * pl.ntiles;
+  int mchunks = (4 * DL3P_NUM_CUS) / tiles;
+  const int most = ceil_div(M, 256);
+  if (mchunks > most) mchunks = most;
+  if (mchunks > 512) mchunks = 512;
+  if (mchunks < 1) mchunks = 1;
+  pl.mrows = ceil_div(ceil_div(M, mchunks), 32) * 32;
+  pl.mchunks = ceil_div(M, pl.mrows);
+  return pl;
+}
+
+}  // namespace
+
+extern "C" int dl3p_pwconv_fwd_bf16(const void* x, int ldx, int x_is_f32, const float* in_scale, const float* in_shift,
+                                    int in_act, const void* wt, const float* bias, void* y, int ldy, int y_is_f32,
+                                    float* stat_partials, int* rows_out, int M, int K, int N, void* stream) {
+  int rc = check_mat_b("dl3p_pwconv_fwd_bf16", x, ldx, K, x_is_f32);
+  if (rc) return rc;
+  rc = check_mat_b("dl3p_pwconv_fwd_bf16", y, ldy, N, y_is_f32);
+  if (rc) return rc;
+  DL3P_CHECK_ARG(wt && aligned16(wt) && M > 0, "dl3p_pwconv_fwd_bf16: bad arguments");
+  DL3P_CHECK_ARG(!stat_partials || !(x_is_f32 || y_is_f32), "dl3p_pwconv_fwd_bf16: statistics need bf16 in and out");
+  GemmB p = {};
+  p.A = x; p.lda = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act;
+  p.B = (const bf16*)wt; p.ldb = K; p.bias = bias; p.Y = y; p.ldy = ldy; p.partials = stat_partials;
+  p.M = M; p.K = K; p.N = N;
+  return gemm_b("dl3p_pwconv_fwd_bf16", p, x_is_f32 != 0, y_is_f32 != 0, rows_out, (hipStream_t)stream);
+}
+
+extern "C" int dl3p_pwconv_bwd_data_bf16(const void* dy, int lddy, int dy_is_f32, const void* w, void* gx, int ldgx,
+                                         int accumulate, int M, int K, int N, void* stream) {
+  int rc = check_mat_b("dl3p_pwconv_bwd_data_bf16", dy, lddy, N, dy_is_f32);
+  if (rc) return rc;
+  rc = check_mat_b("dl3p_pwconv_bwd_data_bf16", gx, ldgx, K, false);
+  if (rc) return rc;
+  DL3P_CHECK_ARG(w && aligned16(w) && M > 0, "dl3p_pwconv_bwd_data_bf16: bad arguments");
+  GemmB p = {};
+  p.A = dy; p.lda = lddy; p.act = DL3P_ACT_NONE;
+  p.B = (const bf16*)w; p.ldb = N;          // W[K][N]: output column k, reduction n contiguous
+  p.Y = gx; p.ldy = ldgx; p.accumulate = accumulate;
+  p.M = M; p.K = N; p.N = K;
+  return gemm_b("dl3p_pwconv_bwd_data_bf16", p, dy_is_f32 != 0, false, nullptr, (hipStream_t)stream);
+}
+
+extern "C" size_t dl3p_pwconv_bwd_weight_workspace_bf16(int M, int K, int N) {
+  if (M <= 0 || K <= 0 || N <= 0) return 0;
+  const WgradPlan pl = wgrad_plan_b(M, K, N);
+  return ((size_t)pl.mchunks * K * N + (size_t)DL3P_NUM_CUS * 2 * N) * sizeof(float);
+}
+
+extern "C" int dl3p_pwconv_bwd_weight_bf16(const void* x, int ldx, const float* in_scale, const float* in_shift,
+                                           int in_act, const void* dy, int lddy, int dy_is_f32, float* gw, float* gb,
+                                           float* workspace, size_t workspace_bytes, int M, int K, int N, void* stream) {
+  int rc = check_mat_b("dl3p_pwconv_bwd_weight_bf16", x, ldx, K, false);
+  if (rc) return rc;
+  rc = check_mat_b("dl3p_pwconv_bwd_weight_bf16", dy, lddy, N, dy_is_f32);
+  if (rc) return rc;
+  DL3P_CHECK_ARG(gw && M > 0, "dl3p_pwconv_bwd_weight_bf16: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  WgradB p = {};
+  p.X = (const bf16*)x; p.ldx = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act; p.DY = dy; p.lddy = lddy;
+  p.M = M; p.K = K; p.N = N;
+  if (M <= 64) {
+    long long blocks = ceil_div_ll((long long)K * N, 256);
+    if (blocks > 4096) blocks = 4096;
+    if (dy_is_f32) hipLaunchKernelGGL((pwb_tiny_wgrad<true>), dim3((unsigned)blocks), dim3(256), 0, st, p, gw, gb);
+    else hipLaunchKernelGGL((pwb_tiny_wgrad<false>), dim3((unsigned)blocks), dim3(256), 0, st, p, gw, gb);
+    DL3P_CHECK_LAUNCH("dl3p_pwconv_bwd_weight_bf16");
+    return DL3P_OK;
+  }
+  DL3P_CHECK_ARG(workspace && workspace_bytes >= dl3p_pwconv_bwd_weight_workspace_bf16(M, K, N),
+                 "dl3p_pwconv_bwd_weight_bf16: workspace too small");
+  const WgradPlan pl = wgrad_plan_b(M, K, N);
+  p.slabs = workspace; p.ktiles = pl.ktiles; p.ntiles = pl.ntiles; p.mrows = pl.mrows;
+  const dim3 grid(pl.ktiles * pl.ntiles, pl.mchunks);
+  if (pl.nw == 8) {
+    if (dy_is_f32) hipLaunchKernelGGL((pwb_wgrad<8, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((pwb_wgrad<8, false>), grid, dim3(256), 0, st, p);
+  } else {
+    if (dy_is_f32) hipLaunchKernelGGL((pwb_wgrad<4, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((pwb_wgrad<4, false>), grid, dim3(256), 0, st, p);
+  }
+  DL3P_CHECK_LAUNCH("dl3p_pwconv_bwd_weight_bf16");
+  rc = dl3p_reduce_rows_impl(workspace, pl.mchunks, (size_t)K * N, gw, 0, st);
+  if (rc) return rc;
+  if (gb) {
+    float* part = workspace + (size_t)pl.mchunks * K * N;
+    const int blocks = DL3P_NUM_CUS * 2;
+    if (dy_is_f32) hipLaunchKernelGGL((pwb_colsum<true>), dim3(blocks), dim3(256), 0, st, dy, lddy, M, N, part);
+    else hipLaunchKernelGGL((pwb_colsum<false>), dim3(blocks), dim3(256), 0, st, dy, lddy, M, N, part);
+    DL3P_CHECK_LAUNCH("dl3p_pwconv_bwd_weight_bf16");
+    rc = dl3p_reduce_rows_impl(part, blocks, (size_t)N, gb, 0, st);
+  }
+  return rc;
+}

@@ -363,7 +363,10 @@ extern "C" int dl3p_upsample_softmax_loss(const float* z, int ldz, const float* 
   if (blocks > DL3P_MAX_STAT_ROWS) blocks = DL3P_MAX_STAT_ROWS;
   if (rows_out) *rows_out = (int)blocks;
   hipStream_t st = (hipStream_t)stream;
-  const int cp = ((C + 3) / 4) * 4;
+  int cp = ((C + 3) / 4) * 4;
+  // rows padded further than that (the bf16 graphs pad the class dimension to a multiple of 8: 19 classes -> 24): run the
+  // instantiation that matches the row, so that the gradient still leaves as whole 16-byte vectors
+  if ((logits_big || dlogits_big) && ld_big % 4 == 0 && ld_big > cp && ld_big <= 32 && ldz >= ld_big) cp = ld_big;
   // one instantiation per padded class count (a multiple of 4 up to 32): the kernel reads exactly the cp floats a
   // pixel of the (N,h,w,cp) logits holds, so 2-class models work like 21-class ones
   switch (cp) {

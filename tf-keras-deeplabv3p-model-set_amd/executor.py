@@ -27,9 +27,10 @@ class ParamStore:
     """all weights of a model in three flat float32 device buffers (value, gradient, momentum), laid out
     in Keras weight order with 16-byte aligned offsets.  One SGD launch and one all-reduce cover it."""
 
-    def __init__(self, graph, device):
+    def __init__(self, graph, device, bf16=False):
         self.graph = graph
         self.device = device
+        self.bf16 = bool(bf16)
         self.params = graph.all_params()
         self.offset, off = param_offsets(self.params)
         self.total = off
@@ -49,13 +50,25 @@ class ParamStore:
         rows = [[self.offset[op.w], op.cin if op.kind == 'conv_pw' else op.kp, op.cout, 0]
                 for op in graph.ops if op.kind in ('conv_pw', 'conv_dense')]
         self.tr_table = torch.tensor(rows, dtype=torch.int32, device=device) if rows else None
+        # mixed precision: bf16 mirrors of the fp32 master copy, same offsets.  Pb = the parameters as they are (read by the
+        # data-gradient GEMM as W[K][N] and by the depthwise kernels), Pbt = the [N][K] transposes the forward GEMM reads
+        # (they take the place of Pt); both refreshed after every optimiser step
+        self.Pb = torch.zeros(off, dtype=torch.bfloat16, device=device) if self.bf16 else None
+        self.Pbt = torch.zeros(off, dtype=torch.bfloat16, device=device) if self.bf16 else None
         self.upload()
         self.refresh_masks()
 
     def transpose(self):
+        st = torch.cuda.current_stream().cuda_stream
+        if self.bf16:
+            lib().f32_to_bf16(self.P.data_ptr(), self.Pb.data_ptr(), self.total, st)
+            if self.tr_table is not None:
+                lib().transpose_batch_bf16(self.P.data_ptr(), self.Pbt.data_ptr(), self.tr_table.data_ptr(),
+                                           int(self.tr_table.shape[0]), st)
+            return
         if self.tr_table is not None:
             lib().transpose_batch(self.P.data_ptr(), self.Pt.data_ptr(), self.tr_table.data_ptr(),
-                                  int(self.tr_table.shape[0]), torch.cuda.current_stream().cuda_stream)
+                                  int(self.tr_table.shape[0]), st)
 
     def view(self, p, buf=None):
         buf = self.P if buf is None else buf
@@ -64,7 +77,7 @@ class ParamStore:
 
     def ptr(self, p, buf=None):
         buf = self.P if buf is None else buf
-        return buf.data_ptr() + 4 * self.offset[p]
+        return buf.data_ptr() + buf.element_size() * self.offset[p]
 
     @staticmethod
     def _pad(p, value):
@@ -320,6 +333,10 @@ class Executor:
         self.dev = store.device
         self.L = lib()
         self.f32 = dict(dtype=torch.float32, device=self.dev)
+        # mixed precision (train.py:37-46, BASELINE configs[4]): activations / activation gradients in bf16, fp32 everywhere
+        # else; the logits tensor (conv_upsample output) and its gradient stay fp32 so the softmax / loss head is unchanged
+        self.bf16 = bool(getattr(store, 'bf16', False))
+        self.adt = torch.bfloat16 if self.bf16 else torch.float32
         self._alloc()
         # tracing runs every kernel once on zero inputs: keep the weights / optimiser state intact
         snap_p, snap_v, snap_step = store.P.clone(), store.V.clone(), store.step.clone()
@@ -345,10 +362,11 @@ class Executor:
         self.buf, self.grad = {}, {}
         self._mark_requires_grad()
         for t in g.tensors:
+            dt = torch.float32 if t is self.head.tensor else self.adt
             if not getattr(t, 'grad_only', False):
-                self.buf[t.id] = torch.zeros(N * t.H * t.W * t.C, **self.f32)
+                self.buf[t.id] = torch.zeros(N * t.H * t.W * t.C, dtype=dt, device=self.dev)
             if self.training and t.requires_grad:
-                self.grad[t.id] = torch.zeros(N * t.H * t.W * t.C, **self.f32)
+                self.grad[t.id] = torch.zeros(N * t.H * t.W * t.C, dtype=dt, device=self.dev)
         self.gscale, self.gshift = {}, {}
         for grp in g.groups:
             self.gscale[grp.id] = torch.ones(grp.C, **self.f32)
@@ -363,13 +381,15 @@ class Executor:
         self.partials = torch.zeros(MAX_ROWS * 2 * cmax, **self.f32)
         ws = 1 << 20
         L = self.L
+        pw_ws = L.pwconv_bwd_weight_workspace_bf16 if self.bf16 else L.pwconv_bwd_weight_workspace
+        dw_ws = L.dwconv2d_bwd_weight_workspace_bf16 if self.bf16 else L.dwconv2d_bwd_weight_workspace
         for op in g.ops:
             if op.kind == 'conv_pw':
-                ws = max(ws, L.pwconv_bwd_weight_workspace(N * op.Ho * op.Wo, op.cin, op.cout))
+                ws = max(ws, pw_ws(N * op.Ho * op.Wo, op.cin, op.cout))
             elif op.kind == 'conv_dw':
-                ws = max(ws, L.dwconv2d_bwd_weight_workspace(N, op.Ho, op.Wo, op.c, op.k))
+                ws = max(ws, dw_ws(N, op.Ho, op.Wo, op.c, op.k))
             elif op.kind == 'conv_dense':
-                ws = max(ws, L.pwconv_bwd_weight_workspace(N * op.Ho * op.Wo, op.kp, op.cout))
+                ws = max(ws, pw_ws(N * op.Ho * op.Wo, op.kp, op.cout))
         self.workspace = torch.zeros(ws // 4 + 4, **self.f32) if self.training else None
         # tickets + partial rows of the chunked per-image reductions (pooling, SE backward): zero once, every call
         # leaves its tickets at zero again; one stream runs all of them
@@ -377,12 +397,12 @@ class Executor:
         for op in g.ops:
             if op.kind in ('gap', 'se_mul', 'broadcast'):
                 t = op.x.tensor if op.kind != 'broadcast' else op.out
-                pws = max(pws, L.pool_workspace(N, t.H * t.W, t.C))
+                pws = max(pws, (L.pool_workspace_bf16 if self.bf16 else L.pool_workspace)(N, t.H * t.W, t.C))
         self.pool_ws = torch.zeros(pws // 4 + 4, **self.f32)
         self.pool_wsb = pws
         H, W, _ = g.input_shape
         self.H, self.W = H, W
-        self.cpad = (self.C + 3) // 4 * 4
+        self.cpad = self.head.tensor.C       # padded class count of the logits rows (a multiple of 4; of 8 on the bf16 path)
         self.labels = torch.zeros(N * H * W, **self.f32)
         self.loss_partials = torch.zeros(MAX_ROWS, **self.f32)
         self.loss = torch.zeros(1, **self.f32)
@@ -398,7 +418,7 @@ class Executor:
         # per-image class counts for the Jaccard training metric (deeplabv3p/metrics.py:29-46), refreshed every step
         self.metric_counts = (torch.zeros(N * 3 * self.C, dtype=torch.int32, device=self.dev).view(N, 3, self.C)
                               if (self.training and self.want_class_counts) else None)
-        self.fused_head = bool(self.training and self.loss_kind == 0 and not self.sample_weighted and os.environ.get('DL3P_FUSED_HEAD', '0') != '0' and zt is not None and
+        self.fused_head = bool(self.training and not self.bf16 and self.loss_kind == 0 and not self.sample_weighted and os.environ.get('DL3P_FUSED_HEAD', '0') != '0' and zt is not None and
                                zt.requires_grad and L.head_train_supported(zt.H, zt.W, self.C, H, W))
         self.dlogits_big = (torch.zeros(N * H * W * self.cpad, **self.f32)
                             if (self.training and not self.fused_head) else None)
@@ -440,7 +460,11 @@ class Executor:
     # ---------------------------------------------------------------- addressing helpers
     def tptr(self, t, grad=False):
         store = self.grad if grad else self.buf
-        return store[t.root.id].data_ptr() + 4 * t.c0
+        b = store[t.root.id]
+        return b.data_ptr() + b.element_size() * t.c0
+
+    def _is_f32(self, t):
+        return 1 if (t.root is self.head.tensor or t is self.head.tensor) else 0
 
     def vargs(self, v):
         """(ptr, ld, scale_ptr, shift_ptr, act) of a Value as a kernel prologue"""
@@ -473,7 +497,9 @@ class Executor:
                 part = self.partials.data_ptr() if want_stats else None
                 rows = ctypes.c_int(0)
                 xt = op.x.tensor
-                if k == 'conv_pw':
+                if self.bf16:
+                    self._conv_forward_bf16(P, op, xp, ldx, sp, hp, act, part, rows)
+                elif k == 'conv_pw':
                     P.k(L.pwconv_fwd_wt, xp, ldx, sp, hp, act, st.ptr(op.w, st.Pt), st.ptr(op.b) if op.b else None,
                         self.tptr(op.out), op.out.ld, part, ctypes.byref(rows), N * op.Ho * op.Wo, op.cin, op.cout)
                 elif k == 'conv_dw':
@@ -498,14 +524,16 @@ class Executor:
                     rp, ldr, rsp, rhp, ract = self.vargs(op.r)
                 rate = op.rate if train else 0.0
                 t = op.out
-                P.k(L.affine_act, xp, ldx, sp, hp, act, rp, ldr or 0, rsp, rhp, ract, float(rate),
+                P.k(L.affine_act_bf16 if self.bf16 else L.affine_act, xp, ldx, sp, hp, act, rp, ldr or 0, rsp, rhp, ract, float(rate),
                     self._dropout_seed(op), self.step.data_ptr(), self.tptr(t), t.ld, N * t.H * t.W, t.C)
             elif k == 'gap':
                 xp, ldx, sp, hp, act = self.vargs(op.x)
                 xt = op.x.tensor
-                P.k(L.global_avgpool_fwd, xp, ldx, sp, hp, act, self.tptr(op.out), op.out.ld, 1.0, N, xt.H * xt.W,
-                    xt.C, self.pool_ws.data_ptr(), self.pool_wsb)
+                P.k(L.global_avgpool_fwd_bf16 if self.bf16 else L.global_avgpool_fwd, xp, ldx, sp, hp, act, self.tptr(op.out),
+                    op.out.ld, 1.0, N, xt.H * xt.W, xt.C, self.pool_ws.data_ptr(), self.pool_wsb)
             elif k == 'maxpool':
+                if self.bf16:
+                    raise NotImplementedError('max pooling (ResNet50) is not built for the bf16 path')
                 xp, ldx, sp, hp, act = self.vargs(op.x)
                 xt, t = op.x.tensor, op.out
                 arg = None
@@ -517,10 +545,12 @@ class Executor:
                 xp, ldx, sp, hp, act = self.vargs(op.x)
                 s_ptr, lds, _, _, sact = self.vargs(op.s)
                 t = op.out
-                P.k(L.scale_bcast_fwd, xp, ldx, sp, hp, act, s_ptr, lds, sact, self.tptr(t), t.ld, N, t.H * t.W, t.C)
+                P.k(L.scale_bcast_fwd_bf16 if self.bf16 else L.scale_bcast_fwd, xp, ldx, sp, hp, act, s_ptr, lds, sact,
+                    self.tptr(t), t.ld, N, t.H * t.W, t.C)
             elif k in ('resize', 'broadcast'):
                 xt, t = op.x.tensor, op.out
-                P.k(L.resize_bilinear_fwd, self.tptr(xt), xt.ld, self.tptr(t), t.ld, N, xt.H, xt.W, xt.C, t.H, t.W)
+                P.k(L.resize_bilinear_fwd_bf16 if self.bf16 else L.resize_bilinear_fwd, self.tptr(xt), xt.ld, self.tptr(t),
+                    t.ld, N, xt.H, xt.W, xt.C, t.H, t.W)
             else:
                 raise NotImplementedError(k)
         # head: pred_resize + softmax (+ loss and its gradient when training)
@@ -549,6 +579,23 @@ class Executor:
             P.k(L.class_counts, self.tptr(zt), zt.ld, self.labels.data_ptr(), self.metric_counts.data_ptr(), N, zt.H, zt.W,
                 self.C, self.H, self.W)
         return P
+
+    def _conv_forward_bf16(self, P, op, xp, ldx, sp, hp, act, part, rows):
+        L, N, st, k = self.L, self.N, self.store, op.kind
+        xt = op.x.tensor
+        if k == 'conv_pw':
+            P.k(L.pwconv_fwd_bf16, xp, ldx, self._is_f32(xt), sp, hp, act, st.ptr(op.w, st.Pbt), st.ptr(op.b) if op.b else None,
+                self.tptr(op.out), op.out.ld, self._is_f32(op.out), part, ctypes.byref(rows), N * op.Ho * op.Wo, op.cin, op.cout)
+        elif k == 'conv_dw':
+            P.k(L.dwconv2d_fwd_bf16, xp, ldx, sp, hp, act, st.ptr(op.w, st.Pb), self.tptr(op.out), op.out.ld, part,
+                ctypes.byref(rows), N, xt.H, xt.W, op.c, op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo,
+                tag=op.name)
+        else:
+            P.k(L.im2col_bf16, xp, ldx, sp, hp, act, self.tptr(op.col), op.col.ld, N, xt.H, xt.W, op.cin, op.k, op.stride,
+                op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
+            P.k(L.pwconv_fwd_bf16, self.tptr(op.col), op.col.ld, 0, None, None, ACT_NONE, st.ptr(op.w, st.Pbt),
+                st.ptr(op.b) if op.b else None, self.tptr(op.out), op.out.ld, self._is_f32(op.out), part, ctypes.byref(rows),
+                N * op.Ho * op.Wo, op.kp, op.cout)
 
     def _dropout_seed(self, op):
         return (self.seed * 1000003 + zlib.crc32((op.dropout_name or '').encode()) % 65521) & 0x7FFFFFFFFFFFFFFF
@@ -605,8 +652,8 @@ class Executor:
             if vt.id in done:
                 continue
             done.add(vt.id)
-            P.k(self.L.bn_bwd_apply, self.tptr(vt, True), vt.ld, self.tptr(tt), tt.ld, None, None, act, None, None, None,
-                self.tptr(tt, True), tt.ld, self._acc(tt), self.N * tt.H * tt.W, tt.C)
+            P.k(self.L.bn_bwd_apply_bf16 if self.bf16 else self.L.bn_bwd_apply, self.tptr(vt, True), vt.ld, self.tptr(tt),
+                tt.ld, None, None, act, None, None, None, self.tptr(tt, True), tt.ld, self._acc(tt), self.N * tt.H * tt.W, tt.C)
 
     def _trace_backward(self):
         P, L, N, st = Plan(), self.L, self.N, self.store
@@ -628,7 +675,7 @@ class Executor:
         # issued while the NEXT BatchNorm's statistics all-reduce is on the wire (hides the collective's latency)
         self._deferred = []
         defer = self.sync_bn
-        fuse = self._bn_fusion_map()
+        fuse = {} if self.bf16 else self._bn_fusion_map()      # (the bf16 GEMM / depthwise kernels do not carry the fused sums)
         bn_done = set()
 
         def wgrad(fn, *args):
@@ -652,7 +699,9 @@ class Executor:
                 continue
             if out is None or not out.requires_grad:
                 continue
-            if k in ('conv_pw', 'conv_dense', 'conv_dw'):
+            if self.bf16 and k in ('conv_pw', 'conv_dense', 'conv_dw'):
+                self._conv_backward_bf16(P, op, wgrad, ws, wsb)
+            elif k in ('conv_pw', 'conv_dense', 'conv_dw'):
                 xp, ldx, sp, hp, act = self.vargs(op.x)
                 xt = op.x.tensor
                 dz, lddz = self.tptr(out, True), out.ld
@@ -718,18 +767,20 @@ class Executor:
                 M = N * out.H * out.W
                 if op.x.tensor.requires_grad or op.x.tensor.root.requires_grad:
                     gp, ldg, keyt = self._gbuf(op.x)
-                    P.k(L.scale_mask_bwd, gt, ldt, float(op.rate), self._dropout_seed(op), self.step.data_ptr(), gp, ldg,
-                        self._acc(keyt), M, out.C)
+                    P.k(L.scale_mask_bwd_bf16 if self.bf16 else L.scale_mask_bwd, gt, ldt, float(op.rate), self._dropout_seed(op),
+                        self.step.data_ptr(), gp, ldg, self._acc(keyt), M, out.C)
                 if op.r is not None and (op.r.tensor.requires_grad or op.r.tensor.root.requires_grad):
                     gp, ldg, keyt = self._gbuf(op.r)
-                    P.k(L.scale_mask_bwd, gt, ldt, 0.0, 0, None, gp, ldg, self._acc(keyt), M, out.C)
+                    P.k(L.scale_mask_bwd_bf16 if self.bf16 else L.scale_mask_bwd, gt, ldt, 0.0, 0, None, gp, ldg,
+                        self._acc(keyt), M, out.C)
             elif k == 'se_mul':
                 xp, ldx, sp, hp, act = self.vargs(op.x)
                 s_ptr, lds, _, _, sact = self.vargs(op.s)
                 gp, ldg, keyx = self._gbuf(op.x)
                 gsp, ldgs, keys = self._gbuf(op.s)
                 assert self._acc(keys) == 0, 'SE scale gradient has a single producer'
-                P.k(L.scale_bcast_bwd, self.tptr(out, True), out.ld, xp, ldx, sp, hp, act, s_ptr, lds, sact, gp, ldg,
+                P.k(L.scale_bcast_bwd_bf16 if self.bf16 else L.scale_bcast_bwd, self.tptr(out, True), out.ld, xp, ldx, sp, hp,
+                    act, s_ptr, lds, sact, gp, ldg,
                     self._acc(keyx), gsp, ldgs, N, out.H * out.W, out.C, self.pool_ws.data_ptr(), self.pool_wsb)
             elif k == 'maxpool':
                 xp, ldx, sp, hp, act = self.vargs(op.x)
@@ -740,17 +791,19 @@ class Executor:
             elif k == 'gap':
                 xt = op.x.tensor
                 gp, ldg, keyt = self._gbuf(op.x)
-                P.k(L.global_avgpool_bwd, self.tptr(out, True), out.ld, gp, ldg, self._acc(keyt), N, xt.H * xt.W, xt.C)
+                P.k(L.global_avgpool_bwd_bf16 if self.bf16 else L.global_avgpool_bwd, self.tptr(out, True), out.ld, gp, ldg,
+                    self._acc(keyt), N, xt.H * xt.W, xt.C)
             elif k == 'broadcast':
                 # gradient w.r.t. the (lazy) 1x1 value = sum over the pixels it was broadcast to
                 xt = op.x.tensor
                 assert self._acc(xt) == 0
-                P.k(L.global_avgpool_fwd, self.tptr(out, True), out.ld, None, None, ACT_NONE, self.tptr(xt, True),
-                    xt.ld, float(out.H * out.W), N, out.H * out.W, out.C, self.pool_ws.data_ptr(), self.pool_wsb)
+                P.k(L.global_avgpool_fwd_bf16 if self.bf16 else L.global_avgpool_fwd, self.tptr(out, True), out.ld, None, None,
+                    ACT_NONE, self.tptr(xt, True), xt.ld, float(out.H * out.W), N, out.H * out.W, out.C,
+                    self.pool_ws.data_ptr(), self.pool_wsb)
             elif k == 'resize':
                 xt = op.x.tensor
-                P.k(L.resize_bilinear_bwd, self.tptr(out, True), out.ld, self.tptr(xt, True), xt.ld, self._acc(xt),
-                    N, xt.H, xt.W, xt.C, out.H, out.W)
+                P.k(L.resize_bilinear_bwd_bf16 if self.bf16 else L.resize_bilinear_bwd, self.tptr(out, True), out.ld,
+                    self.tptr(xt, True), xt.ld, self._acc(xt), N, xt.H, xt.W, xt.C, out.H, out.W)
             else:
                 raise NotImplementedError(k)
         self._flush_deferred(P)
@@ -759,6 +812,39 @@ class Executor:
             # join the side stream inside this plan: a captured graph may not end with forked work in flight
             P.py(self.dist.wait_all)
         return P
+
+    def _conv_backward_bf16(self, P, op, wgrad, ws, wsb):
+        """weight and data gradient of one conv on the bf16 path (the BatchNorm-backward sums are NOT fused into the
+        data-gradient kernels here: every trainable BN takes the separate reduce pass)"""
+        L, N, st, k = self.L, self.N, self.store, op.kind
+        G, out = st.G, op.out
+        xp, ldx, sp, hp, act = self.vargs(op.x)
+        xt = op.x.tensor
+        dz, lddz, dzf = self.tptr(out, True), out.ld, self._is_f32(out)
+        need_gx = xt.requires_grad or xt.root.requires_grad
+        M = N * op.Ho * op.Wo
+        if op.layer.trainable:
+            gw = st.ptr(op.w, G)
+            gb = st.ptr(op.b, G) if getattr(op, 'b', None) else None
+            if k == 'conv_pw':
+                wgrad(L.pwconv_bwd_weight_bf16, xp, ldx, sp, hp, act, dz, lddz, dzf, gw, gb, ws, wsb, M, op.cin, op.cout)
+            elif k == 'conv_dw':
+                wgrad(L.dwconv2d_bwd_weight_bf16, xp, ldx, sp, hp, act, dz, lddz, gw, ws, wsb, N, xt.H, xt.W, op.c, op.k,
+                      op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
+            else:
+                wgrad(L.pwconv_bwd_weight_bf16, self.tptr(op.col), op.col.ld, None, None, ACT_NONE, dz, lddz, dzf, gw, gb,
+                      ws, wsb, M, op.kp, op.cout)
+        if not need_gx:
+            return
+        gp, ldg, keyt = self._gbuf(op.x)
+        acc = self._acc(keyt)
+        if k == 'conv_pw':
+            P.k(L.pwconv_bwd_data_bf16, dz, lddz, dzf, st.ptr(op.w, st.Pb), gp, ldg, acc, M, op.cin, op.cout)
+        elif k == 'conv_dw':
+            P.k(L.dwconv2d_bwd_data_bf16, dz, lddz, st.ptr(op.w, st.Pb), gp, ldg, acc, N, xt.H, xt.W, op.c, op.k, op.stride,
+                op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
+        else:
+            raise NotImplementedError('data gradient of a dense k x k conv is not built for the bf16 path (only RGB stems)')
 
     def _bn_fusion_map(self):
         """{consumer conv op: 'bn' op} for every trainable BatchNorm whose output value has exactly ONE consumer and that
@@ -813,8 +899,8 @@ class Executor:
         else:
             rows = ctypes.c_int(fused_rows or 0)
             if fused_rows is None:      # (otherwise the producer of g already left the partial sums in self.partials)
-                P.k(L.bn_bwd_reduce, g, ldg, zp, ldz, sp, hp, bn.act, mean, invstd, self.partials.data_ptr(),
-                    ctypes.byref(rows), M, bn.C)
+                P.k(L.bn_bwd_reduce_bf16 if self.bf16 else L.bn_bwd_reduce, g, ldg, zp, ldz, sp, hp, bn.act, mean, invstd,
+                    self.partials.data_ptr(), ctypes.byref(rows), M, bn.C)
             P.k(L.bn_bwd_finalize, self.partials.data_ptr(), rows.value, None, bn.C, float(M), st.ptr(lp['gamma']),
                 invstd, sp, 0, st.ptr(lp['gamma'], G), st.ptr(lp['beta'], G), coef)
             if self.sync_bn:
@@ -827,7 +913,8 @@ class Executor:
                 P.py(self.dist.bn_all_reduce_end)
                 P.k(L.bn_bwd_finalize, None, 0, aux['sums'].data_ptr(), bn.C, float(M * self.dist.world_size),
                     st.ptr(lp['gamma']), invstd, sp, 0, None, None, coef)
-        P.k(L.bn_bwd_apply, g, ldg, zp, ldz, sp, hp, bn.act, mean, invstd, coef, g, ldg, 0, M, bn.C)
+        P.k(L.bn_bwd_apply_bf16 if self.bf16 else L.bn_bwd_apply, g, ldg, zp, ldz, sp, hp, bn.act, mean, invstd, coef, g, ldg,
+            0, M, bn.C)
 
     # ---------------------------------------------------------------- optimiser
     def _trace_sgd(self):
@@ -847,7 +934,11 @@ class Executor:
         else:
             P.k(L.sgd_momentum, st.P.data_ptr(), st.V.data_ptr(), st.G.data_ptr(), st.total, self.lr.data_ptr(),
                 float(self.momentum), 0.0, scale, st.l2.data_ptr(), st.lr_scale.data_ptr())
-        if st.tr_table is not None:        # the forward GEMMs read the transposed kernel copies
+        if self.bf16:                       # refresh the bf16 mirrors the next forward / backward read
+            P.k(L.f32_to_bf16, st.P.data_ptr(), st.Pb.data_ptr(), st.total)
+            if st.tr_table is not None:
+                P.k(L.transpose_batch_bf16, st.P.data_ptr(), st.Pbt.data_ptr(), st.tr_table.data_ptr(), int(st.tr_table.shape[0]))
+        elif st.tr_table is not None:      # the forward GEMMs read the transposed kernel copies
             P.k(L.transpose_batch, st.P.data_ptr(), st.Pt.data_ptr(), st.tr_table.data_ptr(), int(st.tr_table.shape[0]))
         return P
 
@@ -861,9 +952,10 @@ class Executor:
         return stage
 
     def _upload_u8(self, src, dst, div, sub, slot):
-        """bytes over PCIe, float32 on the device (dl3p_u8_to_float)"""
+        """bytes over PCIe, float32 (or bf16 activations) on the device (dl3p_u8_to_float / dl3p_u8_to_bf16)"""
         stage = self._stage_u8(src, slot)
-        self.L.u8_to_float(stage.data_ptr(), dst.data_ptr(), stage.numel(), div, sub, torch.cuda.current_stream().cuda_stream)
+        fn = self.L.u8_to_bf16 if dst.dtype == torch.bfloat16 else self.L.u8_to_float
+        fn(stage.data_ptr(), dst.data_ptr(), stage.numel(), div, sub, torch.cuda.current_stream().cuda_stream)
 
     def set_inputs(self, x, y=None, sample_weight=None):
         """x float32 in [-1, 1] -- or uint8 pixels, normalised on the device like normalize_image does on the host
@@ -875,7 +967,15 @@ class Executor:
             self._upload_u8(x, inp, 127.5, 1.0, 'x')
         else:
             x = torch.as_tensor(x, dtype=torch.float32)
-            inp.copy_(x.reshape(-1), non_blocking=True)
+            if self.bf16:
+                # float images over PCIe as they are, rounded to bf16 on the device (dl3p_f32_to_bf16)
+                stage = self._u8.get('xf')
+                if stage is None or stage.numel() != inp.numel():
+                    stage = self._u8['xf'] = torch.empty(inp.numel(), **self.f32)
+                stage.copy_(x.reshape(-1), non_blocking=True)
+                self.L.f32_to_bf16(stage.data_ptr(), inp.data_ptr(), stage.numel(), torch.cuda.current_stream().cuda_stream)
+            else:
+                inp.copy_(x.reshape(-1), non_blocking=True)
         adaptive = isinstance(sample_weight, str)
         if adaptive:
             if sample_weight != 'adaptive':

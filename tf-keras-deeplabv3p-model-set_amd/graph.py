@@ -11,6 +11,9 @@ import math
 import numpy as np
 
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_HSWISH, ACT_HSIGMOID = 0, 1, 2, 3, 4
+# device-side channel padding granule: 4 floats (16 bytes) on the fp32 path; the bf16 GEMMs read 8-element (16-byte)
+# chunks, so a mixed-precision graph pads the class dimension and the im2col rows to multiples of 8 (mixed_precision.py)
+CHANNEL_ALIGN = 4
 L2_FACTOR = 2e-5  # reference deeplabv3p/models/layers.py:12
 
 
@@ -193,6 +196,7 @@ class GraphBuilder:
     def __init__(self, input_shape, name='model', seed=0):
         H, W, C = input_shape
         self.name = name
+        self.align = CHANNEL_ALIGN
         self.rng = np.random.default_rng(seed)
         self.layers = []
         self.layer_by_name = {}
@@ -253,7 +257,7 @@ class GraphBuilder:
         layer = self.add_layer(name, 'Conv2D', (Ho, Wo, filters), inbound=[src])
         cdev = pad_to or filters
         # dense (k > 1) kernels are stored as the im2col GEMM operand [k*k*cin padded to a multiple of 4][cout]
-        kp = (k * k * cin + 3) // 4 * 4
+        kp = (k * k * cin + self.align - 1) // self.align * self.align
         dev_shape = (k, k, cin, cdev) if k == 1 else (kp, cdev)
         if kernel_initializer == 'he_normal':
             init = lambda s: he_normal(self.rng, s, k * k * cin)

@@ -269,8 +269,9 @@ class DistContext:
 
 
 class DeeplabModel:
-    def __init__(self, graph, head, model_type, num_classes, input_shape, training, backbone_len, seed=0):
+    def __init__(self, graph, head, model_type, num_classes, input_shape, training, backbone_len, seed=0, bf16=False):
         self.graph, self.head = graph, head
+        self.bf16 = bool(bf16)          # mixed_precision policy at build time (train.py:37-46)
         self.name = 'deeplabv3p_' + model_type
         self.model_type, self.num_classes = model_type, num_classes
         self.input_shape_hw = tuple(input_shape)
@@ -357,7 +358,7 @@ class DeeplabModel:
             if not torch.cuda.is_available():
                 raise RuntimeError('the DeepLabV3+ HIP path needs an MI355X device; there is no CPU fallback')
             from .executor import ParamStore
-            self._store = ParamStore(self.graph, torch.device('cuda', torch.cuda.current_device()))
+            self._store = ParamStore(self.graph, torch.device('cuda', torch.cuda.current_device()), bf16=self.bf16)
             if self.dist is not None:
                 self.dist.broadcast(self._store.P, 0)   # identical replicas (MirroredStrategy semantics)
                 self._store.transpose()
@@ -681,6 +682,18 @@ DeeplabModel.evaluate_miou = _evaluate_miou
 
 def get_deeplabv3p_model(model_type, num_classes, model_input_shape, output_stride, freeze_level=0,
                          weights_path=None, training=True, use_subpixel=False, seed=0):
+    from . import graph as graph_mod, mixed_precision
+    bf16 = mixed_precision.is_bf16()        # the global policy at build time, like Keras layers pick theirs up
+    graph_mod.CHANNEL_ALIGN = 8 if bf16 else 4
+    try:
+        return _build_model(model_type, num_classes, model_input_shape, output_stride, freeze_level, weights_path, training,
+                            use_subpixel, seed, bf16)
+    finally:
+        graph_mod.CHANNEL_ALIGN = 4
+
+
+def _build_model(model_type, num_classes, model_input_shape, output_stride, freeze_level, weights_path, training,
+                 use_subpixel, seed, bf16):
     # check if model type is valid
     if model_type not in deeplab_model_map.keys():
         raise ValueError('This model type is not supported now')
@@ -701,7 +714,7 @@ def get_deeplabv3p_model(model_type, num_classes, model_input_shape, output_stri
 
     # new head (model.py:75-86): conv_upsample 1x1 (+bias) -> pred_resize -> [Reshape] -> Softmax('pred_mask').
     # The class dimension is padded to a multiple of 4 on the device (pad weights/bias stay exactly 0).
-    cpad = (num_classes + 3) // 4 * 4
+    cpad = (num_classes + g.align - 1) // g.align * g.align
     x = g.conv2d(x, num_classes, 1, 'conv_upsample', use_bias=True, pad_to=cpad)
     out = g.passthrough(x, 'Lambda', (H, W, num_classes), name='pred_resize')
     if training:
@@ -711,7 +724,7 @@ def get_deeplabv3p_model(model_type, num_classes, model_input_shape, output_stri
     if x.tensor.C != cpad or not x.is_plain:
         raise AssertionError('head tensor layout')
 
-    model = DeeplabModel(g, x, model_type, num_classes, (H, W), training, backbone_len, seed=seed)
+    model = DeeplabModel(g, x, model_type, num_classes, (H, W), training, backbone_len, seed=seed, bf16=bf16)
 
     if weights_path:
         model.load_weights(weights_path, by_name=False)

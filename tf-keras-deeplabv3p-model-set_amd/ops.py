@@ -531,3 +531,169 @@ def scale_bcast_bwd(gy, x, s, scale=None, shift=None, act=ACT_NONE, s_act=ACT_NO
     lib().scale_bcast_bwd(gp, ldg, xp, ldx, _p(scale), _p(shift), act, sp, lds, s_act, _p(gx), C, 0, _p(gs), C, N, H * W, C,
                           _p(ws), wsb, _stream())
     return gx, gs
+
+
+# ------------------------------------------------------------------------------------- mixed precision (bf16 storage)
+# wrappers over the *_bf16 entry points: activation tensors are torch.bfloat16 (or float32 where the C ABI takes an
+# `*_is_f32` flag), BatchNorm coefficients / partial rows / weight gradients float32
+def _plb(t):
+    """(device pointer, row stride in ELEMENTS, is_f32) of a bf16 (or f32) activation tensor or channel-slice view"""
+    if t is None:
+        return None, 0, 0
+    if not t.is_cuda or t.dtype not in (torch.bfloat16, torch.float32):
+        raise Dl3pError('bf16 ops need bfloat16 / float32 tensors on the HIP device (got %s on %s)' % (t.dtype, t.device))
+    if t.stride(-1) != 1:
+        raise Dl3pError('channel dim must be contiguous')
+    ld = t.stride(-2) if t.dim() >= 2 else t.shape[-1]
+    return t.data_ptr(), ld, int(t.dtype == torch.float32)
+
+
+def _bf(t):
+    return t if t.dtype == torch.bfloat16 else t.to(torch.bfloat16)
+
+
+def pwconv_fwd_bf16(x, w, bias=None, in_scale=None, in_shift=None, in_act=ACT_NONE, partials=None, out_f32=False):
+    """x (.., K) bf16 / f32, w (K, N) float32 master kernel -> y (.., N) bf16 (f32 with out_f32); (y, rows) with partials"""
+    K, Nn = w.shape
+    M = _rows(x)
+    wt = _bf(w.t().contiguous())
+    y = torch.empty(tuple(x.shape[:-1]) + (Nn,), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    xp, ldx, xf = _plb(x)
+    yp, ldy, yf = _plb(y)
+    rows = ctypes.c_int(0)
+    lib().pwconv_fwd_bf16(xp, ldx, xf, _p(in_scale), _p(in_shift), in_act, _p(wt), _p(bias), yp, ldy, yf, _p(partials),
+                          ctypes.byref(rows), M, K, Nn, _stream())
+    return (y, rows.value) if partials is not None else y
+
+
+def pwconv_bwd_data_bf16(dy, w, out=None, accumulate=False):
+    K, Nn = w.shape
+    M = _rows(dy)
+    gx = out if out is not None else torch.empty(tuple(dy.shape[:-1]) + (K,), dtype=torch.bfloat16, device=dy.device)
+    dp, ldd, df = _plb(dy)
+    gp, ldg, _ = _plb(gx)
+    lib().pwconv_bwd_data_bf16(dp, ldd, df, _p(_bf(w.contiguous())), gp, ldg, int(accumulate), M, K, Nn, _stream())
+    return gx
+
+
+def pwconv_bwd_weight_bf16(x, dy, in_scale=None, in_shift=None, in_act=ACT_NONE, with_bias=False):
+    K, Nn = x.shape[-1], dy.shape[-1]
+    M = _rows(x)
+    need = lib().pwconv_bwd_weight_workspace_bf16(M, K, Nn)
+    ws = torch.empty(need // 4 + 4, dtype=torch.float32, device=x.device)
+    gw = torch.empty((K, Nn), dtype=torch.float32, device=x.device)
+    gb = torch.empty((Nn,), dtype=torch.float32, device=x.device) if with_bias else None
+    xp, ldx, _ = _plb(x)
+    dp, ldd, df = _plb(dy)
+    lib().pwconv_bwd_weight_bf16(xp, ldx, _p(in_scale), _p(in_shift), in_act, dp, ldd, df, _p(gw), _p(gb), _p(ws),
+                                 ws.numel() * 4, M, K, Nn, _stream())
+    return (gw, gb) if with_bias else gw
+
+
+def dwconv2d_fwd_bf16(x, w, stride=1, rate=1, padding='same', in_scale=None, in_shift=None, in_act=ACT_NONE, partials=None):
+    N, H, W, C = x.shape
+    k = w.shape[0]
+    Ho, Wo, pt, pl = conv_geometry(H, W, k, stride, rate, padding)
+    y = torch.empty((N, Ho, Wo, C), dtype=torch.bfloat16, device=x.device)
+    xp, ldx, _ = _plb(x)
+    yp, ldy, _ = _plb(y)
+    rows = ctypes.c_int(0)
+    lib().dwconv2d_fwd_bf16(xp, ldx, _p(in_scale), _p(in_shift), in_act, _p(_bf(w.contiguous())), yp, ldy, _p(partials),
+                            ctypes.byref(rows), N, H, W, C, k, stride, rate, pt, pl, Ho, Wo, _stream())
+    return (y, rows.value) if partials is not None else y
+
+
+def dwconv2d_bwd_data_bf16(dy, w, x_shape, stride=1, rate=1, padding='same', out=None, accumulate=False):
+    N, H, W, C = x_shape
+    k = w.shape[0]
+    Ho, Wo, pt, pl = conv_geometry(H, W, k, stride, rate, padding)
+    gx = out if out is not None else torch.empty((N, H, W, C), dtype=torch.bfloat16, device=dy.device)
+    dp, ldd, _ = _plb(dy)
+    gp, ldg, _ = _plb(gx)
+    lib().dwconv2d_bwd_data_bf16(dp, ldd, _p(_bf(w.contiguous())), gp, ldg, int(accumulate), N, H, W, C, k, stride, rate,
+                                 pt, pl, Ho, Wo, _stream())
+    return gx
+
+
+def dwconv2d_bwd_weight_bf16(x, dy, k, stride=1, rate=1, padding='same', in_scale=None, in_shift=None, in_act=ACT_NONE):
+    N, H, W, C = x.shape
+    Ho, Wo, pt, pl = conv_geometry(H, W, k, stride, rate, padding)
+    need = lib().dwconv2d_bwd_weight_workspace_bf16(N, Ho, Wo, C, k)
+    ws = torch.empty(need // 4 + 4, dtype=torch.float32, device=x.device)
+    gw = torch.empty((k, k, C), dtype=torch.float32, device=x.device)
+    xp, ldx, _ = _plb(x)
+    dp, ldd, _ = _plb(dy)
+    lib().dwconv2d_bwd_weight_bf16(xp, ldx, _p(in_scale), _p(in_shift), in_act, dp, ldd, _p(gw), _p(ws), ws.numel() * 4,
+                                   N, H, W, C, k, stride, rate, pt, pl, Ho, Wo, _stream())
+    return gw
+
+
+def bn_backward_bf16(bn, g, z, act, partials):
+    """in-place BatchNorm backward on bf16 tensors (reduce + finalize + apply); bn: BNState with scale/shift/mean/invstd"""
+    M = _rows(z)
+    gp, ldg, _ = _plb(g)
+    zp, ldz, _ = _plb(z)
+    rows = ctypes.c_int(0)
+    lib().bn_bwd_reduce_bf16(gp, ldg, zp, ldz, _p(bn.scale), _p(bn.shift), act, _p(bn.mean), _p(bn.invstd), _p(partials),
+                             ctypes.byref(rows), M, bn.C, _stream())
+    lib().bn_bwd_finalize(_p(partials), rows.value, None, bn.C, float(M), _p(bn.gamma), _p(bn.invstd), _p(bn.scale), 0,
+                          _p(bn.dgamma), _p(bn.dbeta), _p(bn.coef), _stream())
+    lib().bn_bwd_apply_bf16(gp, ldg, zp, ldz, _p(bn.scale), _p(bn.shift), act, _p(bn.mean), _p(bn.invstd), _p(bn.coef),
+                            gp, ldg, 0, M, bn.C, _stream())
+    return g
+
+
+def affine_act_bf16(x, scale=None, shift=None, act=ACT_NONE, residual=None, rscale=None, rshift=None, ract=ACT_NONE):
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    xp, ldx, _ = _plb(x)
+    rp, ldr, _ = _plb(residual)
+    yp, ldy, _ = _plb(y)
+    lib().affine_act_bf16(xp, ldx, _p(scale), _p(shift), act, rp, ldr, _p(rscale), _p(rshift), ract, 0.0, 0, None, yp, ldy,
+                          _rows(x), x.shape[-1], _stream())
+    return y
+
+
+def global_avgpool_fwd_bf16(x, in_scale=None, in_shift=None, in_act=ACT_NONE, out_scale=1.0):
+    N, H, W, C = x.shape
+    y = torch.empty((N, 1, 1, C), dtype=torch.bfloat16, device=x.device)
+    ws = torch.zeros(lib().pool_workspace_bf16(N, H * W, C) // 4 + 4, dtype=torch.float32, device=x.device)
+    xp, ldx, _ = _plb(x)
+    lib().global_avgpool_fwd_bf16(xp, ldx, _p(in_scale), _p(in_shift), in_act, y.data_ptr(), C, float(out_scale), N, H * W, C,
+                                  _p(ws), ws.numel() * 4, _stream())
+    return y
+
+
+def scale_bcast_fwd_bf16(x, s, scale=None, shift=None, act=ACT_NONE, s_act=ACT_NONE):
+    N, H, W, C = x.shape
+    y = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=x.device)
+    xp, ldx, _ = _plb(x)
+    lib().scale_bcast_fwd_bf16(xp, ldx, _p(scale), _p(shift), act, s.data_ptr(), C, s_act, y.data_ptr(), C, N, H * W, C, _stream())
+    return y
+
+
+def scale_bcast_bwd_bf16(gy, x, s, scale=None, shift=None, act=ACT_NONE, s_act=ACT_NONE):
+    N, H, W, C = x.shape
+    gx = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=x.device)
+    gs = torch.empty((N, 1, 1, C), dtype=torch.bfloat16, device=x.device)
+    ws = torch.zeros(lib().pool_workspace_bf16(N, H * W, C) // 4 + 4, dtype=torch.float32, device=x.device)
+    gp, ldg, _ = _plb(gy)
+    xp, ldx, _ = _plb(x)
+    lib().scale_bcast_bwd_bf16(gp, ldg, xp, ldx, _p(scale), _p(shift), act, s.data_ptr(), C, s_act, gx.data_ptr(), C, 0,
+                               gs.data_ptr(), C, N, H * W, C, _p(ws), ws.numel() * 4, _stream())
+    return gx, gs
+
+
+def resize_bilinear_fwd_bf16(x, H, W):
+    N, h, w, C = x.shape
+    y = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=x.device)
+    xp, ldx, _ = _plb(x)
+    lib().resize_bilinear_fwd_bf16(xp, ldx, y.data_ptr(), C, N, h, w, C, H, W, _stream())
+    return y
+
+
+def resize_bilinear_bwd_bf16(gy, h, w):
+    N, H, W, C = gy.shape
+    gx = torch.empty((N, h, w, C), dtype=torch.bfloat16, device=gy.device)
+    gp, ldg, _ = _plb(gy)
+    lib().resize_bilinear_bwd_bf16(gp, ldg, gx.data_ptr(), C, 0, N, h, w, C, H, W, _stream())
+    return gx
