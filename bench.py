@@ -40,6 +40,8 @@ def parse():
     ap.add_argument('--model', default='mobilenetv2')
     ap.add_argument('--classes', type=int, default=21)
     ap.add_argument('--os', type=int, default=16, help='output stride')
+    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
+                    help="bf16: the mixed-precision policy of train.py:37-46 (bf16 storage, fp32 accumulate; BASELINE configs[4])")
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-sync-bn', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -140,6 +142,8 @@ def main():
             raise SystemExit('--scaling strong: the global batch %d does not divide over %d ranks' % (args.batch, world))
         N = args.batch // world
 
+    if args.dtype == 'bf16':
+        pkg.mixed_precision.set_policy(pkg.mixed_precision.Policy('mixed_bfloat16'))
     model = pkg.get_deeplabv3p_model(args.model, C, (H, W), args.os, freeze_level=0, training=True)
     model.compile(optimizer=pkg.SGD(0.01, momentum=0.9), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255),
                   sync_bn=not args.no_sync_bn)
@@ -190,7 +194,7 @@ def main():
             'metric': 'images/sec (513x513, 21-class) MobileNetV2-DeepLabV3+ OS=16 training step',
             'value': round(N * world * args.steps / dt, 2), 'unit': 'images/sec', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000 * dt / args.steps, 3),
-            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': '%s + ASPP(%s) + decoder, OS=%d, %dx%d, %d classes, per-GPU batch %d, '
                                    'fwd+loss+bwd+SGD(momentum 0.9, l2 2e-5), BN training mode, dropout 0.5'
                                    % (args.model, {8: '12/24/36', 16: '6/12/18', 32: '3/6/9'}[args.os], args.os, H, W, C, N),
@@ -204,7 +208,8 @@ def main():
             ms = probe.mean_ms()
             op = probe.op
             t = op.out
-            algo = 2.0 * N * t.H * t.W * op.c * 4 + op.k * op.k * op.c * 4     # read x once, write y once, weights
+            es = 2 if args.dtype == 'bf16' else 4
+            algo = 2.0 * N * t.H * t.W * op.c * es + op.k * op.k * op.c * es     # read x once, write y once, weights
             ach = algo / (ms * 1e-3) / 1e9
             traffic, src = (measured_traffic(probe.kernel_name) if (args.size, N, args.model) == (513, 16, 'mobilenetv2')
                             else (None, None))

@@ -63,6 +63,13 @@ class Net:
         # matrix cores read them; statistics, biases, the logits (`keep_f32`) and the whole backward stay in this net's
         # dtype.  Forward values then follow the device's rounding points; gradients are compared with a tolerance.
         self.bf16 = False
+        self.record = None      # optional dict: raw conv / depthwise outputs by layer name, as THIS net computes them
+        # optional {layer name: array}: after recording its own result, a conv / depthwise layer continues with the given
+        # output instead ("teacher forcing" with the device's stored tensors).  Two bf16 computations of one model drift
+        # apart after the first element that rounds the other way (BatchNorm spreads it over the channel); forcing keeps
+        # this oracle on the device's trajectory so that EVERY layer is compared on identical inputs and the backward
+        # pass is linearised at the device's own activations.
+        self.force = None
         # optional SyncBatchNorm: (all_reduce_sum(ndarray) -> ndarray, world_size).  Statistics are
         # summed over ranks in forward (sum x, sum x^2, count) and backward (sum dy, sum dy*xhat); the
         # parameter gradients stay local and are averaged with all other gradients (README.md:38,
@@ -117,6 +124,12 @@ class Net:
         wq = self.q(w)
         yv = O.conv2d_fwd(x.v, wq, stride, rate, padding, b)
         y = Var(yv if keep_f32 else self.q(yv))
+        if self.record is not None:
+            self.record[name] = y.v
+        if self.force is not None and name in self.force:
+            y.v = np.asarray(self.force[name], dtype=self.dtype).reshape(y.v.shape)
+        if self.force is not None and name in self.force:
+            y.v = np.asarray(self.force[name], dtype=self.dtype).reshape(y.v.shape)
         need_gx = True
 
         def bwd():
@@ -138,6 +151,8 @@ class Net:
                         lambda s: O.glorot_uniform(self.rng, s, k * k * c, k * k * 1), l2=0.0)
         w = self.q(w4[..., 0])
         y = Var(self.q(O.dwconv2d_fwd(x.v, w, stride, rate, padding)))
+        if self.record is not None:
+            self.record[name] = y.v
 
         def bwd():
             if y.g is None:

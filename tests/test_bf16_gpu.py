@@ -27,6 +27,8 @@ def TF(a):
 
 
 def np64(t):
+    if not torch.is_tensor(t):
+        return np.asarray(t, np.float64)
     return t.detach().float().cpu().numpy().astype(np.float64)
 
 
@@ -163,6 +165,17 @@ def _cos(a, b):
 @pytest.mark.parametrize('model_type,H,W', [('mobilenetv3large', 64, 96), ('mobilenetv3large', 128, 256), ('mobilenetv3large_lite', 65, 65),
                                             ('mobilenetv2', 65, 65)])
 def test_train_step_bf16_matches_rounding_oracle(model_type, H, W):
+    """Whole train step in bf16 against the fp64 oracle with bf16 rounding at the device's storage points, kept on the
+    device's trajectory (oracle/np_net.py Net.force): two bf16 evaluations of one model drift apart after the first element
+    that fp32 accumulation rounds the other way -- BatchNorm over the few hundred samples of these maps spreads it over
+    the whole channel (scripts/bf16_layer_diff.py shows bit-identical layers up to that point, then exponential growth).
+    Each conv / depthwise layer's output is therefore compared with what the oracle computes FROM THE DEVICE'S inputs to
+    that layer, and the oracle then continues with the device's tensor:
+      * forward: every one of the ~100 conv layers within one bf16 ulp (+ 2e-3 of the layer's range) on 99.9 % of its
+        elements; logits and loss (fp32 head) to 1e-3;
+      * backward: fp64 back-propagation through the device's own activations against gradients that were stored as bf16
+        at every layer: cosine similarity > 0.98 and relative L2 error < 0.2 per parameter tensor, < 0.08 over all
+        (measured: 0.03 - 0.055)."""
     from oracle.np_net import OracleModel
     pkg = load_pkg()
     mp = pkg.mixed_precision
@@ -193,28 +206,42 @@ def test_train_step_bf16_matches_rounding_oracle(model_type, H, W):
     assert ex.bf16 and ex.buf[m.graph.input.tensor.id].dtype == torch.bfloat16
     drop = [op for op in m.graph.ops if op.kind == 'materialize' and op.rate > 0][0]
     mask = ex.dropout_mask(drop).cpu().numpy()
-    total, ce, logits_ref = o.loss_and_grads(x, y, {'aspp_dropout': mask})
+    convs = [op for op in m.graph.ops if op.kind in ('conv_pw', 'conv_dense', 'conv_dw')]
+    real = {op.name: op.layer.params[0].shape[-1] if op.kind != 'conv_dw' else op.c for op in convs}
+    o.net.force = {op.name: ex.view(op.out).float().cpu().numpy()[..., :real[op.name]] for op in convs}
+    o.net.record = {}
+    _, ce, logits_ref = o.loss_and_grads(x, y, {'aspp_dropout': mask})
+    assert set(o.net.record) == set(o.net.force)
+    for op in convs:
+        ref, got = o.net.record[op.name], o.net.force[op.name]
+        tol = 1.01 * 2.0 ** -8 * np.abs(ref) + 2e-3 * np.abs(ref).max() + 1e-30
+        if op.name == 'conv_upsample':
+            tol = 1e-4 * max(1.0, np.abs(ref).max())          # the logits layer writes fp32
+        frac = float((np.abs(got - ref) <= tol).mean())
+        assert frac > 0.999, (op.name, frac, float(np.abs(got - ref).max()), float(np.abs(ref).max()))
     ops = load_pkg('ops')
     out = ops.upsample_softmax_ce(ex.view(m.head.tensor), C, H, W, want_logits=True)
     lg = out['logits'][..., :C].cpu().numpy()
-    rng_l = float(np.abs(logits_ref).max())
-    assert np.abs(lg - logits_ref).max() < 3e-2 * max(1.0, rng_l), (np.abs(lg - logits_ref).max(), rng_l)
-    assert abs(loss - ce) < 1e-2 * max(1.0, abs(ce)), (loss, ce)
+    assert np.abs(lg - logits_ref).max() < 1e-3 * max(1.0, np.abs(logits_ref).max())
+    assert abs(loss - ce) < 1e-3 * max(1.0, abs(ce)), (loss, ce)
     st = m._store
-    worst = ('', 1.0)
+    worst, num, den = [], 0.0, 0.0
     for p in m.graph.all_params():
-        if not p.trainable:
+        ge = o.net.grads.get(p.name)
+        if not p.trainable or ge is None:
             continue
-        gref = o.net.grads[p.name]
-        if np.abs(gref).max() < 1e-7 or gref.size < 8:
+        g = st.get(p, st.G).astype(np.float64)
+        num += float(((g - ge) ** 2).sum()); den += float((ge ** 2).sum())
+        if ge.size < 16 or np.abs(ge).max() < 1e-7:
             continue
-        c = _cos(st.get(p, st.G), gref)
-        if c < worst[1]:
-            worst = (p.name, c)
-    assert worst[1] > 0.99, worst
-    # master weights stay fp32 and move by lr * (g + l2): the update itself is the fp32 optimiser kernel
+        c = _cos(g, ge)
+        rel = float(np.linalg.norm(g - ge) / max(1e-30, np.linalg.norm(ge)))
+        if c < 0.98 or rel > 0.2:
+            worst.append((p.name, round(c, 4), round(rel, 4)))
+    assert not worst, worst[:10]
+    assert np.sqrt(num / den) < 0.08, np.sqrt(num / den)
     w = m.get_weights_by_name()
-    assert all(v.dtype == np.float32 for v in w.values())
+    assert all(v.dtype == np.float32 and np.isfinite(v).all() for v in w.values())
 
 
 def test_bf16_full_size_properties():

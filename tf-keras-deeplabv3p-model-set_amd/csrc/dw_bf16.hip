@@ -216,9 +216,10 @@ extern "C" int dl3p_dwconv2d_fwd_bf16(const void* x, int ldx, const float* in_sc
   if (rows_out) *rows_out = p.nbx;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(p.nbx * p.nslab);
-  if (k == 3 && v8) hipLaunchKernelGGL((dwb_fwd<8, 3>), grid, dim3(256), 0, st, p);
-  else if (k == 3) hipLaunchKernelGGL((dwb_fwd<4, 3>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((dwb_fwd<4, 5>), grid, dim3(256), 0, st, p);
+  // (dl3p_launch: the forward depthwise launch can carry bench.py's HIP event pair, dl3p_probe_arm)
+  if (k == 3 && v8) dl3p_launch(dwb_fwd<8, 3>, grid, dim3(256), 0, st, p);
+  else if (k == 3) dl3p_launch(dwb_fwd<4, 3>, grid, dim3(256), 0, st, p);
+  else dl3p_launch(dwb_fwd<4, 5>, grid, dim3(256), 0, st, p);
   DL3P_CHECK_LAUNCH("dl3p_dwconv2d_fwd_bf16");
   return DL3P_OK;
 }
