@@ -21,16 +21,23 @@ PKG = 'tf-keras-deeplabv3p-model-set_amd'
 
 
 def run(model_type='mobilenetv2', N=None, size=513, C=21):
-    N = N or (4 if model_type == 'xception' else 16)
+    # DL3P_ST_{N,H,W,C,DTYPE}: other shapes / the bf16 policy (configs[4]: H=1024 W=2048 N=1 C=19 DTYPE=bf16)
+    env = os.environ.get
+    N = int(env('DL3P_ST_N', 0)) or N or (4 if model_type == 'xception' else 16)
+    H, W = int(env('DL3P_ST_H', size)), int(env('DL3P_ST_W', env('DL3P_ST_H', size)))
+    C = int(env('DL3P_ST_C', C))
+    bf16 = env('DL3P_ST_DTYPE', 'f32') == 'bf16'
     import torch
     pkg = importlib.import_module(PKG)
     lib = importlib.import_module(PKG + '._lib').lib()
-    model = pkg.get_deeplabv3p_model(model_type, C, (size, size), 16, freeze_level=0, training=True)
+    if bf16:
+        pkg.mixed_precision.set_policy(pkg.mixed_precision.Policy('mixed_bfloat16'))
+    model = pkg.get_deeplabv3p_model(model_type, C, (H, W), 16, freeze_level=0, training=True)
     model.compile(optimizer=pkg.SGD(0.01, momentum=0.9), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
     gen = torch.Generator(device='cuda')
     gen.manual_seed(1234)
-    x = torch.rand((N, size, size, 3), device='cuda', generator=gen) * 2 - 1
-    y = torch.randint(0, C, (N, size * size, 1), device='cuda', generator=gen).float()
+    x = torch.rand((N, H, W, 3), device='cuda', generator=gen) * 2 - 1
+    y = torch.randint(0, C, (N, H * W, 1), device='cuda', generator=gen).float()
     ex = model._executor(N, True)
     ex.set_inputs(x, y)
     ex.lr.fill_(0.01)
@@ -67,6 +74,7 @@ def run(model_type='mobilenetv2', N=None, size=513, C=21):
         elif getattr(op, 'out', None) is not None:
             shapes[lab] = dict(M=N * op.out.H * op.out.W, C=op.out.C)
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    shapes['__esize__'] = 2 if bf16 else 4
     json.dump(shapes, open(os.path.join(ROOT, 'gpurun_out', 'st_shapes.json'), 'w'))
     json.dump(labels, open(os.path.join(ROOT, 'gpurun_out', 'st_labels.json'), 'w'))
 
@@ -105,7 +113,8 @@ def parse(d):
         tot += t
         out.append((pname, ep, ctx, t, ['%s %.1f' % (r['Kernel_Name'].split('(')[0][:40], us(r)) for r in ks]))
     shapes = json.load(open(os.path.join(ROOT, 'gpurun_out', 'st_shapes.json')))
-    HBM, MFMA = 6.3e6, 157e6          # achievable bytes/us (guide: ~6.3 TB/s), fp32 MFMA flop/us
+    ES = shapes.get('__esize__', 4)     # bytes per stored activation element (2 on the bf16 path)
+    HBM, MFMA = 6.3e6, (157e6 if ES == 4 else 2500e6)   # achievable bytes/us (guide: ~6.3 TB/s), dense MFMA flop/us of the dtype
 
     pw, dw, bn = ('M', 'K', 'N'), ('Min', 'M', 'C'), ('M', 'C')
     NEED = dict(pwconv_fwd=pw, pwconv_fwd_wt=pw, pwconv_bwd_data=pw, pwconv_bwd_data_bn=pw, pwconv_bwd_weight=pw,
@@ -116,18 +125,18 @@ def parse(d):
         sh = shapes.get(ctx)
         if not sh:
             return None
-        ep = ep.replace('dl3p_', '')
+        ep = ep.replace('dl3p_', '').replace('_bf16', '')
         if not all(k in sh for k in NEED.get(ep, ())):
             return None
         if ep in ('pwconv_fwd', 'pwconv_fwd_wt', 'pwconv_bwd_data', 'pwconv_bwd_data_bn', 'pwconv_bwd_weight'):
-            by = 4.0 * sh['M'] * (sh['K'] + sh['N'])
+            by = ES * sh['M'] * (sh['K'] + sh['N'])
             return max(by / HBM, 2.0 * sh['M'] * sh['K'] * sh['N'] / MFMA)
         if ep in ('dwconv2d_fwd', 'dwconv2d_bwd_data', 'dwconv2d_bwd_data_bn', 'dwconv2d_bwd_weight'):
-            return 4.0 * (sh['Min'] + sh['M']) * sh['C'] / HBM
+            return ES * (sh['Min'] + sh['M']) * sh['C'] / HBM
         if ep == 'bn_bwd_reduce':
-            return 8.0 * sh['M'] * sh['C'] / HBM
+            return 2.0 * ES * sh['M'] * sh['C'] / HBM
         if ep == 'bn_bwd_apply':
-            return 12.0 * sh['M'] * sh['C'] / HBM
+            return 3.0 * ES * sh['M'] * sh['C'] / HBM
         return None
     print('# %d items, %.3f ms of kernel time' % (len(out), tot / 1e3))
     slack = {}
