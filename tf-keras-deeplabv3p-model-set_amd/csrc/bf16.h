@@ -65,10 +65,21 @@ template <int V> __device__ __forceinline__ void stv(float* p, const fvec<V>& o)
 #pragma unroll
   for (int i = 0; i < V; i += 4) st4(p + i, make_float4(o.v[i], o.v[i + 1], o.v[i + 2], o.v[i + 3]));
 }
+// per-channel coefficients (scale, shift, mean, ...): 16-byte loads -- c is a multiple of 4 and the arrays are 16-byte
+// aligned (scalar loads here cost a thread 8 address-unit passes per coefficient vector; with 7 vectors per thread that
+// was 4/5 of the BatchNorm-backward kernels on the 64 x 128 maps, where a thread only has one or two pixels to amortise them)
 template <int V> __device__ __forceinline__ fvec<V> ldv_f32_or(const float* p, int c, float dflt) {
   fvec<V> o;
+  if (p) {
 #pragma unroll
-  for (int i = 0; i < V; ++i) o.v[i] = p ? p[c + i] : dflt;
+    for (int i = 0; i < V; i += 4) {
+      const float4 a = ld4(p + c + i);
+      o.v[i] = a.x; o.v[i + 1] = a.y; o.v[i + 2] = a.z; o.v[i + 3] = a.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < V; ++i) o.v[i] = dflt;
+  }
   return o;
 }
 template <int V> __device__ __forceinline__ fvec<V> fzero() {

@@ -26,7 +26,8 @@ inline bool vec8(int C, int lda, int ldb = 8, int ldc = 8) { return C % 8 == 0 &
 inline int ew_setup_b(EwB& p, long long M, int C, int V, int max_rows, int per_cu = 4) {
   const LaneSplit s = lane_split(C, V);
   p.cs = s.cs; p.px = s.px; p.nslab = s.nslab;
-  long long need = ceil_div_ll(M, p.px);
+  // at least 4 rows per thread: the per-thread coefficient loads and the launch are amortised over them
+  long long need = ceil_div_ll(M, (long long)p.px * 4);
   long long target = DL3P_NUM_CUS * per_cu / p.nslab;
   if (target < 1) target = 1;
   long long nbx = need < target ? need : target;

@@ -170,6 +170,8 @@ __global__ __launch_bounds__(256) void dwb_bwd_weight(DwB p) {
   dw_block_reduce<4, KS * KS>(acc, active, pl, cl, p.cs, p.px, cbase, p.C, p.partials + (size_t)bx * KS * KS * p.C);
 }
 
+#include "dw_bf16_strip.h"
+
 int dw_check(const char* fn, const void* a, int lda, int C, int k, int stride) {
   DL3P_CHECK_ARG(a != nullptr && ((uintptr_t)a & 7u) == 0, "%s: bad pointer", fn);
   DL3P_CHECK_ARG(C > 0 && C % 4 == 0 && lda % 4 == 0 && lda >= C, "%s: bad layout (C=%d ld=%d)", fn, C, lda);
@@ -212,11 +214,23 @@ extern "C" int dl3p_dwconv2d_fwd_bf16(const void* x, int ldx, const float* in_sc
   p.N = N; p.H = H; p.W = W; p.C = C; p.k = k; p.stride = stride; p.rate = rate; p.pad_t = pad_t; p.pad_l = pad_l;
   p.Ho = Ho; p.Wo = Wo;
   const bool v8 = k == 3 && ok8(C, x, ldx, y, ldy) && aligned16(w);
+  hipStream_t st = (hipStream_t)stream;
+  // (dl3p_launch: the forward depthwise launch can carry bench.py's HIP event pair, dl3p_probe_arm)
+  if (stride == 1) {
+    const StripGeo geo = strip_geo(Wo, rate, 4);
+    dw_grid(p, v8 ? 8 : 4, (long long)N * Ho * geo.nsr, 4, DL3P_MAX_STAT_ROWS);
+    if (rows_out) *rows_out = p.nbx;
+    const dim3 grid(p.nbx * p.nslab);
+    const bool hs = in_act >= DL3P_ACT_HSWISH;
+    if (k == 3 && v8) { if (hs) dl3p_launch(dwb_fwd_strip<8, 3, 4, true>, grid, dim3(256), 0, st, p, geo); else dl3p_launch(dwb_fwd_strip<8, 3, 4, false>, grid, dim3(256), 0, st, p, geo); }
+    else if (k == 3) { if (hs) dl3p_launch(dwb_fwd_strip<4, 3, 4, true>, grid, dim3(256), 0, st, p, geo); else dl3p_launch(dwb_fwd_strip<4, 3, 4, false>, grid, dim3(256), 0, st, p, geo); }
+    else { if (hs) dl3p_launch(dwb_fwd_strip<4, 5, 4, true>, grid, dim3(256), 0, st, p, geo); else dl3p_launch(dwb_fwd_strip<4, 5, 4, false>, grid, dim3(256), 0, st, p, geo); }
+    DL3P_CHECK_LAUNCH("dl3p_dwconv2d_fwd_bf16");
+    return DL3P_OK;
+  }
   dw_grid(p, v8 ? 8 : 4, (long long)N * Ho * Wo, 8, DL3P_MAX_STAT_ROWS);
   if (rows_out) *rows_out = p.nbx;
-  hipStream_t st = (hipStream_t)stream;
   const dim3 grid(p.nbx * p.nslab);
-  // (dl3p_launch: the forward depthwise launch can carry bench.py's HIP event pair, dl3p_probe_arm)
   if (k == 3 && v8) dl3p_launch(dwb_fwd<8, 3>, grid, dim3(256), 0, st, p);
   else if (k == 3) dl3p_launch(dwb_fwd<4, 3>, grid, dim3(256), 0, st, p);
   else dl3p_launch(dwb_fwd<4, 5>, grid, dim3(256), 0, st, p);
@@ -237,8 +251,18 @@ extern "C" int dl3p_dwconv2d_bwd_data_bf16(const void* dy, int lddy, const void*
   p.N = N; p.H = H; p.W = W; p.C = C; p.k = k; p.stride = stride; p.rate = rate; p.pad_t = pad_t; p.pad_l = pad_l;
   p.Ho = Ho; p.Wo = Wo;
   const bool v8 = k == 3 && ok8(C, dy, lddy, gx, ldgx) && aligned16(w);
-  dw_grid(p, v8 ? 8 : 4, (long long)N * H * W, 8, 1 << 20);
   hipStream_t st = (hipStream_t)stream;
+  if (stride == 1) {
+    const StripGeo geo = strip_geo(W, rate, 4);
+    dw_grid(p, v8 ? 8 : 4, (long long)N * H * geo.nsr, 4, 1 << 20);
+    const dim3 sgrid(p.nbx * p.nslab);
+    if (k == 3 && v8) hipLaunchKernelGGL((dwb_bwd_data_strip<8, 3, 4>), sgrid, dim3(256), 0, st, p, geo);
+    else if (k == 3) hipLaunchKernelGGL((dwb_bwd_data_strip<4, 3, 4>), sgrid, dim3(256), 0, st, p, geo);
+    else hipLaunchKernelGGL((dwb_bwd_data_strip<4, 5, 4>), sgrid, dim3(256), 0, st, p, geo);
+    DL3P_CHECK_LAUNCH("dl3p_dwconv2d_bwd_data_bf16");
+    return DL3P_OK;
+  }
+  dw_grid(p, v8 ? 8 : 4, (long long)N * H * W, 8, 1 << 20);
   const dim3 grid(p.nbx * p.nslab);
   if (k == 3 && v8) hipLaunchKernelGGL((dwb_bwd_data<8, 3>), grid, dim3(256), 0, st, p);
   else if (k == 3) hipLaunchKernelGGL((dwb_bwd_data<4, 3>), grid, dim3(256), 0, st, p);
@@ -276,8 +300,19 @@ extern "C" int dl3p_dwconv2d_bwd_weight_bf16(const void* x, int ldx, const float
   p.dy = (const bf16*)dy; p.lddy = lddy; p.partials = workspace;
   p.N = N; p.H = H; p.W = W; p.C = C; p.k = k; p.stride = stride; p.rate = rate; p.pad_t = pad_t; p.pad_l = pad_l;
   p.Ho = Ho; p.Wo = Wo;
-  dw_grid(p, 4, (long long)N * Ho * Wo, 2, 512);
   hipStream_t st = (hipStream_t)stream;
+  const int rows = dww_rows(N, Ho, Wo, C);          // what the workspace was sized for
+  if (stride == 1) {
+    const StripGeo geo = strip_geo(Wo, rate, 4);
+    dw_grid(p, 4, (long long)N * Ho * geo.nsr, 2, rows);
+    const dim3 sgrid(p.nbx * p.nslab);
+    const bool hs = in_act >= DL3P_ACT_HSWISH;
+    if (k == 3) { if (hs) hipLaunchKernelGGL((dwb_bwd_weight_strip<3, 4, true>), sgrid, dim3(256), 0, st, p, geo); else hipLaunchKernelGGL((dwb_bwd_weight_strip<3, 4, false>), sgrid, dim3(256), 0, st, p, geo); }
+    else { if (hs) hipLaunchKernelGGL((dwb_bwd_weight_strip<5, 4, true>), sgrid, dim3(256), 0, st, p, geo); else hipLaunchKernelGGL((dwb_bwd_weight_strip<5, 4, false>), sgrid, dim3(256), 0, st, p, geo); }
+    DL3P_CHECK_LAUNCH("dl3p_dwconv2d_bwd_weight_bf16");
+    return dl3p_reduce_rows_impl(workspace, p.nbx, (size_t)k * k * C, gw, 0, st);
+  }
+  dw_grid(p, 4, (long long)N * Ho * Wo, 2, rows);
   const dim3 grid(p.nbx * p.nslab);
   if (k == 3) hipLaunchKernelGGL((dwb_bwd_weight<3>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((dwb_bwd_weight<5>), grid, dim3(256), 0, st, p);

@@ -16,6 +16,7 @@
 // over rows): tiles are staged row-major and read back with ds_read_b64_tr_b16, the hardware transpose read.
 #include "bf16.h"
 #include <string.h>
+#include <type_traits>
 
 namespace {
 
@@ -37,16 +38,32 @@ struct GemmB {
 template <bool F32> struct AType { typedef bf16 type; };
 template <> struct AType<true> { typedef float type; };
 
-// NT: 16-column tiles per workgroup; A_F32 / Y_F32: the logits tensor (conv_upsample output and its gradient) stays
-// fp32 so that the softmax / loss head is the fp32 one
-template <int NT, bool A_F32, bool Y_F32, bool STATS>
+// raw (as loaded) 8-element chunk of an operand: 4 VGPRs for bf16, 8 for fp32
+template <bool F32> struct Raw8 { bf16x8 v; };
+template <> struct Raw8<true> { float4 a, b; };
+__device__ __forceinline__ Raw8<false> ld_raw(const bf16* p) { Raw8<false> r; r.v = *reinterpret_cast<const bf16x8*>(p); return r; }
+__device__ __forceinline__ Raw8<true> ld_raw(const float* p) { Raw8<true> r; r.a = ld4(p); r.b = ld4(p + 4); return r; }
+__device__ __forceinline__ float raw_get(const Raw8<false>& r, int e) { return (float)r.v[e]; }
+__device__ __forceinline__ float raw_get(const Raw8<true>& r, int e) {
+  return e == 0 ? r.a.x : e == 1 ? r.a.y : e == 2 ? r.a.z : e == 3 ? r.a.w : e == 4 ? r.b.x : e == 5 ? r.b.y : e == 6 ? r.b.z : r.b.w;
+}
+
+constexpr int KMAX_LDS = 2048;      // per-channel prologue coefficients of up to this many input channels sit in LDS
+
+// NT: 16-column tiles per workgroup; MI: 16-row tiles per wave (BM = 64 MI rows per workgroup); A_F32 / Y_F32: the logits
+// tensor (conv_upsample output and its gradient) stays fp32 so that the softmax / loss head is the fp32 one.
+// The operand loads of K-step it + 2 are issued while step it is multiplied (two register slots): at 1-2 workgroups of
+// work per CU and 0.3 us per K-step a single step of lookahead left the ~2 us HBM latency exposed on every step.
+template <int NT, int MI, bool A_F32, bool Y_F32, bool STATS>
 __global__ __launch_bounds__(256, 2) void pwb_gemm(GemmB p) {
-  constexpr int BM = 128, BN = 16 * NT;
+  constexpr int BM = 64 * MI, BN = 16 * NT;
   constexpr int NB = (BN * 4 + 255) / 256;      // 16-B chunks of the B tile per thread
+  constexpr int PD = 2;                         // K-steps of loads in flight
   typedef typename AType<A_F32>::type TA;
   typedef typename AType<Y_F32>::type TY;
   __shared__ __attribute__((aligned(16))) bf16 As[BM * LP];
   __shared__ __attribute__((aligned(16))) bf16 Bs[BN * LP];
+  __shared__ __attribute__((aligned(16))) float coef[2 * KMAX_LDS];
   __shared__ float red[STATS ? 2 * 4 * BN : 1];
   const int t = threadIdx.x, l = t & 63, w = t >> 6, r = l & 15, kg = l >> 4;
   const int n0 = blockIdx.y * BN;
@@ -55,50 +72,71 @@ __global__ __launch_bounds__(256, 2) void pwb_gemm(GemmB p) {
   const int it_total = my_tiles * nk;
   const TA* Ap = reinterpret_cast<const TA*>(p.A);
   TY* Yp = reinterpret_cast<TY*>(p.Y);
-  const int ar = t >> 2, ac = (t & 3) * 8;      // A staging role: rows ar, ar + 64; k offset ac
+  const int ar = t >> 2, ac = (t & 3) * 8;      // A staging role: rows ar + 64 i; k offset ac
   const bool has_pro = p.scale != nullptr || p.act != DL3P_ACT_NONE;
+  const bool coef_lds = p.scale != nullptr && p.K <= KMAX_LDS;
+  if (coef_lds) {
+    const int kpad = nk * BK;
+    for (int i = t; i < kpad; i += 256) {
+      coef[i] = i < p.K ? p.scale[i] : 1.f;
+      coef[KMAX_LDS + i] = i < p.K ? p.shift[i] : 0.f;
+    }
+  }
 
-  fvec<8> ra[2], sc, sh;
-  bf16x8 rb[NB];
-  bool a_ok[2], b_ok[NB];
-  sc = ldv_f32_or<8>(nullptr, 0, 1.f);
-  sh = fzero<8>();
+  Raw8<A_F32> ra[PD][MI];
+  bf16x8 rb[PD][NB];
+  bool a_ok[PD][MI], b_ok[PD][NB];
 
-  auto prefetch = [&](int it) {
+  auto prefetch = [&](auto slot_c, int it) {
+    constexpr int S = decltype(slot_c)::value;
     const int kt = it % nk, mt = blockIdx.x + (it / nk) * gridDim.x;
     const int m0 = mt * BM, k0 = kt * BK;
     const int k = k0 + ac;
     const bool kok = k < p.K;                     // K % 8 == 0: a chunk is inside or outside as a whole
     const int kc = kok ? k : 0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
       const int m = m0 + ar + 64 * i;
-      a_ok[i] = kok && m < p.M;
-      ra[i] = ldv<8>(Ap + (size_t)min(m, p.M - 1) * p.lda + kc);
-    }
-    if (p.scale) {
-      sc = ldv<8>(p.scale + kc);
-      sh = ldv<8>(p.shift + kc);
+      a_ok[S][i] = kok && m < p.M;
+      ra[S][i] = ld_raw(Ap + (size_t)min(m, p.M - 1) * p.lda + kc);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int idx = t + 256 * i;
       const int br = idx >> 2, bc = (idx & 3) * 8;
       const int n = n0 + br, kk = k0 + bc;
-      b_ok[i] = idx < BN * 4 && n < p.N && kk < p.K;
-      rb[i] = *reinterpret_cast<const bf16x8*>(p.B + (size_t)min(n, p.N - 1) * p.ldb + (kk < p.K ? kk : 0));
+      b_ok[S][i] = idx < BN * 4 && n < p.N && kk < p.K;
+      rb[S][i] = *reinterpret_cast<const bf16x8*>(p.B + (size_t)min(n, p.N - 1) * p.ldb + (kk < p.K ? kk : 0));
     }
   };
 
-  auto stage = [&]() {
+  auto stage = [&](auto slot_c, int it) {
+    constexpr int S = decltype(slot_c)::value;
+    const int k = (it % nk) * BK + ac;
+    float sc[8], sh[8];
+    if (p.scale) {
+      if (coef_lds) {
+        const float4 s0 = *reinterpret_cast<const float4*>(&coef[k]), s1 = *reinterpret_cast<const float4*>(&coef[k + 4]);
+        const float4 h0 = *reinterpret_cast<const float4*>(&coef[KMAX_LDS + k]), h1 = *reinterpret_cast<const float4*>(&coef[KMAX_LDS + k + 4]);
+        sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+        sh[0] = h0.x; sh[1] = h0.y; sh[2] = h0.z; sh[3] = h0.w; sh[4] = h1.x; sh[5] = h1.y; sh[6] = h1.z; sh[7] = h1.w;
+      } else {
+        const int kc = k < p.K ? k : 0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+        for (int e = 0; e < 8; ++e) { sc[e] = p.scale[kc + e]; sh[e] = p.shift[kc + e]; }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
       bf16x8 v;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float x = ra[i].v[e];
-        if (has_pro) x = act_apply(fmaf(x, sc.v[e], sh.v[e]), p.act);
-        v[e] = a_ok[i] ? (bf16)x : (bf16)0.f;
+        float x = raw_get(ra[S][i], e);
+        if (has_pro) x = act_apply(fmaf(x, sc[e], sh[e]), p.act);
+        v[e] = a_ok[S][i] ? (bf16)x : (bf16)0.f;
       }
       *reinterpret_cast<bf16x8*>(&As[(ar + 64 * i) * LP + ac]) = v;
     }
@@ -106,8 +144,8 @@ __global__ __launch_bounds__(256, 2) void pwb_gemm(GemmB p) {
     for (int i = 0; i < NB; ++i) {
       const int idx = t + 256 * i;
       if (idx < BN * 4) {
-        bf16x8 v = rb[i];
-        if (!b_ok[i]) {
+        bf16x8 v = rb[S][i];
+        if (!b_ok[S][i]) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
         }
@@ -116,9 +154,9 @@ __global__ __launch_bounds__(256, 2) void pwb_gemm(GemmB p) {
     }
   };
 
-  f32x4v acc[2][NT];
+  f32x4v acc[MI][NT];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = (f32x4v){0.f, 0.f, 0.f, 0.f};
   float st_s[STATS ? NT : 1][4], st_q[STATS ? NT : 1][4];
@@ -129,28 +167,27 @@ __global__ __launch_bounds__(256, 2) void pwb_gemm(GemmB p) {
       for (int j = 0; j < 4; ++j) { st_s[ni][j] = 0.f; st_q[ni][j] = 0.f; }
   }
 
-  if (it_total > 0) prefetch(0);
-  for (int it = 0; it < it_total; ++it) {
-    stage();
+  auto step = [&](auto slot_c, int it) {
+    stage(slot_c, it);
     __syncthreads();
-    if (it + 1 < it_total) prefetch(it + 1);
-    bf16x8 af[2];
+    if (it + PD < it_total) prefetch(slot_c, it + PD);      // the slot just staged is free again
+    bf16x8 af[MI];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(&As[(w * 32 + mi * 16 + r) * LP + kg * 8]);
+    for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(&As[(w * 16 * MI + mi * 16 + r) * LP + kg * 8]);
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
       const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(&Bs[(ni * 16 + r) * LP + kg * 8]);
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr, af[mi], acc[mi][ni], 0, 0, 0);
+      for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr, af[mi], acc[mi][ni], 0, 0, 0);
     }
     __syncthreads();
     if (it % nk == nk - 1) {
-      // epilogue of this M tile: lane (r, kg) holds channels n = n0 + 16 ni + 4 kg + j of pixel m = m0 + 32 w + 16 mi + r
+      // epilogue of this M tile: lane (r, kg) holds channels n = n0 + 16 ni + 4 kg + j of pixel m = m0 + 16 MI w + 16 mi + r
       const int mt = blockIdx.x + (it / nk) * gridDim.x;
       const int m0 = mt * BM;
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int m = m0 + w * 32 + mi * 16 + r;
+      for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + w * 16 * MI + mi * 16 + r;
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
           const int n = n0 + ni * 16 + kg * 4;
@@ -172,6 +209,14 @@ __global__ __launch_bounds__(256, 2) void pwb_gemm(GemmB p) {
         }
       }
     }
+  };
+
+  __syncthreads();                 // the coefficient table
+  if (it_total > 0) prefetch(std::integral_constant<int, 0>{}, 0);
+  if (it_total > 1) prefetch(std::integral_constant<int, 1>{}, 1);
+  for (int it = 0; it < it_total; it += PD) {
+    step(std::integral_constant<int, 0>{}, it);
+    if (it + 1 < it_total) step(std::integral_constant<int, 1>{}, it + 1);
   }
 
   if (STATS) {
@@ -258,6 +303,7 @@ __global__ __launch_bounds__(256, 2) void pwb_wgrad(WgradB p) {
   constexpr int TK = 64, TN = 16 * NW;
   constexpr int XP = TK + 8, DP = TN + 8;           // pitches (bf16): 8-byte aligned rows for the transposed reads
   constexpr int ND = (32 * TN / 8 + 255) / 256;     // 16-B chunks of the DY tile per thread
+  constexpr int PD = 4;                             // 32-row steps of loads in flight (a step is ~0.2 us of work)
   typedef typename AType<DY_F32>::type TD;
   __shared__ __attribute__((aligned(16))) bf16 Xs[32 * XP];
   __shared__ __attribute__((aligned(16))) bf16 Ds[32 * DP];
@@ -276,31 +322,32 @@ __global__ __launch_bounds__(256, 2) void pwb_wgrad(WgradB p) {
   for (int ni = 0; ni < NW; ++ni) acc[ni] = (f32x4v){0.f, 0.f, 0.f, 0.f};
   // transposed-read addresses: lane (g = l >> 4, i = l & 15 = 4q + pp) supplies row 8g + q (+4), columns 4pp..4pp+3
   const int g = l >> 4, q = (l & 15) >> 2, pp = l & 3;
-  fvec<8> rx;
-  fvec<8> rd[ND];
-  bool x_ok, d_ok[ND];
-  auto prefetch = [&](int m0) {
+  Raw8<false> rx[PD];
+  Raw8<DY_F32> rd[PD][ND];
+  bool x_ok[PD], d_ok[PD][ND];
+  auto prefetch = [&](auto slot_c, int m0) {
+    constexpr int S = decltype(slot_c)::value;
     const int m = m0 + xm;
-    x_ok = xk_ok && m < mend;
-    rx = ldv<8>(p.X + (size_t)min(m, p.M - 1) * p.ldx + (xk_ok ? xk : 0));
+    x_ok[S] = xk_ok && m < mend;
+    rx[S] = ld_raw(p.X + (size_t)min(m, p.M - 1) * p.ldx + (xk_ok ? xk : 0));
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
       const int idx = t + 256 * i;
       const int dm = idx / (TN / 8), dc = (idx - dm * (TN / 8)) * 8;
       const int mm = m0 + dm, n = n0 + dc;
-      d_ok[i] = idx < 32 * TN / 8 && mm < mend && n < p.N;
-      rd[i] = ldv<8>(Dp + (size_t)min(mm, p.M - 1) * p.lddy + (n < p.N ? n : 0));
+      d_ok[S][i] = idx < 32 * TN / 8 && mm < mend && n < p.N;
+      rd[S][i] = ld_raw(Dp + (size_t)min(mm, p.M - 1) * p.lddy + (n < p.N ? n : 0));
     }
   };
-  if (mbeg < mend) prefetch(mbeg);
-  for (int m0 = mbeg; m0 < mend; m0 += 32) {
+  auto step = [&](auto slot_c, int m0) {
+    constexpr int S = decltype(slot_c)::value;
     {
       bf16x8 v;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float x = rx.v[e];
+        float x = raw_get(rx[S], e);
         if (has_pro) x = act_apply(fmaf(x, sc.v[e], sh.v[e]), p.act);
-        v[e] = x_ok ? (bf16)x : (bf16)0.f;
+        v[e] = x_ok[S] ? (bf16)x : (bf16)0.f;
       }
       *reinterpret_cast<bf16x8*>(&Xs[xm * XP + (t & 7) * 8]) = v;
 #pragma unroll
@@ -310,13 +357,13 @@ __global__ __launch_bounds__(256, 2) void pwb_wgrad(WgradB p) {
           const int dm = idx / (TN / 8), dc = (idx - dm * (TN / 8)) * 8;
           bf16x8 dv;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) dv[e] = d_ok[i] ? (bf16)rd[i].v[e] : (bf16)0.f;
+          for (int e = 0; e < 8; ++e) dv[e] = d_ok[S][i] ? (bf16)raw_get(rd[S][i], e) : (bf16)0.f;
           *reinterpret_cast<bf16x8*>(&Ds[dm * DP + dc]) = dv;
         }
       }
     }
     __syncthreads();
-    if (m0 + 32 < mend) prefetch(m0 + 32);
+    if (m0 + 32 * PD < mend) prefetch(slot_c, m0 + 32 * PD);
     // A operand (16 k rows x 32 m) of this wave, B operands (32 m x 16 n) per column tile; EXEC is full here
     const bf16x4 a0 = tr_read(&Xs[(8 * g + q) * XP + w * 16 + 4 * pp]);
     const bf16x4 a1 = tr_read(&Xs[(8 * g + 4 + q) * XP + w * 16 + 4 * pp]);
@@ -329,6 +376,16 @@ __global__ __launch_bounds__(256, 2) void pwb_wgrad(WgradB p) {
       acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[ni], 0, 0, 0);
     }
     __syncthreads();
+  };
+  if (mbeg < mend) prefetch(std::integral_constant<int, 0>{}, mbeg);
+  if (mbeg + 32 < mend) prefetch(std::integral_constant<int, 1>{}, mbeg + 32);
+  if (mbeg + 64 < mend) prefetch(std::integral_constant<int, 2>{}, mbeg + 64);
+  if (mbeg + 96 < mend) prefetch(std::integral_constant<int, 3>{}, mbeg + 96);
+  for (int m0 = mbeg; m0 < mend; m0 += 32 * PD) {
+    step(std::integral_constant<int, 0>{}, m0);
+    if (m0 + 32 < mend) step(std::integral_constant<int, 1>{}, m0 + 32);
+    if (m0 + 64 < mend) step(std::integral_constant<int, 2>{}, m0 + 64);
+    if (m0 + 96 < mend) step(std::integral_constant<int, 3>{}, m0 + 96);
   }
   // D[row = 4 (l >> 4) + j -> k][col = l & 15 -> n]
   float* slab = p.slabs + (size_t)blockIdx.y * p.K * p.N;
@@ -405,14 +462,15 @@ int pick_nt_b(int N, bool stats) {
   return nt;
 }
 
-template <bool A_F32, bool Y_F32, bool STATS>
+template <int MI, bool A_F32, bool Y_F32, bool STATS>
 void launch_gemm_b(const GemmB& p, int nt, dim3 grid, hipStream_t st) {
   switch (nt) {
-    case 2: hipLaunchKernelGGL((pwb_gemm<2, A_F32, Y_F32, STATS>), grid, dim3(256), 0, st, p); break;
-    case 4: hipLaunchKernelGGL((pwb_gemm<4, A_F32, Y_F32, STATS>), grid, dim3(256), 0, st, p); break;
-    case 8: hipLaunchKernelGGL((pwb_gemm<8, A_F32, Y_F32, STATS>), grid, dim3(256), 0, st, p); break;
+    case 2: hipLaunchKernelGGL((pwb_gemm<2, MI, A_F32, Y_F32, STATS>), grid, dim3(256), 0, st, p); break;
+    case 4: hipLaunchKernelGGL((pwb_gemm<4, MI, A_F32, Y_F32, STATS>), grid, dim3(256), 0, st, p); break;
+    case 8: hipLaunchKernelGGL((pwb_gemm<8, MI, A_F32, Y_F32, STATS>), grid, dim3(256), 0, st, p); break;
     default:
-      if constexpr (!STATS) hipLaunchKernelGGL((pwb_gemm<16, A_F32, Y_F32, false>), grid, dim3(256), 0, st, p);
+      // 256 columns per workgroup: 64-row tiles only (128 accumulator registers at 128 rows spill next to the load ring)
+      if constexpr (!STATS && MI == 1) hipLaunchKernelGGL((pwb_gemm<16, 1, A_F32, Y_F32, false>), grid, dim3(256), 0, st, p);
       break;
   }
 }
@@ -430,7 +488,9 @@ int gemm_b(const char* fn, GemmB p, bool a_f32, bool y_f32, int* rows_out, hipSt
   const bool stats = p.partials != nullptr;
   const int nt = pick_nt_b(p.N, stats);
   const int gy = ceil_div(p.N, 16 * nt);
-  p.num_m_tiles = ceil_div(p.M, 128);
+  // 64-row tiles whenever 128-row tiles would leave the chip under two workgroups per CU (the 64 x 128 maps: M = 8192)
+  const int mi = (nt == 16 || (long long)ceil_div(p.M, 128) * gy < 2LL * DL3P_NUM_CUS) ? 1 : 2;
+  p.num_m_tiles = ceil_div(p.M, 64 * mi);
   int gx_max = (DL3P_NUM_CUS * 4) / gy;
   if (gx_max < 8) gx_max = 8;
   if (gx_max > DL3P_MAX_STAT_ROWS) gx_max = DL3P_MAX_STAT_ROWS;
@@ -438,10 +498,15 @@ int gemm_b(const char* fn, GemmB p, bool a_f32, bool y_f32, int* rows_out, hipSt
   if (gx > gx_max) gx = ceil_div(p.num_m_tiles, ceil_div(p.num_m_tiles, gx_max));
   if (rows_out) *rows_out = gx;
   const dim3 grid(gx, gy);
-  if (a_f32) launch_gemm_b<true, false, false>(p, nt, grid, st);
-  else if (y_f32) launch_gemm_b<false, true, false>(p, nt, grid, st);
-  else if (stats) launch_gemm_b<false, false, true>(p, nt, grid, st);
-  else launch_gemm_b<false, false, false>(p, nt, grid, st);
+#define DL3P_GB(MIV)                                                                \
+  do {                                                                              \
+    if (a_f32) launch_gemm_b<MIV, true, false, false>(p, nt, grid, st);             \
+    else if (y_f32) launch_gemm_b<MIV, false, true, false>(p, nt, grid, st);        \
+    else if (stats) launch_gemm_b<MIV, false, false, true>(p, nt, grid, st);        \
+    else launch_gemm_b<MIV, false, false, false>(p, nt, grid, st);                  \
+  } while (0)
+  if (mi == 1) DL3P_GB(1); else DL3P_GB(2);
+#undef DL3P_GB
   DL3P_CHECK_LAUNCH(fn);
   return DL3P_OK;
 }
