@@ -16,6 +16,7 @@
 // over rows): tiles are staged row-major and read back with ds_read_b64_tr_b16, the hardware transpose read.
 #include "bf16.h"
 #include <string.h>
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -33,14 +34,21 @@ struct GemmB {
   int M, K, N;
   int accumulate;
   int num_m_tiles;
+  int dbg;              // DL3P_BF16_DBG ablation bits (timing experiments only): 1 no stores, 2 no A loads, 4 no B loads
 };
 
 template <bool F32> struct AType { typedef bf16 type; };
 template <> struct AType<true> { typedef float type; };
 
 // raw (as loaded) 8-element chunk of an operand: 4 VGPRs for bf16, 8 for fp32
-template <bool F32> struct Raw8 { bf16x8 v; };
-template <> struct Raw8<true> { float4 a, b; };
+template <bool F32> struct Raw8 {
+  bf16x8 v;
+  __device__ __forceinline__ bf16x8 v_or_zero() const { return v; }
+};
+template <> struct Raw8<true> {
+  float4 a, b;
+  __device__ __forceinline__ bf16x8 v_or_zero() const { return bf16x8{}; }     // (never taken: fp32 operands are converted)
+};
 __device__ __forceinline__ Raw8<false> ld_raw(const bf16* p) { Raw8<false> r; r.v = *reinterpret_cast<const bf16x8*>(p); return r; }
 __device__ __forceinline__ Raw8<true> ld_raw(const float* p) { Raw8<true> r; r.a = ld4(p); r.b = ld4(p + 4); return r; }
 __device__ __forceinline__ float raw_get(const Raw8<false>& r, int e) { return (float)r.v[e]; }
@@ -55,7 +63,7 @@ constexpr int KMAX_LDS = 2048;      // per-channel prologue coefficients of up t
 // The operand loads of K-step it + 2 are issued while step it is multiplied (two register slots): at 1-2 workgroups of
 // work per CU and 0.3 us per K-step a single step of lookahead left the ~2 us HBM latency exposed on every step.
 template <int NT, int MI, bool A_F32, bool Y_F32, bool STATS>
-__global__ __launch_bounds__(256, 2) void pwb_gemm(GemmB p) {
+__global__ __launch_bounds__(256, (NT * MI <= 8 && !(STATS && NT * MI > 4)) ? 4 : (NT * MI <= 8 ? 3 : 2)) void pwb_gemm(GemmB p) {
   constexpr int BM = 64 * MI, BN = 16 * NT;
   constexpr int NB = (BN * 4 + 255) / 256;      // 16-B chunks of the B tile per thread
   constexpr int PD = 2;                         // K-steps of loads in flight
@@ -74,6 +82,8 @@ __global__ __launch_bounds__(256, 2) void pwb_gemm(GemmB p) {
   TY* Yp = reinterpret_cast<TY*>(p.Y);
   const int ar = t >> 2, ac = (t & 3) * 8;      // A staging role: rows ar + 64 i; k offset ac
   const bool has_pro = p.scale != nullptr || p.act != DL3P_ACT_NONE;
+  const float act_lo = p.act == DL3P_ACT_NONE ? -DL3P_INF : 0.f;
+  const float act_hi = (p.act == DL3P_ACT_NONE || p.act == DL3P_ACT_RELU) ? DL3P_INF : 6.f;
   const bool coef_lds = p.scale != nullptr && p.K <= KMAX_LDS;
   if (coef_lds) {
     const int kpad = nk * BK;
@@ -98,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void pwb_gemm(GemmB p) {
     for (int i = 0; i < MI; ++i) {
       const int m = m0 + ar + 64 * i;
       a_ok[S][i] = kok && m < p.M;
-      ra[S][i] = ld_raw(Ap + (size_t)min(m, p.M - 1) * p.lda + kc);
+      if (!(p.dbg & 2) || it < PD) ra[S][i] = ld_raw(Ap + (size_t)min(m, p.M - 1) * p.lda + kc);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -106,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void pwb_gemm(GemmB p) {
       const int br = idx >> 2, bc = (idx & 3) * 8;
       const int n = n0 + br, kk = k0 + bc;
       b_ok[S][i] = idx < BN * 4 && n < p.N && kk < p.K;
-      rb[S][i] = *reinterpret_cast<const bf16x8*>(p.B + (size_t)min(n, p.N - 1) * p.ldb + (kk < p.K ? kk : 0));
+      if (!(p.dbg & 4) || it < PD) rb[S][i] = *reinterpret_cast<const bf16x8*>(p.B + (size_t)min(n, p.N - 1) * p.ldb + (kk < p.K ? kk : 0));
     }
   };
 
@@ -129,14 +139,26 @@ __global__ __launch_bounds__(256, 2) void pwb_gemm(GemmB p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
     }
+    // interior tiles (wave-uniform: no M / K / N tail in this step) skip the zero-fill selects; the clamp family of
+    // activations is one fma + one clamp per element (the same arithmetic as act_apply, so both paths round alike)
+    const int mt_ = blockIdx.x + (it / nk) * gridDim.x;
+    const bool edge = mt_ * BM + BM > p.M || (it % nk) * BK + BK > p.K || n0 + BN > p.N;
+    const bool hsw = p.act >= DL3P_ACT_HSWISH;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       bf16x8 v;
+      if (!has_pro && !A_F32) {
+        v = ra[S][i].v_or_zero();
+      } else if (!hsw) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float x = raw_get(ra[S][i], e);
-        if (has_pro) x = act_apply(fmaf(x, sc[e], sh[e]), p.act);
-        v[e] = a_ok[S][i] ? (bf16)x : (bf16)0.f;
+        for (int e = 0; e < 8; ++e) v[e] = (bf16)fminf(fmaxf(fmaf(raw_get(ra[S][i], e), sc[e], sh[e]), act_lo), act_hi);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (bf16)act_apply(fmaf(raw_get(ra[S][i], e), sc[e], sh[e]), p.act);
+      }
+      if (edge && !a_ok[S][i]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
       }
       *reinterpret_cast<bf16x8*>(&As[(ar + 64 * i) * LP + ac]) = v;
     }
@@ -145,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void pwb_gemm(GemmB p) {
       const int idx = t + 256 * i;
       if (idx < BN * 4) {
         bf16x8 v = rb[S][i];
-        if (!b_ok[S][i]) {
+        if (edge && !b_ok[S][i]) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
         }
@@ -198,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void pwb_gemm(GemmB p) {
             if (p.bias) o = add4(o, ld4(p.bias + n));
             TY* yp = Yp + (size_t)m * p.ldy + n;
             if (p.accumulate) o = add4(o, ld4(yp));
-            st4(yp, o);
+            if (!(p.dbg & 1)) st4(yp, o);
             if (STATS) {
               const float4 q = Y_F32 ? o : bf16_round4(o);      // statistics of the values the consumers will read
               st_s[ni][0] += q.x; st_s[ni][1] += q.y; st_s[ni][2] += q.z; st_s[ni][3] += q.w;
@@ -485,11 +507,15 @@ int gemm_b(const char* fn, GemmB p, bool a_f32, bool y_f32, int* rows_out, hipSt
     DL3P_CHECK_LAUNCH(fn);
     return DL3P_OK;
   }
+  static const int dbg = getenv("DL3P_BF16_DBG") ? atoi(getenv("DL3P_BF16_DBG")) : 0;
+  p.dbg = dbg;
   const bool stats = p.partials != nullptr;
   const int nt = pick_nt_b(p.N, stats);
   const int gy = ceil_div(p.N, 16 * nt);
   // 64-row tiles whenever 128-row tiles would leave the chip under two workgroups per CU (the 64 x 128 maps: M = 8192)
-  const int mi = (nt == 16 || (long long)ceil_div(p.M, 128) * gy < 2LL * DL3P_NUM_CUS) ? 1 : 2;
+  int mi = (nt == 16 || (long long)ceil_div(p.M, 128) * gy < 2LL * DL3P_NUM_CUS) ? 1 : 2;
+  static const int force_mi = getenv("DL3P_BF16_MI") ? atoi(getenv("DL3P_BF16_MI")) : 0;     // A/B knob
+  if (force_mi && nt != 16) mi = force_mi;
   p.num_m_tiles = ceil_div(p.M, 64 * mi);
   int gx_max = (DL3P_NUM_CUS * 4) / gy;
   if (gx_max < 8) gx_max = 8;
