@@ -267,6 +267,225 @@ __global__ __launch_bounds__(256, (NT * MI <= 8 && !(STATS && NT * MI > 4)) ? 4 
   }
 }
 
+// ------------------------------------------------------------------------------ streaming GEMM: B resident in LDS
+// For K <= 640 the whole [BN][K] weight tile of a workgroup fits LDS as bf16.  Then nothing in the K loop is shared
+// any more: every WAVE walks its own 32-row tiles, loads its A fragments straight from global memory in MFMA operand
+// layout (lane (r, kg) reads the 16 bytes X[m0 + r][32 ks + 8 kg ..]: the same 16 rows x 64 B per instruction the staged
+// kernel issued), applies the BatchNorm + activation prologue in registers and multiplies against B fragments read from
+// LDS.  No barrier, no A staging pass, no lockstep between waves: the 8 waves of a workgroup drift apart and cover each
+// other's memory latency, which is what these HBM-bound layers need (the tiled kernel above spent ~2 us per 32-deep
+// K-step in staging + two barriers, with or without its global loads).  Loads run one chunk of CH K-steps ahead: raw
+// registers are converted to fragments, re-issued for the next chunk, then the chunk's MFMAs run.
+template <int NT, bool A_F32, bool Y_F32, bool STATS>
+__global__ __launch_bounds__(512, 1) void pwb_stream(GemmB p, int kp, int tiles) {
+  constexpr int MI = 2, BN = 16 * NT, NWAVE = 8;
+  // K-steps per chunk (raw + converted fragments of a chunk live next to 64 accumulator and, with statistics, 64
+  // statistics registers: 256 VGPRs at two waves per SIMD)
+  constexpr int SCH = (NT == 8 && (STATS || A_F32)) ? 3 : 5;
+  typedef typename AType<A_F32>::type TA;
+  typedef typename AType<Y_F32>::type TY;
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
+  const int nk = (p.K + BK - 1) / BK, kpad = nk * BK;
+  bf16* Bs = reinterpret_cast<bf16*>(sm_raw);
+  float* coef = reinterpret_cast<float*>(sm_raw + (size_t)BN * kp * 2);     // [2][kpad]
+  float* red = coef + 2 * kpad;                                             // [2][NWAVE][BN] (STATS)
+  const int t = threadIdx.x, l = t & 63, w = t >> 6, r = l & 15, kg = l >> 4;
+  const int n0 = blockIdx.y * BN;
+  const TA* Ap = reinterpret_cast<const TA*>(p.A);
+  TY* Yp = reinterpret_cast<TY*>(p.Y);
+  {
+    const int cpr = kpad / 8;                          // 16-B chunks per B row
+    for (int idx = t; idx < BN * cpr; idx += 512) {
+      const int n = idx / cpr, kc = (idx - n * cpr) * 8;
+      bf16x8 v = {};
+      if (n0 + n < p.N && kc < p.K) v = *reinterpret_cast<const bf16x8*>(p.B + (size_t)(n0 + n) * p.ldb + kc);
+      *reinterpret_cast<bf16x8*>(&Bs[n * kp + kc]) = v;
+    }
+    for (int i = t; i < kpad; i += 512) {
+      coef[i] = (p.scale && i < p.K) ? p.scale[i] : 1.f;
+      coef[kpad + i] = (p.scale && i < p.K) ? p.shift[i] : 0.f;
+    }
+  }
+  __syncthreads();
+  const bool has_pro = p.scale != nullptr || p.act != DL3P_ACT_NONE;
+  const bool hsw = p.act >= DL3P_ACT_HSWISH;
+  const float act_lo = p.act == DL3P_ACT_NONE ? -DL3P_INF : 0.f;
+  const float act_hi = (p.act == DL3P_ACT_NONE || p.act == DL3P_ACT_RELU) ? DL3P_INF : 6.f;
+  const int ncpt = (nk + SCH - 1) / SCH;               // chunks per tile
+  const int first = blockIdx.x * NWAVE + w, stride = gridDim.x * NWAVE;
+  const int my_tiles = first < tiles ? (tiles - first + stride - 1) / stride : 0;
+  const int n_items = my_tiles * ncpt;
+
+  Raw8<A_F32> raw[SCH][MI];
+  f32x4v acc[MI][NT];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+  float st_s[STATS ? NT : 1][4], st_q[STATS ? NT : 1][4];
+  if (STATS) {
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { st_s[ni][j] = 0.f; st_q[ni][j] = 0.f; }
+  }
+
+  auto issue = [&](int item) {
+    const int tile = first + (item / ncpt) * stride, c = item % ncpt;
+#pragma unroll
+    for (int s2 = 0; s2 < SCH; ++s2) {
+      const int k = min((c * SCH + s2) * BK + kg * 8, p.K - 8);       // clamped: steps / chunks past K are zeroed below
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int m = min(tile * 32 + mi * 16 + r, p.M - 1);
+        raw[s2][mi] = ld_raw(Ap + (size_t)m * p.lda + k);
+      }
+    }
+  };
+
+  if (n_items > 0) issue(0);
+  for (int item = 0; item < n_items; ++item) {
+    const int tile = first + (item / ncpt) * stride, c = item % ncpt;
+    const int m0 = tile * 32;
+    bf16x8 fr[SCH][MI];
+#pragma unroll
+    for (int s2 = 0; s2 < SCH; ++s2) {
+      const int k = (c * SCH + s2) * BK + kg * 8;
+      const bool kok = k < p.K;
+      float sc[8], sh[8];
+      if (has_pro) {
+        const int kc = kok ? k : 0;
+        const float4 s0 = *reinterpret_cast<const float4*>(&coef[kc]), s1 = *reinterpret_cast<const float4*>(&coef[kc + 4]);
+        const float4 h0 = *reinterpret_cast<const float4*>(&coef[kpad + kc]), h1 = *reinterpret_cast<const float4*>(&coef[kpad + kc + 4]);
+        sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+        sh[0] = h0.x; sh[1] = h0.y; sh[2] = h0.z; sh[3] = h0.w; sh[4] = h1.x; sh[5] = h1.y; sh[6] = h1.z; sh[7] = h1.w;
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        bf16x8 v;
+        if (!has_pro && !A_F32) {
+          v = raw[s2][mi].v_or_zero();
+        } else if (!has_pro) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (bf16)raw_get(raw[s2][mi], e);
+        } else if (!hsw) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (bf16)fminf(fmaxf(fmaf(raw_get(raw[s2][mi], e), sc[e], sh[e]), act_lo), act_hi);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (bf16)act_apply(fmaf(raw_get(raw[s2][mi], e), sc[e], sh[e]), p.act);
+        }
+        if (!kok || m0 + mi * 16 + r >= p.M) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+        }
+        fr[s2][mi] = v;
+      }
+    }
+    if (item + 1 < n_items) issue(item + 1);            // the raw registers are free again: next chunk on its way
+#pragma unroll
+    for (int s2 = 0; s2 < SCH; ++s2) {
+      const int ks = c * SCH + s2;
+      if (ks < nk) {
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+          const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(&Bs[(ni * 16 + r) * kp + ks * BK + kg * 8]);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr, fr[s2][mi], acc[mi][ni], 0, 0, 0);
+        }
+      }
+    }
+    if (c == ncpt - 1) {
+      // lane (r, kg) holds channels n = n0 + 16 ni + 4 kg + j of pixel m = m0 + 16 mi + r
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + mi * 16 + r;
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+          const int n = n0 + ni * 16 + kg * 4;
+          f32x4v v = acc[mi][ni];
+          acc[mi][ni] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+          if (m < p.M && n < p.N) {
+            float4 o = make_float4(v[0], v[1], v[2], v[3]);
+            if (p.bias) o = add4(o, ld4(p.bias + n));
+            TY* yp = Yp + (size_t)m * p.ldy + n;
+            if (p.accumulate) o = add4(o, ld4(yp));
+            st4(yp, o);
+            if (STATS) {
+              const float4 q = Y_F32 ? o : bf16_round4(o);
+              st_s[ni][0] += q.x; st_s[ni][1] += q.y; st_s[ni][2] += q.z; st_s[ni][3] += q.w;
+              st_q[ni][0] = fmaf(q.x, q.x, st_q[ni][0]); st_q[ni][1] = fmaf(q.y, q.y, st_q[ni][1]);
+              st_q[ni][2] = fmaf(q.z, q.z, st_q[ni][2]); st_q[ni][3] = fmaf(q.w, q.w, st_q[ni][3]);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if (STATS) {
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float s1 = st_s[ni][j], s2 = st_q[ni][j];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        if (r == 0) {
+          red[(0 * NWAVE + w) * BN + ni * 16 + kg * 4 + j] = s1;
+          red[(1 * NWAVE + w) * BN + ni * 16 + kg * 4 + j] = s2;
+        }
+      }
+    __syncthreads();
+    if (p.partials) {
+      for (int i = t; i < 2 * BN; i += 512) {
+        const int which = i / BN, nn = i - which * BN;
+        if (n0 + nn < p.N) {
+          float a = 0.f;
+#pragma unroll
+          for (int q = 0; q < NWAVE; ++q) a += red[(which * NWAVE + q) * BN + nn];
+          p.partials[((size_t)blockIdx.x * 2 + which) * p.N + n0 + nn] = a;
+        }
+      }
+    }
+  }
+}
+
+struct StreamPlan { bool ok; int nt, kp, gy; size_t lds; };
+StreamPlan stream_plan_b(int K, int N, bool stats) {
+  StreamPlan pl = {};
+  const int kpad = ceil_div(K, BK) * BK;
+  pl.kp = kpad + 8;
+  if (kpad > 640) return pl;
+  int nt = 2;
+  while (nt < 8 && 16 * nt < N) nt *= 2;
+  auto bytes = [&](int ntv) { return (size_t)16 * ntv * pl.kp * 2 + (size_t)2 * kpad * 4 + (stats ? (size_t)2 * 8 * 16 * ntv * 4 : 0); };
+  while (nt > 2 && bytes(nt) > 150 * 1024) nt /= 2;
+  if (bytes(nt) > 150 * 1024) return pl;
+  // narrow column blocks re-read A once per block: keep the staged kernel when that is more than 3 passes
+  if (ceil_div(N, 16 * nt) > 3) return pl;
+  pl.ok = true; pl.nt = nt; pl.gy = ceil_div(N, 16 * nt); pl.lds = bytes(nt);
+  return pl;
+}
+
+template <int NT, bool A_F32, bool Y_F32, bool STATS>
+void launch_stream_one(const GemmB& p, const StreamPlan& pl, dim3 grid, int tiles, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)pwb_stream<NT, A_F32, Y_F32, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((pwb_stream<NT, A_F32, Y_F32, STATS>), grid, dim3(512), pl.lds, st, p, pl.kp, tiles);
+}
+template <bool A_F32, bool Y_F32, bool STATS>
+void launch_stream(const GemmB& p, const StreamPlan& pl, dim3 grid, int tiles, hipStream_t st) {
+  switch (pl.nt) {
+    case 2: launch_stream_one<2, A_F32, Y_F32, STATS>(p, pl, grid, tiles, st); break;
+    case 4: launch_stream_one<4, A_F32, Y_F32, STATS>(p, pl, grid, tiles, st); break;
+    default: launch_stream_one<8, A_F32, Y_F32, STATS>(p, pl, grid, tiles, st); break;
+  }
+}
+
 // M <= 64 rows (convs behind a global pooling: ASPP image pooling, squeeze-excite): one wave per output column, lanes
 // stride the reduction in 16-byte chunks
 template <bool A_F32, bool Y_F32>
@@ -510,6 +729,24 @@ int gemm_b(const char* fn, GemmB p, bool a_f32, bool y_f32, int* rows_out, hipSt
   static const int dbg = getenv("DL3P_BF16_DBG") ? atoi(getenv("DL3P_BF16_DBG")) : 0;
   p.dbg = dbg;
   const bool stats = p.partials != nullptr;
+  static const int no_stream = getenv("DL3P_BF16_NOSTREAM") ? atoi(getenv("DL3P_BF16_NOSTREAM")) : 0;
+  const StreamPlan sp = stream_plan_b(p.K, p.N, stats);
+  if (sp.ok && !no_stream) {
+    const int tiles = ceil_div(p.M, 32);
+    const int per_cu = sp.lds > 75 * 1024 ? 1 : 2;
+    int gx = ceil_div(tiles, 8 * 2);                       // at least two tiles per wave
+    const int gx_max = (DL3P_NUM_CUS * per_cu) / sp.gy > 0 ? (DL3P_NUM_CUS * per_cu) / sp.gy : 1;
+    if (gx > gx_max) gx = gx_max;
+    if (gx < 1) gx = 1;
+    if (rows_out) *rows_out = gx;
+    const dim3 grid(gx, sp.gy);
+    if (a_f32) launch_stream<true, false, false>(p, sp, grid, tiles, st);
+    else if (y_f32) launch_stream<false, true, false>(p, sp, grid, tiles, st);
+    else if (stats) launch_stream<false, false, true>(p, sp, grid, tiles, st);
+    else launch_stream<false, false, false>(p, sp, grid, tiles, st);
+    DL3P_CHECK_LAUNCH(fn);
+    return DL3P_OK;
+  }
   const int nt = pick_nt_b(p.N, stats);
   const int gy = ceil_div(p.N, 16 * nt);
   // 64-row tiles whenever 128-row tiles would leave the chip under two workgroups per CU (the 64 x 128 maps: M = 8192)
