@@ -334,11 +334,13 @@ __global__ __launch_bounds__(512, 1) void pwb_stream(GemmB p, int kp, int tiles)
     const int tile = first + (item / ncpt) * stride, c = item % ncpt;
 #pragma unroll
     for (int s2 = 0; s2 < SCH; ++s2) {
-      const int k = min((c * SCH + s2) * BK + kg * 8, p.K - 8);       // clamped: steps / chunks past K are zeroed below
+      if (c * SCH + s2 < nk) {                                         // (wave-uniform: short K loops skip the slots they lack)
+        const int k = min((c * SCH + s2) * BK + kg * 8, p.K - 8);      // clamped: chunks past K are zeroed below
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        const int m = min(tile * 32 + mi * 16 + r, p.M - 1);
-        raw[s2][mi] = ld_raw(Ap + (size_t)m * p.lda + k);
+        for (int mi = 0; mi < MI; ++mi) {
+          const int m = min(tile * 32 + mi * 16 + r, p.M - 1);
+          raw[s2][mi] = ld_raw(Ap + (size_t)m * p.lda + k);
+        }
       }
     }
   };
@@ -350,6 +352,7 @@ __global__ __launch_bounds__(512, 1) void pwb_stream(GemmB p, int kp, int tiles)
     bf16x8 fr[SCH][MI];
 #pragma unroll
     for (int s2 = 0; s2 < SCH; ++s2) {
+      if (c * SCH + s2 >= nk) continue;
       const int k = (c * SCH + s2) * BK + kg * 8;
       const bool kok = k < p.K;
       float sc[8], sh[8];
