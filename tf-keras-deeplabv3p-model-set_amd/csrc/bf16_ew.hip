@@ -267,12 +267,17 @@ struct PoolB {
 };
 
 inline void pool_plan_b(PoolB& p, int N, int HW, int C) {
-  const LaneSplit s = lane_split(C, 4);
-  p.cs = s.cs; p.px = s.px; p.nslab = s.nslab;
+  // reductions want pixel lanes: the NARROWEST channel-lane group that still reads >= 64 contiguous bytes per pixel
+  const int cv = C / 4;
+  int cs = cv;
+  for (int d = 8; d < cv; ++d)
+    if (cv % d == 0) { cs = d; break; }
+  if (cs > 256) cs = 256;                      // (C > 1024 with no divisor in [8, 256]: not a shape of these models)
+  p.cs = cs; p.px = 256 / cs; p.nslab = cv / cs;
   int nchunk = (2 * DL3P_NUM_CUS + N * p.nslab - 1) / (N * p.nslab);
   const int most = (HW + 4 * p.px - 1) / (4 * p.px);
   if (nchunk > most) nchunk = most;
-  if (nchunk > 64) nchunk = 64;
+  if (nchunk > 32) nchunk = 32;
   if (nchunk < 1) nchunk = 1;
   p.per = (HW + nchunk - 1) / nchunk;
   p.nchunk = (HW + p.per - 1) / p.per;
@@ -323,13 +328,18 @@ __global__ __launch_bounds__(256) void pool_partial_b(PoolB p) {
   block_reduce_rows<4, 1>(acc, active, pl, cl, p.cs, p.px, cbase, p.C, p.ws + ((size_t)n * p.nchunk + chunk) * p.C);
 }
 
+// out[n][c] = scale * sum over chunks (chunk order: deterministic); 64 channels x 4 chunk lanes per workgroup
 __global__ __launch_bounds__(256) void pool_finish_b(const float* ws, int nchunk, int C, float scale, bf16* out, int ldo) {
+  __shared__ float sm[4][64];
   const int n = blockIdx.y;
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  const int cl = threadIdx.x & 63, ql = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float a = 0.f;
-  for (int q = 0; q < nchunk; ++q) a += ws[((size_t)n * nchunk + q) * C + c];
-  out[(size_t)n * ldo + c] = (bf16)(a * scale);
+  if (c < C)
+    for (int q = ql; q < nchunk; q += 4) a += ws[((size_t)n * nchunk + q) * C + c];
+  sm[ql][cl] = a;
+  __syncthreads();
+  if (ql == 0 && c < C) out[(size_t)n * ldo + c] = (bf16)(((sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl])) * scale);
 }
 
 template <int V>
@@ -394,7 +404,7 @@ extern "C" int dl3p_global_avgpool_fwd_bf16(const void* x, int ldx, const float*
   p.x = (const bf16*)x; p.ldx = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act; p.ws = workspace;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL((pool_partial_b<false>), dim3(N * p.nslab * p.nchunk), dim3(256), 0, st, p);
-  hipLaunchKernelGGL(pool_finish_b, dim3(ceil_div(C, 256), N), dim3(256), 0, st, workspace, p.nchunk, C,
+  hipLaunchKernelGGL(pool_finish_b, dim3(ceil_div(C, 64), N), dim3(256), 0, st, workspace, p.nchunk, C,
                      out_scale / (float)HW, (bf16*)y, ldy);
   DL3P_CHECK_LAUNCH("dl3p_global_avgpool_fwd_bf16");
   return DL3P_OK;
@@ -454,7 +464,7 @@ extern "C" int dl3p_scale_bcast_bwd_bf16(const void* gy, int ldgy, const void* x
   p.ws = workspace;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL((pool_partial_b<true>), dim3(N * p.nslab * p.nchunk), dim3(256), 0, st, p);
-  hipLaunchKernelGGL(pool_finish_b, dim3(ceil_div(C, 256), N), dim3(256), 0, st, workspace, p.nchunk, C, 1.f, (bf16*)gs, ldgs);
+  hipLaunchKernelGGL(pool_finish_b, dim3(ceil_div(C, 64), N), dim3(256), 0, st, workspace, p.nchunk, C, 1.f, (bf16*)gs, ldgs);
   DL3P_CHECK_LAUNCH("dl3p_scale_bcast_bwd_bf16");
   return DL3P_OK;
 }

@@ -542,94 +542,94 @@ __device__ __forceinline__ bf16x4 tr_read(const bf16* lds_ptr) {
   return *reinterpret_cast<const bf16x4*>(&v);
 }
 
+// MS rows of M per step (one barrier pair per step: at 32 rows a step was 8 MFMAs per wave against two barriers and a
+// staging pass, and the kernel sat at 1/4 of its HBM floor whatever the load lookahead)
 template <int NW, bool DY_F32>
 __global__ __launch_bounds__(256, 2) void pwb_wgrad(WgradB p) {
-  constexpr int TK = 64, TN = 16 * NW;
+  constexpr int TK = 64, TN = 16 * NW, MS = 128;
   constexpr int XP = TK + 8, DP = TN + 8;           // pitches (bf16): 8-byte aligned rows for the transposed reads
-  constexpr int ND = (32 * TN / 8 + 255) / 256;     // 16-B chunks of the DY tile per thread
-  constexpr int PD = 4;                             // 32-row steps of loads in flight (a step is ~0.2 us of work)
+  constexpr int NX = MS * TK / 8 / 256;             // 16-B chunks of the X tile per thread (4)
+  constexpr int ND = MS * TN / 8 / 256;             // ... of the DY tile (NW / 2 * 2)
   typedef typename AType<DY_F32>::type TD;
-  __shared__ __attribute__((aligned(16))) bf16 Xs[32 * XP];
-  __shared__ __attribute__((aligned(16))) bf16 Ds[32 * DP];
+  __shared__ __attribute__((aligned(16))) bf16 Xs[MS * XP];
+  __shared__ __attribute__((aligned(16))) bf16 Ds[MS * DP];
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int tile = blockIdx.x, kt = tile / p.ntiles, nt = tile - kt * p.ntiles;
   const int k0 = kt * TK, n0 = nt * TN;
   const int mbeg = blockIdx.y * p.mrows, mend = min(p.M, mbeg + p.mrows);
   const TD* Dp = reinterpret_cast<const TD*>(p.DY);
-  // staging roles: X tile 32 rows x 64 k = 256 chunks, one per thread; the thread's 8 channels are fixed for the kernel
+  // staging roles: X tile rows xm + 32 i (i < NX), the thread's 8 channels are fixed for the kernel
   const int xm = t >> 3, xk = k0 + (t & 7) * 8;
   const bool xk_ok = xk < p.K;
   const fvec<8> sc = ldv_f32_or<8>(xk_ok ? p.scale : nullptr, xk, 1.f), sh = ldv_f32_or<8>(xk_ok ? p.shift : nullptr, xk, 0.f);
   const bool has_pro = p.scale != nullptr || p.act != DL3P_ACT_NONE;
+  const bool hsw = p.act >= DL3P_ACT_HSWISH;
+  const float act_lo = p.act == DL3P_ACT_NONE ? -DL3P_INF : 0.f;
+  const float act_hi = (p.act == DL3P_ACT_NONE || p.act == DL3P_ACT_RELU) ? DL3P_INF : 6.f;
+  constexpr int DCPR = TN / 8;                      // DY chunks per row
+  const int dm = t / DCPR, dc = (t - dm * DCPR) * 8;   // DY tile rows dm + (256 / DCPR) i
+  constexpr int DROWS = 256 / DCPR;
+  const bool dn_ok = n0 + dc < p.N;
   f32x4v acc[NW];
 #pragma unroll
   for (int ni = 0; ni < NW; ++ni) acc[ni] = (f32x4v){0.f, 0.f, 0.f, 0.f};
   // transposed-read addresses: lane (g = l >> 4, i = l & 15 = 4q + pp) supplies row 8g + q (+4), columns 4pp..4pp+3
   const int g = l >> 4, q = (l & 15) >> 2, pp = l & 3;
-  Raw8<false> rx[PD];
-  Raw8<DY_F32> rd[PD][ND];
-  bool x_ok[PD], d_ok[PD][ND];
-  auto prefetch = [&](auto slot_c, int m0) {
-    constexpr int S = decltype(slot_c)::value;
-    const int m = m0 + xm;
-    x_ok[S] = xk_ok && m < mend;
-    rx[S] = ld_raw(p.X + (size_t)min(m, p.M - 1) * p.ldx + (xk_ok ? xk : 0));
+  Raw8<false> rx[NX];
+  Raw8<DY_F32> rd[ND];
+  auto prefetch = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+      rx[i] = ld_raw(p.X + (size_t)min(m0 + xm + 32 * i, p.M - 1) * p.ldx + (xk_ok ? xk : 0));
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+      rd[i] = ld_raw(Dp + (size_t)min(m0 + dm + DROWS * i, p.M - 1) * p.lddy + (dn_ok ? n0 + dc : 0));
+  };
+  if (mbeg < mend) prefetch(mbeg);
+  for (int m0 = mbeg; m0 < mend; m0 += MS) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      bf16x8 v;
+      if (!has_pro) {
+        v = rx[i].v;
+      } else if (!hsw) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (bf16)fminf(fmaxf(fmaf((float)rx[i].v[e], sc.v[e], sh.v[e]), act_lo), act_hi);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (bf16)act_apply(fmaf((float)rx[i].v[e], sc.v[e], sh.v[e]), p.act);
+      }
+      if (!xk_ok || m0 + xm + 32 * i >= mend) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+      }
+      *reinterpret_cast<bf16x8*>(&Xs[(xm + 32 * i) * XP + (t & 7) * 8]) = v;
+    }
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
-      const int idx = t + 256 * i;
-      const int dm = idx / (TN / 8), dc = (idx - dm * (TN / 8)) * 8;
-      const int mm = m0 + dm, n = n0 + dc;
-      d_ok[S][i] = idx < 32 * TN / 8 && mm < mend && n < p.N;
-      rd[S][i] = ld_raw(Dp + (size_t)min(mm, p.M - 1) * p.lddy + (n < p.N ? n : 0));
+      bf16x8 dv;
+      const bool ok = dn_ok && m0 + dm + DROWS * i < mend;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dv[e] = ok ? (bf16)raw_get(rd[i], e) : (bf16)0.f;
+      *reinterpret_cast<bf16x8*>(&Ds[(dm + DROWS * i) * DP + dc]) = dv;
     }
-  };
-  auto step = [&](auto slot_c, int m0) {
-    constexpr int S = decltype(slot_c)::value;
-    {
-      bf16x8 v;
+    __syncthreads();
+    if (m0 + MS < mend) prefetch(m0 + MS);
+    // per 32-row sub-step: A operand (16 k rows x 32 m) of this wave, B operands (32 m x 16 n) per column tile
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float x = raw_get(rx[S], e);
-        if (has_pro) x = act_apply(fmaf(x, sc.v[e], sh.v[e]), p.act);
-        v[e] = x_ok[S] ? (bf16)x : (bf16)0.f;
-      }
-      *reinterpret_cast<bf16x8*>(&Xs[xm * XP + (t & 7) * 8]) = v;
+    for (int ms = 0; ms < MS / 32; ++ms) {
+      const bf16x4 a0 = tr_read(&Xs[(32 * ms + 8 * g + q) * XP + w * 16 + 4 * pp]);
+      const bf16x4 a1 = tr_read(&Xs[(32 * ms + 8 * g + 4 + q) * XP + w * 16 + 4 * pp]);
+      const bf16x8 af = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
 #pragma unroll
-      for (int i = 0; i < ND; ++i) {
-        const int idx = t + 256 * i;
-        if (idx < 32 * TN / 8) {
-          const int dm = idx / (TN / 8), dc = (idx - dm * (TN / 8)) * 8;
-          bf16x8 dv;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) dv[e] = d_ok[S][i] ? (bf16)raw_get(rd[S][i], e) : (bf16)0.f;
-          *reinterpret_cast<bf16x8*>(&Ds[dm * DP + dc]) = dv;
-        }
+      for (int ni = 0; ni < NW; ++ni) {
+        const bf16x4 b0 = tr_read(&Ds[(32 * ms + 8 * g + q) * DP + ni * 16 + 4 * pp]);
+        const bf16x4 b1 = tr_read(&Ds[(32 * ms + 8 * g + 4 + q) * DP + ni * 16 + 4 * pp]);
+        const bf16x8 bfr = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[ni], 0, 0, 0);
       }
     }
     __syncthreads();
-    if (m0 + 32 * PD < mend) prefetch(slot_c, m0 + 32 * PD);
-    // A operand (16 k rows x 32 m) of this wave, B operands (32 m x 16 n) per column tile; EXEC is full here
-    const bf16x4 a0 = tr_read(&Xs[(8 * g + q) * XP + w * 16 + 4 * pp]);
-    const bf16x4 a1 = tr_read(&Xs[(8 * g + 4 + q) * XP + w * 16 + 4 * pp]);
-    const bf16x8 af = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-#pragma unroll
-    for (int ni = 0; ni < NW; ++ni) {
-      const bf16x4 b0 = tr_read(&Ds[(8 * g + q) * DP + ni * 16 + 4 * pp]);
-      const bf16x4 b1 = tr_read(&Ds[(8 * g + 4 + q) * DP + ni * 16 + 4 * pp]);
-      const bf16x8 bfr = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-      acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[ni], 0, 0, 0);
-    }
-    __syncthreads();
-  };
-  if (mbeg < mend) prefetch(std::integral_constant<int, 0>{}, mbeg);
-  if (mbeg + 32 < mend) prefetch(std::integral_constant<int, 1>{}, mbeg + 32);
-  if (mbeg + 64 < mend) prefetch(std::integral_constant<int, 2>{}, mbeg + 64);
-  if (mbeg + 96 < mend) prefetch(std::integral_constant<int, 3>{}, mbeg + 96);
-  for (int m0 = mbeg; m0 < mend; m0 += 32 * PD) {
-    step(std::integral_constant<int, 0>{}, m0);
-    if (m0 + 32 < mend) step(std::integral_constant<int, 1>{}, m0 + 32);
-    if (m0 + 64 < mend) step(std::integral_constant<int, 2>{}, m0 + 64);
-    if (m0 + 96 < mend) step(std::integral_constant<int, 3>{}, m0 + 96);
   }
   // D[row = 4 (l >> 4) + j -> k][col = l & 15 -> n]
   float* slab = p.slabs + (size_t)blockIdx.y * p.K * p.N;
@@ -734,7 +734,9 @@ int gemm_b(const char* fn, GemmB p, bool a_f32, bool y_f32, int* rows_out, hipSt
   const bool stats = p.partials != nullptr;
   static const int no_stream = getenv("DL3P_BF16_NOSTREAM") ? atoi(getenv("DL3P_BF16_NOSTREAM")) : 0;
   const StreamPlan sp = stream_plan_b(p.K, p.N, stats);
-  if (sp.ok && !no_stream) {
+  // (the streaming kernel pays a [BN][K] weight load per workgroup and runs one workgroup of 8 waves per CU: it wins from
+  // ~2^16 rows up -- 131072 x 304 -> 256: 67 us against 91 us tiled -- and loses on the 128 x 256 and 64 x 128 maps)
+  if (sp.ok && !no_stream && p.M >= (1 << 16)) {
     const int tiles = ceil_div(p.M, 32);
     const int per_cu = sp.lds > 75 * 1024 ? 1 : 2;
     int gx = ceil_div(tiles, 8 * 2);                       // at least two tiles per wave
@@ -785,11 +787,11 @@ WgradPlan wgrad_plan_b(int M, int K, int N) {
   pl.ntiles = ceil_div(N, 16 * pl.nw);
   const int tiles = pl.ktiles * pl.ntiles;
   int mchunks = (4 * DL3P_NUM_CUS) / tiles;
-  const int most = ceil_div(M, 256);
+  const int most = ceil_div(M, 512);
   if (mchunks > most) mchunks = most;
   if (mchunks > 512) mchunks = 512;
   if (mchunks < 1) mchunks = 1;
-  pl.mrows = ceil_div(ceil_div(M, mchunks), 32) * 32;
+  pl.mrows = ceil_div(ceil_div(M, mchunks), 128) * 128;
   pl.mchunks = ceil_div(M, pl.mrows);
   return pl;
 }
