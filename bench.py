@@ -191,7 +191,9 @@ def main():
 
     if rank == 0:
         out = {
-            'metric': 'images/sec (513x513, 21-class) MobileNetV2-DeepLabV3+ OS=16 training step',
+            'metric': ('images/sec (513x513, 21-class) MobileNetV2-DeepLabV3+ OS=16 training step'
+                       if (args.model, H, W, C, args.os) == ('mobilenetv2', 513, 513, 21, 16) else
+                       'images/sec (%dx%d, %d-class) %s-DeepLabV3+ OS=%d training step' % (H, W, C, args.model, args.os)),
             'value': round(N * world * args.steps / dt, 2), 'unit': 'images/sec', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000 * dt / args.steps, 3),
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
