@@ -32,4 +32,5 @@ def test_bench_runs_under_the_launcher_with_one_rank():
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert r.returncode == 0 and lines, (r.stdout[-1500:], r.stderr[-1500:])
     out = json.loads(lines[-1])
-    assert out['n_gpus'] == 1 and out['value'] > 0 and out['config']['collectives_per_step'] > 0
+    # 65 BatchNorms x (forward + backward) + 4 gradient buckets = 134 un-coalesced; the ASPP branches share all-reduces
+    assert out['n_gpus'] == 1 and out['value'] > 0 and 0 < out['config']['collectives_per_step'] <= 124

@@ -379,6 +379,12 @@ class Executor:
                                    sums=torch.zeros(2 * bn.C, dtype=torch.float64, device=self.dev))
             cmax = max(cmax, bn.C)
         self.partials = torch.zeros(MAX_ROWS * 2 * cmax, **self.f32)
+        # SyncBatchNorm: the (sum, sum^2) / (sum dy, sum dy xhat) vectors of BatchNorms whose statistics are needed at the
+        # same point of the graph travel in ONE all-reduce.  Slices of this buffer are handed out in trace order, so the
+        # BatchNorms waiting for a flush are contiguous (forward and backward use separate halves).
+        self._sync_total = sum(2 * bn.C for bn in g.bns)
+        self.sync_stage = (torch.zeros(2 * self._sync_total, dtype=torch.float64, device=self.dev)
+                           if (self.sync_bn and self.training) else None)
         ws = 1 << 20
         L = self.L
         pw_ws = L.pwconv_bwd_weight_workspace_bf16 if self.bf16 else L.pwconv_bwd_weight_workspace
@@ -487,9 +493,12 @@ class Executor:
         train = self.training
         if train:
             P.k(L.increment_counter, self.step.data_ptr())
+        self._fwd_pending, self._fwd_stage_off = [], 0
         for op in self.g.ops:
             k = op.kind
             P.ctx = _op_label(op)
+            if self._fwd_pending and k not in ('bn', 'broadcast') and self._reads_pending(op):
+                self._flush_bn_forward(P)
             if k in ('conv_pw', 'conv_dense', 'conv_dw'):
                 xp, ldx, sp, hp, act = self.vargs(op.x)
                 bn = op.bn
@@ -553,6 +562,8 @@ class Executor:
                     t.ld, N, xt.H, xt.W, xt.C, t.H, t.W)
             else:
                 raise NotImplementedError(k)
+        if self._fwd_pending:
+            self._flush_bn_forward(P)
         # head: pred_resize + softmax (+ loss and its gradient when training)
         P.ctx = 'head'
         zt = self.head.tensor
@@ -608,19 +619,54 @@ class Executor:
         hp = self.gshift[bn.group.id].data_ptr() + 4 * bn.offset
         z = op.z
         count = float(N * z.H * z.W)
-        if self.training and bn.layer.trainable:
+        if self.training and bn.layer.trainable and self.sync_bn:
+            # local sums into this BatchNorm's slice of the staging buffer; the all-reduce and the finalize wait until a
+            # consumer needs the coefficients (_flush_bn_forward), together with every other BatchNorm pending by then
+            off = self._fwd_stage_off
+            self._fwd_stage_off += 2 * bn.C
+            sl = self.sync_stage[off:off + 2 * bn.C]
+            P.k(L.bn_reduce_partials, self.partials.data_ptr(), op.producer.rows, 2 * bn.C, sl.data_ptr())
+            self._fwd_pending.append((op, off, P.ctx))
+        elif self.training and bn.layer.trainable:
             rows = op.producer.rows
             sums = None
-            if self.sync_bn:
-                P.k(L.bn_reduce_partials, self.partials.data_ptr(), rows, 2 * bn.C, aux['sums'].data_ptr())
-                P.coll(lambda s=aux['sums']: self.dist.all_reduce(s))
-                sums, count = aux['sums'].data_ptr(), count * self.dist.world_size
             P.k(L.bn_finalize, self.partials.data_ptr(), rows, sums, bn.C, count, st.ptr(lp['gamma']),
                 st.ptr(lp['beta']), bn.eps, bn.momentum, st.ptr(lp['moving_mean']), st.ptr(lp['moving_variance']), 1,
                 sp, hp, aux['mean'].data_ptr(), aux['invstd'].data_ptr())
         else:
             P.k(L.bn_infer_coeffs, st.ptr(lp['gamma']), st.ptr(lp['beta']), st.ptr(lp['moving_mean']),
                 st.ptr(lp['moving_variance']), bn.eps, sp, hp, aux['mean'].data_ptr(), aux['invstd'].data_ptr(), bn.C)
+
+    def _reads_pending(self, op):
+        """does `op` apply the coefficients of a BatchNorm whose statistics are still waiting for their all-reduce?"""
+        groups = {id(b.bn.group) for b, _, _ in self._fwd_pending}
+        for slot in ('x', 'r', 's'):
+            v = getattr(op, slot, None)
+            if v is not None and v.group is not None and id(v.group) in groups:
+                return True
+        return False
+
+    def _flush_bn_forward(self, P):
+        """ONE all-reduce for every pending BatchNorm (their slices are contiguous), then their finalize kernels"""
+        pend, self._fwd_pending = self._fwd_pending, []
+        lo = pend[0][1]
+        hi = pend[-1][1] + 2 * pend[-1][0].bn.C
+        ctx = P.ctx
+        P.ctx = 'syncbn:' + '+'.join(b.bn.name for b, _, _ in pend)
+        P.coll(lambda t=self.sync_stage[lo:hi]: self.dist.all_reduce(t))
+        st, L = self.store, self.L
+        for op, off, c in pend:
+            bn = op.bn
+            P.ctx = c
+            aux = self.bn_aux[bn]
+            lp = {p.key: p for p in bn.layer.params}
+            sp = self.gscale[bn.group.id].data_ptr() + 4 * bn.offset
+            hp = self.gshift[bn.group.id].data_ptr() + 4 * bn.offset
+            count = float(self.N * op.z.H * op.z.W) * self.dist.world_size
+            P.k(L.bn_finalize, None, 0, self.sync_stage[off:].data_ptr(), bn.C, count, st.ptr(lp['gamma']),
+                st.ptr(lp['beta']), bn.eps, bn.momentum, st.ptr(lp['moving_mean']), st.ptr(lp['moving_variance']), 1,
+                sp, hp, aux['mean'].data_ptr(), aux['invstd'].data_ptr())
+        P.ctx = ctx
 
     # ---------------------------------------------------------------- backward
     def _acc(self, t):
@@ -677,15 +723,22 @@ class Executor:
         defer = self.sync_bn
         fuse = {} if self.bf16 else self._bn_fusion_map()      # (the bf16 GEMM / depthwise kernels do not carry the fused sums)
         bn_done = set()
+        self._bwd_pending, self._bwd_stage_off = [], self._sync_total
+        processed = set()
+        readers = self._bn_readers() if self.sync_bn else {}
+        rops = list(reversed(self.g.ops))
 
         def wgrad(fn, *args):
             if defer:
                 self._deferred.append((fn, args, P.ctx))
             else:
                 P.k(fn, *args)
-        for op in reversed(self.g.ops):
+        for ri, op in enumerate(rops):
             k = op.kind
             P.ctx = _op_label(op)
+            # SyncBatchNorm: the producer of a pending BatchNorm's input needs that BatchNorm's dz now
+            if self._bwd_pending and getattr(op, 'out', None) is not None and any(b.z is op.out for b, _, _ in self._bwd_pending):
+                self._flush_bn_backward(P)
             if op in bucket_edges:
                 self._flush_deferred(P)        # every gradient of the finished bucket must have been produced
                 lo, hi = bucket_edges[op]
@@ -696,7 +749,22 @@ class Executor:
             if k == 'bn':
                 if op.z.requires_grad and op not in bn_done:
                     self._bn_backward(P, op)
+                    bn_done.add(op)
+                    if self.sync_bn and op.bn.layer.trainable:
+                        # other BatchNorms whose gradient is complete already (every reader of their output has been
+                        # processed: the ASPP branches behind concat_projection, a shortcut beside its residual branch):
+                        # take their local sums now, so that one all-reduce serves them all
+                        for op2 in rops[ri + 1:]:
+                            if (op2.kind == 'bn' and op2 not in bn_done and op2.z.requires_grad and op2.bn.layer.trainable
+                                    and readers.get(op2) and readers[op2] <= processed and op2 not in fuse.values()):
+                                ctx = P.ctx
+                                P.ctx = _op_label(op2)
+                                self._bn_backward(P, op2)
+                                bn_done.add(op2)
+                                P.ctx = ctx
+                processed.add(op)
                 continue
+            processed.add(op)
             if out is None or not out.requires_grad:
                 continue
             if self.bf16 and k in ('conv_pw', 'conv_dense', 'conv_dw'):
@@ -806,6 +874,8 @@ class Executor:
                     self.tptr(xt, True), xt.ld, self._acc(xt), N, xt.H, xt.W, xt.C, out.H, out.W)
             else:
                 raise NotImplementedError(k)
+        if self._bwd_pending:
+            self._flush_bn_backward(P)
         self._flush_deferred(P)
         if self.dist is not None:
             P.coll(lambda hi=self._first_bucket_hi: self.dist.all_reduce_async(G[0:hi]))
@@ -904,17 +974,64 @@ class Executor:
             P.k(L.bn_bwd_finalize, self.partials.data_ptr(), rows.value, None, bn.C, float(M), st.ptr(lp['gamma']),
                 invstd, sp, 0, st.ptr(lp['gamma'], G), st.ptr(lp['beta'], G), coef)
             if self.sync_bn:
-                # parameter gradients stay local (they are averaged with every other gradient); the
-                # normalisation terms use the global sums.  The all-reduce runs beside the deferred weight
-                # gradient(s) of the layer(s) processed before this one.
-                P.k(L.bn_reduce_partials, self.partials.data_ptr(), rows.value, 2 * bn.C, aux['sums'].data_ptr())
-                P.coll(lambda s=aux['sums']: self.dist.bn_all_reduce_begin(s))
-                self._flush_deferred(P)
-                P.py(self.dist.bn_all_reduce_end)
-                P.k(L.bn_bwd_finalize, None, 0, aux['sums'].data_ptr(), bn.C, float(M * self.dist.world_size),
-                    st.ptr(lp['gamma']), invstd, sp, 0, None, None, coef)
+                # parameter gradients stay local (they are averaged with every other gradient); the normalisation terms
+                # use the global sums: local sums into this BatchNorm's slice of the staging buffer, all-reduce +
+                # finalize + apply when the producer of z is reached (_flush_bn_backward), together with every other
+                # BatchNorm pending by then
+                off = self._bwd_stage_off
+                self._bwd_stage_off += 2 * bn.C
+                P.k(L.bn_reduce_partials, self.partials.data_ptr(), rows.value, 2 * bn.C, self.sync_stage[off:].data_ptr())
+                self._bwd_pending.append((op, off, P.ctx))
+                return
         P.k(L.bn_bwd_apply_bf16 if self.bf16 else L.bn_bwd_apply, g, ldg, zp, ldz, sp, hp, bn.act, mean, invstd, coef, g, ldg,
             0, M, bn.C)
+
+    def _bn_readers(self):
+        """{'bn' op: set of ops that read the BatchNorm's output} (a Concatenate's consumer reads every branch)"""
+        out = {}
+        by_t = {}
+        for op in self.g.ops:
+            for slot in ('x', 'r', 's'):
+                v = getattr(op, slot, None)
+                if v is not None:
+                    by_t.setdefault(v.tensor.id, set()).add(op)
+        for op in self.g.ops:
+            if op.kind == 'bn':
+                z = op.z
+                rd = set(by_t.get(z.id, ()))
+                if z.base is not None:
+                    rd |= by_t.get(z.base.id, set())
+                out[op] = rd
+        return out
+
+    def _flush_bn_backward(self, P):
+        """ONE all-reduce (on the side stream, beside the deferred weight gradients) for every pending BatchNorm, then
+        their finalize (global sums -> coefficients) and apply kernels"""
+        pend, self._bwd_pending = self._bwd_pending, []
+        lo = pend[0][1]
+        hi = pend[-1][1] + 2 * pend[-1][0].bn.C
+        L, st = self.L, self.store
+        ctx = P.ctx
+        P.ctx = 'syncbn:' + '+'.join(b.bn.name for b, _, _ in pend)
+        P.coll(lambda t=self.sync_stage[lo:hi]: self.dist.bn_all_reduce_begin(t))
+        self._flush_deferred(P)
+        P.py(self.dist.bn_all_reduce_end)
+        for op, off, c in pend:
+            bn = op.bn
+            P.ctx = c
+            aux = self.bn_aux[bn]
+            lp = {p.key: p for p in bn.layer.params}
+            z = op.z
+            M = self.N * z.H * z.W
+            sp = self.gscale[bn.group.id].data_ptr() + 4 * bn.offset
+            hp = self.gshift[bn.group.id].data_ptr() + 4 * bn.offset
+            g, ldg, zp = self.tptr(z, True), z.ld, self.tptr(z)
+            mean, invstd, coef = aux['mean'].data_ptr(), aux['invstd'].data_ptr(), aux['coef'].data_ptr()
+            P.k(L.bn_bwd_finalize, None, 0, self.sync_stage[off:].data_ptr(), bn.C, float(M * self.dist.world_size),
+                st.ptr(lp['gamma']), invstd, sp, 0, None, None, coef)
+            P.k(L.bn_bwd_apply_bf16 if self.bf16 else L.bn_bwd_apply, g, ldg, zp, z.ld, sp, hp, bn.act, mean, invstd, coef,
+                g, ldg, 0, M, bn.C)
+        P.ctx = ctx
 
     # ---------------------------------------------------------------- optimiser
     def _trace_sgd(self):
