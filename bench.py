@@ -45,34 +45,57 @@ def parse():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-sync-bn', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-steps', type=int, default=4)
+    ap.add_argument('--cpu-steps', type=int, default=10)
     return ap.parse_args()
 
 
 def cpu_baseline(args):
-    """time the CPU port (oracle, float32 NumPy + BLAS) on a bounded sample of the workload"""
+    """the CPU stand-in for the reference's tf.keras train.py (which cannot be installed here):
+    the same graph (configs[0]: mobilenetv2_lite, 513x513, batch 2, fwd + CE(ignore 255) + L2 + bwd + SGD momentum,
+    fp32) restated with torch-CPU ops (oneDNN) on all host cores -- oracle/torch_net.py, the checker's code, never the
+    product path -- 3 warm-up + 10 timed steps; one core and the NumPy oracle are reported beside it"""
     import numpy as np
-    from oracle.np_net import OracleModel
+    import torch
+    from oracle.torch_net import TorchModel
     H = W = args.size
     B, C = 2, args.classes
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count()
-    m = OracleModel('mobilenetv2_lite', C, (H, W), 16, dtype=np.float32, seed=0)
     rng = np.random.default_rng(1234)
     x = rng.uniform(-1, 1, (B, H, W, 3)).astype(np.float32)
     y = rng.integers(0, C, (B, H * W, 1)).astype(np.float32)
     y[rng.uniform(size=y.shape) < 0.05] = 255
     mask = (rng.uniform(size=(B, (H + 15) // 16, (W + 15) // 16, 256)) >= 0.5).astype(np.float32)
-    m.train_step(x, y, {'aspp_dropout': mask})          # warm-up
-    t0 = time.time()
-    for _ in range(args.cpu_steps):
-        m.train_step(x, y, {'aspp_dropout': mask})
-    dt = time.time() - t0
-    return {'value': round(B * args.cpu_steps / dt, 3), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': '%d train steps of mobilenetv2_lite %dx%d batch %d fp32 (NumPy oracle, BLAS threads = cores); '
-                      'the tf.keras reference itself is not installable here' % (args.cpu_steps, H, W, B)}
+
+    def rate(threads, warm, steps, budget_s):
+        torch.set_num_threads(threads)
+        m = TorchModel('mobilenetv2_lite', C, (H, W), 16, dtype=np.float32, seed=0)
+        for _ in range(warm):
+            m.train_step(x, y, {'aspp_dropout': mask})
+        t0, n = time.time(), 0
+        while n < steps and (n == 0 or time.time() - t0 < budget_s):
+            m.train_step(x, y, {'aspp_dropout': mask})
+            n += 1
+        return B * n / (time.time() - t0), n
+    threads = min(cores, 64)                  # oneDNN stops scaling on these shapes well before 256 threads
+    all_rate, all_n = rate(threads, 3, args.cpu_steps, 40.0)
+    one_rate, one_n = rate(1, 1, 3, 15.0)
+    out = {'value': round(all_rate, 3), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+           'sample': '%d train steps (3 warm-up) of mobilenetv2_lite %dx%d batch %d fp32: torch-CPU (oneDNN) restatement of the '
+                     'same graph, NOT tf.keras (not installable here); host has %d cores' % (all_n, H, W, B, cores),
+           'one_core': {'value': round(one_rate, 3), 'steps': one_n}}
+    try:
+        from oracle.np_net import OracleModel
+        o = OracleModel('mobilenetv2_lite', C, (H, W), 16, dtype=np.float32, seed=0)
+        o.train_step(x, y, {'aspp_dropout': mask})
+        t0 = time.time()
+        o.train_step(x, y, {'aspp_dropout': mask})
+        out['numpy_oracle'] = {'value': round(B / (time.time() - t0), 3), 'steps': 1, 'cores': cores}
+    except Exception as e:      # noqa: BLE001 - the second figure is optional
+        out['numpy_oracle'] = {'error': str(e)[:80]}
+    return out
 
 
 def measured_traffic(kernel_name):

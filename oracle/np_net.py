@@ -677,6 +677,8 @@ class OracleModel:
     21-class stub head dropped at layers[-5] and replaced by conv_upsample (1x1 + bias) ->
     pred_resize (bilinear to the input size) -> [Reshape] -> Softmax('pred_mask')."""
 
+    net_class = Net          # oracle/torch_net.py substitutes a torch-autograd implementation of the same layer set
+
     def __init__(self, model_type, num_classes, input_shape, output_stride, dtype=np.float64, seed=0,
                  freeze_level=0):
         if model_type not in MODEL_TYPES:
@@ -685,12 +687,12 @@ class OracleModel:
         self.num_classes = num_classes
         self.H, self.W = input_shape
         self.OS = output_stride
-        self.net = Net(dtype, seed)
+        self.net = self.net_class(dtype, seed)
         self.velocity = {}
         self.freeze_level = freeze_level
         # materialise parameters with one dry forward at batch 1 on a small probe (shapes of the
         # parameters do not depend on the spatial size)
-        probe = np.zeros((1, 33, 33, 3), dtype=dtype)
+        probe = np.zeros((1, 33, 33, 3), dtype=np.float64)
         self._forward_graph(probe, 33, 33, training=False)
         self.backbone_param_names = list(self._backbone_names)
         if freeze_level in (1, 2):

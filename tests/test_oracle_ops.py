@@ -183,3 +183,34 @@ def test_oracle_model_gradient_check():
         fd = (cp - cm) / (2 * eps)
         an = float((g * d).sum())
         assert abs(fd - an) < 1e-3 * max(1.0, abs(an)), (name, fd, an)
+
+
+@pytest.mark.parametrize('mt', ['mobilenetv2_lite', 'mobilenetv3large'])
+def test_whole_model_matches_torch_autograd(mt):
+    """The oracle's whole train step (forward, hand-written reverse-mode tape, CE with ignore 255) against an independent
+    implementation of every primitive AND of differentiation: oracle/torch_net.py runs the same builders on
+    torch.nn.functional ops + torch autograd (fp64).  Activations agree to 1e-11; the final bilinear pred_resize carries
+    torch's float32 interpolation weights under autograd (6e-7), which bounds loss / gradient agreement at 1e-5."""
+    from oracle.np_net import OracleModel
+    from oracle.torch_net import TorchModel
+    H = W = 33
+    N, C = 2, 5
+    o = OracleModel(mt, C, (H, W), 16, dtype=np.float64, seed=0)
+    t = TorchModel(mt, C, (H, W), 16, dtype=np.float64, seed=0)
+    assert list(o.net.order) == list(t.net.order)
+    rng = np.random.default_rng(1)
+    x = rng.uniform(-1, 1, (N, H, W, 3))
+    y = rng.integers(0, C, (N, H * W, 1)).astype(np.float64)
+    y[rng.uniform(size=y.shape) < 0.05] = 255
+    mask = (rng.uniform(size=(N, 3, 3, 256)) >= 0.5).astype(np.float64)
+    lo, po = o.predict(x)
+    lt, pt = t.predict(x)
+    np.testing.assert_allclose(lo, lt, atol=1e-10, rtol=0)   # inference: every op
+    _, co, _ = o.loss_and_grads(x, y, {'aspp_dropout': mask})
+    _, ct, _ = t.loss_and_grads(x, y, {'aspp_dropout': mask})
+    for k in ('backbone_out', 'head_in', 'conv_upsample'):
+        np.testing.assert_allclose(o.net.taps[k].v, t.net.taps[k].v.detach().numpy(), atol=1e-10, err_msg=k)
+    assert abs(co - ct) < 1e-7
+    for k, g in o.net.grads.items():
+        if np.abs(g).max() > 1e-7:                            # (a beta in front of conv + BN has an exactly-zero gradient)
+            assert np.abs(g - t.net.grads[k]).max() < 1e-5 * np.abs(g).max(), k
