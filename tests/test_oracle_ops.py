@@ -208,8 +208,9 @@ def test_whole_model_matches_torch_autograd(mt):
     np.testing.assert_allclose(lo, lt, atol=1e-10, rtol=0)   # inference: every op
     _, co, _ = o.loss_and_grads(x, y, {'aspp_dropout': mask})
     _, ct, _ = t.loss_and_grads(x, y, {'aspp_dropout': mask})
-    for k in ('backbone_out', 'head_in', 'conv_upsample'):
-        np.testing.assert_allclose(o.net.taps[k].v, t.net.taps[k].v.detach().numpy(), atol=1e-10, err_msg=k)
+    # (behind a decoder_resize / pred_resize the torch side carries its float32 bilinear weights)
+    for k, tol in (('backbone_out', 1e-10), ('head_in', 5e-6), ('conv_upsample', 5e-6)):
+        np.testing.assert_allclose(o.net.taps[k].v, t.net.taps[k].v.detach().numpy(), atol=tol, rtol=0, err_msg=k)
     assert abs(co - ct) < 1e-7
     for k, g in o.net.grads.items():
         if np.abs(g).max() > 1e-7:                            # (a beta in front of conv + BN has an exactly-zero gradient)
