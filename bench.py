@@ -24,13 +24,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = 'tf-keras-deeplabv3p-model-set_amd'
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+MFMA_F32_PEAK_TFLOPS = 157.3   # same guide: dense fp32 matrix peak (v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=100)      # warm-up 20, >= 100 timed steps
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=16, help='per-GPU batch (with --scaling strong: the GLOBAL batch)')
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
                     help="weak: per-GPU batch fixed (default, what the driver measures); strong: the reference's semantics, "
@@ -45,6 +46,7 @@ def parse():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-sync-bn', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-streaming', action='store_true', help='skip the N=256 DRAM-streaming run of the roofline kernel')
     ap.add_argument('--cpu-steps', type=int, default=10)
     return ap.parse_args()
 
@@ -96,6 +98,35 @@ def cpu_baseline(args):
     except Exception as e:      # noqa: BLE001 - the second figure is optional
         out['numpy_oracle'] = {'error': str(e)[:80]}
     return out
+
+
+def streaming_variant(pkg, op):
+    """the roofline kernel on a tensor that cannot be cache-resident (N = 256: 357 MB in, 357 MB out
+    against 256 MB of Infinity Cache), outside the step, timed per launch with the library's HIP event pair"""
+    import ctypes
+    import torch
+    ops = importlib.import_module(PKG + '.ops')
+    L = importlib.import_module(PKG + '._lib').lib()
+    t = op.out
+    Nb, H, W, C = 256, t.H, t.W, op.c
+    x = torch.randn((Nb, H, W, C), device='cuda')
+    y = torch.empty_like(x)
+    w = torch.randn((op.k, op.k, C), device='cuda')
+    sc, sh = torch.rand(C, device='cuda') + 0.5, torch.randn(C, device='cuda')
+    part = ops.new_partials(C, 'cuda')
+    ts = []
+    for i in range(12):
+        L.probe_arm(4000 + i)
+        ops.dwconv2d_fwd(x, w, 1, op.rate, 'same', sc, sh, ops.ACT_RELU, out=y, partials=part)
+    torch.cuda.synchronize()
+    for i in range(2, 12):
+        ms = ctypes.c_float(0)
+        L.probe_read(4000 + i, ctypes.addressof(ms))
+        ts.append(ms.value)
+    us = 1e3 * sum(ts) / len(ts)
+    by = 2.0 * Nb * H * W * C * 4 + op.k * op.k * C * 4
+    return {'streaming_frac': round(by / us / 1e3 / HBM_PEAK_GBS, 4), 'streaming_avg_us': round(us, 2),
+            'streaming_shape': 'N=%d %dx%dx%d (%.0f MB each way)' % (Nb, H, W, C, by / 2e6)}
 
 
 def measured_traffic(kernel_name):
@@ -187,6 +218,10 @@ def main():
     probe_name = 'aspp3_depthwise' if any(getattr(o, 'name', '') == 'aspp3_depthwise' for o in model.graph.ops) else None
     # (N == 1 only: with collectives captured into the graph the forward must stay one segment)
     probe = ex.install_probe(probe_name) if (probe_name and world == 1) else None
+    # second probe: the largest pointwise GEMM of the step (decoder_conv0_pointwise) against the fp32 MFMA peak
+    # (north_star: "MFMA utilisation for the pointwise GEMMs"); fp32 path only
+    pw_name = 'decoder_conv0_pointwise' if any(getattr(o, 'name', '') == 'decoder_conv0_pointwise' for o in model.graph.ops) else None
+    pw_probe = ex.install_pw_probe(pw_name) if (pw_name and world == 1 and args.dtype == 'f32') else None
 
     def barrier():
         if world > 1:
@@ -200,6 +235,8 @@ def main():
         ex.train_step()
     if probe:
         probe.reset()
+    if pw_probe:
+        pw_probe.reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -243,6 +280,17 @@ def main():
                                'kernel': probe.kernel_name, 'avg_us': round(ms * 1e3, 3),
                                'algorithmic_bytes': int(algo),
                                'shape': 'N=%d %dx%dx%d k=%d rate=%d' % (N, t.H, t.W, op.c, op.k, op.rate)}
+        if pw_probe:
+            ms = pw_probe.mean_ms()
+            op = pw_probe.op
+            M, K, Nc = N * op.Ho * op.Wo, op.cin, op.cout
+            tf = 2.0 * M * K * Nc / (ms * 1e-3) / 1e12
+            out['roofline_mfma'] = {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                    'frac': round(tf / MFMA_F32_PEAK_TFLOPS, 4), 'kernel': 'pw_gemm_kernel (%s forward)' % op.name,
+                                    'avg_us': round(ms * 1e3, 2), 'flops': int(2.0 * M * K * Nc),
+                                    'shape': 'M=%d K=%d N=%d fp32 (v_mfma_f32_16x16x4_f32)' % (M, K, Nc)}
+        if probe and args.dtype == 'f32' and not args.no_streaming:
+            out['roofline'].update(streaming_variant(pkg, probe.op))
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)
     if torch.distributed.is_initialized():

@@ -201,7 +201,7 @@ class Plan:
         L = lib()
 
         def timed():
-            L.probe_arm(probe.count % 4096)
+            L.probe_arm(probe.base + probe.count % 2048)
             probe.count += 1
             fn(*args, torch.cuda.current_stream().cuda_stream)
         timed.no_capture = True
@@ -289,8 +289,10 @@ class Plan:
 
 
 class Probe:
-    def __init__(self, op, kernel_name):
-        self.op, self.kernel_name, self.count, self.first = op, kernel_name, 0, 0
+    """`base`: first of the 2048 event slots this probe cycles through (two probes can run in one step)"""
+
+    def __init__(self, op, kernel_name, base=0):
+        self.op, self.kernel_name, self.count, self.first, self.base = op, kernel_name, 0, 0, base
 
     def reset(self):
         torch.cuda.synchronize()
@@ -300,9 +302,9 @@ class Probe:
         torch.cuda.synchronize()
         L = lib()
         ts = []
-        for i in range(max(self.first, self.count - 4096), self.count):
+        for i in range(max(self.first, self.count - 2048), self.count):
             ms = ctypes.c_float(0)
-            L.probe_read(i % 4096, ctypes.addressof(ms))
+            L.probe_read(self.base + i % 2048, ctypes.addressof(ms))
             ts.append(ms.value)
         return sum(ts) / max(1, len(ts))
 
@@ -510,7 +512,8 @@ class Executor:
                     self._conv_forward_bf16(P, op, xp, ldx, sp, hp, act, part, rows)
                 elif k == 'conv_pw':
                     P.k(L.pwconv_fwd_wt, xp, ldx, sp, hp, act, st.ptr(op.w, st.Pt), st.ptr(op.b) if op.b else None,
-                        self.tptr(op.out), op.out.ld, part, ctypes.byref(rows), N * op.Ho * op.Wo, op.cin, op.cout)
+                        self.tptr(op.out), op.out.ld, part, ctypes.byref(rows), N * op.Ho * op.Wo, op.cin, op.cout,
+                        tag='pw:' + op.name)
                 elif k == 'conv_dw':
                     P.k(L.dwconv2d_fwd, xp, ldx, sp, hp, act, st.ptr(op.w), self.tptr(op.out), op.out.ld, part,
                         ctypes.byref(rows), N, xt.H, xt.W, op.c, op.k, op.stride, op.rate, op.pad_t, op.pad_l,
@@ -1191,6 +1194,13 @@ class Executor:
             kname = ('dwb_fwd_strip<%d, %d' if op.stride == 1 else 'dwb_fwd<%d, %d') % (8 if (op.k == 3 and op.c % 8 == 0) else 4, op.k)
         probe = Probe(op, kname)
         self.fwd.probe(name, probe)
+        return probe
+
+    def install_pw_probe(self, name):
+        """the same for one forward pointwise GEMM (fp32 path): the MFMA roofline entry of the bench line"""
+        op = [o for o in self.g.ops if getattr(o, 'name', None) == name and o.kind == 'conv_pw'][0]
+        probe = Probe(op, 'pw_gemm_kernel', base=2048)
+        self.fwd.probe('pw:' + name, probe)
         return probe
 
     def dropout_mask(self, op):
