@@ -149,7 +149,7 @@ class TorchModel(OracleModel):
         ce.backward()
         net.grads = {n: (t.grad.numpy() if t.grad is not None else np.zeros(tuple(t.shape))) for n, t in net.t.items()
                      if t.requires_grad}
-        return float(ce) + float(reg), float(ce), logits.detach().numpy()
+        return float(ce.detach()) + float(reg), float(ce.detach()), logits.detach().numpy()
 
     def sgd_step(self, lr=1e-2, momentum=0.9, optimizer='sgd'):
         net = self.net

@@ -183,6 +183,31 @@ def test_train_step_matches_oracle(model_type, H, W, freeze, OS):
         assert all(not p.trainable for p in m.graph.all_params() if p.layer.name.startswith('expanded_conv'))
 
 
+def test_train_step_150_classes():
+    """num_classes above 32 (ADE20K-sized label sets; the reference allows < 254, train.py:34): the head walks the
+    classes instead of holding them in registers -- loss, logits, head gradients and evaluation against the oracle"""
+    N, C, H, W = 2, 150, 65, 65
+    m, o = _pair('mobilenetv2_lite', H, W, C)
+    m.use_graphs = False
+    x, y = _data(N, H, W, C, seed=5)
+    loss = m.train_on_batch(x, y)
+    ex = m._executor(N, True)
+    drop = [op for op in m.graph.ops if op.kind == 'materialize' and op.rate > 0][0]
+    o.net.act_derivs = _act_derivs(m, ex)
+    o.net.act_derivs_seq = _act_derivs_seq(m, ex, o.net.act_derivs)
+    total, ce, logits = o.loss_and_grads(x, y, {'aspp_dropout': ex.dropout_mask(drop).cpu().numpy()})
+    assert abs(loss - ce) < TOL * max(1.0, abs(ce)), (loss, ce)
+    st = m._store
+    for name in ('conv_upsample/kernel', 'conv_upsample/bias', 'concat_projection/kernel', 'Conv/kernel'):
+        p = [q for q in m.graph.all_params() if q.name == name][0]
+        assert _rel(st.get(p, st.G), o.net.grads[name]) < 5e-3, name
+    mi = load_pkg().get_deeplabv3p_model('mobilenetv2_lite', C, (H, W), 16, training=False)
+    mi.set_weights_by_name(m.get_weights_by_name())
+    p = mi.predict(x)
+    assert p.shape == (N, H, W, C) and np.abs(p.sum(-1) - 1).max() < 1e-4
+    assert np.array_equal(mi.predict_mask(x), p.argmax(-1))
+
+
 def _record_injection(rec):
     import json
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')

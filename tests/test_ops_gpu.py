@@ -416,7 +416,8 @@ def test_resize_bilinear(ops, case):
     close(gx, O.resize_bilinear_bwd(g, h, w), rtol=3e-4, what='resize bwd')
 
 
-@pytest.mark.parametrize('C,ignore', [(21, 255), (19, 255), (21, 0), (2, 255), (5, 255), (13, 255), (27, 255), (32, 255)])
+@pytest.mark.parametrize('C,ignore', [(21, 255), (19, 255), (21, 0), (2, 255), (5, 255), (13, 255), (27, 255), (32, 255),
+                                      (33, 255), (150, 255), (253, 255)])      # > 32 classes: the class-walking kernels (train.py:34)
 def test_head_softmax_ce(ops, C, ignore):
     rng = np.random.default_rng(C)
     N, h, w, H, W = 2, 9, 9, 33, 33

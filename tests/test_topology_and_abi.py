@@ -97,6 +97,9 @@ def test_factory_surface():
     assert m.layers[-1].name == 'pred_mask' and m.get_layer('conv_upsample').count_params() == 256 * 21 + 21
     mi = pkg.get_deeplabv3p_model('mobilenetv2', 21, (513, 513), 16, training=False)
     assert mi.output_shape == (None, 513, 513, 21)
+    with pytest.raises(ValueError, match='num_classes'):
+        pkg.get_deeplabv3p_model('mobilenetv2', 254, (65, 65), 16)          # PNG label maps: < 254 classes (train.py:34)
+    assert pkg.get_deeplabv3p_model('mobilenetv2_lite', 150, (65, 65), 16).output_shape == (None, 65 * 65, 150)
     # freeze levels (model.py:106-115)
     m1 = pkg.get_deeplabv3p_model('mobilenetv2_lite', 21, (513, 513), 16, freeze_level=1)
     assert not m1.get_layer('expanded_conv_16_project').trainable and m1.get_layer('aspp0').trainable

@@ -330,6 +330,76 @@ __global__ __launch_bounds__(256) void head_kernel(HeadParams p) {
   }
 }
 
+// More than 32 classes (the reference allows up to 253: train.py:34): a pixel's class vector no longer fits registers.
+// One thread per output pixel walks the classes three times (maximum, sum of exponentials, outputs), re-interpolating
+// each logit from its 4 neighbours (L1 / L2 hits); same arithmetic as head_kernel, class by class.
+__global__ __launch_bounds__(256) void head_kernel_big(HeadParams p) {
+  __shared__ float wsum[4];
+  const float sy = (float)p.h / (float)p.H, sx = (float)p.w / (float)p.W;
+  float loss = 0.f;
+  for (long long s = (long long)blockIdx.x * 256 + threadIdx.x; s < p.total; s += (long long)gridDim.x * 256) {
+    const int ox = s % p.W;
+    const long long row = s / p.W;
+    const int oy = (int)(row % p.H), n = (int)(row / p.H);
+    const Lerp ly = lerp_coeff(oy, sy, p.h), lx = lerp_coeff(ox, sx, p.w);
+    const float* img = p.z + (size_t)n * p.h * p.w * p.ldz;
+    const float* ptl = img + ((size_t)ly.lo * p.w + lx.lo) * p.ldz;
+    const float* ptr = img + ((size_t)ly.lo * p.w + lx.hi) * p.ldz;
+    const float* pbl = img + ((size_t)ly.hi * p.w + lx.lo) * p.ldz;
+    const float* pbr = img + ((size_t)ly.hi * p.w + lx.hi) * p.ldz;
+    auto logit = [&](int c) {
+      const float top = ptl[c] + (ptr[c] - ptl[c]) * lx.t, bot = pbl[c] + (pbr[c] - pbl[c]) * lx.t;
+      return top + (bot - top) * ly.t;
+    };
+    float mx = -3.0e38f;
+    for (int c = 0; c < p.C; ++c) mx = fmaxf(mx, logit(c));
+    float sum = 0.f;
+    for (int c = 0; c < p.C; ++c) sum += __expf(logit(c) - mx);
+    const float inv = 1.f / sum;
+    const int lab = p.labels ? (int)p.labels[s] : -1;
+    const bool masked = p.ignore_index != 0 && lab == p.ignore_index;
+    const bool valid = p.labels && !masked && lab >= 0 && lab < p.C;
+    float li = 0.f, f = 0.f;
+    if (p.labels) {
+      const float pt = valid ? __expf(logit(lab) - mx) * inv : 0.f;
+      if (p.loss_kind == DL3P_LOSS_WEIGHTED_CE) {
+        const float wy = valid ? p.class_w[lab] : 0.f;
+        li = -wy * logf(pt);
+        f = wy;
+      } else if (p.loss_kind == DL3P_LOSS_FOCAL) {
+        const float pc = fmaxf(pt, 1e-15f);
+        const float om = 1.f - pc, lp = logf(pc);
+        const float pw1 = om > 0.f ? powf(om, p.focal_gamma - 1.f) : (p.focal_gamma == 1.f ? 1.f : 0.f);
+        const float pw = pw1 * om;
+        li = -p.focal_alpha * pw * lp;
+        f = pt >= 1e-15f ? p.focal_alpha * (pw - p.focal_gamma * pw1 * pc * lp) : 0.f;
+      } else {
+        const bool unclipped = pt > 1e-7f && pt < 1.f - 1e-7f;
+        li = -logf(fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f));
+        f = unclipped ? 1.f : 0.f;
+      }
+      if (p.pixel_w) { const float sw = p.pixel_w[s]; li *= sw; f *= sw; }
+      if (valid) loss += li;
+    }
+    const float gs = valid ? f * p.inv_count : 0.f;
+    for (int c = 0; c < p.ld_big; ++c) {
+      const bool in = c < p.C;
+      const float v = in ? logit(c) : 0.f;
+      const float pr = in ? __expf(v - mx) * inv : 0.f;
+      if (p.logits_big) p.logits_big[(size_t)s * p.ld_big + c] = v;
+      if (p.dlogits) p.dlogits[(size_t)s * p.ld_big + c] = in ? gs * (pr - (c == lab ? 1.f : 0.f)) : 0.f;
+      if (p.probs && in) p.probs[(size_t)s * p.C + c] = pr;
+    }
+  }
+  if (p.loss_partials) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) loss += __shfl_xor(loss, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = loss;
+    __syncthreads();
+    if (threadIdx.x == 0) p.loss_partials[blockIdx.x] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * p.inv_count;
+  }
+}
+
 extern "C" int dl3p_upsample_softmax_ce(const float* z, int ldz, const float* labels, int ignore_index,
                                         float inv_count, float* logits_big, float* probs, float* dlogits_big,
                                         int ld_big, float* loss_partials, int* rows_out, int N, int h, int w, int C,
@@ -348,7 +418,7 @@ extern "C" int dl3p_upsample_softmax_loss(const float* z, int ldz, const float* 
   DL3P_CHECK_ARG(z && aligned16(z) && ldz % 4 == 0, "dl3p_upsample_softmax_ce: logits must be 16-byte aligned, ld %% 4 == 0");
   DL3P_CHECK_ARG(loss_kind == DL3P_LOSS_CE || loss_kind == DL3P_LOSS_FOCAL || (loss_kind == DL3P_LOSS_WEIGHTED_CE && class_weights),
                  "dl3p_upsample_softmax_loss: bad loss kind %d (weighted CE needs class_weights[C])", loss_kind);
-  DL3P_CHECK_ARG(C > 0 && C <= 32 && ldz >= ((C + 3) / 4) * 4, "dl3p_upsample_softmax_ce: C=%d (ld=%d) unsupported", C, ldz);
+  DL3P_CHECK_ARG(C > 0 && C <= 256 && ldz >= ((C + 3) / 4) * 4, "dl3p_upsample_softmax_ce: C=%d (ld=%d) unsupported", C, ldz);
   DL3P_CHECK_ARG(!labels || loss_partials, "dl3p_upsample_softmax_ce: loss_partials required with labels");
   DL3P_CHECK_ARG((!logits_big && !dlogits_big) || (ld_big >= C && (ld_big % 4 || (aligned16(logits_big) && aligned16(dlogits_big)))),
                  "dl3p_upsample_softmax_ce: bad ld_big=%d", ld_big);
@@ -363,6 +433,11 @@ extern "C" int dl3p_upsample_softmax_loss(const float* z, int ldz, const float* 
   if (blocks > DL3P_MAX_STAT_ROWS) blocks = DL3P_MAX_STAT_ROWS;
   if (rows_out) *rows_out = (int)blocks;
   hipStream_t st = (hipStream_t)stream;
+  if (C > 32) {
+    hipLaunchKernelGGL(head_kernel_big, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    DL3P_CHECK_LAUNCH("dl3p_upsample_softmax_ce");
+    return DL3P_OK;
+  }
   int cp = ((C + 3) / 4) * 4;
   // rows padded further than that (the bf16 graphs pad the class dimension to a multiple of 8: 19 classes -> 24): run the
   // instantiation that matches the row, so that the gradient still leaves as whole 16-byte vectors
@@ -439,11 +514,38 @@ __global__ __launch_bounds__(256) void argmax_confusion_kernel(EvalParams p) {
   }
 }
 
+__global__ __launch_bounds__(256) void argmax_confusion_big(EvalParams p) {
+  const float sy = (float)p.h / (float)p.H, sx = (float)p.w / (float)p.W;
+  for (long long s = (long long)blockIdx.x * 256 + threadIdx.x; s < p.total; s += (long long)gridDim.x * 256) {
+    const int ox = s % p.W;
+    const long long row = s / p.W;
+    const int oy = (int)(row % p.H), n = (int)(row / p.H);
+    const Lerp ly = lerp_coeff(oy, sy, p.h), lx = lerp_coeff(ox, sx, p.w);
+    const float* img = p.z + (size_t)n * p.h * p.w * p.ldz;
+    const float* ptl = img + ((size_t)ly.lo * p.w + lx.lo) * p.ldz;
+    const float* ptr = img + ((size_t)ly.lo * p.w + lx.hi) * p.ldz;
+    const float* pbl = img + ((size_t)ly.hi * p.w + lx.lo) * p.ldz;
+    const float* pbr = img + ((size_t)ly.hi * p.w + lx.hi) * p.ldz;
+    float best = -3.0e38f;
+    int arg = 0;
+    for (int c = 0; c < p.C; ++c) {
+      const float top = ptl[c] + (ptr[c] - ptl[c]) * lx.t, bot = pbl[c] + (pbr[c] - pbl[c]) * lx.t;
+      const float v = top + (bot - top) * ly.t;
+      if (v > best) { best = v; arg = c; }
+    }
+    if (p.pred) p.pred[s] = arg;
+    if (p.labels && p.cm) {
+      const int lab = (int)p.labels[s];
+      if (lab >= 0 && lab < p.C) atomicAdd(&p.cm[(size_t)lab * p.C + arg], 1ull);
+    }
+  }
+}
+
 extern "C" int dl3p_argmax_confusion(const float* z, int ldz, const float* labels, int32_t* pred_mask,
                                      unsigned long long* confusion, int N, int h, int w, int C, int H, int W,
                                      void* stream) {
   DL3P_CHECK_ARG(z && aligned16(z) && ldz % 4 == 0, "dl3p_argmax_confusion: logits must be 16-byte aligned, ld %% 4 == 0");
-  DL3P_CHECK_ARG(C > 0 && C <= 32 && N > 0 && h > 0 && w > 0 && H > 0 && W > 0, "dl3p_argmax_confusion: bad dims (C=%d)", C);
+  DL3P_CHECK_ARG(C > 0 && C <= 256 && N > 0 && h > 0 && w > 0 && H > 0 && W > 0, "dl3p_argmax_confusion: bad dims (C=%d)", C);
   DL3P_CHECK_ARG(pred_mask || (labels && confusion), "dl3p_argmax_confusion: nothing to produce");
   DL3P_CHECK_ARG(!confusion || labels, "dl3p_argmax_confusion: a confusion matrix needs labels");
   EvalParams p = {};
@@ -455,8 +557,13 @@ extern "C" int dl3p_argmax_confusion(const float* z, int ldz, const float* label
   if (blocks > 4096) blocks = 4096;
   const int cp = ((C + 3) / 4) * 4;
   DL3P_CHECK_ARG(ldz >= cp, "dl3p_argmax_confusion: ld=%d must be >= %d for C=%d", ldz, cp, C);
-  const size_t lds = (labels && confusion) ? (size_t)C * C * sizeof(unsigned int) : 0;
   hipStream_t st = (hipStream_t)stream;
+  if (C > 32) {
+    hipLaunchKernelGGL(argmax_confusion_big, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    DL3P_CHECK_LAUNCH("dl3p_argmax_confusion");
+    return DL3P_OK;
+  }
+  const size_t lds = (labels && confusion) ? (size_t)C * C * sizeof(unsigned int) : 0;
   switch (cp) {
 #define DL3P_AC_CASE(CP) case CP: hipLaunchKernelGGL((argmax_confusion_kernel<CP>), dim3((unsigned)blocks), dim3(256), lds, st, p); break;
     DL3P_AC_CASE(4) DL3P_AC_CASE(8) DL3P_AC_CASE(12) DL3P_AC_CASE(16) DL3P_AC_CASE(20) DL3P_AC_CASE(24) DL3P_AC_CASE(28)

@@ -699,9 +699,10 @@ def _build_model(model_type, num_classes, model_input_shape, output_stride, free
         raise ValueError('This model type is not supported now')
     if use_subpixel:
         raise ValueError('Subpixel head is experimental in the reference (README TODO) and not on the hot path')
-    if not 1 <= int(num_classes) <= 32:
-        # the loss / argmax head kernels keep a pixel's class vector in registers (VOC 21, Cityscapes 19)
-        raise ValueError('num_classes must be in [1, 32] (got %r): the HIP head kernels hold one pixel\'s classes in registers' % (num_classes,))
+    if not 1 <= int(num_classes) <= 253:
+        # PNG label maps hold fewer than 254 classes (train.py:34); up to 32 classes a pixel's class vector stays in
+        # registers in the head kernels, beyond that they walk the classes (dl3p_upsample_softmax_loss)
+        raise ValueError('num_classes must be in [1, 253] (got %r)' % (num_classes,))
 
     model_function = deeplab_model_map[model_type]
     H, W = model_input_shape
