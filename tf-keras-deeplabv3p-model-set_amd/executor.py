@@ -213,19 +213,6 @@ class Plan:
         self.items.append((None, fn))
         self.labels.append(('py', self.ctx))
 
-    def k_side(self, side, fn, *args):
-        """a launch on the side stream `side`, ordered behind everything queued on the current stream so far; the caller
-        joins the streams again (Plan.join_side).  Captured into the hipGraph as a parallel branch."""
-        def run():
-            side.wait_stream(torch.cuda.current_stream())
-            fn(*args, side.cuda_stream)
-        run.label = getattr(fn, '__name__', str(fn))
-        self.py(run)
-        self.labels[-1] = (run.label, self.ctx)
-
-    def join_side(self, side):
-        self.py(lambda: torch.cuda.current_stream().wait_stream(side))
-
     def coll(self, fn):
         """a collective (RCCL all-reduce); counted for the bench line"""
         self.n_collectives = getattr(self, 'n_collectives', 0) + 1
@@ -744,26 +731,9 @@ class Executor:
         readers = self._bn_readers() if self.sync_bn else {}
         rops = list(reversed(self.g.ops))
 
-        # Weight gradients of the small maps (33 x 33 at OS 16: kernels of 10-25 us that fill a fraction of the chip and
-        # feed nothing further down the chain) run on a side stream beside the data-gradient chain, with their own slab
-        # workspace; the large ones stay in line (two bandwidth- or MFMA-bound kernels side by side thrash each other's
-        # L2 working sets: DESIGN.md section 4, "One stream for the compute kernels")
-        side_rows = int(os.environ.get('DL3P_SIDE_WGRAD_ROWS', '20000'))
-        side = None
-        if side_rows > 0 and not defer and self.dist is None:
-            side = self._side_stream = getattr(self, '_side_stream', None) or torch.cuda.Stream()
-            if getattr(self, 'workspace_side', None) is None:
-                self.workspace_side = torch.zeros_like(self.workspace)
-        used_side = [False]
-
-        def wgrad(fn, *args, rows=None):
+        def wgrad(fn, *args):
             if defer:
                 self._deferred.append((fn, args, P.ctx))
-            elif side is not None and rows is not None and rows <= side_rows:
-                a = list(args)
-                a[a.index(ws)] = self.workspace_side.data_ptr()      # the slab workspace argument
-                P.k_side(side, fn, *a)
-                used_side[0] = True
             else:
                 P.k(fn, *args)
         for ri, op in enumerate(rops):
@@ -809,16 +779,15 @@ class Executor:
                 need_gx = xt.requires_grad or xt.root.requires_grad
                 if op.layer.trainable:
                     gw = st.ptr(op.w, G)
-                    mrows = N * op.Ho * op.Wo
                     if k == 'conv_pw':
                         wgrad(L.pwconv_bwd_weight, xp, ldx, sp, hp, act, dz, lddz, gw, st.ptr(op.b, G) if op.b else None,
-                              ws, wsb, mrows, op.cin, op.cout, rows=mrows)
+                              ws, wsb, N * op.Ho * op.Wo, op.cin, op.cout)
                     elif k == 'conv_dw':
                         wgrad(L.dwconv2d_bwd_weight, xp, ldx, sp, hp, act, dz, lddz, gw, ws, wsb, N, xt.H, xt.W, op.c,
-                              op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo, rows=mrows)
+                              op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
                     else:
                         wgrad(L.pwconv_bwd_weight, self.tptr(op.col), op.col.ld, None, None, ACT_NONE, dz, lddz, gw,
-                              st.ptr(op.b, G) if op.b else None, ws, wsb, mrows, op.kp, op.cout, rows=mrows)
+                              st.ptr(op.b, G) if op.b else None, ws, wsb, N * op.Ho * op.Wo, op.kp, op.cout)
                 if need_gx:
                     gp, ldg, keyt = self._gbuf(op.x)
                     acc = self._acc(keyt)
@@ -910,8 +879,6 @@ class Executor:
                 raise NotImplementedError(k)
         if self._bwd_pending:
             self._flush_bn_backward(P)
-        if used_side[0]:
-            P.join_side(side)
         self._flush_deferred(P)
         if self.dist is not None:
             P.coll(lambda hi=self._first_bucket_hi: self.dist.all_reduce_async(G[0:hi]))
