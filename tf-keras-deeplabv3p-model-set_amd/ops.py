@@ -499,6 +499,41 @@ def im2col(x, k, stride=1, rate=1, padding='same', in_scale=None, in_shift=None,
     return col
 
 
+def stem_conv_supported(Cin, Cout, k, stride, rate):
+    return bool(lib().stem_conv_supported(Cin, Cout, k, stride, rate))
+
+
+def stem_conv_fwd(x, w, padding='same', partials=None):
+    """the RGB stem (3x3 stride 2) without an im2col matrix: x (N,H,W,3); w (3,3,3,Cout) -> y (N,Ho,Wo,Cout) [, rows]"""
+    N, H, W, Cin = x.shape
+    Cout = w.shape[-1]
+    assert stem_conv_supported(Cin, Cout, w.shape[0], 2, 1)
+    Ho, Wo, pt, pl = conv_geometry(H, W, 3, 2, 1, padding)
+    wk = torch.zeros((28, Cout), dtype=torch.float32, device=x.device)
+    wk[:27] = w.reshape(27, Cout)
+    y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+    xp, ldx = _pl(x)
+    rows = ctypes.c_int(0)
+    lib().stem_conv_fwd(xp, ldx, _p(wk), _p(y), Cout, _p(partials), ctypes.byref(rows), N, H, W, Cout, pt, pl, Ho, Wo,
+                        _stream())
+    return (y, rows.value) if partials is not None else y
+
+
+def stem_conv_bwd_weight(x, dy, padding='same'):
+    """-> gw (3,3,3,Cout)"""
+    N, H, W, Cin = x.shape
+    Cout = dy.shape[-1]
+    Ho, Wo, pt, pl = conv_geometry(H, W, 3, 2, 1, padding)
+    need = lib().stem_conv_bwd_weight_workspace(N, Ho, Wo, Cout)
+    ws = torch.empty(need // 4, dtype=torch.float32, device=x.device)
+    gw = torch.full((28, Cout), float('nan'), dtype=torch.float32, device=x.device)
+    xp, ldx = _pl(x)
+    dp, ldd = _pl(dy)
+    lib().stem_conv_bwd_weight(xp, ldx, dp, ldd, _p(gw), _p(ws), need, N, H, W, Cout, pt, pl, Ho, Wo, _stream())
+    assert float(gw[27].abs().max()) == 0.0
+    return gw[:27].reshape(3, 3, 3, Cout)
+
+
 def col2im(gcol, x_shape, k, stride=1, rate=1, padding='same', out=None, accumulate=False):
     N, H, W, Cin = x_shape
     Ho, Wo, pt, pl = conv_geometry(H, W, k, stride, rate, padding)
