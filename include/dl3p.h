@@ -60,6 +60,21 @@ int dl3p_device_cus(void);
  * restores it).  Unknown names return DL3P_EINVAL. */
 int dl3p_set_option(const char* name, int value);
 
+/* ---------------------------------------------------------------- data-parallel collectives (RCCL over xGMI)
+ * replaces tf.distribute.MirroredStrategy's cross-replica sums (reference train.py:143-158: gradients, and
+ * SyncBatchNormalization's batch statistics) for hosts that are not Python; one process per GPU.  librccl is bound at
+ * run time (DL3P_RCCL_LIB overrides the search).  Rank 0 calls dl3p_comm_unique_id and hands the 128 bytes to the
+ * other ranks by whatever channel the host has; every rank then calls dl3p_comm_init.  The reductions are in-place
+ * sums, asynchronous on `stream`: fp32 for contiguous slices of the flat gradient buffer, fp64 for the BatchNorm
+ * staging vector of (sum, sum^2) / (sum g', sum g' xhat) pairs (DESIGN.md section 6 has the order of calls of a step).
+ * The Python facade uses torch.distributed (backend 'nccl' = RCCL) instead, so that the collectives are captured
+ * into the step's hipGraph. */
+int dl3p_comm_unique_id(void* id128);
+int dl3p_comm_init(void** comm_out, int rank, int world_size, const void* id128);
+int dl3p_comm_allreduce(void* comm, float* buf, size_t count, void* stream);
+int dl3p_comm_syncbn_allreduce(void* comm, double* sums, size_t count, void* stream);
+int dl3p_comm_destroy(void* comm);
+
 /* ---------------------------------------------------------------- depthwise convolution
  * replaces DepthwiseConv2D (DepthwiseConv2dNative [+SpaceToBatchND for dilation]) at
  * layers.py:100 (SepConv_BN, ASPP rates 6/12/18), deeplabv3p_mobilenetv2.py:56,

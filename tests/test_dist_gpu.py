@@ -34,3 +34,40 @@ def test_bench_runs_under_the_launcher_with_one_rank():
     out = json.loads(lines[-1])
     # 65 BatchNorms x (forward + backward) + 4 gradient buckets = 134 un-coalesced; the ASPP branches share all-reduces
     assert out['n_gpus'] == 1 and out['value'] > 0 and 0 < out['config']['collectives_per_step'] <= 124
+
+
+def test_comm_c_abi_single_rank():
+    """dl3p_comm_* (RCCL behind the C ABI, for hosts that are not Python): a one-rank communicator, fp32 gradient-bucket
+    and fp64 SyncBatchNorm all-reduces in place on a side stream (sums over one rank = identity), destroy.  Run in a
+    child process: the communicator must not share a process with torch.distributed's."""
+    code = r'''
+import ctypes, importlib, sys, torch
+sys.path.insert(0, %r)
+L = importlib.import_module('tf-keras-deeplabv3p-model-set_amd._lib').lib()
+uid = ctypes.create_string_buffer(128)
+L.comm_unique_id(uid)
+assert any(uid.raw), 'unique id is empty'
+comm = ctypes.c_void_p()
+L.comm_init(ctypes.byref(comm), 0, 1, uid)
+g = torch.randn(1 << 20, device='cuda')
+s = torch.randn(4096, device='cuda', dtype=torch.float64)
+g0, s0 = g.clone(), s.clone()
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    L.comm_allreduce(comm, g.data_ptr(), g.numel(), side.cuda_stream)
+    L.comm_syncbn_allreduce(comm, s.data_ptr(), s.numel(), side.cuda_stream)
+    L.comm_allreduce(comm, g[1000:5000].data_ptr(), 4000, side.cuda_stream)      # a bucket = a slice of the flat buffer
+torch.cuda.current_stream().wait_stream(side)
+torch.cuda.synchronize()
+assert torch.equal(g, g0) and torch.equal(s, s0)
+L.comm_destroy(comm)
+try:
+    L.comm_allreduce(None, g.data_ptr(), 4, None)
+    raise SystemExit('null communicator accepted')
+except Exception as e:
+    assert 'bad arguments' in str(e), e
+print('COMM OK')
+''' % ROOT
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0 and 'COMM OK' in r.stdout, (r.stdout[-1500:], r.stderr[-2500:])
