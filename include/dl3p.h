@@ -178,6 +178,30 @@ int dl3p_stem_conv_bwd_weight(const float* x, int ldx, const float* dy, int lddy
                               size_t workspace_bytes, int N, int H, int W, int Cout, int pad_t, int pad_l,
                               int Ho, int Wo, void* stream);
 
+/* Dense k x k convolutions with Cin % 4 == 0 (k <= 7, stride 1 or 2, any rate) as IMPLICIT GEMMs on the MFMA kernels of
+ * dl3p_pwconv_*: the patch operand is gathered while the A tile is staged into LDS, so no im2col matrix exists in HBM
+ * (reference: deeplabv3p_xception.py:119-127 strided 1x1 shortcuts, :175-183 entry_flow_conv1_2; ResNet50's 3x3 convs).
+ *   fwd:        wt = the HWIO kernel flattened [k*k*Cin][Cout] and TRANSPOSED to [Cout][k*k*Cin] (what dl3p_pwconv_fwd_wt
+ *               takes); prologue / bias / statistics epilogue as for dl3p_pwconv_fwd.
+ *   bwd_data:   wd = dl3p_conv2d_gemm_dgrad_weights(w) = [Cin][k*k*Cout]; gx (N,H,W,Cin) is written (or accumulated)
+ *               completely, pixels no output tap reaches get zero.
+ *   bwd_weight: gw [k*k*Cin][Cout] (+ gb [Cout] = column sums of dy, or NULL), deterministic slab reduction in
+ *               `workspace`. */
+int dl3p_conv2d_gemm_supported(int Cin, int Cout, int k, int stride);
+int dl3p_conv2d_gemm_fwd(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                         const float* wt, const float* bias, float* y, int ldy, float* stat_partials, int* rows_out,
+                         int N, int H, int W, int Cin, int Cout, int k, int stride, int rate, int pad_t, int pad_l,
+                         int Ho, int Wo, void* stream);
+int dl3p_conv2d_gemm_dgrad_weights(const float* w, float* wd, int k, int Cin, int Cout, void* stream);
+int dl3p_conv2d_gemm_bwd_data(const float* dy, int lddy, const float* wd, float* gx, int ldgx, int accumulate,
+                              int N, int H, int W, int Cin, int Cout, int k, int stride, int rate, int pad_t, int pad_l,
+                              int Ho, int Wo, void* stream);
+size_t dl3p_conv2d_gemm_bwd_weight_workspace(int N, int Ho, int Wo, int Cin, int Cout, int k);
+int dl3p_conv2d_gemm_bwd_weight(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                                const float* dy, int lddy, float* gw, float* gb, float* workspace,
+                                size_t workspace_bytes, int N, int H, int W, int Cin, int Cout, int k, int stride,
+                                int rate, int pad_t, int pad_l, int Ho, int Wo, void* stream);
+
 /* transpose of dl3p_im2col in gather form (deterministic): gx[n,iy,ix,ci] (+)= sum over the taps that read
  * it of gcol[m][tap*Cin+ci].  Cin % 4 == 0. */
 int dl3p_col2im(const float* gcol, int ld_col, float* gx, int ldgx, int accumulate, int N, int H, int W, int Cin,

@@ -289,6 +289,52 @@ def test_conv2d_stem(ops, case):
     close(gx, gx_ref, rtol=3e-4, what='conv bwd data')
 
 
+# (N, H, W, Cin, Cout, k, stride, rate, padding, act)
+CONV_GEMM = [(2, 33, 33, 32, 64, 3, 1, 1, 'same', O.ACT_RELU),          # Xception entry_flow_conv1_2
+             (2, 33, 33, 64, 128, 1, 2, 1, 'same', O.ACT_NONE),         # strided 1x1 shortcut, odd size
+             (1, 32, 40, 128, 256, 1, 2, 1, 'same', O.ACT_NONE),        # ... even size
+             (2, 17, 23, 64, 64, 3, 2, 1, 'same', O.ACT_RELU),          # ResNet 3x3 stride 2, odd
+             (1, 16, 24, 8, 24, 3, 2, 1, (0, 1, 0, 1), O.ACT_RELU6),    # explicit (0,1) padding + 'valid', even
+             (1, 19, 19, 16, 32, 3, 1, 2, 'same', O.ACT_RELU6),         # atrous
+             (3, 9, 11, 12, 20, 5, 1, 1, 'same', O.ACT_HSWISH),         # 5x5, channel counts not multiples of 16
+             (1, 21, 21, 4, 8, 7, 2, 1, 'same', O.ACT_NONE),            # 7x7 stride 2
+             (2, 65, 65, 728, 1024, 1, 2, 1, 'same', O.ACT_NONE)]       # exit-flow shortcut width
+
+
+@pytest.mark.parametrize('case', CONV_GEMM)
+def test_conv2d_implicit_gemm(ops, case):
+    """dense convolutions on the GEMM kernels with the patch operand gathered during LDS staging (no im2col / col2im):
+    forward + statistics, data gradient (stride-2 parity gaps written as zeros, accumulate), weight gradient"""
+    N, H, W, Cin, Cout, k, s, r, pad, act = case
+    rng = np.random.default_rng(Cin + Cout + k)
+    x = rng.standard_normal((N, H, W, Cin))
+    w = rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)
+    sc = rng.uniform(0.5, 1.5, Cin)
+    sh = rng.standard_normal(Cin) * 0.3
+    a = O.act_fwd(x * sc + sh, act) if act != O.ACT_NONE else x
+    pro = (T(sc), T(sh), act) if act != O.ACT_NONE else (None, None, O.ACT_NONE)
+    y_ref = O.conv2d_fwd(a, w, s, r, pad)
+    part = ops.new_partials(Cout, DEV)
+    y, rows = ops.conv2d_gemm_fwd(T(x), T(w), s, r, pad, *pro, partials=part)
+    close(y, y_ref, rtol=3e-4, what='implicit conv fwd')
+    s1, s2 = stats_from(part, rows, Cout)
+    close(s1, y_ref.reshape(-1, Cout).sum(0), rtol=2e-4, atol=1e-2, what='implicit conv stat')
+    close(s2, (y_ref ** 2).reshape(-1, Cout).sum(0), rtol=2e-4, what='implicit conv stat sq')
+    gy = rng.standard_normal(y_ref.shape)
+    gx_ref, gw_ref, _ = O.conv2d_bwd(a, w, gy, s, r, pad)
+    gx = ops.conv2d_gemm_bwd_data(T(gy), T(w), (N, H, W, Cin), s, r, pad)
+    close(gx, gx_ref, rtol=3e-4, what='implicit conv bwd data')
+    base = rng.standard_normal((N, H, W, Cin))
+    acc = T(base)
+    ops.conv2d_gemm_bwd_data(T(gy), T(w), (N, H, W, Cin), s, r, pad, out=acc, accumulate=True)
+    close(acc, base + gx_ref, rtol=3e-4, what='implicit conv bwd data accumulate')
+    gw, gb = ops.conv2d_gemm_bwd_weight(T(x), T(gy), k, s, r, pad, *pro, with_bias=True)
+    close(gw, gw_ref, rtol=5e-4, what='implicit conv bwd weight')
+    close(gb, gy.reshape(-1, Cout).sum(0), rtol=2e-4, atol=1e-3, what='implicit conv bias gradient')
+    b = rng.standard_normal(Cout)
+    close(ops.conv2d_gemm_fwd(T(x), T(w), s, r, pad, *pro, bias=T(b)), y_ref + b, rtol=3e-4, what='implicit conv fwd + bias')
+
+
 @pytest.mark.parametrize('case', [(2, 33, 33, 32, 'same'), (1, 32, 48, 16, (0, 1, 0, 1)), (3, 65, 129, 32, 'same'),
                                   (1, 64, 258, 16, 'same'), (2, 17, 263, 32, (0, 1, 0, 1)), (1, 3, 3, 32, 'same'),
                                   (1, 130, 513, 32, 'same')])

@@ -46,6 +46,15 @@ struct GemmParams {
   // i.e. exactly what dl3p_bn_bwd_reduce would compute from the finished gradient y in a separate pass
   const float* bb_z; int bb_ldz;
   const float* bb_scale; const float* bb_shift; const float* bb_mean; const float* bb_invstd; int bb_act;
+  // implicit-GEMM gather of the A operand (dense k x k convolutions without a patch matrix in HBM; GA instantiations
+  // only).  Row m = (n, y, x) over g_RH x g_RW; column k = tap * g_C + c; the element is the source tensor
+  // [N][g_SH][g_SW][lda] at (sy, sx) = ((y * g_mul + g_ay + ky * g_d) >> g_shift, likewise x with g_ax), zero when that is
+  // outside the source or (data gradient of a strided conv) not a multiple of the stride.
+  //   forward:        rows = output pixels, source = input,   g_mul = stride, g_ay = -pad_t, g_d = +rate, g_shift = 0
+  //   data gradient:  rows = input pixels,  source = dy,      g_mul = 1,      g_ay = +pad_t, g_d = -rate, g_shift = log2(stride)
+  int g_RH, g_RW, g_SH, g_SW, g_C, g_kw, g_mul, g_ay, g_ax, g_d, g_shift;
+  uint32_t g_cmagic;   // floor(2^32 / g_C) + 1: tap = umulhi(k, g_cmagic), exact for k < 2^16 (hosts check K)
+  int g_kwmagic;       // 65536 / g_kw + 1: ky = (tap * g_kwmagic) >> 16 for tap < 64
 #ifdef DL3P_STAMP
   long long* stamp;   // dev instrument: per-wave cycle counts of the loop phases (scripts/micro/stamp_gemm.py)
 #endif
@@ -56,7 +65,7 @@ struct GemmParams {
 #ifndef DL3P_GEMM_PIN_B
 #define DL3P_GEMM_PIN_B 1      // 0 builds the unpinned loop for A/B runs (scripts/micro/build_variant.sh)
 #endif
-template <int NT, bool B_KN, bool STATS, int MI, int BKT, bool BNB = false>
+template <int NT, bool B_KN, bool STATS, int MI, int BKT, bool BNB = false, bool GA = false>
 __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
   constexpr int AP = BKT + 4;   // A pitch: rows 4 apart land 16 banks apart -> ds_read_b128 conflict-free
   constexpr int KQ = BKT / 4;   // float4 per K-tile row
@@ -109,6 +118,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
   float4 rb[NB4];
   float4 rsc = make_float4(1.f, 1.f, 1.f, 1.f), rsh = zero4();
   uint32_t a_row[NA];        // byte offset of this thread's A rows in the current M tile
+  int g_by[GA ? NA : 1], g_bx[GA ? NA : 1];   // GA: source coordinates of tap (0, 0) of this thread's rows
+  uint32_t g_ok = 0;                          // GA: which of the NA loads in flight hit the source tensor
   uint32_t b_off[NB4];           // byte offset of this thread's B float4s at k0 = 0
   bool b_nok[NB4];               // column (B_KN) / row (!B_KN) of the B tile inside the matrix
   int pf_m0 = -1;
@@ -133,6 +144,42 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
     const int mt = blockIdx.x + (it / nk) * gridDim.x;
     const int m0 = mt * BM;
     const int k0 = kt * BKT;
+    if (GA) {
+      if (m0 != pf_m0) {
+        pf_m0 = m0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+          const int m = m0 + ar + RP * i;
+          const int mc = min(m, p.M - 1);
+          const int row = mc / p.g_RW, x = mc - row * p.g_RW;
+          const int n = row / p.g_RH, y = row - n * p.g_RH;
+          // rows past M get a base far outside the source: every tap fails the bounds check
+          g_by[i] = m < p.M ? y * p.g_mul + p.g_ay : -(1 << 20);
+          g_bx[i] = x * p.g_mul + p.g_ax;
+          a_row[i] = (uint32_t)n * (uint32_t)(p.g_SH * p.g_SW);      // pixel index of the image in the source
+        }
+      }
+      const int k = min(k0 + akq, p.K - 4);
+      const int tap = (int)__umulhi((uint32_t)k, p.g_cmagic);
+      const int c = k - tap * p.g_C;
+      const int ky = (tap * p.g_kwmagic) >> 16, kx = tap - ky * p.g_kw;
+      const int dyo = ky * p.g_d, dxo = kx * p.g_d;
+      const int par = (1 << p.g_shift) - 1;
+      g_ok = 0;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int ty = g_by[i] + dyo, tx = g_bx[i] + dxo;
+        const int sy = ty >> p.g_shift, sx = tx >> p.g_shift;
+        const bool ok = ty >= 0 && tx >= 0 && ((ty | tx) & par) == 0 && sy < p.g_SH && sx < p.g_SW && k0 + akq < p.K;
+        const uint32_t off = ok ? ((a_row[i] + (uint32_t)(sy * p.g_SW + sx)) * (uint32_t)p.lda + (uint32_t)c) * 4u : 0u;
+        ra[i] = *reinterpret_cast<const float4*>(Ab + off);
+        g_ok |= ok ? (1u << i) : 0u;
+      }
+      if (p.scale) {
+        rsc = *reinterpret_cast<const float4*>(p.scale + c);
+        rsh = *reinterpret_cast<const float4*>(p.shift + c);
+      }
+    } else {
     if (m0 != pf_m0) {
       pf_m0 = m0;
 #pragma unroll
@@ -144,6 +191,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
     if (p.scale) {
       rsc = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.scale) + kb);
       rsh = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.shift) + kb);
+    }
     }
 #ifdef DL3P_STAMP
     if (p.stagger == 104 && it > 0) return;      // ablation: no B loads after the first K-step
@@ -194,8 +242,9 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
       float4 v = ra[i];
       if (skip_a) { asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); continue; }
       if (has_pro) v = prologue4(v);
-      // zero rows/cols stay exactly zero (padding of the M and K tails)
-      if (a_edge) v = (kok && m0 + r < p.M) ? v : zero4();
+      // zero rows/cols stay exactly zero (padding of the M and K tails; GA: taps outside the source)
+      if (GA) v = ((g_ok >> i) & 1u) ? v : zero4();
+      else if (a_edge) v = (kok && m0 + r < p.M) ? v : zero4();
       *reinterpret_cast<float4*>(&As[r * AP + akq]) = v;
     }
 #ifdef DL3P_STAMP
@@ -701,7 +750,7 @@ static void gemm_grid(int M, int N, int nt, int* gx, int* gy, int* num_m_tiles, 
   *gx = g; *gy = nb; *num_m_tiles = mt; *mi_out = mi;
 }
 
-template <int NT, bool B_KN, bool STATS, int MI, int BKT, bool BNB = false>
+template <int NT, bool B_KN, bool STATS, int MI, int BKT, bool BNB = false, bool GA = false>
 static void launch_gemm_one(const GemmParams& p, dim3 grid, hipStream_t st) {
   constexpr int BM = 64 * MI, BN = 16 * NT, AP = BKT + 4;
   constexpr int BS = B_KN ? BKT * (BN + 4) : BN * AP;
@@ -713,27 +762,27 @@ static void launch_gemm_one(const GemmParams& p, dim3 grid, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)pw_gemm_kernel<NT, B_KN, STATS, MI, BKT, BNB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)pw_gemm_kernel<NT, B_KN, STATS, MI, BKT, BNB, GA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  dl3p_launch(pw_gemm_kernel<NT, B_KN, STATS, MI, BKT, BNB>, grid, dim3(256), lds, st, p);
+  dl3p_launch(pw_gemm_kernel<NT, B_KN, STATS, MI, BKT, BNB, GA>, grid, dim3(256), lds, st, p);
 }
 
-template <bool B_KN, bool STATS, int MI, int BKT, bool BNB = false>
+template <bool B_KN, bool STATS, int MI, int BKT, bool BNB = false, bool GA = false>
 static void launch_gemm_mi(const GemmParams& p, int nt, dim3 grid, hipStream_t st) {
   switch (nt) {
-    case 1: launch_gemm_one<1, B_KN, STATS, MI, BKT, BNB>(p, grid, st); break;
-    case 2: launch_gemm_one<2, B_KN, STATS, MI, BKT, BNB>(p, grid, st); break;
-    case 3: launch_gemm_one<3, B_KN, STATS, MI, BKT, BNB>(p, grid, st); break;
-    case 4: launch_gemm_one<4, B_KN, STATS, MI, BKT, BNB>(p, grid, st); break;
-    case 5: launch_gemm_one<5, B_KN, STATS, MI, BKT, BNB>(p, grid, st); break;
-    case 6: launch_gemm_one<6, B_KN, STATS, MI, BKT, BNB>(p, grid, st); break;
-    case 7: launch_gemm_one<7, B_KN, STATS, MI, BKT, BNB>(p, grid, st); break;
-    default: launch_gemm_one<8, B_KN, STATS, MI, BKT, BNB>(p, grid, st); break;
+    case 1: launch_gemm_one<1, B_KN, STATS, MI, BKT, BNB, GA>(p, grid, st); break;
+    case 2: launch_gemm_one<2, B_KN, STATS, MI, BKT, BNB, GA>(p, grid, st); break;
+    case 3: launch_gemm_one<3, B_KN, STATS, MI, BKT, BNB, GA>(p, grid, st); break;
+    case 4: launch_gemm_one<4, B_KN, STATS, MI, BKT, BNB, GA>(p, grid, st); break;
+    case 5: launch_gemm_one<5, B_KN, STATS, MI, BKT, BNB, GA>(p, grid, st); break;
+    case 6: launch_gemm_one<6, B_KN, STATS, MI, BKT, BNB, GA>(p, grid, st); break;
+    case 7: launch_gemm_one<7, B_KN, STATS, MI, BKT, BNB, GA>(p, grid, st); break;
+    default: launch_gemm_one<8, B_KN, STATS, MI, BKT, BNB, GA>(p, grid, st); break;
   }
 }
 
-template <bool B_KN, bool STATS, bool BNB = false>
+template <bool B_KN, bool STATS, bool BNB = false, bool GA = false>
 static void launch_gemm(const GemmParams& p_in, int nt, int mi, dim3 grid, hipStream_t st) {
   GemmParams p = p_in;
 #ifdef DL3P_STAMP
@@ -743,8 +792,8 @@ static void launch_gemm(const GemmParams& p_in, int nt, int mi, dim3 grid, hipSt
   { const char* e = getenv("DL3P_GEMM_STAGGER"); p.stagger = e ? atoi(e) : 0; }
   // (BKT = 64 -- half the barriers and staging passes per MFMA -- was measured neutral on the decoder layers and is
   // not instantiated: the loop is bound by matrix-pipe sharing between the two resident workgroups)
-  if (mi == 1) launch_gemm_mi<B_KN, STATS, 1, 32, BNB>(p, nt, grid, st);
-  else launch_gemm_mi<B_KN, STATS, 2, 32, BNB>(p, nt, grid, st);
+  if (mi == 1) launch_gemm_mi<B_KN, STATS, 1, 32, BNB, GA>(p, nt, grid, st);
+  else launch_gemm_mi<B_KN, STATS, 2, 32, BNB, GA>(p, nt, grid, st);
 }
 
 static int check_mat(const char* fn, const void* ptr, int ld, int cols) {
@@ -926,12 +975,27 @@ struct WgradParams {
   float* slabs;
   int M, K, N;
   int ktiles, ntiles, mchunk;
+  // implicit-GEMM gather of X (GX instantiations; see GemmParams): row m = (n, y, x) over g_RH x g_RW output pixels,
+  // column k = tap * g_C + c, element = input [N][g_SH][g_SW][ldx] at (y * g_mul + g_ay + ky * g_d, ...), zero outside
+  int g_RH, g_RW, g_SH, g_SW, g_C, g_kw, g_mul, g_ay, g_ax, g_d;
+  float g_invRW, g_invRH;   // 1 / g_RW, 1 / g_RH for divmod_small
 };
+
+// q = a / d, *r = a % d for 0 <= a < 2^24 (exact in float) and 0 < d < 2^14: one multiply by the reciprocal and one
+// correction step instead of the ~30-instruction 32-bit division (the weight-gradient gather decodes every staged row)
+__device__ __forceinline__ int divmod_small(int a, int d, float inv, int* r) {
+  int q = (int)((float)a * inv);
+  int rem = a - q * d;
+  if (rem < 0) { --q; rem += d; }
+  if (rem >= d) { ++q; rem -= d; }
+  *r = rem;
+  return q;
+}
 
 // Tile = (64 KW) x (16 NW) of GW: wave w owns k rows [16 KW w, 16 KW (w+1)) and all NW column tiles.  Larger
 // tiles re-read X (N / TN times) and DY (K / TK times) less often -- at 64 x 64 the 304 x 256 decoder layer
 // pulls 2.7 GB through L2 for 0.6 GB of operands.  Loads are unconditional on clamped offsets, zeroed by select.
-template <int KW, int NW>
+template <int KW, int NW, bool GX = false>
 __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradParams p) {
   constexpr int TK = 64 * KW, TN = 16 * NW;
   constexpr int XP = TK + 4, DP = TN + 4;      // pitches: rows 4 apart land 16 banks apart
@@ -950,6 +1014,8 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradParams p) {
   uint32_t xo[NX], dof[ND];
   bool xok[NX], dok[ND];
   float4 xsc[NX], xsh[NX];
+  int gx_dy[GX ? NX : 1], gx_dx[GX ? NX : 1];
+  uint32_t gx_ok = 0;
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
     const int idx = t + 256 * i;
@@ -958,7 +1024,16 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradParams p) {
     xok[i] = c < p.K;
     xo[i] = (uint32_t)min(c, p.K - 4) * 4u;
     xsc[i] = make_float4(1.f, 1.f, 1.f, 1.f); xsh[i] = zero4();
-    if (p.scale) { xsc[i] = ld4(p.scale + min(c, p.K - 4)); xsh[i] = ld4(p.shift + min(c, p.K - 4)); }
+    if (GX) {
+      // this thread's k columns never change: tap offsets and channel of each, once
+      const int k = min(c, p.K - 4);
+      const int tap = k / p.g_C, ch = k - tap * p.g_C;
+      const int ky = tap / p.g_kw, kx = tap - ky * p.g_kw;
+      gx_dy[i] = p.g_ay + ky * p.g_d;
+      gx_dx[i] = p.g_ax + kx * p.g_d;
+      xo[i] = (uint32_t)ch * 4u;
+      if (p.scale) { xsc[i] = ld4(p.scale + ch); xsh[i] = ld4(p.shift + ch); }
+    } else if (p.scale) { xsc[i] = ld4(p.scale + min(c, p.K - 4)); xsh[i] = ld4(p.shift + min(c, p.K - 4)); }
   }
 #pragma unroll
   for (int i = 0; i < ND; ++i) {
@@ -973,9 +1048,26 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradParams p) {
   const char* Xb = reinterpret_cast<const char*>(p.X);
   const char* Db = reinterpret_cast<const char*>(p.DY);
   float4 rx[NX], rd[ND];
+  auto gather_x = [&](int m0_) {
+    gx_ok = 0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int m = m0_ + xr[i];
+      const int mc = min(m, m_end - 1);
+      int x, y;
+      const int row = divmod_small(mc, p.g_RW, p.g_invRW, &x);
+      const int n = divmod_small(row, p.g_RH, p.g_invRH, &y);
+      const int sy = y * p.g_mul + gx_dy[i], sx = x * p.g_mul + gx_dx[i];
+      const bool ok = m < m_end && sy >= 0 && sx >= 0 && sy < p.g_SH && sx < p.g_SW;
+      const uint32_t off = ok ? (((uint32_t)n * (uint32_t)(p.g_SH * p.g_SW) + (uint32_t)(sy * p.g_SW + sx)) * (uint32_t)p.ldx) * 4u + xo[i] : 0u;
+      rx[i] = *reinterpret_cast<const float4*>(Xb + off);
+      gx_ok |= ok ? (1u << i) : 0u;
+    }
+  };
 #define WT_PREFETCH(m0_)                                                                                              \
   {                                                                                                                   \
-    _Pragma("unroll") for (int i = 0; i < NX; ++i)                                                                    \
+    if (GX) gather_x(m0_);                                                                                            \
+    else _Pragma("unroll") for (int i = 0; i < NX; ++i)                                                               \
       rx[i] = *reinterpret_cast<const float4*>(Xb + ((uint32_t)min((m0_) + xr[i], m_end - 1) * (uint32_t)p.ldx * 4u + xo[i]));   \
     _Pragma("unroll") for (int i = 0; i < ND; ++i)                                                                    \
       rd[i] = *reinterpret_cast<const float4*>(Db + ((uint32_t)min((m0_) + dr[i], m_end - 1) * (uint32_t)p.lddy * 4u + dof[i])); \
@@ -993,7 +1085,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradParams p) {
       if (p.act >= DL3P_ACT_HSWISH) v = act_apply4(v, p.act);
       else v = make_float4(__builtin_amdgcn_fmed3f(v.x, act_lo, act_hi), __builtin_amdgcn_fmed3f(v.y, act_lo, act_hi),
                            __builtin_amdgcn_fmed3f(v.z, act_lo, act_hi), __builtin_amdgcn_fmed3f(v.w, act_lo, act_hi));
-      const bool ok = xok[i] && m0 + xr[i] < m_end;
+      const bool ok = xok[i] && (GX ? ((gx_ok >> i) & 1u) != 0 : m0 + xr[i] < m_end);
       *reinterpret_cast<float4*>(&Xs[xr[i] * XP + (t + 256 * i - xr[i] * XQ) * 4]) = ok ? v : zero4();
     }
 #pragma unroll
@@ -1272,14 +1364,15 @@ static void wgrad_split(int M, int K, int N, int* ktiles, int* ntiles, int* spli
   *mchunk = chunk;
 }
 
+template <bool GX = false>
 static void launch_wgrad_tiled(const WgradParams& p, int splits, hipStream_t st) {
   int kw, nw;
   wgrad_pick_tile(p.M, p.K, p.N, &kw, &nw);
   const dim3 grid(p.ktiles * p.ntiles, splits), block(256);
-  if (kw == 1 && nw == 4) dl3p_launch(pw_wgrad_kernel<1, 4>, grid, block, 0, st, p);
-  else if (kw == 2 && nw == 4) dl3p_launch(pw_wgrad_kernel<2, 4>, grid, block, 0, st, p);
-  else if (kw == 1 && nw == 8) dl3p_launch(pw_wgrad_kernel<1, 8>, grid, block, 0, st, p);
-  else dl3p_launch(pw_wgrad_kernel<2, 8>, grid, block, 0, st, p);
+  if (kw == 1 && nw == 4) dl3p_launch(pw_wgrad_kernel<1, 4, GX>, grid, block, 0, st, p);
+  else if (kw == 2 && nw == 4) dl3p_launch(pw_wgrad_kernel<2, 4, GX>, grid, block, 0, st, p);
+  else if (kw == 1 && nw == 8) dl3p_launch(pw_wgrad_kernel<1, 8, GX>, grid, block, 0, st, p);
+  else dl3p_launch(pw_wgrad_kernel<2, 8, GX>, grid, block, 0, st, p);
 }
 
 // column sums of dy (bias gradient): one partial row per workgroup
@@ -1340,7 +1433,7 @@ extern "C" int dl3p_pwconv_bwd_weight(const float* x, int ldx, const float* in_s
     launch_wgrad_small_any(p, sh, splits, st);
   } else {
     wgrad_split(M, K, N, &p.ktiles, &p.ntiles, &splits, &p.mchunk);
-    launch_wgrad_tiled(p, splits, st);
+    launch_wgrad_tiled<false>(p, splits, st);
   }
   DL3P_CHECK_LAUNCH("dl3p_pwconv_bwd_weight");
   rc = dl3p_reduce_rows_impl(workspace, splits, (size_t)K * N, gw, 0, st);
@@ -1356,4 +1449,171 @@ extern "C" int dl3p_pwconv_bwd_weight(const float* x, int ldx, const float* in_s
     rc = dl3p_reduce_rows_impl(workspace, nbx, (size_t)N, gb, 0, st);
   }
   return rc;
+}
+
+
+// ------------------------------------------------------------------------------ dense convolutions as implicit GEMMs
+// k x k convolutions with Cin % 4 == 0 (Xception entry_flow_conv1_2 3x3 32->64 and its strided 1x1 shortcuts,
+// deeplabv3p_xception.py:119-127,175-183; ResNet50's 3x3 / strided convs) on the tiled GEMM kernels above with the patch
+// operand GATHERED while the A tile is staged into LDS (north_star "LDS-staged im2col tiles"): no [M][k*k*Cin] matrix in
+// HBM, no im2col / col2im pass.  Four consecutive k are four channels of one tap (Cin % 4 == 0), so the gather keeps the
+// 16-byte loads of the pointwise path; taps in the padding are selected to zero after the prologue.
+static int conv_gemm_check(const char* fn, int N, int H, int W, int Cin, int Cout, int k, int stride, int rate, int pad_t,
+                           int pad_l, int Ho, int Wo) {
+  DL3P_CHECK_ARG(dl3p_conv2d_gemm_supported(Cin, Cout, k, stride), "%s: unsupported conv (Cin=%d Cout=%d k=%d stride=%d)", fn,
+                 Cin, Cout, k, stride);
+  DL3P_CHECK_ARG(N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && rate > 0 && pad_t >= 0 && pad_l >= 0, "%s: bad geometry", fn);
+  DL3P_CHECK_ARG((long long)N * H * W < (1ll << 24) && (long long)N * Ho * Wo < (1ll << 24) && H < 16384 && W < 16384,
+                 "%s: tensor too large", fn);
+  DL3P_CHECK_ARG((Ho - 1) * stride - pad_t < H && (Wo - 1) * stride - pad_l < W, "%s: output larger than the strided input", fn);
+  return DL3P_OK;
+}
+
+extern "C" int dl3p_conv2d_gemm_supported(int Cin, int Cout, int k, int stride) {
+  static const int enabled = getenv("DL3P_CONV_GEMM") ? atoi(getenv("DL3P_CONV_GEMM")) : 1;
+  return enabled && Cin > 0 && Cout > 0 && Cin % 4 == 0 && Cout % 4 == 0 && k >= 1 && k <= 7 && (stride == 1 || stride == 2) &&
+         (long long)k * k * Cin < 65536;
+}
+
+static void conv_gather_fwd(GemmParams* p, int H, int W, int Cin, int k, int stride, int rate, int pad_t, int pad_l, int Ho,
+                            int Wo) {
+  p->g_RH = Ho; p->g_RW = Wo; p->g_SH = H; p->g_SW = W; p->g_C = Cin; p->g_kw = k;
+  p->g_mul = stride; p->g_ay = -pad_t; p->g_ax = -pad_l; p->g_d = rate; p->g_shift = 0;
+  p->g_cmagic = (uint32_t)((1ull << 32) / (unsigned)Cin) + 1u;
+  p->g_kwmagic = 65536 / k + 1;
+}
+
+extern "C" int dl3p_conv2d_gemm_fwd(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                                    const float* wt, const float* bias, float* y, int ldy, float* stat_partials,
+                                    int* rows_out, int N, int H, int W, int Cin, int Cout, int k, int stride, int rate,
+                                    int pad_t, int pad_l, int Ho, int Wo, void* stream) {
+  const char* fn = "dl3p_conv2d_gemm_fwd";
+  int rc = conv_gemm_check(fn, N, H, W, Cin, Cout, k, stride, rate, pad_t, pad_l, Ho, Wo);
+  if (rc) return rc;
+  rc = check_mat(fn, x, ldx, Cin);
+  if (rc) return rc;
+  rc = check_mat(fn, y, ldy, Cout);
+  if (rc) return rc;
+  DL3P_CHECK_ARG(wt && aligned16(wt), "%s: bad kernel pointer", fn);
+  const int M = N * Ho * Wo, K = k * k * Cin;
+  DL3P_CHECK_ARG((unsigned long long)N * H * W * (unsigned long long)ldx * 4ull < (1ull << 32) &&
+                     (unsigned long long)M * (unsigned long long)ldy * 4ull < (1ull << 32),
+                 "%s: operands of 4 GiB or more are not supported", fn);
+  GemmParams p = {};
+  p.A = x; p.lda = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act;
+  p.B = wt; p.ldb = K; p.bias = bias; p.Y = y; p.ldy = ldy; p.partials = stat_partials;
+  p.M = M; p.K = K; p.N = Cout;
+  conv_gather_fwd(&p, H, W, Cin, k, stride, rate, pad_t, pad_l, Ho, Wo);
+  const int nt = pick_nt(Cout, M);
+  int gx, gy, mi;
+  gemm_grid(M, Cout, nt, &gx, &gy, &p.num_m_tiles, &mi);
+  if (rows_out) *rows_out = gx;
+  if (stat_partials) launch_gemm<false, true, false, true>(p, nt, mi, dim3(gx, gy), (hipStream_t)stream);
+  else launch_gemm<false, false, false, true>(p, nt, mi, dim3(gx, gy), (hipStream_t)stream);
+  DL3P_CHECK_LAUNCH(fn);
+  return DL3P_OK;
+}
+
+// wd[ci][tap * Cout + co] = w[(tap * Cin + ci) * Cout + co]: the kernel as the [Nout = Cin][Kred = taps * Cout] operand of
+// the data-gradient GEMM (one launch per step and conv; the kernels are a few hundred KB)
+__global__ void conv_dgrad_weights_kernel(const float* w, float* wd, int taps, int Cin, int Cout) {
+  const int total = taps * Cin * Cout;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int co = i % Cout, r = i / Cout;
+    const int ci = r % Cin, tap = r / Cin;
+    wd[((size_t)ci * taps + tap) * Cout + co] = w[i];
+  }
+}
+
+extern "C" int dl3p_conv2d_gemm_dgrad_weights(const float* w, float* wd, int k, int Cin, int Cout, void* stream) {
+  DL3P_CHECK_ARG(w && wd && k >= 1 && Cin > 0 && Cout > 0, "dl3p_conv2d_gemm_dgrad_weights: bad arguments");
+  const int total = k * k * Cin * Cout;
+  hipLaunchKernelGGL(conv_dgrad_weights_kernel, dim3(ceil_div(total, 256) < 1024 ? ceil_div(total, 256) : 1024), dim3(256), 0,
+                     (hipStream_t)stream, w, wd, k * k, Cin, Cout);
+  DL3P_CHECK_LAUNCH("dl3p_conv2d_gemm_dgrad_weights");
+  return DL3P_OK;
+}
+
+extern "C" int dl3p_conv2d_gemm_bwd_data(const float* dy, int lddy, const float* wd, float* gx, int ldgx, int accumulate,
+                                         int N, int H, int W, int Cin, int Cout, int k, int stride, int rate, int pad_t,
+                                         int pad_l, int Ho, int Wo, void* stream) {
+  const char* fn = "dl3p_conv2d_gemm_bwd_data";
+  int rc = conv_gemm_check(fn, N, H, W, Cin, Cout, k, stride, rate, pad_t, pad_l, Ho, Wo);
+  if (rc) return rc;
+  rc = check_mat(fn, dy, lddy, Cout);
+  if (rc) return rc;
+  rc = check_mat(fn, gx, ldgx, Cin);
+  if (rc) return rc;
+  DL3P_CHECK_ARG(wd && aligned16(wd) && (long long)k * k * Cout < 65536, "%s: bad kernel operand", fn);
+  const int M = N * H * W, K = k * k * Cout;
+  DL3P_CHECK_ARG((unsigned long long)N * Ho * Wo * (unsigned long long)lddy * 4ull < (1ull << 32) &&
+                     (unsigned long long)M * (unsigned long long)ldgx * 4ull < (1ull << 32),
+                 "%s: operands of 4 GiB or more are not supported", fn);
+  GemmParams p = {};
+  p.A = dy; p.lda = lddy; p.act = DL3P_ACT_NONE;
+  p.B = wd; p.ldb = K; p.Y = gx; p.ldy = ldgx; p.accumulate = accumulate;
+  p.M = M; p.K = K; p.N = Cin;
+  // rows = input pixels; the tap (ky, kx) of input pixel (iy, ix) is output pixel ((iy + pad_t - ky*rate) / stride, ...)
+  p.g_RH = H; p.g_RW = W; p.g_SH = Ho; p.g_SW = Wo; p.g_C = Cout; p.g_kw = k;
+  p.g_mul = 1; p.g_ay = pad_t; p.g_ax = pad_l; p.g_d = -rate; p.g_shift = stride == 2 ? 1 : 0;
+  p.g_cmagic = (uint32_t)((1ull << 32) / (unsigned)Cout) + 1u;
+  p.g_kwmagic = 65536 / k + 1;
+  const int nt = pick_nt(Cin, M);
+  int gxn, gy, mi;
+  gemm_grid(M, Cin, nt, &gxn, &gy, &p.num_m_tiles, &mi);
+  launch_gemm<false, false, false, true>(p, nt, mi, dim3(gxn, gy), (hipStream_t)stream);
+  DL3P_CHECK_LAUNCH(fn);
+  return DL3P_OK;
+}
+
+extern "C" size_t dl3p_conv2d_gemm_bwd_weight_workspace(int N, int Ho, int Wo, int Cin, int Cout, int k) {
+  if (N <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || k <= 0) return 0;
+  int kt, nt, s, mc;
+  wgrad_split(N * Ho * Wo, k * k * Cin, Cout, &kt, &nt, &s, &mc);
+  const size_t a = (size_t)s * k * k * Cin * Cout, b = (size_t)512 * Cout;   // slabs; bias column-sum partial rows
+  return (a > b ? a : b) * sizeof(float);
+}
+
+extern "C" int dl3p_conv2d_gemm_bwd_weight(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                                           const float* dy, int lddy, float* gw, float* gb, float* workspace,
+                                           size_t workspace_bytes, int N, int H, int W, int Cin, int Cout, int k, int stride,
+                                           int rate, int pad_t, int pad_l, int Ho, int Wo, void* stream) {
+  const char* fn = "dl3p_conv2d_gemm_bwd_weight";
+  int rc = conv_gemm_check(fn, N, H, W, Cin, Cout, k, stride, rate, pad_t, pad_l, Ho, Wo);
+  if (rc) return rc;
+  rc = check_mat(fn, x, ldx, Cin);
+  if (rc) return rc;
+  rc = check_mat(fn, dy, lddy, Cout);
+  if (rc) return rc;
+  DL3P_CHECK_ARG(gw && workspace && aligned16(workspace) && aligned16(gw), "%s: bad arguments", fn);
+  const int M = N * Ho * Wo, K = k * k * Cin;
+  DL3P_CHECK_ARG((unsigned long long)N * H * W * (unsigned long long)ldx * 4ull < (1ull << 32) &&
+                     (unsigned long long)M * (unsigned long long)lddy * 4ull < (1ull << 32),
+                 "%s: operands of 4 GiB or more are not supported", fn);
+  const size_t need = dl3p_conv2d_gemm_bwd_weight_workspace(N, Ho, Wo, Cin, Cout, k);
+  if (workspace_bytes < need) {
+    dl3p_set_error("%s: workspace %zu < %zu bytes", fn, workspace_bytes, need);
+    return DL3P_EWORKSPACE;
+  }
+  WgradParams p = {};
+  p.X = x; p.ldx = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act;
+  p.DY = dy; p.lddy = lddy; p.slabs = workspace; p.M = M; p.K = K; p.N = Cout;
+  p.g_RH = Ho; p.g_RW = Wo; p.g_SH = H; p.g_SW = W; p.g_C = Cin; p.g_kw = k;
+  p.g_mul = stride; p.g_ay = -pad_t; p.g_ax = -pad_l; p.g_d = rate;
+  p.g_invRW = 1.f / (float)Wo; p.g_invRH = 1.f / (float)Ho;
+  int splits;
+  wgrad_split(M, K, Cout, &p.ktiles, &p.ntiles, &splits, &p.mchunk);
+  hipStream_t st = (hipStream_t)stream;
+  launch_wgrad_tiled<true>(p, splits, st);
+  DL3P_CHECK_LAUNCH(fn);
+  rc = dl3p_reduce_rows_impl(workspace, splits, (size_t)K * Cout, gw, 0, st);
+  if (rc || !gb) return rc;
+  DL3P_CHECK_ARG(aligned16(gb), "%s: gb must be 16-byte aligned", fn);
+  int c4s, px, nslab;
+  pick_lanes(Cout, &c4s, &px, &nslab);
+  const long long need_b = ceil_div_ll(M, px);
+  const int nbx = (int)(need_b < 512 ? need_b : 512);
+  hipLaunchKernelGGL(colsum_kernel, dim3(nbx * nslab), dim3(256), 0, st, dy, lddy, (long long)M, Cout, c4s, px, nbx, workspace);
+  DL3P_CHECK_LAUNCH("dl3p_conv2d_gemm_bwd_weight(colsum)");
+  return dl3p_reduce_rows_impl(workspace, nbx, (size_t)Cout, gb, 0, st);
 }

@@ -363,12 +363,18 @@ class Executor:
         g, N = self.g, self.N
         self.buf, self.grad = {}, {}
         self._mark_requires_grad()
-        direct_cols = {op.col.id for op in g.ops if op.kind == 'conv_dense' and self._stem_direct(op)}
+        direct_cols = {op.col.id for op in g.ops if op.kind == 'conv_dense' and (self._stem_direct(op) or self._dense_gemm(op))}
+        # the data-gradient GEMM of an implicit-GEMM conv reads the kernel as [Cin][k*k*Cout] (rebuilt every step)
+        self.dense_wd = {id(op): torch.zeros(op.k * op.k * op.cin * op.cout, **self.f32) for op in g.ops
+                         if op.kind == 'conv_dense' and self.training and self._dense_gemm(op) and op.k > 1}
+        # (a strided 1x1 conv keeps the gradient of its compact patch matrix = dz @ W^T on the output pixels: scattering
+        # that onto the strided input pixels is cheaper than a data-gradient GEMM over all input pixels, 3/4 of them zero)
+        grad_cols = {op.col.id for op in g.ops if op.kind == 'conv_dense' and self._dense_gemm(op) and op.k == 1}
         for t in g.tensors:
             dt = torch.float32 if t is self.head.tensor else self.adt
-            if t.id in direct_cols:
+            if t.id in direct_cols and not (t.id in grad_cols and self.training and t.requires_grad):
                 continue
-            if not getattr(t, 'grad_only', False):
+            if not getattr(t, 'grad_only', False) and t.id not in direct_cols:
                 self.buf[t.id] = torch.zeros(N * t.H * t.W * t.C, dtype=dt, device=self.dev)
             if self.training and t.requires_grad:
                 self.grad[t.id] = torch.zeros(N * t.H * t.W * t.C, dtype=dt, device=self.dev)
@@ -403,6 +409,8 @@ class Executor:
                 ws = max(ws, pw_ws(N * op.Ho * op.Wo, op.kp, op.cout))
                 if self._stem_direct(op):
                     ws = max(ws, L.stem_conv_bwd_weight_workspace(N, op.Ho, op.Wo, op.cout))
+                if self._dense_gemm(op):
+                    ws = max(ws, L.conv2d_gemm_bwd_weight_workspace(N, op.Ho, op.Wo, op.cin, op.cout, op.k))
         self.workspace = torch.zeros(ws // 4 + 4, **self.f32) if self.training else None
         # tickets + partial rows of the chunked per-image reductions (pooling, SE backward): zero once, every call
         # leaves its tickets at zero again; one stream runs all of them
@@ -449,6 +457,12 @@ class Executor:
                 and not (xt.requires_grad or xt.root.requires_grad)
                 and self.L.stem_conv_supported(op.cin, op.cout, op.k, op.stride, op.rate)
                 and os.environ.get('DL3P_STEM_DIRECT', '1') != '0')
+
+    def _dense_gemm(self, op):
+        """dense conv with Cin % 4 == 0 on the fp32 path: implicit GEMM, the patch operand gathered while the GEMM stages
+        its A tile (csrc/pwconv.hip, dl3p_conv2d_gemm_*) -- no im2col matrix, no col2im pass"""
+        return (not self.bf16 and not self._stem_direct(op)
+                and bool(self.L.conv2d_gemm_supported(op.cin, op.cout, op.k, op.stride)))
 
     def _mark_requires_grad(self):
         for t in self.g.tensors:
@@ -536,8 +550,12 @@ class Executor:
                 elif self._stem_direct(op):
                     P.k(L.stem_conv_fwd, xp, ldx, st.ptr(op.w), self.tptr(op.out), op.out.ld, part, ctypes.byref(rows), N,
                         xt.H, xt.W, op.cout, op.pad_t, op.pad_l, op.Ho, op.Wo, tag=op.name)
+                elif self._dense_gemm(op):
+                    P.k(L.conv2d_gemm_fwd, xp, ldx, sp, hp, act, st.ptr(op.w, st.Pt), st.ptr(op.b) if op.b else None,
+                        self.tptr(op.out), op.out.ld, part, ctypes.byref(rows), N, xt.H, xt.W, op.cin, op.cout, op.k,
+                        op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo, tag=op.name)
                 else:
-                    # other small dense convs: im2col once (kept for the weight gradient), then the MFMA GEMM
+                    # what is left (Cin not a multiple of 4, e.g. a 7x7 RGB stem): im2col once, then the MFMA GEMM
                     P.k(L.im2col, xp, ldx, sp, hp, act, self.tptr(op.col), op.col.ld, N, xt.H, xt.W, op.cin, op.k,
                         op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
                     P.k(L.pwconv_fwd_wt, self.tptr(op.col), op.col.ld, None, None, ACT_NONE, st.ptr(op.w, st.Pt),
@@ -806,6 +824,10 @@ class Executor:
                     elif self._stem_direct(op):
                         wgrad(L.stem_conv_bwd_weight, xp, ldx, dz, lddz, gw, ws, wsb, N, xt.H, xt.W, op.cout, op.pad_t,
                               op.pad_l, op.Ho, op.Wo)
+                    elif self._dense_gemm(op):
+                        wgrad(L.conv2d_gemm_bwd_weight, xp, ldx, sp, hp, act, dz, lddz, gw, st.ptr(op.b, G) if op.b else None,
+                              ws, wsb, N, xt.H, xt.W, op.cin, op.cout, op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho,
+                              op.Wo)
                     else:
                         wgrad(L.pwconv_bwd_weight, self.tptr(op.col), op.col.ld, None, None, ACT_NONE, dz, lddz, gw,
                               st.ptr(op.b, G) if op.b else None, ws, wsb, N * op.Ho * op.Wo, op.kp, op.cout)
@@ -848,6 +870,11 @@ class Executor:
                     elif k == 'conv_dw':
                         P.k(L.dwconv2d_bwd_data, dz, lddz, st.ptr(op.w), gp, ldg, acc, N, xt.H, xt.W, op.c, op.k,
                             op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
+                    elif k == 'conv_dense' and self._dense_gemm(op) and op.k > 1:
+                        wd = self.dense_wd[id(op)]
+                        P.k(L.conv2d_gemm_dgrad_weights, st.ptr(op.w), wd.data_ptr(), op.k, op.cin, op.cout)
+                        P.k(L.conv2d_gemm_bwd_data, dz, lddz, wd.data_ptr(), gp, ldg, acc, N, xt.H, xt.W, op.cin, op.cout,
+                            op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
                     else:
                         # d/d(im2col matrix) by the GEMM, then the transposed gather back onto the input pixels
                         P.k(L.pwconv_bwd_data, dz, lddz, st.ptr(op.w), self.tptr(op.col, True), op.col.ld, 0,

@@ -499,6 +499,55 @@ def im2col(x, k, stride=1, rate=1, padding='same', in_scale=None, in_shift=None,
     return col
 
 
+def conv2d_gemm_supported(Cin, Cout, k, stride):
+    return bool(lib().conv2d_gemm_supported(Cin, Cout, k, stride))
+
+
+def conv2d_gemm_fwd(x, w, stride=1, rate=1, padding='same', in_scale=None, in_shift=None, in_act=ACT_NONE, bias=None,
+                    partials=None):
+    """dense conv as an implicit GEMM (no im2col matrix): x (N,H,W,Cin), w (k,k,Cin,Cout) -> y (N,Ho,Wo,Cout) [, rows]"""
+    N, H, W, Cin = x.shape
+    k, Cout = w.shape[0], w.shape[-1]
+    Ho, Wo, pt, pl = conv_geometry(H, W, k, stride, rate, padding)
+    wt = w.reshape(k * k * Cin, Cout).t().contiguous()
+    y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+    xp, ldx = _pl(x)
+    rows = ctypes.c_int(0)
+    lib().conv2d_gemm_fwd(xp, ldx, _p(in_scale), _p(in_shift), in_act, _p(wt), _p(bias), _p(y), Cout, _p(partials),
+                          ctypes.byref(rows), N, H, W, Cin, Cout, k, stride, rate, pt, pl, Ho, Wo, _stream())
+    return (y, rows.value) if partials is not None else y
+
+
+def conv2d_gemm_bwd_data(dy, w, x_shape, stride=1, rate=1, padding='same', out=None, accumulate=False):
+    N, H, W, Cin = x_shape
+    k, Cout = w.shape[0], w.shape[-1]
+    Ho, Wo, pt, pl = conv_geometry(H, W, k, stride, rate, padding)
+    wd = torch.empty(Cin * k * k * Cout, dtype=torch.float32, device=dy.device)
+    lib().conv2d_gemm_dgrad_weights(_p(w.contiguous()), _p(wd), k, Cin, Cout, _stream())
+    gx = out if out is not None else torch.empty(x_shape, dtype=torch.float32, device=dy.device)
+    dp, ldd = _pl(dy)
+    gp, ldg = _pl(gx)
+    lib().conv2d_gemm_bwd_data(dp, ldd, _p(wd), gp, ldg, int(accumulate), N, H, W, Cin, Cout, k, stride, rate, pt, pl, Ho,
+                               Wo, _stream())
+    return gx
+
+
+def conv2d_gemm_bwd_weight(x, dy, k, stride=1, rate=1, padding='same', in_scale=None, in_shift=None, in_act=ACT_NONE,
+                           with_bias=False):
+    N, H, W, Cin = x.shape
+    Cout = dy.shape[-1]
+    Ho, Wo, pt, pl = conv_geometry(H, W, k, stride, rate, padding)
+    need = lib().conv2d_gemm_bwd_weight_workspace(N, Ho, Wo, Cin, Cout, k)
+    ws = torch.empty(need // 4 + 4, dtype=torch.float32, device=x.device)
+    gw = torch.empty((k, k, Cin, Cout), dtype=torch.float32, device=x.device)
+    xp, ldx = _pl(x)
+    dp, ldd = _pl(dy)
+    gb = torch.empty(Cout, dtype=torch.float32, device=x.device) if with_bias else None
+    lib().conv2d_gemm_bwd_weight(xp, ldx, _p(in_scale), _p(in_shift), in_act, dp, ldd, _p(gw), _p(gb), _p(ws), need, N, H, W,
+                                 Cin, Cout, k, stride, rate, pt, pl, Ho, Wo, _stream())
+    return (gw, gb) if with_bias else gw
+
+
 def stem_conv_supported(Cin, Cout, k, stride, rate):
     return bool(lib().stem_conv_supported(Cin, Cout, k, stride, rate))
 
