@@ -270,6 +270,20 @@ int dl3p_scale_bcast_bwd(const float* gy, int ldgy, const float* x, int ldx, con
 /* dst[i] = (float)src[i] / divide_by - subtract: normalize_image (common/data_utils.py:403-417: /127.5 - 1) and the
  * label cast (deeplabv3p/data.py:116-124: /1 - 0) for batches that arrive as bytes; bit-identical to NumPy float32 */
 int dl3p_u8_to_float(const unsigned char* src, float* dst, size_t n, float divide_by, float subtract, void* stream);
+/* Byte-level augmentations of SegmentationGenerator.__getitem__ (deeplabv3p/data.py:72-104) for uint8 RGB batches
+ * (N,H,W,3) and uint8 label maps (N,H,W); the random draws stay on the host, as in the reference.
+ * dl3p_aug_enhance_u8: PIL ImageEnhance.{Brightness (op 0), Color (1), Contrast (2), Sharpness (3)}(img).enhance(factor[n])
+ * = random_brightness / random_chroma / random_contrast / random_sharpness (common/data_utils.py:83-239), bit for bit
+ * (pinned against PIL, tests/golden/make_pil_enhance.py).  factor: N floats on the device.  sums: N uint64 workspace
+ * (Contrast only).  out may be img except for Sharpness.
+ * dl3p_aug_flip_crop_u8: random_horizontal_flip / random_vertical_flip (flags[n] bit 0 / bit 1; data_utils.py:14-60) and
+ * the crop branch of random_crop (:364-400: an (h, w) window at yx[n] = (y, x) of the flipped image) in one gather;
+ * img or label may be NULL, flags / yx may be NULL (no flip / whole image). */
+int dl3p_aug_enhance_u8(const unsigned char* img, unsigned char* out, const float* factor, int op,
+                        unsigned long long* sums, int N, int H, int W, void* stream);
+int dl3p_aug_flip_crop_u8(const unsigned char* img, unsigned char* out, const unsigned char* label,
+                          unsigned char* label_out, const int* flags, const int* yx, int N, int H, int W, int h, int w,
+                          void* stream);
 /* The label tail of SegmentationGenerator.__getitem__ for byte labels (N images of P pixels each):
  * labels_out = float(label), with label > num_classes-1 replaced by ignore_index (deeplabv3p/data.py:116-121);
  * weights_out (optional) = the `--weighted_type adaptive` pixel weights (data.py:134-145): sklearn's

@@ -1,0 +1,100 @@
+"""Byte-level augmentations (reference deeplabv3p/data.py:72-104, common/data_utils.py:14-60,83-239,364-400).
+CPU: the NumPy restatement (oracle/np_augment.py) against vectors made by PIL itself (tests/golden/pil_enhance.npz) and,
+when PIL is importable, against live PIL on larger images.  GPU: the device kernels against the restatement, bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import np_augment as A
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'pil_enhance.npz')
+
+
+def test_oracle_matches_pil_golden_vectors():
+    g = np.load(GOLD)
+    factors = g['factors']
+    n = 0
+    for i in range(4):
+        img = g['img%d' % i]
+        for op in range(4):
+            for j, f in enumerate(factors):
+                want = g['out%d_op%d_f%d' % (i, op, j)]
+                got = A.enhance(img, op, float(f))
+                assert np.array_equal(got, want), (i, op, f, int(np.abs(got.astype(int) - want.astype(int)).max()))
+                n += 1
+    assert n == 4 * 4 * len(factors)
+
+
+def test_oracle_matches_live_pil():
+    PIL = pytest.importorskip('PIL')
+    from PIL import Image, ImageEnhance
+    rng = np.random.default_rng(3)
+    ENH = [ImageEnhance.Brightness, ImageEnhance.Color, ImageEnhance.Contrast, ImageEnhance.Sharpness]
+    for shape in ((129, 161, 3), (3, 3, 3), (2, 9, 3), (300, 210, 3)):
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        for op, E in enumerate(ENH):
+            for f in (0.5, rng.uniform(0.5, 2.0), 1.0, 2.0):
+                want = np.asarray(E(Image.fromarray(img)).enhance(f))
+                assert np.array_equal(A.enhance(img, op, f), want), (shape, op, f)
+
+
+def test_flip_crop_restatement():
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (9, 11, 3), dtype=np.uint8)
+    lab = rng.integers(0, 21, (9, 11), dtype=np.uint8)
+    a, b = A.flip_crop(img, lab, 3, (2, 1), (5, 7))
+    assert np.array_equal(a, img[::-1, ::-1][2:7, 1:8]) and np.array_equal(b, lab[::-1, ::-1][2:7, 1:8])
+    a, b = A.flip_crop(img, lab, 1)
+    assert np.array_equal(a, np.flip(img, 1)) and np.array_equal(b, np.flip(lab, 1))       # cv2.flip(x, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(3, 37, 53), (2, 513, 513), (1, 1, 1), (5, 2, 3), (2, 64, 1024)])
+def test_device_enhance_matches_restatement(shape):
+    import torch
+    from conftest import load_pkg
+    aug = load_pkg('augment')
+    N, H, W = shape
+    rng = np.random.default_rng(H * W + N)
+    imgs = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)
+    if N > 1:
+        imgs[1] = np.clip(imgs[1].astype(int) // 3 + 170, 0, 255)      # an image that saturates under f > 1
+    t = torch.from_numpy(imgs).cuda()
+    for op in range(4):
+        for fs in ([0.5] * N, [2.0] * N, list(rng.uniform(0.5, 2.0, N)), [1.0] * N, [0.0] * N):
+            got = aug.enhance(t, op, fs).cpu().numpy()
+            for n in range(N):
+                want = A.enhance(imgs[n], op, float(np.float32(fs[n])))
+                assert np.array_equal(got[n], want), (shape, op, fs[n], int(np.abs(got[n].astype(int) - want.astype(int)).max()))
+    # in place (allowed for the pointwise ones)
+    t2 = t.clone()
+    aug.enhance(t2, A.COLOR, [1.5] * N, out=t2)
+    assert np.array_equal(t2.cpu().numpy(), np.stack([A.enhance(imgs[n], A.COLOR, 1.5) for n in range(N)]))
+
+
+@pytest.mark.gpu
+def test_device_flip_crop_matches_numpy():
+    import torch
+    from conftest import load_pkg
+    aug = load_pkg('augment')
+    rng = np.random.default_rng(8)
+    N, H, W = 6, 45, 67
+    imgs = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)
+    labs = rng.integers(0, 256, (N, H, W), dtype=np.uint8)
+    ti, tl = torch.from_numpy(imgs).cuda(), torch.from_numpy(labs).cuda()
+    flags = [0, 1, 2, 3, 1, 2]
+    yx = [(0, 0), (12, 30), (5, 0), (13, 31), (1, 2), (7, 7)]
+    for args in ((flags, None, None), (None, yx, (32, 36)), (flags, yx, (32, 36))):
+        a, b = aug.flip_crop(ti, tl, *args)
+        for n in range(N):
+            wa, wb = A.flip_crop(imgs[n], labs[n], 0 if args[0] is None else args[0][n], None if args[1] is None else args[1][n],
+                                 args[2])
+            assert np.array_equal(a[n].cpu().numpy(), wa) and np.array_equal(b[n].cpu().numpy(), wb), (args, n)
+    # the reference-named wrappers run and keep shapes / dtypes
+    np.random.seed(0)
+    a, b = aug.random_horizontal_flip(ti, tl)
+    a, b = aug.random_vertical_flip(a, b)
+    a = aug.random_sharpness(aug.random_contrast(aug.random_chroma(aug.random_brightness(a))))
+    a, b = aug.random_crop(a, b, (33, 33), prob=1.0)
+    assert a.shape == (N, 33, 33, 3) and b.shape == (N, 33, 33) and a.dtype == torch.uint8

@@ -15,7 +15,7 @@ _CT = {
     'const float*': ctypes.c_void_p, 'float*': ctypes.c_void_p,
     'const double*': ctypes.c_void_p, 'double*': ctypes.c_void_p,
     'const int64_t*': ctypes.c_void_p, 'int64_t*': ctypes.c_void_p,
-    'void*': ctypes.c_void_p, 'const void*': ctypes.c_void_p, 'void**': ctypes.POINTER(ctypes.c_void_p), 'int*': ctypes.POINTER(ctypes.c_int), 'unsigned long long*': ctypes.c_void_p, 'int32_t*': ctypes.c_void_p, 'uint32_t*': ctypes.c_void_p, 'const unsigned char*': ctypes.c_void_p, 'uint8_t*': ctypes.c_void_p, 'const uint8_t*': ctypes.c_void_p, 'const int*': ctypes.c_void_p, 'float*': ctypes.c_void_p,
+    'void*': ctypes.c_void_p, 'const void*': ctypes.c_void_p, 'void**': ctypes.POINTER(ctypes.c_void_p), 'int*': ctypes.POINTER(ctypes.c_int), 'unsigned long long*': ctypes.c_void_p, 'int32_t*': ctypes.c_void_p, 'uint32_t*': ctypes.c_void_p, 'const unsigned char*': ctypes.c_void_p, 'unsigned char*': ctypes.c_void_p, 'uint8_t*': ctypes.c_void_p, 'const uint8_t*': ctypes.c_void_p, 'const int*': ctypes.c_void_p, 'float*': ctypes.c_void_p,
     'int': ctypes.c_int, 'float': ctypes.c_float, 'double': ctypes.c_double,
     'size_t': ctypes.c_size_t, 'uint64_t': ctypes.c_uint64,
     'const char*': ctypes.c_char_p, 'void': None,

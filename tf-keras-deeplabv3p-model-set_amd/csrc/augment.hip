@@ -1,0 +1,133 @@
+// Byte-level augmentations of SegmentationGenerator.__getitem__ on the device (reference deeplabv3p/data.py:72-104,
+// common/data_utils.py): the two flips, the crop branch of random_crop, and the four PIL ImageEnhance adjustments
+// (random_brightness / random_chroma / random_contrast / random_sharpness, data_utils.py:83-239).  The random draws stay
+// on the host (the reference draws them with np.random / random); these kernels apply a batch of drawn decisions to a
+// batch of uint8 RGB images (N,H,W,3) and uint8 label maps (N,H,W), bit for bit what PIL / NumPy produce:
+//   ImageEnhance.X(img).enhance(f) = Image.blend(degenerate, img, f):
+//     0 <= f <= 1:  out = (uint8)(d + f * (v - d))            (float32, truncation)
+//     otherwise  :  out = clip(d + f * (v - d)) to [0, 255], then truncation
+//   degenerate:  Brightness 0;  Color L(pixel) = (19595 R + 38470 G + 7471 B + 0x8000) >> 16;
+//                Contrast int(mean(L over the image) + 0.5);  Sharpness ImageFilter.SMOOTH = 3x3 (1 1 1 / 1 5 1 / 1 1 1) / 13,
+//                + 0.5 then truncation (= (2 S + 13) / 26 in integers), border pixels copied.
+// Pinned against PIL itself by tests/golden/make_pil_enhance.py.
+#include "common.h"
+
+__device__ __forceinline__ unsigned char pil_blend(int d, int v, float f, bool interp) {
+  const float t = (float)d + f * (float)(v - d);
+  if (interp) return (unsigned char)t;
+  return t <= 0.f ? 0 : (t >= 255.f ? 255 : (unsigned char)t);
+}
+__device__ __forceinline__ int pil_luma(int r, int g, int b) { return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16; }
+
+// sum of L over each image (integer atomics: exact, order-independent)
+__global__ __launch_bounds__(256) void aug_luma_sum_kernel(const unsigned char* img, unsigned long long* sums, long long P) {
+  const int n = blockIdx.y;
+  const unsigned char* p = img + (size_t)n * P * 3;
+  unsigned long long s = 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < P; i += (long long)gridDim.x * 256)
+    s += (unsigned)pil_luma(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&sums[n], s);
+}
+
+template <int OP>
+__global__ __launch_bounds__(256) void aug_enhance_kernel(const unsigned char* img, unsigned char* out, const float* factor,
+                                                          const unsigned long long* sums, int H, int W) {
+  const int n = blockIdx.y;
+  const long long P = (long long)H * W;
+  const unsigned char* src = img + (size_t)n * P * 3;
+  unsigned char* dst = out + (size_t)n * P * 3;
+  const float f = factor[n];
+  const bool interp = f >= 0.f && f <= 1.f;
+  int mean = 0;
+  if (OP == 2) mean = (int)((double)sums[n] / (double)P + 0.5);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < P; i += (long long)gridDim.x * 256) {
+    const int r = src[3 * i], g = src[3 * i + 1], b = src[3 * i + 2];
+    int dr = 0, dg = 0, db = 0;
+    if (OP == 1) dr = dg = db = pil_luma(r, g, b);
+    if (OP == 2) dr = dg = db = mean;
+    if (OP == 3) {
+      const int y = (int)(i / W), x = (int)(i - (long long)y * W);
+      if (y == 0 || x == 0 || y == H - 1 || x == W - 1) {
+        dr = r; dg = g; db = b;
+      } else {
+        int s[3] = {0, 0, 0};
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+          for (int dx = -1; dx <= 1; ++dx) {
+            const unsigned char* q = src + ((long long)(y + dy) * W + (x + dx)) * 3;
+            const int k = (dy == 0 && dx == 0) ? 5 : 1;
+            s[0] += k * q[0]; s[1] += k * q[1]; s[2] += k * q[2];
+          }
+        dr = (2 * s[0] + 13) / 26; dg = (2 * s[1] + 13) / 26; db = (2 * s[2] + 13) / 26;
+      }
+    }
+    dst[3 * i] = pil_blend(dr, r, f, interp);
+    dst[3 * i + 1] = pil_blend(dg, g, f, interp);
+    dst[3 * i + 2] = pil_blend(db, b, f, interp);
+  }
+}
+
+extern "C" int dl3p_aug_enhance_u8(const unsigned char* img, unsigned char* out, const float* factor, int op,
+                                   unsigned long long* sums, int N, int H, int W, void* stream) {
+  DL3P_CHECK_ARG(img && out && factor && N > 0 && H > 0 && W > 0 && op >= 0 && op <= 3, "dl3p_aug_enhance_u8: bad arguments");
+  DL3P_CHECK_ARG(op != 3 || img != out, "dl3p_aug_enhance_u8: sharpness cannot run in place");
+  DL3P_CHECK_ARG(op != 2 || sums, "dl3p_aug_enhance_u8: contrast needs the N-entry sums workspace");
+  hipStream_t st = (hipStream_t)stream;
+  const long long P = (long long)H * W;
+  long long gx = ceil_div_ll(P, 256 * 8);
+  if (gx > 1024) gx = 1024;
+  if (gx < 1) gx = 1;
+  const dim3 grid((unsigned)gx, N), block(256);
+  if (op == 2) {
+    hipError_t e = hipMemsetAsync(sums, 0, sizeof(unsigned long long) * N, st);
+    DL3P_CHECK_ARG(e == hipSuccess, "dl3p_aug_enhance_u8: memset failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(aug_luma_sum_kernel, grid, block, 0, st, img, sums, P);
+  }
+  if (op == 0) hipLaunchKernelGGL(aug_enhance_kernel<0>, grid, block, 0, st, img, out, factor, sums, H, W);
+  else if (op == 1) hipLaunchKernelGGL(aug_enhance_kernel<1>, grid, block, 0, st, img, out, factor, sums, H, W);
+  else if (op == 2) hipLaunchKernelGGL(aug_enhance_kernel<2>, grid, block, 0, st, img, out, factor, sums, H, W);
+  else hipLaunchKernelGGL(aug_enhance_kernel<3>, grid, block, 0, st, img, out, factor, sums, H, W);
+  DL3P_CHECK_LAUNCH("dl3p_aug_enhance_u8");
+  return DL3P_OK;
+}
+
+// flips (flags[n] bit 0: horizontal = cv2.flip(.., 1), bit 1: vertical = cv2.flip(.., 0)) and a crop window, in one
+// gather: out[n, y, x] = in[n, fy(y0[n] + y), fx(x0[n] + x)] for an (h, w) window at (y0, x0) (NULL: the whole image)
+__global__ __launch_bounds__(256) void aug_flip_crop_kernel(const unsigned char* img, unsigned char* out, const unsigned char* label,
+                                                            unsigned char* label_out, const int* flags, const int* yx, int H,
+                                                            int W, int h, int w) {
+  const int n = blockIdx.y;
+  const int fl = flags ? flags[n] : 0;
+  const int y0 = yx ? yx[2 * n] : 0, x0 = yx ? yx[2 * n + 1] : 0;
+  const long long P = (long long)h * w;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < P; i += (long long)gridDim.x * 256) {
+    const int y = (int)(i / w), x = (int)(i - (long long)y * w);
+    // the reference flips first, then crops: the window is taken from the flipped image
+    int sy = y0 + y, sx = x0 + x;
+    if (fl & 2) sy = H - 1 - sy;
+    if (fl & 1) sx = W - 1 - sx;
+    const long long s = ((long long)n * H + sy) * W + sx, d = (long long)n * P + i;
+    if (img) {
+      out[3 * d] = img[3 * s]; out[3 * d + 1] = img[3 * s + 1]; out[3 * d + 2] = img[3 * s + 2];
+    }
+    if (label) label_out[d] = label[s];
+  }
+}
+
+extern "C" int dl3p_aug_flip_crop_u8(const unsigned char* img, unsigned char* out, const unsigned char* label,
+                                     unsigned char* label_out, const int* flags, const int* yx, int N, int H, int W, int h,
+                                     int w, void* stream) {
+  DL3P_CHECK_ARG((img || label) && N > 0 && H > 0 && W > 0 && h > 0 && w > 0 && h <= H && w <= W, "dl3p_aug_flip_crop_u8: bad arguments");
+  DL3P_CHECK_ARG((!img || (out && out != img)) && (!label || (label_out && label_out != label)), "dl3p_aug_flip_crop_u8: needs distinct outputs");
+  DL3P_CHECK_ARG(yx || (h == H && w == W), "dl3p_aug_flip_crop_u8: a window smaller than the image needs its offsets");
+  const long long P = (long long)h * w;
+  long long gx = ceil_div_ll(P, 256 * 8);
+  if (gx > 1024) gx = 1024;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(aug_flip_crop_kernel, dim3((unsigned)gx, N), dim3(256), 0, (hipStream_t)stream, img, out, label, label_out,
+                     flags, yx, H, W, h, w);
+  DL3P_CHECK_LAUNCH("dl3p_aug_flip_crop_u8");
+  return DL3P_OK;
+}
