@@ -217,11 +217,12 @@ def main():
     # roofline probe: the rate-18 depthwise launch stays outside the graph segments, between two events
     probe_name = 'aspp3_depthwise' if any(getattr(o, 'name', '') == 'aspp3_depthwise' for o in model.graph.ops) else None
     # (N == 1 only: with collectives captured into the graph the forward must stay one segment)
-    probe = ex.install_probe(probe_name) if (probe_name and world == 1) else None
+    dist_mode = world > 1 or os.environ.get('DL3P_FORCE_DIST', '0') not in ('', '0')
+    probe = ex.install_probe(probe_name) if (probe_name and not dist_mode) else None
     # second probe: the largest pointwise GEMM of the step (decoder_conv0_pointwise) against the fp32 MFMA peak
     # (north_star: "MFMA utilisation for the pointwise GEMMs"); fp32 path only
     pw_name = 'decoder_conv0_pointwise' if any(getattr(o, 'name', '') == 'decoder_conv0_pointwise' for o in model.graph.ops) else None
-    want_pw_probe = bool(pw_name and world == 1 and args.dtype == 'f32')
+    want_pw_probe = bool(pw_name and not dist_mode and args.dtype == 'f32')
 
     def barrier():
         if world > 1:
@@ -275,8 +276,21 @@ def main():
                        'launches_per_step': ex.fwd.n_launches + ex.bwd.n_launches + ex.opt.n_launches,
                        'collectives_per_step': sum(getattr(pl, 'n_collectives', 0) for pl in (ex.fwd, ex.bwd, ex.opt))},
         }
+        standalone = None
+        if not probe and probe_name and dist_mode and args.dtype == 'f32':
+            # N > 1: the forward is one graph (collectives captured), so the roofline launch is re-issued on the buffers of
+            # the last step and timed with the same HIP event pair
+            class _P:
+                pass
+            probe = _P()
+            probe.op = [o for o in model.graph.ops if getattr(o, 'name', '') == probe_name and o.kind == 'conv_dw'][0]
+            probe.kernel_name = 'dw_fwd_lattice2' if (args.model, args.size, args.os) == ('mobilenetv2', 513, 16) else 'depthwise forward'
+            # ... behind the launches that precede it in the step, from the GEMM that writes its input (so that it meets
+            # the step's cache state, not one warmed by its own previous run)
+            prod = ex.g.producer_of(probe.op.x.tensor)
+            standalone = ex.time_tagged_launch(probe_name, context_from='pw:' + getattr(prod, 'name', ''))
         if probe:
-            ms = probe.mean_ms()
+            ms = standalone if standalone is not None else probe.mean_ms()
             op = probe.op
             t = op.out
             es = 2 if args.dtype == 'bf16' else 4
@@ -289,6 +303,9 @@ def main():
                                'kernel': probe.kernel_name, 'avg_us': round(ms * 1e3, 3),
                                'algorithmic_bytes': int(algo),
                                'shape': 'N=%d %dx%dx%d k=%d rate=%d' % (N, t.H, t.W, op.c, op.k, op.rate)}
+            if standalone is not None:
+                out['roofline']['measured'] = ('rank 0, after the timed region: 20 x [the launches of the step from the GEMM that writes its '
+                                               'input up to it, re-issued on the last step\'s buffers], the last one timed')
         if pw_probe:
             ms = pw_probe.mean_ms()
             op = pw_probe.op
@@ -298,7 +315,7 @@ def main():
                                     'frac': round(tf / MFMA_F32_PEAK_TFLOPS, 4), 'kernel': 'pw_gemm_kernel (%s forward)' % op.name,
                                     'avg_us': round(ms * 1e3, 2), 'flops': int(2.0 * M * K * Nc),
                                     'shape': 'M=%d K=%d N=%d fp32 (v_mfma_f32_16x16x4_f32)' % (M, K, Nc)}
-        if probe and args.dtype == 'f32' and not args.no_streaming:
+        if probe and standalone is None and args.dtype == 'f32' and not args.no_streaming:
             out['roofline'].update(streaming_variant(pkg, probe.op))
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)

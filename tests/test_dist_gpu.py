@@ -34,6 +34,8 @@ def test_bench_runs_under_the_launcher_with_one_rank():
     out = json.loads(lines[-1])
     # 65 BatchNorms x (forward + backward) + 4 gradient buckets = 134 un-coalesced; the ASPP branches share all-reduces
     assert out['n_gpus'] == 1 and out['value'] > 0 and 0 < out['config']['collectives_per_step'] <= 124
+    # with the collectives inside the graph the roofline launch is timed by re-issuing it after the timed region
+    assert out['roofline']['achieved'] > 0 and 'measured' in out['roofline']
 
 
 def test_comm_c_abi_single_rank():
