@@ -727,10 +727,21 @@ static int pick_nt(int N, int M) {
 // grid: persistent workgroups over M tiles.  Small maps (M = N*33*33) give only ~137 tiles of 128 rows,
 // which quantises badly over 256 CUs; 64-row tiles (MI = 1) are used whenever 128-row tiles would leave
 // the chip under two rounds of work.
-static void gemm_grid(int M, int N, int nt, int* gx, int* gy, int* num_m_tiles, int* mi_out) {
+static void gemm_grid(int M, int N, int nt, int* gx, int* gy, int* num_m_tiles, int* mi_out, bool bn_sums = false) {
   const int nb = ceil_div(N, 16 * nt);
   int mi = 2;
   if ((long long)ceil_div(M, 128) * nb < 4LL * DL3P_NUM_CUS) mi = 1;
+  // Long GEMMs with wide column blocks (the decoder layers: 266256 rows, 256 / 304 columns): 64-row tiles leave room for
+  // THREE resident workgroups per CU (137 VGPRs, 44 KB of LDS each) instead of two of 128 rows.  The SQ counters show
+  // the two-workgroup version's waves parked on their barriers / load waits 21 % of the time and, sharing one matrix
+  // pipe, in step with each other (profiles/r02_gemm_wave_state_counters.txt); a third workgroup fills those gaps:
+  // 266256x304->256 forward 492 -> 455 us, data gradient 462 -> 428; 256->256 400 -> 376 / 348 -> 319 (same box).
+  static const int long_rows = getenv("DL3P_GEMM_LONG_ROWS") ? atoi(getenv("DL3P_GEMM_LONG_ROWS")) : 60000;
+  static const int long_nt = getenv("DL3P_GEMM_LONG_NT") ? atoi(getenv("DL3P_GEMM_LONG_NT")) : 2;
+  // (not for the data gradient with the fused BatchNorm sums: its z-prefetch registers cap it at two workgroups per CU
+  // either way -- forced under 168 VGPRs it spills 7-26 registers and is no faster -- and at 64 rows with two it is 6-15 %
+  // slower: 537 -> 615 us in the step)
+  if (M >= long_rows && nt >= long_nt && !bn_sums) mi = 1;
   int per_cu = nt <= 1 ? 6 : (nt == 2 ? 5 : (nt <= 4 ? 3 : 2));
   if (mi == 1 && per_cu < 3) per_cu = 3;
   static const int e_mi = getenv("DL3P_GEMM_MI") ? atoi(getenv("DL3P_GEMM_MI")) : 0;
@@ -957,7 +968,7 @@ extern "C" int dl3p_pwconv_bwd_data_bn(const float* dy, int lddy, const float* w
   p.bb_act = act;
   const int nt = pick_nt(K, M);
   int gxn, gy, mi;
-  gemm_grid(M, K, nt, &gxn, &gy, &p.num_m_tiles, &mi);
+  gemm_grid(M, K, nt, &gxn, &gy, &p.num_m_tiles, &mi, true);
   *rows_out = gxn;
   launch_gemm<false, true, true>(p, nt, mi, dim3(gxn, gy), (hipStream_t)stream);
   DL3P_CHECK_LAUNCH("dl3p_pwconv_bwd_data_bn");
