@@ -57,7 +57,9 @@ const char* dl3p_last_error_string(void);
 int dl3p_device_cus(void);
 /* dispatch knobs that tests need to move at run time.  "pw_small_min_rows": the row count from which the
  * wave-independent streaming GEMM kernels replace the tiled kernel for small K x N (production 131072; value < 0
- * restores it).  Unknown names return DL3P_EINVAL. */
+ * restores it).  "gemm_nt" (1..8) / "gemm_mi" (1, 2): pin the column-block width (16 * nt) / tile rows (64 * mi) of the
+ * tiled GEMM, 0 = automatic; "gemm_tuned" 0: ignore the measured tile table (csrc/gemm_tuned.h) -- what
+ * scripts/tune_gemm.py uses to time the candidates.  Unknown names return DL3P_EINVAL. */
 int dl3p_set_option(const char* name, int value);
 
 /* ---------------------------------------------------------------- data-parallel collectives (RCCL over xGMI)

@@ -48,5 +48,15 @@ def wgrad():
     ops.pwconv_bwd_weight(xs[i[0]], gs[i[0]], sc, sh, ops.ACT_RELU)
 
 
+zs = [torch.randn(M, K, device='cuda') for _ in range(2)]
+mean, invstd = torch.zeros(K, device='cuda'), torch.ones(K, device='cuda')
+
+
+def dgrad_bn():
+    # the data gradient with the fused BatchNorm-backward sums (what the executor launches behind a BN + activation)
+    i[0] = (i[0] + 1) % NB
+    ops.pwconv_bwd_data_bn(gs[i[0]], w, zs[i[0] % 2], sc, sh, ops.ACT_RELU6, mean, invstd, part, out=gxs[i[0]])
+
+
 fl = 2.0 * M * K * N / 157e6
-print('M=%d K=%d N=%d  floor %.1f us (157 TF)   fwd %.1f us  dgrad %.1f us  wgrad %.1f us' % (M, K, N, fl, timeit(fwd), timeit(dgrad), timeit(wgrad)))
+print('M=%d K=%d N=%d  floor %.1f us (157 TF)   fwd %.1f us  dgrad %.1f us  dgrad+bn %.1f us  wgrad %.1f us' % (M, K, N, fl, timeit(fwd), timeit(dgrad), timeit(dgrad_bn), timeit(wgrad)))

@@ -666,6 +666,7 @@ static bool pw_small_pick(int K, int N, SmallShape* out) {
 // rows from which the streaming small-K.N kernels take over from the tiled kernel (production: 2^17).  The parity
 // tests lower it through dl3p_set_option so that small test shapes reach those kernels too, and reset it for the
 // tests that check the production dispatch at the production shapes.
+static int g_gemm_force_nt = 0, g_gemm_force_mi = 0, g_gemm_use_table = -1;   // see gemm_tuned_lookup / gemm_plan
 static int g_pw_small_min_rows = -1;
 static int pw_small_min_rows() {
   if (g_pw_small_min_rows < 0)
@@ -678,6 +679,9 @@ extern "C" int dl3p_set_option(const char* name, int value) {
     g_pw_small_min_rows = value < 0 ? (1 << 17) : value;      // value < 0 restores the production threshold
     return DL3P_OK;
   }
+  if (!strcmp(name, "gemm_nt")) { g_gemm_force_nt = (value >= 1 && value <= 8) ? value : 0; return DL3P_OK; }
+  if (!strcmp(name, "gemm_mi")) { g_gemm_force_mi = (value == 1 || value == 2) ? value : 0; return DL3P_OK; }
+  if (!strcmp(name, "gemm_tuned")) { g_gemm_use_table = value ? 1 : 0; return DL3P_OK; }
   dl3p_set_error("dl3p_set_option: unknown option '%s'", name);
   return DL3P_EINVAL;
 }
@@ -695,6 +699,23 @@ static void launch_pw_small_any(const GemmParams& p, SmallShape sh, int grid, hi
   DL3P_PS(1, 2) DL3P_PS(2, 1) DL3P_PS(6, 1) DL3P_PS(1, 6) DL3P_PS(2, 3) DL3P_PS(3, 2) DL3P_PS(6, 2) DL3P_PS(2, 6)
   DL3P_PS(2, 9) DL3P_PS(9, 2)
 #undef DL3P_PS
+}
+
+// Measured tile choices for the GEMM shapes of the BASELINE graphs (scripts/tune_gemm.py writes gemm_tuned.h from timings
+// on an MI355X; the heuristics below serve every other shape).  role: 0 forward, 1 forward + BatchNorm statistics,
+// 2 data gradient, 3 data gradient + fused BatchNorm-backward sums; M rows, K reduction length, N output columns of the
+// GEMM as launched.  dl3p_set_option("gemm_nt" / "gemm_mi", v) pins a choice (v = 0: automatic) -- that is how the
+// tuner tries the candidates; ("gemm_tuned", 0) ignores the table.
+struct GemmTuned { int role, M, K, N, nt, mi; };
+#include "gemm_tuned.h"
+static const GemmTuned* gemm_tuned_lookup(int role, int M, int K, int N) {
+  if (g_gemm_use_table < 0) g_gemm_use_table = getenv("DL3P_GEMM_TUNED") ? atoi(getenv("DL3P_GEMM_TUNED")) : 1;
+  if (!g_gemm_use_table) return nullptr;
+  for (size_t i = 0; i < sizeof(g_gemm_tuned) / sizeof(g_gemm_tuned[0]); ++i) {
+    const GemmTuned& e = g_gemm_tuned[i];
+    if (e.role == role && e.M == M && e.K == K && e.N == N) return &e;
+  }
+  return nullptr;
 }
 
 // choose the columns-per-workgroup (NT tiles of 16) that wastes the fewest MFMA columns
@@ -727,7 +748,7 @@ static int pick_nt(int N, int M) {
 // grid: persistent workgroups over M tiles.  Small maps (M = N*33*33) give only ~137 tiles of 128 rows,
 // which quantises badly over 256 CUs; 64-row tiles (MI = 1) are used whenever 128-row tiles would leave
 // the chip under two rounds of work.
-static void gemm_grid(int M, int N, int nt, int* gx, int* gy, int* num_m_tiles, int* mi_out, bool bn_sums = false) {
+static void gemm_grid(int M, int N, int nt, int* gx, int* gy, int* num_m_tiles, int* mi_out, bool bn_sums = false, int force_mi = 0) {
   const int nb = ceil_div(N, 16 * nt);
   int mi = 2;
   if ((long long)ceil_div(M, 128) * nb < 4LL * DL3P_NUM_CUS) mi = 1;
@@ -746,6 +767,7 @@ static void gemm_grid(int M, int N, int nt, int* gx, int* gy, int* num_m_tiles, 
   if (mi == 1 && per_cu < 3) per_cu = 3;
   static const int e_mi = getenv("DL3P_GEMM_MI") ? atoi(getenv("DL3P_GEMM_MI")) : 0;
   static const int e_pc = getenv("DL3P_GEMM_PER_CU") ? atoi(getenv("DL3P_GEMM_PER_CU")) : 0;
+  if (force_mi) { mi = force_mi; if (mi == 1 && per_cu < 3) per_cu = 3; }
   if (e_mi) mi = e_mi;
   if (e_pc) per_cu = e_pc;
   const int bm = 64 * mi;
@@ -759,6 +781,16 @@ static void gemm_grid(int M, int N, int nt, int* gx, int* gy, int* num_m_tiles, 
     g = ceil_div(mt, per);
   }
   *gx = g; *gy = nb; *num_m_tiles = mt; *mi_out = mi;
+}
+
+// tile choice of one GEMM launch: the tuned table, a pinned option, or the heuristics
+static void gemm_plan(int role, int M, int K, int N, int* nt, int* gx, int* gy, int* num_m_tiles, int* mi) {
+  int force_mi = 0;
+  *nt = pick_nt(N, M);
+  if (const GemmTuned* e = gemm_tuned_lookup(role, M, K, N)) { *nt = e->nt; force_mi = e->mi; }
+  if (g_gemm_force_nt) *nt = g_gemm_force_nt;
+  if (g_gemm_force_mi) force_mi = g_gemm_force_mi;
+  gemm_grid(M, N, *nt, gx, gy, num_m_tiles, mi, role == 3, force_mi);
 }
 
 template <int NT, bool B_KN, bool STATS, int MI, int BKT, bool BNB = false, bool GA = false>
@@ -845,9 +877,13 @@ static int pwconv_fwd_impl(const char* fn, const float* x, int ldx, const float*
     DL3P_CHECK_LAUNCH(fn);
     return DL3P_OK;
   }
-  const int nt = pick_nt(N, M);
-  int gx, gy, mi;
-  gemm_grid(M, N, nt, &gx, &gy, &p.num_m_tiles, &mi);
+  int nt, gx, gy, mi;
+  if (w_kn) {
+    nt = pick_nt(N, M);
+    gemm_grid(M, N, nt, &gx, &gy, &p.num_m_tiles, &mi);
+  } else {
+    gemm_plan(stat_partials ? 1 : 0, M, K, N, &nt, &gx, &gy, &p.num_m_tiles, &mi);
+  }
   if (rows_out) *rows_out = gx;
   if (w_kn) {
     if (stat_partials) launch_gemm<true, true>(p, nt, mi, dim3(gx, gy), st);
@@ -934,9 +970,8 @@ extern "C" int dl3p_pwconv_bwd_data(const float* dy, int lddy, const float* w, f
     DL3P_CHECK_LAUNCH("dl3p_pwconv_bwd_data");
     return DL3P_OK;
   }
-  const int nt = pick_nt(K, M);
-  int gxn, gy, mi;
-  gemm_grid(M, K, nt, &gxn, &gy, &p.num_m_tiles, &mi);
+  int nt, gxn, gy, mi;
+  gemm_plan(2, M, N, K, &nt, &gxn, &gy, &p.num_m_tiles, &mi);
   launch_gemm<false, false>(p, nt, mi, dim3(gxn, gy), (hipStream_t)stream);
   DL3P_CHECK_LAUNCH("dl3p_pwconv_bwd_data");
   return DL3P_OK;
@@ -966,9 +1001,8 @@ extern "C" int dl3p_pwconv_bwd_data_bn(const float* dy, int lddy, const float* w
   p.partials = partials;
   p.bb_z = z; p.bb_ldz = ldz; p.bb_scale = scale; p.bb_shift = shift; p.bb_mean = save_mean; p.bb_invstd = save_invstd;
   p.bb_act = act;
-  const int nt = pick_nt(K, M);
-  int gxn, gy, mi;
-  gemm_grid(M, K, nt, &gxn, &gy, &p.num_m_tiles, &mi, true);
+  int nt, gxn, gy, mi;
+  gemm_plan(3, M, N, K, &nt, &gxn, &gy, &p.num_m_tiles, &mi);
   *rows_out = gxn;
   launch_gemm<false, true, true>(p, nt, mi, dim3(gxn, gy), (hipStream_t)stream);
   DL3P_CHECK_LAUNCH("dl3p_pwconv_bwd_data_bn");
