@@ -37,6 +37,7 @@ def shapes():
             out[(0, M, op.cin, op.cout)] = mt           # inference / frozen BatchNorm
             out[(2, M, op.cout, op.cin)] = mt           # data gradient: reduce over cout, produce cin columns
             out[(3, M, op.cout, op.cin)] = mt
+            out[(4, M, op.cin, op.cout)] = mt           # weight gradient: gw[K = cin][N = cout] over M rows
     return out
 
 
@@ -58,6 +59,29 @@ def bench_shape(role, M, K, N):
     """-> {(nt, mi): us} over the candidates, and the heuristic's own time under key None"""
     dev = 'cuda'
     NB = 3
+    if role == 4:
+        xs = [torch.randn(M, K, device=dev) for _ in range(NB)]
+        gs = [torch.randn(M, N, device=dev) for _ in range(NB)]
+        sc, sh = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev)
+        i = [0]
+
+        def run():
+            i[0] = (i[0] + 1) % NB
+            ops.pwconv_bwd_weight(xs[i[0]], gs[i[0]], sc, sh, ops.ACT_RELU6)
+        res = {}
+        L.set_option(b'gemm_tuned', 0)
+        L.set_option(b'wgrad_tile', -1)
+        L.set_option(b'wgrad_per_cu', 0)
+        res[None] = timeit(run)
+        for tile in range(4):
+            for per_cu in (2, 3, 4, 6, 8):
+                L.set_option(b'wgrad_tile', tile)
+                L.set_option(b'wgrad_per_cu', per_cu)
+                res[(tile, per_cu)] = timeit(run)
+        L.set_option(b'wgrad_tile', -1)
+        L.set_option(b'wgrad_per_cu', 0)
+        L.set_option(b'gemm_tuned', 1)
+        return res
     if role in (0, 1):
         xs = [torch.randn(M, K, device=dev) for _ in range(NB)]
         wt = torch.randn(N, K, device=dev) / K ** 0.5
@@ -127,7 +151,7 @@ def main():
         cands = {k: v for k, v in res.items() if k is not None}
         best = min(cands, key=cands.get)
         spread = max(cands.values()) / min(cands.values())
-        line = 'role %d M=%7d K=%4d N=%4d (%s): heuristic %7.1f us, best nt=%d mi=%d %7.1f us (%.0f%%), spread %.2f' % (
+        line = 'role %d M=%7d K=%4d N=%4d (%s): heuristic %7.1f us, best nt|tile=%d mi|per_cu=%d %7.1f us (%.0f%%), spread %.2f' % (
             role, M, K, N, mt, base, best[0], best[1], cands[best], 100 * cands[best] / base, spread)
         log.append(line)
         print(line, flush=True)

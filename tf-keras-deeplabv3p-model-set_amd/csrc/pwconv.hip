@@ -667,6 +667,7 @@ static bool pw_small_pick(int K, int N, SmallShape* out) {
 // tests lower it through dl3p_set_option so that small test shapes reach those kernels too, and reset it for the
 // tests that check the production dispatch at the production shapes.
 static int g_gemm_force_nt = 0, g_gemm_force_mi = 0, g_gemm_use_table = -1;   // see gemm_tuned_lookup / gemm_plan
+static int g_wgrad_force_tile = -1, g_wgrad_force_per_cu = 0;                    // see wgrad_pick_tile / wgrad_split
 static int g_pw_small_min_rows = -1;
 static int pw_small_min_rows() {
   if (g_pw_small_min_rows < 0)
@@ -682,6 +683,8 @@ extern "C" int dl3p_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm_nt")) { g_gemm_force_nt = (value >= 1 && value <= 8) ? value : 0; return DL3P_OK; }
   if (!strcmp(name, "gemm_mi")) { g_gemm_force_mi = (value == 1 || value == 2) ? value : 0; return DL3P_OK; }
   if (!strcmp(name, "gemm_tuned")) { g_gemm_use_table = value ? 1 : 0; return DL3P_OK; }
+  if (!strcmp(name, "wgrad_tile")) { g_wgrad_force_tile = (value >= 0 && value <= 3) ? value : -1; return DL3P_OK; }
+  if (!strcmp(name, "wgrad_per_cu")) { g_wgrad_force_per_cu = value > 0 ? value : 0; return DL3P_OK; }
   dl3p_set_error("dl3p_set_option: unknown option '%s'", name);
   return DL3P_EINVAL;
 }
@@ -1378,7 +1381,11 @@ static void launch_wgrad_small_any(const WgradParams& p, SmallShape sh, int grid
 // tile shape (KW, NW) -> (64 KW) x (16 NW): fewest padded MFMA columns, weighted by the operand re-reads
 static void wgrad_pick_tile(int M, int K, int N, int* kw, int* nw) {
   static const int cand[4][2] = {{1, 4}, {2, 4}, {1, 8}, {2, 8}};
-  static const int force = getenv("DL3P_WGRAD_TILE") ? atoi(getenv("DL3P_WGRAD_TILE")) : -1;
+  static const int env_force = getenv("DL3P_WGRAD_TILE") ? atoi(getenv("DL3P_WGRAD_TILE")) : -1;
+  int force = env_force;
+  // role 4 of the measured table: nt = tile index (0: 64x64, 1: 128x64, 2: 64x128, 3: 128x128), mi = workgroups per CU
+  if (const GemmTuned* e = gemm_tuned_lookup(4, M, K, N)) force = e->nt;
+  if (g_wgrad_force_tile >= 0) force = g_wgrad_force_tile;
   // measured: larger tiles pay only when M is large (decoder layers: 64 x 128 is 8-10 % faster than 64 x 64);
   // on the 17424-row layers they cut the number of workgroups too far
   if (force < 0 && M < 65536) { *kw = 1; *nw = 4; return; }
@@ -1398,7 +1405,10 @@ static void wgrad_split(int M, int K, int N, int* ktiles, int* ntiles, int* spli
   *ktiles = ceil_div(K, 64 * kw);
   *ntiles = ceil_div(N, 16 * nw);
   const int tiles = *ktiles * *ntiles;
-  static const int per_cu = getenv("DL3P_WGRAD_PER_CU") ? atoi(getenv("DL3P_WGRAD_PER_CU")) : 4;
+  static const int env_per_cu = getenv("DL3P_WGRAD_PER_CU") ? atoi(getenv("DL3P_WGRAD_PER_CU")) : 4;
+  int per_cu = env_per_cu;
+  if (const GemmTuned* e = gemm_tuned_lookup(4, M, K, N)) per_cu = e->mi;
+  if (g_wgrad_force_per_cu) per_cu = g_wgrad_force_per_cu;
   int s = (DL3P_NUM_CUS * per_cu) / tiles;
   if (s < 1) s = 1;
   int max_s = ceil_div(M, 256);          // at least 256 rows per slice
