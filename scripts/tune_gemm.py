@@ -77,7 +77,7 @@ def bench_shape(role, M, K, N):
             for per_cu in (2, 3, 4, 6, 8):
                 L.set_option(b'wgrad_tile', tile)
                 L.set_option(b'wgrad_per_cu', per_cu)
-                res[(tile, per_cu)] = timeit(run)
+                res[(tile, per_cu, 0)] = timeit(run)
         L.set_option(b'wgrad_tile', -1)
         L.set_option(b'wgrad_per_cu', 0)
         L.set_option(b'gemm_tuned', 1)
@@ -124,7 +124,15 @@ def bench_shape(role, M, K, N):
                 continue
             L.set_option(b'gemm_nt', nt)
             L.set_option(b'gemm_mi', mi)
-            res[(nt, mi)] = timeit(run)
+            res[(nt, mi, 0)] = timeit(run)
+    # persistent workgroups per CU (tile -> workgroup granularity) around the best tile
+    nt, mi, _ = min(res.items(), key=lambda kv: kv[1] if kv[0] is not None else 1e30)[0]
+    L.set_option(b'gemm_nt', nt)
+    L.set_option(b'gemm_mi', mi)
+    for pc in (2, 3, 4, 5, 6, 8):
+        L.set_option(b'gemm_per_cu', pc)
+        res[(nt, mi, pc)] = timeit(run)
+    L.set_option(b'gemm_per_cu', 0)
     L.set_option(b'gemm_nt', 0)
     L.set_option(b'gemm_mi', 0)
     L.set_option(b'gemm_tuned', 1)
@@ -151,17 +159,18 @@ def main():
         cands = {k: v for k, v in res.items() if k is not None}
         best = min(cands, key=cands.get)
         spread = max(cands.values()) / min(cands.values())
-        line = 'role %d M=%7d K=%4d N=%4d (%s): heuristic %7.1f us, best nt|tile=%d mi|per_cu=%d %7.1f us (%.0f%%), spread %.2f' % (
-            role, M, K, N, mt, base, best[0], best[1], cands[best], 100 * cands[best] / base, spread)
+        line = 'role %d M=%7d K=%4d N=%4d (%s): heuristic %7.1f us, best nt|tile=%d mi|per_cu=%d pc=%d %7.1f us (%.0f%%), spread %.2f' % (
+            role, M, K, N, mt, base, best[0], best[1], best[2], cands[best], 100 * cands[best] / base, spread)
         log.append(line)
         print(line, flush=True)
         if spread > 1.02 and cands[best] < 0.97 * base:
-            rows.append((role, M, K, N, best[0], best[1], base, cands[best]))
+            rows.append((role, M, K, N, best[0], best[1], best[2], base, cands[best]))
     out = ['// GENERATED by scripts/tune_gemm.py on an MI355X -- measured (nt, mi) per GEMM shape of the BASELINE graphs where the',
-           '// best candidate beats the heuristic by more than 3 %.  {role, M, K, N, nt, mi}   // heuristic us -> tuned us',
-           'static const GemmTuned g_gemm_tuned[] = {', '    {-1, 0, 0, 0, 0, 0},']
+           '// best candidate beats the heuristic by more than 3 %.  {role, M, K, N, nt, mi, pc}   // heuristic us -> tuned us\n'
+           '// (role 4 = weight gradient: nt = tile index, mi = workgroups per CU for the M split)',
+           'static const GemmTuned g_gemm_tuned[] = {', '    {-1, 0, 0, 0, 0, 0, 0},']
     for r in rows:
-        out.append('    {%d, %d, %d, %d, %d, %d},   // %.1f -> %.1f' % r)
+        out.append('    {%d, %d, %d, %d, %d, %d, %d},   // %.1f -> %.1f' % r)
     out.append('};')
     txt = '\n'.join(out) + '\n'
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)

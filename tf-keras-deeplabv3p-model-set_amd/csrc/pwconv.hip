@@ -666,7 +666,7 @@ static bool pw_small_pick(int K, int N, SmallShape* out) {
 // rows from which the streaming small-K.N kernels take over from the tiled kernel (production: 2^17).  The parity
 // tests lower it through dl3p_set_option so that small test shapes reach those kernels too, and reset it for the
 // tests that check the production dispatch at the production shapes.
-static int g_gemm_force_nt = 0, g_gemm_force_mi = 0, g_gemm_use_table = -1;   // see gemm_tuned_lookup / gemm_plan
+static int g_gemm_force_nt = 0, g_gemm_force_mi = 0, g_gemm_force_pc = 0, g_gemm_use_table = -1;   // see gemm_tuned_lookup / gemm_plan
 static int g_wgrad_force_tile = -1, g_wgrad_force_per_cu = 0;                    // see wgrad_pick_tile / wgrad_split
 static int g_pw_small_min_rows = -1;
 static int pw_small_min_rows() {
@@ -682,6 +682,7 @@ extern "C" int dl3p_set_option(const char* name, int value) {
   }
   if (!strcmp(name, "gemm_nt")) { g_gemm_force_nt = (value >= 1 && value <= 8) ? value : 0; return DL3P_OK; }
   if (!strcmp(name, "gemm_mi")) { g_gemm_force_mi = (value == 1 || value == 2) ? value : 0; return DL3P_OK; }
+  if (!strcmp(name, "gemm_per_cu")) { g_gemm_force_pc = value > 0 ? value : 0; return DL3P_OK; }
   if (!strcmp(name, "gemm_tuned")) { g_gemm_use_table = value ? 1 : 0; return DL3P_OK; }
   if (!strcmp(name, "wgrad_tile")) { g_wgrad_force_tile = (value >= 0 && value <= 3) ? value : -1; return DL3P_OK; }
   if (!strcmp(name, "wgrad_per_cu")) { g_wgrad_force_per_cu = value > 0 ? value : 0; return DL3P_OK; }
@@ -709,7 +710,7 @@ static void launch_pw_small_any(const GemmParams& p, SmallShape sh, int grid, hi
 // 2 data gradient, 3 data gradient + fused BatchNorm-backward sums; M rows, K reduction length, N output columns of the
 // GEMM as launched.  dl3p_set_option("gemm_nt" / "gemm_mi", v) pins a choice (v = 0: automatic) -- that is how the
 // tuner tries the candidates; ("gemm_tuned", 0) ignores the table.
-struct GemmTuned { int role, M, K, N, nt, mi; };
+struct GemmTuned { int role, M, K, N, nt, mi, pc; };   // pc: persistent workgroups per CU (0 = by tile width)
 #include "gemm_tuned.h"
 static const GemmTuned* gemm_tuned_lookup(int role, int M, int K, int N) {
   if (g_gemm_use_table < 0) g_gemm_use_table = getenv("DL3P_GEMM_TUNED") ? atoi(getenv("DL3P_GEMM_TUNED")) : 1;
@@ -751,7 +752,8 @@ static int pick_nt(int N, int M) {
 // grid: persistent workgroups over M tiles.  Small maps (M = N*33*33) give only ~137 tiles of 128 rows,
 // which quantises badly over 256 CUs; 64-row tiles (MI = 1) are used whenever 128-row tiles would leave
 // the chip under two rounds of work.
-static void gemm_grid(int M, int N, int nt, int* gx, int* gy, int* num_m_tiles, int* mi_out, bool bn_sums = false, int force_mi = 0) {
+static void gemm_grid(int M, int N, int nt, int* gx, int* gy, int* num_m_tiles, int* mi_out, bool bn_sums = false, int force_mi = 0,
+                      int force_pc = 0) {
   const int nb = ceil_div(N, 16 * nt);
   int mi = 2;
   if ((long long)ceil_div(M, 128) * nb < 4LL * DL3P_NUM_CUS) mi = 1;
@@ -771,6 +773,7 @@ static void gemm_grid(int M, int N, int nt, int* gx, int* gy, int* num_m_tiles, 
   static const int e_mi = getenv("DL3P_GEMM_MI") ? atoi(getenv("DL3P_GEMM_MI")) : 0;
   static const int e_pc = getenv("DL3P_GEMM_PER_CU") ? atoi(getenv("DL3P_GEMM_PER_CU")) : 0;
   if (force_mi) { mi = force_mi; if (mi == 1 && per_cu < 3) per_cu = 3; }
+  if (force_pc) per_cu = force_pc;
   if (e_mi) mi = e_mi;
   if (e_pc) per_cu = e_pc;
   const int bm = 64 * mi;
@@ -788,12 +791,13 @@ static void gemm_grid(int M, int N, int nt, int* gx, int* gy, int* num_m_tiles, 
 
 // tile choice of one GEMM launch: the tuned table, a pinned option, or the heuristics
 static void gemm_plan(int role, int M, int K, int N, int* nt, int* gx, int* gy, int* num_m_tiles, int* mi) {
-  int force_mi = 0;
+  int force_mi = 0, force_pc = 0;
   *nt = pick_nt(N, M);
-  if (const GemmTuned* e = gemm_tuned_lookup(role, M, K, N)) { *nt = e->nt; force_mi = e->mi; }
+  if (const GemmTuned* e = gemm_tuned_lookup(role, M, K, N)) { *nt = e->nt; force_mi = e->mi; force_pc = e->pc; }
   if (g_gemm_force_nt) *nt = g_gemm_force_nt;
   if (g_gemm_force_mi) force_mi = g_gemm_force_mi;
-  gemm_grid(M, N, *nt, gx, gy, num_m_tiles, mi, role == 3, force_mi);
+  if (g_gemm_force_pc) force_pc = g_gemm_force_pc;
+  gemm_grid(M, N, *nt, gx, gy, num_m_tiles, mi, role == 3, force_mi, force_pc);
 }
 
 template <int NT, bool B_KN, bool STATS, int MI, int BKT, bool BNB = false, bool GA = false>
