@@ -18,7 +18,7 @@ L = importlib.import_module(PKG + '._lib').lib()
 
 # (model, classes, (H, W), OS, batch): BASELINE.json configs[1..4] per-GPU shapes + the other backbones of the model map
 CONFIGS = [('mobilenetv2', 21, (513, 513), 16, 16), ('mobilenetv3large', 21, (513, 513), 16, 16),
-           ('xception', 21, (513, 513), 16, 4), ('xception', 19, (769, 769), 8, 2), ('mobilenetv3large', 19, (1024, 2048), 16, 1),
+           ('xception', 21, (513, 513), 16, 4), ('xception', 19, (769, 769), 8, 2), ('xception', 19, (769, 769), 16, 4), ('mobilenetv3large', 19, (1024, 2048), 16, 1),
            ('resnet50', 21, (513, 513), 16, 16), ('mobilenetv2_lite', 21, (513, 513), 16, 16)]
 
 
