@@ -159,3 +159,33 @@ def test_c_abi_exports_every_declared_symbol():
     with pytest.raises(libm.Dl3pError, match='multiple of 4'):
         L.dwconv2d_fwd(16, 6, None, None, 0, 16, 16, 6, None, ctypes.byref(ctypes.c_int()), 1, 4, 4, 6, 3, 1, 1, 1, 1,
                        4, 4, None)
+
+
+def test_dispatch_options_and_tile_table():
+    """dl3p_set_option: the knobs the tile tuner (scripts/tune_gemm.py) and the small-shape tests move; the measured tile
+    table is well-formed (host-side only, no GPU)"""
+    libm = load_pkg('_lib')
+    L = libm.lib()
+    for name, v in ((b'gemm_nt', 4), (b'gemm_mi', 1), (b'gemm_per_cu', 3), (b'wgrad_tile', 2), (b'wgrad_per_cu', 4),
+                    (b'gemm_tuned', 0), (b'pw_small_min_rows', 64)):
+        assert L.set_option(name, v) == 0
+    for name, v in ((b'gemm_nt', 0), (b'gemm_mi', 0), (b'gemm_per_cu', 0), (b'wgrad_tile', -1), (b'wgrad_per_cu', 0),
+                    (b'gemm_tuned', 1), (b'pw_small_min_rows', -1)):
+        assert L.set_option(name, v) == 0
+    with pytest.raises(libm.Dl3pError, match='unknown option'):
+        L.set_option(b'no_such_knob', 1)
+    import re
+    rows = re.findall(r'\{(-?\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\}',
+                      open(os.path.join(os.path.dirname(libm.LIBPATH), 'csrc', 'gemm_tuned.h')).read())
+    assert len(rows) > 100
+    seen = set()
+    for role, M, K, N, nt, mi, pc in (tuple(int(v) for v in r) for r in rows):
+        if role < 0:
+            continue
+        assert 0 <= role <= 4 and M > 64 and K > 0 and N > 0
+        assert (role, M, K, N) not in seen, 'duplicate key'
+        seen.add((role, M, K, N))
+        if role == 4:
+            assert 0 <= nt <= 3 and mi >= 1            # weight gradient: tile index, workgroups per CU
+        else:
+            assert 1 <= nt <= 8 and mi in (1, 2) and 0 <= pc <= 16

@@ -793,6 +793,21 @@ static void gemm_grid(int M, int N, int nt, int* gx, int* gy, int* num_m_tiles, 
 static void gemm_plan(int role, int M, int K, int N, int* nt, int* gx, int* gy, int* num_m_tiles, int* mi) {
   int force_mi = 0, force_pc = 0;
   *nt = pick_nt(N, M);
+  if (role == 3 && N <= 768 && K <= 320) {
+    // the data gradient with the fused BatchNorm sums: up to 64-column blocks of 64-row tiles are the widest that fit
+    // three resident workgroups per CU (147 VGPRs; wider ones need 180-256) -- what the tuner picks for 9 shapes in 10
+    // of this role with a short reduction (the project convs of the inverted residuals: K = 24..256), 20-34 % faster
+    // than the widest-block choice on the 17424-row layers.  Long reductions (Xception: K = 728..2048 on 4356 rows) pay
+    // more for re-staging A per column block than the third workgroup returns: they keep the wide blocks.
+    int best = 4, waste = 1 << 30;
+    for (int c = 4; c >= 2; --c) {
+      const int w = ceil_div(N, 16 * c) * 16 * c - N;
+      if (w < waste) { waste = w; best = c; }
+    }
+    if (ceil_div(N, 16) < best) best = ceil_div(N, 16);
+    *nt = best;
+    force_mi = 1;
+  }
   if (const GemmTuned* e = gemm_tuned_lookup(role, M, K, N)) { *nt = e->nt; force_mi = e->mi; force_pc = e->pc; }
   if (g_gemm_force_nt) *nt = g_gemm_force_nt;
   if (g_gemm_force_mi) force_mi = g_gemm_force_mi;
