@@ -145,8 +145,12 @@ def main():
     sh = shapes()
     rows = []
     log = []
+    roles = None
+    for a in sys.argv[1:]:
+        if a.startswith('--roles='):
+            roles = {int(v) for v in a.split('=')[1].split(',')}
     for (role, M, K, N), mt in sorted(sh.items()):
-        if M <= 64 or (M * max(K, N) * 4) >= (1 << 32):
+        if M <= 64 or (M * max(K, N) * 4) >= (1 << 32) or (roles is not None and role not in roles):
             continue
         # shapes the streaming / tiny kernels take never reach the tiled kernel: detect by timing with a pinned tile -- the
         # pin has no effect on them, so all candidates tie; cheap enough to just measure
