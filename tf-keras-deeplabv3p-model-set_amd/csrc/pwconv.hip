@@ -691,8 +691,10 @@ extern "C" int dl3p_set_option(const char* name, int value) {
 }
 
 static int pw_small_grid(int M) {
+  static const int per_cu = getenv("DL3P_PW_SMALL_PER_CU") ? atoi(getenv("DL3P_PW_SMALL_PER_CU")) : 2;
   int g = ceil_div(M, 16) / (4 * 2);          // >= 2 row tiles per wave
-  if (g > DL3P_NUM_CUS * 2) g = DL3P_NUM_CUS * 2;   // two resident workgroups per CU
+  if (g > DL3P_NUM_CUS * per_cu) g = DL3P_NUM_CUS * per_cu;   // two resident workgroups per CU
+  if (g > DL3P_MAX_STAT_ROWS) g = DL3P_MAX_STAT_ROWS;
   if (g < 1) g = 1;
   return g;
 }
@@ -1355,7 +1357,8 @@ static int wgrad_small_grid(int M, int KT, int NTN) {
   const int tiles = ceil_div(M, 16);
   // measured (kernel + slab reduce): two workgroups per CU stream as fast as four and halve the slabs;
   // below two row tiles per wave the per-wave prologue / reduction dominates
-  const int occ = 2, tpw = 2;
+  static const int occ_env = getenv("DL3P_WGRAD_SMALL_PER_CU") ? atoi(getenv("DL3P_WGRAD_SMALL_PER_CU")) : 2;
+  const int occ = occ_env, tpw = 2;
   (void)KT; (void)NTN;
   int g = tiles / (4 * tpw);
   if (g > DL3P_NUM_CUS * occ) g = DL3P_NUM_CUS * occ;
