@@ -59,7 +59,9 @@ int dl3p_device_cus(void);
  * wave-independent streaming GEMM kernels replace the tiled kernel for small K x N (production 131072; value < 0
  * restores it).  "gemm_nt" (1..8) / "gemm_mi" (1, 2): pin the column-block width (16 * nt) / tile rows (64 * mi) of the
  * tiled GEMM, 0 = automatic; "gemm_tuned" 0: ignore the measured tile table (csrc/gemm_tuned.h) -- what
- * scripts/tune_gemm.py uses to time the candidates.  Unknown names return DL3P_EINVAL. */
+ * scripts/tune_gemm.py uses to time the candidates; "gemm_per_cu", "wgrad_tile", "wgrad_per_cu" likewise.  "dw_per_cu" /
+ * "dw_want" / "dw_maxth" / "dw_tuned": the same for the plan of the depthwise window kernels (csrc/dw_tuned.h,
+ * scripts/tune_dw.py).  Unknown names return DL3P_EINVAL. */
 int dl3p_set_option(const char* name, int value);
 
 /* ---------------------------------------------------------------- data-parallel collectives (RCCL over xGMI)

@@ -167,10 +167,12 @@ def test_dispatch_options_and_tile_table():
     libm = load_pkg('_lib')
     L = libm.lib()
     for name, v in ((b'gemm_nt', 4), (b'gemm_mi', 1), (b'gemm_per_cu', 3), (b'wgrad_tile', 2), (b'wgrad_per_cu', 4),
-                    (b'gemm_tuned', 0), (b'pw_small_min_rows', 64)):
+                    (b'gemm_tuned', 0), (b'pw_small_min_rows', 64), (b'dw_per_cu', 4), (b'dw_want', 384), (b'dw_maxth', 8),
+                    (b'dw_tuned', 0)):
         assert L.set_option(name, v) == 0
     for name, v in ((b'gemm_nt', 0), (b'gemm_mi', 0), (b'gemm_per_cu', 0), (b'wgrad_tile', -1), (b'wgrad_per_cu', 0),
-                    (b'gemm_tuned', 1), (b'pw_small_min_rows', -1)):
+                    (b'gemm_tuned', 1), (b'pw_small_min_rows', -1), (b'dw_per_cu', 0), (b'dw_want', 0), (b'dw_maxth', 0),
+                    (b'dw_tuned', 1)):
         assert L.set_option(name, v) == 0
     with pytest.raises(libm.Dl3pError, match='unknown option'):
         L.set_option(b'no_such_knob', 1)

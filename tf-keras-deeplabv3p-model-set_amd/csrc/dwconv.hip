@@ -1042,8 +1042,36 @@ static int dw5_rows_tw(int uw) {
 }
 static int dw5_tw(int uw) { return dw5_rows_tw(uw) == 4 ? 4 : 2; }
 
+// Measured plan choices of the window kernels for the depthwise shapes of the BASELINE graphs (scripts/tune_dw.py writes
+// dw_tuned.h): role 0 forward, 1 data gradient, 2 data gradient + fused BatchNorm sums, 3 weight gradient; the key is the
+// geometry the planner sees (for the data gradient that is the flipped problem: H x W of dy).  per_cu: persistent
+// workgroups per CU; want: workgroup-iterations the row-band split aims for; maxth: tallest band.  0 = keep the default.
+struct DwTuned { int role, N, H, W, C, k, stride, rate, per_cu, want, maxth; };
+#include "dw_tuned.h"
+int dl3p_dw_force_per_cu = 0, dl3p_dw_force_want = 0, dl3p_dw_force_maxth = 0, dl3p_dw_use_table = -1;
+static const DwTuned* dw_tuned_lookup(const DwParams& p) {
+  if (dl3p_dw_use_table < 0) dl3p_dw_use_table = getenv("DL3P_DW_TUNED") ? atoi(getenv("DL3P_DW_TUNED")) : 1;
+  if (!dl3p_dw_use_table) return nullptr;
+  const int role = p.bb_z ? 2 : (p.flip ? 1 : (p.dy ? 3 : 0));
+  for (size_t i = 0; i < sizeof(g_dw_tuned) / sizeof(g_dw_tuned[0]); ++i) {
+    const DwTuned& e = g_dw_tuned[i];
+    if (e.role == role && e.N == p.N && e.H == p.H && e.W == p.W && e.C == p.C && e.k == (p.ks5 ? 5 : 3) && e.stride == p.stride &&
+        e.rate == p.rate)
+      return &e;
+  }
+  return nullptr;
+}
+
 static int fwd_plan(DwParams& p, int per_cu = 8, bool window5 = false, int tw5 = 0) {
   int kind = 0;
+  int t_want = 0, t_maxth = 0;
+  if (const DwTuned* e = dw_tuned_lookup(p)) {
+    if (e->per_cu) per_cu = e->per_cu;
+    t_want = e->want; t_maxth = e->maxth;
+  }
+  if (dl3p_dw_force_per_cu) per_cu = dl3p_dw_force_per_cu;
+  if (dl3p_dw_force_want) t_want = dl3p_dw_force_want;
+  if (dl3p_dw_force_maxth) t_maxth = dl3p_dw_force_maxth;
   // 5x5: window kernels with LDS weights in the forward / data-gradient role (strips of 2 at stride 1, 1 at stride 2);
   // the weight gradient keeps the per-pixel gather (25 tap accumulators + a 5-row window do not fit)
   if (p.ks5 && !window5) kind = 0;
@@ -1067,8 +1095,9 @@ static int fwd_plan(DwParams& p, int per_cu = 8, bool window5 = false, int tw5 =
     static const int balance = getenv("DL3P_DW_BALANCE") ? atoi(getenv("DL3P_DW_BALANCE")) : 2;
     if (balance == 2) {
       // the fewest bands (tallest, least halo re-reading) that still give every CU its workgroup-iterations
-      static const int want = getenv("DL3P_DW_WANT") ? atoi(getenv("DL3P_DW_WANT")) : DL3P_NUM_CUS * 3 / 2;
-      static const int maxth = getenv("DL3P_DW_MAXTH") ? atoi(getenv("DL3P_DW_MAXTH")) : 16;
+      static const int want_env = getenv("DL3P_DW_WANT") ? atoi(getenv("DL3P_DW_WANT")) : DL3P_NUM_CUS * 3 / 2;
+      static const int maxth_env = getenv("DL3P_DW_MAXTH") ? atoi(getenv("DL3P_DW_MAXTH")) : 16;
+      const int want = t_want ? t_want : want_env, maxth = t_maxth ? t_maxth : maxth_env;
       const long long per_band = (long long)p.N * r * r * p.spr;
       int nb = ceil_div(uh, maxth);
       while (nb < uh && (per_band * nb / p.px) * p.nslab < want) ++nb;
