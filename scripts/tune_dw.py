@@ -54,29 +54,34 @@ def timeit(fn, reps=10):
     return 1e3 * sum(ts[:3]) / 3 / reps
 
 
-def set_knobs(per_cu=0, want=0, maxth=0):
+def set_knobs(per_cu=0, want=0, maxth=0, tw=0):
     L.set_option(b'dw_per_cu', per_cu)
     L.set_option(b'dw_want', want)
     L.set_option(b'dw_maxth', maxth)
+    L.set_option(b'dw_tw', tw)
 
 
 def tune_role(run, per_cus):
     L.set_option(b'dw_tuned', 0)
     set_knobs()
     base = timeit(run)
-    best, best_t = (0, 0, 0), base
-    # coordinate search: band split first (the default grid), then the grid around the best split
-    for want in (128, 256, 384, 512, 768, 1024, 2048):
-        for maxth in (4, 8, 16, 33, 65):
-            set_knobs(0, want, maxth)
+    best, best_t = (0, 0, 0, 0), base
+    # coordinate search per strip width: band split first (the default grid), then the grid around the best split
+    for tw in (0, 2):
+        loc, loc_t = (0, 0, 0, tw), 1e30
+        for want in (128, 256, 384, 512, 768, 1024, 2048):
+            for maxth in (4, 8, 16, 33, 65):
+                set_knobs(0, want, maxth, tw)
+                t = timeit(run)
+                if t < loc_t:
+                    loc, loc_t = (0, want, maxth, tw), t
+        for pc in per_cus:
+            set_knobs(pc, loc[1], loc[2], tw)
             t = timeit(run)
-            if t < best_t:
-                best, best_t = (0, want, maxth), t
-    for pc in per_cus:
-        set_knobs(pc, best[1], best[2])
-        t = timeit(run)
-        if t < best_t:
-            best, best_t = (pc, best[1], best[2]), t
+            if t < loc_t:
+                loc, loc_t = (pc, loc[1], loc[2], tw), t
+        if loc_t < best_t:
+            best, best_t = loc, loc_t
     set_knobs()
     L.set_option(b'dw_tuned', 1)
     return base, best, best_t
@@ -111,17 +116,17 @@ def main():
                 continue
             # the planner's key: the data gradient plans the flipped problem on dy's geometry
             kh, kw = (Ho, Wo) if role in (1, 2) and s == 1 else (H, W)
-            line = 'role %d N=%d %dx%dx%d k=%d s=%d r=%d (%s): default %.1f us, best per_cu=%d want=%d maxth=%d %.1f us (%.0f%%)' % (
-                role, N, H, W, C, k, s, r, mt, base, best[0], best[1], best[2], bt, 100 * bt / base)
+            line = 'role %d N=%d %dx%dx%d k=%d s=%d r=%d (%s): default %.1f us, best per_cu=%d want=%d maxth=%d tw=%d %.1f us (%.0f%%)' % (
+                role, N, H, W, C, k, s, r, mt, base, best[0], best[1], best[2], best[3], bt, 100 * bt / base)
             print(line, flush=True)
             log.append(line)
-            if bt < 0.96 * base and best != (0, 0, 0):
-                rows.append((role, N, kh, kw, C, k, s if role not in (1, 2) or s != 1 else 1, r, best[0], best[1], best[2], base, bt))
+            if bt < 0.96 * base and best != (0, 0, 0, 0):
+                rows.append((role, N, kh, kw, C, k, s, r, best[0], best[1], best[2], best[3], base, bt))
     out = ['// GENERATED by scripts/tune_dw.py on an MI355X -- measured plan choices of the depthwise window kernels where the best',
-           '// candidate beats the default by more than 4 %.  {role, N, H, W, C, k, stride, rate, per_cu, want, maxth}   // default us -> tuned us',
-           'static const DwTuned g_dw_tuned[] = {', '    {-1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},']
+           '// candidate beats the default by more than 4 %.  {role, N, H, W, C, k, stride, rate, per_cu, want, maxth, tw}   // default us -> tuned us',
+           'static const DwTuned g_dw_tuned[] = {', '    {-1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},']
     for r_ in rows:
-        out.append('    {%d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d},   // %.1f -> %.1f' % r_)
+        out.append('    {%d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d},   // %.1f -> %.1f' % r_)
     out.append('};')
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     open(os.path.join(ROOT, 'gpurun_out', 'dw_tuned.h'), 'w').write('\n'.join(out) + '\n')

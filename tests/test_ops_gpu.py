@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import load_pkg
 from oracle import np_ops as O
 
 pytestmark = pytest.mark.gpu
@@ -76,6 +77,24 @@ def test_dwconv_fwd_bwd(ops, case):
     close(gx2, gx_ref + base, what='dw bwd data accumulate')
     gw = ops.dwconv2d_bwd_weight(T(x), T(gy), k, s, r, pad, T(sc), T(sh), ops.ACT_RELU6)
     close(gw, gw_ref, rtol=3e-4, what='dw bwd weight')
+
+
+@pytest.fixture
+def strips_of_two():
+    """the 3x3 stride-1 window kernels with 2-output strips (three waves per SIMD) instead of 4 -- what the tuned plan table
+    (csrc/dw_tuned.h) selects for some shapes"""
+    L = load_pkg('_lib').lib()
+    L.set_option(b'dw_tw', 2)
+    yield
+    L.set_option(b'dw_tw', 0)
+
+
+@pytest.mark.parametrize('case', [c for c in DW_CASES if c[4] == 3 and c[5] == 1] + [(3, 9, 7, 8, 3, 1, 1, 'same'),
+                                                                                  (1, 129, 129, 24, 3, 1, 1, 'same')])
+def test_dwconv_strips_of_two(ops, strips_of_two, case):
+    test_dwconv_fwd_bwd(ops, case)
+    N, H, W, C, k, s, r, pad = case
+    test_dwconv_bwd_data_fused_bn_stats(ops, (N, H, W, C, k, s, r, pad, O.ACT_RELU6))
 
 
 PW_CASES = [

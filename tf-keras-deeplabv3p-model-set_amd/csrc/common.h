@@ -166,7 +166,7 @@ void dl3p_pw_tiny_wgrad(const float* x, int ldx, const float* scale, const float
                         int lddy, float* gw, float* gb, int M, int K, int N, hipStream_t st);
 
 // depthwise plan knobs moved by dl3p_set_option (defined in dwconv.hip): 0 = automatic
-extern int dl3p_dw_force_per_cu, dl3p_dw_force_want, dl3p_dw_force_maxth, dl3p_dw_use_table;
+extern int dl3p_dw_force_per_cu, dl3p_dw_force_want, dl3p_dw_force_maxth, dl3p_dw_force_tw, dl3p_dw_use_table;
 
 int dl3p_reduce_rows_impl(const float* partials, int rows, size_t n, float* out, int accumulate, hipStream_t st);
 int dl3p_reduce_rows_strided_impl(const float* partials, int rows, size_t row_stride, size_t n, float* out,

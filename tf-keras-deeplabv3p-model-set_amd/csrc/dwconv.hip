@@ -28,6 +28,7 @@ struct DwParams {
   long long total;
   int flip, accumulate;
   int nt;              // streaming stores for the output (forward role only)
+  int tw;              // strip width the plan was made for (3x3 window kernels)
   // fused BatchNorm-backward statistics (data-gradient role, output = gradient of act(BN(z))): partial rows hold
   // (sum g', sum g' * xhat) as dl3p_bn_bwd_reduce would compute them from the finished gradient
   const float* bb_z; int bb_ldz;
@@ -1046,9 +1047,9 @@ static int dw5_tw(int uw) { return dw5_rows_tw(uw) == 4 ? 4 : 2; }
 // dw_tuned.h): role 0 forward, 1 data gradient, 2 data gradient + fused BatchNorm sums, 3 weight gradient; the key is the
 // geometry the planner sees (for the data gradient that is the flipped problem: H x W of dy).  per_cu: persistent
 // workgroups per CU; want: workgroup-iterations the row-band split aims for; maxth: tallest band.  0 = keep the default.
-struct DwTuned { int role, N, H, W, C, k, stride, rate, per_cu, want, maxth; };
+struct DwTuned { int role, N, H, W, C, k, stride, rate, per_cu, want, maxth, tw; };   // tw: strip width of the 3x3 stride-1 window kernels (0 / 4, or 2)
 #include "dw_tuned.h"
-int dl3p_dw_force_per_cu = 0, dl3p_dw_force_want = 0, dl3p_dw_force_maxth = 0, dl3p_dw_use_table = -1;
+int dl3p_dw_force_per_cu = 0, dl3p_dw_force_want = 0, dl3p_dw_force_maxth = 0, dl3p_dw_force_tw = 0, dl3p_dw_use_table = -1;
 static const DwTuned* dw_tuned_lookup(const DwParams& p) {
   if (dl3p_dw_use_table < 0) dl3p_dw_use_table = getenv("DL3P_DW_TUNED") ? atoi(getenv("DL3P_DW_TUNED")) : 1;
   if (!dl3p_dw_use_table) return nullptr;
@@ -1064,11 +1065,12 @@ static const DwTuned* dw_tuned_lookup(const DwParams& p) {
 
 static int fwd_plan(DwParams& p, int per_cu = 8, bool window5 = false, int tw5 = 0) {
   int kind = 0;
-  int t_want = 0, t_maxth = 0;
+  int t_want = 0, t_maxth = 0, t_tw = 0;
   if (const DwTuned* e = dw_tuned_lookup(p)) {
     if (e->per_cu) per_cu = e->per_cu;
-    t_want = e->want; t_maxth = e->maxth;
+    t_want = e->want; t_maxth = e->maxth; t_tw = e->tw;
   }
+  if (dl3p_dw_force_tw) t_tw = dl3p_dw_force_tw;
   if (dl3p_dw_force_per_cu) per_cu = dl3p_dw_force_per_cu;
   if (dl3p_dw_force_want) t_want = dl3p_dw_force_want;
   if (dl3p_dw_force_maxth) t_maxth = dl3p_dw_force_maxth;
@@ -1089,7 +1091,10 @@ static int fwd_plan(DwParams& p, int per_cu = 8, bool window5 = false, int tw5 =
   } else {
     const int r = p.rate;
     const int uw = ceil_div(p.Wo, r), uh = ceil_div(p.Ho, r);      // sub-lattice size
-    const int TW = p.ks5 ? (kind == 1 ? (tw5 ? tw5 : dw5_tw(uw)) : 1) : (kind == 1 ? 4 : 2);
+    // 3x3 stride 1: strips of 4 outputs (6-column window, 184-240 VGPRs: two waves per SIMD) or of 2 (160-192 VGPRs, three
+    // waves per SIMD for the forward and the weight gradient, a third more window loads per output) -- the tuner's call
+    const int TW = p.ks5 ? (kind == 1 ? (tw5 ? tw5 : dw5_tw(uw)) : 1) : (kind == 1 ? (t_tw == 2 ? 2 : 4) : 2);
+    p.tw = TW;
     p.spr = ceil_div(uw, TW);
     // bands of equal height (+-1 row) instead of full ones and a remainder: 33 rows as 11+11+11, not 16+16+1
     static const int balance = getenv("DL3P_DW_BALANCE") ? atoi(getenv("DL3P_DW_BALANCE")) : 2;
@@ -1131,7 +1136,8 @@ static void launch_fwd_pro(const DwParams& p, int kind, dim3 grid, hipStream_t s
     else dl3p_launch(dw_fwd_gather<5, PRO>, grid, block, 0, st, p);
     return;
   }
-  if (kind == 1) dl3p_launch(dw_fwd_seg<3, 4, 1, PRO>, grid, block, 0, st, p);
+  if (kind == 1 && p.tw == 2) dl3p_launch(dw_fwd_seg<3, 2, 1, PRO>, grid, block, 0, st, p);
+  else if (kind == 1) dl3p_launch(dw_fwd_seg<3, 4, 1, PRO>, grid, block, 0, st, p);
   else if (kind == 2) dl3p_launch(dw_fwd_seg<3, 2, 2, PRO>, grid, block, 0, st, p);
   else if (kind == 3) dl3p_launch(dw_fwd_lattice2<PRO>, grid, block, 0, st, p);
   else dl3p_launch(dw_fwd_gather<3, PRO>, grid, block, 0, st, p);
@@ -1268,7 +1274,8 @@ extern "C" int dl3p_dwconv2d_bwd_data_bn(const float* dy, int lddy, const float*
     p.act = DL3P_ACT_NONE;
     const int kind = plan_forward(p, k);
     if (kind == 1) {
-      dl3p_launch(dw_fwd_seg<3, 4, 1, 0, true>, dim3(p.nbx * p.nslab), dim3(256), 0, st, p);
+      if (p.tw == 2) dl3p_launch(dw_fwd_seg<3, 2, 1, 0, true>, dim3(p.nbx * p.nslab), dim3(256), 0, st, p);
+      else dl3p_launch(dw_fwd_seg<3, 4, 1, 0, true>, dim3(p.nbx * p.nslab), dim3(256), 0, st, p);
       fused = true;
     }
   } else if (stride == 2 && rate == 1 && k == 3) {
@@ -1299,7 +1306,8 @@ static void launch_bwdw(const DwParams& p, int kind, dim3 grid, hipStream_t st) 
     hipLaunchKernelGGL((dw_bwd_weight<5, PRO>), grid, block, 0, st, p);
     return;
   }
-  if (kind == 1) hipLaunchKernelGGL((dw_bwd_weight_seg<3, 4, 1, PRO>), grid, block, 0, st, p);
+  if (kind == 1 && p.tw == 2) hipLaunchKernelGGL((dw_bwd_weight_seg<3, 2, 1, PRO>), grid, block, 0, st, p);
+  else if (kind == 1) hipLaunchKernelGGL((dw_bwd_weight_seg<3, 4, 1, PRO>), grid, block, 0, st, p);
   else if (kind == 2) hipLaunchKernelGGL((dw_bwd_weight_seg<3, 2, 2, PRO>), grid, block, 0, st, p);
   else hipLaunchKernelGGL((dw_bwd_weight<3, PRO>), grid, block, 0, st, p);   // kind 0 (ks == 0 there: no kind 3)
 }

@@ -687,6 +687,7 @@ extern "C" int dl3p_set_option(const char* name, int value) {
   if (!strcmp(name, "dw_per_cu")) { dl3p_dw_force_per_cu = value > 0 ? value : 0; return DL3P_OK; }
   if (!strcmp(name, "dw_want")) { dl3p_dw_force_want = value > 0 ? value : 0; return DL3P_OK; }
   if (!strcmp(name, "dw_maxth")) { dl3p_dw_force_maxth = value > 0 ? value : 0; return DL3P_OK; }
+  if (!strcmp(name, "dw_tw")) { dl3p_dw_force_tw = (value == 2 || value == 4) ? value : 0; return DL3P_OK; }
   if (!strcmp(name, "dw_tuned")) { dl3p_dw_use_table = value ? 1 : 0; return DL3P_OK; }
   if (!strcmp(name, "wgrad_tile")) { g_wgrad_force_tile = (value >= 0 && value <= 3) ? value : -1; return DL3P_OK; }
   if (!strcmp(name, "wgrad_per_cu")) { g_wgrad_force_per_cu = value > 0 ? value : 0; return DL3P_OK; }
