@@ -379,6 +379,30 @@ int dl3p_head_train(const float* z, int ldz, const float* labels, int ignore_ind
                     int N, int h, int w, int C, int H, int W, void* stream);
 /* out[n] (+)= sum over rows of partials[rows][n]   (loss, wgrad slabs) */
 int dl3p_reduce_rows(const float* partials, int rows, size_t n, float* out, int accumulate, void* stream);
+/* The weight gradients of a whole step reduced in two launches instead of one per layer.  dl3p_*_bwd_weight_slabs are the
+ * weight-gradient entry points without their final reduction: they leave `*rows_out` slabs of n floats each at the start
+ * of `workspace` (n = the gradient's element count: K*N, k*k*C, 28*Cout, k*k*Cin*Cout; no bias gradient, M > 64).
+ * dl3p_reduce_rows_batched then sums every job = {const float* slabs; float* dst; int rows; int n;} (a device array of
+ * 24-byte records) into its destination with exactly the arithmetic dl3p_reduce_rows applies to it:
+ * dl3p_reduce_rows_variant(rows, n) says which of the two kernels that is (0 or 1), and blockmapV[b] = {job, block within
+ * the job} lists the blocks of the jobs of variant V (64 elements per block). */
+int dl3p_reduce_rows_variant(int rows, size_t n);
+int dl3p_reduce_rows_batched(const void* jobs, const int* blockmap0, int blocks0, const int* blockmap1, int blocks1,
+                             void* stream);
+int dl3p_pwconv_bwd_weight_slabs(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                                 const float* dy, int lddy, float* workspace, size_t workspace_bytes, int* rows_out,
+                                 int M, int K, int N, void* stream);
+int dl3p_dwconv2d_bwd_weight_slabs(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                                   const float* dy, int lddy, float* workspace, size_t workspace_bytes, int* rows_out,
+                                   int N, int H, int W, int C, int k, int stride, int rate, int pad_t, int pad_l,
+                                   int Ho, int Wo, void* stream);
+int dl3p_stem_conv_bwd_weight_slabs(const float* x, int ldx, const float* dy, int lddy, float* workspace,
+                                    size_t workspace_bytes, int* rows_out, int N, int H, int W, int Cout, int pad_t,
+                                    int pad_l, int Ho, int Wo, void* stream);
+int dl3p_conv2d_gemm_bwd_weight_slabs(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                                      const float* dy, int lddy, float* workspace, size_t workspace_bytes, int* rows_out,
+                                      int N, int H, int W, int Cin, int Cout, int k, int stride, int rate,
+                                      int pad_t, int pad_l, int Ho, int Wo, void* stream);
 
 /* ---------------------------------------------------------------- optimiser
  * Keras SGD(momentum, nesterov=False) (common/model_utils.py:124) with the l2(2e-5) regulariser

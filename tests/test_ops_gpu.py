@@ -97,6 +97,34 @@ def test_dwconv_strips_of_two(ops, strips_of_two, case):
     test_dwconv_bwd_data_fused_bn_stats(ops, (N, H, W, C, k, s, r, pad, O.ACT_RELU6))
 
 
+def test_reduce_rows_batched_is_bitwise_the_per_layer_reduction(ops):
+    """dl3p_reduce_rows_batched (every weight gradient of a step in two launches) against dl3p_reduce_rows job by job: both
+    kernel variants, ragged element counts, 1 .. 300 rows"""
+    L = ops.lib()
+    rng = np.random.default_rng(21)
+    shapes = [(1, 36), (7, 16 * 96), (16, 70000), (17, 864), (64, 28 * 32), (300, 640), (2, 65536), (33, 9 * 960 + 4)]
+    srcs, dsts, refs, rec = [], [], [], []
+    st = torch.cuda.current_stream().cuda_stream
+    for rows, n in shapes:
+        a = torch.from_numpy(rng.standard_normal((rows, n)).astype(np.float32) * 100).to(DEV)
+        ref = torch.empty(n, dtype=torch.float32, device=DEV)
+        L.reduce_rows(a.data_ptr(), rows, n, ref.data_ptr(), 0, st)
+        out = torch.full((n,), float('nan'), dtype=torch.float32, device=DEV)
+        srcs.append(a); dsts.append(out); refs.append(ref)
+        rec.append((a.data_ptr(), out.data_ptr(), rows, n))
+    jobs = np.array(rec, dtype=np.dtype([('src', '<u8'), ('dst', '<u8'), ('rows', '<i4'), ('n', '<i4')]))
+    maps = ([], [])
+    for j, (_, _, rows, n) in enumerate(rec):
+        v = L.reduce_rows_variant(rows, n)
+        maps[v].extend((j, b) for b in range((n + 63) // 64))
+    assert maps[0] and maps[1], 'both variants exercised'
+    jt = torch.from_numpy(jobs.view(np.uint8).copy()).to(DEV)
+    m0, m1 = (torch.tensor(m, dtype=torch.int32, device=DEV) for m in maps)
+    L.reduce_rows_batched(jt.data_ptr(), m0.data_ptr(), len(maps[0]), m1.data_ptr(), len(maps[1]), st)
+    for out, ref in zip(dsts, refs):
+        assert torch.equal(out, ref)
+
+
 PW_CASES = [
     # M, K, N
     (2 * 33 * 33, 320, 256), (1000, 24, 144), (777, 144, 24), (4096 + 5, 32, 16), (513, 16, 96),

@@ -97,6 +97,98 @@ extern "C" int dl3p_reduce_rows(const float* partials, int rows, size_t n, float
   return dl3p_reduce_rows_impl(partials, rows, n, out, accumulate, (hipStream_t)stream);
 }
 
+// Every weight gradient of a step in TWO launches instead of one per layer: the wgrad kernels leave their slabs
+// (dl3p_*_bwd_weight_slabs), and each job (slab address, rows, n, destination in the flat gradient buffer) is reduced with
+// exactly the arithmetic of reduce_rows_kernel<64, 4> / <16, 64> -- the same variant dl3p_reduce_rows would have picked
+// for it, so the sums are bit-identical to the per-layer path.  blockmap[b] = (job, block within the job).
+struct ReduceJob { const float* src; float* dst; int rows; int n; };
+template <int EL, int RL>
+__global__ __launch_bounds__(EL * RL) void reduce_rows_batched_kernel(const ReduceJob* __restrict__ jobs,
+                                                                      const int2* __restrict__ blockmap) {
+  __shared__ double sm[RL][EL];
+  const int2 bm = blockmap[blockIdx.x];
+  const ReduceJob jb = jobs[bm.x];
+  const float* __restrict__ partials = jb.src;
+  const size_t n = (size_t)jb.n;
+  const int rows = jb.rows;
+  const int ex = threadIdx.x % EL, ry = threadIdx.x / EL;
+  const size_t i = (size_t)bm.y * EL + ex;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (i < n) {
+    int r = ry;
+    for (; r + 3 * RL < rows; r += 4 * RL) {
+      a0 += (double)partials[(size_t)r * n + i];
+      a1 += (double)partials[(size_t)(r + RL) * n + i];
+      a2 += (double)partials[(size_t)(r + 2 * RL) * n + i];
+      a3 += (double)partials[(size_t)(r + 3 * RL) * n + i];
+    }
+    for (; r < rows; r += RL) a0 += (double)partials[(size_t)r * n + i];
+  }
+  sm[ry][ex] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (ry == 0 && i < n) {
+    double acc = 0.0;
+#pragma unroll 8
+    for (int q = 0; q < RL; ++q) acc += sm[q][ex];
+    jb.dst[i] = (float)acc;
+  }
+}
+
+// The arithmetic of reduce_rows_kernel<16, 64> (64 row lanes, each with four interleaved accumulators, lane totals added in
+// lane order) on a 64-element x 4-thread-group mapping: a thread walks 16 of the 64 lanes one after the other, so a wave
+// reads 256 contiguous bytes per row instead of 64 -- the batched launch streams ~10^8 bytes of slabs and is bound by
+// that, where the per-layer launches were bound by their own latency.  Bit-identical sums.
+__global__ __launch_bounds__(256) void reduce_rows_batched_lanes64_kernel(const ReduceJob* __restrict__ jobs,
+                                                                          const int2* __restrict__ blockmap) {
+  constexpr int EL = 64, RL = 64, G = 4;
+  __shared__ double sm[RL][EL];
+  const int2 bm = blockmap[blockIdx.x];
+  const ReduceJob jb = jobs[bm.x];
+  const float* __restrict__ partials = jb.src;
+  const size_t n = (size_t)jb.n;
+  const int rows = jb.rows;
+  const int ex = threadIdx.x % EL, g = threadIdx.x / EL;
+  const size_t i = (size_t)bm.y * EL + ex;
+  for (int q = g; q < RL; q += G) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (i < n) {
+      int r = q;
+      for (; r + 3 * RL < rows; r += 4 * RL) {
+        a0 += (double)partials[(size_t)r * n + i];
+        a1 += (double)partials[(size_t)(r + RL) * n + i];
+        a2 += (double)partials[(size_t)(r + 2 * RL) * n + i];
+        a3 += (double)partials[(size_t)(r + 3 * RL) * n + i];
+      }
+      for (; r < rows; r += RL) a0 += (double)partials[(size_t)r * n + i];
+    }
+    sm[q][ex] = (a0 + a1) + (a2 + a3);
+  }
+  __syncthreads();
+  if (g == 0 && i < n) {
+    double acc = 0.0;
+#pragma unroll 8
+    for (int q = 0; q < RL; ++q) acc += sm[q][ex];
+    jb.dst[i] = (float)acc;
+  }
+}
+
+extern "C" int dl3p_reduce_rows_variant(int rows, size_t n) { return (n >= 64 * 1024 || rows <= 16) ? 0 : 1; }
+
+extern "C" int dl3p_reduce_rows_batched(const void* jobs, const int* blockmap0, int blocks0, const int* blockmap1, int blocks1,
+                                        void* stream) {
+  DL3P_CHECK_ARG(jobs && blocks0 >= 0 && blocks1 >= 0 && (!blocks0 || blockmap0) && (!blocks1 || blockmap1),
+                 "dl3p_reduce_rows_batched: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (blocks0)
+    hipLaunchKernelGGL((reduce_rows_batched_kernel<64, 4>), dim3(blocks0), dim3(256), 0, st, (const ReduceJob*)jobs,
+                       (const int2*)blockmap0);
+  if (blocks1)
+    hipLaunchKernelGGL(reduce_rows_batched_lanes64_kernel, dim3(blocks1), dim3(256), 0, st, (const ReduceJob*)jobs,
+                       (const int2*)blockmap1);
+  DL3P_CHECK_LAUNCH("dl3p_reduce_rows_batched");
+  return DL3P_OK;
+}
+
 // sums[i] = sum_r partials[r][i] in double (SyncBN: these sums are all-reduced across ranks).
 // 16 elements x 64 row lanes per workgroup, two rows in flight per thread.
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partials, int rows, int n,

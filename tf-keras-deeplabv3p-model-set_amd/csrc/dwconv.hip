@@ -1318,14 +1318,15 @@ extern "C" size_t dl3p_dwconv2d_bwd_weight_workspace(int N, int Ho, int Wo, int 
   return (size_t)DL3P_MAX_STAT_ROWS * k * k * C * sizeof(float);   // one partial row per workgroup, at most
 }
 
-extern "C" int dl3p_dwconv2d_bwd_weight(const float* x, int ldx, const float* in_scale, const float* in_shift,
-                                        int in_act, const float* dy, int lddy, float* gw, float* workspace,
-                                        size_t workspace_bytes, int N, int H, int W, int C, int k, int stride,
-                                        int rate, int pad_t, int pad_l, int Ho, int Wo, void* stream) {
+// rows_out != NULL: leave the partial rows in the workspace for dl3p_reduce_rows_batched (gw unused) and report how many
+static int dwconv2d_bwd_weight_impl(const float* x, int ldx, const float* in_scale, const float* in_shift,
+                                    int in_act, const float* dy, int lddy, float* gw, float* workspace,
+                                    size_t workspace_bytes, int N, int H, int W, int C, int k, int stride,
+                                    int rate, int pad_t, int pad_l, int Ho, int Wo, int* rows_out, void* stream) {
   int rc = check_dw_common("dl3p_dwconv2d_bwd_weight", x, ldx, C, k);
   if (rc) return rc;
-  DL3P_CHECK_ARG(x && dy && gw && workspace, "dl3p_dwconv2d_bwd_weight: null pointer");
-  DL3P_CHECK_ARG(lddy % 4 == 0 && lddy >= C && aligned16(dy) && aligned16(workspace) && aligned16(gw),
+  DL3P_CHECK_ARG(x && dy && (gw || rows_out) && workspace, "dl3p_dwconv2d_bwd_weight: null pointer");
+  DL3P_CHECK_ARG(lddy % 4 == 0 && lddy >= C && aligned16(dy) && aligned16(workspace) && (rows_out || aligned16(gw)),
                  "dl3p_dwconv2d_bwd_weight: bad dy/workspace layout");
   const size_t need = dl3p_dwconv2d_bwd_weight_workspace(N, Ho, Wo, C, k);
   if (workspace_bytes < need) {
@@ -1364,5 +1365,23 @@ extern "C" int dl3p_dwconv2d_bwd_weight(const float* x, int ldx, const float* in
     if (pro == 2) launch_bwdw<5, 2>(p, kind, grid, st); else if (pro == 1) launch_bwdw<5, 1>(p, kind, grid, st); else launch_bwdw<5, 0>(p, kind, grid, st);
   }
   DL3P_CHECK_LAUNCH("dl3p_dwconv2d_bwd_weight");
+  if (rows_out) { *rows_out = p.nbx; return DL3P_OK; }
   return dl3p_reduce_rows_impl(workspace, p.nbx, (size_t)k * k * C, gw, 0, st);
+}
+
+extern "C" int dl3p_dwconv2d_bwd_weight(const float* x, int ldx, const float* in_scale, const float* in_shift,
+                                        int in_act, const float* dy, int lddy, float* gw, float* workspace,
+                                        size_t workspace_bytes, int N, int H, int W, int C, int k, int stride,
+                                        int rate, int pad_t, int pad_l, int Ho, int Wo, void* stream) {
+  return dwconv2d_bwd_weight_impl(x, ldx, in_scale, in_shift, in_act, dy, lddy, gw, workspace, workspace_bytes, N, H, W, C, k,
+                                  stride, rate, pad_t, pad_l, Ho, Wo, nullptr, stream);
+}
+
+extern "C" int dl3p_dwconv2d_bwd_weight_slabs(const float* x, int ldx, const float* in_scale, const float* in_shift,
+                                              int in_act, const float* dy, int lddy, float* workspace,
+                                              size_t workspace_bytes, int* rows_out, int N, int H, int W, int C, int k,
+                                              int stride, int rate, int pad_t, int pad_l, int Ho, int Wo, void* stream) {
+  DL3P_CHECK_ARG(rows_out != nullptr, "dl3p_dwconv2d_bwd_weight_slabs: rows_out is required");
+  return dwconv2d_bwd_weight_impl(x, ldx, in_scale, in_shift, in_act, dy, lddy, nullptr, workspace, workspace_bytes, N, H, W, C,
+                                  k, stride, rate, pad_t, pad_l, Ho, Wo, rows_out, stream);
 }

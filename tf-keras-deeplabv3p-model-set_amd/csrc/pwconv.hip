@@ -1485,14 +1485,17 @@ extern "C" size_t dl3p_pwconv_bwd_weight_workspace(int M, int K, int N) {
   return (a > b ? a : b) * sizeof(float);
 }
 
-extern "C" int dl3p_pwconv_bwd_weight(const float* x, int ldx, const float* in_scale, const float* in_shift,
-                                      int in_act, const float* dy, int lddy, float* gw, float* gb, float* workspace,
-                                      size_t workspace_bytes, int M, int K, int N, void* stream) {
+// rows_out != NULL: leave the slabs in the workspace for dl3p_reduce_rows_batched (gw / gb unused) and report how many
+static int pwconv_bwd_weight_impl(const float* x, int ldx, const float* in_scale, const float* in_shift,
+                                  int in_act, const float* dy, int lddy, float* gw, float* gb, float* workspace,
+                                  size_t workspace_bytes, int M, int K, int N, int* rows_out, void* stream) {
   int rc = check_mat("dl3p_pwconv_bwd_weight", x, ldx, K);
   if (rc) return rc;
   rc = check_mat("dl3p_pwconv_bwd_weight", dy, lddy, N);
   if (rc) return rc;
-  DL3P_CHECK_ARG(gw && workspace && aligned16(workspace) && M > 0, "dl3p_pwconv_bwd_weight: bad arguments");
+  DL3P_CHECK_ARG((gw || rows_out) && workspace && aligned16(workspace) && M > 0, "dl3p_pwconv_bwd_weight: bad arguments");
+  DL3P_CHECK_ARG(!rows_out || (!gb && !dl3p_pw_tiny_applies(M)),
+                 "dl3p_pwconv_bwd_weight_slabs: no bias gradient and more than %d rows (use dl3p_pwconv_bwd_weight)", 64);
   const size_t need = dl3p_pwconv_bwd_weight_workspace(M, K, N);
   if (workspace_bytes < need) {
     dl3p_set_error("dl3p_pwconv_bwd_weight: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -1518,6 +1521,7 @@ extern "C" int dl3p_pwconv_bwd_weight(const float* x, int ldx, const float* in_s
     launch_wgrad_tiled<false>(p, splits, st);
   }
   DL3P_CHECK_LAUNCH("dl3p_pwconv_bwd_weight");
+  if (rows_out) { *rows_out = splits; return DL3P_OK; }
   rc = dl3p_reduce_rows_impl(workspace, splits, (size_t)K * N, gw, 0, st);
   if (rc) return rc;
   if (gb) {
@@ -1531,6 +1535,21 @@ extern "C" int dl3p_pwconv_bwd_weight(const float* x, int ldx, const float* in_s
     rc = dl3p_reduce_rows_impl(workspace, nbx, (size_t)N, gb, 0, st);
   }
   return rc;
+}
+
+extern "C" int dl3p_pwconv_bwd_weight(const float* x, int ldx, const float* in_scale, const float* in_shift,
+                                      int in_act, const float* dy, int lddy, float* gw, float* gb, float* workspace,
+                                      size_t workspace_bytes, int M, int K, int N, void* stream) {
+  return pwconv_bwd_weight_impl(x, ldx, in_scale, in_shift, in_act, dy, lddy, gw, gb, workspace, workspace_bytes, M, K, N,
+                                nullptr, stream);
+}
+
+extern "C" int dl3p_pwconv_bwd_weight_slabs(const float* x, int ldx, const float* in_scale, const float* in_shift,
+                                            int in_act, const float* dy, int lddy, float* workspace, size_t workspace_bytes,
+                                            int* rows_out, int M, int K, int N, void* stream) {
+  DL3P_CHECK_ARG(rows_out != nullptr, "dl3p_pwconv_bwd_weight_slabs: rows_out is required");
+  return pwconv_bwd_weight_impl(x, ldx, in_scale, in_shift, in_act, dy, lddy, nullptr, nullptr, workspace, workspace_bytes, M, K,
+                                N, rows_out, stream);
 }
 
 
@@ -1656,10 +1675,10 @@ extern "C" size_t dl3p_conv2d_gemm_bwd_weight_workspace(int N, int Ho, int Wo, i
   return (a > b ? a : b) * sizeof(float);
 }
 
-extern "C" int dl3p_conv2d_gemm_bwd_weight(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
-                                           const float* dy, int lddy, float* gw, float* gb, float* workspace,
-                                           size_t workspace_bytes, int N, int H, int W, int Cin, int Cout, int k, int stride,
-                                           int rate, int pad_t, int pad_l, int Ho, int Wo, void* stream) {
+static int conv2d_gemm_bwd_weight_impl(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                                      const float* dy, int lddy, float* gw, float* gb, float* workspace,
+                                      size_t workspace_bytes, int N, int H, int W, int Cin, int Cout, int k, int stride,
+                                      int rate, int pad_t, int pad_l, int Ho, int Wo, int* rows_out, void* stream) {
   const char* fn = "dl3p_conv2d_gemm_bwd_weight";
   int rc = conv_gemm_check(fn, N, H, W, Cin, Cout, k, stride, rate, pad_t, pad_l, Ho, Wo);
   if (rc) return rc;
@@ -1667,7 +1686,7 @@ extern "C" int dl3p_conv2d_gemm_bwd_weight(const float* x, int ldx, const float*
   if (rc) return rc;
   rc = check_mat(fn, dy, lddy, Cout);
   if (rc) return rc;
-  DL3P_CHECK_ARG(gw && workspace && aligned16(workspace) && aligned16(gw), "%s: bad arguments", fn);
+  DL3P_CHECK_ARG((rows_out || (gw && aligned16(gw))) && workspace && aligned16(workspace) && !(rows_out && gb), "%s: bad arguments", fn);
   const int M = N * Ho * Wo, K = k * k * Cin;
   DL3P_CHECK_ARG((unsigned long long)N * H * W * (unsigned long long)ldx * 4ull < (1ull << 32) &&
                      (unsigned long long)M * (unsigned long long)lddy * 4ull < (1ull << 32),
@@ -1688,6 +1707,7 @@ extern "C" int dl3p_conv2d_gemm_bwd_weight(const float* x, int ldx, const float*
   hipStream_t st = (hipStream_t)stream;
   launch_wgrad_tiled<true>(p, splits, st);
   DL3P_CHECK_LAUNCH(fn);
+  if (rows_out) { *rows_out = splits; return DL3P_OK; }
   rc = dl3p_reduce_rows_impl(workspace, splits, (size_t)K * Cout, gw, 0, st);
   if (rc || !gb) return rc;
   DL3P_CHECK_ARG(aligned16(gb), "%s: gb must be 16-byte aligned", fn);
@@ -1698,4 +1718,22 @@ extern "C" int dl3p_conv2d_gemm_bwd_weight(const float* x, int ldx, const float*
   hipLaunchKernelGGL(colsum_kernel, dim3(nbx * nslab), dim3(256), 0, st, dy, lddy, (long long)M, Cout, c4s, px, nbx, workspace);
   DL3P_CHECK_LAUNCH("dl3p_conv2d_gemm_bwd_weight(colsum)");
   return dl3p_reduce_rows_impl(workspace, nbx, (size_t)Cout, gb, 0, st);
+}
+
+extern "C" int dl3p_conv2d_gemm_bwd_weight(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                                           const float* dy, int lddy, float* gw, float* gb, float* workspace,
+                                           size_t workspace_bytes, int N, int H, int W, int Cin, int Cout, int k, int stride,
+                                           int rate, int pad_t, int pad_l, int Ho, int Wo, void* stream) {
+  return conv2d_gemm_bwd_weight_impl(x, ldx, in_scale, in_shift, in_act, dy, lddy, gw, gb, workspace, workspace_bytes, N, H, W,
+                                     Cin, Cout, k, stride, rate, pad_t, pad_l, Ho, Wo, nullptr, stream);
+}
+
+extern "C" int dl3p_conv2d_gemm_bwd_weight_slabs(const float* x, int ldx, const float* in_scale, const float* in_shift,
+                                                 int in_act, const float* dy, int lddy, float* workspace,
+                                                 size_t workspace_bytes, int* rows_out, int N, int H, int W, int Cin, int Cout,
+                                                 int k, int stride, int rate, int pad_t, int pad_l, int Ho, int Wo,
+                                                 void* stream) {
+  DL3P_CHECK_ARG(rows_out != nullptr, "dl3p_conv2d_gemm_bwd_weight_slabs: rows_out is required");
+  return conv2d_gemm_bwd_weight_impl(x, ldx, in_scale, in_shift, in_act, dy, lddy, nullptr, nullptr, workspace, workspace_bytes,
+                                     N, H, W, Cin, Cout, k, stride, rate, pad_t, pad_l, Ho, Wo, rows_out, stream);
 }

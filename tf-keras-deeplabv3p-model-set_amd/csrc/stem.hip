@@ -296,14 +296,14 @@ extern "C" size_t dl3p_stem_conv_bwd_weight_workspace(int N, int Ho, int Wo, int
   return (size_t)stem_wgrad_grid(N, Ho, Wo) * 28 * Cout * sizeof(float);
 }
 
-extern "C" int dl3p_stem_conv_bwd_weight(const float* x, int ldx, const float* dy, int lddy, float* gw, float* workspace,
-                                         size_t workspace_bytes, int N, int H, int W, int Cout, int pad_t, int pad_l,
-                                         int Ho, int Wo, void* stream) {
+static int stem_conv_bwd_weight_impl(const float* x, int ldx, const float* dy, int lddy, float* gw, float* workspace,
+                                     size_t workspace_bytes, int N, int H, int W, int Cout, int pad_t, int pad_l,
+                                     int Ho, int Wo, int* rows_out, void* stream) {
   StemParams p = {};
   int rc = stem_fill("dl3p_stem_conv_bwd_weight", &p, N, H, W, Cout, pad_t, pad_l, Ho, Wo);
   if (rc) return rc;
-  DL3P_CHECK_ARG(x && dy && gw && workspace && ldx >= 3 && lddy >= Cout && lddy % 4 == 0 && aligned16(dy) &&
-                     aligned16(workspace) && aligned16(gw),
+  DL3P_CHECK_ARG(x && dy && (rows_out || (gw && aligned16(gw))) && workspace && ldx >= 3 && lddy >= Cout && lddy % 4 == 0 &&
+                     aligned16(dy) && aligned16(workspace),
                  "dl3p_stem_conv_bwd_weight: bad layout");
   const size_t need = dl3p_stem_conv_bwd_weight_workspace(N, Ho, Wo, Cout);
   DL3P_CHECK_ARG(workspace_bytes >= need, "dl3p_stem_conv_bwd_weight: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -312,5 +312,21 @@ extern "C" int dl3p_stem_conv_bwd_weight(const float* x, int ldx, const float* d
   if (Cout == 32) dl3p_launch(stem_wgrad_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   else dl3p_launch(stem_wgrad_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   DL3P_CHECK_LAUNCH("dl3p_stem_conv_bwd_weight");
+  if (rows_out) { *rows_out = grid; return DL3P_OK; }
   return dl3p_reduce_rows_impl(workspace, grid, (size_t)28 * Cout, gw, 0, (hipStream_t)stream);
+}
+
+extern "C" int dl3p_stem_conv_bwd_weight(const float* x, int ldx, const float* dy, int lddy, float* gw, float* workspace,
+                                         size_t workspace_bytes, int N, int H, int W, int Cout, int pad_t, int pad_l,
+                                         int Ho, int Wo, void* stream) {
+  return stem_conv_bwd_weight_impl(x, ldx, dy, lddy, gw, workspace, workspace_bytes, N, H, W, Cout, pad_t, pad_l, Ho, Wo, nullptr,
+                                   stream);
+}
+
+extern "C" int dl3p_stem_conv_bwd_weight_slabs(const float* x, int ldx, const float* dy, int lddy, float* workspace,
+                                               size_t workspace_bytes, int* rows_out, int N, int H, int W, int Cout, int pad_t,
+                                               int pad_l, int Ho, int Wo, void* stream) {
+  DL3P_CHECK_ARG(rows_out != nullptr, "dl3p_stem_conv_bwd_weight_slabs: rows_out is required");
+  return stem_conv_bwd_weight_impl(x, ldx, dy, lddy, nullptr, workspace, workspace_bytes, N, H, W, Cout, pad_t, pad_l, Ho, Wo,
+                                   rows_out, stream);
 }

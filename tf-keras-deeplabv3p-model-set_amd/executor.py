@@ -458,6 +458,37 @@ class Executor:
                 and self.L.stem_conv_supported(op.cin, op.cout, op.k, op.stride, op.rate)
                 and os.environ.get('DL3P_STEM_DIRECT', '1') != '0')
 
+    def _slab_bytes(self, op):
+        """workspace bytes of a conv's weight gradient when it can leave its slabs for the batched reduction (0: it has a bias
+        gradient, runs on <= 64 rows, or is a dense conv on the im2col route)"""
+        L, N = self.L, self.N
+        if getattr(op, 'b', None) is not None or N * op.Ho * op.Wo <= 64:
+            return 0
+        if op.kind == 'conv_pw':
+            return L.pwconv_bwd_weight_workspace(N * op.Ho * op.Wo, op.cin, op.cout)
+        if op.kind == 'conv_dw':
+            return L.dwconv2d_bwd_weight_workspace(N, op.Ho, op.Wo, op.c, op.k)
+        if self._stem_direct(op):
+            return L.stem_conv_bwd_weight_workspace(N, op.Ho, op.Wo, op.cout)
+        if self._dense_gemm(op):
+            return L.conv2d_gemm_bwd_weight_workspace(N, op.Ho, op.Wo, op.cin, op.cout, op.k)
+        return 0
+
+    def _reduce_all(self, P, jobs):
+        """one dl3p_reduce_rows_batched call for every (slabs, destination, rows, n) job of the step"""
+        import numpy as np
+        L = self.L
+        rec = np.zeros(len(jobs), dtype=np.dtype([('src', '<u8'), ('dst', '<u8'), ('rows', '<i4'), ('n', '<i4')]))
+        maps = ([], [])
+        for j, (src, dst, rows, n) in enumerate(jobs):
+            rec[j] = (src, dst, rows, n)
+            v = L.reduce_rows_variant(rows, n)
+            maps[v].extend((j, b) for b in range((n + 63) // 64))
+        self._wgrad_jobs = torch.from_numpy(rec.view(np.uint8).copy()).to(self.dev)
+        self._wgrad_maps = [torch.tensor(m if m else [(0, 0)], dtype=torch.int32, device=self.dev) for m in maps]
+        P.k(L.reduce_rows_batched, self._wgrad_jobs.data_ptr(), self._wgrad_maps[0].data_ptr(), len(maps[0]),
+            self._wgrad_maps[1].data_ptr(), len(maps[1]))
+
     def _dense_gemm(self, op):
         """dense conv with Cin % 4 == 0 on the fp32 path: implicit GEMM, the patch operand gathered while the GEMM stages
         its A tile (csrc/pwconv.hip, dl3p_conv2d_gemm_*) -- no im2col matrix, no col2im pass"""
@@ -772,6 +803,29 @@ class Executor:
                 self._deferred.append((fn, args, P.ctx))
             else:
                 P.k(fn, *args)
+
+        # Single-GPU fp32: the weight-gradient kernels leave their slabs in per-layer regions of one buffer and ONE pair
+        # of launches at the end of backward reduces them all (dl3p_reduce_rows_batched; 65 reduce launches of 5-13 us
+        # each otherwise).  Same per-element arithmetic as the per-layer reduction, so the gradients are bit-identical to
+        # the data-parallel path, which keeps reducing per layer (its buckets leave while backward still runs).
+        batch = (self.dist is None and not self.bf16 and os.environ.get('DL3P_BATCHED_WGRAD', '1') != '0')
+        jobs = []            # (slab offset in floats, destination pointer, rows, n)
+        slab_off = [0]
+        slab_need = 0
+        if batch:
+            for op in self.g.ops:
+                if op.kind in ('conv_pw', 'conv_dense', 'conv_dw') and op.layer.trainable and self._slab_bytes(op):
+                    slab_need += (self._slab_bytes(op) + 255) // 256 * 256
+            self.slab_ws = torch.zeros(slab_need // 4 + 64, **self.f32) if slab_need else None
+
+        def wgrad_slabs(fn, n, dst, nbytes, *args):
+            """fn(*args[:split], region, bytes, &rows, *args[split:]) with args given as (before, after)"""
+            before, after = args
+            region = self.slab_ws.data_ptr() + 4 * slab_off[0]
+            rows = ctypes.c_int(0)
+            P.k(fn, *before, region, nbytes, ctypes.byref(rows), *after)
+            jobs.append((region, dst, rows.value, n))
+            slab_off[0] += ((nbytes + 255) // 256 * 256) // 4
         for ri, op in enumerate(rops):
             k = op.kind
             P.ctx = _op_label(op)
@@ -813,7 +867,23 @@ class Executor:
                 xt = op.x.tensor
                 dz, lddz = self.tptr(out, True), out.ld
                 need_gx = xt.requires_grad or xt.root.requires_grad
-                if op.layer.trainable:
+                if op.layer.trainable and batch and self._slab_bytes(op):
+                    gw = st.ptr(op.w, G)
+                    nb = self._slab_bytes(op)
+                    if k == 'conv_pw':
+                        wgrad_slabs(L.pwconv_bwd_weight_slabs, op.cin * op.cout, gw, nb, (xp, ldx, sp, hp, act, dz, lddz),
+                                    (N * op.Ho * op.Wo, op.cin, op.cout))
+                    elif k == 'conv_dw':
+                        wgrad_slabs(L.dwconv2d_bwd_weight_slabs, op.k * op.k * op.c, gw, nb, (xp, ldx, sp, hp, act, dz, lddz),
+                                    (N, xt.H, xt.W, op.c, op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo))
+                    elif self._stem_direct(op):
+                        wgrad_slabs(L.stem_conv_bwd_weight_slabs, 28 * op.cout, gw, nb, (xp, ldx, dz, lddz),
+                                    (N, xt.H, xt.W, op.cout, op.pad_t, op.pad_l, op.Ho, op.Wo))
+                    else:
+                        wgrad_slabs(L.conv2d_gemm_bwd_weight_slabs, op.k * op.k * op.cin * op.cout, gw, nb,
+                                    (xp, ldx, sp, hp, act, dz, lddz),
+                                    (N, xt.H, xt.W, op.cin, op.cout, op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo))
+                elif op.layer.trainable:
                     gw = st.ptr(op.w, G)
                     if k == 'conv_pw':
                         wgrad(L.pwconv_bwd_weight, xp, ldx, sp, hp, act, dz, lddz, gw, st.ptr(op.b, G) if op.b else None,
@@ -928,6 +998,9 @@ class Executor:
         if self._bwd_pending:
             self._flush_bn_backward(P)
         self._flush_deferred(P)
+        if jobs:
+            P.ctx = 'wgrad:reduce_all'
+            self._reduce_all(P, jobs)
         if self.dist is not None:
             P.coll(lambda hi=self._first_bucket_hi: self.dist.all_reduce_async(G[0:hi]))
             # join the side stream inside this plan: a captured graph may not end with forked work in flight
