@@ -492,8 +492,11 @@ class Executor:
     def _dense_gemm(self, op):
         """dense conv with Cin % 4 == 0 on the fp32 path: implicit GEMM, the patch operand gathered while the GEMM stages
         its A tile (csrc/pwconv.hip, dl3p_conv2d_gemm_*) -- no im2col matrix, no col2im pass"""
+        xt = op.x.tensor
         return (not self.bf16 and not self._stem_direct(op)
-                and bool(self.L.conv2d_gemm_supported(op.cin, op.cout, op.k, op.stride)))
+                and bool(self.L.conv2d_gemm_supported(op.cin, op.cout, op.k, op.stride))
+                # the gather decodes row indices in 24-bit arithmetic; larger tensors keep the im2col route
+                and self.N * xt.H * xt.W < (1 << 24) and self.N * op.Ho * op.Wo < (1 << 24))
 
     def _mark_requires_grad(self):
         for t in self.g.tensors:
