@@ -154,6 +154,8 @@ def bench_shape(role, M, K, N):
 def main():
     dry = '--dry' in sys.argv
     L.set_option(b'pw_small_min_rows', -1)
+    if '--no-small' in sys.argv:      # what would the tiled kernel do on the shapes the streaming small-K*N kernels take?
+        L.set_option(b'pw_small_min_rows', 1 << 30)
     sh = shapes()
     rows = []
     log = []
