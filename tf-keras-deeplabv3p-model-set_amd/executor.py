@@ -484,10 +484,11 @@ class Executor:
             rec[j] = (src, dst, rows, n)
             v = L.reduce_rows_variant(rows, n)
             maps[v].extend((j, b) for b in range((n + 63) // 64))
-        self._wgrad_jobs = torch.from_numpy(rec.view(np.uint8).copy()).to(self.dev)
-        self._wgrad_maps = [torch.tensor(m if m else [(0, 0)], dtype=torch.int32, device=self.dev) for m in maps]
-        P.k(L.reduce_rows_batched, self._wgrad_jobs.data_ptr(), self._wgrad_maps[0].data_ptr(), len(maps[0]),
-            self._wgrad_maps[1].data_ptr(), len(maps[1]))
+        jt = torch.from_numpy(rec.view(np.uint8).copy()).to(self.dev)
+        mt = [torch.tensor(m if m else [(0, 0)], dtype=torch.int32, device=self.dev) for m in maps]
+        self._wgrad_tables.append((jt, mt))         # the launches read them at every replay
+        self._wgrad_jobs = jt
+        P.k(L.reduce_rows_batched, jt.data_ptr(), mt[0].data_ptr(), len(maps[0]), mt[1].data_ptr(), len(maps[1]))
 
     def _dense_gemm(self, op):
         """dense conv with Cin % 4 == 0 on the fp32 path: implicit GEMM, the patch operand gathered while the GEMM stages
@@ -807,12 +808,13 @@ class Executor:
             else:
                 P.k(fn, *args)
 
-        # Single-GPU fp32: the weight-gradient kernels leave their slabs in per-layer regions of one buffer and ONE pair
-        # of launches at the end of backward reduces them all (dl3p_reduce_rows_batched; 65 reduce launches of 5-13 us
-        # each otherwise).  Same per-element arithmetic as the per-layer reduction, so the gradients are bit-identical to
-        # the data-parallel path, which keeps reducing per layer (its buckets leave while backward still runs).
-        batch = (self.dist is None and not self.bf16 and os.environ.get('DL3P_BATCHED_WGRAD', '1') != '0')
-        jobs = []            # (slab offset in floats, destination pointer, rows, n)
+        # fp32: the weight-gradient kernels leave their slabs in per-layer regions of one buffer and ONE pair of launches
+        # reduces them all (dl3p_reduce_rows_batched; 65 reduce launches of 5-13 us each otherwise) -- at the end of
+        # backward on one GPU, per gradient bucket under data parallelism (in front of the bucket's all-reduce).  Same
+        # per-element arithmetic as the per-layer reduction, whichever way the jobs are grouped.
+        batch = (not self.bf16 and os.environ.get('DL3P_BATCHED_WGRAD', '1') != '0')
+        jobs = self._jobs = []            # (slab pointer, destination pointer, rows, n) issued and not yet reduced
+        self._wgrad_tables = []
         slab_off = [0]
         slab_need = 0
         if batch:
@@ -825,10 +827,16 @@ class Executor:
             """fn(*args[:split], region, bytes, &rows, *args[split:]) with args given as (before, after)"""
             before, after = args
             region = self.slab_ws.data_ptr() + 4 * slab_off[0]
-            rows = ctypes.c_int(0)
-            P.k(fn, *before, region, nbytes, ctypes.byref(rows), *after)
-            jobs.append((region, dst, rows.value, n))
             slab_off[0] += ((nbytes + 255) // 256 * 256) // 4
+
+            def issue(P2):
+                rows = ctypes.c_int(0)
+                P2.k(fn, *before, region, nbytes, ctypes.byref(rows), *after)
+                self._jobs.append((region, dst, rows.value, n))
+            if defer:
+                self._deferred.append((issue, None, P.ctx))      # runs at the next _flush_deferred, like the plain ones
+            else:
+                issue(P)
         for ri, op in enumerate(rops):
             k = op.kind
             P.ctx = _op_label(op)
@@ -837,6 +845,7 @@ class Executor:
                 self._flush_bn_backward(P)
             if op in bucket_edges:
                 self._flush_deferred(P)        # every gradient of the finished bucket must have been produced
+                self._reduce_pending(P)        # ... and reduced from its slabs
                 lo, hi = bucket_edges[op]
                 P.coll(lambda lo=lo, hi=hi: self.dist.all_reduce_async(G[lo:hi]))
             out = getattr(op, 'out', None)
@@ -1001,9 +1010,7 @@ class Executor:
         if self._bwd_pending:
             self._flush_bn_backward(P)
         self._flush_deferred(P)
-        if jobs:
-            P.ctx = 'wgrad:reduce_all'
-            self._reduce_all(P, jobs)
+        self._reduce_pending(P)
         if self.dist is not None:
             P.coll(lambda hi=self._first_bucket_hi: self.dist.all_reduce_async(G[0:hi]))
             # join the side stream inside this plan: a captured graph may not end with forked work in flight
@@ -1070,9 +1077,20 @@ class Executor:
         ctx = P.ctx
         for fn, args, c in self._deferred:
             P.ctx = c
-            P.k(fn, *args)
+            if args is None:
+                fn(P)                 # a slab-leaving weight gradient: launches and files its reduction job
+            else:
+                P.k(fn, *args)
         self._deferred = []
         P.ctx = ctx
+
+    def _reduce_pending(self, P):
+        if getattr(self, '_jobs', None):
+            ctx = P.ctx
+            P.ctx = 'wgrad:reduce_all'
+            self._reduce_all(P, self._jobs)
+            del self._jobs[:]
+            P.ctx = ctx
 
     def _bucket_edges(self):
         edges, self._first_bucket_hi = bucket_edges(self.g, self.store.offset, self.store.total, self.dist.n_buckets)
