@@ -403,6 +403,14 @@ int dl3p_conv2d_gemm_bwd_weight_slabs(const float* x, int ldx, const float* in_s
                                       const float* dy, int lddy, float* workspace, size_t workspace_bytes, int* rows_out,
                                       int N, int H, int W, int Cin, int Cout, int k, int stride, int rate,
                                       int pad_t, int pad_l, int Ho, int Wo, void* stream);
+/* the bf16 path's weight gradients (fp32 slabs there too; same contract) */
+int dl3p_pwconv_bwd_weight_slabs_bf16(const void* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                                      const void* dy, int lddy, int dy_is_f32, float* workspace, size_t workspace_bytes,
+                                      int* rows_out, int M, int K, int N, void* stream);
+int dl3p_dwconv2d_bwd_weight_slabs_bf16(const void* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                                        const void* dy, int lddy, float* workspace, size_t workspace_bytes, int* rows_out,
+                                        int N, int H, int W, int C, int k, int stride, int rate, int pad_t, int pad_l,
+                                        int Ho, int Wo, void* stream);
 
 /* ---------------------------------------------------------------- optimiser
  * Keras SGD(momentum, nesterov=False) (common/model_utils.py:124) with the l2(2e-5) regulariser

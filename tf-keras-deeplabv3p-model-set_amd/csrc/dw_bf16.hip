@@ -285,15 +285,15 @@ extern "C" size_t dl3p_dwconv2d_bwd_weight_workspace_bf16(int N, int Ho, int Wo,
   return (size_t)dww_rows(N, Ho, Wo, C) * k * k * C * sizeof(float);
 }
 
-extern "C" int dl3p_dwconv2d_bwd_weight_bf16(const void* x, int ldx, const float* in_scale, const float* in_shift,
-                                             int in_act, const void* dy, int lddy, float* gw, float* workspace,
-                                             size_t workspace_bytes, int N, int H, int W, int C, int k, int stride,
-                                             int rate, int pad_t, int pad_l, int Ho, int Wo, void* stream) {
+static int dwb_bwd_weight_impl(const void* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                               const void* dy, int lddy, float* gw, float* workspace, size_t workspace_bytes, int N, int H,
+                               int W, int C, int k, int stride, int rate, int pad_t, int pad_l, int Ho, int Wo, int* rows_out,
+                               void* stream) {
   int rc = dw_check("dl3p_dwconv2d_bwd_weight_bf16", x, ldx, C, k, stride);
   if (rc) return rc;
   rc = dw_check("dl3p_dwconv2d_bwd_weight_bf16", dy, lddy, C, k, stride);
   if (rc) return rc;
-  DL3P_CHECK_ARG(gw && workspace && workspace_bytes >= dl3p_dwconv2d_bwd_weight_workspace_bf16(N, Ho, Wo, C, k) &&
+  DL3P_CHECK_ARG((gw || rows_out) && workspace && workspace_bytes >= dl3p_dwconv2d_bwd_weight_workspace_bf16(N, Ho, Wo, C, k) &&
                  (long long)N * Ho * Wo < (1LL << 31), "dl3p_dwconv2d_bwd_weight_bf16: bad arguments / workspace too small");
   DwB p = {};
   p.x = (const bf16*)x; p.ldx = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act;
@@ -310,6 +310,7 @@ extern "C" int dl3p_dwconv2d_bwd_weight_bf16(const void* x, int ldx, const float
     if (k == 3) { if (hs) hipLaunchKernelGGL((dwb_bwd_weight_strip<3, 4, true>), sgrid, dim3(256), 0, st, p, geo); else hipLaunchKernelGGL((dwb_bwd_weight_strip<3, 4, false>), sgrid, dim3(256), 0, st, p, geo); }
     else { if (hs) hipLaunchKernelGGL((dwb_bwd_weight_strip<5, 4, true>), sgrid, dim3(256), 0, st, p, geo); else hipLaunchKernelGGL((dwb_bwd_weight_strip<5, 4, false>), sgrid, dim3(256), 0, st, p, geo); }
     DL3P_CHECK_LAUNCH("dl3p_dwconv2d_bwd_weight_bf16");
+    if (rows_out) { *rows_out = p.nbx; return DL3P_OK; }
     return dl3p_reduce_rows_impl(workspace, p.nbx, (size_t)k * k * C, gw, 0, st);
   }
   dw_grid(p, 4, (long long)N * Ho * Wo, 2, rows);
@@ -317,5 +318,23 @@ extern "C" int dl3p_dwconv2d_bwd_weight_bf16(const void* x, int ldx, const float
   if (k == 3) hipLaunchKernelGGL((dwb_bwd_weight<3>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((dwb_bwd_weight<5>), grid, dim3(256), 0, st, p);
   DL3P_CHECK_LAUNCH("dl3p_dwconv2d_bwd_weight_bf16");
+  if (rows_out) { *rows_out = p.nbx; return DL3P_OK; }
   return dl3p_reduce_rows_impl(workspace, p.nbx, (size_t)k * k * C, gw, 0, st);
+}
+
+extern "C" int dl3p_dwconv2d_bwd_weight_bf16(const void* x, int ldx, const float* in_scale, const float* in_shift,
+                                             int in_act, const void* dy, int lddy, float* gw, float* workspace,
+                                             size_t workspace_bytes, int N, int H, int W, int C, int k, int stride,
+                                             int rate, int pad_t, int pad_l, int Ho, int Wo, void* stream) {
+  return dwb_bwd_weight_impl(x, ldx, in_scale, in_shift, in_act, dy, lddy, gw, workspace, workspace_bytes, N, H, W, C, k,
+                             stride, rate, pad_t, pad_l, Ho, Wo, nullptr, stream);
+}
+
+extern "C" int dl3p_dwconv2d_bwd_weight_slabs_bf16(const void* x, int ldx, const float* in_scale, const float* in_shift,
+                                                   int in_act, const void* dy, int lddy, float* workspace,
+                                                   size_t workspace_bytes, int* rows_out, int N, int H, int W, int C, int k,
+                                                   int stride, int rate, int pad_t, int pad_l, int Ho, int Wo, void* stream) {
+  DL3P_CHECK_ARG(rows_out != nullptr, "dl3p_dwconv2d_bwd_weight_slabs_bf16: rows_out is required");
+  return dwb_bwd_weight_impl(x, ldx, in_scale, in_shift, in_act, dy, lddy, nullptr, workspace, workspace_bytes, N, H, W, C, k,
+                             stride, rate, pad_t, pad_l, Ho, Wo, rows_out, stream);
 }

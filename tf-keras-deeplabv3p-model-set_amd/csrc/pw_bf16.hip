@@ -835,14 +835,16 @@ extern "C" size_t dl3p_pwconv_bwd_weight_workspace_bf16(int M, int K, int N) {
   return ((size_t)pl.mchunks * K * N + (size_t)DL3P_NUM_CUS * 2 * N) * sizeof(float);
 }
 
-extern "C" int dl3p_pwconv_bwd_weight_bf16(const void* x, int ldx, const float* in_scale, const float* in_shift,
-                                           int in_act, const void* dy, int lddy, int dy_is_f32, float* gw, float* gb,
-                                           float* workspace, size_t workspace_bytes, int M, int K, int N, void* stream) {
+static int pwb_bwd_weight_impl(const void* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                               const void* dy, int lddy, int dy_is_f32, float* gw, float* gb, float* workspace,
+                               size_t workspace_bytes, int M, int K, int N, int* rows_out, void* stream) {
   int rc = check_mat_b("dl3p_pwconv_bwd_weight_bf16", x, ldx, K, false);
   if (rc) return rc;
   rc = check_mat_b("dl3p_pwconv_bwd_weight_bf16", dy, lddy, N, dy_is_f32);
   if (rc) return rc;
-  DL3P_CHECK_ARG(gw && M > 0, "dl3p_pwconv_bwd_weight_bf16: bad arguments");
+  DL3P_CHECK_ARG((gw || rows_out) && M > 0, "dl3p_pwconv_bwd_weight_bf16: bad arguments");
+  DL3P_CHECK_ARG(!rows_out || (!gb && M > 64),
+                 "dl3p_pwconv_bwd_weight_slabs_bf16: no bias gradient and more than 64 rows (use dl3p_pwconv_bwd_weight_bf16)");
   hipStream_t st = (hipStream_t)stream;
   WgradB p = {};
   p.X = (const bf16*)x; p.ldx = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act; p.DY = dy; p.lddy = lddy;
@@ -868,6 +870,10 @@ extern "C" int dl3p_pwconv_bwd_weight_bf16(const void* x, int ldx, const float* 
     else hipLaunchKernelGGL((pwb_wgrad<4, false>), grid, dim3(256), 0, st, p);
   }
   DL3P_CHECK_LAUNCH("dl3p_pwconv_bwd_weight_bf16");
+  if (rows_out) {                      // the caller reduces the slabs (dl3p_reduce_rows_batched)
+    *rows_out = pl.mchunks;
+    return DL3P_OK;
+  }
   rc = dl3p_reduce_rows_impl(workspace, pl.mchunks, (size_t)K * N, gw, 0, st);
   if (rc) return rc;
   if (gb) {
@@ -879,4 +885,19 @@ extern "C" int dl3p_pwconv_bwd_weight_bf16(const void* x, int ldx, const float* 
     rc = dl3p_reduce_rows_impl(part, blocks, (size_t)N, gb, 0, st);
   }
   return rc;
+}
+
+extern "C" int dl3p_pwconv_bwd_weight_bf16(const void* x, int ldx, const float* in_scale, const float* in_shift,
+                                           int in_act, const void* dy, int lddy, int dy_is_f32, float* gw, float* gb,
+                                           float* workspace, size_t workspace_bytes, int M, int K, int N, void* stream) {
+  return pwb_bwd_weight_impl(x, ldx, in_scale, in_shift, in_act, dy, lddy, dy_is_f32, gw, gb, workspace, workspace_bytes, M, K,
+                             N, nullptr, stream);
+}
+
+extern "C" int dl3p_pwconv_bwd_weight_slabs_bf16(const void* x, int ldx, const float* in_scale, const float* in_shift,
+                                                 int in_act, const void* dy, int lddy, int dy_is_f32, float* workspace,
+                                                 size_t workspace_bytes, int* rows_out, int M, int K, int N, void* stream) {
+  DL3P_CHECK_ARG(rows_out != nullptr, "dl3p_pwconv_bwd_weight_slabs_bf16: rows_out is required");
+  return pwb_bwd_weight_impl(x, ldx, in_scale, in_shift, in_act, dy, lddy, dy_is_f32, nullptr, nullptr, workspace,
+                             workspace_bytes, M, K, N, rows_out, stream);
 }

@@ -464,6 +464,10 @@ class Executor:
         L, N = self.L, self.N
         if getattr(op, 'b', None) is not None or N * op.Ho * op.Wo <= 64:
             return 0
+        if self.bf16:
+            if op.kind == 'conv_dw':
+                return L.dwconv2d_bwd_weight_workspace_bf16(N, op.Ho, op.Wo, op.c, op.k)
+            return L.pwconv_bwd_weight_workspace_bf16(N * op.Ho * op.Wo, op.cin if op.kind == 'conv_pw' else op.kp, op.cout)
         if op.kind == 'conv_pw':
             return L.pwconv_bwd_weight_workspace(N * op.Ho * op.Wo, op.cin, op.cout)
         if op.kind == 'conv_dw':
@@ -808,11 +812,11 @@ class Executor:
             else:
                 P.k(fn, *args)
 
-        # fp32: the weight-gradient kernels leave their slabs in per-layer regions of one buffer and ONE pair of launches
+        # the weight-gradient kernels leave their (fp32) slabs in per-layer regions of one buffer and ONE pair of launches
         # reduces them all (dl3p_reduce_rows_batched; 65 reduce launches of 5-13 us each otherwise) -- at the end of
         # backward on one GPU, per gradient bucket under data parallelism (in front of the bucket's all-reduce).  Same
         # per-element arithmetic as the per-layer reduction, whichever way the jobs are grouped.
-        batch = (not self.bf16 and os.environ.get('DL3P_BATCHED_WGRAD', '1') != '0')
+        batch = os.environ.get('DL3P_BATCHED_WGRAD', '1') != '0'
         jobs = self._jobs = []            # (slab pointer, destination pointer, rows, n) issued and not yet reduced
         self._wgrad_tables = []
         slab_off = [0]
@@ -873,7 +877,7 @@ class Executor:
             if out is None or not out.requires_grad:
                 continue
             if self.bf16 and k in ('conv_pw', 'conv_dense', 'conv_dw'):
-                self._conv_backward_bf16(P, op, wgrad, ws, wsb)
+                self._conv_backward_bf16(P, op, wgrad, ws, wsb, wgrad_slabs if batch else None)
             elif k in ('conv_pw', 'conv_dense', 'conv_dw'):
                 xp, ldx, sp, hp, act = self.vargs(op.x)
                 xt = op.x.tensor
@@ -1017,7 +1021,7 @@ class Executor:
             P.py(self.dist.wait_all)
         return P
 
-    def _conv_backward_bf16(self, P, op, wgrad, ws, wsb):
+    def _conv_backward_bf16(self, P, op, wgrad, ws, wsb, wgrad_slabs=None):
         """weight and data gradient of one conv on the bf16 path (the BatchNorm-backward sums are NOT fused into the
         data-gradient kernels here: every trainable BN takes the separate reduce pass)"""
         L, N, st, k = self.L, self.N, self.store, op.kind
@@ -1030,7 +1034,17 @@ class Executor:
         if op.layer.trainable:
             gw = st.ptr(op.w, G)
             gb = st.ptr(op.b, G) if getattr(op, 'b', None) else None
-            if k == 'conv_pw':
+            nb = self._slab_bytes(op) if wgrad_slabs else 0
+            if nb and k == 'conv_dw':
+                wgrad_slabs(L.dwconv2d_bwd_weight_slabs_bf16, op.k * op.k * op.c, gw, nb, (xp, ldx, sp, hp, act, dz, lddz),
+                            (N, xt.H, xt.W, op.c, op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo))
+            elif nb and k == 'conv_pw':
+                wgrad_slabs(L.pwconv_bwd_weight_slabs_bf16, op.cin * op.cout, gw, nb, (xp, ldx, sp, hp, act, dz, lddz, dzf),
+                            (M, op.cin, op.cout))
+            elif nb:
+                wgrad_slabs(L.pwconv_bwd_weight_slabs_bf16, op.kp * op.cout, gw, nb,
+                            (self.tptr(op.col), op.col.ld, None, None, ACT_NONE, dz, lddz, dzf), (M, op.kp, op.cout))
+            elif k == 'conv_pw':
                 wgrad(L.pwconv_bwd_weight_bf16, xp, ldx, sp, hp, act, dz, lddz, dzf, gw, gb, ws, wsb, M, op.cin, op.cout)
             elif k == 'conv_dw':
                 wgrad(L.dwconv2d_bwd_weight_bf16, xp, ldx, sp, hp, act, dz, lddz, gw, ws, wsb, N, xt.H, xt.W, op.c, op.k,
