@@ -236,6 +236,23 @@ __device__ __forceinline__ void reduce2_rows(const float* partials, int rows, co
       if (ry == 0) { s0 = sums[c]; s1 = sums[C + c]; }
     } else {
       int r = ry;
+      // the partial rows were just written by workgroups all over the chip: every load is an L2 miss, so 16 of them are
+      // in flight per thread before the first add (same accumulators, same order as the two-row loop below)
+      for (; r + 7 * FIN_RY < rows; r += 8 * FIN_RY) {
+        float v[8][2];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          v[u][0] = partials[((size_t)(r + u * FIN_RY) * 2) * C + c];
+          v[u][1] = partials[((size_t)(r + u * FIN_RY) * 2 + 1) * C + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+          s0 += (double)v[u][0];
+          s1 += (double)v[u][1];
+          t0 += (double)v[u + 1][0];
+          t1 += (double)v[u + 1][1];
+        }
+      }
       for (; r + FIN_RY < rows; r += 2 * FIN_RY) {
         s0 += (double)partials[((size_t)r * 2) * C + c];
         s1 += (double)partials[((size_t)r * 2 + 1) * C + c];
@@ -265,6 +282,13 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* partials
                                                           float* shift, float* save_mean, float* save_invstd) {
   const int cx = threadIdx.x % FIN_CX, ry = threadIdx.x / FIN_CX;
   const int c = blockIdx.x * FIN_CX + cx;
+  // the per-channel parameters are fetched under the reduction, not after it
+  float ga = 0.f, be = 0.f, mm = 0.f, mv = 0.f;
+  if (ry == 0 && c < C) {
+    ga = gamma[c];
+    be = beta[c];
+    if (update_moving) { mm = moving_mean[c]; mv = moving_var[c]; }
+  }
   double s, ss;
   reduce2_rows(partials, rows, sums, C, c, ry, s, ss);
   if (ry == 0 && c < C) {
@@ -272,15 +296,15 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* partials
     double var = ss / count - mean * mean;
     if (var < 0.0) var = 0.0;
     float invstd = (float)(1.0 / sqrt(var + (double)eps));
-    float sc = gamma[c] * invstd;
+    float sc = ga * invstd;
     scale[c] = sc;
-    shift[c] = beta[c] - (float)mean * sc;
+    shift[c] = be - (float)mean * sc;
     save_mean[c] = (float)mean;
     save_invstd[c] = invstd;
     if (update_moving) {
       // SyncBatchNormalization (non-fused Keras path): the biased batch variance feeds the moving average too
-      moving_mean[c] = moving_mean[c] * momentum + (float)mean * (1.f - momentum);
-      moving_var[c] = moving_var[c] * momentum + (float)var * (1.f - momentum);
+      moving_mean[c] = mm * momentum + (float)mean * (1.f - momentum);
+      moving_var[c] = mv * momentum + (float)var * (1.f - momentum);
     }
   }
 }
@@ -416,17 +440,19 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* part
                                                               float* dgamma, float* dbeta, float* coef) {
   const int cx = threadIdx.x % FIN_CX, ry = threadIdx.x / FIN_CX;
   const int c = blockIdx.x * FIN_CX + cx;
+  float c0 = 0.f;
+  if (ry == 0 && c < C) c0 = frozen ? scale[c] : gamma[c] * invstd[c];      // fetched under the reduction
   double s, sx;
   reduce2_rows(partials, rows, sums, C, c, ry, s, sx);
   if (ry == 0 && c < C) {
     if (frozen) {
-      coef[c] = scale[c];
+      coef[c] = c0;
       coef[C + c] = 0.f;
       coef[2 * C + c] = 0.f;
     } else {
       if (dgamma) dgamma[c] = (float)sx;
       if (dbeta) dbeta[c] = (float)s;
-      coef[c] = gamma[c] * invstd[c];
+      coef[c] = c0;
       coef[C + c] = (float)(s / count);
       coef[2 * C + c] = (float)(sx / count);
     }
