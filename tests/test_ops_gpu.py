@@ -452,6 +452,39 @@ def test_batchnorm_fwd_bwd(ops, shape, act):
     close(dz2, O.act_bwd(y2, g, act) * (gamma / np.sqrt(mv + eps)), rtol=3e-4, atol=1e-4, what='bn frozen bwd')
 
 
+@pytest.mark.parametrize('ratio', [30.0, 300.0])
+def test_batchnorm_variance_when_mean_dwarfs_sigma(ops, ratio):
+    """E[x^2] - E[x]^2 loses digits when |mean| >> sigma.  The reference computes exactly that in float32
+    (Keras SyncBatchNormalization: reduce_sum(y), reduce_sum(square(y)), variance = E[y^2] - mean^2; layers.py:19-26 make it
+    the CustomBatchNormalization); here the per-workgroup partial sums are float32 and everything above them is double.
+    The kernel has to be at least as close to the float64 statistics as that float32 formula is."""
+    rng = np.random.default_rng(17)
+    N, H, W, C = 4, 33, 33, 32
+    sigma = 0.02
+    mean = ratio * sigma * rng.choice([-1.0, 1.0], C)
+    z = (rng.standard_normal((N, H, W, C)) * sigma + mean).astype(np.float32).astype(np.float64)
+    M = z.size // C
+    eps = 1e-5
+    var64 = z.reshape(-1, C).var(0)
+    inv64 = 1.0 / np.sqrt(var64 + eps)
+    # the reference's formula carried out in float32 (pairwise sums, as NumPy / Eigen do them)
+    z32 = z.reshape(-1, C).astype(np.float32)
+    m32 = z32.sum(0, dtype=np.float32) / np.float32(M)
+    v32 = np.maximum((z32 * z32).sum(0, dtype=np.float32) / np.float32(M) - m32 * m32, 0)
+    inv32 = 1.0 / np.sqrt(v32.astype(np.float64) + eps)
+    bn = ops.BNState(C, DEV, eps, 0.99)
+    part = ops.new_partials(C, DEV)
+    w = np.zeros((3, 3, C)); w[1, 1] = 1
+    _, rows = ops.dwconv2d_fwd(T(z), T(w), partials=part)
+    ops.bn_finalize(bn, part, rows, M)
+    inv = bn.invstd.cpu().numpy().astype(np.float64)
+    err = np.abs(inv / inv64 - 1).max()
+    err_ref = np.abs(inv32 / inv64 - 1).max()
+    assert err <= max(2 * err_ref, 2e-6), (err, err_ref)
+    assert err < 1e-2 * (ratio / 300.0) ** 2 + 1e-5, err          # measured: 1/sigma off by 0.4 % at mean = 300 sigma, 4e-5 at 30
+    close(bn.mean, z.reshape(-1, C).mean(0), rtol=1e-6, what='mean')
+
+
 def test_residual_dropout(ops):
     rng = np.random.default_rng(8)
     M, C = 500, 48
