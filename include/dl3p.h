@@ -403,6 +403,29 @@ int dl3p_conv2d_gemm_bwd_weight_slabs(const float* x, int ldx, const float* in_s
                                       const float* dy, int lddy, float* workspace, size_t workspace_bytes, int* rows_out,
                                       int N, int H, int W, int Cin, int Cout, int k, int stride, int rate,
                                       int pad_t, int pad_l, int Ho, int Wo, void* stream);
+/* dl3p_pwconv_bwd_weight_slabs with the BatchNorm-backward apply of the conv's own output folded in (replaces
+ * dl3p_bn_bwd_apply + dl3p_pwconv_bwd_weight_slabs; layers.py:19-26 BN behind every conv): g is the gradient of
+ * act(BN(z)), coef what dl3p_bn_bwd_finalize wrote.  dz = coef0 * (g * act'(z*scale+shift) - coef1 - xhat * coef2) is formed
+ * while the tiles are staged and, if dz != NULL, written once for the data gradient that follows (dz must not alias g:
+ * the kernel re-reads g).  dl3p_pwconv_bwd_weight_bn_supported: 1 for the shapes whose kernel reads the gradient operand
+ * once (the few-channel streaming kernels; tiled launches with a single k tile) -- elsewhere every k tile would re-form
+ * dz and the separate apply pass is cheaper (measured). */
+int dl3p_pwconv_bwd_weight_bn_supported(int M, int K, int N);
+int dl3p_pwconv_bwd_weight_slabs_bn(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                                    const float* g, int ldg, const float* z, int ldz, const float* bn_scale,
+                                    const float* bn_shift, int bn_act, const float* save_mean, const float* save_invstd,
+                                    const float* coef, float* dz, int lddz, float* workspace, size_t workspace_bytes,
+                                    int* rows_out, int M, int K, int N, void* stream);
+/* the same for the depthwise 3x3 window kernels (stride 1 at any rate, stride 2): the weight gradient visits every output
+ * pixel once, forms dz there and writes it (SepConv_BN: BN behind the depthwise conv, layers.py:100-105) */
+int dl3p_dwconv2d_bwd_weight_bn_supported(int N, int H, int W, int C, int k, int stride, int rate, int pad_t, int pad_l,
+                                          int Ho, int Wo);
+int dl3p_dwconv2d_bwd_weight_slabs_bn(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                                      const float* g, int ldg, const float* z, int ldz, const float* bn_scale,
+                                      const float* bn_shift, int bn_act, const float* save_mean, const float* save_invstd,
+                                      const float* coef, float* dz, int lddz, float* workspace, size_t workspace_bytes,
+                                      int* rows_out, int N, int H, int W, int C, int k, int stride, int rate, int pad_t,
+                                      int pad_l, int Ho, int Wo, void* stream);
 /* the bf16 path's weight gradients (fp32 slabs there too; same contract) */
 int dl3p_pwconv_bwd_weight_slabs_bf16(const void* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
                                       const void* dy, int lddy, int dy_is_f32, float* workspace, size_t workspace_bytes,

@@ -452,6 +452,84 @@ def test_batchnorm_fwd_bwd(ops, shape, act):
     close(dz2, O.act_bwd(y2, g, act) * (gamma / np.sqrt(mv + eps)), rtol=3e-4, atol=1e-4, what='bn frozen bwd')
 
 
+@pytest.mark.parametrize('M,K,N,act', [(1000, 64, 384, O.ACT_RELU6), (2 * 33 * 33, 64, 384, O.ACT_RELU6), (333, 32, 256, O.ACT_RELU),
+                                       (777, 144, 24, O.ACT_NONE), (70001, 16, 96, O.ACT_RELU6), (5003, 96, 24, O.ACT_NONE),
+                                       (3001, 32, 192, O.ACT_RELU6), (2005, 192, 32, O.ACT_NONE), (4007, 24, 48, O.ACT_HSWISH),
+                                       (2 * 129 * 129, 24, 144, O.ACT_RELU6), (65, 16, 16, O.ACT_RELU)])
+def test_pwconv_bwd_weight_with_folded_bn_apply(ops, M, K, N, act):
+    """dl3p_pwconv_bwd_weight_slabs_bn = dl3p_bn_bwd_apply + dl3p_pwconv_bwd_weight: same dz (written once), same gw"""
+    L = ops.lib()
+    if (K, N) == (32, 192):
+        assert L.pwconv_bwd_weight_bn_supported(M, K, N) == 0, 'the (2, 12)-tile streaming kernel has no registers for the fold'
+        pytest.skip('not served')
+    assert L.pwconv_bwd_weight_bn_supported(M, K, N) == 1
+    assert L.pwconv_bwd_weight_bn_supported(2 * 33 * 33, 320, 256) == 0, 'several k tiles: the apply pass stays'
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((M, K))
+    z = rng.standard_normal((M, N)) * 1.5 + 0.3
+    g = rng.standard_normal((M, N))
+    gamma, beta = rng.uniform(0.5, 1.5, N), rng.standard_normal(N) * 0.3
+    eps = 1e-3
+    y_ref, cache, _ = O.bn_train_fwd(z, gamma, beta, eps)
+    gz_ref, _, _ = O.bn_train_bwd(O.act_bwd(y_ref, g, act), cache)
+    bn = ops.BNState(N, DEV, eps, 0.99)
+    bn.gamma.copy_(T(gamma)); bn.beta.copy_(T(beta))
+    part = ops.new_partials(N, DEV)
+    # statistics of z through the producer's epilogue, then the backward sums and coefficients; apply stays out
+    w1 = np.zeros((3, 3, N)); w1[1, 1] = 1
+    _, rows = ops.dwconv2d_fwd(T(z.reshape(1, 1, M, N)), T(w1), partials=part)
+    ops.bn_finalize(bn, part, rows, M)
+    gt, zt, xt = T(g), T(z), T(x)
+    dz_sep = ops.bn_backward(bn, gt.clone(), zt, act, part)            # reduce + finalize (bn.coef) + apply
+    gw_sep = ops.pwconv_bwd_weight(xt, dz_sep)
+    gw, dz = ops.pwconv_bwd_weight_bn(xt, gt, zt, bn, act)
+    close(dz, gz_ref, rtol=5e-4, atol=5e-4, what='folded dz vs oracle')
+    close(dz, dz_sep.cpu().numpy().astype(np.float64), rtol=1e-5, atol=2e-6, what='folded dz vs apply kernel')
+    close(gw, x.T @ gz_ref, rtol=3e-4, atol=3e-3, what='folded gw vs oracle')
+    close(gw, gw_sep.cpu().numpy().astype(np.float64), rtol=1e-4, atol=1e-4, what='folded gw vs separate')
+    gw2, none = ops.pwconv_bwd_weight_bn(xt, gt, zt, bn, act, want_dz=False)
+    assert none is None and torch.equal(gw2, gw)
+
+
+@pytest.mark.parametrize('shape,stride,rate,act', [((2, 33, 33, 64), 1, 1, O.ACT_RELU6), ((1, 65, 65, 32), 1, 1, O.ACT_RELU),
+                                                   ((2, 34, 30, 24), 2, 1, O.ACT_RELU6), ((2, 33, 33, 32), 1, 2, O.ACT_NONE),
+                                                   ((1, 129, 129, 16), 1, 1, O.ACT_HSWISH), ((3, 17, 19, 96), 2, 1, O.ACT_NONE),
+                                                   ((2, 40, 40, 304), 1, 1, O.ACT_RELU)])
+def test_dwconv_bwd_weight_with_folded_bn_apply(ops, shape, stride, rate, act):
+    """dl3p_dwconv2d_bwd_weight_slabs_bn = dl3p_bn_bwd_apply + dl3p_dwconv2d_bwd_weight: same dz (every output pixel written
+    once), same gw"""
+    L = ops.lib()
+    N, H, W, C = shape
+    Ho, Wo, pt, pl = ops.conv_geometry(H, W, 3, stride, rate, 'same')
+    if not L.dwconv2d_bwd_weight_bn_supported(N, H, W, C, 3, stride, rate, pt, pl, Ho, Wo):
+        pytest.skip('geometry served by the gather kernel')
+    rng = np.random.default_rng(33)
+    x = rng.standard_normal(shape)
+    z = rng.standard_normal((N, Ho, Wo, C)) * 1.5 + 0.3
+    g = rng.standard_normal((N, Ho, Wo, C))
+    gamma, beta = rng.uniform(0.5, 1.5, C), rng.standard_normal(C) * 0.3
+    isc, ish = rng.uniform(0.5, 1.5, C), rng.standard_normal(C) * 0.2
+    eps = 1e-3
+    y_ref, cache, _ = O.bn_train_fwd(z, gamma, beta, eps)
+    gz_ref, _, _ = O.bn_train_bwd(O.act_bwd(y_ref, g, act), cache)
+    bn = ops.BNState(C, DEV, eps, 0.99)
+    bn.gamma.copy_(T(gamma)); bn.beta.copy_(T(beta))
+    part = ops.new_partials(C, DEV)
+    w1 = np.zeros((3, 3, C)); w1[1, 1] = 1
+    _, rows = ops.dwconv2d_fwd(T(z), T(w1), partials=part)
+    ops.bn_finalize(bn, part, rows, z.size // C)
+    gt, zt, xt = T(g), T(z), T(x)
+    dz_sep = ops.bn_backward(bn, gt.clone(), zt, act, part)
+    kw = dict(in_scale=T(isc), in_shift=T(ish), in_act=O.ACT_RELU6)
+    gw_sep = ops.dwconv2d_bwd_weight(xt, dz_sep, 3, stride, rate, **kw)
+    gw, dz = ops.dwconv2d_bwd_weight_bn(xt, gt, zt, bn, act, 3, stride, rate, **kw)
+    close(dz, gz_ref, rtol=5e-4, atol=5e-4, what='folded dz vs oracle')
+    close(dz, dz_sep.cpu().numpy().astype(np.float64), rtol=1e-5, atol=2e-6, what='folded dz vs apply kernel')
+    close(gw, gw_sep.cpu().numpy().astype(np.float64), rtol=1e-4, atol=1e-4, what='folded gw vs separate')
+    gw2, none = ops.dwconv2d_bwd_weight_bn(xt, gt, zt, bn, act, 3, stride, rate, want_dz=False, **kw)
+    assert none is None and torch.equal(gw2, gw)
+
+
 @pytest.mark.parametrize('ratio', [30.0, 300.0])
 def test_batchnorm_variance_when_mean_dwarfs_sigma(ops, ratio):
     """E[x^2] - E[x]^2 loses digits when |mean| >> sigma.  The reference computes exactly that in float32

@@ -33,6 +33,12 @@ struct DwParams {
   // (sum g', sum g' * xhat) as dl3p_bn_bwd_reduce would compute them from the finished gradient
   const float* bb_z; int bb_ldz;
   const float* bb_scale; const float* bb_shift; const float* bb_mean; const float* bb_invstd; int bb_act;
+  // weight-gradient role with the BatchNorm-backward apply of the conv's own output folded in (BNA instantiations): dy is
+  // the gradient of act(BN(z)); dz = c0 * (dy * act'(z*scale+shift) - c1 - xhat * c2) is formed at the output pixel (each is
+  // visited once) and written to fa_dz for the data gradient that follows
+  const float* fa_z; int fa_ldz;
+  const float* fa_scale; const float* fa_shift; const float* fa_mean; const float* fa_invstd; const float* fa_coef; int fa_act;
+  float* fa_dz; int fa_lddz;
 };
 
 // g' = g * act'(z*scale+shift), xhat = (z - mean) * invstd  ->  s[0] += g', s[1] += g' * xhat
@@ -510,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void dw5_wgrad_rows(DwParams p) {
 // Same window walk as the forward kernel (the activated input rows live in registers); every output
 // row adds win[ky][tw+kx] * dy[tw] into the k*k per-thread tap accumulators.  One partial row
 // [k*k][C] per workgroup, summed in a fixed order afterwards.
-template <int KS, int TW, int S, int PRO>
+template <int KS, int TW, int S, int PRO, bool BNA = false>
 __global__ __launch_bounds__(256) void dw_bwd_weight_seg(DwParams p) {
   constexpr int SEG = (TW - 1) * S + KS;
   const int b = blockIdx.x;
@@ -530,6 +536,16 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_seg(DwParams p) {
     if (p.scale) { sc = ld4(p.scale + c); sh = ld4(p.shift + c); }
     const int act = p.act;
     const int th = p.th, nbands = p.nbands, rate = p.rate;
+    // BNA: dz = bA * dy * act'(z * bsc + bsh) - bC * z + bD  (bA = c0, bC = c0 * invstd * c2, bD = bC * mean - c0 * c1)
+    float4 bA = zero4(), bC = zero4(), bD = zero4(), bsc = make_float4(1.f, 1.f, 1.f, 1.f), bsh = zero4();
+    if (BNA) {
+      if (p.fa_scale) { bsc = ld4(p.fa_scale + c); bsh = ld4(p.fa_shift + c); }
+      const float4 mu = ld4(p.fa_mean + c), is = ld4(p.fa_invstd + c);
+      const float4 c0 = ld4(p.fa_coef + c), c1 = ld4(p.fa_coef + p.C + c), c2 = ld4(p.fa_coef + 2 * p.C + c);
+      bA = c0;
+      bC = mul4(mul4(c0, is), c2);
+      bD = make_float4(bC.x * mu.x - c0.x * c1.x, bC.y * mu.y - c0.y * c1.y, bC.z * mu.z - c0.z * c1.z, bC.w * mu.w - c0.w * c1.w);
+    }
     XcdRange r = xcd_range(p.total, bx, p.nbx, p.px, pl);
     for (int s = r.begin; s < r.end; s += r.step) {
       const int strip = s % p.spr;
@@ -603,6 +619,29 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_seg(DwParams p) {
         for (int tw = 0; tw < TW; ++tw) {
           dyv[tw] = zero4();
           if (ox0 + tw * rate < p.Wo) dyv[tw] = ld4(drow + (size_t)tw * rate * p.lddy);
+        }
+        if (BNA) {
+          const size_t pix = ((size_t)n * p.Ho + oy) * p.Wo + ox0;
+          const float* zrow = p.fa_z + pix * p.fa_ldz + c;
+          float4 zv[TW];
+#pragma unroll
+          for (int tw = 0; tw < TW; ++tw) {
+            zv[tw] = zero4();
+            if (ox0 + tw * rate < p.Wo) zv[tw] = ld4(zrow + (size_t)tw * rate * p.fa_ldz);
+          }
+          const int fact = p.fa_act;
+#pragma unroll
+          for (int tw = 0; tw < TW; ++tw) {
+            const float4 z = zv[tw], g = dyv[tw];
+            const float4 u = fma4(z, bsc, bsh);
+            const float4 v = make_float4(fmaf(bA.x, g.x * act_grad(u.x, fact), fmaf(-bC.x, z.x, bD.x)),
+                                         fmaf(bA.y, g.y * act_grad(u.y, fact), fmaf(-bC.y, z.y, bD.y)),
+                                         fmaf(bA.z, g.z * act_grad(u.z, fact), fmaf(-bC.z, z.z, bD.z)),
+                                         fmaf(bA.w, g.w * act_grad(u.w, fact), fmaf(-bC.w, z.w, bD.w)));
+            const bool ok = ox0 + tw * rate < p.Wo;
+            if (ok && p.fa_dz) st4(p.fa_dz + (pix + (size_t)tw * rate) * p.fa_lddz + c, v);
+            dyv[tw] = ok ? v : zero4();
+          }
         }
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky)
@@ -1299,6 +1338,14 @@ extern "C" int dl3p_dwconv2d_bwd_data_bn(const float* dy, int lddy, const float*
                             stream);
 }
 
+template <int PRO>
+static void launch_bwdw_bna(const DwParams& p, int kind, dim3 grid, hipStream_t st) {
+  dim3 block(256);
+  if (kind == 1 && p.tw == 2) hipLaunchKernelGGL((dw_bwd_weight_seg<3, 2, 1, PRO, true>), grid, block, 0, st, p);
+  else if (kind == 1) hipLaunchKernelGGL((dw_bwd_weight_seg<3, 4, 1, PRO, true>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((dw_bwd_weight_seg<3, 2, 2, PRO, true>), grid, block, 0, st, p);
+}
+
 template <int KS, int PRO>
 static void launch_bwdw(const DwParams& p, int kind, dim3 grid, hipStream_t st) {
   dim3 block(256);
@@ -1322,7 +1369,8 @@ extern "C" size_t dl3p_dwconv2d_bwd_weight_workspace(int N, int Ho, int Wo, int 
 static int dwconv2d_bwd_weight_impl(const float* x, int ldx, const float* in_scale, const float* in_shift,
                                     int in_act, const float* dy, int lddy, float* gw, float* workspace,
                                     size_t workspace_bytes, int N, int H, int W, int C, int k, int stride,
-                                    int rate, int pad_t, int pad_l, int Ho, int Wo, int* rows_out, void* stream) {
+                                    int rate, int pad_t, int pad_l, int Ho, int Wo, int* rows_out, void* stream,
+                                    const DwParams* fold = nullptr, int* kind_out = nullptr) {
   int rc = check_dw_common("dl3p_dwconv2d_bwd_weight", x, ldx, C, k);
   if (rc) return rc;
   DL3P_CHECK_ARG(x && dy && (gw || rows_out) && workspace, "dl3p_dwconv2d_bwd_weight: null pointer");
@@ -1346,9 +1394,16 @@ static int dwconv2d_bwd_weight_impl(const float* x, int ldx, const float* in_sca
   static const int wrows = getenv("DL3P_DW5_WROWS") ? atoi(getenv("DL3P_DW5_WROWS")) : 2;
   const bool rows5 = k == 5 && stride == 1 && wrows > 0;
   const int kind = fwd_plan(p, dww_per_cu, rows5, wrows);
+  if (kind_out) { *kind_out = kind; return DL3P_OK; }      // plan query (dl3p_dwconv2d_bwd_weight_bn_supported)
   dim3 grid(p.nbx * p.nslab);
   const int pro = (in_act != DL3P_ACT_NONE) ? 2 : (in_scale ? 1 : 0);
-  if (rows5 && kind == 1) {
+  if (fold) {
+    DL3P_CHECK_ARG(k == 3 && (kind == 1 || kind == 2), "dl3p_dwconv2d_bwd_weight_slabs_bn: geometry not served by the window kernels");
+    p.fa_z = fold->fa_z; p.fa_ldz = fold->fa_ldz; p.fa_scale = fold->fa_scale; p.fa_shift = fold->fa_shift;
+    p.fa_mean = fold->fa_mean; p.fa_invstd = fold->fa_invstd; p.fa_coef = fold->fa_coef; p.fa_act = fold->fa_act;
+    p.fa_dz = fold->fa_dz; p.fa_lddz = fold->fa_lddz;
+    if (pro == 2) launch_bwdw_bna<2>(p, kind, grid, st); else if (pro == 1) launch_bwdw_bna<1>(p, kind, grid, st); else launch_bwdw_bna<0>(p, kind, grid, st);
+  } else if (rows5 && kind == 1) {
     dim3 block(256);
     if (wrows == 1) {
       if (pro == 2) hipLaunchKernelGGL((dw5_wgrad_rows<1, 2>), grid, block, 0, st, p);
@@ -1375,6 +1430,36 @@ extern "C" int dl3p_dwconv2d_bwd_weight(const float* x, int ldx, const float* in
                                         int rate, int pad_t, int pad_l, int Ho, int Wo, void* stream) {
   return dwconv2d_bwd_weight_impl(x, ldx, in_scale, in_shift, in_act, dy, lddy, gw, workspace, workspace_bytes, N, H, W, C, k,
                                   stride, rate, pad_t, pad_l, Ho, Wo, nullptr, stream);
+}
+
+// dl3p_dwconv2d_bwd_weight_slabs with the BatchNorm-backward apply of the conv's own output folded in (the depthwise
+// weight gradient visits every output pixel once, so dz is formed there from g and z and written for the data gradient:
+// the apply pass over (g, z, dz) and its launch disappear).  3x3 window kernels only (stride 1 at any rate, stride 2).
+extern "C" int dl3p_dwconv2d_bwd_weight_bn_supported(int N, int H, int W, int C, int k, int stride, int rate, int pad_t,
+                                                     int pad_l, int Ho, int Wo) {
+  if (k != 3 || C <= 0 || C % 4 || N <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return 0;
+  int kind = -1;
+  alignas(16) static float dummy[4];
+  const int rc = dwconv2d_bwd_weight_impl(dummy, C, nullptr, nullptr, DL3P_ACT_NONE, dummy, C, dummy, dummy, (size_t)-1, N, H, W, C,
+                                          k, stride, rate, pad_t, pad_l, Ho, Wo, nullptr, nullptr, nullptr, &kind);
+  return rc == DL3P_OK && (kind == 1 || kind == 2);
+}
+
+extern "C" int dl3p_dwconv2d_bwd_weight_slabs_bn(const float* x, int ldx, const float* in_scale, const float* in_shift,
+                                                 int in_act, const float* g, int ldg, const float* z, int ldz,
+                                                 const float* bn_scale, const float* bn_shift, int bn_act,
+                                                 const float* save_mean, const float* save_invstd, const float* coef,
+                                                 float* dz, int lddz, float* workspace, size_t workspace_bytes,
+                                                 int* rows_out, int N, int H, int W, int C, int k, int stride, int rate,
+                                                 int pad_t, int pad_l, int Ho, int Wo, void* stream) {
+  const char* fn = "dl3p_dwconv2d_bwd_weight_slabs_bn";
+  DL3P_CHECK_ARG(rows_out && z && save_mean && save_invstd && coef && ldz % 4 == 0 && ldz >= C && aligned16(z) && dz != g &&
+                     (!dz || (lddz % 4 == 0 && lddz >= C && aligned16(dz))), "%s: bad arguments", fn);
+  DwParams f = {};
+  f.fa_z = z; f.fa_ldz = ldz; f.fa_scale = bn_scale; f.fa_shift = bn_shift; f.fa_mean = save_mean; f.fa_invstd = save_invstd;
+  f.fa_coef = coef; f.fa_act = bn_act; f.fa_dz = dz; f.fa_lddz = lddz;
+  return dwconv2d_bwd_weight_impl(x, ldx, in_scale, in_shift, in_act, g, ldg, nullptr, workspace, workspace_bytes, N, H, W, C, k,
+                                  stride, rate, pad_t, pad_l, Ho, Wo, rows_out, stream, &f);
 }
 
 extern "C" int dl3p_dwconv2d_bwd_weight_slabs(const float* x, int ldx, const float* in_scale, const float* in_shift,

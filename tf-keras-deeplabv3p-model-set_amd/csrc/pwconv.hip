@@ -1053,6 +1053,12 @@ struct WgradParams {
   // column k = tap * g_C + c, element = input [N][g_SH][g_SW][ldx] at (y * g_mul + g_ay + ky * g_d, ...), zero outside
   int g_RH, g_RW, g_SH, g_SW, g_C, g_kw, g_mul, g_ay, g_ax, g_d;
   float g_invRW, g_invRH;   // 1 / g_RW, 1 / g_RH for divmod_small
+  // BNA instantiations: DY is the gradient g of act(BN(z)), not of z.  dz = c0 * (g * act'(z*scale+shift) - c1 - xhat * c2)
+  // (what dl3p_bn_bwd_apply writes) is formed while the tile is staged and, by the workgroups of the first k tile, written
+  // to DZ for the data gradient that follows: the apply pass over (g, z, dz) and its launch disappear.
+  const float* Z; int ldz;
+  const float* b_scale; const float* b_shift; const float* b_mean; const float* b_invstd; const float* b_coef; int b_act;
+  float* DZ; int lddz;
 };
 
 // q = a / d, *r = a % d for 0 <= a < 2^24 (exact in float) and 0 < d < 2^14: one multiply by the reciprocal and one
@@ -1069,7 +1075,7 @@ __device__ __forceinline__ int divmod_small(int a, int d, float inv, int* r) {
 // Tile = (64 KW) x (16 NW) of GW: wave w owns k rows [16 KW w, 16 KW (w+1)) and all NW column tiles.  Larger
 // tiles re-read X (N / TN times) and DY (K / TK times) less often -- at 64 x 64 the 304 x 256 decoder layer
 // pulls 2.7 GB through L2 for 0.6 GB of operands.  Loads are unconditional on clamped offsets, zeroed by select.
-template <int KW, int NW, bool GX = false>
+template <int KW, int NW, bool GX = false, bool BNA = false>
 __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradParams p) {
   constexpr int TK = 64 * KW, TN = 16 * NW;
   constexpr int XP = TK + 4, DP = TN + 4;      // pitches: rows 4 apart land 16 banks apart
@@ -1109,6 +1115,8 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradParams p) {
       if (p.scale) { xsc[i] = ld4(p.scale + ch); xsh[i] = ld4(p.shift + ch); }
     } else if (p.scale) { xsc[i] = ld4(p.scale + min(c, p.K - 4)); xsh[i] = ld4(p.shift + min(c, p.K - 4)); }
   }
+  // BNA: dz = bA * g * act'(z * bsc + bsh) - bC * z + bD per channel (bA = c0, bC = c0 * invstd * c2, bD = bC * mean - c0 * c1)
+  float4 bA[BNA ? ND : 1], bC[BNA ? ND : 1], bD[BNA ? ND : 1], bsc[BNA ? ND : 1], bsh[BNA ? ND : 1];
 #pragma unroll
   for (int i = 0; i < ND; ++i) {
     const int idx = min(t + 256 * i, 32 * DQ - 1);
@@ -1116,12 +1124,27 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradParams p) {
     const int c = n0 + (idx - dr[i] * DQ) * 4;
     dok[i] = (t + 256 * i < 32 * DQ) && c < p.N;
     dof[i] = (uint32_t)min(c, p.N - 4) * 4u;
+    if (BNA) {
+      const int cc = min(c, p.N - 4);
+      const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+      bsc[i] = p.b_scale ? ld4(p.b_scale + cc) : one;
+      bsh[i] = p.b_shift ? ld4(p.b_shift + cc) : zero4();
+      const float4 mu = ld4(p.b_mean + cc), is = ld4(p.b_invstd + cc);
+      const float4 c0 = ld4(p.b_coef + cc), c1 = ld4(p.b_coef + p.N + cc), c2 = ld4(p.b_coef + 2 * p.N + cc);
+      bA[i] = c0;
+      bC[i] = mul4(mul4(c0, is), c2);
+      bD[i] = make_float4(bC[i].x * mu.x - c0.x * c1.x, bC[i].y * mu.y - c0.y * c1.y, bC[i].z * mu.z - c0.z * c1.z,
+                          bC[i].w * mu.w - c0.w * c1.w);
+    }
   }
   const float act_lo = p.act == DL3P_ACT_NONE ? -DL3P_INF : 0.f;
   const float act_hi = (p.act == DL3P_ACT_NONE || p.act == DL3P_ACT_RELU) ? DL3P_INF : 6.f;
   const char* Xb = reinterpret_cast<const char*>(p.X);
   const char* Db = reinterpret_cast<const char*>(p.DY);
-  float4 rx[NX], rd[ND];
+  const char* Zb = reinterpret_cast<const char*>(p.Z);
+  char* DZb = reinterpret_cast<char*>(p.DZ);
+  const bool write_dz = BNA && p.DZ != nullptr && kt == 0;
+  float4 rx[NX], rd[ND], rz[BNA ? ND : 1];
   auto gather_x = [&](int m0_) {
     gx_ok = 0;
 #pragma unroll
@@ -1145,6 +1168,8 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradParams p) {
       rx[i] = *reinterpret_cast<const float4*>(Xb + ((uint32_t)min((m0_) + xr[i], m_end - 1) * (uint32_t)p.ldx * 4u + xo[i]));   \
     _Pragma("unroll") for (int i = 0; i < ND; ++i)                                                                    \
       rd[i] = *reinterpret_cast<const float4*>(Db + ((uint32_t)min((m0_) + dr[i], m_end - 1) * (uint32_t)p.lddy * 4u + dof[i])); \
+    if (BNA) _Pragma("unroll") for (int i = 0; i < ND; ++i)                                                           \
+      rz[i] = *reinterpret_cast<const float4*>(Zb + ((uint32_t)min((m0_) + dr[i], m_end - 1) * (uint32_t)p.ldz * 4u + dof[i])); \
   }
   f32x4 acc[KW][NW];
 #pragma unroll
@@ -1167,7 +1192,18 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradParams p) {
       const int idx = t + 256 * i;
       if (idx < 32 * DQ) {
         const bool ok = dok[i] && m0 + dr[i] < m_end;
-        *reinterpret_cast<float4*>(&Ds[dr[i] * DP + (idx - dr[i] * DQ) * 4]) = ok ? make_float4(rd[i].x, rd[i].y, rd[i].z, rd[i].w) : zero4();
+        float4 v = make_float4(rd[i].x, rd[i].y, rd[i].z, rd[i].w);
+        if (BNA) {
+          const float4 z = rz[i];
+          const float4 u = fma4(z, bsc[i], bsh[i]);
+          const int act = p.b_act;
+          v = make_float4(fmaf(bA[i].x, v.x * act_grad(u.x, act), fmaf(-bC[i].x, z.x, bD[i].x)),
+                          fmaf(bA[i].y, v.y * act_grad(u.y, act), fmaf(-bC[i].y, z.y, bD[i].y)),
+                          fmaf(bA[i].z, v.z * act_grad(u.z, act), fmaf(-bC[i].z, z.z, bD[i].z)),
+                          fmaf(bA[i].w, v.w * act_grad(u.w, act), fmaf(-bC[i].w, z.w, bD[i].w)));
+          if (write_dz && ok) st4(reinterpret_cast<float*>(DZb + ((uint32_t)(m0 + dr[i]) * (uint32_t)p.lddz * 4u + dof[i])), v);
+        }
+        *reinterpret_cast<float4*>(&Ds[dr[i] * DP + (idx - dr[i] * DQ) * 4]) = ok ? v : zero4();
       }
     }
     __syncthreads();
@@ -1215,21 +1251,36 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradParams p) {
 // No workgroup barrier in the loop -- the 16 waves of a CU drift apart and cover each other's latencies --
 // every input byte is read exactly once, and the next tile's loads are in flight during the MFMAs.
 // The four waves of a workgroup are summed through LDS at the end (fixed order), one slab per workgroup.
-template <int KT, int NTN>
+template <int KT, int NTN, bool BNA = false>
 __global__ __launch_bounds__(256, 2) void pw_wgrad_small_kernel(WgradParams p) {
   constexpr int KP = 16 * KT, NP = 16 * NTN;
   constexpr int XP = KP + 4, DP = NP + 4;          // pitches: rows 4 apart land 16 banks apart
   constexpr int WAVE_FLOATS = 16 * (XP + DP);
+  constexpr int CF = BNA ? 5 * NP : 0;             // BNA: per-channel bA, bC, bD, scale, shift of the folded BatchNorm apply
   extern __shared__ __attribute__((aligned(16))) float ws_lds[];
-  // layout: [scale KP][shift KP][4 waves x WAVE_FLOATS]; the end-of-kernel reduction reuses it from 0
+  // layout: [scale KP][shift KP][BNA: 5 x NP coefficients][4 waves x WAVE_FLOATS]; the end-of-kernel reduction reuses it from 0
   float* sc_s = ws_lds;
   float* sh_s = ws_lds + KP;
+  float* cf_s = ws_lds + 2 * KP;
   const int t = threadIdx.x, l = t & 63, w = t >> 6, l15 = l & 15, q = l >> 4;
-  float* Xs = ws_lds + 2 * KP + w * WAVE_FLOATS;
+  float* Xs = ws_lds + 2 * KP + CF + w * WAVE_FLOATS;
   float* Ds = Xs + 16 * XP;
   for (int i = t; i < KP; i += 256) {
     sc_s[i] = (p.scale && i < p.K) ? p.scale[i] : 1.f;
     sh_s[i] = (p.scale && i < p.K) ? p.shift[i] : 0.f;
+  }
+  if (BNA) {
+    // dz = bA * g * act'(z * scale + shift) - bC * z + bD  (bA = c0, bC = c0 * invstd * c2, bD = bC * mean - c0 * c1)
+    for (int i = t; i < NP; i += 256) {
+      const bool in = i < p.N;
+      const float c0 = in ? p.b_coef[i] : 0.f, c1 = in ? p.b_coef[p.N + i] : 0.f, c2 = in ? p.b_coef[2 * p.N + i] : 0.f;
+      const float bc = in ? c0 * p.b_invstd[i] * c2 : 0.f;
+      cf_s[i] = c0;
+      cf_s[NP + i] = bc;
+      cf_s[2 * NP + i] = in ? bc * p.b_mean[i] - c0 * c1 : 0.f;
+      cf_s[3 * NP + i] = (in && p.b_scale) ? p.b_scale[i] : 1.f;
+      cf_s[4 * NP + i] = (in && p.b_shift) ? p.b_shift[i] : 0.f;
+    }
   }
   // columns K..KP-1 / N..NP-1 of the wave's slices are never loaded: zero them once
   for (int i = l; i < 16 * XP; i += 64) Xs[i] = 0.f;
@@ -1240,7 +1291,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_small_kernel(WgradParams p) {
   const int nx = 4 * p.K, nd = 4 * p.N;            // float4 per 16-row tile
   // per-lane constants of the i-th load of a tile: row within the tile, LDS offset, global offset
   int xrow[KT], drow[NTN];
-  uint32_t xg[KT], dg[NTN];
+  uint32_t xg[KT], dg[NTN], zg[BNA ? NTN : 1], og[BNA ? NTN : 1];
   int xl[KT], dl[NTN];
 #pragma unroll
   for (int i = 0; i < KT; ++i) {
@@ -1257,6 +1308,10 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_small_kernel(WgradParams p) {
     drow[i] = (l + 64 * i < nd) ? r : 16;
     dl[i] = r * DP + c * 4;
     dg[i] = ((uint32_t)r * (uint32_t)p.lddy + (uint32_t)c * 4u) * 4u;
+    if (BNA) {
+      zg[i] = ((uint32_t)r * (uint32_t)p.ldz + (uint32_t)c * 4u) * 4u;
+      og[i] = ((uint32_t)r * (uint32_t)p.lddz + (uint32_t)c * 4u) * 4u;
+    }
   }
   const float act_lo = p.act == DL3P_ACT_NONE ? -DL3P_INF : 0.f;
   const float act_hi = (p.act == DL3P_ACT_NONE || p.act == DL3P_ACT_RELU) ? DL3P_INF : 6.f;
@@ -1272,7 +1327,9 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_small_kernel(WgradParams p) {
   const int gw = blockIdx.x * 4 + w;
   const char* Xb = reinterpret_cast<const char*>(p.X);
   const char* Db = reinterpret_cast<const char*>(p.DY);
-  float4 rx[KT], rd[NTN];
+  const char* Zb = reinterpret_cast<const char*>(p.Z);
+  char* Ob = reinterpret_cast<char*>(p.DZ);
+  float4 rx[KT], rd[NTN], rz[BNA ? NTN : 1];
   // (a macro, not a lambda: hipcc keeps a by-reference captured float4[] in scratch here)
 #define WS_PREFETCH(tile_)                                                                          \
   {                                                                                                 \
@@ -1283,6 +1340,10 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_small_kernel(WgradParams p) {
     const uint32_t db0 = (uint32_t)(pm0 - pback) * (uint32_t)p.lddy * 4u;                           \
     _Pragma("unroll") for (int i = 0; i < KT; ++i) rx[i] = *reinterpret_cast<const float4*>(Xb + (xb0 + xg[i]));   \
     _Pragma("unroll") for (int i = 0; i < NTN; ++i) rd[i] = *reinterpret_cast<const float4*>(Db + (db0 + dg[i]));  \
+    if (BNA) {                                                                                      \
+      const uint32_t zb0 = (uint32_t)(pm0 - pback) * (uint32_t)p.ldz * 4u;                          \
+      _Pragma("unroll") for (int i = 0; i < NTN; ++i) rz[i] = *reinterpret_cast<const float4*>(Zb + (zb0 + zg[i])); \
+    }                                                                                               \
   }
   WS_PREFETCH(min(gw, ntiles - 1))
   for (int tile = gw; tile < ntiles; tile += nwaves) {
@@ -1303,7 +1364,28 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_small_kernel(WgradParams p) {
     }
 #pragma unroll
     for (int i = 0; i < NTN; ++i)
-      if (drow[i] < 16) *reinterpret_cast<float4*>(&Ds[dl[i]]) = make_float4(rd[i].x, rd[i].y, rd[i].z, rd[i].w);
+      if (drow[i] < 16) {
+        float4 v = make_float4(rd[i].x, rd[i].y, rd[i].z, rd[i].w);
+        if (BNA) {
+          const int cf = dl[i] - drow[i] * DP;       // channel of this float4
+          const float4 a4 = *reinterpret_cast<const float4*>(&cf_s[cf]);
+          const float4 c4 = *reinterpret_cast<const float4*>(&cf_s[NP + cf]);
+          const float4 d4 = *reinterpret_cast<const float4*>(&cf_s[2 * NP + cf]);
+          const float4 s4 = *reinterpret_cast<const float4*>(&cf_s[3 * NP + cf]);
+          const float4 h4 = *reinterpret_cast<const float4*>(&cf_s[4 * NP + cf]);
+          const float4 z = rz[i];
+          const float4 u = fma4(z, s4, h4);
+          const int act = p.b_act;
+          v = make_float4(fmaf(a4.x, v.x * act_grad(u.x, act), fmaf(-c4.x, z.x, d4.x)),
+                          fmaf(a4.y, v.y * act_grad(u.y, act), fmaf(-c4.y, z.y, d4.y)),
+                          fmaf(a4.z, v.z * act_grad(u.z, act), fmaf(-c4.z, z.z, d4.z)),
+                          fmaf(a4.w, v.w * act_grad(u.w, act), fmaf(-c4.w, z.w, d4.w)));
+          // (rows [0, back) of a shifted last tile were written by the tile before it)
+          if (p.DZ && drow[i] >= back)
+            st4(reinterpret_cast<float*>(Ob + ((uint32_t)(m0 - back) * (uint32_t)p.lddz * 4u + og[i])), v);
+        }
+        *reinterpret_cast<float4*>(&Ds[dl[i]]) = v;
+      }
     WS_PREFETCH(min(tile + nwaves, ntiles - 1))   // unconditional (the last one is a harmless re-read)
     // fragments: reduction index m = 4q + j; lane l15 = channel within the 16-wide tile
     float b[NTN][4];
@@ -1350,9 +1432,9 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_small_kernel(WgradParams p) {
   }
 }
 
-template <int KT, int NTN>
+template <int KT, int NTN, bool BNA = false>
 static constexpr size_t wgrad_small_lds() {
-  constexpr size_t stage = sizeof(float) * (size_t)(2 * 16 * KT + 4 * 16 * (16 * KT + 4 + 16 * NTN + 4));
+  constexpr size_t stage = sizeof(float) * (size_t)(2 * 16 * KT + (BNA ? 5 * 16 * NTN : 0) + 4 * 16 * (16 * KT + 4 + 16 * NTN + 4));
   constexpr size_t red = 16 * (size_t)(3 * KT * NTN * 64);
   return stage > red ? stage : red;
 }
@@ -1372,15 +1454,15 @@ static int wgrad_small_grid(int M, int KT, int NTN) {
   return g;
 }
 
-template <int KT, int NTN>
+template <int KT, int NTN, bool BNA = false>
 static void launch_wgrad_small(const WgradParams& p, int grid, hipStream_t st) {
-  constexpr size_t lds = wgrad_small_lds<KT, NTN>();
+  constexpr size_t lds = wgrad_small_lds<KT, NTN, BNA>();
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)pw_wgrad_small_kernel<KT, NTN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)pw_wgrad_small_kernel<KT, NTN, BNA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  dl3p_launch(pw_wgrad_small_kernel<KT, NTN>, dim3(grid), dim3(256), lds, st, p);
+  dl3p_launch(pw_wgrad_small_kernel<KT, NTN, BNA>, dim3(grid), dim3(256), lds, st, p);
 }
 
 // the (KT, NTN) instantiations: kernels of the 513x513 MobileNetV2 / V3 / Xception graphs at OS 2-8
@@ -1398,8 +1480,9 @@ static bool wgrad_small_pick(int K, int N, SmallShape* out) {
   return true;
 }
 
+template <bool BNA = false>
 static void launch_wgrad_small_any(const WgradParams& p, SmallShape sh, int grid, hipStream_t st) {
-#define DL3P_WS(a, b) if (sh.kt == a && sh.ntn == b) { launch_wgrad_small<a, b>(p, grid, st); return; }
+#define DL3P_WS(a, b) if (sh.kt == a && sh.ntn == b) { launch_wgrad_small<a, b, BNA>(p, grid, st); return; }
   DL3P_WS(1, 2) DL3P_WS(2, 1) DL3P_WS(2, 2) DL3P_WS(1, 6) DL3P_WS(2, 3) DL3P_WS(2, 4) DL3P_WS(4, 2) DL3P_WS(6, 2)
   DL3P_WS(2, 6) DL3P_WS(2, 9) DL3P_WS(9, 2) DL3P_WS(2, 12) DL3P_WS(12, 2) DL3P_WS(4, 4)
 #undef DL3P_WS
@@ -1446,15 +1529,15 @@ static void wgrad_split(int M, int K, int N, int* ktiles, int* ntiles, int* spli
   *mchunk = chunk;
 }
 
-template <bool GX = false>
+template <bool GX = false, bool BNA = false>
 static void launch_wgrad_tiled(const WgradParams& p, int splits, hipStream_t st) {
   int kw, nw;
   wgrad_pick_tile(p.M, p.K, p.N, &kw, &nw);
   const dim3 grid(p.ktiles * p.ntiles, splits), block(256);
-  if (kw == 1 && nw == 4) dl3p_launch(pw_wgrad_kernel<1, 4, GX>, grid, block, 0, st, p);
-  else if (kw == 2 && nw == 4) dl3p_launch(pw_wgrad_kernel<2, 4, GX>, grid, block, 0, st, p);
-  else if (kw == 1 && nw == 8) dl3p_launch(pw_wgrad_kernel<1, 8, GX>, grid, block, 0, st, p);
-  else dl3p_launch(pw_wgrad_kernel<2, 8, GX>, grid, block, 0, st, p);
+  if (kw == 1 && nw == 4) dl3p_launch(pw_wgrad_kernel<1, 4, GX, BNA>, grid, block, 0, st, p);
+  else if (kw == 2 && nw == 4) dl3p_launch(pw_wgrad_kernel<2, 4, GX, BNA>, grid, block, 0, st, p);
+  else if (kw == 1 && nw == 8) dl3p_launch(pw_wgrad_kernel<1, 8, GX, BNA>, grid, block, 0, st, p);
+  else dl3p_launch(pw_wgrad_kernel<2, 8, GX, BNA>, grid, block, 0, st, p);
 }
 
 // column sums of dy (bias gradient): one partial row per workgroup
@@ -1550,6 +1633,73 @@ extern "C" int dl3p_pwconv_bwd_weight_slabs(const float* x, int ldx, const float
   DL3P_CHECK_ARG(rows_out != nullptr, "dl3p_pwconv_bwd_weight_slabs: rows_out is required");
   return pwconv_bwd_weight_impl(x, ldx, in_scale, in_shift, in_act, dy, lddy, nullptr, nullptr, workspace, workspace_bytes, M, K,
                                 N, rows_out, stream);
+}
+
+
+// Weight gradient of a conv whose output z goes through BatchNorm (+ activation), with that BatchNorm's backward apply
+// folded in: `g` is the gradient of act(BN(z)), `coef` what dl3p_bn_bwd_finalize left.  The kernel forms dz while it stages
+// its tiles, multiplies with it, and (dz != nullptr) writes it for the data gradient that follows -- dz must not alias g.
+// Served where the kernel reads the gradient operand ONCE: the streaming kernels of the few-channel layers (every wave
+// owns the whole K x N gradient) and tiled launches with a single k tile.  With several k tiles every one of them would
+// re-form dz from two operands instead of reading one: measured 46 % slower per launch on the 17424 x 64..960 layers
+// and a net loss per step (14.64 against 14.32 ms), so those shapes keep dl3p_bn_bwd_apply.
+static int wgrad_bn_route(int M, int K, int N) {      // 0: not served, 1: streaming kernel, 2: tiled kernel, one k tile
+  SmallShape sh;
+  if (M <= 64 || dl3p_pw_tiny_applies(M) || N % 4 || K % 4) return 0;
+  if (M >= 16 && wgrad_small_pick(K, N, &sh)) return (sh.kt == 2 && sh.ntn == 12) ? 0 : 1;   // (2, 12) + the fold spills
+  int kw, nw;
+  wgrad_pick_tile(M, K, N, &kw, &nw);
+  return (K <= 64 * kw && !(kw == 2 && nw == 8)) ? 2 : 0;      // (the 128 x 128 tile has no registers left for the fold)
+}
+
+extern "C" int dl3p_pwconv_bwd_weight_bn_supported(int M, int K, int N) { return wgrad_bn_route(M, K, N) != 0; }
+
+extern "C" int dl3p_pwconv_bwd_weight_slabs_bn(const float* x, int ldx, const float* in_scale, const float* in_shift,
+                                               int in_act, const float* g, int ldg, const float* z, int ldz,
+                                               const float* bn_scale, const float* bn_shift, int bn_act,
+                                               const float* save_mean, const float* save_invstd, const float* coef,
+                                               float* dz, int lddz, float* workspace, size_t workspace_bytes,
+                                               int* rows_out, int M, int K, int N, void* stream) {
+  const char* fn = "dl3p_pwconv_bwd_weight_slabs_bn";
+  int rc = check_mat(fn, x, ldx, K);
+  if (rc) return rc;
+  rc = check_mat(fn, g, ldg, N);
+  if (rc) return rc;
+  rc = check_mat(fn, z, ldz, N);
+  if (rc) return rc;
+  if (dz) {
+    rc = check_mat(fn, dz, lddz, N);
+    if (rc) return rc;
+  }
+  DL3P_CHECK_ARG(rows_out && workspace && aligned16(workspace) && save_mean && save_invstd && coef && dz != g,
+                 "%s: bad arguments", fn);
+  DL3P_CHECK_ARG(dl3p_pwconv_bwd_weight_bn_supported(M, K, N), "%s: shape M=%d K=%d N=%d is not served by the tiled kernel", fn,
+                 M, K, N);
+  const int ldmax = ldx > ldg ? (ldx > ldz ? ldx : ldz) : (ldg > ldz ? ldg : ldz);
+  DL3P_CHECK_ARG((unsigned long long)M * (unsigned long long)(ldmax > lddz ? ldmax : lddz) * 4ull < (1ull << 32),
+                 "%s: operands of 4 GiB or more are not supported (M=%d)", fn, M);
+  const size_t need = dl3p_pwconv_bwd_weight_workspace(M, K, N);
+  if (workspace_bytes < need) {
+    dl3p_set_error("%s: workspace %zu < %zu bytes", fn, workspace_bytes, need);
+    return DL3P_EWORKSPACE;
+  }
+  WgradParams p = {};
+  p.X = x; p.ldx = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act;
+  p.DY = g; p.lddy = ldg; p.slabs = workspace; p.M = M; p.K = K; p.N = N;
+  p.Z = z; p.ldz = ldz; p.b_scale = bn_scale; p.b_shift = bn_shift; p.b_mean = save_mean; p.b_invstd = save_invstd;
+  p.b_coef = coef; p.b_act = bn_act; p.DZ = dz; p.lddz = lddz;
+  int splits;
+  SmallShape sh;
+  if (wgrad_bn_route(M, K, N) == 1 && wgrad_small_pick(K, N, &sh)) {
+    splits = wgrad_small_grid(M, sh.kt, sh.ntn);
+    launch_wgrad_small_any<true>(p, sh, splits, (hipStream_t)stream);
+  } else {
+    wgrad_split(M, K, N, &p.ktiles, &p.ntiles, &splits, &p.mchunk);
+    launch_wgrad_tiled<false, true>(p, splits, (hipStream_t)stream);
+  }
+  DL3P_CHECK_LAUNCH(fn);
+  *rows_out = splits;
+  return DL3P_OK;
 }
 
 

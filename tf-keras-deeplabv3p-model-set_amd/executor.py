@@ -817,6 +817,12 @@ class Executor:
         # backward on one GPU, per gradient bucket under data parallelism (in front of the bucket's all-reduce).  Same
         # per-element arithmetic as the per-layer reduction, whichever way the jobs are grouped.
         batch = os.environ.get('DL3P_BATCHED_WGRAD', '1') != '0'
+        self._batch_wgrad = batch and not defer
+        if self._batch_wgrad and not self.bf16 and getattr(self, 'dz_scratch', None) is None:
+            need = max([N * op.Ho * op.Wo * (op.cout if op.kind == 'conv_pw' else op.c) for op in self.g.ops
+                        if op.kind in ('conv_pw', 'conv_dw')] or [0])
+            self.dz_scratch = torch.zeros(need + 64, **self.f32)      # dz of the layer whose weight gradient just ran
+        self._folded = {}                 # z tensor id -> BatchNorm-backward apply arguments taken over by the conv's wgrad
         jobs = self._jobs = []            # (slab pointer, destination pointer, rows, n) issued and not yet reduced
         self._wgrad_tables = []
         slab_off = [0]
@@ -886,9 +892,21 @@ class Executor:
                 if op.layer.trainable and batch and self._slab_bytes(op):
                     gw = st.ptr(op.w, G)
                     nb = self._slab_bytes(op)
-                    if k == 'conv_pw':
+                    if k == 'conv_pw' and out.id in self._folded:
+                        fg, fldg, fz, fldz, fsp, fhp, fact, fmean, finv, fcoef = self._folded.pop(out.id)
+                        dz, lddz = (self.dz_scratch.data_ptr(), op.cout) if need_gx else (None, 0)
+                        wgrad_slabs(L.pwconv_bwd_weight_slabs_bn, op.cin * op.cout, gw, nb,
+                                    (xp, ldx, sp, hp, act, fg, fldg, fz, fldz, fsp, fhp, fact, fmean, finv, fcoef, dz, lddz),
+                                    (N * op.Ho * op.Wo, op.cin, op.cout))
+                    elif k == 'conv_pw':
                         wgrad_slabs(L.pwconv_bwd_weight_slabs, op.cin * op.cout, gw, nb, (xp, ldx, sp, hp, act, dz, lddz),
                                     (N * op.Ho * op.Wo, op.cin, op.cout))
+                    elif k == 'conv_dw' and out.id in self._folded:
+                        fg, fldg, fz, fldz, fsp, fhp, fact, fmean, finv, fcoef = self._folded.pop(out.id)
+                        dz, lddz = (self.dz_scratch.data_ptr(), op.c) if need_gx else (None, 0)
+                        wgrad_slabs(L.dwconv2d_bwd_weight_slabs_bn, op.k * op.k * op.c, gw, nb,
+                                    (xp, ldx, sp, hp, act, fg, fldg, fz, fldz, fsp, fhp, fact, fmean, finv, fcoef, dz, lddz),
+                                    (N, xt.H, xt.W, op.c, op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo))
                     elif k == 'conv_dw':
                         wgrad_slabs(L.dwconv2d_bwd_weight_slabs, op.k * op.k * op.c, gw, nb, (xp, ldx, sp, hp, act, dz, lddz),
                                     (N, xt.H, xt.W, op.c, op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo))
@@ -1142,8 +1160,33 @@ class Executor:
                 P.k(L.bn_reduce_partials, self.partials.data_ptr(), rows.value, 2 * bn.C, self.sync_stage[off:].data_ptr())
                 self._bwd_pending.append((op, off, P.ctx))
                 return
+        if not frozen and self._folds_apply(op):
+            # the conv that produced z forms dz inside its weight-gradient kernel and hands it to its data gradient
+            self._folded[z.id] = (g, ldg, zp, ldz, sp, hp, bn.act, mean, invstd, coef)
+            return
         P.k(L.bn_bwd_apply_bf16 if self.bf16 else L.bn_bwd_apply, g, ldg, zp, ldz, sp, hp, bn.act, mean, invstd, coef, g, ldg,
             0, M, bn.C)
+
+    def _folds_apply(self, bn_op):
+        """BatchNorm-backward apply folded into the weight gradient of the pointwise conv that produced z (fp32, local
+        statistics, weight gradient issued in line in front of the data gradient)"""
+        conv = getattr(bn_op, 'producer', None)
+        if (self.bf16 or self.sync_bn or self.dist is not None or conv is None or conv.kind not in ('conv_pw', 'conv_dw')
+                or conv.out is not bn_op.z or not conv.layer.trainable or not getattr(self, '_batch_wgrad', False)
+                or os.environ.get('DL3P_FOLD_APPLY', '1') == '0' or not self._slab_bytes(conv)):
+            return False
+        M = self.N * conv.Ho * conv.Wo
+        if conv.kind == 'conv_dw':
+            # measured on MI355X: the depthwise window kernel with the fold takes as much longer as the apply pass it
+            # replaces took (MobileNetV2 step 14.12 ms against 14.05 with the pointwise folds alone, 14.25 without any)
+            if os.environ.get('DL3P_FOLD_APPLY', '1') != '2':       # 2: depthwise convs too
+                return False
+            xt = conv.x.tensor
+            return bool(self.L.dwconv2d_bwd_weight_bn_supported(self.N, xt.H, xt.W, conv.c, conv.k, conv.stride, conv.rate,
+                                                                conv.pad_t, conv.pad_l, conv.Ho, conv.Wo))
+        if M * max(conv.x.tensor.ld, bn_op.z.ld, conv.cout) * 4 >= 2 ** 32:
+            return False
+        return bool(self.L.pwconv_bwd_weight_bn_supported(M, conv.cin, conv.cout))
 
     def _bn_readers(self):
         """{'bn' op: set of ops that read the BatchNorm's output} (a Concatenate's consumer reads every branch)"""

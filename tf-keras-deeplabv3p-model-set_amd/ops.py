@@ -122,6 +122,29 @@ def dwconv2d_bwd_weight(x, dy, k, stride=1, rate=1, padding='same', in_scale=Non
     return gw
 
 
+def dwconv2d_bwd_weight_bn(x, g, z, bn, act, k, stride=1, rate=1, padding='same', in_scale=None, in_shift=None,
+                           in_act=ACT_NONE, want_dz=True):
+    """depthwise weight gradient with the BatchNorm-backward apply of the conv's output folded in
+    (dl3p_dwconv2d_bwd_weight_slabs_bn + the slab reduction) -> (gw, dz)"""
+    N, H, W, C = x.shape
+    Ho, Wo, pt, pl = conv_geometry(H, W, k, stride, rate, padding)
+    need = lib().dwconv2d_bwd_weight_workspace(N, Ho, Wo, C, k)
+    ws = torch.empty(need // 4, dtype=torch.float32, device=x.device)
+    gw = torch.empty((k, k, C), dtype=torch.float32, device=x.device)
+    dz = torch.empty(g.shape, dtype=torch.float32, device=x.device) if want_dz else None
+    xp, ldx = _pl(x)
+    gp, ldg = _pl(g)
+    zp, ldz = _pl(z)
+    dp, ldd = _pl(dz)
+    rows = ctypes.c_int(0)
+    lib().dwconv2d_bwd_weight_slabs_bn(xp, ldx, _p(in_scale), _p(in_shift), in_act, gp, ldg, zp, ldz, _p(bn.scale),
+                                       _p(bn.shift), act, _p(bn.mean), _p(bn.invstd), _p(bn.coef), dp, ldd or 0, _p(ws),
+                                       ws.numel() * 4, ctypes.byref(rows), N, H, W, C, k, stride, rate, pt, pl, Ho, Wo,
+                                       _stream())
+    lib().reduce_rows(_p(ws), rows.value, k * k * C, _p(gw), 0, _stream())
+    return gw, dz
+
+
 # ------------------------------------------------------------------------------------- pointwise
 def _rows(t):
     return t.numel() // t.shape[-1]
@@ -193,6 +216,27 @@ def pwconv_bwd_weight(x, dy, in_scale=None, in_shift=None, in_act=ACT_NONE, with
     lib().pwconv_bwd_weight(xp, ldx, _p(in_scale), _p(in_shift), in_act, dp, ldd, _p(gw), _p(gb), _p(ws),
                             ws.numel() * 4, M, K, Nn, _stream())
     return (gw, gb) if with_bias else gw
+
+
+def pwconv_bwd_weight_bn(x, g, z, bn, act, in_scale=None, in_shift=None, in_act=ACT_NONE, want_dz=True):
+    """weight gradient with the BatchNorm-backward apply of the conv's output folded in (dl3p_pwconv_bwd_weight_slabs_bn
+    + the slab reduction): g = gradient of act(bn(z)), bn.coef from bn_bwd_finalize -> (gw, dz)"""
+    K, Nn = x.shape[-1], g.shape[-1]
+    M = _rows(x)
+    need = lib().pwconv_bwd_weight_workspace(M, K, Nn)
+    ws = torch.empty(need // 4, dtype=torch.float32, device=x.device)
+    gw = torch.empty((K, Nn), dtype=torch.float32, device=x.device)
+    dz = torch.empty(g.shape, dtype=torch.float32, device=x.device) if want_dz else None
+    xp, ldx = _pl(x)
+    gp, ldg = _pl(g)
+    zp, ldz = _pl(z)
+    dp, ldd = _pl(dz)
+    rows = ctypes.c_int(0)
+    lib().pwconv_bwd_weight_slabs_bn(xp, ldx, _p(in_scale), _p(in_shift), in_act, gp, ldg, zp, ldz, _p(bn.scale), _p(bn.shift),
+                                     act, _p(bn.mean), _p(bn.invstd), _p(bn.coef), dp, ldd or 0, _p(ws), ws.numel() * 4,
+                                     ctypes.byref(rows), M, K, Nn, _stream())
+    lib().reduce_rows(_p(ws), rows.value, K * Nn, _p(gw), 0, _stream())
+    return gw, dz
 
 
 # ------------------------------------------------------------------------------------- dense conv
