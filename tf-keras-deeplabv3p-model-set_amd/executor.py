@@ -803,7 +803,10 @@ class Executor:
         bn_done = set()
         self._bwd_pending, self._bwd_stage_off = [], self._sync_total
         processed = set()
-        readers = self._bn_readers() if self.sync_bn else {}
+        readers = self._bn_readers()
+        bn_of = {id(o.z): o for o in self.g.ops if o.kind == 'bn'}
+        self._galias = {}                 # z tensor id -> (ptr, ld) of the buffer that already holds d/d(BN(z) output)
+        alias_ok = (not self.sync_bn and os.environ.get('DL3P_GRAD_ALIAS', '1') != '0')
         rops = list(reversed(self.g.ops))
 
         def wgrad(fn, *args):
@@ -989,13 +992,38 @@ class Executor:
                 gt, ldt = self.tptr(out, True), out.ld
                 M = N * out.H * out.W
                 if op.x.tensor.requires_grad or op.x.tensor.root.requires_grad:
-                    gp, ldg, keyt = self._gbuf(op.x)
-                    P.k(L.scale_mask_bwd_bf16 if self.bf16 else L.scale_mask_bwd, gt, ldt, float(op.rate), self._dropout_seed(op),
-                        self.step.data_ptr(), gp, ldg, self._acc(keyt), M, out.C)
+                    xb = bn_of.get(id(op.x.tensor)) if op.x.bn is not None else None
+                    if (alias_ok and xb is not None and float(op.rate) == 0.0 and getattr(op.x, 'view_grad', None) is None
+                            and op.x.tensor.C == out.C and readers.get(xb) == {op} and op.x.tensor.id not in self._written
+                            and (op.x.tensor.base is None or op.x.tensor.base.id not in self._written)):
+                        # a residual Add hands its gradient to the BatchNorm branch unchanged: that BatchNorm's backward
+                        # reads it where it is (no copy into the branch's own buffer, one launch less per Add)
+                        self._galias[op.x.tensor.id] = (gt, ldt)
+                        self._written.add(op.x.tensor.id)
+                    else:
+                        gp, ldg, keyt = self._gbuf(op.x)
+                        P.k(L.scale_mask_bwd_bf16 if self.bf16 else L.scale_mask_bwd, gt, ldt, float(op.rate),
+                            self._dropout_seed(op), self.step.data_ptr(), gp, ldg, self._acc(keyt), M, out.C)
                 if op.r is not None and (op.r.tensor.requires_grad or op.r.tensor.root.requires_grad):
-                    gp, ldg, keyt = self._gbuf(op.r)
-                    P.k(L.scale_mask_bwd_bf16 if self.bf16 else L.scale_mask_bwd, gt, ldt, 0.0, 0, None, gp, ldg,
-                        self._acc(keyt), M, out.C)
+                    rt = op.r.tensor
+                    rb = bn_of.get(id(rt)) if op.r.bn is not None else None
+                    fresh = (alias_ok and getattr(op.r, 'view_grad', None) is None and rt.C == out.C
+                             and rt.id not in self._written and (rt.base is None or rt.base.id not in self._written))
+                    if fresh and rb is not None and readers.get(rb) == {op}:
+                        self._galias[rt.id] = (gt, ldt)        # the other branch is a BatchNorm too (Xception shortcut)
+                        self._written.add(rt.id)
+                    elif (fresh and op.r.is_plain and rt.base is None and out.base is None and rt.ld == out.ld
+                          and rt.id in self.grad and out.id in self.grad
+                          and self.grad[rt.id].numel() == self.grad[out.id].numel()):
+                        # the identity branch: d/d(r) starts as d/d(out) and only ever gains contributions that are issued
+                        # after every reader of d/d(out) (the producer of r precedes this Add's other branch): the two
+                        # gradients share one buffer from here on, no copy
+                        self.grad[rt.id] = self.grad[out.id]
+                        self._written.add(rt.id)
+                    else:
+                        gp, ldg, keyt = self._gbuf(op.r)
+                        P.k(L.scale_mask_bwd_bf16 if self.bf16 else L.scale_mask_bwd, gt, ldt, 0.0, 0, None, gp, ldg,
+                            self._acc(keyt), M, out.C)
             elif k == 'se_mul':
                 xp, ldx, sp, hp, act = self.vargs(op.x)
                 s_ptr, lds, _, _, sact = self.vargs(op.s)
@@ -1137,6 +1165,9 @@ class Executor:
         sp = self.gscale[bn.group.id].data_ptr() + 4 * bn.offset
         hp = self.gshift[bn.group.id].data_ptr() + 4 * bn.offset
         g, ldg = self.tptr(z, True), z.ld
+        dzo, lddzo = g, ldg                 # where dz goes (g itself unless the gradient is read from another buffer)
+        if z.id in getattr(self, '_galias', {}):
+            g, ldg = self._galias.pop(z.id)
         zp, ldz = self.tptr(z), z.ld
         mean, invstd, coef = aux['mean'].data_ptr(), aux['invstd'].data_ptr(), aux['coef'].data_ptr()
         frozen = not bn.layer.trainable
@@ -1164,8 +1195,8 @@ class Executor:
             # the conv that produced z forms dz inside its weight-gradient kernel and hands it to its data gradient
             self._folded[z.id] = (g, ldg, zp, ldz, sp, hp, bn.act, mean, invstd, coef)
             return
-        P.k(L.bn_bwd_apply_bf16 if self.bf16 else L.bn_bwd_apply, g, ldg, zp, ldz, sp, hp, bn.act, mean, invstd, coef, g, ldg,
-            0, M, bn.C)
+        P.k(L.bn_bwd_apply_bf16 if self.bf16 else L.bn_bwd_apply, g, ldg, zp, ldz, sp, hp, bn.act, mean, invstd, coef, dzo,
+            lddzo, 0, M, bn.C)
 
     def _folds_apply(self, bn_op):
         """BatchNorm-backward apply folded into the weight gradient of the pointwise conv that produced z (fp32, local
