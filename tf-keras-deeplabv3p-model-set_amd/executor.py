@@ -390,6 +390,7 @@ class Executor:
                                    sums=torch.zeros(2 * bn.C, dtype=torch.float64, device=self.dev))
             cmax = max(cmax, bn.C)
         self.partials = torch.zeros(MAX_ROWS * 2 * cmax, **self.f32)
+        self.partials2 = torch.zeros(MAX_ROWS * 2 * cmax, **self.f32) if self.training else None   # sums that wait (_presums)
         # SyncBatchNorm: the (sum, sum^2) / (sum dy, sum dy xhat) vectors of BatchNorms whose statistics are needed at the
         # same point of the graph travel in ONE all-reduce.  Slices of this buffer are handed out in trace order, so the
         # BatchNorms waiting for a flush are contiguous (forward and backward use separate halves).
@@ -807,6 +808,10 @@ class Executor:
         bn_of = {id(o.z): o for o in self.g.ops if o.kind == 'bn'}
         self._galias = {}                 # z tensor id -> (ptr, ld) of the buffer that already holds d/d(BN(z) output)
         alias_ok = (not self.sync_bn and os.environ.get('DL3P_GRAD_ALIAS', '1') != '0')
+        # BatchNorm -> residual Add -> pointwise conv: the conv's data gradient is the last writer of d/d(Add output), which
+        # IS the gradient of the BatchNorm output, so it carries that BatchNorm's backward sums too (no bn_bwd_reduce pass)
+        fuse_add = self._bn_fusion_through_adds(readers) if (alias_ok and not self.bf16) else {}
+        self._presums = {}                # 'bn' op -> partial rows left in self.partials2 by such a data gradient
         rops = list(reversed(self.g.ops))
 
         def wgrad(fn, *args):
@@ -956,6 +961,17 @@ class Executor:
                         self._bn_backward(P, bn_op, fused_rows=rows.value)
                         P.ctx = ctx
                         bn_done.add(bn_op)
+                    elif k == 'conv_pw' and op in fuse_add and fuse_add[op].z.requires_grad:
+                        bn_op = fuse_add[op]
+                        bn = bn_op.bn
+                        aux = self.bn_aux[bn]
+                        rows = ctypes.c_int(0)
+                        P.k(L.pwconv_bwd_data_bn, dz, lddz, st.ptr(op.w), gp, ldg, acc, N * op.Ho * op.Wo, op.cin,
+                            op.cout, self.tptr(bn_op.z), bn_op.z.ld,
+                            self.gscale[bn.group.id].data_ptr() + 4 * bn.offset,
+                            self.gshift[bn.group.id].data_ptr() + 4 * bn.offset, bn.act, aux['mean'].data_ptr(),
+                            aux['invstd'].data_ptr(), self.partials2.data_ptr(), ctypes.byref(rows))
+                        self._presums[bn_op] = rows.value
                     elif k == 'conv_pw':
                         P.k(L.pwconv_bwd_data, dz, lddz, st.ptr(op.w), gp, ldg, acc, N * op.Ho * op.Wo, op.cin,
                             op.cout)
@@ -1133,6 +1149,35 @@ class Executor:
                 fuse[op] = bn_ops[bn]
         return fuse
 
+    def _bn_fusion_through_adds(self, readers):
+        """{pointwise conv op: 'bn' op} for BatchNorm -> Add (BatchNorm branch + another branch, no dropout) -> conv, where the
+        conv is the FIRST consumer of the Add's output in graph order (so its data gradient is issued last in backward and
+        completes d/d(Add output) = d/d(BatchNorm output)), reads it plain, and the Add is the BatchNorm's only reader"""
+        if os.environ.get('DL3P_FUSE_BN_BWD', '1') == '0':
+            return {}
+        bn_of = {id(o.z): o for o in self.g.ops if o.kind == 'bn'}
+        first = {}                        # tensor id -> first op (graph order) that reads it
+        for op in self.g.ops:
+            for slot in ('x', 'r', 's'):
+                v = getattr(op, slot, None)
+                if v is not None:
+                    first.setdefault(v.tensor.id, op)
+                    if v.tensor.base is not None:
+                        first.setdefault(v.tensor.base.id, op)
+        out = {}
+        for add in self.g.ops:
+            if add.kind != 'materialize' or add.r is None or float(add.rate) != 0.0 or add.x.bn is None:
+                continue
+            bn_op = bn_of.get(id(add.x.tensor))
+            if (bn_op is None or not bn_op.bn.layer.trainable or readers.get(bn_op) != {add} or add.out.base is not None
+                    or getattr(add.x, 'view_grad', None) is not None or add.x.tensor.C != add.out.C):
+                continue
+            conv = first.get(add.out.id)
+            if (conv is not None and conv.kind == 'conv_pw' and conv.x.tensor is add.out and conv.x.is_plain
+                    and getattr(conv.x, 'view_grad', None) is None and conv not in out):
+                out[conv] = bn_op
+        return out
+
     def _flush_deferred(self, P):
         ctx = P.ctx
         for fn, args, c in self._deferred:
@@ -1175,11 +1220,14 @@ class Executor:
         if frozen:
             P.k(L.bn_bwd_finalize, None, 0, None, bn.C, float(M), st.ptr(lp['gamma']), invstd, sp, 1, None, None, coef)
         else:
+            part = self.partials.data_ptr()
+            if fused_rows is None and op in getattr(self, '_presums', {}):
+                fused_rows, part = self._presums.pop(op), self.partials2.data_ptr()
             rows = ctypes.c_int(fused_rows or 0)
-            if fused_rows is None:      # (otherwise the producer of g already left the partial sums in self.partials)
+            if fused_rows is None:      # (otherwise the producer of g already left the partial sums)
                 P.k(L.bn_bwd_reduce_bf16 if self.bf16 else L.bn_bwd_reduce, g, ldg, zp, ldz, sp, hp, bn.act, mean, invstd,
-                    self.partials.data_ptr(), ctypes.byref(rows), M, bn.C)
-            P.k(L.bn_bwd_finalize, self.partials.data_ptr(), rows.value, None, bn.C, float(M), st.ptr(lp['gamma']),
+                    part, ctypes.byref(rows), M, bn.C)
+            P.k(L.bn_bwd_finalize, part, rows.value, None, bn.C, float(M), st.ptr(lp['gamma']),
                 invstd, sp, 0, st.ptr(lp['gamma'], G), st.ptr(lp['beta'], G), coef)
             if self.sync_bn:
                 # parameter gradients stay local (they are averaged with every other gradient); the normalisation terms
