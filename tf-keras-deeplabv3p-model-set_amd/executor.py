@@ -1028,7 +1028,7 @@ class Executor:
                     if fresh and rb is not None and readers.get(rb) == {op}:
                         self._galias[rt.id] = (gt, ldt)        # the other branch is a BatchNorm too (Xception shortcut)
                         self._written.add(rt.id)
-                    elif (fresh and op.r.is_plain and rt.base is None and out.base is None and rt.ld == out.ld
+                    elif (fresh and (op.r.is_plain or rb is not None) and rt.base is None and out.base is None and rt.ld == out.ld
                           and rt.id in self.grad and out.id in self.grad
                           and self.grad[rt.id].numel() == self.grad[out.id].numel()):
                         # the identity branch: d/d(r) starts as d/d(out) and only ever gains contributions that are issued
@@ -1127,8 +1127,8 @@ class Executor:
             raise NotImplementedError('data gradient of a dense k x k conv is not built for the bf16 path (only RGB stems)')
 
     def _bn_fusion_map(self):
-        """{consumer conv op: 'bn' op} for every trainable BatchNorm whose output value has exactly ONE consumer and that
-        consumer is a pointwise or depthwise conv: its data-gradient kernel is then the only (= last) writer of the gradient
+        """{consumer conv op: 'bn' op} for every trainable BatchNorm whose output value is read FIRST (in graph order) by a
+        pointwise or depthwise conv: its data-gradient kernel is then the last writer of the gradient
         of the BN output and emits the BN-backward partial sums itself (dl3p_pwconv_bwd_data_bn / dl3p_dwconv2d_bwd_data_bn); the BN's
         finalize + apply are issued right behind it and the separate reduce pass over (g, z) disappears."""
         if os.environ.get('DL3P_FUSE_BN_BWD', '1') == '0':
@@ -1142,10 +1142,16 @@ class Executor:
         bn_ops = {op.bn: op for op in self.g.ops if op.kind == 'bn'}
         fuse = {}
         for bn, lst in cons.items():
-            if len(lst) != 1 or bn not in bn_ops or not bn.layer.trainable:
+            if bn not in bn_ops or not bn.layer.trainable:
                 continue
+            # the FIRST consumer in graph order is the last to run in backward: every other reader of the BatchNorm output
+            # (a residual Add's identity input, ...) has added its share to the gradient buffer by then
             op, slot, v = lst[0]
-            if slot == 'x' and op.kind in ('conv_pw', 'conv_dw') and getattr(v, 'view_grad', None) is None and v.tensor is bn.z:
+            if any(getattr(vv, 'view_grad', None) is not None for _, _, vv in lst):
+                continue
+            if len(lst) > 1 and os.environ.get('DL3P_FUSE_BN_BWD', '1') == '1single':
+                continue
+            if slot == 'x' and op.kind in ('conv_pw', 'conv_dw') and v.tensor is bn.z and op not in fuse:
                 fuse[op] = bn_ops[bn]
         return fuse
 
