@@ -810,7 +810,7 @@ class Executor:
         alias_ok = (not self.sync_bn and os.environ.get('DL3P_GRAD_ALIAS', '1') != '0')
         # BatchNorm -> residual Add -> pointwise conv: the conv's data gradient is the last writer of d/d(Add output), which
         # IS the gradient of the BatchNorm output, so it carries that BatchNorm's backward sums too (no bn_bwd_reduce pass)
-        fuse_add = self._bn_fusion_through_adds(readers) if (alias_ok and not self.bf16) else {}
+        fuse_add = self._bn_fusion_through_adds(readers) if not self.bf16 else {}
         self._presums = {}                # 'bn' op -> partial rows left in self.partials2 by such a data gradient
         rops = list(reversed(self.g.ops))
 
@@ -1242,7 +1242,7 @@ class Executor:
                 # BatchNorm pending by then
                 off = self._bwd_stage_off
                 self._bwd_stage_off += 2 * bn.C
-                P.k(L.bn_reduce_partials, self.partials.data_ptr(), rows.value, 2 * bn.C, self.sync_stage[off:].data_ptr())
+                P.k(L.bn_reduce_partials, part, rows.value, 2 * bn.C, self.sync_stage[off:].data_ptr())
                 self._bwd_pending.append((op, off, P.ctx))
                 return
         if not frozen and self._folds_apply(op):
