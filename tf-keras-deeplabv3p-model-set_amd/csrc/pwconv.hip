@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
 // (row l15, quarter q) loads the float4 X[row][16 kt + 4q ..]: the k-permutation of the big kernel makes
 // that exactly its MFMA operand), the 16 x N result is transposed through a wave-private LDS slice and
 // leaves as whole rows; BN statistics are kept per lane in that row-major form and reduced once at the end.
-template <int KT, int NTN, bool STATS>
+template <int KT, int NTN, bool STATS, bool BNB = false>
 __global__ __launch_bounds__(256, 2) void pw_small_kernel(GemmParams p) {
   constexpr int KP = 16 * KT, NP = 16 * NTN;
   constexpr int BP = NP + 4, TP = NP + 4;
@@ -496,7 +496,8 @@ __global__ __launch_bounds__(256, 2) void pw_small_kernel(GemmParams p) {
   float* Bs = sm_lds;                         // [KP][BP], zero padded
   float* sc_s = Bs + KP * BP;
   float* sh_s = sc_s + KP;
-  float* Tall = sh_s + KP;                    // 4 wave slices of [16][TP]
+  float* bq_s = sh_s + KP;                    // BNB: [scale | shift | mean | invstd][NP] of the BatchNorm whose sums ride along
+  float* Tall = bq_s + (BNB ? 4 * NP : 0);    // 4 wave slices of [16][TP]
   const int t = threadIdx.x, l = t & 63, w = t >> 6, l15 = l & 15, q = l >> 4;
   float* Ts = Tall + w * 16 * TP;
   if (p.b_kn) {
@@ -514,6 +515,15 @@ __global__ __launch_bounds__(256, 2) void pw_small_kernel(GemmParams p) {
     sc_s[i] = (p.scale && i < p.K) ? p.scale[i] : 1.f;
     sh_s[i] = (p.scale && i < p.K) ? p.shift[i] : 0.f;
   }
+  if (BNB) {
+    for (int i = t; i < NP; i += 256) {
+      const bool in = i < p.N;
+      bq_s[i] = in ? p.bb_scale[i] : 1.f;
+      bq_s[NP + i] = in ? p.bb_shift[i] : 0.f;
+      bq_s[2 * NP + i] = in ? p.bb_mean[i] : 0.f;
+      bq_s[3 * NP + i] = in ? p.bb_invstd[i] : 0.f;
+    }
+  }
   __syncthreads();
 
   // A fragment loads: clamped 32-bit byte offsets, invalid lanes zeroed by select
@@ -528,7 +538,7 @@ __global__ __launch_bounds__(256, 2) void pw_small_kernel(GemmParams p) {
   // row-major output mapping of a 16 x N tile: float4 f = l + 64 i  ->  (row f / (N/4), column group f % (N/4))
   const int n4 = p.N >> 2, nf = 4 * p.N;
   int yrow[NTN], yl[NTN];
-  uint32_t yg[NTN];
+  uint32_t yg[NTN], zg[BNB ? NTN : 1];
 #pragma unroll
   for (int i = 0; i < NTN; ++i) {
     const int f = min(l + 64 * i, nf - 1);
@@ -536,7 +546,9 @@ __global__ __launch_bounds__(256, 2) void pw_small_kernel(GemmParams p) {
     yrow[i] = (l + 64 * i < nf) ? r : (1 << 20);
     yl[i] = r * TP + c * 4;
     yg[i] = ((uint32_t)r * (uint32_t)p.ldy + (uint32_t)c * 4u) * 4u;
+    if (BNB) zg[i] = ((uint32_t)r * (uint32_t)p.bb_ldz + (uint32_t)c * 4u) * 4u;
   }
+  const char* Zb = reinterpret_cast<const char*>(p.bb_z);
   const float act_lo = p.act == DL3P_ACT_NONE ? -DL3P_INF : 0.f;
   const float act_hi = (p.act == DL3P_ACT_NONE || p.act == DL3P_ACT_RELU) ? DL3P_INF : 6.f;
 
@@ -564,6 +576,16 @@ __global__ __launch_bounds__(256, 2) void pw_small_kernel(GemmParams p) {
   for (int tile = gw; tile < ntiles; tile += nwaves) {
     const int m0 = tile << 4;
     const bool row_ok = m0 + l15 < p.M;
+    // BNB: the z rows this lane's outputs meet are requested now and used after the MFMAs
+    float4 zpre[BNB ? NTN : 1];
+    if (BNB) {
+      const uint32_t zbase = (uint32_t)m0 * (uint32_t)p.bb_ldz * 4u;
+#pragma unroll
+      for (int i = 0; i < NTN; ++i) {
+        const uint32_t off = (yrow[i] < p.M - m0) ? zg[i] : 0u;        // rows past M re-read the tile's first row (unused)
+        zpre[i] = *reinterpret_cast<const float4*>(Zb + (zbase + off));
+      }
+    }
     float4 a[KT];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
@@ -601,7 +623,18 @@ __global__ __launch_bounds__(256, 2) void pw_small_kernel(GemmParams p) {
         float* yp = reinterpret_cast<float*>(Yb + (ybase + yg[i]));
         if (p.accumulate) o = add4(o, ld4(yp));
         st4(yp, o);
-        if (STATS) {
+        if (STATS && BNB) {
+          // (sum g', sum g' * xhat) of the BatchNorm behind this gradient, as dl3p_bn_bwd_reduce forms them
+          const int cf = yl[i] - yrow[i] * TP;
+          const float4 zv = zpre[i];
+          const float4 u = fma4(zv, *reinterpret_cast<const float4*>(&bq_s[cf]), *reinterpret_cast<const float4*>(&bq_s[NP + cf]));
+          const float4 mu = *reinterpret_cast<const float4*>(&bq_s[2 * NP + cf]), is = *reinterpret_cast<const float4*>(&bq_s[3 * NP + cf]);
+          const float4 d = make_float4(o.x * act_grad(u.x, p.bb_act), o.y * act_grad(u.y, p.bb_act),
+                                       o.z * act_grad(u.z, p.bb_act), o.w * act_grad(u.w, p.bb_act));
+          const float4 xh = make_float4((zv.x - mu.x) * is.x, (zv.y - mu.y) * is.y, (zv.z - mu.z) * is.z, (zv.w - mu.w) * is.w);
+          st_s[i] = add4(st_s[i], d);
+          st_q[i] = fma4(d, xh, st_q[i]);
+        } else if (STATS) {
           st_s[i] = add4(st_s[i], o);
           st_q[i] = fma4(o, o, st_q[i]);
         }
@@ -630,20 +663,20 @@ __global__ __launch_bounds__(256, 2) void pw_small_kernel(GemmParams p) {
   }
 }
 
-template <int KT, int NTN>
+template <int KT, int NTN, bool BNB = false>
 static constexpr size_t pw_small_lds() {
-  return sizeof(float) * (size_t)(16 * KT * (16 * NTN + 4) + 2 * 16 * KT + 4 * 16 * (16 * NTN + 4));
+  return sizeof(float) * (size_t)(16 * KT * (16 * NTN + 4) + 2 * 16 * KT + (BNB ? 4 * 16 * NTN : 0) + 4 * 16 * (16 * NTN + 4));
 }
 
-template <int KT, int NTN, bool STATS>
+template <int KT, int NTN, bool STATS, bool BNB = false>
 static void launch_pw_small(const GemmParams& p, int grid, hipStream_t st) {
-  constexpr size_t lds = pw_small_lds<KT, NTN>();
+  constexpr size_t lds = pw_small_lds<KT, NTN, BNB>();
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)pw_small_kernel<KT, NTN, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)pw_small_kernel<KT, NTN, STATS, BNB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  dl3p_launch(pw_small_kernel<KT, NTN, STATS>, dim3(grid), dim3(256), lds, st, p);
+  dl3p_launch(pw_small_kernel<KT, NTN, STATS, BNB>, dim3(grid), dim3(256), lds, st, p);
 }
 
 struct SmallShape { int kt, ntn; };
@@ -704,9 +737,9 @@ static int pw_small_grid(int M) {
   return g;
 }
 
-template <bool STATS>
+template <bool STATS, bool BNB = false>
 static void launch_pw_small_any(const GemmParams& p, SmallShape sh, int grid, hipStream_t st) {
-#define DL3P_PS(a, b) if (sh.kt == a && sh.ntn == b) { launch_pw_small<a, b, STATS>(p, grid, st); return; }
+#define DL3P_PS(a, b) if (sh.kt == a && sh.ntn == b) { launch_pw_small<a, b, STATS, BNB>(p, grid, st); return; }
   DL3P_PS(1, 2) DL3P_PS(2, 1) DL3P_PS(6, 1) DL3P_PS(1, 6) DL3P_PS(2, 3) DL3P_PS(3, 2) DL3P_PS(6, 2) DL3P_PS(2, 6)
   DL3P_PS(2, 9) DL3P_PS(9, 2)
 #undef DL3P_PS
@@ -1030,6 +1063,17 @@ extern "C" int dl3p_pwconv_bwd_data_bn(const float* dy, int lddy, const float* w
   p.partials = partials;
   p.bb_z = z; p.bb_ldz = ldz; p.bb_scale = scale; p.bb_shift = shift; p.bb_mean = save_mean; p.bb_invstd = save_invstd;
   p.bb_act = act;
+  SmallShape sh;
+  static const int small_bnb = getenv("DL3P_PW_SMALL_BNB") ? atoi(getenv("DL3P_PW_SMALL_BNB")) : 1;
+  if (small_bnb && M >= pw_small_min_rows() && pw_small_pick(N, K, &sh)) {
+    // few channels, many rows: the streaming kernel (the whole kernel matrix in LDS, no workgroup barrier in the row loop)
+    p.b_kn = 0;
+    const int g = pw_small_grid(M);
+    *rows_out = g;
+    launch_pw_small_any<true, true>(p, sh, g, (hipStream_t)stream);
+    DL3P_CHECK_LAUNCH("dl3p_pwconv_bwd_data_bn");
+    return DL3P_OK;
+  }
   int nt, gxn, gy, mi;
   gemm_plan(3, M, N, K, &nt, &gxn, &gy, &p.num_m_tiles, &mi);
   *rows_out = gxn;
