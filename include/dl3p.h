@@ -474,6 +474,11 @@ int dl3p_pwconv_fwd_bf16(const void* x, int ldx, int x_is_f32, const float* in_s
                          float* stat_partials, int* rows_out, int M, int K, int N, void* stream);
 int dl3p_pwconv_bwd_data_bf16(const void* dy, int lddy, int dy_is_f32, const void* w, void* gx, int ldgx, int accumulate,
                               int M, int K, int N, void* stream);
+/* dl3p_pwconv_bwd_data_bn for bf16 tensors (gradient, gx and z in bf16; M > 64) */
+int dl3p_pwconv_bwd_data_bn_bf16(const void* dy, int lddy, const void* w, void* gx, int ldgx, int accumulate, int M, int K,
+                                 int N, const void* z, int ldz, const float* scale, const float* shift, int act,
+                                 const float* save_mean, const float* save_invstd, float* partials, int* rows_out,
+                                 void* stream);
 size_t dl3p_pwconv_bwd_weight_workspace_bf16(int M, int K, int N);
 int dl3p_pwconv_bwd_weight_bf16(const void* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
                                 const void* dy, int lddy, int dy_is_f32, float* gw, float* gb,

@@ -86,6 +86,41 @@ def test_pointwise_bf16(ops, case):
     close_f32(gb, gy.sum(0), 'bias gradient', 1e-4)
 
 
+@pytest.mark.parametrize('case', [(2 * 33 * 33, 320, 256), (1000, 24, 72), (777, 72, 24), (4101, 16, 64), (513, 304, 256),
+                                  (300, 960, 160), (64 * 128 * 9 + 5, 160, 304), (70003, 64, 24), (66000, 256, 144)])
+@pytest.mark.parametrize('act', [O.ACT_RELU6, O.ACT_NONE, O.ACT_HSWISH])
+def test_pointwise_bf16_data_gradient_with_bn_sums(ops, case, act):
+    """dl3p_pwconv_bwd_data_bn_bf16: the data gradient of dl3p_pwconv_bwd_data_bf16 bit for bit, and the partial sums
+    dl3p_bn_bwd_reduce_bf16 forms from the stored gradient (tiled and streaming kernels, accumulate)"""
+    M, K, Nn = case
+    if act != O.ACT_RELU6 and M > 5000:
+        pytest.skip('large shapes once')
+    rng = np.random.default_rng(M + K + Nn)
+    gy = Q(rng.standard_normal((M, Nn)))
+    w = rng.standard_normal((K, Nn)) / np.sqrt(Nn)
+    z = Q(rng.standard_normal((M, K)) * 1.5 + 0.4)
+    sc = rng.uniform(0.5, 1.5, K).astype(np.float32)
+    sh = (rng.standard_normal(K) * 0.3).astype(np.float32)
+    mu = (rng.standard_normal(K) * 0.2).astype(np.float32)
+    inv = rng.uniform(0.5, 2.0, K).astype(np.float32)
+    base = Q(rng.standard_normal((M, K)))
+    for accumulate in (False, True):
+        part = ops.new_partials(K, DEV)
+        out0 = TB(base) if accumulate else None
+        out1 = TB(base) if accumulate else None
+        gx_ref = ops.pwconv_bwd_data_bf16(TB(gy), TF(w), out=out0, accumulate=accumulate)
+        gx, rows = ops.pwconv_bwd_data_bn_bf16(TB(gy), TF(w), TB(z), TF(sc), TF(sh), act, TF(mu), TF(inv), part, out=out1,
+                                               accumulate=accumulate)
+        assert torch.equal(gx, gx_ref), 'the sums epilogue changes the gradient'
+        g = np64(gx)
+        u = np.float32(np.float64(z) * sc + sh)
+        d = g * O.act_bwd(u.astype(np.float64), np.ones_like(g), act)
+        xh = (np.float64(z) - mu) * inv
+        p = part[:rows * 2 * K].reshape(rows, 2, K).double().sum(0).cpu().numpy()
+        close_f32(p[0], d.sum(0), 'sum g\'', 2e-5 * np.sqrt(M) + 1e-5)
+        close_f32(p[1], (d * xh).sum(0), 'sum g\' xhat', 2e-5 * np.sqrt(M) + 1e-5)
+
+
 DW = [(2, 33, 33, 160, 3, 1, 18), (2, 33, 33, 160, 3, 1, 6), (1, 65, 47, 72, 3, 2, 1), (2, 16, 20, 24, 3, 2, 1), (1, 16, 24, 40, 5, 1, 2),
       (1, 16, 24, 72, 5, 2, 1), (2, 33, 33, 960, 5, 1, 2), (1, 7, 6, 24, 5, 1, 1), (1, 64, 96, 16, 3, 1, 1), (3, 9, 9, 12, 3, 1, 1)]
 

@@ -35,7 +35,32 @@ struct GemmB {
   int accumulate;
   int num_m_tiles;
   int dbg;              // DL3P_BF16_DBG ablation bits (timing experiments only): 1 no stores, 2 no A loads, 4 no B loads
+  // data-gradient role with the BatchNorm-backward sums of the BatchNorm behind the gradient (bb_z != nullptr, STATS
+  // instantiations): the partial rows hold (sum g', sum g' * xhat), g' = y * act'(z*scale+shift), as dl3p_bn_bwd_reduce_bf16
+  // forms them from the stored (bf16) gradient
+  const bf16* bb_z; int bb_ldz;
+  const float* bb_scale; const float* bb_shift; const float* bb_mean; const float* bb_invstd; int bb_act;
 };
+
+// statistics of one stored float4 q at (row m, columns n..n+3): forward (sum, sum^2) or, with bb_z, the backward pair
+template <bool BNB>
+__device__ __forceinline__ void stats_accumulate_b(const GemmB& p, int m, int n, float4 q, float (&ss)[4], float (&sq)[4]) {
+  if (BNB) {
+    const float4 z = ld4(p.bb_z + (size_t)m * p.bb_ldz + n);
+    const float4 sc = ld4(p.bb_scale + n), sh = ld4(p.bb_shift + n), mu = ld4(p.bb_mean + n), is = ld4(p.bb_invstd + n);
+    const float qv[4] = {q.x, q.y, q.z, q.w}, zv[4] = {z.x, z.y, z.z, z.w}, scv[4] = {sc.x, sc.y, sc.z, sc.w};
+    const float shv[4] = {sh.x, sh.y, sh.z, sh.w}, muv[4] = {mu.x, mu.y, mu.z, mu.w}, isv[4] = {is.x, is.y, is.z, is.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float d = qv[j] * act_grad(fmaf(zv[j], scv[j], shv[j]), p.bb_act);
+      ss[j] += d;
+      sq[j] = fmaf(d, (zv[j] - muv[j]) * isv[j], sq[j]);
+    }
+  } else {
+    ss[0] += q.x; ss[1] += q.y; ss[2] += q.z; ss[3] += q.w;
+    sq[0] = fmaf(q.x, q.x, sq[0]); sq[1] = fmaf(q.y, q.y, sq[1]); sq[2] = fmaf(q.z, q.z, sq[2]); sq[3] = fmaf(q.w, q.w, sq[3]);
+  }
+}
 
 template <bool F32> struct AType { typedef bf16 type; };
 template <> struct AType<true> { typedef float type; };
@@ -62,8 +87,8 @@ constexpr int KMAX_LDS = 2048;      // per-channel prologue coefficients of up t
 // tensor (conv_upsample output and its gradient) stays fp32 so that the softmax / loss head is the fp32 one.
 // The operand loads of K-step it + 2 are issued while step it is multiplied (two register slots): at 1-2 workgroups of
 // work per CU and 0.3 us per K-step a single step of lookahead left the ~2 us HBM latency exposed on every step.
-template <int NT, int MI, bool A_F32, bool Y_F32, bool STATS>
-__global__ __launch_bounds__(256, (NT * MI <= 8 && !(STATS && NT * MI > 4)) ? 4 : (NT * MI <= 8 ? 3 : 2)) void pwb_gemm(GemmB p) {
+template <int NT, int MI, bool A_F32, bool Y_F32, bool STATS, bool BNB = false>
+__global__ __launch_bounds__(256, BNB ? 2 : ((NT * MI <= 8 && !(STATS && NT * MI > 4)) ? 4 : (NT * MI <= 8 ? 3 : 2))) void pwb_gemm(GemmB p) {
   constexpr int BM = 64 * MI, BN = 16 * NT;
   constexpr int NB = (BN * 4 + 255) / 256;      // 16-B chunks of the B tile per thread
   constexpr int PD = 2;                         // K-steps of loads in flight
@@ -223,9 +248,7 @@ __global__ __launch_bounds__(256, (NT * MI <= 8 && !(STATS && NT * MI > 4)) ? 4 
             if (!(p.dbg & 1)) st4(yp, o);
             if (STATS) {
               const float4 q = Y_F32 ? o : bf16_round4(o);      // statistics of the values the consumers will read
-              st_s[ni][0] += q.x; st_s[ni][1] += q.y; st_s[ni][2] += q.z; st_s[ni][3] += q.w;
-              st_q[ni][0] = fmaf(q.x, q.x, st_q[ni][0]); st_q[ni][1] = fmaf(q.y, q.y, st_q[ni][1]);
-              st_q[ni][2] = fmaf(q.z, q.z, st_q[ni][2]); st_q[ni][3] = fmaf(q.w, q.w, st_q[ni][3]);
+              stats_accumulate_b<BNB>(p, m, n, q, st_s[ni], st_q[ni]);
             }
           }
         }
@@ -276,7 +299,7 @@ __global__ __launch_bounds__(256, (NT * MI <= 8 && !(STATS && NT * MI > 4)) ? 4 
 // other's memory latency, which is what these HBM-bound layers need (the tiled kernel above spent ~2 us per 32-deep
 // K-step in staging + two barriers, with or without its global loads).  Loads run one chunk of CH K-steps ahead: raw
 // registers are converted to fragments, re-issued for the next chunk, then the chunk's MFMAs run.
-template <int NT, bool A_F32, bool Y_F32, bool STATS>
+template <int NT, bool A_F32, bool Y_F32, bool STATS, bool BNB = false>
 __global__ __launch_bounds__(512, 1) void pwb_stream(GemmB p, int kp, int tiles) {
   constexpr int MI = 2, BN = 16 * NT, NWAVE = 8;
   // K-steps per chunk (raw + converted fragments of a chunk live next to 64 accumulator and, with statistics, 64
@@ -416,9 +439,7 @@ __global__ __launch_bounds__(512, 1) void pwb_stream(GemmB p, int kp, int tiles)
             st4(yp, o);
             if (STATS) {
               const float4 q = Y_F32 ? o : bf16_round4(o);
-              st_s[ni][0] += q.x; st_s[ni][1] += q.y; st_s[ni][2] += q.z; st_s[ni][3] += q.w;
-              st_q[ni][0] = fmaf(q.x, q.x, st_q[ni][0]); st_q[ni][1] = fmaf(q.y, q.y, st_q[ni][1]);
-              st_q[ni][2] = fmaf(q.z, q.z, st_q[ni][2]); st_q[ni][3] = fmaf(q.w, q.w, st_q[ni][3]);
+              stats_accumulate_b<BNB>(p, m, n, q, st_s[ni], st_q[ni]);
             }
           }
         }
@@ -471,21 +492,21 @@ StreamPlan stream_plan_b(int K, int N, bool stats) {
   return pl;
 }
 
-template <int NT, bool A_F32, bool Y_F32, bool STATS>
+template <int NT, bool A_F32, bool Y_F32, bool STATS, bool BNB = false>
 void launch_stream_one(const GemmB& p, const StreamPlan& pl, dim3 grid, int tiles, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)pwb_stream<NT, A_F32, Y_F32, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)pwb_stream<NT, A_F32, Y_F32, STATS, BNB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((pwb_stream<NT, A_F32, Y_F32, STATS>), grid, dim3(512), pl.lds, st, p, pl.kp, tiles);
+  hipLaunchKernelGGL((pwb_stream<NT, A_F32, Y_F32, STATS, BNB>), grid, dim3(512), pl.lds, st, p, pl.kp, tiles);
 }
-template <bool A_F32, bool Y_F32, bool STATS>
+template <bool A_F32, bool Y_F32, bool STATS, bool BNB = false>
 void launch_stream(const GemmB& p, const StreamPlan& pl, dim3 grid, int tiles, hipStream_t st) {
   switch (pl.nt) {
-    case 2: launch_stream_one<2, A_F32, Y_F32, STATS>(p, pl, grid, tiles, st); break;
-    case 4: launch_stream_one<4, A_F32, Y_F32, STATS>(p, pl, grid, tiles, st); break;
-    default: launch_stream_one<8, A_F32, Y_F32, STATS>(p, pl, grid, tiles, st); break;
+    case 2: launch_stream_one<2, A_F32, Y_F32, STATS, BNB>(p, pl, grid, tiles, st); break;
+    case 4: launch_stream_one<4, A_F32, Y_F32, STATS, BNB>(p, pl, grid, tiles, st); break;
+    default: launch_stream_one<8, A_F32, Y_F32, STATS, BNB>(p, pl, grid, tiles, st); break;
   }
 }
 
@@ -706,12 +727,12 @@ int pick_nt_b(int N, bool stats) {
   return nt;
 }
 
-template <int MI, bool A_F32, bool Y_F32, bool STATS>
+template <int MI, bool A_F32, bool Y_F32, bool STATS, bool BNB = false>
 void launch_gemm_b(const GemmB& p, int nt, dim3 grid, hipStream_t st) {
   switch (nt) {
-    case 2: hipLaunchKernelGGL((pwb_gemm<2, MI, A_F32, Y_F32, STATS>), grid, dim3(256), 0, st, p); break;
-    case 4: hipLaunchKernelGGL((pwb_gemm<4, MI, A_F32, Y_F32, STATS>), grid, dim3(256), 0, st, p); break;
-    case 8: hipLaunchKernelGGL((pwb_gemm<8, MI, A_F32, Y_F32, STATS>), grid, dim3(256), 0, st, p); break;
+    case 2: hipLaunchKernelGGL((pwb_gemm<2, MI, A_F32, Y_F32, STATS, BNB>), grid, dim3(256), 0, st, p); break;
+    case 4: hipLaunchKernelGGL((pwb_gemm<4, MI, A_F32, Y_F32, STATS, BNB>), grid, dim3(256), 0, st, p); break;
+    case 8: hipLaunchKernelGGL((pwb_gemm<8, MI, A_F32, Y_F32, STATS, BNB>), grid, dim3(256), 0, st, p); break;
     default:
       // 256 columns per workgroup: 64-row tiles only (128 accumulator registers at 128 rows spill next to the load ring)
       if constexpr (!STATS && MI == 1) hipLaunchKernelGGL((pwb_gemm<16, 1, A_F32, Y_F32, false>), grid, dim3(256), 0, st, p);
@@ -736,7 +757,7 @@ int gemm_b(const char* fn, GemmB p, bool a_f32, bool y_f32, int* rows_out, hipSt
   const StreamPlan sp = stream_plan_b(p.K, p.N, stats);
   // (the streaming kernel pays a [BN][K] weight load per workgroup and runs one workgroup of 8 waves per CU: it wins from
   // ~2^16 rows up -- 131072 x 304 -> 256: 67 us against 91 us tiled -- and loses on the 128 x 256 and 64 x 128 maps)
-  if (sp.ok && !no_stream && p.M >= (1 << 16)) {
+  if (sp.ok && !no_stream && p.M >= (1 << 16) && !(p.bb_z && sp.nt == 8)) {      // (128 columns + the backward sums spill)
     const int tiles = ceil_div(p.M, 32);
     const int per_cu = sp.lds > 75 * 1024 ? 1 : 2;
     int gx = ceil_div(tiles, 8 * 2);                       // at least two tiles per wave
@@ -747,6 +768,7 @@ int gemm_b(const char* fn, GemmB p, bool a_f32, bool y_f32, int* rows_out, hipSt
     const dim3 grid(gx, sp.gy);
     if (a_f32) launch_stream<true, false, false>(p, sp, grid, tiles, st);
     else if (y_f32) launch_stream<false, true, false>(p, sp, grid, tiles, st);
+    else if (stats && p.bb_z) launch_stream<false, false, true, true>(p, sp, grid, tiles, st);
     else if (stats) launch_stream<false, false, true>(p, sp, grid, tiles, st);
     else launch_stream<false, false, false>(p, sp, grid, tiles, st);
     DL3P_CHECK_LAUNCH(fn);
@@ -770,6 +792,7 @@ int gemm_b(const char* fn, GemmB p, bool a_f32, bool y_f32, int* rows_out, hipSt
   do {                                                                              \
     if (a_f32) launch_gemm_b<MIV, true, false, false>(p, nt, grid, st);             \
     else if (y_f32) launch_gemm_b<MIV, false, true, false>(p, nt, grid, st);        \
+    else if (stats && p.bb_z) launch_gemm_b<MIV, false, false, true, true>(p, nt, grid, st); \
     else if (stats) launch_gemm_b<MIV, false, false, true>(p, nt, grid, st);        \
     else launch_gemm_b<MIV, false, false, false>(p, nt, grid, st);                  \
   } while (0)
@@ -827,6 +850,32 @@ extern "C" int dl3p_pwconv_bwd_data_bf16(const void* dy, int lddy, int dy_is_f32
   p.Y = gx; p.ldy = ldgx; p.accumulate = accumulate;
   p.M = M; p.K = N; p.N = K;
   return gemm_b("dl3p_pwconv_bwd_data_bf16", p, dy_is_f32 != 0, false, nullptr, (hipStream_t)stream);
+}
+
+// data gradient of a layer whose input is act(BN(z)) + the BatchNorm-backward partial sums of that BN (bf16 gradient and z;
+// the separate dl3p_bn_bwd_reduce_bf16 pass over them disappears).  More than 64 rows: the few-row kernel carries no sums.
+extern "C" int dl3p_pwconv_bwd_data_bn_bf16(const void* dy, int lddy, const void* w, void* gx, int ldgx, int accumulate,
+                                            int M, int K, int N, const void* z, int ldz, const float* scale,
+                                            const float* shift, int act, const float* save_mean,
+                                            const float* save_invstd, float* partials, int* rows_out, void* stream) {
+  const char* fn = "dl3p_pwconv_bwd_data_bn_bf16";
+  int rc = check_mat_b(fn, dy, lddy, N, false);
+  if (rc) return rc;
+  rc = check_mat_b(fn, gx, ldgx, K, false);
+  if (rc) return rc;
+  rc = check_mat_b(fn, z, ldz, K, false);
+  if (rc) return rc;
+  DL3P_CHECK_ARG(w && aligned16(w) && M > 64 && scale && shift && save_mean && save_invstd && partials && rows_out && K % 4 == 0,
+                 "%s: bad arguments (M > 64 rows, all BatchNorm vectors, K %% 4 == 0)", fn);
+  GemmB p = {};
+  p.A = dy; p.lda = lddy; p.act = DL3P_ACT_NONE;
+  p.B = (const bf16*)w; p.ldb = N;
+  p.Y = gx; p.ldy = ldgx; p.accumulate = accumulate;
+  p.M = M; p.K = N; p.N = K;
+  p.partials = partials;
+  p.bb_z = (const bf16*)z; p.bb_ldz = ldz; p.bb_scale = scale; p.bb_shift = shift; p.bb_mean = save_mean;
+  p.bb_invstd = save_invstd; p.bb_act = act;
+  return gemm_b(fn, p, false, false, rows_out, (hipStream_t)stream);
 }
 
 extern "C" size_t dl3p_pwconv_bwd_weight_workspace_bf16(int M, int K, int N) {

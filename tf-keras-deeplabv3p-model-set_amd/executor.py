@@ -800,7 +800,13 @@ class Executor:
         # issued while the NEXT BatchNorm's statistics all-reduce is on the wire (hides the collective's latency)
         self._deferred = []
         defer = self.sync_bn
-        fuse = {} if self.bf16 else self._bn_fusion_map()      # (the bf16 GEMM / depthwise kernels do not carry the fused sums)
+        fuse = self._bn_fusion_map()
+        if self.bf16:
+            # bf16: the pointwise GEMMs can carry the sums (dl3p_pwconv_bwd_data_bn_bf16, more than 64 rows), the depthwise
+            # kernels cannot.  Opt-in: measured slower than the separate reduce pass (the epilogue meets z in 8-byte pieces:
+            # MobileNetV2 513x513 batch 16 12.37 against 11.83 ms, MobileNetV3-Large 1024x2048 batch 1 6.92 against 6.86)
+            fuse = {c: b for c, b in fuse.items() if c.kind == 'conv_pw' and self.N * c.Ho * c.Wo > 64
+                    and os.environ.get('DL3P_BF16_FUSE_BN_BWD', '0') == '1'}
         bn_done = set()
         self._bwd_pending, self._bwd_stage_off = [], self._sync_total
         processed = set()
@@ -891,7 +897,10 @@ class Executor:
             if out is None or not out.requires_grad:
                 continue
             if self.bf16 and k in ('conv_pw', 'conv_dense', 'conv_dw'):
-                self._conv_backward_bf16(P, op, wgrad, ws, wsb, wgrad_slabs if batch else None)
+                fused_bn = fuse.get(op) if (op in fuse and fuse[op].z.requires_grad) else None
+                self._conv_backward_bf16(P, op, wgrad, ws, wsb, wgrad_slabs if batch else None, fused_bn)
+                if fused_bn is not None:
+                    bn_done.add(fused_bn)
             elif k in ('conv_pw', 'conv_dense', 'conv_dw'):
                 xp, ldx, sp, hp, act = self.vargs(op.x)
                 xt = op.x.tensor
@@ -1083,9 +1092,9 @@ class Executor:
             P.py(self.dist.wait_all)
         return P
 
-    def _conv_backward_bf16(self, P, op, wgrad, ws, wsb, wgrad_slabs=None):
-        """weight and data gradient of one conv on the bf16 path (the BatchNorm-backward sums are NOT fused into the
-        data-gradient kernels here: every trainable BN takes the separate reduce pass)"""
+    def _conv_backward_bf16(self, P, op, wgrad, ws, wsb, wgrad_slabs=None, fused_bn=None):
+        """weight and data gradient of one conv on the bf16 path; `fused_bn`: the 'bn' op whose backward sums the pointwise
+        data gradient carries (its finalize + apply are issued right behind it)"""
         L, N, st, k = self.L, self.N, self.store, op.kind
         G, out = st.G, op.out
         xp, ldx, sp, hp, act = self.vargs(op.x)
@@ -1118,7 +1127,27 @@ class Executor:
             return
         gp, ldg, keyt = self._gbuf(op.x)
         acc = self._acc(keyt)
-        if k == 'conv_pw':
+        if k == 'conv_pw' and fused_bn is not None and not dzf:
+            # the BatchNorm-backward sums of the BatchNorm behind this gradient ride on the data gradient (dl3p_pwconv_bwd_data_bn)
+            bn = fused_bn.bn
+            aux = self.bn_aux[bn]
+            rows = ctypes.c_int(0)
+            P.k(L.pwconv_bwd_data_bn_bf16, dz, lddz, st.ptr(op.w, st.Pb), gp, ldg, acc, M, op.cin, op.cout,
+                self.tptr(fused_bn.z), fused_bn.z.ld, self.gscale[bn.group.id].data_ptr() + 4 * bn.offset,
+                self.gshift[bn.group.id].data_ptr() + 4 * bn.offset, bn.act, aux['mean'].data_ptr(),
+                aux['invstd'].data_ptr(), self.partials.data_ptr(), ctypes.byref(rows))
+            ctx = P.ctx
+            P.ctx = _op_label(fused_bn)
+            self._bn_backward(P, fused_bn, fused_rows=rows.value)
+            P.ctx = ctx
+        elif k == 'conv_pw':
+            if fused_bn is not None:          # (an fp32 gradient operand: the kernel with the sums takes bf16 only)
+                ctx = P.ctx
+                P.k(L.pwconv_bwd_data_bf16, dz, lddz, dzf, st.ptr(op.w, st.Pb), gp, ldg, acc, M, op.cin, op.cout)
+                P.ctx = _op_label(fused_bn)
+                self._bn_backward(P, fused_bn)
+                P.ctx = ctx
+                return
             P.k(L.pwconv_bwd_data_bf16, dz, lddz, dzf, st.ptr(op.w, st.Pb), gp, ldg, acc, M, op.cin, op.cout)
         elif k == 'conv_dw':
             P.k(L.dwconv2d_bwd_data_bf16, dz, lddz, st.ptr(op.w, st.Pb), gp, ldg, acc, N, xt.H, xt.W, op.c, op.k, op.stride,

@@ -704,6 +704,20 @@ def pwconv_bwd_data_bf16(dy, w, out=None, accumulate=False):
     return gx
 
 
+def pwconv_bwd_data_bn_bf16(dy, w, z, scale, shift, act, mean, invstd, partials, out=None, accumulate=False):
+    """bf16 data gradient + the BatchNorm-backward partial sums of the BatchNorm behind it -> (gx, rows)"""
+    K, Nn = w.shape
+    M = _rows(dy)
+    gx = out if out is not None else torch.empty(tuple(dy.shape[:-1]) + (K,), dtype=torch.bfloat16, device=dy.device)
+    dp, ldd, _ = _plb(dy)
+    gp, ldg, _ = _plb(gx)
+    zp, ldz, _ = _plb(z)
+    rows = ctypes.c_int(0)
+    lib().pwconv_bwd_data_bn_bf16(dp, ldd, _p(_bf(w.contiguous())), gp, ldg, int(accumulate), M, K, Nn, zp, ldz, _p(scale),
+                                  _p(shift), act, _p(mean), _p(invstd), _p(partials), ctypes.byref(rows), _stream())
+    return gx, rows.value
+
+
 def pwconv_bwd_weight_bf16(x, dy, in_scale=None, in_shift=None, in_act=ACT_NONE, with_bias=False):
     K, Nn = x.shape[-1], dy.shape[-1]
     M = _rows(x)
