@@ -385,7 +385,8 @@ int dl3p_reduce_rows(const float* partials, int rows, size_t n, float* out, int 
  * dl3p_reduce_rows_batched then sums every job = {const float* slabs; float* dst; int rows; int n;} (a device array of
  * 24-byte records) into its destination with exactly the arithmetic dl3p_reduce_rows applies to it:
  * dl3p_reduce_rows_variant(rows, n) says which of the two kernels that is (0 or 1), and blockmapV[b] = {job, block within
- * the job} lists the blocks of the jobs of variant V (64 elements per block). */
+ * the job} lists the blocks of the jobs of variant V (dl3p_reduce_rows_block_elements(V) consecutive elements per block). */
+int dl3p_reduce_rows_block_elements(int variant);
 int dl3p_reduce_rows_variant(int rows, size_t n);
 int dl3p_reduce_rows_batched(const void* jobs, const int* blockmap0, int blocks0, const int* blockmap1, int blocks1,
                              void* stream);

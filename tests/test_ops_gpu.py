@@ -116,7 +116,8 @@ def test_reduce_rows_batched_is_bitwise_the_per_layer_reduction(ops):
     maps = ([], [])
     for j, (_, _, rows, n) in enumerate(rec):
         v = L.reduce_rows_variant(rows, n)
-        maps[v].extend((j, b) for b in range((n + 63) // 64))
+        be = L.reduce_rows_block_elements(v)
+        maps[v].extend((j, b) for b in range((n + be - 1) // be))
     assert maps[0] and maps[1], 'both variants exercised'
     jt = torch.from_numpy(jobs.view(np.uint8).copy()).to(DEV)
     m0, m1 = (torch.tensor(m, dtype=torch.int32, device=DEV) for m in maps)

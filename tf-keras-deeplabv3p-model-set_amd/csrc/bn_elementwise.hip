@@ -102,34 +102,55 @@ extern "C" int dl3p_reduce_rows(const float* partials, int rows, size_t n, float
 // exactly the arithmetic of reduce_rows_kernel<64, 4> / <16, 64> -- the same variant dl3p_reduce_rows would have picked
 // for it, so the sums are bit-identical to the per-layer path.  blockmap[b] = (job, block within the job).
 struct ReduceJob { const float* src; float* dst; int rows; int n; };
-template <int EL, int RL>
-__global__ __launch_bounds__(EL * RL) void reduce_rows_batched_kernel(const ReduceJob* __restrict__ jobs,
-                                                                      const int2* __restrict__ blockmap) {
-  __shared__ double sm[RL][EL];
+// The arithmetic of reduce_rows_kernel<64, 4> on 256 consecutive elements per workgroup (four 64-element chunks, one per
+// row-lane group in the final add): a 64-element workgroup of a 7-slab job reads 1.8 KB and the launch becomes a stream of
+// 400 000 workgroups (Xception: 730 us for 0.7 GB of slabs); here a thread has 4 chunks x 4 rows in flight.  Bit-identical sums.
+#define DL3P_RB_WIDE 4
+__global__ __launch_bounds__(256) void reduce_rows_batched_wide_kernel(const ReduceJob* __restrict__ jobs,
+                                                                       const int2* __restrict__ blockmap) {
+  constexpr int EL = 64, RL = 4, CH = DL3P_RB_WIDE;
+  __shared__ double sm[CH][RL][EL];
   const int2 bm = blockmap[blockIdx.x];
   const ReduceJob jb = jobs[bm.x];
   const float* __restrict__ partials = jb.src;
   const size_t n = (size_t)jb.n;
   const int rows = jb.rows;
   const int ex = threadIdx.x % EL, ry = threadIdx.x / EL;
-  const size_t i = (size_t)bm.y * EL + ex;
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  if (i < n) {
-    int r = ry;
-    for (; r + 3 * RL < rows; r += 4 * RL) {
-      a0 += (double)partials[(size_t)r * n + i];
-      a1 += (double)partials[(size_t)(r + RL) * n + i];
-      a2 += (double)partials[(size_t)(r + 2 * RL) * n + i];
-      a3 += (double)partials[(size_t)(r + 3 * RL) * n + i];
-    }
-    for (; r < rows; r += RL) a0 += (double)partials[(size_t)r * n + i];
+  const size_t i0 = (size_t)bm.y * (EL * CH) + ex;
+  size_t idx[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) idx[c] = i0 + (size_t)c * EL < n ? i0 + (size_t)c * EL : n - 1;     // clamped: loads stay in the job
+  double a[CH][4];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) a[c][0] = a[c][1] = a[c][2] = a[c][3] = 0.0;
+  int r = ry;
+  for (; r + 3 * RL < rows; r += 4 * RL) {
+    float v[CH][4];
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[c][u] = partials[(size_t)(r + u * RL) * n + idx[c]];
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[c][u] += (double)v[c][u];
   }
-  sm[ry][ex] = (a0 + a1) + (a2 + a3);
+  for (; r < rows; r += RL) {
+    float v[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) v[c] = partials[(size_t)r * n + idx[c]];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) a[c][0] += (double)v[c];
+  }
+#pragma unroll
+  for (int c = 0; c < CH; ++c) sm[c][ry][ex] = (a[c][0] + a[c][1]) + (a[c][2] + a[c][3]);
   __syncthreads();
-  if (ry == 0 && i < n) {
+  // the thread group ry finishes chunk ry (CH == RL)
+  const size_t i = i0 + (size_t)ry * EL;
+  if (i < n) {
     double acc = 0.0;
-#pragma unroll 8
-    for (int q = 0; q < RL; ++q) acc += sm[q][ex];
+#pragma unroll
+    for (int q = 0; q < RL; ++q) acc += sm[ry][q][ex];
     jb.dst[i] = (float)acc;
   }
 }
@@ -173,6 +194,7 @@ __global__ __launch_bounds__(256) void reduce_rows_batched_lanes64_kernel(const 
 }
 
 extern "C" int dl3p_reduce_rows_variant(int rows, size_t n) { return (n >= 64 * 1024 || rows <= 16) ? 0 : 1; }
+extern "C" int dl3p_reduce_rows_block_elements(int variant) { return variant == 0 ? 64 * DL3P_RB_WIDE : 64; }
 
 extern "C" int dl3p_reduce_rows_batched(const void* jobs, const int* blockmap0, int blocks0, const int* blockmap1, int blocks1,
                                         void* stream) {
@@ -180,7 +202,7 @@ extern "C" int dl3p_reduce_rows_batched(const void* jobs, const int* blockmap0, 
                  "dl3p_reduce_rows_batched: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   if (blocks0)
-    hipLaunchKernelGGL((reduce_rows_batched_kernel<64, 4>), dim3(blocks0), dim3(256), 0, st, (const ReduceJob*)jobs,
+    hipLaunchKernelGGL(reduce_rows_batched_wide_kernel, dim3(blocks0), dim3(256), 0, st, (const ReduceJob*)jobs,
                        (const int2*)blockmap0);
   if (blocks1)
     hipLaunchKernelGGL(reduce_rows_batched_lanes64_kernel, dim3(blocks1), dim3(256), 0, st, (const ReduceJob*)jobs,

@@ -488,7 +488,8 @@ class Executor:
         for j, (src, dst, rows, n) in enumerate(jobs):
             rec[j] = (src, dst, rows, n)
             v = L.reduce_rows_variant(rows, n)
-            maps[v].extend((j, b) for b in range((n + 63) // 64))
+            be = L.reduce_rows_block_elements(v)
+            maps[v].extend((j, b) for b in range((n + be - 1) // be))
         jt = torch.from_numpy(rec.view(np.uint8).copy()).to(self.dev)
         mt = [torch.tensor(m if m else [(0, 0)], dtype=torch.int32, device=self.dev) for m in maps]
         self._wgrad_tables.append((jt, mt))         # the launches read them at every replay
