@@ -814,7 +814,8 @@ class Executor:
         readers = self._bn_readers()
         bn_of = {id(o.z): o for o in self.g.ops if o.kind == 'bn'}
         self._galias = {}                 # z tensor id -> (ptr, ld) of the buffer that already holds d/d(BN(z) output)
-        alias_ok = (not self.sync_bn and os.environ.get('DL3P_GRAD_ALIAS', '1') != '0')
+        alias_ok = os.environ.get('DL3P_GRAD_ALIAS', '1') != '0'
+        self._sync_g = {}                 # SyncBatchNorm: 'bn' op -> (ptr, ld) its apply reads the gradient from (after the all-reduce)
         # BatchNorm -> residual Add -> pointwise conv: the conv's data gradient is the last writer of d/d(Add output), which
         # IS the gradient of the BatchNorm output, so it carries that BatchNorm's backward sums too (no bn_bwd_reduce pass)
         fuse_add = self._bn_fusion_through_adds(readers) if not self.bf16 else {}
@@ -1274,6 +1275,7 @@ class Executor:
                 self._bwd_stage_off += 2 * bn.C
                 P.k(L.bn_reduce_partials, part, rows.value, 2 * bn.C, self.sync_stage[off:].data_ptr())
                 self._bwd_pending.append((op, off, P.ctx))
+                self._sync_g[op] = (g, ldg)
                 return
         if not frozen and self._folds_apply(op):
             # the conv that produced z forms dz inside its weight-gradient kernel and hands it to its data gradient
@@ -1342,12 +1344,13 @@ class Executor:
             M = self.N * z.H * z.W
             sp = self.gscale[bn.group.id].data_ptr() + 4 * bn.offset
             hp = self.gshift[bn.group.id].data_ptr() + 4 * bn.offset
-            g, ldg, zp = self.tptr(z, True), z.ld, self.tptr(z)
+            dzo, lddzo, zp = self.tptr(z, True), z.ld, self.tptr(z)
+            g, ldg = self._sync_g.pop(op, (dzo, lddzo))          # (a residual Add's buffer when the gradient was handed on in place)
             mean, invstd, coef = aux['mean'].data_ptr(), aux['invstd'].data_ptr(), aux['coef'].data_ptr()
             P.k(L.bn_bwd_finalize, None, 0, self.sync_stage[off:].data_ptr(), bn.C, float(M * self.dist.world_size),
                 st.ptr(lp['gamma']), invstd, sp, 0, None, None, coef)
             P.k(L.bn_bwd_apply_bf16 if self.bf16 else L.bn_bwd_apply, g, ldg, zp, z.ld, sp, hp, bn.act, mean, invstd, coef,
-                g, ldg, 0, M, bn.C)
+                dzo, lddzo, 0, M, bn.C)
         P.ctx = ctx
 
     # ---------------------------------------------------------------- optimiser
