@@ -697,3 +697,46 @@ def test_evaluate_loss_matches_oracle(kind):
     assert abs(got - np.mean(want)) < TOL * max(1.0, abs(np.mean(want))), (got, want)
     assert 0.0 <= m.last_val_metrics['Jaccard'] <= 1.0
 
+
+
+@pytest.mark.parametrize('model_type,H,W', [('mobilenetv2', 65, 65), ('mobilenetv2_lite', 65, 65), ('xception', 65, 65),
+                                            ('mobilenetv3large', 65, 65), ('mobilenetv3small_lite', 65, 65),
+                                            ('resnet50', 65, 65), ('mobilenetv2', 129, 97)])
+def test_backward_shortcuts_do_not_change_gradients(model_type, H, W, monkeypatch):
+    """The launches removed from backward -- BatchNorm-backward apply folded into weight gradients, residual Adds handing
+    their gradient on in place, BatchNorm sums riding on the first reader's data gradient (also through Adds), the
+    batched slab reduction -- are bookkeeping: with all of them off the same step must give the same gradients, to
+    rounding (the folds re-associate a handful of multiplies), for every graph shape the factory builds."""
+    pkg = load_pkg()
+    N, C = 2, 21
+    x, y = _data(N, H, W, C, seed=11)
+
+    def grads(env):
+        for k in ('DL3P_FOLD_APPLY', 'DL3P_GRAD_ALIAS', 'DL3P_FUSE_BN_BWD', 'DL3P_BATCHED_WGRAD'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        torch.manual_seed(0)
+        m, _ = _pair(model_type, H, W, C)
+        m.use_graphs = False
+        loss = m.train_on_batch(x, y)
+        st = m._store
+        return loss, {p.name: np.array(st.get(p, st.G), dtype=np.float64)
+                      for p in m.graph.all_params() if p.trainable}, len(m._executor(N, True).bwd.items)
+
+    l1, g1, n1 = grads({})
+    l0, g0, n0 = grads({'DL3P_FOLD_APPLY': '0', 'DL3P_GRAD_ALIAS': '0', 'DL3P_FUSE_BN_BWD': '0', 'DL3P_BATCHED_WGRAD': '0'})
+    assert n1 < n0, 'the shortcuts remove launches (%d vs %d)' % (n1, n0)
+    assert abs(l1 - l0) <= 1e-6 * abs(l0)
+    # (the beta gradient of a BatchNorm that feeds a 1x1 conv + BatchNorm is zero in exact arithmetic -- the next BatchNorm
+    # removes a per-channel shift -- and pure cancellation noise in float32, like a conv bias in front of a BatchNorm:
+    # differences are measured against the tensor's scale plus 1e-4 of the largest gradient of the model; those noise
+    # tensors then sit at <= 1.2e-3, every other tensor below 1e-4 -- scripts/micro/ab_shortcuts.py prints the list)
+    gmax = max(float(np.abs(a).max()) for a in g0.values())
+    worst = ('', 0.0)
+    for name, a in g0.items():
+        b = g1[name]
+        r = float(np.abs(a - b).max() / (np.abs(a).max() + 1e-4 * gmax))
+        if r > worst[1]:
+            worst = (name, r)
+    assert worst[1] < 3e-3, worst
