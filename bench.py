@@ -48,6 +48,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-streaming', action='store_true', help='skip the N=256 DRAM-streaming run of the roofline kernel')
     ap.add_argument('--cpu-steps', type=int, default=10)
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip the short runs of BASELINE.json configs[2..4] behind the headline region')
     return ap.parse_args()
 
 
@@ -143,6 +145,66 @@ def measured_traffic(kernel_name):
     return None, None
 
 
+# BASELINE.json configs[2..4] at their per-GPU shapes (C3 Xception 513x513 batch 32 over 8 GPUs -> 4 per
+# GPU; C4 Xception 769x769 OS 8, 19 classes, batch 16 over 8 -> 2; C5 MobileNetV3-Large 1024x2048, 19 classes, bf16, batch 8
+# over 8 -> 1): (tag, model, classes, H, W, output stride, per-GPU batch, dtype)
+OTHER_CONFIGS = [('configs[2]', 'xception', 21, 513, 513, 16, 4, 'f32'),
+                 ('configs[3]', 'xception', 19, 769, 769, 8, 2, 'f32'),
+                 ('configs[4]', 'mobilenetv3large', 19, 1024, 2048, 16, 1, 'bf16')]
+
+
+def other_config(pkg, tag, model_type, C, H, W, OS, N, dtype, steps=20, warmup=5):
+    """a short timed loop of one of the other BASELINE configs on this GPU, AFTER the headline region (its numbers never
+    enter `value`): the same step (fwd + loss + bwd + SGD, BN training, dropout), hipGraph replay, with the config's own top
+    atrous kernel (the highest ASPP rate) between HIP events inside the steps"""
+    import torch
+    mp = pkg.mixed_precision
+    mp.set_policy(mp.Policy('mixed_bfloat16' if dtype == 'bf16' else 'float32'))
+    try:
+        model = pkg.get_deeplabv3p_model(model_type, C, (H, W), OS, freeze_level=0, training=True)
+    finally:
+        mp.set_policy(mp.Policy('float32'))
+    model.compile(optimizer=pkg.SGD(0.01, momentum=0.9), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
+    gen = torch.Generator(device='cuda')
+    gen.manual_seed(4321)
+    x = torch.rand((N, H, W, 3), device='cuda', generator=gen) * 2 - 1
+    y = torch.randint(0, C, (N, H * W, 1), device='cuda', generator=gen).float()
+    y[torch.rand(y.shape, device='cuda', generator=gen) < 0.05] = 255.0
+    ex = model._executor(N, True)
+    ex.set_inputs(x, y)
+    ex.lr.fill_(0.01)
+    probe = ex.install_probe('aspp3_depthwise')
+    ex.train_step()
+    ex.capture()
+    for _ in range(warmup):
+        ex.train_step()
+    probe.reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ex.train_step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    loss = float(ex.loss.item())
+    op, t = probe.op, probe.op.out
+    es = 2 if dtype == 'bf16' else 4
+    algo = 2.0 * N * t.H * t.W * op.c * es + op.k * op.k * op.c * es
+    us = probe.mean_ms() * 1e3
+    out = {'config': tag,
+           'workload': '%s + ASPP(%s) + decoder, OS=%d, %dx%d, %d classes, per-GPU batch %d, fwd+loss+bwd+SGD' % (
+               model_type, {8: '12/24/36', 16: '6/12/18'}[OS], OS, H, W, C, N),
+           'dtype': dtype, 'steps': steps, 'warmup': warmup, 'ms_per_step': round(1000 * dt / steps, 3),
+           'images_per_sec': round(N * steps / dt, 2), 'final_loss': round(loss, 5),
+           'launches_per_step': ex.fwd.n_launches + ex.bwd.n_launches + ex.opt.n_launches,
+           'roofline': {'bound': 'hbm', 'kernel': probe.kernel_name, 'avg_us': round(us, 3), 'algorithmic_bytes': int(algo),
+                        'achieved': round(algo / (us * 1e-6) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': round(algo / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                        'shape': 'N=%d %dx%dx%d k=%d rate=%d' % (N, t.H, t.W, op.c, op.k, op.rate)}}
+    del ex, model, x, y
+    torch.cuda.empty_cache()
+    return out
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD torch.distributed.run job (this
     process has not touched the GPU and never will), pass its output through and relay rank 0's JSON line as the last
@@ -210,6 +272,10 @@ def main():
     y = torch.randint(0, C, (N, H * W, 1), device='cuda', generator=gen).float()
     y[torch.rand(y.shape, device='cuda', generator=gen) < 0.05] = 255.0
 
+    # world > 1: bound the part where a multi-rank job can hang (executor trace = every collective once, graph capture, first
+    # replays); on expiry the guard prints the switches to try and exits non-zero (watchdog.py)
+    guard = pkg.watchdog.FirstStepsGuard(rank, world, 'executor trace')
+    guard.__enter__()
     ex = model._executor(N, True)
     ex.set_inputs(x, y)
     ex.lr.fill_(0.01)
@@ -229,14 +295,18 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    guard.stage('first eager step')
     ex.train_step()                      # first step eager (also the graph-capture warm-up)
     if model.use_graphs:
+        guard.stage('graph capture')
         ex.capture()
+    guard.stage('warm-up replays')
     for _ in range(args.warmup):
         ex.train_step()
     if probe:
         probe.reset()
     barrier()
+    guard.__exit__(None, None, None)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ex.train_step()
@@ -317,6 +387,18 @@ def main():
                                     'shape': 'M=%d K=%d N=%d fp32 (v_mfma_f32_16x16x4_f32)' % (M, K, Nc)}
         if probe and standalone is None and args.dtype == 'f32' and not args.no_streaming:
             out['roofline'].update(streaming_variant(pkg, probe.op))
+        headline = (args.model, H, W, C, args.os, args.dtype) == ('mobilenetv2', 513, 513, 21, 16, 'f32')
+        if world == 1 and headline and not dist_mode and not args.no_other_configs:
+            # the other BASELINE configs, each a short loop behind the headline region
+            del ex
+            model._exec = {}
+            torch.cuda.empty_cache()
+            out['other_configs'] = []
+            for cfg in OTHER_CONFIGS:
+                try:
+                    out['other_configs'].append(other_config(pkg, *cfg))
+                except Exception as e:      # noqa: BLE001 -- never lose the headline line to a side run
+                    out['other_configs'].append({'config': cfg[0], 'error': '%s: %s' % (type(e).__name__, str(e)[:300])})
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)
     if torch.distributed.is_initialized():

@@ -63,6 +63,19 @@ int dl3p_device_cus(void);
  * "dw_want" / "dw_maxth" / "dw_tuned": the same for the plan of the depthwise window kernels (csrc/dw_tuned.h,
  * scripts/tune_dw.py).  Unknown names return DL3P_EINVAL. */
 int dl3p_set_option(const char* name, int value);
+/* What the dispatcher WOULD launch for a pointwise GEMM / a depthwise conv, without launching it (the parity tests over
+ * the measured tables use it to prove that a table row is reached and what it selects).
+ * dl3p_gemm_plan_query: role 0 forward, 1 forward + BatchNorm statistics (dl3p_pwconv_fwd_wt), 2 data gradient, 3 data
+ * gradient + fused BatchNorm sums, 4 weight gradient; (M, K, N) = rows, reduction length, output columns of the GEMM as
+ * launched (data gradient: K = the conv's output channels).  out6 = {kernel family (0 tiled MFMA, 1 wave-streaming, 2 few-row),
+ * nt (role 4: tile index), tile rows / 64 (role 4: workgroups per CU), grid x (role 4: tiles), grid y (role 4: M splits), 1 if
+ * the row came from csrc/gemm_tuned.h}.
+ * dl3p_dw_plan_query: role 0 forward, 1 data gradient, 2 data gradient + fused BatchNorm sums, 3 weight gradient, with the
+ * conv's OWN geometry (as the entry points take it).  out6 = {kind (0 gather, 1 window stride 1, 2 window stride 2, 3 residue
+ * lattice, 4 quad / strided data gradient), strip width, band height, bands, workgroups per slab, 1 if from csrc/dw_tuned.h}. */
+int dl3p_gemm_plan_query(int role, int M, int K, int N, int* out6);
+int dl3p_dw_plan_query(int role, int N, int H, int W, int C, int k, int stride, int rate, int pad_t, int pad_l, int Ho, int Wo,
+                       int* out6);
 
 /* ---------------------------------------------------------------- data-parallel collectives (RCCL over xGMI)
  * replaces tf.distribute.MirroredStrategy's cross-replica sums (reference train.py:143-158: gradients, and
@@ -214,10 +227,14 @@ int dl3p_col2im(const float* gcol, int ld_col, float* gx, int ldgx, int accumula
 /* ---------------------------------------------------------------- batch normalisation
  * replaces BatchNormalization/FusedBatchNormV3 (layers.py:63-70 CustomBatchNormalization).
  * Training: the biased batch variance normalises AND feeds the moving average
- * moving <- moving*momentum + batch*(1-momentum)  (CustomBatchNormalization is Keras SyncBatchNormalization, the
- * non-fused path: no Bessel correction).
+ * moving <- moving*momentum + batch*(1-momentum).  Which variance feeds the moving average depends on the Keras class
+ * CustomBatchNormalization resolves to (layers.py:63-70; the test at :64 is a STRING compare): under TF 2.2 .. 2.9
+ * it is SyncBatchNormalization, Keras' non-fused path -> the biased batch variance (update_moving = 1, the default of the
+ * Python facade); under the pinned tensorflow==2.11.0 ('2.11.0' >= '2.2' is False) it is plain BatchNormalization, the fused
+ * FusedBatchNormV3 kernel -> Bessel-corrected, count / (count - 1) (update_moving = 2; model option
+ * bn_moving_variance='unbiased').  Training-mode outputs and gradients are the same either way.
  * dl3p_bn_finalize: partial rows [rows][2][C] -> scale = gamma*invstd, shift = beta - mean*scale,
- * save_mean, save_invstd, and (update_moving) the moving statistics.  `count` = elements per
+ * save_mean, save_invstd, and (update_moving: 0 no, 1 biased, 2 unbiased variance) the moving statistics.  `count` = elements per
  * channel that produced the sums (N*H*W, or the global count under SyncBN with rows == 1). */
 int dl3p_bn_reduce_partials(const float* partials, int rows, int C2, double* sums, void* stream);
 int dl3p_bn_finalize(const float* partials, int rows, const double* sums, int C, double count,

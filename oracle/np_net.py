@@ -70,11 +70,21 @@ class Net:
         # this oracle on the device's trajectory so that EVERY layer is compared on identical inputs and the backward
         # pass is linearised at the device's own activations.
         self.force = None
+        # the same for the BACKWARD pass: {layer name: d loss / d (raw conv output) as the device stored it}.  A conv / depthwise
+        # layer's backward first records the gradient THIS net computed for its output (record_grad), then continues with the
+        # device's: its weight gradient and everything up to the next conv outputs (data gradient, BatchNorm backward with the
+        # activation derivative, Add / concat / resize / pooling transposes) are then compared segment by segment on the
+        # device's own inputs, instead of through a hundred layers of accumulated bf16 rounding.
+        self.force_grad = None
+        self.record_grad = None
         # optional SyncBatchNorm: (all_reduce_sum(ndarray) -> ndarray, world_size).  Statistics are
         # summed over ranks in forward (sum x, sum x^2, count) and backward (sum dy, sum dy*xhat); the
         # parameter gradients stay local and are averaged with all other gradients (README.md:38,
         # layers.py:63-70; the protocol the HIP executor implements with RCCL).
         self.sync = None
+        # which batch variance feeds the moving average: 'biased' (Keras SyncBatchNormalization, non-fused path) or 'unbiased'
+        # (fused BatchNormalization, Bessel's correction) -- see np_ops.bn_moving_variance_of
+        self.bn_moving_variance = 'biased'
 
     # ---- parameters -------------------------------------------------------------------
     def param(self, name, shape, init, trainable=True, l2=0.0):
@@ -113,6 +123,13 @@ class Net:
     def acc_grad(self, name, g):
         self.grads[name] = g if name not in self.grads else self.grads[name] + g
 
+    def _teacher_grad(self, name, y):
+        """record_grad / force_grad at a conv output (see __init__)"""
+        if self.record_grad is not None:
+            self.record_grad[name] = y.g
+        if self.force_grad is not None and name in self.force_grad:
+            y.g = np.asarray(self.force_grad[name], dtype=self.dtype).reshape(y.g.shape)
+
     # ---- layers -----------------------------------------------------------------------
     def conv2d(self, x, filters, k, name, stride=1, rate=1, padding='same', use_bias=False, he_normal=False, keep_f32=False):
         """DeeplabConv2D (layers.py:14-21): glorot_uniform kernel (he_normal in ResNet50), zero bias, l2(2e-5) on both."""
@@ -128,13 +145,12 @@ class Net:
             self.record[name] = y.v
         if self.force is not None and name in self.force:
             y.v = np.asarray(self.force[name], dtype=self.dtype).reshape(y.v.shape)
-        if self.force is not None and name in self.force:
-            y.v = np.asarray(self.force[name], dtype=self.dtype).reshape(y.v.shape)
         need_gx = True
 
         def bwd():
             if y.g is None:
                 return
+            self._teacher_grad(name, y)
             gx, gw, gb = O.conv2d_bwd(x.v, wq, y.g, stride, rate, padding, need_gx)
             self.acc_grad(name + '/kernel', gw)
             if use_bias:
@@ -153,10 +169,13 @@ class Net:
         y = Var(self.q(O.dwconv2d_fwd(x.v, w, stride, rate, padding)))
         if self.record is not None:
             self.record[name] = y.v
+        if self.force is not None and name in self.force:
+            y.v = np.asarray(self.force[name], dtype=self.dtype).reshape(y.v.shape)
 
         def bwd():
             if y.g is None:
                 return
+            self._teacher_grad(name, y)
             gx, gw = O.dwconv2d_bwd(x.v, w, y.g, stride, rate, padding)
             self.acc_grad(name + '/depthwise_kernel', gw[..., None])
             x.acc(gx)
@@ -176,6 +195,7 @@ class Net:
         if self.training and self.layer_is_trainable(name):
             yv, cache, (bm, bv) = O.bn_train_fwd(x.v, gamma, beta, eps)
             self.moving_updates[name + '/moving_mean'] = O.bn_moving_update(mm, bm, momentum)
+            bv = O.bn_moving_variance_of(bv, x.v.size // c, self.bn_moving_variance)
             self.moving_updates[name + '/moving_variance'] = O.bn_moving_update(mv, bv, momentum)
             y = Var(self.q(yv))
             if self.bf16:
@@ -221,7 +241,8 @@ class Net:
         y = Var(xhat * gamma + beta)
         y.tag = name
         self.moving_updates[name + '/moving_mean'] = O.bn_moving_update(mm, mean, momentum)
-        self.moving_updates[name + '/moving_variance'] = O.bn_moving_update(mv, var, momentum)
+        self.moving_updates[name + '/moving_variance'] = O.bn_moving_update(
+            mv, O.bn_moving_variance_of(var, m, self.bn_moving_variance), momentum)
 
         def bwd():
             if y.g is None:
@@ -680,7 +701,7 @@ class OracleModel:
     net_class = Net          # oracle/torch_net.py substitutes a torch-autograd implementation of the same layer set
 
     def __init__(self, model_type, num_classes, input_shape, output_stride, dtype=np.float64, seed=0,
-                 freeze_level=0):
+                 freeze_level=0, bn_moving_variance='biased'):
         if model_type not in MODEL_TYPES:
             raise ValueError('This model type is not supported now')
         self.model_type = model_type
@@ -688,6 +709,7 @@ class OracleModel:
         self.H, self.W = input_shape
         self.OS = output_stride
         self.net = self.net_class(dtype, seed)
+        self.net.bn_moving_variance = bn_moving_variance
         self.velocity = {}
         self.freeze_level = freeze_level
         # materialise parameters with one dry forward at batch 1 on a small probe (shapes of the

@@ -166,11 +166,8 @@ def dwconv2d_bwd(x, w, gy, stride=1, rate=1, padding='same'):
 
 def bn_train_fwd(x, gamma, beta, eps):
     """Training-mode BN over (N,H,W).  Normalises with the BIASED batch variance.
-    returns y, cache, (batch_mean, batch_var) for the moving-average update.  CustomBatchNormalization is
-    tf.keras SyncBatchNormalization under TF >= 2.2 (layers.py:63-70), i.e. the NON-fused BatchNormalizationBase
-    path: `_calculate_mean_and_var` returns E[x^2] - E[x]^2 and that same biased variance feeds the moving
-    average (only the fused FusedBatchNormV3 kernel applies Bessel's correction; SyncBatchNormalization refuses
-    fused=True)."""
+    returns y, cache, (batch_mean, biased batch_var); bn_moving_variance_of turns the variance into what the moving
+    average takes."""
     C = x.shape[-1]
     x2 = x.reshape(-1, C)
     mean = x2.mean(0)
@@ -197,6 +194,29 @@ def bn_train_bwd(gy, cache):
 def bn_infer_fwd(x, gamma, beta, moving_mean, moving_var, eps):
     scale = gamma / np.sqrt(moving_var + eps)
     return x * scale + (beta - moving_mean * scale)
+
+
+def bn_moving_variance_of(biased_var, count, rule='biased'):
+    """The variance CustomBatchNormalization (layers.py:63-70) feeds into moving_variance.  The layer is
+        SyncBatchNormalization  if tf.__version__ >= '2.2'   (layers.py:64-66)
+        BatchNormalization      otherwise                    (layers.py:67-68)
+    and the test is a STRING compare: True for TF 2.2 .. 2.9, False for the pinned tensorflow==2.11.0
+    ('2.11.0' >= '2.2' is False).  The two Keras classes differ in this one statistic:
+      'biased'   SyncBatchNormalization refuses fused=True and runs Keras' non-fused BatchNormalizationBase path:
+                 `_calculate_mean_and_var` returns E[x^2] - E[x]^2 and that same biased variance is assigned to the
+                 moving average;
+      'unbiased' plain BatchNormalization on a 4-D input runs the fused FusedBatchNormV3 kernel, whose batch_variance
+                 output -- the one Keras' `_fused_batch_norm` feeds to the moving average -- carries Bessel's correction
+                 count / (count - 1).
+    Both normalise the batch with the biased variance, so training-mode outputs and gradients are identical; only inference
+    after training differs (by count / (count - 1) per contributing step: 1 + 1/17423 on a 16 x 33 x 33 map, a factor 2 for
+    image_pooling_BN at batch 2).  The product's default is 'biased' (north_star asks for SyncBN over the global batch;
+    README.md:38 claims it); get_deeplabv3p_model(..., bn_moving_variance='unbiased') gives the pinned-TF behaviour."""
+    if rule == 'unbiased':
+        return biased_var * (count / (count - 1.0)) if count > 1 else biased_var
+    if rule != 'biased':
+        raise ValueError(rule)
+    return biased_var
 
 
 def bn_moving_update(moving, batch_value, momentum):

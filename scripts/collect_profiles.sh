@@ -1,16 +1,32 @@
 #!/bin/bash
-# run on the GPU box from the repo root: bench line + rocprofv3 kernel stats + HBM counters (separate passes)
+# run on the GPU box: bench line + rocprofv3 kernel stats + HBM / MFMA counters (separate passes).
+#   collect_profiles.sh r03                                   the headline config (BASELINE configs[1])
+#   collect_profiles.sh r03 xception --model xception --batch 4 ...      another config: files get the tag in their names,
+#                                                                        the roofline-traffic json is headline-only
+# (no `set -e`: a pass that fails must not lose the others)
+set -uo pipefail
 set -x
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-R=${1:-r01}
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+export TMPDIR=/tmp
+cd "$ROOT"
+R0=${1:-r01}
+TAG=${2:-}
+if [ -n "$TAG" ]; then shift 2; R=${R0}_$TAG; else shift $(( $# > 0 ? 1 : 0 )); R=$R0; fi
+ARGS="$* --no-other-configs"
+MFMA_INSTS=SQ_INSTS_VALU_MFMA_F32
+case " $ARGS " in *" bf16 "*) MFMA_INSTS=;; esac      # (pipe utilisation = busy cycles / CU busy cycles needs no instruction count)
 O=gpurun_out/profiles_$R
 mkdir -p $O
-python3 bench.py > $O/bench_$R.log 2>&1
+if [ -z "$TAG" ]; then
+  python3 bench.py > $O/bench_$R.log 2>&1
+else
+  python3 bench.py $ARGS --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_$R.log 2>&1
+fi
 grep '"metric"' $O/bench_$R.log > $O/bench_$R.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/kt.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $O/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $O/pmc_write.log 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_F32 --kernel-trace --output-format csv -d $O/pmc_mfma -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $O/pmc_mfma.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py $ARGS --steps 10 --warmup 3 --no-cpu-baseline > $O/kt.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py $ARGS --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py $ARGS --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $O/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES $MFMA_INSTS --kernel-trace --output-format csv -d $O/pmc_mfma -- python3 bench.py $ARGS --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $O/pmc_mfma.log 2>&1
 cp $O/kt/*/*kernel_stats.csv $O/${R}_kernel_stats.csv
 # steps in the trace = launches of the once-per-step loss kernel (warm-up + timed + the bench's extra probe steps)
 STEPS=$(python3 - <<PY
@@ -29,7 +45,7 @@ for tag in ('pmc_fetch', 'pmc_write'):
     if not f: continue
     agg = {}
     for r in csv.DictReader(open(f[0])):
-        if 'dw_' not in r['Kernel_Name']: continue
+        if 'dw_' not in r['Kernel_Name'] and 'dwb_' not in r['Kernel_Name']: continue
         k = (r['Counter_Name'], r['Kernel_Name'][:60], r['Grid_Size'])
         agg.setdefault(k, []).append(float(r['Counter_Value']))
     for (c, kn, g), v in sorted(agg.items()):
@@ -62,16 +78,16 @@ python3 - <<PY
 import csv, glob, collections
 f = glob.glob('$O/pmc_mfma/**/*counter_collection.csv', recursive=True)
 out = open('$O/${R}_mfma_counters_gemm.csv', 'w')
-out.write('kernel,grid,calls,mfma_busy_cycles,busy_cu_cycles,mfma_insts_f32,mfma_pipe_utilisation\n')
+out.write('kernel,grid,calls,mfma_busy_cycles,busy_cu_cycles,mfma_insts,mfma_pipe_utilisation\n')
 if f:
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f[0])):
         kn = r['Kernel_Name']
-        if 'pw_' not in kn: continue
+        if 'pw_' not in kn and 'pwb_' not in kn: continue
         agg[(kn[:70], r['Grid_Size'])][r['Counter_Name']].append(float(r['Counter_Value']))
     rows = []
     for (kn, g), c in agg.items():
-        m = c.get('SQ_VALU_MFMA_BUSY_CYCLES', [0]); b = c.get('SQ_BUSY_CU_CYCLES', [0]); i = c.get('SQ_INSTS_VALU_MFMA_F32', [0])
+        m = c.get('SQ_VALU_MFMA_BUSY_CYCLES', [0]); b = c.get('SQ_BUSY_CU_CYCLES', [0]); i = c.get('$MFMA_INSTS' or 'none', [0])
         mm, bb, ii = sum(m) / len(m), sum(b) / len(b), sum(i) / len(i)
         rows.append((mm, '"%s",%s,%d,%.0f,%.0f,%.0f,%.3f\n' % (kn, g, len(m), mm, bb, ii, mm / bb / 4 if bb else 0)))
     for _, line in sorted(rows, reverse=True)[:40]:

@@ -1,6 +1,9 @@
 #!/bin/bash
+set -euo pipefail
 # usage: ktrace.sh <kernel substring> -- <python args> : mean kernel duration (us) from rocprofv3 kernel trace
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+export TMPDIR=/tmp
+cd "$ROOT"
 K="$1"; shift 2
 rm -rf gpurun_out/kt_tmp
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/kt_tmp -- python3 "$@" > /dev/null 2>&1

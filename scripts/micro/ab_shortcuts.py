@@ -1,5 +1,6 @@
 import os, sys, numpy as np
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..')
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 os.environ.setdefault('DL3P_PW_SMALL_MIN_ROWS', '64')
 from conftest import load_pkg
 import torch

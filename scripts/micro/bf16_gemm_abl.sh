@@ -1,5 +1,8 @@
 #!/bin/bash
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+set -euo pipefail
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}"
+export TMPDIR=/tmp
+cd "$ROOT"
 for dbg in 0 1 2 4 6 7; do
   export DL3P_BF16_DBG=$dbg
   for shape in "131072 304 256 fwd" "131072 256 256 dgrad" "524288 16 64 fwd"; do

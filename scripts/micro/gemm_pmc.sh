@@ -1,6 +1,9 @@
 #!/bin/bash
+set -euo pipefail
 # where do the waves of the tiled GEMM spend their cycles?  SQ wait / issue counters of one shape (separate passes)
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}"
+export TMPDIR=/tmp
+cd "$ROOT"
 S=${1:-"266256 304 256"}
 O=gpurun_out/gemm_pmc
 rm -rf $O; mkdir -p $O

@@ -1,6 +1,9 @@
 #!/bin/bash
+set -euo pipefail
 # usage: pmc_kernel.sh "<counters>" <kernel substring> -- <python args>
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+export TMPDIR=/tmp
+cd "$ROOT"
 C="$1"; K="$2"; shift 3
 rm -rf gpurun_out/pmc_tmp
 rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/pmc_tmp -- python3 "$@" > /dev/null 2>&1

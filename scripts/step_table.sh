@@ -1,6 +1,9 @@
 #!/bin/bash
+set -euo pipefail
 # usage (GPU box, repo root): bash scripts/step_table.sh [model]  -> gpurun_out/step_table_<model>.txt
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+export TMPDIR=/tmp
+cd "$ROOT"
 M=${1:-mobilenetv2}
 rm -rf gpurun_out/st
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/st -- python3 scripts/step_table.py run $M > gpurun_out/st_run.log 2>&1

@@ -151,6 +151,58 @@ def bench_shape(role, M, K, N):
     return res
 
 
+def verify(role, M, K, N, best):
+    """'' if the candidate's output equals the heuristic pick's to rounding (same products, another summation grouping), else
+    what differs"""
+    dev = 'cuda'
+    g = torch.Generator(device=dev)
+    g.manual_seed(role + M + K + N)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
+
+    def outputs():
+        if role == 4:
+            x, dy = rnd(M, K), rnd(M, N)
+            return [ops.pwconv_bwd_weight(x, dy, None, None, ops.ACT_NONE)]
+        if role in (0, 1):
+            x, wt = rnd(M, K), rnd(N, K) / K ** 0.5
+            part = ops.new_partials(N, dev) if role == 1 else None
+            o = ops.pwconv_fwd_wt(x, wt, None, None, None, ops.ACT_NONE, partials=part)
+            return [o[0], part[:o[1] * 2 * N].reshape(o[1], 2, N).double().sum(0)] if role == 1 else [o]
+        dy, w = rnd(M, K), rnd(N, K) / K ** 0.5
+        if role == 2:
+            return [ops.pwconv_bwd_data(dy, w)]
+        z, part = rnd(M, N), ops.new_partials(N, dev)
+        one, zero = torch.ones(N, device=dev), torch.zeros(N, device=dev)
+        gx, rows = ops.pwconv_bwd_data_bn(dy, w, z, one, zero, ops.ACT_RELU6, zero, one, part)
+        return [gx, part[:rows * 2 * N].reshape(rows, 2, N).double().sum(0)]
+
+    def pin(nt, mi, pc):
+        if role == 4:
+            L.set_option(b'wgrad_tile', nt if nt is not None else -1)
+            L.set_option(b'wgrad_per_cu', mi or 0)
+        else:
+            L.set_option(b'gemm_nt', nt or 0)
+            L.set_option(b'gemm_mi', mi or 0)
+            L.set_option(b'gemm_per_cu', pc or 0)
+    L.set_option(b'gemm_tuned', 0)
+    try:
+        pin(None, 0, 0)
+        g.manual_seed(role + M + K + N)
+        ref = [t.double() for t in outputs()]
+        pin(*best)
+        g.manual_seed(role + M + K + N)
+        got = [t.double() for t in outputs()]
+    finally:
+        pin(None, 0, 0)
+        L.set_option(b'gemm_tuned', 1)
+    tol = 3e-5 * M ** 0.5 if role == 4 else 1e-4
+    for a, b in zip(got, ref):
+        d = float((a - b).abs().max())
+        if not torch.isfinite(a).all() or d > tol * max(1e-30, float(b.abs().max())):
+            return 'max diff %.3g of %.3g' % (d, float(b.abs().max()))
+    return ''
+
+
 def main():
     dry = '--dry' in sys.argv
     L.set_option(b'pw_small_min_rows', -1)
@@ -168,6 +220,10 @@ def main():
             continue
         # shapes the streaming / tiny kernels take never reach the tiled kernel: detect by timing with a pinned tile -- the
         # pin has no effect on them, so all candidates tie; cheap enough to just measure
+        plan = (ctypes.c_int * 6)()
+        L.gemm_plan_query(role, M, K, N, plan)
+        if plan[0] != 0:        # the streaming / few-row kernels take this shape: a row for it would never be read
+            continue
         try:
             res = bench_shape(role, M, K, N)
         except Exception as e:      # noqa: BLE001
@@ -182,6 +238,13 @@ def main():
         log.append(line)
         print(line, flush=True)
         if spread > 1.02 and cands[best] < 0.97 * base:
+            # a faster tile only counts if it computes the same thing (tests/test_tuned_tables_gpu.py then holds every row
+            # against float64)
+            bad = verify(role, M, K, N, best)
+            if bad:
+                log.append('REFUSED %s: %s' % ((role, M, K, N, best), bad))
+                print(log[-1], flush=True)
+                continue
             rows.append((role, M, K, N, best[0], best[1], best[2], base, cands[best]))
     out = ['// GENERATED by scripts/tune_gemm.py on an MI355X -- measured (nt, mi) per GEMM shape of the BASELINE graphs where the',
            '// best candidate beats the heuristic by more than 3 %.  {role, M, K, N, nt, mi, pc}   // heuristic us -> tuned us\n'

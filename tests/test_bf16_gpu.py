@@ -18,6 +18,17 @@ DEV = 'cuda'
 Q = O.bf16_round
 
 
+def _record_bf16_backward(rec):
+    import json, os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, 'bf16_backward_parity.jsonl'), 'a') as f:
+            f.write(json.dumps(rec) + '\n')
+    except OSError:
+        pass
+
+
 def TB(a):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV).to(torch.bfloat16)
 
@@ -48,7 +59,11 @@ def close_f32(got, want, what, rtol=2e-3):
 
 
 PW = [(2 * 33 * 33, 320, 256), (1000, 24, 72), (777, 72, 24), (4101, 16, 64), (513, 304, 256), (300, 960, 160), (131, 184, 80),
-      (64 * 128 + 5, 160, 960), (3, 240, 64), (1, 960, 240), (257, 1280, 256), (5000, 256, 24)]
+      (64 * 128 + 5, 160, 960), (3, 240, 64), (1, 960, 240), (257, 1280, 256), (5000, 256, 24),
+      # BASELINE configs[4] launch shapes (MobileNetV3-Large 1024 x 2048, batch 1): the decoder GEMMs on the wave-streaming
+      # kernel, the 512 x 1024 stem-side layers, the 64 x 128 body and ASPP
+      (256 * 512, 304, 256), (256 * 512, 256, 256), (512 * 1024, 16, 64), (128 * 256, 120, 40), (64 * 128, 960, 160),
+      (64 * 128, 1280, 256), (256 * 512, 256, 24)]
 
 
 @pytest.mark.parametrize('case', PW)
@@ -122,7 +137,10 @@ def test_pointwise_bf16_data_gradient_with_bn_sums(ops, case, act):
 
 
 DW = [(2, 33, 33, 160, 3, 1, 18), (2, 33, 33, 160, 3, 1, 6), (1, 65, 47, 72, 3, 2, 1), (2, 16, 20, 24, 3, 2, 1), (1, 16, 24, 40, 5, 1, 2),
-      (1, 16, 24, 72, 5, 2, 1), (2, 33, 33, 960, 5, 1, 2), (1, 7, 6, 24, 5, 1, 1), (1, 64, 96, 16, 3, 1, 1), (3, 9, 9, 12, 3, 1, 1)]
+      (1, 16, 24, 72, 5, 2, 1), (2, 33, 33, 960, 5, 1, 2), (1, 7, 6, 24, 5, 1, 1), (1, 64, 96, 16, 3, 1, 1), (3, 9, 9, 12, 3, 1, 1),
+      # configs[4] launch shapes: decoder 256 x 512 x 304, 5 x 5 rate 2 on 64 x 128 x 960, the three ASPP rates, a stride-2 layer
+      (1, 256, 512, 304, 3, 1, 1), (1, 64, 128, 960, 5, 1, 2), (1, 64, 128, 160, 3, 1, 6), (1, 64, 128, 160, 3, 1, 12),
+      (1, 64, 128, 160, 3, 1, 18), (1, 256, 512, 72, 3, 2, 1), (1, 128, 256, 120, 5, 1, 1)]
 
 
 @pytest.mark.parametrize('case', DW)
@@ -208,9 +226,10 @@ def test_train_step_bf16_matches_rounding_oracle(model_type, H, W):
     that layer, and the oracle then continues with the device's tensor:
       * forward: every one of the ~100 conv layers within one bf16 ulp (+ 2e-3 of the layer's range) on 99.9 % of its
         elements; logits and loss (fp32 head) to 1e-3;
-      * backward: fp64 back-propagation through the device's own activations against gradients that were stored as bf16
-        at every layer: cosine similarity > 0.98 and relative L2 error < 0.2 per parameter tensor, < 0.08 over all
-        (measured: 0.03 - 0.055)."""
+      * backward: teacher-forced as well (Net.force_grad): the oracle's backward continues, at every conv output, with the
+        gradient the DEVICE stored there.  Activation gradients are compared segment by segment (two bf16 ulps), parameter
+        gradients become layer-local quantities and are held to 4e-3 of their scale per tensor, 2e-3 in relative L2 over all
+        (round 2 accepted cos > 0.98 / relative L2 < 0.2 against an un-forced backward)."""
     from oracle.np_net import OracleModel
     pkg = load_pkg()
     mp = pkg.mixed_precision
@@ -245,6 +264,11 @@ def test_train_step_bf16_matches_rounding_oracle(model_type, H, W):
     real = {op.name: op.layer.params[0].shape[-1] if op.kind != 'conv_dw' else op.c for op in convs}
     o.net.force = {op.name: ex.view(op.out).float().cpu().numpy()[..., :real[op.name]] for op in convs}
     o.net.record = {}
+    # ... and the backward pass the same way: the device's d loss / d (conv output) of every layer (bf16 as stored; the
+    # logits layer's is fp32) is what the oracle's backward continues with at that layer
+    o.net.force_grad = {op.name: ex.view(op.out, grad=True).float().cpu().numpy()[..., :real[op.name]] for op in convs
+                        if op.out.requires_grad}
+    o.net.record_grad = {}
     _, ce, logits_ref = o.loss_and_grads(x, y, {'aspp_dropout': mask})
     assert set(o.net.record) == set(o.net.force)
     for op in convs:
@@ -259,6 +283,31 @@ def test_train_step_bf16_matches_rounding_oracle(model_type, H, W):
     lg = out['logits'][..., :C].cpu().numpy()
     assert np.abs(lg - logits_ref).max() < 1e-3 * max(1.0, np.abs(logits_ref).max())
     assert abs(loss - ce) < 1e-3 * max(1.0, abs(ce)), (loss, ce)
+    # backward, layer by layer.  (a) activation gradients: what the oracle derives for a conv output from
+    # the DEVICE's gradients at the conv outputs downstream of it -- one data-gradient kernel, the BatchNorm backward with the
+    # activation derivative, Add / concat / resize / pooling / squeeze-excite transposes in between, each storing bf16 -- to two
+    # bf16 ulps of the element + 2^-7 of the tensor's rms on 99.9 % of the elements, 1 % in relative L2
+    assert set(o.net.record_grad) == set(o.net.force_grad)
+    report = []
+    for op in convs:
+        if op.name not in o.net.force_grad:
+            continue
+        ref, got = np.asarray(o.net.record_grad[op.name], np.float64), o.net.force_grad[op.name].astype(np.float64)
+        rms = float(np.sqrt((ref ** 2).mean()))
+        if rms < 1e-12:
+            assert float(np.abs(got).max()) < 1e-9, op.name
+            continue
+        if op.name == 'conv_upsample':          # fp32 gradient of the logits (softmax - onehot through the resize transpose)
+            tol = 1e-5 * np.abs(ref).max() + 0 * ref
+        else:
+            tol = 2.0 ** -6 * np.abs(ref) + 2.0 ** -7 * rms
+        frac = float((np.abs(got - ref) <= tol).mean())
+        rel = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+        report.append((op.name, round(frac, 5), round(rel, 5)))
+        assert frac > 0.999 and rel < 1e-2, (op.name, frac, rel)
+    # (b) parameter gradients (fp32 on the device): each is now a LAYER-LOCAL quantity -- the weight gradient of a conv from the
+    # device's own input activations and output gradient, a BatchNorm's (dgamma, dbeta) from the device's gradients one segment
+    # downstream -- at the tolerance of the op tests (1e-4 .. 2e-3 of the tensor's scale), not cos > 0.98
     st = m._store
     worst, num, den = [], 0.0, 0.0
     for p in m.graph.all_params():
@@ -267,14 +316,17 @@ def test_train_step_bf16_matches_rounding_oracle(model_type, H, W):
             continue
         g = st.get(p, st.G).astype(np.float64)
         num += float(((g - ge) ** 2).sum()); den += float((ge ** 2).sum())
-        if ge.size < 16 or np.abs(ge).max() < 1e-7:
+        if np.abs(ge).max() < 1e-7:
+            assert np.abs(g).max() < 1e-5, p.name
             continue
-        c = _cos(g, ge)
-        rel = float(np.linalg.norm(g - ge) / max(1e-30, np.linalg.norm(ge)))
-        if c < 0.98 or rel > 0.2:
-            worst.append((p.name, round(c, 4), round(rel, 4)))
+        err = float(np.abs(g - ge).max() / np.abs(ge).max())
+        rel = float(np.linalg.norm(g - ge) / np.linalg.norm(ge))
+        if err > 4e-3 or rel > 4e-3:
+            worst.append((p.name, round(err, 5), round(rel, 5)))
+    _record_bf16_backward(dict(model=model_type, H=H, W=W, worst_activation_gradients=sorted(report, key=lambda r: -r[2])[:5],
+                               overall_relative_l2=float(np.sqrt(num / den)), outside=worst[:10]))
     assert not worst, worst[:10]
-    assert np.sqrt(num / den) < 0.08, np.sqrt(num / den)
+    assert np.sqrt(num / den) < 2e-3, np.sqrt(num / den)
     w = m.get_weights_by_name()
     assert all(v.dtype == np.float32 and np.isfinite(v).all() for v in w.values())
 

@@ -73,3 +73,165 @@ print('COMM OK')
 ''' % ROOT
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert r.returncode == 0 and 'COMM OK' in r.stdout, (r.stdout[-1500:], r.stderr[-2500:])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# World-size-2 ARITHMETIC on one GPU: a test double of DistContext with world_size = 2 whose sum
+# all-reduce is a multiplication by 2 -- two ranks holding the SAME batch.  Every place the executor uses the world size
+# (count * world in bn_finalize / bn_bwd_finalize, 1 / world in the optimiser, the fp64 staging sums, the bucket slices of the
+# flat gradient buffer) then has to reproduce the single-GPU step on that batch: SyncBatchNorm over two copies of a batch
+# has the batch's own statistics, the summed gradient is twice the gradient.  A wrong M * world, a missing 1 / world, a
+# slice no bucket covers or a slice reduced twice all change the result.
+def _two_identical_ranks(check=None):
+    import torch
+    from conftest import load_pkg
+    DistContext = load_pkg('model').DistContext
+
+    class TwoIdenticalRanks(DistContext):
+        def __init__(self, sync_bn=True, n_buckets=4):
+            self.dist = None
+            self.world_size, self.rank = 2, 0
+            self.sync_bn, self.n_buckets = sync_bn, n_buckets
+            self._streams, self._bn_pg = {}, None
+            self.buckets = []           # (lo element, n elements) of every gradient-bucket all-reduce of the last step
+            self.bn_calls = 0
+
+        def broadcast(self, t, src=0):
+            pass
+
+        def all_reduce(self, t):
+            self.bn_calls += 1
+            t.mul_(2)
+
+        def all_reduce_async(self, t):
+            if check is not None:
+                check(self, t)
+            side = self._side('grad')
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                t.mul_(2)
+
+        def bn_all_reduce_begin(self, t):
+            self.bn_calls += 1
+            side = self._side('bn')
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                t.mul_(2)
+    return TwoIdenticalRanks
+
+
+def _trajectory(model_type, H, W, N, dist_ctx, steps, graphs, seed=5, OS=16):
+    """(losses, weights after `steps` steps) of a fresh model; dropout and weights are seeded identically for every call"""
+    import numpy as np
+    import torch
+    from conftest import load_pkg
+    pkg = load_pkg()
+    m = pkg.get_deeplabv3p_model(model_type, 21, (H, W), OS, training=True)
+    m.compile(optimizer=pkg.SGD(0.02, momentum=0.9), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255),
+              distributed=dist_ctx if dist_ctx is not None else False)
+    m.use_graphs = graphs
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-1, 1, (N, H, W, 3)).astype(np.float32)
+    y = rng.integers(0, 21, (N, H * W, 1)).astype(np.float32)
+    y[rng.uniform(size=y.shape) < 0.05] = 255
+    losses = [m.train_on_batch(x, y) for _ in range(steps)]
+    torch.cuda.synchronize()
+    return losses, m.get_weights_by_name(), m
+
+
+@pytest.mark.parametrize('model_type,H,W', [('mobilenetv2', 65, 65), ('xception', 65, 65), ('mobilenetv3large', 64, 96)])
+@pytest.mark.parametrize('graphs', [False, True])
+def test_two_identical_ranks_reproduce_the_single_gpu_step(model_type, H, W, graphs, monkeypatch):
+    import numpy as np
+    ctx = _two_identical_ranks()()
+    # the single-GPU reference without its folded BatchNorm-backward apply (dz = A g m - C z + D against
+    # c0 (g m - c1 - xhat c2), DESIGN section 7: equal to rounding only, and three steps amplify rounding): the data-parallel
+    # path has no fold, and x2 / x0.5 are exact in binary floating point, so the two trajectories must be IDENTICAL
+    monkeypatch.setenv('DL3P_FOLD_APPLY', '0')
+    ref_l, ref_w, _ = _trajectory(model_type, H, W, 2, None, 3, graphs)
+    monkeypatch.delenv('DL3P_FOLD_APPLY')
+    got_l, got_w, m = _trajectory(model_type, H, W, 2, ctx, 3, graphs)
+    ex = m._executor(2, True)
+    assert ex.dist is ctx and ex.sync_bn and ctx.bn_calls > 0
+    assert got_l == ref_l, (got_l, ref_l)
+    worst = max((float(np.abs(got_w[k] - ref_w[k]).max()), k) for k in ref_w)
+    assert worst[0] == 0.0, worst
+
+
+def test_two_identical_ranks_match_the_oracle():
+    """the same double against the float64 oracle on that batch: loss, gradients (after the 1 / world scaling the optimiser
+    applies) through the updated weights"""
+    import numpy as np
+    from test_model_gpu import _pair, _data, _act_derivs, _act_derivs_seq
+    from conftest import load_pkg
+    pkg = load_pkg()
+    N, C, H, W = 2, 21, 65, 65
+    m, o = _pair('mobilenetv2', H, W, C)
+    ctx = _two_identical_ranks()()
+    m.compile(optimizer=pkg.SGD(0.01), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255), distributed=ctx)
+    m.use_graphs = False
+    x, y = _data(N, H, W, C, seed=3)
+    loss = m.train_on_batch(x, y)
+    ex = m._executor(N, True)
+    assert ex.dist is ctx
+    drop = [op for op in m.graph.ops if op.kind == 'materialize' and op.rate > 0][0]
+    mask = ex.dropout_mask(drop).cpu().numpy()
+    o.net.act_derivs = _act_derivs(m, ex)
+    o.net.act_derivs_seq = _act_derivs_seq(m, ex, o.net.act_derivs)
+    total, ce, logits = o.loss_and_grads(x, y, {'aspp_dropout': mask})
+    assert abs(loss - ce) < 1e-3 * max(1.0, abs(ce)), (loss, ce)
+    st = m._store
+    for p in m.graph.all_params():
+        if p.trainable and np.abs(o.net.grads[p.name]).max() > 1e-7:
+            g = st.get(p, st.G) / 2.0                 # the flat buffer holds the SUM over the two ranks
+            r = float(np.abs(g - o.net.grads[p.name]).max() / max(1e-6, np.abs(o.net.grads[p.name]).max()))
+            assert r < 8e-3, (p.name, r)
+    o.sgd_step(0.01, 0.9)
+    w = m.get_weights_by_name()
+    for k, v in w.items():
+        assert np.abs(v - o.net.params[k]).max() < 1e-3 * max(1.0, np.abs(o.net.params[k]).max()), k
+
+
+@pytest.mark.parametrize('model_type', ['mobilenetv2', 'xception', 'resnet50'])
+def test_every_gradient_is_final_when_its_bucket_is_reduced(model_type):
+    """NaN canary: the gradient slots of every trainable parameter are filled with NaN before backward; at each bucket's
+    all-reduce (eager mode, so the double sees the live buffer) the slice must be NaN-free -- a gradient still to be written,
+    or a deferred weight gradient / slab reduction that had not run yet, would show -- and the slices tile the buffer"""
+    import numpy as np
+    import torch
+    from conftest import load_pkg
+    pkg = load_pkg()
+    seen = []
+
+    def check(ctx, t):
+        torch.cuda.synchronize()
+        bad = int(torch.isnan(t).sum().item())
+        seen.append((t.data_ptr(), t.numel(), bad))
+    ctx = _two_identical_ranks(check)()
+    H = W = 65
+    m = pkg.get_deeplabv3p_model(model_type, 21, (H, W), 16, training=True)
+    m.compile(optimizer=pkg.SGD(0.01), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255), distributed=ctx)
+    m.use_graphs = False
+    rng = np.random.default_rng(1)
+    x = rng.uniform(-1, 1, (2, H, W, 3)).astype(np.float32)
+    y = rng.integers(0, 21, (2, H * W, 1)).astype(np.float32)
+    ex = m._executor(2, True)             # the trace runs every launch once
+    st = m._store
+    del seen[:]
+    ex.set_inputs(x, y)
+    ex.lr.fill_(0.01)
+    ex.fwd.run()
+    for p in m.graph.all_params():
+        if p.trainable:
+            st.view(p, st.G).fill_(float('nan'))
+    ex.bwd.run()
+    torch.cuda.synchronize()
+    assert len(seen) == ctx.n_buckets, seen
+    assert all(bad == 0 for _, _, bad in seen), [(n, bad) for _, n, bad in seen]
+    # the slices tile [0, total) of the flat gradient buffer, back to front
+    base = st.G.data_ptr()
+    spans = sorted(((ptr - base) // 4, (ptr - base) // 4 + n) for ptr, n, _ in seen)
+    assert spans[0][0] == 0 and spans[-1][1] == st.total and all(a[1] == b[0] for a, b in zip(spans, spans[1:])), spans
+    ex.opt.run()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(st.P).all())

@@ -740,3 +740,58 @@ def test_backward_shortcuts_do_not_change_gradients(model_type, H, W, monkeypatc
         if r > worst[1]:
             worst = (name, r)
     assert worst[1] < 3e-3, worst
+
+
+@pytest.mark.parametrize('rule', ['biased', 'unbiased'])
+def test_bn_moving_variance_rule(rule):
+    """get_deeplabv3p_model(..., bn_moving_variance=...) (layers.py:63-70 resolves to SyncBatchNormalization or to
+    the fused BatchNormalization): after one train step every moving_variance follows the oracle built with the same rule,
+    image_pooling_BN (2 samples per channel: the two rules differ by a factor 2 in the batch term) included"""
+    pkg = load_pkg()
+    N, C, H, W = 2, 21, 65, 65
+    m = pkg.get_deeplabv3p_model('mobilenetv2', C, (H, W), 16, training=True, bn_moving_variance=rule)
+    m.compile(optimizer=pkg.SGD(0.01), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
+    o = OracleModel('mobilenetv2', C, (H, W), 16, dtype=np.float64, seed=0, bn_moving_variance=rule)
+    m.set_weights_by_name(dict(o.net.params))
+    m.use_graphs = False
+    x, y = _data(N, H, W, C, seed=9)
+    m.train_on_batch(x, y)
+    ex = m._executor(N, True)
+    drop = [op for op in m.graph.ops if op.kind == 'materialize' and op.rate > 0][0]
+    o.loss_and_grads(x, y, {'aspp_dropout': ex.dropout_mask(drop).cpu().numpy()})
+    o.sgd_step(0.01, 0.9)
+    w = m.get_weights_by_name()
+    n = 0
+    for k, v in w.items():
+        if k.endswith('moving_variance'):
+            assert np.abs(v - o.net.params[k]).max() < 2e-5 * max(1.0, np.abs(o.net.params[k]).max()), k
+            n += 1
+    assert n >= 60
+    with pytest.raises(ValueError):
+        pkg.get_deeplabv3p_model('mobilenetv2', C, (H, W), 16, bn_moving_variance='bessel')
+
+
+def test_recompile_with_a_new_optimizer_keeps_the_dropout_stream():
+    """train.py:190-224: the second training stage builds a NEW optimizer and compiles again.  Its iteration counter and
+    slots restart; the dropout stream must not (Keras' dropout RNG is independent of optimizer.iterations): the masks of
+    stage 2 are new ones, not a replay of stage 1's."""
+    pkg = load_pkg()
+    N, C, H, W = 2, 21, 65, 65
+    m = pkg.get_deeplabv3p_model('mobilenetv2_lite', C, (H, W), 16, training=True)
+    m.compile(optimizer=pkg.Adam(1e-3), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
+    m.use_graphs = False
+    x, y = _data(N, H, W, C, seed=1)
+    drop = [op for op in m.graph.ops if op.kind == 'materialize' and op.rate > 0][0]
+    masks = []
+    for _ in range(2):
+        m.train_on_batch(x, y)
+        masks.append(m._executor(N, True).dropout_mask(drop).cpu().numpy().copy())
+    st = m._store
+    assert int(st.step.item()) == 2 and int(st.opt_step.item()) == 2
+    m.compile(optimizer=pkg.Adam(1e-3), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
+    assert int(st.step.item()) == 2 and int(st.opt_step.item()) == 0 and float(st.V.abs().max()) == 0.0
+    m.train_on_batch(x, y)
+    masks.append(m._executor(N, True).dropout_mask(drop).cpu().numpy().copy())
+    assert int(st.step.item()) == 3 and int(st.opt_step.item()) == 1
+    assert not np.array_equal(masks[2], masks[0]) and not np.array_equal(masks[2], masks[1]) and not np.array_equal(masks[0], masks[1])
+    assert 0.4 < masks[2].mean() < 0.6

@@ -433,6 +433,12 @@ def test_batchnorm_fwd_bwd(ops, shape, act):
     close(bn.shift, beta - z.reshape(-1, C).mean(0) * gamma * cache[1], what='shift', atol=1e-4)
     close(bn.moving_mean, 0 * mom + bm * (1 - mom), what='moving mean', atol=1e-5)
     close(bn.moving_var, 1 * mom + bv * (1 - mom), what='moving var', atol=1e-5)
+    # update_moving = 2: the Bessel-corrected variance of the fused BatchNormalization (np_ops.bn_moving_variance_of)
+    bn.moving_mean.zero_(); bn.moving_var.fill_(1.0)
+    ops.bn_finalize(bn, part, rows, M, update_moving=2)
+    close(bn.moving_var, 1 * mom + O.bn_moving_variance_of(bv, M, 'unbiased') * (1 - mom), what='moving var (unbiased)', atol=1e-5)
+    close(bn.moving_mean, 0 * mom + bm * (1 - mom), what='moving mean', atol=1e-5)
+    close(bn.scale, gamma * cache[1], what='scale (unchanged by the moving rule)')
     a = ops.affine_act(zz, bn.scale, bn.shift, act)
     close(a, O.act_fwd(y_ref, act), rtol=3e-4, atol=1e-4, what='bn apply + act')
     g = rng.standard_normal(shape)

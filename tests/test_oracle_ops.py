@@ -95,6 +95,11 @@ def test_batchnorm_matches_torch():
     np.testing.assert_allclose(O.bn_moving_update(np.zeros(4), bm, mom), rm.numpy(), atol=1e-12)
     m = x.size // 4
     np.testing.assert_allclose(O.bn_moving_update(np.ones(4), bv * m / (m - 1), mom), rv.numpy(), atol=1e-12)
+    # the two rules of np_ops.bn_moving_variance_of: 'unbiased' IS what a fused batch-norm kernel feeds its running
+    # variance (torch's does the same as TF's FusedBatchNormV3), 'biased' the plain E[x^2] - E[x]^2 of Keras' non-fused path
+    np.testing.assert_allclose(O.bn_moving_update(np.ones(4), O.bn_moving_variance_of(bv, m, 'unbiased'), mom), rv.numpy(), atol=1e-12)
+    np.testing.assert_allclose(O.bn_moving_variance_of(bv, m, 'biased'), x.reshape(-1, 4).var(0), atol=1e-12)
+    np.testing.assert_allclose(O.bn_moving_variance_of(bv, m, 'unbiased'), x.reshape(-1, 4).var(0, ddof=1), atol=1e-12)
     gy = RNG.standard_normal(y.shape)
     yt.backward(nchw(gy))
     gx, gg, gb = O.bn_train_bwd(gy, cache)
@@ -215,3 +220,38 @@ def test_whole_model_matches_torch_autograd(mt):
     for k, g in o.net.grads.items():
         if np.abs(g).max() > 1e-7:                            # (a beta in front of conv + BN has an exactly-zero gradient)
             assert np.abs(g - t.net.grads[k]).max() < 1e-5 * np.abs(g).max(), k
+
+
+def test_moving_variance_rule_reaches_the_model():
+    """OracleModel(bn_moving_variance=...): one train step moves every moving_variance by the rule chosen, the
+    two differ by exactly count / (count - 1) in the batch term, and nothing else (loss, gradients, moving means) differs"""
+    from oracle.np_net import OracleModel
+    rng = np.random.default_rng(2)
+    x = rng.uniform(-1, 1, (2, 33, 33, 3))
+    y = rng.integers(0, 5, (2, 33 * 33, 1)).astype(np.float64)
+    res = {}
+    for rule in ('biased', 'unbiased'):
+        o = OracleModel('mobilenetv2_lite', 5, (33, 33), 16, dtype=np.float64, seed=0, bn_moving_variance=rule)
+        mv0 = {k: v.copy() for k, v in o.net.params.items() if k.endswith('moving_variance')}
+        out = o.loss_and_grads(x, y, {})
+        o.sgd_step(0.01, 0.9)
+        res[rule] = (out[0], {k: v.copy() for k, v in o.net.grads.items()}, dict(o.net.params), mv0)
+    (la, ga, pa, mv0), (lb, gb, pb, _) = res['biased'], res['unbiased']
+    assert la == lb and all(np.array_equal(ga[k], gb[k]) for k in ga)
+    checked = 0
+    for k in pa:
+        if k.endswith('moving_variance'):
+            mom = 0.999 if k.startswith(('Conv', 'expanded_conv', 'bn_Conv1')) else 0.99
+            batch_a = (pa[k] - mom * mv0[k]) / (1 - mom)
+            batch_b = (pb[k] - mom * mv0[k]) / (1 - mom)
+            # image_pooling_BN normalises N = 2 samples per channel: count / (count - 1) = 2
+            count = 2 if k.startswith('image_pooling') else None
+            ratio = batch_b[batch_a > 1e-12] / batch_a[batch_a > 1e-12]
+            if count:
+                np.testing.assert_allclose(ratio, 2.0, rtol=1e-6)
+                checked += 1
+            else:
+                assert np.all(ratio > 1.0) and np.all(ratio < 1.13), (k, ratio.min(), ratio.max())
+        else:
+            assert np.array_equal(pa[k], pb[k]), k
+    assert checked == 1

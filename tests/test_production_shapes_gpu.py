@@ -42,7 +42,8 @@ def rel(got, want):
 
 
 # ------------------------------------------------------------------------------------------- whole model, 513 x 513
-@pytest.mark.parametrize('model_type', ['mobilenetv2', 'mobilenetv2_lite'])
+# (+ Xception, BASELINE configs[2]: the fp64 oracle needs ~50 s per image for it on 8 cores)
+@pytest.mark.parametrize('model_type', ['mobilenetv2', 'mobilenetv2_lite', 'xception'])
 def test_train_step_513_production_dispatch(model_type):
     from test_model_gpu import _pair, _data, _act_derivs, _act_derivs_seq, _rel
     N, C, H, W = 2, 21, 513, 513
@@ -91,7 +92,15 @@ def test_train_step_513_production_dispatch(model_type):
 # expanded_conv_1_expand / expanded_conv_1_project (257 x 257 -> tiled + streaming kernels), feature_projection0,
 # concat_projection (33 x 33, K = 1280) and the 21-class head (N padded to 24)
 PW_PROD = [(16 * 129 * 129, 304, 256), (16 * 129 * 129, 256, 256), (16 * 257 * 257, 16, 96), (16 * 257 * 257, 96, 24),
-           (16 * 129 * 129, 24, 48), (16 * 33 * 33, 1280, 256), (16 * 129 * 129, 256, 24), (16 * 33 * 33, 960, 160)]
+           (16 * 129 * 129, 24, 48), (16 * 33 * 33, 1280, 256), (16 * 129 * 129, 256, 24), (16 * 33 * 33, 960, 160),
+           # BASELINE configs[2] / [3] / [4] at their per-GPU launch shapes: Xception 513 x 513 batch 4
+           # (33 x 33 maps: middle flow 728 -> 728, exit flow 1536 -> 2048, ASPP 2048 -> 256, concat 1280 -> 256; decoder
+           # 129 x 129), Xception 769 x 769 OS 8 batch 2 (97 x 97 and 193 x 193 maps), MobileNetV3-Large 1024 x 2048 batch 1
+           # in fp32 (decoder 256 x 512 x 304 -> 256)
+           (4 * 33 * 33, 728, 728), (4 * 33 * 33, 1536, 2048), (4 * 33 * 33, 2048, 256), (4 * 33 * 33, 1280, 256),
+           (4 * 129 * 129, 304, 256), (4 * 65 * 65, 256, 728), (2 * 97 * 97, 728, 728), (2 * 97 * 97, 2048, 256),
+           (2 * 97 * 97, 1536, 2048), (2 * 193 * 193, 304, 256), (2 * 193 * 193, 256, 20), (256 * 512, 304, 256),
+           (256 * 512, 256, 20), (64 * 128, 960, 160)]
 
 
 @pytest.mark.parametrize('case', PW_PROD)
@@ -146,7 +155,14 @@ def test_pointwise_at_config1_shapes(ops, case):
 # expanded_conv_depthwise (257 x 257 x 32), the three ASPP branches (rate 18 = the roofline kernel) and a rate-2 block
 DW_PROD = [(16, 129, 129, 304, 3, 1, 1), (16, 257, 257, 96, 3, 2, 1), (16, 257, 257, 32, 3, 1, 1),
            (16, 33, 33, 320, 3, 1, 18), (16, 33, 33, 320, 3, 1, 12), (16, 33, 33, 320, 3, 1, 6),
-           (16, 33, 33, 960, 3, 1, 2), (16, 65, 65, 192, 3, 2, 1)]
+           (16, 33, 33, 960, 3, 1, 2), (16, 65, 65, 192, 3, 2, 1),
+           # configs[2]: Xception batch 4, the three ASPP rates on 33 x 33 x 2048 (rate 18 = dw_fwd_lattice2 at N = 4), exit flow
+           # rate 2, entry flow stride 2; configs[3]: OS 8 batch 2, ASPP 12 / 24 / 36 on 97 x 97 x 2048, middle flow rate 2, exit
+           # flow rate 4; configs[4] (fp32 twin): 5 x 5 rate 2 on 64 x 128 x 960, ASPP on 64 x 128 x 160
+           (4, 33, 33, 2048, 3, 1, 6), (4, 33, 33, 2048, 3, 1, 12), (4, 33, 33, 2048, 3, 1, 18), (4, 33, 33, 1536, 3, 1, 2),
+           (4, 65, 65, 728, 3, 2, 1), (2, 97, 97, 2048, 3, 1, 12), (2, 97, 97, 2048, 3, 1, 24), (2, 97, 97, 2048, 3, 1, 36),
+           (2, 97, 97, 728, 3, 1, 2), (2, 97, 97, 1536, 3, 1, 4), (1, 64, 128, 960, 5, 1, 2), (1, 64, 128, 160, 3, 1, 6),
+           (1, 64, 128, 160, 3, 1, 12), (1, 64, 128, 160, 3, 1, 18)]
 
 
 @pytest.mark.parametrize('case', DW_PROD)

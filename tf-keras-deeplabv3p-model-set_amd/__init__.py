@@ -10,6 +10,7 @@ from .model import (get_deeplabv3p_model, deeplab_model_map, DeeplabModel, SGD, 
                     miou_from_confusion, Jaccard, jaccard_from_counts, EvalCallBack)
 
 from . import mixed_precision  # noqa: F401,E402
+from . import watchdog  # noqa: F401,E402
 
 __all__ = ['get_deeplabv3p_model', 'deeplab_model_map', 'DeeplabModel', 'SGD', 'Adam', 'RMSprop', 'get_optimizer',
            'SparseCategoricalCrossEntropy', 'WeightedSparseCategoricalCrossEntropy', 'SparseSoftmaxFocalLoss',

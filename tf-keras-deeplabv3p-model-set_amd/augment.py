@@ -77,13 +77,19 @@ def random_sharpness(images, jitter=.5):
 
 
 def random_crop(images, labels, crop_shape, prob=.1):
-    """the crop branch of the reference's random_crop for a batch (one draw for the batch: every image must end with the
-    same shape); returns the inputs unchanged when the draw says no or the window is not smaller than the image (the
-    reference then resizes with cv2, which stays on the host)"""
+    """the crop branch of the reference's random_crop (common/data_utils.py:364-400) for a batch.  DEVIATION, by
+    construction: the reference decides `rand() < prob` per image; a batch tensor needs one output shape, so the decision is
+    drawn ONCE for the batch.  Within a cropping batch the window of every image is drawn as the reference draws it -- x
+    (`randrange(W - crop_w)`) first, then y (data_utils.py:390-391) -- so a seeded `random` yields the reference's windows.
+    Returns the inputs unchanged when the draw says no or the window is not smaller than the image (the reference then
+    resizes with cv2, which stays on the host)."""
     import random
     N, H, W, _ = images.shape
     if not (rand() < prob) or not (crop_shape[0] < H and crop_shape[1] < W):
         return images, labels
-    yx = [(random.randrange(H - crop_shape[0]), random.randrange(W - crop_shape[1])) for _ in range(N)]
-    yx = [(y, x) for (y, x) in yx]
+    yx = []
+    for _ in range(N):
+        x = random.randrange(W - crop_shape[1])
+        y = random.randrange(H - crop_shape[0])
+        yx.append((y, x))
     return flip_crop(images, labels, None, yx, tuple(crop_shape))

@@ -344,9 +344,13 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* partials
     save_mean[c] = (float)mean;
     save_invstd[c] = invstd;
     if (update_moving) {
-      // SyncBatchNormalization (non-fused Keras path): the biased batch variance feeds the moving average too
+      // update_moving 1: the biased batch variance feeds the moving average too (Keras' non-fused path =
+      // SyncBatchNormalization, layers.py:65-66); 2: Bessel-corrected, count / (count - 1) (the fused FusedBatchNormV3 kernel
+      // behind plain BatchNormalization, layers.py:68 -- what the string compare at layers.py:64 selects under the pinned
+      // tensorflow==2.11.0)
+      const double mvar = (update_moving == 2 && count > 1.0) ? var * (count / (count - 1.0)) : var;
       moving_mean[c] = mm * momentum + (float)mean * (1.f - momentum);
-      moving_var[c] = mv * momentum + (float)var * (1.f - momentum);
+      moving_var[c] = mv * momentum + (float)mvar * (1.f - momentum);
     }
   }
 }

@@ -1470,3 +1470,42 @@ extern "C" int dl3p_dwconv2d_bwd_weight_slabs(const float* x, int ldx, const flo
   return dwconv2d_bwd_weight_impl(x, ldx, in_scale, in_shift, in_act, dy, lddy, nullptr, workspace, workspace_bytes, N, H, W, C,
                                   k, stride, rate, pad_t, pad_l, Ho, Wo, rows_out, stream);
 }
+
+// ------------------------------------------------------------------------------ plan query (include/dl3p.h)
+// the decomposition the entry points above would launch for this conv, reported instead of launched
+extern "C" int dl3p_dw_plan_query(int role, int N, int H, int W, int C, int k, int stride, int rate, int pad_t, int pad_l, int Ho,
+                                  int Wo, int* out6) {
+  DL3P_CHECK_ARG(out6 && role >= 0 && role <= 3 && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && (k == 3 || k == 5) &&
+                     stride >= 1 && rate >= 1 && Ho > 0 && Wo > 0, "dl3p_dw_plan_query: bad arguments");
+  for (int i = 0; i < 6; ++i) out6[i] = 0;
+  alignas(16) static float dummy[4];
+  DwParams p = {};
+  p.C = C; p.N = N; p.w = dummy;
+  pick_lanes(C, &p.c4s, &p.px, &p.nslab);
+  int kind;
+  if (role == 0) {
+    p.x = dummy; p.ldx = C; p.y = dummy; p.ldy = C;
+    p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.rate = rate; p.pad_t = pad_t; p.pad_l = pad_l;
+    kind = plan_forward(p, k);
+  } else if (role == 1 || role == 2) {
+    if (role == 2) p.bb_z = dummy;
+    if (stride == 1 && (role == 1 || k == 3)) {
+      p.x = dummy; p.ldx = C; p.y = dummy; p.ldy = C; p.flip = 1;
+      p.H = Ho; p.W = Wo; p.Ho = H; p.Wo = W; p.stride = 1; p.rate = rate;
+      p.pad_t = rate * (k - 1) - pad_t; p.pad_l = rate * (k - 1) - pad_l;
+      kind = plan_forward(p, k);
+    } else {
+      out6[0] = 4;          // stride-2 quads / strided gather of the data gradient: no row bands, no table
+      return DL3P_OK;
+    }
+  } else {
+    p.x = dummy; p.ldx = C; p.dy = dummy; p.lddy = C;
+    p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.rate = rate; p.pad_t = pad_t; p.pad_l = pad_l;
+    p.ks5 = k == 5;
+    static const int dww_per_cu = getenv("DL3P_DWW_PER_CU") ? atoi(getenv("DL3P_DWW_PER_CU")) : 2;
+    static const int wrows = getenv("DL3P_DW5_WROWS") ? atoi(getenv("DL3P_DW5_WROWS")) : 2;
+    kind = fwd_plan(p, dww_per_cu, k == 5 && stride == 1 && wrows > 0, wrows);
+  }
+  out6[0] = kind; out6[1] = p.tw; out6[2] = p.th; out6[3] = p.nbands; out6[4] = p.nbx; out6[5] = dw_tuned_lookup(p) != nullptr;
+  return DL3P_OK;
+}

@@ -1931,3 +1931,35 @@ extern "C" int dl3p_conv2d_gemm_bwd_weight_slabs(const float* x, int ldx, const 
   return conv2d_gemm_bwd_weight_impl(x, ldx, in_scale, in_shift, in_act, dy, lddy, nullptr, nullptr, workspace, workspace_bytes,
                                      N, H, W, Cin, Cout, k, stride, rate, pad_t, pad_l, Ho, Wo, rows_out, stream);
 }
+
+// ------------------------------------------------------------------------------ plan query (include/dl3p.h)
+// the same decisions the entry points above take, reported instead of launched
+extern "C" int dl3p_gemm_plan_query(int role, int M, int K, int N, int* out6) {
+  DL3P_CHECK_ARG(out6 && role >= 0 && role <= 4 && M > 0 && K > 0 && N > 0, "dl3p_gemm_plan_query: bad arguments");
+  for (int i = 0; i < 6; ++i) out6[i] = 0;
+  SmallShape sh;
+  if (role == 4) {
+    if (dl3p_pw_tiny_applies(M)) { out6[0] = 2; return DL3P_OK; }
+    if (M >= 16 && wgrad_small_pick(K, N, &sh)) {
+      out6[0] = 1; out6[1] = sh.kt; out6[2] = sh.ntn; out6[4] = wgrad_small_grid(M, sh.kt, sh.ntn);
+      return DL3P_OK;
+    }
+    int kw, nw, kt, nt, splits, mchunk;
+    wgrad_pick_tile(M, K, N, &kw, &nw);
+    wgrad_split(M, K, N, &kt, &nt, &splits, &mchunk);
+    out6[1] = (kw == 2 ? 1 : 0) + (nw == 8 ? 2 : 0);
+    const GemmTuned* e = gemm_tuned_lookup(4, M, K, N);
+    out6[2] = g_wgrad_force_per_cu ? g_wgrad_force_per_cu : (e ? e->mi : 0);
+    out6[3] = kt * nt; out6[4] = splits; out6[5] = e != nullptr;
+    return DL3P_OK;
+  }
+  if (dl3p_pw_tiny_applies(M)) { out6[0] = 2; return DL3P_OK; }
+  if (M >= pw_small_min_rows() && pw_small_pick(K, N, &sh)) {
+    out6[0] = 1; out6[1] = sh.kt; out6[2] = sh.ntn; out6[3] = pw_small_grid(M);
+    return DL3P_OK;
+  }
+  int nt, gx, gy, mt, mi;
+  gemm_plan(role, M, K, N, &nt, &gx, &gy, &mt, &mi);
+  out6[1] = nt; out6[2] = mi; out6[3] = gx; out6[4] = gy; out6[5] = gemm_tuned_lookup(role, M, K, N) != nullptr;
+  return DL3P_OK;
+}

@@ -42,6 +42,10 @@ class ParamStore:
         # optimiser iteration counter (Adam's bias correction, the dropout stream): one per model, shared by the
         # executors of every batch size, so a last partial batch continues the count instead of restarting it
         self.step = torch.zeros(1, dtype=torch.int64, device=device)
+        # Adam's iteration count (bias correction) is a separate counter: compile() with a NEW optimizer object restarts it
+        # (train.py:190-224 builds a fresh optimizer for the second stage) while the dropout stream above keeps counting --
+        # in Keras the dropout RNG does not depend on optimizer.iterations, so stage 2 must not replay stage 1's masks
+        self.opt_step = torch.zeros(1, dtype=torch.int64, device=device)
         self.l2 = torch.zeros(off, **f)
         self.lr_scale = torch.zeros(off, **f)
         # transposed copies [N][K] of the pointwise / im2col'd kernels (same offsets as in P): the forward GEMM reads
@@ -334,6 +338,9 @@ class Executor:
             store.V2 = torch.zeros_like(store.V)
         self.dev = store.device
         self.L = lib()
+        # which batch variance feeds BatchNormalization's moving average (dl3p_bn_finalize update_moving): 1 biased (Keras
+        # SyncBatchNormalization), 2 Bessel-corrected (fused BatchNormalization); graph.bn_moving_variance, model.py
+        self.moving_mode = 2 if getattr(graph, 'bn_moving_variance', 'biased') == 'unbiased' else 1
         self.f32 = dict(dtype=torch.float32, device=self.dev)
         # mixed precision (train.py:37-46, BASELINE configs[4]): activations / activation gradients in bf16, fp32 everywhere
         # else; the logits tensor (conv_upsample output) and its gradient stay fp32 so the softmax / loss head is unchanged
@@ -341,7 +348,7 @@ class Executor:
         self.adt = torch.bfloat16 if self.bf16 else torch.float32
         self._alloc()
         # tracing runs every kernel once on zero inputs: keep the weights / optimiser state intact
-        snap_p, snap_v, snap_step = store.P.clone(), store.V.clone(), store.step.clone()
+        snap_p, snap_v, snap_step, snap_ostep = store.P.clone(), store.V.clone(), store.step.clone(), store.opt_step.clone()
         snap_v2 = store.V2.clone() if store.V2 is not None else None
         if training:
             self.fwd = self._trace_forward()
@@ -356,6 +363,7 @@ class Executor:
             store.V2.copy_(snap_v2)
         store.transpose()
         store.step.copy_(snap_step)
+        store.opt_step.copy_(snap_ostep)
         self.graphed = False
 
     # ---------------------------------------------------------------- buffers
@@ -565,6 +573,8 @@ class Executor:
         train = self.training
         if train:
             P.k(L.increment_counter, self.step.data_ptr())
+            if self.optimizer[0] == 'adam':
+                P.k(L.increment_counter, self.store.opt_step.data_ptr())
         self._fwd_pending, self._fwd_stage_off = [], 0
         for op in self.g.ops:
             k = op.kind
@@ -711,8 +721,8 @@ class Executor:
             rows = op.producer.rows
             sums = None
             P.k(L.bn_finalize, self.partials.data_ptr(), rows, sums, bn.C, count, st.ptr(lp['gamma']),
-                st.ptr(lp['beta']), bn.eps, bn.momentum, st.ptr(lp['moving_mean']), st.ptr(lp['moving_variance']), 1,
-                sp, hp, aux['mean'].data_ptr(), aux['invstd'].data_ptr())
+                st.ptr(lp['beta']), bn.eps, bn.momentum, st.ptr(lp['moving_mean']), st.ptr(lp['moving_variance']),
+                self.moving_mode, sp, hp, aux['mean'].data_ptr(), aux['invstd'].data_ptr())
         else:
             P.k(L.bn_infer_coeffs, st.ptr(lp['gamma']), st.ptr(lp['beta']), st.ptr(lp['moving_mean']),
                 st.ptr(lp['moving_variance']), bn.eps, sp, hp, aux['mean'].data_ptr(), aux['invstd'].data_ptr(), bn.C)
@@ -744,8 +754,8 @@ class Executor:
             hp = self.gshift[bn.group.id].data_ptr() + 4 * bn.offset
             count = float(self.N * op.z.H * op.z.W) * self.dist.world_size
             P.k(L.bn_finalize, None, 0, self.sync_stage[off:].data_ptr(), bn.C, count, st.ptr(lp['gamma']),
-                st.ptr(lp['beta']), bn.eps, bn.momentum, st.ptr(lp['moving_mean']), st.ptr(lp['moving_variance']), 1,
-                sp, hp, aux['mean'].data_ptr(), aux['invstd'].data_ptr())
+                st.ptr(lp['beta']), bn.eps, bn.momentum, st.ptr(lp['moving_mean']), st.ptr(lp['moving_variance']),
+                self.moving_mode, sp, hp, aux['mean'].data_ptr(), aux['invstd'].data_ptr())
         P.ctx = ctx
 
     # ---------------------------------------------------------------- backward
@@ -1363,7 +1373,7 @@ class Executor:
         if kind == 'adam':
             _, b1, b2, eps = self.optimizer
             P.k(L.adam_step, st.P.data_ptr(), st.V.data_ptr(), st.V2.data_ptr(), st.G.data_ptr(), st.total,
-                self.lr.data_ptr(), self.step.data_ptr(), b1, b2, eps, scale, st.l2.data_ptr(), st.lr_scale.data_ptr())
+                self.lr.data_ptr(), st.opt_step.data_ptr(), b1, b2, eps, scale, st.l2.data_ptr(), st.lr_scale.data_ptr())
         elif kind == 'rmsprop':
             _, rho, eps = self.optimizer
             P.k(L.rmsprop_step, st.P.data_ptr(), st.V.data_ptr(), st.G.data_ptr(), st.total, self.lr.data_ptr(), rho, eps,

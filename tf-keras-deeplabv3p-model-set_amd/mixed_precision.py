@@ -35,6 +35,10 @@ def set_global_policy(policy):
     name = policy.name if isinstance(policy, Policy) else policy
     if name not in _NAMES:
         raise ValueError('Unknown mixed-precision policy %r' % (name,))
+    if name == 'mixed_float16':
+        import warnings
+        warnings.warn("policy 'mixed_float16' (train.py:41) runs as mixed_bfloat16 on MI355X: bf16 storage, fp32 accumulation, "
+                      "no loss scaling", stacklevel=2)
     _GLOBAL = name
 
 

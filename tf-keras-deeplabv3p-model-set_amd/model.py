@@ -218,7 +218,10 @@ class DistContext:
 
     def _bn_group(self):
         # SyncBatchNorm gets its own communicator (own RCCL stream): a statistics all-reduce never queues behind
-        # a gradient bucket that is still on the wire
+        # a gradient bucket that is still on the wire.  DL3P_ONE_COMM=1 keeps everything on the default communicator
+        # (one of the switches watchdog.FirstStepsGuard names when the first steps of a multi-rank job hang)
+        if os.environ.get('DL3P_ONE_COMM', '0') not in ('', '0'):
+            return None
         if self._bn_pg is None and self.dist.is_initialized() and self.dist.get_backend() == 'nccl':
             self._bn_pg = self.dist.new_group(backend='nccl')
         return self._bn_pg
@@ -341,7 +344,11 @@ class DeeplabModel:
             import torch.distributed as dist
             distributed = dist.is_available() and dist.is_initialized() and (
                 dist.get_world_size() > 1 or bool(os.environ.get('DL3P_FORCE_DIST')))
-        self.dist = DistContext(sync_bn) if distributed else None
+        if os.environ.get('DL3P_SYNC_BN', '1') in ('0',):
+            sync_bn = False            # per-replica BatchNorm statistics (no forward collectives)
+        # `distributed` may also be a DistContext (or a test double of one: tests/test_dist_gpu.py drives the executor's
+        # world-size arithmetic on one GPU with a context whose sum over two identical ranks is a multiplication by 2)
+        self.dist = distributed if isinstance(distributed, DistContext) else (DistContext(sync_bn) if distributed else None)
         self._exec = {}
         if self._store is not None:
             self._store.refresh_masks()
@@ -349,7 +356,7 @@ class DeeplabModel:
                 self._store.V.zero_()
                 if self._store.V2 is not None:
                     self._store.V2.zero_()
-                self._store.step.zero_()
+                self._store.opt_step.zero_()       # (the dropout stream, store.step, keeps counting)
         return self
 
     def _ensure_store(self):
@@ -385,12 +392,23 @@ class DeeplabModel:
         the device from uint8 labels]); returns the data loss"""
         if self.optimizer is None:
             raise RuntimeError('You must compile your model before training')
+        # more than one rank: the executor trace (every collective once), the graph capture and the first replays are where
+        # a multi-process job can hang -- bounded by watchdog.FirstStepsGuard (prints the switches to try, exits non-zero)
+        guarded = self.dist is not None and self.dist.world_size > 1 and self._steps < 3
+        if guarded:
+            from .watchdog import FirstStepsGuard
+            guard = FirstStepsGuard(self.dist.rank, self.dist.world_size, 'train step %d' % self._steps)
+            guard.__enter__()
         ex = self._executor(int(x.shape[0]), True)
         ex.set_inputs(x, y, sample_weight)
         ex.lr.fill_(self.optimizer.lr_at(self.optimizer.iterations))
         if self.use_graphs and not ex.graphed and self._steps_on(ex) >= 1:
             ex.capture()
         ex.train_step()
+        if guarded:
+            import torch
+            torch.cuda.synchronize()
+            guard.__exit__(None, None, None)
         ex._steps = self._steps_on(ex) + 1
         self._steps += 1
         self.optimizer.iterations += 1
@@ -680,14 +698,31 @@ def _evaluate_miou(self, gen, steps=None, class_names=None, verbose=0):
 DeeplabModel.evaluate_miou = _evaluate_miou
 
 
+# model types whose graphs contain ops without a bf16 kernel on the TRAINING path: the data gradient of a dense
+# k x k conv whose input needs a gradient, max pooling
+_NO_BF16_TRAINING = {'xception': 'dense 3x3 entry_flow_conv1_2 needs a bf16 data gradient',
+                     'resnet50': 'dense 3x3 convs and max pooling need bf16 kernels'}
+
+
 def get_deeplabv3p_model(model_type, num_classes, model_input_shape, output_stride, freeze_level=0,
-                         weights_path=None, training=True, use_subpixel=False, seed=0):
+                         weights_path=None, training=True, use_subpixel=False, seed=0, bn_moving_variance='biased'):
+    """deeplabv3p/model.py:51-117, same positional / keyword arguments.  Two extras, keyword-only in spirit:
+    `seed` (weight initialisation) and `bn_moving_variance`, which of the two Keras classes CustomBatchNormalization
+    (layers.py:63-70) can resolve to is restated for the MOVING variance: 'biased' = SyncBatchNormalization, Keras' non-fused
+    path (TF 2.2 .. 2.9, and what north_star asks for: SyncBN over the global batch); 'unbiased' = plain fused
+    BatchNormalization with Bessel's correction, which is what the string compare at layers.py:64 selects under the pinned
+    tensorflow==2.11.0.  Training-mode outputs, losses and gradients do not depend on it; inference after
+    training does (factor count / (count - 1) in the variance each step contributes)."""
+    if bn_moving_variance not in ('biased', 'unbiased'):
+        raise ValueError("bn_moving_variance must be 'biased' or 'unbiased' (got %r)" % (bn_moving_variance,))
     from . import graph as graph_mod, mixed_precision
     bf16 = mixed_precision.is_bf16()        # the global policy at build time, like Keras layers pick theirs up
     graph_mod.CHANNEL_ALIGN = 8 if bf16 else 4
     try:
-        return _build_model(model_type, num_classes, model_input_shape, output_stride, freeze_level, weights_path, training,
-                            use_subpixel, seed, bf16)
+        model = _build_model(model_type, num_classes, model_input_shape, output_stride, freeze_level, weights_path, training,
+                             use_subpixel, seed, bf16)
+        model.graph.bn_moving_variance = model.bn_moving_variance = bn_moving_variance
+        return model
     finally:
         graph_mod.CHANNEL_ALIGN = 4
 
@@ -706,6 +741,11 @@ def _build_model(model_type, num_classes, model_input_shape, output_stride, free
 
     model_function = deeplab_model_map[model_type]
     H, W = model_input_shape
+    if bf16 and training and model_type in _NO_BF16_TRAINING:
+        # the policy of train.py:37-46 applies to every model type there; here the mixed-precision kernels cover the
+        # MobileNet families (BASELINE configs[4]).  Say so when the model is built, not at the first train step.
+        raise ValueError("mixed_bfloat16 training is not built for model type '%s' (%s); build it under the float32 policy"
+                         % (model_type, _NO_BF16_TRAINING[model_type]))
     # the reference builds a 21-class stub head and cuts it off again at layers[-5] (model.py:59-65);
     # the builders here stop at that tensor.  weights=None: offline, random init.
     g, x, backbone_len = model_function(input_shape=(H, W, 3), weights=None, num_classes=21, OS=output_stride,
