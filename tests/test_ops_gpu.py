@@ -34,7 +34,10 @@ def stats_from(partials, rows, C):
 DW_CASES = [
     # N, H, W, C, k, stride, rate, padding
     (2, 33, 33, 320, 3, 1, 18, 'same'),
-    (2, 33, 33, 320, 3, 1, 12, 'same'),
+    (2, 33, 33, 320, 3, 1, 12, 'same'),      # 3 x 3 pixels per residue class: dw_fwd_lattice3
+    (3, 33, 29, 24, 3, 1, 12, 'same'),       # ... ragged: classes of 3 x 3, 3 x 2, 2 x 3 (rows / columns 9 .. 11 hold two pixels)
+    (1, 20, 31, 8, 3, 1, 11, 'same'),        # ... 2 x 3 and 1 x 3 classes
+    (2, 97, 97, 16, 3, 1, 36, 'same'),       # BASELINE configs[3]: ASPP rate 36 on the 97 x 97 map
     (2, 33, 33, 320, 3, 1, 6, 'same'),
     (2, 33, 33, 64, 3, 1, 2, 'same'),
     (2, 17, 19, 144, 3, 1, 1, 'same'),

@@ -191,3 +191,26 @@ def test_dispatch_options_and_tile_table():
             assert 0 <= nt <= 3 and mi >= 1            # weight gradient: tile index, workgroups per CU
         else:
             assert 1 <= nt <= 8 and mi in (1, 2) and 0 <= pc <= 16
+
+
+def test_mixed_precision_policy_is_checked_when_the_model_is_built():
+    """train.py:37-46 applies the policy to every model type; the bf16 kernels cover the MobileNet families.  A model type
+    whose training graph holds an op without a bf16 kernel is refused by get_deeplabv3p_model -- not at the first train
+    step -- and 'mixed_float16' says that it runs as bf16"""
+    import warnings
+    pkg = load_pkg()
+    mp = pkg.mixed_precision
+    try:
+        mp.set_policy(mp.Policy('mixed_bfloat16'))
+        for mt in ('xception', 'resnet50'):
+            with pytest.raises(ValueError, match='mixed_bfloat16 training is not built'):
+                pkg.get_deeplabv3p_model(mt, 21, (65, 65), 16, training=True)
+        m = pkg.get_deeplabv3p_model('mobilenetv3large', 19, (64, 96), 16, training=True)
+        assert m.bf16
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            mp.set_policy(mp.Policy('mixed_float16'))
+        assert any('mixed_bfloat16' in str(x.message) for x in w)
+    finally:
+        mp.set_policy(mp.Policy('float32'))
+    assert not pkg.get_deeplabv3p_model('xception', 21, (65, 65), 16, training=True).bf16

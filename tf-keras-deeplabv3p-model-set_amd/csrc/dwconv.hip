@@ -29,6 +29,7 @@ struct DwParams {
   int flip, accumulate;
   int nt;              // streaming stores for the output (forward role only)
   int tw;              // strip width the plan was made for (3x3 window kernels)
+  int lat;             // residue-lattice kernels (kind 3): pixels per class and dimension, 2 or 3
   // fused BatchNorm-backward statistics (data-gradient role, output = gradient of act(BN(z))): partial rows hold
   // (sum g', sum g' * xhat) as dl3p_bn_bwd_reduce would compute them from the finished gradient
   const float* bb_z; int bb_ldz;
@@ -868,6 +869,108 @@ __global__ __launch_bounds__(256) void dw_fwd_lattice2(DwParams p) {
   if (p.partials) block_reduce_store<2>(s1, active, pl, cl, p.c4s, p.px, cbase4, p.C, p.partials + (size_t)bx * 2 * p.C);
 }
 
+// ------------------------------------------------------------------------------ forward, the atrous rate below it
+// 3*rate >= max(H, W) > 2*rate (ASPP rate 12 on the 33x33 map, rate 36 on the 97x97 map of a 769x769 input at OS 8): a
+// residue class holds at most 3 x 3 pixels and the atrous 3x3 is a dense 3x3 with padding 1 ON the class: its <= 9 outputs
+// depend on exactly its <= 9 inputs.  The same scheme as dw_fwd_lattice2 with a 3 x 3 class per thread: 9 loads feed 9 outputs,
+// every input element crosses the load path once (the per-pixel gather it replaces fetched each element ~5 times and sat at
+// 0.35 of the HBM rate), one class ahead in flight, tap indices compile-time, weights in registers, streaming stores.
+struct Lat3Item { unsigned base; bool rv[3], cv[3]; };
+
+__device__ __forceinline__ void lat3_decode(int s, int end, int rate, int H, int W, Lat3Item& it) {
+  const bool live = s < end;
+  const int pxo = s % rate;
+  const int t2 = s / rate;
+  const int py = t2 % rate;
+  const int n = t2 / rate;
+  it.base = ((unsigned)n * H + (unsigned)py) * W + (unsigned)pxo;       // pixel (a, b) of the class = base + (a * W + b) * rate
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    it.rv[a] = live && py + a * rate < H;
+    it.cv[a] = live && pxo + a * rate < W;
+  }
+}
+
+template <int PRO>
+__global__ __launch_bounds__(256) void dw_fwd_lattice3(DwParams p) {
+  const int b = blockIdx.x;
+  const int slab = b / p.nbx;
+  const int bx = b - slab * p.nbx;
+  const int t = threadIdx.x;
+  const int pl = t / p.c4s;
+  const int cl = t - pl * p.c4s;
+  const bool active = pl < p.px;
+  const int cbase4 = slab * p.c4s;
+  const int c = (cbase4 + cl) * 4;
+  float4 s1[2] = {zero4(), zero4()};
+  if (active) {
+    const int rate = p.rate, H = p.H, W = p.W;
+    const unsigned ldx = (unsigned)p.ldx, ldy = (unsigned)p.ldy;
+    const unsigned rW = (unsigned)rate * (unsigned)W, r1 = (unsigned)rate;
+    const float* xb = p.x + c;
+    float* yb = p.y + c;
+    XcdRange r = xcd_range(p.total, bx, p.nbx, p.px, pl);
+    Lat3Item cur, nxt;
+    float4 in[3][3], inn[3][3];
+    lat3_decode(r.begin, r.end, rate, H, W, cur);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int bb = 0; bb < 3; ++bb)          // unconditional loads (pixel 0 outside the map, masked below): no branch per load
+        in[a][bb] = ld4(xb + ((cur.rv[a] && cur.cv[bb]) ? cur.base + a * rW + bb * r1 : 0u) * ldx);
+    float4 wreg[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wreg[i] = ld4(p.w + (size_t)(p.flip ? 8 - i : i) * p.C + c);
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero4();
+    if (PRO && p.scale) { sc = ld4(p.scale + c); sh = ld4(p.shift + c); }
+    const int act = p.act;
+    const bool nt_store = p.flip == 0;
+    for (int s = r.begin; s < r.end; s += r.step) {
+      lat3_decode(s + r.step, r.end, rate, H, W, nxt);
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb)
+          inn[a][bb] = ld4(xb + ((nxt.rv[a] && nxt.cv[bb]) ? nxt.base + a * rW + bb * r1 : 0u) * ldx);
+      float4 av[3][3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb) {
+          const float4 v = prologue4<PRO>(in[a][bb], sc, sh, act);
+          av[a][bb] = (cur.rv[a] && cur.cv[bb]) ? v : zero4();          // zero padding is in activation space
+        }
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb) {
+          // output (a, bb) of the class: tap (ky, kx) = (a' - a + 1, b' - bb + 1) reads input (a', b'), |a' - a| <= 1
+          float4 acc = zero4();
+#pragma unroll
+          for (int a2 = 0; a2 < 3; ++a2)
+#pragma unroll
+            for (int b2 = 0; b2 < 3; ++b2)
+              if (a2 - a >= -1 && a2 - a <= 1 && b2 - bb >= -1 && b2 - bb <= 1)
+                acc = fma4(av[a2][b2], wreg[(a2 - a + 1) * 3 + (b2 - bb + 1)], acc);
+          if (cur.rv[a] && cur.cv[bb]) {
+            float* yp = yb + (cur.base + a * rW + bb * r1) * ldy;
+            if (p.accumulate) acc = add4(acc, ld4(yp));
+            if (nt_store) st4_nt(yp, acc);
+            else st4(yp, acc);
+            s1[0] = add4(s1[0], acc);
+            s1[1] = fma4(acc, acc, s1[1]);
+          }
+        }
+      cur = nxt;
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb) in[a][bb] = inn[a][bb];
+    }
+  }
+  if (p.partials) block_reduce_store<2>(s1, active, pl, cl, p.c4s, p.px, cbase4, p.C, p.partials + (size_t)bx * 2 * p.C);
+}
+
 // ------------------------------------------------------------------------------ backward data, stride > 1
 // gx[n,iy,ix] = sum_taps w[ky,kx] * dy[n,(iy+pad_t-ky*r)/s,(ix+pad_l-kx*r)/s] where divisible.
 // Here (H,W) are the conv INPUT dims (the output of this kernel) and (Ho,Wo) the dy dims.
@@ -1120,7 +1223,12 @@ static int fwd_plan(DwParams& p, int per_cu = 8, bool window5 = false, int tw5 =
   else if (p.stride == 2 && p.rate == 1 && p.Wo >= 4) kind = 2;
   if (kind == 0 && p.ks == 3 && p.stride == 1 && p.pad_t == p.rate && p.pad_l == p.rate && p.Ho == p.H && p.Wo == p.W &&
       2 * p.rate >= p.H && 2 * p.rate >= p.W && p.rate < p.H && p.rate < p.W &&
-      (long long)p.N * p.H * p.W * (p.ldx > p.ldy ? p.ldx : p.ldy) < (1LL << 31)) kind = 3;
+      (long long)p.N * p.H * p.W * (p.ldx > p.ldy ? p.ldx : p.ldy) < (1LL << 31)) { kind = 3; p.lat = 2; }
+  // one step down: 3 * rate covers the map (rate 12 on 33 x 33, rate 36 on 97 x 97) -> 3 x 3 pixels per class
+  static const int lat3 = getenv("DL3P_DW_LAT3") ? atoi(getenv("DL3P_DW_LAT3")) : 1;
+  if (kind == 0 && lat3 && p.ks == 3 && p.stride == 1 && p.pad_t == p.rate && p.pad_l == p.rate && p.Ho == p.H && p.Wo == p.W &&
+      3 * p.rate >= p.H && 3 * p.rate >= p.W && p.rate < p.H && p.rate < p.W &&
+      (long long)p.N * p.H * p.W * (p.ldx > p.ldy ? p.ldx : p.ldy) < (1LL << 31)) { kind = 3; p.lat = 3; }
   if (kind == 3) {
     p.spr = p.rate; p.th = 1; p.nbands = p.rate;
     p.total = (long long)p.N * p.rate * p.rate;      // one work item per residue class (py, px)
@@ -1157,7 +1265,8 @@ static int fwd_plan(DwParams& p, int per_cu = 8, bool window5 = false, int tw5 =
     p.total = (long long)p.N * r * r * p.nbands * p.spr;
   }
   static const int lat2_per_cu = getenv("DL3P_LAT2_PER_CU") ? atoi(getenv("DL3P_LAT2_PER_CU")) : DL3P_LAT2_PER_CU;
-  p.nbx = pick_nbx(p.total, p.px, p.nslab, kind == 3 ? lat2_per_cu : per_cu);
+  static const int lat3_per_cu = getenv("DL3P_LAT3_PER_CU") ? atoi(getenv("DL3P_LAT3_PER_CU")) : 3;
+  p.nbx = pick_nbx(p.total, p.px, p.nslab, kind == 3 ? (p.lat == 3 ? lat3_per_cu : lat2_per_cu) : per_cu);
   return kind;
 }
 
@@ -1178,6 +1287,7 @@ static void launch_fwd_pro(const DwParams& p, int kind, dim3 grid, hipStream_t s
   if (kind == 1 && p.tw == 2) dl3p_launch(dw_fwd_seg<3, 2, 1, PRO>, grid, block, 0, st, p);
   else if (kind == 1) dl3p_launch(dw_fwd_seg<3, 4, 1, PRO>, grid, block, 0, st, p);
   else if (kind == 2) dl3p_launch(dw_fwd_seg<3, 2, 2, PRO>, grid, block, 0, st, p);
+  else if (kind == 3 && p.lat == 3) dl3p_launch(dw_fwd_lattice3<PRO>, grid, block, 0, st, p);
   else if (kind == 3) dl3p_launch(dw_fwd_lattice2<PRO>, grid, block, 0, st, p);
   else dl3p_launch(dw_fwd_gather<3, PRO>, grid, block, 0, st, p);
 }

@@ -1516,7 +1516,8 @@ class Executor:
         op = [o for o in self.g.ops if getattr(o, 'name', None) == name and o.kind == 'conv_dw'][0]
         seg = op.rate == 1 and op.stride in (1, 2) and op.Wo >= 4
         lat2 = (op.k == 3 and op.stride == 1 and 2 * op.rate >= max(op.x.tensor.H, op.x.tensor.W) and op.rate < min(op.x.tensor.H, op.x.tensor.W))
-        kname = 'dw_fwd_lattice2' if lat2 else (('dw_fwd_seg<%d,%d,%d>' % (op.k, 4 if op.stride == 1 else 2, op.stride)) if seg else 'dw_fwd_gather<%d>' % op.k)
+        lat3 = (not lat2 and op.k == 3 and op.stride == 1 and 3 * op.rate >= max(op.x.tensor.H, op.x.tensor.W) and op.rate < min(op.x.tensor.H, op.x.tensor.W))
+        kname = 'dw_fwd_lattice2' if lat2 else 'dw_fwd_lattice3' if lat3 else (('dw_fwd_seg<%d,%d,%d>' % (op.k, 4 if op.stride == 1 else 2, op.stride)) if seg else 'dw_fwd_gather<%d>' % op.k)
         if self.bf16:
             kname = ('dwb_fwd_strip<%d, %d' if op.stride == 1 else 'dwb_fwd<%d, %d') % (8 if (op.k == 3 and op.c % 8 == 0) else 4, op.k)
         probe = Probe(op, kname)
