@@ -92,6 +92,27 @@ int dl3p_comm_allreduce(void* comm, float* buf, size_t count, void* stream);
 int dl3p_comm_syncbn_allreduce(void* comm, double* sums, size_t count, void* stream);
 int dl3p_comm_destroy(void* comm);
 
+/* ---------------------------------------------------------------- fp32-accurate GEMMs on the bf16 matrix pipe ("split bf16")
+ * Twins of dl3p_pwconv_fwd_wt / dl3p_pwconv_bwd_data / dl3p_pwconv_bwd_data_bn (same reference call sites: layers.py:105,157,
+ * 209-218, deeplabv3p_mobilenetv2.py:47,63) for the compute-bound 1x1 convs.  Every fp32 operand is split exactly into three
+ * bf16 pieces (a = a1 + a2 + a3) and the product accumulated in fp32 from the six cross terms down to 2^-16 on
+ * v_mfma_f32_16x16x32_bf16 -- the dropped terms are below one fp32 product rounding -- at 6/16 of the fp32-input MFMA's cost.
+ * The conv kernel is handed over pre-split: dl3p_split_bf16x3_batch writes, for every table row {source offset (floats), rows,
+ * cols, source row pitch, destination offset (bf16 elements), destination pitch}, the planes [3][rows][pitch] of
+ * src[rows][cols] (pitch a multiple of 32, zero padded).  rows = the GEMM's OUTPUT columns, cols = its reduction length:
+ * the transposed kernel wt[N][K] for the forward, the kernel w[K][N] as stored for the data gradient.
+ * dl3p_pwconv_sb_supported(role, M, K, N) (roles and (M, K, N) as dl3p_gemm_plan_query): 0 for shapes the tiled kernel does
+ * not serve (few rows; few-channel layers on the streaming kernels) -- those keep the fp32 entry points. */
+int dl3p_split_bf16x3_batch(const float* src, void* dst, const int64_t* table, int n_matrices, void* stream);
+int dl3p_pwconv_sb_supported(int role, int M, int K, int N);
+int dl3p_pwconv_fwd_sb(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                       const void* wsp, int pitch, const float* bias, float* y, int ldy, float* stat_partials,
+                       int* rows_out, int M, int K, int N, void* stream);
+int dl3p_pwconv_bwd_data_sb(const float* dy, int lddy, const void* wsp, int pitch, float* gx, int ldgx, int accumulate,
+                            int M, int K, int N, const float* z, int ldz, const float* scale, const float* shift,
+                            int act, const float* save_mean, const float* save_invstd, float* partials,
+                            int* rows_out, void* stream);
+
 /* ---------------------------------------------------------------- depthwise convolution
  * replaces DepthwiseConv2D (DepthwiseConv2dNative [+SpaceToBatchND for dilation]) at
  * layers.py:100 (SepConv_BN, ASPP rates 6/12/18), deeplabv3p_mobilenetv2.py:56,

@@ -77,6 +77,10 @@ class Net:
         # device's own inputs, instead of through a hundred layers of accumulated bf16 rounding.
         self.force_grad = None
         self.record_grad = None
+        # optional dict: for every BatchNorm (dgamma, dbeta) the l2 norm of the terms that were summed (||g' xhat||, ||g'||).
+        # A beta in front of a conv + BatchNorm pair has an exactly zero gradient (the next BatchNorm removes the shift), so
+        # what a run computes for it is the rounding noise of its terms: this is the scale that noise is measured against.
+        self.grad_term_norm = None
         # optional SyncBatchNorm: (all_reduce_sum(ndarray) -> ndarray, world_size).  Statistics are
         # summed over ranks in forward (sum x, sum x^2, count) and backward (sum dy, sum dy*xhat); the
         # parameter gradients stay local and are averaged with all other gradients (README.md:38,
@@ -208,6 +212,10 @@ class Net:
                 gx, gg, gb = O.bn_train_bwd(y.g, cache)
                 self.acc_grad(name + '/gamma', gg)
                 self.acc_grad(name + '/beta', gb)
+                if self.grad_term_norm is not None:
+                    g2 = np.asarray(y.g, np.float64).reshape(-1, c)
+                    self.grad_term_norm[name + '/beta'] = np.sqrt((g2 ** 2).sum(0))
+                    self.grad_term_norm[name + '/gamma'] = np.sqrt(((g2 * np.asarray(cache[0], np.float64).reshape(-1, c)) ** 2).sum(0))
                 x.acc(gx)
         else:
             yv = O.bn_infer_fwd(x.v, gamma, beta, mm, mv, eps)

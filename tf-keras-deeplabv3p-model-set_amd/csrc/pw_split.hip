@@ -1,0 +1,441 @@
+// fp32-ACCURATE pointwise GEMM on the bf16 matrix pipe (gfx950): every fp32 operand is split into three bf16 pieces,
+//   a = a1 + a2 + a3   (a1 = rn_bf16(a), a2 = rn_bf16(a - a1), a3 = rn_bf16(a - a1 - a2); the split is exact: 3 x 8 = 24 bits),
+// and the product is accumulated in fp32 from the six cross terms of weight 2^-16 and above,
+//   a b ~= a1 b1 + a1 b2 + a2 b1 + a2 b2 + a1 b3 + a3 b1        (dropped: a2 b3 + a3 b2 + a3 b3 <= 2^-23 |a b|),
+// on v_mfma_f32_16x16x32_bf16.  A bf16 x bf16 product is exact in fp32 and the pipe accumulates in fp32, so the result carries
+// the rounding of an fp32 GEMM (the accumulation) plus one dropped term of the size of an fp32 product rounding per product.
+// On this chip the bf16 matrix pipe runs 16x the fp32-input MFMA (MI355X_MICROARCH.md, Matrix cores), so six bf16 MFMAs cost
+// 6/16 of the fp32 one: 2.67x the fp32-MFMA ceiling for the compute-bound 1x1 convs (K >= 64) that are 93-98 % of the model's MACs
+// (reference call sites: deeplabv3p/models/layers.py:105,157,209-218, deeplabv3p_xception.py:81).
+//
+// Same tiling, staging roles, prologue (the producer's BatchNorm + activation applied while the tile is staged) and epilogue
+// (bias, accumulate, BatchNorm statistics / BatchNorm-backward sums) as pw_gemm_kernel in pwconv.hip; what differs:
+//   * the A tile is split by the staging thread (each element once) and lives in LDS as three bf16 planes [rows][32 k], 80-byte
+//     row pitch (a 16-lane ds_read_b128 group then covers all 64 banks);
+//   * the B operand (the conv kernel) arrives PRE-SPLIT from global memory (dl3p_split_bf16x3 after every optimiser step, like the
+//     transposed copies), [plane][Nout][Kpad] with the reduction index contiguous and zero-padded to 32;
+//   * one K-step = 32 reduction indices = 6 MFMAs per 16 x 16 accumulator (the fp32 kernel: 8 MFMAs of twice the cycles);
+//   * the epilogue buffer overlays the operand tiles (two workgroups per CU keep fitting).
+#include "common.h"
+#include "pw_gemm.h"
+#include <type_traits>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+
+#define SB_BKT 32
+#define SB_PB 40   // bf16 elements per LDS tile row: 64 B of data + 16 B pad
+
+// (x, y) -> three packed bf16 pairs (low half = x): the exact 3-way split, round to nearest even at every level
+__device__ __forceinline__ void split2(float x, float y, uint32_t& h, uint32_t& m, uint32_t& l) {
+  const bf16x2v hv = {(__bf16)x, (__bf16)y};
+  h = __builtin_bit_cast(uint32_t, hv);
+  const float rx = x - __builtin_bit_cast(float, h << 16);
+  const float ry = y - __builtin_bit_cast(float, h & 0xffff0000u);
+  const bf16x2v mv = {(__bf16)rx, (__bf16)ry};
+  m = __builtin_bit_cast(uint32_t, mv);
+  const float sx = rx - __builtin_bit_cast(float, m << 16);
+  const float sy = ry - __builtin_bit_cast(float, m & 0xffff0000u);
+  const bf16x2v lv = {(__bf16)sx, (__bf16)sy};
+  l = __builtin_bit_cast(uint32_t, lv);
+}
+
+// ------------------------------------------------------------------------------ the pre-split B operand
+// rows x cols fp32 (row pitch ld) -> dst[plane][rows][pitch] bf16, columns >= cols zero.  table rows: {src offset (floats),
+// rows, cols, ld, dst offset (bf16 elements, of plane 0), pitch}; `plane` = elements between the planes of ONE matrix is
+// rows * pitch, so the three planes of a matrix are contiguous: [3][rows][pitch].
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* src, unsigned short* dst, const long long* table) {
+  const long long* e = table + (size_t)blockIdx.x * 6;
+  const long long soff = e[0], doff = e[4];
+  const int rows = (int)e[1], cols = (int)e[2], ld = (int)e[3], pitch = (int)e[5];
+  const int p2 = pitch / 2;
+  const long long plane = (long long)rows * pitch;
+  for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < (long long)rows * p2; i += (long long)gridDim.y * 256) {
+    const int r = (int)(i / p2), c = (int)(i - (long long)r * p2) * 2;
+    const float x = c < cols ? src[soff + (long long)r * ld + c] : 0.f;
+    const float y = c + 1 < cols ? src[soff + (long long)r * ld + c + 1] : 0.f;
+    uint32_t h, m, l;
+    split2(x, y, h, m, l);
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst + doff + (long long)r * pitch + c);
+    d[0] = h;
+    *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned short*>(d) + plane) = m;
+    *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned short*>(d) + 2 * plane) = l;
+  }
+}
+
+extern "C" int dl3p_split_bf16x3_batch(const float* src, void* dst, const int64_t* table, int n_matrices, void* stream) {
+  DL3P_CHECK_ARG(src && dst && table && n_matrices > 0, "dl3p_split_bf16x3_batch: bad arguments");
+  hipLaunchKernelGGL(split_bf16x3_kernel, dim3(n_matrices, 64), dim3(256), 0, (hipStream_t)stream, src,
+                     reinterpret_cast<unsigned short*>(dst), reinterpret_cast<const long long*>(table));
+  DL3P_CHECK_LAUNCH("dl3p_split_bf16x3_batch");
+  return DL3P_OK;
+}
+
+// ------------------------------------------------------------------------------ forward / data gradient
+template <int NT, bool STATS, int MI, bool BNB, bool GA>
+__global__ __launch_bounds__(256, 2) void pw_gemm_sb_kernel(GemmParams p) {
+  constexpr int BKT = SB_BKT, PB = SB_PB;
+  constexpr int BM = 64 * MI, BN = 16 * NT;
+  constexpr int A_PLANE = BM * PB, B_PLANE = BN * PB;          // bf16 elements
+  constexpr int OPER_BYTES = 3 * (A_PLANE + B_PLANE) * 2;
+  constexpr int NA = MI;                                       // A passes of 64 rows: a thread stages 8 consecutive k of one row
+  constexpr int NBC = (3 * BN * 4 + 255) / 256;                // 16-byte chunks of the B tile per thread
+  constexpr int TPP = NT < 4 ? NT : 4;
+  constexpr int NPASS = (NT + TPP - 1) / TPP;
+  constexpr int CH = 16 * TPP;
+  constexpr int EPITCH = CH + 4;
+  constexpr int RW = 16 * MI;
+  constexpr int ES_BYTES = 4 * RW * EPITCH * 4;
+  constexpr int RED_OFF = (OPER_BYTES > ES_BYTES ? OPER_BYTES : ES_BYTES);
+  extern __shared__ __attribute__((aligned(16))) unsigned char sb_lds[];
+  unsigned short* As = reinterpret_cast<unsigned short*>(sb_lds);
+  unsigned short* Bs = As + 3 * A_PLANE;
+  float* Es = reinterpret_cast<float*>(sb_lds);                // overlays the operand tiles (barrier-separated)
+  float* red = reinterpret_cast<float*>(sb_lds + RED_OFF);
+
+  const int t = threadIdx.x;
+  const int l = t & 63;
+  const int w = t >> 6;
+  const int l15 = l & 15;
+  const int q = l >> 4;
+  const int n0 = blockIdx.y * BN;
+  const int nk = (p.K + BKT - 1) / BKT;
+  const int my_tiles = (p.num_m_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int it_total = my_tiles * nk;
+
+  const int ar = t >> 2;           // A row within a pass of 64 rows
+  const int ak8 = (t & 3) * 8;     // first of this thread's 8 k of the K tile
+  const char* Ab = reinterpret_cast<const char*>(p.A);
+
+  float4 ra[NA][2];
+  uint4 rb[NBC];
+  float4 rsc[2] = {make_float4(1.f, 1.f, 1.f, 1.f), make_float4(1.f, 1.f, 1.f, 1.f)}, rsh[2] = {zero4(), zero4()};
+  uint32_t a_row[NA];
+  int g_by[GA ? NA : 1], g_bx[GA ? NA : 1];
+  uint32_t g_ok = 0;               // GA: bit (2 i + h) = float4 h of pass i hit the source tensor
+  uint32_t b_off[NBC];             // byte offset of this thread's B chunks at k0 = 0
+  bool b_ok[NBC];
+  int b_lds[NBC];                  // bf16 element offset of the chunk in Bs
+  int pf_m0 = -1;
+#pragma unroll
+  for (int i = 0; i < NBC; ++i) {
+    const int idx = t + 256 * i;
+    const int c = idx < 3 * BN * 4 ? idx : 3 * BN * 4 - 1;
+    const int plane = c / (BN * 4), rem = c - plane * (BN * 4);
+    const int r = rem >> 2, ch = rem & 3;
+    const int n = n0 + r;
+    b_ok[i] = idx < 3 * BN * 4 && n < p.N;
+    b_off[i] = (uint32_t)(((long long)plane * p.bsp_plane + (long long)min(n, p.N - 1) * p.bsp_pitch + ch * 8) * 2);
+    b_lds[i] = plane * B_PLANE + r * PB + ch * 8;
+  }
+  const char* Bb = reinterpret_cast<const char*>(p.Bsp);
+
+  auto prefetch = [&](int it) {
+    const int kt = it % nk;
+    const int mt = blockIdx.x + (it / nk) * gridDim.x;
+    const int m0 = mt * BM;
+    const int k0 = kt * BKT;
+    if (GA) {
+      if (m0 != pf_m0) {
+        pf_m0 = m0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+          const int m = m0 + ar + 64 * i;
+          const int mc = min(m, p.M - 1);
+          const int row = mc / p.g_RW, x = mc - row * p.g_RW;
+          const int n = row / p.g_RH, y = row - n * p.g_RH;
+          g_by[i] = m < p.M ? y * p.g_mul + p.g_ay : -(1 << 20);
+          g_bx[i] = x * p.g_mul + p.g_ax;
+          a_row[i] = (uint32_t)n * (uint32_t)(p.g_SH * p.g_SW);
+        }
+      }
+      g_ok = 0;
+      const int par = (1 << p.g_shift) - 1;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int kraw = k0 + ak8 + 4 * h;
+        const int k = min(kraw, p.K - 4);
+        const int tap = (int)__umulhi((uint32_t)k, p.g_cmagic);
+        const int c = k - tap * p.g_C;
+        const int ky = (tap * p.g_kwmagic) >> 16, kx = tap - ky * p.g_kw;
+        const int dyo = ky * p.g_d, dxo = kx * p.g_d;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+          const int ty = g_by[i] + dyo, tx = g_bx[i] + dxo;
+          const int sy = ty >> p.g_shift, sx = tx >> p.g_shift;
+          const bool ok = ty >= 0 && tx >= 0 && ((ty | tx) & par) == 0 && sy < p.g_SH && sx < p.g_SW && kraw < p.K;
+          const uint32_t off = ok ? ((a_row[i] + (uint32_t)(sy * p.g_SW + sx)) * (uint32_t)p.lda + (uint32_t)c) * 4u : 0u;
+          ra[i][h] = *reinterpret_cast<const float4*>(Ab + off);
+          g_ok |= ok ? (1u << (2 * i + h)) : 0u;
+        }
+        if (p.scale) {
+          rsc[h] = *reinterpret_cast<const float4*>(p.scale + c);
+          rsh[h] = *reinterpret_cast<const float4*>(p.shift + c);
+        }
+      }
+    } else {
+      if (m0 != pf_m0) {
+        pf_m0 = m0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) a_row[i] = (uint32_t)min(m0 + ar + 64 * i, p.M - 1) * (uint32_t)p.lda * 4u;
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const uint32_t kb = (uint32_t)min(k0 + ak8 + 4 * h, p.K - 4) * 4u;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ra[i][h] = *reinterpret_cast<const float4*>(Ab + (a_row[i] + kb));
+        if (p.scale) {
+          rsc[h] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.scale) + kb);
+          rsh[h] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.shift) + kb);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NBC; ++i) rb[i] = *reinterpret_cast<const uint4*>(Bb + (b_off[i] + (uint32_t)k0 * 2u));
+  };
+
+  const float act_lo = p.act == DL3P_ACT_NONE ? -DL3P_INF : 0.f;
+  const float act_hi = (p.act == DL3P_ACT_NONE || p.act == DL3P_ACT_RELU) ? DL3P_INF : 6.f;
+  auto prologue4 = [&](float4 v, int h) {
+    v = fma4(v, rsc[h], rsh[h]);
+    if (p.act >= DL3P_ACT_HSWISH) return act_apply4(v, p.act);
+    return make_float4(__builtin_amdgcn_fmed3f(v.x, act_lo, act_hi), __builtin_amdgcn_fmed3f(v.y, act_lo, act_hi),
+                       __builtin_amdgcn_fmed3f(v.z, act_lo, act_hi), __builtin_amdgcn_fmed3f(v.w, act_lo, act_hi));
+  };
+  const bool has_pro = p.scale != nullptr || p.act != DL3P_ACT_NONE;
+
+  auto stage = [&](int it) {
+    const int kt = it % nk;
+    const int mt = blockIdx.x + (it / nk) * gridDim.x;
+    const int m0 = mt * BM;
+    const int k0 = kt * BKT;
+    const bool a_edge = m0 + BM > p.M || k0 + BKT > p.K;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int r = ar + 64 * i;
+      float4 v[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        v[h] = ra[i][h];
+        if (has_pro) v[h] = prologue4(v[h], h);
+        // padding of the M / K tails and (GA) taps outside the source stay exactly zero
+        if (GA) v[h] = ((g_ok >> (2 * i + h)) & 1u) ? v[h] : zero4();
+        else if (a_edge) v[h] = (k0 + ak8 + 4 * h < p.K && m0 + r < p.M) ? v[h] : zero4();
+      }
+      uint4 hh, mm, ll;
+      split2(v[0].x, v[0].y, hh.x, mm.x, ll.x);
+      split2(v[0].z, v[0].w, hh.y, mm.y, ll.y);
+      split2(v[1].x, v[1].y, hh.z, mm.z, ll.z);
+      split2(v[1].z, v[1].w, hh.w, mm.w, ll.w);
+      unsigned short* d = As + r * PB + ak8;
+      *reinterpret_cast<uint4*>(d) = hh;
+      *reinterpret_cast<uint4*>(d + A_PLANE) = mm;
+      *reinterpret_cast<uint4*>(d + 2 * A_PLANE) = ll;
+    }
+#pragma unroll
+    for (int i = 0; i < NBC; ++i) {
+      // (the empty asm pins the wait for rb[i] in front of its store, as in pw_gemm_kernel: left alone, the compiler parks an
+      // s_waitcnt inside the next K-step's prefetch burst)
+      asm volatile("" :: "v"(rb[i].x), "v"(rb[i].y), "v"(rb[i].z), "v"(rb[i].w));
+      if (t + 256 * i < 3 * BN * 4) {
+        uint4 v = rb[i];
+        if (!b_ok[i]) v = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4*>(Bs + b_lds[i]) = v;
+      }
+    }
+  };
+
+  f32x4 acc[MI][NT];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 st_s[STATS ? NPASS : 1], st_q[STATS ? NPASS : 1];
+  if (STATS) {
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) { st_s[i] = zero4(); st_q[i] = zero4(); }
+  }
+
+  if (it_total > 0) prefetch(0);
+  for (int it = 0; it < it_total; ++it) {
+    stage(it);
+    __syncthreads();
+    if (it + 1 < it_total) prefetch(it + 1);
+    {
+      s16x8 xa[MI][3];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          xa[mi][pl] = *reinterpret_cast<const s16x8*>(As + pl * A_PLANE + (w * 16 * MI + mi * 16 + l15) * PB + q * 8);
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) {
+        s16x8 wb[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) wb[pl] = *reinterpret_cast<const s16x8*>(Bs + pl * B_PLANE + (ni * 16 + l15) * PB + q * 8);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          // smallest terms first; MFMA "A" = weights (row = output channel), "B" = activations (column = pixel): a lane ends with
+          // 4 consecutive output channels of one pixel
+          f32x4 c = acc[mi][ni];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[2], xa[mi][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[0], xa[mi][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[1], xa[mi][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[1], xa[mi][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[0], xa[mi][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[0], xa[mi][0], c, 0, 0, 0);
+          acc[mi][ni] = c;
+        }
+      }
+    }
+    __syncthreads();
+    if (it % nk == nk - 1) {
+      const int mt = blockIdx.x + (it / nk) * gridDim.x;
+      const int m0 = mt * BM;
+      float* es = Es + w * RW * EPITCH;
+      const int rr = l >> 4, cq = l & 15;
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int ni0 = ps * TPP;
+#pragma unroll
+        for (int nl = 0; nl < TPP; ++nl) {
+          if (ni0 + nl < NT) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+              const f32x4 v = acc[mi][ni0 + nl];
+              acc[mi][ni0 + nl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+              *reinterpret_cast<float4*>(&es[(mi * 16 + l15) * EPITCH + nl * 16 + q * 4]) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+          }
+        }
+        const int n = n0 + ni0 * 16 + cq * 4;
+        const bool col_ok = (ni0 * 16 + cq * 4 < BN) && (cq * 4 < CH) && n < p.N && (ni0 + cq / 4 < NT);
+        const int row_lim = p.M - (m0 + w * RW);
+        if (col_ok) {
+          float4 bias4 = zero4();
+          if (p.bias) bias4 = ld4(p.bias + n);
+          char* yb = reinterpret_cast<char*>(p.Y) + ((uint32_t)(m0 + w * RW + rr) * (uint32_t)p.ldy + (uint32_t)n) * 4u;
+          const uint32_t ystep = (uint32_t)p.ldy * 16u;
+          constexpr bool bnb = STATS && BNB;
+          float4 bsc = zero4(), bsh = zero4(), bmu = zero4(), bis = zero4();
+          float4 zpre[RW / 4];
+          if (bnb) {
+            bsc = ld4(p.bb_scale + n); bsh = ld4(p.bb_shift + n); bmu = ld4(p.bb_mean + n); bis = ld4(p.bb_invstd + n);
+            const char* zbase = reinterpret_cast<const char*>(p.bb_z) + (uint32_t)n * 4u;
+#pragma unroll
+            for (int i = 0; i < RW / 4; ++i) {
+              const int mrow = min(m0 + w * RW + 4 * i + rr, p.M - 1);
+              zpre[i] = *reinterpret_cast<const float4*>(zbase + (uint32_t)mrow * (uint32_t)p.bb_ldz * 4u);
+            }
+          }
+          auto rows = [&](auto full) {
+#pragma unroll
+            for (int r0 = 0; r0 < RW; r0 += 4) {
+              const int row = r0 + rr;
+              if (decltype(full)::value || row < row_lim) {
+                float4 o = add4(*reinterpret_cast<const float4*>(&es[row * EPITCH + cq * 4]), bias4);
+                float* yp = reinterpret_cast<float*>(yb + (r0 / 4) * ystep);
+                if (p.accumulate) o = add4(o, ld4(yp));
+                st4(yp, o);
+                if (STATS) {
+                  if (bnb) {
+                    const float4 zv = zpre[r0 / 4];
+                    const float4 u = fma4(zv, bsc, bsh);
+                    const float4 d = make_float4(o.x * act_grad(u.x, p.bb_act), o.y * act_grad(u.y, p.bb_act),
+                                                 o.z * act_grad(u.z, p.bb_act), o.w * act_grad(u.w, p.bb_act));
+                    const float4 xh = make_float4((zv.x - bmu.x) * bis.x, (zv.y - bmu.y) * bis.y, (zv.z - bmu.z) * bis.z,
+                                                  (zv.w - bmu.w) * bis.w);
+                    st_s[ps] = add4(st_s[ps], d);
+                    st_q[ps] = fma4(d, xh, st_q[ps]);
+                  } else {
+                    st_s[ps] = add4(st_s[ps], o);
+                    st_q[ps] = fma4(o, o, st_q[ps]);
+                  }
+                }
+              }
+            }
+          };
+          if (row_lim >= RW) rows(std::true_type{});
+          else rows(std::false_type{});
+        }
+      }
+      __syncthreads();   // the next stage() overwrites the epilogue buffer
+    }
+  }
+
+  if (STATS) {
+    const int rr = l >> 4, cq = l & 15;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      float sv[4] = {st_s[ps].x, st_s[ps].y, st_s[ps].z, st_s[ps].w};
+      float qv[4] = {st_q[ps].x, st_q[ps].y, st_q[ps].z, st_q[ps].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float s1 = sv[e], s2 = qv[e];
+        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        const int col = ps * CH + cq * 4 + e;
+        if (rr == 0 && cq * 4 < CH && col < BN) {
+          red[(0 * 4 + w) * BN + col] = s1;
+          red[(1 * 4 + w) * BN + col] = s2;
+        }
+      }
+    }
+    __syncthreads();
+    if (p.partials) {
+      for (int i = t; i < 2 * BN; i += 256) {
+        const int which = i / BN, nn = i - which * BN;
+        if (n0 + nn < p.N) {
+          float s = red[(which * 4 + 0) * BN + nn] + red[(which * 4 + 1) * BN + nn] +
+                    red[(which * 4 + 2) * BN + nn] + red[(which * 4 + 3) * BN + nn];
+          p.partials[((size_t)blockIdx.x * 2 + which) * p.N + n0 + nn] = s;
+        }
+      }
+    }
+  }
+}
+
+template <int NT, bool STATS, int MI, bool BNB, bool GA>
+static void launch_sb_one(const GemmParams& p, dim3 grid, hipStream_t st) {
+  constexpr int BM = 64 * MI, BN = 16 * NT;
+  constexpr int OPER = 3 * (BM + BN) * SB_PB * 2;
+  constexpr int TPP = NT < 4 ? NT : 4;
+  constexpr int ES = 4 * 16 * MI * (16 * TPP + 4) * 4;
+  constexpr int RED = STATS ? 2 * 4 * BN * 4 : 0;
+  constexpr size_t lds = (size_t)(OPER > ES ? OPER : ES) + RED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)pw_gemm_sb_kernel<NT, STATS, MI, BNB, GA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dl3p_launch(pw_gemm_sb_kernel<NT, STATS, MI, BNB, GA>, grid, dim3(256), lds, st, p);
+}
+
+template <bool STATS, int MI, bool BNB, bool GA>
+static void launch_sb_mi(const GemmParams& p, int nt, dim3 grid, hipStream_t st) {
+  switch (nt) {
+    case 1: launch_sb_one<1, STATS, MI, BNB, GA>(p, grid, st); break;
+    case 2: launch_sb_one<2, STATS, MI, BNB, GA>(p, grid, st); break;
+    case 3: launch_sb_one<3, STATS, MI, BNB, GA>(p, grid, st); break;
+    case 4: launch_sb_one<4, STATS, MI, BNB, GA>(p, grid, st); break;
+    case 5: launch_sb_one<5, STATS, MI, BNB, GA>(p, grid, st); break;
+    case 6: launch_sb_one<6, STATS, MI, BNB, GA>(p, grid, st); break;
+    case 7: launch_sb_one<7, STATS, MI, BNB, GA>(p, grid, st); break;
+    default: launch_sb_one<8, STATS, MI, BNB, GA>(p, grid, st); break;
+  }
+}
+
+// what pwconv.hip calls once it has planned the launch (same (nt, mi, grid) conventions as its launch_gemm)
+void dl3p_launch_gemm_sb(const GemmParams& p, bool stats, bool bnb, bool ga, int nt, int mi, dim3 grid, hipStream_t st) {
+#define DL3P_SB(S, B, G) \
+  { if (mi == 1) launch_sb_mi<S, 1, B, G>(p, nt, grid, st); else launch_sb_mi<S, 2, B, G>(p, nt, grid, st); return; }
+  if (ga) {
+    if (stats) DL3P_SB(true, false, true) else DL3P_SB(false, false, true)
+  }
+  if (bnb) DL3P_SB(true, true, false)
+  if (stats) DL3P_SB(true, false, false)
+  DL3P_SB(false, false, false)
+#undef DL3P_SB
+}

@@ -29,36 +29,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define BK 32
 #define APITCH 36  // 32 + 4: rows 4 apart land 16 banks apart -> ds_read_b128 conflict-free
 
-struct GemmParams {
-  const float* A; int lda;
-  const float* scale; const float* shift; int act;
-  const float* B; int ldb;
-  const float* bias;
-  float* Y; int ldy;
-  float* partials;
-  int M, K, N;
-  int accumulate;
-  int num_m_tiles;
-  int stagger;
-  int b_kn;            // pw_small_kernel: B stored [K][N] (forward) or [N][K] (data gradient)
-  // fused BatchNorm-backward statistics (data gradient writing the gradient of a BN+activation output): with bb_z
-  // set, the per-channel partials are (sum g', sum g' * xhat), g' = y * act'(z*scale+shift), xhat = (z-mean)*invstd,
-  // i.e. exactly what dl3p_bn_bwd_reduce would compute from the finished gradient y in a separate pass
-  const float* bb_z; int bb_ldz;
-  const float* bb_scale; const float* bb_shift; const float* bb_mean; const float* bb_invstd; int bb_act;
-  // implicit-GEMM gather of the A operand (dense k x k convolutions without a patch matrix in HBM; GA instantiations
-  // only).  Row m = (n, y, x) over g_RH x g_RW; column k = tap * g_C + c; the element is the source tensor
-  // [N][g_SH][g_SW][lda] at (sy, sx) = ((y * g_mul + g_ay + ky * g_d) >> g_shift, likewise x with g_ax), zero when that is
-  // outside the source or (data gradient of a strided conv) not a multiple of the stride.
-  //   forward:        rows = output pixels, source = input,   g_mul = stride, g_ay = -pad_t, g_d = +rate, g_shift = 0
-  //   data gradient:  rows = input pixels,  source = dy,      g_mul = 1,      g_ay = +pad_t, g_d = -rate, g_shift = log2(stride)
-  int g_RH, g_RW, g_SH, g_SW, g_C, g_kw, g_mul, g_ay, g_ax, g_d, g_shift;
-  uint32_t g_cmagic;   // floor(2^32 / g_C) + 1: tap = umulhi(k, g_cmagic), exact for k < 2^16 (hosts check K)
-  int g_kwmagic;       // 65536 / g_kw + 1: ky = (tap * g_kwmagic) >> 16 for tap < 64
-#ifdef DL3P_STAMP
-  long long* stamp;   // dev instrument: per-wave cycle counts of the loop phases (scripts/micro/stamp_gemm.py)
-#endif
-};
+#include "pw_gemm.h"
 
 // B_KN: B is [Kred][Nout] row-major (forward: the Keras kernel as stored);
 // !B_KN: B is [Nout][Kred] row-major (dgrad: the same kernel read as its transpose).
@@ -1079,6 +1050,101 @@ extern "C" int dl3p_pwconv_bwd_data_bn(const float* dy, int lddy, const float* w
   *rows_out = gxn;
   launch_gemm<false, true, true>(p, nt, mi, dim3(gxn, gy), (hipStream_t)stream);
   DL3P_CHECK_LAUNCH("dl3p_pwconv_bwd_data_bn");
+  return DL3P_OK;
+}
+
+// ------------------------------------------------------------------------------ split-bf16 twins (pw_split.hip)
+// The same three products on the bf16 matrix pipe with fp32-accurate results: the conv kernel arrives pre-split into three bf16
+// planes [3][rows][pitch] (dl3p_split_bf16x3_batch; rows = the GEMM's OUTPUT columns, reduction index contiguous, pitch a
+// multiple of 32 with zero padding), the activations are split while their tile is staged.  Shapes the tiled kernel does not serve
+// (few rows, or few-channel layers on the streaming kernels) must go through the fp32 entry points: *_sb_supported says which.
+void dl3p_launch_gemm_sb(const GemmParams& p, bool stats, bool bnb, bool ga, int nt, int mi, dim3 grid, hipStream_t st);
+
+static void gemm_plan_sb(int role, int M, int K, int N, int* nt, int* gx, int* gy, int* num_m_tiles, int* mi) {
+  int force_mi = 0, force_pc = 0;
+  *nt = pick_nt(N, M);
+  if (const GemmTuned* e = gemm_tuned_lookup(role + 5, M, K, N)) { *nt = e->nt; force_mi = e->mi; force_pc = e->pc; }   // roles 5..8
+  if (g_gemm_force_nt) *nt = g_gemm_force_nt;
+  if (g_gemm_force_mi) force_mi = g_gemm_force_mi;
+  if (g_gemm_force_pc) force_pc = g_gemm_force_pc;
+  gemm_grid(M, N, *nt, gx, gy, num_m_tiles, mi, role == 3, force_mi, force_pc);
+}
+
+extern "C" int dl3p_pwconv_sb_supported(int role, int M, int K, int N) {
+  // role 0 / 1 forward, 2 / 3 data gradient: (M, K, N) as launched (K = reduction length)
+  SmallShape sh;
+  if (M <= 0 || K < 4 || N < 4 || K % 4 || N % 4 || dl3p_pw_tiny_applies(M)) return 0;
+  if (M >= pw_small_min_rows() && pw_small_pick(K, N, &sh)) return 0;
+  return 1;
+}
+
+static int check_sb(const char* fn, const void* wsp, int pitch, int K) {
+  DL3P_CHECK_ARG(wsp && aligned16(wsp) && pitch % 32 == 0 && pitch >= K, "%s: the split kernel must be [3][rows][pitch], pitch a multiple of 32 >= %d (got %d)", fn, K, pitch);
+  return DL3P_OK;
+}
+
+extern "C" int dl3p_pwconv_fwd_sb(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                                  const void* wsp, int pitch, const float* bias, float* y, int ldy, float* stat_partials,
+                                  int* rows_out, int M, int K, int N, void* stream) {
+  const char* fn = "dl3p_pwconv_fwd_sb";
+  int rc = check_mat(fn, x, ldx, K);
+  if (rc) return rc;
+  rc = check_mat(fn, y, ldy, N);
+  if (rc) return rc;
+  rc = check_sb(fn, wsp, pitch, K);
+  if (rc) return rc;
+  DL3P_CHECK_ARG(M > 0 && dl3p_pwconv_sb_supported(stat_partials ? 1 : 0, M, K, N), "%s: shape M=%d K=%d N=%d is not served by the tiled kernel", fn, M, K, N);
+  DL3P_CHECK_ARG((unsigned long long)M * (unsigned long long)(ldx > ldy ? ldx : ldy) * 4ull < (1ull << 32),
+                 "%s: operands of 4 GiB or more are not supported (M=%d)", fn, M);
+  GemmParams p = {};
+  p.A = x; p.lda = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act;
+  p.Bsp = (const unsigned short*)wsp; p.bsp_pitch = pitch; p.bsp_plane = (long long)N * pitch;
+  p.bias = bias; p.Y = y; p.ldy = ldy; p.partials = stat_partials;
+  p.M = M; p.K = K; p.N = N;
+  int nt, gx, gy, mi;
+  gemm_plan_sb(stat_partials ? 1 : 0, M, K, N, &nt, &gx, &gy, &p.num_m_tiles, &mi);
+  if (rows_out) *rows_out = gx;
+  dl3p_launch_gemm_sb(p, stat_partials != nullptr, false, false, nt, mi, dim3(gx, gy), (hipStream_t)stream);
+  DL3P_CHECK_LAUNCH(fn);
+  return DL3P_OK;
+}
+
+// gx[M][K] (+)= dy[M][N] . W[K][N]^T with W pre-split as [3][K][pitch >= N]; z != NULL: also the BatchNorm-backward partial sums
+// of dl3p_pwconv_bwd_data_bn
+extern "C" int dl3p_pwconv_bwd_data_sb(const float* dy, int lddy, const void* wsp, int pitch, float* gx, int ldgx, int accumulate,
+                                       int M, int K, int N, const float* z, int ldz, const float* scale, const float* shift,
+                                       int act, const float* save_mean, const float* save_invstd, float* partials,
+                                       int* rows_out, void* stream) {
+  const char* fn = "dl3p_pwconv_bwd_data_sb";
+  int rc = check_mat(fn, dy, lddy, N);
+  if (rc) return rc;
+  rc = check_mat(fn, gx, ldgx, K);
+  if (rc) return rc;
+  rc = check_sb(fn, wsp, pitch, N);
+  if (rc) return rc;
+  const bool bnb = z != nullptr;
+  if (bnb) {
+    rc = check_mat(fn, z, ldz, K);
+    if (rc) return rc;
+    DL3P_CHECK_ARG(scale && shift && save_mean && save_invstd && partials && rows_out, "%s: bad BatchNorm arguments", fn);
+  }
+  DL3P_CHECK_ARG(M > 0 && dl3p_pwconv_sb_supported(bnb ? 3 : 2, M, N, K), "%s: shape M=%d K=%d N=%d is not served by the tiled kernel", fn, M, K, N);
+  const int ldm = lddy > ldgx ? (lddy > ldz ? lddy : ldz) : (ldgx > ldz ? ldgx : ldz);
+  DL3P_CHECK_ARG((unsigned long long)M * (unsigned long long)ldm * 4ull < (1ull << 32), "%s: operands of 4 GiB or more are not supported (M=%d)", fn, M);
+  GemmParams p = {};
+  p.A = dy; p.lda = lddy; p.act = DL3P_ACT_NONE;
+  p.Bsp = (const unsigned short*)wsp; p.bsp_pitch = pitch; p.bsp_plane = (long long)K * pitch;
+  p.Y = gx; p.ldy = ldgx; p.accumulate = accumulate;
+  p.M = M; p.K = N; p.N = K;    // reduce over N, produce K columns
+  if (bnb) {
+    p.partials = partials;
+    p.bb_z = z; p.bb_ldz = ldz; p.bb_scale = scale; p.bb_shift = shift; p.bb_mean = save_mean; p.bb_invstd = save_invstd; p.bb_act = act;
+  }
+  int nt, gxn, gy, mi;
+  gemm_plan_sb(bnb ? 3 : 2, M, N, K, &nt, &gxn, &gy, &p.num_m_tiles, &mi);
+  if (rows_out) *rows_out = gxn;
+  dl3p_launch_gemm_sb(p, bnb, bnb, false, nt, mi, dim3(gxn, gy), (hipStream_t)stream);
+  DL3P_CHECK_LAUNCH(fn);
   return DL3P_OK;
 }
 

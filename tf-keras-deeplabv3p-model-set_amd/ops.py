@@ -839,3 +839,44 @@ def resize_bilinear_bwd_bf16(gy, h, w):
     gp, ldg, _ = _plb(gy)
     lib().resize_bilinear_bwd_bf16(gp, ldg, gx.data_ptr(), C, 0, N, h, w, C, H, W, _stream())
     return gx
+
+
+# ------------------------------------------------------------------------------------- split-bf16 GEMMs (fp32-accurate)
+def split_bf16x3(mat):
+    """mat (rows, cols) float32 -> (3, rows, pitch) int16: the exact 3-way bf16 split of every element (planes hi, mid, lo),
+    pitch = cols rounded up to 32, zero padded -- the pre-split B operand of the *_sb entry points"""
+    rows, cols = mat.shape
+    assert mat.is_contiguous() and mat.dtype == torch.float32
+    pitch = (cols + 31) // 32 * 32
+    out = torch.empty((3, rows, pitch), dtype=torch.int16, device=mat.device)
+    table = torch.tensor([[0, rows, cols, cols, 0, pitch]], dtype=torch.int64, device=mat.device)
+    lib().split_bf16x3_batch(_p(mat), _p(out), _p(table), 1, _stream())
+    return out
+
+
+def pwconv_fwd_sb(x, wt_sp, K, bias=None, in_scale=None, in_shift=None, in_act=ACT_NONE, out=None, partials=None):
+    """pwconv_fwd_wt on the bf16 matrix pipe; wt_sp = split_bf16x3(wt) with wt (N, K)"""
+    M = _rows(x)
+    N, pitch = wt_sp.shape[1], wt_sp.shape[2]
+    y = out if out is not None else torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+    xp, ldx = _pl(x)
+    yp, ldy = _pl(y)
+    rows = ctypes.c_int(0)
+    lib().pwconv_fwd_sb(xp, ldx, _p(in_scale), _p(in_shift), in_act, _p(wt_sp), pitch, _p(bias), yp, ldy, _p(partials),
+                        ctypes.byref(rows), M, K, N, _stream())
+    return (y, rows.value) if partials is not None else y
+
+
+def pwconv_bwd_data_sb(dy, w_sp, N, out=None, accumulate=False, z=None, scale=None, shift=None, act=ACT_NONE, mean=None,
+                       invstd=None, partials=None):
+    """pwconv_bwd_data (z is None) / pwconv_bwd_data_bn on the bf16 matrix pipe; w_sp = split_bf16x3(w) with w (K, N)"""
+    M = _rows(dy)
+    K, pitch = w_sp.shape[1], w_sp.shape[2]
+    gx = out if out is not None else torch.empty(tuple(dy.shape[:-1]) + (K,), dtype=torch.float32, device=dy.device)
+    dp, ldd = _pl(dy)
+    gp, ldg = _pl(gx)
+    zp, ldz = _pl(z)
+    rows = ctypes.c_int(0)
+    lib().pwconv_bwd_data_sb(dp, ldd, _p(w_sp), pitch, gp, ldg, int(accumulate), M, K, N, zp, ldz or 0, _p(scale), _p(shift), act,
+                             _p(mean), _p(invstd), _p(partials), ctypes.byref(rows), _stream())
+    return (gx, rows.value) if z is not None else gx
