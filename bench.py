@@ -48,6 +48,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-streaming', action='store_true', help='skip the N=256 DRAM-streaming run of the roofline kernel')
     ap.add_argument('--cpu-steps', type=int, default=10)
+    ap.add_argument('--split-gemm', type=int, default=None, choices=[0, 1],
+                    help='1: compute-bound 1x1 convs as fp32-accurate split-bf16 GEMMs on the bf16 matrix pipe (csrc/pw_split.hip); '
+                         '0: fp32-input MFMA everywhere; default: DL3P_SPLIT_GEMM or 0')
     ap.add_argument('--no-other-configs', action='store_true',
                     help='skip the short runs of BASELINE.json configs[2..4] behind the headline region')
     return ap.parse_args()
@@ -250,6 +253,8 @@ def main():
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    if args.split_gemm is not None:
+        os.environ['DL3P_SPLIT_GEMM'] = str(args.split_gemm)
     pkg = importlib.import_module(PKG)
     H, W = args.size, (args.width or args.size)
     N, C = args.batch, args.classes
@@ -343,6 +348,8 @@ def main():
                        'global_batch': N * world,
                        'parallelism': 'dp%d%s' % (world, '+syncbn' if (world > 1 and not args.no_sync_bn) else ''),
                        'hip_graph': bool(model.use_graphs), 'final_loss': round(loss, 5),
+                       'gemm': ('fp32-accurate split-bf16 (3 x bf16 pieces, 6 products, fp32 accumulate) for the compute-bound 1x1 convs, '
+                                'fp32-input MFMA elsewhere' if model._store.Sb is not None else 'fp32-input MFMA'),
                        'launches_per_step': ex.fwd.n_launches + ex.bwd.n_launches + ex.opt.n_launches,
                        'collectives_per_step': sum(getattr(pl, 'n_collectives', 0) for pl in (ex.fwd, ex.bwd, ex.opt))},
         }
@@ -388,6 +395,17 @@ def main():
         if probe and standalone is None and args.dtype == 'f32' and not args.no_streaming:
             out['roofline'].update(streaming_variant(pkg, probe.op))
         headline = (args.model, H, W, C, args.os, args.dtype) == ('mobilenetv2', 513, 513, 21, 16, 'f32')
+        if world == 1 and headline and not dist_mode and model._store.Sb is None and not args.no_other_configs:
+            # the same step with the compute-bound 1x1 convs on the fp32-accurate split-bf16 GEMMs (opt-in):
+            # a short loop behind the headline region, reported beside it, never as `value`
+            try:
+                os.environ['DL3P_SPLIT_GEMM'] = '1'
+                out['split_gemm'] = other_config(pkg, 'configs[1] + split-bf16 GEMMs', 'mobilenetv2', C, H, W, args.os, N, 'f32', steps=30, warmup=10)
+                out['split_gemm']['gemm'] = 'fp32-accurate split-bf16 (3 bf16 pieces per operand, 6 products, fp32 accumulate); parity at the fp32 tolerances: tests/test_split_model_gpu.py'
+            except Exception as e:      # noqa: BLE001
+                out['split_gemm'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+            finally:
+                os.environ['DL3P_SPLIT_GEMM'] = '0' if args.split_gemm is None else str(args.split_gemm)
         if world == 1 and headline and not dist_mode and not args.no_other_configs:
             # the other BASELINE configs, each a short loop behind the headline region
             del ex

@@ -27,9 +27,20 @@ def timeit(fn, reps=10):
 
 SHAPES = [(266256, 304, 256), (266256, 256, 256), (17424, 1280, 256), (17424, 960, 160), (17424, 160, 960), (17424, 576, 96),
           (67600, 192, 64), (67600, 384, 64), (4356, 728, 728), (4356, 2048, 256), (4356, 1536, 2048), (18818, 728, 728), (74498, 304, 256)]
-cands = [(None, None)] + [(nt, mi) for mi in (1, 2) for nt in (4, 6, 8)]
-if len(sys.argv) > 2:
-    cands = [(int(sys.argv[1]), int(sys.argv[2]))]
+# (nt, mi, wm): wm = 0 -> the 2-workgroups-per-CU tiles (gemm_nt / gemm_mi), wm >= 1 with nt in (8, 12, 16) -> the wide family
+cands = [(None, None, None), (4, 2, 0), (8, 1, 0), (8, 2, 0), (16, 2, 1), (16, 1, 1), (16, 1, 2), (12, 2, 1), (12, 2, 2), (8, 2, 2)]
+if len(sys.argv) > 3:
+    cands = [(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]))]
+
+
+def pin(nt, mi, wm):
+    if nt is None:
+        for k in (b'gemm_nt', b'gemm_mi', b'sb_wm', b'sb_nt'):
+            L.set_option(k, 0)
+    elif wm == 0:
+        L.set_option(b'sb_wm', -1); L.set_option(b'sb_nt', 0); L.set_option(b'gemm_nt', nt); L.set_option(b'gemm_mi', mi)
+    else:
+        L.set_option(b'sb_wm', wm); L.set_option(b'sb_nt', nt); L.set_option(b'gemm_mi', mi); L.set_option(b'gemm_nt', 0)
 for (M, K, N) in SHAPES:
     x = torch.randn(M, K, device=dev)
     wt = torch.randn(N, K, device=dev) / K ** 0.5
@@ -41,12 +52,14 @@ for (M, K, N) in SHAPES:
     t32 = timeit(lambda: ops.pwconv_fwd_wt(x, wt, None, sc, sh, ops.ACT_RELU6, out=y, partials=part))
     e32 = float((y.double() - y64).abs().max() / y64.abs().max())
     line = 'fwd  M=%6d K=%4d N=%4d  fp32 %7.1f us (err %.1e) |' % (M, K, N, t32, e32)
-    for nt, mi in cands:
-        L.set_option(b'gemm_nt', nt or 0); L.set_option(b'gemm_mi', mi or 0)
+    for nt, mi, wm in cands:
+        if wm and nt and N <= 16 * (nt - 4):
+            continue
+        pin(nt, mi, wm)
         t = timeit(lambda: ops.pwconv_fwd_sb(x, wsp, K, None, sc, sh, ops.ACT_RELU6, out=y, partials=part))
         e = float((y.double() - y64).abs().max() / y64.abs().max())
-        line += ' sb[%s,%s] %6.1f (%.1e)' % (nt, mi, t, e)
-    L.set_option(b'gemm_nt', 0); L.set_option(b'gemm_mi', 0)
+        line += ' [%s,%s,%s] %6.1f (%.0e)' % (nt, mi, wm, t, e)
+    pin(None, None, None)
     print(line, flush=True)
     del y64
     # data gradient + BN sums: dy (M, N) -> gx (M, K)
@@ -59,10 +72,12 @@ for (M, K, N) in SHAPES:
     partk = ops.new_partials(K, dev)
     t32 = timeit(lambda: ops.pwconv_bwd_data_bn(dy, w, z, sc, sh, ops.ACT_RELU6, mean, invstd, partk, out=gx))
     line = 'dgbn M=%6d K=%4d N=%4d  fp32 %7.1f us             |' % (M, K, N, t32)
-    for nt, mi in cands:
-        L.set_option(b'gemm_nt', nt or 0); L.set_option(b'gemm_mi', mi or 0)
+    for nt, mi, wm in cands:
+        if wm and nt and K <= 16 * (nt - 4):
+            continue
+        pin(nt, mi, wm)
         t = timeit(lambda: ops.pwconv_bwd_data_sb(dy, w_sp, N, out=gx, z=z, scale=sc, shift=sh, act=ops.ACT_RELU6, mean=mean,
                                                   invstd=invstd, partials=partk))
-        line += ' sb[%s,%s] %6.1f          ' % (nt, mi, t)
-    L.set_option(b'gemm_nt', 0); L.set_option(b'gemm_mi', 0)
+        line += ' [%s,%s,%s] %6.1f        ' % (nt, mi, wm, t)
+    pin(None, None, None)
     print(line, flush=True)

@@ -143,3 +143,21 @@ def _run(ops, case):
     d = gx64 * (z.double() > 0)
     p = part[:rows * 2 * K].reshape(rows, 2, K).double().sum(0)
     assert float((p[0] - d.sum(0)).abs().max()) < 2e-4 * float(d.abs().sum(0).max())
+
+
+@pytest.mark.parametrize('nt,mi,wm', [(16, 2, 1), (16, 1, 1), (16, 1, 2), (12, 2, 1), (12, 2, 2), (8, 2, 2)])
+def test_every_wide_split_gemm_tile(ops, nt, mi, wm):
+    """the one-workgroup-per-CU family (128 / 256 rows x up to 256 columns, 256 or 512 threads)"""
+    L = ops.lib()
+    L.set_option(b'pw_small_min_rows', 1 << 30)
+    L.set_option(b'sb_wm', wm)
+    L.set_option(b'sb_nt', nt)
+    L.set_option(b'gemm_mi', mi)
+    try:
+        for case in [(4357, 100, 200), (2600, 728, 252), (70001, 304, 256), (1301, 260, 132)]:
+            _run(ops, case)
+    finally:
+        L.set_option(b'sb_wm', 0)
+        L.set_option(b'sb_nt', 0)
+        L.set_option(b'gemm_mi', 0)
+        L.set_option(b'pw_small_min_rows', 64)

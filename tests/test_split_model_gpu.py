@@ -1,0 +1,67 @@
+"""Whole-model parity with the split-bf16 GEMMs switched on (DL3P_SPLIT_GEMM=1): the same train-step /
+predict comparisons against the float64 oracle as tests/test_model_gpu.py and tests/test_production_shapes_gpu.py, at their
+UNCHANGED tolerances (logits and loss 1e-3, parameter gradients 8e-3 / 1e-2 at 65 x 65 and 5e-3 at 513 x 513, weights after the
+step 1e-3).  The opt-in only stays a candidate for the default if these hold."""
+import pytest
+
+from conftest import load_pkg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def split_on(monkeypatch):
+    monkeypatch.setenv('DL3P_SPLIT_GEMM', '1')
+    monkeypatch.setenv('DL3P_SPLIT_MIN_K', '32')      # small test models: let every GEMM the tiled kernel serves take the split path
+    monkeypatch.setenv('DL3P_SPLIT_MIN_N', '16')
+    monkeypatch.setenv('DL3P_SPLIT_MIN_ROWS', '64')
+    monkeypatch.setenv('DL3P_SPLIT_MIN_ROWS_BN', '64')
+    yield
+
+
+def _uses_split(m):
+    ex = next(iter(m._exec.values()))
+    return m._store.Sb is not None and any('pwconv_fwd_sb' in lab[0] for lab in ex.fwd.labels)
+
+
+@pytest.mark.parametrize('model_type,H,W,freeze,OS', [('mobilenetv2', 65, 65, 0, 16), ('xception', 65, 65, 0, 16),
+                                                      ('mobilenetv3large', 64, 96, 0, 16), ('resnet50', 65, 65, 0, 16),
+                                                      ('xception', 97, 97, 0, 8)])
+def test_train_step_matches_oracle_with_split_gemms(model_type, H, W, freeze, OS):
+    import test_model_gpu as T
+    T.test_train_step_matches_oracle(model_type, H, W, freeze, OS)
+
+
+@pytest.mark.parametrize('model_type,H,W', [('mobilenetv2', 65, 65), ('xception', 65, 65)])
+def test_predict_matches_oracle_with_split_gemms(model_type, H, W):
+    import test_model_gpu as T
+    T.test_predict_matches_oracle(model_type, H, W)
+
+
+@pytest.mark.parametrize('model_type', ['mobilenetv2', 'xception'])
+def test_train_step_513_with_split_gemms(model_type, monkeypatch):
+    """production shapes, production thresholds of the split dispatch (K >= 128, N >= 128, 16384 rows)"""
+    for k in ('DL3P_SPLIT_MIN_K', 'DL3P_SPLIT_MIN_N', 'DL3P_SPLIT_MIN_ROWS', 'DL3P_SPLIT_MIN_ROWS_BN'):
+        monkeypatch.delenv(k)
+    import test_production_shapes_gpu as T
+    L = load_pkg('_lib').lib()
+    L.set_option(b'pw_small_min_rows', -1)
+    try:
+        T.test_train_step_513_production_dispatch(model_type)
+    finally:
+        L.set_option(b'pw_small_min_rows', 64)
+
+
+def test_the_split_path_is_actually_taken():
+    import numpy as np
+    pkg = load_pkg()
+    m = pkg.get_deeplabv3p_model('mobilenetv2', 21, (65, 65), 16, training=True)
+    m.compile(optimizer=pkg.SGD(0.01), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
+    m.use_graphs = False
+    x = np.random.default_rng(0).uniform(-1, 1, (2, 65, 65, 3)).astype(np.float32)
+    y = np.zeros((2, 65 * 65, 1), np.float32)
+    m.train_on_batch(x, y)
+    assert _uses_split(m)
+    ex = m._executor(2, True)
+    names = [lab[0] for lab in ex.fwd.labels + ex.bwd.labels + ex.opt.labels]
+    assert any('pwconv_bwd_data_sb' in n for n in names) and any('split_bf16x3_batch' in n for n in names)

@@ -73,20 +73,25 @@ extern "C" int dl3p_split_bf16x3_batch(const float* src, void* dst, const int64_
 }
 
 // ------------------------------------------------------------------------------ forward / data gradient
-template <int NT, bool STATS, int MI, bool BNB, bool GA>
-__global__ __launch_bounds__(256, 2) void pw_gemm_sb_kernel(GemmParams p) {
+// WM: groups of four waves along M (256 * WM threads; the B tile is staged once for all of them).  NT up to 16 (256 output
+// columns per workgroup: the A tile of a 256-wide layer is then split ONCE, not once per column block).  Big tiles run one
+// workgroup per CU -- what they buy is operand traffic: at 128 x 128 the split kernel re-fetches 40 KB from L2 / Infinity Cache per
+// K-step and sits at that bandwidth, not at the matrix pipe.
+template <int NT, bool STATS, int MI, bool BNB, bool GA, int WM>
+__global__ __launch_bounds__(256 * WM, (WM == 1 && NT <= 8) ? 2 : 1) void pw_gemm_sb_kernel(GemmParams p) {
   constexpr int BKT = SB_BKT, PB = SB_PB;
-  constexpr int BM = 64 * MI, BN = 16 * NT;
+  constexpr int NTHR = 256 * WM, NW = 4 * WM, RPP = 64 * WM;     // threads, waves, A rows staged per pass
+  constexpr int BM = 64 * MI * WM, BN = 16 * NT;
   constexpr int A_PLANE = BM * PB, B_PLANE = BN * PB;          // bf16 elements
   constexpr int OPER_BYTES = 3 * (A_PLANE + B_PLANE) * 2;
-  constexpr int NA = MI;                                       // A passes of 64 rows: a thread stages 8 consecutive k of one row
-  constexpr int NBC = (3 * BN * 4 + 255) / 256;                // 16-byte chunks of the B tile per thread
+  constexpr int NA = MI;                                       // A passes of RPP rows: a thread stages 8 consecutive k of one row
+  constexpr int NBC = (3 * BN * 4 + NTHR - 1) / NTHR;          // 16-byte chunks of the B tile per thread
   constexpr int TPP = NT < 4 ? NT : 4;
   constexpr int NPASS = (NT + TPP - 1) / TPP;
   constexpr int CH = 16 * TPP;
   constexpr int EPITCH = CH + 4;
   constexpr int RW = 16 * MI;
-  constexpr int ES_BYTES = 4 * RW * EPITCH * 4;
+  constexpr int ES_BYTES = NW * RW * EPITCH * 4;
   constexpr int RED_OFF = (OPER_BYTES > ES_BYTES ? OPER_BYTES : ES_BYTES);
   extern __shared__ __attribute__((aligned(16))) unsigned char sb_lds[];
   unsigned short* As = reinterpret_cast<unsigned short*>(sb_lds);
@@ -108,19 +113,27 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_sb_kernel(GemmParams p) {
   const int ak8 = (t & 3) * 8;     // first of this thread's 8 k of the K tile
   const char* Ab = reinterpret_cast<const char*>(p.A);
 
-  float4 ra[NA][2];
+  // A is prefetched TWO K-steps ahead (two register sets, PAR = it & 1): with six bf16 MFMAs per tile the multiply phase of a
+  // K-step lasts ~0.7 us, less than an HBM round trip under load -- one step ahead, the kernel sat at bytes-in-flight / latency
+  // (28 % of the matrix peak whatever the tile shape).  B (L2 hits) stays one step ahead and is issued BEFORE the A loads of the
+  // step after next, so that the wait for it does not drain those.
+  float4 ra[2][NA][2];
   uint4 rb[NBC];
-  float4 rsc[2] = {make_float4(1.f, 1.f, 1.f, 1.f), make_float4(1.f, 1.f, 1.f, 1.f)}, rsh[2] = {zero4(), zero4()};
-  uint32_t a_row[NA];
-  int g_by[GA ? NA : 1], g_bx[GA ? NA : 1];
-  uint32_t g_ok = 0;               // GA: bit (2 i + h) = float4 h of pass i hit the source tensor
+  float4 rsc[2][2], rsh[2][2];
+  uint32_t a_row[2][NA];
+  int g_by[2][GA ? NA : 1], g_bx[2][GA ? NA : 1];
+  uint32_t g_ok[2] = {0, 0};       // GA: bit (2 i + h) = float4 h of pass i hit the source tensor
   uint32_t b_off[NBC];             // byte offset of this thread's B chunks at k0 = 0
   bool b_ok[NBC];
   int b_lds[NBC];                  // bf16 element offset of the chunk in Bs
-  int pf_m0 = -1;
+  int pf_m0[2] = {-1, -1};
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { rsc[s2][h] = make_float4(1.f, 1.f, 1.f, 1.f); rsh[s2][h] = zero4(); }
 #pragma unroll
   for (int i = 0; i < NBC; ++i) {
-    const int idx = t + 256 * i;
+    const int idx = t + NTHR * i;
     const int c = idx < 3 * BN * 4 ? idx : 3 * BN * 4 - 1;
     const int plane = c / (BN * 4), rem = c - plane * (BN * 4);
     const int r = rem >> 2, ch = rem & 3;
@@ -131,27 +144,34 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_sb_kernel(GemmParams p) {
   }
   const char* Bb = reinterpret_cast<const char*>(p.Bsp);
 
-  auto prefetch = [&](int it) {
+  auto prefetch_b = [&](int it) {
+    const int k0 = (it % nk) * BKT;
+#pragma unroll
+    for (int i = 0; i < NBC; ++i) rb[i] = *reinterpret_cast<const uint4*>(Bb + (b_off[i] + (uint32_t)k0 * 2u));
+  };
+
+  auto prefetch_a = [&](int it, auto par) {
+    constexpr int P = decltype(par)::value;
     const int kt = it % nk;
     const int mt = blockIdx.x + (it / nk) * gridDim.x;
     const int m0 = mt * BM;
     const int k0 = kt * BKT;
     if (GA) {
-      if (m0 != pf_m0) {
-        pf_m0 = m0;
+      if (m0 != pf_m0[P]) {
+        pf_m0[P] = m0;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-          const int m = m0 + ar + 64 * i;
+          const int m = m0 + ar + RPP * i;
           const int mc = min(m, p.M - 1);
           const int row = mc / p.g_RW, x = mc - row * p.g_RW;
           const int n = row / p.g_RH, y = row - n * p.g_RH;
-          g_by[i] = m < p.M ? y * p.g_mul + p.g_ay : -(1 << 20);
-          g_bx[i] = x * p.g_mul + p.g_ax;
-          a_row[i] = (uint32_t)n * (uint32_t)(p.g_SH * p.g_SW);
+          g_by[P][i] = m < p.M ? y * p.g_mul + p.g_ay : -(1 << 20);
+          g_bx[P][i] = x * p.g_mul + p.g_ax;
+          a_row[P][i] = (uint32_t)n * (uint32_t)(p.g_SH * p.g_SW);
         }
       }
-      g_ok = 0;
-      const int par = (1 << p.g_shift) - 1;
+      g_ok[P] = 0;
+      const int par_mask = (1 << p.g_shift) - 1;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int kraw = k0 + ak8 + 4 * h;
@@ -162,50 +182,49 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_sb_kernel(GemmParams p) {
         const int dyo = ky * p.g_d, dxo = kx * p.g_d;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-          const int ty = g_by[i] + dyo, tx = g_bx[i] + dxo;
+          const int ty = g_by[P][i] + dyo, tx = g_bx[P][i] + dxo;
           const int sy = ty >> p.g_shift, sx = tx >> p.g_shift;
-          const bool ok = ty >= 0 && tx >= 0 && ((ty | tx) & par) == 0 && sy < p.g_SH && sx < p.g_SW && kraw < p.K;
-          const uint32_t off = ok ? ((a_row[i] + (uint32_t)(sy * p.g_SW + sx)) * (uint32_t)p.lda + (uint32_t)c) * 4u : 0u;
-          ra[i][h] = *reinterpret_cast<const float4*>(Ab + off);
-          g_ok |= ok ? (1u << (2 * i + h)) : 0u;
+          const bool ok = ty >= 0 && tx >= 0 && ((ty | tx) & par_mask) == 0 && sy < p.g_SH && sx < p.g_SW && kraw < p.K;
+          const uint32_t off = ok ? ((a_row[P][i] + (uint32_t)(sy * p.g_SW + sx)) * (uint32_t)p.lda + (uint32_t)c) * 4u : 0u;
+          ra[P][i][h] = *reinterpret_cast<const float4*>(Ab + off);
+          g_ok[P] |= ok ? (1u << (2 * i + h)) : 0u;
         }
         if (p.scale) {
-          rsc[h] = *reinterpret_cast<const float4*>(p.scale + c);
-          rsh[h] = *reinterpret_cast<const float4*>(p.shift + c);
+          rsc[P][h] = *reinterpret_cast<const float4*>(p.scale + c);
+          rsh[P][h] = *reinterpret_cast<const float4*>(p.shift + c);
         }
       }
     } else {
-      if (m0 != pf_m0) {
-        pf_m0 = m0;
+      if (m0 != pf_m0[P]) {
+        pf_m0[P] = m0;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) a_row[i] = (uint32_t)min(m0 + ar + 64 * i, p.M - 1) * (uint32_t)p.lda * 4u;
+        for (int i = 0; i < NA; ++i) a_row[P][i] = (uint32_t)min(m0 + ar + RPP * i, p.M - 1) * (uint32_t)p.lda * 4u;
       }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const uint32_t kb = (uint32_t)min(k0 + ak8 + 4 * h, p.K - 4) * 4u;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) ra[i][h] = *reinterpret_cast<const float4*>(Ab + (a_row[i] + kb));
+        for (int i = 0; i < NA; ++i) ra[P][i][h] = *reinterpret_cast<const float4*>(Ab + (a_row[P][i] + kb));
         if (p.scale) {
-          rsc[h] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.scale) + kb);
-          rsh[h] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.shift) + kb);
+          rsc[P][h] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.scale) + kb);
+          rsh[P][h] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.shift) + kb);
         }
       }
     }
-#pragma unroll
-    for (int i = 0; i < NBC; ++i) rb[i] = *reinterpret_cast<const uint4*>(Bb + (b_off[i] + (uint32_t)k0 * 2u));
   };
 
   const float act_lo = p.act == DL3P_ACT_NONE ? -DL3P_INF : 0.f;
   const float act_hi = (p.act == DL3P_ACT_NONE || p.act == DL3P_ACT_RELU) ? DL3P_INF : 6.f;
-  auto prologue4 = [&](float4 v, int h) {
-    v = fma4(v, rsc[h], rsh[h]);
+  auto prologue4 = [&](float4 v, float4 sc4, float4 sh4) {
+    v = fma4(v, sc4, sh4);
     if (p.act >= DL3P_ACT_HSWISH) return act_apply4(v, p.act);
     return make_float4(__builtin_amdgcn_fmed3f(v.x, act_lo, act_hi), __builtin_amdgcn_fmed3f(v.y, act_lo, act_hi),
                        __builtin_amdgcn_fmed3f(v.z, act_lo, act_hi), __builtin_amdgcn_fmed3f(v.w, act_lo, act_hi));
   };
   const bool has_pro = p.scale != nullptr || p.act != DL3P_ACT_NONE;
 
-  auto stage = [&](int it) {
+  auto stage = [&](int it, auto par) {
+    constexpr int P = decltype(par)::value;
     const int kt = it % nk;
     const int mt = blockIdx.x + (it / nk) * gridDim.x;
     const int m0 = mt * BM;
@@ -213,21 +232,33 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_sb_kernel(GemmParams p) {
     const bool a_edge = m0 + BM > p.M || k0 + BKT > p.K;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int r = ar + 64 * i;
+      const int r = ar + RPP * i;
       float4 v[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        v[h] = ra[i][h];
-        if (has_pro) v[h] = prologue4(v[h], h);
+        v[h] = ra[P][i][h];
+        if (has_pro) v[h] = prologue4(v[h], rsc[P][h], rsh[P][h]);
         // padding of the M / K tails and (GA) taps outside the source stay exactly zero
-        if (GA) v[h] = ((g_ok >> (2 * i + h)) & 1u) ? v[h] : zero4();
+        if (GA) v[h] = ((g_ok[P] >> (2 * i + h)) & 1u) ? v[h] : zero4();
         else if (a_edge) v[h] = (k0 + ak8 + 4 * h < p.K && m0 + r < p.M) ? v[h] : zero4();
       }
       uint4 hh, mm, ll;
+#ifdef DL3P_SB_ABLATE
+      if (p.stagger == 1) {          // ablation: no split arithmetic (results wrong, time only)
+        hh = make_uint4(__builtin_bit_cast(uint32_t, v[0].x), __builtin_bit_cast(uint32_t, v[0].z), __builtin_bit_cast(uint32_t, v[1].x), __builtin_bit_cast(uint32_t, v[1].z));
+        mm = make_uint4(__builtin_bit_cast(uint32_t, v[0].y), __builtin_bit_cast(uint32_t, v[0].w), __builtin_bit_cast(uint32_t, v[1].y), __builtin_bit_cast(uint32_t, v[1].w));
+        ll = hh;
+      } else
+#endif
+      {
       split2(v[0].x, v[0].y, hh.x, mm.x, ll.x);
       split2(v[0].z, v[0].w, hh.y, mm.y, ll.y);
       split2(v[1].x, v[1].y, hh.z, mm.z, ll.z);
       split2(v[1].z, v[1].w, hh.w, mm.w, ll.w);
+      }
+#ifdef DL3P_SB_ABLATE
+      if (p.stagger == 6 && it > 0) continue;      // ablation: no A-tile LDS stores after the first step
+#endif
       unsigned short* d = As + r * PB + ak8;
       *reinterpret_cast<uint4*>(d) = hh;
       *reinterpret_cast<uint4*>(d + A_PLANE) = mm;
@@ -238,7 +269,10 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_sb_kernel(GemmParams p) {
       // (the empty asm pins the wait for rb[i] in front of its store, as in pw_gemm_kernel: left alone, the compiler parks an
       // s_waitcnt inside the next K-step's prefetch burst)
       asm volatile("" :: "v"(rb[i].x), "v"(rb[i].y), "v"(rb[i].z), "v"(rb[i].w));
-      if (t + 256 * i < 3 * BN * 4) {
+#ifdef DL3P_SB_ABLATE
+      if (p.stagger == 5 && it > 0) continue;      // ablation: no B-tile LDS stores after the first step
+#endif
+      if (t + NTHR * i < 3 * BN * 4) {
         uint4 v = rb[i];
         if (!b_ok[i]) v = make_uint4(0u, 0u, 0u, 0u);
         *reinterpret_cast<uint4*>(Bs + b_lds[i]) = v;
@@ -257,12 +291,18 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_sb_kernel(GemmParams p) {
     for (int i = 0; i < NPASS; ++i) { st_s[i] = zero4(); st_q[i] = zero4(); }
   }
 
-  if (it_total > 0) prefetch(0);
-  for (int it = 0; it < it_total; ++it) {
-    stage(it);
+  auto step = [&](int it, auto par) {
+    constexpr int P = decltype(par)::value;
+    stage(it, par);
     __syncthreads();
-    if (it + 1 < it_total) prefetch(it + 1);
-    {
+#ifdef DL3P_SB_ABLATE
+    const int abl = p.stagger;
+#else
+    constexpr int abl = 0;
+#endif
+    if (it + 1 < it_total && !(abl == 7 && it > 1)) prefetch_b(it + 1);
+    if (it + 2 < it_total && !(abl == 3 && it > 1)) prefetch_a(it + 2, par);       // into the register set this step has just consumed
+    if (abl != 2) {
       s16x8 xa[MI][3];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
@@ -290,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_sb_kernel(GemmParams p) {
       }
     }
     __syncthreads();
-    if (it % nk == nk - 1) {
+    if (it % nk == nk - 1 && abl != 4) {
       const int mt = blockIdx.x + (it / nk) * gridDim.x;
       const int m0 = mt * BM;
       float* es = Es + w * RW * EPITCH;
@@ -362,6 +402,12 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_sb_kernel(GemmParams p) {
       }
       __syncthreads();   // the next stage() overwrites the epilogue buffer
     }
+  };
+  if (it_total > 0) { prefetch_b(0); prefetch_a(0, std::integral_constant<int, 0>{}); }
+  if (it_total > 1) prefetch_a(1, std::integral_constant<int, 1>{});
+  for (int it = 0; it < it_total; it += 2) {
+    step(it, std::integral_constant<int, 0>{});
+    if (it + 1 < it_total) step(it + 1, std::integral_constant<int, 1>{});
   }
 
   if (STATS) {
@@ -377,18 +423,19 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_sb_kernel(GemmParams p) {
         s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
         const int col = ps * CH + cq * 4 + e;
         if (rr == 0 && cq * 4 < CH && col < BN) {
-          red[(0 * 4 + w) * BN + col] = s1;
-          red[(1 * 4 + w) * BN + col] = s2;
+          red[(0 * NW + w) * BN + col] = s1;
+          red[(1 * NW + w) * BN + col] = s2;
         }
       }
     }
     __syncthreads();
     if (p.partials) {
-      for (int i = t; i < 2 * BN; i += 256) {
+      for (int i = t; i < 2 * BN; i += NTHR) {
         const int which = i / BN, nn = i - which * BN;
         if (n0 + nn < p.N) {
-          float s = red[(which * 4 + 0) * BN + nn] + red[(which * 4 + 1) * BN + nn] +
-                    red[(which * 4 + 2) * BN + nn] + red[(which * 4 + 3) * BN + nn];
+          float s = 0.f;
+#pragma unroll
+          for (int ww = 0; ww < NW; ++ww) s += red[(which * NW + ww) * BN + nn];
           p.partials[((size_t)blockIdx.x * 2 + which) * p.N + n0 + nn] = s;
         }
       }
@@ -396,39 +443,61 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_sb_kernel(GemmParams p) {
   }
 }
 
-template <int NT, bool STATS, int MI, bool BNB, bool GA>
+template <int NT, bool STATS, int MI, bool BNB, bool GA, int WM>
 static void launch_sb_one(const GemmParams& p, dim3 grid, hipStream_t st) {
-  constexpr int BM = 64 * MI, BN = 16 * NT;
+  constexpr int BM = 64 * MI * WM, BN = 16 * NT;
   constexpr int OPER = 3 * (BM + BN) * SB_PB * 2;
   constexpr int TPP = NT < 4 ? NT : 4;
-  constexpr int ES = 4 * 16 * MI * (16 * TPP + 4) * 4;
-  constexpr int RED = STATS ? 2 * 4 * BN * 4 : 0;
+  constexpr int ES = 4 * WM * 16 * MI * (16 * TPP + 4) * 4;
+  constexpr int RED = STATS ? 2 * 4 * WM * BN * 4 : 0;
   constexpr size_t lds = (size_t)(OPER > ES ? OPER : ES) + RED;
   static bool attr_set = false;
   if (!attr_set) {
     if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)pw_gemm_sb_kernel<NT, STATS, MI, BNB, GA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)pw_gemm_sb_kernel<NT, STATS, MI, BNB, GA, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  dl3p_launch(pw_gemm_sb_kernel<NT, STATS, MI, BNB, GA>, grid, dim3(256), lds, st, p);
+  dl3p_launch(pw_gemm_sb_kernel<NT, STATS, MI, BNB, GA, WM>, grid, dim3(256 * WM), lds, st, p);
 }
 
 template <bool STATS, int MI, bool BNB, bool GA>
 static void launch_sb_mi(const GemmParams& p, int nt, dim3 grid, hipStream_t st) {
   switch (nt) {
-    case 1: launch_sb_one<1, STATS, MI, BNB, GA>(p, grid, st); break;
-    case 2: launch_sb_one<2, STATS, MI, BNB, GA>(p, grid, st); break;
-    case 3: launch_sb_one<3, STATS, MI, BNB, GA>(p, grid, st); break;
-    case 4: launch_sb_one<4, STATS, MI, BNB, GA>(p, grid, st); break;
-    case 5: launch_sb_one<5, STATS, MI, BNB, GA>(p, grid, st); break;
-    case 6: launch_sb_one<6, STATS, MI, BNB, GA>(p, grid, st); break;
-    case 7: launch_sb_one<7, STATS, MI, BNB, GA>(p, grid, st); break;
-    default: launch_sb_one<8, STATS, MI, BNB, GA>(p, grid, st); break;
+    case 1: launch_sb_one<1, STATS, MI, BNB, GA, 1>(p, grid, st); break;
+    case 2: launch_sb_one<2, STATS, MI, BNB, GA, 1>(p, grid, st); break;
+    case 3: launch_sb_one<3, STATS, MI, BNB, GA, 1>(p, grid, st); break;
+    case 4: launch_sb_one<4, STATS, MI, BNB, GA, 1>(p, grid, st); break;
+    case 5: launch_sb_one<5, STATS, MI, BNB, GA, 1>(p, grid, st); break;
+    case 6: launch_sb_one<6, STATS, MI, BNB, GA, 1>(p, grid, st); break;
+    case 7: launch_sb_one<7, STATS, MI, BNB, GA, 1>(p, grid, st); break;
+    default: launch_sb_one<8, STATS, MI, BNB, GA, 1>(p, grid, st); break;
   }
 }
 
-// what pwconv.hip calls once it has planned the launch (same (nt, mi, grid) conventions as its launch_gemm)
-void dl3p_launch_gemm_sb(const GemmParams& p, bool stats, bool bnb, bool ga, int nt, int mi, dim3 grid, hipStream_t st) {
+// the wide-tile family (one workgroup per CU): nt in {8, 12, 16}, mi in {1, 2}, wm in {1, 2}; never with the implicit-GEMM gather
+template <bool STATS, bool BNB>
+static void launch_sb_wide(const GemmParams& p, int nt, int mi, int wm, dim3 grid, hipStream_t st) {
+#define DL3P_SBW(N_, M_, W_) if (nt == N_ && mi == M_ && wm == W_) { launch_sb_one<N_, STATS, M_, BNB, false, W_>(p, grid, st); return; }
+  DL3P_SBW(16, 2, 1) DL3P_SBW(16, 1, 2) DL3P_SBW(16, 2, 2) DL3P_SBW(12, 2, 1) DL3P_SBW(12, 2, 2) DL3P_SBW(8, 2, 2) DL3P_SBW(16, 1, 1)
+#undef DL3P_SBW
+  launch_sb_one<16, STATS, 2, BNB, false, 1>(p, grid, st);
+}
+
+bool dl3p_sb_wide_config(int nt, int mi, int wm) {
+  static const int ok[][3] = {{16, 2, 1}, {16, 1, 2}, {16, 2, 2}, {12, 2, 1}, {12, 2, 2}, {8, 2, 2}, {16, 1, 1}};
+  for (auto& c : ok) if (c[0] == nt && c[1] == mi && c[2] == wm) return true;
+  return false;
+}
+
+// what pwconv.hip calls once it has planned the launch (same (nt, mi, grid) conventions as its launch_gemm; wm > 1 or nt > 8
+// selects the wide-tile family)
+void dl3p_launch_gemm_sb(const GemmParams& p, bool stats, bool bnb, bool ga, int nt, int mi, int wm, dim3 grid, hipStream_t st) {
+  if (wm > 1 || nt > 8) {
+    if (bnb) launch_sb_wide<true, true>(p, nt, mi, wm, grid, st);
+    else if (stats) launch_sb_wide<true, false>(p, nt, mi, wm, grid, st);
+    else launch_sb_wide<false, false>(p, nt, mi, wm, grid, st);
+    return;
+  }
 #define DL3P_SB(S, B, G) \
   { if (mi == 1) launch_sb_mi<S, 1, B, G>(p, nt, grid, st); else launch_sb_mi<S, 2, B, G>(p, nt, grid, st); return; }
   if (ga) {

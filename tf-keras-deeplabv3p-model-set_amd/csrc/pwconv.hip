@@ -671,6 +671,7 @@ static bool pw_small_pick(int K, int N, SmallShape* out) {
 // tests lower it through dl3p_set_option so that small test shapes reach those kernels too, and reset it for the
 // tests that check the production dispatch at the production shapes.
 static int g_gemm_force_nt = 0, g_gemm_force_mi = 0, g_gemm_force_pc = 0, g_gemm_use_table = -1;   // see gemm_tuned_lookup / gemm_plan
+static int g_sb_force_wm = 0, g_sb_force_nt = 0;      // dl3p_set_option("sb_wm" / "sb_nt"): pin the split kernel's wide-tile family (gemm_plan_sb)
 static int g_wgrad_force_tile = -1, g_wgrad_force_per_cu = 0;                    // see wgrad_pick_tile / wgrad_split
 static int g_pw_small_min_rows = -1;
 static int pw_small_min_rows() {
@@ -688,6 +689,8 @@ extern "C" int dl3p_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm_mi")) { g_gemm_force_mi = (value == 1 || value == 2) ? value : 0; return DL3P_OK; }
   if (!strcmp(name, "gemm_per_cu")) { g_gemm_force_pc = value > 0 ? value : 0; return DL3P_OK; }
   if (!strcmp(name, "gemm_tuned")) { g_gemm_use_table = value ? 1 : 0; return DL3P_OK; }
+  if (!strcmp(name, "sb_wm")) { g_sb_force_wm = (value >= -1 && value <= 2) ? value : 0; return DL3P_OK; }    // -1: never wide
+  if (!strcmp(name, "sb_nt")) { g_sb_force_nt = (value == 8 || value == 12 || value == 16) ? value : 0; return DL3P_OK; }
   if (!strcmp(name, "dw_per_cu")) { dl3p_dw_force_per_cu = value > 0 ? value : 0; return DL3P_OK; }
   if (!strcmp(name, "dw_want")) { dl3p_dw_force_want = value > 0 ? value : 0; return DL3P_OK; }
   if (!strcmp(name, "dw_maxth")) { dl3p_dw_force_maxth = value > 0 ? value : 0; return DL3P_OK; }
@@ -1058,16 +1061,47 @@ extern "C" int dl3p_pwconv_bwd_data_bn(const float* dy, int lddy, const float* w
 // planes [3][rows][pitch] (dl3p_split_bf16x3_batch; rows = the GEMM's OUTPUT columns, reduction index contiguous, pitch a
 // multiple of 32 with zero padding), the activations are split while their tile is staged.  Shapes the tiled kernel does not serve
 // (few rows, or few-channel layers on the streaming kernels) must go through the fp32 entry points: *_sb_supported says which.
-void dl3p_launch_gemm_sb(const GemmParams& p, bool stats, bool bnb, bool ga, int nt, int mi, dim3 grid, hipStream_t st);
+void dl3p_launch_gemm_sb(const GemmParams& p, bool stats, bool bnb, bool ga, int nt, int mi, int wm, dim3 grid, hipStream_t st);
+bool dl3p_sb_wide_config(int nt, int mi, int wm);
 
-static void gemm_plan_sb(int role, int M, int K, int N, int* nt, int* gx, int* gy, int* num_m_tiles, int* mi) {
+// tile choice of a split-bf16 launch.  Wide tiles (one workgroup per CU: 128 or 256 rows x up to 256 columns, the A tile split
+// once for all of N) where there are enough row tiles to go round; otherwise the 2-workgroups-per-CU tiles of the fp32 kernel.
+static void gemm_plan_sb(int role, int M, int K, int N, int* nt, int* gx, int* gy, int* num_m_tiles, int* mi, int* wm) {
   int force_mi = 0, force_pc = 0;
   *nt = pick_nt(N, M);
-  if (const GemmTuned* e = gemm_tuned_lookup(role + 5, M, K, N)) { *nt = e->nt; force_mi = e->mi; force_pc = e->pc; }   // roles 5..8
+  *wm = 1;
+  // measured (scripts/micro/sb_gemm.py, profiles/r03_split_gemm.txt): 128-row tiles with the widest column block win on every
+  // shape with a few thousand rows or more (the fp32 kernel's 64-row / three-workgroup choice for long GEMMs loses here: two A
+  // register sets); with the fused BatchNorm sums 128 x 64, the widest that does not spill.  The one-workgroup-per-CU wide tiles
+  // (sb_wm) are no faster -- the kernel is bound by its staging pipeline, not by operand traffic -- and stay opt-in.
+  if (M >= 4096) force_mi = 2;
+  if (role == 3 && N > 64) { *nt = 4; force_mi = 2; }
+  int wide_nt = 0, wide_mi = 2, wide_wm = 1;
+  if (const GemmTuned* e = gemm_tuned_lookup(role + 5, M, K, N)) {      // roles 5..8; pc > 100: wide family, wm = pc - 100
+    if (e->pc > 100) { wide_nt = e->nt; wide_mi = e->mi; wide_wm = e->pc - 100; }
+    else { wide_nt = 0; *nt = e->nt; force_mi = e->mi; force_pc = e->pc; }
+  }
+  if (g_sb_force_wm > 0) { wide_nt = g_sb_force_nt ? g_sb_force_nt : 16; wide_wm = g_sb_force_wm; wide_mi = g_gemm_force_mi ? g_gemm_force_mi : 2; }
+  if (g_sb_force_wm < 0) wide_nt = 0;
+  if (wide_nt && dl3p_sb_wide_config(wide_nt, wide_mi, wide_wm) && role != 3) {     // (role 3: the z-prefetch registers of the fused BatchNorm sums do not fit the wide tiles)
+    *nt = wide_nt; *mi = wide_mi; *wm = wide_wm;
+    const int bm = 64 * wide_mi * wide_wm, nb = ceil_div(N, 16 * wide_nt);
+    const int mt = ceil_div(M, bm);
+    int gxm = DL3P_NUM_CUS / nb;
+    if (gxm < 1) gxm = 1;
+    if (gxm > DL3P_MAX_STAT_ROWS) gxm = DL3P_MAX_STAT_ROWS;
+    int g = mt;
+    if (mt > gxm) g = ceil_div(mt, ceil_div(mt, gxm));
+    *gx = g; *gy = nb; *num_m_tiles = mt;
+    return;
+  }
   if (g_gemm_force_nt) *nt = g_gemm_force_nt;
   if (g_gemm_force_mi) force_mi = g_gemm_force_mi;
   if (g_gemm_force_pc) force_pc = g_gemm_force_pc;
+  if (*nt > 8) *nt = 8;
   gemm_grid(M, N, *nt, gx, gy, num_m_tiles, mi, role == 3, force_mi, force_pc);
+  // 128-row tiles with the fused BatchNorm sums spill from 80 columns up (two A register sets + the z prefetch)
+  if (role == 3 && *mi == 2 && *nt > 4) gemm_grid(M, N, *nt, gx, gy, num_m_tiles, mi, true, 1, force_pc);
 }
 
 extern "C" int dl3p_pwconv_sb_supported(int role, int M, int K, int N) {
@@ -1101,10 +1135,11 @@ extern "C" int dl3p_pwconv_fwd_sb(const float* x, int ldx, const float* in_scale
   p.Bsp = (const unsigned short*)wsp; p.bsp_pitch = pitch; p.bsp_plane = (long long)N * pitch;
   p.bias = bias; p.Y = y; p.ldy = ldy; p.partials = stat_partials;
   p.M = M; p.K = K; p.N = N;
-  int nt, gx, gy, mi;
-  gemm_plan_sb(stat_partials ? 1 : 0, M, K, N, &nt, &gx, &gy, &p.num_m_tiles, &mi);
+  int nt, gx, gy, mi, wm;
+  gemm_plan_sb(stat_partials ? 1 : 0, M, K, N, &nt, &gx, &gy, &p.num_m_tiles, &mi, &wm);
+  { const char* e = getenv("DL3P_SB_ABLATE"); p.stagger = e ? atoi(e) : 0; }
   if (rows_out) *rows_out = gx;
-  dl3p_launch_gemm_sb(p, stat_partials != nullptr, false, false, nt, mi, dim3(gx, gy), (hipStream_t)stream);
+  dl3p_launch_gemm_sb(p, stat_partials != nullptr, false, false, nt, mi, wm, dim3(gx, gy), (hipStream_t)stream);
   DL3P_CHECK_LAUNCH(fn);
   return DL3P_OK;
 }
@@ -1140,10 +1175,10 @@ extern "C" int dl3p_pwconv_bwd_data_sb(const float* dy, int lddy, const void* ws
     p.partials = partials;
     p.bb_z = z; p.bb_ldz = ldz; p.bb_scale = scale; p.bb_shift = shift; p.bb_mean = save_mean; p.bb_invstd = save_invstd; p.bb_act = act;
   }
-  int nt, gxn, gy, mi;
-  gemm_plan_sb(bnb ? 3 : 2, M, N, K, &nt, &gxn, &gy, &p.num_m_tiles, &mi);
+  int nt, gxn, gy, mi, wm;
+  gemm_plan_sb(bnb ? 3 : 2, M, N, K, &nt, &gxn, &gy, &p.num_m_tiles, &mi, &wm);
   if (rows_out) *rows_out = gxn;
-  dl3p_launch_gemm_sb(p, bnb, bnb, false, nt, mi, dim3(gxn, gy), (hipStream_t)stream);
+  dl3p_launch_gemm_sb(p, bnb, bnb, false, nt, mi, wm, dim3(gxn, gy), (hipStream_t)stream);
   DL3P_CHECK_LAUNCH(fn);
   return DL3P_OK;
 }

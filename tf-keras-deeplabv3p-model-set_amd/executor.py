@@ -23,6 +23,12 @@ from .graph import ACT_NONE
 MAX_ROWS = 2048
 
 
+def split_gemm_enabled():
+    """DL3P_SPLIT_GEMM=1 (or model.split_gemm / bench.py --split-gemm, which set it before the store is built): the
+    compute-bound pointwise convs run as fp32-accurate split-bf16 GEMMs on the bf16 matrix pipe (csrc/pw_split.hip)"""
+    return os.environ.get('DL3P_SPLIT_GEMM', '0') not in ('', '0')
+
+
 class ParamStore:
     """all weights of a model in three flat float32 device buffers (value, gradient, momentum), laid out
     in Keras weight order with 16-byte aligned offsets.  One SGD launch and one all-reduce cover it."""
@@ -59,6 +65,27 @@ class ParamStore:
         # (they take the place of Pt); both refreshed after every optimiser step
         self.Pb = torch.zeros(off, dtype=torch.bfloat16, device=device) if self.bf16 else None
         self.Pbt = torch.zeros(off, dtype=torch.bfloat16, device=device) if self.bf16 else None
+        # fp32-accurate GEMMs on the bf16 matrix pipe (csrc/pw_split.hip; opt-in, split_gemm_enabled()): every pointwise kernel
+        # pre-split into three bf16 planes, once as [3][N][Kpad] (from the transposed copy: the forward's B operand) and once as
+        # [3][K][Npad] (from the kernel as stored: the data gradient's); refreshed after every optimiser step like Pt
+        self.Sb = None
+        self.sb_fwd, self.sb_bwd = {}, {}           # op -> (element offset in Sb, pitch)
+        if split_gemm_enabled() and not self.bf16:
+            pw = [op for op in graph.ops if op.kind == 'conv_pw']
+            rows_f, rows_b, o = [], [], 0
+            for op in pw:
+                K, Nn = op.cin, op.cout
+                pk, pn = (K + 31) // 32 * 32, (Nn + 31) // 32 * 32
+                self.sb_fwd[op] = (o, pk)
+                rows_f.append([self.offset[op.w], Nn, K, K, o, pk])
+                o += 3 * Nn * pk
+                self.sb_bwd[op] = (o, pn)
+                rows_b.append([self.offset[op.w], K, Nn, Nn, o, pn])
+                o += 3 * K * pn
+            if pw:
+                self.Sb = torch.zeros(o, dtype=torch.int16, device=device)
+                self.sb_table_f = torch.tensor(rows_f, dtype=torch.int64, device=device)
+                self.sb_table_b = torch.tensor(rows_b, dtype=torch.int64, device=device)
         self.upload()
         self.refresh_masks()
 
@@ -73,6 +100,13 @@ class ParamStore:
         if self.tr_table is not None:
             lib().transpose_batch(self.P.data_ptr(), self.Pt.data_ptr(), self.tr_table.data_ptr(),
                                   int(self.tr_table.shape[0]), st)
+        if self.Sb is not None:
+            lib().split_bf16x3_batch(self.Pt.data_ptr(), self.Sb.data_ptr(), self.sb_table_f.data_ptr(), int(self.sb_table_f.shape[0]), st)
+            lib().split_bf16x3_batch(self.P.data_ptr(), self.Sb.data_ptr(), self.sb_table_b.data_ptr(), int(self.sb_table_b.shape[0]), st)
+
+    def sb_ptr(self, op, fwd):
+        off, pitch = (self.sb_fwd if fwd else self.sb_bwd)[op]
+        return self.Sb.data_ptr() + 2 * off, pitch
 
     def view(self, p, buf=None):
         buf = self.P if buf is None else buf
@@ -590,6 +624,11 @@ class Executor:
                 xt = op.x.tensor
                 if self.bf16:
                     self._conv_forward_bf16(P, op, xp, ldx, sp, hp, act, part, rows)
+                elif k == 'conv_pw' and self._use_sb(op, True, part is not None):
+                    wsp, pitch = st.sb_ptr(op, True)
+                    P.k(L.pwconv_fwd_sb, xp, ldx, sp, hp, act, wsp, pitch, st.ptr(op.b) if op.b else None,
+                        self.tptr(op.out), op.out.ld, part, ctypes.byref(rows), N * op.Ho * op.Wo, op.cin, op.cout,
+                        tag='pw:' + op.name)
                 elif k == 'conv_pw':
                     P.k(L.pwconv_fwd_wt, xp, ldx, sp, hp, act, st.ptr(op.w, st.Pt), st.ptr(op.b) if op.b else None,
                         self.tptr(op.out), op.out.ld, part, ctypes.byref(rows), N * op.Ho * op.Wo, op.cin, op.cout,
@@ -972,11 +1011,7 @@ class Executor:
                         bn = bn_op.bn
                         aux = self.bn_aux[bn]
                         rows = ctypes.c_int(0)
-                        P.k(L.pwconv_bwd_data_bn, dz, lddz, st.ptr(op.w), gp, ldg, acc, N * op.Ho * op.Wo, op.cin,
-                            op.cout, self.tptr(bn_op.z), bn_op.z.ld,
-                            self.gscale[bn.group.id].data_ptr() + 4 * bn.offset,
-                            self.gshift[bn.group.id].data_ptr() + 4 * bn.offset, bn.act, aux['mean'].data_ptr(),
-                            aux['invstd'].data_ptr(), self.partials.data_ptr(), ctypes.byref(rows))
+                        self._pw_dgrad_bn(P, op, dz, lddz, gp, ldg, acc, bn_op, self.partials, rows)
                         ctx = P.ctx
                         P.ctx = _op_label(bn_op)
                         self._bn_backward(P, bn_op, fused_rows=rows.value)
@@ -987,12 +1022,12 @@ class Executor:
                         bn = bn_op.bn
                         aux = self.bn_aux[bn]
                         rows = ctypes.c_int(0)
-                        P.k(L.pwconv_bwd_data_bn, dz, lddz, st.ptr(op.w), gp, ldg, acc, N * op.Ho * op.Wo, op.cin,
-                            op.cout, self.tptr(bn_op.z), bn_op.z.ld,
-                            self.gscale[bn.group.id].data_ptr() + 4 * bn.offset,
-                            self.gshift[bn.group.id].data_ptr() + 4 * bn.offset, bn.act, aux['mean'].data_ptr(),
-                            aux['invstd'].data_ptr(), self.partials2.data_ptr(), ctypes.byref(rows))
+                        self._pw_dgrad_bn(P, op, dz, lddz, gp, ldg, acc, bn_op, self.partials2, rows)
                         self._presums[bn_op] = rows.value
+                    elif k == 'conv_pw' and self._use_sb(op, False, False):
+                        wsp, pitch = st.sb_ptr(op, False)
+                        P.k(L.pwconv_bwd_data_sb, dz, lddz, wsp, pitch, gp, ldg, acc, N * op.Ho * op.Wo, op.cin, op.cout,
+                            None, 0, None, None, ACT_NONE, None, None, None, None)
                     elif k == 'conv_pw':
                         P.k(L.pwconv_bwd_data, dz, lddz, st.ptr(op.w), gp, ldg, acc, N * op.Ho * op.Wo, op.cin,
                             op.cout)
@@ -1166,6 +1201,40 @@ class Executor:
                 op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
         else:
             raise NotImplementedError('data gradient of a dense k x k conv is not built for the bf16 path (only RGB stems)')
+
+    def _use_sb(self, op, fwd, stats):
+        """does this pointwise conv run on the split-bf16 GEMM (forward / data-gradient role)?  Only where the tiled kernel
+        serves the shape and the product is compute-bound enough for the bf16 pipe to pay: reduction length and output width from
+        DL3P_SPLIT_MIN_K / DL3P_SPLIT_MIN_N (measured: scripts/micro/sb_gemm.py)"""
+        st = self.store
+        if st.Sb is None or op not in st.sb_fwd:
+            return False
+        M = self.N * op.Ho * op.Wo
+        kred, nout = (op.cin, op.cout) if fwd else (op.cout, op.cin)
+        # where it pays (profiles/r03_split_gemm.txt): many output tiles and a moderate reduction length.  Few-row layers with a
+        # long reduction (Xception's 4356 x 2048 -> 256) and narrow outputs (576 -> 96) are faster on the fp32-input MFMA kernel;
+        # the data gradient with the fused BatchNorm sums only wins on the long decoder layers.
+        env = os.environ.get
+        if kred < int(env('DL3P_SPLIT_MIN_K', '128')) or nout < int(env('DL3P_SPLIT_MIN_N', '128')):
+            return False
+        if M < int(env('DL3P_SPLIT_MIN_ROWS', '16384')) or (not fwd and stats and M < int(env('DL3P_SPLIT_MIN_ROWS_BN', '60000'))):
+            return False
+        role = (1 if stats else 0) if fwd else (3 if stats else 2)
+        return bool(self.L.pwconv_sb_supported(role, M, kred, nout))
+
+    def _pw_dgrad_bn(self, P, op, dz, lddz, gp, ldg, acc, bn_op, partials, rows):
+        """data gradient of a pointwise conv + the BatchNorm-backward partial sums of the BatchNorm in front of it"""
+        st, L, bn = self.store, self.L, bn_op.bn
+        aux = self.bn_aux[bn]
+        M = self.N * op.Ho * op.Wo
+        bnargs = (self.tptr(bn_op.z), bn_op.z.ld, self.gscale[bn.group.id].data_ptr() + 4 * bn.offset,
+                  self.gshift[bn.group.id].data_ptr() + 4 * bn.offset, bn.act, aux['mean'].data_ptr(), aux['invstd'].data_ptr(),
+                  partials.data_ptr(), ctypes.byref(rows))
+        if self._use_sb(op, False, True):
+            wsp, pitch = st.sb_ptr(op, False)
+            P.k(L.pwconv_bwd_data_sb, dz, lddz, wsp, pitch, gp, ldg, acc, M, op.cin, op.cout, *bnargs)
+        else:
+            P.k(L.pwconv_bwd_data_bn, dz, lddz, st.ptr(op.w), gp, ldg, acc, M, op.cin, op.cout, *bnargs)
 
     def _bn_fusion_map(self):
         """{consumer conv op: 'bn' op} for every trainable BatchNorm whose output value is read FIRST (in graph order) by a
@@ -1387,6 +1456,9 @@ class Executor:
                 P.k(L.transpose_batch_bf16, st.P.data_ptr(), st.Pbt.data_ptr(), st.tr_table.data_ptr(), int(st.tr_table.shape[0]))
         elif st.tr_table is not None:      # the forward GEMMs read the transposed kernel copies
             P.k(L.transpose_batch, st.P.data_ptr(), st.Pt.data_ptr(), st.tr_table.data_ptr(), int(st.tr_table.shape[0]))
+        if st.Sb is not None:               # ... and the split-bf16 GEMMs the pre-split planes of both
+            P.k(L.split_bf16x3_batch, st.Pt.data_ptr(), st.Sb.data_ptr(), st.sb_table_f.data_ptr(), int(st.sb_table_f.shape[0]))
+            P.k(L.split_bf16x3_batch, st.P.data_ptr(), st.Sb.data_ptr(), st.sb_table_b.data_ptr(), int(st.sb_table_b.shape[0]))
         return P
 
     # ---------------------------------------------------------------- running
