@@ -265,7 +265,12 @@ class Net:
         return y
 
     def act(self, x, kind):
-        y = Var(self.q(O.act_fwd(getattr(x, 'raw', x.v) if self.bf16 else x.v, kind)))
+        # bf16: the device forms act(z * scale + shift) from the UNROUNDED affine value (fp32 in the consumer's prologue) and
+        # evaluates the activation's derivative there too -- the BatchNorm output itself is never stored -- so both directions
+        # use x.raw here; through the rounded x.v every pre-activation within 2^-9 of a kink (0, 6, +-3) would take the other
+        # branch of the derivative (an O(1) error in that element's gradient, ~1e-3 of all elements)
+        xin = getattr(x, 'raw', x.v) if self.bf16 else x.v
+        y = Var(self.q(O.act_fwd(xin, kind)))
         y.tag = ('act',)
         deriv = None
         if isinstance(x.tag, str):
@@ -276,7 +281,7 @@ class Net:
 
         if deriv is not None:
             # how much the injection changes: elements whose branch differs from this oracle's own derivative
-            own = O.act_bwd(x.v, np.ones_like(x.v), kind)
+            own = O.act_bwd(xin, np.ones_like(x.v), kind)
             self.flip_count += int(np.count_nonzero(np.abs(own - deriv) > 1e-3))      # a flipped branch moves the derivative by O(1)
             self.flip_total += int(own.size)
 
@@ -285,7 +290,7 @@ class Net:
                 if deriv is not None:
                     x.acc(y.g * deriv)
                 else:
-                    x.acc(O.act_bwd(x.v, y.g, kind))
+                    x.acc(O.act_bwd(xin, y.g, kind))
         self.tape.append(bwd)
         return y
 
