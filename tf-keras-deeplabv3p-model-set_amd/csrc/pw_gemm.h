@@ -13,7 +13,7 @@ struct GemmParams {
   int M, K, N;
   int accumulate;
   int num_m_tiles;
-  int stagger;
+  int stagger;         // pw_split.hip's ablation build only (-DDL3P_SB_ABLATE, scripts/micro/sb_ablate.sh)
   int b_kn;            // pw_small_kernel: B stored [K][N] (forward) or [N][K] (data gradient)
   // fused BatchNorm-backward statistics (data gradient writing the gradient of a BN+activation output): with bb_z
   // set, the per-channel partials are (sum g', sum g' * xhat), g' = y * act'(z*scale+shift), xhat = (z-mean)*invstd,
@@ -32,7 +32,4 @@ struct GemmParams {
   // pw_split.hip: the B operand pre-split into three bf16 planes (dl3p_split_bf16x3), [plane][Nout rows][bsp_pitch] with the
   // reduction index contiguous and zero-padded to a multiple of 32; bsp_plane = elements per plane
   const unsigned short* Bsp; int bsp_pitch; long long bsp_plane;
-#ifdef DL3P_STAMP
-  long long* stamp;   // dev instrument: per-wave cycle counts of the loop phases (scripts/micro/stamp_gemm.py)
-#endif
 };

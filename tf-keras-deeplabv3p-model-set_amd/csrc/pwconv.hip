@@ -164,9 +164,6 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
       rsh = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.shift) + kb);
     }
     }
-#ifdef DL3P_STAMP
-    if (p.stagger == 104 && it > 0) return;      // ablation: no B loads after the first K-step
-#endif
 #pragma unroll
     for (int i = 0; i < NB4; ++i) {
       const int idx = min(t + 256 * i, KQ * BN - 1);
@@ -202,40 +199,19 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
     const bool a_edge = m0 + BM > p.M || k0 + BKT > p.K;
     const bool b_edge = n_edge || k0 + BKT > p.K;
     const bool kok = k0 + akq < p.K;
-#ifdef DL3P_STAMP
-    const bool skip_a = p.stagger == 106 && it > 0;     // ablation: A tile not restored (its loads still waited for)
-#else
-    constexpr bool skip_a = false;
-#endif
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int r = ar + RP * i;
       float4 v = ra[i];
-      if (skip_a) { asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); continue; }
       if (has_pro) v = prologue4(v);
       // zero rows/cols stay exactly zero (padding of the M and K tails; GA: taps outside the source)
       if (GA) v = ((g_ok >> i) & 1u) ? v : zero4();
       else if (a_edge) v = (kok && m0 + r < p.M) ? v : zero4();
       *reinterpret_cast<float4*>(&As[r * AP + akq]) = v;
     }
-#ifdef DL3P_STAMP
-    if ((p.stagger == 103 || p.stagger == 104) && it > 0) return;   // ablation: the B tile of the first K-step stays
-    if (p.stagger == 105 && it > 0) {                               // ... but the loads are still waited for
-#pragma unroll
-      for (int i = 0; i < NB4; ++i) asm volatile("" :: "v"(rb[i].x), "v"(rb[i].y), "v"(rb[i].z), "v"(rb[i].w));
-      return;
-    }
-#endif
 #pragma unroll
     for (int i = 0; i < NB4; ++i) {
       const int idx = t + 256 * i;
-#ifdef DL3P_STAMP
-      // ablation: 107 stores only the first half of the B tile, 108 all but its last float4 per thread
-      if (it > 0 && ((p.stagger == 107 && i >= NB4 / 2) || (p.stagger == 108 && i == NB4 - 1))) {
-        asm volatile("" :: "v"(rb[i].x), "v"(rb[i].y), "v"(rb[i].z), "v"(rb[i].w));
-        continue;
-      }
-#endif
 #if DL3P_GEMM_PIN_B
       // An empty asm that reads rb[i] right before its LDS store.  Without it clang hoists the B stores' address math
       // and, in 64 of the 80 instantiations, ends up with an s_waitcnt vmcnt(5)/(6) INSIDE the next K-step's prefetch
@@ -270,32 +246,11 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
     for (int i = 0; i < NPASS; ++i) { st_s[i] = zero4(); st_q[i] = zero4(); }
   }
 
-#ifdef DL3P_STAMP
-  long long tacc[5] = {0, 0, 0, 0, 0};
-  long long t0 = __builtin_amdgcn_s_memtime(), t1;
-#define STAMP(i) { t1 = __builtin_amdgcn_s_memtime(); tacc[i] += t1 - t0; t0 = t1; }
-#else
-#define STAMP(i) {}
-#endif
-  // ablation modes of the instrumented build (scripts/micro/build_stamp.sh, DL3P_GEMM_STAGGER): 100 = no staging
-  // after the first K-step, 101 = also no epilogue, 102 = no global prefetch, 103 = no B-tile LDS stores (and no wait for its loads), 104 = no
-  // B-tile loads either, 105 = B loads waited for but not stored, 106 = the same for A.  Measured on 266256x304x256:
-  // 497 us -> 447 (102) -> 386 (100) -> 355 (101): the MFMA loop alone runs at 94 % of the clock- and
-  // tile-quantisation-adjusted peak; staging costs 22 %, the epilogue 6 %.
-#ifdef DL3P_STAMP
-  const int dbg = p.stagger;
-#elif defined(DL3P_ABLATE)
-  constexpr int dbg = DL3P_ABLATE;   // compile-time ablation of the production kernel: build_variant.sh abl100 -DDL3P_ABLATE=100
-#else
-  constexpr int dbg = 0;
-#endif
   if (it_total > 0) prefetch(0);
   for (int it = 0; it < it_total; ++it) {
-    if (dbg < 100 || dbg == 102 || it == 0) stage(it);
-    STAMP(0)
+    stage(it);
     __syncthreads();
-    STAMP(1)
-    if (it + 1 < it_total && dbg < 100) prefetch(it + 1);
+    if (it + 1 < it_total) prefetch(it + 1);
 #pragma unroll
     for (int g = 0; g < BKT / 16; ++g) {
       const int kc = g * 16 + q * 4;
@@ -322,10 +277,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
         }
       }
     }
-    STAMP(2)
     __syncthreads();
-    STAMP(3)
-    if (it % nk == nk - 1 && dbg != 101) {
+    if (it % nk == nk - 1) {
       // epilogue of this M tile.  After the MFMAs a lane holds 4 consecutive channels of pixel l15 per
       // accumulator; stored directly that is 16 rows x 64 B per store instruction (half cache lines,
       // measured: 13.6k cycles per tile, and the next tile's staging waits behind those stores).  The tile
@@ -402,18 +355,9 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
         }
       }
       if (OVERLAY) __syncthreads();   // the next stage() overwrites the epilogue buffer
-      STAMP(4)
     }
   }
 
-#ifdef DL3P_STAMP
-  STAMP(4)   // epilogues (the last one; earlier ones are counted with the next stage's wait)
-  if (p.stamp && l == 0) {
-    long long* o = p.stamp + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + w) * 8;
-    for (int i = 0; i < 5; ++i) o[i] = tacc[i];
-    o[5] = it_total;
-  }
-#endif
   if (STATS) {
     // reduce over the 4 row groups of the wave, then over the 4 waves; one partial row per workgroup
     const int rr = l >> 4, cq = l & 15;
@@ -864,11 +808,6 @@ static void launch_gemm_mi(const GemmParams& p, int nt, dim3 grid, hipStream_t s
 template <bool B_KN, bool STATS, bool BNB = false, bool GA = false>
 static void launch_gemm(const GemmParams& p_in, int nt, int mi, dim3 grid, hipStream_t st) {
   GemmParams p = p_in;
-#ifdef DL3P_STAMP
-  const char* sp = getenv("DL3P_STAMP_PTR");
-  p.stamp = sp ? (long long*)strtoull(sp, nullptr, 10) : nullptr;
-#endif
-  { const char* e = getenv("DL3P_GEMM_STAGGER"); p.stagger = e ? atoi(e) : 0; }
   // (BKT = 64 -- half the barriers and staging passes per MFMA -- was measured neutral on the decoder layers and is
   // not instantiated: the loop is bound by matrix-pipe sharing between the two resident workgroups)
   if (mi == 1) launch_gemm_mi<B_KN, STATS, 1, 32, BNB, GA>(p, nt, grid, st);
