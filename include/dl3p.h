@@ -326,6 +326,11 @@ int dl3p_aug_enhance_u8(const unsigned char* img, unsigned char* out, const floa
 int dl3p_aug_flip_crop_u8(const unsigned char* img, unsigned char* out, const unsigned char* label,
                           unsigned char* label_out, const int* flags, const int* yx, int N, int H, int W, int h, int w,
                           void* stream);
+/* dl3p_aug_gridmask_u8: random_gridmask (common/data_utils.py:276-361, Grid.__call__ with mode = 1) in place: image and label
+ * times 1 - rotate(grid), the rotation being PIL's Image.rotate (NEAREST, zero fill) evaluated per pixel through Pillow's
+ * 16.16 fixed-point affine map (pinned against PIL, tests/golden/make_pil_gridmask.py).  params: N x 16 ints on the device,
+ * {apply, hh, d, l, st_h, st_w, kind, a0..a5, top, left, 0} from the host's draws (augment.random_gridmask). */
+int dl3p_aug_gridmask_u8(unsigned char* img, unsigned char* label, const int* params, int N, int H, int W, void* stream);
 /* The label tail of SegmentationGenerator.__getitem__ for byte labels (N images of P pixels each):
  * labels_out = float(label), with label > num_classes-1 replaced by ignore_index (deeplabv3p/data.py:116-121);
  * weights_out (optional) = the `--weighted_type adaptive` pixel weights (data.py:134-145): sklearn's

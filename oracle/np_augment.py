@@ -74,3 +74,78 @@ def flip_crop(img, label, flags=0, yx=None, hw=None):
         h, w = hw
         img, label = img[y:y + h, x:x + w], label[y:y + h, x:x + w]
     return np.ascontiguousarray(img), np.ascontiguousarray(label)
+
+
+# ---------------------------------------------------------------------------------------------------- GridMask
+def gridmask_keep(h, w, d, st_h, st_w, r, ratio=0.5):
+    """The uint8 (h, w) factor the reference's Grid.__call__ multiplies image and label with (common/data_utils.py:288-339,
+    mode = 1), for one set of draws (d = randint(d1, d2), st_h = randint(d), st_w = randint(d), r = randint(360)).
+
+    Restated, not called: a square of ones with edge hh = ceil(sqrt(h^2 + w^2)), zero on the row bands
+    [d i + st_h, d i + st_h + l) and the column bands [d i + st_w, ...), l = ceil(d ratio); rotated by r degrees with
+    PIL's Image.rotate (NEAREST, no expand, zero fill); centre crop to (h, w); 1 - mask.
+
+    Pillow's rotate (Image.py, 12.x): angle 0 -> copy, 180 -> ROTATE_180, 90 / 270 on a square image -> ROTATE_90 / ROTATE_270;
+    otherwise matrix = [cos, sin, 0, -sin, cos, 0] of -angle, each rounded to 15 decimals, the centre (hh/2, hh/2) mapped onto
+    itself, and ImagingTransformAffine with the NEAREST filter in 16.16 FIXED POINT (Geometry.c affine_fixed):
+        a0 = FIX(a[0]) ... a2 = FIX(a[2] + a[0]/2 + a[1]/2), FIX(v) = floor(v 65536 + 0.5)
+        source x of output (x, y) = (a2 + a1 y + a0 x) >> 16 (the C code accumulates these sums step by step: integers, same value),
+        out of range -> 0.
+    Pinned against PIL itself: tests/golden/make_pil_gridmask.py, tests/test_augment.py."""
+    import math
+    hh = math.ceil(math.sqrt(h * h + w * w))
+    l = math.ceil(d * ratio)
+    yy = np.arange(hh)
+    band_r = ((yy - st_h) % d) < l
+    band_c = ((yy - st_w) % d) < l
+    m = (~(band_r[:, None] | band_c[None, :])).astype(np.uint8)      # 1 = kept by the grid
+    r = r % 360
+    if r == 0:
+        rot = m
+    elif r == 180:
+        rot = m[::-1, ::-1]
+    elif r == 90:
+        rot = np.rot90(m, 1)
+    elif r == 270:
+        rot = np.rot90(m, 3)
+    else:
+        ang = -math.radians(r)
+        a = [round(math.cos(ang), 15), round(math.sin(ang), 15), 0.0, round(-math.sin(ang), 15), round(math.cos(ang), 15), 0.0]
+        cx = cy = hh / 2.0
+        a[2] = a[0] * -cx + a[1] * -cy + a[2]
+        a[5] = a[3] * -cx + a[4] * -cy + a[5]
+        a[2] += cx
+        a[5] += cy
+        fix = lambda v: int(math.floor(v * 65536.0 + 0.5))
+        a0, a1, a3, a4 = fix(a[0]), fix(a[1]), fix(a[3]), fix(a[4])
+        a2 = fix(a[2] + a[0] * 0.5 + a[1] * 0.5)
+        a5 = fix(a[5] + a[3] * 0.5 + a[4] * 0.5)
+        X, Y = np.meshgrid(np.arange(hh, dtype=np.int64), np.arange(hh, dtype=np.int64))
+        xin = (a2 + a1 * Y + a0 * X) >> 16
+        yin = (a5 + a4 * Y + a3 * X) >> 16
+        ok = (xin >= 0) & (xin < hh) & (yin >= 0) & (yin < hh)
+        rot = np.where(ok, m[np.clip(yin, 0, hh - 1), np.clip(xin, 0, hh - 1)], 0).astype(np.uint8)
+    t, lft = (hh - h) // 2, (hh - w) // 2
+    return (1 - rot[t:t + h, lft:lft + w]).astype(np.uint8)
+
+
+def gridmask_params(h, w, d, st_h, st_w, r, ratio=0.5):
+    """the integers the device kernel takes for one image: [apply, hh, d, l, st_h, st_w, kind, a0, a1, a2, a3, a4, a5, top, left]
+    (kind 0 identity, 1 ROTATE_90, 2 ROTATE_180, 3 ROTATE_270, 4 affine in 16.16 fixed point)"""
+    import math
+    hh = math.ceil(math.sqrt(h * h + w * w))
+    l = math.ceil(d * ratio)
+    r = r % 360
+    kind = {0: 0, 90: 1, 180: 2, 270: 3}.get(r, 4)
+    a0 = a1 = a2 = a3 = a4 = a5 = 0
+    if kind == 4:
+        ang = -math.radians(r)
+        a = [round(math.cos(ang), 15), round(math.sin(ang), 15), 0.0, round(-math.sin(ang), 15), round(math.cos(ang), 15), 0.0]
+        cx = cy = hh / 2.0
+        a[2] = a[0] * -cx + a[1] * -cy + a[2] + cx
+        a[5] = a[3] * -cx + a[4] * -cy + a[5] + cy
+        fix = lambda v: int(math.floor(v * 65536.0 + 0.5))
+        a0, a1, a3, a4 = fix(a[0]), fix(a[1]), fix(a[3]), fix(a[4])
+        a2 = fix(a[2] + a[0] * 0.5 + a[1] * 0.5)
+        a5 = fix(a[5] + a[3] * 0.5 + a[4] * 0.5)
+    return [1, hh, d, l, st_h, st_w, kind, a0, a1, a2, a3, a4, a5, (hh - h) // 2, (hh - w) // 2]

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box, repo root: the DESIGN.md §8 table (one bench.py line per configuration) -> gpurun_out/bench_table.txt
-B="python3 bench.py --no-cpu-baseline --steps 20 --warmup 4"
+B="python3 bench.py --no-cpu-baseline --no-other-configs --steps 20 --warmup 4"
 run() { echo "== $*"; $B "$@" 2>&1 | grep '"metric"' | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.1f img/s  %.2f ms  %s launches' % (d['value'], d['ms_per_step'], d['config'].get('launches_per_step')))"; }
 {
 run --model mobilenetv2

@@ -98,3 +98,80 @@ def test_device_flip_crop_matches_numpy():
     a = aug.random_sharpness(aug.random_contrast(aug.random_chroma(aug.random_brightness(a))))
     a, b = aug.random_crop(a, b, (33, 33), prob=1.0)
     assert a.shape == (N, 33, 33, 3) and b.shape == (N, 33, 33) and a.dtype == torch.uint8
+
+
+# ---------------------------------------------------------------------------------------------------- GridMask
+def _gridmask_cases():
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'pil_gridmask.npz'))
+    for i, (h, w, d, st_h, st_w, r) in enumerate(g['cases']):
+        yield (int(h), int(w), int(d), int(st_h), int(st_w), int(r)), np.unpackbits(g['m%d' % i])[:h * w].reshape(h, w)
+
+
+def test_gridmask_restatement_matches_pil_golden_and_live_pil():
+    """oracle/np_augment.gridmask_keep (Pillow's rotate restated: transpose fast paths + 16.16 fixed-point affine map) against
+    the vectors PIL wrote (tests/golden/make_pil_gridmask.py) and against PIL itself on fresh draws"""
+    n = 0
+    for case, want in _gridmask_cases():
+        assert np.array_equal(A.gridmask_keep(*case), want), case
+        n += 1
+    assert n == 32
+    from golden.make_pil_gridmask import pil_mask
+    rng = np.random.default_rng(5)
+    for (h, w) in ((129, 129), (96, 160), (17, 40)):
+        for _ in range(25):
+            d = int(rng.integers(max(2, w // 7), max(3, w // 3)))
+            case = (h, w, d, int(rng.integers(d)), int(rng.integers(d)), int(rng.integers(360)))
+            assert np.array_equal(A.gridmask_keep(*case), pil_mask(*case)), case
+
+
+def test_gridmask_draws_follow_the_reference_order():
+    """augment.random_gridmask draws rand(), randint(W//7, W//3), randint(d), randint(d), randint(360) per image, in the
+    reference's order (Grid.__call__, data_utils.py:292-322): a seeded np.random gives the reference's grids"""
+    from conftest import load_pkg
+    aug = load_pkg('augment')
+    np.random.seed(11)
+    want = []
+    for _ in range(5):
+        if np.random.rand() > 0.6:
+            want.append(None)
+            continue
+        d = np.random.randint(97 // 7, 97 // 3)
+        want.append((d, np.random.randint(d), np.random.randint(d), np.random.randint(360)))
+    got = []
+    np.random.seed(11)
+    orig = aug.gridmask
+    aug.gridmask = lambda images, labels, draws: got.extend(draws) or (images, labels)
+    try:
+        class _T:          # shape-only stand-in: the draws do not touch the data
+            shape = (5, 65, 97, 3)
+        aug.random_gridmask(_T(), None, prob=0.6)
+    finally:
+        aug.gridmask = orig
+    assert got == want and any(g is not None for g in got)
+    # the parameter block the kernel takes agrees with the oracle's
+    assert aug.gridmask_params(65, 97, 20, 3, 7, 123)[:15] == A.gridmask_params(65, 97, 20, 3, 7, 123)
+
+
+@pytest.mark.gpu
+def test_device_gridmask_matches_pil():
+    """dl3p_aug_gridmask_u8 against the masks PIL produced: image and label times the mask, bit for bit, untouched images
+    stay untouched"""
+    import torch
+    from conftest import load_pkg
+    aug = load_pkg('augment')
+    rng = np.random.default_rng(3)
+    by_shape = {}
+    for case, mask in _gridmask_cases():
+        by_shape.setdefault(case[:2], []).append((case, mask))
+    for (h, w), items in by_shape.items():
+        N = len(items) + 1
+        imgs = rng.integers(1, 256, (N, h, w, 3), dtype=np.uint8)
+        labs = rng.integers(1, 22, (N, h, w), dtype=np.uint8)
+        ti, tl = torch.from_numpy(imgs).cuda(), torch.from_numpy(labs).cuda()
+        draws = [c[2:] for c, _ in items] + [None]
+        aug.gridmask(ti, tl, draws)
+        gi, gl = ti.cpu().numpy(), tl.cpu().numpy()
+        for n, (case, mask) in enumerate(items):
+            assert np.array_equal(gi[n], imgs[n] * mask[..., None]), case
+            assert np.array_equal(gl[n], labs[n] * mask), case
+        assert np.array_equal(gi[-1], imgs[-1]) and np.array_equal(gl[-1], labs[-1])

@@ -4,8 +4,11 @@ sits on the GPU as bytes: images (N,H,W,3) uint8, labels (N,H,W) uint8 torch ten
 host exactly as the reference makes them (`rand() < prob` per image, `rand(jitter, 1/jitter)` per image); the kernels
 (csrc/augment.hip) reproduce PIL / NumPy bit for bit for a given draw.
 
-Not here: random_zoom_rotate, random_gridmask's rotation, random_grayscale, random_blur, random_histeq and the final
-cv2.resize -- OpenCV code whose fixed-point arithmetic cannot be pinned in an image without OpenCV; they stay on the host.
+random_gridmask is here too: its rotation is PIL's (Image.rotate, NEAREST), restated from Pillow's 16.16 fixed-point affine
+map and pinned against PIL itself.
+
+Not here: random_zoom_rotate, random_grayscale, random_blur, random_histeq and the final cv2.resize -- OpenCV code whose
+fixed-point arithmetic cannot be pinned in an image without OpenCV; they stay on the host.
 """
 import numpy as np
 import torch
@@ -74,6 +77,57 @@ def random_contrast(images, jitter=.5):
 
 def random_sharpness(images, jitter=.5):
     return enhance(images, SHARPNESS, [rand(jitter, 1 / jitter) for _ in range(images.shape[0])])
+
+
+def gridmask_params(h, w, d, st_h, st_w, r, ratio=0.5):
+    """the 16 integers dl3p_aug_gridmask_u8 takes for one image, from the reference's draws (Grid.__call__,
+    common/data_utils.py:288-339): hh = ceil(sqrt(h^2 + w^2)), band width l = ceil(d ratio), and Pillow's rotate as it
+    computes it -- transpose fast paths at 0 / 90 / 180 / 270 degrees, otherwise the affine matrix of -r (entries rounded to 15
+    decimals, centre (hh/2, hh/2) fixed) in 16.16 fixed point, FIX(v) = floor(65536 v + 0.5), half-pixel offset folded in"""
+    import math
+    hh = math.ceil(math.sqrt(h * h + w * w))
+    l = math.ceil(d * ratio)
+    r = r % 360
+    kind = {0: 0, 90: 1, 180: 2, 270: 3}.get(r, 4)
+    a0 = a1 = a2 = a3 = a4 = a5 = 0
+    if kind == 4:
+        ang = -math.radians(r)
+        a = [round(math.cos(ang), 15), round(math.sin(ang), 15), 0.0, round(-math.sin(ang), 15), round(math.cos(ang), 15), 0.0]
+        c = hh / 2.0
+        a[2] = a[0] * -c + a[1] * -c + a[2] + c
+        a[5] = a[3] * -c + a[4] * -c + a[5] + c
+        fix = lambda v: int(math.floor(v * 65536.0 + 0.5))
+        a0, a1, a3, a4 = fix(a[0]), fix(a[1]), fix(a[3]), fix(a[4])
+        a2 = fix(a[2] + a[0] * 0.5 + a[1] * 0.5)
+        a5 = fix(a[5] + a[3] * 0.5 + a[4] * 0.5)
+    return [1, hh, d, l, st_h, st_w, kind, a0, a1, a2, a3, a4, a5, (hh - h) // 2, (hh - w) // 2, 0]
+
+
+def gridmask(images, labels, draws):
+    """apply GridMask IN PLACE; draws[n] = None (image left alone) or (d, st_h, st_w, r)"""
+    N, H, W, _ = images.shape
+    assert images.dtype == torch.uint8 and labels.dtype == torch.uint8 and labels.shape == (N, H, W)
+    assert images.is_contiguous() and labels.is_contiguous()
+    rows = [[0] * 16 if dr is None else gridmask_params(H, W, *dr) for dr in draws]
+    prm = torch.as_tensor(np.asarray(rows, np.int32)).to(images.device)
+    lib().aug_gridmask_u8(images.data_ptr(), labels.data_ptr(), prm.data_ptr(), N, H, W, _stream())
+    return images, labels
+
+
+def random_gridmask(images, labels, prob=0.2):
+    """random_gridmask (common/data_utils.py:342-361) for a batch, in place.  Per image, in the reference's order:
+    np.random.rand() > prob -> untouched; d = randint(W // 7, W // 3); st_h = randint(d); st_w = randint(d); r = randint(360)"""
+    N, H, W, _ = images.shape
+    draws = []
+    for _ in range(N):
+        if np.random.rand() > prob:
+            draws.append(None)
+            continue
+        d = np.random.randint(W // 7, W // 3)
+        st_h = np.random.randint(d)
+        st_w = np.random.randint(d)
+        draws.append((int(d), int(st_h), int(st_w), int(np.random.randint(360))))
+    return gridmask(images, labels, draws)
 
 
 def random_crop(images, labels, crop_shape, prob=.1):

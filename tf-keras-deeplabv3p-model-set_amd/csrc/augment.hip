@@ -131,3 +131,52 @@ extern "C" int dl3p_aug_flip_crop_u8(const unsigned char* img, unsigned char* ou
   DL3P_CHECK_LAUNCH("dl3p_aug_flip_crop_u8");
   return DL3P_OK;
 }
+
+// GridMask (random_gridmask, common/data_utils.py:276-361; Grid.__call__ with mode = 1): image and label are multiplied by
+// 1 - rotate(grid) where grid is a square of ones of edge hh = ceil(sqrt(h^2 + w^2)) with zero row / column bands of width l
+// every d pixels, rotated by PIL's Image.rotate (NEAREST, zero fill) and centre-cropped.  Nothing is materialised here: the
+// factor of pixel (y, x) is evaluated from the draws -- source pixel through Pillow's 16.16 fixed-point affine map (or its
+// transpose fast paths at 0 / 90 / 180 / 270 degrees), then the band test.  params[n] = {apply, hh, d, l, st_h, st_w, kind,
+// a0 .. a5, top, left} as oracle/np_augment.gridmask_params writes them (the host draws d, st_h, st_w, r like the reference).
+__global__ __launch_bounds__(256) void aug_gridmask_kernel(unsigned char* img, unsigned char* label, const int* params, int H, int W) {
+  const int n = blockIdx.y;
+  const int* q = params + 16 * n;
+  if (!q[0]) return;
+  const int hh = q[1], d = q[2], l = q[3], st_h = q[4], st_w = q[5], kind = q[6];
+  const long long a0 = q[7], a1 = q[8], a2 = q[9], a3 = q[10], a4 = q[11], a5 = q[12];
+  const int top = q[13], left = q[14];
+  const long long P = (long long)H * W;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < P; i += (long long)gridDim.x * 256) {
+    const int y = (int)(i / W), x = (int)(i - (long long)y * W);
+    const int Y = y + top, X = x + left;
+    long long xin, yin;
+    if (kind == 0) { xin = X; yin = Y; }
+    else if (kind == 1) { yin = X; xin = hh - 1 - Y; }          // ROTATE_90:  rot[Y][X] = m[X][hh-1-Y]
+    else if (kind == 2) { yin = hh - 1 - Y; xin = hh - 1 - X; }
+    else if (kind == 3) { yin = hh - 1 - X; xin = Y; }          // ROTATE_270: rot[Y][X] = m[hh-1-X][Y]
+    else { xin = (a2 + a1 * Y + a0 * X) >> 16; yin = (a5 + a4 * Y + a3 * X) >> 16; }
+    int rot = 0;                                                 // outside the source: fill 0
+    if (xin >= 0 && xin < hh && yin >= 0 && yin < hh) {
+      int ry = ((int)yin - st_h) % d, rx = ((int)xin - st_w) % d;
+      if (ry < 0) ry += d;
+      if (rx < 0) rx += d;
+      rot = (ry < l || rx < l) ? 0 : 1;
+    }
+    if (rot) {                                                   // factor 1 - rot = 0
+      const long long o = (long long)n * P + i;
+      if (img) { img[3 * o] = 0; img[3 * o + 1] = 0; img[3 * o + 2] = 0; }
+      if (label) label[o] = 0;
+    }
+  }
+}
+
+extern "C" int dl3p_aug_gridmask_u8(unsigned char* img, unsigned char* label, const int* params, int N, int H, int W, void* stream) {
+  DL3P_CHECK_ARG((img || label) && params && N > 0 && H > 0 && W > 0, "dl3p_aug_gridmask_u8: bad arguments");
+  const long long P = (long long)H * W;
+  long long gx = ceil_div_ll(P, 256 * 8);
+  if (gx > 1024) gx = 1024;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(aug_gridmask_kernel, dim3((unsigned)gx, N), dim3(256), 0, (hipStream_t)stream, img, label, params, H, W);
+  DL3P_CHECK_LAUNCH("dl3p_aug_gridmask_u8");
+  return DL3P_OK;
+}
