@@ -23,10 +23,10 @@ else
   python3 bench.py $ARGS --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_$R.log 2>&1
 fi
 grep '"metric"' $O/bench_$R.log > $O/bench_$R.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py $ARGS --steps 10 --warmup 3 --no-cpu-baseline > $O/kt.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py $ARGS --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $O/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py $ARGS --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $O/pmc_write.log 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES $MFMA_INSTS --kernel-trace --output-format csv -d $O/pmc_mfma -- python3 bench.py $ARGS --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $O/pmc_mfma.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py $ARGS --steps 10 --warmup 3 --no-cpu-baseline > $O/kt.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py $ARGS --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $O/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py $ARGS --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $O/pmc_write.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES $MFMA_INSTS --kernel-trace --output-format csv -d $O/pmc_mfma -- python3 bench.py $ARGS --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $O/pmc_mfma.log 2>&1
 cp $O/kt/*/*kernel_stats.csv $O/${R}_kernel_stats.csv
 # steps in the trace = launches of the once-per-step loss kernel (warm-up + timed + the bench's extra probe steps)
 STEPS=$(python3 - <<PY

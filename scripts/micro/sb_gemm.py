@@ -28,15 +28,19 @@ def timeit(fn, reps=10):
 SHAPES = [(266256, 304, 256), (266256, 256, 256), (17424, 1280, 256), (17424, 960, 160), (17424, 160, 960), (17424, 576, 96),
           (67600, 192, 64), (67600, 384, 64), (4356, 728, 728), (4356, 2048, 256), (4356, 1536, 2048), (18818, 728, 728), (74498, 304, 256)]
 # (nt, mi, wm): wm = 0 -> the 2-workgroups-per-CU tiles (gemm_nt / gemm_mi), wm >= 1 with nt in (8, 12, 16) -> the wide family
-cands = [(None, None, None), (4, 2, 0), (8, 1, 0), (8, 2, 0), (16, 2, 1), (16, 1, 1), (16, 1, 2), (12, 2, 1), (12, 2, 2), (8, 2, 2)]
+# wm = -1 -> the producer / consumer form (sb_pipe) with (nt, mi)
+cands = [(None, None, None), (8, 2, -1), (8, 1, -1), (4, 2, -1), (4, 2, 0), (8, 2, 0), (16, 1, 2)]
 if len(sys.argv) > 3:
     cands = [(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]))]
 
 
 def pin(nt, mi, wm):
+    L.set_option(b'sb_pipe', 1 if wm == -1 else 0)
     if nt is None:
         for k in (b'gemm_nt', b'gemm_mi', b'sb_wm', b'sb_nt'):
             L.set_option(k, 0)
+    elif wm == -1:
+        L.set_option(b'sb_wm', 0); L.set_option(b'sb_nt', 0); L.set_option(b'gemm_nt', nt); L.set_option(b'gemm_mi', mi)
     elif wm == 0:
         L.set_option(b'sb_wm', -1); L.set_option(b'sb_nt', 0); L.set_option(b'gemm_nt', nt); L.set_option(b'gemm_mi', mi)
     else:
@@ -53,7 +57,7 @@ for (M, K, N) in SHAPES:
     e32 = float((y.double() - y64).abs().max() / y64.abs().max())
     line = 'fwd  M=%6d K=%4d N=%4d  fp32 %7.1f us (err %.1e) |' % (M, K, N, t32, e32)
     for nt, mi, wm in cands:
-        if wm and nt and N <= 16 * (nt - 4):
+        if wm and wm > 0 and nt and N <= 16 * (nt - 4):
             continue
         pin(nt, mi, wm)
         t = timeit(lambda: ops.pwconv_fwd_sb(x, wsp, K, None, sc, sh, ops.ACT_RELU6, out=y, partials=part))
@@ -73,7 +77,7 @@ for (M, K, N) in SHAPES:
     t32 = timeit(lambda: ops.pwconv_bwd_data_bn(dy, w, z, sc, sh, ops.ACT_RELU6, mean, invstd, partk, out=gx))
     line = 'dgbn M=%6d K=%4d N=%4d  fp32 %7.1f us             |' % (M, K, N, t32)
     for nt, mi, wm in cands:
-        if wm and nt and K <= 16 * (nt - 4):
+        if wm and wm > 0 and nt and K <= 16 * (nt - 4):
             continue
         pin(nt, mi, wm)
         t = timeit(lambda: ops.pwconv_bwd_data_sb(dy, w_sp, N, out=gx, z=z, scale=sc, shift=sh, act=ops.ACT_RELU6, mean=mean,

@@ -1,0 +1,74 @@
+"""The costliest launches of BASELINE configs[2] (Xception 513x513, batch 4 per GPU) and configs[4] (MobileNetV3-Large 1024x2048,
+bf16, batch 1) as stand-alone op calls at their exact launch shapes -- what scripts/pmc_ops.sh runs under rocprofv3 --pmc to get
+FETCH_SIZE / WRITE_SIZE / MFMA-busy counters for kernels outside the headline graph (whole-step PMC runs of those graphs abort
+inside the profiler: "AQL packet is malformed").   python3 scripts/pmc_ops.py xception | bf16"""
+import importlib
+import os
+import sys
+
+import torch
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+sys.path.insert(0, ROOT)
+PKG = 'tf-keras-deeplabv3p-model-set_amd'
+ops = importlib.import_module(PKG + '.ops')
+L = importlib.import_module(PKG + '._lib').lib()
+L.set_option(b'pw_small_min_rows', -1)
+dev = 'cuda'
+REPS = 5
+
+
+def xception():
+    for (M, K, N) in [(4356, 1536, 2048), (4356, 728, 728), (4356, 2048, 256), (66564, 304, 256)]:
+        x = torch.randn(M, K, device=dev)
+        wt = torch.randn(N, K, device=dev) / K ** 0.5
+        w = wt.t().contiguous()
+        sc, sh = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.3
+        part, partk = ops.new_partials(N, dev), ops.new_partials(K, dev)
+        dy, z = torch.randn(M, N, device=dev), torch.randn(M, K, device=dev)
+        mean, invstd = torch.zeros(K, device=dev), torch.ones(K, device=dev)
+        for _ in range(REPS):
+            ops.pwconv_fwd_wt(x, wt, None, sc, sh, ops.ACT_RELU, partials=part)
+            ops.pwconv_bwd_data_bn(dy, w, z, sc, sh, ops.ACT_RELU, mean, invstd, partk)
+            ops.pwconv_bwd_weight(x, dy, sc, sh, ops.ACT_RELU)
+    for r in (6, 12, 18):
+        x = torch.randn(4, 33, 33, 2048, device=dev)
+        w = torch.randn(3, 3, 2048, device=dev) * 0.3
+        sc, sh = torch.rand(2048, device=dev) + 0.5, torch.randn(2048, device=dev) * 0.3
+        part = ops.new_partials(2048, dev)
+        gy = torch.randn(4, 33, 33, 2048, device=dev)
+        for _ in range(REPS):
+            ops.dwconv2d_fwd(x, w, 1, r, 'same', sc, sh, ops.ACT_RELU, partials=part)
+            ops.dwconv2d_bwd_data(gy, w, (4, 33, 33, 2048), 1, r, 'same')
+            ops.dwconv2d_bwd_weight(x, gy, 3, 1, r, 'same', sc, sh, ops.ACT_RELU)
+    torch.cuda.synchronize()
+
+
+def bf16():
+    bf = torch.bfloat16
+    for (M, K, N) in [(131072, 304, 256), (131072, 256, 256), (8192, 1280, 256), (524288, 16, 64)]:
+        x = torch.randn(M, K, device=dev).to(bf)
+        w = torch.randn(K, N, device=dev) / K ** 0.5
+        sc, sh = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.3
+        part = ops.new_partials(N, dev)
+        dy = torch.randn(M, N, device=dev).to(bf)
+        for _ in range(REPS):
+            ops.pwconv_fwd_bf16(x, w, None, sc, sh, ops.ACT_HSWISH, partials=part)
+            ops.pwconv_bwd_data_bf16(dy, w)
+            ops.pwconv_bwd_weight_bf16(x, dy, sc, sh, ops.ACT_HSWISH)
+    for (N, H, W, C, k, s, r) in [(1, 256, 512, 304, 3, 1, 1), (1, 64, 128, 960, 5, 1, 2), (1, 64, 128, 160, 3, 1, 18),
+                                  (1, 64, 128, 160, 3, 1, 6)]:
+        x = torch.randn(N, H, W, C, device=dev).to(bf)
+        w = torch.randn(k, k, C, device=dev) * 0.3
+        sc, sh = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev) * 0.3
+        part = ops.new_partials(C, dev)
+        gy = torch.randn(N, H, W, C, device=dev).to(bf)
+        for _ in range(REPS):
+            ops.dwconv2d_fwd_bf16(x, w, s, r, 'same', sc, sh, ops.ACT_RELU6, partials=part)
+            ops.dwconv2d_bwd_data_bf16(gy, w, (N, H, W, C), s, r, 'same')
+            ops.dwconv2d_bwd_weight_bf16(x, gy, k, s, r, 'same', sc, sh, ops.ACT_RELU6)
+    torch.cuda.synchronize()
+
+
+if __name__ == '__main__':
+    {'xception': xception, 'bf16': bf16}[sys.argv[1]]()

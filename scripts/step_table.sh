@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 cd "$ROOT"
 M=${1:-mobilenetv2}
 rm -rf gpurun_out/st
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/st -- python3 scripts/step_table.py run $M > gpurun_out/st_run.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/st -- python3 scripts/step_table.py run $M > gpurun_out/st_run.log 2>&1
 python3 scripts/step_table.py parse gpurun_out/st > gpurun_out/step_table_$M.txt 2> gpurun_out/st_parse.log
 rm -rf gpurun_out/st
 tail -40 gpurun_out/step_table_$M.txt; tail -5 gpurun_out/st_parse.log

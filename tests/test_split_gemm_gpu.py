@@ -43,11 +43,13 @@ SHAPES = [(16 * 129 * 129, 304, 256), (16 * 129 * 129, 256, 256), (16 * 33 * 33,
           (4357, 100, 200), (1089, 36, 24), (9001, 304, 252), (2600, 728, 132), (130, 20, 12)]
 
 
+@pytest.mark.parametrize('pipe', [1, 0], ids=['producer_consumer', 'symmetric'])
 @pytest.mark.parametrize('case', SHAPES)
-def test_split_gemm_matches_float64_at_the_fp32_tolerances(ops, case):
+def test_split_gemm_matches_float64_at_the_fp32_tolerances(ops, case, pipe):
     M, K, N = case
     L = ops.lib()
     L.set_option(b'pw_small_min_rows', -1)
+    L.set_option(b'sb_pipe', pipe)
     try:
         g = torch.Generator(device=DEV); g.manual_seed(M % 9973 + 7 * K + 13 * N)
         rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)
@@ -101,21 +103,25 @@ def test_split_gemm_matches_float64_at_the_fp32_tolerances(ops, case):
         assert float((p[1] - (d * xh).sum(0)).abs().max()) < 2e-4 * float((d * xh).abs().sum(0).max()), 'BN backward sum * xhat'
     finally:
         L.set_option(b'pw_small_min_rows', 64)
+        L.set_option(b'sb_pipe', 0)
 
 
+@pytest.mark.parametrize('pipe', [1, 0], ids=['producer_consumer', 'symmetric'])
 @pytest.mark.parametrize('mi', [1, 2])
 @pytest.mark.parametrize('nt', [1, 2, 3, 4, 5, 6, 7, 8])
-def test_every_split_gemm_tile_choice(ops, nt, mi):
+def test_every_split_gemm_tile_choice(ops, nt, mi, pipe):
     L = ops.lib()
     L.set_option(b'pw_small_min_rows', 1 << 30)
     L.set_option(b'gemm_nt', nt)
     L.set_option(b'gemm_mi', mi)
+    L.set_option(b'sb_pipe', pipe)
     try:
         for case in [(4357, 100, 200), (2600, 728, 132)]:
             _run(ops, case)
     finally:
         L.set_option(b'gemm_nt', 0)
         L.set_option(b'gemm_mi', 0)
+        L.set_option(b'sb_pipe', 0)
         L.set_option(b'pw_small_min_rows', 64)
 
 

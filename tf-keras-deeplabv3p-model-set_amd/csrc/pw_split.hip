@@ -27,6 +27,13 @@ typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
 #define SB_BKT 32
 #define SB_PB 40   // bf16 elements per LDS tile row: 64 B of data + 16 B pad
 
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() is `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`: the
+// vmcnt(0) drains every global load in flight, i.e. the operand prefetch issued for the NEXT K-steps -- each K-step then contains a
+// full memory round trip, and with six bf16 MFMAs per tile the multiply phase (~0.7 us) is too short to cover one.  The tiles
+// handed over at the barrier live in LDS; global loads land in registers nobody else reads, and the compiler keeps its own vmcnt
+// bookkeeping for them.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // (x, y) -> three packed bf16 pairs (low half = x): the exact 3-way split, round to nearest even at every level
 __device__ __forceinline__ void split2(float x, float y, uint32_t& h, uint32_t& m, uint32_t& l) {
   const bf16x2v hv = {(__bf16)x, (__bf16)y};
@@ -114,9 +121,9 @@ __global__ __launch_bounds__(256 * WM, (WM == 1 && NT <= 8) ? 2 : 1) void pw_gem
   const char* Ab = reinterpret_cast<const char*>(p.A);
 
   // A is prefetched TWO K-steps ahead (two register sets, PAR = it & 1): with six bf16 MFMAs per tile the multiply phase of a
-  // K-step lasts ~0.7 us, less than an HBM round trip under load -- one step ahead, the kernel sat at bytes-in-flight / latency
-  // (28 % of the matrix peak whatever the tile shape).  B (L2 hits) stays one step ahead and is issued BEFORE the A loads of the
-  // step after next, so that the wait for it does not drain those.
+  // K-step lasts ~0.7 us, less than an HBM round trip under load (measured neutral to -3 %: the loop is bound by its staging
+  // pipeline).  B (L2 hits) stays one step ahead and is issued BEFORE the A loads of the step after next, so that the
+  // wait for it does not drain those.
   float4 ra[2][NA][2];
   uint4 rb[NBC];
   float4 rsc[2][2], rsh[2][2];
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(256 * WM, (WM == 1 && NT <= 8) ? 2 : 1) void pw_gem
   auto step = [&](int it, auto par) {
     constexpr int P = decltype(par)::value;
     stage(it, par);
-    __syncthreads();
+    lds_barrier();
 #ifdef DL3P_SB_ABLATE
     const int abl = p.stagger;
 #else
@@ -329,7 +336,7 @@ __global__ __launch_bounds__(256 * WM, (WM == 1 && NT <= 8) ? 2 : 1) void pw_gem
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (it % nk == nk - 1 && abl != 4) {
       const int mt = blockIdx.x + (it / nk) * gridDim.x;
       const int m0 = mt * BM;
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(256 * WM, (WM == 1 && NT <= 8) ? 2 : 1) void pw_gem
           else rows(std::false_type{});
         }
       }
-      __syncthreads();   // the next stage() overwrites the epilogue buffer
+      lds_barrier();   // the next stage() overwrites the epilogue buffer
     }
   };
   if (it_total > 0) { prefetch_b(0); prefetch_a(0, std::integral_constant<int, 0>{}); }
@@ -428,7 +435,7 @@ __global__ __launch_bounds__(256 * WM, (WM == 1 && NT <= 8) ? 2 : 1) void pw_gem
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (p.partials) {
       for (int i = t; i < 2 * BN; i += NTHR) {
         const int which = i / BN, nn = i - which * BN;
@@ -441,6 +448,388 @@ __global__ __launch_bounds__(256 * WM, (WM == 1 && NT <= 8) ? 2 : 1) void pw_gem
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------ producer / consumer form
+// The same product with the workgroup's eight waves SPECIALISED (512 threads, one workgroup per CU): waves 0-3 only multiply (one
+// per SIMD: fragments from LDS, six MFMAs per tile, epilogue), waves 4-7 only stage (global loads two K-steps ahead, the producer's
+// BatchNorm + activation, the 3-way split, LDS stores) into the OTHER of two operand buffers -- one barrier per K-step hands a
+// buffer over.  On every SIMD a multiplying wave and a staging wave sit side by side: the MFMA holds the vector issue for 8 of
+// its 16 cycles, the staging wave's VALU / LDS / memory instructions take the rest, so the staging pipeline that bounded the
+// symmetric kernel (283 of 425 us with the MFMAs removed) runs UNDER the multiply phase instead of in front of it,
+// and the epilogue of a row tile overlaps the staging of the next one's first K-steps.
+template <int NT, bool STATS, int MI, bool BNB>
+__global__ __launch_bounds__(512, 1) void pw_gemm_sbp_kernel(GemmParams p) {
+  constexpr int BKT = SB_BKT, PB = SB_PB;
+  constexpr int BM = 64 * MI, BN = 16 * NT;
+  constexpr int A_PLANE = BM * PB, B_PLANE = BN * PB;          // bf16 elements
+  constexpr int STAGE = 3 * (A_PLANE + B_PLANE);               // one operand buffer, bf16 elements
+  constexpr int NA = MI;
+  constexpr int NBC = (3 * BN * 4 + 255) / 256;
+  constexpr int TPP = NT < 4 ? NT : 4;
+  constexpr int NPASS = (NT + TPP - 1) / TPP;
+  constexpr int CH = 16 * TPP;
+  constexpr int EPITCH = CH + 4;
+  constexpr int RW = 16 * MI;
+  extern __shared__ __attribute__((aligned(16))) unsigned char sbp_lds[];
+  unsigned short* Stage0 = reinterpret_cast<unsigned short*>(sbp_lds);
+  float* Es = reinterpret_cast<float*>(sbp_lds + 2 * STAGE * 2);       // consumer-wave-private epilogue slices
+  float* red = Es;                                                      // the final statistics reduction reuses them
+
+  const int t = threadIdx.x;
+  const int l = t & 63;
+  const int wv = t >> 6;
+  const bool producer = wv >= 4;
+  const int w = wv & 3;                 // consumer wave / producer wave index
+  const int l15 = l & 15;
+  const int q = l >> 4;
+  const int n0 = blockIdx.y * BN;
+  const int nk = (p.K + BKT - 1) / BKT;
+  const int my_tiles = (p.num_m_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int it_total = my_tiles * nk;
+
+  if (producer) {
+    const int pt = t - 256;            // 0 .. 255
+    const int ar = pt >> 2;
+    const int ak8 = (pt & 3) * 8;
+    const char* Ab = reinterpret_cast<const char*>(p.A);
+    const char* Bb = reinterpret_cast<const char*>(p.Bsp);
+    float4 ra[2][NA][2];
+    uint4 rb[NBC];
+    float4 rsc[2][2], rsh[2][2];
+    uint32_t b_off[NBC];
+    bool b_ok[NBC];
+    int b_lds[NBC];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) { rsc[s2][h] = make_float4(1.f, 1.f, 1.f, 1.f); rsh[s2][h] = zero4(); }
+#pragma unroll
+    for (int i = 0; i < NBC; ++i) {
+      const int idx = pt + 256 * i;
+      const int c = idx < 3 * BN * 4 ? idx : 3 * BN * 4 - 1;
+      const int plane = c / (BN * 4), rem = c - plane * (BN * 4);
+      const int r = rem >> 2, ch = rem & 3;
+      const int n = n0 + r;
+      b_ok[i] = idx < 3 * BN * 4 && n < p.N;
+      b_off[i] = (uint32_t)(((long long)plane * p.bsp_plane + (long long)min(n, p.N - 1) * p.bsp_pitch + ch * 8) * 2);
+      b_lds[i] = 3 * A_PLANE + plane * B_PLANE + r * PB + ch * 8;
+    }
+    auto prefetch_b = [&](int it) {
+      const int k0 = (it % nk) * BKT;
+#pragma unroll
+      for (int i = 0; i < NBC; ++i) rb[i] = *reinterpret_cast<const uint4*>(Bb + (b_off[i] + (uint32_t)k0 * 2u));
+    };
+    auto prefetch_a = [&](int it, auto par) {
+      constexpr int P = decltype(par)::value;
+      const int kt = it % nk;
+      const int m0 = (blockIdx.x + (it / nk) * gridDim.x) * BM;
+      const int k0 = kt * BKT;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const uint32_t kb = (uint32_t)min(k0 + ak8 + 4 * h, p.K - 4) * 4u;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+          const uint32_t rowb = (uint32_t)min(m0 + ar + 64 * i, p.M - 1) * (uint32_t)p.lda * 4u;
+          ra[P][i][h] = *reinterpret_cast<const float4*>(Ab + (rowb + kb));
+        }
+        if (p.scale) {
+          rsc[P][h] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.scale) + kb);
+          rsh[P][h] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.shift) + kb);
+        }
+      }
+    };
+    const float act_lo = p.act == DL3P_ACT_NONE ? -DL3P_INF : 0.f;
+    const float act_hi = (p.act == DL3P_ACT_NONE || p.act == DL3P_ACT_RELU) ? DL3P_INF : 6.f;
+    const bool has_pro = p.scale != nullptr || p.act != DL3P_ACT_NONE;
+    auto stage = [&](int it, auto par) {
+      constexpr int P = decltype(par)::value;
+      unsigned short* buf = Stage0 + (it & 1) * STAGE;
+      const int kt = it % nk;
+      const int m0 = (blockIdx.x + (it / nk) * gridDim.x) * BM;
+      const int k0 = kt * BKT;
+      const bool a_edge = m0 + BM > p.M || k0 + BKT > p.K;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int r = ar + 64 * i;
+        float4 v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          v[h] = ra[P][i][h];
+          if (has_pro) {
+            v[h] = fma4(v[h], rsc[P][h], rsh[P][h]);
+            if (p.act >= DL3P_ACT_HSWISH) v[h] = act_apply4(v[h], p.act);
+            else v[h] = make_float4(__builtin_amdgcn_fmed3f(v[h].x, act_lo, act_hi), __builtin_amdgcn_fmed3f(v[h].y, act_lo, act_hi),
+                                    __builtin_amdgcn_fmed3f(v[h].z, act_lo, act_hi), __builtin_amdgcn_fmed3f(v[h].w, act_lo, act_hi));
+          }
+          if (a_edge) v[h] = (k0 + ak8 + 4 * h < p.K && m0 + r < p.M) ? v[h] : zero4();
+        }
+        uint4 hh, mm, ll;
+#ifdef DL3P_SB_ABLATE
+        if (p.stagger == 1) {
+          hh = make_uint4(__builtin_bit_cast(uint32_t, v[0].x), __builtin_bit_cast(uint32_t, v[0].z), __builtin_bit_cast(uint32_t, v[1].x), __builtin_bit_cast(uint32_t, v[1].z));
+          mm = make_uint4(__builtin_bit_cast(uint32_t, v[0].y), __builtin_bit_cast(uint32_t, v[0].w), __builtin_bit_cast(uint32_t, v[1].y), __builtin_bit_cast(uint32_t, v[1].w));
+          ll = hh;
+        } else
+#endif
+        {
+        split2(v[0].x, v[0].y, hh.x, mm.x, ll.x);
+        split2(v[0].z, v[0].w, hh.y, mm.y, ll.y);
+        split2(v[1].x, v[1].y, hh.z, mm.z, ll.z);
+        split2(v[1].z, v[1].w, hh.w, mm.w, ll.w);
+        }
+#ifdef DL3P_SB_ABLATE
+        if (p.stagger == 6 && it > 1) continue;
+#endif
+        unsigned short* d = buf + r * PB + ak8;
+        *reinterpret_cast<uint4*>(d) = hh;
+        *reinterpret_cast<uint4*>(d + A_PLANE) = mm;
+        *reinterpret_cast<uint4*>(d + 2 * A_PLANE) = ll;
+      }
+#pragma unroll
+      for (int i = 0; i < NBC; ++i) {
+        asm volatile("" :: "v"(rb[i].x), "v"(rb[i].y), "v"(rb[i].z), "v"(rb[i].w));
+#ifdef DL3P_SB_ABLATE
+        if (p.stagger == 5 && it > 1) continue;
+#endif
+        if (pt + 256 * i < 3 * BN * 4) {
+          uint4 v = rb[i];
+          if (!b_ok[i]) v = make_uint4(0u, 0u, 0u, 0u);
+          *reinterpret_cast<uint4*>(buf + b_lds[i]) = v;
+        }
+      }
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    if (it_total > 0) { prefetch_b(0); prefetch_a(0, P0{}); }
+    if (it_total > 1) prefetch_a(1, P1{});
+    if (it_total > 0) {
+      stage(0, P0{});
+      if (it_total > 1) prefetch_b(1);
+      if (it_total > 2) prefetch_a(2, P0{});
+    }
+    lds_barrier();
+    // iteration i (the multiplying waves work on buffer i & 1): stage K-step i + 1 into the other buffer
+    for (int i = 0; i < it_total; i += 2) {
+#ifdef DL3P_SB_ABLATE
+      const int abl = p.stagger;
+#else
+      constexpr int abl = 0;
+#endif
+      if (i + 1 < it_total) {
+        stage(i + 1, P1{});
+        if (i + 2 < it_total && abl != 7) prefetch_b(i + 2);
+        if (i + 3 < it_total && abl != 3) prefetch_a(i + 3, P1{});
+      }
+      lds_barrier();
+      if (i + 1 < it_total) {
+        if (i + 2 < it_total) {
+          stage(i + 2, P0{});
+          if (i + 3 < it_total && abl != 7) prefetch_b(i + 3);
+          if (i + 4 < it_total && abl != 3) prefetch_a(i + 4, P0{});
+        }
+        lds_barrier();
+      }
+    }
+    if (STATS) lds_barrier();       // the statistics reduction's barrier (consumers write `red` in front of it)
+    return;
+  }
+
+  // ---------------------------------------------------------------- multiplying waves
+  f32x4 acc[MI][NT];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 st_s[STATS ? NPASS : 1], st_q[STATS ? NPASS : 1];
+  if (STATS) {
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) { st_s[i] = zero4(); st_q[i] = zero4(); }
+  }
+  float* es = Es + w * RW * EPITCH;
+  lds_barrier();
+  for (int it = 0; it < it_total; ++it) {
+    const unsigned short* As = Stage0 + (it & 1) * STAGE;
+    const unsigned short* Bs = As + 3 * A_PLANE;
+#ifdef DL3P_SB_ABLATE
+    const int abl = p.stagger;
+#else
+    constexpr int abl = 0;
+#endif
+    if (abl != 2) {
+      s16x8 xa[MI][3];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          xa[mi][pl] = *reinterpret_cast<const s16x8*>(As + pl * A_PLANE + (w * 16 * MI + mi * 16 + l15) * PB + q * 8);
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) {
+        s16x8 wb[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) wb[pl] = *reinterpret_cast<const s16x8*>(Bs + pl * B_PLANE + (ni * 16 + l15) * PB + q * 8);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          f32x4 c = acc[mi][ni];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[2], xa[mi][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[0], xa[mi][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[1], xa[mi][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[1], xa[mi][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[0], xa[mi][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[0], xa[mi][0], c, 0, 0, 0);
+          acc[mi][ni] = c;
+        }
+      }
+    }
+    if (it % nk == nk - 1 && abl != 4) {
+      // epilogue of this row tile, through the wave's private LDS slice (no barrier: LDS executes one wave's accesses in order)
+      const int m0 = (blockIdx.x + (it / nk) * gridDim.x) * BM;
+      const int rr = l >> 4, cq = l & 15;
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int ni0 = ps * TPP;
+#pragma unroll
+        for (int nl = 0; nl < TPP; ++nl) {
+          if (ni0 + nl < NT) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+              const f32x4 v = acc[mi][ni0 + nl];
+              acc[mi][ni0 + nl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+              *reinterpret_cast<float4*>(&es[(mi * 16 + l15) * EPITCH + nl * 16 + q * 4]) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+          }
+        }
+        const int n = n0 + ni0 * 16 + cq * 4;
+        const bool col_ok = (ni0 * 16 + cq * 4 < BN) && (cq * 4 < CH) && n < p.N && (ni0 + cq / 4 < NT);
+        const int row_lim = p.M - (m0 + w * RW);
+        if (col_ok) {
+          float4 bias4 = zero4();
+          if (p.bias) bias4 = ld4(p.bias + n);
+          char* yb = reinterpret_cast<char*>(p.Y) + ((uint32_t)(m0 + w * RW + rr) * (uint32_t)p.ldy + (uint32_t)n) * 4u;
+          const uint32_t ystep = (uint32_t)p.ldy * 16u;
+          constexpr bool bnb = STATS && BNB;
+          float4 bsc = zero4(), bsh = zero4(), bmu = zero4(), bis = zero4();
+          float4 zpre[RW / 4];
+          if (bnb) {
+            bsc = ld4(p.bb_scale + n); bsh = ld4(p.bb_shift + n); bmu = ld4(p.bb_mean + n); bis = ld4(p.bb_invstd + n);
+            const char* zbase = reinterpret_cast<const char*>(p.bb_z) + (uint32_t)n * 4u;
+#pragma unroll
+            for (int i = 0; i < RW / 4; ++i) {
+              const int mrow = min(m0 + w * RW + 4 * i + rr, p.M - 1);
+              zpre[i] = *reinterpret_cast<const float4*>(zbase + (uint32_t)mrow * (uint32_t)p.bb_ldz * 4u);
+            }
+          }
+          auto rows = [&](auto full) {
+#pragma unroll
+            for (int r0 = 0; r0 < RW; r0 += 4) {
+              const int row = r0 + rr;
+              if (decltype(full)::value || row < row_lim) {
+                float4 o = add4(*reinterpret_cast<const float4*>(&es[row * EPITCH + cq * 4]), bias4);
+                float* yp = reinterpret_cast<float*>(yb + (r0 / 4) * ystep);
+                if (p.accumulate) o = add4(o, ld4(yp));
+                st4(yp, o);
+                if (STATS) {
+                  if (bnb) {
+                    const float4 zv = zpre[r0 / 4];
+                    const float4 u = fma4(zv, bsc, bsh);
+                    const float4 d = make_float4(o.x * act_grad(u.x, p.bb_act), o.y * act_grad(u.y, p.bb_act),
+                                                 o.z * act_grad(u.z, p.bb_act), o.w * act_grad(u.w, p.bb_act));
+                    const float4 xh = make_float4((zv.x - bmu.x) * bis.x, (zv.y - bmu.y) * bis.y, (zv.z - bmu.z) * bis.z,
+                                                  (zv.w - bmu.w) * bis.w);
+                    st_s[ps] = add4(st_s[ps], d);
+                    st_q[ps] = fma4(d, xh, st_q[ps]);
+                  } else {
+                    st_s[ps] = add4(st_s[ps], o);
+                    st_q[ps] = fma4(o, o, st_q[ps]);
+                  }
+                }
+              }
+            }
+          };
+          if (row_lim >= RW) rows(std::true_type{});
+          else rows(std::false_type{});
+        }
+      }
+    }
+    lds_barrier();
+  }
+  if (STATS) {
+    const int rr = l >> 4, cq = l & 15;
+    // (every multiplying wave is past its last epilogue read of `es` here only for ITSELF: `red` overlays all four slices, so the
+    // four waves meet first)
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      float sv[4] = {st_s[ps].x, st_s[ps].y, st_s[ps].z, st_s[ps].w};
+      float qv[4] = {st_q[ps].x, st_q[ps].y, st_q[ps].z, st_q[ps].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float s1 = sv[e], s2 = qv[e];
+        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        sv[e] = s1; qv[e] = s2;
+      }
+      st_s[ps] = make_float4(sv[0], sv[1], sv[2], sv[3]);
+      st_q[ps] = make_float4(qv[0], qv[1], qv[2], qv[3]);
+    }
+    // the last loop barrier above separates every wave's final epilogue from these writes
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const float sv[4] = {st_s[ps].x, st_s[ps].y, st_s[ps].z, st_s[ps].w};
+      const float qv[4] = {st_q[ps].x, st_q[ps].y, st_q[ps].z, st_q[ps].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int col = ps * CH + cq * 4 + e;
+        if (rr == 0 && cq * 4 < CH && col < BN) {
+          red[(0 * 4 + w) * BN + col] = sv[e];
+          red[(1 * 4 + w) * BN + col] = qv[e];
+        }
+      }
+    }
+    lds_barrier();
+    if (p.partials) {
+      for (int i = t; i < 2 * BN; i += 256) {
+        const int which = i / BN, nn = i - which * BN;
+        if (n0 + nn < p.N) {
+          const float s = red[(which * 4 + 0) * BN + nn] + red[(which * 4 + 1) * BN + nn] +
+                          red[(which * 4 + 2) * BN + nn] + red[(which * 4 + 3) * BN + nn];
+          p.partials[((size_t)blockIdx.x * 2 + which) * p.N + n0 + nn] = s;
+        }
+      }
+    }
+  }
+}
+
+template <int NT, bool STATS, int MI, bool BNB>
+static void launch_sbp_one(const GemmParams& p, dim3 grid, hipStream_t st) {
+  constexpr int BM = 64 * MI, BN = 16 * NT;
+  constexpr int STAGE_B = 3 * (BM + BN) * SB_PB * 2;
+  constexpr int TPP = NT < 4 ? NT : 4;
+  constexpr int ES = 4 * 16 * MI * (16 * TPP + 4) * 4;
+  constexpr int RED = STATS ? 2 * 4 * BN * 4 : 0;
+  constexpr size_t lds = (size_t)2 * STAGE_B + (ES > RED ? ES : RED);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)pw_gemm_sbp_kernel<NT, STATS, MI, BNB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dl3p_launch(pw_gemm_sbp_kernel<NT, STATS, MI, BNB>, grid, dim3(512), lds, st, p);
+}
+
+template <bool STATS, bool BNB>
+static void launch_sbp_nt(const GemmParams& p, int nt, int mi, dim3 grid, hipStream_t st) {
+#define DL3P_SBP(N_) case N_: if (mi == 1) launch_sbp_one<N_, STATS, 1, BNB>(p, grid, st); else launch_sbp_one<N_, STATS, 2, BNB>(p, grid, st); break;
+  switch (nt) {
+    DL3P_SBP(1) DL3P_SBP(2) DL3P_SBP(3) DL3P_SBP(4) DL3P_SBP(5) DL3P_SBP(6) DL3P_SBP(7)
+    default: if (mi == 1) launch_sbp_one<8, STATS, 1, BNB>(p, grid, st); else launch_sbp_one<8, STATS, 2, BNB>(p, grid, st); break;
+  }
+#undef DL3P_SBP
+}
+
+// producer / consumer form: (nt <= 8, mi) tiles, one 512-thread workgroup per CU
+void dl3p_launch_gemm_sbp(const GemmParams& p, bool stats, bool bnb, int nt, int mi, dim3 grid, hipStream_t st) {
+  if (bnb) launch_sbp_nt<true, true>(p, nt, mi, grid, st);
+  else if (stats) launch_sbp_nt<true, false>(p, nt, mi, grid, st);
+  else launch_sbp_nt<false, false>(p, nt, mi, grid, st);
 }
 
 template <int NT, bool STATS, int MI, bool BNB, bool GA, int WM>

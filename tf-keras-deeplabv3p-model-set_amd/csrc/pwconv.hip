@@ -615,6 +615,7 @@ static bool pw_small_pick(int K, int N, SmallShape* out) {
 // tests lower it through dl3p_set_option so that small test shapes reach those kernels too, and reset it for the
 // tests that check the production dispatch at the production shapes.
 static int g_gemm_force_nt = 0, g_gemm_force_mi = 0, g_gemm_force_pc = 0, g_gemm_use_table = -1;   // see gemm_tuned_lookup / gemm_plan
+static int g_sb_pipe = -1;      // dl3p_set_option("sb_pipe", 0 | 1): the producer / consumer form of the split kernel (default DL3P_SB_PIPE or 0)
 static int g_sb_force_wm = 0, g_sb_force_nt = 0;      // dl3p_set_option("sb_wm" / "sb_nt"): pin the split kernel's wide-tile family (gemm_plan_sb)
 static int g_wgrad_force_tile = -1, g_wgrad_force_per_cu = 0;                    // see wgrad_pick_tile / wgrad_split
 static int g_pw_small_min_rows = -1;
@@ -633,6 +634,7 @@ extern "C" int dl3p_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm_mi")) { g_gemm_force_mi = (value == 1 || value == 2) ? value : 0; return DL3P_OK; }
   if (!strcmp(name, "gemm_per_cu")) { g_gemm_force_pc = value > 0 ? value : 0; return DL3P_OK; }
   if (!strcmp(name, "gemm_tuned")) { g_gemm_use_table = value ? 1 : 0; return DL3P_OK; }
+  if (!strcmp(name, "sb_pipe")) { g_sb_pipe = value ? 1 : 0; return DL3P_OK; }
   if (!strcmp(name, "sb_wm")) { g_sb_force_wm = (value >= -1 && value <= 2) ? value : 0; return DL3P_OK; }    // -1: never wide
   if (!strcmp(name, "sb_nt")) { g_sb_force_nt = (value == 8 || value == 12 || value == 16) ? value : 0; return DL3P_OK; }
   if (!strcmp(name, "dw_per_cu")) { dl3p_dw_force_per_cu = value > 0 ? value : 0; return DL3P_OK; }
@@ -1002,6 +1004,8 @@ extern "C" int dl3p_pwconv_bwd_data_bn(const float* dy, int lddy, const float* w
 // (few rows, or few-channel layers on the streaming kernels) must go through the fp32 entry points: *_sb_supported says which.
 void dl3p_launch_gemm_sb(const GemmParams& p, bool stats, bool bnb, bool ga, int nt, int mi, int wm, dim3 grid, hipStream_t st);
 bool dl3p_sb_wide_config(int nt, int mi, int wm);
+void dl3p_launch_gemm_sbp(const GemmParams& p, bool stats, bool bnb, int nt, int mi, dim3 grid, hipStream_t st);
+
 
 // tile choice of a split-bf16 launch.  Wide tiles (one workgroup per CU: 128 or 256 rows x up to 256 columns, the A tile split
 // once for all of N) where there are enough row tiles to go round; otherwise the 2-workgroups-per-CU tiles of the fp32 kernel.
@@ -1009,6 +1013,21 @@ static void gemm_plan_sb(int role, int M, int K, int N, int* nt, int* gx, int* g
   int force_mi = 0, force_pc = 0;
   *nt = pick_nt(N, M);
   *wm = 1;
+  if (g_sb_pipe < 0) g_sb_pipe = getenv("DL3P_SB_PIPE") ? atoi(getenv("DL3P_SB_PIPE")) : 0;     // measured slower than the symmetric form: opt-in
+  if (g_sb_pipe && g_sb_force_wm <= 0) {
+    // producer / consumer form: one 512-thread workgroup per CU, 128 (or 64) rows x up to 128 columns; *wm = 0 marks it
+    if (*nt > 8) *nt = 8;
+    if (g_gemm_force_nt) *nt = g_gemm_force_nt > 8 ? 8 : g_gemm_force_nt;
+    *mi = g_gemm_force_mi ? g_gemm_force_mi : (M >= 4096 ? 2 : 1);
+    const int nb = ceil_div(N, 16 * *nt), mt = ceil_div(M, 64 * *mi);
+    int gxm = DL3P_NUM_CUS / nb;
+    if (gxm < 1) gxm = 1;
+    if (gxm > DL3P_MAX_STAT_ROWS) gxm = DL3P_MAX_STAT_ROWS;
+    int g = mt;
+    if (mt > gxm) g = ceil_div(mt, ceil_div(mt, gxm));
+    *gx = g; *gy = nb; *num_m_tiles = mt; *wm = 0;
+    return;
+  }
   // measured (scripts/micro/sb_gemm.py, profiles/r03_split_gemm.txt): 128-row tiles with the widest column block win on every
   // shape with a few thousand rows or more (the fp32 kernel's 64-row / three-workgroup choice for long GEMMs loses here: two A
   // register sets); with the fused BatchNorm sums 128 x 64, the widest that does not spill.  The one-workgroup-per-CU wide tiles
@@ -1078,7 +1097,8 @@ extern "C" int dl3p_pwconv_fwd_sb(const float* x, int ldx, const float* in_scale
   gemm_plan_sb(stat_partials ? 1 : 0, M, K, N, &nt, &gx, &gy, &p.num_m_tiles, &mi, &wm);
   { const char* e = getenv("DL3P_SB_ABLATE"); p.stagger = e ? atoi(e) : 0; }
   if (rows_out) *rows_out = gx;
-  dl3p_launch_gemm_sb(p, stat_partials != nullptr, false, false, nt, mi, wm, dim3(gx, gy), (hipStream_t)stream);
+  if (wm == 0) dl3p_launch_gemm_sbp(p, stat_partials != nullptr, false, nt, mi, dim3(gx, gy), (hipStream_t)stream);
+  else dl3p_launch_gemm_sb(p, stat_partials != nullptr, false, false, nt, mi, wm, dim3(gx, gy), (hipStream_t)stream);
   DL3P_CHECK_LAUNCH(fn);
   return DL3P_OK;
 }
@@ -1117,7 +1137,8 @@ extern "C" int dl3p_pwconv_bwd_data_sb(const float* dy, int lddy, const void* ws
   int nt, gxn, gy, mi, wm;
   gemm_plan_sb(bnb ? 3 : 2, M, N, K, &nt, &gxn, &gy, &p.num_m_tiles, &mi, &wm);
   if (rows_out) *rows_out = gxn;
-  dl3p_launch_gemm_sb(p, bnb, bnb, false, nt, mi, wm, dim3(gxn, gy), (hipStream_t)stream);
+  if (wm == 0) dl3p_launch_gemm_sbp(p, bnb, bnb, nt, mi, dim3(gxn, gy), (hipStream_t)stream);
+  else dl3p_launch_gemm_sb(p, bnb, bnb, false, nt, mi, wm, dim3(gxn, gy), (hipStream_t)stream);
   DL3P_CHECK_LAUNCH(fn);
   return DL3P_OK;
 }
