@@ -86,11 +86,12 @@ def cpu_baseline(args):
             m.train_step(x, y, {'aspp_dropout': mask})
             n += 1
         return B * n / (time.time() - t0), n
-    # the thread count is MEASURED, not guessed: a short probe at 32 / 64 / 128 / all cores, then the
-    # timed sample at the best of them (oneDNN does not scale to 256 threads on a batch-2 graph)
+    # the thread count is MEASURED, not guessed: a short probe at 8 / 16 / 32 / 64 threads, then the timed
+    # sample at the best of them.  (oneDNN does not scale on a batch-2 graph: on the 256-core GPU host 32 threads gave 6.8
+    # images/s, 64 threads 2.8, 128 threads 1.2 and all 256 cores 0.011 -- three minutes per step -- so the probe stops at 64.)
     probe = {}
-    for th in sorted({t for t in (32, 64, 128, cores) if t <= cores}):
-        probe[th] = rate(th, 1, 3, 8.0)[0]
+    for th in sorted({t for t in (8, 16, 32, 64) if t <= cores}):
+        probe[th] = rate(th, 1, 2, 6.0)[0]
     threads = max(probe, key=probe.get)
     all_rate, all_n = rate(threads, 3, args.cpu_steps, 30.0)
     one_rate, one_n = rate(1, 1, 3, 15.0)

@@ -358,7 +358,8 @@ def test_train_py_flow(tmp_path):
     # 0.001 for the first 500 steps) with fresh slots
     opt2 = pkg.get_optimizer('sgd', 0.02, decay_type='piecewise_constant', decay_steps=1000)
     m.compile(optimizer=opt2, loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
-    assert float(m._store.V.abs().max()) == 0.0 and int(m._store.step.item()) == 0
+    # a NEW optimizer object: fresh slots, its iteration counter restarts; the dropout stream (store.step) keeps counting
+    assert float(m._store.V.abs().max()) == 0.0 and int(m._store.opt_step.item()) == 0 and int(m._store.step.item()) == 9
     m.train_on_batch(*gen[0])
     assert abs(float(m._executor(B, True).lr.item()) - 0.001) < 1e-9 and opt2.iterations == 1
     w2 = m.get_weights_by_name()
