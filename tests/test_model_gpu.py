@@ -796,3 +796,76 @@ def test_recompile_with_a_new_optimizer_keeps_the_dropout_stream():
     assert int(st.step.item()) == 3 and int(st.opt_step.item()) == 1
     assert not np.array_equal(masks[2], masks[0]) and not np.array_equal(masks[2], masks[1]) and not np.array_equal(masks[0], masks[1])
     assert 0.4 < masks[2].mean() < 0.6
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Layer-local parity in fp32 (round 3): the train-step tests above bound a gradient's error THROUGH the whole network (8e-3 of
+# a tensor's scale: 65 - 146 BatchNorms of accumulated fp32-vs-fp64 rounding).  Here the float64 oracle is kept on the device's
+# trajectory in both directions -- every conv output is compared with what the oracle computes from the DEVICE's inputs to that
+# layer and the oracle continues with the device's tensor (Net.force); every conv-output gradient likewise (Net.force_grad) --
+# so each layer's forward, data gradient + BatchNorm backward segment, and weight gradient is held against float64 on identical
+# inputs, at op-test tolerances.  The shortcuts of the production backward (folded apply, aliased Add gradients) are off so that
+# every conv output's gradient buffer holds d loss / d z at the end of the step; tests/test_ops_gpu.py and the
+# "backward shortcuts == same step with all of them off" test carry the result over to the production plan.
+def _teacher_forced_step(model_type, H, W, OS, N, tol_fwd, tol_dz, tol_w):
+    _skip_if_missing(model_type)
+    C = 21
+    m, o = _pair(model_type, H, W, C, OS=OS)
+    m.use_graphs = False
+    x, y = _data(N, H, W, C, seed=13)
+    loss = m.train_on_batch(x, y)
+    ex = m._executor(N, True)
+    drop = [op for op in m.graph.ops if op.kind == 'materialize' and op.rate > 0][0]
+    mask = ex.dropout_mask(drop).cpu().numpy()
+    convs = [op for op in m.graph.ops if op.kind in ('conv_pw', 'conv_dense', 'conv_dw')]
+    real = {op.name: op.layer.params[0].shape[-1] if op.kind != 'conv_dw' else op.c for op in convs}
+    o.net.act_derivs = _act_derivs(m, ex)
+    o.net.act_derivs_seq = _act_derivs_seq(m, ex, o.net.act_derivs)
+    o.net.force = {op.name: ex.view(op.out).float().cpu().numpy()[..., :real[op.name]] for op in convs}
+    o.net.record = {}
+    o.net.force_grad = {op.name: ex.view(op.out, grad=True).float().cpu().numpy()[..., :real[op.name]] for op in convs
+                        if op.out.requires_grad}
+    o.net.record_grad = {}
+    o.net.grad_term_norm = {}
+    total, ce, logits = o.loss_and_grads(x, y, {'aspp_dropout': mask})
+    assert abs(loss - ce) < 1e-5 * max(1.0, abs(ce)), (loss, ce)
+    worst_f = worst_g = ('', 0.0)
+    for op in convs:
+        ref, got = np.asarray(o.net.record[op.name], np.float64), o.net.force[op.name].astype(np.float64)
+        r = float(np.abs(got - ref).max() / max(1e-30, np.abs(ref).max()))
+        if r > worst_f[1]:
+            worst_f = (op.name, r)
+        if op.name in o.net.force_grad:
+            ref, got = np.asarray(o.net.record_grad[op.name], np.float64), o.net.force_grad[op.name].astype(np.float64)
+            if np.abs(ref).max() > 1e-30:
+                r = float(np.abs(got - ref).max() / np.abs(ref).max())
+                if r > worst_g[1]:
+                    worst_g = (op.name, r)
+    st = m._store
+    worst_w = ('', 0.0)
+    for p in m.graph.all_params():
+        ge = o.net.grads.get(p.name)
+        if not p.trainable or ge is None:
+            continue
+        g = st.get(p, st.G).astype(np.float64)
+        noise = o.net.grad_term_norm.get(p.name)
+        # BatchNorm sums: against the l2 norm of their terms (a beta in front of a conv + BatchNorm pair is an exact zero)
+        scale = np.maximum(np.abs(ge).max(), 0.0 if noise is None else float(noise.max()) * 1e-2)
+        if scale < 1e-12:
+            continue
+        r = float(np.abs(g - ge).max() / scale)
+        if r > worst_w[1]:
+            worst_w = (p.name, r)
+    _record_injection(dict(test='teacher_forced_fp32', model=model_type, H=H, W=W, OS=OS, worst_forward=worst_f,
+                           worst_activation_gradient=worst_g, worst_parameter_gradient=worst_w))
+    assert worst_f[1] < tol_fwd, ('forward', worst_f)
+    assert worst_g[1] < tol_dz, ('activation gradient', worst_g)
+    assert worst_w[1] < tol_w, ('parameter gradient', worst_w)
+
+
+@pytest.mark.parametrize('model_type,H,W,OS', [('mobilenetv2', 65, 65, 16), ('xception', 65, 65, 16), ('mobilenetv3large', 64, 96, 16),
+                                               ('resnet50', 65, 65, 16), ('xception', 97, 97, 8), ('mobilenetv2_lite', 65, 97, 16)])
+def test_every_layer_matches_float64_on_the_devices_own_inputs(model_type, H, W, OS, monkeypatch):
+    monkeypatch.setenv('DL3P_FOLD_APPLY', '0')
+    monkeypatch.setenv('DL3P_GRAD_ALIAS', '0')
+    _teacher_forced_step(model_type, H, W, OS, 4 if model_type == 'resnet50' else 2, 2e-5, 2e-4, 5e-4)

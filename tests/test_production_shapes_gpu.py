@@ -252,3 +252,13 @@ def test_bn_backward_at_config1_shape(ops):
     invstd_ref = 1.0 / np.sqrt(var + 1e-3)
     assert np.abs(bn.invstd.cpu().numpy()[8:] - invstd_ref[8:]).max() < 1e-4 * invstd_ref[8:].max()
     assert np.abs(bn.invstd.cpu().numpy()[:8] - invstd_ref[:8]).max() < 2e-2 * invstd_ref[:8].max()
+
+
+@pytest.mark.parametrize('model_type', ['mobilenetv2', 'xception'])
+def test_every_layer_at_513_matches_float64_on_the_devices_own_inputs(model_type, monkeypatch):
+    """the layer-local comparison of tests/test_model_gpu.py at the production shapes and dispatch: every conv layer's forward,
+    its data-gradient + BatchNorm-backward segment and its weight gradient against float64 on the device's own inputs"""
+    from test_model_gpu import _teacher_forced_step
+    monkeypatch.setenv('DL3P_FOLD_APPLY', '0')
+    monkeypatch.setenv('DL3P_GRAD_ALIAS', '0')
+    _teacher_forced_step(model_type, 513, 513, 16, 2, 2e-5, 2e-4, 5e-4)
