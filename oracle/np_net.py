@@ -159,6 +159,8 @@ class Net:
             self.acc_grad(name + '/kernel', gw)
             if use_bias:
                 self.acc_grad(name + '/bias', gb)
+                if self.grad_term_norm is not None:      # (a bias in front of a BatchNorm has an exactly zero gradient: noise scale)
+                    self.grad_term_norm[name + '/bias'] = np.sqrt((np.asarray(y.g, np.float64).reshape(-1, filters) ** 2).sum(0))
             x.acc(gx)
         self.tape.append(bwd)
         return y
