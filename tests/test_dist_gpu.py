@@ -82,7 +82,7 @@ print('COMM OK')
 # flat gradient buffer) then has to reproduce the single-GPU step on that batch: SyncBatchNorm over two copies of a batch
 # has the batch's own statistics, the summed gradient is twice the gradient.  A wrong M * world, a missing 1 / world, a
 # slice no bucket covers or a slice reduced twice all change the result.
-def _two_identical_ranks(check=None):
+def _two_identical_ranks(check=None, world=2):
     import torch
     from conftest import load_pkg
     DistContext = load_pkg('model').DistContext
@@ -90,7 +90,7 @@ def _two_identical_ranks(check=None):
     class TwoIdenticalRanks(DistContext):
         def __init__(self, sync_bn=True, n_buckets=4):
             self.dist = None
-            self.world_size, self.rank = 2, 0
+            self.world_size, self.rank = world, 0
             self.sync_bn, self.n_buckets = sync_bn, n_buckets
             self._streams, self._bn_pg = {}, None
             self.buckets = []           # (lo element, n elements) of every gradient-bucket all-reduce of the last step
@@ -101,7 +101,7 @@ def _two_identical_ranks(check=None):
 
         def all_reduce(self, t):
             self.bn_calls += 1
-            t.mul_(2)
+            t.mul_(world)
 
         def all_reduce_async(self, t):
             if check is not None:
@@ -109,14 +109,14 @@ def _two_identical_ranks(check=None):
             side = self._side('grad')
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                t.mul_(2)
+                t.mul_(world)
 
         def bn_all_reduce_begin(self, t):
             self.bn_calls += 1
             side = self._side('bn')
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                t.mul_(2)
+                t.mul_(world)
     return TwoIdenticalRanks
 
 
@@ -235,3 +235,22 @@ def test_every_gradient_is_final_when_its_bucket_is_reduced(model_type):
     ex.opt.run()
     torch.cuda.synchronize()
     assert bool(torch.isfinite(st.P).all())
+
+
+@pytest.mark.parametrize('world,segmented', [(8, False), (2, True), (4, True)])
+def test_identical_ranks_other_world_sizes_and_the_segmented_fallback(world, segmented, monkeypatch):
+    """the same identity for 4 and 8 identical ranks (x4 / x8 and their reciprocals are exact too: nothing may be hard-wired to
+    two), and with the collectives issued eagerly between hipGraph segments (DL3P_COLLECTIVES_IN_GRAPH=0, the fallback the hang
+    guard names)"""
+    import numpy as np
+    if segmented:
+        monkeypatch.setenv('DL3P_COLLECTIVES_IN_GRAPH', '0')
+    ctx = _two_identical_ranks(world=world)()
+    monkeypatch.setenv('DL3P_FOLD_APPLY', '0')
+    ref_l, ref_w, _ = _trajectory('mobilenetv2', 65, 65, 2, None, 3, True)
+    monkeypatch.delenv('DL3P_FOLD_APPLY')
+    got_l, got_w, m = _trajectory('mobilenetv2', 65, 65, 2, ctx, 3, True)
+    ex = m._executor(2, True)
+    assert ex.dist is ctx and ex.dist.world_size == world and ex.graphed
+    assert got_l == ref_l, (got_l, ref_l)
+    assert max(float(np.abs(got_w[k] - ref_w[k]).max()) for k in ref_w) == 0.0
