@@ -27,6 +27,14 @@ typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
 #define SB_BKT 32
 #define SB_PB 40   // bf16 elements per LDS tile row: 64 B of data + 16 B pad
 
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
 // Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() is `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`: the
 // vmcnt(0) drains every global load in flight, i.e. the operand prefetch issued for the NEXT K-steps -- each K-step then contains a
 // full memory round trip, and with six bf16 MFMAs per tile the multiply phase (~0.7 us) is too short to cover one.  The tiles
@@ -119,6 +127,10 @@ __global__ __launch_bounds__(256 * WM, (WM == 1 && NT <= 8) ? 2 : 1) void pw_gem
   const int ar = t >> 2;           // A row within a pass of 64 rows
   const int ak8 = (t & 3) * 8;     // first of this thread's 8 k of the K tile
   const char* Ab = reinterpret_cast<const char*>(p.A);
+  // the producer's BN scale / shift ride along with the A loads; without one the loads still happen (from A: any valid address)
+  // and stage() ignores them -- see the note on unconditional prefetches in step()
+  const float* scp = p.scale ? p.scale : p.A;
+  const float* shp = p.scale ? p.shift : p.A;
 
   // A is prefetched TWO K-steps ahead (two register sets, PAR = it & 1): with six bf16 MFMAs per tile the multiply phase of a
   // K-step lasts ~0.7 us, less than an HBM round trip under load (measured neutral to -3 %: the loop is bound by its staging
@@ -151,13 +163,13 @@ __global__ __launch_bounds__(256 * WM, (WM == 1 && NT <= 8) ? 2 : 1) void pw_gem
   }
   const char* Bb = reinterpret_cast<const char*>(p.Bsp);
 
-  auto prefetch_b = [&](int it) {
+  auto prefetch_b = [&](int it) __attribute__((always_inline)) {
     const int k0 = (it % nk) * BKT;
 #pragma unroll
     for (int i = 0; i < NBC; ++i) rb[i] = *reinterpret_cast<const uint4*>(Bb + (b_off[i] + (uint32_t)k0 * 2u));
   };
 
-  auto prefetch_a = [&](int it, auto par) {
+  auto prefetch_a = [&](int it, auto par) __attribute__((always_inline)) {
     constexpr int P = decltype(par)::value;
     const int kt = it % nk;
     const int mt = blockIdx.x + (it / nk) * gridDim.x;
@@ -196,10 +208,8 @@ __global__ __launch_bounds__(256 * WM, (WM == 1 && NT <= 8) ? 2 : 1) void pw_gem
           ra[P][i][h] = *reinterpret_cast<const float4*>(Ab + off);
           g_ok[P] |= ok ? (1u << (2 * i + h)) : 0u;
         }
-        if (p.scale) {
-          rsc[P][h] = *reinterpret_cast<const float4*>(p.scale + c);
-          rsh[P][h] = *reinterpret_cast<const float4*>(p.shift + c);
-        }
+        rsc[P][h] = *reinterpret_cast<const float4*>(scp + c);
+        rsh[P][h] = *reinterpret_cast<const float4*>(shp + c);
       }
     } else {
       if (m0 != pf_m0[P]) {
@@ -212,25 +222,23 @@ __global__ __launch_bounds__(256 * WM, (WM == 1 && NT <= 8) ? 2 : 1) void pw_gem
         const uint32_t kb = (uint32_t)min(k0 + ak8 + 4 * h, p.K - 4) * 4u;
 #pragma unroll
         for (int i = 0; i < NA; ++i) ra[P][i][h] = *reinterpret_cast<const float4*>(Ab + (a_row[P][i] + kb));
-        if (p.scale) {
-          rsc[P][h] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.scale) + kb);
-          rsh[P][h] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.shift) + kb);
-        }
+        rsc[P][h] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(scp) + kb);
+        rsh[P][h] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(shp) + kb);
       }
     }
   };
 
   const float act_lo = p.act == DL3P_ACT_NONE ? -DL3P_INF : 0.f;
   const float act_hi = (p.act == DL3P_ACT_NONE || p.act == DL3P_ACT_RELU) ? DL3P_INF : 6.f;
-  auto prologue4 = [&](float4 v, float4 sc4, float4 sh4) {
-    v = fma4(v, sc4, sh4);
+  auto prologue4 = [&](float4 v, float4 sc4, float4 sh4) __attribute__((always_inline)) {
+    if (p.scale) v = fma4(v, sc4, sh4);
     if (p.act >= DL3P_ACT_HSWISH) return act_apply4(v, p.act);
     return make_float4(__builtin_amdgcn_fmed3f(v.x, act_lo, act_hi), __builtin_amdgcn_fmed3f(v.y, act_lo, act_hi),
                        __builtin_amdgcn_fmed3f(v.z, act_lo, act_hi), __builtin_amdgcn_fmed3f(v.w, act_lo, act_hi));
   };
   const bool has_pro = p.scale != nullptr || p.act != DL3P_ACT_NONE;
 
-  auto stage = [&](int it, auto par) {
+  auto stage = [&](int it, auto par) __attribute__((always_inline)) {
     constexpr int P = decltype(par)::value;
     const int kt = it % nk;
     const int mt = blockIdx.x + (it / nk) * gridDim.x;
@@ -298,7 +306,7 @@ __global__ __launch_bounds__(256 * WM, (WM == 1 && NT <= 8) ? 2 : 1) void pw_gem
     for (int i = 0; i < NPASS; ++i) { st_s[i] = zero4(); st_q[i] = zero4(); }
   }
 
-  auto step = [&](int it, auto par) {
+  auto step = [&](int it, auto par) __attribute__((always_inline)) {
     constexpr int P = decltype(par)::value;
     stage(it, par);
     lds_barrier();
@@ -307,8 +315,11 @@ __global__ __launch_bounds__(256 * WM, (WM == 1 && NT <= 8) ? 2 : 1) void pw_gem
 #else
     constexpr int abl = 0;
 #endif
-    if (it + 1 < it_total && !(abl == 7 && it > 1)) prefetch_b(it + 1);
-    if (it + 2 < it_total && !(abl == 3 && it > 1)) prefetch_a(it + 2, par);       // into the register set this step has just consumed
+    // UNCONDITIONAL (the index clamps at the last step, whose loads are then simply repeated): a prefetch under `if` leaves the
+    // compiler's s_waitcnt pass unable to count the younger loads in the queue, and every wait of the next stage() degrades to
+    // vmcnt(0) -- the two-steps-ahead A prefetch then waits for the loads issued one step ago as well
+    if (!(abl == 7 && it > 1)) prefetch_b(min(it + 1, it_total - 1));
+    if (!(abl == 3 && it > 1)) prefetch_a(min(it + 2, it_total - 1), par);       // into the register set this step has just consumed
     if (abl != 2) {
       s16x8 xa[MI][3];
 #pragma unroll
@@ -410,12 +421,18 @@ __global__ __launch_bounds__(256 * WM, (WM == 1 && NT <= 8) ? 2 : 1) void pw_gem
       lds_barrier();   // the next stage() overwrites the epilogue buffer
     }
   };
-  if (it_total > 0) { prefetch_b(0); prefetch_a(0, std::integral_constant<int, 0>{}); }
-  if (it_total > 1) prefetch_a(1, std::integral_constant<int, 1>{});
-  for (int it = 0; it < it_total; it += 2) {
-    step(it, std::integral_constant<int, 0>{});
-    if (it + 1 < it_total) step(it + 1, std::integral_constant<int, 1>{});
+  if (it_total > 0) {
+    prefetch_b(0);
+    prefetch_a(0, std::integral_constant<int, 0>{});
+    prefetch_a(min(1, it_total - 1), std::integral_constant<int, 1>{});
   }
+  // pairs of steps in a branch-free body (see the note at the prefetches), the odd last one after the loop
+  int it = 0;
+  for (; it + 1 < it_total; it += 2) {
+    step(it, std::integral_constant<int, 0>{});
+    step(it + 1, std::integral_constant<int, 1>{});
+  }
+  if (it < it_total) step(it, std::integral_constant<int, 0>{});
 
   if (STATS) {
     const int rr = l >> 4, cq = l & 15;
@@ -494,14 +511,22 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_sbp_kernel(GemmParams p) {
     const int ak8 = (pt & 3) * 8;
     const char* Ab = reinterpret_cast<const char*>(p.A);
     const char* Bb = reinterpret_cast<const char*>(p.Bsp);
-    float4 ra[2][NA][2];
-    uint4 rb[NBC];
-    float4 rsc[2][2], rsh[2][2];
+    const float* scp = p.scale ? p.scale : p.A;      // loaded either way (see pw_gemm_sb_kernel), used only with a producer BN
+    const float* shp = p.scale ? p.shift : p.A;
+    // DEPTH K-steps of operands in flight per staging wave.  Little's law: the multiply phase wants 40 KB per CU every ~0.75 us; at the
+    // ~2.5 us a load takes with every CU pulling, that is ~130 KB in flight per CU -- two steps (56 KB) delivered 4.8 TB/s chip-wide
+    // and set the pace of the whole kernel (its time with the MFMAs removed, 331 us, is that rate).  Four register sets of
+    // (A: 2 x NA float4, B: NBC x 16 bytes) per thread = 160 KB per CU.
+    // (three where four would spill: the 128 x 128 tile).
+    constexpr int DEPTH = (NT >= 6 && MI >= 2) ? 3 : 4;
+    float4 ra[DEPTH][NA][2];
+    uint4 rb[DEPTH][NBC];
+    float4 rsc[DEPTH][2], rsh[DEPTH][2];
     uint32_t b_off[NBC];
     bool b_ok[NBC];
     int b_lds[NBC];
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
+    for (int s2 = 0; s2 < DEPTH; ++s2)
 #pragma unroll
       for (int h = 0; h < 2; ++h) { rsc[s2][h] = make_float4(1.f, 1.f, 1.f, 1.f); rsh[s2][h] = zero4(); }
 #pragma unroll
@@ -515,16 +540,21 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_sbp_kernel(GemmParams p) {
       b_off[i] = (uint32_t)(((long long)plane * p.bsp_plane + (long long)min(n, p.N - 1) * p.bsp_pitch + ch * 8) * 2);
       b_lds[i] = 3 * A_PLANE + plane * B_PLANE + r * PB + ch * 8;
     }
-    auto prefetch_b = [&](int it) {
-      const int k0 = (it % nk) * BKT;
-#pragma unroll
-      for (int i = 0; i < NBC; ++i) rb[i] = *reinterpret_cast<const uint4*>(Bb + (b_off[i] + (uint32_t)k0 * 2u));
-    };
-    auto prefetch_a = [&](int it, auto par) {
+#ifdef DL3P_SB_ABLATE
+    const int abl = p.stagger;
+#else
+    constexpr int abl = 0;
+#endif
+    auto prefetch = [&](int it, auto par) __attribute__((always_inline)) {
       constexpr int P = decltype(par)::value;
       const int kt = it % nk;
       const int m0 = (blockIdx.x + (it / nk) * gridDim.x) * BM;
       const int k0 = kt * BKT;
+      if (!(abl == 7 && it >= DEPTH)) {
+#pragma unroll
+        for (int i = 0; i < NBC; ++i) rb[P][i] = *reinterpret_cast<const uint4*>(Bb + (b_off[i] + (uint32_t)k0 * 2u));
+      }
+      if (abl == 3 && it >= DEPTH) return;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const uint32_t kb = (uint32_t)min(k0 + ak8 + 4 * h, p.K - 4) * 4u;
@@ -533,18 +563,16 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_sbp_kernel(GemmParams p) {
           const uint32_t rowb = (uint32_t)min(m0 + ar + 64 * i, p.M - 1) * (uint32_t)p.lda * 4u;
           ra[P][i][h] = *reinterpret_cast<const float4*>(Ab + (rowb + kb));
         }
-        if (p.scale) {
-          rsc[P][h] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.scale) + kb);
-          rsh[P][h] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.shift) + kb);
-        }
+        rsc[P][h] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(scp) + kb);
+        rsh[P][h] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(shp) + kb);
       }
     };
     const float act_lo = p.act == DL3P_ACT_NONE ? -DL3P_INF : 0.f;
     const float act_hi = (p.act == DL3P_ACT_NONE || p.act == DL3P_ACT_RELU) ? DL3P_INF : 6.f;
     const bool has_pro = p.scale != nullptr || p.act != DL3P_ACT_NONE;
-    auto stage = [&](int it, auto par) {
+    auto stage = [&](int it, auto par, int slot = 0) __attribute__((always_inline)) {
       constexpr int P = decltype(par)::value;
-      unsigned short* buf = Stage0 + (it & 1) * STAGE;
+      unsigned short* buf = Stage0 + (slot & 1) * STAGE;
       const int kt = it % nk;
       const int m0 = (blockIdx.x + (it / nk) * gridDim.x) * BM;
       const int k0 = kt * BKT;
@@ -557,7 +585,7 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_sbp_kernel(GemmParams p) {
         for (int h = 0; h < 2; ++h) {
           v[h] = ra[P][i][h];
           if (has_pro) {
-            v[h] = fma4(v[h], rsc[P][h], rsh[P][h]);
+            if (p.scale) v[h] = fma4(v[h], rsc[P][h], rsh[P][h]);
             if (p.act >= DL3P_ACT_HSWISH) v[h] = act_apply4(v[h], p.act);
             else v[h] = make_float4(__builtin_amdgcn_fmed3f(v[h].x, act_lo, act_hi), __builtin_amdgcn_fmed3f(v[h].y, act_lo, act_hi),
                                     __builtin_amdgcn_fmed3f(v[h].z, act_lo, act_hi), __builtin_amdgcn_fmed3f(v[h].w, act_lo, act_hi));
@@ -566,7 +594,7 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_sbp_kernel(GemmParams p) {
         }
         uint4 hh, mm, ll;
 #ifdef DL3P_SB_ABLATE
-        if (p.stagger == 1) {
+        if (abl == 1) {
           hh = make_uint4(__builtin_bit_cast(uint32_t, v[0].x), __builtin_bit_cast(uint32_t, v[0].z), __builtin_bit_cast(uint32_t, v[1].x), __builtin_bit_cast(uint32_t, v[1].z));
           mm = make_uint4(__builtin_bit_cast(uint32_t, v[0].y), __builtin_bit_cast(uint32_t, v[0].w), __builtin_bit_cast(uint32_t, v[1].y), __builtin_bit_cast(uint32_t, v[1].w));
           ll = hh;
@@ -578,9 +606,7 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_sbp_kernel(GemmParams p) {
         split2(v[1].x, v[1].y, hh.z, mm.z, ll.z);
         split2(v[1].z, v[1].w, hh.w, mm.w, ll.w);
         }
-#ifdef DL3P_SB_ABLATE
-        if (p.stagger == 6 && it > 1) continue;
-#endif
+        if (abl == 6 && it > 1) continue;
         unsigned short* d = buf + r * PB + ak8;
         *reinterpret_cast<uint4*>(d) = hh;
         *reinterpret_cast<uint4*>(d + A_PLANE) = mm;
@@ -588,49 +614,43 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_sbp_kernel(GemmParams p) {
       }
 #pragma unroll
       for (int i = 0; i < NBC; ++i) {
-        asm volatile("" :: "v"(rb[i].x), "v"(rb[i].y), "v"(rb[i].z), "v"(rb[i].w));
-#ifdef DL3P_SB_ABLATE
-        if (p.stagger == 5 && it > 1) continue;
-#endif
+        asm volatile("" :: "v"(rb[P][i].x), "v"(rb[P][i].y), "v"(rb[P][i].z), "v"(rb[P][i].w));
+        if (abl == 5 && it > 1) continue;
         if (pt + 256 * i < 3 * BN * 4) {
-          uint4 v = rb[i];
+          uint4 v = rb[P][i];
           if (!b_ok[i]) v = make_uint4(0u, 0u, 0u, 0u);
           *reinterpret_cast<uint4*>(buf + b_lds[i]) = v;
         }
       }
     };
     using P0 = std::integral_constant<int, 0>;
-    using P1 = std::integral_constant<int, 1>;
-    if (it_total > 0) { prefetch_b(0); prefetch_a(0, P0{}); }
-    if (it_total > 1) prefetch_a(1, P1{});
+    // every load below is UNCONDITIONAL and the main loop body branch-free (indices clamp at the last K-step; what is staged past
+    // it goes to the buffer nobody reads any more): under `if`, the compiler's s_waitcnt pass cannot count the younger loads in
+    // the queue and each stage() waits with vmcnt(0) -- for the requests just issued, not only for its own
+    const int last = it_total - 1;
     if (it_total > 0) {
+      static_for<DEPTH>([&](auto j) { prefetch(min((int)decltype(j)::value, last), j); });
       stage(0, P0{});
-      if (it_total > 1) prefetch_b(1);
-      if (it_total > 2) prefetch_a(2, P0{});
+      prefetch(min(DEPTH, last), P0{});
     }
     lds_barrier();
-    // iteration i (the multiplying waves work on buffer i & 1): stage K-step i + 1 into the other buffer
-    for (int i = 0; i < it_total; i += 2) {
-#ifdef DL3P_SB_ABLATE
-      const int abl = p.stagger;
-#else
-      constexpr int abl = 0;
-#endif
-      if (i + 1 < it_total) {
-        stage(i + 1, P1{});
-        if (i + 2 < it_total && abl != 7) prefetch_b(i + 2);
-        if (i + 3 < it_total && abl != 3) prefetch_a(i + 3, P1{});
-      }
+    // iteration i (the multiplying waves work on buffer i & 1): stage K-step i + 1 (register set (i + 1) % DEPTH) into the other
+    // buffer and request step i + 1 + DEPTH into the set just consumed; one barrier per iteration, like the multiplying waves
+    auto body = [&](int i, auto par) __attribute__((always_inline)) {
+      stage(min(i + 1, last), par, i + 1);
+      prefetch(min(i + 1 + DEPTH, last), par);
       lds_barrier();
-      if (i + 1 < it_total) {
-        if (i + 2 < it_total) {
-          stage(i + 2, P0{});
-          if (i + 3 < it_total && abl != 7) prefetch_b(i + 3);
-          if (i + 4 < it_total && abl != 3) prefetch_a(i + 4, P0{});
-        }
-        lds_barrier();
-      }
-    }
+    };
+    int i = 0;
+    for (; i + DEPTH <= it_total; i += DEPTH)
+      static_for<DEPTH>([&](auto j) {
+        constexpr int J = decltype(j)::value;
+        body(i + J, std::integral_constant<int, (J + 1) % DEPTH>{});
+      });
+    static_for<DEPTH - 1>([&](auto j) {
+      constexpr int J = decltype(j)::value;
+      if (i + J < it_total) body(i + J, std::integral_constant<int, (J + 1) % DEPTH>{});
+    });
     if (STATS) lds_barrier();       // the statistics reduction's barrier (consumers write `red` in front of it)
     return;
   }

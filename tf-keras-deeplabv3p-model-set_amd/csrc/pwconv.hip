@@ -1031,7 +1031,7 @@ static void gemm_plan_sb(int role, int M, int K, int N, int* nt, int* gx, int* g
   // measured (scripts/micro/sb_gemm.py, profiles/r03_split_gemm.txt): 128-row tiles with the widest column block win on every
   // shape with a few thousand rows or more (the fp32 kernel's 64-row / three-workgroup choice for long GEMMs loses here: two A
   // register sets); with the fused BatchNorm sums 128 x 64, the widest that does not spill.  The one-workgroup-per-CU wide tiles
-  // (sb_wm) are no faster -- the kernel is bound by its staging pipeline, not by operand traffic -- and stay opt-in.
+  // (sb_wm) pay on long forwards onto 256-column layers only (below); elsewhere they tie or lose and stay opt-in.
   if (M >= 4096) force_mi = 2;
   if (role == 3 && N > 64) { *nt = 4; force_mi = 2; }
   int wide_nt = 0, wide_mi = 2, wide_wm = 1;
@@ -1039,6 +1039,10 @@ static void gemm_plan_sb(int role, int M, int K, int N, int* nt, int* gx, int* g
     if (e->pc > 100) { wide_nt = e->nt; wide_mi = e->mi; wide_wm = e->pc - 100; }
     else { wide_nt = 0; *nt = e->nt; force_mi = e->mi; force_pc = e->pc; }
   }
+  // long forwards onto 256-column layers: 128 rows x 256 columns, 512 threads, one workgroup per CU (the A tile is split once for
+  // all of N): 306 against 335 us on 266256 x 304 -> 256, 255 against 278 on K = 256, 98 against 107 on 74498 rows -- since the
+  // operand requests stopped being drained at every stage (pw_split.hip, the note in step()); before that the wide tiles tied
+  if (!wide_nt && role <= 1 && N % 256 == 0 && M >= 65536) { wide_nt = 16; wide_mi = 1; wide_wm = 2; }
   if (g_sb_force_wm > 0) { wide_nt = g_sb_force_nt ? g_sb_force_nt : 16; wide_wm = g_sb_force_wm; wide_mi = g_gemm_force_mi ? g_gemm_force_mi : 2; }
   if (g_sb_force_wm < 0) wide_nt = 0;
   if (wide_nt && dl3p_sb_wide_config(wide_nt, wide_mi, wide_wm) && role != 3) {     // (role 3: the z-prefetch registers of the fused BatchNorm sums do not fit the wide tiles)
