@@ -542,6 +542,17 @@ int dl3p_dwconv2d_bwd_weight_bf16(const void* x, int ldx, const float* in_scale,
 int dl3p_im2col_bf16(const void* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
                      void* col, int ld_col, int N, int H, int W, int Cin, int k, int stride, int rate,
                      int pad_t, int pad_l, int Ho, int Wo, void* stream);
+/* The rest of a dense k x k conv and max pooling under the mixed policy (train.py:37-46 sets it for every model type: Xception's
+ * entry_flow_conv1_2, deeplabv3p_xception.py:107-113; ResNet50's 3x3 convs and pool1, deeplabv3p_resnet50.py:262-267).  bf16 twins
+ * of dl3p_col2im / dl3p_maxpool2d_fwd / dl3p_maxpool2d_bwd: same gather forms, bf16 tensors, fp32 sums, one rounding at the store.
+ * dl3p_maxpool2d_bwd_bf16 needs the winners the forward pass recorded (argmax, [N][Ho][Wo][C] tap indices). */
+int dl3p_col2im_bf16(const void* gcol, int ld_col, void* gx, int ldgx, int accumulate, int N, int H, int W, int Cin,
+                     int k, int stride, int rate, int pad_t, int pad_l, int Ho, int Wo, void* stream);
+int dl3p_maxpool2d_fwd_bf16(const void* x, int ldx, const float* in_scale, const float* in_shift, int in_act, void* y,
+                            int ldy, uint8_t* argmax, int N, int H, int W, int C, int k, int stride, int pad_t,
+                            int pad_l, int Ho, int Wo, void* stream);
+int dl3p_maxpool2d_bwd_bf16(const void* dy, int lddy, const uint8_t* argmax, void* gx, int ldgx, int accumulate, int N,
+                            int H, int W, int C, int k, int stride, int pad_t, int pad_l, int Ho, int Wo, void* stream);
 int dl3p_bn_bwd_reduce_bf16(const void* g, int ldg, const void* z, int ldz, const float* scale, const float* shift,
                             int act, const float* save_mean, const float* save_invstd,
                             float* partials, int* rows_out, int M, int C, void* stream);

@@ -194,17 +194,23 @@ def test_dispatch_options_and_tile_table():
 
 
 def test_mixed_precision_policy_is_checked_when_the_model_is_built():
-    """train.py:37-46 applies the policy to every model type; the bf16 kernels cover the MobileNet families.  A model type
-    whose training graph holds an op without a bf16 kernel is refused by get_deeplabv3p_model -- not at the first train
-    step -- and 'mixed_float16' says that it runs as bf16"""
+    """train.py:37-46 applies the policy to every model type.  A model type whose training graph holds an op without a bf16 kernel
+    is refused by get_deeplabv3p_model -- not at the first train step: the mechanism stays, the list is empty since
+    the dense-conv data gradient and max pooling got their bf16 kernels -- and 'mixed_float16' says that it runs as bf16"""
     import warnings
     pkg = load_pkg()
     mp = pkg.mixed_precision
+    model_mod = load_pkg('model')
     try:
         mp.set_policy(mp.Policy('mixed_bfloat16'))
         for mt in ('xception', 'resnet50'):
+            assert pkg.get_deeplabv3p_model(mt, 21, (65, 65), 16, training=True).bf16
+        model_mod._NO_BF16_TRAINING['mobilenetv2'] = 'test entry'
+        try:
             with pytest.raises(ValueError, match='mixed_bfloat16 training is not built'):
-                pkg.get_deeplabv3p_model(mt, 21, (65, 65), 16, training=True)
+                pkg.get_deeplabv3p_model('mobilenetv2', 21, (65, 65), 16, training=True)
+        finally:
+            del model_mod._NO_BF16_TRAINING['mobilenetv2']
         m = pkg.get_deeplabv3p_model('mobilenetv3large', 19, (64, 96), 16, training=True)
         assert m.bf16
         with warnings.catch_warnings(record=True) as w:

@@ -674,6 +674,120 @@ __global__ __launch_bounds__(256) void transpose_batch_b(const float* src, bf16*
     }
   }
 }
+
+// ---- dense k x k convs and max pooling under the mixed policy (Xception's entry_flow_conv1_2, ResNet50's 3x3 convs and pool1:
+// train.py:37-46 applies the policy to every model type).  Same gather forms as conv.hip / pool.hip, bf16 in HBM, fp32 sums.
+struct Col2imB {
+  const bf16* gcol; int ld_col; bf16* gx; int ldgx; int accumulate;
+  int N, H, W, Cin, Ho, Wo, k, stride, rate, pad_t, pad_l;
+};
+// gx[n, iy, ix, ci] (+)= sum over the taps (ky, kx) and output pixels that read this input pixel of gcol[m][(ky k + kx) Cin + ci]
+__global__ __launch_bounds__(256) void col2im_b(Col2imB p) {
+  const int c4n = p.Cin / 4;
+  const long long total = (long long)p.N * p.H * p.W * c4n;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c4 = (int)(i % c4n);
+    long long pix = i / c4n;
+    const int ix = (int)(pix % p.W);
+    pix /= p.W;
+    const int iy = (int)(pix % p.H);
+    const int n = (int)(pix / p.H);
+    float4 acc = zero4();
+    for (int ky = 0; ky < p.k; ++ky) {
+      const int ty = iy + p.pad_t - ky * p.rate;
+      if (ty < 0 || ty % p.stride) continue;
+      const int oy = ty / p.stride;
+      if (oy >= p.Ho) continue;
+      for (int kx = 0; kx < p.k; ++kx) {
+        const int tx = ix + p.pad_l - kx * p.rate;
+        if (tx < 0 || tx % p.stride) continue;
+        const int ox = tx / p.stride;
+        if (ox >= p.Wo) continue;
+        const size_t m = ((size_t)n * p.Ho + oy) * p.Wo + ox;
+        acc = add4(acc, ld4(p.gcol + m * p.ld_col + (size_t)(ky * p.k + kx) * p.Cin + c4 * 4));
+      }
+    }
+    bf16* o = p.gx + (((size_t)n * p.H + iy) * p.W + ix) * p.ldgx + c4 * 4;
+    if (p.accumulate) acc = add4(acc, ld4(o));
+    st4(o, acc);
+  }
+}
+
+struct MaxPoolB {
+  const bf16* x; int ldx; const float* scale; const float* shift; int act;
+  bf16* y; int ldy;
+  const bf16* dy; int lddy;
+  unsigned char* arg;
+  int accumulate;
+  int N, H, W, C, k, stride, pad_t, pad_l, Ho, Wo;
+  long long total;
+};
+// ZeroPadding2D + MaxPooling2D (deeplabv3p_resnet50.py:266-267), one thread per (output pixel, 4 channels); the input carries its
+// producer's BatchNorm + activation as a prologue, rounded to bf16 like every consumer-side prologue of this path
+__global__ __launch_bounds__(256) void maxpool_fwd_b(MaxPoolB p) {
+  const int c4s = p.C / 4;
+  for (long long s = (long long)blockIdx.x * 256 + threadIdx.x; s < p.total; s += (long long)gridDim.x * 256) {
+    const int c = (int)(s % c4s) * 4;
+    long long r = s / c4s;
+    const int ox = (int)(r % p.Wo); r /= p.Wo;
+    const int oy = (int)(r % p.Ho);
+    const int n = (int)(r / p.Ho);
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero4();
+    if (p.scale) { sc = ld4(p.scale + c); sh = ld4(p.shift + c); }
+    const bf16* img = p.x + (size_t)n * p.H * p.W * p.ldx;
+    float4 m = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+    uchar4 a = make_uchar4(0, 0, 0, 0);
+    for (int ky = 0; ky < p.k; ++ky)
+      for (int kx = 0; kx < p.k; ++kx) {
+        const int iy = oy * p.stride - p.pad_t + ky, ix = ox * p.stride - p.pad_l + kx;
+        float4 v = zero4();                                    // ZeroPadding2D: real zeros that take part in the maximum
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+          v = ld4(img + ((size_t)iy * p.W + ix) * p.ldx + c);
+          if (p.scale || p.act != DL3P_ACT_NONE) v = bf16_round4(act_apply4(p.scale ? fma4(v, sc, sh) : v, p.act));
+        }
+        const unsigned char t = (unsigned char)(ky * p.k + kx);
+        if (v.x > m.x) { m.x = v.x; a.x = t; }             // strict: the first maximum in (ky, kx) order wins
+        if (v.y > m.y) { m.y = v.y; a.y = t; }
+        if (v.z > m.z) { m.z = v.z; a.z = t; }
+        if (v.w > m.w) { m.w = v.w; a.w = t; }
+      }
+    st4(p.y + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.ldy + c, m);
+    if (p.arg) *reinterpret_cast<uchar4*>(p.arg + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.C + c) = a;
+  }
+}
+// gather form: an input pixel collects dy of every window whose recorded winner it is
+__global__ __launch_bounds__(256) void maxpool_bwd_b(MaxPoolB p) {
+  const int c4s = p.C / 4;
+  for (long long s = (long long)blockIdx.x * 256 + threadIdx.x; s < p.total; s += (long long)gridDim.x * 256) {
+    const int c = (int)(s % c4s) * 4;
+    long long r = s / c4s;
+    const int ix = (int)(r % p.W); r /= p.W;
+    const int iy = (int)(r % p.H);
+    const int n = (int)(r / p.H);
+    float4 g = zero4();
+    const int oy_hi = (iy + p.pad_t) / p.stride, ox_hi = (ix + p.pad_l) / p.stride;
+    for (int oy = oy_hi; oy >= 0 && oy * p.stride - p.pad_t + p.k > iy; --oy) {
+      if (oy >= p.Ho) continue;
+      for (int ox = ox_hi; ox >= 0 && ox * p.stride - p.pad_l + p.k > ix; --ox) {
+        if (ox >= p.Wo) continue;
+        const unsigned char t = (unsigned char)((iy - (oy * p.stride - p.pad_t)) * p.k + ix - (ox * p.stride - p.pad_l));
+        const size_t o = ((size_t)n * p.Ho + oy) * p.Wo + ox;
+        const uchar4 a = *reinterpret_cast<const uchar4*>(p.arg + o * p.C + c);
+        const float4 d = ld4(p.dy + o * p.lddy + c);
+        g = make_float4(g.x + (a.x == t ? d.x : 0.f), g.y + (a.y == t ? d.y : 0.f), g.z + (a.z == t ? d.z : 0.f),
+                        g.w + (a.w == t ? d.w : 0.f));
+      }
+    }
+    bf16* o = p.y + (((size_t)n * p.H + iy) * p.W + ix) * p.ldy + c;
+    if (p.accumulate) g = add4(g, ld4(o));
+    st4(o, g);
+  }
+}
+inline unsigned pool_grid_b(long long total) {
+  long long b = (total + 255) / 256;
+  const long long cap = (long long)DL3P_NUM_CUS * 16;
+  return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
+}
 }  // namespace
 
 extern "C" int dl3p_im2col_bf16(const void* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
@@ -689,6 +803,53 @@ extern "C" int dl3p_im2col_bf16(const void* x, int ldx, const float* in_scale, c
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(im2col_b, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
   DL3P_CHECK_LAUNCH("dl3p_im2col_bf16");
+  return DL3P_OK;
+}
+
+extern "C" int dl3p_col2im_bf16(const void* gcol, int ld_col, void* gx, int ldgx, int accumulate, int N, int H, int W, int Cin,
+                                int k, int stride, int rate, int pad_t, int pad_l, int Ho, int Wo, void* stream) {
+  DL3P_CHECK_ARG(gcol && gx && ((uintptr_t)gcol & 7u) == 0 && ((uintptr_t)gx & 7u) == 0 && Cin > 0 && Cin % 4 == 0 && ld_col % 4 == 0 &&
+                 ld_col >= k * k * Cin && ldgx % 4 == 0 && ldgx >= Cin && N > 0 && k >= 1 && stride >= 1 && rate >= 1,
+                 "dl3p_col2im_bf16: bad layout");
+  Col2imB p = {};
+  p.gcol = (const bf16*)gcol; p.ld_col = ld_col; p.gx = (bf16*)gx; p.ldgx = ldgx; p.accumulate = accumulate;
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.k = k; p.stride = stride; p.rate = rate;
+  p.pad_t = pad_t; p.pad_l = pad_l;
+  long long blocks = ceil_div_ll((long long)N * H * W * (Cin / 4), 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(col2im_b, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  DL3P_CHECK_LAUNCH("dl3p_col2im_bf16");
+  return DL3P_OK;
+}
+
+extern "C" int dl3p_maxpool2d_fwd_bf16(const void* x, int ldx, const float* in_scale, const float* in_shift, int in_act, void* y,
+                                       int ldy, uint8_t* argmax, int N, int H, int W, int C, int k, int stride, int pad_t,
+                                       int pad_l, int Ho, int Wo, void* stream) {
+  DL3P_CHECK_ARG(x && y && ((uintptr_t)x & 7u) == 0 && ((uintptr_t)y & 7u) == 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldx >= C &&
+                 ldy % 4 == 0 && ldy >= C && N > 0 && k >= 1 && k <= 15 && stride >= 1 && Ho > 0 && Wo > 0,
+                 "dl3p_maxpool2d_fwd_bf16: bad arguments");
+  DL3P_CHECK_ARG(!argmax || (uintptr_t)argmax % 4 == 0, "dl3p_maxpool2d_fwd_bf16: argmax must be 4-byte aligned");
+  MaxPoolB p = {};
+  p.x = (const bf16*)x; p.ldx = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act; p.y = (bf16*)y; p.ldy = ldy;
+  p.arg = argmax; p.N = N; p.H = H; p.W = W; p.C = C; p.k = k; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
+  p.Ho = Ho; p.Wo = Wo; p.total = (long long)N * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool_fwd_b, dim3(pool_grid_b(p.total)), dim3(256), 0, (hipStream_t)stream, p);
+  DL3P_CHECK_LAUNCH("dl3p_maxpool2d_fwd_bf16");
+  return DL3P_OK;
+}
+
+extern "C" int dl3p_maxpool2d_bwd_bf16(const void* dy, int lddy, const uint8_t* argmax, void* gx, int ldgx, int accumulate, int N,
+                                       int H, int W, int C, int k, int stride, int pad_t, int pad_l, int Ho, int Wo,
+                                       void* stream) {
+  DL3P_CHECK_ARG(dy && gx && argmax && ((uintptr_t)dy & 7u) == 0 && ((uintptr_t)gx & 7u) == 0 && (uintptr_t)argmax % 4 == 0 && C > 0 &&
+                 C % 4 == 0 && lddy % 4 == 0 && lddy >= C && ldgx % 4 == 0 && ldgx >= C && N > 0 && k >= 1 && stride >= 1 &&
+                 Ho > 0 && Wo > 0, "dl3p_maxpool2d_bwd_bf16: bad arguments (the recorded winners of the forward pass are required)");
+  MaxPoolB p = {};
+  p.dy = (const bf16*)dy; p.lddy = lddy; p.arg = const_cast<uint8_t*>(argmax); p.y = (bf16*)gx; p.ldy = ldgx;
+  p.accumulate = accumulate; p.N = N; p.H = H; p.W = W; p.C = C; p.k = k; p.stride = stride; p.pad_t = pad_t;
+  p.pad_l = pad_l; p.Ho = Ho; p.Wo = Wo; p.total = (long long)N * H * W * (C / 4);
+  hipLaunchKernelGGL(maxpool_bwd_b, dim3(pool_grid_b(p.total)), dim3(256), 0, (hipStream_t)stream, p);
+  DL3P_CHECK_LAUNCH("dl3p_maxpool2d_bwd_bf16");
   return DL3P_OK;
 }
 

@@ -670,14 +670,13 @@ class Executor:
                 P.k(L.global_avgpool_fwd_bf16 if self.bf16 else L.global_avgpool_fwd, xp, ldx, sp, hp, act, self.tptr(op.out),
                     op.out.ld, 1.0, N, xt.H * xt.W, xt.C, self.pool_ws.data_ptr(), self.pool_wsb)
             elif k == 'maxpool':
-                if self.bf16:
-                    raise NotImplementedError('max pooling (ResNet50) is not built for the bf16 path')
                 xp, ldx, sp, hp, act = self.vargs(op.x)
                 xt, t = op.x.tensor, op.out
                 arg = None
                 if train:          # the backward pass reads the winning taps instead of re-evaluating the windows
                     arg = self._pool_arg[op] = torch.empty(N * op.Ho * op.Wo * xt.C, dtype=torch.uint8, device=self.dev)
-                P.k(L.maxpool2d_fwd, xp, ldx, sp, hp, act, self.tptr(t), t.ld, None if arg is None else arg.data_ptr(), N,
+                P.k(L.maxpool2d_fwd_bf16 if self.bf16 else L.maxpool2d_fwd, xp, ldx, sp, hp, act, self.tptr(t), t.ld,
+                    None if arg is None else arg.data_ptr(), N,
                     xt.H, xt.W, xt.C, op.k, op.stride, op.pad_t, op.pad_l, op.Ho, op.Wo)
             elif k == 'se_mul':
                 xp, ldx, sp, hp, act = self.vargs(op.x)
@@ -1109,8 +1108,12 @@ class Executor:
                 xp, ldx, sp, hp, act = self.vargs(op.x)
                 xt = op.x.tensor
                 gp, ldg, keyt = self._gbuf(op.x)
-                P.k(L.maxpool2d_bwd, xp, ldx, sp, hp, act, self.tptr(out, True), out.ld, self._pool_arg[op].data_ptr(), gp,
-                    ldg, self._acc(keyt), N, xt.H, xt.W, xt.C, op.k, op.stride, op.pad_t, op.pad_l, op.Ho, op.Wo)
+                if self.bf16:
+                    P.k(L.maxpool2d_bwd_bf16, self.tptr(out, True), out.ld, self._pool_arg[op].data_ptr(), gp, ldg, self._acc(keyt),
+                        N, xt.H, xt.W, xt.C, op.k, op.stride, op.pad_t, op.pad_l, op.Ho, op.Wo)
+                else:
+                    P.k(L.maxpool2d_bwd, xp, ldx, sp, hp, act, self.tptr(out, True), out.ld, self._pool_arg[op].data_ptr(), gp,
+                        ldg, self._acc(keyt), N, xt.H, xt.W, xt.C, op.k, op.stride, op.pad_t, op.pad_l, op.Ho, op.Wo)
             elif k == 'gap':
                 xt = op.x.tensor
                 gp, ldg, keyt = self._gbuf(op.x)
@@ -1200,7 +1203,12 @@ class Executor:
             P.k(L.dwconv2d_bwd_data_bf16, dz, lddz, st.ptr(op.w, st.Pb), gp, ldg, acc, N, xt.H, xt.W, op.c, op.k, op.stride,
                 op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
         else:
-            raise NotImplementedError('data gradient of a dense k x k conv is not built for the bf16 path (only RGB stems)')
+            # dense k x k conv (Xception's entry_flow_conv1_2, ResNet50's 3x3 convs): d/d(im2col matrix) by the GEMM, then the
+            # transposed gather back onto the input pixels -- the route of the forward (im2col_bf16 + GEMM), mirrored
+            P.k(L.pwconv_bwd_data_bf16, dz, lddz, dzf, st.ptr(op.w, st.Pb), self.tptr(op.col, True), op.col.ld, 0, M, op.kp,
+                op.cout)
+            P.k(L.col2im_bf16, self.tptr(op.col, True), op.col.ld, gp, ldg, acc, N, xt.H, xt.W, op.cin, op.k, op.stride, op.rate,
+                op.pad_t, op.pad_l, op.Ho, op.Wo)
 
     def _use_sb(self, op, fwd, stats):
         """does this pointwise conv run on the split-bf16 GEMM (forward / data-gradient role)?  Only where the tiled kernel

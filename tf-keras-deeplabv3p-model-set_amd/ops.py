@@ -880,3 +880,36 @@ def pwconv_bwd_data_sb(dy, w_sp, N, out=None, accumulate=False, z=None, scale=No
     lib().pwconv_bwd_data_sb(dp, ldd, _p(w_sp), pitch, gp, ldg, int(accumulate), M, K, N, zp, ldz or 0, _p(scale), _p(shift), act,
                              _p(mean), _p(invstd), _p(partials), ctypes.byref(rows), _stream())
     return (gx, rows.value) if z is not None else gx
+
+
+def col2im_bf16(gcol, x_shape, k, stride=1, rate=1, padding='same', out=None, accumulate=False):
+    """bf16 twin of col2im: gcol (N,Ho,Wo,kp) bf16 -> gx (N,H,W,Cin) bf16"""
+    N, H, W, Cin = x_shape
+    Ho, Wo, pt, pl = conv_geometry(H, W, k, stride, rate, padding)
+    gx = out if out is not None else torch.empty(x_shape, dtype=torch.bfloat16, device=gcol.device)
+    gp, ldg, _ = _plb(gx)
+    lib().col2im_bf16(_p(gcol), gcol.shape[-1], gp, ldg, int(accumulate), N, H, W, Cin, k, stride, rate, pt, pl, Ho, Wo, _stream())
+    return gx
+
+
+def maxpool2d_fwd_bf16(x, k, stride, pad, in_scale=None, in_shift=None, in_act=ACT_NONE, argmax=None):
+    N, H, W, C = x.shape
+    pt, pb, pl, pr = pad
+    Ho, Wo = (H + pt + pb - k) // stride + 1, (W + pl + pr - k) // stride + 1
+    y = torch.empty((N, Ho, Wo, C), dtype=torch.bfloat16, device=x.device)
+    xp, ldx, _ = _plb(x)
+    yp, ldy, _ = _plb(y)
+    lib().maxpool2d_fwd_bf16(xp, ldx, _p(in_scale), _p(in_shift), in_act, yp, ldy, _p(argmax), N, H, W, C, k, stride, pt, pl, Ho,
+                             Wo, _stream())
+    return y
+
+
+def maxpool2d_bwd_bf16(dy, argmax, x_shape, k, stride, pad, out=None, accumulate=False):
+    N, H, W, C = x_shape
+    pt, pb, pl, pr = pad
+    Ho, Wo = dy.shape[1], dy.shape[2]
+    gx = out if out is not None else torch.empty(x_shape, dtype=torch.bfloat16, device=dy.device)
+    dp, ldd, _ = _plb(dy)
+    gp, ldg, _ = _plb(gx)
+    lib().maxpool2d_bwd_bf16(dp, ldd, _p(argmax), gp, ldg, int(accumulate), N, H, W, C, k, stride, pt, pl, Ho, Wo, _stream())
+    return gx
