@@ -3,7 +3,8 @@ minimal reverse-mode tape (forward, backward, SGD step).
 
 TEST INFRASTRUCTURE ONLY (see oracle/np_ops.py header).  PARITY UNPINNED (TensorFlow not
 importable).  Graph topology IS pinned: parameter counts are checked against the
-reference's README.md:312-317 table in tests/test_oracle_topology.py.
+reference's README.md:312-317 table in tests/test_oracle_topology.py, and the MobileNetV2 body + ASPP-Lite head agree layer by
+layer with an unrelated third implementation (HuggingFace transformers' TF-slim ports, tests/test_oracle_vs_transformers.py).
 
 Each builder cites the reference function it follows.  Parameter names follow the Keras layer
 names of the reference so that weights can be exchanged by name with the HIP implementation:

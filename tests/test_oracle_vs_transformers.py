@@ -1,0 +1,130 @@
+"""A THIRD implementation for the oracle's MobileNetV2 body (TensorFlow cannot be installed here and the reference holds
+no arithmetic vectors, so the oracle is pinned by triangulation): HuggingFace `transformers`' MobileNetV2 -- a PyTorch port of the
+TF-slim network that HF validates against Google's checkpoints, written by other people from other sources -- is in the image.
+With the SAME weights, inference-mode BatchNorm and `tf_padding=True` (TensorFlow's 'SAME' padding, asymmetric on stride 2), its
+conv outputs must equal what oracle/np_net.py's restatement of deeplabv3p_mobilenetv2.py:38-199 computes, layer by layer, at
+output strides 16 and 8 (the atrous schedule of blocks 6 / 13 on) -- stem conv, depthwise convs, 1x1 convs, BatchNorm (eps 1e-3),
+ReLU6, residual adds, block order, channel rounding (make_divisible).  Not the reference itself -- parity stays "unpinned" in the
+sense of SURVEY 8c -- but a restatement error in the backbone would have to be made identically by an unrelated code base."""
+import numpy as np
+import pytest
+
+transformers = pytest.importorskip('transformers')
+torch = pytest.importorskip('torch')
+
+
+def _load(hf, net):
+    """oracle parameters (HWIO kernels, Keras BatchNorm names) -> the HF module tree"""
+    sd = hf.state_dict()
+
+    def conv(dst, name, depthwise=False):
+        w = net.params[name + ('/depthwise_kernel' if depthwise else '/kernel')]
+        # HWIO (k, k, cin, cout) -> OIHW; depthwise (k, k, C, 1) -> (C, 1, k, k)
+        t = np.transpose(w, (2, 3, 0, 1)) if depthwise else np.transpose(w, (3, 2, 0, 1))
+        assert tuple(sd[dst + '.convolution.weight'].shape) == t.shape, (dst, t.shape)
+        sd[dst + '.convolution.weight'] = torch.from_numpy(np.ascontiguousarray(t)).double()
+
+    def bn(dst, name):
+        for a, b in (('weight', 'gamma'), ('bias', 'beta'), ('running_mean', 'moving_mean'), ('running_var', 'moving_variance')):
+            sd[dst + '.normalization.' + a] = torch.from_numpy(net.params[name + '/' + b].copy()).double()
+    conv('conv_stem.first_conv', 'Conv'); bn('conv_stem.first_conv', 'Conv_BN')
+    conv('conv_stem.conv_3x3', 'expanded_conv_depthwise', True); bn('conv_stem.conv_3x3', 'expanded_conv_depthwise_BN')
+    conv('conv_stem.reduce_1x1', 'expanded_conv_project'); bn('conv_stem.reduce_1x1', 'expanded_conv_project_BN')
+    for i in range(16):
+        p = 'expanded_conv_%d_' % (i + 1)
+        conv('layer.%d.expand_1x1' % i, p + 'expand'); bn('layer.%d.expand_1x1' % i, p + 'expand_BN')
+        conv('layer.%d.conv_3x3' % i, p + 'depthwise', True); bn('layer.%d.conv_3x3' % i, p + 'depthwise_BN')
+        conv('layer.%d.reduce_1x1' % i, p + 'project'); bn('layer.%d.reduce_1x1' % i, p + 'project_BN')
+    hf.load_state_dict(sd)
+
+
+@pytest.mark.parametrize('OS,size', [(16, 65), (16, 97), (8, 65)])
+def test_mobilenetv2_body_equals_the_transformers_port(OS, size):
+    from oracle.np_net import OracleModel
+    o = OracleModel('mobilenetv2', 21, (size, size), OS, dtype=np.float64, seed=3)
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-1, 1, (2, size, size, 3))
+    o.predict(x)                                   # creates every parameter
+    for k, v in o.net.params.items():
+        if k.endswith('/gamma'):
+            v[...] = rng.uniform(0.5, 1.5, v.shape)
+        elif k.endswith('/beta') or k.endswith('/moving_mean'):
+            v[...] = rng.standard_normal(v.shape) * 0.2
+        elif k.endswith('/moving_variance'):
+            v[...] = rng.uniform(0.5, 2.0, v.shape)
+    o.net.record = {}
+    o.predict(x)
+    rec = o.net.record
+    cfg = transformers.MobileNetV2Config(output_stride=OS, tf_padding=True, finegrained_output=True, depth_multiplier=1.0,
+                                         hidden_act='relu6', layer_norm_eps=1e-3)
+    hf = transformers.MobileNetV2Model(cfg, add_pooling_layer=False).double().eval()
+    _load(hf, o.net)
+    got = {}
+    taps = {'conv_stem.first_conv': 'Conv', 'conv_stem.conv_3x3': 'expanded_conv_depthwise', 'conv_stem.reduce_1x1': 'expanded_conv_project'}
+    for i in range(16):
+        p = 'expanded_conv_%d_' % (i + 1)
+        taps['layer.%d.expand_1x1' % i] = p + 'expand'
+        taps['layer.%d.conv_3x3' % i] = p + 'depthwise'
+        taps['layer.%d.reduce_1x1' % i] = p + 'project'
+    mods = dict(hf.named_modules())
+    hooks = [mods[k + '.convolution'].register_forward_hook(lambda m, a, out, name=v: got.__setitem__(name, out.detach().numpy()))
+             for k, v in taps.items()]
+    with torch.no_grad():
+        hf(torch.from_numpy(np.transpose(x, (0, 3, 1, 2)).copy()))
+    for h in hooks:
+        h.remove()
+    assert set(got) == set(taps.values())
+    for name in taps.values():
+        ref = np.transpose(got[name], (0, 2, 3, 1))
+        mine = rec[name]
+        assert mine.shape == ref.shape, (name, mine.shape, ref.shape)
+        err = float(np.abs(mine - ref).max()) / max(1e-30, float(np.abs(ref).max()))
+        assert err < 1e-10, (name, err)
+    # (the output stride really is what was asked for: 65 -> 5 at OS 16, 9 at OS 8)
+    last = rec['expanded_conv_16_project']
+    assert last.shape[1] == (size + OS - 1) // OS and last.shape[-1] == 320
+
+
+@pytest.mark.parametrize('OS,size,classes', [(16, 65, 21), (8, 97, 19)])
+def test_mobilenetv2_lite_logits_equal_the_transformers_deeplab_head(OS, size, classes):
+    """the BASELINE configs[0] model (MobileNetV2 + ASPP_Lite_block, layers.py:166-196, + the conv_upsample logits conv,
+    model.py:75-79) against transformers' MobileNetV2ForSemanticSegmentation: the image-pooling branch, the 1x1 branch, the concat
+    ORDER ([pooled, 1x1]), the projection and the classifier -- same weights, inference mode, logits at the backbone's resolution"""
+    from oracle.np_net import OracleModel
+    o = OracleModel('mobilenetv2_lite', classes, (size, size), OS, dtype=np.float64, seed=5)
+    rng = np.random.default_rng(13)
+    x = rng.uniform(-1, 1, (2, size, size, 3))
+    o.predict(x)
+    for k, v in o.net.params.items():
+        if k.endswith('/gamma'):
+            v[...] = rng.uniform(0.5, 1.5, v.shape)
+        elif k.endswith('/beta') or k.endswith('/moving_mean') or k.endswith('/bias'):
+            v[...] = rng.standard_normal(v.shape) * 0.2
+        elif k.endswith('/moving_variance'):
+            v[...] = rng.uniform(0.5, 2.0, v.shape)
+    o.net.record = {}
+    o.predict(x)
+    cfg = transformers.MobileNetV2Config(output_stride=OS, tf_padding=True, finegrained_output=True, depth_multiplier=1.0,
+                                         hidden_act='relu6', layer_norm_eps=1e-3, num_labels=classes)
+    hf = transformers.MobileNetV2ForSemanticSegmentation(cfg).double().eval()
+    _load(hf.mobilenet_v2, o.net)
+    sd = hf.state_dict()
+    P = o.net.params
+
+    def put(dst, name, bn_name=None):
+        sd[dst + '.convolution.weight'] = torch.from_numpy(np.ascontiguousarray(np.transpose(P[name + '/kernel'], (3, 2, 0, 1)))).double()
+        if bn_name:
+            for a, b in (('weight', 'gamma'), ('bias', 'beta'), ('running_mean', 'moving_mean'), ('running_var', 'moving_variance')):
+                sd[dst + '.normalization.' + a] = torch.from_numpy(P[bn_name + '/' + b].copy()).double()
+    put('segmentation_head.conv_pool', 'image_pooling', 'image_pooling_BN')
+    put('segmentation_head.conv_aspp', 'aspp0', 'aspp0_BN')
+    put('segmentation_head.conv_projection', 'concat_projection', 'concat_projection_BN')
+    put('segmentation_head.classifier', 'conv_upsample')
+    sd['segmentation_head.classifier.convolution.bias'] = torch.from_numpy(P['conv_upsample/bias'].copy()).double()
+    hf.load_state_dict(sd)
+    with torch.no_grad():
+        logits = hf(torch.from_numpy(np.transpose(x, (0, 3, 1, 2)).copy())).logits.numpy()
+    ref = np.transpose(logits, (0, 2, 3, 1))
+    mine = o.net.record['conv_upsample'][..., :classes]
+    assert mine.shape == ref.shape, (mine.shape, ref.shape)
+    assert float(np.abs(mine - ref).max()) < 1e-10 * max(1.0, float(np.abs(ref).max()))
