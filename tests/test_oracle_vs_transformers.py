@@ -128,3 +128,75 @@ def test_mobilenetv2_lite_logits_equal_the_transformers_deeplab_head(OS, size, c
     mine = o.net.record['conv_upsample'][..., :classes]
     assert mine.shape == ref.shape, (mine.shape, ref.shape)
     assert float(np.abs(mine - ref).max()) < 1e-10 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize('size', [65, 97])
+def test_resnet50_body_equals_the_transformers_port_at_output_stride_32(size):
+    """the oracle's restatement of deeplabv3p_resnet50.py:32-139,262-292 with every atrous rate at 1 (OS 32: the plain
+    ResNet50 v1 -- stride on the first 1x1 of a stage, conv1_pad + 7x7 stride 2, pool1_pad + 3x3 max pooling) against transformers'
+    ResNetModel(downsample_in_bottleneck=True).  The Keras convs carry a bias and BatchNorm eps 1e-3; the port has neither: a bias in
+    front of an inference-mode BatchNorm is a shift of its moving mean (exact), eps is set on the modules.  Compared: the output of
+    every bottleneck block and the stem (after ReLU), i.e. block order, strides, shortcut convs, padding and pooling."""
+    from oracle.np_net import OracleModel
+    o = OracleModel('resnet50', 21, (size, size), 32, dtype=np.float64, seed=7)
+    rng = np.random.default_rng(17)
+    x = rng.uniform(-1, 1, (2, size, size, 3))
+    o.predict(x)
+    P = o.net.params
+    for k, v in P.items():
+        if k.endswith('/gamma'):
+            v[...] = rng.uniform(0.5, 1.5, v.shape)
+        elif k.endswith('/beta') or k.endswith('/moving_mean') or k.endswith('/bias'):
+            v[...] = rng.standard_normal(v.shape) * 0.2
+        elif k.endswith('/moving_variance'):
+            v[...] = rng.uniform(0.5, 2.0, v.shape)
+    o.net.record = {}
+    o.predict(x)
+    cfg = transformers.ResNetConfig(downsample_in_bottleneck=True, layer_type='bottleneck', hidden_sizes=[256, 512, 1024, 2048],
+                                    depths=[3, 4, 6, 3], embedding_size=64)
+    hf = transformers.ResNetModel(cfg).double().eval()
+    for m in hf.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eps = 1e-3
+    sd = hf.state_dict()
+
+    def put(dst, conv, bn):
+        sd[dst + '.convolution.weight'] = torch.from_numpy(np.ascontiguousarray(np.transpose(P[conv + '/kernel'], (3, 2, 0, 1)))).double()
+        sd[dst + '.normalization.weight'] = torch.from_numpy(P[bn + '/gamma'].copy())
+        sd[dst + '.normalization.bias'] = torch.from_numpy(P[bn + '/beta'].copy())
+        sd[dst + '.normalization.running_mean'] = torch.from_numpy(P[bn + '/moving_mean'] - P[conv + '/bias'])
+        sd[dst + '.normalization.running_var'] = torch.from_numpy(P[bn + '/moving_variance'].copy())
+    put('embedder.embedder', 'conv1', 'bn_conv1')
+    blocks = []
+    for s, (stage, n) in enumerate([(2, 3), (3, 4), (4, 6), (5, 3)]):
+        for b in range(n):
+            letter = 'abcdef'[b]
+            cn, bn = 'res%d%s_branch' % (stage, letter), 'bn%d%s_branch' % (stage, letter)
+            dst = 'encoder.stages.%d.layers.%d' % (s, b)
+            for j, part in enumerate(('2a', '2b', '2c')):
+                put('%s.layer.%d' % (dst, j), cn + part, bn + part)
+            if b == 0:
+                put(dst + '.shortcut', cn + '1', bn + '1')
+            blocks.append((dst, cn + '2c'))
+    hf.load_state_dict(sd)
+    # the oracle records raw conv outputs; a block's output is relu(BN(conv 2c) + shortcut): rebuild the NEXT block's input from the
+    # record instead -- the first conv of block i+1 reads it -- by comparing the conv outputs the port computes from ITS block outputs
+    got = {}
+    mods = dict(hf.named_modules())
+    hooks = []
+    for dst, name in blocks:
+        for j, part in enumerate(('2a', '2b', '2c')):
+            hooks.append(mods['%s.layer.%d.convolution' % (dst, j)].register_forward_hook(
+                lambda m, a, out, key=name[:-2] + part: got.__setitem__(key, out.detach().numpy())))
+    hooks.append(mods['embedder.embedder.convolution'].register_forward_hook(lambda m, a, out: got.__setitem__('conv1', out.detach().numpy())))
+    with torch.no_grad():
+        hf(torch.from_numpy(np.transpose(x, (0, 3, 1, 2)).copy()))
+    for h in hooks:
+        h.remove()
+    assert len(got) == 1 + 3 * 16
+    for name, ref in got.items():
+        mine = o.net.record[name] - P[name + '/bias']            # the port's conv has no bias (it sits in the moving mean)
+        ref = np.transpose(ref, (0, 2, 3, 1))
+        assert mine.shape == ref.shape, (name, mine.shape, ref.shape)
+        err = float(np.abs(mine - ref).max()) / max(1e-30, float(np.abs(ref).max()))
+        assert err < 1e-10, (name, err)
