@@ -56,6 +56,13 @@ def parse():
     return ap.parse_args()
 
 
+def head_name(model_type, OS):
+    """what sits on the backbone: ASPP_block + Decoder_block (layers.py:114-219) or ASPP_Lite_block (:166-196) for the *_lite types"""
+    if model_type.endswith('_lite'):
+        return 'ASPP-Lite (image pooling + 1x1), no decoder'
+    return 'ASPP(%s) + decoder' % {8: '12/24/36', 16: '6/12/18', 32: '3/6/9'}[OS]
+
+
 def cpu_baseline(args):
     """the CPU stand-in for the reference's tf.keras train.py (which cannot be installed here):
     the same graph (configs[0]: mobilenetv2_lite, 513x513, batch 2, fwd + CE(ignore 255) + L2 + bwd + SGD momentum,
@@ -201,8 +208,8 @@ def other_config(pkg, tag, model_type, C, H, W, OS, N, dtype, steps=20, warmup=5
     algo = 2.0 * N * t.H * t.W * op.c * es + op.k * op.k * op.c * es
     us = probe.mean_ms() * 1e3
     out = {'config': tag,
-           'workload': '%s + ASPP(%s) + decoder, OS=%d, %dx%d, %d classes, per-GPU batch %d, fwd+loss+bwd+SGD' % (
-               model_type, {8: '12/24/36', 16: '6/12/18'}[OS], OS, H, W, C, N),
+           'workload': '%s + %s, OS=%d, %dx%d, %d classes, per-GPU batch %d, fwd+loss+bwd+SGD' % (
+               model_type, head_name(model_type, OS), OS, H, W, C, N),
            'dtype': dtype, 'steps': steps, 'warmup': warmup, 'ms_per_step': round(1000 * dt / steps, 3),
            'images_per_sec': round(N * steps / dt, 2), 'final_loss': round(loss, 5),
            'launches_per_step': ex.fwd.n_launches + ex.bwd.n_launches + ex.opt.n_launches,
@@ -349,9 +356,9 @@ def main():
             'value': round(N * world * args.steps / dt, 2), 'unit': 'images/sec', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000 * dt / args.steps, 3),
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': '%s + ASPP(%s) + decoder, OS=%d, %dx%d, %d classes, per-GPU batch %d, '
+            'config': {'workload': '%s + %s, OS=%d, %dx%d, %d classes, per-GPU batch %d, '
                                    'fwd+loss+bwd+SGD(momentum 0.9, l2 2e-5), BN training mode, dropout 0.5'
-                                   % (args.model, {8: '12/24/36', 16: '6/12/18', 32: '3/6/9'}[args.os], args.os, H, W, C, N),
+                                   % (args.model, head_name(args.model, args.os), args.os, H, W, C, N),
                        'global_batch': N * world,
                        'parallelism': 'dp%d%s' % (world, '+syncbn' if (world > 1 and not args.no_sync_bn) else ''),
                        'hip_graph': bool(model.use_graphs), 'final_loss': round(loss, 5),
