@@ -200,3 +200,86 @@ def test_resnet50_body_equals_the_transformers_port_at_output_stride_32(size):
         assert mine.shape == ref.shape, (name, mine.shape, ref.shape)
         err = float(np.abs(mine - ref).max()) / max(1e-30, float(np.abs(ref).max()))
         assert err < 1e-10, (name, err)
+
+
+def test_mobilenetv2_lite_training_gradients_equal_the_transformers_port():
+    """the TRAINING path of the configs[0] model against the same third party: BatchNorm on batch statistics forward AND backward,
+    ReLU6 / ReLU derivatives, depthwise / 1x1 / strided 3x3 data and weight gradients, the residual adds, global average pooling and
+    its broadcast back -- torch autograd through transformers' modules on one side, the oracle's hand-written tape on the other.
+    Both get the same weights, the same batch and the same gradient at the logits conv (Net.force_grad); every one of the 158
+    trainable tensors' gradients must agree (fp64, 1e-7 of the tensor's scale: BatchNorm backward is a difference of sums)."""
+    from oracle.np_net import OracleModel
+    size, classes, OS, N = 65, 21, 16, 3
+    o = OracleModel('mobilenetv2_lite', classes, (size, size), OS, dtype=np.float64, seed=9)
+    rng = np.random.default_rng(23)
+    x = rng.uniform(-1, 1, (N, size, size, 3))
+    o.predict(x)
+    P = o.net.params
+    for k, v in P.items():
+        if k.endswith('/gamma'):
+            v[...] = rng.uniform(0.5, 1.5, v.shape)
+        elif k.endswith('/beta') or k.endswith('/bias'):
+            v[...] = rng.standard_normal(v.shape) * 0.2
+    cfg = transformers.MobileNetV2Config(output_stride=OS, tf_padding=True, finegrained_output=True, depth_multiplier=1.0,
+                                         hidden_act='relu6', layer_norm_eps=1e-3, num_labels=classes, classifier_dropout_prob=0.0)
+    hf = transformers.MobileNetV2ForSemanticSegmentation(cfg).double()
+    _load(hf.mobilenet_v2, o.net)
+    sd = hf.state_dict()
+
+    def put(dst, name, bn_name=None):
+        sd[dst + '.convolution.weight'] = torch.from_numpy(np.ascontiguousarray(np.transpose(P[name + '/kernel'], (3, 2, 0, 1)))).double()
+        if bn_name:
+            sd[dst + '.normalization.weight'] = torch.from_numpy(P[bn_name + '/gamma'].copy())
+            sd[dst + '.normalization.bias'] = torch.from_numpy(P[bn_name + '/beta'].copy())
+    put('segmentation_head.conv_pool', 'image_pooling', 'image_pooling_BN')
+    put('segmentation_head.conv_aspp', 'aspp0', 'aspp0_BN')
+    put('segmentation_head.conv_projection', 'concat_projection', 'concat_projection_BN')
+    put('segmentation_head.classifier', 'conv_upsample')
+    sd['segmentation_head.classifier.convolution.bias'] = torch.from_numpy(P['conv_upsample/bias'].copy())
+    hf.load_state_dict(sd)
+    hf.train()                                        # BatchNorm on batch statistics (the head's dropout has p = 0)
+    logits = hf(torch.from_numpy(np.transpose(x, (0, 3, 1, 2)).copy())).logits
+    R = rng.standard_normal(tuple(logits.shape))      # d objective / d logits, NCHW
+    (logits * torch.from_numpy(R)).sum().backward()
+    # the oracle: same batch, no dropout mask (identity), the backward continued at the logits conv with R
+    labels = rng.integers(0, classes, (N, size * size, 1)).astype(np.float64)
+    cpad = o.net.params['conv_upsample/kernel'].shape[-1]
+    Rn = np.zeros(tuple(np.transpose(R, (0, 2, 3, 1)).shape[:3]) + (cpad,))
+    Rn[..., :classes] = np.transpose(R, (0, 2, 3, 1))
+    o.net.force_grad = {'conv_upsample': Rn}
+    o.net.record = {}
+    o.loss_and_grads(x, labels)
+    assert float(np.abs(o.net.record['conv_upsample'][..., :classes] - np.transpose(logits.detach().numpy(), (0, 2, 3, 1))).max()) < 1e-9
+    grads = o.net.grads
+    named = dict(hf.named_parameters())
+    pairs = [('mobilenet_v2.conv_stem.first_conv', 'Conv', 'Conv_BN', False), ('mobilenet_v2.conv_stem.conv_3x3', 'expanded_conv_depthwise', 'expanded_conv_depthwise_BN', True),
+             ('mobilenet_v2.conv_stem.reduce_1x1', 'expanded_conv_project', 'expanded_conv_project_BN', False)]
+    for i in range(16):
+        p = 'expanded_conv_%d_' % (i + 1)
+        pairs += [('mobilenet_v2.layer.%d.expand_1x1' % i, p + 'expand', p + 'expand_BN', False),
+                  ('mobilenet_v2.layer.%d.conv_3x3' % i, p + 'depthwise', p + 'depthwise_BN', True),
+                  ('mobilenet_v2.layer.%d.reduce_1x1' % i, p + 'project', p + 'project_BN', False)]
+    pairs += [('segmentation_head.conv_pool', 'image_pooling', 'image_pooling_BN', False), ('segmentation_head.conv_aspp', 'aspp0', 'aspp0_BN', False),
+              ('segmentation_head.conv_projection', 'concat_projection', 'concat_projection_BN', False),
+              ('segmentation_head.classifier', 'conv_upsample', None, False)]
+    checked = 0
+    for dst, conv, bn, dw in pairs:
+        gw = named[dst + '.convolution.weight'].grad.numpy()
+        mine = grads[conv + ('/depthwise_kernel' if dw else '/kernel')]
+        ref = np.transpose(gw, (2, 3, 0, 1)) if dw else np.transpose(gw, (2, 3, 1, 0))
+        if conv == 'conv_upsample':
+            mine = mine[..., :classes]
+        todo = [(conv + ' kernel', mine, ref)]
+        if bn:
+            todo += [(bn + ' gamma', grads[bn + '/gamma'], named[dst + '.normalization.weight'].grad.numpy()),
+                     (bn + ' beta', grads[bn + '/beta'], named[dst + '.normalization.bias'].grad.numpy())]
+        else:
+            todo += [(conv + ' bias', grads[conv + '/bias'][:classes], named[dst + '.convolution.bias'].grad.numpy())]
+        for what, a, b in todo:
+            assert a.shape == b.shape, (what, a.shape, b.shape)
+            scale = max(float(np.abs(b).max()), 1e-12)
+            # (+ 1e-10 absolute: a beta in front of a conv + BatchNorm pair has an exactly zero gradient -- the next BatchNorm
+            # removes the shift -- and both sides then hold 1e-12 of summation noise around it)
+            assert float(np.abs(a - b).max()) < 1e-7 * scale + 1e-10, (what, float(np.abs(a - b).max()), scale)
+            checked += 1
+    assert checked == 3 * 55 - 1        # 54 conv + BatchNorm triples and the classifier's (kernel, bias)
