@@ -42,7 +42,10 @@ def lib_time(fn, reps=20):
 
 _w = torch.randn(65536, 256, device=dev)
 lib_time(lambda: ops.pwconv_fwd_wt(_w, _w[:256].contiguous()), reps=30)
-for (M, K, N) in [(266256, 304, 256), (266256, 256, 256), (17424, 960, 160), (17424, 320, 256), (17424, 1280, 256), (4356, 728, 728), (18818, 1536, 1536)]:
+SHAPES = [(266256, 304, 256), (266256, 256, 256), (17424, 960, 160), (17424, 320, 256), (17424, 1280, 256), (4356, 728, 728), (18818, 1536, 1536)]
+if len(sys.argv) > 3:
+    SHAPES = [tuple(int(v) for v in sys.argv[i:i + 3]) for i in range(1, len(sys.argv) - 2, 3)]
+for (M, K, N) in SHAPES:
     x = torch.randn(M, K, device=dev)
     wt = torch.randn(N, K, device=dev) / K ** 0.5
     w = wt.t().contiguous()
