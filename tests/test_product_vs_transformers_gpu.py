@@ -69,10 +69,10 @@ def _weights(pkg, model_type, classes, size, OS, training):
     return m, w
 
 
-@pytest.mark.parametrize('size', [65, 97])
-def test_predict_equals_the_transformers_port(size):
+@pytest.mark.parametrize('size,OS', [(65, 16), (97, 16), (97, 8), (129, 8)])
+def test_predict_equals_the_transformers_port(size, OS):
     pkg = load_pkg()
-    classes, OS, N = 21, 16, 2
+    classes, N = 21, 2
     m, w = _weights(pkg, 'mobilenetv2_lite', classes, size, OS, training=False)
     rng = np.random.default_rng(5)
     x = rng.uniform(-1, 1, (N, size, size, 3)).astype(np.float32)
@@ -83,7 +83,8 @@ def test_predict_equals_the_transformers_port(size):
         up = torch.nn.functional.interpolate(logits, size=(size, size), mode='bilinear', align_corners=False)
         ref = torch.softmax(up, 1).permute(0, 2, 3, 1).numpy()
     assert p.shape == ref.shape
-    assert float(np.abs(p - ref).max()) < 2e-5, float(np.abs(p - ref).max())
+    err = float(np.abs(p - ref).max())
+    assert err < 2e-5, err          # (measured: 1e-6 .. 3e-6)
 
 
 @pytest.mark.parametrize('size', [65, 129])
