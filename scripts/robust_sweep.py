@@ -1,5 +1,6 @@
 """robustness sweep (GPU): every model type x odd / even input sizes x batch sizes x class counts through one eager
-train step, one graph-replayed step and one predict; reports anything that raises or is not finite"""
+train step, one graph-replayed step and one predict; reports anything that raises or is not finite.
+`--bf16`: the same under the mixed_bfloat16 policy (train.py:37-46 applies it to every model type)"""
 import importlib, os, sys, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,6 +9,8 @@ import torch
 pkg = importlib.import_module('tf-keras-deeplabv3p-model-set_amd')
 rng = np.random.default_rng(0)
 bad = 0
+BF16 = '--bf16' in sys.argv
+mp = pkg.mixed_precision
 cases = []
 for mt in sorted(pkg.deeplab_model_map):
     for (H, W), B, C, OS in [((64, 64), 1, 2, 16), ((97, 65), 3, 21, 16), ((128, 160), 2, 19, 8), ((33, 33), 5, 7, 16),
@@ -18,7 +21,13 @@ for mt in sorted(pkg.deeplab_model_map):
 for mt, H, W, B, C, OS in cases:
     tag = '%-22s %3dx%-3d B=%d C=%-2d OS=%-2d' % (mt, H, W, B, C, OS)
     try:
-        m = pkg.get_deeplabv3p_model(mt, C, (H, W), OS, training=True)
+        if BF16:
+            mp.set_policy(mp.Policy('mixed_bfloat16'))
+        try:
+            m = pkg.get_deeplabv3p_model(mt, C, (H, W), OS, training=True)
+        finally:
+            mp.set_policy(mp.Policy('float32'))
+        assert bool(m.bf16) == BF16
         m.compile(optimizer=pkg.SGD(0.01), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
         x = rng.uniform(-1, 1, (B, H, W, 3)).astype(np.float32)
         y = rng.integers(0, C, (B, H * W, 1)).astype(np.float32)
