@@ -199,6 +199,15 @@ inline bool ok8(int C, const void* a, int lda, const void* b, int ldb) {
 
 }  // namespace
 
+// the sliding-window kernels of dwconv.hip instantiated for bf16 tensors (1 = launched, 0 = geometry not served: the strip / gather
+// kernels below take it, < 0 = error)
+int dl3p_dw_window_bf16(int role, const void* x, int ldx, const float* in_scale, const float* in_shift, int in_act, const void* w,
+                        void* y, int ldy, float* partials, int* rows_out, int accumulate, int N, int H, int W, int C, int k,
+                        int stride, int rate, int pad_t, int pad_l, int Ho, int Wo, hipStream_t st);
+int dl3p_dw_window_wgrad_bf16(const void* x, int ldx, const float* in_scale, const float* in_shift, int in_act, const void* dy,
+                              int lddy, float* workspace, int max_rows, int* rows_out, int N, int H, int W, int C, int k,
+                              int stride, int rate, int pad_t, int pad_l, int Ho, int Wo, hipStream_t st);
+
 extern "C" int dl3p_dwconv2d_fwd_bf16(const void* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
                                       const void* w, void* y, int ldy, float* stat_partials, int* rows_out, int N, int H,
                                       int W, int C, int k, int stride, int rate, int pad_t, int pad_l, int Ho, int Wo,
@@ -215,6 +224,17 @@ extern "C" int dl3p_dwconv2d_fwd_bf16(const void* x, int ldx, const float* in_sc
   p.Ho = Ho; p.Wo = Wo;
   const bool v8 = k == 3 && ok8(C, x, ldx, y, ldy) && aligned16(w);
   hipStream_t st = (hipStream_t)stream;
+  {
+    int rows = 0;
+    const int served = dl3p_dw_window_bf16(0, x, ldx, in_scale, in_shift, in_act, w, y, ldy, stat_partials, &rows, 0, N, H, W, C, k,
+                                           stride, rate, pad_t, pad_l, Ho, Wo, st);
+    if (served < 0) return served;
+    if (served) {
+      if (rows_out) *rows_out = rows;
+      DL3P_CHECK_LAUNCH("dl3p_dwconv2d_fwd_bf16");
+      return DL3P_OK;
+    }
+  }
   // (dl3p_launch: the forward depthwise launch can carry bench.py's HIP event pair, dl3p_probe_arm)
   if (stride == 1) {
     const StripGeo geo = strip_geo(Wo, rate, 4);
@@ -253,6 +273,15 @@ extern "C" int dl3p_dwconv2d_bwd_data_bf16(const void* dy, int lddy, const void*
   const bool v8 = k == 3 && ok8(C, dy, lddy, gx, ldgx) && aligned16(w);
   hipStream_t st = (hipStream_t)stream;
   if (stride == 1) {
+    const int served = dl3p_dw_window_bf16(1, dy, lddy, nullptr, nullptr, DL3P_ACT_NONE, w, gx, ldgx, nullptr, nullptr, accumulate, N, H,
+                                           W, C, k, stride, rate, pad_t, pad_l, Ho, Wo, st);
+    if (served < 0) return served;
+    if (served) {
+      DL3P_CHECK_LAUNCH("dl3p_dwconv2d_bwd_data_bf16");
+      return DL3P_OK;
+    }
+  }
+  if (stride == 1) {
     const StripGeo geo = strip_geo(W, rate, 4);
     dw_grid(p, v8 ? 8 : 4, (long long)N * H * geo.nsr, 4, 1 << 20);
     const dim3 sgrid(p.nbx * p.nslab);
@@ -282,7 +311,9 @@ int dww_rows(int N, int Ho, int Wo, int C) {
 
 extern "C" size_t dl3p_dwconv2d_bwd_weight_workspace_bf16(int N, int Ho, int Wo, int C, int k) {
   if (N <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || C % 4) return 0;
-  return (size_t)dww_rows(N, Ho, Wo, C) * k * k * C * sizeof(float);
+  // room for the window kernels' plan as well (dwconv.hip: at most two workgroups per CU = 512 partial rows)
+  const int rows = dww_rows(N, Ho, Wo, C);
+  return (size_t)(rows > 512 ? rows : 512) * k * k * C * sizeof(float);
 }
 
 static int dwb_bwd_weight_impl(const void* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
@@ -302,6 +333,18 @@ static int dwb_bwd_weight_impl(const void* x, int ldx, const float* in_scale, co
   p.Ho = Ho; p.Wo = Wo;
   hipStream_t st = (hipStream_t)stream;
   const int rows = dww_rows(N, Ho, Wo, C);          // what the workspace was sized for
+  {
+    int nrows = 0;
+    const int served = dl3p_dw_window_wgrad_bf16(x, ldx, in_scale, in_shift, in_act, dy, lddy, workspace,
+                                                 (int)(workspace_bytes / ((size_t)k * k * C * sizeof(float))), &nrows, N, H, W, C, k,
+                                                 stride, rate, pad_t, pad_l, Ho, Wo, st);
+    if (served < 0) return served;
+    if (served) {
+      DL3P_CHECK_LAUNCH("dl3p_dwconv2d_bwd_weight_bf16");
+      if (rows_out) { *rows_out = nrows; return DL3P_OK; }
+      return dl3p_reduce_rows_impl(workspace, nrows, (size_t)k * k * C, gw, 0, st);
+    }
+  }
   if (stride == 1) {
     const StripGeo geo = strip_geo(Wo, rate, 4);
     dw_grid(p, 4, (long long)N * Ho * geo.nsr, 2, rows);

@@ -12,8 +12,9 @@
 // the whole 33x33 map from every tile) reads x from HBM once.
 // The BN+activation of the producing layer is applied on load (prologue): zero padding is in
 // activation space, so out-of-range taps contribute exactly 0.
-#include "common.h"
+#include "bf16.h"
 #include <stdlib.h>
+#include <type_traits>
 
 struct DwParams {
   const float* x; int ldx;
@@ -30,6 +31,7 @@ struct DwParams {
   int nt;              // streaming stores for the output (forward role only)
   int tw;              // strip width the plan was made for (3x3 window kernels)
   int lat;             // residue-lattice kernels (kind 3): pixels per class and dimension, 2 or 3
+  int bf16_io;         // x / w / y / dy are bf16 (the mixed-precision entry at the end of this file; window kernels only)
   // fused BatchNorm-backward statistics (data-gradient role, output = gradient of act(BN(z))): partial rows hold
   // (sum g', sum g' * xhat) as dl3p_bn_bwd_reduce would compute them from the finished gradient
   const float* bb_z; int bb_ldz;
@@ -1293,7 +1295,7 @@ static void launch_fwd_pro(const DwParams& p, int kind, dim3 grid, hipStream_t s
 }
 
 // lanes + work decomposition of a forward-role launch (also what dl3p_dwconv2d_fwd reports as partial rows)
-static int plan_forward(DwParams& p, int KS) {
+static int plan_forward(DwParams& p, int KS, int tw5 = 0) {
   p.ks = KS;
   p.ks5 = KS == 5;
   static const int dwf_per_cu = getenv("DL3P_DWF_PER_CU") ? atoi(getenv("DL3P_DWF_PER_CU")) : 8;
@@ -1304,7 +1306,7 @@ static int plan_forward(DwParams& p, int KS) {
       if (c4 % d == 0 && (256 / d) * d >= (256 / best) * best) best = d;
     p.c4s = best; p.px = 256 / best; p.nslab = c4 / best;
   }
-  return fwd_plan(p, dwf_per_cu, true);
+  return fwd_plan(p, dwf_per_cu, true, tw5);
 }
 
 template <int KS>
@@ -1579,6 +1581,95 @@ extern "C" int dl3p_dwconv2d_bwd_weight_slabs(const float* x, int ldx, const flo
   DL3P_CHECK_ARG(rows_out != nullptr, "dl3p_dwconv2d_bwd_weight_slabs: rows_out is required");
   return dwconv2d_bwd_weight_impl(x, ldx, in_scale, in_shift, in_act, dy, lddy, nullptr, workspace, workspace_bytes, N, H, W, C,
                                   k, stride, rate, pad_t, pad_l, Ho, Wo, rows_out, stream);
+}
+
+#include "dw_bf16_window.h"
+
+// ------------------------------------------------------------------------------ mixed-precision entry of the window kernels
+// Called by dw_bf16.hip (dl3p_dwconv2d_{fwd,bwd_data,bwd_weight}_bf16) before its own strip / gather kernels: the sliding-window
+// decomposition above -- every input row loaded and activated ONCE per strip, bands of rows for parallelism at batch 1, the
+// XCD-aware split -- with bf16 tensors (T = bf16 instantiations).  The strip kernels of dw_bf16_strip.h re-load and re-activate the
+// k input rows for every output row; on BASELINE configs[4] (MobileNetV3-Large 1024 x 2048, batch 1) they ran at 0.4-2.4 TB/s.
+// Returns 1 = launched, 0 = geometry not served by a window kernel (caller falls back), < 0 = error code.
+// role 0: forward x (N,H,W,C) -> y (N,Ho,Wo,C) [+ statistics]; role 1: data gradient of a STRIDE-1 conv, x = dy (N,Ho,Wo,C),
+// y = gx (N,H,W,C), the kernel mirror read back to front.
+int dl3p_dw_window_bf16(int role, const void* x, int ldx, const float* in_scale, const float* in_shift, int in_act, const void* w,
+                        void* y, int ldy, float* partials, int* rows_out, int accumulate, int N, int H, int W, int C, int k,
+                        int stride, int rate, int pad_t, int pad_l, int Ho, int Wo, hipStream_t st) {
+  static const int on = getenv("DL3P_BF16_DW_WINDOW") ? atoi(getenv("DL3P_BF16_DW_WINDOW")) : 1;
+  if (!on || C <= 0 || C % 4 || (k != 3 && k != 5) || ldx % 4 || ldy % 4 || ((uintptr_t)x & 7u) || ((uintptr_t)y & 7u) || ((uintptr_t)w & 7u))
+    return 0;
+  if (role == 1 && stride != 1) return 0;
+  // 5x5: the 2-column window kernel needs all 256 registers (one wave per SIMD) and loses to the strip kernels (64x128x960 rate 2:
+  // 44.7 against 38.6 us); stride 2 ties.  3x3 only.
+  if (k != 3) return 0;
+  DwParams p = {};
+  p.bf16_io = 1;
+  p.x = reinterpret_cast<const float*>(x); p.ldx = ldx; p.w = reinterpret_cast<const float*>(w);
+  p.y = reinterpret_cast<float*>(y); p.ldy = ldy; p.C = C; p.N = N; p.accumulate = accumulate;
+  if (role == 0) {
+    p.scale = in_scale; p.shift = in_shift; p.act = in_act; p.partials = partials;
+    p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.rate = rate; p.pad_t = pad_t; p.pad_l = pad_l;
+  } else {
+    p.flip = 1; p.act = DL3P_ACT_NONE;
+    p.H = Ho; p.W = Wo; p.Ho = H; p.Wo = W; p.stride = 1; p.rate = rate;
+    p.pad_t = rate * (k - 1) - pad_t; p.pad_l = rate * (k - 1) - pad_l;
+  }
+  pick_lanes(C, &p.c4s, &p.px, &p.nslab);
+  const int kind = plan_forward(p, k, 2);
+  if (kind != 1 && kind != 2) return 0;
+  if (rows_out) *rows_out = p.nbx;
+  const dim3 grid(p.nbx * p.nslab), block(256);
+  const int pro = (p.act != DL3P_ACT_NONE) ? 2 : (p.scale ? 1 : 0);
+  const bool hs = p.act >= DL3P_ACT_HSWISH;
+  const size_t lds5 = (size_t)25 * p.c4s * sizeof(float4);
+  // (dl3p_launch: the forward depthwise launch can carry bench.py's HIP event pair, dl3p_probe_arm)
+#define DL3P_DWB_F(PRO, HS)                                                                                              \
+  do {                                                                                                                   \
+    if (k == 5 && kind == 1) dl3p_launch(dwb_fwd_seg<5, 2, 1, PRO, HS>, grid, block, lds5, st, p);                       \
+    else if (k == 5) dl3p_launch(dwb_fwd_seg<5, 1, 2, PRO, HS>, grid, block, lds5, st, p);                               \
+    else if (kind == 1 && p.tw == 2) dl3p_launch(dwb_fwd_seg<3, 2, 1, PRO, HS>, grid, block, 0, st, p);                  \
+    else if (kind == 1) dl3p_launch(dwb_fwd_seg<3, 4, 1, PRO, HS>, grid, block, 0, st, p);                               \
+    else dl3p_launch(dwb_fwd_seg<3, 2, 2, PRO, HS>, grid, block, 0, st, p);                                              \
+  } while (0)
+  if (pro == 2 && hs) DL3P_DWB_F(2, true); else if (pro == 2) DL3P_DWB_F(2, false); else if (pro == 1) DL3P_DWB_F(1, false); else DL3P_DWB_F(0, false);
+#undef DL3P_DWB_F
+  return 1;
+}
+
+// weight gradient, 3x3: x (bf16, producer's BatchNorm + activation applied and rounded on load) x dy (bf16) -> fp32 partial rows
+// [rows][9][C] in `workspace` (room for max_rows of them)
+int dl3p_dw_window_wgrad_bf16(const void* x, int ldx, const float* in_scale, const float* in_shift, int in_act, const void* dy,
+                              int lddy, float* workspace, int max_rows, int* rows_out, int N, int H, int W, int C, int k,
+                              int stride, int rate, int pad_t, int pad_l, int Ho, int Wo, hipStream_t st) {
+  static const int on = getenv("DL3P_BF16_DW_WINDOW") ? atoi(getenv("DL3P_BF16_DW_WINDOW")) : 1;
+  if (!on || k != 3 || C <= 0 || C % 4 || ldx % 4 || lddy % 4 || ((uintptr_t)x & 7u) || ((uintptr_t)dy & 7u) || max_rows < DL3P_NUM_XCDS) return 0;
+  // few pixels (Xception's 33 x 33 maps at batch 4: 4356): the strip kernel's finer work items fill the chip better -- 27.4 against
+  // 34.2 us on 33 x 33 x 728; from 65 x 65 x 4 up the window kernel ties or wins (129 x 129 x 256 stride 2: 35.5 against 49.5)
+  if ((long long)N * Ho * Wo < 16384) return 0;
+  DwParams p = {};
+  p.bf16_io = 1;
+  p.x = reinterpret_cast<const float*>(x); p.ldx = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act;
+  p.dy = reinterpret_cast<const float*>(dy); p.lddy = lddy; p.partials = workspace;
+  p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.rate = rate; p.pad_t = pad_t; p.pad_l = pad_l;
+  pick_lanes(C, &p.c4s, &p.px, &p.nslab);
+  p.ks = 3;
+  const int kind = fwd_plan(p, 2, false, 0);
+  if (kind != 1 && kind != 2) return 0;
+  if (p.nbx > max_rows) p.nbx = max_rows / DL3P_NUM_XCDS * DL3P_NUM_XCDS;      // the workspace's rows (a multiple of the XCD count stays one)
+  const dim3 grid(p.nbx * p.nslab), block(256);
+  const int pro = (in_act != DL3P_ACT_NONE) ? 2 : (in_scale ? 1 : 0);
+  const bool hs = in_act >= DL3P_ACT_HSWISH;
+#define DL3P_DWW_B(PRO, HS)                                                                                              \
+  do {                                                                                                                   \
+    if (kind == 1 && p.tw == 2) hipLaunchKernelGGL((dwb_bwd_weight_seg<3, 2, 1, PRO, HS>), grid, block, 0, st, p);        \
+    else if (kind == 1) hipLaunchKernelGGL((dwb_bwd_weight_seg<3, 4, 1, PRO, HS>), grid, block, 0, st, p);                \
+    else hipLaunchKernelGGL((dwb_bwd_weight_seg<3, 2, 2, PRO, HS>), grid, block, 0, st, p);                               \
+  } while (0)
+  if (pro == 2 && hs) DL3P_DWW_B(2, true); else if (pro == 2) DL3P_DWW_B(2, false); else if (pro == 1) DL3P_DWW_B(1, false); else DL3P_DWW_B(0, false);
+#undef DL3P_DWW_B
+  *rows_out = p.nbx;
+  return 1;
 }
 
 // ------------------------------------------------------------------------------ plan query (include/dl3p.h)

@@ -1600,6 +1600,12 @@ class Executor:
         kname = 'dw_fwd_lattice2' if lat2 else 'dw_fwd_lattice3' if lat3 else (('dw_fwd_seg<%d,%d,%d>' % (op.k, 4 if op.stride == 1 else 2, op.stride)) if seg else 'dw_fwd_gather<%d>' % op.k)
         if self.bf16:
             kname = ('dwb_fwd_strip<%d, %d' if op.stride == 1 else 'dwb_fwd<%d, %d') % (8 if (op.k == 3 and op.c % 8 == 0) else 4, op.k)
+            # 3x3 convs the window plan serves run on the bf16 instantiation of the sliding-window kernels (csrc/dw_bf16_window.h)
+            plan = (ctypes.c_int * 6)()
+            xt = op.x.tensor
+            self.L.dw_plan_query(0, self.N, xt.H, xt.W, op.c, op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo, plan)
+            if op.k == 3 and plan[0] in (1, 2) and os.environ.get('DL3P_BF16_DW_WINDOW', '1') != '0':
+                kname = 'dwb_fwd_seg<3, %d, %d' % (plan[1] if plan[0] == 1 else 2, op.stride)
         probe = Probe(op, kname)
         self.fwd.probe(name, probe)
         return probe
