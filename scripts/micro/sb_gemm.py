@@ -29,9 +29,13 @@ SHAPES = [(266256, 304, 256), (266256, 256, 256), (17424, 1280, 256), (17424, 96
           (67600, 192, 64), (67600, 384, 64), (4356, 728, 728), (4356, 2048, 256), (4356, 1536, 2048), (18818, 728, 728), (74498, 304, 256)]
 # (nt, mi, wm): wm = 0 -> the 2-workgroups-per-CU tiles (gemm_nt / gemm_mi), wm >= 1 with nt in (8, 12, 16) -> the wide family
 # wm = -1 -> the producer / consumer form (sb_pipe) with (nt, mi)
+if os.environ.get('SB_SHAPES'):          # e.g. SB_SHAPES=66564x256x256,66564x304x256
+    SHAPES = [tuple(int(v) for v in t.split('x')) for t in os.environ['SB_SHAPES'].split(',')]
 cands = [(None, None, None), (8, 2, -1), (8, 1, -1), (4, 2, -1), (4, 2, 0), (8, 2, 0), (16, 1, 2)]
 if len(sys.argv) > 3:
     cands = [(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]))]
+elif len(sys.argv) > 1 and sys.argv[1] == 'tiles':
+    cands = [(None, None, None), (8, 2, 0), (4, 2, 0), (16, 1, 2), (16, 2, 1)]
 
 
 def pin(nt, mi, wm):

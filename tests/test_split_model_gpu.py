@@ -1,7 +1,9 @@
-"""Whole-model parity with the split-bf16 GEMMs switched on (DL3P_SPLIT_GEMM=1): the same train-step /
-predict comparisons against the float64 oracle as tests/test_model_gpu.py and tests/test_production_shapes_gpu.py, at their
-UNCHANGED tolerances (logits and loss 1e-3, parameter gradients 8e-3 / 1e-2 at 65 x 65 and 5e-3 at 513 x 513, weights after the
-step 1e-3).  The opt-in only stays a candidate for the default if these hold."""
+"""Whole-model parity with the split-bf16 GEMMs: the same train-step / predict comparisons against the
+float64 oracle as tests/test_model_gpu.py and tests/test_production_shapes_gpu.py, at their UNCHANGED tolerances (logits and loss
+1e-3, parameter gradients 8e-3 / 1e-2 at 65 x 65 and 5e-3 at 513 x 513, weights after the step 1e-3).  That they hold is the
+condition under which the split kernels became the default for the compute-bound 1 x 1 convs (executor.split_gemm_enabled).
+At the default thresholds only layers with >= 16384 rows take them, so the small-model tests here lower the thresholds; the last
+tests run the 513 x 513 steps with the switch OFF, so the fp32-input MFMA kernels keep their production-dispatch coverage."""
 import pytest
 
 from conftest import load_pkg
@@ -65,3 +67,51 @@ def test_the_split_path_is_actually_taken():
     ex = m._executor(2, True)
     names = [lab[0] for lab in ex.fwd.labels + ex.bwd.labels + ex.opt.labels]
     assert any('pwconv_bwd_data_sb' in n for n in names) and any('split_bf16x3_batch' in n for n in names)
+
+
+@pytest.mark.parametrize('model_type', ['mobilenetv2', 'xception'])
+def test_train_step_513_on_the_fp32_input_mfma_kernels_only(model_type, monkeypatch):
+    """DL3P_SPLIT_GEMM=0: the path the headline ran on until round 3, still selectable, still held to the same bounds"""
+    monkeypatch.setenv('DL3P_SPLIT_GEMM', '0')
+    import test_production_shapes_gpu as T
+    T.test_train_step_513_production_dispatch(model_type)
+    pkg = load_pkg()
+    m = pkg.get_deeplabv3p_model('mobilenetv2', 21, (65, 65), 16, training=True)
+    m._ensure_store()
+    assert m._store.Sb is None
+
+
+def test_an_executor_that_did_not_take_the_optimiser_step_reads_fresh_planes(monkeypatch):
+    """the optimiser step refreshes only the split planes its own executor's GEMMs read; an executor of another batch size on the
+    same weights (predict after fit) must see every plane re-split first (Executor._sb_sync)"""
+    import numpy as np
+    pkg = load_pkg()
+    rng = np.random.default_rng(3)
+    S = 129
+
+    def build():
+        m = pkg.get_deeplabv3p_model('mobilenetv2', 21, (S, S), 16, training=True)
+        m.compile(optimizer=pkg.SGD(0.1), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
+        m.use_graphs = False
+        return m
+    x1 = rng.uniform(-1, 1, (1, S, S, 3)).astype(np.float32)
+    y1 = rng.integers(0, 21, (1, S * S, 1)).astype(np.float32)
+    xb = rng.uniform(-1, 1, (2, S, S, 3)).astype(np.float32)
+    for min_rows in (400, 150, 1500, 6000):          # a row threshold some map size sits under at batch 1 and over at batch 2
+        monkeypatch.setenv('DL3P_SPLIT_MIN_ROWS', str(min_rows))
+        monkeypatch.setenv('DL3P_SPLIT_MIN_ROWS_BN', str(min_rows))
+        m = build()
+        p0 = m.predict(xb)              # the batch-2 executor exists before the steps (its planes are fresh NOW)
+        m.train_on_batch(x1, y1)
+        exA, exB = m._executor(1, True), m._executor(2, False)
+        if exB._sb_used_f - exA._sb_used_f:
+            break
+    else:
+        raise AssertionError('no threshold made the two executors read different planes')
+    for _ in range(2):
+        m.train_on_batch(x1, y1)
+    p = m.predict(xb)
+    assert float(np.abs(p - p0).max()) > 1e-4          # the steps moved the weights
+    m2 = build()
+    m2.set_weights_by_name(m.get_weights_by_name())
+    assert np.array_equal(m2.predict(xb), p)

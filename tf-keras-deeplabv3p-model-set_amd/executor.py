@@ -24,9 +24,12 @@ MAX_ROWS = 2048
 
 
 def split_gemm_enabled():
-    """DL3P_SPLIT_GEMM=1 (or model.split_gemm / bench.py --split-gemm, which set it before the store is built): the
-    compute-bound pointwise convs run as fp32-accurate split-bf16 GEMMs on the bf16 matrix pipe (csrc/pw_split.hip)"""
-    return os.environ.get('DL3P_SPLIT_GEMM', '0') not in ('', '0')
+    """The compute-bound pointwise convs (K >= 128, N >= 128, >= 16384 rows) run as fp32-accurate split-bf16 GEMMs on the bf16
+    matrix pipe (csrc/pw_split.hip): every fp32 operand split exactly into three bf16 pieces, six cross products
+    accumulated in fp32 -- parity held at the tolerances of the fp32-input MFMA kernels (tests/test_split_gemm_gpu.py, and the whole
+    GPU suite runs with it).  On by default since round 3; DL3P_SPLIT_GEMM=0 (bench.py --split-gemm 0), read when the parameter
+    store is built, keeps every GEMM on the fp32-input MFMA kernels."""
+    return os.environ.get('DL3P_SPLIT_GEMM', '1') not in ('', '0')
 
 
 class ParamStore:
@@ -65,27 +68,33 @@ class ParamStore:
         # (they take the place of Pt); both refreshed after every optimiser step
         self.Pb = torch.zeros(off, dtype=torch.bfloat16, device=device) if self.bf16 else None
         self.Pbt = torch.zeros(off, dtype=torch.bfloat16, device=device) if self.bf16 else None
-        # fp32-accurate GEMMs on the bf16 matrix pipe (csrc/pw_split.hip; opt-in, split_gemm_enabled()): every pointwise kernel
+        # fp32-accurate GEMMs on the bf16 matrix pipe (csrc/pw_split.hip; split_gemm_enabled()): every pointwise kernel
         # pre-split into three bf16 planes, once as [3][N][Kpad] (from the transposed copy: the forward's B operand) and once as
         # [3][K][Npad] (from the kernel as stored: the data gradient's); refreshed after every optimiser step like Pt
         self.Sb = None
         self.sb_fwd, self.sb_bwd = {}, {}           # op -> (element offset in Sb, pitch)
+        self.sb_row_f, self.sb_row_b = {}, {}       # op -> its row of the dl3p_split_bf16x3_batch job table
+        # An optimiser step refreshes only the planes ITS executor's GEMMs read (Xception's 728 x 728 middle-flow kernels run at
+        # 4356 rows, under the split dispatch threshold: splitting all 40 M parameters after every step cost more than the split
+        # GEMMs returned).  sb_partial = the executor whose subset is fresh, None = every plane is; another executor on the same
+        # store (a different batch size, predict after fit) re-splits everything before it runs (Executor._sb_sync).
+        self.sb_partial = None
         if split_gemm_enabled() and not self.bf16:
             pw = [op for op in graph.ops if op.kind == 'conv_pw']
-            rows_f, rows_b, o = [], [], 0
+            o = 0
             for op in pw:
                 K, Nn = op.cin, op.cout
                 pk, pn = (K + 31) // 32 * 32, (Nn + 31) // 32 * 32
                 self.sb_fwd[op] = (o, pk)
-                rows_f.append([self.offset[op.w], Nn, K, K, o, pk])
+                self.sb_row_f[op] = [self.offset[op.w], Nn, K, K, o, pk]
                 o += 3 * Nn * pk
                 self.sb_bwd[op] = (o, pn)
-                rows_b.append([self.offset[op.w], K, Nn, Nn, o, pn])
+                self.sb_row_b[op] = [self.offset[op.w], K, Nn, Nn, o, pn]
                 o += 3 * K * pn
             if pw:
                 self.Sb = torch.zeros(o, dtype=torch.int16, device=device)
-                self.sb_table_f = torch.tensor(rows_f, dtype=torch.int64, device=device)
-                self.sb_table_b = torch.tensor(rows_b, dtype=torch.int64, device=device)
+                self.sb_table_f = torch.tensor([self.sb_row_f[op] for op in pw], dtype=torch.int64, device=device)
+                self.sb_table_b = torch.tensor([self.sb_row_b[op] for op in pw], dtype=torch.int64, device=device)
         self.upload()
         self.refresh_masks()
 
@@ -103,6 +112,7 @@ class ParamStore:
         if self.Sb is not None:
             lib().split_bf16x3_batch(self.Pt.data_ptr(), self.Sb.data_ptr(), self.sb_table_f.data_ptr(), int(self.sb_table_f.shape[0]), st)
             lib().split_bf16x3_batch(self.P.data_ptr(), self.Sb.data_ptr(), self.sb_table_b.data_ptr(), int(self.sb_table_b.shape[0]), st)
+            self.sb_partial = None
 
     def sb_ptr(self, op, fwd):
         off, pitch = (self.sb_fwd if fwd else self.sb_bwd)[op]
@@ -380,6 +390,7 @@ class Executor:
         # else; the logits tensor (conv_upsample output) and its gradient stay fp32 so the softmax / loss head is unchanged
         self.bf16 = bool(getattr(store, 'bf16', False))
         self.adt = torch.bfloat16 if self.bf16 else torch.float32
+        self._sb_used_f, self._sb_used_b = set(), set()      # pointwise convs whose forward / data gradient took the split GEMM
         self._alloc()
         # tracing runs every kernel once on zero inputs: keep the weights / optimiser state intact
         snap_p, snap_v, snap_step, snap_ostep = store.P.clone(), store.V.clone(), store.step.clone(), store.opt_step.clone()
@@ -1228,7 +1239,10 @@ class Executor:
         if M < int(env('DL3P_SPLIT_MIN_ROWS', '16384')) or (not fwd and stats and M < int(env('DL3P_SPLIT_MIN_ROWS_BN', '60000'))):
             return False
         role = (1 if stats else 0) if fwd else (3 if stats else 2)
-        return bool(self.L.pwconv_sb_supported(role, M, kred, nout))
+        if not self.L.pwconv_sb_supported(role, M, kred, nout):
+            return False
+        (self._sb_used_f if fwd else self._sb_used_b).add(op)       # the optimiser step refreshes these planes (_trace_sgd)
+        return True
 
     def _pw_dgrad_bn(self, P, op, dz, lddz, gp, ldg, acc, bn_op, partials, rows):
         """data gradient of a pointwise conv + the BatchNorm-backward partial sums of the BatchNorm in front of it"""
@@ -1464,9 +1478,16 @@ class Executor:
                 P.k(L.transpose_batch_bf16, st.P.data_ptr(), st.Pbt.data_ptr(), st.tr_table.data_ptr(), int(st.tr_table.shape[0]))
         elif st.tr_table is not None:      # the forward GEMMs read the transposed kernel copies
             P.k(L.transpose_batch, st.P.data_ptr(), st.Pt.data_ptr(), st.tr_table.data_ptr(), int(st.tr_table.shape[0]))
-        if st.Sb is not None:               # ... and the split-bf16 GEMMs the pre-split planes of both
-            P.k(L.split_bf16x3_batch, st.Pt.data_ptr(), st.Sb.data_ptr(), st.sb_table_f.data_ptr(), int(st.sb_table_f.shape[0]))
-            P.k(L.split_bf16x3_batch, st.P.data_ptr(), st.Sb.data_ptr(), st.sb_table_b.data_ptr(), int(st.sb_table_b.shape[0]))
+        if st.Sb is not None:               # ... and the split-bf16 GEMMs of THIS executor the pre-split planes they read
+            order = [op for op in self.g.ops if op.kind == 'conv_pw']
+            rf = [st.sb_row_f[op] for op in order if op in self._sb_used_f]
+            rb = [st.sb_row_b[op] for op in order if op in self._sb_used_b]
+            self._sb_tab_f = torch.tensor(rf, dtype=torch.int64, device=self.dev) if rf else None
+            self._sb_tab_b = torch.tensor(rb, dtype=torch.int64, device=self.dev) if rb else None
+            if rf:
+                P.k(L.split_bf16x3_batch, st.Pt.data_ptr(), st.Sb.data_ptr(), self._sb_tab_f.data_ptr(), len(rf))
+            if rb:
+                P.k(L.split_bf16x3_batch, st.P.data_ptr(), st.Sb.data_ptr(), self._sb_tab_b.data_ptr(), len(rb))
         return P
 
     # ---------------------------------------------------------------- running
@@ -1541,12 +1562,23 @@ class Executor:
             plan.capture(collectives_in_graph=in_graph)
         self.graphed = True
 
+    def _sb_sync(self):
+        """the split planes this executor reads are current: after another executor's optimiser step only ITS subset is
+        (ParamStore.sb_partial), so everything is re-split once before this one runs"""
+        st = self.store
+        if st.Sb is not None and st.sb_partial is not None and st.sb_partial is not self:
+            st.transpose()
+
     def train_step(self):
+        self._sb_sync()
         self.fwd.run()
         self.bwd.run()
         self.opt.run()
+        if self.store.Sb is not None:
+            self.store.sb_partial = self
 
     def forward(self):
+        self._sb_sync()
         self.fwd.run()
 
     def eval_step(self, confusion, pred=None):
@@ -1559,6 +1591,7 @@ class Executor:
             P.items = list(self.fwd.items[:-1])            # the body; the last item is the softmax head
             P.labels = list(self.fwd.labels[:-1])
             self._eval_plan = P
+        self._sb_sync()
         self._eval_plan.run()
         zt = self.head.tensor
         self.L.argmax_confusion(self.tptr(zt), zt.ld, None if confusion is None else self.labels.data_ptr(),
@@ -1575,6 +1608,7 @@ class Executor:
             P.items = list(self.fwd.items[:-1])
             P.labels = list(self.fwd.labels[:-1])
             self._eval_plan = P
+        self._sb_sync()
         self._eval_plan.run()
         zt, L = self.head.tensor, self.L
         st = torch.cuda.current_stream().cuda_stream
