@@ -36,6 +36,8 @@ if len(sys.argv) > 3:
     cands = [(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]))]
 elif len(sys.argv) > 1 and sys.argv[1] == 'tiles':
     cands = [(None, None, None), (8, 2, 0), (4, 2, 0), (16, 1, 2), (16, 2, 1)]
+elif len(sys.argv) > 1 and sys.argv[1] == 'wide':
+    cands = [(None, None, None), (16, 1, 2), (16, 1, 1), (12, 2, 1), (16, 2, 1), (8, 2, 2)]
 
 
 def pin(nt, mi, wm):

@@ -1043,9 +1043,13 @@ static void gemm_plan_sb(int role, int M, int K, int N, int* nt, int* gx, int* g
   // all of N): 306 against 335 us on 266256 x 304 -> 256, 255 against 278 on K = 256, 98 against 107 on 74498 rows -- since the
   // operand requests stopped being drained at every stage (pw_split.hip, the note in step()); before that the wide tiles tied
   if (!wide_nt && role <= 1 && N % 256 == 0 && M >= 65536) { wide_nt = 16; wide_mi = 1; wide_wm = 2; }
+  // the long decoder data gradients with the fused BatchNorm sums: 256 rows x 128 columns, 512 threads (334 against 368 us on
+  // 266256 x 256 -> 256, 469 against 495 onto 304 columns; the 256-column tiles lose here -- the z tile of the sums comes on top)
+  bool wide_bnb = false;
+  if (!wide_nt && role == 3 && N >= 256 && M >= 131072) { wide_nt = 8; wide_mi = 2; wide_wm = 2; wide_bnb = true; }
   if (g_sb_force_wm > 0) { wide_nt = g_sb_force_nt ? g_sb_force_nt : 16; wide_wm = g_sb_force_wm; wide_mi = g_gemm_force_mi ? g_gemm_force_mi : 2; }
   if (g_sb_force_wm < 0) wide_nt = 0;
-  if (wide_nt && dl3p_sb_wide_config(wide_nt, wide_mi, wide_wm) && role != 3) {     // (role 3: the z-prefetch registers of the fused BatchNorm sums do not fit the wide tiles)
+  if (wide_nt && dl3p_sb_wide_config(wide_nt, wide_mi, wide_wm) && (role != 3 || wide_bnb || g_sb_force_wm > 0)) {     // (role 3 takes the wide family only where measured -- above -- or pinned)
     *nt = wide_nt; *mi = wide_mi; *wm = wide_wm;
     const int bm = 64 * wide_mi * wide_wm, nb = ceil_div(N, 16 * wide_nt);
     const int mt = ceil_div(M, bm);
