@@ -102,9 +102,13 @@ int dl3p_comm_destroy(void* comm);
  * src[rows][cols] (pitch a multiple of 32, zero padded).  rows = the GEMM's OUTPUT columns, cols = its reduction length:
  * the transposed kernel wt[N][K] for the forward, the kernel w[K][N] as stored for the data gradient.
  * dl3p_pwconv_sb_supported(role, M, K, N) (roles and (M, K, N) as dl3p_gemm_plan_query): 0 for shapes the tiled kernel does
- * not serve (few rows; few-channel layers on the streaming kernels) -- those keep the fp32 entry points. */
+ * not serve (few rows; few-channel layers on the streaming kernels) -- those keep the fp32 entry points.
+ * dl3p_pwconv_sb_pays(role, M, K, N): the measured verdict for that exact launch (csrc/sb_tuned.h, scripts/tune_split.py):
+ * 1 the split kernel beat the fp32-input MFMA kernel, 0 it did not, -1 never measured -- then the caller's rule decides
+ * (the executor's: K >= 128, N >= 128, >= 16384 rows). */
 int dl3p_split_bf16x3_batch(const float* src, void* dst, const int64_t* table, int n_matrices, void* stream);
 int dl3p_pwconv_sb_supported(int role, int M, int K, int N);
+int dl3p_pwconv_sb_pays(int role, int M, int K, int N);
 int dl3p_pwconv_fwd_sb(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
                        const void* wsp, int pitch, const float* bias, float* y, int ldy, float* stat_partials,
                        int* rows_out, int M, int K, int N, void* stream);

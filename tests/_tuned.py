@@ -24,6 +24,16 @@ def gemm_rows():
     return _rows(os.path.join(CSRC, 'gemm_tuned.h'), 7)
 
 
+def sb_rows():
+    """(role + 5, M, K, N, nt, mi, pc) of the split-bf16 GEMM (csrc/sb_tuned.h, g_sb_tuned; pc > 100: the wide family, wm = pc - 100)"""
+    return [r for r in _rows(os.path.join(CSRC, 'sb_tuned.h'), 7)]
+
+
+def sb_pays_rows():
+    """(role, M, K, N, pays): the measured split-against-fp32 verdicts that differ from the executor's threshold rule (g_sb_pays)"""
+    return _rows(os.path.join(CSRC, 'sb_tuned.h'), 5)
+
+
 def dw_rows():
     """(role, N, H, W, C, k, stride, rate, per_cu, want, maxth, tw): role 0 forward, 1 data gradient, 2 data gradient + BN
     sums, 3 weight gradient; geometry as the planner sees it"""

@@ -18,10 +18,12 @@ import numpy as np
 import pytest
 
 from conftest import load_pkg
-from _tuned import gemm_rows, dw_rows, same_geometry
+from _tuned import gemm_rows, dw_rows, sb_rows, sb_pays_rows, same_geometry
 
 GEMM = gemm_rows()
 DW = dw_rows()
+SB = sb_rows()
+SB_PAYS = sb_pays_rows()
 
 
 def _lib():
@@ -57,6 +59,31 @@ def test_every_gemm_table_row_is_reached_by_the_dispatcher():
         # and the switch: with the table off the same keys fall back to the heuristics
         L.set_option(b'gemm_tuned', 0)
         assert all(_gemm_plan(L, r[0], r[1], r[2], r[3])[5] == 0 for r in GEMM[:20])
+    finally:
+        L.set_option(b'gemm_tuned', 1)
+        L.set_option(b'pw_small_min_rows', 64)
+
+
+def test_every_split_gemm_table_row_is_reached_by_the_dispatcher():
+    """csrc/sb_tuned.h: the tile rows through dl3p_gemm_plan_query(role + 5 ...), the verdict rows through dl3p_pwconv_sb_pays"""
+    L = _lib()
+    L.set_option(b'pw_small_min_rows', -1)
+    L.set_option(b'gemm_tuned', 1)
+    try:
+        assert len(SB) > 100 and len(SB_PAYS) > 20
+        dead = []
+        for (role, M, K, N, nt, mi, pc) in SB:
+            assert 5 <= role <= 8
+            fam, q_nt, q_mi, q_wm, wgs, from_table = _gemm_plan(L, role, M, K, N)
+            want_wm = pc - 100 if pc > 100 else 1
+            if fam != 3 or not from_table or q_nt != nt or q_mi != mi or q_wm != want_wm:
+                dead.append(((role, M, K, N, nt, mi, pc), (fam, q_nt, q_mi, q_wm, from_table)))
+        assert not dead, dead[:10]
+        assert all(L.pwconv_sb_pays(r[0], r[1], r[2], r[3]) == r[4] for r in SB_PAYS)
+        assert L.pwconv_sb_pays(0, 12345, 128, 128) == -1
+        L.set_option(b'gemm_tuned', 0)
+        assert all(_gemm_plan(L, r[0], r[1], r[2], r[3])[5] == 0 for r in SB[:20])
+        assert all(L.pwconv_sb_pays(r[0], r[1], r[2], r[3]) == -1 for r in SB_PAYS[:20])
     finally:
         L.set_option(b'gemm_tuned', 1)
         L.set_option(b'pw_small_min_rows', 64)
@@ -102,8 +129,9 @@ def _act6(u):
     return u.clamp(0.0, 6.0)
 
 
-def run_gemm_row(ops, role, M, K, N, seed=0):
-    """one (role, M, K, N) of the tiled pointwise GEMM as the executor launches it, against float64"""
+def run_gemm_row(ops, role, M, K, N, seed=0, split=False):
+    """one (role, M, K, N) of the tiled pointwise GEMM as the executor launches it, against float64 (split: the same launch
+    on the split-bf16 kernel, held to the SAME bounds)"""
     torch = _t()
     g = torch.Generator(device=DEV)
     g.manual_seed(1000 * role + M % 9973 + 7 * K + 13 * N + seed)
@@ -114,7 +142,10 @@ def run_gemm_row(ops, role, M, K, N, seed=0):
         sc = torch.rand(K, device=DEV, generator=g) + 0.5
         sh = rnd(K) * 0.3
         part = ops.new_partials(N, DEV) if role == 1 else None
-        out = ops.pwconv_fwd_wt(x, wt, None, sc, sh, ops.ACT_RELU6, partials=part)
+        if split:
+            out = ops.pwconv_fwd_sb(x, ops.split_bf16x3(wt), K, None, sc, sh, ops.ACT_RELU6, partials=part)
+        else:
+            out = ops.pwconv_fwd_wt(x, wt, None, sc, sh, ops.ACT_RELU6, partials=part)
         y, rows = out if role == 1 else (out, 0)
         a64 = _act6(x.double() * sc.double() + sh.double())
         y64 = a64 @ wt.double().t()
@@ -136,7 +167,7 @@ def run_gemm_row(ops, role, M, K, N, seed=0):
         w = rnd(N, K) / K ** 0.5
         gx64 = dy.double() @ w.double().t()
         if role == 2:
-            gx = ops.pwconv_bwd_data(dy, w)
+            gx = ops.pwconv_bwd_data_sb(dy, ops.split_bf16x3(w), K) if split else ops.pwconv_bwd_data(dy, w)
         else:
             z = rnd(M, N)
             sc = torch.rand(N, device=DEV, generator=g) + 0.5
@@ -144,7 +175,11 @@ def run_gemm_row(ops, role, M, K, N, seed=0):
             mean = z.mean(0)
             invstd = 1.0 / torch.sqrt(z.var(0, unbiased=False) + 1e-3)
             part = ops.new_partials(N, DEV)
-            gx, rows = ops.pwconv_bwd_data_bn(dy, w, z, sc, sh, ops.ACT_RELU6, mean, invstd, part)
+            if split:
+                gx, rows = ops.pwconv_bwd_data_sb(dy, ops.split_bf16x3(w), K, z=z, scale=sc, shift=sh, act=ops.ACT_RELU6, mean=mean,
+                                                  invstd=invstd, partials=part)
+            else:
+                gx, rows = ops.pwconv_bwd_data_bn(dy, w, z, sc, sh, ops.ACT_RELU6, mean, invstd, part)
             u = z.double() * sc.double() + sh.double()
             d = gx64 * ((u > 0) & (u < 6))
             xh = (z.double() - mean.double()) * invstd.double()
@@ -183,6 +218,22 @@ def test_gemm_table_row_matches_float64(ops, row):
         plan = _gemm_plan(L, role, M, K, N)
         assert plan[0] == 0 and plan[5] == 1 and plan[1] == nt, plan
         run_gemm_row(ops, role, M, K, N)
+    finally:
+        L.set_option(b'pw_small_min_rows', 64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('row', SB, ids=lambda r: 's%d_%dx%dx%d' % (r[0] - 5, r[1], r[2], r[3]))
+def test_split_gemm_table_row_matches_float64(ops, row):
+    """every tile row of csrc/sb_tuned.h at its exact launch shape, at the bounds of the fp32-input MFMA kernel's rows"""
+    L = _lib()
+    L.set_option(b'pw_small_min_rows', -1)
+    L.set_option(b'gemm_tuned', 1)
+    try:
+        role, M, K, N, nt, mi, pc = row
+        plan = _gemm_plan(L, role, M, K, N)
+        assert plan[0] == 3 and plan[5] == 1 and plan[1] == nt and plan[2] == mi, plan
+        run_gemm_row(ops, role - 5, M, K, N, split=True)
     finally:
         L.set_option(b'pw_small_min_rows', 64)
 

@@ -671,10 +671,19 @@ static void launch_pw_small_any(const GemmParams& p, SmallShape sh, int grid, hi
 // GEMM as launched.  dl3p_set_option("gemm_nt" / "gemm_mi", v) pins a choice (v = 0: automatic) -- that is how the
 // tuner tries the candidates; ("gemm_tuned", 0) ignores the table.
 struct GemmTuned { int role, M, K, N, nt, mi, pc; };   // pc: persistent workgroups per CU (0 = by tile width)
+struct SbPays { int role, M, K, N, pays; };
 #include "gemm_tuned.h"
+#include "sb_tuned.h"
 static const GemmTuned* gemm_tuned_lookup(int role, int M, int K, int N) {
   if (g_gemm_use_table < 0) g_gemm_use_table = getenv("DL3P_GEMM_TUNED") ? atoi(getenv("DL3P_GEMM_TUNED")) : 1;
   if (!g_gemm_use_table) return nullptr;
+  if (role >= 5) {      // the split-bf16 kernel's rows (scripts/tune_split.py): role + 5
+    for (size_t i = 0; i < sizeof(g_sb_tuned) / sizeof(g_sb_tuned[0]); ++i) {
+      const GemmTuned& e = g_sb_tuned[i];
+      if (e.role == role && e.M == M && e.K == K && e.N == N) return &e;
+    }
+    return nullptr;
+  }
   for (size_t i = 0; i < sizeof(g_gemm_tuned) / sizeof(g_gemm_tuned[0]); ++i) {
     const GemmTuned& e = g_gemm_tuned[i];
     if (e.role == role && e.M == M && e.K == K && e.N == N) return &e;
@@ -1035,18 +1044,20 @@ static void gemm_plan_sb(int role, int M, int K, int N, int* nt, int* gx, int* g
   if (M >= 4096) force_mi = 2;
   if (role == 3 && N > 64) { *nt = 4; force_mi = 2; }
   int wide_nt = 0, wide_mi = 2, wide_wm = 1;
-  if (const GemmTuned* e = gemm_tuned_lookup(role + 5, M, K, N)) {      // roles 5..8; pc > 100: wide family, wm = pc - 100
-    if (e->pc > 100) { wide_nt = e->nt; wide_mi = e->mi; wide_wm = e->pc - 100; }
+  bool measured = false;
+  bool wide_bnb = false;
+  if (const GemmTuned* e = gemm_tuned_lookup(role + 5, M, K, N)) {      // roles 5..8 (csrc/sb_tuned.h); pc > 100: wide family, wm = pc - 100
+    measured = true;
+    if (e->pc > 100) { wide_nt = e->nt; wide_mi = e->mi; wide_wm = e->pc - 100; wide_bnb = true; }
     else { wide_nt = 0; *nt = e->nt; force_mi = e->mi; force_pc = e->pc; }
   }
   // long forwards onto 256-column layers: 128 rows x 256 columns, 512 threads, one workgroup per CU (the A tile is split once for
   // all of N): 306 against 335 us on 266256 x 304 -> 256, 255 against 278 on K = 256, 98 against 107 on 74498 rows -- since the
   // operand requests stopped being drained at every stage (pw_split.hip, the note in step()); before that the wide tiles tied
-  if (!wide_nt && role <= 1 && N % 256 == 0 && M >= 65536) { wide_nt = 16; wide_mi = 1; wide_wm = 2; }
+  if (!measured && role <= 1 && N % 256 == 0 && M >= 65536) { wide_nt = 16; wide_mi = 1; wide_wm = 2; }
   // the long decoder data gradients with the fused BatchNorm sums: 256 rows x 128 columns, 512 threads (334 against 368 us on
   // 266256 x 256 -> 256, 469 against 495 onto 304 columns; the 256-column tiles lose here -- the z tile of the sums comes on top)
-  bool wide_bnb = false;
-  if (!wide_nt && role == 3 && N >= 256 && M >= 131072) { wide_nt = 8; wide_mi = 2; wide_wm = 2; wide_bnb = true; }
+  if (!measured && role == 3 && N >= 256 && M >= 131072) { wide_nt = 8; wide_mi = 2; wide_wm = 2; wide_bnb = true; }
   if (g_sb_force_wm > 0) { wide_nt = g_sb_force_nt ? g_sb_force_nt : 16; wide_wm = g_sb_force_wm; wide_mi = g_gemm_force_mi ? g_gemm_force_mi : 2; }
   if (g_sb_force_wm < 0) wide_nt = 0;
   if (wide_nt && dl3p_sb_wide_config(wide_nt, wide_mi, wide_wm) && (role != 3 || wide_bnb || g_sb_force_wm > 0)) {     // (role 3 takes the wide family only where measured -- above -- or pinned)
@@ -1068,6 +1079,18 @@ static void gemm_plan_sb(int role, int M, int K, int N, int* nt, int* gx, int* g
   gemm_grid(M, N, *nt, gx, gy, num_m_tiles, mi, role == 3, force_mi, force_pc);
   // 128-row tiles with the fused BatchNorm sums spill from 80 columns up (two A register sets + the z prefetch)
   if (role == 3 && *mi == 2 && *nt > 4) gemm_grid(M, N, *nt, gx, gy, num_m_tiles, mi, true, 1, force_pc);
+}
+
+extern "C" int dl3p_pwconv_sb_pays(int role, int M, int K, int N) {
+  // measured verdict for this exact launch (csrc/sb_tuned.h): 1 the split kernel is faster than the fp32-input MFMA kernel,
+  // 0 it is not, -1 never measured (or the tables are switched off) -- the caller's threshold rule decides
+  if (g_gemm_use_table < 0) g_gemm_use_table = getenv("DL3P_GEMM_TUNED") ? atoi(getenv("DL3P_GEMM_TUNED")) : 1;
+  if (!g_gemm_use_table) return -1;
+  for (size_t i = 0; i < sizeof(g_sb_pays) / sizeof(g_sb_pays[0]); ++i) {
+    const SbPays& e = g_sb_pays[i];
+    if (e.role == role && e.M == M && e.K == K && e.N == N) return e.pays;
+  }
+  return -1;
 }
 
 extern "C" int dl3p_pwconv_sb_supported(int role, int M, int K, int N) {
@@ -2004,9 +2027,16 @@ extern "C" int dl3p_conv2d_gemm_bwd_weight_slabs(const float* x, int ldx, const 
 // ------------------------------------------------------------------------------ plan query (include/dl3p.h)
 // the same decisions the entry points above take, reported instead of launched
 extern "C" int dl3p_gemm_plan_query(int role, int M, int K, int N, int* out6) {
-  DL3P_CHECK_ARG(out6 && role >= 0 && role <= 4 && M > 0 && K > 0 && N > 0, "dl3p_gemm_plan_query: bad arguments");
+  DL3P_CHECK_ARG(out6 && role >= 0 && role <= 8 && M > 0 && K > 0 && N > 0, "dl3p_gemm_plan_query: bad arguments");
   for (int i = 0; i < 6; ++i) out6[i] = 0;
   SmallShape sh;
+  if (role >= 5) {      // the split-bf16 twin of role - 5: {3, nt, mi, wm (0 = producer / consumer form), workgroups, from table}
+    if (!dl3p_pwconv_sb_supported(role - 5, M, K, N)) { out6[0] = -1; return DL3P_OK; }
+    int nt, gx, gy, mt, mi, wm;
+    gemm_plan_sb(role - 5, M, K, N, &nt, &gx, &gy, &mt, &mi, &wm);
+    out6[0] = 3; out6[1] = nt; out6[2] = mi; out6[3] = wm; out6[4] = gx * gy; out6[5] = gemm_tuned_lookup(role, M, K, N) != nullptr;
+    return DL3P_OK;
+  }
   if (role == 4) {
     if (dl3p_pw_tiny_applies(M)) { out6[0] = 2; return DL3P_OK; }
     if (M >= 16 && wgrad_small_pick(K, N, &sh)) {

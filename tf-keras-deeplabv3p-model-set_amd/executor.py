@@ -1234,11 +1234,17 @@ class Executor:
         # long reduction (Xception's 4356 x 2048 -> 256) and narrow outputs (576 -> 96) are faster on the fp32-input MFMA kernel;
         # the data gradient with the fused BatchNorm sums only wins on the long decoder layers.
         env = os.environ.get
-        if kred < int(env('DL3P_SPLIT_MIN_K', '128')) or nout < int(env('DL3P_SPLIT_MIN_N', '128')):
-            return False
-        if M < int(env('DL3P_SPLIT_MIN_ROWS', '16384')) or (not fwd and stats and M < int(env('DL3P_SPLIT_MIN_ROWS_BN', '60000'))):
-            return False
         role = (1 if stats else 0) if fwd else (3 if stats else 2)
+        pinned = any(k in os.environ for k in ('DL3P_SPLIT_MIN_K', 'DL3P_SPLIT_MIN_N', 'DL3P_SPLIT_MIN_ROWS', 'DL3P_SPLIT_MIN_ROWS_BN'))
+        # the measured verdict for this exact launch where there is one (csrc/sb_tuned.h, scripts/tune_split.py), else the rule
+        pays = -1 if pinned else self.L.pwconv_sb_pays(role, M, kred, nout)
+        if pays == 0:
+            return False
+        if pays < 0:
+            if kred < int(env('DL3P_SPLIT_MIN_K', '128')) or nout < int(env('DL3P_SPLIT_MIN_N', '128')):
+                return False
+            if M < int(env('DL3P_SPLIT_MIN_ROWS', '16384')) or (not fwd and stats and M < int(env('DL3P_SPLIT_MIN_ROWS_BN', '60000'))):
+                return False
         if not self.L.pwconv_sb_supported(role, M, kred, nout):
             return False
         (self._sb_used_f if fwd else self._sb_used_b).add(op)       # the optimiser step refreshes these planes (_trace_sgd)
