@@ -24,7 +24,7 @@ WIDE = [(16, 1, 2), (16, 2, 1), (12, 2, 1), (8, 2, 2), (16, 1, 1)]
 
 
 def rule(role, M, K, N):
-    """the executor's threshold rule (Executor._use_sb)"""
+    """the executor's threshold rule (Executor._use_sb; role 4: wgrad_sb_route in pwconv.hip)"""
     return K >= 128 and N >= 128 and M >= 16384 and (role != 3 or M >= 60000)
 
 
@@ -146,23 +146,80 @@ def measure(role, M, K, N):
     return t32, res, best, bad
 
 
+def measure_wgrad(M, K, N):
+    """weight gradient: the fp32-input MFMA kernel (tables on) against pw_wgrad_sb_kernel over tile x workgroups-per-CU; cost = kernel
+    time + the slabs' share of the batched reduction (tune_gemm.py's rate) -> (fp32 us, {None | (tile, per_cu, 0): us}, best, refusal)"""
+    xs = [torch.randn(M, K, device=dev) for _ in range(3)]
+    gs = [torch.randn(M, N, device=dev) for _ in range(3)]
+    sc, sh = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.3
+    ws = torch.empty(96 << 20, device=dev)
+    rows = ctypes.c_int(0)
+    st = torch.cuda.current_stream().cuda_stream
+    i = [0]
+
+    def run():
+        i[0] = (i[0] + 1) % 3
+        L.pwconv_bwd_weight_slabs(xs[i[0]].data_ptr(), K, sc.data_ptr(), sh.data_ptr(), ops.ACT_RELU6, gs[i[0]].data_ptr(), N, ws.data_ptr(),
+                                  ws.numel() * 4, ctypes.byref(rows), M, K, N, st)
+
+    def cost():
+        t = T.timeit(run)
+        return t + rows.value * K * N * 4 / 3.3e6
+
+    def out():
+        i[0] = 0
+        run()
+        return ws[:rows.value * K * N].reshape(rows.value, K, N).double().sum(0)
+    L.set_option(b'gemm_tuned', 1)
+    L.set_option(b'split_wgrad', 0)
+    t32 = cost()
+    L.set_option(b'split_wgrad', 1)
+    L.set_option(b'gemm_tuned', 0)
+    res = {}
+    L.set_option(b'split_wgrad_tile', -1); L.set_option(b'split_wgrad_per_cu', 0)
+    # (pinned: the verdict tables are bypassed; the heuristic plan = tile -1 is what an unmeasured shape would get)
+    heur = (ctypes.c_int * 6)()
+    for tile in range(4):
+        for pc in (2, 3, 4, 6):
+            L.set_option(b'split_wgrad_tile', tile); L.set_option(b'split_wgrad_per_cu', pc)
+            res[(tile, pc, 0)] = cost()
+    # the heuristic's own pick: its tile at its workgroups per CU (pw_split.hip: dl3p_wgrad_sb_plan)
+    tk = [128, 64, 128, 64]; tn = [128, 128, 64, 64]
+    area = [((K + tk[i] - 1) // tk[i] * tk[i]) * ((N + tn[i] - 1) // tn[i] * tn[i]) * (1 + 0.5 * (64 / tk[i] + 64 / tn[i])) for i in range(4)]
+    ht = min(range(4), key=lambda i: area[i])
+    res[None] = res[(ht, 2 if ht == 0 else 4, 0)]
+    best = min((k for k in res if k is not None), key=lambda k: res[k])
+    bad = ''
+    if res[best] < 0.97 * res[None]:
+        L.set_option(b'split_wgrad_tile', ht); L.set_option(b'split_wgrad_per_cu', 2 if ht == 0 else 4)
+        ref = out()
+        L.set_option(b'split_wgrad_tile', best[0]); L.set_option(b'split_wgrad_per_cu', best[1])
+        got = out()
+        d = float((got - ref).abs().max())
+        if not torch.isfinite(got).all() or d > 3e-5 * M ** 0.5:
+            bad = 'max diff %.3g of %.3g' % (d, float(ref.abs().max()))
+    L.set_option(b'split_wgrad_tile', -1); L.set_option(b'split_wgrad_per_cu', 0)
+    L.set_option(b'gemm_tuned', 1)
+    return t32, res, best, bad
+
+
 def main():
     L.set_option(b'pw_small_min_rows', -1)
-    roles = {0, 1, 2, 3}
+    roles = {0, 1, 2, 3, 4}
     for a in sys.argv[1:]:
         if a.startswith('--roles='):
             roles = {int(v) for v in a.split('=')[1].split(',')}
     sh = T.shapes()
     tuned, pays, log = [], [], []
     for (role, M, K, N), mt in sorted(sh.items()):
-        if role not in roles or role > 3 or K < 64 or N < 64 or M < 4096 or M * max(K, N) * 4 >= (1 << 32):
+        if role not in roles or role > 4 or K < 64 or N < 64 or M < 4096 or M * max(K, N) * 4 >= (1 << 32):
             continue
         plan = (ctypes.c_int * 6)()
         L.gemm_plan_query(role, M, K, N, plan)
-        if plan[0] != 0 or not L.pwconv_sb_supported(role, M, K, N):
+        if plan[0] != 0 or (role < 4 and not L.pwconv_sb_supported(role, M, K, N)):
             continue
         try:
-            t32, res, best, bad = measure(role, M, K, N)
+            t32, res, best, bad = measure(role, M, K, N) if role < 4 else measure_wgrad(M, K, N)
         except Exception as e:      # noqa: BLE001
             log.append('skip %s: %s' % ((role, M, K, N), str(e)[:80]))
             continue
@@ -173,10 +230,10 @@ def main():
         log.append(line)
         print(line, flush=True)
         use_best = not bad and res[best] < 0.97 * res[None]
-        if use_best:
-            tuned.append((role + 5, M, K, N, best[0], best[1], best[2], res[None], res[best]))
         t_split = res[best] if use_best else res[None]
         verdict = 1 if t_split < 0.97 * t32 else 0
+        if use_best and verdict:          # (a tile row for a launch that stays on the fp32 kernel would never be read)
+            tuned.append((role + 5, M, K, N, best[0], best[1], best[2], res[None], res[best]))      # (weight gradient: role 9 {tile, per CU})
         if verdict != int(rule(role, M, K, N)):
             pays.append((role, M, K, N, verdict, t32, t_split))
     out = ['// GENERATED by scripts/tune_split.py on an MI355X -- the split-bf16 GEMM (pw_split.hip) per GEMM shape of the BASELINE graphs.',

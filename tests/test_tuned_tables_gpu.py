@@ -73,7 +73,12 @@ def test_every_split_gemm_table_row_is_reached_by_the_dispatcher():
         assert len(SB) > 100 and len(SB_PAYS) > 20
         dead = []
         for (role, M, K, N, nt, mi, pc) in SB:
-            assert 5 <= role <= 8
+            assert 5 <= role <= 9
+            if role == 9:       # the weight gradient: {tile index, workgroups per CU}
+                fam, q_tile, q_kf, slabs, tiles, from_table = _gemm_plan(L, 9, M, K, N)
+                if fam != 4 or not from_table or q_tile != nt or slabs < 1:
+                    dead.append(((role, M, K, N, nt, mi, pc), (fam, q_tile, q_kf, slabs, from_table)))
+                continue
             fam, q_nt, q_mi, q_wm, wgs, from_table = _gemm_plan(L, role, M, K, N)
             want_wm = pc - 100 if pc > 100 else 1
             if fam != 3 or not from_table or q_nt != nt or q_mi != mi or q_wm != want_wm:
@@ -217,13 +222,15 @@ def test_gemm_table_row_matches_float64(ops, row):
         role, M, K, N, nt, mi, pc = row
         plan = _gemm_plan(L, role, M, K, N)
         assert plan[0] == 0 and plan[5] == 1 and plan[1] == nt, plan
+        L.set_option(b'split_wgrad', 0)          # this row is the fp32-input MFMA kernel's (the split kernel has its own: SB, role 9)
         run_gemm_row(ops, role, M, K, N)
     finally:
+        L.set_option(b'split_wgrad', 1)
         L.set_option(b'pw_small_min_rows', 64)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('row', SB, ids=lambda r: 's%d_%dx%dx%d' % (r[0] - 5, r[1], r[2], r[3]))
+@pytest.mark.parametrize('row', SB, ids=lambda r: 's%d_%dx%dx%d' % (r[0] - 5, r[1], r[2], r[3]))      # (s4 = the weight gradient, role 9)
 def test_split_gemm_table_row_matches_float64(ops, row):
     """every tile row of csrc/sb_tuned.h at its exact launch shape, at the bounds of the fp32-input MFMA kernel's rows"""
     L = _lib()
@@ -232,8 +239,13 @@ def test_split_gemm_table_row_matches_float64(ops, row):
     try:
         role, M, K, N, nt, mi, pc = row
         plan = _gemm_plan(L, role, M, K, N)
-        assert plan[0] == 3 and plan[5] == 1 and plan[1] == nt and plan[2] == mi, plan
-        run_gemm_row(ops, role - 5, M, K, N, split=True)
+        if role == 9:       # weight gradient: dl3p_pwconv_bwd_weight takes the split kernel by itself (wgrad_sb_route)
+            L.set_option(b'split_wgrad', 1)
+            assert plan[0] == 4 and plan[5] == 1 and plan[1] == nt, plan
+            run_gemm_row(ops, 4, M, K, N)
+        else:
+            assert plan[0] == 3 and plan[5] == 1 and plan[1] == nt and plan[2] == mi, plan
+            run_gemm_row(ops, role - 5, M, K, N, split=True)
     finally:
         L.set_option(b'pw_small_min_rows', 64)
 
@@ -284,6 +296,7 @@ def test_every_wgrad_tile_choice_is_correct(ops, tile, per_cu):
     L = _lib()
     L.set_option(b'wgrad_tile', tile)
     L.set_option(b'wgrad_per_cu', per_cu)
+    L.set_option(b'split_wgrad', 0)
     try:
         for (M, K, N) in [(70001, 100, 200), (9001, 304, 256), (2600, 728, 132)]:
             plan = _gemm_plan(L, 4, M, K, N)
@@ -292,6 +305,26 @@ def test_every_wgrad_tile_choice_is_correct(ops, tile, per_cu):
     finally:
         L.set_option(b'wgrad_tile', -1)
         L.set_option(b'wgrad_per_cu', 0)
+        L.set_option(b'split_wgrad', 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('per_cu', [1, 2, 3, 4, 6])
+@pytest.mark.parametrize('tile', [0, 1, 2, 3])
+def test_every_split_wgrad_tile_choice_is_correct(ops, tile, per_cu):
+    """pw_wgrad_sb_kernel: 128 x 128 (waves 2 x 2), 64 x 128, 128 x 64, 64 x 64 tiles x workgroups per CU, ragged M / K / N"""
+    L = _lib()
+    L.set_option(b'split_wgrad', 1)
+    L.set_option(b'split_wgrad_tile', tile)
+    L.set_option(b'split_wgrad_per_cu', per_cu)
+    try:
+        for (M, K, N) in [(70001, 100, 200), (9001, 304, 256), (2600, 728, 132), (33333, 132, 68)]:
+            plan = _gemm_plan(L, 9, M, K, N)
+            assert plan[0] == 4 and plan[1] == tile, plan
+            run_gemm_row(ops, 4, M, K, N, seed=tile * 8 + per_cu)
+    finally:
+        L.set_option(b'split_wgrad_tile', -1)
+        L.set_option(b'split_wgrad_per_cu', 0)
 
 
 # ------------------------------------------------------------------------------------------------ depthwise rows

@@ -917,3 +917,204 @@ void dl3p_launch_gemm_sb(const GemmParams& p, bool stats, bool bnb, bool ga, int
   DL3P_SB(false, false, false)
 #undef DL3P_SB
 }
+
+// ------------------------------------------------------------------------------ weight gradient
+// GW[K][N] = act(X * scale + shift)^T @ DY over M rows, both operands fp32 ACTIVATIONS: each is split by the thread that stages it
+// (the prologue first, in fp32) into three bf16 planes in LDS, [32 rows of M][tile columns]; the MFMA operands -- 16 output rows /
+// columns x 32 rows of M -- come out of LDS transposed (ds_read_b64_tr_b16).  One workgroup = TK x TN entries of GW over a slice of
+// M; the slices leave fp32 slabs for the batched slab reduction (same contract as pw_wgrad_kernel: dl3p_pwconv_bwd_weight_slabs).
+// A 128 x 128 tile reads (128 + 128) x 4 B per row of M for 2 x 128 x 128 flop: 32 flop / B against 21 for the fp32 kernel's widest.
+struct WgradSB {
+  const float* X; int ldx; const float* scale; const float* shift; int act;
+  const float* DY; int lddy;
+  float* slabs;
+  int M, K, N;
+  int ktiles, ntiles, mrows;      // rows of M per slice (multiple of 32)
+};
+
+typedef short s16x4w __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4w tr_read16(const unsigned short* lds_ptr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4w __attribute__((address_space(3)))*)lds_ptr);
+}
+
+// WN: the four waves as (4 / WN) x WN over (k, n): a wave owns KFW = KF WN sixteen-row blocks of k and NWW = NW / WN column blocks, and
+// reads 6 (KFW + NWW) fragments from LDS per step for 6 KFW NWW MFMAs -- 2 x 2 halves the LDS reads of the 4 x 1 arrangement at 128 x 128
+template <int KF, int NW, int WN>
+__global__ __launch_bounds__(256, 2) void pw_wgrad_sb_kernel(WgradSB p) {
+  constexpr int TK = 64 * KF, TN = 16 * NW, MS = 32;
+  constexpr int KFW = KF * WN, NWW = NW / WN;
+  constexpr int XP = TK + 8, DP = TN + 8;             // bf16 pitches: 16-byte aligned rows
+  constexpr int X_PLANE = MS * XP, D_PLANE = MS * DP;
+  constexpr int XCPR = TK / 8, DCPR = TN / 8;         // 8-element chunks per tile row
+  constexpr int XROWS = 256 / XCPR, DROWS = 256 / DCPR;   // rows staged per pass
+  constexpr int NXP = MS / XROWS, NDP = MS / DROWS;
+  __shared__ __attribute__((aligned(16))) unsigned short Xs[3 * X_PLANE];
+  __shared__ __attribute__((aligned(16))) unsigned short Ds[3 * D_PLANE];
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int wk = w / WN, wn = w - wk * WN;
+  const int tile = blockIdx.x, kt = tile / p.ntiles, nt = tile - kt * p.ntiles;
+  const int k0 = kt * TK, n0 = nt * TN;
+  const int mbeg = blockIdx.y * p.mrows, mend = min(p.M, mbeg + p.mrows);
+  const int xm = t / XCPR, xc = (t - xm * XCPR) * 8;
+  const int dm = t / DCPR, dc = (t - dm * DCPR) * 8;
+  const int xk = k0 + xc, dn = n0 + dc;
+  const bool xok0 = xk < p.K, xok1 = xk + 4 < p.K, dok0 = dn < p.N, dok1 = dn + 4 < p.N;
+  const int xk0 = min(xk, p.K - 4), xk1 = min(xk + 4, p.K - 4), dn0 = min(dn, p.N - 4), dn1 = min(dn + 4, p.N - 4);
+  const float* scp = p.scale ? p.scale : p.X;
+  const float* shp = p.scale ? p.shift : p.X;
+  const float4 sc0 = ld4(scp + xk0), sc1 = ld4(scp + xk1), sh0 = ld4(shp + xk0), sh1 = ld4(shp + xk1);
+  const float act_lo = p.act == DL3P_ACT_NONE ? -DL3P_INF : 0.f;
+  const float act_hi = (p.act == DL3P_ACT_NONE || p.act == DL3P_ACT_RELU) ? DL3P_INF : 6.f;
+  auto prologue4 = [&](float4 v, float4 sc4, float4 sh4) __attribute__((always_inline)) {
+    if (p.scale) v = fma4(v, sc4, sh4);
+    if (p.act >= DL3P_ACT_HSWISH) return act_apply4(v, p.act);
+    return make_float4(__builtin_amdgcn_fmed3f(v.x, act_lo, act_hi), __builtin_amdgcn_fmed3f(v.y, act_lo, act_hi),
+                       __builtin_amdgcn_fmed3f(v.z, act_lo, act_hi), __builtin_amdgcn_fmed3f(v.w, act_lo, act_hi));
+  };
+  const bool has_pro = p.scale != nullptr || p.act != DL3P_ACT_NONE;
+
+  f32x4 acc[KFW][NWW];
+#pragma unroll
+  for (int kf = 0; kf < KFW; ++kf)
+#pragma unroll
+    for (int ni = 0; ni < NWW; ++ni) acc[kf][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 rx[NXP][2], rd[NDP][2];
+  // every request unconditional on clamped indices (see the note at the prefetches of pw_gemm_sb_kernel)
+  auto prefetch = [&](int m0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NXP; ++i) {
+      const float* xr = p.X + (size_t)min(m0 + xm + XROWS * i, p.M - 1) * p.ldx;
+      rx[i][0] = ld4(xr + xk0); rx[i][1] = ld4(xr + xk1);
+    }
+#pragma unroll
+    for (int i = 0; i < NDP; ++i) {
+      const float* dr = p.DY + (size_t)min(m0 + dm + DROWS * i, p.M - 1) * p.lddy;
+      rd[i][0] = ld4(dr + dn0); rd[i][1] = ld4(dr + dn1);
+    }
+  };
+  // transposed-read lanes: lane (g = l >> 4, q = (l & 15) >> 2, pp = l & 3) supplies rows 8 g + q and 8 g + 4 + q, columns 4 pp .. 4 pp + 3
+  const int g = l >> 4, q = (l & 15) >> 2, pp = l & 3;
+  const int r0 = (8 * g + q), r1 = (8 * g + 4 + q);
+  const int nsteps = (mend - mbeg + MS - 1) / MS;
+  if (nsteps > 0) prefetch(mbeg);
+  for (int s = 0; s < nsteps; ++s) {
+    const int m0 = mbeg + s * MS;
+#pragma unroll
+    for (int i = 0; i < NXP; ++i) {
+      float4 v0 = rx[i][0], v1 = rx[i][1];
+      if (has_pro) { v0 = prologue4(v0, sc0, sh0); v1 = prologue4(v1, sc1, sh1); }
+      const bool rok = m0 + xm + XROWS * i < mend;
+      if (!(rok && xok0)) v0 = zero4();
+      if (!(rok && xok1)) v1 = zero4();
+      uint4 hh, mm, ll;
+      split2(v0.x, v0.y, hh.x, mm.x, ll.x);
+      split2(v0.z, v0.w, hh.y, mm.y, ll.y);
+      split2(v1.x, v1.y, hh.z, mm.z, ll.z);
+      split2(v1.z, v1.w, hh.w, mm.w, ll.w);
+      unsigned short* d = Xs + (xm + XROWS * i) * XP + xc;
+      *reinterpret_cast<uint4*>(d) = hh;
+      *reinterpret_cast<uint4*>(d + X_PLANE) = mm;
+      *reinterpret_cast<uint4*>(d + 2 * X_PLANE) = ll;
+    }
+#pragma unroll
+    for (int i = 0; i < NDP; ++i) {
+      float4 v0 = rd[i][0], v1 = rd[i][1];
+      const bool rok = m0 + dm + DROWS * i < mend;
+      if (!(rok && dok0)) v0 = zero4();
+      if (!(rok && dok1)) v1 = zero4();
+      uint4 hh, mm, ll;
+      split2(v0.x, v0.y, hh.x, mm.x, ll.x);
+      split2(v0.z, v0.w, hh.y, mm.y, ll.y);
+      split2(v1.x, v1.y, hh.z, mm.z, ll.z);
+      split2(v1.z, v1.w, hh.w, mm.w, ll.w);
+      unsigned short* d = Ds + (dm + DROWS * i) * DP + dc;
+      *reinterpret_cast<uint4*>(d) = hh;
+      *reinterpret_cast<uint4*>(d + D_PLANE) = mm;
+      *reinterpret_cast<uint4*>(d + 2 * D_PLANE) = ll;
+    }
+    lds_barrier();
+    prefetch(mbeg + min(s + 1, nsteps - 1) * MS);
+    s16x8 af[KFW][3];
+#pragma unroll
+    for (int kf = 0; kf < KFW; ++kf)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        const unsigned short* b = Xs + pl * X_PLANE + (wk * KFW + kf) * 16 + 4 * pp;
+        const s16x4w a0 = tr_read16(b + r0 * XP), a1 = tr_read16(b + r1 * XP);
+        af[kf][pl] = (s16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      }
+#pragma unroll
+    for (int ni = 0; ni < NWW; ++ni) {
+      s16x8 bf[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        const unsigned short* b = Ds + pl * D_PLANE + (wn * NWW + ni) * 16 + 4 * pp;
+        const s16x4w b0 = tr_read16(b + r0 * DP), b1 = tr_read16(b + r1 * DP);
+        bf[pl] = (s16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      }
+#pragma unroll
+      for (int kf = 0; kf < KFW; ++kf) {
+        f32x4 c = acc[kf][ni];      // smallest terms first
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kf][2], bf[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kf][0], bf[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kf][1], bf[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kf][1], bf[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kf][0], bf[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kf][0], bf[0], c, 0, 0, 0);
+        acc[kf][ni] = c;
+      }
+    }
+    lds_barrier();
+  }
+  // D[row = 4 (l >> 4) + j -> k][col = l & 15 -> n]
+  float* slab = p.slabs + (size_t)blockIdx.y * p.K * p.N;
+#pragma unroll
+  for (int kf = 0; kf < KFW; ++kf)
+#pragma unroll
+    for (int ni = 0; ni < NWW; ++ni) {
+      const int n = n0 + (wn * NWW + ni) * 16 + (l & 15);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = k0 + (wk * KFW + kf) * 16 + 4 * g + j;
+        if (k < p.K && n < p.N) slab[(size_t)k * p.N + n] = acc[kf][ni][j];
+      }
+    }
+}
+
+// tile (64 KF x 16 NW; index into {128x128, 64x128, 128x64, 64x64}) and slices for one launch; -> number of slabs (0: shape not
+// served).  max_slabs: what the caller's workspace holds; tile < 0 / per_cu <= 0: the heuristics (measured: scripts/micro/sb_wgrad.py)
+int dl3p_wgrad_sb_plan(int M, int K, int N, int max_slabs, int tile, int per_cu, int* kf, int* nw, int* ktiles, int* ntiles, int* mrows) {
+  if (M < 1024 || K < 32 || N < 32 || K % 4 || N % 4 || max_slabs < 1) return 0;
+  static const int cand[4][2] = {{2, 8}, {1, 8}, {2, 4}, {1, 4}};
+  float best = 1e30f;
+  for (int i = 0; i < 4; ++i) {
+    const int tk = 64 * cand[i][0], tn = 16 * cand[i][1];
+    const float area = (float)((K + tk - 1) / tk * tk) * (float)((N + tn - 1) / tn * tn);
+    const float cost = area * (1.f + 0.5f * (64.f / tk + 64.f / tn));
+    if ((tile < 0 && cost < best) || tile == i) { best = cost; *kf = cand[i][0]; *nw = cand[i][1]; }
+  }
+  *ktiles = (K + 64 * *kf - 1) / (64 * *kf);
+  *ntiles = (N + 16 * *nw - 1) / (16 * *nw);
+  const int tiles = *ktiles * *ntiles;
+  if (per_cu <= 0) per_cu = (*kf == 2 && *nw == 8) ? 2 : 4;      // 128 x 128: two resident workgroups per CU (registers)
+  int s = (DL3P_NUM_CUS * per_cu) / tiles;
+  if (s < 1) s = 1;
+  const int max_s = (M + 255) / 256;
+  if (s > max_s) s = max_s;
+  if (s > max_slabs) s = max_slabs;
+  const int chunk = ((M + s - 1) / s + 31) / 32 * 32;
+  *mrows = chunk;
+  return (M + chunk - 1) / chunk;
+}
+
+void dl3p_launch_wgrad_sb(const float* x, int ldx, const float* scale, const float* shift, int act, const float* dy, int lddy,
+                          float* slabs, int M, int K, int N, int kf, int nw, int ktiles, int ntiles, int mrows, int splits, hipStream_t st) {
+  WgradSB p = {x, ldx, scale, shift, act, dy, lddy, slabs, M, K, N, ktiles, ntiles, mrows};
+  const dim3 grid(ktiles * ntiles, splits), block(256);
+  // the 128 x 128 tile with its waves 2 x 2 (247-258 against 270-278 us on 266256 x 256 x 256); 64 x 128 stays 4 x 1 (2 x 2 costs it
+  // a resident workgroup: 327 against 284)
+  if (kf == 2 && nw == 8) dl3p_launch(pw_wgrad_sb_kernel<2, 8, 2>, grid, block, 0, st, p);
+  else if (kf == 1 && nw == 8) dl3p_launch(pw_wgrad_sb_kernel<1, 8, 1>, grid, block, 0, st, p);
+  else if (kf == 2 && nw == 4) dl3p_launch(pw_wgrad_sb_kernel<2, 4, 1>, grid, block, 0, st, p);
+  else dl3p_launch(pw_wgrad_sb_kernel<1, 4, 1>, grid, block, 0, st, p);
+}

@@ -615,6 +615,8 @@ static bool pw_small_pick(int K, int N, SmallShape* out) {
 // tests lower it through dl3p_set_option so that small test shapes reach those kernels too, and reset it for the
 // tests that check the production dispatch at the production shapes.
 static int g_gemm_force_nt = 0, g_gemm_force_mi = 0, g_gemm_force_pc = 0, g_gemm_use_table = -1;   // see gemm_tuned_lookup / gemm_plan
+static int g_split_wgrad = -1;      // dl3p_set_option("split_wgrad", 0 | 1): weight gradients on the split-bf16 kernel (default DL3P_SPLIT_WGRAD, else DL3P_SPLIT_GEMM, else 1)
+static int g_sbw_force_tile = -1, g_sbw_force_pc = 0;      // "split_wgrad_tile" (0..3, -1 none) / "split_wgrad_per_cu": pin its plan (and bypass the verdicts)
 static int g_sb_pipe = -1;      // dl3p_set_option("sb_pipe", 0 | 1): the producer / consumer form of the split kernel (default DL3P_SB_PIPE or 0)
 static int g_sb_force_wm = 0, g_sb_force_nt = 0;      // dl3p_set_option("sb_wm" / "sb_nt"): pin the split kernel's wide-tile family (gemm_plan_sb)
 static int g_wgrad_force_tile = -1, g_wgrad_force_per_cu = 0;                    // see wgrad_pick_tile / wgrad_split
@@ -635,6 +637,9 @@ extern "C" int dl3p_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm_per_cu")) { g_gemm_force_pc = value > 0 ? value : 0; return DL3P_OK; }
   if (!strcmp(name, "gemm_tuned")) { g_gemm_use_table = value ? 1 : 0; return DL3P_OK; }
   if (!strcmp(name, "sb_pipe")) { g_sb_pipe = value ? 1 : 0; return DL3P_OK; }
+  if (!strcmp(name, "split_wgrad")) { g_split_wgrad = value ? 1 : 0; return DL3P_OK; }
+  if (!strcmp(name, "split_wgrad_tile")) { g_sbw_force_tile = (value >= 0 && value <= 3) ? value : -1; return DL3P_OK; }
+  if (!strcmp(name, "split_wgrad_per_cu")) { g_sbw_force_pc = value > 0 ? value : 0; return DL3P_OK; }
   if (!strcmp(name, "sb_wm")) { g_sb_force_wm = (value >= -1 && value <= 2) ? value : 0; return DL3P_OK; }    // -1: never wide
   if (!strcmp(name, "sb_nt")) { g_sb_force_nt = (value == 8 || value == 12 || value == 16) ? value : 0; return DL3P_OK; }
   if (!strcmp(name, "dw_per_cu")) { dl3p_dw_force_per_cu = value > 0 ? value : 0; return DL3P_OK; }
@@ -1012,6 +1017,28 @@ extern "C" int dl3p_pwconv_bwd_data_bn(const float* dy, int lddy, const float* w
 // multiple of 32 with zero padding), the activations are split while their tile is staged.  Shapes the tiled kernel does not serve
 // (few rows, or few-channel layers on the streaming kernels) must go through the fp32 entry points: *_sb_supported says which.
 void dl3p_launch_gemm_sb(const GemmParams& p, bool stats, bool bnb, bool ga, int nt, int mi, int wm, dim3 grid, hipStream_t st);
+int dl3p_wgrad_sb_plan(int M, int K, int N, int max_slabs, int tile, int per_cu, int* kf, int* nw, int* ktiles, int* ntiles, int* mrows);
+void dl3p_launch_wgrad_sb(const float* x, int ldx, const float* scale, const float* shift, int act, const float* dy, int lddy,
+                          float* slabs, int M, int K, int N, int kf, int nw, int ktiles, int ntiles, int mrows, int splits, hipStream_t st);
+static bool split_wgrad_on() {      // follows the switch of the split forward / data-gradient GEMMs unless set itself
+  if (g_split_wgrad < 0)
+    g_split_wgrad = getenv("DL3P_SPLIT_WGRAD") ? atoi(getenv("DL3P_SPLIT_WGRAD")) : (getenv("DL3P_SPLIT_GEMM") ? atoi(getenv("DL3P_SPLIT_GEMM")) : 1);
+  return g_split_wgrad > 0;
+}
+extern "C" int dl3p_pwconv_sb_pays(int role, int M, int K, int N);
+// does this weight gradient run on the split-bf16 kernel?  -> slabs (0: no) + its plan.  The measured verdict / tile of this exact
+// launch where there is one (csrc/sb_tuned.h: g_sb_pays role 4, g_sb_tuned role 9 {tile, workgroups per CU}), else the rule
+static int wgrad_sb_route(int M, int K, int N, size_t max_slabs, int* kf, int* nw, int* kt, int* nt, int* mrows) {
+  if (!split_wgrad_on()) return 0;
+  int tile = g_sbw_force_tile, per_cu = g_sbw_force_pc;
+  if (tile < 0 && per_cu <= 0) {
+    const int pays = dl3p_pwconv_sb_pays(4, M, K, N);
+    if (pays == 0 || (pays < 0 && (K < 128 || N < 128 || M < 16384))) return 0;
+    if (const GemmTuned* e = gemm_tuned_lookup(9, M, K, N)) { tile = e->nt; per_cu = e->mi; }
+  }
+  if (max_slabs > (size_t)DL3P_MAX_STAT_ROWS) max_slabs = DL3P_MAX_STAT_ROWS;
+  return dl3p_wgrad_sb_plan(M, K, N, (int)max_slabs, tile, per_cu, kf, nw, kt, nt, mrows);
+}
 bool dl3p_sb_wide_config(int nt, int mi, int wm);
 void dl3p_launch_gemm_sbp(const GemmParams& p, bool stats, bool bnb, int nt, int mi, dim3 grid, hipStream_t st);
 
@@ -1700,6 +1727,11 @@ extern "C" size_t dl3p_pwconv_bwd_weight_workspace(int M, int K, int N) {
   size_t a = (size_t)s * K * N;
   SmallShape sh;
   if (wgrad_small_pick(K, N, &sh)) a = (size_t)wgrad_small_grid(M, sh.kt, sh.ntn) * K * N;
+  else {
+    int kf, nw, kt2, nt2, mrows;
+    const size_t s2 = (size_t)wgrad_sb_route(M, K, N, DL3P_MAX_STAT_ROWS, &kf, &nw, &kt2, &nt2, &mrows) * K * N;
+    if (s2 > a) a = s2;
+  }
   size_t b = (size_t)512 * N;  // bias column-sum partial rows
   return (a > b ? a : b) * sizeof(float);
 }
@@ -1736,8 +1768,16 @@ static int pwconv_bwd_weight_impl(const float* x, int ldx, const float* in_scale
     splits = wgrad_small_grid(M, sh.kt, sh.ntn);
     launch_wgrad_small_any(p, sh, splits, st);
   } else {
-    wgrad_split(M, K, N, &p.ktiles, &p.ntiles, &splits, &p.mchunk);
-    launch_wgrad_tiled<false>(p, splits, st);
+    // fp32-accurate on the bf16 matrix pipe (pw_split.hip, pw_wgrad_sb_kernel): both operands split while they are staged
+    int kf, nw, kt2, nt2, mrows, s2 = 0;
+    s2 = wgrad_sb_route(M, K, N, workspace_bytes / ((size_t)K * N * 4), &kf, &nw, &kt2, &nt2, &mrows);
+    if (s2 > 0) {
+      splits = s2;
+      dl3p_launch_wgrad_sb(x, ldx, in_scale, in_shift, in_act, dy, lddy, workspace, M, K, N, kf, nw, kt2, nt2, mrows, s2, st);
+    } else {
+      wgrad_split(M, K, N, &p.ktiles, &p.ntiles, &splits, &p.mchunk);
+      launch_wgrad_tiled<false>(p, splits, st);
+    }
   }
   DL3P_CHECK_LAUNCH("dl3p_pwconv_bwd_weight");
   if (rows_out) { *rows_out = splits; return DL3P_OK; }
@@ -2027,9 +2067,16 @@ extern "C" int dl3p_conv2d_gemm_bwd_weight_slabs(const float* x, int ldx, const 
 // ------------------------------------------------------------------------------ plan query (include/dl3p.h)
 // the same decisions the entry points above take, reported instead of launched
 extern "C" int dl3p_gemm_plan_query(int role, int M, int K, int N, int* out6) {
-  DL3P_CHECK_ARG(out6 && role >= 0 && role <= 8 && M > 0 && K > 0 && N > 0, "dl3p_gemm_plan_query: bad arguments");
+  DL3P_CHECK_ARG(out6 && role >= 0 && role <= 9 && M > 0 && K > 0 && N > 0, "dl3p_gemm_plan_query: bad arguments");
   for (int i = 0; i < 6; ++i) out6[i] = 0;
   SmallShape sh;
+  if (role == 9) {      // the split-bf16 weight gradient: {4, tile index, 64-row blocks of k per tile, slabs, k tiles x n tiles, from table}; -1: not taken
+    int kf, nw, kt, nt, mrows;
+    const int s = (dl3p_pw_tiny_applies(M) || (M >= 16 && wgrad_small_pick(K, N, &sh))) ? 0 : wgrad_sb_route(M, K, N, DL3P_MAX_STAT_ROWS, &kf, &nw, &kt, &nt, &mrows);
+    if (s <= 0) { out6[0] = -1; return DL3P_OK; }
+    out6[0] = 4; out6[1] = (kf == 2 ? 0 : 1) + (nw == 8 ? 0 : 2); out6[2] = kf; out6[3] = s; out6[4] = kt * nt; out6[5] = gemm_tuned_lookup(9, M, K, N) != nullptr;
+    return DL3P_OK;
+  }
   if (role >= 5) {      // the split-bf16 twin of role - 5: {3, nt, mi, wm (0 = producer / consumer form), workgroups, from table}
     if (!dl3p_pwconv_sb_supported(role - 5, M, K, N)) { out6[0] = -1; return DL3P_OK; }
     int nt, gx, gy, mt, mi, wm;
