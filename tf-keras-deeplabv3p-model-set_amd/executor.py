@@ -391,6 +391,10 @@ class Executor:
         self.bf16 = bool(getattr(store, 'bf16', False))
         self.adt = torch.bfloat16 if self.bf16 else torch.float32
         self._sb_used_f, self._sb_used_b = set(), set()      # pointwise convs whose forward / data gradient took the split GEMM
+        # the weight gradients pick the split kernel inside the library (dl3p_pwconv_bwd_weight[_slabs], wgrad_sb_route): the switch
+        # is process-wide there, so every executor states its own before it sizes workspaces, traces, or runs eagerly
+        self._split_wgrad = int(split_gemm_enabled() and not self.bf16 and os.environ.get('DL3P_SPLIT_WGRAD', '1') not in ('', '0'))
+        self.L.set_option(b'split_wgrad', self._split_wgrad)
         self._alloc()
         # tracing runs every kernel once on zero inputs: keep the weights / optimiser state intact
         snap_p, snap_v, snap_step, snap_ostep = store.P.clone(), store.V.clone(), store.step.clone(), store.opt_step.clone()
@@ -1562,6 +1566,7 @@ class Executor:
     def capture(self):
         """capture the traced plans into hipGraphs (done once, after a warm-up eager step)"""
         torch.cuda.synchronize()
+        self.L.set_option(b'split_wgrad', self._split_wgrad)      # (the capture re-issues every C call)
         # the trace already ran every kernel once; undo its side effects on the step counter only
         in_graph = os.environ.get('DL3P_COLLECTIVES_IN_GRAPH', '1') != '0'     # 0: force the segmented fallback
         for plan in ([self.fwd, self.bwd, self.opt] if self.training else [self.fwd]):
@@ -1577,6 +1582,8 @@ class Executor:
 
     def train_step(self):
         self._sb_sync()
+        if not self.graphed:
+            self.L.set_option(b'split_wgrad', self._split_wgrad)
         self.fwd.run()
         self.bwd.run()
         self.opt.run()
