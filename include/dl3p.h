@@ -98,7 +98,7 @@ int dl3p_comm_destroy(void* comm);
  * bf16 pieces (a = a1 + a2 + a3) and the product accumulated in fp32 from the six cross terms down to 2^-16 on
  * v_mfma_f32_16x16x32_bf16 -- the dropped terms are below one fp32 product rounding -- at 6/16 of the fp32-input MFMA's cost.
  * The conv kernel is handed over pre-split: dl3p_split_bf16x3_batch writes, for every table row {source offset (floats), rows,
- * cols, source row pitch, destination offset (bf16 elements), destination pitch}, the planes [3][rows][pitch] of
+ * cols, source row pitch, destination offset (bf16 elements, a multiple of 8), destination pitch}, the planes [3][rows][pitch] of
  * src[rows][cols] (pitch a multiple of 32, zero padded).  rows = the GEMM's OUTPUT columns, cols = its reduction length:
  * the transposed kernel wt[N][K] for the forward, the kernel w[K][N] as stored for the data gradient.
  * dl3p_pwconv_sb_supported(role, M, K, N) (roles and (M, K, N) as dl3p_gemm_plan_query): 0 for shapes the tiled kernel does

@@ -64,18 +64,28 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* src, uns
   const long long* e = table + (size_t)blockIdx.x * 6;
   const long long soff = e[0], doff = e[4];
   const int rows = (int)e[1], cols = (int)e[2], ld = (int)e[3], pitch = (int)e[5];
-  const int p2 = pitch / 2;
+  const int p8 = pitch / 8;       // (pitch is a multiple of 32) eight elements per thread: two 16-byte loads, three 16-byte stores
   const long long plane = (long long)rows * pitch;
-  for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < (long long)rows * p2; i += (long long)gridDim.y * 256) {
-    const int r = (int)(i / p2), c = (int)(i - (long long)r * p2) * 2;
-    const float x = c < cols ? src[soff + (long long)r * ld + c] : 0.f;
-    const float y = c + 1 < cols ? src[soff + (long long)r * ld + c + 1] : 0.f;
-    uint32_t h, m, l;
-    split2(x, y, h, m, l);
-    uint32_t* d = reinterpret_cast<uint32_t*>(dst + doff + (long long)r * pitch + c);
-    d[0] = h;
-    *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned short*>(d) + plane) = m;
-    *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned short*>(d) + 2 * plane) = l;
+  for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < (long long)rows * p8; i += (long long)gridDim.y * 256) {
+    const int r = (int)(i / p8), c = (int)(i - (long long)r * p8) * 8;
+    const long long so = soff + (long long)r * ld + c;
+    float v[8];
+    if (c + 8 <= cols && (so & 3) == 0) {
+      const float4 a = *reinterpret_cast<const float4*>(src + so), b = *reinterpret_cast<const float4*>(src + so + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = c + k < cols ? src[so + k] : 0.f;
+    }
+    uint4 h, m, l;
+    split2(v[0], v[1], h.x, m.x, l.x);
+    split2(v[2], v[3], h.y, m.y, l.y);
+    split2(v[4], v[5], h.z, m.z, l.z);
+    split2(v[6], v[7], h.w, m.w, l.w);
+    unsigned short* d = dst + doff + (long long)r * pitch + c;      // 16-byte aligned: doff and pitch are multiples of 8 elements
+    *reinterpret_cast<uint4*>(d) = h;
+    *reinterpret_cast<uint4*>(d + plane) = m;
+    *reinterpret_cast<uint4*>(d + 2 * plane) = l;
   }
 }
 
