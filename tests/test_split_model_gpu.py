@@ -18,7 +18,12 @@ def split_on(monkeypatch):
     monkeypatch.setenv('DL3P_SPLIT_MIN_N', '16')
     monkeypatch.setenv('DL3P_SPLIT_MIN_ROWS', '64')
     monkeypatch.setenv('DL3P_SPLIT_MIN_ROWS_BN', '64')
+    # ... and every weight gradient the tiled kernel serves (>= 1024 rows) onto pw_wgrad_sb_kernel: a pinned plan bypasses its
+    # verdict table / row threshold (pwconv.hip, wgrad_sb_route)
+    L = load_pkg('_lib').lib()
+    L.set_option(b'split_wgrad_per_cu', 2)
     yield
+    L.set_option(b'split_wgrad_per_cu', 0)
 
 
 def _uses_split(m):
@@ -47,6 +52,7 @@ def test_train_step_513_with_split_gemms(model_type, monkeypatch):
         monkeypatch.delenv(k)
     import test_production_shapes_gpu as T
     L = load_pkg('_lib').lib()
+    L.set_option(b'split_wgrad_per_cu', 0)        # the weight gradients by their own table / rule, as in production
     L.set_option(b'pw_small_min_rows', -1)
     try:
         T.test_train_step_513_production_dispatch(model_type)
@@ -67,6 +73,12 @@ def test_the_split_path_is_actually_taken():
     ex = m._executor(2, True)
     names = [lab[0] for lab in ex.fwd.labels + ex.bwd.labels + ex.opt.labels]
     assert any('pwconv_bwd_data_sb' in n for n in names) and any('split_bf16x3_batch' in n for n in names)
+    # the weight gradients too (decided inside the library): the 2 x 33 x 33-row layers of this model report the split plan
+    import ctypes
+    out = (ctypes.c_int * 6)()
+    L = load_pkg('_lib').lib()
+    L.gemm_plan_query(9, 2 * 33 * 33, 96, 144, out)      # (rows, cin, cout) of a tiled-kernel layer at this size
+    assert out[0] == 4, list(out)
 
 
 @pytest.mark.parametrize('model_type', ['mobilenetv2', 'xception'])
