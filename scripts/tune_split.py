@@ -177,8 +177,7 @@ def measure_wgrad(M, K, N):
     L.set_option(b'gemm_tuned', 0)
     res = {}
     L.set_option(b'split_wgrad_tile', -1); L.set_option(b'split_wgrad_per_cu', 0)
-    # (pinned: the verdict tables are bypassed; the heuristic plan = tile -1 is what an unmeasured shape would get)
-    heur = (ctypes.c_int * 6)()
+    # (a pinned tile / workgroups-per-CU bypasses the verdict tables: wgrad_sb_route in pwconv.hip)
     for tile in range(4):
         for pc in (2, 3, 4, 6):
             L.set_option(b'split_wgrad_tile', tile); L.set_option(b'split_wgrad_per_cu', pc)
