@@ -296,37 +296,39 @@ def main():
     # replays); on expiry the guard prints the switches to try and exits non-zero (watchdog.py)
     guard = pkg.watchdog.FirstStepsGuard(rank, world, 'executor trace')
     guard.__enter__()
-    ex = model._executor(N, True)
-    ex.set_inputs(x, y)
-    ex.lr.fill_(0.01)
+    try:
+        ex = model._executor(N, True)
+        ex.set_inputs(x, y)
+        ex.lr.fill_(0.01)
 
-    # roofline probe: the rate-18 depthwise launch stays outside the graph segments, between two events
-    probe_name = 'aspp3_depthwise' if any(getattr(o, 'name', '') == 'aspp3_depthwise' for o in model.graph.ops) else None
-    # (N == 1 only: with collectives captured into the graph the forward must stay one segment)
-    dist_mode = world > 1 or os.environ.get('DL3P_FORCE_DIST', '0') not in ('', '0')
-    probe = ex.install_probe(probe_name) if (probe_name and not dist_mode) else None
-    # second probe: the largest pointwise GEMM of the step (decoder_conv0_pointwise) against the fp32 MFMA peak
-    # (north_star: "MFMA utilisation for the pointwise GEMMs"); fp32 path only
-    pw_name = 'decoder_conv0_pointwise' if any(getattr(o, 'name', '') == 'decoder_conv0_pointwise' for o in model.graph.ops) else None
-    want_pw_probe = bool(pw_name and not dist_mode and args.dtype == 'f32')
+        # roofline probe: the rate-18 depthwise launch stays outside the graph segments, between two events
+        probe_name = 'aspp3_depthwise' if any(getattr(o, 'name', '') == 'aspp3_depthwise' for o in model.graph.ops) else None
+        # (N == 1 only: with collectives captured into the graph the forward must stay one segment)
+        dist_mode = world > 1 or os.environ.get('DL3P_FORCE_DIST', '0') not in ('', '0')
+        probe = ex.install_probe(probe_name) if (probe_name and not dist_mode) else None
+        # second probe: the largest pointwise GEMM of the step (decoder_conv0_pointwise) against the fp32 MFMA peak
+        # (north_star: "MFMA utilisation for the pointwise GEMMs"); fp32 path only
+        pw_name = 'decoder_conv0_pointwise' if any(getattr(o, 'name', '') == 'decoder_conv0_pointwise' for o in model.graph.ops) else None
+        want_pw_probe = bool(pw_name and not dist_mode and args.dtype == 'f32')
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
+        def barrier():
+            if world > 1:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
 
-    guard.stage('first eager step')
-    ex.train_step()                      # first step eager (also the graph-capture warm-up)
-    if model.use_graphs:
-        guard.stage('graph capture')
-        ex.capture()
-    guard.stage('warm-up replays')
-    for _ in range(args.warmup):
-        ex.train_step()
-    if probe:
-        probe.reset()
-    barrier()
-    guard.__exit__(None, None, None)
+        guard.stage('first eager step')
+        ex.train_step()                      # first step eager (also the graph-capture warm-up)
+        if model.use_graphs:
+            guard.stage('graph capture')
+            ex.capture()
+        guard.stage('warm-up replays')
+        for _ in range(args.warmup):
+            ex.train_step()
+        if probe:
+            probe.reset()
+        barrier()
+    finally:
+        guard.__exit__(None, None, None)      # always cancelled: an exception must not leave the timer armed
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ex.train_step()

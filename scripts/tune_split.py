@@ -31,10 +31,13 @@ def rule(role, M, K, N):
 def pin(c):
     for k in (b'gemm_nt', b'gemm_mi', b'gemm_per_cu', b'sb_wm', b'sb_nt'):
         L.set_option(k, 0)
+    L.set_option(b'sb_rs', 0)          # (the heuristic pick and the tile candidates are the tiled kernels')
     if c is None:
         return
     nt, mi, pc = c
-    if pc > 100:
+    if pc == 103:                      # the row-stationary form (csrc/pw_split_rs.hip): {2, 1, 103} = wm 3
+        L.set_option(b'sb_rs', 1)
+    elif pc > 100:
         L.set_option(b'sb_wm', pc - 100); L.set_option(b'sb_nt', nt); L.set_option(b'gemm_mi', mi)
     else:
         L.set_option(b'sb_wm', -1); L.set_option(b'gemm_nt', nt); L.set_option(b'gemm_mi', mi); L.set_option(b'gemm_per_cu', pc)
@@ -129,6 +132,12 @@ def measure(role, M, K, N):
                 continue
             pin((nt, mi, 100 + wm))
             res[(nt, mi, 100 + wm)] = T.timeit(sb)
+    out6 = (ctypes.c_int * 6)()
+    L.set_option(b'sb_rs', 1)
+    L.gemm_plan_query(role + 5, M, K, N, out6)
+    if out6[0] == 3 and out6[3] == 3 and M >= 65536:       # served by the row-stationary form
+        pin((2, 1, 103))
+        res[(2, 1, 103)] = T.timeit(sb)
     pin(None)
     best = min((k for k in res if k is not None), key=lambda k: res[k])
     # a faster tile only counts if it computes the same thing as the heuristic pick
@@ -237,7 +246,7 @@ def main():
             pays.append((role, M, K, N, verdict, t32, t_split))
     out = ['// GENERATED by scripts/tune_split.py on an MI355X -- the split-bf16 GEMM (pw_split.hip) per GEMM shape of the BASELINE graphs.',
            '// g_sb_tuned: {role + 5, M, K, N, nt, mi, pc} where the best measured tile beats gemm_plan_sb\'s heuristic by more than 3 %',
-           '//             (pc > 100: the wide family, wm = pc - 100; else persistent workgroups per CU, 0 = by tile width)   // heuristic us -> tuned us',
+           '//             (pc > 100: the wide family, wm = pc - 100 -- {2, 1, 103}: the row-stationary form, pw_split_rs.hip; else persistent workgroups per CU, 0 = by tile width)   // heuristic us -> tuned us',
            '// g_sb_pays:  {role, M, K, N, pays}: 1 where the best split launch beat the fp32-input MFMA kernel\'s production pick by more than',
            '//             3 %, 0 where it did not -- only rows where that differs from the executor\'s threshold rule (K, N >= 128, rows >= 16384)',
            '//             // fp32 us, split us',

@@ -204,8 +204,19 @@ def test_first_steps_guard_exits_nonzero_and_names_the_switches():
         pass                                # finished in time: the timer is cancelled
     with wd.FirstStepsGuard(0, 1, 'x', timeout=0.05, _exit=fired2.append, _out=io.StringIO()):
         time.sleep(0.2)                     # a single rank arms nothing
+    try:                                    # an exception the caller catches must not leave the timer armed
+        with wd.FirstStepsGuard(0, 2, 'x', timeout=0.2, _exit=fired2.append, _out=io.StringIO()):
+            raise ValueError('bad input shape')
+    except ValueError:
+        pass
     time.sleep(0.5)
     assert fired2 == []
+    # ... and train_on_batch / bench.py hold the guard in a `with` / try-finally, not a bare __enter__ / __exit__ pair
+    import inspect
+    model_src = inspect.getsource(load_pkg('model').DeeplabModel.train_on_batch)
+    assert 'with FirstStepsGuard(' in model_src and 'guard.__enter__()' not in model_src
+    bench_src = open(os.path.join(ROOT, 'bench.py')).read()
+    assert bench_src.index('guard.__enter__()') < bench_src.index('    finally:\n        guard.__exit__(None, None, None)')
     # the real thing: a child process stuck in its "first step" is ended by the guard with the documented code
     code = ("import importlib, sys, time; sys.path.insert(0, %r); "
             "wd = importlib.import_module('tf-keras-deeplabv3p-model-set_amd.watchdog'); "

@@ -167,3 +167,186 @@ def test_every_wide_split_gemm_tile(ops, nt, mi, wm):
         L.set_option(b'sb_nt', 0)
         L.set_option(b'gemm_mi', 0)
         L.set_option(b'pw_small_min_rows', 64)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# round 4: operands that are NOT randn: wide per-channel dynamic range, saturated activations, tiny gradients,
+# with an ELEMENTWISE bound -- |y - y64| against sum_k |a_mk| |w_nk| of that very element -- instead of one max-abs over the output
+def _elementwise_err(y, y64, a64, w64):
+    """max over elements of |y - y64| / (|a| @ |w|^T): the condition-aware error of an fp32 inner product (K eps / 2 worst case,
+    ~sqrt(K) eps typical); columns or rows 2^20 below the largest count like every other"""
+    cond = a64.abs() @ w64.abs().t()
+    cond = cond.clamp_min(float(torch.finfo(torch.float64).tiny))
+    return float(((y.double() - y64).abs() / cond).max())
+
+
+WIDE = [(16 * 33 * 33, 320, 256), (9001, 304, 252), (70001, 256, 304)]
+
+
+@pytest.mark.parametrize('rs', [0, 1], ids=['tiled', 'row_stationary'])
+@pytest.mark.parametrize('case', WIDE)
+def test_split_gemm_wide_dynamic_range(ops, case, rs):
+    """per-column scales spanning 2^+-20 on either operand, a saturated-ReLU6 column block, an all-zero block; the split kernel
+    stays within 3x the fp32-input MFMA kernel's own elementwise error and under the fp32 inner-product bound"""
+    M, K, N = case
+    L = ops.lib()
+    L.set_option(b'pw_small_min_rows', -1)
+    L.set_option(b'sb_rs', rs)
+    try:
+        g = torch.Generator(device=DEV); g.manual_seed(11 * M + K + N)
+        rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)
+        kscale = torch.exp2(torch.randint(-20, 21, (K,), device=DEV, generator=g).float())     # activation channels over 2^40
+        nscale = torch.exp2(torch.randint(-20, 21, (N,), device=DEV, generator=g).float())     # output channels over 2^40
+        x = rnd(M, K) * kscale
+        wt = rnd(N, K) / K ** 0.5 * nscale[:, None]
+        wsp = ops.split_bf16x3(wt)
+        # (1) no prologue: the raw dynamic range reaches the split
+        y64 = x.double() @ wt.double().t()
+        y = ops.pwconv_fwd_sb(x, wsp, K)
+        y32 = ops.pwconv_fwd_wt(x, wt)
+        e_sb, e_32 = _elementwise_err(y, y64, x.double(), wt.double()), _elementwise_err(y32, y64, x.double(), wt.double())
+        assert e_sb < 1e-5 and e_sb < 3 * e_32 + 1e-7, ('forward, raw', e_sb, e_32)
+        # every COLUMN on its own scale (what max-abs over the whole output cannot see)
+        col = (y.double() - y64).abs().max(0).values / y64.abs().max(0).values
+        assert float(col.max()) < 2e-5, ('forward, per column', float(col.max()))
+        # (2) BatchNorm + ReLU6 prologue with a saturated block (u >> 6 -> exactly 6), a dead block (u << 0 -> exactly 0) and
+        # the rest spanning decades below the clamp
+        sc = torch.exp2(torch.randint(-12, 3, (K,), device=DEV, generator=g).float())
+        sh = rnd(K) * 0.1
+        sh[: K // 8] = 100.0          # saturated at 6
+        sh[K // 8: K // 4] = -100.0   # dead
+        xs = rnd(M, K)
+        a64 = (xs.double() * sc.double() + sh.double()).clamp(0.0, 6.0)
+        assert bool((a64[:, : K // 8] == 6.0).all()) and bool((a64[:, K // 8: K // 4] == 0.0).all())
+        y64 = a64 @ wt.double().t()
+        part = ops.new_partials(N, DEV)
+        y, rows = ops.pwconv_fwd_sb(xs, wsp, K, None, sc, sh, ops.ACT_RELU6, partials=part)
+        y32 = ops.pwconv_fwd_wt(xs, wt, None, sc, sh, ops.ACT_RELU6)
+        e_sb, e_32 = _elementwise_err(y, y64, a64, wt.double()), _elementwise_err(y32, y64, a64, wt.double())
+        assert e_sb < 1e-5 and e_sb < 3 * e_32 + 1e-7, ('forward, saturated prologue', e_sb, e_32)
+        p = part[:rows * 2 * N].reshape(rows, 2, N).double().sum(0)
+        s1, s2 = y64.sum(0), (y64 * y64).sum(0)
+        assert float(((p[0] - s1).abs() / y64.abs().sum(0)).max()) < 1e-5, 'statistics, per column'
+        assert float(((p[1] - s2).abs() / s2).max()) < 1e-5, 'statistics of squares, per column'
+        del y, y32, y64, a64
+        # (3) data gradient of a late-training step: dy at 1e-12 with per-channel scales on top
+        dy = rnd(M, N) * 1e-12 * nscale
+        w = (rnd(K, N) / N ** 0.5).contiguous()
+        w_sp = ops.split_bf16x3(w)
+        gx64 = dy.double() @ w.double().t()
+        gx = ops.pwconv_bwd_data_sb(dy, w_sp, N)
+        gx32 = ops.pwconv_bwd_data(dy, w)
+        e_sb, e_32 = _elementwise_err(gx, gx64, dy.double(), w.double()), _elementwise_err(gx32, gx64, dy.double(), w.double())
+        assert e_sb < 1e-5 and e_sb < 3 * e_32 + 1e-7, ('data gradient at 1e-12', e_sb, e_32)
+        assert float(gx.abs().max()) > 0.0
+    finally:
+        L.set_option(b'pw_small_min_rows', 64)
+        L.set_option(b'sb_rs', -1)
+
+
+def test_split_gemm_domain_edges(ops):
+    """What the 3-way split does at the ends of the float32 range, stated at GEMM level (include/dl3p.h):
+    * |a| below 2^-110: the third (then the second) piece of a falls under bf16's smallest normal 2^-126; whatever the matrix pipe
+      does with such pieces, the product loses at most 2^-126 |w| per term -- an ABSOLUTE error far below any float32-normal
+      output scale -- and nothing else;
+    * an element that is Inf, NaN, or rounds to bf16 Inf (|a| >= 3.3962e38, half a bf16 step past the largest finite bf16 3.3895e38): the residual a - rn_bf16(a) is NaN, so every output of
+      that ROW is non-finite (the fp32-input kernel gives Inf / NaN for Inf / NaN and a finite value for the huge finite one);
+      other rows are untouched."""
+    M, K, N = 4357, 304, 256
+    L = ops.lib()
+    L.set_option(b'pw_small_min_rows', -1)
+    try:
+        g = torch.Generator(device=DEV); g.manual_seed(5)
+        rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)
+        wt = rnd(N, K) / K ** 0.5
+        wsp = ops.split_bf16x3(wt)
+        for lo, hi in ((-112, -106), (-120, -112), (-126, -119)):
+            x = rnd(M, K).sign() * torch.exp2(torch.empty(M, K, device=DEV).uniform_(lo, hi, generator=g))
+            y64 = x.double() @ wt.double().t()
+            y = ops.pwconv_fwd_sb(x, wsp, K)
+            bound = 2.0 ** -126 * wt.double().abs().sum(1)[None, :] + 1e-5 * (x.double().abs() @ wt.double().abs().t())
+            assert bool(((y.double() - y64).abs() <= bound).all()), ('tiny operands', lo, hi, float(((y.double() - y64).abs() / bound).max()))
+        x = rnd(M, K)
+        x[7, 3] = float('inf'); x[19, 100] = float('nan'); x[33, 300] = 3.4e38; x[40, 1] = -3.4e38
+        y = ops.pwconv_fwd_sb(x, wsp, K)
+        y32 = ops.pwconv_fwd_wt(x, wt)
+        bad = torch.zeros(M, dtype=torch.bool, device=DEV); bad[[7, 19, 33, 40]] = True
+        assert bool((~torch.isfinite(y[bad])).all()), 'a row holding Inf / NaN / |a| > bf16 max must not produce finite values'
+        assert bool((~torch.isfinite(y32[[7, 19]])).all()) and bool(torch.isfinite(y32[[33, 40]]).all())       # the fp32 kernel, for the record
+        xg = x[~bad]
+        y64 = xg.double() @ wt.double().t()
+        assert bool(torch.isfinite(y[~bad]).all())
+        assert float((y[~bad].double() - y64).abs().max()) < 2e-5 * float(y64.abs().max())
+    finally:
+        L.set_option(b'pw_small_min_rows', 64)
+
+
+RS_SHAPES = [(70001, 304, 256), (66564, 256, 256), (9001, 256, 304), (4357, 128, 48), (33289, 192, 48), (2600, 100, 200), (2111, 320, 16)]
+
+
+@pytest.mark.parametrize('case', RS_SHAPES)
+def test_row_stationary_split_gemm(ops, case):
+    """csrc/pw_split_rs.hip (dl3p_set_option('sb_rs', 1)): forward + statistics, bias, data gradient (+ accumulate, + fused
+    BatchNorm-backward sums) against float64 at the fp32 kernels' tolerances; the planner reports the row-stationary form"""
+    import ctypes
+    M, K, N = case
+    L = ops.lib()
+    L.set_option(b'pw_small_min_rows', -1)
+    L.set_option(b'sb_rs', 1)
+    try:
+        out6 = (ctypes.c_int * 6)()
+        L.gemm_plan_query(6, M, K, N, out6)
+        assert out6[0] == 3 and out6[3] == 3, list(out6)       # role 1 (forward + statistics) on the split path, wm = 3: row-stationary
+        g = torch.Generator(device=DEV); g.manual_seed(M % 9973 + 7 * K + 13 * N)
+        rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)
+        x = rnd(M, K)
+        wt = rnd(N, K) / K ** 0.5
+        sc = torch.rand(K, device=DEV, generator=g) + 0.5
+        sh = rnd(K) * 0.3
+        bias = rnd(N) * 0.1
+        a64 = (x.double() * sc.double() + sh.double()).clamp(0.0, 6.0)
+        y64 = a64 @ wt.double().t()
+        wsp = ops.split_bf16x3(wt)
+        part = ops.new_partials(N, DEV)
+        y = torch.full((M, N), float('nan'), device=DEV)
+        _, rows = ops.pwconv_fwd_sb(x, wsp, K, None, sc, sh, ops.ACT_RELU6, out=y, partials=part)
+        assert float((y.double() - y64).abs().max()) < 2e-5 * float(y64.abs().max()), 'forward'
+        p = part[:rows * 2 * N].reshape(rows, 2, N).double().sum(0)
+        s1, s2 = y64.sum(0), (y64 * y64).sum(0)
+        assert float((p[0] - s1).abs().max()) < 1e-4 * max(float(s1.abs().max()), float(M) ** 0.5), 'stat sum'
+        assert float((p[1] - s2).abs().max()) < 1e-4 * float(s2.abs().max()), 'stat sum of squares'
+        # bit-identical between two launches (fixed summation order everywhere)
+        part2 = ops.new_partials(N, DEV)
+        y_again, rows2 = ops.pwconv_fwd_sb(x, wsp, K, None, sc, sh, ops.ACT_RELU6, partials=part2)
+        assert rows2 == rows and torch.equal(y_again, y) and torch.equal(part2[:rows * 2 * N], part[:rows * 2 * N])
+        y2 = ops.pwconv_fwd_sb(x, wsp, K, bias, None, None, ops.ACT_RELU)
+        r64 = x.double().clamp_min(0) @ wt.double().t() + bias.double()
+        assert float((y2.double() - r64).abs().max()) < 2e-5 * float(r64.abs().max()), 'bias + bare ReLU prologue'
+        del y, y2, a64, y64, r64
+        dy = rnd(M, N)
+        w = wt.t().contiguous()          # (K, N)
+        w_sp = ops.split_bf16x3(w)
+        L.gemm_plan_query(8, M, N, K, out6)       # the data gradient reduces over N: row-stationary for N in 97..128, 161..192, 225..256, 289..320
+        served = out6[0] == 3 and out6[3] == 3
+        gx64 = dy.double() @ w.double().t()
+        gx = ops.pwconv_bwd_data_sb(dy, w_sp, N)
+        assert float((gx.double() - gx64).abs().max()) < 2e-5 * float(gx64.abs().max()), ('data gradient', served)
+        base = rnd(M, K)
+        gx_acc = ops.pwconv_bwd_data_sb(dy, w_sp, N, out=base.clone(), accumulate=True)
+        assert float((gx_acc.double() - (gx64 + base.double())).abs().max()) < 2e-5 * float(gx64.abs().max()), 'accumulate'
+        z = rnd(M, K)
+        mean = z.mean(0)
+        invstd = 1.0 / torch.sqrt(z.var(0, unbiased=False) + 1e-3)
+        part = ops.new_partials(K, DEV)
+        gx2, rows = ops.pwconv_bwd_data_sb(dy, w_sp, N, z=z, scale=sc, shift=sh, act=ops.ACT_RELU6, mean=mean, invstd=invstd,
+                                           partials=part)
+        assert float((gx2.double() - gx64).abs().max()) < 2e-5 * float(gx64.abs().max()), 'data gradient (+BN sums)'
+        u = z.double() * sc.double() + sh.double()
+        d = gx64 * ((u > 0) & (u < 6))
+        xh = (z.double() - mean.double()) * invstd.double()
+        p = part[:rows * 2 * K].reshape(rows, 2, K).double().sum(0)
+        assert float((p[0] - d.sum(0)).abs().max()) < 2e-4 * float(d.abs().sum(0).max()), 'BN backward sum'
+        assert float((p[1] - (d * xh).sum(0)).abs().max()) < 2e-4 * float((d * xh).abs().sum(0).max()), 'BN backward sum * xhat'
+    finally:
+        L.set_option(b'pw_small_min_rows', 64)
+        L.set_option(b'sb_rs', -1)

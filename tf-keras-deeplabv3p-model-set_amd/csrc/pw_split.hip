@@ -18,43 +18,7 @@
 //   * the epilogue buffer overlays the operand tiles (two workgroups per CU keep fitting).
 #include "common.h"
 #include "pw_gemm.h"
-#include <type_traits>
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
-
-#define SB_BKT 32
-#define SB_PB 40   // bf16 elements per LDS tile row: 64 B of data + 16 B pad
-
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (N > 0) {
-    static_for<N - 1>(f);
-    f(std::integral_constant<int, N - 1>{});
-  }
-}
-
-// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() is `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`: the
-// vmcnt(0) drains every global load in flight, i.e. the operand prefetch issued for the NEXT K-steps -- each K-step then contains a
-// full memory round trip, and with six bf16 MFMAs per tile the multiply phase (~0.7 us) is too short to cover one.  The tiles
-// handed over at the barrier live in LDS; global loads land in registers nobody else reads, and the compiler keeps its own vmcnt
-// bookkeeping for them.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// (x, y) -> three packed bf16 pairs (low half = x): the exact 3-way split, round to nearest even at every level
-__device__ __forceinline__ void split2(float x, float y, uint32_t& h, uint32_t& m, uint32_t& l) {
-  const bf16x2v hv = {(__bf16)x, (__bf16)y};
-  h = __builtin_bit_cast(uint32_t, hv);
-  const float rx = x - __builtin_bit_cast(float, h << 16);
-  const float ry = y - __builtin_bit_cast(float, h & 0xffff0000u);
-  const bf16x2v mv = {(__bf16)rx, (__bf16)ry};
-  m = __builtin_bit_cast(uint32_t, mv);
-  const float sx = rx - __builtin_bit_cast(float, m << 16);
-  const float sy = ry - __builtin_bit_cast(float, m & 0xffff0000u);
-  const bf16x2v lv = {(__bf16)sx, (__bf16)sy};
-  l = __builtin_bit_cast(uint32_t, lv);
-}
+#include "sb_common.h"
 
 // ------------------------------------------------------------------------------ the pre-split B operand
 // rows x cols fp32 (row pitch ld) -> dst[plane][rows][pitch] bf16, columns >= cols zero.  table rows: {src offset (floats),

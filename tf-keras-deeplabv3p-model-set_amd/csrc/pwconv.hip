@@ -619,6 +619,7 @@ static int g_split_wgrad = -1;      // dl3p_set_option("split_wgrad", 0 | 1): we
 static int g_sbw_force_tile = -1, g_sbw_force_pc = 0;      // "split_wgrad_tile" (0..3, -1 none) / "split_wgrad_per_cu": pin its plan (and bypass the verdicts)
 static int g_sb_pipe = -1;      // dl3p_set_option("sb_pipe", 0 | 1): the producer / consumer form of the split kernel (default DL3P_SB_PIPE or 0)
 static int g_sb_force_wm = 0, g_sb_force_nt = 0;      // dl3p_set_option("sb_wm" / "sb_nt"): pin the split kernel's wide-tile family (gemm_plan_sb)
+static int g_sb_rs = -1;      // dl3p_set_option("sb_rs", 0 | 1 | -1): the row-stationary split kernel (pw_split_rs.hip) never / wherever it serves the shape / by rule (DL3P_SB_RS)
 static int g_wgrad_force_tile = -1, g_wgrad_force_per_cu = 0;                    // see wgrad_pick_tile / wgrad_split
 static int g_pw_small_min_rows = -1;
 static int pw_small_min_rows() {
@@ -641,6 +642,7 @@ extern "C" int dl3p_set_option(const char* name, int value) {
   if (!strcmp(name, "split_wgrad_tile")) { g_sbw_force_tile = (value >= 0 && value <= 3) ? value : -1; return DL3P_OK; }
   if (!strcmp(name, "split_wgrad_per_cu")) { g_sbw_force_pc = value > 0 ? value : 0; return DL3P_OK; }
   if (!strcmp(name, "sb_wm")) { g_sb_force_wm = (value >= -1 && value <= 2) ? value : 0; return DL3P_OK; }    // -1: never wide
+  if (!strcmp(name, "sb_rs")) { g_sb_rs = value < 0 ? -1 : (value ? 1 : 0); return DL3P_OK; }
   if (!strcmp(name, "sb_nt")) { g_sb_force_nt = (value == 8 || value == 12 || value == 16) ? value : 0; return DL3P_OK; }
   if (!strcmp(name, "dw_per_cu")) { dl3p_dw_force_per_cu = value > 0 ? value : 0; return DL3P_OK; }
   if (!strcmp(name, "dw_want")) { dl3p_dw_force_want = value > 0 ? value : 0; return DL3P_OK; }
@@ -1040,6 +1042,28 @@ static int wgrad_sb_route(int M, int K, int N, size_t max_slabs, int* kf, int* n
   return dl3p_wgrad_sb_plan(M, K, N, (int)max_slabs, tile, per_cu, kf, nw, kt, nt, mrows);
 }
 bool dl3p_sb_wide_config(int nt, int mi, int wm);
+bool dl3p_sb_rs_supported(int role, int M, int K, int N);
+int dl3p_sb_rs_grid(int M);
+void dl3p_launch_gemm_sbr(const GemmParams& p, int mode, int grid, hipStream_t st);
+// the row-stationary form (pw_split_rs.hip; gemm_plan_sb reports it as wm = 3): pinned by dl3p_set_option("sb_rs", 1), otherwise by
+// the measured table ({2, 1, 103} rows of csrc/sb_tuned.h) or the rule below
+static bool sb_rs_route(int role, int M, int K, int N) {
+  if (!dl3p_sb_rs_supported(role, M, K, N)) return false;
+  if (g_sb_force_wm != 0 || g_sb_pipe > 0 || g_gemm_force_nt || g_gemm_force_mi) return false;     // another form is pinned
+  if (g_sb_rs < 0) {
+    static const int env = getenv("DL3P_SB_RS") ? atoi(getenv("DL3P_SB_RS")) : -1;
+    if (env >= 0) return env != 0;
+    // the measured table (csrc/sb_tuned.h, {2, 1, 103} rows) decides where it knows the launch; elsewhere the rule measured on the
+    // decoder shapes (scripts/micro/sb_rs.py, profiles/r04_split_gemm_row_stationary.txt): long data gradients with a reduction of
+    // 225-320 -- with the fused BatchNorm-backward sums 362 against 494-512 us on 266256 x 256 -> 304, 288 against 340 onto 256
+    // columns, 175 against 216 at 131072 rows; plain 258 against 345, 213 against 234, 120 against 146.  Forwards tie (247 against
+    // 255 at K = 256) or lose (K = 304: 372 against 349), as does everything under ~10^5 rows (one workgroup per CU and 64-row half
+    // tiles: tile quantisation)
+    if (const GemmTuned* e = gemm_tuned_lookup(role + 5, M, K, N)) return e->pc == 103;
+    return role >= 2 && M >= 131072 && K > 224;
+  }
+  return g_sb_rs == 1;
+}
 void dl3p_launch_gemm_sbp(const GemmParams& p, bool stats, bool bnb, int nt, int mi, dim3 grid, hipStream_t st);
 
 
@@ -1049,6 +1073,10 @@ static void gemm_plan_sb(int role, int M, int K, int N, int* nt, int* gx, int* g
   int force_mi = 0, force_pc = 0;
   *nt = pick_nt(N, M);
   *wm = 1;
+  if (sb_rs_route(role, M, K, N)) {
+    *wm = 3; *nt = 2; *mi = 1; *gx = dl3p_sb_rs_grid(M); *gy = 1; *num_m_tiles = ceil_div(M, 64);
+    return;
+  }
   if (g_sb_pipe < 0) g_sb_pipe = getenv("DL3P_SB_PIPE") ? atoi(getenv("DL3P_SB_PIPE")) : 0;     // measured slower than the symmetric form: opt-in
   if (g_sb_pipe && g_sb_force_wm <= 0) {
     // producer / consumer form: one 512-thread workgroup per CU, 128 (or 64) rows x up to 128 columns; *wm = 0 marks it
@@ -1153,9 +1181,10 @@ extern "C" int dl3p_pwconv_fwd_sb(const float* x, int ldx, const float* in_scale
   p.M = M; p.K = K; p.N = N;
   int nt, gx, gy, mi, wm;
   gemm_plan_sb(stat_partials ? 1 : 0, M, K, N, &nt, &gx, &gy, &p.num_m_tiles, &mi, &wm);
-  { const char* e = getenv("DL3P_SB_ABLATE"); p.stagger = e ? atoi(e) : 0; }
+  { const char* e = getenv("DL3P_SB_ABLATE"); p.stagger = e ? atoi(e) : 0; if (p.stagger == 100) p.B = stat_partials + (size_t)DL3P_MAX_STAT_ROWS * 2 * N; }      // (ablation build: stamps behind the partial rows)
   if (rows_out) *rows_out = gx;
-  if (wm == 0) dl3p_launch_gemm_sbp(p, stat_partials != nullptr, false, nt, mi, dim3(gx, gy), (hipStream_t)stream);
+  if (wm == 3) dl3p_launch_gemm_sbr(p, stat_partials ? 1 : 0, gx, (hipStream_t)stream);
+  else if (wm == 0) dl3p_launch_gemm_sbp(p, stat_partials != nullptr, false, nt, mi, dim3(gx, gy), (hipStream_t)stream);
   else dl3p_launch_gemm_sb(p, stat_partials != nullptr, false, false, nt, mi, wm, dim3(gx, gy), (hipStream_t)stream);
   DL3P_CHECK_LAUNCH(fn);
   return DL3P_OK;
@@ -1195,7 +1224,8 @@ extern "C" int dl3p_pwconv_bwd_data_sb(const float* dy, int lddy, const void* ws
   int nt, gxn, gy, mi, wm;
   gemm_plan_sb(bnb ? 3 : 2, M, N, K, &nt, &gxn, &gy, &p.num_m_tiles, &mi, &wm);
   if (rows_out) *rows_out = gxn;
-  if (wm == 0) dl3p_launch_gemm_sbp(p, bnb, bnb, nt, mi, dim3(gxn, gy), (hipStream_t)stream);
+  if (wm == 3) dl3p_launch_gemm_sbr(p, bnb ? 2 : 0, gxn, (hipStream_t)stream);
+  else if (wm == 0) dl3p_launch_gemm_sbp(p, bnb, bnb, nt, mi, dim3(gxn, gy), (hipStream_t)stream);
   else dl3p_launch_gemm_sb(p, bnb, bnb, false, nt, mi, wm, dim3(gxn, gy), (hipStream_t)stream);
   DL3P_CHECK_LAUNCH(fn);
   return DL3P_OK;

@@ -395,20 +395,20 @@ class DeeplabModel:
         # more than one rank: the executor trace (every collective once), the graph capture and the first replays are where
         # a multi-process job can hang -- bounded by watchdog.FirstStepsGuard (prints the switches to try, exits non-zero)
         guarded = self.dist is not None and self.dist.world_size > 1 and self._steps < 3
-        if guarded:
-            from .watchdog import FirstStepsGuard
-            guard = FirstStepsGuard(self.dist.rank, self.dist.world_size, 'train step %d' % self._steps)
-            guard.__enter__()
-        ex = self._executor(int(x.shape[0]), True)
-        ex.set_inputs(x, y, sample_weight)
-        ex.lr.fill_(self.optimizer.lr_at(self.optimizer.iterations))
-        if self.use_graphs and not ex.graphed and self._steps_on(ex) >= 1:
-            ex.capture()
-        ex.train_step()
-        if guarded:
-            import torch
-            torch.cuda.synchronize()
-            guard.__exit__(None, None, None)
+        from .watchdog import FirstStepsGuard
+        # (an unguarded step arms nothing: world 1 / timeout 0; `with` cancels the timer on every exit path -- an exception
+        # the caller catches must not leave it armed to os._exit(3) the process minutes later)
+        with FirstStepsGuard(self.dist.rank if guarded else 0, self.dist.world_size if guarded else 1,
+                             'train step %d' % self._steps):
+            ex = self._executor(int(x.shape[0]), True)
+            ex.set_inputs(x, y, sample_weight)
+            ex.lr.fill_(self.optimizer.lr_at(self.optimizer.iterations))
+            if self.use_graphs and not ex.graphed and self._steps_on(ex) >= 1:
+                ex.capture()
+            ex.train_step()
+            if guarded:
+                import torch
+                torch.cuda.synchronize()
         ex._steps = self._steps_on(ex) + 1
         self._steps += 1
         self.optimizer.iterations += 1
