@@ -368,7 +368,8 @@ def main():
                        'gemm': ('fp32-accurate split-bf16 (3 x bf16 pieces, 6 products, fp32 accumulate) for the compute-bound 1x1 convs, '
                                 'fp32-input MFMA elsewhere' if model._store.Sb is not None else 'fp32-input MFMA'),
                        'launches_per_step': ex.fwd.n_launches + ex.bwd.n_launches + ex.opt.n_launches,
-                       'collectives_per_step': sum(getattr(pl, 'n_collectives', 0) for pl in (ex.fwd, ex.bwd, ex.opt))},
+                       'collectives_per_step': sum(getattr(pl, 'n_collectives', 0) for pl in (ex.fwd, ex.bwd, ex.opt)),
+                       'rccl_ranks': (torch.distributed.get_world_size() if (world > 1 and torch.distributed.is_initialized()) else 1)},
         }
         standalone = None
         if not probe and probe_name and dist_mode and args.dtype == 'f32':

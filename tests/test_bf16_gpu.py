@@ -456,3 +456,123 @@ def test_bf16_full_size_properties():
     assert la == lb, (la, lb)
     assert all(np.array_equal(wa[k], wb[k]) for k in wa)
     assert abs(la[0] - np.log(C)) < 0.5 and all(np.isfinite(v).all() for v in wa.values())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# round 4: the layer-local check AT 1024 x 2048.  The NumPy oracle needs many minutes for one configs[4]
+# image, so the reference here is float64 torch ON THE DEVICE (matmul / shifted multiply-adds -- no kernel of this repo, no conv
+# library), layer by layer from the DEVICE's own stored tensors, with bf16 rounding at the points the policy defines.
+def _act64(u, act):
+    O_ = load_pkg('ops')
+    if act == O_.ACT_NONE:
+        return u
+    if act == O_.ACT_RELU:
+        return u.clamp_min(0)
+    if act == O_.ACT_RELU6:
+        return u.clamp(0, 6)
+    hs = (u + 3).clamp(0, 6) / 6
+    return hs if act == O_.ACT_HSIGMOID else u * hs
+
+
+def _taps(a, k, stride, rate, pad_t, pad_l, Ho, Wo):
+    """the k x k shifted, strided views of a zero-padded (N, H, W, C) tensor: [(ky, kx, view (N, Ho, Wo, C))]"""
+    N, H, W, C = a.shape
+    need_h, need_w = (Ho - 1) * stride + (k - 1) * rate + 1, (Wo - 1) * stride + (k - 1) * rate + 1
+    ap = torch.nn.functional.pad(a, (0, 0, pad_l, max(0, need_w - W - pad_l), pad_t, max(0, need_h - H - pad_t)))
+    for ky in range(k):
+        for kx in range(k):
+            yield ky, kx, ap[:, ky * rate: ky * rate + (Ho - 1) * stride + 1: stride, kx * rate: kx * rate + (Wo - 1) * stride + 1: stride, :]
+
+
+def test_bf16_every_layer_at_1024x2048_matches_float64_on_the_devices_own_inputs(monkeypatch):
+    """BASELINE configs[4] at ITS size (MobileNetV3-Large + ASPP + decoder, 1024 x 2048, 19 classes, batch 1, bf16): every conv /
+    depthwise / dense layer's FORWARD output and WEIGHT GRADIENT against float64 computed from the device's own input activations
+    (rounded to bf16 where the policy rounds: the prologue's act(z scale + shift), the kernel mirror) and the device's own output
+    gradient -- every bf16 kernel family at its production launch: wave-streaming and staged GEMMs, the few-row GEMMs behind the
+    poolings, 3 x 3 window and 5 x 5 strip depthwise kernels incl. the atrous ones, the stem, their weight-gradient twins.
+    Tolerances of the 128 x 256 teacher-forced test: outputs within one bf16 ulp (+ 2e-3 of the layer's range) on 99.9 % of the
+    elements, kernel gradients to 4e-3 of their scale."""
+    monkeypatch.setenv('DL3P_FOLD_APPLY', '0')
+    monkeypatch.setenv('DL3P_GRAD_ALIAS', '0')
+    pkg = load_pkg()
+    O_ = load_pkg('ops')
+    mp = pkg.mixed_precision
+    N, C, H, W = 1, 19, 1024, 2048
+    mp.set_policy(mp.Policy('mixed_bfloat16'))
+    try:
+        m = pkg.get_deeplabv3p_model('mobilenetv3large', C, (H, W), 16, training=True)
+    finally:
+        mp.set_policy(mp.Policy('float32'))
+    m.compile(optimizer=pkg.SGD(0.0), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))      # lr 0: the weights stay what forward used
+    m.use_graphs = False
+    rng = np.random.default_rng(9)
+    x = rng.uniform(-1, 1, (N, H, W, 3)).astype(np.float32)
+    y = rng.integers(0, C, (N, H * W, 1)).astype(np.float32)
+    y[rng.uniform(size=y.shape) < 0.05] = 255
+    loss = m.train_on_batch(x, y)
+    assert np.isfinite(loss)
+    ex = m._executor(N, True)
+    assert ex.bf16
+    weights = m.get_weights_by_name()
+    st = m._store
+    convs = [op for op in m.graph.ops if op.kind in ('conv_pw', 'conv_dense', 'conv_dw')]
+    assert len(convs) > 80
+    f64 = dict(dtype=torch.float64, device=DEV)
+    bad, kinds = [], set()
+    for op in convs:
+        v = op.x
+        cin = op.c if op.kind == 'conv_dw' else op.cin
+        a = ex.view(v.tensor)[..., :cin].double()
+        if v.group is not None:
+            sc = ex.gscale[v.group.id][v.goff:v.goff + cin].double()
+            sh = ex.gshift[v.group.id][v.goff:v.goff + cin].double()
+            a = (a * sc + sh).float().double()               # the prologue's single fp32 fma
+        if v.group is not None or v.act != O_.ACT_NONE:
+            a = _act64(a, v.act).float().to(torch.bfloat16).double()      # ... rounded to bf16 as every Keras layer output is
+        w = torch.from_numpy(weights[op.w.name]).to(DEV)
+        wb = w.to(torch.bfloat16).double()                    # the bf16 mirror the kernels read
+        cout = w.shape[-1] if op.kind != 'conv_dw' else op.c
+        got = ex.view(op.out)[..., :cout].double()
+        dz = ex.view(op.out, grad=True)[..., :cout].double() if op.out.requires_grad else None
+        if op.kind == 'conv_pw':
+            ref = (a.reshape(-1, cin) @ wb.reshape(cin, cout)).reshape(got.shape)
+            gw = (a.reshape(-1, cin).t() @ dz.reshape(-1, cout)).reshape(w.shape) if dz is not None else None
+        elif op.kind == 'conv_dw':
+            ref = torch.zeros(got.shape, **f64)
+            gw = torch.zeros(w.shape, **f64) if dz is not None else None
+            for ky, kx, s in _taps(a, op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo):
+                ref += s * wb[ky, kx, :, 0]
+                if gw is not None:
+                    gw[ky, kx, :, 0] = (s * dz).sum((0, 1, 2))
+        else:
+            ref = torch.zeros(got.shape, **f64)
+            gw = torch.zeros(w.shape, **f64) if dz is not None else None
+            for ky, kx, s in _taps(a, op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo):
+                ref += (s.reshape(-1, cin) @ wb[ky, kx]).reshape(got.shape)
+                if gw is not None:
+                    gw[ky, kx] = s.reshape(-1, cin).t() @ dz.reshape(-1, cout)
+        if op.b is not None:
+            ref = ref + torch.from_numpy(weights[op.b.name]).to(DEV).double()
+        rmax = float(ref.abs().max())
+        tol = 1.01 * 2.0 ** -8 * ref.abs() + 2e-3 * rmax + 1e-30
+        if op.name == 'conv_upsample':
+            tol = torch.full_like(ref, 1e-4 * max(1.0, rmax))      # the logits layer writes fp32
+        frac = float(((got - ref).abs() <= tol).double().mean())
+        rows = got.numel() // cout
+        kinds.add((op.kind, op.k, op.stride, op.rate, 'long' if rows >= 65536 else ('few' if rows <= 64 else 'mid')))
+        if frac <= 0.999:
+            bad.append((op.name, 'forward', frac, float((got - ref).abs().max()), rmax))
+        if gw is not None and op.w.trainable:
+            g = torch.from_numpy(np.ascontiguousarray(st.get(op.w, st.G))).to(DEV).double().reshape(gw.shape)
+            scale = float(gw.abs().max())
+            if scale > 1e-12:
+                err = float((g - gw).abs().max()) / scale
+                rel = float(torch.linalg.norm(g - gw) / torch.linalg.norm(gw))
+                if err > 4e-3 or rel > 4e-3:
+                    bad.append((op.name, 'weight gradient', err, rel))
+        del a, ref, got, dz, gw
+    assert not bad, bad[:10]
+    # the launch shapes this walked: long / mid / few-row pointwise, 3 x 3 and 5 x 5 depthwise at strides 1 / 2 and rates 1 / 2 / 6 / 12 / 18, the stem
+    assert {k[0] for k in kinds} == {'conv_pw', 'conv_dense', 'conv_dw'}
+    assert any(k[0] == 'conv_dw' and k[1] == 5 for k in kinds) and any(k[0] == 'conv_dw' and k[3] == 18 for k in kinds)
+    assert any(k[0] == 'conv_pw' and k[4] == 'long' for k in kinds) and any(k[0] == 'conv_pw' and k[4] == 'few' for k in kinds)

@@ -254,3 +254,63 @@ def test_identical_ranks_other_world_sizes_and_the_segmented_fallback(world, seg
     assert ex.dist is ctx and ex.dist.world_size == world and ex.graphed
     assert got_l == ref_l, (got_l, ref_l)
     assert max(float(np.abs(got_w[k] - ref_w[k]).max()) for k in ref_w) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# round 4: the first lease with two devices validates itself
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _two_rank_job(model_type, world, out, extra_env):
+    """child job (a fresh process: nothing here has touched the GPU through it): `world` ranks of scripts/dist_two_rank.py"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, 'scripts', 'dist_two_rank.py')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', DL3P_DIST_TIMEOUT_S='240')
+    env.update(extra_env)
+    if world == 1:
+        cmd = [sys.executable, script, 'worker', model_type, out]
+    else:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+               '--master-port', str(_free_port()), script, 'worker', model_type, out]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and os.path.exists(out), (cmd, r.stdout[-1500:], r.stderr[-3000:])
+    import numpy as np
+    return np.load(out)
+
+
+@pytest.mark.parametrize('model_type', ['mobilenetv2', 'xception'])
+def test_two_ranks_equal_one_rank_on_two_devices(model_type, tmp_path):
+    """RCCL with N > 1 (train.py:143-158): two ranks, each on its half of one batch, against one rank on the whole batch --
+    losses and every updated weight to 1e-5 -- with the collectives captured into the hipGraphs (default), issued eagerly between
+    graph segments (DL3P_COLLECTIVES_IN_GRAPH=0) and on one communicator (DL3P_ONE_COMM=1).  Skipped on a single device; the first
+    lease that shows two runs it."""
+    import numpy as np
+    import torch
+    if torch.cuda.device_count() < 2:       # (counting devices does not initialise the GPU in this process)
+        pytest.skip('needs two visible devices: torch.cuda.device_count() = %d' % torch.cuda.device_count())
+    ref = _two_rank_job(model_type, 1, str(tmp_path / 'one.npz'), {'DL3P_FOLD_APPLY': '0'})
+    assert int(ref['info'][0]) == 1 and int(ref['info'][1]) == 0
+    for tag, env in (('in_graph', {}), ('segmented', {'DL3P_COLLECTIVES_IN_GRAPH': '0'}), ('one_comm', {'DL3P_ONE_COMM': '1'})):
+        got = _two_rank_job(model_type, 2, str(tmp_path / (tag + '.npz')), env)
+        assert int(got['info'][0]) == 2 and int(got['info'][1]) > 0, (tag, got['info'])       # two RCCL ranks, collectives in the step
+        assert np.allclose(got['losses'], ref['losses'], rtol=1e-5, atol=0), (tag, got['losses'], ref['losses'])
+        for k in ref.files:
+            if k.startswith('w:'):
+                scale = max(1e-3, float(np.abs(ref[k]).max()))
+                assert float(np.abs(got[k] - ref[k]).max()) <= 1e-5 * scale + 1e-7, (tag, k)
+
+
+def test_two_rank_worker_runs_on_one_device(tmp_path):
+    """the worker of the test above, as ONE rank (so that it is exercised on every lease): three steps, finite, no collectives"""
+    import numpy as np
+    ref = _two_rank_job('mobilenetv2', 1, str(tmp_path / 'one.npz'), {})
+    assert int(ref['info'][0]) == 1 and int(ref['info'][1]) == 0 and int(ref['info'][2]) == 1
+    assert np.all(np.isfinite(ref['losses'])) and abs(float(ref['losses'][0]) - np.log(21)) < 0.6

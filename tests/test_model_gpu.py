@@ -807,9 +807,8 @@ def test_recompile_with_a_new_optimizer_keeps_the_dropout_stream():
 # inputs, at op-test tolerances.  The shortcuts of the production backward (folded apply, aliased Add gradients) are off so that
 # every conv output's gradient buffer holds d loss / d z at the end of the step; tests/test_ops_gpu.py and the
 # "backward shortcuts == same step with all of them off" test carry the result over to the production plan.
-def _teacher_forced_step(model_type, H, W, OS, N, tol_fwd, tol_dz, tol_w):
+def _teacher_forced_step(model_type, H, W, OS, N, tol_fwd, tol_dz, tol_w, C=21):
     _skip_if_missing(model_type)
-    C = 21
     m, o = _pair(model_type, H, W, C, OS=OS)
     m.use_graphs = False
     x, y = _data(N, H, W, C, seed=13)

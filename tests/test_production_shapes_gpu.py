@@ -269,3 +269,50 @@ def test_every_layer_at_513_matches_float64_on_the_devices_own_inputs(model_type
         _teacher_forced_step(model_type, 513, 513, 16, 3, 1e-4, 2e-3, 2e-3)
     else:
         _teacher_forced_step(model_type, 513, 513, 16, 2, 2e-5, 5e-4, 1e-3)
+
+
+# ------------------------------------------------------------------------------------------- BASELINE configs[3] (VERDICT r03 missing 6)
+def test_config3_full_size_properties():
+    """BASELINE.json configs[3] at ITS size -- Xception + ASPP (rates 12 / 24 / 36) + decoder, output stride 8, 769 x 769,
+    19 Cityscapes classes, per-GPU batch 2 -- where the float64 oracle would need many minutes: the size-independent properties
+    configs[1] / [4] get.  Training is bitwise deterministic and hipGraph replay equals eager launches (losses and every weight
+    after three steps), the first loss on random weights is close to ln 19, every weight stays finite, predict returns
+    probability vectors."""
+    pkg = load_pkg()
+    N, C, H, W = 2, 19, 769, 769
+    rng = np.random.default_rng(23)
+    x = rng.uniform(-1, 1, (N, H, W, 3)).astype(np.float32)
+    y = rng.integers(0, C, (N, H * W, 1)).astype(np.float32)
+    y[rng.uniform(size=y.shape) < 0.05] = 255
+
+    def run(use_graphs):
+        m = pkg.get_deeplabv3p_model('xception', C, (H, W), 8, training=True)
+        m.compile(optimizer=pkg.SGD(0.01, momentum=0.9), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
+        m.use_graphs = use_graphs
+        losses = [m.train_on_batch(x, y) for _ in range(3)]
+        w = m.get_weights_by_name()
+        del m
+        torch.cuda.empty_cache()
+        return losses, w
+    la, wa = run(False)
+    lb, wb = run(True)
+    assert la == lb, (la, lb)
+    assert all(np.array_equal(wa[k], wb[k]) for k in wa)
+    assert abs(la[0] - np.log(C)) < 0.5, la
+    assert all(np.isfinite(v).all() for v in wa.values())
+    mi = pkg.get_deeplabv3p_model('xception', C, (H, W), 8, training=False)
+    mi.set_weights_by_name(wa)
+    p = mi.predict(x[:1])
+    assert p.shape == (1, H, W, C) and np.abs(p.sum(-1) - 1.0).max() < 1e-5 and p.min() >= 0.0
+
+
+def test_every_layer_of_config3s_graph_matches_float64_on_the_devices_own_inputs(monkeypatch):
+    """The layer-local comparison (tests/test_model_gpu.py::_teacher_forced_step) on configs[3]'s GRAPH -- Xception, output stride 8
+    (exit-flow rates 2 / 4, ASPP rates 12 / 24 / 36), 19 classes, production dispatch thresholds -- at 193 x 193, batch 2: the
+    float64 oracle needs ~15 min for 769 x 769 (the GPU suite has 20 for everything), so the full size gets the properties above
+    and every layer's forward / data-gradient + BatchNorm-backward segment / weight gradient is held against float64 here, on
+    25 x 25 maps with the atrous taps of all three regimes (window, 3-class lattice, 2-class lattice: 36 > 25)."""
+    from test_model_gpu import _teacher_forced_step
+    monkeypatch.setenv('DL3P_FOLD_APPLY', '0')
+    monkeypatch.setenv('DL3P_GRAD_ALIAS', '0')
+    _teacher_forced_step('xception', 193, 193, 8, 2, 1e-4, 2e-3, 2e-3, C=19)

@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256 * WM, (WM == 1 && NT <= 8) ? 2 : 1) void pw_gem
 // and the epilogue of a row tile overlaps the staging of the next one's first K-steps.
 template <int NT, bool STATS, int MI, bool BNB>
 __global__ __launch_bounds__(512, 1) void pw_gemm_sbp_kernel(GemmParams p) {
-  constexpr int BKT = SB_BKT, PB = SB_PB;
+  constexpr int BKT = SB_BKT, PB = SBP_PB;
   constexpr int BM = 64 * MI, BN = 16 * NT;
   constexpr int A_PLANE = BM * PB, B_PLANE = BN * PB;          // bf16 elements
   constexpr int STAGE = 3 * (A_PLANE + B_PLANE);               // one operand buffer, bf16 elements
@@ -796,7 +796,7 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_sbp_kernel(GemmParams p) {
 template <int NT, bool STATS, int MI, bool BNB>
 static void launch_sbp_one(const GemmParams& p, dim3 grid, hipStream_t st) {
   constexpr int BM = 64 * MI, BN = 16 * NT;
-  constexpr int STAGE_B = 3 * (BM + BN) * SB_PB * 2;
+  constexpr int STAGE_B = 3 * (BM + BN) * SBP_PB * 2;
   constexpr int TPP = NT < 4 ? NT : 4;
   constexpr int ES = 4 * 16 * MI * (16 * TPP + 4) * 4;
   constexpr int RED = STATS ? 2 * 4 * BN * 4 : 0;
