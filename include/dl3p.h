@@ -116,6 +116,20 @@ int dl3p_pwconv_bwd_data_sb(const float* dy, int lddy, const void* wsp, int pitc
                             int M, int K, int N, const float* z, int ldz, const float* scale, const float* shift,
                             int act, const float* save_mean, const float* save_invstd, float* partials,
                             int* rows_out, void* stream);
+/* The data gradient above with the BatchNorm-backward APPLY of the conv's own BatchNormalization (reference layers.py:63-70 behind
+ * layers.py:105,209-218) folded into its staged operand (csrc/pw_split_rs.hip, the row-stationary form): instead of dy it reads the
+ * gradient g of act(BN(z_out)) and z_out, forms dz = coef0 (g act'(z_out bn_scale + bn_shift) - coef1 - xhat coef2) -- exactly
+ * dl3p_bn_bwd_apply's arithmetic, evaluated as A g act' - C z + D -- once per element while the row tile is staged, multiplies with
+ * it and writes it to dz (dz may be g: every element is read and written by the same lane), where the weight gradient that follows
+ * reads it.  One pass over the [M][N] tensor and one launch less per BatchNorm.  dl3p_pwconv_bwd_data_sb_apply_supported: long
+ * layers (M >= 131072) with a reduction N of 225 .. 256 and none / ReLU / ReLU6 behind the BatchNorm. */
+int dl3p_pwconv_bwd_data_sb_apply_supported(int M, int K, int N, int bn_act, int with_sums);
+int dl3p_pwconv_bwd_data_sb_apply(const float* g, int ldg, const float* z_out, int ldz_out, const float* bn_scale,
+                                  const float* bn_shift, int bn_act, const float* bn_mean, const float* bn_invstd,
+                                  const float* bn_coef, float* dz, int lddz, const void* wsp, int pitch, float* gx, int ldgx,
+                                  int accumulate, int M, int K, int N, const float* z, int ldz, const float* scale,
+                                  const float* shift, int act, const float* save_mean, const float* save_invstd,
+                                  float* partials, int* rows_out, void* stream);
 
 /* ---------------------------------------------------------------- depthwise convolution
  * replaces DepthwiseConv2D (DepthwiseConv2dNative [+SpaceToBatchND for dilation]) at

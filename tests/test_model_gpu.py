@@ -871,3 +871,48 @@ def test_every_layer_matches_float64_on_the_devices_own_inputs(model_type, H, W,
     # and after 100+ randomly initialised layers the two images' pooled features nearly coincide (variance << eps): the layer
     # then amplifies fp32 rounding of its input by 1 / sqrt(eps) = 316 whatever the kernels do
     _teacher_forced_step(model_type, H, W, OS, 4 if model_type in ('resnet50', 'xception') else 2, 2e-5, 5e-4, 1e-3)
+
+
+def test_the_apply_folded_into_the_data_gradient_does_not_change_gradients(monkeypatch):
+    """round 4: the BatchNorm-backward apply folded into the staged operand of the row-stationary data gradient
+    (dl3p_pwconv_bwd_data_sb_apply, executor._folds_apply_dgrad) serves the long decoder layers only (>= 131072 rows): MobileNetV2 at
+    513 x 513, batch 8 (133128 rows at 129 x 129) -- with it the step has two bn_bwd_apply launches fewer and gives the same
+    gradients as without it, to rounding (dz = A g m - C z + D against c0 (g m - c1 - xhat c2))"""
+    pkg = load_pkg()
+    ops = load_pkg('ops')
+    N, C, H, W = 8, 21, 513, 513
+    x, y = _data(N, H, W, C, seed=19)
+    ops.lib().set_option(b'pw_small_min_rows', -1)          # production dispatch
+
+    def grads(env):
+        for k in ('DL3P_FOLD_APPLY_DGRAD',):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        torch.manual_seed(0)
+        m = pkg.get_deeplabv3p_model('mobilenetv2', C, (H, W), 16, training=True)
+        m.compile(optimizer=pkg.SGD(0.01), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
+        m.use_graphs = False
+        loss = m.train_on_batch(x, y)
+        st = m._store
+        ex = m._executor(N, True)
+        labels = [getattr(it, 'label', '') or '' for it in ex.bwd.items]
+        g = {p.name: np.array(st.get(p, st.G), dtype=np.float64) for p in m.graph.all_params() if p.trainable}
+        n_items = len(ex.bwd.items)
+        del m, ex
+        torch.cuda.empty_cache()
+        return loss, g, n_items
+    try:
+        l1, g1, n1 = grads({})
+        l0, g0, n0 = grads({'DL3P_FOLD_APPLY_DGRAD': '0'})
+    finally:
+        ops.lib().set_option(b'pw_small_min_rows', 64)
+    assert n0 - n1 == 2, 'two apply launches fewer (decoder_conv0 / conv1 pointwise): %d vs %d' % (n1, n0)
+    assert abs(l1 - l0) <= 1e-6 * abs(l0)
+    gmax = max(float(np.abs(a).max()) for a in g0.values())
+    worst = ('', 0.0)
+    for name, a in g0.items():
+        r = float(np.abs(a - g1[name]).max() / (np.abs(a).max() + 1e-4 * gmax))
+        if r > worst[1]:
+            worst = (name, r)
+    assert worst[1] < 3e-3, worst

@@ -350,3 +350,58 @@ def test_row_stationary_split_gemm(ops, case):
     finally:
         L.set_option(b'pw_small_min_rows', 64)
         L.set_option(b'sb_rs', -1)
+
+
+@pytest.mark.parametrize('case', [(131072 + 77, 304, 256), (140000, 256, 256), (133000, 48, 232)])
+@pytest.mark.parametrize('act_name', ['relu6', 'relu', 'none'])
+def test_data_gradient_with_the_folded_batchnorm_apply(ops, case, act_name):
+    """dl3p_pwconv_bwd_data_sb_apply (csrc/pw_split_rs.hip, FOLD): dz = c0 (g act'(z s + t) - c1 - xhat c2) formed while the row
+    tile is staged, written once (over g when no other destination is given), multiplied -> gx, with and without the fused
+    BatchNorm-backward sums of the layer in front; all of it against float64"""
+    M, K, N = case          # K output columns, N the reduction (= channels of the folded BatchNorm)
+    act = {'relu6': ops.ACT_RELU6, 'relu': ops.ACT_RELU, 'none': ops.ACT_NONE}[act_name]
+    L = ops.lib()
+    assert L.pwconv_bwd_data_sb_apply_supported(M, K, N, act, 1) == 1
+    assert L.pwconv_bwd_data_sb_apply_supported(M, K, N, ops.ACT_HSWISH, 1) == 0 and L.pwconv_bwd_data_sb_apply_supported(4096, K, N, act, 1) == 0
+    g_ = torch.Generator(device=DEV); g_.manual_seed(M + K + N)
+    rnd = lambda *s: torch.randn(*s, device=DEV, generator=g_)
+    g = rnd(M, N)
+    z_out = rnd(M, N) * 1.5 + 0.3
+    bsc, bsh = torch.rand(N, device=DEV, generator=g_) + 0.5, rnd(N) * 0.5 + (1.0 if act == ops.ACT_RELU6 else 0.0)
+    mu, istd = rnd(N) * 0.2, torch.rand(N, device=DEV, generator=g_) + 0.5
+    coef = torch.stack([torch.rand(N, device=DEV, generator=g_) + 0.5, rnd(N) * 0.1, rnd(N) * 0.1]).contiguous()
+    w = (rnd(K, N) / N ** 0.5).contiguous()
+    w_sp = ops.split_bf16x3(w)
+    u = z_out.double() * bsc.double() + bsh.double()
+    if act == ops.ACT_RELU6:
+        m = ((u > 0) & (u < 6)).double()
+    elif act == ops.ACT_RELU:
+        m = (u > 0).double()
+    else:
+        m = torch.ones_like(u)
+    dz64 = coef[0].double() * (g.double() * m - coef[1].double() - (z_out.double() - mu.double()) * istd.double() * coef[2].double())
+    gx64 = dz64 @ w.double().t()
+    # plain, dz to its own buffer
+    dz = torch.full((M, N), float('nan'), device=DEV)
+    gx = torch.full((M, K), float('nan'), device=DEV)
+    ops.pwconv_bwd_data_sb_apply(g, z_out, bsc, bsh, act, mu, istd, coef, w_sp, N, dz=dz, out=gx)
+    assert float((dz.double() - dz64).abs().max()) < 4e-6 * float(dz64.abs().max()), 'dz'
+    assert float((gx.double() - gx64).abs().max()) < 2e-5 * float(gx64.abs().max()), 'gx'
+    # with the fused BatchNorm-backward sums of the layer in front, dz IN PLACE of g, accumulate into gx
+    z = rnd(M, K)
+    sc, sh = torch.rand(K, device=DEV, generator=g_) + 0.5, rnd(K) * 0.3
+    mean, invstd = z.mean(0), 1.0 / torch.sqrt(z.var(0, unbiased=False) + 1e-3)
+    part = ops.new_partials(K, DEV)
+    base = rnd(M, K)
+    g2 = g.clone()
+    dz2, gx2, rows = ops.pwconv_bwd_data_sb_apply(g2, z_out, bsc, bsh, act, mu, istd, coef, w_sp, N, out=base.clone(), accumulate=True,
+                                                  z=z, scale=sc, shift=sh, act=ops.ACT_RELU6, mean=mean, invstd=invstd, partials=part)
+    assert dz2.data_ptr() == g2.data_ptr() and torch.equal(dz2, dz), 'in place == separate buffer, bit for bit'
+    tot64 = gx64 + base.double()
+    assert float((gx2.double() - tot64).abs().max()) < 2e-5 * float(gx64.abs().max()), 'gx (accumulate)'
+    uu = z.double() * sc.double() + sh.double()
+    d = tot64 * ((uu > 0) & (uu < 6))
+    xh = (z.double() - mean.double()) * invstd.double()
+    p = part[:rows * 2 * K].reshape(rows, 2, K).double().sum(0)
+    assert float((p[0] - d.sum(0)).abs().max()) < 2e-4 * float(d.abs().sum(0).max()), 'BN backward sum'
+    assert float((p[1] - (d * xh).sum(0)).abs().max()) < 2e-4 * float((d * xh).abs().sum(0).max()), 'BN backward sum * xhat'

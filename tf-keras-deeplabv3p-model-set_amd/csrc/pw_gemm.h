@@ -32,4 +32,9 @@ struct GemmParams {
   // pw_split.hip: the B operand pre-split into three bf16 planes (dl3p_split_bf16x3), [plane][Nout rows][bsp_pitch] with the
   // reduction index contiguous and zero-padded to a multiple of 32; bsp_plane = elements per plane
   const unsigned short* Bsp; int bsp_pitch; long long bsp_plane;
+  // pw_split_rs.hip, FOLD instantiations (data gradient): the A operand is the BatchNorm-backward apply of (A = g, f_z) formed
+  // while the row tile is staged -- dz = c0 (g act'(z scale + shift) - c1 - xhat c2), dl3p_bn_bwd_apply's arithmetic as
+  // A g act' - C z + D -- and written once to f_dz (the weight gradient that follows reads it there)
+  const float* f_z; int f_ldz; const float* f_scale; const float* f_shift; const float* f_mean; const float* f_invstd;
+  const float* f_coef; int f_act; float* f_dz; int f_lddz;
 };

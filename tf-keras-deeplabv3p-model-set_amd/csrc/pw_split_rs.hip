@@ -28,13 +28,13 @@ template <int NK, int CG>
 struct RsCfg {
   static_assert(NK % 2 == 0, "the two staging slots take NK / 2 chunks each");
   static constexpr int NI = CG / 16;
-  static constexpr int NMAX = NK <= 8 ? 512 : 256;   // output columns served (LDS: the epilogue coefficients; 16 statistics registers)
+  static constexpr int NMAX = NK <= 8 ? 320 : 256;   // output columns served (LDS: the epilogue coefficients; one statistics register per column group)
   // bytes per B-tile row: + 32 -> 16 consecutive rows x four 16-byte chunks cover the 64 banks once (+ 16 at K = 320, two-way, to fit)
   static constexpr int PITCHB = NK * 64 + ((NK <= 8 || CG == 16) ? 32 : 16);
   static constexpr int BPLANE = CG * PITCHB;
   static constexpr int BTILE = 3 * BPLANE;
   // producer scale / shift (zero-padded to 32 NK) + the epilogue's per-column vectors: bias, or the four of the fused BatchNorm-backward sums
-  static constexpr int COEF = 2 * NK * 32 * 4 + 4 * NMAX * 4;
+  static constexpr int COEF = (NK <= 8 ? 5 : 2) * NK * 32 * 4 + 4 * NMAX * 4;      // (five per reduction channel for the folded BatchNorm-backward apply, K <= 256)
   static constexpr int APITCH = (2 * BTILE + 8 * 3 * 16 * 96 + COEF <= 160 * 1024) ? 96 : 80;   // bytes per row of the wave-private A slice
   static constexpr int AREG = 3 * 16 * APITCH;       // (also the 16 x 36-float statistics patch: 2304 B)
   static constexpr int COEF_OFF = 2 * BTILE + 8 * AREG;
@@ -46,7 +46,8 @@ struct RsCfg {
 };
 
 // MODE 0: plain, 1: + BatchNorm statistics of the output, 2: + fused BatchNorm-backward sums (data gradient; GemmParams::bb_*)
-template <int NK, int CG, int MODE>
+// CPS: K chunks staged per staging slot (NK / CPS staging slots per row tile, CPS chunk loads of 32 bytes in flight per lane)
+template <int NK, int CG, int MODE, int CPS, bool FOLD = false>
 __global__ __launch_bounds__(512, 1) void pw_gemm_sbr_kernel(GemmParams p) {
   using C = RsCfg<NK, CG>;
   static_assert(MODE != 2 || C::AREG >= 2 * 16 * 36 * 4, "two statistics patches");
@@ -74,13 +75,27 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_sbr_kernel(GemmParams p) {
 #else
 #define RS_STAMP(slot, k) do { } while (0)
 #endif
+  static_assert(!FOLD || NK <= 8, "LDS for the five folded coefficient vectors");
   for (int i = t; i < NK * 32; i += 512) {
-    const bool in = p.scale && i < p.K;
-    coef[i] = in ? p.scale[i] : 1.f;
-    coef[NK * 32 + i] = in ? p.shift[i] : 0.f;
+    if (FOLD) {
+      // dz = c0 (g m - c1 - (z - mean) invstd c2) = fA g m + fnC z + fD with fA = c0, fnC = -c0 c2 invstd, fD = -fnC mean - c0 c1
+      const bool in = i < p.K;
+      const int k = min(i, p.K - 1);
+      const float c0 = p.f_coef[k], c1 = p.f_coef[p.K + k], c2 = p.f_coef[2 * p.K + k];
+      const float nC = -(c0 * p.f_invstd[k] * c2);
+      coef[i] = in ? p.f_scale[k] : 1.f;
+      coef[NK * 32 + i] = in ? p.f_shift[k] : 0.f;
+      coef[2 * NK * 32 + i] = in ? c0 : 0.f;
+      coef[3 * NK * 32 + i] = in ? nC : 0.f;
+      coef[4 * NK * 32 + i] = in ? -(nC * p.f_mean[k]) - c0 * c1 : 0.f;
+    } else {
+      const bool in = p.scale && i < p.K;
+      coef[i] = in ? p.scale[i] : 1.f;
+      coef[NK * 32 + i] = in ? p.shift[i] : 0.f;
+    }
   }
   // per-output-column vectors of the epilogue: a global load there is a full memory latency in front of every slot's barrier
-  float* ecoef = coef + 2 * NK * 32;                 // [4][NMAX]
+  float* ecoef = coef + (NK <= 8 ? 5 : 2) * NK * 32;                 // [4][NMAX]
   for (int i = t; i < C::NMAX; i += 512) {
     const int n = min(i, p.N - 1);
     if (BNB) {
@@ -91,7 +106,9 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_sbr_kernel(GemmParams p) {
   }
 
   const int ncg = (p.N + CG - 1) / CG;
-  const int P = ncg + 2, SKEW = P / 2;
+  static_assert(NK % CPS == 0, "whole staging slots");
+  constexpr int ASL = NK / CPS;                      // staging slots per row tile
+  const int P = ncg + ASL, SKEW = P / 2;
   const int nht = p.num_m_tiles;                     // half tiles of 64 rows (one per wave group and period)
   const int stride = 2 * (int)gridDim.x;
   const int first = 2 * (int)blockIdx.x + grp;
@@ -146,7 +163,7 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_sbr_kernel(GemmParams p) {
 
   // ---------------------------------------------------------------- staging a row tile (wave-private)
   s16x8 afr[NK][3];
-  constexpr int NH = NK / 2;        // chunks per staging slot = row-tile loads in flight per lane (NH x 32 bytes)
+  constexpr int NH = CPS;           // chunks per staging slot = row-tile loads in flight per lane (NH x 32 bytes)
   float4 ra[NH][2];
   const float act_lo = p.act == DL3P_ACT_NONE ? -DL3P_INF : 0.f;
   const float act_hi = (p.act == DL3P_ACT_NONE || p.act == DL3P_ACT_RELU) ? DL3P_INF : 6.f;
@@ -154,10 +171,30 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_sbr_kernel(GemmParams p) {
   // one base address per row tile (set when its chunk 0 is requested), chunks at immediate offsets; only the LAST chunk can reach
   // past K and clamps per lane (per-chunk clamps and masks are loop invariants the compiler keeps in registers: 20 per chunk)
   const char* arow = Ab;
+  const char* zrow = reinterpret_cast<const char*>(p.f_z);       // FOLD: the second tensor of the staged operand, and where dz goes
+  char* dzrow = reinterpret_cast<char*>(p.f_dz);
+  float4 rz[FOLD ? NH : 1][2];
   const float* coef_l = coef + ac * 8;
   auto issue_a = [&](int m0w, auto ktc) __attribute__((always_inline)) {
     constexpr int KT = decltype(ktc)::value;
-    if constexpr (KT == 0) arow = Ab + ((size_t)min(m0w + ar, p.M - 1) * (size_t)p.lda * 4u + (size_t)ac * 32u);
+    if constexpr (KT == 0) {
+      const size_t r = (size_t)min(m0w + ar, p.M - 1);
+      arow = Ab + (r * (size_t)p.lda * 4u + (size_t)ac * 32u);
+      if (FOLD) {
+        zrow = reinterpret_cast<const char*>(p.f_z) + (r * (size_t)p.f_ldz * 4u + (size_t)ac * 32u);
+        dzrow = reinterpret_cast<char*>(p.f_dz) + (r * (size_t)p.f_lddz * 4u + (size_t)ac * 32u);
+      }
+    }
+    if (FOLD) {
+      if constexpr (KT == NK - 1) {
+        const int kk = KT * 32 + ac * 8;
+        rz[KT % NH][0] = *reinterpret_cast<const float4*>(zrow + (min(kk, p.K - 4) - ac * 8) * 4);
+        rz[KT % NH][1] = *reinterpret_cast<const float4*>(zrow + (min(kk + 4, p.K - 4) - ac * 8) * 4);
+      } else {
+        rz[KT % NH][0] = *reinterpret_cast<const float4*>(zrow + KT * 128);
+        rz[KT % NH][1] = *reinterpret_cast<const float4*>(zrow + KT * 128 + 16);
+      }
+    }
     if constexpr (KT == NK - 1) {
       const int kk = KT * 32 + ac * 8;
       ra[KT % NH][0] = *reinterpret_cast<const float4*>(arow + (min(kk, p.K - 4) - ac * 8) * 4);
@@ -183,7 +220,21 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_sbr_kernel(GemmParams p) {
     const bool rok = m0w + ar < p.M;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      if (has_pro) {
+      if (FOLD) {
+        // the BatchNorm-backward apply of (g, z), channel k of the reduction: none / ReLU / ReLU6 derivative as a 0 / 1 mask
+        const float* c5 = coef_l + KT * 32 + 4 * h;
+        const float4 z = rz[KT % NH][h];
+        const float4 u = fma4(z, *reinterpret_cast<const float4*>(c5), *reinterpret_cast<const float4*>(c5 + NK * 32));
+        const float glo = p.f_act == DL3P_ACT_NONE ? -DL3P_INF : 0.f;
+        const float ghi = (p.f_act == DL3P_ACT_NONE || p.f_act == DL3P_ACT_RELU) ? DL3P_INF : 6.f;
+        const float4 gm = make_float4((u.x > glo && u.x < ghi) ? v[h].x : 0.f, (u.y > glo && u.y < ghi) ? v[h].y : 0.f,
+                                      (u.z > glo && u.z < ghi) ? v[h].z : 0.f, (u.w > glo && u.w < ghi) ? v[h].w : 0.f);
+        v[h] = fma4(gm, *reinterpret_cast<const float4*>(c5 + 2 * NK * 32),
+                    fma4(z, *reinterpret_cast<const float4*>(c5 + 3 * NK * 32), *reinterpret_cast<const float4*>(c5 + 4 * NK * 32)));
+        bool okf = rok;
+        if constexpr (KT == NK - 1) okf = okf && KT * 32 + ac * 8 + 4 * h < p.K;
+        if (okf) *reinterpret_cast<float4*>(dzrow + KT * 128 + 16 * h) = v[h];      // each element exactly once: in place of g is fine
+      } else if (has_pro) {
         if (p.scale) v[h] = fma4(v[h], *reinterpret_cast<const float4*>(coef_l + KT * 32 + 4 * h), *reinterpret_cast<const float4*>(coef_l + NK * 32 + KT * 32 + 4 * h));
         if (p.act >= DL3P_ACT_HSWISH) v[h] = act_apply4(v[h], p.act);
         else v[h] = make_float4(__builtin_amdgcn_fmed3f(v[h].x, act_lo, act_hi), __builtin_amdgcn_fmed3f(v[h].y, act_lo, act_hi),
@@ -272,17 +323,19 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_sbr_kernel(GemmParams p) {
     // NK x NI steps of six MFMAs; the B fragments of step + 1 are requested in front of the MFMAs of step (two register sets) and a
     // scheduling barrier closes every step: left alone, the scheduler hoists the fragment reads of the whole slot to its top
     // (24 registers per K chunk -- 150 spilled at K = 320)
-    s16x8 wb[2][3];
+    constexpr int WBD = (FOLD && BNB) ? 1 : 2;        // fragment sets (one where the registers are needed for the second staged tensor)
+    s16x8 wb[WBD][3];
     auto read_b = [&](auto stc) __attribute__((always_inline)) {
       constexpr int ST = decltype(stc)::value, KT = ST / NI, ni = ST % NI;
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) wb[ST & 1][pl] = *reinterpret_cast<const s16x8*>(Bt + pl * BPLANE + ni * 16 * PITCHB + KT * 64);
+      for (int pl = 0; pl < 3; ++pl) wb[ST % WBD][pl] = *reinterpret_cast<const s16x8*>(Bt + pl * BPLANE + ni * 16 * PITCHB + KT * 64);
     };
     RS_STAMP(s, 1);
-    if (abl != 6) read_b(std::integral_constant<int, 0>{});
+    if (abl != 6 && WBD == 2) read_b(std::integral_constant<int, 0>{});
     if (abl != 6) static_for<NK * NI>([&](auto stc) {
-      constexpr int ST = decltype(stc)::value, KT = ST / NI, ni = ST % NI, S2 = ST & 1;
-      if constexpr (ST + 1 < NK * NI) read_b(std::integral_constant<int, ST + 1>{});
+      constexpr int ST = decltype(stc)::value, KT = ST / NI, ni = ST % NI, S2 = ST % WBD;
+      if constexpr (WBD == 1) read_b(stc);
+      else if constexpr (ST + 1 < NK * NI) read_b(std::integral_constant<int, ST + 1>{});
       if (abl != 4) b_piece(stc);          // (pieces past NBC are empty)
       // smallest terms first; MFMA "A" = weights (row = output channel), "B" = activations (column = pixel): a lane ends with 4
       // consecutive output channels of one pixel
@@ -297,7 +350,7 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_sbr_kernel(GemmParams p) {
       acc[ni] = c;
       // inside the step: the next step's fragment reads FIRST (left alone they sink behind the fourth MFMA and the step after
       // waits a whole LDS round trip for them), then this step's piece of the B stream, then the six MFMAs
-      if constexpr (ST + 1 < NK * NI) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      if constexpr (WBD == 1 || ST + 1 < NK * NI) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
       if constexpr (ST < NBC) { __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
       __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
       __builtin_amdgcn_sched_barrier(0);
@@ -394,32 +447,24 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_sbr_kernel(GemmParams p) {
     // (it cannot know what the slot before issued: vmcnt(6) at every piece), so a B piece behind a row-tile request waits out that
     // request's whole HBM latency (in-kernel stamps: 1.2-4.6 k cycles per staged chunk, the multiply loop of the slot that prefetches
     // the next tile twice as long).  Hence, in every slot: ALL B pieces first, row-tile requests after them.
-    slot_head();
-    if (STATS) lazy_stats();                          // (the patch lives in the slice the chunks are about to overwrite)
-    if (abl != 4) b_all();
-    RS_STAMP(s, 1);
-    static_for<NH>([&](auto ktc) {
-      constexpr int KT = decltype(ktc)::value;
-      if (do_a) stage_chunk(m0w, ktc);
-      if (!(abl == 7 && j > 0)) issue_a(m0w, std::integral_constant<int, KT + NH>{});
-      if constexpr (KT > 0) { if (do_a) fetch_chunk(std::integral_constant<int, KT - 1>{}); }
-      if (do_a) commit_chunk();
-      RS_STAMP(s, 4 + (KT & 3));
-      __builtin_amdgcn_sched_barrier(0);      // one chunk at a time: the scheduler would otherwise start every chunk's loads first (33 registers per chunk)
+    static_for<ASL>([&](auto slc) {
+      constexpr int SL = decltype(slc)::value;
+      slot_head();
+      if constexpr (SL == 0) { if (STATS) lazy_stats(); }      // (the patch lives in the slice the chunks are about to overwrite)
+      if (abl != 4) b_all();
+      RS_STAMP(s, 1);
+      static_for<CPS>([&](auto ic) {
+        constexpr int I = decltype(ic)::value, KT = SL * CPS + I;
+        if (do_a) stage_chunk(m0w, std::integral_constant<int, KT>{});
+        if constexpr (KT + CPS < NK) { if (!(abl == 7 && j > 0)) issue_a(m0w, std::integral_constant<int, KT + CPS>{}); }
+        if constexpr (I > 0) { if (do_a) fetch_chunk(std::integral_constant<int, KT - 1>{}); }
+        if (do_a) commit_chunk();
+        RS_STAMP(s, 4 + (I & 3));
+        __builtin_amdgcn_sched_barrier(0);      // one chunk at a time: the scheduler would otherwise start every chunk's loads first (33 registers per chunk)
+      });
+      if (do_a) fetch_chunk(std::integral_constant<int, SL * CPS + CPS - 1>{});
+      slot_tail();
     });
-    if (do_a) fetch_chunk(std::integral_constant<int, NH - 1>{});
-    slot_tail();
-    slot_head();
-    if (abl != 4) b_all();
-    static_for<NH>([&](auto kc) {
-      constexpr int KC = decltype(kc)::value;
-      if (do_a) stage_chunk(m0w, std::integral_constant<int, NH + KC>{});
-      if constexpr (KC > 0) { if (do_a) fetch_chunk(std::integral_constant<int, NH + KC - 1>{}); }
-      if (do_a) commit_chunk();
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    if (do_a) fetch_chunk(std::integral_constant<int, NK - 1>{});
-    slot_tail();
     for (int c = 0; c < ncg; ++c) {
       slot_head();
       mfma_slot((s & 1), cg0, m0w, (c == ncg - 1 && j + 1 < my_nt && abl != 7) ? m0w + stride * 64 : -1);
@@ -457,15 +502,15 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_sbr_kernel(GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------ host side
-template <int NK, int CG, int MODE>
+template <int NK, int CG, int MODE, int CPS = 2, bool FOLD = false>
 static void launch_sbr_one(const GemmParams& p, int grid, hipStream_t st) {
   using C = RsCfg<NK, CG>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)pw_gemm_sbr_kernel<NK, CG, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)pw_gemm_sbr_kernel<NK, CG, MODE, CPS, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     attr_set = true;
   }
-  dl3p_launch(pw_gemm_sbr_kernel<NK, CG, MODE>, dim3(grid), dim3(512), (size_t)C::LDS_BYTES, st, p);
+  dl3p_launch(pw_gemm_sbr_kernel<NK, CG, MODE, CPS, FOLD>, dim3(grid), dim3(512), (size_t)C::LDS_BYTES, st, p);
 }
 
 template <int MODE>
@@ -473,7 +518,15 @@ static void launch_sbr_nk(const GemmParams& p, int grid, hipStream_t st) {
   const int nk = (p.K + 31) / 32;
   if (nk == 4) launch_sbr_one<4, 32, MODE>(p, grid, st);
   else if (nk == 6) launch_sbr_one<6, 32, MODE>(p, grid, st);
-  else if (nk == 8) launch_sbr_one<8, 32, MODE>(p, grid, st);
+  else if (nk == 8 && p.f_z) {      // the folded BatchNorm-backward apply (data gradients only): two chunks per staging slot (registers)
+    if constexpr (MODE != 1) launch_sbr_one<8, 32, MODE, 2, true>(p, grid, st);
+  } else if (nk == 8) {
+    // K = 256: four chunks per staging slot (244 / 288 / 218 us forward / data gradient + sums / plain on 266256 rows against 255 / 311 /
+    // 233 with two); K = 320: two -- five spill (335 against 372 us)
+    static const int cps = getenv("DL3P_SB_RS_CPS") ? atoi(getenv("DL3P_SB_RS_CPS")) : 4;
+    if (cps == 4) launch_sbr_one<8, 32, MODE, 4>(p, grid, st);
+    else launch_sbr_one<8, 32, MODE, 2>(p, grid, st);
+  }
   else if constexpr (MODE != 2) {      // (K = 320 leaves no room for the second statistics patch)
     static const int cg16 = getenv("DL3P_SB_RS_CG16") ? atoi(getenv("DL3P_SB_RS_CG16")) : 0;
     if (cg16) launch_sbr_one<10, 16, MODE>(p, grid, st);
@@ -481,12 +534,12 @@ static void launch_sbr_nk(const GemmParams& p, int grid, hipStream_t st) {
   }
 }
 
-// shapes served: reduction up to 320 (the A fragments of a row tile live in registers), up to 512 output columns (16 statistics
+// shapes served: reduction up to 320 (the A fragments of a row tile live in registers), up to 320 output columns (10 statistics
 // registers per lane), 2 N floats of statistics scratch per wave inside the B buffers
 bool dl3p_sb_rs_supported(int role, int M, int K, int N) {
   const int nk = (K + 31) / 32;
   if (role == 3 && nk > 8) return false;        // instantiated reduction lengths: 32 nk (the pre-split kernel's pitch, its zero padding included)
-  return M >= 2048 && (nk == 4 || nk == 6 || nk == 8 || nk == 10) && K % 4 == 0 && N >= 16 && N <= (nk <= 8 ? 512 : 256) && N % 4 == 0;
+  return M >= 2048 && (nk == 4 || nk == 6 || nk == 8 || nk == 10) && K % 4 == 0 && N >= 16 && N <= (nk <= 8 ? 320 : 256) && N % 4 == 0;
 }
 
 // workgroups for M rows: one per CU, each wave group at least one half tile
@@ -502,4 +555,10 @@ void dl3p_launch_gemm_sbr(const GemmParams& p, int mode, int grid, hipStream_t s
   if (mode == 2) launch_sbr_nk<2>(p, grid, st);
   else if (mode == 1) launch_sbr_nk<1>(p, grid, st);
   else launch_sbr_nk<0>(p, grid, st);
+}
+
+// the BatchNorm-backward apply folded into the staged operand of the data gradient: reductions of 225 .. 256 (the five per-channel
+// coefficient vectors in LDS), none / ReLU / ReLU6
+bool dl3p_sb_rs_fold_supported(int M, int K, int N, int act) {
+  return dl3p_sb_rs_supported(2, M, K, N) && (K + 31) / 32 == 8 && (act == DL3P_ACT_NONE || act == DL3P_ACT_RELU || act == DL3P_ACT_RELU6);
 }

@@ -1059,6 +1059,8 @@ static bool sb_rs_route(int role, int M, int K, int N) {
     // columns, 175 against 216 at 131072 rows; plain 258 against 345, 213 against 234, 120 against 146.  Forwards tie (247 against
     // 255 at K = 256) or lose (K = 304: 372 against 349), as does everything under ~10^5 rows (one workgroup per CU and 64-row half
     // tiles: tile quantisation)
+    static const int fwd = getenv("DL3P_SB_RS_FWD") ? atoi(getenv("DL3P_SB_RS_FWD")) : 0;      // (A/B switch: forwards too)
+    if (fwd && role <= 1 && M >= 131072 && K > 224) return true;
     if (const GemmTuned* e = gemm_tuned_lookup(role + 5, M, K, N)) return e->pc == 103;
     return role >= 2 && M >= 131072 && K > 224;
   }
@@ -1227,6 +1229,63 @@ extern "C" int dl3p_pwconv_bwd_data_sb(const float* dy, int lddy, const void* ws
   if (wm == 3) dl3p_launch_gemm_sbr(p, bnb ? 2 : 0, gxn, (hipStream_t)stream);
   else if (wm == 0) dl3p_launch_gemm_sbp(p, bnb, bnb, nt, mi, dim3(gxn, gy), (hipStream_t)stream);
   else dl3p_launch_gemm_sb(p, bnb, bnb, false, nt, mi, wm, dim3(gxn, gy), (hipStream_t)stream);
+  DL3P_CHECK_LAUNCH(fn);
+  return DL3P_OK;
+}
+
+bool dl3p_sb_rs_fold_supported(int M, int K, int N, int act);
+extern "C" int dl3p_pwconv_bwd_data_sb_apply_supported(int M, int K, int N, int bn_act, int with_sums) {
+  // (M, K, N) as dl3p_pwconv_bwd_data_sb: K output columns, N the reduction = channels of the folded BatchNorm
+  if (M < 131072 || !dl3p_sb_rs_fold_supported(M, N, K, bn_act)) return 0;
+  (void)with_sums;
+  return 1;
+}
+
+extern "C" int dl3p_pwconv_bwd_data_sb_apply(const float* g, int ldg, const float* z_out, int ldz_out, const float* bn_scale,
+                                             const float* bn_shift, int bn_act, const float* bn_mean, const float* bn_invstd,
+                                             const float* bn_coef, float* dz, int lddz, const void* wsp, int pitch, float* gx,
+                                             int ldgx, int accumulate, int M, int K, int N, const float* z, int ldz,
+                                             const float* scale, const float* shift, int act, const float* save_mean,
+                                             const float* save_invstd, float* partials, int* rows_out, void* stream) {
+  const char* fn = "dl3p_pwconv_bwd_data_sb_apply";
+  int rc = check_mat(fn, g, ldg, N);
+  if (rc) return rc;
+  rc = check_mat(fn, z_out, ldz_out, N);
+  if (rc) return rc;
+  rc = check_mat(fn, dz, lddz, N);
+  if (rc) return rc;
+  rc = check_mat(fn, gx, ldgx, K);
+  if (rc) return rc;
+  rc = check_sb(fn, wsp, pitch, N);
+  if (rc) return rc;
+  DL3P_CHECK_ARG(bn_scale && bn_shift && bn_mean && bn_invstd && bn_coef, "%s: bad BatchNorm-apply arguments", fn);
+  const bool bnb = z != nullptr;
+  if (bnb) {
+    rc = check_mat(fn, z, ldz, K);
+    if (rc) return rc;
+    DL3P_CHECK_ARG(scale && shift && save_mean && save_invstd && partials && rows_out, "%s: bad BatchNorm arguments", fn);
+  }
+  DL3P_CHECK_ARG(dl3p_pwconv_bwd_data_sb_apply_supported(M, K, N, bn_act, bnb), "%s: shape M=%d K=%d N=%d act %d is not served", fn, M, K, N, bn_act);
+  int ldm = ldg > ldgx ? ldg : ldgx;
+  if (ldz > ldm) ldm = ldz;
+  if (ldz_out > ldm) ldm = ldz_out;
+  if (lddz > ldm) ldm = lddz;
+  DL3P_CHECK_ARG((unsigned long long)M * (unsigned long long)ldm * 4ull < (1ull << 32), "%s: operands of 4 GiB or more are not supported (M=%d)", fn, M);
+  GemmParams p = {};
+  p.A = g; p.lda = ldg; p.act = DL3P_ACT_NONE;
+  p.f_z = z_out; p.f_ldz = ldz_out; p.f_scale = bn_scale; p.f_shift = bn_shift; p.f_mean = bn_mean; p.f_invstd = bn_invstd;
+  p.f_coef = bn_coef; p.f_act = bn_act; p.f_dz = dz; p.f_lddz = lddz;
+  p.Bsp = (const unsigned short*)wsp; p.bsp_pitch = pitch; p.bsp_plane = (long long)K * pitch;
+  p.Y = gx; p.ldy = ldgx; p.accumulate = accumulate;
+  p.M = M; p.K = N; p.N = K;    // reduce over N, produce K columns
+  if (bnb) {
+    p.partials = partials;
+    p.bb_z = z; p.bb_ldz = ldz; p.bb_scale = scale; p.bb_shift = shift; p.bb_mean = save_mean; p.bb_invstd = save_invstd; p.bb_act = act;
+  }
+  p.num_m_tiles = ceil_div(M, 64);
+  const int gxn = dl3p_sb_rs_grid(M);
+  if (rows_out) *rows_out = gxn;
+  dl3p_launch_gemm_sbr(p, bnb ? 2 : 0, gxn, (hipStream_t)stream);
   DL3P_CHECK_LAUNCH(fn);
   return DL3P_OK;
 }

@@ -902,6 +902,7 @@ class Executor:
                         if op.kind in ('conv_pw', 'conv_dw')] or [0])
             self.dz_scratch = torch.zeros(need + 64, **self.f32)      # dz of the layer whose weight gradient just ran
         self._folded = {}                 # z tensor id -> BatchNorm-backward apply arguments taken over by the conv's wgrad
+        self._folded_dg = {}              # ... taken over by the conv's DATA gradient (row-stationary split GEMM, pw_split_rs.hip)
         jobs = self._jobs = []            # (slab pointer, destination pointer, rows, n) issued and not yet reduced
         self._wgrad_tables = []
         slab_off = [0]
@@ -971,6 +972,30 @@ class Executor:
                 xt = op.x.tensor
                 dz, lddz = self.tptr(out, True), out.ld
                 need_gx = xt.requires_grad or xt.root.requires_grad
+                dgrad_done = False
+                if k == 'conv_pw' and out.id in self._folded_dg:
+                    # data gradient FIRST: it forms dz = BatchNorm-backward apply of (g, z) in its staging pass and leaves it at
+                    # (dz, lddz) for the weight gradient below
+                    fg, fldg, fz, fldz, fsp, fhp, fact, fmean, finv, fcoef, dz, lddz = self._folded_dg.pop(out.id)
+                    gp, ldg, keyt = self._gbuf(op.x)
+                    acc = self._acc(keyt)
+                    wsp, pitch = st.sb_ptr(op, False)
+                    M_ = N * op.Ho * op.Wo
+                    fold_args = (fg, fldg, fz, fldz, fsp, fhp, fact, fmean, finv, fcoef, dz, lddz, wsp, pitch, gp, ldg, acc, M_, op.cin, op.cout)
+                    front = fuse.get(op) if (op in fuse and fuse[op].z.requires_grad) else None
+                    front_add = fuse_add.get(op) if (front is None and op in fuse_add and fuse_add[op].z.requires_grad) else None
+                    bn_front = front or front_add
+                    rows_f = ctypes.c_int(0)
+                    if bn_front is not None:
+                        bnf = bn_front.bn
+                        auxf = self.bn_aux[bnf]
+                        part_f = self.partials if front is not None else self.partials2
+                        P.k(L.pwconv_bwd_data_sb_apply, *fold_args, self.tptr(bn_front.z), bn_front.z.ld,
+                            self.gscale[bnf.group.id].data_ptr() + 4 * bnf.offset, self.gshift[bnf.group.id].data_ptr() + 4 * bnf.offset,
+                            bnf.act, auxf['mean'].data_ptr(), auxf['invstd'].data_ptr(), part_f.data_ptr(), ctypes.byref(rows_f))
+                    else:
+                        P.k(L.pwconv_bwd_data_sb_apply, *fold_args, None, 0, None, None, ACT_NONE, None, None, None, None)
+                    dgrad_done = True
                 if op.layer.trainable and batch and self._slab_bytes(op):
                     gw = st.ptr(op.w, G)
                     nb = self._slab_bytes(op)
@@ -1017,7 +1042,17 @@ class Executor:
                     else:
                         wgrad(L.pwconv_bwd_weight, self.tptr(op.col), op.col.ld, None, None, ACT_NONE, dz, lddz, gw,
                               st.ptr(op.b, G) if op.b else None, ws, wsb, N * op.Ho * op.Wo, op.kp, op.cout)
-                if need_gx:
+                if dgrad_done:
+                    # (the data gradient ran in front of the weight gradient; what is left is the BatchNorm in front of the conv)
+                    if front is not None:
+                        ctx = P.ctx
+                        P.ctx = _op_label(front)
+                        self._bn_backward(P, front, fused_rows=rows_f.value)
+                        P.ctx = ctx
+                        bn_done.add(front)
+                    elif front_add is not None:
+                        self._presums[front_add] = rows_f.value
+                elif need_gx:
                     gp, ldg, keyt = self._gbuf(op.x)
                     acc = self._acc(keyt)
                     if k == 'conv_pw' and op in fuse and fuse[op].z.requires_grad:
@@ -1388,12 +1423,34 @@ class Executor:
                 self._bwd_pending.append((op, off, P.ctx))
                 self._sync_g[op] = (g, ldg)
                 return
+        if not frozen and self._folds_apply_dgrad(op):
+            # the conv that produced z forms dz while its DATA gradient stages its operand, writes it where the apply pass would
+            # have, and its weight gradient (issued behind the data gradient for that) reads it there
+            self._folded_dg[z.id] = (g, ldg, zp, ldz, sp, hp, bn.act, mean, invstd, coef, dzo, lddzo)
+            return
         if not frozen and self._folds_apply(op):
             # the conv that produced z forms dz inside its weight-gradient kernel and hands it to its data gradient
             self._folded[z.id] = (g, ldg, zp, ldz, sp, hp, bn.act, mean, invstd, coef)
             return
         P.k(L.bn_bwd_apply_bf16 if self.bf16 else L.bn_bwd_apply, g, ldg, zp, ldz, sp, hp, bn.act, mean, invstd, coef, dzo,
             lddzo, 0, M, bn.C)
+
+    def _folds_apply_dgrad(self, bn_op):
+        """BatchNorm-backward apply folded into the staged operand of the DATA gradient of the pointwise conv that produced z
+        (dl3p_pwconv_bwd_data_sb_apply: the long decoder layers on the row-stationary split GEMM; fp32, local statistics)"""
+        conv = getattr(bn_op, 'producer', None)
+        if (self.bf16 or self.sync_bn or self.dist is not None or conv is None or conv.kind != 'conv_pw' or conv.out is not bn_op.z
+                or os.environ.get('DL3P_FOLD_APPLY', '1') == '0' or os.environ.get('DL3P_FOLD_APPLY_DGRAD', '1') == '0'):
+            return False
+        xt = conv.x.tensor
+        if not (xt.requires_grad or xt.root.requires_grad):
+            return False
+        M = self.N * conv.Ho * conv.Wo
+        if M * max(xt.ld, bn_op.z.ld, conv.cout) * 4 >= 2 ** 32:
+            return False
+        if not self.L.pwconv_bwd_data_sb_apply_supported(M, conv.cin, conv.cout, bn_op.bn.act, 1):
+            return False
+        return self._use_sb(conv, False, True)
 
     def _folds_apply(self, bn_op):
         """BatchNorm-backward apply folded into the weight gradient of the pointwise conv that produced z (fp32, local

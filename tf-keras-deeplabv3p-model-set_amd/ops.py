@@ -882,6 +882,26 @@ def pwconv_bwd_data_sb(dy, w_sp, N, out=None, accumulate=False, z=None, scale=No
     return (gx, rows.value) if z is not None else gx
 
 
+def pwconv_bwd_data_sb_apply(g, z_out, bn_scale, bn_shift, bn_act, bn_mean, bn_invstd, bn_coef, w_sp, N, dz=None, out=None,
+                             accumulate=False, z=None, scale=None, shift=None, act=ACT_NONE, mean=None, invstd=None, partials=None):
+    """pwconv_bwd_data_sb with the BatchNorm-backward apply of (g, z_out) folded into its staged operand; -> (dz, gx[, rows]):
+    dz = bn_coef[0] * (g * act'(z_out * bn_scale + bn_shift) - bn_coef[1] - xhat * bn_coef[2]) is written to `dz` (default: over g)"""
+    M = _rows(g)
+    K, pitch = w_sp.shape[1], w_sp.shape[2]
+    gx = out if out is not None else torch.empty(tuple(g.shape[:-1]) + (K,), dtype=torch.float32, device=g.device)
+    dzt = dz if dz is not None else g
+    gp_, ldg_ = _pl(g)
+    zo, ldzo = _pl(z_out)
+    dzp, lddz = _pl(dzt)
+    gxp, ldgx = _pl(gx)
+    zp, ldz = _pl(z)
+    rows = ctypes.c_int(0)
+    lib().pwconv_bwd_data_sb_apply(gp_, ldg_, zo, ldzo, _p(bn_scale), _p(bn_shift), bn_act, _p(bn_mean), _p(bn_invstd), _p(bn_coef),
+                                   dzp, lddz, _p(w_sp), pitch, gxp, ldgx, int(accumulate), M, K, N, zp, ldz or 0, _p(scale), _p(shift),
+                                   act, _p(mean), _p(invstd), _p(partials), ctypes.byref(rows), _stream())
+    return (dzt, gx, rows.value) if z is not None else (dzt, gx)
+
+
 def col2im_bf16(gcol, x_shape, k, stride=1, rate=1, padding='same', out=None, accumulate=False):
     """bf16 twin of col2im: gcol (N,Ho,Wo,kp) bf16 -> gx (N,H,W,Cin) bf16"""
     N, H, W, Cin = x_shape
