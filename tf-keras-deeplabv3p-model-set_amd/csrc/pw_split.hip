@@ -904,6 +904,7 @@ struct WgradSB {
   float* slabs;
   int M, K, N;
   int ktiles, ntiles, mrows;      // rows of M per slice (multiple of 32)
+  int k_base;                     // first row of GW this launch covers (a K that is not a multiple of the tile: two launches)
 };
 
 typedef short s16x4w __attribute__((ext_vector_type(4)));
@@ -927,7 +928,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_sb_kernel(WgradSB p) {
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int wk = w / WN, wn = w - wk * WN;
   const int tile = blockIdx.x, kt = tile / p.ntiles, nt = tile - kt * p.ntiles;
-  const int k0 = kt * TK, n0 = nt * TN;
+  const int k0 = p.k_base + kt * TK, n0 = nt * TN;
   const int mbeg = blockIdx.y * p.mrows, mend = min(p.M, mbeg + p.mrows);
   const int xm = t / XCPR, xc = (t - xm * XCPR) * 8;
   const int dm = t / DCPR, dc = (t - dm * DCPR) * 8;
@@ -1083,12 +1084,27 @@ int dl3p_wgrad_sb_plan(int M, int K, int N, int max_slabs, int tile, int per_cu,
 
 void dl3p_launch_wgrad_sb(const float* x, int ldx, const float* scale, const float* shift, int act, const float* dy, int lddy,
                           float* slabs, int M, int K, int N, int kf, int nw, int ktiles, int ntiles, int mrows, int splits, hipStream_t st) {
-  WgradSB p = {x, ldx, scale, shift, act, dy, lddy, slabs, M, K, N, ktiles, ntiles, mrows};
-  const dim3 grid(ktiles * ntiles, splits), block(256);
+  WgradSB p = {x, ldx, scale, shift, act, dy, lddy, slabs, M, K, N, ktiles, ntiles, mrows, 0};
+  const dim3 block(256);
   // the 128 x 128 tile with its waves 2 x 2 (247-258 against 270-278 us on 266256 x 256 x 256); 64 x 128 stays 4 x 1 (2 x 2 costs it
   // a resident workgroup: 327 against 284)
-  if (kf == 2 && nw == 8) dl3p_launch(pw_wgrad_sb_kernel<2, 8, 2>, grid, block, 0, st, p);
-  else if (kf == 1 && nw == 8) dl3p_launch(pw_wgrad_sb_kernel<1, 8, 1>, grid, block, 0, st, p);
-  else if (kf == 2 && nw == 4) dl3p_launch(pw_wgrad_sb_kernel<2, 4, 1>, grid, block, 0, st, p);
-  else dl3p_launch(pw_wgrad_sb_kernel<1, 4, 1>, grid, block, 0, st, p);
+  if (kf == 2 && nw == 8) {
+    // a last 128-row tile with at most 64 live rows (K = 304: 48 of 128) multiplies zeros for the rest.  Giving that strip to the
+    // 64 x 128 tile in a second launch (same slices, same slabs, disjoint rows of GW) saves a sixth of the MFMAs and was measured
+    // SLOWER in the step (12.83 against 12.76 ms, same box): the second launch streams dY from HBM once more, where the six tiles
+    // of a slice in ONE launch share it through L2.  Opt-in (DL3P_WGRAD_SB_MIXED=1), parity-tested, not the default.
+    const int rem = K % 128;
+    static const int mixed = getenv("DL3P_WGRAD_SB_MIXED") ? atoi(getenv("DL3P_WGRAD_SB_MIXED")) : 0;
+    if (mixed && rem > 0 && rem <= 64 && ktiles > 1) {
+      p.ktiles = ktiles - 1;
+      dl3p_launch(pw_wgrad_sb_kernel<2, 8, 2>, dim3(p.ktiles * ntiles, splits), block, 0, st, p);
+      p.k_base = 128 * (ktiles - 1);
+      p.ktiles = 1;
+      dl3p_launch(pw_wgrad_sb_kernel<1, 8, 1>, dim3(ntiles, splits), block, 0, st, p);
+      return;
+    }
+    dl3p_launch(pw_wgrad_sb_kernel<2, 8, 2>, dim3(ktiles * ntiles, splits), block, 0, st, p);
+  } else if (kf == 1 && nw == 8) dl3p_launch(pw_wgrad_sb_kernel<1, 8, 1>, dim3(ktiles * ntiles, splits), block, 0, st, p);
+  else if (kf == 2 && nw == 4) dl3p_launch(pw_wgrad_sb_kernel<2, 4, 1>, dim3(ktiles * ntiles, splits), block, 0, st, p);
+  else dl3p_launch(pw_wgrad_sb_kernel<1, 4, 1>, dim3(ktiles * ntiles, splits), block, 0, st, p);
 }
