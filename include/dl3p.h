@@ -105,7 +105,13 @@ int dl3p_comm_destroy(void* comm);
  * not serve (few rows; few-channel layers on the streaming kernels) -- those keep the fp32 entry points.
  * dl3p_pwconv_sb_pays(role, M, K, N): the measured verdict for that exact launch (csrc/sb_tuned.h, scripts/tune_split.py):
  * 1 the split kernel beat the fp32-input MFMA kernel, 0 it did not, -1 never measured -- then the caller's rule decides
- * (the executor's: K >= 128, N >= 128, >= 16384 rows). */
+ * (the executor's: K >= 128, N >= 128, >= 16384 rows).
+ * DOMAIN of the exact split (tests/test_split_gemm_gpu.py::test_split_gemm_domain_edges): finite operands below 3.3962e38 in
+ * magnitude (half a bf16 step past bf16's largest finite value; float32 reaches 3.4028e38).  An operand that is Inf or NaN, or
+ * rounds to bf16 Inf, has the residual a - rn_bf16(a) = NaN: every output of that ROW is NaN, where the fp32-input kernels give
+ * Inf / NaN / a finite value -- an overflowing activation still shows, never as a wrong finite number.  Below 2^-110 the third
+ * (then the second) piece of an operand falls under bf16's smallest normal 2^-126: the product then carries an ABSOLUTE error of
+ * at most 2^-126 |w| per term, far below any float32-normal output. */
 int dl3p_split_bf16x3_batch(const float* src, void* dst, const int64_t* table, int n_matrices, void* stream);
 int dl3p_pwconv_sb_supported(int role, int M, int K, int N);
 int dl3p_pwconv_sb_pays(int role, int M, int K, int N);

@@ -4,9 +4,13 @@ set -euo pipefail
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 export TMPDIR=/tmp
 cd "$ROOT"
+if [ $# -lt 3 ]; then echo 'usage: ktrace.sh <kernel substring> -- <python args>' >&2; exit 2; fi
 K="$1"; shift 2
+mkdir -p gpurun_out
 rm -rf gpurun_out/kt_tmp
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/kt_tmp -- python3 "$@" > /dev/null 2>&1
+if ! rocprofv3 --kernel-trace --output-format csv -d gpurun_out/kt_tmp -- python3 "$@" > gpurun_out/ktrace.log 2>&1; then
+  echo "ktrace.sh: the profiled run failed; tail of gpurun_out/ktrace.log:" >&2; tail -20 gpurun_out/ktrace.log >&2; exit 1
+fi
 python3 - "$K" <<'PY'
 import csv, glob, sys, collections
 k = sys.argv[1]

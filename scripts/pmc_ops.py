@@ -44,6 +44,61 @@ def xception():
     torch.cuda.synchronize()
 
 
+def xception769():
+    """BASELINE configs[3]: Xception, 769 x 769, output stride 8, batch 2 per GPU -- the split-bf16 GEMMs at 2 x 97^2 = 18818 and
+    2 x 193^2 = 74498 rows through the production entry points (sb where the executor takes it), the ASPP rates 12 / 24 / 36"""
+    for (M, K, N) in [(18818, 728, 728), (18818, 1536, 2048), (18818, 2048, 256), (74498, 304, 256), (74498, 256, 256)]:
+        x = torch.randn(M, K, device=dev)
+        wt = torch.randn(N, K, device=dev) / K ** 0.5
+        w = wt.t().contiguous()
+        wsp, w_sp = ops.split_bf16x3(wt), ops.split_bf16x3(w)
+        sc, sh = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.3
+        part, partk = ops.new_partials(N, dev), ops.new_partials(K, dev)
+        dy, z = torch.randn(M, N, device=dev), torch.randn(M, K, device=dev)
+        mean, invstd = torch.zeros(K, device=dev), torch.ones(K, device=dev)
+        for _ in range(REPS):
+            ops.pwconv_fwd_sb(x, wsp, K, None, sc, sh, ops.ACT_RELU, partials=part)
+            ops.pwconv_bwd_data_sb(dy, w_sp, N, z=z, scale=sc, shift=sh, act=ops.ACT_RELU, mean=mean, invstd=invstd, partials=partk)
+            ops.pwconv_bwd_weight(x, dy, sc, sh, ops.ACT_RELU)
+    for r in (12, 24, 36):
+        x = torch.randn(2, 97, 97, 2048, device=dev)
+        w = torch.randn(3, 3, 2048, device=dev) * 0.3
+        sc, sh = torch.rand(2048, device=dev) + 0.5, torch.randn(2048, device=dev) * 0.3
+        part = ops.new_partials(2048, dev)
+        gy = torch.randn(2, 97, 97, 2048, device=dev)
+        for _ in range(REPS):
+            ops.dwconv2d_fwd(x, w, 1, r, 'same', sc, sh, ops.ACT_RELU, partials=part)
+            ops.dwconv2d_bwd_data(gy, w, (2, 97, 97, 2048), 1, r, 'same')
+            ops.dwconv2d_bwd_weight(x, gy, 3, 1, r, 'same', sc, sh, ops.ACT_RELU)
+    torch.cuda.synchronize()
+
+
+def headline_gemms():
+    """the decoder GEMMs of BASELINE configs[1] (266256 rows) on the kernels the step launches them on: wide tiled forward,
+    row-stationary data gradient with the folded BatchNorm-backward apply and the fused sums, split weight gradient"""
+    M = 266256
+    for (K, N) in [(304, 256), (256, 256)]:
+        x = torch.randn(M, K, device=dev)
+        wt = torch.randn(N, K, device=dev) / K ** 0.5
+        w = wt.t().contiguous()
+        wsp, w_sp = ops.split_bf16x3(wt), ops.split_bf16x3(w)
+        sc, sh = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.3
+        bsc, bsh = torch.rand(N, device=dev) + 0.5, torch.randn(N, device=dev) * 0.3
+        mu, istd = torch.randn(N, device=dev) * 0.1, torch.rand(N, device=dev) + 0.5
+        coef = torch.stack([torch.rand(N, device=dev) + 0.5, torch.randn(N, device=dev) * 0.1, torch.randn(N, device=dev) * 0.1]).contiguous()
+        part, partk = ops.new_partials(N, dev), ops.new_partials(K, dev)
+        g, zo, z = torch.randn(M, N, device=dev), torch.randn(M, N, device=dev), torch.randn(M, K, device=dev)
+        dz = torch.empty(M, N, device=dev)
+        mean, invstd = torch.zeros(K, device=dev), torch.ones(K, device=dev)
+        for _ in range(REPS):
+            ops.pwconv_fwd_sb(x, wsp, K, None, sc, sh, ops.ACT_RELU, partials=part)
+            ops.pwconv_bwd_data_sb_apply(g, zo, bsc, bsh, ops.ACT_RELU, mu, istd, coef, w_sp, N, dz=dz, z=z, scale=sc, shift=sh, act=ops.ACT_RELU,
+                                         mean=mean, invstd=invstd, partials=partk)
+            ops.pwconv_bwd_data_sb(dz, w_sp, N, z=z, scale=sc, shift=sh, act=ops.ACT_RELU, mean=mean, invstd=invstd, partials=partk)
+            ops.pwconv_bwd_weight(x, dz, sc, sh, ops.ACT_RELU)
+    torch.cuda.synchronize()
+
+
 def bf16():
     bf = torch.bfloat16
     for (M, K, N) in [(131072, 304, 256), (131072, 256, 256), (8192, 1280, 256), (524288, 16, 64)]:
@@ -71,4 +126,4 @@ def bf16():
 
 
 if __name__ == '__main__':
-    {'xception': xception, 'bf16': bf16}[sys.argv[1]]()
+    {'xception': xception, 'xception769': xception769, 'headline_gemms': headline_gemms, 'bf16': bf16}[sys.argv[1]]()

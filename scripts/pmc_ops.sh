@@ -8,7 +8,7 @@ cd "$ROOT"
 R=${1:-r03}
 O=gpurun_out/pmc_ops_$R
 mkdir -p $O
-for cfg in xception bf16; do
+for cfg in ${PMC_CFGS:-xception xception769 headline_gemms bf16}; do
   timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${cfg}_kt -- python3 scripts/pmc_ops.py $cfg > $O/${cfg}_kt.log 2>&1
   timeout 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${cfg}_fetch -- python3 scripts/pmc_ops.py $cfg > $O/${cfg}_fetch.log 2>&1
   timeout 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${cfg}_write -- python3 scripts/pmc_ops.py $cfg > $O/${cfg}_write.log 2>&1
@@ -34,7 +34,7 @@ out.write('kernel,grid,calls,avg_us,fetch_bytes_x2_gfx950,write_bytes,hbm_bytes,
 lines = []
 for key, c in agg.items():
     kn, g = key
-    if not any(s in kn for s in ('pw_', 'pwb_', 'dw_', 'dwb_')):
+    if not any(s in kn for s in ('pw_', 'pwb_', 'dw_', 'dwb_', 'bn_bwd_apply')):
         continue
     mean = lambda v: sum(v[len(v) // 2:]) / max(1, len(v[len(v) // 2:]))        # second half: warm
     fe = mean(c['FETCH_SIZE']) * 1024 * 2 if c.get('FETCH_SIZE') else 0.0
@@ -50,4 +50,4 @@ out.close()
 PY
   rm -rf $O/${cfg}_kt $O/${cfg}_fetch $O/${cfg}_write $O/${cfg}_mfma
 done
-ls -la $O; head -12 $O/${R}_xception_op_counters.csv; head -12 $O/${R}_bf16_op_counters.csv
+ls -la $O; for cfg in ${PMC_CFGS:-xception xception769 headline_gemms bf16}; do head -8 $O/${R}_${cfg}_op_counters.csv; done

@@ -108,6 +108,12 @@ def test_factory_surface():
     lines = []
     m.summary(print_fn=lines.append)
     assert any('Total params: 2,758,597' in l for l in lines)
+    # which batch variance feeds the moving averages is stated where a user looks
+    assert any('moving variance: biased' in l for l in lines)
+    mu = pkg.get_deeplabv3p_model('mobilenetv2_lite', 21, (65, 65), 16, bn_moving_variance='unbiased')
+    lines = []
+    mu.summary(print_fn=lines.append)
+    assert any('moving variance: unbiased' in l and '2.11.0' in l for l in lines)
     # the reference's import path works
     import deeplabv3p.model as shim
     assert shim.get_deeplabv3p_model is pkg.get_deeplabv3p_model

@@ -324,6 +324,12 @@ class DeeplabModel:
         print_fn('Total params: {:,}'.format(tot))
         print_fn('Trainable params: {:,}'.format(tr))
         print_fn('Non-trainable params: {:,}'.format(tot - tr))
+        # which batch variance feeds the moving averages is a build-time choice that changes inference after training:
+        # say so where a user looks, so weights trained here and reference-trained weights are not compared unawares
+        mv = getattr(self, 'bn_moving_variance', 'biased')
+        print_fn("BatchNormalization moving variance: %s batch variance (%s)" % (
+            mv, 'Keras SyncBatchNormalization, what layers.py:63-70 selects for TF 2.2 .. 2.9' if mv == 'biased'
+            else "fused BatchNormalization with Bessel's correction, what layers.py:63-70 selects under the pinned tensorflow==2.11.0"))
 
     def compile(self, optimizer=None, loss=None, metrics=None, sample_weight_mode=None, distributed=None,
                 sync_bn=True, **kw):
@@ -561,7 +567,9 @@ class DeeplabModel:
                 'name': self.name, 'factory': {'model_type': self.model_type, 'num_classes': self.num_classes,
                                                'model_input_shape': list(self.input_shape_hw),
                                                'output_stride': getattr(self.graph, 'output_stride', None),
-                                               'training': bool(self.flatten_output)}}})
+                                               'training': bool(self.flatten_output),
+                                               # (the moving statistics in this file were accumulated under this rule)
+                                               'bn_moving_variance': getattr(self, 'bn_moving_variance', 'biased')}}})
             h5io.write_keras_h5(path, self._keras_layers(), whole_model=True, model_config=cfg)
             return
         np.savez(path if path.endswith('.npz') else path + '.npz', **self.get_weights_by_name())
