@@ -40,5 +40,13 @@ for (M, K, N) in [(266256, 304, 256), (266256, 256, 256)]:
     t_dg = timeit(lambda: ops.pwconv_bwd_data_sb(dz, w_sp, N, out=gx, z=z, scale=sc, shift=sh, act=ops.ACT_RELU6, mean=mean, invstd=invstd, partials=part))
     ap = lambda: L.bn_bwd_apply(g.data_ptr(), N, zo.data_ptr(), N, bsc.data_ptr(), bsh.data_ptr(), ops.ACT_RELU6, mu.data_ptr(), istd.data_ptr(),
                                 coef.data_ptr(), dz.data_ptr(), N, 0, M, N, None)
-    t_ap = timeit(ap)
+    # (bn_bwd_apply is not launched through the library's probe: torch events around 20 back-to-back launches)
+    for _ in range(3):
+        ap()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        ap()
+    e1.record(); torch.cuda.synchronize()
+    t_ap = e0.elapsed_time(e1) * 1e3 / 20
     print('M=%d %d -> %d: folded %.1f us | apply %.1f + data gradient (+sums) %.1f = %.1f us' % (M, N, K, t_fold, t_ap, t_dg, t_ap + t_dg), flush=True)

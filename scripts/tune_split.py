@@ -133,6 +133,7 @@ def measure(role, M, K, N):
             pin((nt, mi, 100 + wm))
             res[(nt, mi, 100 + wm)] = T.timeit(sb)
     out6 = (ctypes.c_int * 6)()
+    pin(None)                          # (a pinned tile keeps the planner off the row-stationary form)
     L.set_option(b'sb_rs', 1)
     L.gemm_plan_query(role + 5, M, K, N, out6)
     if out6[0] == 3 and out6[3] == 3 and M >= 65536:       # served by the row-stationary form
@@ -214,13 +215,16 @@ def measure_wgrad(M, K, N):
 def main():
     L.set_option(b'pw_small_min_rows', -1)
     roles = {0, 1, 2, 3, 4}
+    min_rows = 4096
     for a in sys.argv[1:]:
         if a.startswith('--roles='):
             roles = {int(v) for v in a.split('=')[1].split(',')}
+        if a.startswith('--min-rows='):       # (a partial re-tune, e.g. --roles=2,3 --min-rows=60000: merge gpurun_out/sb_tuned.h by hand)
+            min_rows = int(a.split('=')[1])
     sh = T.shapes()
     tuned, pays, log = [], [], []
     for (role, M, K, N), mt in sorted(sh.items()):
-        if role not in roles or role > 4 or K < 64 or N < 64 or M < 4096 or M * max(K, N) * 4 >= (1 << 32):
+        if role not in roles or role > 4 or K < 64 or N < 64 or M < min_rows or M * max(K, N) * 4 >= (1 << 32):
             continue
         plan = (ctypes.c_int * 6)()
         L.gemm_plan_query(role, M, K, N, plan)

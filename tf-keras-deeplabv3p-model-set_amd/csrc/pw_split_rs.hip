@@ -173,7 +173,7 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_sbr_kernel(GemmParams p) {
   const char* arow = Ab;
   const char* zrow = reinterpret_cast<const char*>(p.f_z);       // FOLD: the second tensor of the staged operand, and where dz goes
   char* dzrow = reinterpret_cast<char*>(p.f_dz);
-  float4 rz[FOLD ? NH : 1][2];
+  float4 rz[NH][2];      // (FOLD only: dead otherwise)
   const float* coef_l = coef + ac * 8;
   auto issue_a = [&](int m0w, auto ktc) __attribute__((always_inline)) {
     constexpr int KT = decltype(ktc)::value;
