@@ -264,6 +264,28 @@ int dl3p_conv2d_gemm_bwd_weight(const float* x, int ldx, const float* in_scale, 
                                 size_t workspace_bytes, int N, int H, int W, int Cin, int Cout, int k, int stride,
                                 int rate, int pad_t, int pad_l, int Ho, int Wo, void* stream);
 
+/* The same implicit GEMMs on the split-bf16 kernels (fp32-accurate products on the bf16 matrix pipe: see dl3p_pwconv_fwd_sb for
+ * the arithmetic and its domain) -- Xception's entry_flow_conv1_2 (deeplabv3p_xception.py:175-183) and ResNet50's 3x3 convs
+ * (deeplabv3p_resnet50.py:32-142).  The kernel operand is PRE-SPLIT by dl3p_split_bf16x3_batch:
+ *   fwd_sb:      wsp  = [3][Cout][pitch >= k*k*Cin] from wt (the transposed kernel dl3p_conv2d_gemm_fwd takes);
+ *   bwd_data_sb: wdsp = [3][Cin][pitch >= k*k*Cout] from wd (dl3p_conv2d_gemm_dgrad_weights);
+ *   pitch a multiple of 32, columns beyond the matrix zero.  Everything else as for the fp32-input entry points above.
+ * dl3p_conv2d_gemm_sb_supported(role, M, K, N): does the split kernel serve the GEMM as launched -- role 0 / 1 forward without /
+ * with statistics (M = N*Ho*Wo, K = k*k*Cin, N = Cout), 2 data gradient (M = N*H*W, K = k*k*Cout, N = Cin), 4 weight gradient
+ * (M = N*Ho*Wo, K = k*k*Cin, N = Cout); dl3p_conv2d_gemm_sb_pays: is it also the faster one (the measured rule;
+ * dl3p_set_option("conv_sb", 0 | 1 | 2): never / by that rule / wherever supported).  The WEIGHT gradient has no entry point of its
+ * own: dl3p_conv2d_gemm_bwd_weight[_slabs] take the split kernel (both operands split while they are staged) where role 4 pays, and
+ * dl3p_conv2d_gemm_bwd_weight_workspace accounts for it. */
+int dl3p_conv2d_gemm_sb_supported(int role, int M, int K, int N);
+int dl3p_conv2d_gemm_sb_pays(int role, int M, int K, int N);
+int dl3p_conv2d_gemm_fwd_sb(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                            const void* wsp, int pitch, const float* bias, float* y, int ldy, float* stat_partials,
+                            int* rows_out, int N, int H, int W, int Cin, int Cout, int k, int stride, int rate, int pad_t,
+                            int pad_l, int Ho, int Wo, void* stream);
+int dl3p_conv2d_gemm_bwd_data_sb(const float* dy, int lddy, const void* wdsp, int pitch, float* gx, int ldgx, int accumulate,
+                                 int N, int H, int W, int Cin, int Cout, int k, int stride, int rate, int pad_t, int pad_l,
+                                 int Ho, int Wo, void* stream);
+
 /* transpose of dl3p_im2col in gather form (deterministic): gx[n,iy,ix,ci] (+)= sum over the taps that read
  * it of gcol[m][tap*Cin+ci].  Cin % 4 == 0. */
 int dl3p_col2im(const float* gcol, int ld_col, float* gx, int ldgx, int accumulate, int N, int H, int W, int Cin,

@@ -386,6 +386,63 @@ def test_conv2d_implicit_gemm(ops, case):
     close(ops.conv2d_gemm_fwd(T(x), T(w), s, r, pad, *pro, bias=T(b)), y_ref + b, rtol=3e-4, what='implicit conv fwd + bias')
 
 
+CONV_GEMM_SB = [(2, 33, 33, 32, 64, 3, 1, 1, 'same', O.ACT_RELU),         # Xception entry_flow_conv1_2
+                (1, 65, 65, 64, 64, 3, 1, 1, 'same', O.ACT_RELU),         # ResNet50 stage 2
+                (4, 33, 33, 64, 64, 3, 2, 1, 'same', O.ACT_RELU),         # 3x3 stride 2, odd size
+                (4, 32, 40, 128, 128, 3, 2, 1, (0, 1, 0, 1), O.ACT_NONE),  # ... even size, explicit padding
+                (1, 33, 33, 128, 128, 3, 1, 2, 'same', O.ACT_RELU),       # atrous (ResNet50 at output stride 16 / 8)
+                (1, 33, 33, 256, 256, 3, 1, 4, 'same', O.ACT_RELU),
+                (2, 35, 37, 36, 72, 3, 1, 1, 'same', O.ACT_RELU6),        # channel counts not multiples of 32, K tail, N tail
+                (1, 40, 40, 16, 32, 5, 1, 1, 'same', O.ACT_HSWISH),       # 5x5
+                (2, 65, 65, 728, 1024, 1, 2, 1, 'same', O.ACT_NONE)]      # strided 1x1 shortcut
+
+
+@pytest.mark.parametrize('case', CONV_GEMM_SB)
+def test_conv2d_implicit_gemm_split(ops, case):
+    """the same implicit GEMMs on the split-bf16 kernels (dl3p_conv2d_gemm_fwd_sb / _bwd_data_sb, and the weight gradient's split
+    route inside dl3p_conv2d_gemm_bwd_weight): fp32-accurate, so the fp32 kernels' tolerances"""
+    N, H, W, Cin, Cout, k, s, r, pad, act = case
+    L = ops.lib()
+    L.set_option(b'conv_sb', 2)          # wherever supported (the production rule asks for long GEMMs)
+    try:
+        rng = np.random.default_rng(Cin + Cout + k)
+        x = rng.standard_normal((N, H, W, Cin))
+        w = rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)
+        sc = rng.uniform(0.5, 1.5, Cin)
+        sh = rng.standard_normal(Cin) * 0.3
+        a = O.act_fwd(x * sc + sh, act) if act != O.ACT_NONE else x
+        pro = (T(sc), T(sh), act) if act != O.ACT_NONE else (None, None, O.ACT_NONE)
+        y_ref = O.conv2d_fwd(a, w, s, r, pad)
+        Ho, Wo = y_ref.shape[1:3]
+        assert L.conv2d_gemm_sb_supported(1, N * Ho * Wo, k * k * Cin, Cout) and L.conv2d_gemm_sb_supported(2, N * H * W, k * k * Cout, Cin)
+        part = ops.new_partials(Cout, DEV)
+        y, rows = ops.conv2d_gemm_fwd_sb(T(x), T(w), s, r, pad, *pro, partials=part)
+        close(y, y_ref, rtol=3e-4, what='split implicit conv fwd')
+        s1, s2 = stats_from(part, rows, Cout)
+        close(s1, y_ref.reshape(-1, Cout).sum(0), rtol=2e-4, atol=1e-2, what='split implicit conv stat')
+        close(s2, (y_ref ** 2).reshape(-1, Cout).sum(0), rtol=2e-4, what='split implicit conv stat sq')
+        b = rng.standard_normal(Cout)
+        close(ops.conv2d_gemm_fwd_sb(T(x), T(w), s, r, pad, *pro, bias=T(b)), y_ref + b, rtol=3e-4, what='split implicit conv fwd + bias')
+        gy = rng.standard_normal(y_ref.shape)
+        gx_ref, gw_ref, _ = O.conv2d_bwd(a, w, gy, s, r, pad)
+        gx = ops.conv2d_gemm_bwd_data_sb(T(gy), T(w), (N, H, W, Cin), s, r, pad)
+        close(gx, gx_ref, rtol=3e-4, what='split implicit conv bwd data')
+        base = rng.standard_normal((N, H, W, Cin))
+        acc = T(base)
+        ops.conv2d_gemm_bwd_data_sb(T(gy), T(w), (N, H, W, Cin), s, r, pad, out=acc, accumulate=True)
+        close(acc, base + gx_ref, rtol=3e-4, what='split implicit conv bwd data accumulate')
+        assert L.conv2d_gemm_sb_pays(4, N * Ho * Wo, k * k * Cin, Cout)
+        gw, gb = ops.conv2d_gemm_bwd_weight(T(x), T(gy), k, s, r, pad, *pro, with_bias=True)
+        close(gw, gw_ref, rtol=5e-4, what='split implicit conv bwd weight')
+        close(gb, gy.reshape(-1, Cout).sum(0), rtol=2e-4, atol=1e-3, what='implicit conv bias gradient')
+        for tile in range(4):           # every tile of the weight-gradient kernel
+            L.set_option(b'split_wgrad_tile', tile)
+            close(ops.conv2d_gemm_bwd_weight(T(x), T(gy), k, s, r, pad, *pro), gw_ref, rtol=5e-4, what='split implicit conv bwd weight, tile %d' % tile)
+    finally:
+        L.set_option(b'conv_sb', -1)
+        L.set_option(b'split_wgrad_tile', -1)
+
+
 @pytest.mark.parametrize('case', [(2, 33, 33, 32, 'same'), (1, 32, 48, 16, (0, 1, 0, 1)), (3, 65, 129, 32, 'same'),
                                   (1, 64, 258, 16, 'same'), (2, 17, 263, 32, (0, 1, 0, 1)), (1, 3, 3, 32, 'same'),
                                   (1, 130, 513, 32, 'same')])

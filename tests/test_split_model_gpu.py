@@ -22,8 +22,12 @@ def split_on(monkeypatch):
     # verdict table / row threshold (pwconv.hip, wgrad_sb_route)
     L = load_pkg('_lib').lib()
     L.set_option(b'split_wgrad_per_cu', 2)
+    # ... and the dense k x k convs wherever the split implicit-GEMM kernels serve them (>= 1024 rows: Xception's entry_flow_conv1_2,
+    # ResNet50's stage-2 3x3 convs at these sizes), not only where the measured rule says they pay
+    L.set_option(b'conv_sb', 2)
     yield
     L.set_option(b'split_wgrad_per_cu', 0)
+    L.set_option(b'conv_sb', -1)
 
 
 def _uses_split(m):
@@ -53,6 +57,7 @@ def test_train_step_513_with_split_gemms(model_type, monkeypatch):
     import test_production_shapes_gpu as T
     L = load_pkg('_lib').lib()
     L.set_option(b'split_wgrad_per_cu', 0)        # the weight gradients by their own table / rule, as in production
+    L.set_option(b'conv_sb', -1)                  # ... and the dense convs by theirs
     L.set_option(b'pw_small_min_rows', -1)
     try:
         T.test_train_step_513_production_dispatch(model_type)
@@ -79,6 +84,33 @@ def test_the_split_path_is_actually_taken():
     L = load_pkg('_lib').lib()
     L.gemm_plan_query(9, 2 * 33 * 33, 96, 144, out)      # (rows, cin, cout) of a tiled-kernel layer at this size
     assert out[0] == 4, list(out)
+
+
+@pytest.mark.parametrize('model_type,N', [('xception', 2), ('resnet50', 4)])
+def test_the_dense_convs_take_the_split_kernels(model_type, N):
+    """the models above really ran their dense convs on the split implicit-GEMM kernels: forward, data gradient (behind the split of
+    the re-laid kernel) and -- decided inside the library -- the weight gradient"""
+    import ctypes
+    import numpy as np
+    pkg = load_pkg()
+    m = pkg.get_deeplabv3p_model(model_type, 21, (65, 65), 16, training=True)
+    m.compile(optimizer=pkg.SGD(0.01), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
+    m.use_graphs = False
+    x = np.random.default_rng(0).uniform(-1, 1, (N, 65, 65, 3)).astype(np.float32)
+    m.train_on_batch(x, np.zeros((N, 65 * 65, 1), np.float32))
+    ex = m._executor(N, True)
+    fwd, bwd, opt = ([lab[0] for lab in plan.labels] for plan in (ex.fwd, ex.bwd, ex.opt))
+    assert any('conv2d_gemm_fwd_sb' in n for n in fwd), sorted(set(fwd))
+    i = [j for j, n in enumerate(bwd) if 'conv2d_gemm_bwd_data_sb' in n]
+    assert i and all('split_bf16x3_batch' in bwd[j - 1] and 'conv2d_gemm_dgrad_weights' in bwd[j - 2] for j in i), sorted(set(bwd))
+    dense = [op for op in m.graph.ops if op.kind == 'conv_dense' and op in ex._sb_used_f]
+    assert dense and any('split_bf16x3_batch' in n for n in opt)        # the optimiser step refreshes their planes
+    L = load_pkg('_lib').lib()
+    op = dense[0]
+    assert L.conv2d_gemm_sb_pays(4, N * op.Ho * op.Wo, op.k * op.k * op.cin, op.cout)
+    L.set_option(b'conv_sb', -1)        # the production rule: none of these few-row layers
+    assert not L.conv2d_gemm_sb_pays(4, N * op.Ho * op.Wo, op.k * op.k * op.cin, op.cout)
+    assert L.conv2d_gemm_sb_pays(4, 264196, 288, 64) and L.conv2d_gemm_sb_pays(1, 33800, 1152, 128) and not L.conv2d_gemm_sb_pays(1, 264196, 288, 64)
 
 
 @pytest.mark.parametrize('model_type', ['mobilenetv2', 'xception'])

@@ -905,7 +905,22 @@ struct WgradSB {
   int M, K, N;
   int ktiles, ntiles, mrows;      // rows of M per slice (multiple of 32)
   int k_base;                     // first row of GW this launch covers (a K that is not a multiple of the tile: two launches)
+  // GX instantiations (dense k x k convolutions, dl3p_conv2d_gemm_bwd_weight*): X is the input tensor [N][g_SH][g_SW][ldx] and the row
+  // m = (n, y, x) over g_RH x g_RW / column k = tap * g_C + c of the patch matrix is gathered from it while the tile is staged
+  // (the fp32 kernel's convention, pwconv.hip WgradParams); scale / shift are indexed by the channel c
+  int g_RH, g_RW, g_SH, g_SW, g_C, g_kw, g_mul, g_ay, g_ax, g_d;
+  float g_invRW, g_invRH;
 };
+
+// q = a / d, *r = a % d for 0 <= a < 2^24 and 0 < d < 2^14 (pwconv.hip divmod_small)
+__device__ __forceinline__ int sb_divmod(int a, int d, float inv, int* r) {
+  int q = (int)((float)a * inv);
+  int rem = a - q * d;
+  if (rem < 0) { --q; rem += d; }
+  if (rem >= d) { ++q; rem -= d; }
+  *r = rem;
+  return q;
+}
 
 typedef short s16x4w __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ s16x4w tr_read16(const unsigned short* lds_ptr) {
@@ -914,7 +929,7 @@ __device__ __forceinline__ s16x4w tr_read16(const unsigned short* lds_ptr) {
 
 // WN: the four waves as (4 / WN) x WN over (k, n): a wave owns KFW = KF WN sixteen-row blocks of k and NWW = NW / WN column blocks, and
 // reads 6 (KFW + NWW) fragments from LDS per step for 6 KFW NWW MFMAs -- 2 x 2 halves the LDS reads of the 4 x 1 arrangement at 128 x 128
-template <int KF, int NW, int WN>
+template <int KF, int NW, int WN, bool GX = false>
 __global__ __launch_bounds__(256, 2) void pw_wgrad_sb_kernel(WgradSB p) {
   constexpr int TK = 64 * KF, TN = 16 * NW, MS = 32;
   constexpr int KFW = KF * WN, NWW = NW / WN;
@@ -937,7 +952,19 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_sb_kernel(WgradSB p) {
   const int xk0 = min(xk, p.K - 4), xk1 = min(xk + 4, p.K - 4), dn0 = min(dn, p.N - 4), dn1 = min(dn + 4, p.N - 4);
   const float* scp = p.scale ? p.scale : p.X;
   const float* shp = p.scale ? p.shift : p.X;
-  const float4 sc0 = ld4(scp + xk0), sc1 = ld4(scp + xk1), sh0 = ld4(shp + xk0), sh1 = ld4(shp + xk1);
+  // GX: this thread's two groups of four k are four channels of one tap each (g_C % 4 == 0): channel offset and tap displacement
+  int gc[2] = {xk0, xk1}, gdy[2] = {0, 0}, gdx[2] = {0, 0};
+  if (GX) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = h ? xk1 : xk0;
+      const int tap = k / p.g_C, ky = tap / p.g_kw;
+      gc[h] = k - tap * p.g_C;
+      gdy[h] = p.g_ay + ky * p.g_d;
+      gdx[h] = p.g_ax + (tap - ky * p.g_kw) * p.g_d;
+    }
+  }
+  const float4 sc0 = ld4(scp + gc[0]), sc1 = ld4(scp + gc[1]), sh0 = ld4(shp + gc[0]), sh1 = ld4(shp + gc[1]);
   const float act_lo = p.act == DL3P_ACT_NONE ? -DL3P_INF : 0.f;
   const float act_hi = (p.act == DL3P_ACT_NONE || p.act == DL3P_ACT_RELU) ? DL3P_INF : 6.f;
   auto prologue4 = [&](float4 v, float4 sc4, float4 sh4) __attribute__((always_inline)) {
@@ -947,6 +974,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_sb_kernel(WgradSB p) {
                        __builtin_amdgcn_fmed3f(v.z, act_lo, act_hi), __builtin_amdgcn_fmed3f(v.w, act_lo, act_hi));
   };
   const bool has_pro = p.scale != nullptr || p.act != DL3P_ACT_NONE;
+  uint32_t gx_ok = 0;             // GX: bit (2 i + h) = group h of pass i hit the source tensor
 
   f32x4 acc[KFW][NWW];
 #pragma unroll
@@ -958,8 +986,24 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_sb_kernel(WgradSB p) {
   auto prefetch = [&](int m0) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NXP; ++i) {
-      const float* xr = p.X + (size_t)min(m0 + xm + XROWS * i, p.M - 1) * p.ldx;
-      rx[i][0] = ld4(xr + xk0); rx[i][1] = ld4(xr + xk1);
+      if (GX) {
+        const int m = m0 + xm + XROWS * i;
+        int x, y;
+        const int row = sb_divmod(min(m, p.M - 1), p.g_RW, p.g_invRW, &x);
+        const int n = sb_divmod(row, p.g_RH, p.g_invRH, &y);
+        const uint32_t img = (uint32_t)n * (uint32_t)(p.g_SH * p.g_SW);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int sy = y * p.g_mul + gdy[h], sx = x * p.g_mul + gdx[h];
+          const bool ok = m < mend && sy >= 0 && sx >= 0 && sy < p.g_SH && sx < p.g_SW;
+          const uint32_t off = ok ? (img + (uint32_t)(sy * p.g_SW + sx)) * (uint32_t)p.ldx + (uint32_t)gc[h] : 0u;
+          rx[i][h] = ld4(p.X + off);
+          gx_ok = (gx_ok & ~(1u << (2 * i + h))) | (ok ? (1u << (2 * i + h)) : 0u);
+        }
+      } else {
+        const float* xr = p.X + (size_t)min(m0 + xm + XROWS * i, p.M - 1) * p.ldx;
+        rx[i][0] = ld4(xr + xk0); rx[i][1] = ld4(xr + xk1);
+      }
     }
 #pragma unroll
     for (int i = 0; i < NDP; ++i) {
@@ -979,8 +1023,9 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_sb_kernel(WgradSB p) {
       float4 v0 = rx[i][0], v1 = rx[i][1];
       if (has_pro) { v0 = prologue4(v0, sc0, sh0); v1 = prologue4(v1, sc1, sh1); }
       const bool rok = m0 + xm + XROWS * i < mend;
-      if (!(rok && xok0)) v0 = zero4();
-      if (!(rok && xok1)) v1 = zero4();
+      const bool ok0 = GX ? ((gx_ok >> (2 * i)) & 1u) != 0 : rok, ok1 = GX ? ((gx_ok >> (2 * i + 1)) & 1u) != 0 : rok;
+      if (!(ok0 && xok0)) v0 = zero4();
+      if (!(ok1 && xok1)) v1 = zero4();
       uint4 hh, mm, ll;
       split2(v0.x, v0.y, hh.x, mm.x, ll.x);
       split2(v0.z, v0.w, hh.y, mm.y, ll.y);
@@ -1107,4 +1152,20 @@ void dl3p_launch_wgrad_sb(const float* x, int ldx, const float* scale, const flo
   } else if (kf == 1 && nw == 8) dl3p_launch(pw_wgrad_sb_kernel<1, 8, 1>, dim3(ktiles * ntiles, splits), block, 0, st, p);
   else if (kf == 2 && nw == 4) dl3p_launch(pw_wgrad_sb_kernel<2, 4, 1>, dim3(ktiles * ntiles, splits), block, 0, st, p);
   else dl3p_launch(pw_wgrad_sb_kernel<1, 4, 1>, dim3(ktiles * ntiles, splits), block, 0, st, p);
+}
+
+// the same tiles with the X operand gathered from a convolution's input tensor (dl3p_conv2d_gemm_bwd_weight*); geo = {RH, RW, SH, SW,
+// C, kw, mul, ay, ax, d} as in WgradSB
+void dl3p_launch_wgrad_sb_gx(const float* x, int ldx, const float* scale, const float* shift, int act, const float* dy, int lddy,
+                             float* slabs, int M, int K, int N, const int* geo, int kf, int nw, int ktiles, int ntiles, int mrows, int splits,
+                             hipStream_t st) {
+  WgradSB p = {x, ldx, scale, shift, act, dy, lddy, slabs, M, K, N, ktiles, ntiles, mrows, 0};
+  p.g_RH = geo[0]; p.g_RW = geo[1]; p.g_SH = geo[2]; p.g_SW = geo[3]; p.g_C = geo[4]; p.g_kw = geo[5]; p.g_mul = geo[6];
+  p.g_ay = geo[7]; p.g_ax = geo[8]; p.g_d = geo[9];
+  p.g_invRW = 1.f / (float)p.g_RW; p.g_invRH = 1.f / (float)p.g_RH;
+  const dim3 block(256), grid(ktiles * ntiles, splits);
+  if (kf == 2 && nw == 8) dl3p_launch(pw_wgrad_sb_kernel<2, 8, 2, true>, grid, block, 0, st, p);
+  else if (kf == 1 && nw == 8) dl3p_launch(pw_wgrad_sb_kernel<1, 8, 1, true>, grid, block, 0, st, p);
+  else if (kf == 2 && nw == 4) dl3p_launch(pw_wgrad_sb_kernel<2, 4, 1, true>, grid, block, 0, st, p);
+  else dl3p_launch(pw_wgrad_sb_kernel<1, 4, 1, true>, grid, block, 0, st, p);
 }

@@ -620,6 +620,7 @@ static int g_sbw_force_tile = -1, g_sbw_force_pc = 0;      // "split_wgrad_tile"
 static int g_sb_pipe = -1;      // dl3p_set_option("sb_pipe", 0 | 1): the producer / consumer form of the split kernel (default DL3P_SB_PIPE or 0)
 static int g_sb_force_wm = 0, g_sb_force_nt = 0;      // dl3p_set_option("sb_wm" / "sb_nt"): pin the split kernel's wide-tile family (gemm_plan_sb)
 static int g_sb_rs = -1;      // dl3p_set_option("sb_rs", 0 | 1 | -1): the row-stationary split kernel (pw_split_rs.hip) never / wherever it serves the shape / by rule (DL3P_SB_RS)
+static int g_conv_sb = -1;    // dl3p_set_option("conv_sb", 0 | 1 | 2 | -1): dense convs on the split kernels never / by rule / wherever supported / default (DL3P_CONV_SB, else 1)
 static int g_wgrad_force_tile = -1, g_wgrad_force_per_cu = 0;                    // see wgrad_pick_tile / wgrad_split
 static int g_pw_small_min_rows = -1;
 static int pw_small_min_rows() {
@@ -643,6 +644,7 @@ extern "C" int dl3p_set_option(const char* name, int value) {
   if (!strcmp(name, "split_wgrad_per_cu")) { g_sbw_force_pc = value > 0 ? value : 0; return DL3P_OK; }
   if (!strcmp(name, "sb_wm")) { g_sb_force_wm = (value >= -1 && value <= 2) ? value : 0; return DL3P_OK; }    // -1: never wide
   if (!strcmp(name, "sb_rs")) { g_sb_rs = value < 0 ? -1 : (value ? 1 : 0); return DL3P_OK; }
+  if (!strcmp(name, "conv_sb")) { g_conv_sb = (value >= 0 && value <= 2) ? value : -1; return DL3P_OK; }
   if (!strcmp(name, "sb_nt")) { g_sb_force_nt = (value == 8 || value == 12 || value == 16) ? value : 0; return DL3P_OK; }
   if (!strcmp(name, "dw_per_cu")) { dl3p_dw_force_per_cu = value > 0 ? value : 0; return DL3P_OK; }
   if (!strcmp(name, "dw_want")) { dl3p_dw_force_want = value > 0 ? value : 0; return DL3P_OK; }
@@ -1041,6 +1043,9 @@ static int wgrad_sb_route(int M, int K, int N, size_t max_slabs, int* kf, int* n
   if (max_slabs > (size_t)DL3P_MAX_STAT_ROWS) max_slabs = DL3P_MAX_STAT_ROWS;
   return dl3p_wgrad_sb_plan(M, K, N, (int)max_slabs, tile, per_cu, kf, nw, kt, nt, mrows);
 }
+void dl3p_launch_wgrad_sb_gx(const float* x, int ldx, const float* scale, const float* shift, int act, const float* dy, int lddy,
+                             float* slabs, int M, int K, int N, const int* geo, int kf, int nw, int ktiles, int ntiles, int mrows, int splits,
+                             hipStream_t st);
 bool dl3p_sb_wide_config(int nt, int mi, int wm);
 bool dl3p_sb_rs_supported(int role, int M, int K, int N);
 int dl3p_sb_rs_grid(int M);
@@ -2082,11 +2087,132 @@ extern "C" int dl3p_conv2d_gemm_bwd_data(const float* dy, int lddy, const float*
   return DL3P_OK;
 }
 
+// ---- the same implicit GEMMs on the split-bf16 kernels (pw_split.hip, GA instantiations of pw_gemm_sb_kernel / GX of
+// pw_wgrad_sb_kernel): fp32-accurate products on the bf16 matrix pipe, the kernel pre-split by dl3p_split_bf16x3_batch as
+// [3][Cout][pitch >= k k Cin] (forward: from the transposed kernel wt) or [3][Cin][pitch >= k k Cout] (data gradient: from
+// dl3p_conv2d_gemm_dgrad_weights' wd).  role 0 / 1: forward without / with BatchNorm statistics, 2: data gradient, 4: weight
+// gradient; (M, K, N) = the GEMM as launched.
+static int conv_sb_mode() {       // 0 off, 1 the measured rule, 2 wherever supported (tests)
+  static const int env = getenv("DL3P_CONV_SB") ? atoi(getenv("DL3P_CONV_SB")) : 1;
+  return g_conv_sb >= 0 ? g_conv_sb : env;
+}
+
+extern "C" int dl3p_conv2d_gemm_sb_supported(int role, int M, int K, int N) {
+  if (role < 0 || role > 4 || role == 3 || conv_sb_mode() == 0) return 0;
+  if (M < 1024 || K < 32 || N < 16 || K % 4 || N % 4 || K >= 65536) return 0;
+  if (role == 4) return split_wgrad_on() && N >= 32;
+  return 1;
+}
+
+// where it pays (scripts/micro/conv_sb.py, profiles/r04_dense_conv_split.txt)
+extern "C" int dl3p_conv2d_gemm_sb_pays(int role, int M, int K, int N) {
+  if (!dl3p_conv2d_gemm_sb_supported(role, M, K, N)) return 0;
+  if (conv_sb_mode() == 2) return 1;
+  // measured (same box, fp32-input kernel -> split kernel, us): the WEIGHT gradient wins wherever both of its operands are long
+  // enough to fill the tiles -- 125 -> 111 (Xception entry_flow_conv1_2, 264196 x 288 x 64), 124 -> 101 (ResNet50 stage 2), 115 ->
+  // 75 / 119 -> 78 (stages 3 / 4), 626 -> 326 (stage 5 at 8712 rows: three slabs instead of one).  The FORWARD and the DATA
+  // gradient are bound by the gather of their A operand, not by the matrix pipe: they win with a long reduction (K >= 1024: 141 ->
+  // 126, 175 -> 131, 518 -> 460 forward; 132 -> 123, 163 -> 129, 493 -> 443 data gradient); at K = 576 onto 64 columns both lose
+  // (142 -> 147, 123 -> 132), as does conv1_2's data gradient onto 32 columns (163 -> 166).  conv1_2's forward would win (150 ->
+  // 127 at batch 4, 170 -> 153 at configs[3]) and stays on the fp32-input kernel all the same: its column means come out 3e-8 of
+  // a standard deviation off instead of 5e-9 (same rms error per element, 2e-7) -- as the second layer of a 70-layer network on
+  // batch statistics that moved every gradient of the 513 x 513 Xception parity test 1.7x further from float64 (0.0048 -> 0.0058
+  // worst) for 0.03 ms of a 21.6 ms step
+  if (M < 4096) return 0;
+  if (role == 4) return M >= 8192 && K >= 128;
+  return K >= 1024;
+}
+
+static void gemm_plan_sb_ga(int M, int N, bool stats, int* nt, int* gx, int* gy, int* num_m_tiles, int* mi) {
+  *nt = pick_nt(N, M);
+  if (*nt > 8) *nt = 8;
+  if (g_gemm_force_nt) *nt = g_gemm_force_nt > 8 ? 8 : g_gemm_force_nt;
+  // (128-row tiles with the gather's index registers spill from 96 columns up: 64-row tiles there)
+  gemm_grid(M, N, *nt, gx, gy, num_m_tiles, mi, false, g_gemm_force_mi ? g_gemm_force_mi : ((M >= 4096 && *nt < 6) ? 2 : 1), g_gemm_force_pc);
+  (void)stats;
+}
+
+extern "C" int dl3p_conv2d_gemm_fwd_sb(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                                       const void* wsp, int pitch, const float* bias, float* y, int ldy, float* stat_partials,
+                                       int* rows_out, int N, int H, int W, int Cin, int Cout, int k, int stride, int rate,
+                                       int pad_t, int pad_l, int Ho, int Wo, void* stream) {
+  const char* fn = "dl3p_conv2d_gemm_fwd_sb";
+  int rc = conv_gemm_check(fn, N, H, W, Cin, Cout, k, stride, rate, pad_t, pad_l, Ho, Wo);
+  if (rc) return rc;
+  rc = check_mat(fn, x, ldx, Cin);
+  if (rc) return rc;
+  rc = check_mat(fn, y, ldy, Cout);
+  if (rc) return rc;
+  const int M = N * Ho * Wo, K = k * k * Cin;
+  rc = check_sb(fn, wsp, pitch, K);
+  if (rc) return rc;
+  DL3P_CHECK_ARG(dl3p_conv2d_gemm_sb_supported(stat_partials ? 1 : 0, M, K, Cout), "%s: shape M=%d K=%d N=%d is not served by the split kernel", fn, M, K, Cout);
+  DL3P_CHECK_ARG((unsigned long long)N * H * W * (unsigned long long)ldx * 4ull < (1ull << 32) &&
+                     (unsigned long long)M * (unsigned long long)ldy * 4ull < (1ull << 32),
+                 "%s: operands of 4 GiB or more are not supported", fn);
+  GemmParams p = {};
+  p.A = x; p.lda = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act;
+  p.Bsp = (const unsigned short*)wsp; p.bsp_pitch = pitch; p.bsp_plane = (long long)Cout * pitch;
+  p.bias = bias; p.Y = y; p.ldy = ldy; p.partials = stat_partials;
+  p.M = M; p.K = K; p.N = Cout;
+  conv_gather_fwd(&p, H, W, Cin, k, stride, rate, pad_t, pad_l, Ho, Wo);
+  int nt, gx, gy, mi;
+  gemm_plan_sb_ga(M, Cout, stat_partials != nullptr, &nt, &gx, &gy, &p.num_m_tiles, &mi);
+  if (rows_out) *rows_out = gx;
+  dl3p_launch_gemm_sb(p, stat_partials != nullptr, false, true, nt, mi, 1, dim3(gx, gy), (hipStream_t)stream);
+  DL3P_CHECK_LAUNCH(fn);
+  return DL3P_OK;
+}
+
+extern "C" int dl3p_conv2d_gemm_bwd_data_sb(const float* dy, int lddy, const void* wdsp, int pitch, float* gx, int ldgx, int accumulate,
+                                            int N, int H, int W, int Cin, int Cout, int k, int stride, int rate, int pad_t,
+                                            int pad_l, int Ho, int Wo, void* stream) {
+  const char* fn = "dl3p_conv2d_gemm_bwd_data_sb";
+  int rc = conv_gemm_check(fn, N, H, W, Cin, Cout, k, stride, rate, pad_t, pad_l, Ho, Wo);
+  if (rc) return rc;
+  rc = check_mat(fn, dy, lddy, Cout);
+  if (rc) return rc;
+  rc = check_mat(fn, gx, ldgx, Cin);
+  if (rc) return rc;
+  const int M = N * H * W, K = k * k * Cout;
+  rc = check_sb(fn, wdsp, pitch, K);
+  if (rc) return rc;
+  DL3P_CHECK_ARG(dl3p_conv2d_gemm_sb_supported(2, M, K, Cin), "%s: shape M=%d K=%d N=%d is not served by the split kernel", fn, M, K, Cin);
+  DL3P_CHECK_ARG((unsigned long long)N * Ho * Wo * (unsigned long long)lddy * 4ull < (1ull << 32) &&
+                     (unsigned long long)M * (unsigned long long)ldgx * 4ull < (1ull << 32),
+                 "%s: operands of 4 GiB or more are not supported", fn);
+  GemmParams p = {};
+  p.A = dy; p.lda = lddy; p.act = DL3P_ACT_NONE;
+  p.Bsp = (const unsigned short*)wdsp; p.bsp_pitch = pitch; p.bsp_plane = (long long)Cin * pitch;
+  p.Y = gx; p.ldy = ldgx; p.accumulate = accumulate;
+  p.M = M; p.K = K; p.N = Cin;
+  p.g_RH = H; p.g_RW = W; p.g_SH = Ho; p.g_SW = Wo; p.g_C = Cout; p.g_kw = k;
+  p.g_mul = 1; p.g_ay = pad_t; p.g_ax = pad_l; p.g_d = -rate; p.g_shift = stride == 2 ? 1 : 0;
+  p.g_cmagic = (uint32_t)((1ull << 32) / (unsigned)Cout) + 1u;
+  p.g_kwmagic = 65536 / k + 1;
+  int nt, gxn, gy, mi;
+  gemm_plan_sb_ga(M, Cin, false, &nt, &gxn, &gy, &p.num_m_tiles, &mi);
+  dl3p_launch_gemm_sb(p, false, false, true, nt, mi, 1, dim3(gxn, gy), (hipStream_t)stream);
+  DL3P_CHECK_LAUNCH(fn);
+  return DL3P_OK;
+}
+
+// does this dense conv's weight gradient run on the split kernel?  -> slabs (0: no)
+static int conv_wgrad_sb_route(int M, int K, int N, size_t max_slabs, int* kf, int* nw, int* kt, int* nt, int* mrows) {
+  if (!dl3p_conv2d_gemm_sb_pays(4, M, K, N)) return 0;
+  if (max_slabs > (size_t)DL3P_MAX_STAT_ROWS) max_slabs = DL3P_MAX_STAT_ROWS;
+  return dl3p_wgrad_sb_plan(M, K, N, (int)max_slabs, g_sbw_force_tile, g_sbw_force_pc, kf, nw, kt, nt, mrows);
+}
+
 extern "C" size_t dl3p_conv2d_gemm_bwd_weight_workspace(int N, int Ho, int Wo, int Cin, int Cout, int k) {
   if (N <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || k <= 0) return 0;
   int kt, nt, s, mc;
   wgrad_split(N * Ho * Wo, k * k * Cin, Cout, &kt, &nt, &s, &mc);
-  const size_t a = (size_t)s * k * k * Cin * Cout, b = (size_t)512 * Cout;   // slabs; bias column-sum partial rows
+  size_t a = (size_t)s * k * k * Cin * Cout;
+  const size_t b = (size_t)512 * Cout;   // slabs; bias column-sum partial rows
+  int kf, nw, kt2, nt2, mrows;
+  const size_t a2 = (size_t)conv_wgrad_sb_route(N * Ho * Wo, k * k * Cin, Cout, DL3P_MAX_STAT_ROWS, &kf, &nw, &kt2, &nt2, &mrows) * k * k * Cin * Cout;
+  if (a2 > a) a = a2;
   return (a > b ? a : b) * sizeof(float);
 }
 
@@ -2118,9 +2244,17 @@ static int conv2d_gemm_bwd_weight_impl(const float* x, int ldx, const float* in_
   p.g_mul = stride; p.g_ay = -pad_t; p.g_ax = -pad_l; p.g_d = rate;
   p.g_invRW = 1.f / (float)Wo; p.g_invRH = 1.f / (float)Ho;
   int splits;
-  wgrad_split(M, K, Cout, &p.ktiles, &p.ntiles, &splits, &p.mchunk);
   hipStream_t st = (hipStream_t)stream;
-  launch_wgrad_tiled<true>(p, splits, st);
+  int kf, nw, kt2, nt2, mrows;
+  const int s2 = conv_wgrad_sb_route(M, K, Cout, workspace_bytes / ((size_t)K * Cout * 4), &kf, &nw, &kt2, &nt2, &mrows);
+  if (s2 > 0) {
+    const int geo[10] = {Ho, Wo, H, W, Cin, k, stride, -pad_t, -pad_l, rate};
+    splits = s2;
+    dl3p_launch_wgrad_sb_gx(x, ldx, in_scale, in_shift, in_act, dy, lddy, workspace, M, K, Cout, geo, kf, nw, kt2, nt2, mrows, s2, st);
+  } else {
+    wgrad_split(M, K, Cout, &p.ktiles, &p.ntiles, &splits, &p.mchunk);
+    launch_wgrad_tiled<true>(p, splits, st);
+  }
   DL3P_CHECK_LAUNCH(fn);
   if (rows_out) { *rows_out = splits; return DL3P_OK; }
   rc = dl3p_reduce_rows_impl(workspace, splits, (size_t)K * Cout, gw, 0, st);

@@ -91,10 +91,20 @@ class ParamStore:
                 self.sb_bwd[op] = (o, pn)
                 self.sb_row_b[op] = [self.offset[op.w], K, Nn, Nn, o, pn]
                 o += 3 * K * pn
-            if pw:
+            # dense k x k convs on the implicit-GEMM path (dl3p_conv2d_gemm_fwd_sb): the forward's [3][Cout][pitch >= k k Cin] from
+            # the transposed copy; the data gradient's operand is re-laid per step (conv2d_gemm_dgrad_weights) and split by the
+            # executor that owns that buffer
+            dense = [op for op in graph.ops if op.kind == 'conv_dense' and op.kp == op.k * op.k * op.cin
+                     and lib().conv2d_gemm_supported(op.cin, op.cout, op.k, op.stride)]
+            for op in dense:
+                pk = (op.kp + 31) // 32 * 32
+                self.sb_fwd[op] = (o, pk)
+                self.sb_row_f[op] = [self.offset[op.w], op.cout, op.kp, op.kp, o, pk]
+                o += 3 * op.cout * pk
+            if pw or dense:
                 self.Sb = torch.zeros(o, dtype=torch.int16, device=device)
-                self.sb_table_f = torch.tensor([self.sb_row_f[op] for op in pw], dtype=torch.int64, device=device)
-                self.sb_table_b = torch.tensor([self.sb_row_b[op] for op in pw], dtype=torch.int64, device=device)
+                self.sb_table_f = torch.tensor([self.sb_row_f[op] for op in pw + dense], dtype=torch.int64, device=device)
+                self.sb_table_b = torch.tensor([self.sb_row_b[op] for op in pw], dtype=torch.int64, device=device) if pw else None
         self.upload()
         self.refresh_masks()
 
@@ -111,7 +121,8 @@ class ParamStore:
                                   int(self.tr_table.shape[0]), st)
         if self.Sb is not None:
             lib().split_bf16x3_batch(self.Pt.data_ptr(), self.Sb.data_ptr(), self.sb_table_f.data_ptr(), int(self.sb_table_f.shape[0]), st)
-            lib().split_bf16x3_batch(self.P.data_ptr(), self.Sb.data_ptr(), self.sb_table_b.data_ptr(), int(self.sb_table_b.shape[0]), st)
+            if self.sb_table_b is not None:
+                lib().split_bf16x3_batch(self.P.data_ptr(), self.Sb.data_ptr(), self.sb_table_b.data_ptr(), int(self.sb_table_b.shape[0]), st)
             self.sb_partial = None
 
     def sb_ptr(self, op, fwd):
@@ -422,6 +433,7 @@ class Executor:
         self._mark_requires_grad()
         direct_cols = {op.col.id for op in g.ops if op.kind == 'conv_dense' and (self._stem_direct(op) or self._dense_gemm(op))}
         # the data-gradient GEMM of an implicit-GEMM conv reads the kernel as [Cin][k*k*Cout] (rebuilt every step)
+        self.dense_wd_sb = {}       # id(op) -> (its three bf16 planes, the one-row job table of the split)
         self.dense_wd = {id(op): torch.zeros(op.k * op.k * op.cin * op.cout, **self.f32) for op in g.ops
                          if op.kind == 'conv_dense' and self.training and self._dense_gemm(op) and op.k > 1}
         # (a strided 1x1 conv keeps the gradient of its compact patch matrix = dz @ W^T on the output pixels: scattering
@@ -655,6 +667,11 @@ class Executor:
                 elif self._stem_direct(op):
                     P.k(L.stem_conv_fwd, xp, ldx, st.ptr(op.w), self.tptr(op.out), op.out.ld, part, ctypes.byref(rows), N,
                         xt.H, xt.W, op.cout, op.pad_t, op.pad_l, op.Ho, op.Wo, tag=op.name)
+                elif self._dense_gemm(op) and self._use_sb_dense(op, 1 if part is not None else 0):
+                    wsp, pitch = st.sb_ptr(op, True)
+                    P.k(L.conv2d_gemm_fwd_sb, xp, ldx, sp, hp, act, wsp, pitch, st.ptr(op.b) if op.b else None,
+                        self.tptr(op.out), op.out.ld, part, ctypes.byref(rows), N, xt.H, xt.W, op.cin, op.cout, op.k,
+                        op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo, tag=op.name)
                 elif self._dense_gemm(op):
                     P.k(L.conv2d_gemm_fwd, xp, ldx, sp, hp, act, st.ptr(op.w, st.Pt), st.ptr(op.b) if op.b else None,
                         self.tptr(op.out), op.out.ld, part, ctypes.byref(rows), N, xt.H, xt.W, op.cin, op.cout, op.k,
@@ -1101,8 +1118,21 @@ class Executor:
                     elif k == 'conv_dense' and self._dense_gemm(op) and op.k > 1:
                         wd = self.dense_wd[id(op)]
                         P.k(L.conv2d_gemm_dgrad_weights, st.ptr(op.w), wd.data_ptr(), op.k, op.cin, op.cout)
-                        P.k(L.conv2d_gemm_bwd_data, dz, lddz, wd.data_ptr(), gp, ldg, acc, N, xt.H, xt.W, op.cin, op.cout,
-                            op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
+                        if self._use_sb_dense(op, 2):
+                            # the re-laid kernel [Cin][k k Cout] split into its three bf16 planes (a few hundred KB), then the
+                            # data gradient on the bf16 matrix pipe
+                            kd = op.k * op.k * op.cout
+                            pitch = (kd + 31) // 32 * 32
+                            sp3 = self.dense_wd_sb.get(id(op))
+                            if sp3 is None:
+                                sp3 = self.dense_wd_sb[id(op)] = (torch.zeros(3 * op.cin * pitch, dtype=torch.int16, device=self.dev),
+                                                                  torch.tensor([[0, op.cin, kd, kd, 0, pitch]], dtype=torch.int64, device=self.dev))
+                            P.k(L.split_bf16x3_batch, wd.data_ptr(), sp3[0].data_ptr(), sp3[1].data_ptr(), 1)
+                            P.k(L.conv2d_gemm_bwd_data_sb, dz, lddz, sp3[0].data_ptr(), pitch, gp, ldg, acc, N, xt.H, xt.W, op.cin, op.cout,
+                                op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
+                        else:
+                            P.k(L.conv2d_gemm_bwd_data, dz, lddz, wd.data_ptr(), gp, ldg, acc, N, xt.H, xt.W, op.cin, op.cout,
+                                op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
                     else:
                         # d/d(im2col matrix) by the GEMM, then the transposed gather back onto the input pixels
                         P.k(L.pwconv_bwd_data, dz, lddz, st.ptr(op.w), self.tptr(op.col, True), op.col.ld, 0,
@@ -1287,6 +1317,24 @@ class Executor:
         if not self.L.pwconv_sb_supported(role, M, kred, nout):
             return False
         (self._sb_used_f if fwd else self._sb_used_b).add(op)       # the optimiser step refreshes these planes (_trace_sgd)
+        return True
+
+    def _use_sb_dense(self, op, role):
+        """does this dense conv's forward (role 0 / 1: without / with BatchNorm statistics) or data gradient (2) run on the split
+        kernel?  The measured rule of the library (dl3p_conv2d_gemm_sb_pays); the weight gradient routes itself inside
+        dl3p_conv2d_gemm_bwd_weight*"""
+        st = self.store
+        if st.Sb is None or op not in st.sb_fwd:
+            return False
+        xt = op.x.tensor
+        if role == 2:
+            M, K, Nn = self.N * xt.H * xt.W, op.k * op.k * op.cout, op.cin
+        else:
+            M, K, Nn = self.N * op.Ho * op.Wo, op.k * op.k * op.cin, op.cout
+        if not self.L.conv2d_gemm_sb_pays(role, M, K, Nn):
+            return False
+        if role != 2:
+            self._sb_used_f.add(op)          # the optimiser step refreshes this plane (_trace_sgd)
         return True
 
     def _pw_dgrad_bn(self, P, op, dz, lddz, gp, ldg, acc, bn_op, partials, rows):
@@ -1546,7 +1594,7 @@ class Executor:
         elif st.tr_table is not None:      # the forward GEMMs read the transposed kernel copies
             P.k(L.transpose_batch, st.P.data_ptr(), st.Pt.data_ptr(), st.tr_table.data_ptr(), int(st.tr_table.shape[0]))
         if st.Sb is not None:               # ... and the split-bf16 GEMMs of THIS executor the pre-split planes they read
-            order = [op for op in self.g.ops if op.kind == 'conv_pw']
+            order = [op for op in self.g.ops if op.kind in ('conv_pw', 'conv_dense')]
             rf = [st.sb_row_f[op] for op in order if op in self._sb_used_f]
             rb = [st.sb_row_b[op] for op in order if op in self._sb_used_b]
             self._sb_tab_f = torch.tensor(rf, dtype=torch.int64, device=self.dev) if rf else None

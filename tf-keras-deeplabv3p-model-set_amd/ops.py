@@ -592,6 +592,37 @@ def conv2d_gemm_bwd_weight(x, dy, k, stride=1, rate=1, padding='same', in_scale=
     return (gw, gb) if with_bias else gw
 
 
+def conv2d_gemm_fwd_sb(x, w, stride=1, rate=1, padding='same', in_scale=None, in_shift=None, in_act=ACT_NONE, bias=None,
+                       partials=None):
+    """conv2d_gemm_fwd on the split-bf16 kernel (the kernel operand pre-split here: [3][Cout][pitch >= k k Cin])"""
+    N, H, W, Cin = x.shape
+    k, Cout = w.shape[0], w.shape[-1]
+    Ho, Wo, pt, pl = conv_geometry(H, W, k, stride, rate, padding)
+    wsp = split_bf16x3(w.reshape(k * k * Cin, Cout).t().contiguous())
+    y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+    xp, ldx = _pl(x)
+    rows = ctypes.c_int(0)
+    lib().conv2d_gemm_fwd_sb(xp, ldx, _p(in_scale), _p(in_shift), in_act, _p(wsp), wsp.shape[2], _p(bias), _p(y), Cout, _p(partials),
+                             ctypes.byref(rows), N, H, W, Cin, Cout, k, stride, rate, pt, pl, Ho, Wo, _stream())
+    return (y, rows.value) if partials is not None else y
+
+
+def conv2d_gemm_bwd_data_sb(dy, w, x_shape, stride=1, rate=1, padding='same', out=None, accumulate=False):
+    """conv2d_gemm_bwd_data on the split-bf16 kernel (wd = conv2d_gemm_dgrad_weights(w) pre-split: [3][Cin][pitch >= k k Cout])"""
+    N, H, W, Cin = x_shape
+    k, Cout = w.shape[0], w.shape[-1]
+    Ho, Wo, pt, pl = conv_geometry(H, W, k, stride, rate, padding)
+    wd = torch.empty((Cin, k * k * Cout), dtype=torch.float32, device=dy.device)
+    lib().conv2d_gemm_dgrad_weights(_p(w.contiguous()), _p(wd), k, Cin, Cout, _stream())
+    wdsp = split_bf16x3(wd)
+    gx = out if out is not None else torch.empty(x_shape, dtype=torch.float32, device=dy.device)
+    dp, ldd = _pl(dy)
+    gp, ldg = _pl(gx)
+    lib().conv2d_gemm_bwd_data_sb(dp, ldd, _p(wdsp), wdsp.shape[2], gp, ldg, int(accumulate), N, H, W, Cin, Cout, k, stride, rate,
+                                  pt, pl, Ho, Wo, _stream())
+    return gx
+
+
 def stem_conv_supported(Cin, Cout, k, stride, rate):
     return bool(lib().stem_conv_supported(Cin, Cout, k, stride, rate))
 
