@@ -105,6 +105,49 @@ def test_pointwise_bf16(ops, case):
     close_f32(gb, gy.sum(0), 'bias gradient', 1e-4)
 
 
+@pytest.mark.parametrize('kg', [1, 2, 4])
+@pytest.mark.parametrize('case', [(64 * 128, 960, 160), (2000, 672, 112), (1003, 1288, 264), (513, 200, 80), (8192, 80, 480)])
+def test_pointwise_bf16_k_groups(ops, case, kg):
+    """pwb_gemm with its K groups pinned (dl3p_set_option("bf16_kg")): one group (the plain tiled kernel), two and four groups of
+    four waves taking every second / fourth K-step of a tile and summing their accumulators through LDS -- a reduction that is not
+    a multiple of 32 * groups, row and column tails, forward with prologue + statistics and both data gradients"""
+    M, K, Nn = case
+    L = ops.lib()
+    L.set_option(b'bf16_kg', kg)
+    try:
+        rng = np.random.default_rng(M + 7 * K + Nn)
+        x = Q(rng.standard_normal((M, K)))
+        w = rng.standard_normal((K, Nn)) / np.sqrt(K)
+        sc = rng.uniform(0.5, 1.5, K).astype(np.float32)
+        sh = (rng.standard_normal(K) * 0.3).astype(np.float32)
+        wq = Q(w)
+        a = Q(O.act_fwd(np.float32(np.float64(x) * sc + sh), O.ACT_RELU6).astype(np.float64))
+        part = ops.new_partials(Nn, DEV)
+        y, rows = ops.pwconv_fwd_bf16(TB(x), TF(w), None, TF(sc), TF(sh), ops.ACT_RELU6, partials=part)
+        close_bf16(y, Q(a @ wq), 'forward')
+        yq = np64(y)
+        p = part[:rows * 2 * Nn].reshape(rows, 2, Nn).double().sum(0).cpu().numpy()
+        close_f32(p[0], yq.sum(0), 'stat sum (of the stored values)', 1e-4 + 1e-5 * np.sqrt(M))
+        close_f32(p[1], (yq ** 2).sum(0), 'stat sum of squares', 1e-4)
+        close_bf16(ops.pwconv_fwd_bf16(TB(x), TF(w)), Q(np.float64(x) @ wq), 'forward, no prologue, no statistics')
+        gy = Q(rng.standard_normal((M, Nn)))
+        gx = ops.pwconv_bwd_data_bf16(TB(gy), TF(w))
+        close_bf16(gx, Q(gy @ wq.T), 'data gradient')
+        z = Q(rng.standard_normal((M, K)) * 1.5 + 0.4)
+        mu = (rng.standard_normal(K) * 0.2).astype(np.float32)
+        inv = rng.uniform(0.5, 2.0, K).astype(np.float32)
+        part2 = ops.new_partials(K, DEV)
+        gx2, rows2 = ops.pwconv_bwd_data_bn_bf16(TB(gy), TF(w), TB(z), TF(sc), TF(sh), O.ACT_RELU6, TF(mu), TF(inv), part2)
+        assert torch.equal(gx2, gx), 'the sums epilogue changes the gradient'
+        u = np.float32(np.float64(z) * sc + sh)
+        g = np64(gx2) * O.act_bwd(u.astype(np.float64), np.ones((M, K)), O.ACT_RELU6)
+        p2 = part2[:rows2 * 2 * K].reshape(rows2, 2, K).double().sum(0).cpu().numpy()
+        close_f32(p2[0], g.sum(0), 'backward sum', 2e-5 * np.sqrt(M) + 1e-5)
+        close_f32(p2[1], (g * ((np.float64(z) - mu) * inv)).sum(0), 'backward sum with xhat', 2e-5 * np.sqrt(M) + 1e-5)
+    finally:
+        L.set_option(b'bf16_kg', -1)
+
+
 @pytest.mark.parametrize('case', [(2 * 33 * 33, 320, 256), (1000, 24, 72), (777, 72, 24), (4101, 16, 64), (513, 304, 256),
                                   (300, 960, 160), (64 * 128 * 9 + 5, 160, 304), (70003, 64, 24), (66000, 256, 144)])
 @pytest.mark.parametrize('act', [O.ACT_RELU6, O.ACT_NONE, O.ACT_HSWISH])

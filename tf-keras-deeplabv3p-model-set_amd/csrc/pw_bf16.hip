@@ -19,6 +19,8 @@
 #include <stdlib.h>
 #include <type_traits>
 
+int dl3p_bf16_force_kg = -1;      // dl3p_set_option("bf16_kg", 0 | 1 | 2 | 4 | -1): K groups of pwb_gemm by rule / never / pinned / default (DL3P_BF16_KG)
+
 namespace {
 
 constexpr int BK = 32;
@@ -87,32 +89,45 @@ constexpr int KMAX_LDS = 2048;      // per-channel prologue coefficients of up t
 // tensor (conv_upsample output and its gradient) stays fp32 so that the softmax / loss head is the fp32 one.
 // The operand loads of K-step it + 2 are issued while step it is multiplied (two register slots): at 1-2 workgroups of
 // work per CU and 0.3 us per K-step a single step of lookahead left the ~2 us HBM latency exposed on every step.
-template <int NT, int MI, bool A_F32, bool Y_F32, bool STATS, bool BNB = false>
-__global__ __launch_bounds__(256, BNB ? 2 : ((NT * MI <= 8 && !(STATS && NT * MI > 4)) ? 4 : (NT * MI <= 8 ? 3 : 2))) void pwb_gemm(GemmB p) {
+template <int NT, int MI, bool A_F32, bool Y_F32, bool STATS, bool BNB = false, int KG = 1>
+// (with the statistics registers 128 x 64-row tiles need 180 VGPRs: under a three-workgroup bound they spilled 12 of them inside the
+// K loop -- 33.9 against 18.0 us without statistics on 8192 x 672 -> 112; two workgroups per CU there)
+// KG > 1 (few rows, long reduction: the 64 x 128 maps of configs[4] give 128 row tiles for 256 CUs and 20-40 K-steps each): KG groups
+// of four waves share one output tile and take every KG-th K-step each, with their own operand tiles in LDS -- one workgroup per CU
+// then has 4 KG waves whose stage / barrier / multiply phases overlap on the SIMDs instead of one wave per SIMD running them in
+// series; the groups' accumulators are summed through LDS (the dead operand tiles) in a fixed order before group 0 runs the epilogue.
+__global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : (BNB ? 2 : ((NT * MI <= 8 && !(STATS && NT * MI > 4)) ? 4 : ((NT * MI <= 8 && !STATS) ? 3 : 2)))) void pwb_gemm(GemmB p) {
   constexpr int BM = 64 * MI, BN = 16 * NT;
   constexpr int NB = (BN * 4 + 255) / 256;      // 16-B chunks of the B tile per thread
   constexpr int PD = 2;                         // K-steps of loads in flight
+  constexpr int NTHR = 256 * KG;
+  constexpr int GROUP = (BM + BN) * LP;         // bf16 elements of one group's operand tiles
+  constexpr int SLOT = 256 * MI * NT * 4;       // floats of one group's accumulators
+  static_assert(KG == 1 || (size_t)GROUP * KG * 2 >= (size_t)SLOT * 4 * (KG / 2), "accumulator exchange does not fit the operand tiles");
   typedef typename AType<A_F32>::type TA;
   typedef typename AType<Y_F32>::type TY;
-  __shared__ __attribute__((aligned(16))) bf16 As[BM * LP];
-  __shared__ __attribute__((aligned(16))) bf16 Bs[BN * LP];
+  __shared__ __attribute__((aligned(16))) bf16 oper[KG * GROUP];
   __shared__ __attribute__((aligned(16))) float coef[2 * KMAX_LDS];
   __shared__ float red[STATS ? 2 * 4 * BN : 1];
-  const int t = threadIdx.x, l = t & 63, w = t >> 6, r = l & 15, kg = l >> 4;
+  const int grp = threadIdx.x >> 8;             // K group (0 when KG == 1)
+  bf16* As = oper + grp * GROUP;
+  bf16* Bs = As + BM * LP;
+  const int t = threadIdx.x & 255, l = t & 63, w = t >> 6, r = l & 15, kg = l >> 4;
   const int n0 = blockIdx.y * BN;
   const int nk = (p.K + BK - 1) / BK;
+  const int nkg = (nk + KG - 1) / KG;           // K-steps per group and tile (a group's last one may lie beyond K: zeros)
   const int my_tiles = (p.num_m_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int it_total = my_tiles * nk;
+  const int it_total = my_tiles * nkg;
   const TA* Ap = reinterpret_cast<const TA*>(p.A);
   TY* Yp = reinterpret_cast<TY*>(p.Y);
   const int ar = t >> 2, ac = (t & 3) * 8;      // A staging role: rows ar + 64 i; k offset ac
   const bool has_pro = p.scale != nullptr || p.act != DL3P_ACT_NONE;
   const float act_lo = p.act == DL3P_ACT_NONE ? -DL3P_INF : 0.f;
   const float act_hi = (p.act == DL3P_ACT_NONE || p.act == DL3P_ACT_RELU) ? DL3P_INF : 6.f;
-  const bool coef_lds = p.scale != nullptr && p.K <= KMAX_LDS;
+  const bool coef_lds = p.scale != nullptr && nkg * KG * BK <= KMAX_LDS;
   if (coef_lds) {
-    const int kpad = nk * BK;
-    for (int i = t; i < kpad; i += 256) {
+    const int kpad = nkg * KG * BK;
+    for (int i = threadIdx.x; i < kpad; i += NTHR) {
       coef[i] = i < p.K ? p.scale[i] : 1.f;
       coef[KMAX_LDS + i] = i < p.K ? p.shift[i] : 0.f;
     }
@@ -124,7 +139,7 @@ __global__ __launch_bounds__(256, BNB ? 2 : ((NT * MI <= 8 && !(STATS && NT * MI
 
   auto prefetch = [&](auto slot_c, int it) {
     constexpr int S = decltype(slot_c)::value;
-    const int kt = it % nk, mt = blockIdx.x + (it / nk) * gridDim.x;
+    const int kt = (it % nkg) * KG + grp, mt = blockIdx.x + (it / nkg) * gridDim.x;
     const int m0 = mt * BM, k0 = kt * BK;
     const int k = k0 + ac;
     const bool kok = k < p.K;                     // K % 8 == 0: a chunk is inside or outside as a whole
@@ -147,7 +162,8 @@ __global__ __launch_bounds__(256, BNB ? 2 : ((NT * MI <= 8 && !(STATS && NT * MI
 
   auto stage = [&](auto slot_c, int it) {
     constexpr int S = decltype(slot_c)::value;
-    const int k = (it % nk) * BK + ac;
+    const int kt_ = (it % nkg) * KG + grp;
+    const int k = kt_ * BK + ac;
     float sc[8], sh[8];
     if (p.scale) {
       if (coef_lds) {
@@ -166,8 +182,8 @@ __global__ __launch_bounds__(256, BNB ? 2 : ((NT * MI <= 8 && !(STATS && NT * MI
     }
     // interior tiles (wave-uniform: no M / K / N tail in this step) skip the zero-fill selects; the clamp family of
     // activations is one fma + one clamp per element (the same arithmetic as act_apply, so both paths round alike)
-    const int mt_ = blockIdx.x + (it / nk) * gridDim.x;
-    const bool edge = mt_ * BM + BM > p.M || (it % nk) * BK + BK > p.K || n0 + BN > p.N;
+    const int mt_ = blockIdx.x + (it / nkg) * gridDim.x;
+    const bool edge = mt_ * BM + BM > p.M || kt_ * BK + BK > p.K || n0 + BN > p.N;
     const bool hsw = p.act >= DL3P_ACT_HSWISH;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -228,9 +244,42 @@ __global__ __launch_bounds__(256, BNB ? 2 : ((NT * MI <= 8 && !(STATS && NT * MI
       for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr, af[mi], acc[mi][ni], 0, 0, 0);
     }
     __syncthreads();
-    if (it % nk == nk - 1) {
+    if (KG > 1 && it % nkg == nkg - 1) {
+      // the groups' partial sums, in a fixed order: (2, 3) -> (0, 1), then 1 -> 0; element e of thread t sits at ex[e * 256 + t]
+      float* ex = reinterpret_cast<float*>(oper);
+#pragma unroll
+      for (int half = KG / 2; half >= 1; half >>= 1) {
+        if (grp >= half && grp < 2 * half) {
+          float* dst = ex + (grp - half) * SLOT + t;
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) dst[((mi * NT + ni) * 4 + j) * 256] = acc[mi][ni][j];
+        }
+        __syncthreads();
+        if (grp < half) {
+          const float* src = ex + grp * SLOT + t;
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[mi][ni][j] += src[((mi * NT + ni) * 4 + j) * 256];
+        }
+        __syncthreads();
+      }
+      if (grp != 0) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    if (it % nkg == nkg - 1 && grp == 0) {
       // epilogue of this M tile: lane (r, kg) holds channels n = n0 + 16 ni + 4 kg + j of pixel m = m0 + 16 MI w + 16 mi + r
-      const int mt = blockIdx.x + (it / nk) * gridDim.x;
+      const int mt = blockIdx.x + (it / nkg) * gridDim.x;
       const int m0 = mt * BM;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
@@ -273,13 +322,13 @@ __global__ __launch_bounds__(256, BNB ? 2 : ((NT * MI <= 8 && !(STATS && NT * MI
         float s1 = st_s[ni][j], s2 = st_q[ni][j];
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-        if (r == 0) {
+        if (r == 0 && grp == 0) {
           red[(0 * 4 + w) * BN + ni * 16 + kg * 4 + j] = s1;
           red[(1 * 4 + w) * BN + ni * 16 + kg * 4 + j] = s2;
         }
       }
     __syncthreads();
-    if (p.partials) {
+    if (p.partials && grp == 0) {
       for (int i = t; i < 2 * BN; i += 256) {
         const int which = i / BN, nn = i - which * BN;
         if (n0 + nn < p.N)
@@ -774,12 +823,27 @@ int gemm_b(const char* fn, GemmB p, bool a_f32, bool y_f32, int* rows_out, hipSt
     DL3P_CHECK_LAUNCH(fn);
     return DL3P_OK;
   }
-  const int nt = pick_nt_b(p.N, stats);
-  const int gy = ceil_div(p.N, 16 * nt);
+  int nt = pick_nt_b(p.N, stats);
+  int gy = ceil_div(p.N, 16 * nt);
   // 64-row tiles whenever 128-row tiles would leave the chip under two workgroups per CU (the 64 x 128 maps: M = 8192)
   int mi = (nt == 16 || (long long)ceil_div(p.M, 128) * gy < 2LL * DL3P_NUM_CUS) ? 1 : 2;
   static const int force_mi = getenv("DL3P_BF16_MI") ? atoi(getenv("DL3P_BF16_MI")) : 0;     // A/B knob
   if (force_mi && nt != 16) mi = force_mi;
+  // few row tiles and a long reduction: K groups inside the workgroup (pwb_gemm, KG > 1)
+  static const int env_kg = getenv("DL3P_BF16_KG") ? atoi(getenv("DL3P_BF16_KG")) : 0;       // 0: the rule; 1: never; 2 / 4: wherever possible
+  const int force_kg = dl3p_bf16_force_kg >= 0 ? dl3p_bf16_force_kg : env_kg;                 // dl3p_set_option("bf16_kg", ...) first
+  static const int force_kg_nt = getenv("DL3P_BF16_KG_NT") ? atoi(getenv("DL3P_BF16_KG_NT")) : 0;
+  int kgroups = 1;
+  if (force_kg != 1 && !a_f32 && !y_f32 && p.N >= 32) {       // (with or without the backward sums: the two data gradients stay bit-identical)
+    const int nk = ceil_div(p.K, BK);
+    int knt = nt > 8 ? 8 : nt;
+    if (force_kg_nt) knt = force_kg_nt;
+    const long long wgs = (long long)ceil_div(p.M, 64) * ceil_div(p.N, 16 * knt);
+    if (force_kg > 1) kgroups = force_kg;
+    else if (wgs <= 2LL * DL3P_NUM_CUS && nk >= 8) kgroups = 2;
+    if (kgroups == 4 && knt > 4) knt = 4;       // sixteen waves: 128 VGPRs each
+    if (kgroups > 1) { nt = knt; gy = ceil_div(p.N, 16 * nt); mi = 1; }
+  }
   p.num_m_tiles = ceil_div(p.M, 64 * mi);
   int gx_max = (DL3P_NUM_CUS * 4) / gy;
   if (gx_max < 8) gx_max = 8;
@@ -796,6 +860,19 @@ int gemm_b(const char* fn, GemmB p, bool a_f32, bool y_f32, int* rows_out, hipSt
     else if (stats) launch_gemm_b<MIV, false, false, true>(p, nt, grid, st);        \
     else launch_gemm_b<MIV, false, false, false>(p, nt, grid, st);                  \
   } while (0)
+  if (kgroups > 1) {
+#define DL3P_GK(NTV, KGV)                                                                                                          \
+    do {                                                                                                                           \
+      if (stats && p.bb_z) hipLaunchKernelGGL((pwb_gemm<NTV, 1, false, false, true, true, KGV>), grid, dim3(256 * KGV), 0, st, p); \
+      else if (stats) hipLaunchKernelGGL((pwb_gemm<NTV, 1, false, false, true, false, KGV>), grid, dim3(256 * KGV), 0, st, p);     \
+      else hipLaunchKernelGGL((pwb_gemm<NTV, 1, false, false, false, false, KGV>), grid, dim3(256 * KGV), 0, st, p);              \
+    } while (0)
+    if (kgroups == 4) { if (nt == 2) DL3P_GK(2, 4); else DL3P_GK(4, 4); }
+    else { if (nt == 2) DL3P_GK(2, 2); else if (nt == 4) DL3P_GK(4, 2); else DL3P_GK(8, 2); }
+#undef DL3P_GK
+    DL3P_CHECK_LAUNCH(fn);
+    return DL3P_OK;
+  }
   if (mi == 1) DL3P_GB(1); else DL3P_GB(2);
 #undef DL3P_GB
   DL3P_CHECK_LAUNCH(fn);

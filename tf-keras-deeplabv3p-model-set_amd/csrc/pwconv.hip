@@ -620,6 +620,7 @@ static int g_sbw_force_tile = -1, g_sbw_force_pc = 0;      // "split_wgrad_tile"
 static int g_sb_pipe = -1;      // dl3p_set_option("sb_pipe", 0 | 1): the producer / consumer form of the split kernel (default DL3P_SB_PIPE or 0)
 static int g_sb_force_wm = 0, g_sb_force_nt = 0;      // dl3p_set_option("sb_wm" / "sb_nt"): pin the split kernel's wide-tile family (gemm_plan_sb)
 static int g_sb_rs = -1;      // dl3p_set_option("sb_rs", 0 | 1 | -1): the row-stationary split kernel (pw_split_rs.hip) never / wherever it serves the shape / by rule (DL3P_SB_RS)
+extern int dl3p_bf16_force_kg;      // pw_bf16.hip
 static int g_conv_sb = -1;    // dl3p_set_option("conv_sb", 0 | 1 | 2 | -1): dense convs on the split kernels never / by rule / wherever supported / default (DL3P_CONV_SB, else 1)
 static int g_wgrad_force_tile = -1, g_wgrad_force_per_cu = 0;                    // see wgrad_pick_tile / wgrad_split
 static int g_pw_small_min_rows = -1;
@@ -644,6 +645,7 @@ extern "C" int dl3p_set_option(const char* name, int value) {
   if (!strcmp(name, "split_wgrad_per_cu")) { g_sbw_force_pc = value > 0 ? value : 0; return DL3P_OK; }
   if (!strcmp(name, "sb_wm")) { g_sb_force_wm = (value >= -1 && value <= 2) ? value : 0; return DL3P_OK; }    // -1: never wide
   if (!strcmp(name, "sb_rs")) { g_sb_rs = value < 0 ? -1 : (value ? 1 : 0); return DL3P_OK; }
+  if (!strcmp(name, "bf16_kg")) { dl3p_bf16_force_kg = (value == 0 || value == 1 || value == 2 || value == 4) ? value : -1; return DL3P_OK; }
   if (!strcmp(name, "conv_sb")) { g_conv_sb = (value >= 0 && value <= 2) ? value : -1; return DL3P_OK; }
   if (!strcmp(name, "sb_nt")) { g_sb_force_nt = (value == 8 || value == 12 || value == 16) ? value : 0; return DL3P_OK; }
   if (!strcmp(name, "dw_per_cu")) { dl3p_dw_force_per_cu = value > 0 ? value : 0; return DL3P_OK; }

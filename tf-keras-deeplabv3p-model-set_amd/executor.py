@@ -244,13 +244,42 @@ class Plan:
         self.ctx = ''
         self.segments = None
         self.tags = {}
+        self.use_side, self._side = False, None
 
     def k(self, fn, *args, tag=None):
+        if self.use_side:
+            # between fork() and join(): the launch goes onto the side stream (a parallel branch of the captured graph)
+            s = self._side
+
+            def launch():
+                fn(*args, s.cuda_stream)
+            launch()
+            self.items.append((None, launch))
+            self.labels.append((getattr(fn, '__name__', str(fn)), self.ctx))
+            return
         fn(*args, torch.cuda.current_stream().cuda_stream)
         if tag is not None:
             self.tags[tag] = len(self.items)
         self.items.append((fn, args))
         self.labels.append((getattr(fn, '__name__', str(fn)), self.ctx))
+
+    # two launches that do not depend on each other (a conv's weight gradient beside its data gradient): fork() makes the side
+    # stream wait for everything issued so far, launches issued while `use_side` is set go onto it, join() makes the main
+    # stream wait for them.  Captured, that is a parallel branch of the hipGraph; eagerly, two streams.
+    def fork(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        side = self._side
+        self.py(lambda: side.wait_stream(torch.cuda.current_stream()))
+        self.use_side = True
+
+    def side_done(self):
+        self.use_side = False
+
+    def join(self):
+        side = self._side
+        self.use_side = False
+        self.py(lambda: torch.cuda.current_stream().wait_stream(side))
 
     def probe(self, tag, probe):
         """keep one launch outside the graph segments and issue it with the library's HIP event pair
@@ -881,6 +910,7 @@ class Executor:
         # issued while the NEXT BatchNorm's statistics all-reduce is on the wire (hides the collective's latency)
         self._deferred = []
         defer = self.sync_bn
+        self._deferred_mode = bool(defer)
         fuse = self._bn_fusion_map()
         if self.bf16:
             # bf16: the pointwise GEMMs can carry the sums (dl3p_pwconv_bwd_data_bn_bf16, more than 64 rows), the depthwise
@@ -1232,6 +1262,13 @@ class Executor:
         dz, lddz, dzf = self.tptr(out, True), out.ld, self._is_f32(out)
         need_gx = xt.requires_grad or xt.root.requires_grad
         M = N * op.Ho * op.Wo
+        # the weight gradient (slabs in its own region of the slab buffer) beside the data gradient: neither reads what the
+        # other writes.  At one image per device most launches of this path leave CUs idle; two at a time fill them
+        forked = False
+        if (op.layer.trainable and need_gx and wgrad_slabs is not None and self._slab_bytes(op) and not self._deferred_mode
+                and os.environ.get('DL3P_WGRAD_SIDE', '0') == '1'):
+            P.fork()
+            forked = True
         if op.layer.trainable:
             gw = st.ptr(op.w, G)
             gb = st.ptr(op.b, G) if getattr(op, 'b', None) else None
@@ -1253,10 +1290,20 @@ class Executor:
             else:
                 wgrad(L.pwconv_bwd_weight_bf16, self.tptr(op.col), op.col.ld, None, None, ACT_NONE, dz, lddz, dzf, gw, gb,
                       ws, wsb, M, op.kp, op.cout)
+        P.side_done()
         if not need_gx:
             return
         gp, ldg, keyt = self._gbuf(op.x)
         acc = self._acc(keyt)
+        if forked:
+            self._conv_dgrad_bf16(P, op, fused_bn, dz, lddz, dzf, gp, ldg, acc, M, join=True)
+            return
+        self._conv_dgrad_bf16(P, op, fused_bn, dz, lddz, dzf, gp, ldg, acc, M)
+
+    def _conv_dgrad_bf16(self, P, op, fused_bn, dz, lddz, dzf, gp, ldg, acc, M, join=False):
+        L, N, st, k = self.L, self.N, self.store, op.kind
+        xt = op.x.tensor
+        done = P.join if join else (lambda: None)          # right behind the data-gradient launch
         if k == 'conv_pw' and fused_bn is not None and not dzf:
             # the BatchNorm-backward sums of the BatchNorm behind this gradient ride on the data gradient (dl3p_pwconv_bwd_data_bn)
             bn = fused_bn.bn
@@ -1266,6 +1313,7 @@ class Executor:
                 self.tptr(fused_bn.z), fused_bn.z.ld, self.gscale[bn.group.id].data_ptr() + 4 * bn.offset,
                 self.gshift[bn.group.id].data_ptr() + 4 * bn.offset, bn.act, aux['mean'].data_ptr(),
                 aux['invstd'].data_ptr(), self.partials.data_ptr(), ctypes.byref(rows))
+            done()
             ctx = P.ctx
             P.ctx = _op_label(fused_bn)
             self._bn_backward(P, fused_bn, fused_rows=rows.value)
@@ -1274,14 +1322,17 @@ class Executor:
             if fused_bn is not None:          # (an fp32 gradient operand: the kernel with the sums takes bf16 only)
                 ctx = P.ctx
                 P.k(L.pwconv_bwd_data_bf16, dz, lddz, dzf, st.ptr(op.w, st.Pb), gp, ldg, acc, M, op.cin, op.cout)
+                done()
                 P.ctx = _op_label(fused_bn)
                 self._bn_backward(P, fused_bn)
                 P.ctx = ctx
                 return
             P.k(L.pwconv_bwd_data_bf16, dz, lddz, dzf, st.ptr(op.w, st.Pb), gp, ldg, acc, M, op.cin, op.cout)
+            done()
         elif k == 'conv_dw':
             P.k(L.dwconv2d_bwd_data_bf16, dz, lddz, st.ptr(op.w, st.Pb), gp, ldg, acc, N, xt.H, xt.W, op.c, op.k, op.stride,
                 op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
+            done()
         else:
             # dense k x k conv (Xception's entry_flow_conv1_2, ResNet50's 3x3 convs): d/d(im2col matrix) by the GEMM, then the
             # transposed gather back onto the input pixels -- the route of the forward (im2col_bf16 + GEMM), mirrored
@@ -1289,6 +1340,7 @@ class Executor:
                 op.cout)
             P.k(L.col2im_bf16, self.tptr(op.col, True), op.col.ld, gp, ldg, acc, N, xt.H, xt.W, op.cin, op.k, op.stride, op.rate,
                 op.pad_t, op.pad_l, op.Ho, op.Wo)
+            done()
 
     def _use_sb(self, op, fwd, stats):
         """does this pointwise conv run on the split-bf16 GEMM (forward / data-gradient role)?  Only where the tiled kernel
