@@ -83,6 +83,27 @@ __device__ __forceinline__ float raw_get(const Raw8<true>& r, int e) {
   return e == 0 ? r.a.x : e == 1 ? r.a.y : e == 2 ? r.a.z : e == 3 ? r.a.w : e == 4 ? r.b.x : e == 5 ? r.b.y : e == 6 ? r.b.z : r.b.w;
 }
 
+// Workgroup barrier that waits for this wave's LDS traffic only (sb_common.h lds_barrier): __syncthreads() is `s_waitcnt vmcnt(0)
+// lgkmcnt(0); s_barrier`, and the vmcnt(0) drains the operand loads just issued for the K-steps ahead -- every K-step of pwb_gemm
+// then contained a full memory round trip (~1 us at one wave per SIMD), whatever the prefetch depth.  The tiles handed over at the
+// barrier live in LDS; the loads land in registers nobody else reads and the compiler keeps its own vmcnt bookkeeping for them.
+__device__ __forceinline__ void lds_barrier_b() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// sum over the 16 lanes of a DPP row (lanes with equal l >> 4), left in all of them: the butterfly of __shfl_xor(v, 1 / 2 / 4 / 8)
+// -- same tree, same bits -- as four DPP adds on the VALU instead of four ds_bpermute round trips through the LDS crossbar (the
+// statistics epilogue of a 128-column tile reduced 64 values this way: 256 bpermutes per wave)
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_move<0xB1>(v);       // quad_perm [1, 0, 3, 2]
+  v += dpp_move<0x4E>(v);       // quad_perm [2, 3, 0, 1]
+  v += dpp_move<0x141>(v);      // row_half_mirror: the other quad of the 8-lane half
+  v += dpp_move<0x140>(v);      // row_mirror: the other half of the row
+  return v;
+}
+
 constexpr int KMAX_LDS = 2048;      // per-channel prologue coefficients of up to this many input channels sit in LDS
 
 // NT: 16-column tiles per workgroup; MI: 16-row tiles per wave (BM = 64 MI rows per workgroup); A_F32 / Y_F32: the logits
@@ -232,7 +253,7 @@ __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : (BNB ? 2 : ((NT * MI <= 8 &&
 
   auto step = [&](auto slot_c, int it) {
     stage(slot_c, it);
-    __syncthreads();
+    lds_barrier_b();
     if (it + PD < it_total) prefetch(slot_c, it + PD);      // the slot just staged is free again
     bf16x8 af[MI];
 #pragma unroll
@@ -243,7 +264,7 @@ __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : (BNB ? 2 : ((NT * MI <= 8 &&
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr, af[mi], acc[mi][ni], 0, 0, 0);
     }
-    __syncthreads();
+    lds_barrier_b();
     if (KG > 1 && it % nkg == nkg - 1) {
       // the groups' partial sums, in a fixed order: (2, 3) -> (0, 1), then 1 -> 0; element e of thread t sits at ex[e * 256 + t]
       float* ex = reinterpret_cast<float*>(oper);
@@ -320,8 +341,7 @@ __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : (BNB ? 2 : ((NT * MI <= 8 &&
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float s1 = st_s[ni][j], s2 = st_q[ni][j];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        s1 = row16_sum(s1); s2 = row16_sum(s2);
         if (r == 0 && grp == 0) {
           red[(0 * 4 + w) * BN + ni * 16 + kg * 4 + j] = s1;
           red[(1 * 4 + w) * BN + ni * 16 + kg * 4 + j] = s2;
@@ -502,8 +522,7 @@ __global__ __launch_bounds__(512, 1) void pwb_stream(GemmB p, int kp, int tiles)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float s1 = st_s[ni][j], s2 = st_q[ni][j];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        s1 = row16_sum(s1); s2 = row16_sum(s2);
         if (r == 0) {
           red[(0 * NWAVE + w) * BN + ni * 16 + kg * 4 + j] = s1;
           red[(1 * NWAVE + w) * BN + ni * 16 + kg * 4 + j] = s2;
