@@ -6,6 +6,9 @@ import torch
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..')
 sys.path.insert(0, ROOT)
 PKG = 'tf-keras-deeplabv3p-model-set_amd'
+if os.environ.get('DL3P_LIB_VARIANT'):          # A/B against a library built by build_variant.sh
+    libm = importlib.import_module(PKG + '._lib')
+    libm._lib = libm.Lib(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libdl3p_%s.so' % os.environ['DL3P_LIB_VARIANT']))
 ops = importlib.import_module(PKG + '.ops')
 L = importlib.import_module(PKG + '._lib').lib()
 dev = 'cuda'

@@ -310,14 +310,7 @@ __global__ __launch_bounds__(256 * WM, (WM == 1 && NT <= 8) ? 2 : 1) void pw_gem
         for (int mi = 0; mi < MI; ++mi) {
           // smallest terms first; MFMA "A" = weights (row = output channel), "B" = activations (column = pixel): a lane ends with
           // 4 consecutive output channels of one pixel
-          f32x4 c = acc[mi][ni];
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[2], xa[mi][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[0], xa[mi][2], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[1], xa[mi][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[1], xa[mi][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[0], xa[mi][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[0], xa[mi][0], c, 0, 0, 0);
-          acc[mi][ni] = c;
+          acc[mi][ni] = split_mac(acc[mi][ni], wb[0], wb[1], wb[2], xa[mi][0], xa[mi][1], xa[mi][2]);
         }
       }
     }
@@ -664,14 +657,7 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_sbp_kernel(GemmParams p) {
         for (int pl = 0; pl < 3; ++pl) wb[pl] = *reinterpret_cast<const s16x8*>(Bs + pl * B_PLANE + (ni * 16 + l15) * PB + q * 8);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-          f32x4 c = acc[mi][ni];
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[2], xa[mi][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[0], xa[mi][2], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[1], xa[mi][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[1], xa[mi][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[0], xa[mi][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[0], xa[mi][0], c, 0, 0, 0);
-          acc[mi][ni] = c;
+          acc[mi][ni] = split_mac(acc[mi][ni], wb[0], wb[1], wb[2], xa[mi][0], xa[mi][1], xa[mi][2]);
         }
       }
     }
@@ -1074,14 +1060,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_sb_kernel(WgradSB p) {
       }
 #pragma unroll
       for (int kf = 0; kf < KFW; ++kf) {
-        f32x4 c = acc[kf][ni];      // smallest terms first
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kf][2], bf[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kf][0], bf[2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kf][1], bf[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kf][1], bf[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kf][0], bf[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kf][0], bf[0], c, 0, 0, 0);
-        acc[kf][ni] = c;
+        acc[kf][ni] = split_mac(acc[kf][ni], af[kf][0], af[kf][1], af[kf][2], bf[0], bf[1], bf[2]);
       }
     }
     lds_barrier();

@@ -341,13 +341,7 @@ __global__ __launch_bounds__(512, 1) void pw_gemm_sbr_kernel(GemmParams p) {
       // consecutive output channels of one pixel
       f32x4 c = acc[ni];
       if (abl == 2) { c[0] += __builtin_bit_cast(float, (int)wb[S2][0][0] + (int)wb[S2][1][1] + (int)wb[S2][2][2]); acc[ni] = c; __builtin_amdgcn_sched_barrier(0); return; }
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[S2][2], afr[KT][0], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[S2][0], afr[KT][2], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[S2][1], afr[KT][1], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[S2][1], afr[KT][0], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[S2][0], afr[KT][1], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[S2][0], afr[KT][0], c, 0, 0, 0);
-      acc[ni] = c;
+      acc[ni] = split_mac(c, wb[S2][0], wb[S2][1], wb[S2][2], afr[KT][0], afr[KT][1], afr[KT][2]);
       // inside the step: the next step's fragment reads FIRST (left alone they sink behind the fourth MFMA and the step after
       // waits a whole LDS round trip for them), then this step's piece of the B stream, then the six MFMAs
       if constexpr (WBD == 1 || ST + 1 < NK * NI) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);

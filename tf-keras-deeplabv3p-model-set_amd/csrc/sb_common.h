@@ -49,3 +49,37 @@ __device__ __forceinline__ void split2(float x, float y, uint32_t& h, uint32_t& 
   l = __builtin_bit_cast(uint32_t, lv);
 }
 
+
+// One K-step of one 16 x 16 output tile: the six products of the 3-way splits (a = wb, b = xa; plane 0 the leading piece).
+// v_mfma_f32_16x16x32_bf16 cuts addends that sit far below its largest one off when it aligns them (no sticky bit, toward
+// -infinity: scripts/micro/mfma_round.hip), so the five small groups -- 2^-8 and 2^-16 of the leading one -- must not be added
+// into the running sum directly: there they lose their low bits one-sidedly, which showed as a column-mean bias ten times the fp32
+// kernel's (scripts/micro/sb_bias.py).  The TWO-LEVEL form sums them among themselves first (smallest first, from zero: aligned
+// to each other) and lets them join the running sum with ONE correctly rounded fp32 add per K-step: the column means then sit
+// where the fp32 kernel's do (3.6e-9 sigma against 3.4e-9; one level: 3.2e-8) and the rms error per element is HALF the fp32
+// kernel's (1.0e-7 against 2.2e-7 on 66564 x 304 -> 256).  It costs 8-14 % of the tiled kernels' time and 28 % of the wide
+// ones' (four VALU adds and a dependent chain from zero per tile and K-step; the 256-column tiles have no registers for the
+// temporaries), i.e. ~0.4 ms of the 12.7 ms headline step, for an error that is inside every parity bound either way: built with
+// -DDL3P_SB_TWO_LEVEL=1 (scripts/micro/build_variant.sh), not the default.
+#ifndef DL3P_SB_TWO_LEVEL
+#define DL3P_SB_TWO_LEVEL 0
+#endif
+__device__ __forceinline__ f32x4 split_mac(f32x4 c, const s16x8& a0, const s16x8& a1, const s16x8& a2, const s16x8& b0, const s16x8& b1,
+                                           const s16x8& b2) {
+#if DL3P_SB_TWO_LEVEL
+  f32x4 t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b0, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+  t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b2, t, 0, 0, 0);
+  t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, t, 0, 0, 0);
+  t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, t, 0, 0, 0);
+  t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, t, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, c, 0, 0, 0);
+  return c + t;
+#else
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b0, c, 0, 0, 0);      // smallest terms first
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b2, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, c, 0, 0, 0);
+#endif
+}
