@@ -19,7 +19,7 @@ from indep_torch_graphs import DeepLabV3Plus, keras_sparse_ce  # noqa: E402
 from test_product_vs_transformers_gpu import _weights  # noqa: E402
 
 
-@pytest.mark.parametrize('mt,size,OS,classes', [('xception', 65, 16, 21), ('xception', 97, 8, 19), ('xception', 64, 16, 21),
+@pytest.mark.parametrize('mt,size,OS,classes', [('xception', 65, 16, 21), ('xception', 64, 8, 19),
                                                 ('mobilenetv3large', 65, 16, 21), ('mobilenetv3large', 128, 8, 19),
                                                 ('mobilenetv3small', 97, 16, 21)])
 def test_predict_equals_the_independent_graph(mt, size, OS, classes):
@@ -41,7 +41,7 @@ def test_predict_equals_the_independent_graph(mt, size, OS, classes):
 @pytest.mark.parametrize('mt,size,OS', [('xception', 65, 16), ('mobilenetv3large', 97, 16), ('mobilenetv3large', 65, 8)])
 def test_train_step_loss_and_gradients_equal_the_independent_graph(mt, size, OS):
     pkg = load_pkg()
-    classes, N = 21, 4
+    classes, N = 21, 4          # (at batch 3 Xception's worst tensor -- a beta on 5 x 5 maps, 75 samples a channel -- sits at 0.25)
     m, w = _weights(pkg, mt, classes, size, OS, training=True)
     m.compile(optimizer=pkg.SGD(0.01), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
     m.use_graphs = False
