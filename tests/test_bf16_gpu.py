@@ -258,6 +258,18 @@ def test_elementwise_bf16(ops):
 
 
 
+@pytest.mark.parametrize('case', [(2, 17, 19, 256, 65, 73), (1, 9, 11, 20, 33, 41), (1, 16, 32, 256, 64, 128), (3, 5, 7, 24, 5, 7), (1, 1, 1, 64, 9, 5)])
+def test_resize_bf16_channel_vectors(ops, case):
+    """dl3p_resize_bilinear_{fwd,bwd}_bf16 with 8 channels per thread (16-byte accesses: channel counts that are multiples of 8) and
+    with 4 (the rest); up-sampling by non-integer factors, the identity size, a 1 x 1 source"""
+    N, h, w, C, H, W = case
+    rng = np.random.default_rng(h * w + C)
+    z = Q(rng.standard_normal((N, h, w, C)))
+    close_bf16(ops.resize_bilinear_fwd_bf16(TB(z), H, W), Q(O.resize_bilinear_fwd(z, H, W)), 'resize')
+    g = Q(rng.standard_normal((N, H, W, C)))
+    close_bf16(ops.resize_bilinear_bwd_bf16(TB(g), h, w), Q(O.resize_bilinear_bwd(g, h, w)), 'resize backward', slack=2.0 + (H // h) * (W // w) / 8.0)
+
+
 @pytest.mark.parametrize('case', [(2, 33, 33, 32, 3, 1, 1), (2, 17, 23, 64, 3, 2, 1), (1, 20, 20, 8, 1, 2, 1), (2, 19, 19, 16, 3, 1, 2),
                                   (1, 12, 30, 4, 7, 2, 1)])
 def test_col2im_bf16(ops, case):

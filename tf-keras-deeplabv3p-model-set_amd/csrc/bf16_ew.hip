@@ -486,27 +486,34 @@ struct ResizeB {
   int N, h, w, C, H, W, cs, px, nslab, nbx;
   long long total;
   int accumulate;
+  int v;               // channels per thread (8: 16-byte accesses; 4)
 };
 
+// V channels per thread: 8 (16-byte accesses) wherever the channel count and the row pitches allow, else 4.  32-bit index arithmetic
+// (hosts check the pixel counts).
+template <int V>
 __global__ __launch_bounds__(256) void resize_fwd_b(ResizeB p) {
   const int slab = blockIdx.x / p.nbx, bx = blockIdx.x - slab * p.nbx;
   const int pl = threadIdx.x / p.cs, cl = threadIdx.x - pl * p.cs;
   if (pl >= p.px) return;
-  const int c = (slab * p.cs + cl) * 4;
+  const int c = (slab * p.cs + cl) * V;
   const float sy = (float)p.h / (float)p.H, sx = (float)p.w / (float)p.W;
-  for (long long s = (long long)bx * p.px + pl; s < p.total; s += (long long)p.nbx * p.px) {
-    const int ox = (int)(s % p.W);
-    const long long row = s / p.W;
-    const int oy = (int)(row % p.H), n = (int)(row / p.H);
+  const int total = (int)p.total, step = p.nbx * p.px;
+  for (int s = bx * p.px + pl; s < total; s += step) {
+    const int row = s / p.W, ox = s - row * p.W;
+    const int n = row / p.H, oy = row - n * p.H;
     const LerpB ly = lerp_b(oy, sy, p.h), lx = lerp_b(ox, sx, p.w);
     const bf16* img = p.x + (size_t)n * p.h * p.w * p.ldx + c;
-    const float4 tl = ld4(img + ((size_t)ly.lo * p.w + lx.lo) * p.ldx), tr = ld4(img + ((size_t)ly.lo * p.w + lx.hi) * p.ldx);
-    const float4 bl = ld4(img + ((size_t)ly.hi * p.w + lx.lo) * p.ldx), br = ld4(img + ((size_t)ly.hi * p.w + lx.hi) * p.ldx);
-    float4 o;
-#define LERP2(f) { float top = tl.f + (tr.f - tl.f) * lx.t; float bot = bl.f + (br.f - bl.f) * lx.t; o.f = top + (bot - top) * ly.t; }
-    LERP2(x) LERP2(y) LERP2(z) LERP2(w)
-#undef LERP2
-    st4(p.y + (size_t)s * p.ldy + c, o);
+    const fvec<V> tl = ldv<V>(img + ((size_t)ly.lo * p.w + lx.lo) * p.ldx), tr = ldv<V>(img + ((size_t)ly.lo * p.w + lx.hi) * p.ldx);
+    const fvec<V> bl = ldv<V>(img + ((size_t)ly.hi * p.w + lx.lo) * p.ldx), br = ldv<V>(img + ((size_t)ly.hi * p.w + lx.hi) * p.ldx);
+    fvec<V> o;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const float top = tl.v[i] + (tr.v[i] - tl.v[i]) * lx.t;
+      const float bot = bl.v[i] + (br.v[i] - bl.v[i]) * lx.t;
+      o.v[i] = top + (bot - top) * ly.t;
+    }
+    stv<V>(p.y + (size_t)s * p.ldy + c, o);
   }
 }
 
@@ -518,17 +525,18 @@ __device__ __forceinline__ void touch_b(int i, float inv_scale, int out_size, in
 }
 
 // gather form of the transpose (deterministic): each input pixel sums the output pixels that read it
+template <int V>
 __global__ __launch_bounds__(256) void resize_bwd_b(ResizeB p) {
   const int slab = blockIdx.x / p.nbx, bx = blockIdx.x - slab * p.nbx;
   const int pl = threadIdx.x / p.cs, cl = threadIdx.x - pl * p.cs;
   if (pl >= p.px) return;
-  const int c = (slab * p.cs + cl) * 4;
+  const int c = (slab * p.cs + cl) * V;
   const float sy = (float)p.h / (float)p.H, sx = (float)p.w / (float)p.W;
   const float isy = (float)p.H / (float)p.h, isx = (float)p.W / (float)p.w;
-  for (long long s = (long long)bx * p.px + pl; s < p.total; s += (long long)p.nbx * p.px) {
-    const int ix = (int)(s % p.w);
-    const long long row = s / p.w;
-    const int iy = (int)(row % p.h), n = (int)(row / p.h);
+  const int total = (int)p.total, step = p.nbx * p.px;
+  for (int s = bx * p.px + pl; s < total; s += step) {
+    const int row = s / p.w, ix = s - row * p.w;
+    const int n = row / p.h, iy = row - n * p.h;
     int y0, y1, x0, x1;
     touch_b(iy, isy, p.H, y0, y1);
     touch_b(ix, isx, p.W, x0, x1);
@@ -536,7 +544,7 @@ __global__ __launch_bounds__(256) void resize_bwd_b(ResizeB p) {
     if (iy == p.h - 1) y1 = p.H - 1;
     if (ix == 0) x0 = 0;
     if (ix == p.w - 1) x1 = p.W - 1;
-    float4 acc = zero4();
+    fvec<V> acc = fzero<V>();
     const bf16* gimg = p.x + (size_t)n * p.H * p.W * p.ldx + c;
     for (int oy = y0; oy <= y1; ++oy) {
       const LerpB ly = lerp_b(oy, sy, p.h);
@@ -547,14 +555,18 @@ __global__ __launch_bounds__(256) void resize_bwd_b(ResizeB p) {
         const float wx = (lx.lo == ix ? 1.f - lx.t : 0.f) + (lx.hi == ix ? lx.t : 0.f);
         if (wx == 0.f) continue;
         const float wgt = wy * wx;
-        const float4 g = ld4(gimg + ((size_t)oy * p.W + ox) * p.ldx);
-        acc.x = fmaf(g.x, wgt, acc.x); acc.y = fmaf(g.y, wgt, acc.y);
-        acc.z = fmaf(g.z, wgt, acc.z); acc.w = fmaf(g.w, wgt, acc.w);
+        const fvec<V> g = ldv<V>(gimg + ((size_t)oy * p.W + ox) * p.ldx);
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc.v[i] = fmaf(g.v[i], wgt, acc.v[i]);
       }
     }
     bf16* o = p.y + (size_t)s * p.ldy + c;
-    if (p.accumulate) acc = add4(acc, ld4(o));
-    st4(o, acc);
+    if (p.accumulate) {
+      const fvec<V> old = ldv<V>(o);
+#pragma unroll
+      for (int i = 0; i < V; ++i) acc.v[i] += old.v[i];
+    }
+    stv<V>(o, acc);
   }
 }
 
@@ -565,7 +577,9 @@ int resize_setup_b(const char* fn, ResizeB& p, const void* x, int ldx, void* y, 
   rc = check_b(fn, y, ldy, C);
   if (rc) return rc;
   p.x = (const bf16*)x; p.ldx = ldx; p.y = (bf16*)y; p.ldy = ldy; p.N = N; p.h = h; p.w = w; p.C = C; p.H = H; p.W = W;
-  const LaneSplit s = lane_split(C, 4);
+  DL3P_CHECK_ARG(total < (1ll << 31), "%s: tensor too large", fn);
+  p.v = (C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) ? 8 : 4;
+  const LaneSplit s = lane_split(C, p.v);
   p.cs = s.cs; p.px = s.px; p.nslab = s.nslab;
   p.total = total;
   long long nbx = ceil_div_ll(total, p.px);
@@ -581,7 +595,8 @@ extern "C" int dl3p_resize_bilinear_fwd_bf16(const void* x, int ldx, void* y, in
   ResizeB p = {};
   int rc = resize_setup_b("dl3p_resize_bilinear_fwd_bf16", p, x, ldx, y, ldy, N, h, w, C, H, W, (long long)N * H * W);
   if (rc) return rc;
-  hipLaunchKernelGGL(resize_fwd_b, dim3(p.nbx * p.nslab), dim3(256), 0, (hipStream_t)stream, p);
+  if (p.v == 8) hipLaunchKernelGGL(resize_fwd_b<8>, dim3(p.nbx * p.nslab), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(resize_fwd_b<4>, dim3(p.nbx * p.nslab), dim3(256), 0, (hipStream_t)stream, p);
   DL3P_CHECK_LAUNCH("dl3p_resize_bilinear_fwd_bf16");
   return DL3P_OK;
 }
@@ -592,7 +607,8 @@ extern "C" int dl3p_resize_bilinear_bwd_bf16(const void* gy, int ldgy, void* gx,
   int rc = resize_setup_b("dl3p_resize_bilinear_bwd_bf16", p, gy, ldgy, gx, ldgx, N, h, w, C, H, W, (long long)N * h * w);
   if (rc) return rc;
   p.accumulate = accumulate;
-  hipLaunchKernelGGL(resize_bwd_b, dim3(p.nbx * p.nslab), dim3(256), 0, (hipStream_t)stream, p);
+  if (p.v == 8) hipLaunchKernelGGL(resize_bwd_b<8>, dim3(p.nbx * p.nslab), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(resize_bwd_b<4>, dim3(p.nbx * p.nslab), dim3(256), 0, (hipStream_t)stream, p);
   DL3P_CHECK_LAUNCH("dl3p_resize_bilinear_bwd_bf16");
   return DL3P_OK;
 }
