@@ -7,8 +7,8 @@ cd "$ROOT"
 S=${1:-"266256 304 256"}
 O=gpurun_out/gemm_pmc
 rm -rf $O; mkdir -p $O
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/a -- python3 scripts/micro/gemm_shape.py $S > $O/a.log 2>&1
-rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $O/b -- python3 scripts/micro/gemm_shape.py $S > $O/b.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/a -- python3 ${GEMM_PMC_SCRIPT:-scripts/micro/gemm_shape.py} $S > $O/a.log 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $O/b -- python3 ${GEMM_PMC_SCRIPT:-scripts/micro/gemm_shape.py} $S > $O/b.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 for tag in ('a', 'b'):
