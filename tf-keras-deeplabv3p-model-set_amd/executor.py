@@ -68,43 +68,36 @@ class ParamStore:
         # (they take the place of Pt); both refreshed after every optimiser step
         self.Pb = torch.zeros(off, dtype=torch.bfloat16, device=device) if self.bf16 else None
         self.Pbt = torch.zeros(off, dtype=torch.bfloat16, device=device) if self.bf16 else None
-        # fp32-accurate GEMMs on the bf16 matrix pipe (csrc/pw_split.hip; split_gemm_enabled()): every pointwise kernel
-        # pre-split into three bf16 planes, once as [3][N][Kpad] (from the transposed copy: the forward's B operand) and once as
-        # [3][K][Npad] (from the kernel as stored: the data gradient's); refreshed after every optimiser step like Pt
+        # fp32-accurate GEMMs on the bf16 matrix pipe (csrc/pw_split.hip; split_gemm_enabled()): a pointwise kernel pre-split into
+        # three bf16 planes, [3][N][Kpad] (from the transposed copy: the forward's B operand) and [3][K][Npad] (from the kernel as
+        # stored: the data gradient's), refreshed after every optimiser step like Pt.  Planes are allocated when the first GEMM
+        # that reads them is traced (sb_ptr) -- 12 B per parameter for a layer that takes the split kernel, nothing for the many
+        # that never do (few rows, short reductions, narrow outputs: for Xception that was 0.5 GB and a split of all of it at every
+        # upload).  Sb = an anchor the job tables' destination offsets are relative to (None: split GEMMs off).
         self.Sb = None
-        self.sb_fwd, self.sb_bwd = {}, {}           # op -> (element offset in Sb, pitch)
-        self.sb_row_f, self.sb_row_b = {}, {}       # op -> its row of the dl3p_split_bf16x3_batch job table
-        # An optimiser step refreshes only the planes ITS executor's GEMMs read (Xception's 728 x 728 middle-flow kernels run at
-        # 4356 rows, under the split dispatch threshold: splitting all 40 M parameters after every step cost more than the split
-        # GEMMs returned).  sb_partial = the executor whose subset is fresh, None = every plane is; another executor on the same
-        # store (a different batch size, predict after fit) re-splits everything before it runs (Executor._sb_sync).
+        self.sb_fwd, self.sb_bwd = {}, {}           # op -> (its planes, pitch), once allocated
+        self.sb_row_f, self.sb_row_b = {}, {}       # op -> its row of the dl3p_split_bf16x3_batch job table, once allocated
+        self.sb_shape_f, self.sb_shape_b = {}, {}   # every op that may take the split kernels -> (rows, cols, pitch) of its operand
+        self._sb_tables = None                      # (forward table, data-gradient table) over the allocated planes; None: stale
+        self._sb_job_tables = []                    # one-row tables of the splits issued at allocation (read by launches in flight)
+        # An optimiser step refreshes only the planes ITS executor's GEMMs read.  sb_partial = the executor whose subset is fresh,
+        # None = every plane is; another executor on the same store (a different batch size, predict after fit) re-splits
+        # everything allocated before it runs (Executor._sb_sync).
         self.sb_partial = None
         if split_gemm_enabled() and not self.bf16:
-            pw = [op for op in graph.ops if op.kind == 'conv_pw']
-            o = 0
-            for op in pw:
-                K, Nn = op.cin, op.cout
-                pk, pn = (K + 31) // 32 * 32, (Nn + 31) // 32 * 32
-                self.sb_fwd[op] = (o, pk)
-                self.sb_row_f[op] = [self.offset[op.w], Nn, K, K, o, pk]
-                o += 3 * Nn * pk
-                self.sb_bwd[op] = (o, pn)
-                self.sb_row_b[op] = [self.offset[op.w], K, Nn, Nn, o, pn]
-                o += 3 * K * pn
-            # dense k x k convs on the implicit-GEMM path (dl3p_conv2d_gemm_fwd_sb): the forward's [3][Cout][pitch >= k k Cin] from
-            # the transposed copy; the data gradient's operand is re-laid per step (conv2d_gemm_dgrad_weights) and split by the
-            # executor that owns that buffer
-            dense = [op for op in graph.ops if op.kind == 'conv_dense' and op.kp == op.k * op.k * op.cin
-                     and lib().conv2d_gemm_supported(op.cin, op.cout, op.k, op.stride)]
-            for op in dense:
-                pk = (op.kp + 31) // 32 * 32
-                self.sb_fwd[op] = (o, pk)
-                self.sb_row_f[op] = [self.offset[op.w], op.cout, op.kp, op.kp, o, pk]
-                o += 3 * op.cout * pk
-            if pw or dense:
-                self.Sb = torch.zeros(o, dtype=torch.int16, device=device)
-                self.sb_table_f = torch.tensor([self.sb_row_f[op] for op in pw + dense], dtype=torch.int64, device=device)
-                self.sb_table_b = torch.tensor([self.sb_row_b[op] for op in pw], dtype=torch.int64, device=device) if pw else None
+            for op in graph.ops:
+                if op.kind == 'conv_pw':
+                    K, Nn = op.cin, op.cout
+                    self.sb_shape_f[op] = (Nn, K, (K + 31) // 32 * 32)
+                    self.sb_shape_b[op] = (K, Nn, (Nn + 31) // 32 * 32)
+                elif (op.kind == 'conv_dense' and op.kp == op.k * op.k * op.cin
+                      and lib().conv2d_gemm_supported(op.cin, op.cout, op.k, op.stride)):
+                    # dense k x k convs on the implicit-GEMM path (dl3p_conv2d_gemm_fwd_sb): the forward's [3][Cout][pitch >= k k Cin]
+                    # from the transposed copy; the data gradient's operand is re-laid per step (conv2d_gemm_dgrad_weights) and
+                    # split by the executor that owns that buffer
+                    self.sb_shape_f[op] = (op.cout, op.kp, (op.kp + 31) // 32 * 32)
+            if self.sb_shape_f:
+                self.Sb = torch.zeros(64, dtype=torch.int16, device=device)
         self.upload()
         self.refresh_masks()
 
@@ -120,14 +113,34 @@ class ParamStore:
             lib().transpose_batch(self.P.data_ptr(), self.Pt.data_ptr(), self.tr_table.data_ptr(),
                                   int(self.tr_table.shape[0]), st)
         if self.Sb is not None:
-            lib().split_bf16x3_batch(self.Pt.data_ptr(), self.Sb.data_ptr(), self.sb_table_f.data_ptr(), int(self.sb_table_f.shape[0]), st)
-            if self.sb_table_b is not None:
-                lib().split_bf16x3_batch(self.P.data_ptr(), self.Sb.data_ptr(), self.sb_table_b.data_ptr(), int(self.sb_table_b.shape[0]), st)
+            if self._sb_tables is None:
+                i64 = dict(dtype=torch.int64, device=self.device)
+                self._sb_tables = (torch.tensor(list(self.sb_row_f.values()), **i64) if self.sb_row_f else None,
+                                   torch.tensor(list(self.sb_row_b.values()), **i64) if self.sb_row_b else None)
+            tf, tb = self._sb_tables
+            if tf is not None:
+                lib().split_bf16x3_batch(self.Pt.data_ptr(), self.Sb.data_ptr(), tf.data_ptr(), int(tf.shape[0]), st)
+            if tb is not None:
+                lib().split_bf16x3_batch(self.P.data_ptr(), self.Sb.data_ptr(), tb.data_ptr(), int(tb.shape[0]), st)
             self.sb_partial = None
 
     def sb_ptr(self, op, fwd):
-        off, pitch = (self.sb_fwd if fwd else self.sb_bwd)[op]
-        return self.Sb.data_ptr() + 2 * off, pitch
+        """(device pointer, pitch) of the op's pre-split planes; the first call allocates them and splits the current weights"""
+        planes, rows_of, shapes = (self.sb_fwd, self.sb_row_f, self.sb_shape_f) if fwd else (self.sb_bwd, self.sb_row_b, self.sb_shape_b)
+        if op not in planes:
+            rows, cols, pitch = shapes[op]
+            t = torch.zeros(3 * rows * pitch, dtype=torch.int16, device=self.device)
+            delta = t.data_ptr() - self.Sb.data_ptr()       # (either sign; allocations are 256-byte aligned)
+            assert delta % 16 == 0
+            planes[op] = (t, pitch)
+            rows_of[op] = [self.offset[op.w], rows, cols, cols, delta // 2, pitch]
+            self._sb_tables = None
+            tab = torch.tensor([rows_of[op]], dtype=torch.int64, device=self.device)
+            self._sb_job_tables.append(tab)
+            lib().split_bf16x3_batch((self.Pt if fwd else self.P).data_ptr(), self.Sb.data_ptr(), tab.data_ptr(), 1,
+                                     torch.cuda.current_stream().cuda_stream)
+        t, pitch = planes[op]
+        return t.data_ptr(), pitch
 
     def view(self, p, buf=None):
         buf = self.P if buf is None else buf
@@ -1347,7 +1360,7 @@ class Executor:
         serves the shape and the product is compute-bound enough for the bf16 pipe to pay: reduction length and output width from
         DL3P_SPLIT_MIN_K / DL3P_SPLIT_MIN_N (measured: scripts/micro/sb_gemm.py)"""
         st = self.store
-        if st.Sb is None or op not in st.sb_fwd:
+        if st.Sb is None or op not in st.sb_shape_f:
             return False
         M = self.N * op.Ho * op.Wo
         kred, nout = (op.cin, op.cout) if fwd else (op.cout, op.cin)
@@ -1376,7 +1389,7 @@ class Executor:
         kernel?  The measured rule of the library (dl3p_conv2d_gemm_sb_pays); the weight gradient routes itself inside
         dl3p_conv2d_gemm_bwd_weight*"""
         st = self.store
-        if st.Sb is None or op not in st.sb_fwd:
+        if st.Sb is None or op not in st.sb_shape_f:
             return False
         xt = op.x.tensor
         if role == 2:
@@ -1647,8 +1660,8 @@ class Executor:
             P.k(L.transpose_batch, st.P.data_ptr(), st.Pt.data_ptr(), st.tr_table.data_ptr(), int(st.tr_table.shape[0]))
         if st.Sb is not None:               # ... and the split-bf16 GEMMs of THIS executor the pre-split planes they read
             order = [op for op in self.g.ops if op.kind in ('conv_pw', 'conv_dense')]
-            rf = [st.sb_row_f[op] for op in order if op in self._sb_used_f]
-            rb = [st.sb_row_b[op] for op in order if op in self._sb_used_b]
+            rf = [st.sb_row_f[op] for op in order if op in self._sb_used_f and op in st.sb_row_f]
+            rb = [st.sb_row_b[op] for op in order if op in self._sb_used_b and op in st.sb_row_b]
             self._sb_tab_f = torch.tensor(rf, dtype=torch.int64, device=self.dev) if rf else None
             self._sb_tab_b = torch.tensor(rb, dtype=torch.int64, device=self.dev) if rb else None
             if rf:
