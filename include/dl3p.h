@@ -61,7 +61,11 @@ int dl3p_device_cus(void);
  * tiled GEMM, 0 = automatic; "gemm_tuned" 0: ignore the measured tile table (csrc/gemm_tuned.h) -- what
  * scripts/tune_gemm.py uses to time the candidates; "gemm_per_cu", "wgrad_tile", "wgrad_per_cu" likewise.  "dw_per_cu" /
  * "dw_want" / "dw_maxth" / "dw_tuned": the same for the plan of the depthwise window kernels (csrc/dw_tuned.h,
- * scripts/tune_dw.py).  Unknown names return DL3P_EINVAL. */
+ * scripts/tune_dw.py).  The split-bf16 GEMMs: "split_wgrad" (0 | 1), "split_wgrad_tile" / "split_wgrad_per_cu", "sb_wm" / "sb_nt"
+ * (pin the wide-tile family), "sb_pipe", "sb_rs" (0 | 1 | -1: the row-stationary form never / wherever it serves / by rule),
+ * "conv_sb" (0 | 1 | 2: dense convs on the split kernels never / by the measured rule / wherever supported).  The bf16 path:
+ * "bf16_kg" (0 | 1 | 2 | 4: K groups of the tiled GEMM by rule / never / pinned).  A value outside a knob's range restores its
+ * default.  Unknown names return DL3P_EINVAL. */
 int dl3p_set_option(const char* name, int value);
 /* What the dispatcher WOULD launch for a pointwise GEMM / a depthwise conv, without launching it (the parity tests over
  * the measured tables use it to prove that a table row is reached and what it selects).
