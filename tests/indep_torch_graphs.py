@@ -1,6 +1,7 @@
 """An independent torch.nn.Module statement of the DeepLabV3+ graphs that have no third-party port in this image (transformers
-carries MobileNetV2 and ResNet only -- tests/test_oracle_vs_transformers.py): the modified aligned Xception body, the MobileNetV3
-Large / Small bodies with squeeze-excite, the SepConv ASPP, the decoder and the conv_upsample / pred_resize head.
+carries MobileNetV2 and the plain ResNet only -- tests/test_oracle_vs_transformers.py): the modified aligned Xception body, the
+MobileNetV3 Large / Small bodies with squeeze-excite, ResNet50 WITH its atrous schedule (output strides 16 and 8), the SepConv ASPP,
+the decoder and the conv_upsample / pred_resize head.
 
 TEST INFRASTRUCTURE ONLY.  Written from the reference's model files (cited per class), NOT from oracle/np_net.py: it shares
 no builder, no padding helper, no resize and no loss with the oracle -- the graph is a tree of torch modules (nn.Conv2d with
@@ -288,6 +289,67 @@ class MobileNetV3Body(nn.Module):
         return x, skip
 
 
+class ResBlock(nn.Module):
+    """identity_block / conv_block, /root/reference/deeplabv3p/models/deeplabv3p_resnet50.py:32-75, :78-139: 1x1 (the stride of a
+    conv_block sits HERE) -> 3x3 'same' at the block's atrous rate -> 1x1, every conv with a bias, BatchNorm(1e-3, 0.99) behind each;
+    the conv_block's shortcut is a strided 1x1 + BatchNorm"""
+
+    def __init__(self, cin, filters, stage, block, conv_shortcut, stride=1, rate=1):
+        super().__init__()
+        f1, f2, f3 = filters
+        base, bn = 'res%d%s_branch' % (stage, block), 'bn%d%s_branch' % (stage, block)
+        self.a = KConv(base + '2a', cin, f1, 1, stride, 1, 'valid', bias=True)
+        self.a_bn = KBN(bn + '2a', f1, 1e-3, 0.99)
+        self.b = KConv(base + '2b', f1, f2, 3, 1, rate, 'same', bias=True)
+        self.b_bn = KBN(bn + '2b', f2, 1e-3, 0.99)
+        self.c = KConv(base + '2c', f2, f3, 1, 1, 1, 'valid', bias=True)
+        self.c_bn = KBN(bn + '2c', f3, 1e-3, 0.99)
+        self.conv_shortcut = conv_shortcut
+        if conv_shortcut:
+            self.s = KConv(base + '1', cin, f3, 1, stride, 1, 'valid', bias=True)
+            self.s_bn = KBN(bn + '1', f3, 1e-3, 0.99)
+
+    def forward(self, x):
+        y = F.relu(self.a_bn(self.a(x)))
+        y = F.relu(self.b_bn(self.b(y)))
+        y = self.c_bn(self.c(y))
+        # (Keras builds the main path's three convs first, then the shortcut conv: the order the names are recorded in)
+        sc = self.s_bn(self.s(x)) if self.conv_shortcut else x
+        return F.relu(y + sc)
+
+
+class ResNet50Body(nn.Module):
+    """ResNet50 with include_top=False as Deeplabv3pResNet50 uses it, deeplabv3p_resnet50.py:142-292: conv1_pad (3, 3) + 7x7 stride 2
+    'valid' (+ bias) -> BatchNorm -> ReLU -> pool1_pad (1, 1) + 3x3 max pooling stride 2; stages 2-5 with the output-stride table
+    (:158-177): the stride of stage 4 / 5 and the atrous rates of their blocks; the skip feature is the output of stage 2"""
+    out_channels, skip_channels = 2048, 256
+
+    def __init__(self, OS):
+        super().__init__()
+        s16, r16, s32, r32 = {8: (1, 2, 1, 4), 16: (2, 1, 1, 2), 32: (2, 1, 2, 1)}[OS]
+        self.conv1 = KConv('conv1', 3, 64, 7, 2, 1, ((3, 3), (3, 3)), bias=True)
+        self.bn1 = KBN('bn_conv1', 64, 1e-3, 0.99)
+        spec = [(2, 'a', [64, 64, 256], True, 1, 1), (2, 'b', [64, 64, 256], False, 1, 1), (2, 'c', [64, 64, 256], False, 1, 1),
+                (3, 'a', [128, 128, 512], True, 2, 1)] + [(3, b, [128, 128, 512], False, 1, 1) for b in 'bcd'] + \
+               [(4, 'a', [256, 256, 1024], True, s16, 1)] + [(4, b, [256, 256, 1024], False, 1, r16) for b in 'bcdef'] + \
+               [(5, 'a', [512, 512, 2048], True, s32, r16), (5, 'b', [512, 512, 2048], False, 1, r32), (5, 'c', [512, 512, 2048], False, 1, r32)]
+        blocks, c = [], 64
+        for stage, block, filters, conv_sc, stride, rate in spec:
+            blocks.append(ResBlock(c, filters, stage, block, conv_sc, stride, rate))
+            c = filters[2]
+        self.blocks = nn.ModuleList(blocks)
+
+    def forward(self, x):
+        x = F.relu(self.bn1(self.conv1(x)))
+        x = F.max_pool2d(F.pad(x, (1, 1, 1, 1)), 3, 2)          # ZeroPadding2D then 'valid' pooling: the zeros take part (inputs are >= 0)
+        skip = None
+        for i, b in enumerate(self.blocks):
+            x = b(x)
+            if i == 2:
+                skip = x
+        return x, skip
+
+
 class ASPP(nn.Module):
     """ASPP_block, /root/reference/deeplabv3p/models/layers.py:114-163: concat order [image pooling, 1x1, rate a, rate b, rate c]"""
 
@@ -340,6 +402,8 @@ class DeepLabV3Plus(nn.Module):
         super().__init__()
         if model_type == 'xception':
             self.body = XceptionBody(OS)
+        elif model_type == 'resnet50':
+            self.body = ResNet50Body(OS)
         else:
             self.body = MobileNetV3Body(OS, 'large' if 'large' in model_type else 'small', input_hw)
         self.aspp = ASPP(self.body.out_channels, OS)

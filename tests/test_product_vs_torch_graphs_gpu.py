@@ -21,7 +21,7 @@ from test_product_vs_transformers_gpu import _weights  # noqa: E402
 
 @pytest.mark.parametrize('mt,size,OS,classes', [('xception', 65, 16, 21), ('xception', 64, 8, 19),
                                                 ('mobilenetv3large', 65, 16, 21), ('mobilenetv3large', 128, 8, 19),
-                                                ('mobilenetv3small', 97, 16, 21)])
+                                                ('mobilenetv3small', 97, 16, 21), ('resnet50', 65, 16, 21), ('resnet50', 64, 8, 19)])
 def test_predict_equals_the_independent_graph(mt, size, OS, classes):
     pkg = load_pkg()
     N = 2
