@@ -289,6 +289,66 @@ class MobileNetV3Body(nn.Module):
         return x, skip
 
 
+class MNV2Block(nn.Module):
+    """_inverted_res_block, /root/reference/deeplabv3p/models/deeplabv3p_mobilenetv2.py:38-74: 1x1 expand to expansion * cin (not
+    rounded; none in block 0) -> 3x3 depthwise 'same' at (stride, rate) -> 1x1 project to make_divisible(filters), BatchNorm(1e-3,
+    0.999) behind each, ReLU6 behind the first two"""
+
+    def __init__(self, cin, expansion, stride, filters, block_id, skip_connection, rate=1):
+        super().__init__()
+        prefix = 'expanded_conv_%d_' % block_id if block_id else 'expanded_conv_'
+        mid = expansion * cin
+        self.has_expand = bool(block_id)
+        if self.has_expand:
+            self.expand = KConv(prefix + 'expand', cin, mid, 1)
+            self.expand_bn = KBN(prefix + 'expand_BN', mid, 1e-3, 0.999)
+        self.dw = KConv(prefix + 'depthwise', mid, mid, 3, stride, rate, 'same', depthwise=True)
+        self.dw_bn = KBN(prefix + 'depthwise_BN', mid, 1e-3, 0.999)
+        self.out_channels = _depth(filters)
+        self.project = KConv(prefix + 'project', mid, self.out_channels, 1)
+        self.project_bn = KBN(prefix + 'project_BN', self.out_channels, 1e-3, 0.999)
+        self.skip_connection = skip_connection
+
+    def forward(self, x):
+        y = x
+        if self.has_expand:
+            y = F.relu6(self.expand_bn(self.expand(y)))
+        y = F.relu6(self.dw_bn(self.dw(y)))
+        y = self.project_bn(self.project(y))
+        return x + y if self.skip_connection else y
+
+
+class MobileNetV2Body(nn.Module):
+    """MobileNetV2_body, deeplabv3p_mobilenetv2.py:77-199 (alpha = 1): 3x3 stride 2 'same' stem + 17 inverted residual blocks with the
+    output-stride table; the feature handed on is block 16's output (Conv_1 is not part of the DeepLab graph), the skip block 2's"""
+    out_channels, skip_channels = 320, 24
+
+    def __init__(self, OS):
+        super().__init__()
+        s16, r16, s32, r32 = {8: (1, 2, 1, 4), 16: (2, 1, 1, 2), 32: (2, 1, 2, 1)}[OS]
+        self.stem = KConv('Conv', 3, 32, 3, 2)
+        self.stem_bn = KBN('Conv_BN', 32, 1e-3, 0.999)
+        #        filters stride expansion skip rate
+        rows = [(16, 1, 1, False, 1), (24, 2, 6, False, 1), (24, 1, 6, True, 1), (32, 2, 6, False, 1), (32, 1, 6, True, 1), (32, 1, 6, True, 1),
+                (64, s16, 6, False, 1), (64, 1, 6, True, r16), (64, 1, 6, True, r16), (64, 1, 6, True, r16),
+                (96, 1, 6, False, r16), (96, 1, 6, True, r16), (96, 1, 6, True, r16),
+                (160, s32, 6, False, r16), (160, 1, 6, True, r32), (160, 1, 6, True, r32), (320, 1, 6, False, r32)]
+        blocks, c = [], 32
+        for i, (f, st, e, sk, r) in enumerate(rows):
+            blocks.append(MNV2Block(c, e, st, f, i, sk, r))
+            c = blocks[-1].out_channels
+        self.blocks = nn.ModuleList(blocks)
+
+    def forward(self, x):
+        x = F.relu6(self.stem_bn(self.stem(x)))
+        skip = None
+        for i, b in enumerate(self.blocks):
+            x = b(x)
+            if i == 2:
+                skip = x
+        return x, skip
+
+
 class ResBlock(nn.Module):
     """identity_block / conv_block, /root/reference/deeplabv3p/models/deeplabv3p_resnet50.py:32-75, :78-139: 1x1 (the stride of a
     conv_block sits HERE) -> 3x3 'same' at the block's atrous rate -> 1x1, every conv with a bias, BatchNorm(1e-3, 0.99) behind each;
@@ -377,6 +437,28 @@ class ASPP(nn.Module):
         return x
 
 
+class ASPPLite(nn.Module):
+    """ASPP_Lite_block, layers.py:166-196: the image-pooling branch and the 1x1 branch only, concat [pooling, 1x1]"""
+
+    def __init__(self, cin):
+        super().__init__()
+        self.pool = KConv('image_pooling', cin, 256, 1)
+        self.pool_bn = KBN('image_pooling_BN', 256, 1e-5, 0.99)
+        self.b0 = KConv('aspp0', cin, 256, 1)
+        self.b0_bn = KBN('aspp0_BN', 256, 1e-5, 0.99)
+        self.proj = KConv('concat_projection', 512, 256, 1)
+        self.proj_bn = KBN('concat_projection_BN', 256, 1e-5, 0.99)
+
+    def forward(self, x, dropout_mask=None):
+        H, W = x.shape[2:]
+        b4 = bilinear(F.relu(self.pool_bn(self.pool(F.avg_pool2d(x, (H, W))))), H, W)
+        b0 = F.relu(self.b0_bn(self.b0(x)))
+        x = F.relu(self.proj_bn(self.proj(torch.cat([b4, b0], dim=1))))
+        if self.training and dropout_mask is not None:
+            x = x * dropout_mask * 2.0
+        return x
+
+
 class Decoder(nn.Module):
     """Decoder_block, layers.py:199-219"""
 
@@ -404,16 +486,25 @@ class DeepLabV3Plus(nn.Module):
             self.body = XceptionBody(OS)
         elif model_type == 'resnet50':
             self.body = ResNet50Body(OS)
+        elif model_type.startswith('mobilenetv2'):
+            self.body = MobileNetV2Body(OS)
         else:
             self.body = MobileNetV3Body(OS, 'large' if 'large' in model_type else 'small', input_hw)
-        self.aspp = ASPP(self.body.out_channels, OS)
-        self.decoder = Decoder(self.body.skip_channels)
+        # Deeplabv3pLite* (deeplabv3p_mobilenetv2.py:273-351, deeplabv3p_mobilenetv3.py:684-751): ASPP-Lite, no decoder
+        self.lite = model_type.endswith('_lite')
+        if self.lite:
+            self.aspp = ASPPLite(self.body.out_channels)
+        else:
+            self.aspp = ASPP(self.body.out_channels, OS)
+            self.decoder = Decoder(self.body.skip_channels)
         self.head = KConv('conv_upsample', 256, num_classes, 1, bias=True)
         self.input_hw = input_hw
 
     def forward(self, x, dropout_mask=None):
         f, skip = self.body(x)
-        y = self.decoder(self.aspp(f, dropout_mask), skip)
+        y = self.aspp(f, dropout_mask)
+        if not self.lite:
+            y = self.decoder(y, skip)
         return bilinear(self.head(y), *self.input_hw)
 
     # ---- weights by Keras layer name; conv outputs by Keras layer name ----

@@ -36,7 +36,10 @@ def _randomise_bn(params, rng):
 @pytest.mark.parametrize('mt,OS,hw', [('xception', 16, (65, 65)), ('xception', 8, (49, 65)), ('xception', 16, (64, 48)),
                                       ('mobilenetv3large', 16, (65, 65)), ('mobilenetv3large', 8, (64, 96)),
                                       ('mobilenetv3small', 16, (65, 49)), ('mobilenetv3small', 8, (64, 64)),
-                                      ('resnet50', 16, (65, 65)), ('resnet50', 8, (64, 80))])
+                                      ('resnet50', 16, (65, 65)), ('resnet50', 8, (64, 80)),
+                                      # the BASELINE configs[1] / configs[0] models (transformers covers their body and the lite head)
+                                      ('mobilenetv2', 16, (65, 65)), ('mobilenetv2', 8, (48, 64)), ('mobilenetv2_lite', 16, (65, 65)),
+                                      ('mobilenetv3large_lite', 16, (64, 64))])
 def test_every_convolution_output_equals_the_independent_graph(mt, OS, hw):
     from oracle.np_net import OracleModel
     C = 19 if OS == 8 else 21
@@ -69,11 +72,11 @@ def test_every_convolution_output_equals_the_independent_graph(mt, OS, hw):
     assert float(np.abs(probs - pr).max()) < AFTER_RESIZE
     # the output stride is the one asked for
     last = rec['exit_flow_block2_separable_conv3_pointwise' if mt == 'xception' else 'res5c_branch2c' if mt == 'resnet50' else
-               'expanded_conv_%d/project' % (14 if 'large' in mt else 10)]
+               'expanded_conv_16_project' if mt.startswith('mobilenetv2') else 'expanded_conv_%d/project' % (14 if 'large' in mt else 10)]
     assert last.shape[1:3] == (-(-hw[0] // OS), -(-hw[1] // OS))
 
 
-@pytest.mark.parametrize('mt,OS', [('xception', 16), ('mobilenetv3large', 8), ('mobilenetv3small', 16), ('resnet50', 16)])
+@pytest.mark.parametrize('mt,OS', [('xception', 16), ('mobilenetv3large', 8), ('mobilenetv3small', 16), ('resnet50', 16), ('mobilenetv2', 16), ('mobilenetv2_lite', 16)])
 def test_train_step_loss_and_gradients_equal_torch_autograd_on_the_independent_graph(mt, OS, monkeypatch):
     from oracle.np_net import OracleModel
     monkeypatch.setattr(G, 'FLOAT32_COORDS', True)     # (see indep_torch_graphs.py: the resize weights rounded as TF's kernel rounds them)

@@ -21,7 +21,10 @@ from test_product_vs_transformers_gpu import _weights  # noqa: E402
 
 @pytest.mark.parametrize('mt,size,OS,classes', [('xception', 65, 16, 21), ('xception', 64, 8, 19),
                                                 ('mobilenetv3large', 65, 16, 21), ('mobilenetv3large', 128, 8, 19),
-                                                ('mobilenetv3small', 97, 16, 21), ('resnet50', 65, 16, 21), ('resnet50', 64, 8, 19)])
+                                                ('mobilenetv3small', 97, 16, 21), ('resnet50', 65, 16, 21), ('resnet50', 64, 8, 19),
+                                                # the BASELINE configs[1] model (its body also meets transformers' port) and the lite variants
+                                                ('mobilenetv2', 129, 16, 21), ('mobilenetv2', 64, 8, 19), ('mobilenetv2_lite', 65, 16, 21),
+                                                ('mobilenetv3large_lite', 64, 16, 21)])
 def test_predict_equals_the_independent_graph(mt, size, OS, classes):
     pkg = load_pkg()
     N = 2
@@ -38,7 +41,7 @@ def test_predict_equals_the_independent_graph(mt, size, OS, classes):
     assert err < 3e-5, err
 
 
-@pytest.mark.parametrize('mt,size,OS', [('xception', 65, 16), ('mobilenetv3large', 97, 16), ('mobilenetv3large', 65, 8)])
+@pytest.mark.parametrize('mt,size,OS', [('xception', 65, 16), ('mobilenetv3large', 97, 16), ('mobilenetv3large', 65, 8), ('mobilenetv2', 129, 16)])
 def test_train_step_loss_and_gradients_equal_the_independent_graph(mt, size, OS):
     pkg = load_pkg()
     classes, N = 21, 4          # (at batch 3 Xception's worst tensor -- a beta on 5 x 5 maps, 75 samples a channel -- sits at 0.25)
