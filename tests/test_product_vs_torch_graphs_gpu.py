@@ -19,7 +19,7 @@ from indep_torch_graphs import DeepLabV3Plus, keras_sparse_ce  # noqa: E402
 from test_product_vs_transformers_gpu import _weights  # noqa: E402
 
 
-@pytest.mark.parametrize('mt,size,OS,classes', [('xception', 65, 16, 21), ('xception', 64, 8, 19),
+@pytest.mark.parametrize('mt,size,OS,classes', [('xception', 65, 16, 21),
                                                 ('mobilenetv3large', 65, 16, 21), ('mobilenetv3large', 128, 8, 19),
                                                 ('mobilenetv3small', 97, 16, 21), ('resnet50', 65, 16, 21), ('resnet50', 64, 8, 19),
                                                 # the BASELINE configs[1] model (its body also meets transformers' port) and the lite variants
