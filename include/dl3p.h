@@ -633,6 +633,58 @@ int dl3p_resize_bilinear_fwd_bf16(const void* x, int ldx, void* y, int ldy,
 int dl3p_resize_bilinear_bwd_bf16(const void* gy, int ldgy, void* gx, int ldgx, int accumulate,
                                   int N, int h, int w, int C, int H, int W, void* stream);
 
+/* ---------------------------------------------------------------- fused inverted-residual block (csrc/irb_fwd.hip, irb_bwd.hip)
+ * replaces, as ONE unit, Conv2D(expansion * in_channels, 1, use_bias=False) -> BatchNormalization -> ReLU6 ->
+ * DepthwiseConv2D(3, strides=stride) of _inverted_res_block (deeplabv3p_mobilenetv2.py:43-60) where the expanded tensor is
+ * large (the 257 x 257 / 129 x 129 blocks of BASELINE configs[1]): that tensor, 6x the block input, is never written to HBM --
+ * forward and backward recompute the expand conv tile by tile on v_mfma_f32_16x16x4_f32 from the K-channel input.
+ * x: the block input (raw + lazy prologue, as every conv input); w1: the expand kernel (1,1,K,C) = [K][C]; wdw: the depthwise
+ * kernel (3,3,C,1) = [9][C]; bn_*: scale / shift / activation (+ saved mean, invstd, backward coefficient triple) of the
+ * BatchNormalization between the two convs.  K in {16, 24, 32}, C a multiple of 16 (backward: C = 6K), stride 1 | 2, 3x3, rate 1.
+ *
+ * Training-mode statistics of the expand BatchNorm without its input tensor: z = x W1 is linear and bias-free, so
+ * mean_z = W1^T mean_x and var_z[c] = w_c^T Cov(x) w_c.  dl3p_irb_cov_stats leaves rows [rows][K + K*K] of float64 (sum x, then
+ * sum x x^T, exact products, float64 sums on the fp64 matrix pipe); dl3p_irb_cov_reduce adds the rows (the vector a
+ * SyncBatchNorm all-reduces); dl3p_irb_bn_finalize_cov turns it into what dl3p_bn_finalize would have produced from the
+ * materialised tensor (same outputs, same moving-average rule).
+ * dl3p_irb_fwd: y = depthwise(act(BN(x W1))) raw + its stat partial rows (as dl3p_dwconv2d_fwd).
+ * dl3p_irb_bwd_sums (pass A): from dy = gradient w.r.t. the raw depthwise output: the depthwise kernel's gradient as slabs
+ * [slab_rows][9][C] and the BatchNorm-backward partial rows [slab_rows][2][C] (sum g', sum g' xhat) of the expand BatchNorm.
+ * dl3p_irb_bwd_data (pass B), after dl3p_bn_bwd_finalize has made bn_coef from those rows: the expand kernel's gradient as slabs
+ * [slab_rows][K][C]; gx (+)= gradient w.r.t. the block input (NULL: not wanted); optionally the BatchNorm-backward rows
+ * [slab_rows][2][K] of a BatchNorm in FRONT of the block (z0 its raw input, as dl3p_pwconv_bwd_data_bn; sums of the FINISHED
+ * gradient, i.e. including what gx held when accumulate = 1).  Slab regions are sized by dl3p_irb_bwd_workspace(which = 0 | 1). */
+int dl3p_irb_supported(int N, int H, int W, int K, int C, int k, int stride, int rate, int pad_t, int pad_l, int Ho, int Wo);
+int dl3p_irb_bwd_supported(int N, int H, int W, int K, int C, int k, int stride, int rate, int pad_t, int pad_l, int Ho, int Wo);
+int dl3p_irb_cov_stats(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act, double* cov_rows,
+                       int* rows_out, int M, int K, void* stream);
+int dl3p_irb_cov_reduce(const double* cov_rows, int rows, int K, double* sums, void* stream);
+int dl3p_irb_bn_finalize_cov(const double* sums, const float* w1, int K, int C, double count, const float* gamma,
+                             const float* beta, float eps, float momentum, float* moving_mean, float* moving_var,
+                             int update_moving, float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
+int dl3p_irb_fwd(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act, const float* w1,
+                 const float* bn_scale, const float* bn_shift, int bn_act, const float* wdw, float* y, int ldy,
+                 float* stat_partials, int* rows_out, int N, int H, int W, int K, int C, int stride, int pad_t, int pad_l,
+                 int Ho, int Wo, void* stream);
+size_t dl3p_irb_bwd_workspace(int which, int N, int H, int W, int K, int C, int stride, int pad_t, int pad_l);
+int dl3p_irb_bwd_sums(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act, const float* w1,
+                      const float* bn_scale, const float* bn_shift, int bn_act, const float* bn_mean, const float* bn_invstd,
+                      const float* wdw, const float* dy, int lddy, float* gwdw_slabs, size_t slab_bytes, int* slab_rows_out,
+                      float* bn_partials, int N, int H, int W, int K, int C, int stride, int pad_t, int pad_l, int Ho, int Wo,
+                      void* stream);
+int dl3p_irb_bwd_data(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act, const float* w1,
+                      const float* bn_scale, const float* bn_shift, int bn_act, const float* bn_mean, const float* bn_invstd,
+                      const float* bn_coef, const float* wdw, const float* dy, int lddy, float* gw1_slabs, size_t slab_bytes,
+                      int* slab_rows_out, float* gx, int ldgx, int accumulate, const float* z0, int ldz0, const float* scale0,
+                      const float* shift0, int act0, const float* mean0, const float* invstd0, float* partials0, int N, int H,
+                      int W, int K, int C, int stride, int pad_t, int pad_l, int Ho, int Wo, void* stream);
+/* launch-plan knobs of the three kernels (0 = default): channel tiles per wave / waves wanted of the forward; waves wanted of
+ * pass A / workgroups wanted of pass B.  dl3p_irb_selftest: lane-shift primitives as the kernels use them (out[0..63] = id of
+ * the lane a lane reads as "next", out[64..127] as "previous"). */
+int dl3p_irb_set_plan(int ct, int want_waves);
+int dl3p_irb_set_bwd_plan(int want_waves_sums, int want_workgroups_data);
+int dl3p_irb_selftest(float* out128, void* stream);
+
 /* ---------------------------------------------------------------- measurement hook
  * dl3p_probe_arm(i): the NEXT depthwise-forward or pointwise-GEMM kernel launch of the calling thread is issued with a pair of HIP
  * events (hipExtLaunchKernelGGL start/stop events on the launch stream) stored in slot i (0 <= i < 4096);

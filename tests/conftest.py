@@ -17,6 +17,7 @@ os.environ.setdefault('DL3P_PW_SMALL_MIN_ROWS', '64')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'release: once-per-release case, skipped unless DL3P_RELEASE_TESTS=1')
 
 
 def load_pkg(sub=None):
@@ -31,3 +32,38 @@ def ops():
     if not torch.cuda.is_available():
         pytest.skip('no HIP device')
     return load_pkg('ops')
+
+
+# ---- the driver's `-m gpu` run has a wall-clock limit: keep its budget visible and the once-per-release cases out of it
+def pytest_collection_modifyitems(config, items):
+    """`release`-marked tests duplicate a parity chain the default run already closes (named in each test's marker reason); they run
+    with DL3P_RELEASE_TESTS=1 (scripts/validate_gpu.sh --release)"""
+    if os.environ.get('DL3P_RELEASE_TESTS') == '1':
+        return
+    skip = pytest.mark.skip(reason='once-per-release case (DL3P_RELEASE_TESTS=1 runs it)')
+    for it in items:
+        if 'release' in it.keywords:
+            it.add_marker(skip)
+
+
+_durations = []
+
+
+def pytest_runtest_logreport(report):
+    if report.when == 'call':
+        _durations.append((report.duration, report.nodeid))
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """the ten slowest tests and the total of the calls go to gpurun_out/ (merged back by gpurun)"""
+    if not _durations or not any('gpu' in n for _, n in _durations):
+        return
+    try:
+        d = os.path.join(ROOT, 'gpurun_out')
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, 'gpu_suite_durations.txt'), 'w') as f:
+            f.write('%d test calls, %.1f s in calls\n' % (len(_durations), sum(t for t, _ in _durations)))
+            for t, n in sorted(_durations, reverse=True)[:10]:
+                f.write('%8.2f s  %s\n' % (t, n))
+    except OSError:
+        pass

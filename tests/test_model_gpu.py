@@ -816,14 +816,16 @@ def _teacher_forced_step(model_type, H, W, OS, N, tol_fwd, tol_dz, tol_w, C=21):
     ex = m._executor(N, True)
     drop = [op for op in m.graph.ops if op.kind == 'materialize' and op.rate > 0][0]
     mask = ex.dropout_mask(drop).cpu().numpy()
-    convs = [op for op in m.graph.ops if op.kind in ('conv_pw', 'conv_dense', 'conv_dw')]
+    # (the expand conv of a fused inverted-residual block has no output buffer: executor._find_irb; the oracle then continues with its
+    # own value there and the block is compared at its depthwise output)
+    convs = [op for op in m.graph.ops if op.kind in ('conv_pw', 'conv_dense', 'conv_dw') and op.out.root.id in ex.buf]
     real = {op.name: op.layer.params[0].shape[-1] if op.kind != 'conv_dw' else op.c for op in convs}
     o.net.act_derivs = _act_derivs(m, ex)
     o.net.act_derivs_seq = _act_derivs_seq(m, ex, o.net.act_derivs)
     o.net.force = {op.name: ex.view(op.out).float().cpu().numpy()[..., :real[op.name]] for op in convs}
     o.net.record = {}
     o.net.force_grad = {op.name: ex.view(op.out, grad=True).float().cpu().numpy()[..., :real[op.name]] for op in convs
-                        if op.out.requires_grad}
+                        if op.out.requires_grad and op.out.root.id in ex.grad}
     o.net.record_grad = {}
     o.net.grad_term_norm = {}
     total, ce, logits = o.loss_and_grads(x, y, {'aspp_dropout': mask})

@@ -41,7 +41,11 @@ def test_predict_equals_the_independent_graph(mt, size, OS, classes):
     assert err < 3e-5, err
 
 
-@pytest.mark.parametrize('mt,size,OS', [('xception', 65, 16), ('mobilenetv3large', 97, 16), ('mobilenetv3large', 65, 8), ('mobilenetv2', 129, 16)])
+# Xception (68 s of float64 autograd on the host) and the second MobileNetV3 stride are once-per-release: the default run holds the HIP
+# path against the oracle for them (test_model_gpu.py::test_train_step_matches_oracle) and the CPU suite holds the oracle against this
+# graph (test_oracle_vs_torch_graphs.py), so the chain is closed without them
+@pytest.mark.parametrize('mt,size,OS', [pytest.param('xception', 65, 16, marks=pytest.mark.release), ('mobilenetv3large', 97, 16),
+                                        pytest.param('mobilenetv3large', 65, 8, marks=pytest.mark.release), ('mobilenetv2', 129, 16)])
 def test_train_step_loss_and_gradients_equal_the_independent_graph(mt, size, OS):
     pkg = load_pkg()
     classes, N = 21, 4          # (at batch 3 Xception's worst tensor -- a beta on 5 x 5 maps, 75 samples a channel -- sits at 0.25)

@@ -87,7 +87,7 @@ def test_predict_equals_the_transformers_port(size, OS):
     assert err < 2e-5, err          # (measured: 1e-6 .. 3e-6)
 
 
-@pytest.mark.parametrize('size', [65, 129])
+@pytest.mark.parametrize('size', [65, pytest.param(129, marks=pytest.mark.release)])
 def test_train_step_loss_and_gradients_equal_the_transformers_port(size):
     pkg = load_pkg()
     classes, OS, N = 21, 16, 4

@@ -49,7 +49,9 @@ def test_predict_matches_oracle_with_split_gemms(model_type, H, W):
     T.test_predict_matches_oracle(model_type, H, W)
 
 
-@pytest.mark.parametrize('model_type', ['mobilenetv2', 'xception'])
+# (Xception at 513 x 513 on the split GEMMs is what test_production_shapes_gpu.py::test_train_step_513_production_dispatch[xception] runs:
+# the default dispatch; here it is a once-per-release repeat)
+@pytest.mark.parametrize('model_type', ['mobilenetv2', pytest.param('xception', marks=pytest.mark.release)])
 def test_train_step_513_with_split_gemms(model_type, monkeypatch):
     """production shapes, production thresholds of the split dispatch (K >= 128, N >= 128, 16384 rows)"""
     for k in ('DL3P_SPLIT_MIN_K', 'DL3P_SPLIT_MIN_N', 'DL3P_SPLIT_MIN_ROWS', 'DL3P_SPLIT_MIN_ROWS_BN'):
@@ -113,7 +115,8 @@ def test_the_dense_convs_take_the_split_kernels(model_type, N):
     assert L.conv2d_gemm_sb_pays(4, 264196, 288, 64) and L.conv2d_gemm_sb_pays(1, 33800, 1152, 128) and not L.conv2d_gemm_sb_pays(1, 264196, 288, 64)
 
 
-@pytest.mark.parametrize('model_type', ['mobilenetv2', 'xception'])
+# (the fp32-input kernels keep their own op-level and 65 x 65 / 97 x 97 whole-step cases for Xception; its 513 x 513 repeat is once-per-release)
+@pytest.mark.parametrize('model_type', ['mobilenetv2', pytest.param('xception', marks=pytest.mark.release)])
 def test_train_step_513_on_the_fp32_input_mfma_kernels_only(model_type, monkeypatch):
     """DL3P_SPLIT_GEMM=0: the path the headline ran on until round 3, still selectable, still held to the same bounds"""
     monkeypatch.setenv('DL3P_SPLIT_GEMM', '0')

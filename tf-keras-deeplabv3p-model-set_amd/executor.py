@@ -448,6 +448,7 @@ class Executor:
         # is process-wide there, so every executor states its own before it sizes workspaces, traces, or runs eagerly
         self._split_wgrad = int(split_gemm_enabled() and not self.bf16 and os.environ.get('DL3P_SPLIT_WGRAD', '1') not in ('', '0'))
         self.L.set_option(b'split_wgrad', self._split_wgrad)
+        self._find_irb()
         self._alloc()
         # tracing runs every kernel once on zero inputs: keep the weights / optimiser state intact
         snap_p, snap_v, snap_step, snap_ostep = store.P.clone(), store.V.clone(), store.step.clone(), store.opt_step.clone()
@@ -485,6 +486,10 @@ class Executor:
             dt = torch.float32 if t is self.head.tensor else self.adt
             if t.id in direct_cols and not (t.id in grad_cols and self.training and t.requires_grad):
                 continue
+            if t.id in self._irb_tensors:          # the expanded tensor of a fused inverted-residual block is never in HBM
+                if self._irb_keep_z:               # (test hook: a copy for the parity tests to look at; no kernel of the step reads it)
+                    self.buf[t.id] = torch.zeros(N * t.H * t.W * t.C, dtype=dt, device=self.dev)
+                continue
             if not getattr(t, 'grad_only', False) and t.id not in direct_cols:
                 self.buf[t.id] = torch.zeros(N * t.H * t.W * t.C, dtype=dt, device=self.dev)
             if self.training and t.requires_grad:
@@ -500,6 +505,12 @@ class Executor:
                                    coef=torch.zeros(3 * bn.C, **self.f32),
                                    sums=torch.zeros(2 * bn.C, dtype=torch.float64, device=self.dev))
             cmax = max(cmax, bn.C)
+        # fused inverted-residual blocks: covariance rows / sums of the block input (dl3p_irb_cov_stats), float64
+        self.irb_cov_rows = self.irb_cov_sums = None
+        if self._irb_expand and self.training:
+            kmax = max(op.cin for op in self._irb_expand)
+            self.irb_cov_rows = torch.zeros(256 * (kmax + kmax * kmax), dtype=torch.float64, device=self.dev)
+            self.irb_cov_sums = torch.zeros(kmax + kmax * kmax, dtype=torch.float64, device=self.dev)
         self.partials = torch.zeros(MAX_ROWS * 2 * cmax, **self.f32)
         self.partials2 = torch.zeros(MAX_ROWS * 2 * cmax, **self.f32) if self.training else None   # sums that wait (_presums)
         # SyncBatchNorm: the (sum, sum^2) / (sum dy, sum dy xhat) vectors of BatchNorms whose statistics are needed at the
@@ -560,6 +571,69 @@ class Executor:
         self.step = self.store.step
         self.lr = torch.full((1,), 0.01, **self.f32)
 
+    # ---------------------------------------------------------------- fused inverted-residual blocks
+    def _find_irb(self):
+        """expand 1x1 conv -> BatchNorm -> activation -> 3x3 depthwise conv (deeplabv3p_mobilenetv2.py:43-60) as ONE unit where the
+        expanded tensor is large: csrc/irb_fwd.hip / irb_bwd.hip recompute the expand conv instead of storing its output.
+        self._irb_expand / _irb_dw / _irb_bn: the three ops of a fused block -> (expand, bn op, depthwise); fp32, one GPU,
+        every layer of the block trainable (training) -- anything else keeps the unfused kernels"""
+        self._irb_expand, self._irb_dw, self._irb_bn, self._irb_tensors = {}, {}, {}, set()
+        # DL3P_IRB_DEBUG_Z=1: the forward ALSO writes the expand output with the unfused kernel, for tests that inspect every conv
+        # output (activation branch patterns); the fused kernels never read it
+        self._irb_keep_z = os.environ.get('DL3P_IRB_DEBUG_Z', '0') == '1'
+        if self.bf16 or self.dist is not None or os.environ.get('DL3P_IRB', '1') == '0':
+            return
+        g, N, L = self.g, self.N, self.L
+        min_rows = int(os.environ.get('DL3P_IRB_MIN_ROWS', '65536'))
+        readers = {}
+        for op in g.ops:
+            for slot in ('x', 'r', 's'):
+                v = getattr(op, slot, None)
+                if v is not None:
+                    readers.setdefault(v.tensor.root.id, []).append((op, slot, v))
+            if op.kind == 'bn':
+                readers.setdefault(op.z.root.id, []).append((op, 'z', None))
+        views = {t.id for (t, _, _) in g.act_views.values()}
+        for e in g.ops:
+            if e.kind != 'conv_pw' or e.b is not None or e.bn is None or e.out.base is not None or e.out is self.head.tensor:
+                continue
+            rd = readers.get(e.out.id, [])
+            if len(rd) != 2 or e.out.id in views:
+                continue
+            bn_ops = [o for o, slot, _ in rd if o.kind == 'bn' and slot == 'z']
+            dws = [(o, v) for o, slot, v in rd if o.kind == 'conv_dw' and slot == 'x']
+            if len(bn_ops) != 1 or len(dws) != 1:
+                continue
+            b, (d, v) = bn_ops[0], dws[0]
+            if b.bn is not e.bn or v.bn is not e.bn or v.tensor is not e.out or getattr(v, 'view_grad', None) is not None:
+                continue
+            xt = e.x.tensor
+            if N * xt.H * xt.W < min_rows or e.x.tensor.ld % 4 or xt.H != e.Ho or xt.W != e.Wo:
+                continue
+            geo = (N, xt.H, xt.W, e.cin, e.cout, d.k, d.stride, d.rate, d.pad_t, d.pad_l, d.Ho, d.Wo)
+            if d.c != e.cout or not L.irb_supported(*geo):
+                continue
+            if self.training:
+                lay = (e.layer.trainable, b.bn.layer.trainable, d.layer.trainable)
+                if not all(lay) or not L.irb_bwd_supported(*geo):
+                    continue
+            rec = (e, b, d)
+            self._irb_expand[e], self._irb_bn[b], self._irb_dw[d] = rec, rec, rec
+            self._irb_tensors.add(e.out.id)
+
+    def _irb_geo(self, rec):
+        e, b, d = rec
+        xt = e.x.tensor
+        return (self.N, xt.H, xt.W, e.cin, e.cout, d.stride, d.pad_t, d.pad_l, d.Ho, d.Wo)
+
+    def _irb_args(self, rec):
+        """(x, ldx, in_scale, in_shift, in_act, w1, bn_scale, bn_shift, bn_act): the leading arguments of every dl3p_irb_* call"""
+        e, b, d = rec
+        bn = b.bn
+        xp, ldx, sp, hp, act = self.vargs(e.x)
+        return (xp, ldx, sp, hp, act, self.store.ptr(e.w), self.gscale[bn.group.id].data_ptr() + 4 * bn.offset,
+                self.gshift[bn.group.id].data_ptr() + 4 * bn.offset, bn.act)
+
     def _stem_direct(self, op):
         """the RGB stem runs as the LDS-staged implicit GEMM (csrc/stem.hip) instead of im2col + GEMM: fp32 path, raw image
         input (no lazy BatchNorm / activation on it, no gradient wanted for it), no bias"""
@@ -574,6 +648,10 @@ class Executor:
         """workspace bytes of a conv's weight gradient when it can leave its slabs for the batched reduction (0: it has a bias
         gradient, runs on <= 64 rows, or is a dense conv on the im2col route)"""
         L, N = self.L, self.N
+        if op in self._irb_expand or op in self._irb_dw:
+            e, b, d = self._irb_expand.get(op) or self._irb_dw[op]
+            xt = e.x.tensor
+            return L.irb_bwd_workspace(1 if op is e else 0, N, xt.H, xt.W, e.cin, e.cout, d.stride, d.pad_t, d.pad_l)
         if getattr(op, 'b', None) is not None or N * op.Ho * op.Wo <= 64:
             return 0
         if self.bf16:
@@ -667,6 +745,19 @@ class Executor:
         """torch view (N,H,W,C) of a graph tensor (test / debug hook)"""
         store = self.grad if grad else self.buf
         root = t.root
+        if root.id not in store and root.id in self._irb_tensors and not grad:
+            # the expand output of a fused inverted-residual block exists in no buffer: formed here, for the caller only, by the
+            # unfused pointwise kernel from the block input as the device holds it
+            from . import ops
+            e = [o for o in self._irb_expand if o.out is root][0]
+            v = e.x
+            xin = self.view(v.tensor)
+            sc = sh = None
+            if v.group is not None:
+                sc = self.gscale[v.group.id][v.goff:v.goff + v.tensor.C]
+                sh = self.gshift[v.group.id][v.goff:v.goff + v.tensor.C]
+            w = self.store.view(e.w).reshape(e.cin, e.cout)
+            return ops.pwconv_fwd(xin.reshape(-1, e.cin), w, in_scale=sc, in_shift=sh, in_act=v.act).view(self.N, root.H, root.W, root.C)
         full = store[root.id].view(self.N, root.H, root.W, root.C)
         return full[..., t.c0:t.c0 + t.C]
 
@@ -685,13 +776,29 @@ class Executor:
             if self._fwd_pending and k not in ('bn', 'broadcast') and self._reads_pending(op):
                 self._flush_bn_forward(P)
             if k in ('conv_pw', 'conv_dense', 'conv_dw'):
-                xp, ldx, sp, hp, act = self.vargs(op.x)
+                # (the depthwise conv of a fused inverted-residual block reads no buffer of its own: its input is recomputed)
+                xp, ldx, sp, hp, act = self.vargs(op.x) if op not in self._irb_dw else (None, 0, None, None, ACT_NONE)
                 bn = op.bn
                 want_stats = train and bn is not None and bn.layer.trainable
                 part = self.partials.data_ptr() if want_stats else None
                 rows = ctypes.c_int(0)
                 xt = op.x.tensor
-                if self.bf16:
+                if op in self._irb_expand:
+                    # fused block: the expand output is never formed.  Its BatchNorm's statistics come from the covariance of the
+                    # block INPUT (z = x W is linear): one pass over the K-channel tensor, finalised at the 'bn' op
+                    if want_stats:
+                        crow = ctypes.c_int(0)
+                        P.k(L.irb_cov_stats, xp, ldx, sp, hp, act, self.irb_cov_rows.data_ptr(), ctypes.byref(crow),
+                            N * xt.H * xt.W, op.cin)
+                        P.k(L.irb_cov_reduce, self.irb_cov_rows.data_ptr(), crow.value, op.cin, self.irb_cov_sums.data_ptr())
+                    if self._irb_keep_z:
+                        P.k(L.pwconv_fwd_wt, xp, ldx, sp, hp, act, st.ptr(op.w, st.Pt), None, self.tptr(op.out), op.out.ld, None,
+                            ctypes.byref(ctypes.c_int(0)), N * op.Ho * op.Wo, op.cin, op.cout)
+                elif op in self._irb_dw:
+                    rec = self._irb_dw[op]
+                    P.k(L.irb_fwd, *self._irb_args(rec), st.ptr(op.w), self.tptr(op.out), op.out.ld, part, ctypes.byref(rows),
+                        *self._irb_geo(rec), tag=op.name)
+                elif self.bf16:
                     self._conv_forward_bf16(P, op, xp, ldx, sp, hp, act, part, rows)
                 elif k == 'conv_pw' and self._use_sb(op, True, part is not None):
                     wsp, pitch = st.sb_ptr(op, True)
@@ -829,6 +936,11 @@ class Executor:
             sl = self.sync_stage[off:off + 2 * bn.C]
             P.k(L.bn_reduce_partials, self.partials.data_ptr(), op.producer.rows, 2 * bn.C, sl.data_ptr())
             self._fwd_pending.append((op, off, P.ctx))
+        elif self.training and bn.layer.trainable and op in self._irb_bn:
+            e = self._irb_bn[op][0]
+            P.k(L.irb_bn_finalize_cov, self.irb_cov_sums.data_ptr(), st.ptr(e.w), e.cin, e.cout, count, st.ptr(lp['gamma']),
+                st.ptr(lp['beta']), bn.eps, bn.momentum, st.ptr(lp['moving_mean']), st.ptr(lp['moving_variance']),
+                self.moving_mode, sp, hp, aux['mean'].data_ptr(), aux['invstd'].data_ptr())
         elif self.training and bn.layer.trainable:
             rows = op.producer.rows
             sums = None
@@ -959,13 +1071,13 @@ class Executor:
         self._batch_wgrad = batch and not defer
         if self._batch_wgrad and not self.bf16 and getattr(self, 'dz_scratch', None) is None:
             need = max([N * op.Ho * op.Wo * (op.cout if op.kind == 'conv_pw' else op.c) for op in self.g.ops
-                        if op.kind in ('conv_pw', 'conv_dw')] or [0])
+                        if op.kind in ('conv_pw', 'conv_dw') and op not in self._irb_expand] or [0])
             self.dz_scratch = torch.zeros(need + 64, **self.f32)      # dz of the layer whose weight gradient just ran
         self._folded = {}                 # z tensor id -> BatchNorm-backward apply arguments taken over by the conv's wgrad
         self._folded_dg = {}              # ... taken over by the conv's DATA gradient (row-stationary split GEMM, pw_split_rs.hip)
         jobs = self._jobs = []            # (slab pointer, destination pointer, rows, n) issued and not yet reduced
         self._wgrad_tables = []
-        slab_off = [0]
+        slab_off = self._slab_off = [0]
         slab_need = 0
         if batch:
             for op in self.g.ops:
@@ -1021,6 +1133,11 @@ class Executor:
                 continue
             processed.add(op)
             if out is None or not out.requires_grad:
+                continue
+            if op in self._irb_expand:
+                continue                      # its gradients were produced together with the depthwise conv's (below)
+            if op in self._irb_dw:
+                self._irb_backward(P, self._irb_dw[op], fuse, fuse_add, bn_done, batch)
                 continue
             if self.bf16 and k in ('conv_pw', 'conv_dense', 'conv_dw'):
                 fused_bn = fuse.get(op) if (op in fuse and fuse[op].z.requires_grad) else None
@@ -1265,6 +1382,70 @@ class Executor:
             P.py(self.dist.wait_all)
         return P
 
+    def _irb_backward(self, P, rec, fuse, fuse_add, bn_done, batch):
+        """backward of a fused inverted-residual block, issued where the loop reaches its depthwise conv: pass A (depthwise kernel
+        gradient + the expand BatchNorm's backward sums), that BatchNorm's finalize, pass B (expand kernel gradient + gradient of
+        the block input, with the backward sums of a BatchNorm in front of the block where the unfused path would carry them)"""
+        e, b, d = rec
+        L, st, N = self.L, self.store, self.N
+        G = st.G
+        assert batch and self._batch_wgrad, 'fused inverted-residual blocks leave their weight gradients as slabs'
+        bn = b.bn
+        aux = self.bn_aux[bn]
+        geo = self._irb_geo(rec)
+        head = self._irb_args(rec)
+        mean, invstd, coef = aux['mean'].data_ptr(), aux['invstd'].data_ptr(), aux['coef'].data_ptr()
+        dz, lddz = self.tptr(d.out, True), d.out.ld
+
+        def region(op):
+            nb = self._slab_bytes(op)
+            ptr = self.slab_ws.data_ptr() + 4 * self._slab_off[0]
+            self._slab_off[0] += ((nb + 255) // 256 * 256) // 4
+            return ptr, nb
+        ctx = P.ctx
+        # pass A
+        rg, nb = region(d)
+        rows_a = ctypes.c_int(0)
+        P.k(L.irb_bwd_sums, *head, mean, invstd, st.ptr(d.w), dz, lddz, rg, nb, ctypes.byref(rows_a), self.partials.data_ptr(),
+            *geo, tag=d.name)
+        self._jobs.append((rg, st.ptr(d.w, G), rows_a.value, d.k * d.k * d.c))
+        P.ctx = _op_label(b)
+        self._bn_backward(P, b, fused_rows=rows_a.value)
+        bn_done.add(b)
+        # pass B
+        P.ctx = _op_label(e)
+        xt = e.x.tensor
+        need_gx = xt.requires_grad or xt.root.requires_grad
+        gp = ldg = None
+        acc = 0
+        front = front_add = None
+        if need_gx:
+            gp, ldg, keyt = self._gbuf(e.x)
+            acc = self._acc(keyt)
+            front = fuse.get(e) if (e in fuse and fuse[e].z.requires_grad) else None
+            front_add = fuse_add.get(e) if (front is None and e in fuse_add and fuse_add[e].z.requires_grad) else None
+        bn_front = front or front_add
+        fargs = (None, 0, None, None, ACT_NONE, None, None, None)
+        if bn_front is not None:
+            bnf = bn_front.bn
+            auxf = self.bn_aux[bnf]
+            part_f = self.partials if front is not None else self.partials2
+            fargs = (self.tptr(bn_front.z), bn_front.z.ld, self.gscale[bnf.group.id].data_ptr() + 4 * bnf.offset,
+                     self.gshift[bnf.group.id].data_ptr() + 4 * bnf.offset, bnf.act, auxf['mean'].data_ptr(),
+                     auxf['invstd'].data_ptr(), part_f.data_ptr())
+        rg, nb = region(e)
+        rows_b = ctypes.c_int(0)
+        P.k(L.irb_bwd_data, *head, mean, invstd, coef, st.ptr(d.w), dz, lddz, rg, nb, ctypes.byref(rows_b), gp, ldg or 0, acc,
+            *fargs, *geo, tag='pw:' + e.name)
+        self._jobs.append((rg, st.ptr(e.w, G), rows_b.value, e.cin * e.cout))
+        if front is not None:
+            P.ctx = _op_label(front)
+            self._bn_backward(P, front, fused_rows=rows_b.value)
+            bn_done.add(front)
+        elif front_add is not None:
+            self._presums[front_add] = rows_b.value
+        P.ctx = ctx
+
     def _conv_backward_bf16(self, P, op, wgrad, ws, wsb, wgrad_slabs=None, fused_bn=None):
         """weight and data gradient of one conv on the bf16 path; `fused_bn`: the 'bn' op whose backward sums the pointwise
         data gradient carries (its finalize + apply are issued right behind it)"""
@@ -1505,11 +1686,14 @@ class Executor:
         M = N * z.H * z.W
         sp = self.gscale[bn.group.id].data_ptr() + 4 * bn.offset
         hp = self.gshift[bn.group.id].data_ptr() + 4 * bn.offset
-        g, ldg = self.tptr(z, True), z.ld
-        dzo, lddzo = g, ldg                 # where dz goes (g itself unless the gradient is read from another buffer)
-        if z.id in getattr(self, '_galias', {}):
-            g, ldg = self._galias.pop(z.id)
-        zp, ldz = self.tptr(z), z.ld
+        if op in self._irb_bn:              # (a fused block's expand output and its gradient have no buffers: sums in, triple out)
+            g = ldg = dzo = lddzo = zp = ldz = None
+        else:
+            g, ldg = self.tptr(z, True), z.ld
+            dzo, lddzo = g, ldg             # where dz goes (g itself unless the gradient is read from another buffer)
+            if z.id in getattr(self, '_galias', {}):
+                g, ldg = self._galias.pop(z.id)
+            zp, ldz = self.tptr(z), z.ld
         mean, invstd, coef = aux['mean'].data_ptr(), aux['invstd'].data_ptr(), aux['coef'].data_ptr()
         frozen = not bn.layer.trainable
         G = st.G
@@ -1536,6 +1720,8 @@ class Executor:
                 self._bwd_pending.append((op, off, P.ctx))
                 self._sync_g[op] = (g, ldg)
                 return
+        if not frozen and op in self._irb_bn:
+            return                          # dl3p_irb_bwd_data forms dz from the coefficient triple while it recomputes the expand conv
         if not frozen and self._folds_apply_dgrad(op):
             # the conv that produced z forms dz while its DATA gradient stages its operand, writes it where the apply pass would
             # have, and its weight gradient (issued behind the data gradient for that) reads it there
@@ -1553,7 +1739,8 @@ class Executor:
         (dl3p_pwconv_bwd_data_sb_apply: the long decoder layers on the row-stationary split GEMM; fp32, local statistics)"""
         conv = getattr(bn_op, 'producer', None)
         if (self.bf16 or self.sync_bn or self.dist is not None or conv is None or conv.kind != 'conv_pw' or conv.out is not bn_op.z
-                or os.environ.get('DL3P_FOLD_APPLY', '1') == '0' or os.environ.get('DL3P_FOLD_APPLY_DGRAD', '1') == '0'):
+                or os.environ.get('DL3P_FOLD_APPLY', '1') == '0' or os.environ.get('DL3P_FOLD_APPLY_DGRAD', '1') == '0'
+                or conv in self._irb_expand):
             return False
         xt = conv.x.tensor
         if not (xt.requires_grad or xt.root.requires_grad):
@@ -1572,6 +1759,8 @@ class Executor:
         if (self.bf16 or self.sync_bn or self.dist is not None or conv is None or conv.kind not in ('conv_pw', 'conv_dw')
                 or conv.out is not bn_op.z or not conv.layer.trainable or not getattr(self, '_batch_wgrad', False)
                 or os.environ.get('DL3P_FOLD_APPLY', '1') == '0' or not self._slab_bytes(conv)):
+            return False
+        if conv in self._irb_dw or conv in self._irb_expand:
             return False
         M = self.N * conv.Ho * conv.Wo
         if conv.kind == 'conv_dw':

@@ -964,3 +964,97 @@ def maxpool2d_bwd_bf16(dy, argmax, x_shape, k, stride, pad, out=None, accumulate
     gp, ldg, _ = _plb(gx)
     lib().maxpool2d_bwd_bf16(dp, ldd, _p(argmax), gp, ldg, int(accumulate), N, H, W, C, k, stride, pt, pl, Ho, Wo, _stream())
     return gx
+
+
+# ------------------------------------------------------------------------------------- fused inverted-residual block
+def irb_supported(x_shape, C, stride=1, padding='same', backward=False):
+    N, H, W, K = x_shape
+    Ho, Wo, pt, pl = conv_geometry(H, W, 3, stride, 1, padding)
+    fn = lib().irb_bwd_supported if backward else lib().irb_supported
+    return bool(fn(N, H, W, K, C, 3, stride, 1, pt, pl, Ho, Wo))
+
+
+def irb_cov_sums(x, in_scale=None, in_shift=None, in_act=ACT_NONE):
+    """float64 [K + K*K]: sum over pixels of the (prologue-applied) input and of its outer product"""
+    K = x.shape[-1]
+    M = _rows(x)
+    xp, ldx = _pl(x)
+    rows_buf = torch.empty(256 * (K + K * K), dtype=torch.float64, device=x.device)
+    rows = ctypes.c_int(0)
+    lib().irb_cov_stats(xp, ldx, _p(in_scale), _p(in_shift), in_act, _p(rows_buf), ctypes.byref(rows), M, K, _stream())
+    sums = torch.empty(K + K * K, dtype=torch.float64, device=x.device)
+    lib().irb_cov_reduce(_p(rows_buf), rows.value, K, _p(sums), _stream())
+    return sums
+
+
+def irb_bn_finalize_cov(bn, sums, w1, count, update_moving=True):
+    """the expand BatchNorm's coefficients from the covariance sums of the expand conv's INPUT; w1 (K, C)"""
+    K, C = w1.shape[-2], w1.shape[-1]
+    lib().irb_bn_finalize_cov(_p(sums), _p(w1), K, C, float(count), _p(bn.gamma), _p(bn.beta), bn.eps, bn.momentum,
+                              _p(bn.moving_mean), _p(bn.moving_var), int(update_moving), _p(bn.scale), _p(bn.shift),
+                              _p(bn.mean), _p(bn.invstd), _stream())
+
+
+def irb_fwd(x, w1, bn_scale, bn_shift, bn_act, wdw, stride=1, padding='same', in_scale=None, in_shift=None,
+            in_act=ACT_NONE, out=None, partials=None):
+    """x (N,H,W,K); w1 (K,C); wdw (3,3,C) -> raw depthwise output (N,Ho,Wo,C) [, rows]"""
+    N, H, W, K = x.shape
+    C = w1.shape[-1]
+    Ho, Wo, pt, pl = conv_geometry(H, W, 3, stride, 1, padding)
+    y = out if out is not None else torch.empty((N, Ho, Wo, C), dtype=torch.float32, device=x.device)
+    xp, ldx = _pl(x)
+    yp, ldy = _pl(y)
+    rows = ctypes.c_int(0)
+    lib().irb_fwd(xp, ldx, _p(in_scale), _p(in_shift), in_act, _p(w1), _p(bn_scale), _p(bn_shift), bn_act, _p(wdw), yp, ldy,
+                  _p(partials), ctypes.byref(rows), N, H, W, K, C, stride, pt, pl, Ho, Wo, _stream())
+    return (y, rows.value) if partials is not None else y
+
+
+def irb_bwd_sums(x, w1, bn, bn_act, wdw, dy, stride=1, padding='same', in_scale=None, in_shift=None, in_act=ACT_NONE):
+    """pass A -> (depthwise kernel gradient (3,3,C), BatchNorm-backward sums float64 [2][C])"""
+    N, H, W, K = x.shape
+    C = w1.shape[-1]
+    Ho, Wo, pt, pl = conv_geometry(H, W, 3, stride, 1, padding)
+    nbytes = lib().irb_bwd_workspace(0, N, H, W, K, C, stride, pt, pl)
+    slabs = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    part = torch.empty(MAX_STAT_ROWS * 2 * C, dtype=torch.float32, device=x.device)
+    xp, ldx = _pl(x)
+    dp, ldd = _pl(dy)
+    rows = ctypes.c_int(0)
+    lib().irb_bwd_sums(xp, ldx, _p(in_scale), _p(in_shift), in_act, _p(w1), _p(bn.scale), _p(bn.shift), bn_act, _p(bn.mean),
+                       _p(bn.invstd), _p(wdw), dp, ldd, _p(slabs), nbytes, ctypes.byref(rows), _p(part), N, H, W, K, C, stride,
+                       pt, pl, Ho, Wo, _stream())
+    r = rows.value
+    gw = slabs[:r * 9 * C].view(r, 9 * C).double().sum(0).float().view(3, 3, C)
+    return gw, part, r
+
+
+def irb_bwd_data(x, w1, bn, bn_act, wdw, dy, stride=1, padding='same', in_scale=None, in_shift=None, in_act=ACT_NONE,
+                 out=None, accumulate=False, want_gx=True, front=None):
+    """pass B -> (expand kernel gradient (K,C), gx, [front BatchNorm partial rows, rows]); bn.coef must hold the triple;
+    front = (z0, scale0, shift0, act0, mean0, invstd0)"""
+    N, H, W, K = x.shape
+    C = w1.shape[-1]
+    Ho, Wo, pt, pl = conv_geometry(H, W, 3, stride, 1, padding)
+    nbytes = lib().irb_bwd_workspace(1, N, H, W, K, C, stride, pt, pl)
+    slabs = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    gx = None
+    if want_gx:
+        gx = out if out is not None else torch.empty((N, H, W, K), dtype=torch.float32, device=x.device)
+    xp, ldx = _pl(x)
+    dp, ldd = _pl(dy)
+    gp, ldg = _pl(gx)
+    rows = ctypes.c_int(0)
+    part0 = None
+    fz = (None, 0, None, None, ACT_NONE, None, None)
+    if front is not None:
+        z0, s0, h0, a0, m0, i0 = front
+        zp, ldz = _pl(z0)
+        fz = (zp, ldz, _p(s0), _p(h0), a0, _p(m0), _p(i0))
+        part0 = torch.empty(MAX_STAT_ROWS * 2 * K, dtype=torch.float32, device=x.device)
+    lib().irb_bwd_data(xp, ldx, _p(in_scale), _p(in_shift), in_act, _p(w1), _p(bn.scale), _p(bn.shift), bn_act, _p(bn.mean),
+                       _p(bn.invstd), _p(bn.coef), _p(wdw), dp, ldd, _p(slabs), nbytes, ctypes.byref(rows), gp, ldg,
+                       int(accumulate), *fz, _p(part0), N, H, W, K, C, stride, pt, pl, Ho, Wo, _stream())
+    r = rows.value
+    gw = slabs[:r * K * C].view(r, K * C).double().sum(0).float().view(K, C)
+    return gw, gx, part0, r
