@@ -1,6 +1,6 @@
 """The fused inverted-residual blocks INSIDE the model (executor._find_irb): MobileNetV2's expand -> BatchNorm -> ReLU6 -> depthwise
-runs of deeplabv3p_mobilenetv2.py:43-60 on csrc/irb_fwd.hip / irb_bwd.hip.  Production takes them from 65536 input pixels per batch
-up (the 257 x 257 / 129 x 129 / 65 x 65 blocks of BASELINE configs[1]); DL3P_IRB_MIN_ROWS=1 brings the small parity models onto them."""
+runs of deeplabv3p_mobilenetv2.py:43-60 on csrc/irb_fwd.hip / irb_bwd.hip.  Production takes them from 131072 input pixels per batch
+up (the 257 x 257 / 129 x 129 blocks of BASELINE configs[1]); DL3P_IRB_MIN_ROWS=1 brings the small parity models onto them."""
 import numpy as np
 import pytest
 import torch
@@ -37,7 +37,7 @@ def test_which_blocks_are_fused(fused, monkeypatch):
     for e in ex1._irb_expand:
         assert e.out.id not in ex1.buf and e.out.id not in ex1.grad          # ... and outside the debug hook neither has the tensor
     # production threshold: nothing at this size
-    monkeypatch.setenv('DL3P_IRB_MIN_ROWS', '65536')
+    monkeypatch.delenv('DL3P_IRB_MIN_ROWS')
     m2 = pkg.get_deeplabv3p_model('mobilenetv2', 21, (65, 65), 16, training=True)
     m2.compile(optimizer=pkg.SGD(0.01), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
     assert not m2._executor(2, True)._irb_expand

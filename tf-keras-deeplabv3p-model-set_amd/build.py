@@ -14,6 +14,9 @@ OUT = os.path.join(HERE, 'libdl3p.so')
 OBJDIR = os.path.join(HERE, 'build')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-ffp-contract=off']
+# the fused inverted-residual kernels are bound by vector-instruction issue: MFMA results straight into VGPRs (no v_accvgpr_read per
+# result register)
+EXTRA = {'irb_fwd.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form'], 'irb_bwd.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
 
 
 def _sources():
@@ -38,7 +41,7 @@ def build(force=False, verbose=False):
         o = os.path.join(OBJDIR, src.replace('.hip', '.o'))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([HIPCC] + FLAGS + ['-c', s, '-o', o])
+            jobs.append([HIPCC] + FLAGS + EXTRA.get(src, []) + ['-c', s, '-o', o])
 
     def run(cmd):
         if verbose:

@@ -30,6 +30,33 @@ struct IrbParams {
   int nseg, nband, band, ncg, units;
 };
 
+// The activation of the expand BatchNorm as a COMPILE-TIME choice where it is ReLU6 (every MobileNetV2 block; one v_med3_f32 and two
+// compares instead of the branch-free generic evaluation of common.h: the kernels are bound by vector-instruction issue beside their
+// MFMAs); ACT < 0: the run-time code.  irb_inside: act'(u) != 0 for the piecewise-linear activations (TF: 0 at the kinks).
+template <int ACT>
+__device__ __forceinline__ float irb_act(float u, int act_rt) {
+  if constexpr (ACT == DL3P_ACT_RELU6) return __builtin_amdgcn_fmed3f(u, 0.f, 6.f);
+  else if constexpr (ACT == DL3P_ACT_NONE) return u;
+  else return act_apply(u, act_rt);
+}
+template <int ACT>
+__device__ __forceinline__ float irb_act_grad_mul(float g, float u, int act_rt) {     // g * act'(u)
+  if constexpr (ACT == DL3P_ACT_RELU6) return (u > 0.f && u < 6.f) ? g : 0.f;
+  else if constexpr (ACT == DL3P_ACT_NONE) return g;
+  else return g * act_grad(u, act_rt);
+}
+template <int ACT>
+__device__ __forceinline__ float4 irb_act4(float4 u, int act_rt) {
+  return make_float4(irb_act<ACT>(u.x, act_rt), irb_act<ACT>(u.y, act_rt), irb_act<ACT>(u.z, act_rt), irb_act<ACT>(u.w, act_rt));
+}
+template <int ACT>
+__device__ __forceinline__ float4 irb_act_grad_mul4(float4 g, float4 u, int act_rt) {
+  return make_float4(irb_act_grad_mul<ACT>(g.x, u.x, act_rt), irb_act_grad_mul<ACT>(g.y, u.y, act_rt),
+                     irb_act_grad_mul<ACT>(g.z, u.z, act_rt), irb_act_grad_mul<ACT>(g.w, u.w, act_rt));
+}
+__device__ __forceinline__ float4 irb_sel4(bool c, float4 v) { return c ? v : make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 irb_f4_to_float4(irb_f4 z) { return make_float4(z[0], z[1], z[2], z[3]); }
+
 template <int K>
 __device__ __forceinline__ void irb_load_x(const float* p, float (&v)[K / 4]) {
   if constexpr (K == 16) {
@@ -47,11 +74,12 @@ __device__ __forceinline__ void irb_load_x(const float* p, float (&v)[K / 4]) {
   }
 }
 
-// the lazy prologue of the block input (BatchNorm of the previous project conv: act NONE; a materialised Add: identity)
-template <int K>
+// the lazy prologue of the block input (BatchNorm of the previous project conv: act NONE; a materialised Add: identity).
+// XACT: compile-time activation of the prologue (NONE in every MobileNetV2 block), < 0 = run-time code
+template <int K, int XACT = -1>
 __device__ __forceinline__ void irb_prologue(float (&v)[K / 4], const float (&xs)[K / 4], const float (&xh)[K / 4], int act) {
 #pragma unroll
-  for (int s = 0; s < K / 4; ++s) v[s] = act_apply(fmaf(v[s], xs[s], xh[s]), act);
+  for (int s = 0; s < K / 4; ++s) v[s] = irb_act<XACT>(fmaf(v[s], xs[s], xh[s]), act);
 }
 
 // z = W^T x for one 16-channel tile: acc[i] = z[channel 16*tile + 4*(lane>>4) + i][pixel lane&15]
@@ -63,9 +91,20 @@ __device__ __forceinline__ irb_f4 irb_expand(const float (&wf)[K / 4], const flo
   return acc;
 }
 
-// value of lane + 1 / lane - 1 inside the 16-lane pixel row (the row's last / first lane gets its own value back)
-__device__ __forceinline__ float irb_from_next(float v) { return __shfl_down(v, 1, 16); }
-__device__ __forceinline__ float irb_from_prev(float v) { return __shfl_up(v, 1, 16); }
+// value of lane + 1 / lane - 1 inside the 16-lane pixel row: DPP row shifts (row_shl:1 reads lane + 1, row_shr:1 reads lane - 1;
+// scripts/micro/dpp_rows.hip), no LDS round trip.  The row's last / first lane gets 0: no kernel uses it.
+__device__ __forceinline__ float irb_from_next(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float irb_from_prev(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float4 irb_from_next4(float4 v) {
+  return make_float4(irb_from_next(v.x), irb_from_next(v.y), irb_from_next(v.z), irb_from_next(v.w));
+}
+__device__ __forceinline__ float4 irb_from_prev4(float4 v) {
+  return make_float4(irb_from_prev(v.x), irb_from_prev(v.y), irb_from_prev(v.z), irb_from_prev(v.w));
+}
 
 // sum over the 16 pixel lanes of a row (every lane of the row ends with the total)
 __device__ __forceinline__ float irb_row_sum(float v) {
@@ -74,6 +113,9 @@ __device__ __forceinline__ float irb_row_sum(float v) {
   v += __shfl_xor(v, 4, 16);
   v += __shfl_xor(v, 8, 16);
   return v;
+}
+__device__ __forceinline__ float4 irb_row_sum4(float4 v) {
+  return make_float4(irb_row_sum(v.x), irb_row_sum(v.y), irb_row_sum(v.z), irb_row_sum(v.w));
 }
 
 // workgroup b of an XCD-round-robin dispatch -> the b % 8-th contiguous chunk of the work range (speed only)

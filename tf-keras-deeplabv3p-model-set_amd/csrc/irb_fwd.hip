@@ -205,15 +205,38 @@ extern "C" int dl3p_irb_bn_finalize_cov(const double* sums, const float* w1, int
 // Stride 2: lane j of the segment owns output column ox0 + j; tile T0 holds the expanded activation at input column
 // 2*ox - pad_l (tap kx = 0), T1 at + 1 (kx = 1); tap kx = 2 is T0 of lane j + 1, so 15 of the 16 lanes produce an output.
 // Stride 1: lane j holds input column base + j and produces the output centred there from lanes j - 1, j, j + 1: 14 of 16.
-// Rows: every input row is expanded once and added into the one, two (stride 2) or three (stride 1) output rows it feeds.
-template <int K, int CT, int S>
+// Rows: every input row is expanded once and added into the one, two (stride 2) or three (stride 1) output rows it feeds;
+// the block input is fetched one loop iteration ahead into alternating register sets.
+//
+// Measured (scripts/micro/irb_pmc.sh): the kernel is bound by VECTOR-INSTRUCTION ISSUE, not by its MFMAs (15 of 80 us) and not by
+// memory (3 of 80 us): every instruction of a wave holds the SIMD's issue for ~4 cycles and the waves of a SIMD do not overlap
+// each other's vector work.  So the per-element instruction count is the cost, and everything linear is folded into the MFMA:
+// with a plain affine in front of the block (XACT = NONE) the expand kernel is pre-multiplied by the input scale and the
+// BatchNorm scale, and the MFMA chain STARTS from the folded shift (shift + scale * W^T in_shift), so the pre-activation u
+// comes out of the matrix pipe and the vector pipe is left with: v_med3 (ReLU6), the nine depthwise taps, a DPP move per shifted
+// tap, the statistics.  Wave-uniform quantities are forced into SGPRs (readfirstlane) so that addresses are scalar arithmetic.
+template <int K, int CT, int S, int ACT, int XACT>
 __global__ __launch_bounds__(256) void irb_fwd_kernel(IrbParams p) {
-  extern __shared__ float sm[];                      // depthwise kernel [9][C]
-  for (int i = threadIdx.x; i < 9 * p.C; i += 256) sm[i] = p.wdw[i];
+  constexpr bool FOLD = XACT == DL3P_ACT_NONE;
+  constexpr int KQ = K / 4;
+  extern __shared__ float sm[];                      // depthwise kernel [9][C], folded shift [C]
+  const int C = p.C;
+  float* s_bias = sm + 9 * C;
+  for (int i = threadIdx.x; i < 9 * C; i += 256) sm[i] = p.wdw[i];
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float b = p.h1[c];
+    if (FOLD && p.xh) {
+      float acc = 0.f;
+      for (int k = 0; k < K; ++k) acc = fmaf(p.w1[(size_t)k * C + c], p.xh[k], acc);
+      b = fmaf(p.s1[c], acc, b);
+    }
+    s_bias[c] = b;
+  }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, q = lane >> 4;
-  const int unit = irb_wg_index(blockIdx.x, gridDim.x) * 4 + wave;
+  const int unit = irb_wg_index(blockIdx.x, gridDim.x) * 4 + wave;      // (scalar)
   if (unit >= p.units) return;
   int rr = unit;
   const int cg = rr % p.ncg; rr /= p.ncg;
@@ -221,12 +244,11 @@ __global__ __launch_bounds__(256) void irb_fwd_kernel(IrbParams p) {
   const int seg = rr % p.nseg;
   const int n = rr / p.nseg;
   const int row_id = unit / p.ncg;
-  const int H = p.H, W = p.W, C = p.C, Ho = p.Ho, Wo = p.Wo;
+  const int H = p.H, W = p.W, Ho = p.Ho, Wo = p.Wo;
   const int c0 = cg * CT * 16;
-  constexpr int KQ = K / 4;
 
   float wf[CT][KQ], xs[KQ], xh[KQ];
-  float4 sc[CT], sh[CT];
+  float4 sc[CT], sh[CT], wt[CT][9];
 #pragma unroll
   for (int s = 0; s < KQ; ++s) {
     xs[s] = p.xs ? p.xs[q * KQ + s] : 1.f;
@@ -234,10 +256,16 @@ __global__ __launch_bounds__(256) void irb_fwd_kernel(IrbParams p) {
   }
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
+    const float scj = p.s1[c0 + 16 * ct + j];
 #pragma unroll
-    for (int s = 0; s < KQ; ++s) wf[ct][s] = p.w1[(size_t)(q * KQ + s) * C + c0 + 16 * ct + j];
+    for (int s = 0; s < KQ; ++s) {
+      const float w = p.w1[(size_t)(q * KQ + s) * C + c0 + 16 * ct + j];
+      wf[ct][s] = FOLD ? w * xs[s] * scj : w;
+    }
     sc[ct] = ld4(p.s1 + c0 + 16 * ct + 4 * q);
-    sh[ct] = ld4(p.h1 + c0 + 16 * ct + 4 * q);
+    sh[ct] = ld4(s_bias + c0 + 16 * ct + 4 * q);       // FOLD: the complete shift of u; else the BatchNorm shift
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wt[ct][t] = ld4(sm + t * C + c0 + 16 * ct + 4 * q);
   }
   const int xact = p.xact, act1 = p.act1;
   const int oy0 = band * p.band;
@@ -257,39 +285,67 @@ __global__ __launch_bounds__(256) void irb_fwd_kernel(IrbParams p) {
     out_ok = j >= 1 && j <= 14 && ox < Wo;
   }
   const bool va = ixa >= 0 && ixa < W, vb = ixb >= 0 && ixb < W;
+  // does any lane of this segment's tiles lie outside the image?  (wave-uniform: the first and the last segment only)
+  const bool edge = __any(!va) || (S == 2 && __any(!vb));
   const int ixac = ixa < 0 ? 0 : (ixa >= W ? W - 1 : ixa), ixbc = ixb < 0 ? 0 : (ixb >= W ? W - 1 : ixb);
-  const float* xn_ = p.x + (size_t)n * H * W * p.ldx + q * KQ;
+  const float* xn_ = p.x + (size_t)n * H * W * p.ldx;
+  const int offa = ixac * p.ldx + q * KQ, offb = ixbc * p.ldx + q * KQ;      // (per lane; the row base below is scalar)
+  const size_t rowpitch = (size_t)W * p.ldx;
 
   auto load_row = [&](int iy, float (&ra)[KQ], float (&rb)[KQ]) {
     const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
-    const float* rp = xn_ + (size_t)iyc * W * p.ldx;
-    irb_load_x<K>(rp + (size_t)ixac * p.ldx, ra);
-    if constexpr (S == 2) irb_load_x<K>(rp + (size_t)ixbc * p.ldx, rb);
+    const float* rp = xn_ + (size_t)iyc * rowpitch;
+    irb_load_x<K>(rp + offa, ra);
+    if constexpr (S == 2) irb_load_x<K>(rp + offb, rb);
   };
-  // expanded, normalised, activated tile; zero where the pixel lies in the padding
-  auto tile = [&](float (&xv)[KQ], bool valid, float4 (&t)[CT]) {
-    irb_prologue<K>(xv, xs, xh, xact);
+  // pre-activation tiles u[ct][t] of NT pixel tiles: the MFMA chains of all tiles interleaved, one k-step of every tile after
+  // the other (no MFMA waits for its predecessor: 40-cycle dependent latency against a 32-cycle issue)
+  auto expand4 = [&](float (&x0)[KQ], float (&x1)[KQ], float (&x2)[KQ], float (&x3)[KQ], float4 (&u)[CT][4]) {
+    if constexpr (!FOLD) {
+      irb_prologue<K, XACT>(x0, xs, xh, xact); irb_prologue<K, XACT>(x1, xs, xh, xact);
+      irb_prologue<K, XACT>(x2, xs, xh, xact); irb_prologue<K, XACT>(x3, xs, xh, xact);
+    }
+    irb_f4 z[CT][4];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        z[ct][t] = FOLD ? (irb_f4){sh[ct].x, sh[ct].y, sh[ct].z, sh[ct].w} : (irb_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KQ; ++s)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        z[ct][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ct][s], x0[s], z[ct][0], 0, 0, 0);
+        z[ct][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ct][s], x1[s], z[ct][1], 0, 0, 0);
+        z[ct][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ct][s], x2[s], z[ct][2], 0, 0, 0);
+        z[ct][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ct][s], x3[s], z[ct][3], 0, 0, 0);
+      }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        u[ct][t] = FOLD ? irb_f4_to_float4(z[ct][t]) : fma4(irb_f4_to_float4(z[ct][t]), sc[ct], sh[ct]);
+  };
+  auto expand1 = [&](float (&x0)[KQ], float4 (&u)[CT]) {
+    if constexpr (!FOLD) irb_prologue<K, XACT>(x0, xs, xh, xact);
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-      const irb_f4 z = irb_expand<K>(wf[ct], xv);
-      t[ct].x = valid ? act_apply(fmaf(z[0], sc[ct].x, sh[ct].x), act1) : 0.f;
-      t[ct].y = valid ? act_apply(fmaf(z[1], sc[ct].y, sh[ct].y), act1) : 0.f;
-      t[ct].z = valid ? act_apply(fmaf(z[2], sc[ct].z, sh[ct].z), act1) : 0.f;
-      t[ct].w = valid ? act_apply(fmaf(z[3], sc[ct].w, sh[ct].w), act1) : 0.f;
+      irb_f4 z = FOLD ? (irb_f4){sh[ct].x, sh[ct].y, sh[ct].z, sh[ct].w} : (irb_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KQ; ++s) z = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ct][s], x0[s], z, 0, 0, 0);
+      u[ct] = FOLD ? irb_f4_to_float4(z) : fma4(irb_f4_to_float4(z), sc[ct], sh[ct]);
     }
   };
-  auto wtap = [&](int ky, int kx, int ct) { return ld4(sm + (size_t)(3 * ky + kx) * C + c0 + 16 * ct + 4 * q); };
-  auto shl4 = [&](float4 v) { return make_float4(irb_from_next(v.x), irb_from_next(v.y), irb_from_next(v.z), irb_from_next(v.w)); };
-  auto shr4 = [&](float4 v) { return make_float4(irb_from_prev(v.x), irb_from_prev(v.y), irb_from_prev(v.z), irb_from_prev(v.w)); };
 
   float4 s1[CT], s2[CT];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) { s1[ct] = zero4(); s2[ct] = zero4(); }
+  float* ybase = p.y + ((size_t)n * Ho * Wo + (out_ok ? ox : 0)) * p.ldy + c0 + 4 * q;
   auto emit = [&](int o, const float4 (&acc)[CT]) {
-    float* yp = p.y + ((size_t)(n * Ho + o) * Wo + (out_ok ? ox : 0)) * p.ldy + c0 + 4 * q;
+    if (out_ok) {
+      float* yp = ybase + (size_t)o * Wo * p.ldy;
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      if (out_ok) {
+      for (int ct = 0; ct < CT; ++ct) {
         st4(yp + 16 * ct, acc[ct]);
         s1[ct] = add4(s1[ct], acc[ct]);
         s2[ct] = fma4(acc[ct], acc[ct], s2[ct]);
@@ -297,108 +353,120 @@ __global__ __launch_bounds__(256) void irb_fwd_kernel(IrbParams p) {
     }
   };
 
-  float xc0[KQ], xc1[KQ], xn0[KQ], xn1[KQ];
-  float4 ta[CT], tb[CT];
   if constexpr (S == 2) {
+    // two register sets for the block input, used alternately (the loop is unrolled by two): the set an iteration fetches into is
+    // the one the NEXT iteration computes from, so a fetch has a whole iteration to land and no register is copied
+    float A0[KQ], A1[KQ], A2[KQ], A3[KQ], B0[KQ], B1[KQ], B2[KQ], B3[KQ];
     float4 cur[CT], nxt[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) cur[ct] = zero4();
     int iy = 2 * oy0 - p.pad_t;
-    load_row(iy, xc0, xc1);
-    load_row(iy + 1, xn0, xn1);
-    {
-      const bool vr = iy >= 0 && iy < H;
-      tile(xc0, vr && va, ta);
-      tile(xc1, vr && vb, tb);
+    load_row(iy, B0, B1);
+    load_row(iy + 1, A0, A1);
+    load_row(iy + 2, A2, A3);
+    if (iy >= 0 && iy < H) {                          // first even row: ky = 0 of the band's first output row
+      float4 ua[CT], ub[CT];
+      expand1(B0, ua);
+      expand1(B1, ub);
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
-        const float4 tc = shl4(ta[ct]);
-        cur[ct] = fma4(wtap(0, 0, ct), ta[ct], cur[ct]);
-        cur[ct] = fma4(wtap(0, 1, ct), tb[ct], cur[ct]);
-        cur[ct] = fma4(wtap(0, 2, ct), tc, cur[ct]);
+        const float4 ta = irb_sel4(va, irb_act4<ACT>(ua[ct], act1)), tb = irb_sel4(vb, irb_act4<ACT>(ub[ct], act1));
+        const float4 tc = irb_from_next4(ta);
+        cur[ct] = mul4(wt[ct][0], ta);
+        cur[ct] = fma4(wt[ct][1], tb, cur[ct]);
+        cur[ct] = fma4(wt[ct][2], tc, cur[ct]);
       }
     }
-    for (int o = oy0; o < oy1; ++o) {
-      // odd row (ky = 1)
-      ++iy;
+    // one output row: its odd input row (tiles xa0, xb0) and the even row below it (xa1, xb1)
+    auto step = [&](int o, float (&xa0)[KQ], float (&xb0)[KQ], float (&xa1)[KQ], float (&xb1)[KQ], float (&na0)[KQ],
+                    float (&nb0)[KQ], float (&na1)[KQ], float (&nb1)[KQ]) {
+      iy += 2;                                        // iy = the even row that closes output row o
+      load_row(iy + 1, na0, nb0);
+      load_row(iy + 2, na1, nb1);
+      float4 u[CT][4];
+      expand4(xa0, xb0, xa1, xb1, u);
+      const bool vro = iy - 1 < H, vre = iy < H;      // (wave-uniform; false only in the band that ends at the bottom border)
 #pragma unroll
-      for (int s = 0; s < KQ; ++s) { xc0[s] = xn0[s]; xc1[s] = xn1[s]; }
-      load_row(iy + 1, xn0, xn1);
-      {
-        const bool vr = iy >= 0 && iy < H;
-        tile(xc0, vr && va, ta);
-        tile(xc1, vr && vb, tb);
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          const float4 tc = shl4(ta[ct]);
-          cur[ct] = fma4(wtap(1, 0, ct), ta[ct], cur[ct]);
-          cur[ct] = fma4(wtap(1, 1, ct), tb[ct], cur[ct]);
-          cur[ct] = fma4(wtap(1, 2, ct), tc, cur[ct]);
+      for (int ct = 0; ct < CT; ++ct) {
+        float4 t0 = irb_act4<ACT>(u[ct][0], act1), t1 = irb_act4<ACT>(u[ct][1], act1);
+        float4 t2 = irb_act4<ACT>(u[ct][2], act1), t3 = irb_act4<ACT>(u[ct][3], act1);
+        if (edge || !vro || !vre) {
+          t0 = irb_sel4(va && vro, t0); t1 = irb_sel4(vb && vro, t1);
+          t2 = irb_sel4(va && vre, t2); t3 = irb_sel4(vb && vre, t3);
         }
-      }
-      // even row: ky = 2 of this output row, ky = 0 of the next
-      ++iy;
-#pragma unroll
-      for (int s = 0; s < KQ; ++s) { xc0[s] = xn0[s]; xc1[s] = xn1[s]; }
-      load_row(iy + 1, xn0, xn1);
-      {
-        const bool vr = iy >= 0 && iy < H;
-        tile(xc0, vr && va, ta);
-        tile(xc1, vr && vb, tb);
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          const float4 tc = shl4(ta[ct]);
-          cur[ct] = fma4(wtap(2, 0, ct), ta[ct], cur[ct]);
-          cur[ct] = fma4(wtap(2, 1, ct), tb[ct], cur[ct]);
-          cur[ct] = fma4(wtap(2, 2, ct), tc, cur[ct]);
-          nxt[ct] = mul4(wtap(0, 0, ct), ta[ct]);
-          nxt[ct] = fma4(wtap(0, 1, ct), tb[ct], nxt[ct]);
-          nxt[ct] = fma4(wtap(0, 2, ct), tc, nxt[ct]);
-        }
+        const float4 s0 = irb_from_next4(t0), s2t = irb_from_next4(t2);
+        float4 c = cur[ct];
+        c = fma4(wt[ct][3], t0, c); c = fma4(wt[ct][4], t1, c); c = fma4(wt[ct][5], s0, c);
+        c = fma4(wt[ct][6], t2, c); c = fma4(wt[ct][7], t3, c); c = fma4(wt[ct][8], s2t, c);
+        cur[ct] = c;
+        float4 nx = mul4(wt[ct][0], t2);
+        nx = fma4(wt[ct][1], t3, nx); nx = fma4(wt[ct][2], s2t, nx);
+        nxt[ct] = nx;
       }
       emit(o, cur);
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) cur[ct] = nxt[ct];
+    };
+    int o = oy0;
+    for (; o + 1 < oy1; o += 2) {
+      step(o, A0, A1, A2, A3, B0, B1, B2, B3);
+      step(o + 1, B0, B1, B2, B3, A0, A1, A2, A3);
     }
+    if (o < oy1) step(o, A0, A1, A2, A3, B0, B1, B2, B3);
   } else {
+    // three register sets in rotation (the loop is unrolled by three): iteration t computes from set t % 3 and fetches row t + 2
+    float X0[KQ], X1[KQ], X2[KQ], dummy[KQ];
     float4 a2[CT], a1[CT], a0[CT];                    // output rows t - 2, t - 1, t
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) { a2[ct] = zero4(); a1[ct] = zero4(); }
     const int nrows = oy1 - oy0;
     int iy = oy0 - p.pad_t;
-    load_row(iy, xn0, xn1);
-    for (int t = 0; t < nrows + 2; ++t, ++iy) {
+    load_row(iy, X0, dummy);
+    load_row(iy + 1, X1, dummy);
+    auto step = [&](int t, float (&xc)[KQ], float (&xn)[KQ]) {
+      load_row(iy + 2, xn, dummy);
+      if (iy >= 0 && iy < H) {
+        float4 u[CT];
+        expand1(xc, u);
 #pragma unroll
-      for (int s = 0; s < KQ; ++s) xc0[s] = xn0[s];
-      load_row(iy + 1, xn0, xn1);
-      const bool vr = iy >= 0 && iy < H;
-      tile(xc0, vr && va, ta);
+        for (int ct = 0; ct < CT; ++ct) {
+          float4 ta = irb_act4<ACT>(u[ct], act1);
+          if (edge) ta = irb_sel4(va, ta);
+          const float4 tl = irb_from_prev4(ta), tr = irb_from_next4(ta);
+          a2[ct] = fma4(wt[ct][6], tl, a2[ct]);
+          a2[ct] = fma4(wt[ct][7], ta, a2[ct]);
+          a2[ct] = fma4(wt[ct][8], tr, a2[ct]);
+          a1[ct] = fma4(wt[ct][3], tl, a1[ct]);
+          a1[ct] = fma4(wt[ct][4], ta, a1[ct]);
+          a1[ct] = fma4(wt[ct][5], tr, a1[ct]);
+          a0[ct] = mul4(wt[ct][0], tl);
+          a0[ct] = fma4(wt[ct][1], ta, a0[ct]);
+          a0[ct] = fma4(wt[ct][2], tr, a0[ct]);
+        }
+      } else {
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        const float4 tl = shr4(ta[ct]), tr = shl4(ta[ct]);
-        a2[ct] = fma4(wtap(2, 0, ct), tl, a2[ct]);
-        a2[ct] = fma4(wtap(2, 1, ct), ta[ct], a2[ct]);
-        a2[ct] = fma4(wtap(2, 2, ct), tr, a2[ct]);
-        a1[ct] = fma4(wtap(1, 0, ct), tl, a1[ct]);
-        a1[ct] = fma4(wtap(1, 1, ct), ta[ct], a1[ct]);
-        a1[ct] = fma4(wtap(1, 2, ct), tr, a1[ct]);
-        a0[ct] = mul4(wtap(0, 0, ct), tl);
-        a0[ct] = fma4(wtap(0, 1, ct), ta[ct], a0[ct]);
-        a0[ct] = fma4(wtap(0, 2, ct), tr, a0[ct]);
+        for (int ct = 0; ct < CT; ++ct) a0[ct] = zero4();
       }
       if (t >= 2) emit(oy0 + t - 2, a2);
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) { a2[ct] = a1[ct]; a1[ct] = a0[ct]; }
+      ++iy;
+    };
+    int t = 0;
+    for (; t + 2 < nrows + 2; t += 3) {
+      step(t, X0, X2);
+      step(t + 1, X1, X0);
+      step(t + 2, X2, X1);
     }
+    if (t < nrows + 2) { step(t, X0, X2); ++t; }
+    if (t < nrows + 2) { step(t, X1, X0); ++t; }
   }
 
   if (p.partials) {
     float* prow = p.partials + (size_t)row_id * 2 * C + c0 + 4 * q;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-      float4 a, b;
-      a.x = irb_row_sum(s1[ct].x); a.y = irb_row_sum(s1[ct].y); a.z = irb_row_sum(s1[ct].z); a.w = irb_row_sum(s1[ct].w);
-      b.x = irb_row_sum(s2[ct].x); b.y = irb_row_sum(s2[ct].y); b.z = irb_row_sum(s2[ct].z); b.w = irb_row_sum(s2[ct].w);
+      const float4 a = irb_row_sum4(s1[ct]), b = irb_row_sum4(s2[ct]);
       if (j == 0) {
         st4(prow + 16 * ct, a);
         st4(prow + C + 16 * ct, b);
@@ -432,9 +500,9 @@ extern "C" int dl3p_irb_set_plan(int ct, int want_waves) { g_irb_ct = ct; g_irb_
 
 static int irb_pick_ct(int C) {
   if (g_irb_ct > 0 && C % (16 * g_irb_ct) == 0) return g_irb_ct;
-  if (C % 48 == 0) return 3;
-  if (C % 32 == 0) return 2;
-  return 1;
+  // measured (scripts/micro/irb_bench.py): two tiles per wave where C allows it (257 x 257 x 16 -> 96: 62 us against 73 with one, 118 with
+  // three at one wave per SIMD); 144 channels = 9 tiles stay at one
+  return C % 32 == 0 ? 2 : 1;
 }
 
 extern "C" int dl3p_irb_supported(int N, int H, int W, int K, int C, int k, int stride, int rate, int pad_t, int pad_l, int Ho,
@@ -454,11 +522,17 @@ template <int K, int CT>
 static void irb_fwd_launch(const IrbParams& p, int S, hipStream_t st) {
   const int wgs = ceil_div(p.units, 4);
   const int grid = ceil_div(wgs, 8) * 8;
-  const size_t shm = (size_t)9 * p.C * sizeof(float);
-  if (S == 2)
-    dl3p_launch(irb_fwd_kernel<K, CT, 2>, dim3(grid), dim3(256), shm, st, p);
-  else
-    dl3p_launch(irb_fwd_kernel<K, CT, 1>, dim3(grid), dim3(256), shm, st, p);
+  const size_t shm = (size_t)10 * p.C * sizeof(float);
+  // the compile-time activation pair of every MobileNetV2 block (ReLU6 behind the expand BatchNorm, a plain affine in front of the
+  // block); anything else takes the run-time evaluation
+  const bool fast = p.act1 == DL3P_ACT_RELU6 && p.xact == DL3P_ACT_NONE;
+  if (S == 2) {
+    if (fast) dl3p_launch(irb_fwd_kernel<K, CT, 2, DL3P_ACT_RELU6, DL3P_ACT_NONE>, dim3(grid), dim3(256), shm, st, p);
+    else dl3p_launch(irb_fwd_kernel<K, CT, 2, -1, -1>, dim3(grid), dim3(256), shm, st, p);
+  } else {
+    if (fast) dl3p_launch(irb_fwd_kernel<K, CT, 1, DL3P_ACT_RELU6, DL3P_ACT_NONE>, dim3(grid), dim3(256), shm, st, p);
+    else dl3p_launch(irb_fwd_kernel<K, CT, 1, -1, -1>, dim3(grid), dim3(256), shm, st, p);
+  }
 }
 
 extern "C" int dl3p_irb_fwd(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act, const float* w1,
