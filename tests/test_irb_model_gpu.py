@@ -129,3 +129,27 @@ def test_the_production_threshold_fuses_the_high_resolution_blocks():
     assert sorted(e.name for e in m._executor(2, True)._irb_expand) == ['expanded_conv_1_expand']
     del m
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('graphs', [False, True])
+@pytest.mark.parametrize('sync_bn', [True, False])
+def test_two_identical_ranks_reproduce_the_single_gpu_step_with_fused_blocks(graphs, sync_bn, monkeypatch):
+    """data parallelism with the fused blocks (tests/test_dist_gpu.py's double: every all-reduce multiplies by the world size, which is
+    exact in binary floating point): under SyncBatchNorm the expand BatchNorm's covariance sums and backward sums go through the
+    staging buffer and the block's second pass is issued from the statistics flush -- the trajectory must be the single-GPU one, bit
+    for bit"""
+    import test_dist_gpu as TD
+    monkeypatch.setenv('DL3P_IRB_MIN_ROWS', '1')
+    monkeypatch.delenv('DL3P_IRB', raising=False)
+    monkeypatch.delenv('DL3P_IRB_DEBUG_Z', raising=False)
+    ctx = TD._two_identical_ranks()(sync_bn=sync_bn)
+    monkeypatch.setenv('DL3P_FOLD_APPLY', '0')
+    ref_l, ref_w, m0 = TD._trajectory('mobilenetv2', 65, 65, 2, None, 3, graphs)
+    assert len(m0._executor(2, True)._irb_expand) == 6
+    monkeypatch.delenv('DL3P_FOLD_APPLY')
+    got_l, got_w, m = TD._trajectory('mobilenetv2', 65, 65, 2, ctx, 3, graphs)
+    ex = m._executor(2, True)
+    assert ex.dist is ctx and ex.sync_bn == sync_bn and len(ex._irb_expand) == 6
+    assert got_l == ref_l, (got_l, ref_l)
+    worst = max((float(np.abs(got_w[k] - ref_w[k]).max()), k) for k in ref_w)
+    assert worst[0] == 0.0, worst

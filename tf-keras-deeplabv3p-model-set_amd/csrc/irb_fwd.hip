@@ -32,7 +32,7 @@ __global__ __launch_bounds__(64 * IRB_COV_WAVES) void irb_cov_kernel(const float
   const float s1c = (xs && has1) ? xs[16 + r] : 1.f, h1c = (xh && has1) ? xh[16 + r] : 0.f;
   irb_d4 d00 = {0, 0, 0, 0}, d01 = {0, 0, 0, 0}, d11 = {0, 0, 0, 0};
   double sum0 = 0.0, sum1 = 0.0;
-  constexpr int U = 4;
+  constexpr int U = 16;
   for (long long base = p0 + wave * 4; base < p1; base += 4 * IRB_COV_WAVES * U) {
     float v0[U], v1[U];
     bool ok[U];
@@ -96,7 +96,7 @@ extern "C" int dl3p_irb_cov_stats(const float* x, int ldx, const float* in_scale
   DL3P_CHECK_ARG(x && cov_rows && M > 0, "dl3p_irb_cov_stats: bad arguments");
   DL3P_CHECK_ARG(K == 16 || K == 24 || K == 32, "dl3p_irb_cov_stats: K=%d not in {16, 24, 32}", K);
   DL3P_CHECK_ARG(ldx >= K, "dl3p_irb_cov_stats: ld=%d < K", ldx);
-  const long long gran = 4 * IRB_COV_WAVES * 4;
+  const long long gran = 4 * IRB_COV_WAVES * 16;
   long long chunk = ceil_div_ll(ceil_div_ll(M, DL3P_NUM_CUS), gran) * gran;
   const int rows = (int)ceil_div_ll(M, chunk);
   if (rows_out) *rows_out = rows;
@@ -144,33 +144,37 @@ extern "C" int dl3p_irb_cov_reduce(const double* cov_rows, int rows, int K, doub
 }
 
 // BatchNorm coefficients of the expand output from the statistics of its INPUT: z = W^T x, so
-// mean_z[c] = sum_k W[k][c] mean_x[k], var_z[c] = sum_ij W[i][c] Cov_x[i][j] W[j][c]; everything in float64
+// mean_z[c] = sum_k W[k][c] mean_x[k], var_z[c] = sum_ij W[i][c] Cov_x[i][j] W[j][c]; everything in float64.
+// One workgroup per 8 output channels, 32 lanes per channel: lane i forms w_i * (Cov w)_i, the 32 lanes are added by shuffles.
 __global__ __launch_bounds__(256) void irb_bn_finalize_cov_kernel(const double* __restrict__ sums, const float* __restrict__ w1,
                                                                   int K, int C, double count, const float* gamma,
                                                                   const float* beta, float eps, float momentum,
                                                                   float* moving_mean, float* moving_var, int update_moving,
                                                                   float* scale, float* shift, float* save_mean,
                                                                   float* save_invstd) {
-  __shared__ double mu[32], cov[32 * 32];
-  __shared__ float wsm[32][256];                     // this thread's kernel column (no per-thread array: no scratch)
-  for (int k = threadIdx.x; k < K; k += 256) mu[k] = sums[k] / count;
+  __shared__ double mu[32], cov[32 * 33];
+  __shared__ double wsm[8][32];
+  for (int k = threadIdx.x; k < 32; k += 256) mu[k] = k < K ? sums[k] / count : 0.0;
   __syncthreads();
-  for (int e = threadIdx.x; e < K * K; e += 256) cov[e] = sums[K + e] / count - mu[e / K] * mu[e % K];
+  for (int e = threadIdx.x; e < 32 * 32; e += 256) {
+    const int i = e >> 5, jj = e & 31;
+    cov[i * 33 + jj] = (i < K && jj < K) ? sums[K + i * K + jj] / count - mu[i] * mu[jj] : 0.0;
+  }
+  const int cl = threadIdx.x >> 5, i = threadIdx.x & 31;
+  const int c = blockIdx.x * 8 + cl;
+  const double wi = (c < C && i < K) ? (double)w1[(size_t)i * C + c] : 0.0;
+  wsm[cl][i] = wi;
   __syncthreads();
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double mean = 0.0;
-  for (int k = 0; k < K; ++k) {
-    const float wk = w1[(size_t)k * C + c];
-    wsm[k][threadIdx.x] = wk;
-    mean += (double)wk * mu[k];
+  double t = 0.0;
+#pragma unroll 8
+  for (int jj = 0; jj < 32; ++jj) t += cov[i * 33 + jj] * wsm[cl][jj];
+  double var = wi * t, mean = wi * mu[i];
+#pragma unroll
+  for (int m = 16; m >= 1; m >>= 1) {
+    var += __shfl_xor(var, m, 32);
+    mean += __shfl_xor(mean, m, 32);
   }
-  double var = 0.0;
-  for (int i = 0; i < K; ++i) {
-    double t = 0.0;
-    for (int jj = 0; jj < K; ++jj) t += cov[i * K + jj] * (double)wsm[jj][threadIdx.x];
-    var += (double)wsm[i][threadIdx.x] * t;
-  }
+  if (i != 0 || c >= C) return;
   if (var < 0.0) var = 0.0;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
   const float sc = gamma[c] * invstd;
@@ -193,7 +197,7 @@ extern "C" int dl3p_irb_bn_finalize_cov(const double* sums, const float* w1, int
                  "dl3p_irb_bn_finalize_cov: bad arguments");
   DL3P_CHECK_ARG(K > 0 && K <= 32, "dl3p_irb_bn_finalize_cov: K=%d", K);
   DL3P_CHECK_ARG(!update_moving || (moving_mean && moving_var), "dl3p_irb_bn_finalize_cov: moving stats missing");
-  hipLaunchKernelGGL(irb_bn_finalize_cov_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, w1, K, C,
+  hipLaunchKernelGGL(irb_bn_finalize_cov_kernel, dim3(ceil_div(C, 8)), dim3(256), 0, (hipStream_t)stream, sums, w1, K, C,
                      count, gamma, beta, eps, momentum, moving_mean, moving_var, update_moving, scale, shift, save_mean,
                      save_invstd);
   DL3P_CHECK_LAUNCH("dl3p_irb_bn_finalize_cov");

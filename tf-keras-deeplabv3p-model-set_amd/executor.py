@@ -516,7 +516,10 @@ class Executor:
         # SyncBatchNorm: the (sum, sum^2) / (sum dy, sum dy xhat) vectors of BatchNorms whose statistics are needed at the
         # same point of the graph travel in ONE all-reduce.  Slices of this buffer are handed out in trace order, so the
         # BatchNorms waiting for a flush are contiguous (forward and backward use separate halves).
-        self._sync_total = sum(2 * bn.C for bn in g.bns)
+        irb_k = {b.bn: e.cin for e, b, d in self._irb_expand.values()}
+        # (a fused block's expand BatchNorm stages the covariance sums of its K-channel input in the forward half)
+        self._stage_len = {bn: max(2 * bn.C, irb_k[bn] + irb_k[bn] ** 2) if bn in irb_k else 2 * bn.C for bn in g.bns}
+        self._sync_total = sum(self._stage_len.values())
         self.sync_stage = (torch.zeros(2 * self._sync_total, dtype=torch.float64, device=self.dev)
                            if (self.sync_bn and self.training) else None)
         ws = 1 << 20
@@ -575,13 +578,14 @@ class Executor:
     def _find_irb(self):
         """expand 1x1 conv -> BatchNorm -> activation -> 3x3 depthwise conv (deeplabv3p_mobilenetv2.py:43-60) as ONE unit where the
         expanded tensor is large: csrc/irb_fwd.hip / irb_bwd.hip recompute the expand conv instead of storing its output.
-        self._irb_expand / _irb_dw / _irb_bn: the three ops of a fused block -> (expand, bn op, depthwise); fp32, one GPU,
-        every layer of the block trainable (training) -- anything else keeps the unfused kernels"""
+        self._irb_expand / _irb_dw / _irb_bn: the three ops of a fused block -> (expand, bn op, depthwise); fp32, every layer of the
+        block trainable (training) -- anything else keeps the unfused kernels.  Under SyncBatchNorm the expand BatchNorm's
+        covariance sums (K + K*K doubles) and its backward sums travel in the same all-reduces as every other BatchNorm's"""
         self._irb_expand, self._irb_dw, self._irb_bn, self._irb_tensors = {}, {}, {}, set()
         # DL3P_IRB_DEBUG_Z=1: the forward ALSO writes the expand output with the unfused kernel, for tests that inspect every conv
         # output (activation branch patterns); the fused kernels never read it
         self._irb_keep_z = os.environ.get('DL3P_IRB_DEBUG_Z', '0') == '1'
-        if self.bf16 or self.dist is not None or os.environ.get('DL3P_IRB', '1') == '0':
+        if self.bf16 or os.environ.get('DL3P_IRB', '1') == '0':
             return
         g, N, L = self.g, self.N, self.L
         # measured on the headline step (DESIGN 4e): the 257 x 257 and 129 x 129 blocks pay (12.75 -> 12.22 ms), the 65 x 65 ones do not (12.47 with them)
@@ -610,6 +614,10 @@ class Executor:
                 continue
             xt = e.x.tensor
             if N * xt.H * xt.W < min_rows or e.x.tensor.ld % 4 or xt.H != e.Ho or xt.W != e.Wo:
+                continue
+            # a stride-1 depthwise conv reaches every expanded pixel with all nine taps (a stride-2 one with 2.25 on average): the
+            # recomputing backward then costs what the unfused kernels cost (129 x 129 x 24 -> 144: 437 against 421 us per step)
+            if d.stride == 1 and N * xt.H * xt.W < int(os.environ.get('DL3P_IRB_S1_MIN_ROWS', '400000')) and 'DL3P_IRB_MIN_ROWS' not in os.environ:
                 continue
             geo = (N, xt.H, xt.W, e.cin, e.cout, d.k, d.stride, d.rate, d.pad_t, d.pad_l, d.Ho, d.Wo)
             if d.c != e.cout or not L.irb_supported(*geo):
@@ -771,6 +779,7 @@ class Executor:
             if self.optimizer[0] == 'adam':
                 P.k(L.increment_counter, self.store.opt_step.data_ptr())
         self._fwd_pending, self._fwd_stage_off = [], 0
+        self._irb_stage = {}
         for op in self.g.ops:
             k = op.kind
             P.ctx = _op_label(op)
@@ -791,7 +800,13 @@ class Executor:
                         crow = ctypes.c_int(0)
                         P.k(L.irb_cov_stats, xp, ldx, sp, hp, act, self.irb_cov_rows.data_ptr(), ctypes.byref(crow),
                             N * xt.H * xt.W, op.cin)
-                        P.k(L.irb_cov_reduce, self.irb_cov_rows.data_ptr(), crow.value, op.cin, self.irb_cov_sums.data_ptr())
+                        if self.sync_bn:
+                            off = self._fwd_stage_off
+                            self._fwd_stage_off += self._stage_len[bn]
+                            self._irb_stage[bn] = off
+                            P.k(L.irb_cov_reduce, self.irb_cov_rows.data_ptr(), crow.value, op.cin, self.sync_stage[off:].data_ptr())
+                        else:
+                            P.k(L.irb_cov_reduce, self.irb_cov_rows.data_ptr(), crow.value, op.cin, self.irb_cov_sums.data_ptr())
                     if self._irb_keep_z:
                         P.k(L.pwconv_fwd_wt, xp, ldx, sp, hp, act, st.ptr(op.w, st.Pt), None, self.tptr(op.out), op.out.ld, None,
                             ctypes.byref(ctypes.c_int(0)), N * op.Ho * op.Wo, op.cin, op.cout)
@@ -929,11 +944,13 @@ class Executor:
         hp = self.gshift[bn.group.id].data_ptr() + 4 * bn.offset
         z = op.z
         count = float(N * z.H * z.W)
-        if self.training and bn.layer.trainable and self.sync_bn:
+        if self.training and bn.layer.trainable and self.sync_bn and op in self._irb_bn:
+            self._fwd_pending.append((op, self._irb_stage[bn], P.ctx))      # (its covariance sums are in the slice already)
+        elif self.training and bn.layer.trainable and self.sync_bn:
             # local sums into this BatchNorm's slice of the staging buffer; the all-reduce and the finalize wait until a
             # consumer needs the coefficients (_flush_bn_forward), together with every other BatchNorm pending by then
             off = self._fwd_stage_off
-            self._fwd_stage_off += 2 * bn.C
+            self._fwd_stage_off += self._stage_len[bn]
             sl = self.sync_stage[off:off + 2 * bn.C]
             P.k(L.bn_reduce_partials, self.partials.data_ptr(), op.producer.rows, 2 * bn.C, sl.data_ptr())
             self._fwd_pending.append((op, off, P.ctx))
@@ -955,17 +972,25 @@ class Executor:
     def _reads_pending(self, op):
         """does `op` apply the coefficients of a BatchNorm whose statistics are still waiting for their all-reduce?"""
         groups = {id(b.bn.group) for b, _, _ in self._fwd_pending}
+        # (a fused block reads the coefficients in FRONT of it twice: in the covariance pass at its expand op, in the fused launch at
+        # its depthwise op)
+        if op in self._irb_dw and self._reads_pending_value(self._irb_dw[op][0].x, groups):
+            return True
         for slot in ('x', 'r', 's'):
             v = getattr(op, slot, None)
             if v is not None and v.group is not None and id(v.group) in groups:
                 return True
         return False
 
+    @staticmethod
+    def _reads_pending_value(v, groups):
+        return v is not None and v.group is not None and id(v.group) in groups
+
     def _flush_bn_forward(self, P):
         """ONE all-reduce for every pending BatchNorm (their slices are contiguous), then their finalize kernels"""
         pend, self._fwd_pending = self._fwd_pending, []
         lo = pend[0][1]
-        hi = pend[-1][1] + 2 * pend[-1][0].bn.C
+        hi = pend[-1][1] + self._stage_len[pend[-1][0].bn]
         ctx = P.ctx
         P.ctx = 'syncbn:' + '+'.join(b.bn.name for b, _, _ in pend)
         P.coll(lambda t=self.sync_stage[lo:hi]: self.dist.all_reduce(t))
@@ -978,6 +1003,12 @@ class Executor:
             sp = self.gscale[bn.group.id].data_ptr() + 4 * bn.offset
             hp = self.gshift[bn.group.id].data_ptr() + 4 * bn.offset
             count = float(self.N * op.z.H * op.z.W) * self.dist.world_size
+            if op in self._irb_bn:
+                e = self._irb_bn[op][0]
+                P.k(L.irb_bn_finalize_cov, self.sync_stage[off:].data_ptr(), st.ptr(e.w), e.cin, e.cout, count, st.ptr(lp['gamma']),
+                    st.ptr(lp['beta']), bn.eps, bn.momentum, st.ptr(lp['moving_mean']), st.ptr(lp['moving_variance']),
+                    self.moving_mode, sp, hp, aux['mean'].data_ptr(), aux['invstd'].data_ptr())
+                continue
             P.k(L.bn_finalize, None, 0, self.sync_stage[off:].data_ptr(), bn.C, count, st.ptr(lp['gamma']),
                 st.ptr(lp['beta']), bn.eps, bn.momentum, st.ptr(lp['moving_mean']), st.ptr(lp['moving_variance']),
                 self.moving_mode, sp, hp, aux['mean'].data_ptr(), aux['invstd'].data_ptr())
@@ -1057,6 +1088,7 @@ class Executor:
         fuse_add = self._bn_fusion_through_adds(readers) if not self.bf16 else {}
         self._presums = {}                # 'bn' op -> partial rows left in self.partials2 by such a data gradient
         rops = list(reversed(self.g.ops))
+        self._bwd_ctx = (fuse, fuse_add, bn_done)       # (what a fused block's second pass needs when it is issued from a flush)
 
         def wgrad(fn, *args):
             if defer:
@@ -1383,37 +1415,44 @@ class Executor:
             P.py(self.dist.wait_all)
         return P
 
+    def _irb_region(self, op):
+        nb = self._slab_bytes(op)
+        ptr = self.slab_ws.data_ptr() + 4 * self._slab_off[0]
+        self._slab_off[0] += ((nb + 255) // 256 * 256) // 4
+        return ptr, nb
+
     def _irb_backward(self, P, rec, fuse, fuse_add, bn_done, batch):
         """backward of a fused inverted-residual block, issued where the loop reaches its depthwise conv: pass A (depthwise kernel
         gradient + the expand BatchNorm's backward sums), that BatchNorm's finalize, pass B (expand kernel gradient + gradient of
-        the block input, with the backward sums of a BatchNorm in front of the block where the unfused path would carry them)"""
+        the block input, with the backward sums of a BatchNorm in front of the block where the unfused path would carry them).
+        Under SyncBatchNorm pass B waits for the all-reduce of the sums: it is issued from _flush_bn_backward, which the loop
+        triggers when it reaches the expand conv"""
         e, b, d = rec
-        L, st, N = self.L, self.store, self.N
-        G = st.G
-        assert batch and self._batch_wgrad, 'fused inverted-residual blocks leave their weight gradients as slabs'
-        bn = b.bn
-        aux = self.bn_aux[bn]
-        geo = self._irb_geo(rec)
-        head = self._irb_args(rec)
-        mean, invstd, coef = aux['mean'].data_ptr(), aux['invstd'].data_ptr(), aux['coef'].data_ptr()
+        L, st = self.L, self.store
+        assert batch, 'fused inverted-residual blocks leave their weight gradients as slabs'
+        aux = self.bn_aux[b.bn]
         dz, lddz = self.tptr(d.out, True), d.out.ld
-
-        def region(op):
-            nb = self._slab_bytes(op)
-            ptr = self.slab_ws.data_ptr() + 4 * self._slab_off[0]
-            self._slab_off[0] += ((nb + 255) // 256 * 256) // 4
-            return ptr, nb
         ctx = P.ctx
-        # pass A
-        rg, nb = region(d)
+        rg, nb = self._irb_region(d)
         rows_a = ctypes.c_int(0)
-        P.k(L.irb_bwd_sums, *head, mean, invstd, st.ptr(d.w), dz, lddz, rg, nb, ctypes.byref(rows_a), self.partials.data_ptr(),
-            *geo, tag=d.name)
-        self._jobs.append((rg, st.ptr(d.w, G), rows_a.value, d.k * d.k * d.c))
+        P.k(L.irb_bwd_sums, *self._irb_args(rec), aux['mean'].data_ptr(), aux['invstd'].data_ptr(), st.ptr(d.w), dz, lddz, rg, nb,
+            ctypes.byref(rows_a), self.partials.data_ptr(), *self._irb_geo(rec), tag=d.name)
+        self._jobs.append((rg, st.ptr(d.w, st.G), rows_a.value, d.k * d.k * d.c))
         P.ctx = _op_label(b)
         self._bn_backward(P, b, fused_rows=rows_a.value)
         bn_done.add(b)
-        # pass B
+        if not self.sync_bn:
+            self._irb_pass_b(P, rec)
+        P.ctx = ctx
+
+    def _irb_pass_b(self, P, rec):
+        e, b, d = rec
+        L, st = self.L, self.store
+        fuse, fuse_add, bn_done = self._bwd_ctx
+        aux = self.bn_aux[b.bn]
+        mean, invstd, coef = aux['mean'].data_ptr(), aux['invstd'].data_ptr(), aux['coef'].data_ptr()
+        dz, lddz = self.tptr(d.out, True), d.out.ld
+        ctx = P.ctx
         P.ctx = _op_label(e)
         xt = e.x.tensor
         need_gx = xt.requires_grad or xt.root.requires_grad
@@ -1434,11 +1473,11 @@ class Executor:
             fargs = (self.tptr(bn_front.z), bn_front.z.ld, self.gscale[bnf.group.id].data_ptr() + 4 * bnf.offset,
                      self.gshift[bnf.group.id].data_ptr() + 4 * bnf.offset, bnf.act, auxf['mean'].data_ptr(),
                      auxf['invstd'].data_ptr(), part_f.data_ptr())
-        rg, nb = region(e)
+        rg, nb = self._irb_region(e)
         rows_b = ctypes.c_int(0)
-        P.k(L.irb_bwd_data, *head, mean, invstd, coef, st.ptr(d.w), dz, lddz, rg, nb, ctypes.byref(rows_b), gp, ldg or 0, acc,
-            *fargs, *geo, tag='pw:' + e.name)
-        self._jobs.append((rg, st.ptr(e.w, G), rows_b.value, e.cin * e.cout))
+        P.k(L.irb_bwd_data, *self._irb_args(rec), mean, invstd, coef, st.ptr(d.w), dz, lddz, rg, nb, ctypes.byref(rows_b), gp,
+            ldg or 0, acc, *fargs, *self._irb_geo(rec), tag='pw:' + e.name)
+        self._jobs.append((rg, st.ptr(e.w, st.G), rows_b.value, e.cin * e.cout))
         if front is not None:
             P.ctx = _op_label(front)
             self._bn_backward(P, front, fused_rows=rows_b.value)
@@ -1800,6 +1839,7 @@ class Executor:
         pend, self._bwd_pending = self._bwd_pending, []
         lo = pend[0][1]
         hi = pend[-1][1] + 2 * pend[-1][0].bn.C
+        assert all(b[1] - a[1] == 2 * a[0].bn.C for a, b in zip(pend, pend[1:])), 'backward SyncBatchNorm slices are contiguous'
         L, st = self.L, self.store
         ctx = P.ctx
         P.ctx = 'syncbn:' + '+'.join(b.bn.name for b, _, _ in pend)
@@ -1815,9 +1855,16 @@ class Executor:
             M = self.N * z.H * z.W
             sp = self.gscale[bn.group.id].data_ptr() + 4 * bn.offset
             hp = self.gshift[bn.group.id].data_ptr() + 4 * bn.offset
+            mean, invstd, coef = aux['mean'].data_ptr(), aux['invstd'].data_ptr(), aux['coef'].data_ptr()
+            if op in self._irb_bn:
+                # a fused block: the global coefficient triple, then its second pass (which forms dz while it recomputes the expand)
+                self._sync_g.pop(op, None)
+                P.k(L.bn_bwd_finalize, None, 0, self.sync_stage[off:].data_ptr(), bn.C, float(M * self.dist.world_size),
+                    st.ptr(lp['gamma']), invstd, sp, 0, None, None, coef)
+                self._irb_pass_b(P, self._irb_bn[op])
+                continue
             dzo, lddzo, zp = self.tptr(z, True), z.ld, self.tptr(z)
             g, ldg = self._sync_g.pop(op, (dzo, lddzo))          # (a residual Add's buffer when the gradient was handed on in place)
-            mean, invstd, coef = aux['mean'].data_ptr(), aux['invstd'].data_ptr(), aux['coef'].data_ptr()
             P.k(L.bn_bwd_finalize, None, 0, self.sync_stage[off:].data_ptr(), bn.C, float(M * self.dist.world_size),
                 st.ptr(lp['gamma']), invstd, sp, 0, None, None, coef)
             P.k(L.bn_bwd_apply_bf16 if self.bf16 else L.bn_bwd_apply, g, ldg, zp, z.ld, sp, hp, bn.act, mean, invstd, coef,
