@@ -149,16 +149,33 @@ def streaming_variant(pkg, op):
             'streaming_shape': 'N=%d %dx%dx%d (%.0f MB each way)' % (Nb, H, W, C, by / 2e6)}
 
 
+def kernel_source_hash():
+    """what the roofline kernel is built from: the depthwise kernels and their measured plan table (git blob hashes, as
+    `git hash-object` prints them).  scripts/collect_profiles.sh stamps the PMC record with it; a record collected on other
+    sources is refused below instead of surviving a kernel change silently"""
+    import hashlib
+    out = []
+    for f in ('csrc/dwconv.hip', 'csrc/dw_tuned.h'):
+        data = open(os.path.join(ROOT, PKG, f), 'rb').read()
+        out.append(hashlib.sha1(b'blob %d\0' % len(data) + data).hexdigest()[:12])
+    return '+'.join(out)
+
+
 def measured_traffic(kernel_name):
     """HBM bytes per launch of the roofline kernel from the newest committed PMC pass (profiles/*_roofline_traffic.json,
-    written by scripts/collect_profiles.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied)"""
+    written by scripts/collect_profiles.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied).
+    -> (bytes | None, source file | reason)"""
     import glob
+    want = kernel_source_hash()
     for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_roofline_traffic.json')), reverse=True):
         try:
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
         if d.get('kernel') and d['kernel'] in (kernel_name or ''):
+            if d.get('source_hash') != want:
+                return None, '%s was collected on other kernel sources (%s, now %s): re-run scripts/collect_profiles.sh' % (
+                    os.path.basename(f), d.get('source_hash', 'unstamped'), want)
             return int(d['traffic_bytes']), os.path.basename(f)
     return None, None
 

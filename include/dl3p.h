@@ -67,6 +67,9 @@ int dl3p_device_cus(void);
  * "bf16_kg" (0 | 1 | 2 | 4: K groups of the tiled GEMM by rule / never / pinned).  A value outside a knob's range restores its
  * default.  Unknown names return DL3P_EINVAL. */
 int dl3p_set_option(const char* name, int value);
+/* current value of "split_wgrad" | "conv_sb" | "sb_rs" | "sb_pipe" (the knobs that decide how many slabs / partial rows a launch
+ * writes: a host that records launches pins them again before replaying them); INT_MIN for any other name */
+int dl3p_get_option(const char* name);
 /* What the dispatcher WOULD launch for a pointwise GEMM / a depthwise conv, without launching it (the parity tests over
  * the measured tables use it to prove that a table row is reached and what it selects).
  * dl3p_gemm_plan_query: role 0 forward, 1 forward + BatchNorm statistics (dl3p_pwconv_fwd_wt), 2 data gradient, 3 data
@@ -115,7 +118,16 @@ int dl3p_comm_destroy(void* comm);
  * rounds to bf16 Inf, has the residual a - rn_bf16(a) = NaN: every output of that ROW is NaN, where the fp32-input kernels give
  * Inf / NaN / a finite value -- an overflowing activation still shows, never as a wrong finite number.  Below 2^-110 the third
  * (then the second) piece of an operand falls under bf16's smallest normal 2^-126: the product then carries an ABSOLUTE error of
- * at most 2^-126 |w| per term, far below any float32-normal output. */
+ * at most 2^-126 |w| per term, far below any float32-normal output.
+ * ARITHMETIC: the six cross products are exact (8-bit x 8-bit significands in the fp32 accumulate of v_mfma_f32_16x16x32_bf16); the
+ * ACCUMULATION is not a correctly rounded sum: the matrix pipe aligns every addend to the largest one and cuts what falls below its
+ * last bit off toward -infinity, without a sticky bit -- addends below 2^-24 of the running sum are truncated, not rounded.  Per
+ * element the error equals the fp32-input kernels' (2e-7 rms of the output's scale); per COLUMN MEAN it is one-sided and grows with
+ * the reduction length, 1.2 .. 1.3e-10 * K of the column's sigma (3.4e-8 at K = 288, 5.8e-7 at K = 4608), ten times the fp32-input
+ * kernels' -- pinned with a factor-two margin by tests/test_split_gemm_gpu.py::test_split_gemm_column_mean_bias_follows_its_documented_law,
+ * and its effect on 30 training steps by ::test_thirty_steps_on_the_split_gemms_stay_with_the_fp32_kernels.  -DDL3P_SB_TWO_LEVEL=1
+ * (csrc/sb_common.h) removes the bias for 8-28 % of the kernels' time; DL3P_SPLIT_GEMM=0 returns every GEMM to the fp32-input kernels
+ * (bench.py reports that step as `fp32_mfma_only`). */
 int dl3p_split_bf16x3_batch(const float* src, void* dst, const int64_t* table, int n_matrices, void* stream);
 int dl3p_pwconv_sb_supported(int role, int M, int K, int N);
 int dl3p_pwconv_sb_pays(int role, int M, int K, int N);

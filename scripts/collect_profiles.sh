@@ -66,7 +66,12 @@ for line in open('$O/${R}_hbm_counters_dw.csv').read().splitlines()[1:]:
     if 'dw_fwd_lattice2' in kn:
         var.setdefault(kn.split('(')[0].replace('void ', ''), {})[c] = val
 if 'FETCH_SIZE' in t and 'WRITE_SIZE' in t:
-    json.dump({'kernel': 'dw_fwd_lattice2', 'fetch_size_kb_raw': t['FETCH_SIZE'], 'write_size_kb': t['WRITE_SIZE'],
+    import hashlib, os
+    def blob(f):
+        data = open(os.path.join('tf-keras-deeplabv3p-model-set_amd', f), 'rb').read()
+        return hashlib.sha1(b'blob %d\0' % len(data) + data).hexdigest()[:12]
+    json.dump({'kernel': 'dw_fwd_lattice2', 'source_hash': blob('csrc/dwconv.hip') + '+' + blob('csrc/dw_tuned.h'),
+               'fetch_size_kb_raw': t['FETCH_SIZE'], 'write_size_kb': t['WRITE_SIZE'],
                'traffic_bytes': int((2 * t['FETCH_SIZE'] + t['WRITE_SIZE']) * 1024),
                'variants_kb_raw': var,
                'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, eager launches; FETCH_SIZE doubled (gfx950)'},

@@ -13,6 +13,11 @@ PKG_NAME = 'tf-keras-deeplabv3p-model-set_amd'
 # the small-K.N streaming GEMM is only dispatched from 2^17 rows up in production; the parity tests run at
 # small sizes, so let it take every shape it supports (read once by libdl3p at first use)
 os.environ.setdefault('DL3P_PW_SMALL_MIN_ROWS', '64')
+# the oracle tests inject the device's activation branch pattern, which they rebuild from every conv output AS THE FORWARD SAW IT: a
+# fused inverted-residual block (executor._find_irb) keeps no expand output, so under test the forward also writes one with the unfused
+# kernel, for the tests to look at -- the fused kernels never read it (tests/test_irb_model_gpu.py::test_which_blocks_are_fused runs
+# without the hook and checks that the tensor then has no buffer at all)
+os.environ.setdefault('DL3P_IRB_DEBUG_Z', '1')
 
 
 def pytest_configure(config):

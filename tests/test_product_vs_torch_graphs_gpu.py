@@ -27,7 +27,7 @@ from test_product_vs_transformers_gpu import _weights  # noqa: E402
                                                 ('mobilenetv3large_lite', 64, 16, 21)])
 def test_predict_equals_the_independent_graph(mt, size, OS, classes):
     pkg = load_pkg()
-    N = 2
+    N = 1 if mt == 'xception' else 2          # (float64 Xception on the host: 17 s per image; inference-mode BatchNorm does not couple images)
     m, w = _weights(pkg, mt, classes, size, OS, training=False)
     rng = np.random.default_rng(5)
     x = rng.uniform(-1, 1, (N, size, size, 3)).astype(np.float32)

@@ -507,13 +507,16 @@ static void launch_sbr_one(const GemmParams& p, int grid, hipStream_t st) {
   dl3p_launch(pw_gemm_sbr_kernel<NK, CG, MODE, CPS, FOLD>, dim3(grid), dim3(512), (size_t)C::LDS_BYTES, st, p);
 }
 
+// -> false when no instantiation serves (reduction length, mode, fold): the caller then fails with DL3P_EINVAL instead of returning
+// success with the output untouched (the *_supported predicates keep these combinations unreachable today)
 template <int MODE>
-static void launch_sbr_nk(const GemmParams& p, int grid, hipStream_t st) {
+static bool launch_sbr_nk(const GemmParams& p, int grid, hipStream_t st) {
   const int nk = (p.K + 31) / 32;
   if (nk == 4) launch_sbr_one<4, 32, MODE>(p, grid, st);
   else if (nk == 6) launch_sbr_one<6, 32, MODE>(p, grid, st);
   else if (nk == 8 && p.f_z) {      // the folded BatchNorm-backward apply (data gradients only): two chunks per staging slot (registers)
     if constexpr (MODE != 1) launch_sbr_one<8, 32, MODE, 2, true>(p, grid, st);
+    else return false;
   } else if (nk == 8) {
     // K = 256: four chunks per staging slot (244 / 288 / 218 us forward / data gradient + sums / plain on 266256 rows against 255 / 311 /
     // 233 with two); K = 320: two -- five spill (335 against 372 us)
@@ -521,11 +524,14 @@ static void launch_sbr_nk(const GemmParams& p, int grid, hipStream_t st) {
     if (cps == 4) launch_sbr_one<8, 32, MODE, 4>(p, grid, st);
     else launch_sbr_one<8, 32, MODE, 2>(p, grid, st);
   }
-  else if constexpr (MODE != 2) {      // (K = 320 leaves no room for the second statistics patch)
-    static const int cg16 = getenv("DL3P_SB_RS_CG16") ? atoi(getenv("DL3P_SB_RS_CG16")) : 0;
-    if (cg16) launch_sbr_one<10, 16, MODE>(p, grid, st);
-    else launch_sbr_one<10, 32, MODE>(p, grid, st);
-  }
+  else if (nk == 10) {
+    if constexpr (MODE != 2) {      // (K = 320 leaves no room for the second statistics patch)
+      static const int cg16 = getenv("DL3P_SB_RS_CG16") ? atoi(getenv("DL3P_SB_RS_CG16")) : 0;
+      if (cg16) launch_sbr_one<10, 16, MODE>(p, grid, st);
+      else launch_sbr_one<10, 32, MODE>(p, grid, st);
+    } else return false;
+  } else return false;
+  return true;
 }
 
 // shapes served: reduction up to 320 (the A fragments of a row tile live in registers), up to 320 output columns (10 statistics
@@ -545,10 +551,10 @@ int dl3p_sb_rs_grid(int M) {
 }
 
 // p.num_m_tiles = half tiles of 64 rows; mode 0 plain, 1 statistics, 2 fused BatchNorm-backward sums
-void dl3p_launch_gemm_sbr(const GemmParams& p, int mode, int grid, hipStream_t st) {
-  if (mode == 2) launch_sbr_nk<2>(p, grid, st);
-  else if (mode == 1) launch_sbr_nk<1>(p, grid, st);
-  else launch_sbr_nk<0>(p, grid, st);
+bool dl3p_launch_gemm_sbr(const GemmParams& p, int mode, int grid, hipStream_t st) {
+  if (mode == 2) return launch_sbr_nk<2>(p, grid, st);
+  if (mode == 1) return launch_sbr_nk<1>(p, grid, st);
+  return launch_sbr_nk<0>(p, grid, st);
 }
 
 // the BatchNorm-backward apply folded into the staged operand of the data gradient: reductions of 225 .. 256 (the five per-channel

@@ -21,6 +21,7 @@
 // the next tile is issued before the current tile's MFMAs (register double buffering) and applies the
 // producer's BN+activation on the way in, so normalised activations are never materialised in HBM.
 #include "common.h"
+#include <limits.h>
 #include <type_traits>
 #include <string.h>
 
@@ -658,6 +659,18 @@ extern "C" int dl3p_set_option(const char* name, int value) {
   dl3p_set_error("dl3p_set_option: unknown option '%s'", name);
   return DL3P_EINVAL;
 }
+// the current value of the knobs that decide how many slabs / partial rows a traced launch writes ("split_wgrad", "conv_sb", "sb_rs",
+// "sb_pipe"): an executor records them when it traces its plans and pins them again before an eager replay;
+// INT_MIN for an unknown name
+extern "C" int dl3p_get_option(const char* name) {
+  if (!name) return INT_MIN;
+  if (g_sb_pipe < 0) g_sb_pipe = getenv("DL3P_SB_PIPE") ? atoi(getenv("DL3P_SB_PIPE")) : 0;
+  if (!strcmp(name, "split_wgrad")) return g_split_wgrad;
+  if (!strcmp(name, "conv_sb")) return g_conv_sb;
+  if (!strcmp(name, "sb_rs")) return g_sb_rs;
+  if (!strcmp(name, "sb_pipe")) return g_sb_pipe;
+  return INT_MIN;
+}
 
 static int pw_small_grid(int M) {
   static const int per_cu = getenv("DL3P_PW_SMALL_PER_CU") ? atoi(getenv("DL3P_PW_SMALL_PER_CU")) : 2;
@@ -1051,11 +1064,12 @@ void dl3p_launch_wgrad_sb_gx(const float* x, int ldx, const float* scale, const 
 bool dl3p_sb_wide_config(int nt, int mi, int wm);
 bool dl3p_sb_rs_supported(int role, int M, int K, int N);
 int dl3p_sb_rs_grid(int M);
-void dl3p_launch_gemm_sbr(const GemmParams& p, int mode, int grid, hipStream_t st);
+bool dl3p_launch_gemm_sbr(const GemmParams& p, int mode, int grid, hipStream_t st);
 // the row-stationary form (pw_split_rs.hip; gemm_plan_sb reports it as wm = 3): pinned by dl3p_set_option("sb_rs", 1), otherwise by
 // the measured table ({2, 1, 103} rows of csrc/sb_tuned.h) or the rule below
 static bool sb_rs_route(int role, int M, int K, int N) {
   if (!dl3p_sb_rs_supported(role, M, K, N)) return false;
+  if (g_sb_pipe < 0) g_sb_pipe = getenv("DL3P_SB_PIPE") ? atoi(getenv("DL3P_SB_PIPE")) : 0;      // (before its first use: ADVICE r04)
   if (g_sb_force_wm != 0 || g_sb_pipe > 0 || g_gemm_force_nt || g_gemm_force_mi) return false;     // another form is pinned
   if (g_sb_rs < 0) {
     static const int env = getenv("DL3P_SB_RS") ? atoi(getenv("DL3P_SB_RS")) : -1;
@@ -1192,7 +1206,7 @@ extern "C" int dl3p_pwconv_fwd_sb(const float* x, int ldx, const float* in_scale
   gemm_plan_sb(stat_partials ? 1 : 0, M, K, N, &nt, &gx, &gy, &p.num_m_tiles, &mi, &wm);
   { const char* e = getenv("DL3P_SB_ABLATE"); p.stagger = e ? atoi(e) : 0; if (p.stagger == 100) p.B = stat_partials + (size_t)DL3P_MAX_STAT_ROWS * 2 * N; }      // (ablation build: stamps behind the partial rows)
   if (rows_out) *rows_out = gx;
-  if (wm == 3) dl3p_launch_gemm_sbr(p, stat_partials ? 1 : 0, gx, (hipStream_t)stream);
+  if (wm == 3) DL3P_CHECK_ARG(dl3p_launch_gemm_sbr(p, stat_partials ? 1 : 0, gx, (hipStream_t)stream), "%s: no row-stationary instantiation for K=%d", fn, K);
   else if (wm == 0) dl3p_launch_gemm_sbp(p, stat_partials != nullptr, false, nt, mi, dim3(gx, gy), (hipStream_t)stream);
   else dl3p_launch_gemm_sb(p, stat_partials != nullptr, false, false, nt, mi, wm, dim3(gx, gy), (hipStream_t)stream);
   DL3P_CHECK_LAUNCH(fn);
@@ -1233,7 +1247,7 @@ extern "C" int dl3p_pwconv_bwd_data_sb(const float* dy, int lddy, const void* ws
   int nt, gxn, gy, mi, wm;
   gemm_plan_sb(bnb ? 3 : 2, M, N, K, &nt, &gxn, &gy, &p.num_m_tiles, &mi, &wm);
   if (rows_out) *rows_out = gxn;
-  if (wm == 3) dl3p_launch_gemm_sbr(p, bnb ? 2 : 0, gxn, (hipStream_t)stream);
+  if (wm == 3) DL3P_CHECK_ARG(dl3p_launch_gemm_sbr(p, bnb ? 2 : 0, gxn, (hipStream_t)stream), "%s: no row-stationary instantiation for K=%d", fn, N);
   else if (wm == 0) dl3p_launch_gemm_sbp(p, bnb, bnb, nt, mi, dim3(gxn, gy), (hipStream_t)stream);
   else dl3p_launch_gemm_sb(p, bnb, bnb, false, nt, mi, wm, dim3(gxn, gy), (hipStream_t)stream);
   DL3P_CHECK_LAUNCH(fn);
@@ -1292,7 +1306,7 @@ extern "C" int dl3p_pwconv_bwd_data_sb_apply(const float* g, int ldg, const floa
   p.num_m_tiles = ceil_div(M, 64);
   const int gxn = dl3p_sb_rs_grid(M);
   if (rows_out) *rows_out = gxn;
-  dl3p_launch_gemm_sbr(p, bnb ? 2 : 0, gxn, (hipStream_t)stream);
+  DL3P_CHECK_ARG(dl3p_launch_gemm_sbr(p, bnb ? 2 : 0, gxn, (hipStream_t)stream), "dl3p_pwconv_bwd_data_sb_apply: no row-stationary instantiation for K=%d", N);
   DL3P_CHECK_LAUNCH(fn);
   return DL3P_OK;
 }

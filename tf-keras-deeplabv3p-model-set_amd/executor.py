@@ -448,6 +448,9 @@ class Executor:
         # is process-wide there, so every executor states its own before it sizes workspaces, traces, or runs eagerly
         self._split_wgrad = int(split_gemm_enabled() and not self.bf16 and os.environ.get('DL3P_SPLIT_WGRAD', '1') not in ('', '0'))
         self.L.set_option(b'split_wgrad', self._split_wgrad)
+        # ... and the other process-wide knobs that decide how many slabs / partial rows a traced launch writes: recorded now, pinned
+        # again before every eager replay (_pin_options; a captured graph carries its launches' grids with it)
+        self._pinned = {k: self.L.get_option(k) for k in (b'conv_sb', b'sb_rs', b'sb_pipe')}
         self._find_irb()
         self._alloc()
         # tracing runs every kernel once on zero inputs: keep the weights / optimiser state intact
@@ -1987,10 +1990,16 @@ class Executor:
         if st.Sb is not None and st.sb_partial is not None and st.sb_partial is not self:
             st.transpose()
 
-    def train_step(self):
-        self._sb_sync()
+    def _pin_options(self):
         if not self.graphed:
             self.L.set_option(b'split_wgrad', self._split_wgrad)
+            for k, v in self._pinned.items():
+                if self.L.get_option(k) != v:
+                    self.L.set_option(k, v)
+
+    def train_step(self):
+        self._sb_sync()
+        self._pin_options()
         self.fwd.run()
         self.bwd.run()
         self.opt.run()
@@ -1999,6 +2008,7 @@ class Executor:
 
     def forward(self):
         self._sb_sync()
+        self._pin_options()
         self.fwd.run()
 
     def eval_step(self, confusion, pred=None):
