@@ -432,7 +432,7 @@ def test_split_gemm_column_mean_bias_follows_its_documented_law(ops, K):
         rms = float((e ** 2).mean().sqrt() / (y64 ** 2).mean().sqrt())
         noise = rms / M ** 0.5 * 4                      # what the mean of M unbiased errors of that rms could reach
         assert bias < 2.6e-10 * K + 2e-8 + noise, ('forward', K, bias, rms)
-        assert rms < 3e-7, rms
+        assert rms < 2.2e-8 * K ** 0.5, rms             # (the unbiased part grows like a random walk over the reduction)
         # data gradient: the reduction runs over the conv's OUTPUT channels (here K of them), result (M, N2)
         N2 = 256
         dy = torch.randn(M, K, device=DEV, generator=g)
@@ -466,7 +466,7 @@ def test_thirty_steps_on_the_split_gemms_stay_with_the_fp32_kernels(monkeypatch)
         y[rng.uniform(size=y.shape) < 0.05] = 255
         ys.append(y)
 
-    def run(split):
+    def run(split, nudge=1.0):
         monkeypatch.setenv('DL3P_SPLIT_GEMM', '1' if split else '0')
         for k, v in (('DL3P_SPLIT_MIN_K', '32'), ('DL3P_SPLIT_MIN_N', '16'), ('DL3P_SPLIT_MIN_ROWS', '64'), ('DL3P_SPLIT_MIN_ROWS_BN', '64')):
             monkeypatch.setenv(k, v)
@@ -474,23 +474,41 @@ def test_thirty_steps_on_the_split_gemms_stay_with_the_fp32_kernels(monkeypatch)
         m = pkg.get_deeplabv3p_model('mobilenetv2', C, (H, W), 16, training=True)
         m.compile(optimizer=pkg.SGD(0.01, momentum=0.9), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
         m.use_graphs = False
-        losses = [m.train_on_batch(xs[i % 6], ys[i % 6]) for i in range(30)]
+        start = {k: np.array(v, dtype=np.float64) for k, v in m.get_weights_by_name().items()}
+        losses = [m.train_on_batch(xs[i % 6] * np.float32(nudge), ys[i % 6]) for i in range(30)]
         ex = m._executor(N, True)
         took = any('pwconv_fwd_sb' in lab[0] for lab in ex.fwd.labels)
-        return losses, m.get_weights_by_name(), took
+        return losses, m.get_weights_by_name(), took, start
 
-    l1, w1, took1 = run(True)
-    l0, w0, took0 = run(False)
+    l1, w1, took1, _ = run(True)
+    l0, w0, took0, start = run(False)
+    # the control: the fp32-input kernels again on images scaled by 1 + 2.4e-7 (every pixel moves by one or two float32 ulps): what a
+    # rounding-sized perturbation alone does to 30 steps
+    lc, wc, _, _ = run(False, nudge=1.0 + 2.4e-7)
     assert took1 and not took0
-    drift = max(float(np.abs(w1[k] - w0[k]).max() / max(1e-6, np.abs(w0[k]).max())) for k in w0 if not k.endswith(('moving_mean', 'moving_variance')))
+    keys = [k for k in w0 if not k.endswith(('moving_mean', 'moving_variance'))]
+    num = sum(float(((w1[k].astype(np.float64) - w0[k]) ** 2).sum()) for k in keys)
+    den = sum(float((w0[k].astype(np.float64) ** 2).sum()) for k in keys)
+    drift = (num / den) ** 0.5                          # relative l2 distance of the two weight vectors after 30 steps
+    moved = (sum(float(((w0[k].astype(np.float64) - start[k]) ** 2).sum()) for k in keys) / den) ** 0.5      # ... of the fp32 run from its start
+    control = (sum(float(((wc[k].astype(np.float64) - w0[k]) ** 2).sum()) for k in keys) / den) ** 0.5     # ... of two fp32 runs from each other
+    dlc = max(abs(a - b) / abs(b) for a, b in zip(lc, l0))
     dl = max(abs(a - b) / abs(b) for a, b in zip(l1, l0))
     try:
         d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
         os.makedirs(d, exist_ok=True)
-        json.dump({'loss_split': l1, 'loss_fp32': l0, 'worst_relative_weight_drift': drift, 'worst_relative_loss_difference': dl},
+        json.dump({'loss_split': l1, 'loss_fp32': l0, 'relative_l2_weight_drift': drift, 'relative_l2_moved_from_start': moved, 'relative_l2_control_drift': control, 'control_loss_difference': dlc, 'worst_relative_loss_difference': dl},
                   open(os.path.join(d, 'split_trajectory.json'), 'w'))
     except OSError:
         pass
-    assert l1[-1] < l1[0] and l0[-1] < l0[0]           # both learn
+    # Two fp32 trajectories that differ in rounding only part ways too: a ReLU6 branch flipped in step 3 is an O(1) change of one
+    # activation, and 30 steps of momentum SGD carry it on (the un-injected gradient comparisons of tests/test_product_vs_*_gpu.py
+    # sit at 1e-2 for ONE step).  What a biased estimator would add is a DRIFT of the loss curve in one direction; what is measured is
+    # a difference that changes sign from step to step (gpurun_out/split_trajectory.json) and a weight distance far below the
+    # distance either run has moved from its start.
+    assert l1[-1] < l1[0] - 0.05 and l0[-1] < l0[0] - 0.05           # both learn
     assert dl < 2e-2, dl
-    assert drift < 0.1, drift
+    signs = [np.sign(a - b) for a, b in zip(l1[5:], l0[5:])]
+    assert 0.2 < np.mean(np.array(signs) > 0) < 0.8, signs          # no one-sided offset of the loss curve
+    assert abs(float(np.mean(np.array(l1[5:]) - np.array(l0[5:])))) < 5e-3
+    assert drift < 2.0 * control + 1e-3, (drift, control, moved)
