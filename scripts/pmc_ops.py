@@ -19,18 +19,34 @@ REPS = 5
 
 
 def xception():
-    for (M, K, N) in [(4356, 1536, 2048), (4356, 728, 728), (4356, 2048, 256), (66564, 304, 256)]:
+    """BASELINE configs[2]: the 4356-row GEMMs through the entry points the STEP takes them on: the split-bf16
+    kernels wherever the library's verdict table / rule says so (middle flow 728 -> 728, exit flow 1536 -> 2048, the split weight
+    gradients), the fp32-input kernels elsewhere (aspp0 2048 -> 256 and concat_projection 1280 -> 256 forward)"""
+    for (M, K, N) in [(4356, 1536, 2048), (4356, 728, 728), (4356, 2048, 256), (4356, 1280, 256), (66564, 304, 256)]:
         x = torch.randn(M, K, device=dev)
         wt = torch.randn(N, K, device=dev) / K ** 0.5
         w = wt.t().contiguous()
+        wsp, w_sp = ops.split_bf16x3(wt), ops.split_bf16x3(w)
         sc, sh = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.3
         part, partk = ops.new_partials(N, dev), ops.new_partials(K, dev)
         dy, z = torch.randn(M, N, device=dev), torch.randn(M, K, device=dev)
         mean, invstd = torch.zeros(K, device=dev), torch.ones(K, device=dev)
+        # the executor's own question (executor._use_sb): measured verdict first, then the rule K >= 128, N >= 128, 16384 rows
+        def sb(role, kred, nout):
+            pays = L.pwconv_sb_pays(role, M, kred, nout)
+            if pays < 0:
+                pays = int(kred >= 128 and nout >= 128 and M >= (60000 if role == 3 else 16384))
+            return bool(pays) and bool(L.pwconv_sb_supported(role, M, kred, nout))
         for _ in range(REPS):
-            ops.pwconv_fwd_wt(x, wt, None, sc, sh, ops.ACT_RELU, partials=part)
-            ops.pwconv_bwd_data_bn(dy, w, z, sc, sh, ops.ACT_RELU, mean, invstd, partk)
-            ops.pwconv_bwd_weight(x, dy, sc, sh, ops.ACT_RELU)
+            if sb(1, K, N):
+                ops.pwconv_fwd_sb(x, wsp, K, None, sc, sh, ops.ACT_RELU, partials=part)
+            else:
+                ops.pwconv_fwd_wt(x, wt, None, sc, sh, ops.ACT_RELU, partials=part)
+            if sb(3, N, K):
+                ops.pwconv_bwd_data_sb(dy, w_sp, N, z=z, scale=sc, shift=sh, act=ops.ACT_RELU, mean=mean, invstd=invstd, partials=partk)
+            else:
+                ops.pwconv_bwd_data_bn(dy, w, z, sc, sh, ops.ACT_RELU, mean, invstd, partk)
+            ops.pwconv_bwd_weight(x, dy, sc, sh, ops.ACT_RELU)        # (routes itself onto pw_wgrad_sb_kernel: wgrad_sb_route)
     for r in (6, 12, 18):
         x = torch.randn(4, 33, 33, 2048, device=dev)
         w = torch.randn(3, 3, 2048, device=dev) * 0.3
