@@ -482,6 +482,18 @@ int dl3p_head_train_supported(int h, int w, int C, int H, int W);
 int dl3p_head_train(const float* z, int ldz, const float* labels, int ignore_index, float inv_count,
                     float* gz, int ldgz, int accumulate, float* loss_partials, int* rows_out,
                     int N, int h, int w, int C, int H, int W, void* stream);
+/* The fused training head in its SEPARABLE form (round 5, csrc/resize_head.hip): the transposed bilinear resize factorises into an x
+ * and a y half.  x pass: workgroups walk full-resolution rows -- softmax / loss / gradient of a row into LDS, the transposed resize of
+ * that row in x -> workspace (N,H,w,Cpad), 1/(W/w) of the full-resolution gradient; y pass: the rows of the workspace onto the logit
+ * rows.  Arguments and results as dl3p_head_train plus the workspace (dl3p_head_train_rows_workspace bytes, 16-byte aligned); the
+ * gradient equals dl3p_upsample_softmax_loss + dl3p_resize_bilinear_bwd to rounding (x-then-y summation), not bit for bit.
+ * Plain sparse cross-entropy only (no class / pixel weights, no focal loss).  Served: Cpad in {20, 24, 32}, W / w <= 4,
+ * w * Cpad / 4 <= 1024, (2 w + W) * Cpad * 4 bytes of LDS <= 150 KB.  rows_out: loss partial rows written (<= 2 x CUs). */
+int dl3p_head_train_rows_supported(int h, int w, int C, int H, int W);
+size_t dl3p_head_train_rows_workspace(int N, int h, int w, int C, int H, int W);
+int dl3p_head_train_rows(const float* z, int ldz, const float* labels, int ignore_index, float inv_count, float* gz, int ldgz,
+                         int accumulate, float* loss_partials, int* rows_out, void* workspace, size_t workspace_bytes,
+                         int N, int h, int w, int C, int H, int W, void* stream);
 /* out[n] (+)= sum over rows of partials[rows][n]   (loss, wgrad slabs) */
 int dl3p_reduce_rows(const float* partials, int rows, size_t n, float* out, int accumulate, void* stream);
 /* The weight gradients of a whole step reduced in two launches instead of one per layer.  dl3p_*_bwd_weight_slabs are the

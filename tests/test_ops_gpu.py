@@ -807,6 +807,50 @@ def test_head_train_fused(ops, case):
     assert not ops.head_train_supported(33, 33, 21, 513, 513)
 
 
+@pytest.mark.parametrize('case', [(2, 9, 9, 33, 33, 21, 255), (1, 33, 33, 129, 129, 19, 255), (2, 17, 23, 65, 89, 21, 0),
+                                  (3, 5, 7, 5, 7, 18, 255), (2, 11, 6, 41, 21, 32, 255), (1, 129, 129, 513, 513, 21, 255),
+                                  (1, 97, 97, 385, 385, 21, 255)])
+def test_head_train_rows_form(ops, case):
+    """the row-walking fused training head == the two-kernel head to rounding (x-then-y summation), and == the oracle"""
+    N, h, w, H, W, C, ignore = case
+    assert ops.head_train_rows_supported(h, w, C, H, W)
+    rng = np.random.default_rng(C + h)
+    cp = ((C + 3) // 4) * 4
+    z = np.zeros((N, h, w, cp)); z[..., :C] = rng.standard_normal((N, h, w, C)) * 3
+    lab = rng.integers(0, C, (N, H, W)).astype(np.float64)
+    lab[rng.uniform(size=lab.shape) < 0.1] = 255
+    labels = T(lab.reshape(N, H * W, 1))
+    loss, gz = ops.head_train(T(z), C, H, W, labels, ignore, rows_form=True)
+    two = ops.upsample_softmax_ce(T(z), C, H, W, labels, ignore, want_grad=True)
+    gz2 = ops.resize_bilinear_bwd(two['dlogits'], h, w)
+    scale = float(gz2.abs().max())
+    assert float((gz - gz2).abs().max()) <= 4e-6 * scale, (float((gz - gz2).abs().max()), scale)
+    assert float(gz[..., C:].abs().max()) == 0.0 if cp > C else True
+    close(loss, two['loss'].cpu().numpy(), rtol=1e-5, what='rows-form loss vs two-kernel loss')
+    if H * W <= 129 * 129:
+        big = O.resize_bilinear_fwd(z[..., :C], H, W)
+        loss_ref, _, g_ref = O.sparse_ce_fwd_bwd(big, lab, ignore)
+        close(loss, [loss_ref], rtol=1e-4, what='rows-form loss')
+        close(gz[..., :C], O.resize_bilinear_bwd(g_ref, h, w), rtol=1e-4, atol=1e-9, what='rows-form d loss / d z')
+    # accumulate: a second launch on top of the first doubles the gradient
+    L = ops.lib()
+    import ctypes as ct
+    part = torch.zeros(4096, device=DEV); rows = ct.c_int(0)
+    zt = T(z)
+    wsb = L.head_train_rows_workspace(N, h, w, C, H, W)
+    assert wsb == 4 * N * H * w * cp
+    ws = torch.empty(wsb // 4, device=DEV)
+    L.head_train_rows(zt.data_ptr(), cp, labels.data_ptr(), int(ignore or 0), 1.0 / (N * H * W), gz.data_ptr(), cp, 1,
+                      part.data_ptr(), ct.byref(rows), ws.data_ptr(), wsb, N, h, w, C, H, W, None)
+    torch.cuda.synchronize()
+    assert float((gz - 2 * gz2).abs().max()) <= 8e-6 * scale
+    assert 1 <= rows.value <= min(N * H, 2 * L.device_cus())
+    with pytest.raises(ops.Dl3pError):
+        L.head_train_rows(zt.data_ptr(), cp, labels.data_ptr(), int(ignore or 0), 1.0 / (N * H * W), gz.data_ptr(), cp, 1,
+                          part.data_ptr(), ct.byref(rows), ws.data_ptr(), wsb - 16, N, h, w, C, H, W, None)
+    assert not ops.head_train_rows_supported(33, 33, 21, 513, 513) and not ops.head_train_rows_supported(9, 9, 40, 33, 33)
+
+
 def test_se_multiply_and_bare_activation(ops):
     rng = np.random.default_rng(21)
     N, H, W, C = 3, 7, 9, 24

@@ -856,3 +856,255 @@ extern "C" int dl3p_head_train(const float* z, int ldz, const float* labels, int
   DL3P_CHECK_LAUNCH("dl3p_head_train");
   return DL3P_OK;
 }
+
+// ------------------------------------------------------------------------------ fused training head, separable form (round 5)
+// pred_resize + Softmax + cross-entropy + the transposed pred_resize of the gradient with a QUARTER of the (N,H,W,C) gradient's HBM
+// traffic (404 MB written and read back at batch 16 / 513x513): the transposed bilinear resize factorises, G_low = Ry^T (G_high Rx),
+// and its x half needs one full-resolution row at a time.
+//   x pass: a workgroup walks a contiguous chunk of full-resolution rows (2 workgroups per CU cover the batch in one round).  Per row:
+//     the two logit rows it interpolates between are in LDS (they change every ~H/h rows); one pixel per thread -> interpolated
+//     logits, softmax, loss, gradient -> an LDS row [W][CP]; then every (logit column, 4 channels) item gathers its <= 12 pixels of
+//     that row with weights it computed once per workgroup and stores the row of G_high Rx: (N,H,w,CP), 1 / (W/w) of the gradient.
+//   y pass: one thread per (logit pixel, 4 channels) adds up its <= ~2 H/h rows of that tensor -- coalesced, 16 bytes per lane.
+// Against dl3p_head_train (the tile kernel): no 100 KB gradient tile with 2.1x the pixels evaluated and one workgroup per CU.
+// Summation order differs from dl3p_resize_bilinear_bwd (x first, then y): equal to rounding, not bit for bit.
+struct HeadRowsParams {
+  const float* z; int ldz; const float* labels; int ignore_index; float inv_count;
+  float* gxh; float* loss_partials;
+  int N, h, w, C, H, W, chunk;
+};
+
+typedef float hr_f2 __attribute__((ext_vector_type(2)));
+
+// plane stride (floats) of the LDS gradient row [CP/4][W] float4: = 4 (mod 64), so that the six channel quads of a logit column and
+// the columns next to it (16 floats apart at W / w = 4) fall on different LDS banks in the gather
+__host__ __device__ static inline int head_rows_plane(int W) { return 4 * W + ((4 - (4 * W) % 64) + 64) % 64; }
+
+template <int CP, int NI>
+__global__ __launch_bounds__(256, 2) void head_xpass_kernel(HeadRowsParams p) {
+  constexpr int C4 = CP / 4;
+  extern __shared__ __attribute__((aligned(16))) float hr_lds[];
+  float* zr = hr_lds;                                   // [2][w][CP]: logit rows lo, hi
+  float* gr = hr_lds + 2 * p.w * CP;                    // [CP/4][plane]: gradient of the current full-resolution row, channel-quad planes
+  __shared__ float wsum[4];
+  const int t = threadIdx.x;
+  const int PW = head_rows_plane(p.W);
+  const float sy = (float)p.h / (float)p.H, sx = (float)p.w / (float)p.W;
+  const float isx = (float)p.W / (float)p.w;
+  const int rows_total = p.N * p.H;
+  const int r0 = blockIdx.x * p.chunk, r1 = min(r0 + p.chunk, rows_total);
+  // this thread's items of the transposed resize in x: (logit column j, channel quad c4); window start and weights, once
+  int x0s[NI];
+  float wxs[NI][RB_MAXW];
+#pragma unroll
+  for (int m = 0; m < NI; ++m) {
+    const int it = t + 256 * m;
+    const bool on = it < p.w * C4;
+    const int j = on ? it / C4 : -1;
+    int x0 = 0, x1 = -1;
+    if (on) {
+      touch_range(j, isx, p.W, x0, x1);
+      if (j == 0) x0 = 0;
+      if (j == p.w - 1) x1 = p.W - 1;
+    }
+    x0s[m] = x0;
+#pragma unroll
+    for (int k = 0; k < RB_MAXW; ++k) {
+      const int ox = min(x0 + k, p.W - 1);
+      const Lerp lx = lerp_coeff(ox, sx, p.w);
+      const float wx = (lx.lo == j ? 1.f - lx.t : 0.f) + (lx.hi == j ? lx.t : 0.f);
+      wxs[m][k] = (on && x0 + k <= x1) ? wx : 0.f;
+    }
+  }
+  float loss = 0.f;
+  int have_n = -1, have_lo = -1, have_hi = -1;
+  for (int row = r0; row < r1; ++row) {
+    const int n = row / p.H, Y = row - n * p.H;
+    const Lerp ly = lerp_coeff(Y, sy, p.h);
+    __syncthreads();                                     // the previous row's gather is done with gr (and zr)
+    if (n != have_n || ly.lo != have_lo || ly.hi != have_hi) {
+      const float* zimg = p.z + (size_t)n * p.h * p.w * p.ldz;
+      for (int i = t; i < 2 * p.w * C4; i += 256) {
+        const int c4 = i % C4, px = (i / C4) % p.w, which = i / (C4 * p.w);
+        const int zy = which ? ly.hi : ly.lo;
+        *reinterpret_cast<float4*>(&zr[(which * p.w + px) * CP + c4 * 4]) = ld4(zimg + ((size_t)zy * p.w + px) * p.ldz + c4 * 4);
+      }
+      have_n = n; have_lo = ly.lo; have_hi = ly.hi;
+      __syncthreads();
+    }
+    const float* lrow = p.labels + (size_t)row * p.W;
+    for (int X = t; X < p.W; X += 256) {
+      const Lerp lx = lerp_coeff(X, sx, p.w);
+      const float* ptl = zr + lx.lo * CP;
+      const float* ptr = zr + lx.hi * CP;
+      const float* pbl = zr + (p.w + lx.lo) * CP;
+      const float* pbr = zr + (p.w + lx.hi) * CP;
+      // the same expression as head_kernel (top + (bot - top) * ty, unfused), two channels per packed instruction
+      hr_f2 v[CP / 2];
+      const hr_f2 tx2 = {lx.t, lx.t}, ty2 = {ly.t, ly.t};
+#pragma unroll
+      for (int c4 = 0; c4 < C4; ++c4) {
+        const float4 tl = *reinterpret_cast<const float4*>(ptl + c4 * 4), tr = *reinterpret_cast<const float4*>(ptr + c4 * 4);
+        const float4 bl = *reinterpret_cast<const float4*>(pbl + c4 * 4), br = *reinterpret_cast<const float4*>(pbr + c4 * 4);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const hr_f2 a = hh ? hr_f2{tl.z, tl.w} : hr_f2{tl.x, tl.y}, b = hh ? hr_f2{tr.z, tr.w} : hr_f2{tr.x, tr.y};
+          const hr_f2 c = hh ? hr_f2{bl.z, bl.w} : hr_f2{bl.x, bl.y}, d = hh ? hr_f2{br.z, br.w} : hr_f2{br.x, br.y};
+          const hr_f2 top = a + (b - a) * tx2, bot = c + (d - c) * tx2;
+          v[c4 * 2 + hh] = top + (bot - top) * ty2;
+        }
+      }
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int c = 0; c < CP; ++c) if (c < CP - 3 || c < p.C) mx = fmaxf(mx, v[c >> 1][c & 1]);   // (Cpad - C <= 3)
+      float sum = 0.f;
+#pragma unroll
+      for (int c = 0; c < CP; ++c) {
+        const float e = (c < CP - 3 || c < p.C) ? __expf(v[c >> 1][c & 1] - mx) : 0.f;
+        v[c >> 1][c & 1] = e;
+        sum += e;
+      }
+      const float inv = 1.f / sum;
+      const int lab = (int)lrow[X];
+      const bool masked = p.ignore_index != 0 && lab == p.ignore_index;
+      const bool valid = !masked && lab >= 0 && lab < p.C;
+      // the label's probability: its logit again from the four LDS corners (the same expression -> the same bits) instead of a
+      // 24-way select over the registers
+      float pt = 0.f;
+      if (valid) {
+        const float a = ptl[lab], b = ptr[lab], c = pbl[lab], d = pbr[lab];
+        const float top = a + (b - a) * lx.t, bot = c + (d - c) * lx.t;
+        pt = __expf((top + (bot - top) * ly.t) - mx) * inv;
+      }
+      const bool unclipped = pt > 1e-7f && pt < 1.f - 1e-7f;
+      if (valid) loss += -logf(fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f));
+      const float gs = (valid && unclipped) ? p.inv_count : 0.f;
+      const hr_f2 inv2 = {inv, inv}, gs2 = {gs, gs};
+      float* gpx = gr + X * 4;
+#pragma unroll
+      for (int c4 = 0; c4 < C4; ++c4) {
+        // gs * (p - 0): the label's channel is patched below (gs * (p - 1))
+        const hr_f2 d0 = gs2 * (v[c4 * 2] * inv2), d1 = gs2 * (v[c4 * 2 + 1] * inv2);
+        *reinterpret_cast<float4*>(gpx + c4 * PW) = make_float4(d0[0], d0[1], d1[0], d1[1]);
+      }
+      if (valid) gpx[(lab >> 2) * PW + (lab & 3)] = gs * (pt - 1.f);
+    }
+    __syncthreads();
+    float* orow = p.gxh + (size_t)row * p.w * CP;
+#pragma unroll
+    for (int m = 0; m < NI; ++m) {
+      const int it = t + 256 * m;
+      if (it >= p.w * C4) continue;
+      float4 xr = zero4();
+      const float* gp = gr + (it % C4) * PW;
+#pragma unroll
+      for (int k = 0; k < RB_MAXW; ++k) {
+        const float4 g = *reinterpret_cast<const float4*>(gp + min(x0s[m] + k, p.W - 1) * 4);
+        xr.x = fmaf(g.x, wxs[m][k], xr.x); xr.y = fmaf(g.y, wxs[m][k], xr.y);
+        xr.z = fmaf(g.z, wxs[m][k], xr.z); xr.w = fmaf(g.w, wxs[m][k], xr.w);
+      }
+      st4(orow + (size_t)it * 4, xr);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) loss += __shfl_xor(loss, off);
+  if ((t & 63) == 0) wsum[t >> 6] = loss;
+  __syncthreads();
+  if (t == 0) p.loss_partials[blockIdx.x] = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) * p.inv_count;
+}
+
+struct HeadYParams { const float* gxh; float* gz; int ldgz; int accumulate; int N, h, w, H, c4s, cp; long long total; };
+
+__global__ __launch_bounds__(256) void head_ypass_kernel(HeadYParams p) {
+  const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (s >= p.total) return;
+  const int c4 = (int)(s % p.c4s);
+  const long long px = s / p.c4s;
+  const int j = (int)(px % p.w);
+  const int row = (int)(px / p.w);
+  const int i = row % p.h, n = row / p.h;
+  const float sy = (float)p.h / (float)p.H, isy = (float)p.H / (float)p.h;
+  int y0, y1;
+  touch_range(i, isy, p.H, y0, y1);
+  if (i == 0) y0 = 0;
+  if (i == p.h - 1) y1 = p.H - 1;
+  float4 acc = zero4();
+  const float* src = p.gxh + (((size_t)n * p.H) * p.w + j) * p.cp + c4 * 4;
+  for (int Y = y0; Y <= y1; ++Y) {
+    const Lerp ly = lerp_coeff(Y, sy, p.h);
+    const float wy = (ly.lo == i ? 1.f - ly.t : 0.f) + (ly.hi == i ? ly.t : 0.f);
+    if (wy == 0.f) continue;
+    const float4 g = ld4(src + (size_t)Y * p.w * p.cp);
+    acc.x = fmaf(g.x, wy, acc.x); acc.y = fmaf(g.y, wy, acc.y); acc.z = fmaf(g.z, wy, acc.z); acc.w = fmaf(g.w, wy, acc.w);
+  }
+  float* o = p.gz + (size_t)px * p.ldgz + c4 * 4;
+  if (p.accumulate) acc = add4(acc, ld4(o));
+  st4(o, acc);
+}
+
+static int head_rows_ni(int w, int cp) { return ceil_div(w * (cp / 4), 256); }
+static size_t head_rows_lds(int w, int W, int cp) { return sizeof(float) * ((size_t)cp * 2 * w + (size_t)(cp / 4) * head_rows_plane(W)); }
+
+extern "C" int dl3p_head_train_rows_supported(int h, int w, int C, int H, int W) {
+  const int cp = ((C + 3) / 4) * 4;
+  if (!(cp == 20 || cp == 24 || cp == 32) || h < 1 || w < 1 || H < h || W < w) return 0;
+  const float isx = (float)W / (float)w;
+  if (2.f * isx + 4.f > (float)RB_MAXW) return 0;                         // the x window of a logit column fits the weight table
+  if (head_rows_ni(w, cp) > 4) return 0;
+  if (head_rows_lds(w, W, cp) > 150 * 1024) return 0;
+  return 1;
+}
+
+extern "C" size_t dl3p_head_train_rows_workspace(int N, int h, int w, int C, int H, int W) {
+  (void)h; (void)W;
+  const int cp = ((C + 3) / 4) * 4;
+  return sizeof(float) * (size_t)N * H * w * cp;
+}
+
+template <int CP, int NI>
+static void launch_head_xpass(const HeadRowsParams& p, unsigned grid, size_t lds, hipStream_t st) {
+  (void)hipFuncSetAttribute((const void*)head_xpass_kernel<CP, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  hipLaunchKernelGGL((head_xpass_kernel<CP, NI>), dim3(grid), dim3(256), lds, st, p);
+}
+
+extern "C" int dl3p_head_train_rows(const float* z, int ldz, const float* labels, int ignore_index, float inv_count, float* gz,
+                                    int ldgz, int accumulate, float* loss_partials, int* rows_out, void* workspace,
+                                    size_t workspace_bytes, int N, int h, int w, int C, int H, int W, void* stream) {
+  DL3P_CHECK_ARG(z && labels && gz && loss_partials && workspace && aligned16(z) && aligned16(gz) && aligned16(workspace) &&
+                 ldz % 4 == 0 && ldgz % 4 == 0, "dl3p_head_train_rows: null / misaligned pointer");
+  DL3P_CHECK_ARG(dl3p_head_train_rows_supported(h, w, C, H, W), "dl3p_head_train_rows: %dx%d -> %dx%d, %d classes not supported "
+                 "(use dl3p_upsample_softmax_loss + dl3p_resize_bilinear_bwd)", h, w, H, W, C);
+  const int cp = ((C + 3) / 4) * 4;
+  DL3P_CHECK_ARG(ldz >= cp && ldgz >= cp, "dl3p_head_train_rows: ld=%d/%d must be >= %d", ldz, ldgz, cp);
+  DL3P_CHECK_ARG(workspace_bytes >= dl3p_head_train_rows_workspace(N, h, w, C, H, W), "dl3p_head_train_rows: workspace of %zu bytes, "
+                 "%zu needed", workspace_bytes, dl3p_head_train_rows_workspace(N, h, w, C, H, W));
+  DL3P_CHECK_ARG((long long)N * H < (1ll << 31) / (long long)(w * cp), "dl3p_head_train_rows: batch too large");
+  HeadRowsParams p = {};
+  p.z = z; p.ldz = ldz; p.labels = labels; p.ignore_index = ignore_index; p.inv_count = inv_count;
+  p.gxh = (float*)workspace; p.loss_partials = loss_partials;
+  p.N = N; p.h = h; p.w = w; p.C = C; p.H = H; p.W = W;
+  // one round of two workgroups per CU; never more workgroups than loss partial rows
+  const int rows_total = N * H;
+  const int slots = std::min(2 * dl3p_device_cus(), (int)DL3P_MAX_STAT_ROWS);
+  p.chunk = std::max(1, ceil_div(rows_total, slots));
+  const int blocks = ceil_div(rows_total, p.chunk);
+  if (rows_out) *rows_out = blocks;
+  const size_t lds = head_rows_lds(w, W, cp);
+  const int ni = head_rows_ni(w, cp);
+  hipStream_t st = (hipStream_t)stream;
+#define HR_CASE(CC) \
+  if (cp == CC) { \
+    if (ni <= 1) launch_head_xpass<CC, 1>(p, (unsigned)blocks, lds, st); \
+    else if (ni <= 2) launch_head_xpass<CC, 2>(p, (unsigned)blocks, lds, st); \
+    else launch_head_xpass<CC, 4>(p, (unsigned)blocks, lds, st); \
+  }
+  HR_CASE(20) HR_CASE(24) HR_CASE(32)
+#undef HR_CASE
+  DL3P_CHECK_LAUNCH("dl3p_head_train_rows (x pass)");
+  HeadYParams q = {};
+  q.gxh = (const float*)workspace; q.gz = gz; q.ldgz = ldgz; q.accumulate = accumulate;
+  q.N = N; q.h = h; q.w = w; q.H = H; q.c4s = cp / 4; q.cp = cp; q.total = (long long)N * h * w * (cp / 4);
+  hipLaunchKernelGGL(head_ypass_kernel, dim3((unsigned)ceil_div(q.total, 256ll)), dim3(256), 0, st, q);
+  DL3P_CHECK_LAUNCH("dl3p_head_train_rows (y pass)");
+  return DL3P_OK;
+}

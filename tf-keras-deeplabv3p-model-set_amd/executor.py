@@ -556,8 +556,9 @@ class Executor:
         self.labels = torch.zeros(N * H * W, **self.f32)
         self.loss_partials = torch.zeros(MAX_ROWS, **self.f32)
         self.loss = torch.zeros(1, **self.f32)
-        # dl3p_head_train (loss + gradient resize in one launch, no (N,H,W,C) gradient in HBM) is bit-identical to the
-        # two-kernel path but measured slower on MI355X (506 us vs 141 + 165 us at batch 16): opt-in, for memory
+        # The fused training heads (plain cross-entropy only).  dl3p_head_train_rows (x / y separable: a quarter of the full-resolution
+        # gradient's traffic) is the default where it is served; DL3P_FUSED_HEAD=0: the two-kernel path, =tile: dl3p_head_train (one
+        # launch, no workspace, bit-identical to the two-kernel path but measured slower: 506 us vs 141 + 165 us at batch 16).
         zt = self.head.tensor
         self.class_weights = None
         if self._loss_weights_host is not None:
@@ -568,8 +569,14 @@ class Executor:
         # per-image class counts for the Jaccard training metric (deeplabv3p/metrics.py:29-46), refreshed every step
         self.metric_counts = (torch.zeros(N * 3 * self.C, dtype=torch.int32, device=self.dev).view(N, 3, self.C)
                               if (self.training and self.want_class_counts) else None)
-        self.fused_head = bool(self.training and not self.bf16 and self.loss_kind == 0 and not self.sample_weighted and os.environ.get('DL3P_FUSED_HEAD', '0') != '0' and zt is not None and
-                               zt.requires_grad and L.head_train_supported(zt.H, zt.W, self.C, H, W))
+        want = os.environ.get('DL3P_FUSED_HEAD', 'rows')
+        plain = bool(self.training and not self.bf16 and self.loss_kind == 0 and not self.sample_weighted and
+                     self.class_weights is None and zt is not None and zt.requires_grad)
+        self.fused_head_rows = bool(plain and want == 'rows' and L.head_train_rows_supported(zt.H, zt.W, self.C, H, W))
+        self.fused_head = self.fused_head_rows or bool(plain and want not in ('0', 'rows') and
+                                                       L.head_train_supported(zt.H, zt.W, self.C, H, W))
+        self.head_wsb = L.head_train_rows_workspace(N, zt.H, zt.W, self.C, H, W) if self.fused_head_rows else 0
+        self.head_ws = torch.zeros(self.head_wsb // 4, **self.f32) if self.fused_head_rows else None
         self.dlogits_big = (torch.zeros(N * H * W * self.cpad, **self.f32)
                             if (self.training and not self.fused_head) else None)
         self.probs = None if self.training else torch.zeros(N * H * W * self.C, **self.f32)
@@ -898,9 +905,14 @@ class Executor:
         rows = ctypes.c_int(0)
         if train and self.fused_head:
             # loss + d loss / d (conv_upsample output) in one launch; the full-resolution gradient is never written
-            P.k(L.head_train, self.tptr(zt), zt.ld, self.labels.data_ptr(), int(self.ignore_index or 0),
-                1.0 / float(N * self.H * self.W), self.tptr(zt, True), zt.ld, 0, self.loss_partials.data_ptr(),
-                ctypes.byref(rows), N, zt.H, zt.W, self.C, self.H, self.W)
+            if self.fused_head_rows:
+                P.k(L.head_train_rows, self.tptr(zt), zt.ld, self.labels.data_ptr(), int(self.ignore_index or 0),
+                    1.0 / float(N * self.H * self.W), self.tptr(zt, True), zt.ld, 0, self.loss_partials.data_ptr(),
+                    ctypes.byref(rows), self.head_ws.data_ptr(), self.head_wsb, N, zt.H, zt.W, self.C, self.H, self.W)
+            else:
+                P.k(L.head_train, self.tptr(zt), zt.ld, self.labels.data_ptr(), int(self.ignore_index or 0),
+                    1.0 / float(N * self.H * self.W), self.tptr(zt, True), zt.ld, 0, self.loss_partials.data_ptr(),
+                    ctypes.byref(rows), N, zt.H, zt.W, self.C, self.H, self.W)
             P.k(L.reduce_rows, self.loss_partials.data_ptr(), rows.value, 1, self.loss.data_ptr(), 0)
         elif train:
             P.k(L.upsample_softmax_loss, self.tptr(zt), zt.ld, self.labels.data_ptr(), int(self.ignore_index or 0),

@@ -502,16 +502,27 @@ def head_train_supported(h, w, C, H, W):
     return bool(lib().head_train_supported(h, w, C, H, W))
 
 
-def head_train(z, C, H, W, labels, ignore_index=255):
-    """fused training head: z (N,h,w,Cpad) -> (loss [1], d loss / d z (N,h,w,Cpad)) without the (N,H,W,C) gradient"""
+def head_train_rows_supported(h, w, C, H, W):
+    return bool(lib().head_train_rows_supported(h, w, C, H, W))
+
+
+def head_train(z, C, H, W, labels, ignore_index=255, rows_form=False):
+    """fused training head: z (N,h,w,Cpad) -> (loss [1], d loss / d z (N,h,w,Cpad)) without the (N,H,W,C) gradient;
+    rows_form: dl3p_head_train_rows (the row-walking kernel) instead of dl3p_head_train (the tile kernel)"""
     N, h, w, cp = z.shape
     dev = z.device
     zp, ldz = _pl(z)
     gz = torch.zeros((N, h, w, cp), dtype=torch.float32, device=dev)
     partial = torch.zeros(MAX_STAT_ROWS, dtype=torch.float32, device=dev)
     rows = ctypes.c_int(0)
-    lib().head_train(zp, ldz, _p(labels), int(ignore_index or 0), 1.0 / float(N * H * W), _p(gz), cp, 0, _p(partial),
-                     ctypes.byref(rows), N, h, w, C, H, W, _stream())
+    if rows_form:
+        wsb = lib().head_train_rows_workspace(N, h, w, C, H, W)
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
+        lib().head_train_rows(zp, ldz, _p(labels), int(ignore_index or 0), 1.0 / float(N * H * W), _p(gz), cp, 0, _p(partial),
+                              ctypes.byref(rows), _p(ws), wsb, N, h, w, C, H, W, _stream())
+    else:
+        lib().head_train(zp, ldz, _p(labels), int(ignore_index or 0), 1.0 / float(N * H * W), _p(gz), cp, 0, _p(partial),
+                         ctypes.byref(rows), N, h, w, C, H, W, _stream())
     loss = torch.empty(1, dtype=torch.float32, device=dev)
     lib().reduce_rows(_p(partial), rows.value, 1, _p(loss), 0, _stream())
     return loss, gz
