@@ -488,7 +488,7 @@ int dl3p_head_train(const float* z, int ldz, const float* labels, int ignore_ind
  * rows.  Arguments and results as dl3p_head_train plus the workspace (dl3p_head_train_rows_workspace bytes, 16-byte aligned); the
  * gradient equals dl3p_upsample_softmax_loss + dl3p_resize_bilinear_bwd to rounding (x-then-y summation), not bit for bit.
  * Plain sparse cross-entropy only (no class / pixel weights, no focal loss).  Served: Cpad in {20, 24, 32}, W / w <= 4,
- * w * Cpad / 4 <= 1024, (2 w + W) * Cpad * 4 bytes of LDS <= 150 KB.  rows_out: loss partial rows written (<= 2 x CUs). */
+ * w * Cpad / 4 <= 1024, 3 * W * Cpad * 4 bytes of LDS <= 150 KB.  rows_out: loss partial rows written (<= CUs). */
 int dl3p_head_train_rows_supported(int h, int w, int C, int H, int W);
 size_t dl3p_head_train_rows_workspace(int N, int h, int w, int C, int H, int W);
 int dl3p_head_train_rows(const float* z, int ldz, const float* labels, int ignore_index, float inv_count, float* gz, int ldgz,

@@ -809,7 +809,7 @@ def test_head_train_fused(ops, case):
 
 @pytest.mark.parametrize('case', [(2, 9, 9, 33, 33, 21, 255), (1, 33, 33, 129, 129, 19, 255), (2, 17, 23, 65, 89, 21, 0),
                                   (3, 5, 7, 5, 7, 18, 255), (2, 11, 6, 41, 21, 32, 255), (1, 129, 129, 513, 513, 21, 255),
-                                  (1, 97, 97, 385, 385, 21, 255)])
+                                  (1, 97, 97, 385, 385, 21, 255), (1, 17, 33, 65, 130, 21, 255), (2, 2, 2, 3, 2, 21, 255)])
 def test_head_train_rows_form(ops, case):
     """the row-walking fused training head == the two-kernel head to rounding (x-then-y summation), and == the oracle"""
     N, h, w, H, W, C, ignore = case

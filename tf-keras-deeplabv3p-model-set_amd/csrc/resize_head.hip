@@ -14,7 +14,7 @@
 // exp of the max-shifted logits is the hardware v_exp_f32 (1 ulp on the [-87, 0] arguments a softmax sees); the
 // full-range expf costs ~25 instructions x 21 classes per pixel and made the head kernels VALU-bound
 struct Lerp { int lo, hi; float t; };
-__device__ __forceinline__ Lerp lerp_coeff(int o, float scale, int in_size) {
+__host__ __device__ __forceinline__ Lerp lerp_coeff(int o, float scale, int in_size) {
   const float src = ((float)o + 0.5f) * scale - 0.5f;
   const float fl = floorf(src);
   Lerp r;
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(ResizeParams p) {
 }
 
 // output-index range that can read input index i
-__device__ __forceinline__ void touch_range(int i, float inv_scale, int out_size, int& o0, int& o1) {
+__host__ __device__ __forceinline__ void touch_range(int i, float inv_scale, int out_size, int& o0, int& o1) {
   // src(o) in (i-1, i+1)  <=>  o in ((i-0.5)/scale - 0.5, (i+1.5)/scale - 0.5); widen by one for rounding
   const float a = ((float)i - 0.5f) * inv_scale - 0.5f;
   const float b = ((float)i + 1.5f) * inv_scale - 0.5f;
@@ -861,12 +861,16 @@ extern "C" int dl3p_head_train(const float* z, int ldz, const float* labels, int
 // pred_resize + Softmax + cross-entropy + the transposed pred_resize of the gradient with a QUARTER of the (N,H,W,C) gradient's HBM
 // traffic (404 MB written and read back at batch 16 / 513x513): the transposed bilinear resize factorises, G_low = Ry^T (G_high Rx),
 // and its x half needs one full-resolution row at a time.
-//   x pass: a workgroup walks a contiguous chunk of full-resolution rows (2 workgroups per CU cover the batch in one round).  Per row:
-//     the two logit rows it interpolates between are in LDS (they change every ~H/h rows); one pixel per thread -> interpolated
-//     logits, softmax, loss, gradient -> an LDS row [W][CP]; then every (logit column, 4 channels) item gathers its <= 12 pixels of
-//     that row with weights it computed once per workgroup and stores the row of G_high Rx: (N,H,w,CP), 1 / (W/w) of the gradient.
+//   x pass: one workgroup of 512 threads per CU walks a contiguous chunk of full-resolution rows.  LDS holds the two logit rows a
+//     full-resolution row interpolates between ALREADY INTERPOLATED IN x (a ring of two rows [CP/4][W] float4; a logit row is
+//     interpolated once per workgroup, when the walk first needs it -- every ~H/h rows) and the gradient of the current row.  Per row:
+//     one pixel per thread -> top + (bot - top) ty (the expression of head_kernel: same bits), softmax, loss, gradient -> LDS; then
+//     every (logit column, 4 channels) item gathers its <= 9 pixels of that row with weights it computed once per workgroup and stores
+//     the row of G_high Rx: (N,H,w,CP), 1 / (W/w) of the gradient.  The kernel is bound by LDS bandwidth (128 B / clk / CU: a 16-byte
+//     read per lane is 8 clocks a wave), which is why the x interpolation is shared between the rows and every LDS array is laid out
+//     in channel-quad planes (lanes = consecutive pixels -> consecutive 16-byte words, no bank conflicts).
 //   y pass: one thread per (logit pixel, 4 channels) adds up its <= ~2 H/h rows of that tensor -- coalesced, 16 bytes per lane.
-// Against dl3p_head_train (the tile kernel): no 100 KB gradient tile with 2.1x the pixels evaluated and one workgroup per CU.
+// Against dl3p_head_train (the tile kernel): no 100 KB gradient tile with 2.1x the pixels evaluated.
 // Summation order differs from dl3p_resize_bilinear_bwd (x first, then y): equal to rounding, not bit for bit.
 struct HeadRowsParams {
   const float* z; int ldz; const float* labels; int ignore_index; float inv_count;
@@ -875,142 +879,252 @@ struct HeadRowsParams {
 };
 
 typedef float hr_f2 __attribute__((ext_vector_type(2)));
+#define HR_THREADS 1024
 
-// plane stride (floats) of the LDS gradient row [CP/4][W] float4: = 4 (mod 64), so that the six channel quads of a logit column and
-// the columns next to it (16 floats apart at W / w = 4) fall on different LDS banks in the gather
+// plane stride (floats) of the LDS rows [CP/4][W] float4: = 4 (mod 64), so that the channel quads of a logit column and the columns
+// next to it (16 floats apart at W / w = 4) fall on different LDS banks in the gather
 __host__ __device__ static inline int head_rows_plane(int W) { return 4 * W + ((4 - (4 * W) % 64) + 64) % 64; }
 
-template <int CP, int NI>
-__global__ __launch_bounds__(256, 2) void head_xpass_kernel(HeadRowsParams p) {
+// first full-resolution column with a non-zero weight for logit column j and the number of columns up to the last one
+__host__ __device__ static inline void head_rows_window(int j, int w, int W, int& first, int& count) {
+  const float sx = (float)w / (float)W, isx = (float)W / (float)w;
+  int x0, x1;
+  touch_range(j, isx, W, x0, x1);
+  if (j == 0) x0 = 0;
+  if (j == w - 1) x1 = W - 1;
+  first = -1;
+  int last = -1;
+  for (int X = x0; X <= x1; ++X) {
+    const Lerp lx = lerp_coeff(X, sx, w);
+    const float wx = (lx.lo == j ? 1.f - lx.t : 0.f) + (lx.hi == j ? lx.t : 0.f);
+    if (wx != 0.f) {
+      if (first < 0) first = X;
+      last = X;
+    }
+  }
+  if (first < 0) { first = x0; last = x0 - 1; }
+  count = last - first + 1;
+}
+
+template <int CP, int NI, int MAXW>
+__global__ __launch_bounds__(HR_THREADS) void head_xpass_kernel(HeadRowsParams p) {
   constexpr int C4 = CP / 4;
   extern __shared__ __attribute__((aligned(16))) float hr_lds[];
-  float* zr = hr_lds;                                   // [2][w][CP]: logit rows lo, hi
-  float* gr = hr_lds + 2 * p.w * CP;                    // [CP/4][plane]: gradient of the current full-resolution row, channel-quad planes
-  __shared__ float wsum[4];
-  const int t = threadIdx.x;
   const int PW = head_rows_plane(p.W);
+  float* xr = hr_lds;                                   // [2][CP/4][plane]: logit rows i (slot i & 1), interpolated in x
+  float* gr = hr_lds + 2 * C4 * PW;                     // [CP/4][plane]: gradient of the current full-resolution row
+  __shared__ float wsum[HR_THREADS / 64];
+  const int t = threadIdx.x;
   const float sy = (float)p.h / (float)p.H, sx = (float)p.w / (float)p.W;
-  const float isx = (float)p.W / (float)p.w;
   const int rows_total = p.N * p.H;
   const int r0 = blockIdx.x * p.chunk, r1 = min(r0 + p.chunk, rows_total);
   // this thread's items of the transposed resize in x: (logit column j, channel quad c4); window start and weights, once
   int x0s[NI];
-  float wxs[NI][RB_MAXW];
+  float wxs[NI][MAXW];
 #pragma unroll
   for (int m = 0; m < NI; ++m) {
-    const int it = t + 256 * m;
+    const int it = t + HR_THREADS * m;
     const bool on = it < p.w * C4;
-    const int j = on ? it / C4 : -1;
-    int x0 = 0, x1 = -1;
-    if (on) {
-      touch_range(j, isx, p.W, x0, x1);
-      if (j == 0) x0 = 0;
-      if (j == p.w - 1) x1 = p.W - 1;
-    }
-    x0s[m] = x0;
+    const int j = on ? it / C4 : 0;
+    int first, count;
+    head_rows_window(j, p.w, p.W, first, count);
+    x0s[m] = first;
 #pragma unroll
-    for (int k = 0; k < RB_MAXW; ++k) {
-      const int ox = min(x0 + k, p.W - 1);
-      const Lerp lx = lerp_coeff(ox, sx, p.w);
+    for (int k = 0; k < MAXW; ++k) {
+      const Lerp lx = lerp_coeff(min(first + k, p.W - 1), sx, p.w);
       const float wx = (lx.lo == j ? 1.f - lx.t : 0.f) + (lx.hi == j ? lx.t : 0.f);
-      wxs[m][k] = (on && x0 + k <= x1) ? wx : 0.f;
+      wxs[m][k] = (on && k < count) ? wx : 0.f;
     }
   }
   float loss = 0.f;
-  int have_n = -1, have_lo = -1, have_hi = -1;
+  int have_n = -1, have0 = -1, have1 = -1;              // the logit row in slot 0 / 1 (of image have_n)
+  // gfx9 counts loads and stores in one counter (vmcnt), so a wait for any load also waits for every store in flight.  The walk keeps
+  // both out of the way: the gather result of a row stays in registers and is STORED AT THE START OF THE NEXT ROW'S PIXEL PHASE,
+  // together with the request for the next row's label; both are waited for once, at the end of that phase -- nothing is in flight
+  // across the barriers, the ring refresh or the loop edge, where the compiler's waits would expose the latency.
+  // One or two pixels past a multiple of 64 (W = 513, 769, 1025: the crop sizes of the reference are 2^k + 1) would cost a whole
+  // wave-iteration of the pixel phase for one lane -- on the SIMD that already holds the most pixel waves.  Those tail pixels are
+  // evaluated by ONE wave with a channel per lane instead (32 lanes per pixel, reductions by lane shuffles: ~50 instructions, not 230),
+  // a wave that sits on another SIMD.
+  const int lane = t & 63, wave = t >> 6;
+  const int Wfull = (p.W & 63) <= 2 ? (p.W & ~63) : p.W;
+  const int tail_wave = min((Wfull >> 6) + 1, HR_THREADS / 64 - 1);
+  const bool tail_lane = wave == tail_wave && Wfull + (lane >> 5) < p.W;
+  const int tc = tail_lane ? Wfull + (lane >> 5) : min(t, p.W - 1);
+  int lab_cur = r0 < r1 ? (int)p.labels[(size_t)r0 * p.W + tc] : 0;
+  float4 held[NI];
+#pragma unroll
+  for (int m = 0; m < NI; ++m) held[m] = zero4();
   for (int row = r0; row < r1; ++row) {
     const int n = row / p.H, Y = row - n * p.H;
     const Lerp ly = lerp_coeff(Y, sy, p.h);
-    __syncthreads();                                     // the previous row's gather is done with gr (and zr)
-    if (n != have_n || ly.lo != have_lo || ly.hi != have_hi) {
-      const float* zimg = p.z + (size_t)n * p.h * p.w * p.ldz;
-      for (int i = t; i < 2 * p.w * C4; i += 256) {
-        const int c4 = i % C4, px = (i / C4) % p.w, which = i / (C4 * p.w);
-        const int zy = which ? ly.hi : ly.lo;
-        *reinterpret_cast<float4*>(&zr[(which * p.w + px) * CP + c4 * 4]) = ld4(zimg + ((size_t)zy * p.w + px) * p.ldz + c4 * 4);
-      }
-      have_n = n; have_lo = ly.lo; have_hi = ly.hi;
-      __syncthreads();
-    }
-    const float* lrow = p.labels + (size_t)row * p.W;
-    for (int X = t; X < p.W; X += 256) {
-      const Lerp lx = lerp_coeff(X, sx, p.w);
-      const float* ptl = zr + lx.lo * CP;
-      const float* ptr = zr + lx.hi * CP;
-      const float* pbl = zr + (p.w + lx.lo) * CP;
-      const float* pbr = zr + (p.w + lx.hi) * CP;
-      // the same expression as head_kernel (top + (bot - top) * ty, unfused), two channels per packed instruction
-      hr_f2 v[CP / 2];
-      const hr_f2 tx2 = {lx.t, lx.t}, ty2 = {ly.t, ly.t};
+    // the ring: logit rows this full-resolution row needs and does not have.  (Nobody reads xr any more: the previous row's pixel
+    // phase ended at its barrier.)  Every load of a refresh is issued before the first is used.
+    if (n != have_n) { have_n = n; have0 = have1 = -1; }
 #pragma unroll
-      for (int c4 = 0; c4 < C4; ++c4) {
-        const float4 tl = *reinterpret_cast<const float4*>(ptl + c4 * 4), tr = *reinterpret_cast<const float4*>(ptr + c4 * 4);
-        const float4 bl = *reinterpret_cast<const float4*>(pbl + c4 * 4), br = *reinterpret_cast<const float4*>(pbr + c4 * 4);
+    for (int e = 0; e < 2; ++e) {
+      const int i = e ? ly.hi : ly.lo;
+      const int have = (i & 1) ? have1 : have0;
+      if (have == i) continue;
+      const float* zrow = p.z + ((size_t)n * p.h + i) * p.w * p.ldz;
+      float* dst = xr + (i & 1) * C4 * PW;
+      constexpr int U = 4;
+      for (int base = t; base < C4 * p.W; base += U * HR_THREADS) {
+        float4 a[U], b[U];
+        float tx[U];
+        int ofs[U];
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          const hr_f2 a = hh ? hr_f2{tl.z, tl.w} : hr_f2{tl.x, tl.y}, b = hh ? hr_f2{tr.z, tr.w} : hr_f2{tr.x, tr.y};
-          const hr_f2 c = hh ? hr_f2{bl.z, bl.w} : hr_f2{bl.x, bl.y}, d = hh ? hr_f2{br.z, br.w} : hr_f2{br.x, br.y};
-          const hr_f2 top = a + (b - a) * tx2, bot = c + (d - c) * tx2;
-          v[c4 * 2 + hh] = top + (bot - top) * ty2;
+        for (int u = 0; u < U; ++u) {
+          const int it = base + u * HR_THREADS;
+          const bool ok = it < C4 * p.W;
+          const int itc = ok ? it : 0;
+          const int c4 = itc / p.W, X = itc - c4 * p.W;
+          const Lerp lx = lerp_coeff(X, sx, p.w);
+          a[u] = ld4(zrow + (size_t)lx.lo * p.ldz + c4 * 4);
+          b[u] = ld4(zrow + (size_t)lx.hi * p.ldz + c4 * 4);
+          tx[u] = lx.t;
+          ofs[u] = ok ? c4 * PW + X * 4 : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (ofs[u] < 0) continue;
+          float4 o;
+          o.x = a[u].x + (b[u].x - a[u].x) * tx[u]; o.y = a[u].y + (b[u].y - a[u].y) * tx[u];
+          o.z = a[u].z + (b[u].z - a[u].z) * tx[u]; o.w = a[u].w + (b[u].w - a[u].w) * tx[u];
+          *reinterpret_cast<float4*>(dst + ofs[u]) = o;
         }
       }
-      float mx = -3.0e38f;
+      if (i & 1) have1 = i; else have0 = i;
+    }
+    __syncthreads();                                     // xr is in place; the previous row's gather is done with gr
+    const float* top = xr + (ly.lo & 1) * C4 * PW;
+    const float* bot = xr + (ly.hi & 1) * C4 * PW;
+    auto pixel = [&](int X, int lab) {
+      // logits: the expression of head_kernel (top + (bot - top) * ty, unfused), two channels per packed instruction.  From there on
+      // the arithmetic is arranged for instruction count (the phase is bound by VALU issue): exp2 of a fused (v - max) * log2(e),
+      // pairwise sums, one multiplier gs / sum for the gradient -- equal to head_kernel's softmax to rounding, not bit for bit.
+      hr_f2 v[CP / 2];
+      const hr_f2 ty2 = {ly.t, ly.t};
 #pragma unroll
-      for (int c = 0; c < CP; ++c) if (c < CP - 3 || c < p.C) mx = fmaxf(mx, v[c >> 1][c & 1]);   // (Cpad - C <= 3)
-      float sum = 0.f;
-#pragma unroll
-      for (int c = 0; c < CP; ++c) {
-        const float e = (c < CP - 3 || c < p.C) ? __expf(v[c >> 1][c & 1] - mx) : 0.f;
-        v[c >> 1][c & 1] = e;
-        sum += e;
+      for (int c4 = 0; c4 < C4; ++c4) {
+        const float4 a = *reinterpret_cast<const float4*>(top + c4 * PW + X * 4);
+        const float4 b = *reinterpret_cast<const float4*>(bot + c4 * PW + X * 4);
+        const hr_f2 a0 = {a.x, a.y}, a1 = {a.z, a.w}, b0 = {b.x, b.y}, b1 = {b.z, b.w};
+        v[c4 * 2] = a0 + (b0 - a0) * ty2;
+        v[c4 * 2 + 1] = a1 + (b1 - a1) * ty2;
       }
-      const float inv = 1.f / sum;
-      const int lab = (int)lrow[X];
+      // padded channels (Cpad - C <= 3, all in the last quad) never win the maximum and add exp2(-huge) = 0 to the sum
+      if (CP - 3 >= p.C) v[CP / 2 - 2][1] = -3.0e38f;
+      if (CP - 2 >= p.C) v[CP / 2 - 1][0] = -3.0e38f;
+      if (CP - 1 >= p.C) v[CP / 2 - 1][1] = -3.0e38f;
+      float mx = fmaxf(v[0][0], v[0][1]);
+#pragma unroll
+      for (int c2 = 1; c2 < CP / 2; ++c2) mx = fmaxf(fmaxf(mx, v[c2][0]), v[c2][1]);
+      constexpr float LOG2E = 1.4426950408889634f;
+      const float mneg = -mx * LOG2E;
+      const hr_f2 l2 = {LOG2E, LOG2E}, m2 = {mneg, mneg};
+      // (v_exp_f32 of a large negative argument is 0: the padded channels, and anything 126 octaves under the maximum)
+#pragma unroll
+      for (int c2 = 0; c2 < CP / 2; ++c2) v[c2] = __builtin_elementwise_fma(v[c2], l2, m2);
+#pragma unroll
+      for (int c2 = 0; c2 < CP / 2; ++c2) {
+        v[c2][0] = __builtin_amdgcn_exp2f(v[c2][0]);
+        v[c2][1] = __builtin_amdgcn_exp2f(v[c2][1]);
+      }
+      hr_f2 s2 = v[0], s3 = v[1];
+#pragma unroll
+      for (int c2 = 2; c2 < CP / 2; c2 += 2) { s2 += v[c2]; s3 += v[c2 + 1]; }
+      s2 += s3;
+      const float inv = 1.f / (s2[0] + s2[1]);
       const bool masked = p.ignore_index != 0 && lab == p.ignore_index;
       const bool valid = !masked && lab >= 0 && lab < p.C;
-      // the label's probability: its logit again from the four LDS corners (the same expression -> the same bits) instead of a
-      // 24-way select over the registers
+      // the label's probability: its logit again from LDS (the same expressions -> the same bits) instead of a 24-way select
       float pt = 0.f;
       if (valid) {
-        const float a = ptl[lab], b = ptr[lab], c = pbl[lab], d = pbr[lab];
-        const float top = a + (b - a) * lx.t, bot = c + (d - c) * lx.t;
-        pt = __expf((top + (bot - top) * ly.t) - mx) * inv;
+        const int o = (lab >> 2) * PW + X * 4 + (lab & 3);
+        const float a = top[o], b = bot[o];
+        pt = __builtin_amdgcn_exp2f(fmaf(a + (b - a) * ly.t, LOG2E, mneg)) * inv;
       }
       const bool unclipped = pt > 1e-7f && pt < 1.f - 1e-7f;
       if (valid) loss += -logf(fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f));
       const float gs = (valid && unclipped) ? p.inv_count : 0.f;
-      const hr_f2 inv2 = {inv, inv}, gs2 = {gs, gs};
+      const float k = gs * inv;
+      const hr_f2 k2 = {k, k};
       float* gpx = gr + X * 4;
 #pragma unroll
       for (int c4 = 0; c4 < C4; ++c4) {
-        // gs * (p - 0): the label's channel is patched below (gs * (p - 1))
-        const hr_f2 d0 = gs2 * (v[c4 * 2] * inv2), d1 = gs2 * (v[c4 * 2 + 1] * inv2);
+        // gs * p; the label's channel is patched below (gs * (p - 1))
+        const hr_f2 d0 = v[c4 * 2] * k2, d1 = v[c4 * 2 + 1] * k2;
         *reinterpret_cast<float4*>(gpx + c4 * PW) = make_float4(d0[0], d0[1], d1[0], d1[1]);
       }
       if (valid) gpx[(lab >> 2) * PW + (lab & 3)] = gs * (pt - 1.f);
+    };
+    if (row > r0) {
+      float* orow = p.gxh + (size_t)(row - 1) * p.w * CP;
+#pragma unroll
+      for (int m = 0; m < NI; ++m)
+        if (t + HR_THREADS * m < p.w * C4) st4(orow + (size_t)(t + HR_THREADS * m) * 4, held[m]);
     }
+    const float lab_req = p.labels[(size_t)min(row + 1, r1 - 1) * p.W + tc];
+    if (t < Wfull) pixel(t, lab_cur);
+    for (int X = t + HR_THREADS; X < Wfull; X += HR_THREADS) pixel(X, (int)p.labels[(size_t)row * p.W + X]);
+    if (wave == tail_wave && Wfull < p.W) {
+      const int c = lane & 31, X = min(Wfull + (lane >> 5), p.W - 1), lab = lab_cur;
+      const bool on = tail_lane && c < CP;
+      const int o = on ? (c >> 2) * PW + X * 4 + (c & 3) : 0;
+      const float a = top[o], b = bot[o];
+      const float v = (on && c < p.C) ? a + (b - a) * ly.t : -3.0e38f;
+      float mx = v;
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 32));
+      constexpr float LOG2E = 1.4426950408889634f;
+      const float e = __builtin_amdgcn_exp2f(fmaf(v, LOG2E, -mx * LOG2E));
+      float sum = e;
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 32);
+      const float inv = 1.f / sum;
+      const bool masked = p.ignore_index != 0 && lab == p.ignore_index;
+      const bool valid = tail_lane && !masked && lab >= 0 && lab < p.C;
+      const float pt = valid ? __shfl(e, (lane & 32) + (lab & 31)) * inv : 0.f;
+      const bool unclipped = pt > 1e-7f && pt < 1.f - 1e-7f;
+      if (valid && c == 0) loss += -logf(fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f));
+      const float gs = (valid && unclipped) ? p.inv_count : 0.f;
+      if (on) gr[o] = c == lab ? gs * (pt - 1.f) : e * (gs * inv);
+    }
+    lab_cur = (int)lab_req;
+    asm volatile("" : "+v"(lab_cur));                    // the wait for the label (and the stores above) is HERE
     __syncthreads();
-    float* orow = p.gxh + (size_t)row * p.w * CP;
 #pragma unroll
     for (int m = 0; m < NI; ++m) {
-      const int it = t + 256 * m;
+      const int it = t + HR_THREADS * m;
       if (it >= p.w * C4) continue;
-      float4 xr = zero4();
+      float4 acc = zero4();
       const float* gp = gr + (it % C4) * PW;
 #pragma unroll
-      for (int k = 0; k < RB_MAXW; ++k) {
+      for (int k = 0; k < MAXW; ++k) {
         const float4 g = *reinterpret_cast<const float4*>(gp + min(x0s[m] + k, p.W - 1) * 4);
-        xr.x = fmaf(g.x, wxs[m][k], xr.x); xr.y = fmaf(g.y, wxs[m][k], xr.y);
-        xr.z = fmaf(g.z, wxs[m][k], xr.z); xr.w = fmaf(g.w, wxs[m][k], xr.w);
+        acc.x = fmaf(g.x, wxs[m][k], acc.x); acc.y = fmaf(g.y, wxs[m][k], acc.y);
+        acc.z = fmaf(g.z, wxs[m][k], acc.z); acc.w = fmaf(g.w, wxs[m][k], acc.w);
       }
-      st4(orow + (size_t)it * 4, xr);
+      held[m] = acc;
     }
+  }
+  if (r1 > r0) {
+    float* orow = p.gxh + (size_t)(r1 - 1) * p.w * CP;
+#pragma unroll
+    for (int m = 0; m < NI; ++m)
+      if (t + HR_THREADS * m < p.w * C4) st4(orow + (size_t)(t + HR_THREADS * m) * 4, held[m]);
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) loss += __shfl_xor(loss, off);
   if ((t & 63) == 0) wsum[t >> 6] = loss;
   __syncthreads();
-  if (t == 0) p.loss_partials[blockIdx.x] = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) * p.inv_count;
+  if (t == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < HR_THREADS / 64; ++i) s += wsum[i];
+    p.loss_partials[blockIdx.x] = s * p.inv_count;
+  }
 }
 
 struct HeadYParams { const float* gxh; float* gz; int ldgz; int accumulate; int N, h, w, H, c4s, cp; long long total; };
@@ -1042,16 +1156,24 @@ __global__ __launch_bounds__(256) void head_ypass_kernel(HeadYParams p) {
   st4(o, acc);
 }
 
-static int head_rows_ni(int w, int cp) { return ceil_div(w * (cp / 4), 256); }
-static size_t head_rows_lds(int w, int W, int cp) { return sizeof(float) * ((size_t)cp * 2 * w + (size_t)(cp / 4) * head_rows_plane(W)); }
+static int head_rows_ni(int w, int cp) { return ceil_div(w * (cp / 4), HR_THREADS); }
+static size_t head_rows_lds(int W, int cp) { return sizeof(float) * 3 * (size_t)(cp / 4) * head_rows_plane(W); }
+static int head_rows_maxwin(int w, int W) {
+  int m = 0;
+  for (int j = 0; j < w; ++j) {
+    int first, count;
+    head_rows_window(j, w, W, first, count);
+    m = std::max(m, count);
+  }
+  return m;
+}
 
 extern "C" int dl3p_head_train_rows_supported(int h, int w, int C, int H, int W) {
   const int cp = ((C + 3) / 4) * 4;
   if (!(cp == 20 || cp == 24 || cp == 32) || h < 1 || w < 1 || H < h || W < w) return 0;
-  const float isx = (float)W / (float)w;
-  if (2.f * isx + 4.f > (float)RB_MAXW) return 0;                         // the x window of a logit column fits the weight table
-  if (head_rows_ni(w, cp) > 4) return 0;
-  if (head_rows_lds(w, W, cp) > 150 * 1024) return 0;
+  if (head_rows_ni(w, cp) > 1) return 0;                                   // one (logit column, channel quad) item per thread
+  if (head_rows_lds(W, cp) > 150 * 1024) return 0;
+  if (head_rows_maxwin(w, W) > 12) return 0;                               // the x window of a logit column fits the weight table
   return 1;
 }
 
@@ -1061,10 +1183,10 @@ extern "C" size_t dl3p_head_train_rows_workspace(int N, int h, int w, int C, int
   return sizeof(float) * (size_t)N * H * w * cp;
 }
 
-template <int CP, int NI>
+template <int CP, int NI, int MAXW>
 static void launch_head_xpass(const HeadRowsParams& p, unsigned grid, size_t lds, hipStream_t st) {
-  (void)hipFuncSetAttribute((const void*)head_xpass_kernel<CP, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-  hipLaunchKernelGGL((head_xpass_kernel<CP, NI>), dim3(grid), dim3(256), lds, st, p);
+  (void)hipFuncSetAttribute((const void*)head_xpass_kernel<CP, NI, MAXW>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  hipLaunchKernelGGL((head_xpass_kernel<CP, NI, MAXW>), dim3(grid), dim3(HR_THREADS), lds, st, p);
 }
 
 extern "C" int dl3p_head_train_rows(const float* z, int ldz, const float* labels, int ignore_index, float inv_count, float* gz,
@@ -1083,20 +1205,20 @@ extern "C" int dl3p_head_train_rows(const float* z, int ldz, const float* labels
   p.z = z; p.ldz = ldz; p.labels = labels; p.ignore_index = ignore_index; p.inv_count = inv_count;
   p.gxh = (float*)workspace; p.loss_partials = loss_partials;
   p.N = N; p.h = h; p.w = w; p.C = C; p.H = H; p.W = W;
-  // one round of two workgroups per CU; never more workgroups than loss partial rows
+  // one workgroup per CU, one round; never more workgroups than loss partial rows
   const int rows_total = N * H;
-  const int slots = std::min(2 * dl3p_device_cus(), (int)DL3P_MAX_STAT_ROWS);
+  const int slots = std::min(dl3p_device_cus(), (int)DL3P_MAX_STAT_ROWS);
   p.chunk = std::max(1, ceil_div(rows_total, slots));
   const int blocks = ceil_div(rows_total, p.chunk);
   if (rows_out) *rows_out = blocks;
-  const size_t lds = head_rows_lds(w, W, cp);
-  const int ni = head_rows_ni(w, cp);
+  const size_t lds = head_rows_lds(W, cp);
+  const int mw = head_rows_maxwin(w, W);
   hipStream_t st = (hipStream_t)stream;
 #define HR_CASE(CC) \
   if (cp == CC) { \
-    if (ni <= 1) launch_head_xpass<CC, 1>(p, (unsigned)blocks, lds, st); \
-    else if (ni <= 2) launch_head_xpass<CC, 2>(p, (unsigned)blocks, lds, st); \
-    else launch_head_xpass<CC, 4>(p, (unsigned)blocks, lds, st); \
+    if (mw <= 5) launch_head_xpass<CC, 1, 5>(p, (unsigned)blocks, lds, st); \
+    else if (mw <= 9) launch_head_xpass<CC, 1, 9>(p, (unsigned)blocks, lds, st); \
+    else launch_head_xpass<CC, 1, 12>(p, (unsigned)blocks, lds, st); \
   }
   HR_CASE(20) HR_CASE(24) HR_CASE(32)
 #undef HR_CASE
