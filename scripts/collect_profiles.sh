@@ -31,7 +31,8 @@ cp $O/kt/*/*kernel_stats.csv $O/${R}_kernel_stats.csv
 # steps in the trace = launches of the once-per-step loss kernel (warm-up + timed + the bench's extra probe steps)
 STEPS=$(python3 - <<PY
 import csv
-n = [r['Calls'] for r in csv.DictReader(open('$O/${R}_kernel_stats.csv')) if 'head_kernel' in r['Name']]
+rows = list(csv.DictReader(open('$O/${R}_kernel_stats.csv')))
+n = [r['Calls'] for r in rows if 'head_xpass_kernel' in r['Name']] or [r['Calls'] for r in rows if 'head_kernel' in r['Name']]
 print(n[0] if n else 1)
 PY
 )

@@ -968,30 +968,19 @@ __global__ __launch_bounds__(HR_THREADS) void head_xpass_kernel(HeadRowsParams p
       if (have == i) continue;
       const float* zrow = p.z + ((size_t)n * p.h + i) * p.w * p.ldz;
       float* dst = xr + (i & 1) * C4 * PW;
-      constexpr int U = 4;
-      for (int base = t; base < C4 * p.W; base += U * HR_THREADS) {
-        float4 a[U], b[U];
-        float tx[U];
-        int ofs[U];
+      for (int X = t; X < p.W; X += HR_THREADS) {        // a pixel per thread: its two corners, all channel quads, loads first
+        const Lerp lx = lerp_coeff(X, sx, p.w);
+        const float* pa = zrow + (size_t)lx.lo * p.ldz;
+        const float* pb = zrow + (size_t)lx.hi * p.ldz;
+        float4 a[C4], b[C4];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int it = base + u * HR_THREADS;
-          const bool ok = it < C4 * p.W;
-          const int itc = ok ? it : 0;
-          const int c4 = itc / p.W, X = itc - c4 * p.W;
-          const Lerp lx = lerp_coeff(X, sx, p.w);
-          a[u] = ld4(zrow + (size_t)lx.lo * p.ldz + c4 * 4);
-          b[u] = ld4(zrow + (size_t)lx.hi * p.ldz + c4 * 4);
-          tx[u] = lx.t;
-          ofs[u] = ok ? c4 * PW + X * 4 : -1;
-        }
+        for (int c4 = 0; c4 < C4; ++c4) { a[c4] = ld4(pa + c4 * 4); b[c4] = ld4(pb + c4 * 4); }
+        const hr_f2 tx2 = {lx.t, lx.t};
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if (ofs[u] < 0) continue;
-          float4 o;
-          o.x = a[u].x + (b[u].x - a[u].x) * tx[u]; o.y = a[u].y + (b[u].y - a[u].y) * tx[u];
-          o.z = a[u].z + (b[u].z - a[u].z) * tx[u]; o.w = a[u].w + (b[u].w - a[u].w) * tx[u];
-          *reinterpret_cast<float4*>(dst + ofs[u]) = o;
+        for (int c4 = 0; c4 < C4; ++c4) {
+          const hr_f2 a0 = {a[c4].x, a[c4].y}, a1 = {a[c4].z, a[c4].w}, b0 = {b[c4].x, b[c4].y}, b1 = {b[c4].z, b[c4].w};
+          const hr_f2 o0 = a0 + (b0 - a0) * tx2, o1 = a1 + (b1 - a1) * tx2;
+          *reinterpret_cast<float4*>(dst + c4 * PW + X * 4) = make_float4(o0[0], o0[1], o1[0], o1[1]);
         }
       }
       if (i & 1) have1 = i; else have0 = i;
