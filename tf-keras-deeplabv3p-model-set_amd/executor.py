@@ -257,42 +257,13 @@ class Plan:
         self.ctx = ''
         self.segments = None
         self.tags = {}
-        self.use_side, self._side = False, None
 
     def k(self, fn, *args, tag=None):
-        if self.use_side:
-            # between fork() and join(): the launch goes onto the side stream (a parallel branch of the captured graph)
-            s = self._side
-
-            def launch():
-                fn(*args, s.cuda_stream)
-            launch()
-            self.items.append((None, launch))
-            self.labels.append((getattr(fn, '__name__', str(fn)), self.ctx))
-            return
         fn(*args, torch.cuda.current_stream().cuda_stream)
         if tag is not None:
             self.tags[tag] = len(self.items)
         self.items.append((fn, args))
         self.labels.append((getattr(fn, '__name__', str(fn)), self.ctx))
-
-    # two launches that do not depend on each other (a conv's weight gradient beside its data gradient): fork() makes the side
-    # stream wait for everything issued so far, launches issued while `use_side` is set go onto it, join() makes the main
-    # stream wait for them.  Captured, that is a parallel branch of the hipGraph; eagerly, two streams.
-    def fork(self):
-        if self._side is None:
-            self._side = torch.cuda.Stream()
-        side = self._side
-        self.py(lambda: side.wait_stream(torch.cuda.current_stream()))
-        self.use_side = True
-
-    def side_done(self):
-        self.use_side = False
-
-    def join(self):
-        side = self._side
-        self.use_side = False
-        self.py(lambda: torch.cuda.current_stream().wait_stream(side))
 
     def probe(self, tag, probe):
         """keep one launch outside the graph segments and issue it with the library's HIP event pair
@@ -1511,13 +1482,6 @@ class Executor:
         dz, lddz, dzf = self.tptr(out, True), out.ld, self._is_f32(out)
         need_gx = xt.requires_grad or xt.root.requires_grad
         M = N * op.Ho * op.Wo
-        # the weight gradient (slabs in its own region of the slab buffer) beside the data gradient: neither reads what the
-        # other writes.  At one image per device most launches of this path leave CUs idle; two at a time fill them
-        forked = False
-        if (op.layer.trainable and need_gx and wgrad_slabs is not None and self._slab_bytes(op) and not self._deferred_mode
-                and os.environ.get('DL3P_WGRAD_SIDE', '0') == '1'):
-            P.fork()
-            forked = True
         if op.layer.trainable:
             gw = st.ptr(op.w, G)
             gb = st.ptr(op.b, G) if getattr(op, 'b', None) else None
@@ -1539,20 +1503,15 @@ class Executor:
             else:
                 wgrad(L.pwconv_bwd_weight_bf16, self.tptr(op.col), op.col.ld, None, None, ACT_NONE, dz, lddz, dzf, gw, gb,
                       ws, wsb, M, op.kp, op.cout)
-        P.side_done()
         if not need_gx:
             return
         gp, ldg, keyt = self._gbuf(op.x)
         acc = self._acc(keyt)
-        if forked:
-            self._conv_dgrad_bf16(P, op, fused_bn, dz, lddz, dzf, gp, ldg, acc, M, join=True)
-            return
         self._conv_dgrad_bf16(P, op, fused_bn, dz, lddz, dzf, gp, ldg, acc, M)
 
-    def _conv_dgrad_bf16(self, P, op, fused_bn, dz, lddz, dzf, gp, ldg, acc, M, join=False):
+    def _conv_dgrad_bf16(self, P, op, fused_bn, dz, lddz, dzf, gp, ldg, acc, M):
         L, N, st, k = self.L, self.N, self.store, op.kind
         xt = op.x.tensor
-        done = P.join if join else (lambda: None)          # right behind the data-gradient launch
         if k == 'conv_pw' and fused_bn is not None and not dzf:
             # the BatchNorm-backward sums of the BatchNorm behind this gradient ride on the data gradient (dl3p_pwconv_bwd_data_bn)
             bn = fused_bn.bn
@@ -1562,7 +1521,6 @@ class Executor:
                 self.tptr(fused_bn.z), fused_bn.z.ld, self.gscale[bn.group.id].data_ptr() + 4 * bn.offset,
                 self.gshift[bn.group.id].data_ptr() + 4 * bn.offset, bn.act, aux['mean'].data_ptr(),
                 aux['invstd'].data_ptr(), self.partials.data_ptr(), ctypes.byref(rows))
-            done()
             ctx = P.ctx
             P.ctx = _op_label(fused_bn)
             self._bn_backward(P, fused_bn, fused_rows=rows.value)
@@ -1571,17 +1529,14 @@ class Executor:
             if fused_bn is not None:          # (an fp32 gradient operand: the kernel with the sums takes bf16 only)
                 ctx = P.ctx
                 P.k(L.pwconv_bwd_data_bf16, dz, lddz, dzf, st.ptr(op.w, st.Pb), gp, ldg, acc, M, op.cin, op.cout)
-                done()
                 P.ctx = _op_label(fused_bn)
                 self._bn_backward(P, fused_bn)
                 P.ctx = ctx
                 return
             P.k(L.pwconv_bwd_data_bf16, dz, lddz, dzf, st.ptr(op.w, st.Pb), gp, ldg, acc, M, op.cin, op.cout)
-            done()
         elif k == 'conv_dw':
             P.k(L.dwconv2d_bwd_data_bf16, dz, lddz, st.ptr(op.w, st.Pb), gp, ldg, acc, N, xt.H, xt.W, op.c, op.k, op.stride,
                 op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
-            done()
         else:
             # dense k x k conv (Xception's entry_flow_conv1_2, ResNet50's 3x3 convs): d/d(im2col matrix) by the GEMM, then the
             # transposed gather back onto the input pixels -- the route of the forward (im2col_bf16 + GEMM), mirrored
@@ -1589,7 +1544,6 @@ class Executor:
                 op.cout)
             P.k(L.col2im_bf16, self.tptr(op.col, True), op.col.ld, gp, ldg, acc, N, xt.H, xt.W, op.cin, op.k, op.stride, op.rate,
                 op.pad_t, op.pad_l, op.Ho, op.Wo)
-            done()
 
     def _use_sb(self, op, fwd, stats):
         """does this pointwise conv run on the split-bf16 GEMM (forward / data-gradient role)?  Only where the tiled kernel
@@ -1801,11 +1755,19 @@ class Executor:
         if not (xt.requires_grad or xt.root.requires_grad):
             return False
         M = self.N * conv.Ho * conv.Wo
-        if M * max(xt.ld, bn_op.z.ld, conv.cout) * 4 >= 2 ** 32:
+        # the launch this decides about (_trace_backward, `out.id in self._folded_dg`): with the sums of a BatchNorm in front of the
+        # conv (role 3) or without (role 2), the gradient written at the pitch of the buffer that collects d/d(conv input)
+        fuse, fuse_add, _ = self._bwd_ctx
+        front = fuse.get(conv) if (conv in fuse and fuse[conv].z.requires_grad) else None
+        if front is None and conv in fuse_add and fuse_add[conv].z.requires_grad:
+            front = fuse_add[conv]
+        vt = getattr(conv.x, 'view_grad', None)
+        ldg = vt.ld if vt is not None else xt.ld
+        if M * max(xt.ld, ldg, bn_op.z.ld, conv.cout, front.z.ld if front is not None else 0) * 4 >= 2 ** 32:
             return False
-        if not self.L.pwconv_bwd_data_sb_apply_supported(M, conv.cin, conv.cout, bn_op.bn.act, 1):
+        if not self.L.pwconv_bwd_data_sb_apply_supported(M, conv.cin, conv.cout, bn_op.bn.act, 1 if front is not None else 0):
             return False
-        return self._use_sb(conv, False, True)
+        return self._use_sb(conv, False, front is not None)
 
     def _folds_apply(self, bn_op):
         """BatchNorm-backward apply folded into the weight gradient of the pointwise conv that produced z (fp32, local
