@@ -23,5 +23,9 @@ for r in rec:
     out.append((b, int(r['rows']), int(r['n']), (int(r['dst']) - G0) // 4))
 out.sort(reverse=True)
 print('%d jobs, %.1f MB of slabs' % (len(out), tot / 1e6))
+L = ex.L
+for v in (0, 1):
+    sel = [o for o in out if L.reduce_rows_variant(o[1], o[2]) == v]
+    print('  reducer variant %d: %d jobs, %.1f MB, rows %s' % (v, len(sel), sum(o[0] for o in sel) / 1e6, sorted({o[1] for o in sel})))
 for b, rows, n, off in out[:40]:
     print('%8.2f MB  rows %5d  n %8d  grad offset %d' % (b / 1e6, rows, n, off))

@@ -6,6 +6,7 @@
 // Reference call sites: CustomBatchNormalization layers.py:63-70; ReLU/Add/Dropout layers.py:98,161,
 // deeplabv3p_mobilenetv2.py:70; AveragePooling2D layers.py:132; SGD common/model_utils.py:124.
 #include "common.h"
+#include <type_traits>
 #include <string.h>
 
 static thread_local char g_err[512] = "";
@@ -106,52 +107,135 @@ struct ReduceJob { const float* src; float* dst; int rows; int n; };
 // row-lane group in the final add): a 64-element workgroup of a 7-slab job reads 1.8 KB and the launch becomes a stream of
 // 400 000 workgroups (Xception: 730 us for 0.7 GB of slabs); here a thread has 4 chunks x 4 rows in flight.  Bit-identical sums.
 #define DL3P_RB_WIDE 4
+// Round 5: the workgroups are PERSISTENT (a grid of a few per CU walks the block list) and read 16 bytes per lane.  A block is 14 KB for
+// a 14-slab job: as one short-lived workgroup each (dispatch, two dependent descriptor loads, one round of row loads, LDS, store) the
+// launch streamed Xception's 2.2 GB of slabs at 3.3 TB/s; the descriptors of the next block are now requested while the rows of this
+// one are in flight.  Per element the rows still go to the same four accumulators in the same order: bit-identical sums.
+#define DL3P_RB_NV 2          // 256-element sub-blocks per block: 16-byte loads in flight per thread and row = NV
 __global__ __launch_bounds__(256) void reduce_rows_batched_wide_kernel(const ReduceJob* __restrict__ jobs,
-                                                                       const int2* __restrict__ blockmap) {
-  constexpr int EL = 64, RL = 4, CH = DL3P_RB_WIDE;
-  __shared__ double sm[CH][RL][EL];
-  const int2 bm = blockmap[blockIdx.x];
-  const ReduceJob jb = jobs[bm.x];
-  const float* __restrict__ partials = jb.src;
-  const size_t n = (size_t)jb.n;
-  const int rows = jb.rows;
+                                                                       const int2* __restrict__ blockmap, int nblocks) {
+  constexpr int EL = 64, RL = 4, CH = DL3P_RB_WIDE, NV = DL3P_RB_NV, SUB = EL * CH;
+  __shared__ double sm[NV * CH * RL * EL];                 // [RL][NV * 256 elements] (vector path) / [CH][RL][EL] (scalar path)
   const int ex = threadIdx.x % EL, ry = threadIdx.x / EL;
-  const size_t i0 = (size_t)bm.y * (EL * CH) + ex;
-  size_t idx[CH];
+  int2 bm = blockmap[blockIdx.x];
+  ReduceJob jb = jobs[bm.x];
+  for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const float* __restrict__ partials = jb.src;
+    float* dst = jb.dst;
+    const size_t n = (size_t)jb.n;
+    const int rows = jb.rows;
+    const int by = bm.y;
+    const int nxt = min(blk + (int)gridDim.x, nblocks - 1);
+    if ((n & 3) == 0 && ((uintptr_t)partials & 15) == 0) {
+      // lane ex of row-lane group ry owns the four CONSECUTIVE elements 4 ex .. 4 ex + 3 of each 256-element sub-block (a wave reads
+      // 1 KB of a row per instruction)
+      size_t ec[NV];
 #pragma unroll
-  for (int c = 0; c < CH; ++c) idx[c] = i0 + (size_t)c * EL < n ? i0 + (size_t)c * EL : n - 1;     // clamped: loads stay in the job
-  double a[CH][4];
+      for (int c = 0; c < NV; ++c) {
+        const size_t e0 = ((size_t)by * NV + c) * SUB + 4 * ex;
+        ec[c] = e0 < n ? e0 : n - 4;                        // clamped: loads stay in the job (n % 4 == 0)
+      }
+      double a[NV][4][4];
 #pragma unroll
-  for (int c = 0; c < CH; ++c) a[c][0] = a[c][1] = a[c][2] = a[c][3] = 0.0;
-  int r = ry;
-  for (; r + 3 * RL < rows; r += 4 * RL) {
-    float v[CH][4];
+      for (int c = 0; c < NV; ++c)
 #pragma unroll
-    for (int c = 0; c < CH; ++c)
+        for (int k = 0; k < 4; ++k) a[c][k][0] = a[c][k][1] = a[c][k][2] = a[c][k][3] = 0.0;
+      int r = ry;
+      bool first = true;
+      for (; r + 3 * RL < rows; r += 4 * RL) {
+        float4 v[NV][4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[c][u] = partials[(size_t)(r + u * RL) * n + idx[c]];
+        for (int c = 0; c < NV; ++c)
 #pragma unroll
-    for (int c = 0; c < CH; ++c)
+          for (int u = 0; u < 4; ++u) v[c][u] = *reinterpret_cast<const float4*>(partials + (size_t)(r + u * RL) * n + ec[c]);
+        if (first) { bm = blockmap[nxt]; jb = jobs[bm.x]; first = false; }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) a[c][u] += (double)v[c][u];
-  }
-  for (; r < rows; r += RL) {
-    float v[CH];
+        for (int c = 0; c < NV; ++c)
 #pragma unroll
-    for (int c = 0; c < CH; ++c) v[c] = partials[(size_t)r * n + idx[c]];
+          for (int u = 0; u < 4; ++u) {
+            a[c][0][u] += (double)v[c][u].x; a[c][1][u] += (double)v[c][u].y;
+            a[c][2][u] += (double)v[c][u].z; a[c][3][u] += (double)v[c][u].w;
+          }
+      }
+      {
+        // the <= 3 remaining rows of this row lane: all requested before the first is added (same accumulator, same order; clamped,
+        // never conditional loads)
+        float4 v[NV][3];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) a[c][0] += (double)v[c];
-  }
+        for (int c = 0; c < NV; ++c)
 #pragma unroll
-  for (int c = 0; c < CH; ++c) sm[c][ry][ex] = (a[c][0] + a[c][1]) + (a[c][2] + a[c][3]);
-  __syncthreads();
-  // the thread group ry finishes chunk ry (CH == RL)
-  const size_t i = i0 + (size_t)ry * EL;
-  if (i < n) {
-    double acc = 0.0;
+          for (int u = 0; u < 3; ++u) v[c][u] = *reinterpret_cast<const float4*>(partials + (size_t)min(r + u * RL, rows - 1) * n + ec[c]);
+        if (first) { bm = blockmap[nxt]; jb = jobs[bm.x]; }
 #pragma unroll
-    for (int q = 0; q < RL; ++q) acc += sm[ry][q][ex];
-    jb.dst[i] = (float)acc;
+        for (int c = 0; c < NV; ++c)
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            const bool ok = r + u * RL < rows;                // (+0.0 for a skipped row: the accumulators are never -0.0)
+            a[c][0][0] += ok ? (double)v[c][u].x : 0.0; a[c][1][0] += ok ? (double)v[c][u].y : 0.0;
+            a[c][2][0] += ok ? (double)v[c][u].z : 0.0; a[c][3][0] += ok ? (double)v[c][u].w : 0.0;
+          }
+      }
+#pragma unroll
+      for (int c = 0; c < NV; ++c)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sm[(ry * NV + c) * SUB + 4 * ex + k] = (a[c][k][0] + a[c][k][1]) + (a[c][k][2] + a[c][k][3]);
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < NV; ++c) {
+        const size_t i = ((size_t)by * NV + c) * SUB + threadIdx.x;
+        if (i < n) {
+          double acc = 0.0;
+#pragma unroll
+          for (int q = 0; q < RL; ++q) acc += sm[(q * NV + c) * SUB + threadIdx.x];
+          dst[i] = (float)acc;
+        }
+      }
+      __syncthreads();
+      continue;
+    }
+    bm = blockmap[nxt];
+    jb = jobs[bm.x];
+    for (int c2 = 0; c2 < NV; ++c2) {
+      const size_t i0 = ((size_t)by * NV + c2) * SUB + ex;
+      if (i0 - ex >= n) break;
+      size_t idx[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) idx[c] = i0 + (size_t)c * EL < n ? i0 + (size_t)c * EL : n - 1;     // clamped: loads stay in the job
+      double a[CH][4];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) a[c][0] = a[c][1] = a[c][2] = a[c][3] = 0.0;
+      int r = ry;
+      for (; r + 3 * RL < rows; r += 4 * RL) {
+        float v[CH][4];
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[c][u] = partials[(size_t)(r + u * RL) * n + idx[c]];
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) a[c][u] += (double)v[c][u];
+      }
+      for (; r < rows; r += RL) {
+        float v[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) v[c] = partials[(size_t)r * n + idx[c]];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) a[c][0] += (double)v[c];
+      }
+#pragma unroll
+      for (int c = 0; c < CH; ++c) sm[(c * RL + ry) * EL + ex] = (a[c][0] + a[c][1]) + (a[c][2] + a[c][3]);
+      __syncthreads();
+      // the thread group ry finishes chunk ry (CH == RL)
+      const size_t i = i0 + (size_t)ry * EL;
+      if (i < n) {
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < RL; ++q) acc += sm[(ry * RL + q) * EL + ex];
+        dst[i] = (float)acc;
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -173,6 +257,29 @@ __global__ __launch_bounds__(256) void reduce_rows_batched_lanes64_kernel(const 
   // four of the thread's 16 lanes at a time (16 loads in flight instead of 4); every lane's accumulators still receive
   // their rows in the same order
   const size_t ic = i < n ? i : n - 1;
+  if (rows <= 3 * RL) {
+    // at most three rows per lane and no lane with a full group of four (that needs row q + 192): the thread's 16 lanes at once, every
+    // row requested before the first is added.  The lane total goes through the same additions as below (all rows into the first
+    // accumulator in row order, then (a0 + 0.0) + (0.0 + 0.0)), so that a -0.0 comes out as it does there.
+    auto few = [&](auto nr_tag) {
+      constexpr int NR = decltype(nr_tag)::value;
+      float v[RL / G][NR];
+#pragma unroll
+      for (int m = 0; m < RL / G; ++m)
+#pragma unroll
+        for (int t = 0; t < NR; ++t) v[m][t] = partials[(size_t)min(g + G * m + t * RL, rows - 1) * n + ic];
+#pragma unroll
+      for (int m = 0; m < RL / G; ++m) {
+        double a0 = 0.0;
+#pragma unroll
+        for (int t = 0; t < NR; ++t) a0 += g + G * m + t * RL < rows ? (double)v[m][t] : 0.0;
+        sm[g + G * m][ex] = (a0 + 0.0) + (0.0 + 0.0);
+      }
+    };
+    if (rows <= RL) few(std::integral_constant<int, 1>());
+    else if (rows <= 2 * RL) few(std::integral_constant<int, 2>());
+    else few(std::integral_constant<int, 3>());
+  } else
   for (int q0 = g; q0 < RL; q0 += 4 * G) {
     double a[4][4];
     int r[4];
@@ -191,16 +298,23 @@ __global__ __launch_bounds__(256) void reduce_rows_batched_lanes64_kernel(const 
         r[u] += 4 * RL;
       }
     }
+    // what is left of a lane: at most FOUR rows (the highest lane has no full group left and the others start <= 12 rows below it) --
+    // one more full group or a tail of < 4 rows; all requested before the first is added (round 5: one at a time, the 42-144-row
+    // jobs of the 33 x 33 layers ran at 2.5 TB/s with one load in flight per lane).  Same accumulators, same order; a skipped row
+    // adds +0.0 (an accumulator that starts at +0.0 is never -0.0: x + 0.0 == x bitwise).
+    float v[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[u][t] = partials[(size_t)min(r[u] + t * RL, rows - 1) * n + ic];     // (clamped, never conditional: a load inside a branch is waited for on the spot)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      int rr = r[u];
-      for (; rr + 3 * RL < rows; rr += 4 * RL) {
-        a[u][0] += (double)partials[(size_t)rr * n + ic];
-        a[u][1] += (double)partials[(size_t)(rr + RL) * n + ic];
-        a[u][2] += (double)partials[(size_t)(rr + 2 * RL) * n + ic];
-        a[u][3] += (double)partials[(size_t)(rr + 3 * RL) * n + ic];
+      const bool full = r[u] + 3 * RL < rows;          // (wave-uniform: the lane is a function of the wave and u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const double d = r[u] + t * RL < rows ? (double)v[u][t] : 0.0;
+        if (full) a[u][t] += d; else a[u][0] += d;
       }
-      for (; rr < rows; rr += RL) a[u][0] += (double)partials[(size_t)rr * n + ic];
       sm[q0 + G * u][ex] = (a[u][0] + a[u][1]) + (a[u][2] + a[u][3]);
     }
   }
@@ -214,16 +328,17 @@ __global__ __launch_bounds__(256) void reduce_rows_batched_lanes64_kernel(const 
 }
 
 extern "C" int dl3p_reduce_rows_variant(int rows, size_t n) { return (n >= 64 * 1024 || rows <= 16) ? 0 : 1; }
-extern "C" int dl3p_reduce_rows_block_elements(int variant) { return variant == 0 ? 64 * DL3P_RB_WIDE : 64; }
+extern "C" int dl3p_reduce_rows_block_elements(int variant) { return variant == 0 ? 64 * DL3P_RB_WIDE * DL3P_RB_NV : 64; }
 
 extern "C" int dl3p_reduce_rows_batched(const void* jobs, const int* blockmap0, int blocks0, const int* blockmap1, int blocks1,
                                         void* stream) {
   DL3P_CHECK_ARG(jobs && blocks0 >= 0 && blocks1 >= 0 && (!blocks0 || blockmap0) && (!blocks1 || blockmap1),
                  "dl3p_reduce_rows_batched: bad arguments");
   hipStream_t st = (hipStream_t)stream;
+  static const int per_cu = getenv("DL3P_RB_PER_CU") ? atoi(getenv("DL3P_RB_PER_CU")) : 8;      // (0: one workgroup per block)
   if (blocks0)
-    hipLaunchKernelGGL(reduce_rows_batched_wide_kernel, dim3(blocks0), dim3(256), 0, st, (const ReduceJob*)jobs,
-                       (const int2*)blockmap0);
+    hipLaunchKernelGGL(reduce_rows_batched_wide_kernel, dim3(per_cu > 0 ? std::min(blocks0, per_cu * dl3p_device_cus()) : blocks0),
+                       dim3(256), 0, st, (const ReduceJob*)jobs, (const int2*)blockmap0, blocks0);
   if (blocks1)
     hipLaunchKernelGGL(reduce_rows_batched_lanes64_kernel, dim3(blocks1), dim3(256), 0, st, (const ReduceJob*)jobs,
                        (const int2*)blockmap1);
