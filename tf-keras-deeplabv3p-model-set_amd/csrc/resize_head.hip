@@ -1118,6 +1118,7 @@ __global__ __launch_bounds__(HR_THREADS) void head_xpass_kernel(HeadRowsParams p
 
 struct HeadYParams { const float* gxh; float* gz; int ldgz; int accumulate; int N, h, w, H, c4s, cp; long long total; };
 
+template <int MAXW>
 __global__ __launch_bounds__(256) void head_ypass_kernel(HeadYParams p) {
   const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
   if (s >= p.total) return;
@@ -1126,19 +1127,27 @@ __global__ __launch_bounds__(256) void head_ypass_kernel(HeadYParams p) {
   const int j = (int)(px % p.w);
   const int row = (int)(px / p.w);
   const int i = row % p.h, n = row / p.h;
-  const float sy = (float)p.h / (float)p.H, isy = (float)p.H / (float)p.h;
-  int y0, y1;
-  touch_range(i, isy, p.H, y0, y1);
-  if (i == 0) y0 = 0;
-  if (i == p.h - 1) y1 = p.H - 1;
-  float4 acc = zero4();
+  const float sy = (float)p.h / (float)p.H;
+  // the rows of the workspace this logit row owns (<= MAXW, host-checked): weights first, then every load before the first add
+  // (clamped rows with weight 0: fma(g, 0, acc) == acc -- never a load inside a branch)
+  int first, count;
+  head_rows_window(i, p.h, p.H, first, count);
+  float wy[MAXW];
+#pragma unroll
+  for (int k = 0; k < MAXW; ++k) {
+    const Lerp ly = lerp_coeff(min(first + k, p.H - 1), sy, p.h);
+    const float wgt = (ly.lo == i ? 1.f - ly.t : 0.f) + (ly.hi == i ? ly.t : 0.f);
+    wy[k] = k < count ? wgt : 0.f;
+  }
   const float* src = p.gxh + (((size_t)n * p.H) * p.w + j) * p.cp + c4 * 4;
-  for (int Y = y0; Y <= y1; ++Y) {
-    const Lerp ly = lerp_coeff(Y, sy, p.h);
-    const float wy = (ly.lo == i ? 1.f - ly.t : 0.f) + (ly.hi == i ? ly.t : 0.f);
-    if (wy == 0.f) continue;
-    const float4 g = ld4(src + (size_t)Y * p.w * p.cp);
-    acc.x = fmaf(g.x, wy, acc.x); acc.y = fmaf(g.y, wy, acc.y); acc.z = fmaf(g.z, wy, acc.z); acc.w = fmaf(g.w, wy, acc.w);
+  float4 g[MAXW];
+#pragma unroll
+  for (int k = 0; k < MAXW; ++k) g[k] = ld4(src + (size_t)min(first + k, first + max(count, 1) - 1) * p.w * p.cp);
+  float4 acc = zero4();
+#pragma unroll
+  for (int k = 0; k < MAXW; ++k) {
+    acc.x = fmaf(g[k].x, wy[k], acc.x); acc.y = fmaf(g[k].y, wy[k], acc.y);
+    acc.z = fmaf(g[k].z, wy[k], acc.z); acc.w = fmaf(g[k].w, wy[k], acc.w);
   }
   float* o = p.gz + (size_t)px * p.ldgz + c4 * 4;
   if (p.accumulate) acc = add4(acc, ld4(o));
@@ -1162,7 +1171,7 @@ extern "C" int dl3p_head_train_rows_supported(int h, int w, int C, int H, int W)
   if (!(cp == 20 || cp == 24 || cp == 32) || h < 1 || w < 1 || H < h || W < w) return 0;
   if (head_rows_ni(w, cp) > 1) return 0;                                   // one (logit column, channel quad) item per thread
   if (head_rows_lds(W, cp) > 150 * 1024) return 0;
-  if (head_rows_maxwin(w, W) > 12) return 0;                               // the x window of a logit column fits the weight table
+  if (head_rows_maxwin(w, W) > 12 || head_rows_maxwin(h, H) > 12) return 0;     // the window of a logit column / row fits the weight table
   return 1;
 }
 
@@ -1215,7 +1224,11 @@ extern "C" int dl3p_head_train_rows(const float* z, int ldz, const float* labels
   HeadYParams q = {};
   q.gxh = (const float*)workspace; q.gz = gz; q.ldgz = ldgz; q.accumulate = accumulate;
   q.N = N; q.h = h; q.w = w; q.H = H; q.c4s = cp / 4; q.cp = cp; q.total = (long long)N * h * w * (cp / 4);
-  hipLaunchKernelGGL(head_ypass_kernel, dim3((unsigned)ceil_div(q.total, 256ll)), dim3(256), 0, st, q);
+  const int mwy = head_rows_maxwin(h, H);
+  const dim3 ygrid((unsigned)ceil_div(q.total, 256ll));
+  if (mwy <= 5) hipLaunchKernelGGL(head_ypass_kernel<5>, ygrid, dim3(256), 0, st, q);
+  else if (mwy <= 9) hipLaunchKernelGGL(head_ypass_kernel<9>, ygrid, dim3(256), 0, st, q);
+  else hipLaunchKernelGGL(head_ypass_kernel<12>, ygrid, dim3(256), 0, st, q);
   DL3P_CHECK_LAUNCH("dl3p_head_train_rows (y pass)");
   return DL3P_OK;
 }
