@@ -139,6 +139,42 @@ PW_CASES = [
 ]
 
 
+@pytest.mark.parametrize('case', [(4356, 2048, 256, True), (4356, 1280, 256, True), (1089 * 2, 2048, 256, False), (4356 + 3, 1028, 128, True),
+                                  (2 * 33 * 33, 2048, 512, True), (16 * 128, 1536, 256, False)])
+def test_pwconv_fwd_splitk_matches_float64_and_the_one_launch_kernel(ops, case):
+    """dl3p_pwconv_fwd_wt_splitk (few rows, long reduction: Xception's ASPP 1x1 convs) against float64, with the lazy prologue, the
+    bias and the BatchNorm statistic rows; and against dl3p_pwconv_fwd_wt on the same operands (equal to rounding)"""
+    M, K, Nn, stats = case
+    L = ops.lib()
+    S = L.pwconv_fwd_splitk_plan(M, K, Nn)
+    assert S > 1, 'the rule serves this shape'
+    assert L.pwconv_fwd_splitk_workspace(M, K, Nn) == 4 * S * M * Nn
+    rng = np.random.default_rng(M + K + Nn)
+    x = rng.standard_normal((M, K))
+    w = rng.standard_normal((K, Nn)) / np.sqrt(K)
+    b = rng.standard_normal(Nn)
+    sc, sh = rng.uniform(0.5, 1.5, K), rng.standard_normal(K) * 0.3
+    xa = np.clip(x * sc + sh, 0.0, 6.0)
+    ref = xa @ w + b
+    wt = T(np.ascontiguousarray(w.T))
+    part = ops.new_partials(Nn, DEV) if stats else None
+    got = ops.pwconv_fwd_wt_splitk(T(x), wt, T(b), T(sc), T(sh), O.ACT_RELU6, partials=part)
+    one = ops.pwconv_fwd_wt(T(x), wt, T(b), T(sc), T(sh), O.ACT_RELU6)
+    y = got[0] if stats else got
+    close(y, ref, rtol=2e-5, atol=2e-5, what='split-K forward vs float64')
+    assert float((y - one).abs().max()) <= 2e-5 * float(one.abs().max())
+    if stats:
+        rows = got[1]
+        assert 1 <= rows <= 2048
+        pr = part[:rows * 2 * Nn].reshape(rows, 2, Nn).double().sum(0).cpu().numpy()
+        close(pr[0], ref.sum(0), rtol=1e-4, atol=1e-2, what='statistic rows: sum')
+        close(pr[1], (ref ** 2).sum(0), rtol=1e-4, atol=1e-2, what='statistic rows: sum of squares')
+    # shapes the rule leaves to the one-launch kernel are refused, not silently served
+    assert L.pwconv_fwd_splitk_plan(66564, 2048, 256) == 0 and L.pwconv_fwd_splitk_plan(4356, 320, 256) == 0
+    with pytest.raises(ops.Dl3pError):
+        ops.pwconv_fwd_wt_splitk(T(x[:, :320]), T(np.ascontiguousarray(w[:320].T)))
+
+
 @pytest.mark.parametrize('case', PW_CASES)
 def test_pwconv_fwd_bwd(ops, case):
     M, K, Nn = case

@@ -13,6 +13,9 @@ struct GemmParams {
   int M, K, N;
   int accumulate;
   int num_m_tiles;
+  // split-K forward (dl3p_pwconv_fwd_wt_splitk; <B_KN = false, STATS = false> instantiations only): gridDim.y = column blocks x ksplit,
+  // workgroup slice z multiplies columns [z kchunk, (z + 1) kchunk) of A with the same rows of B^T and writes slab z of Y = [ksplit][M][ldy]
+  int ksplit, kchunk;
   int stagger;         // pw_split.hip's ablation build only (-DDL3P_SB_ABLATE, scripts/micro/sb_ablate.sh)
   int b_kn;            // pw_small_kernel: B stored [K][N] (forward) or [N][K] (data gradient)
   // fused BatchNorm-backward statistics (data gradient writing the gradient of a BN+activation output): with bb_z

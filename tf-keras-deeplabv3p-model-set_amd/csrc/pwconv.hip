@@ -38,7 +38,25 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define DL3P_GEMM_PIN_B 1      // 0 builds the unpinned loop for A/B runs (scripts/micro/build_variant.sh)
 #endif
 template <int NT, bool B_KN, bool STATS, int MI, int BKT, bool BNB = false, bool GA = false>
-__global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p_in) {
+  GemmParams p = p_in;
+  int block_y = blockIdx.y;
+#ifndef DL3P_NO_SPLITK
+  if constexpr (!B_KN && !STATS && !BNB && !GA) {
+    if (p.ksplit > 1) {                     // split-K forward: this workgroup's slice of the reduction and its slab of the output
+      const int nbn = (int)gridDim.y / p.ksplit;
+      const int z = block_y / nbn;
+      block_y -= z * nbn;
+      const int k_lo = z * p.kchunk;
+      p.A += k_lo;
+      if (p.scale) { p.scale += k_lo; p.shift += k_lo; }
+      p.B += k_lo;
+      p.K = min(p.kchunk, p.K - k_lo);
+      p.Y += (size_t)z * p.M * p.ldy;
+      p.bias = nullptr;
+    }
+  }
+#endif
   constexpr int AP = BKT + 4;   // A pitch: rows 4 apart land 16 banks apart -> ds_read_b128 conflict-free
   constexpr int KQ = BKT / 4;   // float4 per K-tile row
   constexpr int RP = 256 / KQ;  // A rows staged per pass of the 256 threads
@@ -72,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmParams p) {
   const int w = t >> 6;
   const int l15 = l & 15;
   const int q = l >> 4;
-  const int n0 = blockIdx.y * BN;
+  const int n0 = block_y * BN;
   const int nk = (p.K + BKT - 1) / BKT;
   const int my_tiles = (p.num_m_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int it_total = my_tiles * nk;
@@ -617,6 +635,7 @@ static bool pw_small_pick(int K, int N, SmallShape* out) {
 // tests that check the production dispatch at the production shapes.
 static int g_gemm_force_nt = 0, g_gemm_force_mi = 0, g_gemm_force_pc = 0, g_gemm_use_table = -1;   // see gemm_tuned_lookup / gemm_plan
 static int g_split_wgrad = -1;      // dl3p_set_option("split_wgrad", 0 | 1): weight gradients on the split-bf16 kernel (default DL3P_SPLIT_WGRAD, else DL3P_SPLIT_GEMM, else 1)
+static int g_splitk_force = -1;        // "splitk": -1 the rule, 0 never, S > 0 that many slices where the shape is served (dl3p_pwconv_fwd_splitk_plan)
 static int g_sbw_force_tile = -1, g_sbw_force_pc = 0;      // "split_wgrad_tile" (0..3, -1 none) / "split_wgrad_per_cu": pin its plan (and bypass the verdicts)
 static int g_sb_pipe = -1;      // dl3p_set_option("sb_pipe", 0 | 1): the producer / consumer form of the split kernel (default DL3P_SB_PIPE or 0)
 static int g_sb_force_wm = 0, g_sb_force_nt = 0;      // dl3p_set_option("sb_wm" / "sb_nt"): pin the split kernel's wide-tile family (gemm_plan_sb)
@@ -644,6 +663,7 @@ extern "C" int dl3p_set_option(const char* name, int value) {
   if (!strcmp(name, "split_wgrad")) { g_split_wgrad = value ? 1 : 0; return DL3P_OK; }
   if (!strcmp(name, "split_wgrad_tile")) { g_sbw_force_tile = (value >= 0 && value <= 3) ? value : -1; return DL3P_OK; }
   if (!strcmp(name, "split_wgrad_per_cu")) { g_sbw_force_pc = value > 0 ? value : 0; return DL3P_OK; }
+  if (!strcmp(name, "splitk")) { g_splitk_force = value; return DL3P_OK; }
   if (!strcmp(name, "sb_wm")) { g_sb_force_wm = (value >= -1 && value <= 2) ? value : 0; return DL3P_OK; }    // -1: never wide
   if (!strcmp(name, "sb_rs")) { g_sb_rs = value < 0 ? -1 : (value ? 1 : 0); return DL3P_OK; }
   if (!strcmp(name, "bf16_kg")) { dl3p_bf16_force_kg = (value == 0 || value == 1 || value == 2 || value == 4) ? value : -1; return DL3P_OK; }
@@ -669,6 +689,7 @@ extern "C" int dl3p_get_option(const char* name) {
   if (!strcmp(name, "conv_sb")) return g_conv_sb;
   if (!strcmp(name, "sb_rs")) return g_sb_rs;
   if (!strcmp(name, "sb_pipe")) return g_sb_pipe;
+  if (!strcmp(name, "splitk")) return g_splitk_force;
   return INT_MIN;
 }
 
@@ -920,6 +941,111 @@ extern "C" int dl3p_pwconv_fwd_wt(const float* x, int ldx, const float* in_scale
                                   int* rows_out, int M, int K, int N, void* stream) {
   return pwconv_fwd_impl("dl3p_pwconv_fwd_wt", x, ldx, in_scale, in_shift, in_act, wt, false, bias, y, ldy,
                          stat_partials, rows_out, M, K, N, stream);
+}
+
+// ------------------------------------------------------------------------------ split-K forward
+// Few rows and a long reduction (Xception's / ResNet50's ASPP at a 33 x 33 map: 4356 x 2048 -> 256) give the tiled kernel 34 row
+// tiles for 256 CUs: with 32-column blocks (its best, 552 workgroups) every workgroup re-reads its 64 x 2048 slice of A for a
+// quarter of the output width and the launch runs at a third of the fp32 matrix rate.  Here the REDUCTION is cut into slices of
+// >= 256: 64 x 128 tiles x ~5 slices fill the chip with workgroups that each stream a 64 x 416 panel of A once; the slices leave
+// slabs [S][M][N] in a workspace and splitk_finish_kernel adds them in slice order (+ bias) and takes the BatchNorm statistic rows
+// from the finished output.  Deterministic; the sum is associated differently from the one-launch kernel (equal to rounding).
+// (The same slices on the split-bf16 kernel were measured at 52.8-55.3 us against 59.0 here for 4356 x 2048 -> 256, 39.4-39.9 against
+// 41.2 at K = 1280 -- both forms are bound by the latency of their 13 K-steps per tile, not by the matrix pipe -- and are not built in.)
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ slabs, int S, const float* __restrict__ bias,
+                                                            float* __restrict__ y, int ldy, float* __restrict__ partials, int M,
+                                                            int N, int rows_per_wg) {
+  __shared__ float red[2][256 * 4];
+  const int c4n = N / 4;                       // float4 columns per row; 256 % c4n == 0 (host)
+  const int rpp = 256 / c4n;                   // rows per pass of the workgroup
+  const int c4 = threadIdx.x % c4n, rg = threadIdx.x / c4n;
+  const int r0 = blockIdx.x * rows_per_wg;
+  float4 s = zero4(), ss = zero4();
+  float4 b4 = zero4();
+  if (bias) b4 = ld4(bias + c4 * 4);
+  for (int r = r0 + rg; r < min(r0 + rows_per_wg, M); r += rpp) {
+    float4 acc = ld4(slabs + ((size_t)r * N + c4 * 4));
+    for (int z = 1; z < S; ++z) acc = add4(acc, ld4(slabs + (((size_t)z * M + r) * N + c4 * 4)));
+    acc = add4(acc, b4);
+    st4(y + (size_t)r * ldy + c4 * 4, acc);
+    s = add4(s, acc);
+    ss.x = fmaf(acc.x, acc.x, ss.x); ss.y = fmaf(acc.y, acc.y, ss.y); ss.z = fmaf(acc.z, acc.z, ss.z); ss.w = fmaf(acc.w, acc.w, ss.w);
+  }
+  if (!partials) return;
+  *reinterpret_cast<float4*>(&red[0][threadIdx.x * 4]) = s;
+  *reinterpret_cast<float4*>(&red[1][threadIdx.x * 4]) = ss;
+  __syncthreads();
+  if (rg == 0) {
+    float4 a = zero4(), b = zero4();
+    for (int g = 0; g < rpp; ++g) {
+      a = add4(a, *reinterpret_cast<const float4*>(&red[0][(g * c4n + c4) * 4]));
+      b = add4(b, *reinterpret_cast<const float4*>(&red[1][(g * c4n + c4) * 4]));
+    }
+    st4(partials + ((size_t)blockIdx.x * 2) * N + c4 * 4, a);
+    st4(partials + ((size_t)blockIdx.x * 2 + 1) * N + c4 * 4, b);
+  }
+}
+
+// -> slices (0: the one-launch kernel); kchunk_out = reduction length of a slice (a multiple of 32)
+extern "C" int dl3p_pwconv_fwd_splitk_plan(int M, int K, int N) {
+  static const int env = getenv("DL3P_SPLITK") ? atoi(getenv("DL3P_SPLITK")) : -1;      // (A/B switch: 0 = never)
+  if (g_splitk_force == 0 || (g_splitk_force < 0 && env == 0)) return 0;
+  if (!(N == 128 || N == 256 || N == 512) || K % 4 || K < 512 || M < 1024) return 0;
+  if ((unsigned long long)M * (unsigned long long)K * 4ull >= (1ull << 32)) return 0;
+  // measured (scripts/micro/splitk_bench.py, 64 x 128 tiles): 4356 x 2048 -> 256: one launch 93.8 us, 5 slices 59.8 (8: 64.6, 10: 62.4,
+  // 4: 69.5); 4356 x 1280: 55.2 -> 41.1 (4: 46.7, 8: 46.2); 8712 x 2048: 131.5 -> 102.5; at 17424 rows (272 tiles x 2) the slices tie with
+  // the one-launch kernel.
+  // Rule: about 2.5 workgroups per CU, slices of at least 256.
+  const int tiles = ceil_div(M, 64) * ceil_div(N, 128);
+  if (g_splitk_force < 0 && (tiles > 300 || K < 1024)) return 0;          // the tiled kernel already has a workgroup or two per CU
+  int S = g_splitk_force > 0 ? g_splitk_force : std::max(2, (640 + tiles / 2) / tiles);
+  S = std::min(S, std::min(16, K / 256));
+  while (S > 1 && ceil_div(ceil_div(K, S), 32) * 32 * (S - 1) >= K) --S;   // every slice owns at least one column
+  return S > 1 ? S : 0;
+}
+extern "C" size_t dl3p_pwconv_fwd_splitk_workspace(int M, int K, int N) {
+  const int S = dl3p_pwconv_fwd_splitk_plan(M, K, N);
+  return S ? sizeof(float) * (size_t)S * M * N : 0;
+}
+
+extern "C" int dl3p_pwconv_fwd_wt_splitk(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
+                                         const float* wt, const float* bias, float* y, int ldy, float* stat_partials,
+                                         int* rows_out, void* workspace, size_t workspace_bytes, int M, int K, int N,
+                                         void* stream) {
+  const char* fn = "dl3p_pwconv_fwd_wt_splitk";
+  int rc = check_mat(fn, x, ldx, K);
+  if (rc) return rc;
+  rc = check_mat(fn, y, ldy, N);
+  if (rc) return rc;
+  DL3P_CHECK_ARG(wt && aligned16(wt) && M > 0 && workspace && aligned16(workspace), "%s: bad arguments", fn);
+  const int S = dl3p_pwconv_fwd_splitk_plan(M, K, N);
+  DL3P_CHECK_ARG(S > 1, "%s: M=%d K=%d N=%d is not served (dl3p_pwconv_fwd_splitk_plan; use dl3p_pwconv_fwd_wt)", fn, M, K, N);
+  DL3P_CHECK_ARG(workspace_bytes >= sizeof(float) * (size_t)S * M * N, "%s: workspace of %zu bytes, %zu needed", fn, workspace_bytes,
+                 sizeof(float) * (size_t)S * M * N);
+  DL3P_CHECK_ARG((unsigned long long)M * (unsigned long long)std::max(ldx, ldy) * 4ull < (1ull << 32) &&
+                 (unsigned long long)S * M * N * 4ull < (1ull << 32), "%s: operands of 4 GiB or more are not supported", fn);
+  GemmParams p = {};
+  p.A = x; p.lda = ldx; p.scale = in_scale; p.shift = in_shift; p.act = in_act;
+  p.B = wt; p.ldb = K; p.bias = nullptr; p.Y = (float*)workspace; p.ldy = N; p.partials = nullptr;
+  p.M = M; p.K = K; p.N = N;
+  p.ksplit = S; p.kchunk = ceil_div(ceil_div(K, S), 32) * 32;
+  static const int nt_env = getenv("DL3P_SPLITK_NT") ? atoi(getenv("DL3P_SPLITK_NT")) : 8;
+  static const int mi_env = getenv("DL3P_SPLITK_MI") ? atoi(getenv("DL3P_SPLITK_MI")) : 1;
+  const int nt = std::min(nt_env, ceil_div(N, 16)), mi = mi_env;
+  p.num_m_tiles = ceil_div(M, 64 * mi);
+  const int nb = ceil_div(N, 16 * nt);
+  hipStream_t st = (hipStream_t)stream;
+  launch_gemm<false, false>(p, nt, mi, dim3(p.num_m_tiles, nb * S), st);
+  DL3P_CHECK_LAUNCH(fn);
+  const int rpp = 256 / (N / 4);
+  int rows_per_wg = rpp * 4;
+  while (ceil_div(M, rows_per_wg) > DL3P_MAX_STAT_ROWS) rows_per_wg += rpp;
+  const int wgs = ceil_div(M, rows_per_wg);
+  if (rows_out) *rows_out = wgs;
+  hipLaunchKernelGGL(splitk_finish_kernel, dim3(wgs), dim3(256), 0, st, (const float*)workspace, S, bias, y, ldy, stat_partials, M, N,
+                     rows_per_wg);
+  DL3P_CHECK_LAUNCH(fn);
+  return DL3P_OK;
 }
 
 // dst[off + n*K + k] = src[off + k*N + n] for every (off, K, N) row of `table` (device, int[n][4]): the transposed

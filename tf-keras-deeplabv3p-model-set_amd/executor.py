@@ -421,7 +421,7 @@ class Executor:
         self.L.set_option(b'split_wgrad', self._split_wgrad)
         # ... and the other process-wide knobs that decide how many slabs / partial rows a traced launch writes: recorded now, pinned
         # again before every eager replay (_pin_options; a captured graph carries its launches' grids with it)
-        self._pinned = {k: self.L.get_option(k) for k in (b'conv_sb', b'sb_rs', b'sb_pipe')}
+        self._pinned = {k: self.L.get_option(k) for k in (b'conv_sb', b'sb_rs', b'sb_pipe', b'splitk')}
         self._find_irb()
         self._alloc()
         # tracing runs every kernel once on zero inputs: keep the weights / optimiser state intact
@@ -512,6 +512,10 @@ class Executor:
                 if self._dense_gemm(op):
                     ws = max(ws, L.conv2d_gemm_bwd_weight_workspace(N, op.Ho, op.Wo, op.cin, op.cout, op.k))
         self.workspace = torch.zeros(ws // 4 + 4, **self.f32) if self.training else None
+        # slabs of the split-K forward GEMMs (dl3p_pwconv_fwd_wt_splitk), training and inference
+        sk = 0 if self.bf16 else max([L.pwconv_fwd_splitk_workspace(N * op.Ho * op.Wo, op.cin, op.cout)
+                                      for op in g.ops if op.kind == 'conv_pw'] + [0])
+        self.splitk_ws = torch.zeros(sk // 4 + 4, **self.f32) if sk else None
         # tickets + partial rows of the chunked per-image reductions (pooling, SE backward): zero once, every call
         # leaves its tickets at zero again; one stream runs all of them
         pws = 0
@@ -802,6 +806,11 @@ class Executor:
                     P.k(L.pwconv_fwd_sb, xp, ldx, sp, hp, act, wsp, pitch, st.ptr(op.b) if op.b else None,
                         self.tptr(op.out), op.out.ld, part, ctypes.byref(rows), N * op.Ho * op.Wo, op.cin, op.cout,
                         tag='pw:' + op.name)
+                elif k == 'conv_pw' and self.splitk_ws is not None and L.pwconv_fwd_splitk_plan(N * op.Ho * op.Wo, op.cin, op.cout):
+                    # few rows, long reduction (Xception's / ResNet50's ASPP 1x1 convs on the 33 x 33 map): split-K, two launches
+                    P.k(L.pwconv_fwd_wt_splitk, xp, ldx, sp, hp, act, st.ptr(op.w, st.Pt), st.ptr(op.b) if op.b else None,
+                        self.tptr(op.out), op.out.ld, part, ctypes.byref(rows), self.splitk_ws.data_ptr(), self.splitk_ws.numel() * 4,
+                        N * op.Ho * op.Wo, op.cin, op.cout, tag='pw:' + op.name)
                 elif k == 'conv_pw':
                     P.k(L.pwconv_fwd_wt, xp, ldx, sp, hp, act, st.ptr(op.w, st.Pt), st.ptr(op.b) if op.b else None,
                         self.tptr(op.out), op.out.ld, part, ctypes.byref(rows), N * op.Ho * op.Wo, op.cin, op.cout,

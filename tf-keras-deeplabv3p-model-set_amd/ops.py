@@ -176,6 +176,21 @@ def pwconv_fwd_wt(x, wt, bias=None, in_scale=None, in_shift=None, in_act=ACT_NON
     return (y, rows.value) if partials is not None else y
 
 
+def pwconv_fwd_wt_splitk(x, wt, bias=None, in_scale=None, in_shift=None, in_act=ACT_NONE, out=None, partials=None):
+    """pwconv_fwd_wt through the split-K form (few rows, long reduction); raises Dl3pError where dl3p_pwconv_fwd_splitk_plan says 0"""
+    M, K = _rows(x), x.shape[-1]
+    N = wt.shape[0]
+    y = out if out is not None else torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+    xp, ldx = _pl(x)
+    yp, ldy = _pl(y)
+    rows = ctypes.c_int(0)
+    wsb = lib().pwconv_fwd_splitk_workspace(M, K, N)
+    ws = torch.empty(max(wsb, 16) // 4, dtype=torch.float32, device=x.device)
+    lib().pwconv_fwd_wt_splitk(xp, ldx, _p(in_scale), _p(in_shift), in_act, _p(wt), _p(bias), yp, ldy, _p(partials),
+                               ctypes.byref(rows), _p(ws), wsb, M, K, N, _stream())
+    return (y, rows.value) if partials is not None else y
+
+
 def transpose_batch(src, dst, table):
     lib().transpose_batch(_p(src), _p(dst), _p(table), int(table.shape[0]), _stream())
 
