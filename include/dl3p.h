@@ -528,6 +528,14 @@ int dl3p_dwconv2d_bwd_weight_slabs(const float* x, int ldx, const float* in_scal
 int dl3p_stem_conv_bwd_weight_slabs(const float* x, int ldx, const float* dy, int lddy, float* workspace,
                                     size_t workspace_bytes, int* rows_out, int N, int H, int W, int Cout, int pad_t,
                                     int pad_l, int Ho, int Wo, void* stream);
+/* ... with the BatchNorm-backward apply of the stem's own BatchNorm folded in (g = gradient of act(BN(z)), coef from
+ * dl3p_bn_bwd_finalize; the stem has no data gradient, so dz is never written): replaces dl3p_bn_bwd_apply +
+ * dl3p_stem_conv_bwd_weight_slabs for Conv -> Conv_BN (deeplabv3p_mobilenetv2.py:108-125, layers.py:63-70). */
+int dl3p_stem_conv_bwd_weight_slabs_bn(const float* x, int ldx, const float* g, int ldg, const float* z, int ldz,
+                                       const float* bn_scale, const float* bn_shift, int bn_act, const float* save_mean,
+                                       const float* save_invstd, const float* coef, float* workspace, size_t workspace_bytes,
+                                       int* rows_out, int N, int H, int W, int Cout, int pad_t, int pad_l, int Ho, int Wo,
+                                       void* stream);
 int dl3p_conv2d_gemm_bwd_weight_slabs(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
                                       const float* dy, int lddy, float* workspace, size_t workspace_bytes, int* rows_out,
                                       int N, int H, int W, int Cin, int Cout, int k, int stride, int rate,

@@ -507,6 +507,34 @@ def test_stem_conv_direct(ops, case):
           what='stem bwd weight vs im2col route')
 
 
+@pytest.mark.parametrize('case', [(2, 65, 65, 32, O.ACT_RELU6), (1, 130, 129, 16, O.ACT_HSWISH), (3, 33, 47, 32, O.ACT_NONE)])
+def test_stem_weight_gradient_with_the_batchnorm_apply_folded_in(ops, case):
+    """dl3p_stem_conv_bwd_weight_slabs_bn == dl3p_bn_bwd_apply followed by dl3p_stem_conv_bwd_weight (the stem has no data gradient:
+    dz is formed while the gradient rows are staged and never written), and == float64"""
+    N, H, W, Cout, act = case
+    rng = np.random.default_rng(H + Cout)
+    x = rng.uniform(-1, 1, (N, H, W, 3))
+    w = rng.standard_normal((3, 3, 3, Cout)) * 0.3
+    gamma, beta = rng.uniform(0.5, 1.5, Cout), rng.standard_normal(Cout) * 0.2
+    part = ops.new_partials(Cout, DEV)
+    z, rows = ops.stem_conv_fwd(T(x), T(w), 'same', partials=part)
+    bn = ops.BNState(Cout, DEV, 1e-3, 0.99)
+    bn.gamma.copy_(T(gamma)); bn.beta.copy_(T(beta))
+    M = z.numel() // Cout
+    ops.bn_finalize(bn, part, rows, M)
+    g = T(rng.standard_normal(tuple(z.shape)))
+    dz = ops.bn_backward(bn, g, z, act, part, out=torch.empty_like(g))        # leaves bn.coef; g untouched
+    two = ops.stem_conv_bwd_weight(T(x), dz, 'same')
+    one = ops.stem_conv_bwd_weight_bn(T(x), g, z, bn, act, 'same')
+    scale = float(two.abs().max())
+    assert float((one - two).abs().max()) <= 2e-5 * scale, (float((one - two).abs().max()), scale)
+    z64 = O.conv2d_fwd(x, w, 2, 1, 'same')
+    y_ref, cache, _ = O.bn_train_fwd(z64, gamma, beta, 1e-3)
+    gz_ref, _, _ = O.bn_train_bwd(O.act_bwd(y_ref, g.cpu().numpy().astype(np.float64), act), cache)
+    _, gw_ref, _ = O.conv2d_bwd(x, w, gz_ref, 2, 1, 'same')
+    close(one, gw_ref, rtol=1e-3, atol=2e-4 * float(np.abs(gw_ref).max()), what='folded stem weight gradient vs float64')
+
+
 @pytest.mark.parametrize('shape,act', [((2, 9, 9, 32), O.ACT_RELU6), ((3, 1, 1, 256), O.ACT_RELU),
                                        ((1, 33, 33, 24), O.ACT_NONE), ((2, 8, 8, 64), O.ACT_HSWISH)])
 def test_batchnorm_fwd_bwd(ops, shape, act):

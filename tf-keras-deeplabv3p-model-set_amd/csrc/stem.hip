@@ -25,48 +25,56 @@ struct StemParams {
   float* partials;           // forward: [grid][2][Cout] BatchNorm statistic rows
   const float* dy; int lddy;
   float* slabs;              // weight gradient: [grid][28][Cout]
+  // weight gradient with the BatchNorm-backward apply of the conv's own BatchNorm folded in (FOLD instantiation): dy is the gradient g
+  // of act(BN(z)); dz = c0 (g act'(z scale + shift) - c1 - xhat c2) is formed while the gradient rows are staged (as A g act' - C z + D)
+  const float* f_z; int f_ldz; const float* f_scale; const float* f_shift; const float* f_mean; const float* f_invstd;
+  const float* f_coef; int f_act;
   int N, H, W, Ho, Wo, Cout, pad_t, pad_l, segs, tiles;
 };
 
 // stage the 3 input rows of tile (n, oy, ox0 ..) into this wave's LDS tile; out-of-image taps are zero
-__device__ __forceinline__ void stem_stage(const StemParams& p, float* tile, int n, int oy, int ox0, int l) {
+#define STEM_IT ((STEM_ROW + 63) / 64)
+// The staging of a tile in two halves, so that the loads of the NEXT tile are in flight while this one is multiplied (round 5: a tile
+// was load -> wait -> LDS -> MFMA; with two waves per SIMD -- the LDS tiles allow no more -- the launch sat at 3.3 TB/s).
+// stem_fetch: the three input rows of tile (n, oy, ox0 ..) into registers.  Branch-free: every load is issued from a clamped address and
+// out-of-image taps are selected to zero in stem_put.  (A predicated load per tap -- which is also what the compiler makes of
+// `cond ? load : 0` by sinking the load into the branch -- waits for each load before the next branch: 21 serialized memory latencies
+// per tile, 87 us per launch.)
+__device__ __forceinline__ void stem_fetch(const StemParams& p, int n, int oy, int ox0, int l, float (&v)[3][STEM_IT]) {
   const int ix0 = 2 * ox0 - p.pad_l;
-  constexpr int IT = (STEM_ROW + 63) / 64;
-  float v[3][IT];
-  bool ok[3][IT];
-  // Branch-free: every load is issued from a clamped address and out-of-image taps are selected to zero afterwards.  (A
-  // predicated load per tap -- which is also what the compiler makes of `cond ? load : 0` by sinking the load into the
-  // branch -- waits for each load before the next branch: 21 serialized memory latencies per tile, 87 us per launch.)
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky) {
     const int iy = 2 * oy - p.pad_t + ky;
     const bool rowok = iy >= 0 && iy < p.H;
     const float* src = p.x + ((size_t)n * p.H + (rowok ? iy : 0)) * p.W * p.ldx;
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
+    for (int it = 0; it < STEM_IT; ++it) {
       const int i = l + 64 * it;
       const int ic = i < STEM_ROW ? i : STEM_ROW - 1;
       const int px = ic / 3, ci = ic - 3 * px;
       const int ix = ix0 + px;
       const int ixc = ix < 0 ? 0 : (ix < p.W ? ix : p.W - 1);
       v[ky][it] = src[(size_t)ixc * p.ldx + ci];
-      ok[ky][it] = rowok && ix == ixc;
     }
   }
+}
+// stem_put: what stem_fetch requested for tile (n, oy, ox0 ..) into this wave's LDS tile; out-of-image taps are zero
+__device__ __forceinline__ void stem_put(const StemParams& p, float* tile, int oy, int ox0, int l, float (&v)[3][STEM_IT]) {
+  const int ix0 = 2 * ox0 - p.pad_l;
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky)
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = 2 * oy - p.pad_t + ky;
+    const bool rowok = iy >= 0 && iy < p.H;
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-      asm volatile("" : "+v"(v[ky][it]));  // keeps the load above unconditional
-      v[ky][it] = ok[ky][it] ? v[ky][it] : 0.f;
-    }
-#pragma unroll
-  for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
+    for (int it = 0; it < STEM_IT; ++it) {
       const int i = l + 64 * it;
-      if (i < STEM_ROW) tile[ky * STEM_PP + i] = v[ky][it];
+      const int ic = i < STEM_ROW ? i : STEM_ROW - 1;
+      const int ix = ix0 + ic / 3;
+      asm volatile("" : "+v"(v[ky][it]));  // keeps the load in stem_fetch unconditional
+      const float x = (rowok && ix >= 0 && ix < p.W) ? v[ky][it] : 0.f;
+      if (i < STEM_ROW) tile[ky * STEM_PP + i] = x;
     }
+  }
 }
 
 __device__ __forceinline__ void stem_tile_coords(const StemParams& p, int tile, int* n, int* oy, int* ox0) {
@@ -97,11 +105,23 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
   for (int ni = 0; ni < NI; ++ni) { s1[ni] = zero4(); s2[ni] = zero4(); }
   float* tile = patch[wv];
   const XcdRange rg = xcd_range(p.tiles, blockIdx.x, gridDim.x, 4, wv);
+  float xv3[3][STEM_IT];
+  if (rg.begin < rg.end) {
+    int n, oy, ox0;
+    stem_tile_coords(p, rg.begin, &n, &oy, &ox0);
+    stem_fetch(p, n, oy, ox0, l, xv3);
+  }
   for (int ti = rg.begin; ti < rg.end; ti += rg.step) {
     int n, oy, ox0;
     stem_tile_coords(p, ti, &n, &oy, &ox0);
     __builtin_amdgcn_wave_barrier();
-    stem_stage(p, tile, n, oy, ox0, l);
+    stem_put(p, tile, oy, ox0, l, xv3);
+    {
+      // the next tile's rows: in flight while this one is multiplied (the last tile requests itself again: no branch around loads)
+      int n2, oy2, ox2;
+      stem_tile_coords(p, ti + rg.step < rg.end ? ti + rg.step : ti, &n2, &oy2, &ox2);
+      stem_fetch(p, n2, oy2, ox2, l, xv3);
+    }
     __builtin_amdgcn_wave_barrier();
     typedef float f4v __attribute__((ext_vector_type(4)));
     f4v acc[4][NI];
@@ -153,7 +173,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
   }
 }
 
-template <int NI>
+template <int NI, bool FOLD = false>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
   constexpr int CP = NI * 16 + 8;  // pitch of the staged gradient rows: the four pixel quarters land on disjoint bank octets
   __shared__ float patch[4][3 * STEM_PP];
@@ -177,23 +197,55 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
     for (int ni = 0; ni < NI; ++ni) acc[kt][ni] = (f4v){0.f, 0.f, 0.f, 0.f};
   float* tile = patch[wv];
   float* dt = dys[wv];
+  // FOLD: the lane's four channels are the same in every staging pass (64 % C4 == 0): their coefficients once
+  float4 fA = zero4(), fC = zero4(), fD = zero4(), fsc = make_float4(1.f, 1.f, 1.f, 1.f), fsh = zero4();
+  if (FOLD) {
+    const int c = 4 * (l % (NI * 4));
+    if (p.f_scale) { fsc = ld4(p.f_scale + c); fsh = ld4(p.f_shift + c); }
+    const float4 mu = ld4(p.f_mean + c), is = ld4(p.f_invstd + c);
+    const float4 c0 = ld4(p.f_coef + c), c1 = ld4(p.f_coef + p.Cout + c), c2 = ld4(p.f_coef + 2 * p.Cout + c);
+    fA = c0;
+    fC = mul4(mul4(c0, is), c2);
+    fD = make_float4(fC.x * mu.x - c0.x * c1.x, fC.y * mu.y - c0.y * c1.y, fC.z * mu.z - c0.z * c1.z, fC.w * mu.w - c0.w * c1.w);
+  }
   const XcdRange rg = xcd_range(p.tiles, blockIdx.x, gridDim.x, 4, wv);
-  for (int ti = rg.begin; ti < rg.end; ti += rg.step) {
+  constexpr int C4 = NI * 4;  // 16-byte vectors per row
+  constexpr int IT = STEM_TP * C4 / 64;
+  float xv3[3][STEM_IT];
+  float4 g[IT];
+  float4 zz[FOLD ? IT : 1];
+  // the input rows and the 64 gradient rows of a tile: requested one tile ahead, in flight while the current tile is multiplied
+  auto fetch = [&](int tile_index) __attribute__((always_inline)) {
     int n, oy, ox0;
-    stem_tile_coords(p, ti, &n, &oy, &ox0);
-    __builtin_amdgcn_wave_barrier();
-    stem_stage(p, tile, n, oy, ox0, l);
-    // the 64 gradient rows of the tile (zero beyond the end of the output row)
+    stem_tile_coords(p, tile_index, &n, &oy, &ox0);
+    stem_fetch(p, n, oy, ox0, l, xv3);
     const size_t m0 = ((size_t)n * p.Ho + oy) * p.Wo + ox0;
-    constexpr int C4 = NI * 4;  // 16-byte vectors per row
-    constexpr int IT = STEM_TP * C4 / 64;
-    float4 g[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
       const int i = l + 64 * it;
       const int px = i / C4, c4 = i - px * C4;
       const int last = p.Wo - 1 - ox0;  // >= 0: a tile starts inside the row
       g[it] = ld4(p.dy + (m0 + (px < last ? px : last)) * p.lddy + 4 * c4);
+      if (FOLD) zz[it] = ld4(p.f_z + (m0 + (px < last ? px : last)) * p.f_ldz + 4 * c4);
+    }
+  };
+  if (rg.begin < rg.end) fetch(rg.begin);
+  for (int ti = rg.begin; ti < rg.end; ti += rg.step) {
+    int n, oy, ox0;
+    stem_tile_coords(p, ti, &n, &oy, &ox0);
+    __builtin_amdgcn_wave_barrier();
+    stem_put(p, tile, oy, ox0, l, xv3);
+    if (FOLD) {
+      const int fact = p.f_act;
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const float4 z = zz[it], gg = g[it];
+        const float4 u = fma4(z, fsc, fsh);
+        g[it] = make_float4(fmaf(fA.x, gg.x * act_grad(u.x, fact), fmaf(-fC.x, z.x, fD.x)),
+                            fmaf(fA.y, gg.y * act_grad(u.y, fact), fmaf(-fC.y, z.y, fD.y)),
+                            fmaf(fA.z, gg.z * act_grad(u.z, fact), fmaf(-fC.z, z.z, fD.z)),
+                            fmaf(fA.w, gg.w * act_grad(u.w, fact), fmaf(-fC.w, z.w, fD.w)));
+      }
     }
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
@@ -207,6 +259,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemParams p) {
       const int px = i / C4, c4 = i - px * C4;
       st4(dt + px * CP + 4 * c4, g[it]);
     }
+    fetch(ti + rg.step < rg.end ? ti + rg.step : ti);      // (the last tile requests itself again: no branch around loads)
     __builtin_amdgcn_wave_barrier();
     const int ns = (p.Wo - ox0 + 3) >> 2;  // 4-pixel steps of this tile that lie in the row
 #pragma unroll
@@ -296,9 +349,12 @@ extern "C" size_t dl3p_stem_conv_bwd_weight_workspace(int N, int Ho, int Wo, int
   return (size_t)stem_wgrad_grid(N, Ho, Wo) * 28 * Cout * sizeof(float);
 }
 
+struct StemFold { const float* z; int ldz; const float* scale; const float* shift; int act; const float* mean; const float* invstd;
+                  const float* coef; };
+
 static int stem_conv_bwd_weight_impl(const float* x, int ldx, const float* dy, int lddy, float* gw, float* workspace,
                                      size_t workspace_bytes, int N, int H, int W, int Cout, int pad_t, int pad_l,
-                                     int Ho, int Wo, int* rows_out, void* stream) {
+                                     int Ho, int Wo, int* rows_out, void* stream, const StemFold* fold = nullptr) {
   StemParams p = {};
   int rc = stem_fill("dl3p_stem_conv_bwd_weight", &p, N, H, W, Cout, pad_t, pad_l, Ho, Wo);
   if (rc) return rc;
@@ -309,7 +365,15 @@ static int stem_conv_bwd_weight_impl(const float* x, int ldx, const float* dy, i
   DL3P_CHECK_ARG(workspace_bytes >= need, "dl3p_stem_conv_bwd_weight: workspace %zu < %zu bytes", workspace_bytes, need);
   p.x = x; p.ldx = ldx; p.dy = dy; p.lddy = lddy; p.slabs = workspace;
   const int grid = stem_wgrad_grid(N, Ho, Wo);
-  if (Cout == 32) dl3p_launch(stem_wgrad_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  if (fold) {
+    DL3P_CHECK_ARG(fold->z && aligned16(fold->z) && fold->ldz >= Cout && fold->ldz % 4 == 0 && fold->mean && fold->invstd && fold->coef &&
+                       (!fold->scale || fold->shift),
+                   "dl3p_stem_conv_bwd_weight_slabs_bn: bad BatchNorm operands");
+    p.f_z = fold->z; p.f_ldz = fold->ldz; p.f_scale = fold->scale; p.f_shift = fold->shift; p.f_act = fold->act;
+    p.f_mean = fold->mean; p.f_invstd = fold->invstd; p.f_coef = fold->coef;
+    if (Cout == 32) dl3p_launch(stem_wgrad_kernel<2, true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else dl3p_launch(stem_wgrad_kernel<1, true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  } else if (Cout == 32) dl3p_launch(stem_wgrad_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   else dl3p_launch(stem_wgrad_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   DL3P_CHECK_LAUNCH("dl3p_stem_conv_bwd_weight");
   if (rows_out) { *rows_out = grid; return DL3P_OK; }
@@ -329,4 +393,18 @@ extern "C" int dl3p_stem_conv_bwd_weight_slabs(const float* x, int ldx, const fl
   DL3P_CHECK_ARG(rows_out != nullptr, "dl3p_stem_conv_bwd_weight_slabs: rows_out is required");
   return stem_conv_bwd_weight_impl(x, ldx, dy, lddy, nullptr, workspace, workspace_bytes, N, H, W, Cout, pad_t, pad_l, Ho, Wo,
                                    rows_out, stream);
+}
+
+// dl3p_stem_conv_bwd_weight_slabs with the BatchNorm-backward apply of the stem's own BatchNorm (Conv_BN) folded in: the stem has no data
+// gradient (its input is the image), so dz = apply(g, z) has this one reader and never needs to exist in HBM -- the separate pass read g
+// and z and wrote dz (405 MB at 16 x 257 x 257 x 32), this kernel reads g and z where it read dz.
+extern "C" int dl3p_stem_conv_bwd_weight_slabs_bn(const float* x, int ldx, const float* g, int ldg, const float* z, int ldz,
+                                                  const float* bn_scale, const float* bn_shift, int bn_act, const float* save_mean,
+                                                  const float* save_invstd, const float* coef, float* workspace,
+                                                  size_t workspace_bytes, int* rows_out, int N, int H, int W, int Cout, int pad_t,
+                                                  int pad_l, int Ho, int Wo, void* stream) {
+  DL3P_CHECK_ARG(rows_out != nullptr, "dl3p_stem_conv_bwd_weight_slabs_bn: rows_out is required");
+  const StemFold f = {z, ldz, bn_scale, bn_shift, bn_act, save_mean, save_invstd, coef};
+  return stem_conv_bwd_weight_impl(x, ldx, g, ldg, nullptr, workspace, workspace_bytes, N, H, W, Cout, pad_t, pad_l, Ho, Wo, rows_out,
+                                   stream, &f);
 }

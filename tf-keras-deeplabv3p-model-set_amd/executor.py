@@ -1222,6 +1222,13 @@ class Executor:
                     elif k == 'conv_dw':
                         wgrad_slabs(L.dwconv2d_bwd_weight_slabs, op.k * op.k * op.c, gw, nb, (xp, ldx, sp, hp, act, dz, lddz),
                                     (N, xt.H, xt.W, op.c, op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo))
+                    elif self._stem_direct(op) and out.id in self._folded:
+                        # the stem has no data gradient: dz = BatchNorm-backward apply of (g, z) is formed in the weight gradient's
+                        # staging pass and never written
+                        fg, fldg, fz, fldz, fsp, fhp, fact, fmean, finv, fcoef = self._folded.pop(out.id)
+                        wgrad_slabs(L.stem_conv_bwd_weight_slabs_bn, 28 * op.cout, gw, nb,
+                                    (xp, ldx, fg, fldg, fz, fldz, fsp, fhp, fact, fmean, finv, fcoef),
+                                    (N, xt.H, xt.W, op.cout, op.pad_t, op.pad_l, op.Ho, op.Wo))
                     elif self._stem_direct(op):
                         wgrad_slabs(L.stem_conv_bwd_weight_slabs, 28 * op.cout, gw, nb, (xp, ldx, dz, lddz),
                                     (N, xt.H, xt.W, op.cout, op.pad_t, op.pad_l, op.Ho, op.Wo))
@@ -1782,12 +1789,17 @@ class Executor:
         """BatchNorm-backward apply folded into the weight gradient of the pointwise conv that produced z (fp32, local
         statistics, weight gradient issued in line in front of the data gradient)"""
         conv = getattr(bn_op, 'producer', None)
-        if (self.bf16 or self.sync_bn or self.dist is not None or conv is None or conv.kind not in ('conv_pw', 'conv_dw')
+        if (self.bf16 or self.sync_bn or self.dist is not None or conv is None or conv.kind not in ('conv_pw', 'conv_dw', 'conv_dense')
                 or conv.out is not bn_op.z or not conv.layer.trainable or not getattr(self, '_batch_wgrad', False)
                 or os.environ.get('DL3P_FOLD_APPLY', '1') == '0' or not self._slab_bytes(conv)):
             return False
         if conv in self._irb_dw or conv in self._irb_expand:
             return False
+        if conv.kind == 'conv_dense':
+            # the direct stem kernel (3 input channels, stride 2) whose input needs no gradient: dl3p_stem_conv_bwd_weight_slabs_bn
+            xt = conv.x.tensor
+            return bool(self._stem_direct(conv) and not (xt.requires_grad or xt.root.requires_grad)
+                        and os.environ.get('DL3P_FOLD_APPLY_STEM', '1') != '0')
         M = self.N * conv.Ho * conv.Wo
         if conv.kind == 'conv_dw':
             # measured on MI355X: the depthwise window kernel with the fold takes as much longer as the apply pass it

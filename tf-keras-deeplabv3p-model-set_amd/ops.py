@@ -684,6 +684,24 @@ def stem_conv_bwd_weight(x, dy, padding='same'):
     return gw[:27].reshape(3, 3, 3, Cout)
 
 
+def stem_conv_bwd_weight_bn(x, g, z, bn, act, padding='same'):
+    """stem weight gradient with the BatchNorm-backward apply of (g, z) folded in (bn: BNState after bn_backward's finalize) -> gw"""
+    N, H, W, Cin = x.shape
+    Cout = g.shape[-1]
+    Ho, Wo, pt, pl = conv_geometry(H, W, 3, 2, 1, padding)
+    need = lib().stem_conv_bwd_weight_workspace(N, Ho, Wo, Cout)
+    ws = torch.empty(need // 4, dtype=torch.float32, device=x.device)
+    gw = torch.empty((28, Cout), dtype=torch.float32, device=x.device)
+    xp, ldx = _pl(x)
+    gp, ldg = _pl(g)
+    zp, ldz = _pl(z)
+    rows = ctypes.c_int(0)
+    lib().stem_conv_bwd_weight_slabs_bn(xp, ldx, gp, ldg, zp, ldz, _p(bn.scale), _p(bn.shift), act, _p(bn.mean), _p(bn.invstd),
+                                        _p(bn.coef), _p(ws), need, ctypes.byref(rows), N, H, W, Cout, pt, pl, Ho, Wo, _stream())
+    lib().reduce_rows(_p(ws), rows.value, 28 * Cout, _p(gw), 0, _stream())
+    return gw[:27].reshape(3, 3, 3, Cout)
+
+
 def col2im(gcol, x_shape, k, stride=1, rate=1, padding='same', out=None, accumulate=False):
     N, H, W, Cin = x_shape
     Ho, Wo, pt, pl = conv_geometry(H, W, k, stride, rate, padding)
