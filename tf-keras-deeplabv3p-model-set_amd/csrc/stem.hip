@@ -40,8 +40,24 @@ struct StemParams {
 // out-of-image taps are selected to zero in stem_put.  (A predicated load per tap -- which is also what the compiler makes of
 // `cond ? load : 0` by sinking the load into the branch -- waits for each load before the next branch: 21 serialized memory latencies
 // per tile, 87 us per launch.)
+// (fp32 MFMAs do not overlap vector instructions on this chip -- DESIGN 8, valu_issue.hip -- so the index arithmetic of the staging
+// competes with the multiply: tiles whose three rows and 129 columns all lie inside the image -- three of five per row at 513 x 513 --
+// take a path without clamps and selects: one add per load.)
+__device__ __forceinline__ bool stem_interior(const StemParams& p, int oy, int ox0) {
+  const int ix0 = 2 * ox0 - p.pad_l, iy0 = 2 * oy - p.pad_t;
+  return ix0 >= 0 && ix0 + 2 * STEM_TP < p.W && iy0 >= 0 && iy0 + 2 < p.H;
+}
 __device__ __forceinline__ void stem_fetch(const StemParams& p, int n, int oy, int ox0, int l, float (&v)[3][STEM_IT]) {
   const int ix0 = 2 * ox0 - p.pad_l;
+  if (stem_interior(p, oy, ox0) && p.ldx == 3) {          // (wave-uniform)
+    const float* src = p.x + (((size_t)n * p.H + (2 * oy - p.pad_t)) * p.W + ix0) * 3 + l;
+    const size_t rowf = (size_t)p.W * 3;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int it = 0; it < STEM_IT; ++it) v[ky][it] = src[ky * rowf + (64 * it < STEM_ROW - 63 ? 64 * it : STEM_ROW - 64)];
+    return;
+  }
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky) {
     const int iy = 2 * oy - p.pad_t + ky;
@@ -61,6 +77,14 @@ __device__ __forceinline__ void stem_fetch(const StemParams& p, int n, int oy, i
 // stem_put: what stem_fetch requested for tile (n, oy, ox0 ..) into this wave's LDS tile; out-of-image taps are zero
 __device__ __forceinline__ void stem_put(const StemParams& p, float* tile, int oy, int ox0, int l, float (&v)[3][STEM_IT]) {
   const int ix0 = 2 * ox0 - p.pad_l;
+  if (stem_interior(p, oy, ox0) && p.ldx == 3) {
+    // the last pass of 64 lanes was fetched from element STEM_ROW - 64 + l (inside the row): it lands there
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int it = 0; it < STEM_IT; ++it) tile[ky * STEM_PP + (64 * it < STEM_ROW - 63 ? 64 * it : STEM_ROW - 64) + l] = v[ky][it];
+    return;
+  }
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky) {
     const int iy = 2 * oy - p.pad_t + ky;
