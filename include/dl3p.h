@@ -200,7 +200,7 @@ int dl3p_pwconv_fwd_wt(const float* x, int ldx, const float* in_scale, const flo
 int dl3p_transpose_batch(const float* src, float* dst, const int* table, int n_matrices, void* stream);
 /* dl3p_pwconv_fwd_wt for FEW ROWS AND A LONG REDUCTION (the ASPP 1x1 convs of Xception / ResNet50 on a 33 x 33 map, layers.py:134,141,157:
  * 4356 x 2048 -> 256): the reduction is cut into slices (dl3p_pwconv_fwd_splitk_plan -> slices, 0 = not served / does not pay:
- * N in {128, 256, 512}, K >= 1024, at most 300 tiles of 64 x 128), each slice leaves a slab [M][N] in `workspace`
+ * N in {128, 256, 512}, K >= 1024, at most 640 tiles of 64 x 128), each slice leaves a slab [M][N] in `workspace`
  * (dl3p_pwconv_fwd_splitk_workspace bytes, 16-byte aligned) and a second launch adds the slabs in slice order, adds the bias, writes y
  * and takes the BatchNorm statistic rows from the finished output.  Same arguments and results as dl3p_pwconv_fwd_wt otherwise; the
  * sum is associated differently (equal to fp32 rounding).  dl3p_set_option("splitk", 0 | S): never / S slices. */

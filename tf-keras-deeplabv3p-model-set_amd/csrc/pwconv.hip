@@ -993,12 +993,12 @@ extern "C" int dl3p_pwconv_fwd_splitk_plan(int M, int K, int N) {
   if (!(N == 128 || N == 256 || N == 512) || K % 4 || K < 512 || M < 1024) return 0;
   if ((unsigned long long)M * (unsigned long long)K * 4ull >= (1ull << 32)) return 0;
   // measured (scripts/micro/splitk_bench.py, 64 x 128 tiles): 4356 x 2048 -> 256: one launch 93.8 us, 5 slices 59.8 (8: 64.6, 10: 62.4,
-  // 4: 69.5); 4356 x 1280: 55.2 -> 41.1 (4: 46.7, 8: 46.2); 8712 x 2048: 131.5 -> 102.5; at 17424 rows (272 tiles x 2) the slices tie with
-  // the one-launch kernel.
-  // Rule: about 2.5 workgroups per CU, slices of at least 256.
+  // 4: 69.5); 4356 x 1280: 55.2 -> 41.1 (4: 46.7, 8: 46.2); 8712 x 2048: 131.5 -> 102.5;
+  // 17424 x 2048 (546 tiles): 226.9 -> 182.7 (4: 183.8, 2: 196.9, 8: 197.5), x 1280: 143.9 -> 124.3-127.9.  Five slices are the best
+  // or within 3 % of it at every size measured; rule: five (slices of at least 256) for up to 640 tiles of 64 x 128.
   const int tiles = ceil_div(M, 64) * ceil_div(N, 128);
-  if (g_splitk_force < 0 && (tiles > 300 || K < 1024)) return 0;          // the tiled kernel already has a workgroup or two per CU
-  int S = g_splitk_force > 0 ? g_splitk_force : std::max(2, (640 + tiles / 2) / tiles);
+  if (g_splitk_force < 0 && (tiles > 640 || K < 1024)) return 0;
+  int S = g_splitk_force > 0 ? g_splitk_force : 5;
   S = std::min(S, std::min(16, K / 256));
   while (S > 1 && ceil_div(ceil_div(K, S), 32) * 32 * (S - 1) >= K) --S;   // every slice owns at least one column
   return S > 1 ? S : 0;
