@@ -1804,7 +1804,11 @@ class Executor:
         if conv.kind == 'conv_dw':
             # measured on MI355X: the depthwise window kernel with the fold takes as much longer as the apply pass it
             # replaces took (MobileNetV2 step 14.12 ms against 14.05 with the pointwise folds alone, 14.25 without any)
-            if os.environ.get('DL3P_FOLD_APPLY', '1') != '2':       # 2: depthwise convs too
+            # ... on every depthwise conv.  On the two 129 x 129 decoder layers alone (324 / 272 MB tensors: the apply pass is
+            # 174 / 136 us of pure traffic) the folded weight gradient is 319 / 236 us against 329 / 264 for the pair it replaces
+            # (round 5, same box): those two take it; DL3P_FOLD_APPLY=2 folds every depthwise conv
+            big = M * conv.c * 4 >= int(os.environ.get('DL3P_FOLD_APPLY_DW_MIN_BYTES', str(250 << 20)))
+            if os.environ.get('DL3P_FOLD_APPLY', '1') != '2' and not big:
                 return False
             xt = conv.x.tensor
             return bool(self.L.dwconv2d_bwd_weight_bn_supported(self.N, xt.H, xt.W, conv.c, conv.k, conv.stride, conv.rate,
