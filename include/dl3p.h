@@ -498,8 +498,9 @@ int dl3p_head_train(const float* z, int ldz, const float* labels, int ignore_ind
  * that row in x -> workspace (N,H,w,Cpad), 1/(W/w) of the full-resolution gradient; y pass: the rows of the workspace onto the logit
  * rows.  Arguments and results as dl3p_head_train plus the workspace (dl3p_head_train_rows_workspace bytes, 16-byte aligned); the
  * gradient equals dl3p_upsample_softmax_loss + dl3p_resize_bilinear_bwd to rounding (x-then-y summation), not bit for bit.
- * Plain sparse cross-entropy only (no class / pixel weights, no focal loss).  Served: Cpad in {20, 24, 32}, W / w <= 4,
- * w * Cpad / 4 <= 1024, 3 * W * Cpad * 4 bytes of LDS <= 150 KB.  rows_out: loss partial rows written (<= CUs). */
+ * Plain sparse cross-entropy only (no class / pixel weights, no focal loss).  Served: Cpad in {20, 24, 32}, W / w and H / h <= 4;
+ * rows wider than the LDS holds (W > ~530 at 24 channels) are cut into column segments (up to 32).  rows_out: loss partial rows
+ * written (<= CUs). */
 int dl3p_head_train_rows_supported(int h, int w, int C, int H, int W);
 size_t dl3p_head_train_rows_workspace(int N, int h, int w, int C, int H, int W);
 int dl3p_head_train_rows(const float* z, int ldz, const float* labels, int ignore_index, float inv_count, float* gz, int ldgz,

@@ -873,7 +873,9 @@ def test_head_train_fused(ops, case):
 
 @pytest.mark.parametrize('case', [(2, 9, 9, 33, 33, 21, 255), (1, 33, 33, 129, 129, 19, 255), (2, 17, 23, 65, 89, 21, 0),
                                   (3, 5, 7, 5, 7, 18, 255), (2, 11, 6, 41, 21, 32, 255), (1, 129, 129, 513, 513, 21, 255),
-                                  (1, 97, 97, 385, 385, 21, 255), (1, 17, 33, 65, 130, 21, 255), (2, 2, 2, 3, 2, 21, 255)])
+                                  (1, 97, 97, 385, 385, 21, 255), (1, 17, 33, 65, 130, 21, 255), (2, 2, 2, 3, 2, 21, 255),
+                                  # rows wider than LDS holds: column segments (769 x 769 at OS 8 / 1024 x 2048 map widths; 2, 4 and 3 segments)
+                                  (1, 33, 193, 129, 769, 19, 255), (1, 17, 512, 65, 2048, 19, 255), (2, 9, 300, 33, 1199, 30, 0)])
 def test_head_train_rows_form(ops, case):
     """the row-walking fused training head == the two-kernel head to rounding (x-then-y summation), and == the oracle"""
     N, h, w, H, W, C, ignore = case
@@ -908,11 +910,12 @@ def test_head_train_rows_form(ops, case):
                       part.data_ptr(), ct.byref(rows), ws.data_ptr(), wsb, N, h, w, C, H, W, None)
     torch.cuda.synchronize()
     assert float((gz - 2 * gz2).abs().max()) <= 8e-6 * scale
-    assert 1 <= rows.value <= min(N * H, 2 * L.device_cus())
+    assert 1 <= rows.value <= 2048                        # (row chunks x column segments; never more than the loss partial rows)
     with pytest.raises(ops.Dl3pError):
         L.head_train_rows(zt.data_ptr(), cp, labels.data_ptr(), int(ignore or 0), 1.0 / (N * H * W), gz.data_ptr(), cp, 1,
                           part.data_ptr(), ct.byref(rows), ws.data_ptr(), wsb - 16, N, h, w, C, H, W, None)
     assert not ops.head_train_rows_supported(33, 33, 21, 513, 513) and not ops.head_train_rows_supported(9, 9, 40, 33, 33)
+    assert ops.head_train_rows_supported(256, 512, 19, 1024, 2048) and ops.head_train_rows_supported(193, 193, 19, 769, 769)
 
 
 def test_se_multiply_and_bare_activation(ops):

@@ -876,6 +876,7 @@ struct HeadRowsParams {
   const float* z; int ldz; const float* labels; int ignore_index; float inv_count;
   float* gxh; float* loss_partials;
   int N, h, w, C, H, W, chunk;
+  int nseg, jw, plane;       // column segments of a row (logit columns per segment), LDS plane stride for the widest segment
 };
 
 typedef float hr_f2 __attribute__((ext_vector_type(2)));
@@ -910,25 +911,38 @@ template <int CP, int NI, int MAXW>
 __global__ __launch_bounds__(HR_THREADS) void head_xpass_kernel(HeadRowsParams p) {
   constexpr int C4 = CP / 4;
   extern __shared__ __attribute__((aligned(16))) float hr_lds[];
-  const int PW = head_rows_plane(p.W);
+  // A row wider than LDS holds (W > ~530 at 24 channels: 769 x 769, 1024 x 2048) is cut into COLUMN SEGMENTS of p.jw logit columns: a
+  // workgroup evaluates the pixels [Xs, Xe] that carry weight for its columns [j0, j1) -- neighbours overlap by the ~4 pixels of a
+  // window, evaluated by both -- and counts the loss of the pixels whose left logit column is its own.  LDS indices are segment-local.
+  const int seg = blockIdx.x % p.nseg, chunk_id = blockIdx.x / p.nseg;
+  const int j0 = seg * p.jw, j1 = min(j0 + p.jw, p.w);
+  int Xs, Xe;
+  {
+    int f, c;
+    head_rows_window(j0, p.w, p.W, Xs, c);
+    head_rows_window(j1 - 1, p.w, p.W, f, c);
+    Xe = f + c - 1;
+  }
+  const int Wn = Xe - Xs + 1;
+  const int PW = p.plane;
   float* xr = hr_lds;                                   // [2][CP/4][plane]: logit rows i (slot i & 1), interpolated in x
   float* gr = hr_lds + 2 * C4 * PW;                     // [CP/4][plane]: gradient of the current full-resolution row
   __shared__ float wsum[HR_THREADS / 64];
   const int t = threadIdx.x;
   const float sy = (float)p.h / (float)p.H, sx = (float)p.w / (float)p.W;
   const int rows_total = p.N * p.H;
-  const int r0 = blockIdx.x * p.chunk, r1 = min(r0 + p.chunk, rows_total);
+  const int r0 = chunk_id * p.chunk, r1 = min(r0 + p.chunk, rows_total);
   // this thread's items of the transposed resize in x: (logit column j, channel quad c4); window start and weights, once
   int x0s[NI];
   float wxs[NI][MAXW];
 #pragma unroll
   for (int m = 0; m < NI; ++m) {
     const int it = t + HR_THREADS * m;
-    const bool on = it < p.w * C4;
-    const int j = on ? it / C4 : 0;
+    const bool on = it < (j1 - j0) * C4;
+    const int j = on ? j0 + it / C4 : j0;
     int first, count;
     head_rows_window(j, p.w, p.W, first, count);
-    x0s[m] = first;
+    x0s[m] = first - Xs;
 #pragma unroll
     for (int k = 0; k < MAXW; ++k) {
       const Lerp lx = lerp_coeff(min(first + k, p.W - 1), sx, p.w);
@@ -947,11 +961,13 @@ __global__ __launch_bounds__(HR_THREADS) void head_xpass_kernel(HeadRowsParams p
   // evaluated by ONE wave with a channel per lane instead (32 lanes per pixel, reductions by lane shuffles: ~50 instructions, not 230),
   // a wave that sits on another SIMD.
   const int lane = t & 63, wave = t >> 6;
-  const int Wfull = (p.W & 63) <= 2 ? (p.W & ~63) : p.W;
+  const int Wfull = (Wn & 63) <= 2 ? (Wn & ~63) : Wn;
   const int tail_wave = min((Wfull >> 6) + 1, HR_THREADS / 64 - 1);
-  const bool tail_lane = wave == tail_wave && Wfull + (lane >> 5) < p.W;
-  const int tc = tail_lane ? Wfull + (lane >> 5) : min(t, p.W - 1);
-  int lab_cur = r0 < r1 ? (int)p.labels[(size_t)r0 * p.W + tc] : 0;
+  const bool tail_lane = wave == tail_wave && Wfull + (lane >> 5) < Wn;
+  const int tc = tail_lane ? Wfull + (lane >> 5) : min(t, Wn - 1);          // (segment-local)
+  auto owns = [&](int Xl) { const int lo = lerp_coeff(Xs + Xl, sx, p.w).lo; return lo >= j0 && lo < j1; };
+  const bool own_first = owns(tc);
+  int lab_cur = r0 < r1 ? (int)p.labels[(size_t)r0 * p.W + Xs + tc] : 0;
   float4 held[NI];
 #pragma unroll
   for (int m = 0; m < NI; ++m) held[m] = zero4();
@@ -968,8 +984,8 @@ __global__ __launch_bounds__(HR_THREADS) void head_xpass_kernel(HeadRowsParams p
       if (have == i) continue;
       const float* zrow = p.z + ((size_t)n * p.h + i) * p.w * p.ldz;
       float* dst = xr + (i & 1) * C4 * PW;
-      for (int X = t; X < p.W; X += HR_THREADS) {        // a pixel per thread: its two corners, all channel quads, loads first
-        const Lerp lx = lerp_coeff(X, sx, p.w);
+      for (int X = t; X < Wn; X += HR_THREADS) {         // a pixel per thread: its two corners, all channel quads, loads first
+        const Lerp lx = lerp_coeff(Xs + X, sx, p.w);
         const float* pa = zrow + (size_t)lx.lo * p.ldz;
         const float* pb = zrow + (size_t)lx.hi * p.ldz;
         float4 a[C4], b[C4];
@@ -988,7 +1004,7 @@ __global__ __launch_bounds__(HR_THREADS) void head_xpass_kernel(HeadRowsParams p
     __syncthreads();                                     // xr is in place; the previous row's gather is done with gr
     const float* top = xr + (ly.lo & 1) * C4 * PW;
     const float* bot = xr + (ly.hi & 1) * C4 * PW;
-    auto pixel = [&](int X, int lab) {
+    auto pixel = [&](int X, int lab, bool own) {
       // logits: the expression of head_kernel (top + (bot - top) * ty, unfused), two channels per packed instruction.  From there on
       // the arithmetic is arranged for instruction count (the phase is bound by VALU issue): exp2 of a fused (v - max) * log2(e),
       // pairwise sums, one multiplier gs / sum for the gradient -- equal to head_kernel's softmax to rounding, not bit for bit.
@@ -1035,7 +1051,7 @@ __global__ __launch_bounds__(HR_THREADS) void head_xpass_kernel(HeadRowsParams p
         pt = __builtin_amdgcn_exp2f(fmaf(a + (b - a) * ly.t, LOG2E, mneg)) * inv;
       }
       const bool unclipped = pt > 1e-7f && pt < 1.f - 1e-7f;
-      if (valid) loss += -logf(fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f));
+      if (valid && own) loss += -logf(fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f));
       const float gs = (valid && unclipped) ? p.inv_count : 0.f;
       const float k = gs * inv;
       const hr_f2 k2 = {k, k};
@@ -1052,13 +1068,13 @@ __global__ __launch_bounds__(HR_THREADS) void head_xpass_kernel(HeadRowsParams p
       float* orow = p.gxh + (size_t)(row - 1) * p.w * CP;
 #pragma unroll
       for (int m = 0; m < NI; ++m)
-        if (t + HR_THREADS * m < p.w * C4) st4(orow + (size_t)(t + HR_THREADS * m) * 4, held[m]);
+        if (t + HR_THREADS * m < (j1 - j0) * C4) st4(orow + ((size_t)j0 * C4 + t + HR_THREADS * m) * 4, held[m]);
     }
-    const float lab_req = p.labels[(size_t)min(row + 1, r1 - 1) * p.W + tc];
-    if (t < Wfull) pixel(t, lab_cur);
-    for (int X = t + HR_THREADS; X < Wfull; X += HR_THREADS) pixel(X, (int)p.labels[(size_t)row * p.W + X]);
-    if (wave == tail_wave && Wfull < p.W) {
-      const int c = lane & 31, X = min(Wfull + (lane >> 5), p.W - 1), lab = lab_cur;
+    const float lab_req = p.labels[(size_t)min(row + 1, r1 - 1) * p.W + Xs + tc];
+    if (t < Wfull) pixel(t, lab_cur, own_first);
+    for (int X = t + HR_THREADS; X < Wfull; X += HR_THREADS) pixel(X, (int)p.labels[(size_t)row * p.W + Xs + X], owns(X));
+    if (wave == tail_wave && Wfull < Wn) {
+      const int c = lane & 31, X = min(Wfull + (lane >> 5), Wn - 1), lab = lab_cur;
       const bool on = tail_lane && c < CP;
       const int o = on ? (c >> 2) * PW + X * 4 + (c & 3) : 0;
       const float a = top[o], b = bot[o];
@@ -1076,7 +1092,7 @@ __global__ __launch_bounds__(HR_THREADS) void head_xpass_kernel(HeadRowsParams p
       const bool valid = tail_lane && !masked && lab >= 0 && lab < p.C;
       const float pt = valid ? __shfl(e, (lane & 32) + (lab & 31)) * inv : 0.f;
       const bool unclipped = pt > 1e-7f && pt < 1.f - 1e-7f;
-      if (valid && c == 0) loss += -logf(fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f));
+      if (valid && c == 0 && own_first) loss += -logf(fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f));
       const float gs = (valid && unclipped) ? p.inv_count : 0.f;
       if (on) gr[o] = c == lab ? gs * (pt - 1.f) : e * (gs * inv);
     }
@@ -1086,12 +1102,12 @@ __global__ __launch_bounds__(HR_THREADS) void head_xpass_kernel(HeadRowsParams p
 #pragma unroll
     for (int m = 0; m < NI; ++m) {
       const int it = t + HR_THREADS * m;
-      if (it >= p.w * C4) continue;
+      if (it >= (j1 - j0) * C4) continue;
       float4 acc = zero4();
       const float* gp = gr + (it % C4) * PW;
 #pragma unroll
       for (int k = 0; k < MAXW; ++k) {
-        const float4 g = *reinterpret_cast<const float4*>(gp + min(x0s[m] + k, p.W - 1) * 4);
+        const float4 g = *reinterpret_cast<const float4*>(gp + min(x0s[m] + k, Wn - 1) * 4);
         acc.x = fmaf(g.x, wxs[m][k], acc.x); acc.y = fmaf(g.y, wxs[m][k], acc.y);
         acc.z = fmaf(g.z, wxs[m][k], acc.z); acc.w = fmaf(g.w, wxs[m][k], acc.w);
       }
@@ -1102,7 +1118,7 @@ __global__ __launch_bounds__(HR_THREADS) void head_xpass_kernel(HeadRowsParams p
     float* orow = p.gxh + (size_t)(r1 - 1) * p.w * CP;
 #pragma unroll
     for (int m = 0; m < NI; ++m)
-      if (t + HR_THREADS * m < p.w * C4) st4(orow + (size_t)(t + HR_THREADS * m) * 4, held[m]);
+      if (t + HR_THREADS * m < (j1 - j0) * C4) st4(orow + ((size_t)j0 * C4 + t + HR_THREADS * m) * 4, held[m]);
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) loss += __shfl_xor(loss, off);
@@ -1154,8 +1170,6 @@ __global__ __launch_bounds__(256) void head_ypass_kernel(HeadYParams p) {
   st4(o, acc);
 }
 
-static int head_rows_ni(int w, int cp) { return ceil_div(w * (cp / 4), HR_THREADS); }
-static size_t head_rows_lds(int W, int cp) { return sizeof(float) * 3 * (size_t)(cp / 4) * head_rows_plane(W); }
 static int head_rows_maxwin(int w, int W) {
   int m = 0;
   for (int j = 0; j < w; ++j) {
@@ -1165,14 +1179,34 @@ static int head_rows_maxwin(int w, int W) {
   }
   return m;
 }
+// the fewest column segments whose items fit a workgroup (one (column, channel quad) item per thread) and whose three LDS rows fit 150 KB
+struct HeadSeg { int nseg, jw, wmax; };
+static bool head_rows_segments(int w, int W, int cp, HeadSeg* out) {
+  const int c4 = cp / 4;
+  for (int nseg = 1; nseg <= 32 && nseg <= w; ++nseg) {
+    const int jw = ceil_div(w, nseg);
+    if (jw * c4 > HR_THREADS || ceil_div(w, jw) != nseg) continue;
+    int wmax = 0;
+    for (int s = 0; s < nseg; ++s) {
+      const int j0 = s * jw, j1 = std::min(j0 + jw, w);
+      int xs, c, f;
+      head_rows_window(j0, w, W, xs, c);
+      head_rows_window(j1 - 1, w, W, f, c);
+      wmax = std::max(wmax, f + c - xs);
+    }
+    if (sizeof(float) * 3 * (size_t)c4 * head_rows_plane(wmax) > 150 * 1024) continue;
+    out->nseg = nseg; out->jw = jw; out->wmax = wmax;
+    return true;
+  }
+  return false;
+}
 
 extern "C" int dl3p_head_train_rows_supported(int h, int w, int C, int H, int W) {
   const int cp = ((C + 3) / 4) * 4;
   if (!(cp == 20 || cp == 24 || cp == 32) || h < 1 || w < 1 || H < h || W < w) return 0;
-  if (head_rows_ni(w, cp) > 1) return 0;                                   // one (logit column, channel quad) item per thread
-  if (head_rows_lds(W, cp) > 150 * 1024) return 0;
   if (head_rows_maxwin(w, W) > 12 || head_rows_maxwin(h, H) > 12) return 0;     // the window of a logit column / row fits the weight table
-  return 1;
+  HeadSeg sg;
+  return head_rows_segments(w, W, cp, &sg) ? 1 : 0;
 }
 
 extern "C" size_t dl3p_head_train_rows_workspace(int N, int h, int w, int C, int H, int W) {
@@ -1204,12 +1238,15 @@ extern "C" int dl3p_head_train_rows(const float* z, int ldz, const float* labels
   p.gxh = (float*)workspace; p.loss_partials = loss_partials;
   p.N = N; p.h = h; p.w = w; p.C = C; p.H = H; p.W = W;
   // one workgroup per CU, one round; never more workgroups than loss partial rows
+  HeadSeg sg;
+  (void)head_rows_segments(w, W, cp, &sg);
+  p.nseg = sg.nseg; p.jw = sg.jw; p.plane = head_rows_plane(sg.wmax);
   const int rows_total = N * H;
-  const int slots = std::min(dl3p_device_cus(), (int)DL3P_MAX_STAT_ROWS);
+  const int slots = std::max(1, std::min(dl3p_device_cus(), (int)DL3P_MAX_STAT_ROWS) / sg.nseg);
   p.chunk = std::max(1, ceil_div(rows_total, slots));
-  const int blocks = ceil_div(rows_total, p.chunk);
+  const int blocks = ceil_div(rows_total, p.chunk) * sg.nseg;
   if (rows_out) *rows_out = blocks;
-  const size_t lds = head_rows_lds(W, cp);
+  const size_t lds = sizeof(float) * 3 * (size_t)(cp / 4) * p.plane;
   const int mw = head_rows_maxwin(w, W);
   hipStream_t st = (hipStream_t)stream;
 #define HR_CASE(CC) \

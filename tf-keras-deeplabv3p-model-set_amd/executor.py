@@ -545,10 +545,12 @@ class Executor:
         self.metric_counts = (torch.zeros(N * 3 * self.C, dtype=torch.int32, device=self.dev).view(N, 3, self.C)
                               if (self.training and self.want_class_counts) else None)
         want = os.environ.get('DL3P_FUSED_HEAD', 'rows')
-        plain = bool(self.training and not self.bf16 and self.loss_kind == 0 and not self.sample_weighted and
+        plain = bool(self.training and self.loss_kind == 0 and not self.sample_weighted and
                      self.class_weights is None and zt is not None and zt.requires_grad)
+        # (the logits and their gradient stay fp32 under the bf16 policy -- _is_f32 -- so the separable head serves it too; the padded
+        # classes of the gradient buffer are never written by anyone and keep the zeros they were allocated with)
         self.fused_head_rows = bool(plain and want == 'rows' and L.head_train_rows_supported(zt.H, zt.W, self.C, H, W))
-        self.fused_head = self.fused_head_rows or bool(plain and want not in ('0', 'rows') and
+        self.fused_head = self.fused_head_rows or bool(plain and not self.bf16 and want not in ('0', 'rows') and
                                                        L.head_train_supported(zt.H, zt.W, self.C, H, W))
         self.head_wsb = L.head_train_rows_workspace(N, zt.H, zt.W, self.C, H, W) if self.fused_head_rows else 0
         self.head_ws = torch.zeros(self.head_wsb // 4, **self.f32) if self.fused_head_rows else None
