@@ -688,7 +688,8 @@ int dl3p_resize_bilinear_bwd_bf16(const void* gy, int ldgy, void* gx, int ldgx, 
  *
  * Training-mode statistics of the expand BatchNorm without its input tensor: z = x W1 is linear and bias-free, so
  * mean_z = W1^T mean_x and var_z[c] = w_c^T Cov(x) w_c.  dl3p_irb_cov_stats leaves rows [rows][K + K*K] of float64 (sum x, then
- * sum x x^T, exact products, float64 sums on the fp64 matrix pipe); dl3p_irb_cov_reduce adds the rows (the vector a
+ * sum x x^T, exact products, float64 sums on the fp64 matrix pipe; at most dl3p_irb_cov_rows_max() rows, rows_cap = the rows
+ * cov_rows has room for); dl3p_irb_cov_reduce adds the rows (the vector a
  * SyncBatchNorm all-reduces); dl3p_irb_bn_finalize_cov turns it into what dl3p_bn_finalize would have produced from the
  * materialised tensor (same outputs, same moving-average rule).
  * dl3p_irb_fwd: y = depthwise(act(BN(x W1))) raw + its stat partial rows (as dl3p_dwconv2d_fwd).
@@ -700,8 +701,9 @@ int dl3p_resize_bilinear_bwd_bf16(const void* gy, int ldgy, void* gx, int ldgx, 
  * gradient, i.e. including what gx held when accumulate = 1).  Slab regions are sized by dl3p_irb_bwd_workspace(which = 0 | 1). */
 int dl3p_irb_supported(int N, int H, int W, int K, int C, int k, int stride, int rate, int pad_t, int pad_l, int Ho, int Wo);
 int dl3p_irb_bwd_supported(int N, int H, int W, int K, int C, int k, int stride, int rate, int pad_t, int pad_l, int Ho, int Wo);
+int dl3p_irb_cov_rows_max(void);
 int dl3p_irb_cov_stats(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act, double* cov_rows,
-                       int* rows_out, int M, int K, void* stream);
+                       int rows_cap, int* rows_out, int M, int K, void* stream);
 int dl3p_irb_cov_reduce(const double* cov_rows, int rows, int K, double* sums, void* stream);
 int dl3p_irb_bn_finalize_cov(const double* sums, const float* w1, int K, int C, double count, const float* gamma,
                              const float* beta, float eps, float momentum, float* moving_mean, float* moving_var,
@@ -727,6 +729,7 @@ int dl3p_irb_bwd_data(const float* x, int ldx, const float* in_scale, const floa
  * the lane a lane reads as "next", out[64..127] as "previous"). */
 int dl3p_irb_set_plan(int ct, int want_waves);
 int dl3p_irb_set_bwd_plan(int want_waves_sums, int want_workgroups_data);
+int dl3p_irb_get_plan(int which);
 int dl3p_irb_selftest(float* out128, void* stream);
 
 /* ---------------------------------------------------------------- measurement hook

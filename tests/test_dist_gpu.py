@@ -176,7 +176,7 @@ def test_two_identical_ranks_match_the_oracle():
     assert ex.dist is ctx
     drop = [op for op in m.graph.ops if op.kind == 'materialize' and op.rate > 0][0]
     mask = ex.dropout_mask(drop).cpu().numpy()
-    o.net.act_derivs = _act_derivs(m, ex)
+    o.net.act_derivs = _act_derivs(m, ex, o.net.params)
     o.net.act_derivs_seq = _act_derivs_seq(m, ex, o.net.act_derivs)
     total, ce, logits = o.loss_and_grads(x, y, {'aspp_dropout': mask})
     assert abs(loss - ce) < 1e-3 * max(1.0, abs(ce)), (loss, ce)

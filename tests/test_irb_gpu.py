@@ -21,6 +21,22 @@ def relerr(got, want):
     return float((got - want).abs().max() / want.abs().max().clamp_min(1e-30))
 
 
+def sumerr(got, net, l1):
+    """error of a float32-accumulated sum against float64, relative to the sum of the |terms| (what fp32 accumulation is bounded
+    by: a sum over 10^6 pixels of zero-mean terms cancels by three orders of magnitude and its error does not)"""
+    return float((got.double() - net.double()).abs().max() / l1.double().abs().max().clamp_min(1e-30))
+
+
+def sum_ok(got, net, l1, net_tol, slack=None):
+    """slack: what the elements whose ReLU6 branch is undecided at float32 resolution can move the sum by (see `amb` below)"""
+    if relerr(got, net) < net_tol:
+        return True
+    err = (got.double() - net.double()).abs()
+    if slack is not None:
+        err = (err - slack.double()).clamp_min(0.0)
+    return float(err.max() / l1.double().abs().max().clamp_min(1e-30)) < 2e-6
+
+
 def tf_pad(H, k, s):
     out = -(-H // s)
     total = max((out - 1) * s + k - H, 0)
@@ -62,7 +78,9 @@ def ref64(d, bn_consts=None):
 
 
 CASES = [(2, 33, 33, 16, 96, 2), (2, 32, 40, 16, 96, 2), (1, 65, 65, 24, 144, 1), (2, 31, 29, 24, 144, 2),
-         (1, 17, 19, 32, 192, 1), (1, 20, 24, 32, 192, 2), (2, 30, 47, 16, 96, 1), (1, 129, 129, 16, 96, 2)]
+         (1, 17, 19, 32, 192, 1), (1, 20, 24, 32, 192, 2), (2, 30, 47, 16, 96, 1), (1, 129, 129, 16, 96, 2),
+         # the launches of the timed step (BASELINE configs[1], batch 16: expanded_conv_1 and _3) and the batch-8 form of the second
+         (16, 257, 257, 16, 96, 2), (16, 129, 129, 24, 144, 2), (8, 129, 129, 24, 144, 2)]
 
 
 def test_lane_shift_primitives(ops):
@@ -136,7 +154,7 @@ def test_fused_forward(ops, case, ct):
         assert y.shape == want.shape
         assert relerr(y, want) < 2e-6, relerr(y, want)
         p = part[:rows * 2 * C].view(rows, 2, C).double().sum(0)
-        assert relerr(p[0], want.sum((0, 1, 2))) < 2e-5 and relerr(p[1], (want ** 2).sum((0, 1, 2))) < 2e-5
+        assert sum_ok(p[0], want.sum((0, 1, 2)), want.abs().sum((0, 1, 2)), 2e-5) and relerr(p[1], (want ** 2).sum((0, 1, 2))) < 2e-5
         # ... and the library's own unfused kernels on the same coefficients
         z1d = ops.pwconv_fwd(d['x'].view(-1, K), d['w1'], in_scale=d['xs'], in_shift=d['xh']).view(N, H, W, C)
         yu = ops.dwconv2d_fwd(z1d, d['wdw'], stride, in_scale=bn.scale, in_shift=bn.shift, in_act=ops.ACT_RELU6)
@@ -179,26 +197,42 @@ def test_fused_backward(ops, case):
     dy = d['dy'].double()
     (z2 * dy).sum().backward(retain_graph=True)
     da1 = a1.grad
+    # the sum of the |terms| of the depthwise kernel's gradient (a1 >= 0 behind ReLU6): the same contraction on |dy|
+    wabs = wdw.detach().clone().requires_grad_(True)
+    (dw64(a1.detach(), wabs, stride) * dy.abs()).sum().backward()
+    gwdw_l1 = wabs.grad
     gmask = ((u > 0) & (u < 6)).double()
     gp = da1 * gmask
     xhat1 = (z1.detach() - mu) * inv
+    # elements within float32 rounding of a ReLU6 corner: the device may take the other branch there (at 10^8 elements a few per
+    # channel do), which moves a sum by up to |da1| each -- the bounds below allow exactly that much on top of the rounding bound
+    amb = (((u.detach().abs() < 1e-5) | ((u.detach() - 6).abs() < 1e-5))).double()
+    flip = da1.abs() * amb
     # ---- pass A
     gwdw, part, rows = ops.irb_bwd_sums(d['x'], d['w1'], bn, ops.ACT_RELU6, d['wdw'], d['dy'], stride, in_scale=d['xs'],
                                         in_shift=d['xh'])
-    assert relerr(gwdw, wdw.grad) < 2e-5, relerr(gwdw, wdw.grad)
+    assert sum_ok(gwdw, wdw.grad, gwdw_l1, 2e-5), (relerr(gwdw, wdw.grad), sumerr(gwdw, wdw.grad, gwdw_l1))
     p = part[:rows * 2 * C].view(rows, 2, C).double().sum(0)
     s1, s2 = gp.sum((0, 1, 2)), (gp * xhat1).sum((0, 1, 2))
-    assert relerr(p[0], s1) < 2e-5 and relerr(p[1], s2) < 2e-5, (relerr(p[0], s1), relerr(p[1], s2))
+    l1, l2 = gp.abs().sum((0, 1, 2)), (gp * xhat1).abs().sum((0, 1, 2))
+    f1, f2 = flip.sum((0, 1, 2)), (flip * xhat1.abs()).sum((0, 1, 2))
+    assert sum_ok(p[0], s1, l1, 2e-5, f1) and sum_ok(p[1], s2, l2, 2e-5, f2), (relerr(p[0], s1), relerr(p[1], s2),
+                                                                            sumerr(p[0], s1, l1), sumerr(p[1], s2, l2))
     # ---- BatchNorm-backward coefficients (the library's own finalize), then pass B
     M = N * H * W
     ops.lib().bn_bwd_finalize(part.data_ptr(), rows, None, C, float(M), bn.gamma.data_ptr(), bn.invstd.data_ptr(),
                               bn.scale.data_ptr(), 0, bn.dgamma.data_ptr(), bn.dbeta.data_ptr(), bn.coef.data_ptr(),
                               torch.cuda.current_stream().cuda_stream)
-    assert relerr(bn.dgamma, s2) < 2e-5 and relerr(bn.dbeta, s1) < 2e-5
+    assert sum_ok(bn.dgamma, s2, l2, 2e-5, f2) and sum_ok(bn.dbeta, s1, l1, 2e-5, f1)
     c0, c1, c2 = bn.coef.double().view(3, C)
     dz1 = c0 * (gp - c1 - xhat1 * c2)
     gw1_ref = xh.detach().reshape(-1, K).t() @ dz1.reshape(-1, C)
+    gw1_l1 = xh.detach().abs().reshape(-1, K).t() @ dz1.abs().reshape(-1, C)
     gx_ref = dz1 @ w1.detach().t()
+    dflip = flip * c0.abs()                                   # what an undecided branch moves dz1 by
+    gw1_slack = xh.detach().abs().reshape(-1, K).t() @ dflip.reshape(-1, C)
+    gx_slack = dflip @ w1.detach().abs().t()                  # ... and the input gradient of that pixel
+    clean = (amb.sum(-1, keepdim=True) == 0).double()         # pixels with every branch decided
     # a BatchNorm in front of the block (z0 = the block's raw input here, as for expanded_conv_1)
     mu0 = T(rng.standard_normal(K) * 0.2); is0 = T(rng.uniform(0.5, 2.0, K))
     base = T(rng.standard_normal((N, H, W, K)))
@@ -206,14 +240,16 @@ def test_fused_backward(ops, case):
         gw1, gx, part0, rows0 = ops.irb_bwd_data(d['x'], d['w1'], bn, ops.ACT_RELU6, d['wdw'], d['dy'], stride, in_scale=d['xs'],
                                                  in_shift=d['xh'], out=base.clone() if accumulate else None, accumulate=accumulate,
                                                  front=(d['x'], d['xs'], d['xh'], ops.ACT_NONE, mu0, is0))
-        assert relerr(gw1, gw1_ref) < 3e-5, relerr(gw1, gw1_ref)
+        assert sum_ok(gw1, gw1_ref, gw1_l1, 3e-5, gw1_slack), (relerr(gw1, gw1_ref), sumerr(gw1, gw1_ref, gw1_l1))
         tot = gx_ref + (base.double() if accumulate else 0.0)
-        assert relerr(gx, tot) < 1e-5, relerr(gx, tot)
+        assert relerr(gx * clean, tot * clean) < 1e-5, relerr(gx * clean, tot * clean)
+        assert float(((gx.double() - tot).abs() - gx_slack).max() / tot.abs().max()) < 1e-5
         p0 = part0[:rows0 * 2 * K].view(rows0, 2, K).double().sum(0)
         xhat0 = (x - mu0.double()) * is0.double()
         # (sum over pixels of a BatchNorm-backward result is 0 by construction: the first row is measured against sum |g|)
-        e0 = float((p0[0] - tot.sum((0, 1, 2))).abs().max() / tot.abs().sum((0, 1, 2)).max())
-        e1 = float((p0[1] - (tot * xhat0).sum((0, 1, 2))).abs().max() / (tot * xhat0).abs().sum((0, 1, 2)).max())
+        e0 = float(((p0[0] - tot.sum((0, 1, 2))).abs() - gx_slack.sum((0, 1, 2))).max() / tot.abs().sum((0, 1, 2)).max())
+        e1 = float(((p0[1] - (tot * xhat0).sum((0, 1, 2))).abs() - (gx_slack * xhat0.abs()).sum((0, 1, 2))).max()
+                   / (tot * xhat0).abs().sum((0, 1, 2)).max())
         assert e0 < 1e-6 and e1 < 1e-6, (accumulate, e0, e1)
     # without a gradient for the input: the kernel gradient alone, same bits
     gw1b, none, _, _ = ops.irb_bwd_data(d['x'], d['w1'], bn, ops.ACT_RELU6, d['wdw'], d['dy'], stride, in_scale=d['xs'],

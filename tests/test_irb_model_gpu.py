@@ -15,13 +15,14 @@ pytestmark = pytest.mark.gpu
 def fused(monkeypatch):
     monkeypatch.setenv('DL3P_IRB_MIN_ROWS', '1')
     monkeypatch.delenv('DL3P_IRB', raising=False)
-    # the oracle tests inject the device's activation branches: they need the expand outputs AS THE FORWARD SAW THEM (the weights
-    # have moved by the time the test looks) -- a copy written beside the fused kernels, which never read it
-    monkeypatch.setenv('DL3P_IRB_DEBUG_Z', '1')
+    # the executor the bench runs: no debug copy of the expand output (the oracle tests rebuild the activation pattern of the expand
+    # BatchNorm from the saved block input and the pre-step kernel: test_model_gpu._act_derivs)
+    monkeypatch.delenv('DL3P_IRB_DEBUG_Z', raising=False)
 
 
 def test_which_blocks_are_fused(fused, monkeypatch):
     pkg = load_pkg()
+    monkeypatch.setenv('DL3P_IRB_DEBUG_Z', '1')
     m = pkg.get_deeplabv3p_model('mobilenetv2', 21, (65, 65), 16, training=True)
     m.compile(optimizer=pkg.SGD(0.01), loss=pkg.SparseCategoricalCrossEntropy(ignore_index=255))
     ex = m._executor(2, True)
@@ -96,6 +97,43 @@ def test_fused_blocks_do_not_change_the_step(model_type, H, W, OS, monkeypatch):
     for name, a in w0.items():
         lim = 1e-5 * max(1.0, float(np.abs(a).max())) + (0.01 * 0.35 * float(np.abs(g0[name]).max()) if name in g0 else 0.0)
         assert float(np.abs(a - w1[name]).max()) < lim, name
+
+
+@pytest.mark.parametrize('graphs', [False, True])
+def test_the_debug_copy_of_the_expand_output_changes_no_bit(graphs, monkeypatch):
+    """DL3P_IRB_DEBUG_Z=1 (a test hook: the forward also writes the expand output with the unfused kernel) against the production plan
+    on the same 129 x 129 MobileNetV2 step, every eligible block fused: loss, every gradient, every updated weight and moving
+    statistic bit for bit -- the fused kernels never read the copy"""
+    N, C, H, W = 2, 21, 129, 129
+    x, y = TM._data(N, H, W, C, seed=23)
+    monkeypatch.setenv('DL3P_IRB_MIN_ROWS', '1')
+    monkeypatch.delenv('DL3P_IRB', raising=False)
+
+    def run(hook):
+        if hook:
+            monkeypatch.setenv('DL3P_IRB_DEBUG_Z', '1')
+        else:
+            monkeypatch.delenv('DL3P_IRB_DEBUG_Z', raising=False)
+        torch.manual_seed(0)
+        m, _ = TM._pair('mobilenetv2', H, W, C)
+        m.use_graphs = graphs
+        losses = [m.train_on_batch(x, y) for _ in range(2)]
+        st = m._store
+        ex = m._executor(N, True)
+        assert len(ex._irb_expand) == 6
+        has_copy = [e.out.id in ex.buf for e in ex._irb_expand]
+        g = {p.name: np.array(st.get(p, st.G)) for p in m.graph.all_params() if p.trainable}
+        w = {k: np.array(v) for k, v in m.get_weights_by_name().items()}
+        return losses, g, w, has_copy, len(ex.fwd.items)
+
+    l1, g1, w1, c1, n1 = run(True)
+    l0, g0, w0, c0, n0 = run(False)
+    assert all(c1) and not any(c0) and n1 == n0 + 6
+    assert l1 == l0, (l1, l0)
+    for k in g0:
+        assert np.array_equal(g0[k], g1[k]), k
+    for k in w0:
+        assert np.array_equal(w0[k], w1[k]), k
 
 
 def test_train_step_with_fused_blocks_matches_oracle(fused):

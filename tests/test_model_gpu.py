@@ -40,14 +40,17 @@ def _pair(model_type, H, W, C, OS=16, freeze_level=0, training=True):
     return m, o
 
 
-def _act_derivs(m, ex):
-    """act'(u) of every BN+activation as the HIP kernels evaluate it (same fmaf, same branch)"""
+def _act_derivs(m, ex, pre=None):
+    """act'(u) of every BN+activation as the HIP kernels evaluate it (same fmaf, same branch).  pre: the kernels the step STARTED from
+    ({name: array}): the expand output of a fused inverted-residual block is in no buffer (executor._find_irb), so its pattern is
+    rebuilt by the unfused pointwise kernel from the saved block input -- with the weights the forward multiplied by, not the
+    updated ones"""
     ops = load_pkg('ops')
     out = {}
     for bn in m.graph.bns:
         if bn.act == 0:
             continue
-        z = ex.view(bn.z)
+        z = ex.view(bn.z, weights=pre)
         sc = ex.gscale[bn.group.id][bn.offset:bn.offset + bn.C]
         sh = ex.gshift[bn.group.id][bn.offset:bn.offset + bn.C]
         a = ops.affine_act(z, sc, sh, bn.act).cpu().numpy()
@@ -138,7 +141,7 @@ def test_train_step_matches_oracle(model_type, H, W, freeze, OS):
     mask = ex.dropout_mask(drop).cpu().numpy()
     # the ReLU branch pattern of the float32 run is injected into the float64 oracle (see
     # oracle/np_net.py Net.act_derivs): gradients are then comparable element by element
-    o.net.act_derivs = _act_derivs(m, ex)
+    o.net.act_derivs = _act_derivs(m, ex, o.net.params)
     o.net.act_derivs_seq = _act_derivs_seq(m, ex, o.net.act_derivs)
     total, ce, logits = o.loss_and_grads(x, y, {'aspp_dropout': mask})
     assert abs(loss - ce) < TOL * max(1.0, abs(ce)), (loss, ce)
@@ -199,7 +202,7 @@ def test_train_step_150_classes():
     loss = m.train_on_batch(x, y)
     ex = m._executor(N, True)
     drop = [op for op in m.graph.ops if op.kind == 'materialize' and op.rate > 0][0]
-    o.net.act_derivs = _act_derivs(m, ex)
+    o.net.act_derivs = _act_derivs(m, ex, o.net.params)
     o.net.act_derivs_seq = _act_derivs_seq(m, ex, o.net.act_derivs)
     total, ce, logits = o.loss_and_grads(x, y, {'aspp_dropout': ex.dropout_mask(drop).cpu().numpy()})
     assert abs(loss - ce) < TOL * max(1.0, abs(ce)), (loss, ce)
@@ -433,7 +436,7 @@ def test_train_step_with_optional_losses(kind):
     ex = m._executor(N, True)
     drop = [op for op in m.graph.ops if op.kind == 'materialize' and op.rate > 0][0]
     mask = ex.dropout_mask(drop).cpu().numpy()
-    o.net.act_derivs = _act_derivs(m, ex)
+    o.net.act_derivs = _act_derivs(m, ex, o.net.params)
     o.net.act_derivs_seq = _act_derivs_seq(m, ex, o.net.act_derivs)
     total, data_loss, _ = o.loss_and_grads(x, y, {'aspp_dropout': mask}, loss=spec)
     assert abs(loss - data_loss) < TOL * max(1.0, abs(data_loss)), (loss, data_loss)
@@ -490,7 +493,7 @@ def test_adam_and_rmsprop_step_matches_oracle(kind):
     ex = m._executor(N, True)
     drop = [op for op in m.graph.ops if op.kind == 'materialize' and op.rate > 0][0]
     mask = ex.dropout_mask(drop).cpu().numpy()
-    o.net.act_derivs = _act_derivs(m, ex)
+    o.net.act_derivs = _act_derivs(m, ex, o.net.params)
     o.net.act_derivs_seq = _act_derivs_seq(m, ex, o.net.act_derivs)
     total, ce, _ = o.loss_and_grads(x, y, {'aspp_dropout': mask})
     assert abs(loss - ce) < TOL * max(1.0, abs(ce)), (loss, ce)
@@ -535,7 +538,7 @@ def test_fit_with_adaptive_sample_weights():
     ex = m._executor(N, True)
     drop = [op for op in m.graph.ops if op.kind == 'materialize' and op.rate > 0][0]
     mask = ex.dropout_mask(drop).cpu().numpy()
-    o.net.act_derivs = _act_derivs(m, ex)
+    o.net.act_derivs = _act_derivs(m, ex, o.net.params)
     o.net.act_derivs_seq = _act_derivs_seq(m, ex, o.net.act_derivs)
     total, data_loss, _ = o.loss_and_grads(x, y, {'aspp_dropout': mask}, sample_weight=sw)
     assert abs(hist['loss'][0] - data_loss) < TOL * max(1.0, abs(data_loss)), (hist['loss'][0], data_loss)
@@ -807,7 +810,7 @@ def test_recompile_with_a_new_optimizer_keeps_the_dropout_stream():
 # inputs, at op-test tolerances.  The shortcuts of the production backward (folded apply, aliased Add gradients) are off so that
 # every conv output's gradient buffer holds d loss / d z at the end of the step; tests/test_ops_gpu.py and the
 # "backward shortcuts == same step with all of them off" test carry the result over to the production plan.
-def _teacher_forced_step(model_type, H, W, OS, N, tol_fwd, tol_dz, tol_w, C=21):
+def _teacher_forced_step(model_type, H, W, OS, N, tol_fwd, tol_dz, tol_w, C=21, expect_calls=()):
     _skip_if_missing(model_type)
     m, o = _pair(model_type, H, W, C, OS=OS)
     m.use_graphs = False
@@ -820,12 +823,18 @@ def _teacher_forced_step(model_type, H, W, OS, N, tol_fwd, tol_dz, tol_w, C=21):
     # own value there and the block is compared at its depthwise output)
     convs = [op for op in m.graph.ops if op.kind in ('conv_pw', 'conv_dense', 'conv_dw') and op.out.root.id in ex.buf]
     real = {op.name: op.layer.params[0].shape[-1] if op.kind != 'conv_dw' else op.c for op in convs}
-    o.net.act_derivs = _act_derivs(m, ex)
+    o.net.act_derivs = _act_derivs(m, ex, o.net.params)
     o.net.act_derivs_seq = _act_derivs_seq(m, ex, o.net.act_derivs)
     o.net.force = {op.name: ex.view(op.out).float().cpu().numpy()[..., :real[op.name]] for op in convs}
     o.net.record = {}
+    # (with the production folds on -- the caller did not switch them off -- a conv whose weight gradient takes the BatchNorm-backward
+    # apply over leaves dz in a scratch buffer: the oracle continues with its own dz there and the layer is held to float64 through
+    # its weight gradient and the next layer's dz)
     o.net.force_grad = {op.name: ex.view(op.out, grad=True).float().cpu().numpy()[..., :real[op.name]] for op in convs
-                        if op.out.requires_grad and op.out.root.id in ex.grad}
+                        if op.out.requires_grad and op.out.root.id in ex.grad and op.out.root.id not in ex._dz_not_kept}
+    calls = {ep for plan in (ex.fwd, ex.bwd) for (ep, _) in plan.labels}
+    for c in expect_calls:
+        assert c in calls, (c, sorted(calls))
     o.net.record_grad = {}
     o.net.grad_term_norm = {}
     total, ce, logits = o.loss_and_grads(x, y, {'aspp_dropout': mask})

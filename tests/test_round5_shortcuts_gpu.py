@@ -71,3 +71,16 @@ def test_stem_fold_and_separable_head_are_the_default_and_the_step_stays(monkeyp
     assert 'dl3p_stem_conv_bwd_weight_slabs_bn' not in off[3] and 'dl3p_head_train_rows' not in off[3]
     assert 'dl3p_upsample_softmax_loss' in off[3] and 'dl3p_resize_bilinear_bwd' in off[3]
     _same_step(on, off, 3e-2, 0.35)
+
+
+def test_batched_wgrad_off_at_a_fused_shape_keeps_the_unfused_blocks(monkeypatch):
+    """the fused inverted-residual backward leaves its weight gradients as slabs for the batched reduction, so with
+    DL3P_BATCHED_WGRAD=0 (an A/B switch) a training executor must not fuse -- it used to fuse and die on an assert while tracing"""
+    monkeypatch.setenv('DL3P_IRB_MIN_ROWS', '1')
+    monkeypatch.delenv('DL3P_IRB', raising=False)
+    on = _step('mobilenetv2', 129, 129, 21, 2, monkeypatch, {})
+    off = _step('mobilenetv2', 129, 129, 21, 2, monkeypatch, {'DL3P_BATCHED_WGRAD': '0'})
+    monkeypatch.delenv('DL3P_BATCHED_WGRAD')
+    assert 'dl3p_irb_fwd' in on[3] and 'dl3p_irb_bwd_data' in on[3]
+    assert not any(c.startswith('dl3p_irb_') for c in off[3])
+    _same_step(on, off, 3e-2, 0.35)

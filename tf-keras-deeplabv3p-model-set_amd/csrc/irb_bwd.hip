@@ -21,6 +21,7 @@
 // compile-time activations, padding masks only where a tile touches the border (wave-uniform), and in pass B the
 // BatchNorm-backward triple folded into per-channel constants: dz1 = [0 < u < 6] (w c0) * dz2 + (A z + B) with the depthwise
 // kernel pre-scaled by c0 in LDS, A = -c0 c2 invstd, B = c0 (c2 invstd mean - c1).
+#include <climits>
 #include "irb_common.h"
 
 // ------------------------------------------------------------------------------------------ pass A
@@ -644,6 +645,13 @@ extern "C" int dl3p_irb_set_bwd_plan(int want_waves_sums, int want_waves_data) {
   g_irb_bwd_units_a = want_waves_sums;
   g_irb_bwd_units_b = want_waves_data;
   return DL3P_OK;
+}
+// the four plan knobs as they stand (0 ct, 1 forward waves, 2 pass-A waves, 3 pass-B workgroups): they decide how many partial / slab
+// rows a traced launch writes, so an executor records them with its plan and pins them before an eager replay
+int dl3p_irb_fwd_plan_knob(int which);
+extern "C" int dl3p_irb_get_plan(int which) {
+  if (which == 0 || which == 1) return dl3p_irb_fwd_plan_knob(which);
+  return which == 2 ? g_irb_bwd_units_a : which == 3 ? g_irb_bwd_units_b : INT_MIN;
 }
 static int irb_want_a() { return g_irb_bwd_units_a > 0 ? g_irb_bwd_units_a : 8192; }
 static int irb_want_b() { return g_irb_bwd_units_b > 0 ? g_irb_bwd_units_b : 6144; }

@@ -91,14 +91,18 @@ __global__ __launch_bounds__(64 * IRB_COV_WAVES) void irb_cov_kernel(const float
   }
 }
 
+extern "C" int dl3p_irb_cov_rows_max(void) { return DL3P_NUM_CUS; }
+
 extern "C" int dl3p_irb_cov_stats(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
-                                  double* cov_rows, int* rows_out, int M, int K, void* stream) {
+                                  double* cov_rows, int rows_cap, int* rows_out, int M, int K, void* stream) {
   DL3P_CHECK_ARG(x && cov_rows && M > 0, "dl3p_irb_cov_stats: bad arguments");
   DL3P_CHECK_ARG(K == 16 || K == 24 || K == 32, "dl3p_irb_cov_stats: K=%d not in {16, 24, 32}", K);
   DL3P_CHECK_ARG(ldx >= K, "dl3p_irb_cov_stats: ld=%d < K", ldx);
   const long long gran = 4 * IRB_COV_WAVES * 16;
   long long chunk = ceil_div_ll(ceil_div_ll(M, DL3P_NUM_CUS), gran) * gran;
   const int rows = (int)ceil_div_ll(M, chunk);
+  DL3P_CHECK_ARG(rows <= rows_cap, "dl3p_irb_cov_stats: %d rows of [K + K*K] doubles needed, room for %d (dl3p_irb_cov_rows_max)", rows,
+                 rows_cap);
   if (rows_out) *rows_out = rows;
   if (K == 16)
     dl3p_launch(irb_cov_kernel<1>, dim3(rows), dim3(64 * IRB_COV_WAVES), 0, (hipStream_t)stream, x, ldx, in_scale, in_shift,
@@ -500,7 +504,14 @@ static int irb_plan(IrbParams& p, int N, int Ho, int Wo, int C, int S, int CT, i
 }
 
 static int g_irb_ct = 0, g_irb_waves = 0;
-extern "C" int dl3p_irb_set_plan(int ct, int want_waves) { g_irb_ct = ct; g_irb_waves = want_waves; return DL3P_OK; }
+extern "C" int dl3p_irb_set_plan(int ct, int want_waves) {
+  // (the forward is instantiated for 1 .. 3 channel tiles per wave)
+  DL3P_CHECK_ARG(ct >= 0 && ct <= 3 && want_waves >= 0, "dl3p_irb_set_plan: ct=%d not in 0..3 or want_waves=%d < 0", ct, want_waves);
+  g_irb_ct = ct;
+  g_irb_waves = want_waves;
+  return DL3P_OK;
+}
+int dl3p_irb_fwd_plan_knob(int which) { return which == 0 ? g_irb_ct : g_irb_waves; }
 
 static int irb_pick_ct(int C) {
   if (g_irb_ct > 0 && C % (16 * g_irb_ct) == 0) return g_irb_ct;
@@ -557,11 +568,13 @@ extern "C" int dl3p_irb_fwd(const float* x, int ldx, const float* in_scale, cons
   const int rows = irb_plan(p, N, Ho, Wo, C, stride, CT, stride == 2 ? 15 : 14, g_irb_waves > 0 ? g_irb_waves : 4096);
   if (rows_out) *rows_out = rows;
   hipStream_t st = (hipStream_t)stream;
-#define IRB_FWD_CASE(KK, CC) if (K == KK && CT == CC) irb_fwd_launch<KK, CC>(p, stride, st)
+  bool launched = false;
+#define IRB_FWD_CASE(KK, CC) if (K == KK && CT == CC) { irb_fwd_launch<KK, CC>(p, stride, st); launched = true; }
   IRB_FWD_CASE(16, 1); IRB_FWD_CASE(16, 2); IRB_FWD_CASE(16, 3);
   IRB_FWD_CASE(24, 1); IRB_FWD_CASE(24, 2); IRB_FWD_CASE(24, 3);
   IRB_FWD_CASE(32, 1); IRB_FWD_CASE(32, 2); IRB_FWD_CASE(32, 3);
 #undef IRB_FWD_CASE
+  DL3P_CHECK_ARG(launched, "dl3p_irb_fwd: no kernel for K=%d with %d channel tiles per wave", K, CT);
   DL3P_CHECK_LAUNCH("dl3p_irb_fwd");
   return DL3P_OK;
 }

@@ -422,6 +422,7 @@ class Executor:
         # ... and the other process-wide knobs that decide how many slabs / partial rows a traced launch writes: recorded now, pinned
         # again before every eager replay (_pin_options; a captured graph carries its launches' grids with it)
         self._pinned = {k: self.L.get_option(k) for k in (b'conv_sb', b'sb_rs', b'sb_pipe', b'splitk')}
+        self._pinned_irb = tuple(self.L.irb_get_plan(i) for i in range(4))
         self._find_irb()
         self._alloc()
         # tracing runs every kernel once on zero inputs: keep the weights / optimiser state intact
@@ -483,7 +484,8 @@ class Executor:
         self.irb_cov_rows = self.irb_cov_sums = None
         if self._irb_expand and self.training:
             kmax = max(op.cin for op in self._irb_expand)
-            self.irb_cov_rows = torch.zeros(256 * (kmax + kmax * kmax), dtype=torch.float64, device=self.dev)
+            self.irb_cov_cap = self.L.irb_cov_rows_max()
+            self.irb_cov_rows = torch.zeros(self.irb_cov_cap * (kmax + kmax * kmax), dtype=torch.float64, device=self.dev)
             self.irb_cov_sums = torch.zeros(kmax + kmax * kmax, dtype=torch.float64, device=self.dev)
         self.partials = torch.zeros(MAX_ROWS * 2 * cmax, **self.f32)
         self.partials2 = torch.zeros(MAX_ROWS * 2 * cmax, **self.f32) if self.training else None   # sums that wait (_presums)
@@ -573,6 +575,10 @@ class Executor:
         # output (activation branch patterns); the fused kernels never read it
         self._irb_keep_z = os.environ.get('DL3P_IRB_DEBUG_Z', '0') == '1'
         if self.bf16 or os.environ.get('DL3P_IRB', '1') == '0':
+            return
+        # the fused backward leaves its weight gradients as slabs for the batched slab reduction: with that switched off
+        # (DL3P_BATCHED_WGRAD=0, an A/B switch) a training executor keeps the unfused kernels
+        if self.training and os.environ.get('DL3P_BATCHED_WGRAD', '1') == '0':
             return
         g, N, L = self.g, self.N, self.L
         # measured on the headline step: the 257 x 257 and 129 x 129 blocks pay (12.75 -> 12.22 ms), the 65 x 65 ones do not (12.47 with them)
@@ -737,8 +743,10 @@ class Executor:
             hp = self.gshift[v.group.id].data_ptr() + 4 * v.goff
         return self.tptr(v.tensor), v.tensor.ld, sp, hp, v.act
 
-    def view(self, t, grad=False):
-        """torch view (N,H,W,C) of a graph tensor (test / debug hook)"""
+    def view(self, t, grad=False, weights=None):
+        """torch view (N,H,W,C) of a graph tensor (test / debug hook).  weights: {parameter name: array} standing in for the
+        parameter store where a tensor has to be re-formed (after a training step the store holds the UPDATED kernels; a test that
+        wants the tensor as the forward saw it passes the kernels the step started from)"""
         store = self.grad if grad else self.buf
         root = t.root
         if root.id not in store and root.id in self._irb_tensors and not grad:
@@ -752,7 +760,10 @@ class Executor:
             if v.group is not None:
                 sc = self.gscale[v.group.id][v.goff:v.goff + v.tensor.C]
                 sh = self.gshift[v.group.id][v.goff:v.goff + v.tensor.C]
-            w = self.store.view(e.w).reshape(e.cin, e.cout)
+            if weights is not None and e.w.name in weights:
+                w = torch.from_numpy(np.ascontiguousarray(weights[e.w.name], dtype=np.float32).reshape(e.cin, e.cout)).to(self.dev)
+            else:
+                w = self.store.view(e.w).reshape(e.cin, e.cout)
             return ops.pwconv_fwd(xin.reshape(-1, e.cin), w, in_scale=sc, in_shift=sh, in_act=v.act).view(self.N, root.H, root.W, root.C)
         full = store[root.id].view(self.N, root.H, root.W, root.C)
         return full[..., t.c0:t.c0 + t.C]
@@ -785,7 +796,7 @@ class Executor:
                     # block INPUT (z = x W is linear): one pass over the K-channel tensor, finalised at the 'bn' op
                     if want_stats:
                         crow = ctypes.c_int(0)
-                        P.k(L.irb_cov_stats, xp, ldx, sp, hp, act, self.irb_cov_rows.data_ptr(), ctypes.byref(crow),
+                        P.k(L.irb_cov_stats, xp, ldx, sp, hp, act, self.irb_cov_rows.data_ptr(), self.irb_cov_cap, ctypes.byref(crow),
                             N * xt.H * xt.W, op.cin)
                         if self.sync_bn:
                             off = self._fwd_stage_off
@@ -1104,6 +1115,7 @@ class Executor:
                         if op.kind in ('conv_pw', 'conv_dw') and op not in self._irb_expand] or [0])
             self.dz_scratch = torch.zeros(need + 64, **self.f32)      # dz of the layer whose weight gradient just ran
         self._folded = {}                 # z tensor id -> BatchNorm-backward apply arguments taken over by the conv's wgrad
+        self._dz_not_kept = set()         # (debug record) z tensors whose gradient buffer still holds d/d(BN output) after backward
         self._folded_dg = {}              # ... taken over by the conv's DATA gradient (row-stationary split GEMM, pw_split_rs.hip)
         jobs = self._jobs = []            # (slab pointer, destination pointer, rows, n) issued and not yet reduced
         self._wgrad_tables = []
@@ -1433,7 +1445,9 @@ class Executor:
         triggers when it reaches the expand conv"""
         e, b, d = rec
         L, st = self.L, self.store
-        assert batch, 'fused inverted-residual blocks leave their weight gradients as slabs'
+        if not batch:
+            raise RuntimeError('fused inverted-residual blocks leave their weight gradients as slabs (DL3P_BATCHED_WGRAD=0 and a '
+                               'fused block in the same executor: _find_irb should not have fused)')
         aux = self.bn_aux[b.bn]
         dz, lddz = self.tptr(d.out, True), d.out.ld
         ctx = P.ctx
@@ -1757,6 +1771,7 @@ class Executor:
         if not frozen and self._folds_apply(op):
             # the conv that produced z forms dz inside its weight-gradient kernel and hands it to its data gradient
             self._folded[z.id] = (g, ldg, zp, ldz, sp, hp, bn.act, mean, invstd, coef)
+            self._dz_not_kept.add(z.root.id)
             return
         P.k(L.bn_bwd_apply_bf16 if self.bf16 else L.bn_bwd_apply, g, ldg, zp, ldz, sp, hp, bn.act, mean, invstd, coef, dzo,
             lddzo, 0, M, bn.C)
@@ -1997,6 +2012,9 @@ class Executor:
             for k, v in self._pinned.items():
                 if self.L.get_option(k) != v:
                     self.L.set_option(k, v)
+            if self._irb_expand and tuple(self.L.irb_get_plan(i) for i in range(4)) != self._pinned_irb:
+                self.L.irb_set_plan(*self._pinned_irb[:2])
+                self.L.irb_set_bwd_plan(*self._pinned_irb[2:])
 
     def train_step(self):
         self._sb_sync()

@@ -1023,9 +1023,10 @@ def irb_cov_sums(x, in_scale=None, in_shift=None, in_act=ACT_NONE):
     K = x.shape[-1]
     M = _rows(x)
     xp, ldx = _pl(x)
-    rows_buf = torch.empty(256 * (K + K * K), dtype=torch.float64, device=x.device)
+    cap = lib().irb_cov_rows_max()
+    rows_buf = torch.empty(cap * (K + K * K), dtype=torch.float64, device=x.device)
     rows = ctypes.c_int(0)
-    lib().irb_cov_stats(xp, ldx, _p(in_scale), _p(in_shift), in_act, _p(rows_buf), ctypes.byref(rows), M, K, _stream())
+    lib().irb_cov_stats(xp, ldx, _p(in_scale), _p(in_shift), in_act, _p(rows_buf), cap, ctypes.byref(rows), M, K, _stream())
     sums = torch.empty(K + K * K, dtype=torch.float64, device=x.device)
     lib().irb_cov_reduce(_p(rows_buf), rows.value, K, _p(sums), _stream())
     return sums
