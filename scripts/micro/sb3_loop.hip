@@ -1,0 +1,384 @@
+// The split-bf16 GEMM K loop, third form (round 6): ONE workgroup of four waves per CU on a 128 x 256 output tile
+// (each wave 64 x 128: 2 x 4 accumulators of v_mfma_f32_32x32x16_bf16), two LDS operand stages, ONE barrier per K-step, and the staging of
+// K-step i + 1 (global loads -> prologue -> exact 3-way split -> LDS) cut into units of 3-4 vector instructions that are PINNED into
+// the gaps between the 96 MFMAs of K-step i: every gap is closed by a sched_barrier(0), so the instruction stream is the one written
+// here (scripts/isa_gaps.py counts what the compiler left between two MFMAs of the loop).  The barrier sits 25 gaps before the end of
+// the step; behind it the first fragments of step i + 1 are read from the other stage while the last MFMAs of step i run.
+// Stand-alone: times M x K x N = 266256 x 320 x 256 (the decoder shape, K padded to the tile), checks outputs against float64.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off scripts/micro/sb3_loop.hip -o scripts/micro/bin/sb3_loop
+//   FLAGS bits: 2 = no MFMAs, 4 = no staging arithmetic / LDS stores, 8 = no global loads in the loop, 16 = no epilogue stores,
+//   32 = no barrier in the loop, 64 = no prologue (plain split), 128 = no fragment reads in the loop
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdint.h>
+#include <math.h>
+#include <string.h>
+#include <type_traits>
+#include <vector>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+
+constexpr int BM = 128, BN = 256, BKT = 32;
+constexpr int A_PLANE = BM * 32, B_PLANE = BN * 32;       // bf16 elements; rows of 64 bytes, 16-byte chunks swizzled by (row >> 2) & 3
+constexpr int STAGE = 3 * (A_PLANE + B_PLANE);           // 73728 bytes
+#ifndef BARG
+#define BARG 70                                          // the step's barrier closes this gap
+#endif
+
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+// ---- the schedule: which gap (0 .. 95) of a K-step carries which piece of the staging of the NEXT step -------------------------------
+// 40 arithmetic units: pair p (0..7: two consecutive k of one row; pairs 0-3 row group 0, 4-7 row group 1) x stage s (0..4)
+//   unit u = g * 20 + s * 4 + (p & 3) for group g: stage-major inside a row group, so a plane of the group is complete after 8 / 12 / 20 units
+__host__ __device__ constexpr int unit_gap(int u) { return (u * 5) / 3; }                   // 0 .. 65
+__host__ __device__ constexpr int aw_gap(int g, int pl) { return unit_gap(g * 20 + (pl == 0 ? 7 : pl == 1 ? 11 : 19)) + 1; }
+__host__ __device__ constexpr int aw_gap_i(int i) { return aw_gap(i / 3, i % 3); }
+__host__ __device__ constexpr int al_gap(int j) { return unit_gap((j >> 1) * 20 + 2 * (j & 1) + 1) + 1; }   // raw quad j is free after stage 0 of its two pairs
+__host__ __device__ constexpr int cl_gap(int j) { return unit_gap(23) + 2 + j; }           // coefficients: after the last stage-0 unit
+__host__ __device__ constexpr int bw_gap(int j) { return 5 * j + 4; }                       // 4 .. 59
+__host__ __device__ constexpr int bl_gap(int j) { return 5 * j + 8; }
+// fragment reads.  The MFMAs of a step run k half (2) x column tile ni (4) x row tile mi (2) x 6 products; a column tile's three planes
+// live in register set ni (both k halves), a row tile's in xa[mi][k half].  Reads 0..23 come from the stage being multiplied, in front
+// of the barrier; 24..35 from the other stage behind it (the next step's first fragments):
+//   0-2 B(0,2) | 3-5 A(0,1) | 6-8 A(1,1) | 9-11 B(0,3) | 12-14 B(1,0) | 15-17 B(1,1) | 18-20 B(1,2) | 21-23 B(1,3) | 24-26 A'(0,0) | 27-29 B'(0,0) |
+//   30-32 A'(1,0) | 33-35 B'(0,1)       (B(kh, ni), A(mi, kh))
+__host__ __device__ constexpr int fr_gap(int k) { return k < 21 ? 2 * k + 1 : k < 24 ? 2 * k + 7 : BARG + 1 + (k - 24); }
+
+// the index whose gap is g, or -1 (every table above puts at most one of its entries into a gap)
+template <class F>
+__host__ __device__ constexpr int at(F f, int n, int g) {
+  for (int i = 0; i < n; ++i)
+    if (f(i) == g) return i;
+  return -1;
+}
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+template <int FLAGS>
+__global__ __launch_bounds__(256, 1) void sb3(const float* __restrict__ A, int lda, const float* __restrict__ ps, const float* __restrict__ pt,
+                                              const unsigned short* __restrict__ Bsp, float* __restrict__ Y, int M, int K, int N,
+                                              int num_m_tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned short* S0 = reinterpret_cast<unsigned short*>(lds);
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int wr = w >> 1, wc = w & 1;
+  const int nk = K / BKT;                                // even (the host pads K to 64)
+  const int my_tiles = (num_m_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  if (my_tiles <= 0) return;
+  const __amdgpu_buffer_rsrc_t rA = rsrc(A, (uint32_t)M * (uint32_t)lda * 4u), rS = rsrc(ps, (uint32_t)K * 4u), rT = rsrc(pt, (uint32_t)K * 4u),
+                               rB = rsrc(Bsp, 3u * (uint32_t)N * (uint32_t)K * 2u), rY = rsrc(Y, (uint32_t)M * (uint32_t)N * 4u);
+  const int ar = t >> 2, ac = t & 3;
+  // LDS offsets (bf16 elements): the thread's staging chunks ...
+  const int sw = (ar >> 2) & 3;                            // (the same for rows ar + 64 i)
+  const int a_lds = ar * 32 + ((ac ^ sw) * 8);             // + i * 64 * 32 + plane * A_PLANE
+  const int b_lds = 3 * A_PLANE + a_lds;                   // + (j & 3) * 64 * 32 + (j >> 2) * B_PLANE
+  // ... and its fragments (32x32x16: lane = row (l & 31), 8 k at chunk 2 kh + (l >> 5))
+  const int l31 = l & 31, hh5 = l >> 5, fsw = (l31 >> 2) & 3;
+  int xa_off[2], wb_off[2];
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) {
+    xa_off[kh] = (wr * 64 + l31) * 32 + (((2 * kh + hh5) ^ fsw) * 8);
+    wb_off[kh] = 3 * A_PLANE + (wc * 128 + l31) * 32 + (((2 * kh + hh5) ^ fsw) * 8);
+  }
+  // global offsets (bytes)
+  uint32_t arow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) arow[i] = (uint32_t)((int)blockIdx.x * BM + ar + 64 * i) * (uint32_t)lda * 4u + (uint32_t)ac * 32u;
+  const uint32_t a_tile_stride = gridDim.x * (uint32_t)BM * (uint32_t)lda * 4u;
+  const uint32_t cvo = (uint32_t)ac * 32u;
+  const uint32_t blane = (uint32_t)ar * (uint32_t)K * 2u + (uint32_t)ac * 16u;
+  const uint32_t b_plane = (uint32_t)N * (uint32_t)K * 2u, b_rows = 64u * (uint32_t)K * 2u;
+  uint4 ra[4];                  // raw quads: [row group * 2 + half]
+  uint4 cs[2], ct[2];           // prologue coefficients of the thread's 8 k
+  u32x4 rb[12];
+  float v0[8], v1[8], r0[8], r1[8];
+  uint32_t hp[8], mp[8], lp[8];
+
+  int lkt = 0;                  // k-step of the NEXT global request; arow[] holds its tile
+  auto advance = [&]() __attribute__((always_inline)) {
+    ++lkt;
+    if (lkt == nk) { lkt = 0; arow[0] += a_tile_stride; arow[1] += a_tile_stride; }
+  };
+  auto load_a = [&](int j) __attribute__((always_inline)) {
+    ra[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rA, arow[j >> 1] + 16 * (j & 1), lkt * (BKT * 4), 0));
+  };
+  auto load_c = [&](int j) __attribute__((always_inline)) {
+    if (j < 2) cs[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rS, cvo + 16 * (j & 1), lkt * (BKT * 4), 0));
+    else ct[j - 2] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rT, cvo + 16 * (j & 1), lkt * (BKT * 4), 0));
+  };
+  auto load_b = [&](int j) __attribute__((always_inline)) {
+    rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rB, blane + (uint32_t)lkt * (BKT * 2), (j >> 2) * b_plane + (j & 3) * b_rows, 0);
+  };
+  auto elem = [](const uint4& q, int e) __attribute__((always_inline)) {
+    return __builtin_bit_cast(float, e == 0 ? q.x : e == 1 ? q.y : e == 2 ? q.z : q.w);
+  };
+  // one arithmetic unit of pair p, stage s
+  auto unit = [&](auto pc, auto sc) __attribute__((always_inline)) {
+    constexpr int p = decltype(pc)::value, s = decltype(sc)::value;
+    constexpr int q = (p >> 2) * 2 + ((p & 3) >> 1), e = (p & 1) * 2, h = (p & 3) >> 1;
+    if constexpr (s == 0) {
+      float x = elem(ra[q], e), y = elem(ra[q], e + 1);
+      if (!(FLAGS & 64)) {
+        x = fmaxf(__builtin_fmaf(x, elem(cs[h], e), elem(ct[h], e)), 0.f);
+        y = fmaxf(__builtin_fmaf(y, elem(cs[h], e + 1), elem(ct[h], e + 1)), 0.f);
+      }
+      v0[p] = x; v1[p] = y;
+    } else if constexpr (s == 1) {
+      const bf16x2v hv = {(__bf16)v0[p], (__bf16)v1[p]};
+      hp[p] = __builtin_bit_cast(uint32_t, hv);
+      r0[p] = __builtin_bit_cast(float, hp[p] << 16);
+      r1[p] = __builtin_bit_cast(float, hp[p] & 0xffff0000u);
+    } else if constexpr (s == 2) {
+      r0[p] = v0[p] - r0[p];
+      r1[p] = v1[p] - r1[p];
+      const bf16x2v mv = {(__bf16)r0[p], (__bf16)r1[p]};
+      mp[p] = __builtin_bit_cast(uint32_t, mv);
+    } else if constexpr (s == 3) {
+      v0[p] = r0[p] - __builtin_bit_cast(float, mp[p] << 16);
+      v1[p] = r1[p] - __builtin_bit_cast(float, mp[p] & 0xffff0000u);
+    } else {
+      const bf16x2v lv = {(__bf16)v0[p], (__bf16)v1[p]};
+      lp[p] = __builtin_bit_cast(uint32_t, lv);
+    }
+  };
+  auto write_a = [&](unsigned short* buf, int g, int pl) __attribute__((always_inline)) {
+    const uint32_t* src = pl == 0 ? hp : pl == 1 ? mp : lp;
+    const uint4 val = {src[4 * g], src[4 * g + 1], src[4 * g + 2], src[4 * g + 3]};
+    *reinterpret_cast<uint4*>(buf + a_lds + g * (64 * 32) + pl * A_PLANE) = val;
+  };
+  auto write_b = [&](unsigned short* buf, int j) __attribute__((always_inline)) {
+    *reinterpret_cast<u32x4*>(buf + b_lds + (j & 3) * (64 * 32) + (j >> 2) * B_PLANE) = rb[j];
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+  s16x8 xa[2][2][3], wb[4][3];          // A: [row tile][k half][plane]; B: [column tile = register set][plane]
+
+  auto frag_read = [&](const unsigned short* cur, const unsigned short* nxt, auto kc) __attribute__((always_inline)) {
+    constexpr int k = decltype(kc)::value, grp = k / 3, pl = k % 3;
+    // grp: 0 B(0,2) 1 A(0,1) 2 A(1,1) 3 B(0,3) 4..7 B(1,0..3) 8 A'(0,0) 9 B'(0,0) 10 A'(1,0) 11 B'(0,1)
+    if constexpr (grp == 0) wb[2][pl] = *reinterpret_cast<const s16x8*>(cur + pl * B_PLANE + wb_off[0] + 2 * 32 * 32);
+    else if constexpr (grp == 1) xa[0][1][pl] = *reinterpret_cast<const s16x8*>(cur + pl * A_PLANE + xa_off[1]);
+    else if constexpr (grp == 2) xa[1][1][pl] = *reinterpret_cast<const s16x8*>(cur + pl * A_PLANE + xa_off[1] + 32 * 32);
+    else if constexpr (grp == 3) wb[3][pl] = *reinterpret_cast<const s16x8*>(cur + pl * B_PLANE + wb_off[0] + 3 * 32 * 32);
+    else if constexpr (grp < 8) wb[grp - 4][pl] = *reinterpret_cast<const s16x8*>(cur + pl * B_PLANE + wb_off[1] + (grp - 4) * 32 * 32);
+    else if constexpr (grp == 8) xa[0][0][pl] = *reinterpret_cast<const s16x8*>(nxt + pl * A_PLANE + xa_off[0]);
+    else if constexpr (grp == 9) wb[0][pl] = *reinterpret_cast<const s16x8*>(nxt + pl * B_PLANE + wb_off[0]);
+    else if constexpr (grp == 10) xa[1][0][pl] = *reinterpret_cast<const s16x8*>(nxt + pl * A_PLANE + xa_off[0] + 32 * 32);
+    else wb[1][pl] = *reinterpret_cast<const s16x8*>(nxt + pl * B_PLANE + wb_off[0] + 32 * 32);
+  };
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  // ---- pipeline head: step 0 staged into stage 0, step 1 requested
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { load_a(j); load_c(j); }
+#pragma unroll
+  for (int j = 0; j < 12; ++j) load_b(j);
+  static_for<5>([&](auto sc) { static_for<8>([&](auto pc) { unit(pc, sc); }); });
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) write_a(S0, g, pl);
+#pragma unroll
+  for (int j = 0; j < 12; ++j) write_b(S0, j);
+  advance();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { load_a(j); load_c(j); }
+#pragma unroll
+  for (int j = 0; j < 12; ++j) load_b(j);
+  advance();
+  lds_barrier();
+  static_for<12>([&](auto kc) { frag_read(S0, S0, std::integral_constant<int, 24 + decltype(kc)::value>{}); });
+
+  auto step = [&](auto par) __attribute__((always_inline)) {
+    constexpr int P = decltype(par)::value;
+    const unsigned short* cur = S0 + P * STAGE;
+    unsigned short* nxt = S0 + (P ^ 1) * STAGE;
+    constexpr bool do_stage = !(FLAGS & 4), do_load = !(FLAGS & 8), do_frag = !(FLAGS & 128);
+    static_for<96>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      constexpr int kh = g / 48, rem = g % 48, ni = rem / 12, mi = (rem % 12) / 6, pr = rem % 6;
+      constexpr int WB[6] = {2, 0, 1, 1, 0, 0}, XA[6] = {0, 2, 1, 0, 1, 0};
+      if (!(FLAGS & 2)) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[mi][kh][XA[pr]], wb[ni][WB[pr]], acc[mi][ni], 0, 0, 0);
+      else if (pr == 0) acc[mi][ni][0] += __builtin_bit_cast(float, (int)wb[ni][0][0] + (int)wb[ni][1][1] + (int)wb[ni][2][2] + (int)xa[mi][kh][0][0] + (int)xa[mi][kh][1][1] + (int)xa[mi][kh][2][2]);
+      // ---- the fillers of this gap
+      constexpr int fr = at(fr_gap, 36, g), u = at(unit_gap, 40, g), aw = at(aw_gap_i, 6, g), bw = at(bw_gap, 12, g), al = at(al_gap, 4, g),
+                    cl = at(cl_gap, 4, g), bl = at(bl_gap, 12, g);
+      if constexpr (g == BARG) { if (!(FLAGS & 32)) lds_barrier(); }
+      if constexpr (do_frag && fr >= 0) frag_read(cur, nxt, std::integral_constant<int, (fr >= 0 ? fr : 0)>{});
+      if constexpr (do_stage && u >= 0) {
+        constexpr int uu = u >= 0 ? u : 0, grp = uu / 20, s = (uu % 20) / 4, p = grp * 4 + (uu & 3);
+        unit(std::integral_constant<int, p>{}, std::integral_constant<int, s>{});
+      }
+      if constexpr (do_stage && aw >= 0) write_a(nxt, (aw >= 0 ? aw : 0) / 3, (aw >= 0 ? aw : 0) % 3);
+      if constexpr (do_stage && bw >= 0) write_b(nxt, bw >= 0 ? bw : 0);
+      if constexpr (do_load && al >= 0) load_a(al >= 0 ? al : 0);
+      if constexpr (do_load && cl >= 0) load_c(cl >= 0 ? cl : 0);
+      if constexpr (do_load && bl >= 0) load_b(bl >= 0 ? bl : 0);
+      FENCE();
+    });
+    advance();
+  };
+  const uint32_t yv = (uint32_t)((wr * 64 + 4 * hh5) * N + wc * 128 + l31) * 4u;
+  for (int tile = 0; tile < my_tiles; ++tile) {
+    for (int kp = 0; kp < nk; kp += 2) { step(I0{}); step(I1{}); }
+    if (!(FLAGS & 16)) {
+      // lane = output channel (l & 31), register e = pixel row (e & 3) + 8 (e >> 2) + 4 (l >> 5) of the 32-row tile
+      const uint32_t m0 = (uint32_t)((int)blockIdx.x + tile * (int)gridDim.x) * BM;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const uint32_t row = m0 + mi * 32 + (e & 3) + 8 * (e >> 2);
+            const float val = acc[mi][ni][e];       // (bit_cast straight from the vector element stored element 0 sixteen times)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rY, yv + ni * 128, row * (uint32_t)N * 4u, 0);
+          }
+    }
+    if (!(FLAGS & 16))       // (the store-less variants keep accumulating: zeroed here, the loop would be dead code for them)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+  }
+  if ((FLAGS & 16) && ps[t] == 1234.5678f) {      // never true (the host data holds no such value): keeps the accumulators alive in the store-less variants
+    float sum = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sum += acc[mi][ni][e];
+    Y[t] = sum;
+  }
+}
+
+static void split_host(float x, unsigned short* h, unsigned short* m, unsigned short* l) {
+  auto rn = [](float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (unsigned short)(u >> 16); };
+  auto up = [](unsigned short b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; };
+  *h = rn(x); float r = x - up(*h); *m = rn(r); r -= up(*m); *l = rn(r);
+}
+
+template <int FLAGS>
+static float run(const float* A, const float* ps, const float* pt, const unsigned short* B, float* Y, int M, int K, int N, const char* name) {
+  const int mt = (M + BM - 1) / BM;
+  const int gx = mt < 256 ? mt : 256;
+  const int ldsb = 2 * STAGE * 2;
+  hipFuncSetAttribute((const void*)sb3<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e9f;
+  for (int r = 0; r < 6; ++r) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((sb3<FLAGS>), dim3(gx), dim3(256), ldsb, 0, A, K, ps, pt, B, Y, M, K, N, mt);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (r > 0 && ms < best) best = ms;
+  }
+  const double steps_per_cu = (double)((mt + gx - 1) / gx) * (K / BKT);
+  printf("%-56s M=%6d %7.1f us   %.0f clk/K-step at 2.4 GHz (MFMA floor 3072)\n", name, M, best * 1e3, best * 1e-3 * 2.4e9 / steps_per_cu);
+  return best;
+}
+
+static void check(const std::vector<float>& hA, const std::vector<float>& hs, const std::vector<float>& ht, const std::vector<float>& hW,
+                  const float* Y, int M, int K, int N, bool prologue) {
+  std::vector<float> hY((size_t)M * N);
+  hipMemcpy(hY.data(), Y, hY.size() * 4, hipMemcpyDeviceToHost);
+  double worst = 0, scale = 0;
+  double terr[4][8] = {}, tkerr[10] = {};
+  for (int s = 0; s < 6000; ++s) {
+    const int m = s < 300 ? (s < 150 ? s : M - 1 - (s - 150)) : (int)(((long long)s * 7919 * 131) % M), n = (s * 37) % N;
+    double ref = 0, part[10] = {};
+    for (int k = 0; k < K; ++k) {
+      float a = hA[(size_t)m * K + k];
+      if (prologue) a = fmaxf(fmaf(a, hs[k], ht[k]), 0.f);
+      ref += (double)a * (double)hW[(size_t)n * K + k];
+      part[k / 32] += (double)a * (double)hW[(size_t)n * K + k];
+    }
+    const double e = fabs(ref - hY[(size_t)m * N + n]);
+    worst = fmax(worst, e); scale = fmax(scale, fabs(ref));
+    terr[(m % 128) / 32][n / 32] = fmax(terr[(m % 128) / 32][n / 32], e);
+    if (s < 4) {
+      printf("  sample m=%d n=%d got %.6f ref %.6f  per-k-step partials:", m, n, hY[(size_t)m * N + n], ref);
+      for (int q = 0; q < K / 32; ++q) printf(" %.4f", part[q]);
+      printf("\n");
+    }
+  }
+  printf("  max |err| by (row tile, column tile):\n");
+  for (int a = 0; a < 4; ++a) { printf("   "); for (int b = 0; b < 8; ++b) printf(" %9.2e", terr[a][b]); printf("\n"); }
+  printf("max |err| / max |ref| over 6000 samples: %.2e\n", worst / scale);
+}
+
+int main() {
+  const int Mfull = 266256, K = 320, N = 256;
+  std::vector<float> hA((size_t)Mfull * K), hW((size_t)N * K), hs(K), ht(K);
+  srand(1);
+  for (auto& v : hA) v = (rand() / (float)RAND_MAX - 0.5f) * 4.f;
+  for (auto& v : hW) v = (rand() / (float)RAND_MAX - 0.5f) * 0.2f;
+  for (auto& v : hs) v = 0.5f + rand() / (float)RAND_MAX;
+  for (auto& v : ht) v = (rand() / (float)RAND_MAX - 0.5f);
+  std::vector<unsigned short> hB((size_t)3 * N * K);
+  for (size_t i = 0; i < (size_t)N * K; ++i) split_host(hW[i], &hB[i], &hB[(size_t)N * K + i], &hB[(size_t)2 * N * K + i]);
+  float *A, *Y, *ps, *pt; unsigned short* B;
+  hipMalloc(&A, hA.size() * 4); hipMalloc(&Y, (size_t)Mfull * N * 4); hipMalloc(&B, hB.size() * 2);
+  hipMalloc(&ps, K * 4); hipMalloc(&pt, K * 4);
+  hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(B, hB.data(), hB.size() * 2, hipMemcpyHostToDevice);
+  hipMemcpy(ps, hs.data(), K * 4, hipMemcpyHostToDevice);
+  hipMemcpy(pt, ht.data(), K * 4, hipMemcpyHostToDevice);
+  hipMemset(Y, 0, (size_t)Mfull * N * 4);
+  run<0>(A, ps, pt, B, Y, Mfull, K, N, "pinned schedule");
+  check(hA, hs, ht, hW, Y, Mfull, K, N, true);
+  if (getenv("SB3_MAP")) {
+    // the first tile, element by element: which (row, column) are right
+    std::vector<float> hY((size_t)128 * N);
+    hipMemcpy(hY.data(), Y, hY.size() * 4, hipMemcpyDeviceToHost);
+    std::vector<char> ok((size_t)128 * N);
+    for (int m = 0; m < 128; ++m)
+      for (int n = 0; n < N; ++n) {
+        double ref = 0;
+        for (int k = 0; k < K; ++k) ref += (double)fmaxf(fmaf(hA[(size_t)m * K + k], hs[k], ht[k]), 0.f) * (double)hW[(size_t)n * K + k];
+        ok[(size_t)m * N + n] = fabs(ref - hY[(size_t)m * N + n]) < 1e-4;
+      }
+    printf("first tile: right entries per (32-row tile, 32-column tile) of 1024:\n");
+    for (int a = 0; a < 4; ++a) { for (int b = 0; b < 8; ++b) { int c = 0; for (int i = 0; i < 32; ++i) for (int j = 0; j < 32; ++j) c += ok[(size_t)(a * 32 + i) * N + b * 32 + j]; printf(" %5d", c); } printf("\n"); }
+    printf("rows 0..63 x columns 0..63 (# right):\n");
+    for (int m = 0; m < 64; ++m) { for (int n = 0; n < 64; ++n) putchar(ok[(size_t)m * N + n] ? '#' : '.'); putchar('\n'); }
+  }
+  const int Mb = 256 * 8 * 128;      // eight full tiles per CU
+  run<0>(A, ps, pt, B, Y, Mb, K, N, "pinned schedule, balanced M");
+#ifdef ALL_VARIANTS
+  run<64>(A, ps, pt, B, Y, Mfull, K, N, "no prologue");
+  check(hA, hs, ht, hW, Y, Mfull, K, N, false);
+  run<16>(A, ps, pt, B, Y, Mb, K, N, "no epilogue stores");
+  run<2 | 16>(A, ps, pt, B, Y, Mb, K, N, "no MFMAs, no epilogue stores");
+  run<4 | 16>(A, ps, pt, B, Y, Mb, K, N, "no staging arithmetic / LDS stores, no epilogue stores");
+  run<8 | 16>(A, ps, pt, B, Y, Mb, K, N, "no global loads, no epilogue stores");
+  run<4 | 8 | 16>(A, ps, pt, B, Y, Mb, K, N, "MFMAs + fragment reads + barrier");
+  run<4 | 8 | 16 | 32>(A, ps, pt, B, Y, Mb, K, N, "MFMAs + fragment reads");
+  run<4 | 8 | 16 | 32 | 128>(A, ps, pt, B, Y, Mb, K, N, "MFMAs only");
+#endif
+  return 0;
+}

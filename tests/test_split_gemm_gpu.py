@@ -512,3 +512,101 @@ def test_thirty_steps_on_the_split_gemms_stay_with_the_fp32_kernels(monkeypatch)
     assert 0.2 < np.mean(np.array(signs) > 0) < 0.8, signs          # no one-sided offset of the loss curve
     assert abs(float(np.mean(np.array(l1[5:]) - np.array(l0[5:])))) < 5e-3
     assert drift < 2.0 * control + 1e-3, (drift, control, moved)
+
+
+# ------------------------------------------------------------------------------------------- the pinned-schedule forward (csrc/pw_split3.hip)
+def _plan(L, role, M, K, N):
+    import ctypes
+    out = (ctypes.c_int * 6)()
+    L.gemm_plan_query(role, M, K, N, out)
+    return list(out)
+
+
+SB3_CASES = [
+    # (M, K, N, act, prologue, statistics, bias, input pitch, output pitch)
+    (16 * 129 * 129, 304, 256, 'relu', True, True, False, 304, 256),       # decoder_conv0_pointwise at BASELINE configs[1]
+    (16 * 129 * 129, 256, 256, 'relu', True, True, False, 256, 256),       # decoder_conv1_pointwise
+    (70001, 304, 256, 'relu6', True, True, False, 320, 272),               # ragged rows (last tile: 113 rows), operands inside wider buffers
+    (66000, 256, 256, 'none', False, False, True, 256, 256),               # no prologue, bias, no statistics
+    (65536 + 129, 500, 256, 'none', True, True, False, 500, 256),          # K tail inside the last K-step (pitch 512), one row in the last tile
+    (300, 256, 256, 'relu', True, True, False, 256, 256),                  # fewer tiles than CUs (forced)
+    (128 * 256 * 2 + 64, 384, 256, 'relu', True, False, True, 384, 300),   # two full rounds + a half tile; prologue and bias, no statistics
+]
+
+
+@pytest.mark.parametrize('case', SB3_CASES, ids=lambda c: '%dx%d_%s%s%s' % (c[0], c[1], c[3], '_stats' if c[5] else '', '_bias' if c[6] else ''))
+def test_pinned_schedule_forward_matches_float64(ops, case):
+    """dl3p_pwconv_fwd_sb on pw_gemm_sb3_kernel (one workgroup per CU, the staging pinned into the MFMA gaps, the output tile leaving
+    in slices under the next tile): the forward tolerances of the tiled split kernels, ragged M / K tails, slices of wider buffers"""
+    M, K, N, act, pro, stats, has_bias, ldx, ldy = case
+    L = ops.lib()
+    L.set_option(b'pw_small_min_rows', -1)
+    L.set_option(b'sb3', 1)
+    try:
+        assert _plan(L, 5 + int(stats), M, K, N)[3] == 4, _plan(L, 5 + int(stats), M, K, N)
+        g = torch.Generator(device=DEV); g.manual_seed(M % 9973 + 7 * K + 3)
+        rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)
+        # the operand sits in a wider buffer whose other columns hold large values (a K tail must not leak them in)
+        xbuf = rnd(M, ldx) * 50.0
+        x = xbuf[:, :K]
+        x.copy_(rnd(M, K))
+        wt = rnd(N, K) / K ** 0.5
+        sc = (torch.rand(K, device=DEV, generator=g) + 0.5) if pro else None
+        sh = (rnd(K) * 0.3 + 0.2) if pro else None
+        bias = rnd(N) * 0.1 if has_bias else None
+        actc = {'none': ops.ACT_NONE, 'relu': ops.ACT_RELU, 'relu6': ops.ACT_RELU6}[act]
+        a64 = x.double()
+        if pro:
+            a64 = a64 * sc.double() + sh.double()
+        if act != 'none':
+            a64 = a64.clamp(0.0, 6.0 if act == 'relu6' else float('inf'))
+        y64 = a64 @ wt.double().t()
+        if has_bias:
+            y64 = y64 + bias.double()
+        wsp = ops.split_bf16x3(wt)
+        ybuf = torch.full((M, ldy), 7.0, device=DEV)
+        y = ybuf[:, :N]
+        part = ops.new_partials(N, DEV) if stats else None
+        res = ops.pwconv_fwd_sb(x, wsp, K, bias, sc, sh, actc, out=y, partials=part)
+        scale = float(y64.abs().max())
+        e = float((y.double() - y64).abs().max()) / scale
+        assert e < 2e-5, ('forward', e)
+        if ldy > N:
+            assert float((ybuf[:, N:] - 7.0).abs().max()) == 0.0, 'columns beside the output were written'
+        if stats:
+            rows = res[1]
+            assert rows == min(256, -(-M // 128)), rows
+            p = part[:rows * 2 * N].reshape(rows, 2, N).double().sum(0)
+            s1, s2 = y64.sum(0), (y64 * y64).sum(0)
+            assert float((p[0] - s1).abs().max()) < 1e-4 * max(float(s1.abs().max()), float(M) ** 0.5), 'stat sum'
+            assert float((p[1] - s2).abs().max()) < 1e-4 * float(s2.abs().max()), 'stat sum of squares'
+        # the tiled kernel on the same launch: both within the bound, and of each other
+        L.set_option(b'sb3', 0)
+        y_old = ops.pwconv_fwd_sb(x, wsp, K, bias, sc, sh, actc)
+        assert float((y_old.double() - y.double()).abs().max()) / scale < 2e-5
+    finally:
+        L.set_option(b'pw_small_min_rows', 64)
+        L.set_option(b'sb3', -1)
+
+
+def test_pinned_schedule_forward_is_the_default_on_the_long_decoder_layers_only(ops):
+    L = ops.lib()
+    L.set_option(b'pw_small_min_rows', -1)
+    try:
+        assert _plan(L, 6, 16 * 129 * 129, 304, 256)[3] == 4 and _plan(L, 6, 16 * 129 * 129, 256, 256)[3] == 4
+        assert _plan(L, 5, 2 * 385 * 385, 256, 256)[3] == 4                       # BASELINE configs[3], batch 2
+        assert _plan(L, 6, 16 * 33 * 33, 1280, 256)[3] != 4                       # too few rows
+        assert _plan(L, 6, 16 * 129 * 129, 288, 256)[3] != 4                      # nine K-steps: the loop runs them in pairs
+        assert _plan(L, 6, 16 * 129 * 129, 304, 304)[3] != 4
+        # an activation the kernel does not carry falls back inside the call
+        g = torch.Generator(device=DEV); g.manual_seed(5)
+        x = torch.randn(66000, 256, device=DEV, generator=g)
+        wt = torch.randn(256, 256, device=DEV, generator=g) / 16
+        sc = torch.rand(256, device=DEV, generator=g) + 0.5
+        sh = torch.randn(256, device=DEV, generator=g) * 0.3
+        y = ops.pwconv_fwd_sb(x, ops.split_bf16x3(wt), 256, None, sc, sh, ops.ACT_HSWISH)
+        u = x.double() * sc.double() + sh.double()
+        y64 = (u * (u + 3).clamp(0, 6) / 6) @ wt.double().t()
+        assert float((y.double() - y64).abs().max()) < 2e-5 * float(y64.abs().max())
+    finally:
+        L.set_option(b'pw_small_min_rows', 64)

@@ -1,0 +1,377 @@
+// The split-bf16 forward GEMM with its staging PINNED under the multiply phase (round 6).
+//
+// y[M][256] = act(x * scale + shift)[M][K] . W^T with W pre-split into three bf16 planes [3][256][pitch] (the pointwise convs of
+// deeplabv3p/models/layers.py:105,157,209-218 on the long decoder maps: 266256 rows at BASELINE configs[1]).  Same arithmetic as
+// pw_split.hip (exact 3-way split of the staged operand, six bf16 products per tile and K-step, smallest first); what differs is who
+// waits for whom:
+//  * ONE workgroup of four waves per CU (one wave per SIMD: 512 registers), output tile 128 rows x 256 columns, each wave 64 x 128 =
+//    2 x 4 accumulators of v_mfma_f32_32x32x16_bf16 (an MFMA holds the vector port 8 of its 32 cycles: 24 free for the staging).
+//  * two LDS operand stages (2 x 72 KB), ONE barrier per K-step.  The staging of K-step i + 1 -- buffer loads two steps ahead, the
+//    producer's BatchNorm + activation, the 3-way split, LDS stores -- is cut into units of 3-4 vector instructions and each unit is
+//    assigned to ONE of the 96 MFMA-to-MFMA gaps of step i by the constexpr tables below; every gap ends in a sched_barrier(0), so
+//    the compiler cannot move work across an MFMA and the instruction stream is the one written here (scripts/isa_gaps.py checks it).
+//  * the barrier closes gap 78; behind it the first fragments of step i + 1 are read from the other stage while the last 17 MFMAs
+//    of step i run.  Fragments live in a ring: a column tile's planes in one register set for both k halves.
+//  * the output tile is copied out of the accumulators at the end of its K loop and leaves for HBM in four slices BETWEEN the step
+//    pairs of the next tile (all CUs finish their tiles at the same time: written at once, 33 MB arrive at HBM together and the
+//    matrix pipes wait 4.5 us per tile -- measured 218 -> 183 us without the stores on 262144 x 320 -> 256).  Every step pair issues
+//    one slice of 32 stores, real or to a zero-length buffer, so that every path through the loop carries the same number of
+//    vector-memory operations and the compiler's s_waitcnt vmcnt(N) stay exact.
+// Global accesses are raw buffer loads / stores (row and k-step terms in SGPR offsets: no per-lane address arithmetic, and the
+// hardware's range check -- which includes the SGPR offset on gfx950, scripts/micro/buf_range -- zero-fills the M and K tails).
+// Measured (scripts/micro/sb3_loop.hip, MI355X): the loop alone 183 us against 142 us of bare MFMAs at the 1.73 GHz the chip holds
+// under them; the tiled kernels of pw_split.hip 287-292 us on the same product.
+#include "sb_common.h"
+#include "pw_gemm.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int S3_BM = 128, S3_BN = 256, S3_BKT = 32;
+constexpr int S3_A_PLANE = S3_BM * 32, S3_B_PLANE = S3_BN * 32;     // bf16 elements; rows of 64 bytes, 16-byte chunks swizzled by (row >> 2) & 3
+constexpr int S3_STAGE = 3 * (S3_A_PLANE + S3_B_PLANE);            // 73728 bytes
+constexpr int S3_BARG = 78;                                        // the step's barrier closes this gap
+constexpr int S3_LDS_BYTES = 2 * S3_STAGE * 2;
+
+// ---- the schedule: which gap (0 .. 95) of a K-step carries which piece of the staging of the NEXT step
+// 40 arithmetic units: pair p (0..7: two consecutive k of one row; pairs 0-3 row group 0, 4-7 row group 1) x stage s (0..4);
+// unit u = g * 20 + s * 4 + (p & 3) for row group g: stage-major inside a group, so a plane of the group is complete after 8 / 12 / 20 units
+constexpr int unit_gap(int u) { return (u * 5) / 3; }                                             // 0 .. 65
+constexpr int aw_gap(int i) { return unit_gap((i / 3) * 20 + (i % 3 == 0 ? 7 : i % 3 == 1 ? 11 : 19)) + 1; }     // LDS store of plane i % 3 of group i / 3
+constexpr int al_gap(int j) { return unit_gap((j >> 1) * 20 + 2 * (j & 1) + 1) + 1; }             // raw quad j is free after stage 0 of its two pairs
+constexpr int cl_gap(int j) { return unit_gap(23) + 2 + j; }                                     // coefficients: after the last stage-0 unit
+// the kernel planes come from L2 (491 KB per layer, always resident): ONE step ahead, in two halves of six 16-byte pieces per lane through
+// the same 24 registers -- requested 27-30 gaps (~900 cycles) in front of their LDS store (48 registers for a whole step do not fit
+// beside the tile that is on its way out)
+constexpr int bl_gap(int j) { return j < 6 ? 2 + 3 * j : 33 + 3 * (j - 6); }                       // 2 .. 17, 33 .. 48
+constexpr int bw_gap(int j) { return j < 6 ? 32 + 3 * j : 60 + 3 * (j - 6); }                      // 32 .. 47, 60 .. 75
+// fragment reads.  The MFMAs of a step run k half (2) x column tile ni (4) x row tile mi (2) x 6 products; a column tile's three planes
+// live in register set ni (both k halves), a row tile's in xa[mi][k half].  Reads 0..23 come from the stage being multiplied, in front
+// of the barrier; 24..35 from the other stage behind it (the next step's first fragments):
+//   0-2 B(0,2) | 3-5 A(0,1) | 6-8 A(1,1) | 9-11 B(0,3) | 12-14 B(1,0) | 15-17 B(1,1) | 18-20 B(1,2) | 21-23 B(1,3) | 24-26 A'(0,0) | 27-29 B'(0,0) |
+//   30-32 A'(1,0) | 33-35 B'(0,1)       (B(k half, ni), A(mi, k half))
+constexpr int fr_gap(int k) { return k < 21 ? 2 * k + 1 : k < 24 ? 2 * k + 7 : S3_BARG + 1 + (k - 24); }
+// the index whose gap is g, or -1 (every table puts at most one of its entries into a gap)
+template <class F>
+constexpr int at(F f, int n, int g) {
+  for (int i = 0; i < n; ++i)
+    if (f(i) == g) return i;
+  return -1;
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t s3_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+// ACT: DL3P_ACT_NONE / RELU / RELU6 of the prologue; PRO: the operand passes through x * scale + shift first; STATS: per-column (sum, sum^2)
+// of the outputs, one partial row per workgroup (the contract of pw_gemm_sb_kernel)
+template <int ACT, bool PRO, bool STATS>
+__global__ __launch_bounds__(256, 1) void pw_gemm_sb3_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s3_lds[];
+  unsigned short* S0 = reinterpret_cast<unsigned short*>(s3_lds);
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int wr = w >> 1, wc = w & 1;
+  const int nk = p.bsp_pitch / S3_BKT;                     // even, >= 8 (the host's routing rule)
+  const int my_tiles = (p.num_m_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int M = p.M, ldy = p.ldy;
+  const uint32_t a_bytes = ((uint32_t)(M - 1) * (uint32_t)p.lda + (uint32_t)p.K) * 4u;
+  const __amdgpu_buffer_rsrc_t rA = s3_rsrc(p.A, a_bytes), rS = s3_rsrc(p.scale, PRO ? (uint32_t)p.K * 4u : 0u),
+                               rT = s3_rsrc(p.shift, PRO ? (uint32_t)p.K * 4u : 0u),
+                               rB = s3_rsrc(p.Bsp, (uint32_t)(3 * p.bsp_plane) * 2u),
+                               rY = s3_rsrc(p.Y, ((uint32_t)(M - 1) * (uint32_t)ldy + (uint32_t)S3_BN) * 4u), rNull = s3_rsrc(p.Y, 0u);
+  const int ar = t >> 2, ac = t & 3;
+  // LDS offsets (bf16 elements): the thread's staging chunks ...
+  const int sw = (ar >> 2) & 3;                            // (the same for rows ar + 64 i)
+  const int a_lds = ar * 32 + ((ac ^ sw) * 8);             // + i * 64 * 32 + plane * A_PLANE
+  const int b_lds = 3 * S3_A_PLANE + a_lds;                // + (j & 3) * 64 * 32 + (j >> 2) * B_PLANE
+  // ... and its fragments (32x32x16: lane = row (l & 31), 8 k at chunk 2 kh + (l >> 5))
+  const int l31 = l & 31, hh5 = l >> 5, fsw = (l31 >> 2) & 3;
+  int xa_off[2], wb_off[2];
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) {
+    xa_off[kh] = (wr * 64 + l31) * 32 + (((2 * kh + hh5) ^ fsw) * 8);
+    wb_off[kh] = 3 * S3_A_PLANE + (wc * 128 + l31) * 32 + (((2 * kh + hh5) ^ fsw) * 8);
+  }
+  // global offsets (bytes)
+  uint32_t arow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) arow[i] = (uint32_t)((int)blockIdx.x * S3_BM + ar + 64 * i) * (uint32_t)p.lda * 4u + (uint32_t)ac * 32u;
+  const uint32_t a_tile_stride = gridDim.x * (uint32_t)S3_BM * (uint32_t)p.lda * 4u;
+  const uint32_t cvo = (uint32_t)ac * 32u;
+  const uint32_t blane = (uint32_t)ar * (uint32_t)p.bsp_pitch * 2u + (uint32_t)ac * 16u;
+  const uint32_t b_plane = (uint32_t)p.bsp_plane * 2u, b_rows = 64u * (uint32_t)p.bsp_pitch * 2u;
+  uint4 ra[4];                  // raw quads: [row group * 2 + half]
+  uint4 cs[2], ct[2];           // prologue coefficients of the thread's 8 k
+  u32x4v rb[6];                 // kernel planes: pieces j and j + 6 share a register quad
+  float v0[8], v1[8], r0[8], r1[8];
+  uint32_t hp[8], mp[8], lp[8];
+  // clamp bounds of the prologue; a row beyond M is clamped to [0, 0]: its operand row is exactly zero, whatever shift says
+  constexpr float LO = ACT == DL3P_ACT_NONE ? -DL3P_INF : 0.f, HI = ACT == DL3P_ACT_RELU6 ? 6.f : DL3P_INF;
+  float lo[2] = {LO, LO}, hi[2] = {HI, HI};
+
+  int lkt = 0;                  // k-step of the NEXT global request; arow[] holds its tile
+  int skt = 1 % nk, srem = M - (int)blockIdx.x * S3_BM;     // k-step / rows left (from the tile's first row) of the data being STAGED
+  const int tile_rows = (int)gridDim.x * S3_BM;
+  auto advance = [&]() __attribute__((always_inline)) {
+    ++lkt;
+    if (lkt == nk) { lkt = 0; arow[0] += a_tile_stride; arow[1] += a_tile_stride; }
+    ++skt;
+    if (skt == nk) { skt = 0; srem -= tile_rows; }
+  };
+  auto row_bounds = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool ok = ar + 64 * i < srem;
+      lo[i] = ok ? LO : 0.f;
+      hi[i] = ok ? HI : 0.f;
+    }
+  };
+  auto load_a = [&](int j) __attribute__((always_inline)) {
+    ra[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rA, arow[j >> 1] + 16 * (j & 1), lkt * (S3_BKT * 4), 0));
+  };
+  auto load_c = [&](int j) __attribute__((always_inline)) {
+    if (!PRO) return;
+    if (j < 2) cs[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rS, cvo + 16 * (j & 1), lkt * (S3_BKT * 4), 0));
+    else ct[j - 2] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rT, cvo + 16 * (j & 1), lkt * (S3_BKT * 4), 0));
+  };
+  auto load_b = [&](int j) __attribute__((always_inline)) {
+    rb[j % 6] = __builtin_amdgcn_raw_buffer_load_b128(rB, blane + (uint32_t)skt * (S3_BKT * 2), (j >> 2) * b_plane + (j & 3) * b_rows, 0);
+  };
+  auto elem = [](const uint4& q, int e) __attribute__((always_inline)) {
+    return __builtin_bit_cast(float, e == 0 ? q.x : e == 1 ? q.y : e == 2 ? q.z : q.w);
+  };
+  // one arithmetic unit of pair p, stage s
+  auto unit = [&](auto pc, auto sc) __attribute__((always_inline)) {
+    constexpr int pp = decltype(pc)::value, s = decltype(sc)::value;
+    constexpr int q = (pp >> 2) * 2 + ((pp & 3) >> 1), e = (pp & 1) * 2, h = (pp & 3) >> 1, g = pp >> 2;
+    if constexpr (s == 0) {
+      float x = elem(ra[q], e), y = elem(ra[q], e + 1);
+      if (PRO) {
+        x = __builtin_fmaf(x, elem(cs[h], e), elem(ct[h], e));
+        y = __builtin_fmaf(y, elem(cs[h], e + 1), elem(ct[h], e + 1));
+      }
+      v0[pp] = __builtin_amdgcn_fmed3f(x, lo[g], hi[g]);
+      v1[pp] = __builtin_amdgcn_fmed3f(y, lo[g], hi[g]);
+    } else if constexpr (s == 1) {
+      const bf16x2v hv = {(__bf16)v0[pp], (__bf16)v1[pp]};
+      hp[pp] = __builtin_bit_cast(uint32_t, hv);
+      r0[pp] = __builtin_bit_cast(float, hp[pp] << 16);
+      r1[pp] = __builtin_bit_cast(float, hp[pp] & 0xffff0000u);
+    } else if constexpr (s == 2) {
+      r0[pp] = v0[pp] - r0[pp];
+      r1[pp] = v1[pp] - r1[pp];
+      const bf16x2v mv = {(__bf16)r0[pp], (__bf16)r1[pp]};
+      mp[pp] = __builtin_bit_cast(uint32_t, mv);
+    } else if constexpr (s == 3) {
+      v0[pp] = r0[pp] - __builtin_bit_cast(float, mp[pp] << 16);
+      v1[pp] = r1[pp] - __builtin_bit_cast(float, mp[pp] & 0xffff0000u);
+    } else {
+      const bf16x2v lv = {(__bf16)v0[pp], (__bf16)v1[pp]};
+      lp[pp] = __builtin_bit_cast(uint32_t, lv);
+    }
+  };
+  auto write_a = [&](unsigned short* buf, int g, int pl) __attribute__((always_inline)) {
+    const uint32_t* src = pl == 0 ? hp : pl == 1 ? mp : lp;
+    const uint4 val = {src[4 * g], src[4 * g + 1], src[4 * g + 2], src[4 * g + 3]};
+    *reinterpret_cast<uint4*>(buf + a_lds + g * (64 * 32) + pl * S3_A_PLANE) = val;
+  };
+  auto write_b = [&](unsigned short* buf, int j) __attribute__((always_inline)) {
+    *reinterpret_cast<u32x4v*>(buf + b_lds + (j & 3) * (64 * 32) + (j >> 2) * S3_B_PLANE) = rb[j % 6];
+  };
+
+  f32x16 acc[2][4], out[2][4];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { acc[mi][ni][e] = 0.f; out[mi][ni][e] = 0.f; }
+  s16x8 xa[2][2][3], wb[4][3];          // A: [row tile][k half][plane]; B: [column tile = register set][plane]
+
+  auto frag_read = [&](const unsigned short* cur, const unsigned short* nxt, auto kc) __attribute__((always_inline)) {
+    constexpr int k = decltype(kc)::value, grp = k / 3, pl = k % 3;
+    // grp: 0 B(0,2) 1 A(0,1) 2 A(1,1) 3 B(0,3) 4..7 B(1,0..3) 8 A'(0,0) 9 B'(0,0) 10 A'(1,0) 11 B'(0,1)
+    if constexpr (grp == 0) wb[2][pl] = *reinterpret_cast<const s16x8*>(cur + pl * S3_B_PLANE + wb_off[0] + 2 * 32 * 32);
+    else if constexpr (grp == 1) xa[0][1][pl] = *reinterpret_cast<const s16x8*>(cur + pl * S3_A_PLANE + xa_off[1]);
+    else if constexpr (grp == 2) xa[1][1][pl] = *reinterpret_cast<const s16x8*>(cur + pl * S3_A_PLANE + xa_off[1] + 32 * 32);
+    else if constexpr (grp == 3) wb[3][pl] = *reinterpret_cast<const s16x8*>(cur + pl * S3_B_PLANE + wb_off[0] + 3 * 32 * 32);
+    else if constexpr (grp < 8) wb[grp - 4][pl] = *reinterpret_cast<const s16x8*>(cur + pl * S3_B_PLANE + wb_off[1] + (grp - 4) * 32 * 32);
+    else if constexpr (grp == 8) xa[0][0][pl] = *reinterpret_cast<const s16x8*>(nxt + pl * S3_A_PLANE + xa_off[0]);
+    else if constexpr (grp == 9) wb[0][pl] = *reinterpret_cast<const s16x8*>(nxt + pl * S3_B_PLANE + wb_off[0]);
+    else if constexpr (grp == 10) xa[1][0][pl] = *reinterpret_cast<const s16x8*>(nxt + pl * S3_A_PLANE + xa_off[0] + 32 * 32);
+    else wb[1][pl] = *reinterpret_cast<const s16x8*>(nxt + pl * S3_B_PLANE + wb_off[0] + 32 * 32);
+  };
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  // ---- pipeline head: step 0 staged into stage 0, the operand rows of step 1 requested
+  {
+    row_bounds();
+    skt = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { load_a(j); load_c(j); }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) load_b(6 * h + j);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) write_b(S0, 6 * h + j);
+    }
+    skt = 1;
+    static_for<5>([&](auto sc) { static_for<8>([&](auto pc) { unit(pc, sc); }); });
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) write_a(S0, g, pl);
+    ++lkt;                       // (nk >= 8: no wrap here; skt / srem already describe step 1)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { load_a(j); load_c(j); }
+    ++lkt;
+    lds_barrier();
+    static_for<12>([&](auto kc) { frag_read(S0, S0, std::integral_constant<int, 24 + decltype(kc)::value>{}); });
+  }
+
+  auto step = [&](auto par) __attribute__((always_inline)) {
+    constexpr int P = decltype(par)::value;
+    const unsigned short* cur = S0 + P * S3_STAGE;
+    unsigned short* nxt = S0 + (P ^ 1) * S3_STAGE;
+    row_bounds();
+    static_for<96>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      constexpr int kh = g / 48, rem = g % 48, ni = rem / 12, mi = (rem % 12) / 6, pr = rem % 6;
+      constexpr int WB[6] = {2, 0, 1, 1, 0, 0}, XA[6] = {0, 2, 1, 0, 1, 0};          // smallest terms first
+      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[mi][kh][XA[pr]], wb[ni][WB[pr]], acc[mi][ni], 0, 0, 0);
+      // ---- the fillers of this gap
+      constexpr int fr = at(fr_gap, 36, g), u = at(unit_gap, 40, g), aw = at(aw_gap, 6, g), bw = at(bw_gap, 12, g), al = at(al_gap, 4, g),
+                    cl = at(cl_gap, 4, g), bl = at(bl_gap, 12, g);
+      if constexpr (g == S3_BARG) lds_barrier();
+      if constexpr (fr >= 0) frag_read(cur, nxt, std::integral_constant<int, (fr >= 0 ? fr : 0)>{});
+      if constexpr (u >= 0) {
+        constexpr int uu = u >= 0 ? u : 0, grp = uu / 20, s = (uu % 20) / 4, pp = grp * 4 + (uu & 3);
+        unit(std::integral_constant<int, pp>{}, std::integral_constant<int, s>{});
+      }
+      if constexpr (aw >= 0) write_a(nxt, (aw >= 0 ? aw : 0) / 3, (aw >= 0 ? aw : 0) % 3);
+      if constexpr (bw >= 0) write_b(nxt, bw >= 0 ? bw : 0);
+      if constexpr (al >= 0) load_a(al >= 0 ? al : 0);
+      if constexpr (cl >= 0) load_c(cl >= 0 ? cl : 0);
+      if constexpr (bl >= 0) load_b(bl >= 0 ? bl : 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    advance();
+  };
+
+  // ---- the output tile: lane = output channel (l & 31), register e = pixel row (e & 3) + 8 (e >> 2) + 4 (l >> 5) of a 32-row tile
+  const uint32_t yv = ((uint32_t)(wr * 64 + 4 * hh5) * (uint32_t)ldy + (uint32_t)(wc * 128 + l31)) * 4u;
+  float bias_v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) bias_v[ni] = p.bias[wc * 128 + ni * 32 + l31];
+  }
+  float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_q[4] = {0.f, 0.f, 0.f, 0.f};
+  // slice ni of the tile held in out[][]: 32 stores (real: to rY; otherwise to the zero-length buffer, dropped by the range check)
+  auto slice = [&](auto nic, const __amdgpu_buffer_rsrc_t& r, uint32_t out_m0, bool real) __attribute__((always_inline)) {
+    constexpr int ni = decltype(nic)::value;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float val = out[mi][ni][e] + bias_v[ni];
+        const uint32_t row = out_m0 + mi * 32 + (e & 3) + 8 * (e >> 2);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), r, yv + ni * 128, row * (uint32_t)ldy * 4u, 0);
+        if (STATS && real) { st_s[ni] += val; st_q[ni] = __builtin_fmaf(val, val, st_q[ni]); }
+      }
+  };
+  auto slice_any = [&](int s, const __amdgpu_buffer_rsrc_t& r, uint32_t out_m0, bool real) __attribute__((always_inline)) {
+    if (s == 0) slice(std::integral_constant<int, 0>{}, r, out_m0, real);
+    else if (s == 1) slice(std::integral_constant<int, 1>{}, r, out_m0, real);
+    else if (s == 2) slice(std::integral_constant<int, 2>{}, r, out_m0, real);
+    else slice(std::integral_constant<int, 3>{}, r, out_m0, real);
+  };
+
+  uint32_t out_m0 = 0;
+  bool have_out = false;
+  for (int tile = 0; tile < my_tiles; ++tile) {
+    for (int kp = 0; kp < nk; kp += 2) {
+      step(I0{});
+      step(I1{});
+      const bool real = have_out && kp < 8;
+      slice_any((kp >> 1) & 3, real ? rY : rNull, out_m0, real);
+    }
+    // the finished tile moves out of the accumulators
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        out[mi][ni] = acc[mi][ni];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+      }
+    out_m0 = (uint32_t)((int)blockIdx.x + tile * (int)gridDim.x) * S3_BM;
+    have_out = true;
+  }
+  if (have_out) {
+    slice(std::integral_constant<int, 0>{}, rY, out_m0, true);
+    slice(std::integral_constant<int, 1>{}, rY, out_m0, true);
+    slice(std::integral_constant<int, 2>{}, rY, out_m0, true);
+    slice(std::integral_constant<int, 3>{}, rY, out_m0, true);
+  }
+  if (STATS) {
+    // a column's two half-wave lanes, then the two wave rows through LDS (the operand stages are done with)
+    float* red = reinterpret_cast<float*>(s3_lds);          // [which][wr][256]
+    lds_barrier();
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      float s1 = st_s[ni], s2 = st_q[ni];
+      s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+      if (hh5 == 0) {
+        red[(0 * 2 + wr) * S3_BN + wc * 128 + ni * 32 + l31] = s1;
+        red[(1 * 2 + wr) * S3_BN + wc * 128 + ni * 32 + l31] = s2;
+      }
+    }
+    lds_barrier();
+    if (p.partials) {
+      for (int i = t; i < 2 * S3_BN; i += 256) {
+        const int which = i / S3_BN, nn = i - which * S3_BN;
+        p.partials[((size_t)blockIdx.x * 2 + which) * p.N + nn] = red[(which * 2 + 0) * S3_BN + nn] + red[(which * 2 + 1) * S3_BN + nn];
+      }
+    }
+  }
+}
+
+template <int ACT, bool PRO>
+void launch_sb3_act(const GemmParams& p, bool stats, int grid, hipStream_t st) {
+  if (stats) {
+    static bool once = (hipFuncSetAttribute((const void*)pw_gemm_sb3_kernel<ACT, PRO, true>, hipFuncAttributeMaxDynamicSharedMemorySize, S3_LDS_BYTES), true);
+    (void)once;
+    dl3p_launch(pw_gemm_sb3_kernel<ACT, PRO, true>, dim3(grid), dim3(256), (size_t)S3_LDS_BYTES, st, p);
+  } else {
+    static bool once = (hipFuncSetAttribute((const void*)pw_gemm_sb3_kernel<ACT, PRO, false>, hipFuncAttributeMaxDynamicSharedMemorySize, S3_LDS_BYTES), true);
+    (void)once;
+    dl3p_launch(pw_gemm_sb3_kernel<ACT, PRO, false>, dim3(grid), dim3(256), (size_t)S3_LDS_BYTES, st, p);
+  }
+}
+}  // namespace
+
+// role 0 / 1 (forward without / with statistics), (M, K, N) as launched, pitch = row length of the pre-split kernel planes
+bool dl3p_sb3_supported(int role, int M, int K, int N, int pitch, int act, bool has_scale, bool accumulate, bool bias) {
+  if (role < 0 || role > 1 || N != S3_BN || K % 4 || pitch % 64 || pitch < 256 || pitch < K || M < 2 * S3_BM) return false;
+  if (!(act == DL3P_ACT_NONE || act == DL3P_ACT_RELU || act == DL3P_ACT_RELU6) || accumulate) return false;
+  if (!has_scale && K % 32) return false;                 // (the K tail is zeroed by the out-of-range prologue coefficients)
+  if (role == 1 && bias) return false;                    // (padding rows of the last tile are exact zeros only without a bias)
+  return true;
+}
+int dl3p_sb3_grid(int M) {
+  const int mt = ceil_div(M, S3_BM);
+  return mt < DL3P_NUM_CUS ? mt : DL3P_NUM_CUS;
+}
+
+bool dl3p_launch_gemm_sb3(GemmParams p, bool stats, int grid, hipStream_t st) {
+  p.num_m_tiles = ceil_div(p.M, S3_BM);
+  const bool pro = p.scale != nullptr;
+#define S3_CASE(A) \
+  if (p.act == A) { if (pro) launch_sb3_act<A, true>(p, stats, grid, st); else launch_sb3_act<A, false>(p, stats, grid, st); return true; }
+  S3_CASE(DL3P_ACT_NONE) S3_CASE(DL3P_ACT_RELU) S3_CASE(DL3P_ACT_RELU6)
+#undef S3_CASE
+  return false;
+}

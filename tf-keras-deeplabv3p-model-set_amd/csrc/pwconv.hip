@@ -639,6 +639,7 @@ static int g_splitk_force = -1;        // "splitk": -1 the rule, 0 never, S > 0 
 static int g_sbw_force_tile = -1, g_sbw_force_pc = 0;      // "split_wgrad_tile" (0..3, -1 none) / "split_wgrad_per_cu": pin its plan (and bypass the verdicts)
 static int g_sb_pipe = -1;      // dl3p_set_option("sb_pipe", 0 | 1): the producer / consumer form of the split kernel (default DL3P_SB_PIPE or 0)
 static int g_sb_force_wm = 0, g_sb_force_nt = 0;      // dl3p_set_option("sb_wm" / "sb_nt"): pin the split kernel's wide-tile family (gemm_plan_sb)
+static int g_sb3 = -1;        // dl3p_set_option("sb3", 0 | 1 | -1): the pinned-schedule split forward (pw_split3.hip) never / wherever it serves the shape / by rule (DL3P_SB3)
 static int g_sb_rs = -1;      // dl3p_set_option("sb_rs", 0 | 1 | -1): the row-stationary split kernel (pw_split_rs.hip) never / wherever it serves the shape / by rule (DL3P_SB_RS)
 extern int dl3p_bf16_force_kg;      // pw_bf16.hip
 static int g_conv_sb = -1;    // dl3p_set_option("conv_sb", 0 | 1 | 2 | -1): dense convs on the split kernels never / by rule / wherever supported / default (DL3P_CONV_SB, else 1)
@@ -666,6 +667,7 @@ extern "C" int dl3p_set_option(const char* name, int value) {
   if (!strcmp(name, "splitk")) { g_splitk_force = value; return DL3P_OK; }
   if (!strcmp(name, "sb_wm")) { g_sb_force_wm = (value >= -1 && value <= 2) ? value : 0; return DL3P_OK; }    // -1: never wide
   if (!strcmp(name, "sb_rs")) { g_sb_rs = value < 0 ? -1 : (value ? 1 : 0); return DL3P_OK; }
+  if (!strcmp(name, "sb3")) { g_sb3 = value < 0 ? -1 : (value ? 1 : 0); return DL3P_OK; }
   if (!strcmp(name, "bf16_kg")) { dl3p_bf16_force_kg = (value == 0 || value == 1 || value == 2 || value == 4) ? value : -1; return DL3P_OK; }
   if (!strcmp(name, "conv_sb")) { g_conv_sb = (value >= 0 && value <= 2) ? value : -1; return DL3P_OK; }
   if (!strcmp(name, "sb_nt")) { g_sb_force_nt = (value == 8 || value == 12 || value == 16) ? value : 0; return DL3P_OK; }
@@ -688,6 +690,7 @@ extern "C" int dl3p_get_option(const char* name) {
   if (!strcmp(name, "split_wgrad")) return g_split_wgrad;
   if (!strcmp(name, "conv_sb")) return g_conv_sb;
   if (!strcmp(name, "sb_rs")) return g_sb_rs;
+  if (!strcmp(name, "sb3")) return g_sb3;
   if (!strcmp(name, "sb_pipe")) return g_sb_pipe;
   if (!strcmp(name, "splitk")) return g_splitk_force;
   return INT_MIN;
@@ -1221,6 +1224,23 @@ static bool sb_rs_route(int role, int M, int K, int N) {
   return g_sb_rs == 1;
 }
 void dl3p_launch_gemm_sbp(const GemmParams& p, bool stats, bool bnb, int nt, int mi, dim3 grid, hipStream_t st);
+// the pinned-schedule form (pw_split3.hip; gemm_plan_sb reports it as wm = 4): forwards onto 256 columns from 65536 rows up whose
+// reduction is 8, 10, 12 ... K-steps long.  dl3p_set_option("sb3", 1) takes it wherever it is supported, 0 never, -1 (default) by
+// the rule -- unless the measured table knows the launch
+bool dl3p_sb3_supported(int role, int M, int K, int N, int pitch, int act, bool has_scale, bool accumulate, bool bias);
+int dl3p_sb3_grid(int M);
+bool dl3p_launch_gemm_sb3(GemmParams p, bool stats, int grid, hipStream_t st);
+static thread_local int t_sb3_veto = 0;        // set while a launch whose prologue / epilogue the form does not serve is planned again
+static bool sb3_route(int role, int M, int K, int N) {
+  if (g_sb3 < 0) { static const int env = getenv("DL3P_SB3") ? atoi(getenv("DL3P_SB3")) : -1; if (env >= 0) g_sb3 = env; }
+  const int pitch = (K + 31) / 32 * 32;
+  if (t_sb3_veto || g_sb3 == 0 || !dl3p_sb3_supported(role, M, K, N, pitch, DL3P_ACT_NONE, true, false, false)) return false;
+  if (g_sb3 == 1) return true;
+  if (g_sb_pipe < 0) g_sb_pipe = getenv("DL3P_SB_PIPE") ? atoi(getenv("DL3P_SB_PIPE")) : 0;
+  if (g_sb_force_wm != 0 || g_sb_pipe > 0 || g_gemm_force_nt || g_gemm_force_mi || g_sb_rs == 1) return false;       // another form is pinned
+  if (gemm_tuned_lookup(role + 5, M, K, N)) return false;
+  return M >= 65536;
+}
 
 
 // tile choice of a split-bf16 launch.  Wide tiles (one workgroup per CU: 128 or 256 rows x up to 256 columns, the A tile split
@@ -1229,6 +1249,10 @@ static void gemm_plan_sb(int role, int M, int K, int N, int* nt, int* gx, int* g
   int force_mi = 0, force_pc = 0;
   *nt = pick_nt(N, M);
   *wm = 1;
+  if (sb3_route(role, M, K, N)) {
+    *wm = 4; *nt = 16; *mi = 2; *gx = dl3p_sb3_grid(M); *gy = 1; *num_m_tiles = ceil_div(M, 128);
+    return;
+  }
   if (sb_rs_route(role, M, K, N)) {
     *wm = 3; *nt = 2; *mi = 1; *gx = dl3p_sb_rs_grid(M); *gy = 1; *num_m_tiles = ceil_div(M, 64);
     return;
@@ -1337,11 +1361,17 @@ extern "C" int dl3p_pwconv_fwd_sb(const float* x, int ldx, const float* in_scale
   p.M = M; p.K = K; p.N = N;
   int nt, gx, gy, mi, wm;
   gemm_plan_sb(stat_partials ? 1 : 0, M, K, N, &nt, &gx, &gy, &p.num_m_tiles, &mi, &wm);
+  if (wm == 4 && !dl3p_sb3_supported(stat_partials ? 1 : 0, M, K, N, pitch, in_act, in_scale != nullptr, false, bias != nullptr)) {
+    t_sb3_veto = 1;          // (an activation / bias / pitch the pinned form does not serve: the tiled kernels take the launch)
+    gemm_plan_sb(stat_partials ? 1 : 0, M, K, N, &nt, &gx, &gy, &p.num_m_tiles, &mi, &wm);
+    t_sb3_veto = 0;
+  }
 #ifdef DL3P_SB_ABLATE
   { const char* e = getenv("DL3P_SB_ABLATE"); p.stagger = e ? atoi(e) : 0; if (p.stagger == 100 && stat_partials) p.B = stat_partials + (size_t)DL3P_MAX_STAT_ROWS * 2 * N; }      // (ablation build: stamps behind the partial rows)
 #endif
   if (rows_out) *rows_out = gx;
-  if (wm == 3) DL3P_CHECK_ARG(dl3p_launch_gemm_sbr(p, stat_partials ? 1 : 0, gx, (hipStream_t)stream), "%s: no row-stationary instantiation for K=%d", fn, K);
+  if (wm == 4) DL3P_CHECK_ARG(dl3p_launch_gemm_sb3(p, stat_partials != nullptr, gx, (hipStream_t)stream), "%s: no pinned-schedule instantiation for activation %d", fn, in_act);
+  else if (wm == 3) DL3P_CHECK_ARG(dl3p_launch_gemm_sbr(p, stat_partials ? 1 : 0, gx, (hipStream_t)stream), "%s: no row-stationary instantiation for K=%d", fn, K);
   else if (wm == 0) dl3p_launch_gemm_sbp(p, stat_partials != nullptr, false, nt, mi, dim3(gx, gy), (hipStream_t)stream);
   else dl3p_launch_gemm_sb(p, stat_partials != nullptr, false, false, nt, mi, wm, dim3(gx, gy), (hipStream_t)stream);
   DL3P_CHECK_LAUNCH(fn);

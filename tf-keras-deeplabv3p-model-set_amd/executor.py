@@ -421,7 +421,7 @@ class Executor:
         self.L.set_option(b'split_wgrad', self._split_wgrad)
         # ... and the other process-wide knobs that decide how many slabs / partial rows a traced launch writes: recorded now, pinned
         # again before every eager replay (_pin_options; a captured graph carries its launches' grids with it)
-        self._pinned = {k: self.L.get_option(k) for k in (b'conv_sb', b'sb_rs', b'sb_pipe', b'splitk')}
+        self._pinned = {k: self.L.get_option(k) for k in (b'conv_sb', b'sb_rs', b'sb_pipe', b'splitk', b'sb3')}
         self._pinned_irb = tuple(self.L.irb_get_plan(i) for i in range(4))
         self._find_irb()
         self._alloc()
