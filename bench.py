@@ -424,13 +424,19 @@ def main():
             M, K, Nc = N * op.Ho * op.Wo, op.cin, op.cout
             tf = 2.0 * M * K * Nc / (ms * 1e-3) / 1e12
             if model._store.Sb is not None and op in model._store.sb_fwd:
+                # which split kernel the planner gives this launch (family 3: {3, nt, mi, wm, ...}; wm 4 = the pinned-schedule form)
+                import ctypes as _ct
+                q = (_ct.c_int * 6)()
+                importlib.import_module(PKG + '._lib').lib().gemm_plan_query(6, M, K, Nc, q)
+                sb_kernel, sb_mfma = (('pw_gemm_sb3_kernel', 'v_mfma_f32_32x32x16_bf16') if q[3] == 4 else
+                                      ('pw_gemm_sb_kernel', 'v_mfma_f32_16x16x32_bf16'))
                 # split-bf16 kernel: six bf16 x bf16 products per fp32 product on v_mfma_f32_16x16x32_bf16, priced against the
                 # dense bf16 peak (the guide's 2.5 PFLOP/s; 1.5 PFLOP/s is what the pipe sustains on this instruction mix)
                 out['roofline_mfma'] = {'bound': 'mfma', 'achieved': round(6 * tf, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                                        'frac': round(6 * tf / MFMA_BF16_PEAK_TFLOPS, 4), 'kernel': 'pw_gemm_sb_kernel (%s forward)' % op.name,
+                                        'frac': round(6 * tf / MFMA_BF16_PEAK_TFLOPS, 4), 'kernel': '%s (%s forward)' % (sb_kernel, op.name),
                                         'avg_us': round(ms * 1e3, 2), 'flops': int(12.0 * M * K * Nc),
                                         'fp32_equivalent_tflops': round(tf, 2), 'vs_fp32_mfma_peak': round(tf / MFMA_F32_PEAK_TFLOPS, 4),
-                                        'shape': 'M=%d K=%d N=%d, fp32 operands split into 3 bf16 pieces, 6 products (v_mfma_f32_16x16x32_bf16)' % (M, K, Nc)}
+                                        'shape': 'M=%d K=%d N=%d, fp32 operands split into 3 bf16 pieces, 6 products (%s)' % (M, K, Nc, sb_mfma)}
             else:
                 out['roofline_mfma'] = {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                         'frac': round(tf / MFMA_F32_PEAK_TFLOPS, 4), 'kernel': 'pw_gemm_kernel (%s forward)' % op.name,

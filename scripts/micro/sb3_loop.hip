@@ -42,10 +42,14 @@ __device__ __forceinline__ void static_for(F&& f) {
 // 40 arithmetic units: pair p (0..7: two consecutive k of one row; pairs 0-3 row group 0, 4-7 row group 1) x stage s (0..4)
 //   unit u = g * 20 + s * 4 + (p & 3) for group g: stage-major inside a row group, so a plane of the group is complete after 8 / 12 / 20 units
 __host__ __device__ constexpr int unit_gap(int u) { return (u * 5) / 3; }                   // 0 .. 65
-__host__ __device__ constexpr int aw_gap(int g, int pl) { return unit_gap(g * 20 + (pl == 0 ? 7 : pl == 1 ? 11 : 19)) + 1; }
+// unit order: stage 0 of all eight pairs first (units 0..7: the raw registers are free early and the next requests leave early), then
+// row group 0 stages 1..4 (units 8..23, stage-major), then row group 1 (24..39)
+__host__ __device__ constexpr int unit_pair(int u) { return u < 8 ? u : (u < 24 ? (u - 8) & 3 : 4 + ((u - 24) & 3)); }
+__host__ __device__ constexpr int unit_stage(int u) { return u < 8 ? 0 : (u < 24 ? 1 + (u - 8) / 4 : 1 + (u - 24) / 4); }
+__host__ __device__ constexpr int aw_gap(int g, int pl) { return unit_gap(8 + g * 16 + (pl == 0 ? 3 : pl == 1 ? 7 : 15)) + 1; }
 __host__ __device__ constexpr int aw_gap_i(int i) { return aw_gap(i / 3, i % 3); }
-__host__ __device__ constexpr int al_gap(int j) { return unit_gap((j >> 1) * 20 + 2 * (j & 1) + 1) + 1; }   // raw quad j is free after stage 0 of its two pairs
-__host__ __device__ constexpr int cl_gap(int j) { return unit_gap(23) + 2 + j; }           // coefficients: after the last stage-0 unit
+__host__ __device__ constexpr int al_gap(int j) { return unit_gap(2 * j + 1) + 1; }          // raw quad j is free after stage 0 of pairs 2j, 2j + 1: gaps 2, 6, 9, 12
+__host__ __device__ constexpr int cl_gap(int j) { return 88 + j; }                          // prologue coefficients of the NEXT step's staging, from LDS
 __host__ __device__ constexpr int bw_gap(int j) { return 5 * j + 4; }                       // 4 .. 59
 __host__ __device__ constexpr int bl_gap(int j) { return 5 * j + 8; }
 // fragment reads.  The MFMAs of a step run k half (2) x column tile ni (4) x row tile mi (2) x 6 products; a column tile's three planes
@@ -109,16 +113,22 @@ __global__ __launch_bounds__(256, 1) void sb3(const float* __restrict__ A, int l
   uint32_t hp[8], mp[8], lp[8];
 
   int lkt = 0;                  // k-step of the NEXT global request; arow[] holds its tile
+  int ckt = 0;                  // k-step whose coefficients the next load_c fetches
   auto advance = [&]() __attribute__((always_inline)) {
     ++lkt;
     if (lkt == nk) { lkt = 0; arow[0] += a_tile_stride; arow[1] += a_tile_stride; }
   };
+  auto advance_c = [&]() __attribute__((always_inline)) { ++ckt; if (ckt == nk) ckt = 0; };
   auto load_a = [&](int j) __attribute__((always_inline)) {
     ra[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rA, arow[j >> 1] + 16 * (j & 1), lkt * (BKT * 4), 0));
   };
+  // prologue coefficients: both vectors in LDS behind the operand stages (copied once), read per step for the k-step ckt
+  float* Cs = reinterpret_cast<float*>(lds + 2 * STAGE * 2);
+  for (int i = t; i < K; i += 256) { Cs[i] = ps[i]; Cs[K + i] = pt[i]; }
   auto load_c = [&](int j) __attribute__((always_inline)) {
-    if (j < 2) cs[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rS, cvo + 16 * (j & 1), lkt * (BKT * 4), 0));
-    else ct[j - 2] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rT, cvo + 16 * (j & 1), lkt * (BKT * 4), 0));
+    const float* src = Cs + (j < 2 ? 0 : K) + ckt * BKT + ac * 8 + 4 * (j & 1);
+    if (j < 2) cs[j] = *reinterpret_cast<const uint4*>(src);
+    else ct[j - 2] = *reinterpret_cast<const uint4*>(src);
   };
   auto load_b = [&](int j) __attribute__((always_inline)) {
     rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rB, blane + (uint32_t)lkt * (BKT * 2), (j >> 2) * b_plane + (j & 3) * b_rows, 0);
@@ -190,8 +200,10 @@ __global__ __launch_bounds__(256, 1) void sb3(const float* __restrict__ A, int l
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   // ---- pipeline head: step 0 staged into stage 0, step 1 requested
+  __syncthreads();
 #pragma unroll
   for (int j = 0; j < 4; ++j) { load_a(j); load_c(j); }
+  advance_c();
 #pragma unroll
   for (int j = 0; j < 12; ++j) load_b(j);
   static_for<5>([&](auto sc) { static_for<8>([&](auto pc) { unit(pc, sc); }); });
@@ -204,6 +216,7 @@ __global__ __launch_bounds__(256, 1) void sb3(const float* __restrict__ A, int l
   advance();
 #pragma unroll
   for (int j = 0; j < 4; ++j) { load_a(j); load_c(j); }
+  advance_c();
 #pragma unroll
   for (int j = 0; j < 12; ++j) load_b(j);
   advance();
@@ -227,8 +240,8 @@ __global__ __launch_bounds__(256, 1) void sb3(const float* __restrict__ A, int l
       if constexpr (g == BARG) { if (!(FLAGS & 32)) lds_barrier(); }
       if constexpr (do_frag && fr >= 0) frag_read(cur, nxt, std::integral_constant<int, (fr >= 0 ? fr : 0)>{});
       if constexpr (do_stage && u >= 0) {
-        constexpr int uu = u >= 0 ? u : 0, grp = uu / 20, s = (uu % 20) / 4, p = grp * 4 + (uu & 3);
-        unit(std::integral_constant<int, p>{}, std::integral_constant<int, s>{});
+        constexpr int uu = u >= 0 ? u : 0;
+        unit(std::integral_constant<int, unit_pair(uu)>{}, std::integral_constant<int, unit_stage(uu)>{});
       }
       if constexpr (do_stage && aw >= 0) write_a(nxt, (aw >= 0 ? aw : 0) / 3, (aw >= 0 ? aw : 0) % 3);
       if constexpr (do_stage && bw >= 0) write_b(nxt, bw >= 0 ? bw : 0);
@@ -238,6 +251,7 @@ __global__ __launch_bounds__(256, 1) void sb3(const float* __restrict__ A, int l
       FENCE();
     });
     advance();
+    advance_c();
   };
   const uint32_t yv = (uint32_t)((wr * 64 + 4 * hh5) * N + wc * 128 + l31) * 4u;
   for (int tile = 0; tile < my_tiles; ++tile) {
@@ -286,11 +300,15 @@ template <int FLAGS>
 static float run(const float* A, const float* ps, const float* pt, const unsigned short* B, float* Y, int M, int K, int N, const char* name) {
   const int mt = (M + BM - 1) / BM;
   const int gx = mt < 256 ? mt : 256;
-  const int ldsb = 2 * STAGE * 2;
+  const int ldsb = 2 * STAGE * 2 + 2 * K * 4;
   hipFuncSetAttribute((const void*)sb3<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float best = 1e9f;
+  static char* flush = nullptr;
+  static const bool cold = getenv("SB3_COLD") != nullptr;
+  if (cold && !flush) hipMalloc(&flush, (size_t)512 << 20);
   for (int r = 0; r < 6; ++r) {
+    if (cold) hipMemsetAsync(flush, r, (size_t)512 << 20, 0);
     hipEventRecord(e0);
     hipLaunchKernelGGL((sb3<FLAGS>), dim3(gx), dim3(256), ldsb, 0, A, K, ps, pt, B, Y, M, K, N, mt);
     hipEventRecord(e1); hipEventSynchronize(e1);

@@ -10,13 +10,11 @@
 //    producer's BatchNorm + activation, the 3-way split, LDS stores -- is cut into units of 3-4 vector instructions and each unit is
 //    assigned to ONE of the 96 MFMA-to-MFMA gaps of step i by the constexpr tables below; every gap ends in a sched_barrier(0), so
 //    the compiler cannot move work across an MFMA and the instruction stream is the one written here (scripts/isa_gaps.py checks it).
-//  * the barrier closes gap 78; behind it the first fragments of step i + 1 are read from the other stage while the last 17 MFMAs
+//  * the barrier closes gap 70; behind it the first fragments of step i + 1 are read from the other stage while the last 25 MFMAs
 //    of step i run.  Fragments live in a ring: a column tile's planes in one register set for both k halves.
-//  * the output tile is copied out of the accumulators at the end of its K loop and leaves for HBM in four slices BETWEEN the step
-//    pairs of the next tile (all CUs finish their tiles at the same time: written at once, 33 MB arrive at HBM together and the
-//    matrix pipes wait 4.5 us per tile -- measured 218 -> 183 us without the stores on 262144 x 320 -> 256).  Every step pair issues
-//    one slice of 32 stores, real or to a zero-length buffer, so that every path through the loop carries the same number of
-//    vector-memory operations and the compiler's s_waitcnt vmcnt(N) stay exact.
+//  * the output tile leaves at the end of its K loop (128 row stores per wave).  A form that moved the tile into spare registers and
+//    stored it in four slices between the step pairs of the next tile was built and measured SLOWER (252-264 against 242-251 us on
+//    262144 x 304 -> 256): the vector-memory counter completes in issue order, so every load issued behind a store waits for it.
 // Global accesses are raw buffer loads / stores (row and k-step terms in SGPR offsets: no per-lane address arithmetic, and the
 // hardware's range check -- which includes the SGPR offset on gfx950, scripts/micro/buf_range -- zero-fills the M and K tails).
 // Measured (scripts/micro/sb3_loop.hip, MI355X): the loop alone 183 us against 142 us of bare MFMAs at the 1.73 GHz the chip holds
@@ -31,21 +29,23 @@ namespace {
 constexpr int S3_BM = 128, S3_BN = 256, S3_BKT = 32;
 constexpr int S3_A_PLANE = S3_BM * 32, S3_B_PLANE = S3_BN * 32;     // bf16 elements; rows of 64 bytes, 16-byte chunks swizzled by (row >> 2) & 3
 constexpr int S3_STAGE = 3 * (S3_A_PLANE + S3_B_PLANE);            // 73728 bytes
-constexpr int S3_BARG = 78;                                        // the step's barrier closes this gap
-constexpr int S3_LDS_BYTES = 2 * S3_STAGE * 2;
+constexpr int S3_BARG = 70;                                        // the step's barrier closes this gap
+constexpr int S3_LDS_STAGES = 2 * S3_STAGE * 2;                   // bytes of the two operand stages; the prologue coefficients (2 x pitch floats) follow
+constexpr int S3_LDS_MAX = 160 * 1024;
 
 // ---- the schedule: which gap (0 .. 95) of a K-step carries which piece of the staging of the NEXT step
-// 40 arithmetic units: pair p (0..7: two consecutive k of one row; pairs 0-3 row group 0, 4-7 row group 1) x stage s (0..4);
-// unit u = g * 20 + s * 4 + (p & 3) for row group g: stage-major inside a group, so a plane of the group is complete after 8 / 12 / 20 units
+// 40 arithmetic units: pair p (0..7: two consecutive k of one row; pairs 0-3 row group 0, 4-7 row group 1) x stage s (0..4).  Stage 0
+// of all eight pairs first (units 0..7: the raw registers are free early, so the requests for the step after next leave early and every
+// consumer finds its load a full step old: s_waitcnt vmcnt(15) throughout), then row group 0 stages 1..4 (units 8..23, stage-major: a
+// plane of the group is complete after 4 / 8 / 16 of them), then row group 1 (24..39)
 constexpr int unit_gap(int u) { return (u * 5) / 3; }                                             // 0 .. 65
-constexpr int aw_gap(int i) { return unit_gap((i / 3) * 20 + (i % 3 == 0 ? 7 : i % 3 == 1 ? 11 : 19)) + 1; }     // LDS store of plane i % 3 of group i / 3
-constexpr int al_gap(int j) { return unit_gap((j >> 1) * 20 + 2 * (j & 1) + 1) + 1; }             // raw quad j is free after stage 0 of its two pairs
-constexpr int cl_gap(int j) { return unit_gap(23) + 2 + j; }                                     // coefficients: after the last stage-0 unit
-// the kernel planes come from L2 (491 KB per layer, always resident): ONE step ahead, in two halves of six 16-byte pieces per lane through
-// the same 24 registers -- requested 27-30 gaps (~900 cycles) in front of their LDS store (48 registers for a whole step do not fit
-// beside the tile that is on its way out)
-constexpr int bl_gap(int j) { return j < 6 ? 2 + 3 * j : 33 + 3 * (j - 6); }                       // 2 .. 17, 33 .. 48
-constexpr int bw_gap(int j) { return j < 6 ? 32 + 3 * j : 60 + 3 * (j - 6); }                      // 32 .. 47, 60 .. 75
+constexpr int unit_pair(int u) { return u < 8 ? u : (u < 24 ? (u - 8) & 3 : 4 + ((u - 24) & 3)); }
+constexpr int unit_stage(int u) { return u < 8 ? 0 : (u < 24 ? 1 + (u - 8) / 4 : 1 + (u - 24) / 4); }
+constexpr int aw_gap(int i) { return unit_gap(8 + (i / 3) * 16 + (i % 3 == 0 ? 3 : i % 3 == 1 ? 7 : 15)) + 1; }   // LDS store of plane i % 3 of group i / 3
+constexpr int al_gap(int j) { return unit_gap(2 * j + 1) + 1; }                                   // raw quad j is free after stage 0 of pairs 2j, 2j + 1: gaps 2, 6, 9, 12
+constexpr int cl_gap(int j) { return 88 + j; }                                                    // prologue coefficients of the next step's staging (from LDS)
+constexpr int bw_gap(int j) { return 5 * j + 4; }                                                 // kernel planes: LDS store 4 .. 59, the register's next request behind it
+constexpr int bl_gap(int j) { return 5 * j + 8; }
 // fragment reads.  The MFMAs of a step run k half (2) x column tile ni (4) x row tile mi (2) x 6 products; a column tile's three planes
 // live in register set ni (both k halves), a row tile's in xa[mi][k half].  Reads 0..23 come from the stage being multiplied, in front
 // of the barrier; 24..35 from the other stage behind it (the next step's first fragments):
@@ -76,10 +76,9 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_sb3_kernel(GemmParams p) {
   const int my_tiles = (p.num_m_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int M = p.M, ldy = p.ldy;
   const uint32_t a_bytes = ((uint32_t)(M - 1) * (uint32_t)p.lda + (uint32_t)p.K) * 4u;
-  const __amdgpu_buffer_rsrc_t rA = s3_rsrc(p.A, a_bytes), rS = s3_rsrc(p.scale, PRO ? (uint32_t)p.K * 4u : 0u),
-                               rT = s3_rsrc(p.shift, PRO ? (uint32_t)p.K * 4u : 0u),
+  const __amdgpu_buffer_rsrc_t rA = s3_rsrc(p.A, a_bytes),
                                rB = s3_rsrc(p.Bsp, (uint32_t)(3 * p.bsp_plane) * 2u),
-                               rY = s3_rsrc(p.Y, ((uint32_t)(M - 1) * (uint32_t)ldy + (uint32_t)S3_BN) * 4u), rNull = s3_rsrc(p.Y, 0u);
+                               rY = s3_rsrc(p.Y, ((uint32_t)(M - 1) * (uint32_t)ldy + (uint32_t)S3_BN) * 4u);
   const int ar = t >> 2, ac = t & 3;
   // LDS offsets (bf16 elements): the thread's staging chunks ...
   const int sw = (ar >> 2) & 3;                            // (the same for rows ar + 64 i)
@@ -98,12 +97,11 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_sb3_kernel(GemmParams p) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) arow[i] = (uint32_t)((int)blockIdx.x * S3_BM + ar + 64 * i) * (uint32_t)p.lda * 4u + (uint32_t)ac * 32u;
   const uint32_t a_tile_stride = gridDim.x * (uint32_t)S3_BM * (uint32_t)p.lda * 4u;
-  const uint32_t cvo = (uint32_t)ac * 32u;
   const uint32_t blane = (uint32_t)ar * (uint32_t)p.bsp_pitch * 2u + (uint32_t)ac * 16u;
   const uint32_t b_plane = (uint32_t)p.bsp_plane * 2u, b_rows = 64u * (uint32_t)p.bsp_pitch * 2u;
   uint4 ra[4];                  // raw quads: [row group * 2 + half]
   uint4 cs[2], ct[2];           // prologue coefficients of the thread's 8 k
-  u32x4v rb[6];                 // kernel planes: pieces j and j + 6 share a register quad
+  u32x4v rb[12];
   float v0[8], v1[8], r0[8], r1[8];
   uint32_t hp[8], mp[8], lp[8];
   // clamp bounds of the prologue; a row beyond M is clamped to [0, 0]: its operand row is exactly zero, whatever shift says
@@ -111,6 +109,7 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_sb3_kernel(GemmParams p) {
   float lo[2] = {LO, LO}, hi[2] = {HI, HI};
 
   int lkt = 0;                  // k-step of the NEXT global request; arow[] holds its tile
+  int ckt = 0;                  // k-step whose prologue coefficients the next load_c fetches
   int skt = 1 % nk, srem = M - (int)blockIdx.x * S3_BM;     // k-step / rows left (from the tile's first row) of the data being STAGED
   const int tile_rows = (int)gridDim.x * S3_BM;
   auto advance = [&]() __attribute__((always_inline)) {
@@ -118,6 +117,8 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_sb3_kernel(GemmParams p) {
     if (lkt == nk) { lkt = 0; arow[0] += a_tile_stride; arow[1] += a_tile_stride; }
     ++skt;
     if (skt == nk) { skt = 0; srem -= tile_rows; }
+    ++ckt;
+    if (ckt == nk) ckt = 0;
   };
   auto row_bounds = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -130,13 +131,21 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_sb3_kernel(GemmParams p) {
   auto load_a = [&](int j) __attribute__((always_inline)) {
     ra[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rA, arow[j >> 1] + 16 * (j & 1), lkt * (S3_BKT * 4), 0));
   };
+  // prologue coefficients: both vectors in LDS behind the operand stages (copied once, zero from K up: the K tail of the operand
+  // becomes act(0 x + 0) = 0 whatever the buffer holds there), read per step for k-step ckt
+  float* Cs = reinterpret_cast<float*>(s3_lds + S3_LDS_STAGES);
+  const int kpad = p.bsp_pitch;
+  if (PRO) {
+    for (int i = t; i < kpad; i += 256) { Cs[i] = i < p.K ? p.scale[i] : 0.f; Cs[kpad + i] = i < p.K ? p.shift[i] : 0.f; }
+  }
   auto load_c = [&](int j) __attribute__((always_inline)) {
     if (!PRO) return;
-    if (j < 2) cs[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rS, cvo + 16 * (j & 1), lkt * (S3_BKT * 4), 0));
-    else ct[j - 2] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rT, cvo + 16 * (j & 1), lkt * (S3_BKT * 4), 0));
+    const float* src = Cs + (j < 2 ? 0 : kpad) + ckt * S3_BKT + ac * 8 + 4 * (j & 1);
+    if (j < 2) cs[j] = *reinterpret_cast<const uint4*>(src);
+    else ct[j - 2] = *reinterpret_cast<const uint4*>(src);
   };
   auto load_b = [&](int j) __attribute__((always_inline)) {
-    rb[j % 6] = __builtin_amdgcn_raw_buffer_load_b128(rB, blane + (uint32_t)skt * (S3_BKT * 2), (j >> 2) * b_plane + (j & 3) * b_rows, 0);
+    rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rB, blane + (uint32_t)lkt * (S3_BKT * 2), (j >> 2) * b_plane + (j & 3) * b_rows, 0);
   };
   auto elem = [](const uint4& q, int e) __attribute__((always_inline)) {
     return __builtin_bit_cast(float, e == 0 ? q.x : e == 1 ? q.y : e == 2 ? q.z : q.w);
@@ -177,16 +186,16 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_sb3_kernel(GemmParams p) {
     *reinterpret_cast<uint4*>(buf + a_lds + g * (64 * 32) + pl * S3_A_PLANE) = val;
   };
   auto write_b = [&](unsigned short* buf, int j) __attribute__((always_inline)) {
-    *reinterpret_cast<u32x4v*>(buf + b_lds + (j & 3) * (64 * 32) + (j >> 2) * S3_B_PLANE) = rb[j % 6];
+    *reinterpret_cast<u32x4v*>(buf + b_lds + (j & 3) * (64 * 32) + (j >> 2) * S3_B_PLANE) = rb[j];
   };
 
-  f32x16 acc[2][4], out[2][4];
+  f32x16 acc[2][4];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { acc[mi][ni][e] = 0.f; out[mi][ni][e] = 0.f; }
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
   s16x8 xa[2][2][3], wb[4][3];          // A: [row tile][k half][plane]; B: [column tile = register set][plane]
 
   auto frag_read = [&](const unsigned short* cur, const unsigned short* nxt, auto kc) __attribute__((always_inline)) {
@@ -205,28 +214,28 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_sb3_kernel(GemmParams p) {
 
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
-  // ---- pipeline head: step 0 staged into stage 0, the operand rows of step 1 requested
+  // ---- pipeline head: step 0 staged into stage 0, step 1 requested
   {
+    __syncthreads();             // (the coefficient vectors)
     row_bounds();
-    skt = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { load_a(j); load_c(j); }
+    ckt = 1;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-      for (int j = 0; j < 6; ++j) load_b(6 * h + j);
-#pragma unroll
-      for (int j = 0; j < 6; ++j) write_b(S0, 6 * h + j);
-    }
-    skt = 1;
+    for (int j = 0; j < 12; ++j) load_b(j);
     static_for<5>([&](auto sc) { static_for<8>([&](auto pc) { unit(pc, sc); }); });
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) write_a(S0, g, pl);
+#pragma unroll
+    for (int j = 0; j < 12; ++j) write_b(S0, j);
     ++lkt;                       // (nk >= 8: no wrap here; skt / srem already describe step 1)
 #pragma unroll
     for (int j = 0; j < 4; ++j) { load_a(j); load_c(j); }
+    ckt = 2;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) load_b(j);
     ++lkt;
     lds_barrier();
     static_for<12>([&](auto kc) { frag_read(S0, S0, std::integral_constant<int, 24 + decltype(kc)::value>{}); });
@@ -248,8 +257,8 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_sb3_kernel(GemmParams p) {
       if constexpr (g == S3_BARG) lds_barrier();
       if constexpr (fr >= 0) frag_read(cur, nxt, std::integral_constant<int, (fr >= 0 ? fr : 0)>{});
       if constexpr (u >= 0) {
-        constexpr int uu = u >= 0 ? u : 0, grp = uu / 20, s = (uu % 20) / 4, pp = grp * 4 + (uu & 3);
-        unit(std::integral_constant<int, pp>{}, std::integral_constant<int, s>{});
+        constexpr int uu = u >= 0 ? u : 0;
+        unit(std::integral_constant<int, unit_pair(uu)>{}, std::integral_constant<int, unit_stage(uu)>{});
       }
       if constexpr (aw >= 0) write_a(nxt, (aw >= 0 ? aw : 0) / 3, (aw >= 0 ? aw : 0) % 3);
       if constexpr (bw >= 0) write_b(nxt, bw >= 0 ? bw : 0);
@@ -269,52 +278,23 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_sb3_kernel(GemmParams p) {
     for (int ni = 0; ni < 4; ++ni) bias_v[ni] = p.bias[wc * 128 + ni * 32 + l31];
   }
   float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_q[4] = {0.f, 0.f, 0.f, 0.f};
-  // slice ni of the tile held in out[][]: 32 stores (real: to rY; otherwise to the zero-length buffer, dropped by the range check)
-  auto slice = [&](auto nic, const __amdgpu_buffer_rsrc_t& r, uint32_t out_m0, bool real) __attribute__((always_inline)) {
-    constexpr int ni = decltype(nic)::value;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float val = out[mi][ni][e] + bias_v[ni];
-        const uint32_t row = out_m0 + mi * 32 + (e & 3) + 8 * (e >> 2);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), r, yv + ni * 128, row * (uint32_t)ldy * 4u, 0);
-        if (STATS && real) { st_s[ni] += val; st_q[ni] = __builtin_fmaf(val, val, st_q[ni]); }
-      }
-  };
-  auto slice_any = [&](int s, const __amdgpu_buffer_rsrc_t& r, uint32_t out_m0, bool real) __attribute__((always_inline)) {
-    if (s == 0) slice(std::integral_constant<int, 0>{}, r, out_m0, real);
-    else if (s == 1) slice(std::integral_constant<int, 1>{}, r, out_m0, real);
-    else if (s == 2) slice(std::integral_constant<int, 2>{}, r, out_m0, real);
-    else slice(std::integral_constant<int, 3>{}, r, out_m0, real);
-  };
-
-  uint32_t out_m0 = 0;
-  bool have_out = false;
   for (int tile = 0; tile < my_tiles; ++tile) {
-    for (int kp = 0; kp < nk; kp += 2) {
-      step(I0{});
-      step(I1{});
-      const bool real = have_out && kp < 8;
-      slice_any((kp >> 1) & 3, real ? rY : rNull, out_m0, real);
-    }
-    // the finished tile moves out of the accumulators
+    for (int kp = 0; kp < nk; kp += 2) { step(I0{}); step(I1{}); }
+    // the finished tile: 128 row stores of 128 bytes per wave (rows beyond M fall to the range check; their values are exact zeros)
+    const uint32_t out_m0 = (uint32_t)((int)blockIdx.x + tile * (int)gridDim.x) * S3_BM;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
-        out[mi][ni] = acc[mi][ni];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+        for (int e = 0; e < 16; ++e) {
+          const float val = acc[mi][ni][e] + bias_v[ni];
+          const uint32_t row = out_m0 + mi * 32 + (e & 3) + 8 * (e >> 2);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rY, yv + ni * 128, row * (uint32_t)ldy * 4u, 0);
+          if (STATS) { st_s[ni] += val; st_q[ni] = __builtin_fmaf(val, val, st_q[ni]); }
+          acc[mi][ni][e] = 0.f;
+        }
       }
-    out_m0 = (uint32_t)((int)blockIdx.x + tile * (int)gridDim.x) * S3_BM;
-    have_out = true;
-  }
-  if (have_out) {
-    slice(std::integral_constant<int, 0>{}, rY, out_m0, true);
-    slice(std::integral_constant<int, 1>{}, rY, out_m0, true);
-    slice(std::integral_constant<int, 2>{}, rY, out_m0, true);
-    slice(std::integral_constant<int, 3>{}, rY, out_m0, true);
   }
   if (STATS) {
     // a column's two half-wave lanes, then the two wave rows through LDS (the operand stages are done with)
@@ -342,20 +322,20 @@ __global__ __launch_bounds__(256, 1) void pw_gemm_sb3_kernel(GemmParams p) {
 template <int ACT, bool PRO>
 void launch_sb3_act(const GemmParams& p, bool stats, int grid, hipStream_t st) {
   if (stats) {
-    static bool once = (hipFuncSetAttribute((const void*)pw_gemm_sb3_kernel<ACT, PRO, true>, hipFuncAttributeMaxDynamicSharedMemorySize, S3_LDS_BYTES), true);
+    static bool once = (hipFuncSetAttribute((const void*)pw_gemm_sb3_kernel<ACT, PRO, true>, hipFuncAttributeMaxDynamicSharedMemorySize, S3_LDS_MAX), true);
     (void)once;
-    dl3p_launch(pw_gemm_sb3_kernel<ACT, PRO, true>, dim3(grid), dim3(256), (size_t)S3_LDS_BYTES, st, p);
+    dl3p_launch(pw_gemm_sb3_kernel<ACT, PRO, true>, dim3(grid), dim3(256), (size_t)(S3_LDS_STAGES + 2 * p.bsp_pitch * 4), st, p);
   } else {
-    static bool once = (hipFuncSetAttribute((const void*)pw_gemm_sb3_kernel<ACT, PRO, false>, hipFuncAttributeMaxDynamicSharedMemorySize, S3_LDS_BYTES), true);
+    static bool once = (hipFuncSetAttribute((const void*)pw_gemm_sb3_kernel<ACT, PRO, false>, hipFuncAttributeMaxDynamicSharedMemorySize, S3_LDS_MAX), true);
     (void)once;
-    dl3p_launch(pw_gemm_sb3_kernel<ACT, PRO, false>, dim3(grid), dim3(256), (size_t)S3_LDS_BYTES, st, p);
+    dl3p_launch(pw_gemm_sb3_kernel<ACT, PRO, false>, dim3(grid), dim3(256), (size_t)(S3_LDS_STAGES + 2 * p.bsp_pitch * 4), st, p);
   }
 }
 }  // namespace
 
 // role 0 / 1 (forward without / with statistics), (M, K, N) as launched, pitch = row length of the pre-split kernel planes
 bool dl3p_sb3_supported(int role, int M, int K, int N, int pitch, int act, bool has_scale, bool accumulate, bool bias) {
-  if (role < 0 || role > 1 || N != S3_BN || K % 4 || pitch % 64 || pitch < 256 || pitch < K || M < 2 * S3_BM) return false;
+  if (role < 0 || role > 1 || N != S3_BN || K % 4 || pitch % 64 || pitch < 256 || pitch < K || pitch > 1024 || M < 2 * S3_BM) return false;      // (pitch <= 1024: the coefficient vectors share the LDS)
   if (!(act == DL3P_ACT_NONE || act == DL3P_ACT_RELU || act == DL3P_ACT_RELU6) || accumulate) return false;
   if (!has_scale && K % 32) return false;                 // (the K tail is zeroed by the out-of-range prologue coefficients)
   if (role == 1 && bias) return false;                    // (padding rows of the last tile are exact zeros only without a bias)

@@ -1362,6 +1362,8 @@ extern "C" int dl3p_pwconv_fwd_sb(const float* x, int ldx, const float* in_scale
   int nt, gx, gy, mi, wm;
   gemm_plan_sb(stat_partials ? 1 : 0, M, K, N, &nt, &gx, &gy, &p.num_m_tiles, &mi, &wm);
   if (wm == 4 && !dl3p_sb3_supported(stat_partials ? 1 : 0, M, K, N, pitch, in_act, in_scale != nullptr, false, bias != nullptr)) {
+    static const bool dbg = getenv("DL3P_SB3_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "dl3p_pwconv_fwd_sb: pinned form vetoed (M=%d K=%d N=%d pitch=%d act=%d scale=%d bias=%d stats=%d)\n", M, K, N, pitch, in_act, in_scale != nullptr, bias != nullptr, stat_partials != nullptr);
     t_sb3_veto = 1;          // (an activation / bias / pitch the pinned form does not serve: the tiled kernels take the launch)
     gemm_plan_sb(stat_partials ? 1 : 0, M, K, N, &nt, &gx, &gy, &p.num_m_tiles, &mi, &wm);
     t_sb3_veto = 0;
@@ -1370,6 +1372,7 @@ extern "C" int dl3p_pwconv_fwd_sb(const float* x, int ldx, const float* in_scale
   { const char* e = getenv("DL3P_SB_ABLATE"); p.stagger = e ? atoi(e) : 0; if (p.stagger == 100 && stat_partials) p.B = stat_partials + (size_t)DL3P_MAX_STAT_ROWS * 2 * N; }      // (ablation build: stamps behind the partial rows)
 #endif
   if (rows_out) *rows_out = gx;
+  if (wm == 4 && getenv("DL3P_SB3_DEBUG")) fprintf(stderr, "dl3p_pwconv_fwd_sb: pinned form M=%d K=%d N=%d grid %d\n", M, K, N, gx);
   if (wm == 4) DL3P_CHECK_ARG(dl3p_launch_gemm_sb3(p, stat_partials != nullptr, gx, (hipStream_t)stream), "%s: no pinned-schedule instantiation for activation %d", fn, in_act);
   else if (wm == 3) DL3P_CHECK_ARG(dl3p_launch_gemm_sbr(p, stat_partials ? 1 : 0, gx, (hipStream_t)stream), "%s: no row-stationary instantiation for K=%d", fn, K);
   else if (wm == 0) dl3p_launch_gemm_sbp(p, stat_partials != nullptr, false, nt, mi, dim3(gx, gy), (hipStream_t)stream);
