@@ -37,6 +37,36 @@ dt = time.perf_counter() - t0
 print('train_on_batch with host uint8 batches:  %.1f images/s (%.2f ms/step)' % (N * K / dt, 1e3 * dt / K))
 
 
+# fit_generator (train.py:177-187): the same uint8 batches through a Sequence -- batch k + 1 is copied into pinned memory and crosses
+# PCIe on the copy stream while step k runs, the loss is read one step late (model.BatchFeeder / LateScalar)
+class _Seq:
+    def __init__(self, batches, n):
+        self.b, self.n = batches, n
+    def __len__(self):
+        return self.n
+    def __getitem__(self, i):
+        return self.b[i % len(self.b)]
+for name, bb in (('uint8', batches8), ('float32', batches)):
+    m.fit_generator(_Seq(bb, 6), steps_per_epoch=6, epochs=1, verbose=0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    m.fit_generator(_Seq(bb, 3 * K), steps_per_epoch=3 * K, epochs=1, verbose=0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print('fit_generator with host %-7s batches (staged ahead): %.1f images/s (%.2f ms/step)' % (name, N * 3 * K / dt, 1e3 * dt / (3 * K)))
+# ... and the resident rate of the same executor (inputs left where they are): what bench.py reports as `value`
+ex = m._executor(N, True)
+for i in range(5):
+    ex.train_step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(3 * K):
+    ex.train_step()
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print('resident inputs (bench.py):                              %.1f images/s (%.2f ms/step)' % (N * 3 * K / dt, 1e3 * dt / (3 * K)))
+
+
 # --weighted_type adaptive (deeplabv3p/data.py:134-145): the generator's per-image balanced class weights.  Host side as
 # the reference computes them (np.unique + one putmask per class; sklearn's formula inlined) against 'adaptive' on the
 # device (dl3p_label_prepare)

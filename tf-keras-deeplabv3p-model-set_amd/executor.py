@@ -1929,6 +1929,8 @@ class Executor:
     # ---------------------------------------------------------------- running
     def _stage_u8(self, src, slot):
         src = torch.as_tensor(src).reshape(-1)
+        if src.is_cuda:                 # (a batch staged ahead by model.BatchFeeder: already on the device)
+            return src
         stage = self._u8.get(slot)
         if stage is None or stage.numel() != src.numel():
             stage = self._u8[slot] = torch.empty(src.numel(), dtype=torch.uint8, device=self.dev)

@@ -271,6 +271,90 @@ class DistContext:
             torch.cuda.current_stream().wait_stream(self._streams['bn'])
 
 
+class StagedBatch:
+    """a batch on its way to the device (BatchFeeder.put): device tensors with their host shapes, the staging slot they live in"""
+    def __init__(self, slot, x, y, sample_weight):
+        self.slot, self.x, self.y, self.sample_weight = slot, x, y, sample_weight
+
+
+class BatchFeeder:
+    """fit_generator's host -> device boundary (train.py:177-187 feeds numpy batches): TWO sets of pinned host buffers and device
+    staging buffers and a copy stream, so that batch k + 1 crosses PCIe while the device runs step k.  put() copies the arrays into
+    pinned memory (CPU) and starts the DMA on the copy stream; the consumer makes the compute stream wait for that DMA
+    (consume), enqueues the step (whose first kernels read the staging buffers: uint8 -> float normalisation, label
+    preparation) and releases the slot (release) -- the copy stream does not overwrite a slot before its last consumer ran."""
+    def __init__(self, device='cuda'):
+        import torch
+        self.dev = device
+        self.stream = torch.cuda.Stream()
+        self.bufs = [{}, {}]
+        self.ready = [torch.cuda.Event(), torch.cuda.Event()]
+        self.free = [None, None]
+        self.k = 0
+
+    def _move(self, slot, name, a):
+        import torch
+        t = torch.as_tensor(a)
+        shape = tuple(t.shape)
+        if t.dtype not in (torch.uint8, torch.float32):
+            t = t.to(torch.float32)
+        t = t.reshape(-1)
+        pair = self.bufs[slot].get(name)
+        if pair is None or pair[0].numel() != t.numel() or pair[0].dtype != t.dtype:
+            pair = self.bufs[slot][name] = (torch.empty(t.numel(), dtype=t.dtype, pin_memory=True),
+                                            torch.empty(t.numel(), dtype=t.dtype, device=self.dev))
+        host, dev = pair
+        # one thread's memcpy (0.5 ms for 12.6 MB).  Tensor.copy_ spreads it over every core of the host and the OpenMP workers then
+        # spin for their block time: on the 256-thread GPU box that starved the HIP runtime's own thread and a staged step took
+        # 35 ms instead of 12 (scripts/micro/feed_dbg.py)
+        np.copyto(host.numpy(), t.numpy())
+        with torch.cuda.stream(self.stream):
+            dev.copy_(host, non_blocking=True)
+        return dev.view(shape)
+
+    def put(self, x, y=None, sample_weight=None):
+        slot = self.k & 1
+        self.k += 1
+        self.ready[slot].synchronize()          # (the DMA that last read this slot's pinned buffers; long done)
+        if self.free[slot] is not None:
+            self.stream.wait_event(self.free[slot])
+        sw = sample_weight
+        out = StagedBatch(slot, self._move(slot, 'x', x), None if y is None else self._move(slot, 'y', y),
+                          sw if (sw is None or isinstance(sw, str)) else self._move(slot, 'sw', sw))
+        self.ready[slot].record(self.stream)
+        return out
+
+    def consume(self, staged):
+        import torch
+        torch.cuda.current_stream().wait_event(self.ready[staged.slot])
+
+    def release(self, staged):
+        import torch
+        ev = self.free[staged.slot] = self.free[staged.slot] or torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+
+
+class LateScalar:
+    """a device scalar read back one step late: an asynchronous copy into pinned memory behind the step that produced it, the value
+    taken when the NEXT step has been enqueued (fit's loss: the device never waits for the host to look at a number)"""
+    def __init__(self):
+        import torch
+        self.host = [torch.zeros(1, dtype=torch.float32, pin_memory=True) for _ in range(2)]
+        self.evt = [torch.cuda.Event(), torch.cuda.Event()]
+        self.k = 0
+
+    def post(self, dev_scalar):
+        i = self.k & 1
+        self.k += 1
+        self.host[i].copy_(dev_scalar.reshape(-1)[:1], non_blocking=True)
+        self.evt[i].record()
+        return i
+
+    def value(self, i):
+        self.evt[i].synchronize()
+        return float(self.host[i][0])
+
+
 class DeeplabModel:
     def __init__(self, graph, head, model_type, num_classes, input_shape, training, backbone_len, seed=0, bf16=False):
         self.graph, self.head = graph, head
@@ -398,6 +482,10 @@ class DeeplabModel:
         the device from uint8 labels]); returns the data loss"""
         if self.optimizer is None:
             raise RuntimeError('You must compile your model before training')
+        staged = x if isinstance(x, StagedBatch) else None
+        if staged is not None:              # (prefetch_batch: the arrays are already on their way; the compute stream waits for the DMA)
+            x, y, sample_weight = staged.x, staged.y, staged.sample_weight
+            self._feeder().consume(staged)
         # more than one rank: the executor trace (every collective once), the graph capture and the first replays are where
         # a multi-process job can hang -- bounded by watchdog.FirstStepsGuard (prints the switches to try, exits non-zero)
         guarded = self.dist is not None and self.dist.world_size > 1 and self._steps < 3
@@ -408,6 +496,8 @@ class DeeplabModel:
                              'train step %d' % self._steps):
             ex = self._executor(int(x.shape[0]), True)
             ex.set_inputs(x, y, sample_weight)
+            if staged is not None:
+                self._feeder().release(staged)
             ex.lr.fill_(self.optimizer.lr_at(self.optimizer.iterations))
             if self.use_graphs and not ex.graphed and self._steps_on(ex) >= 1:
                 ex.capture()
@@ -427,6 +517,17 @@ class DeeplabModel:
     @staticmethod
     def _steps_on(ex):
         return getattr(ex, '_steps', 0)
+
+    def _feeder(self):
+        if getattr(self, '_feed', None) is None:
+            self._feed = BatchFeeder()
+        return self._feed
+
+    def prefetch_batch(self, x, y, sample_weight=None):
+        """start moving a host batch to the device (pinned staging, copy stream; double-buffered: at most one batch ahead of the one
+        in flight) -> a StagedBatch that train_on_batch takes in place of the arrays.  fit / fit_generator does this for every
+        batch: the copy of batch k + 1 runs beside step k"""
+        return self._feeder().put(x, y, sample_weight)
 
     def predict(self, x, verbose=0, batch_size=None):
         """probabilities (B,H*W,C) for a training-shaped model, (B,H,W,C) otherwise (eval.py:33-36)"""
@@ -472,25 +573,40 @@ class DeeplabModel:
             t0, losses, metric_sums = time.time(), [], {}
             it = iter(gen) if not hasattr(gen, '__getitem__') else None
             fetch = (lambda i: gen[i]) if it is None else (lambda i: next(it))
-            batch = fetch(0) if n > 0 else None
-            for i in range(n):
+
+            def stage(batch):
                 # generators yield (x, y) or, in adaptive weighting mode, (x, y, sample_weight) (deeplabv3p/data.py:149-154)
                 sw = batch[2] if len(batch) > 2 else None
                 if isinstance(sw, dict):
                     sw = next(iter(sw.values()))          # {'pred_mask': weights}
                 if sw is None and weighted_type == 'adaptive' and getattr(batch[1], 'dtype', None) == np.uint8:
                     sw = 'adaptive'
-                # the step is only enqueued here; the generator prepares the next batch (decode, augment, resize on
-                # the host) while the GPU runs it, and the loss is read back afterwards
-                loss_t = self.train_on_batch(batch[0], batch[1], sample_weight=sw, return_tensor=True)
-                ex = self._executor(int(np.shape(batch[0])[0]), True)
-                batch = fetch(i + 1) if i + 1 < n else None
-                losses.append(float(loss_t.item()))
-                if ex.metric_counts is not None:
-                    metric_sums.setdefault('Jaccard', []).append(jaccard_from_counts(ex.metric_counts.cpu().numpy()))
-                if not np.isfinite(losses[-1]):      # TerminateOnNaN (train.py:64)
+                return self.prefetch_batch(batch[0], batch[1], sw), int(np.shape(batch[0])[0])
+            late = getattr(self, '_late_loss', None) or LateScalar()
+            self._late_loss = late
+            pending = None                                 # the loss of the step before, still on its way to the host
+            staged, bsz = stage(fetch(0)) if n > 0 else (None, 0)
+            for i in range(n):
+                # the step is only enqueued here; while the device runs it the generator prepares the next batch (decode, augment,
+                # resize on the host) and that batch crosses PCIe on the copy stream; the loss is looked at one step late
+                loss_t = self.train_on_batch(staged, None, return_tensor=True)
+                ex = self._executor(bsz, True)
+                slot = late.post(loss_t)
+                counts = ex.metric_counts.cpu().numpy() if ex.metric_counts is not None else None
+                if i + 1 < n:
+                    staged, bsz = stage(fetch(i + 1))
+                if pending is not None:
+                    losses.append(late.value(pending))
+                pending = slot
+                if counts is not None:
+                    metric_sums.setdefault('Jaccard', []).append(jaccard_from_counts(counts))
+                if losses and not np.isfinite(losses[-1]):      # TerminateOnNaN (train.py:64), one step late
                     self.stop_training = True
                     break
+            if pending is not None:
+                losses.append(late.value(pending))
+                if not np.isfinite(losses[-1]):
+                    self.stop_training = True
             logs = {'loss': float(np.mean(losses))}
             for mk, mv in metric_sums.items():             # Keras averages a metric over the epoch's batches
                 logs[mk] = float(np.nanmean(mv))
