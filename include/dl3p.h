@@ -404,6 +404,11 @@ int dl3p_aug_flip_crop_u8(const unsigned char* img, unsigned char* out, const un
  * 16.16 fixed-point affine map (pinned against PIL, tests/golden/make_pil_gridmask.py).  params: N x 16 ints on the device,
  * {apply, hh, d, l, st_h, st_w, kind, a0..a5, top, left, 0} from the host's draws (augment.random_gridmask). */
 int dl3p_aug_gridmask_u8(unsigned char* img, unsigned char* label, const int* params, int N, int H, int W, void* stream);
+/* dl3p_aug_gray_blur_u8: random_grayscale then random_blur (common/data_utils.py:152-172, 105-124; deeplabv3p/data.py:95-99) for the
+ * images whose flags[n] say so (bit 0 grayscale, bit 1 blur; 0 = copy).  UNPINNED restatements of OpenCV's 8-bit arithmetic (cv2 is
+ * absent here): gray = (c0 * 1868 + c1 * 9617 + c2 * 4899 + 8192) >> 14 replicated to three channels; GaussianBlur (5, 5), sigma 0 =
+ * [1 4 6 4 1] / 16 separable in 8.8 fixed point, one rounding, BORDER_REFLECT_101. */
+int dl3p_aug_gray_blur_u8(const unsigned char* img, unsigned char* out, const int* flags, int N, int H, int W, void* stream);
 /* The label tail of SegmentationGenerator.__getitem__ for byte labels (N images of P pixels each):
  * labels_out = float(label), with label > num_classes-1 replaced by ignore_index (deeplabv3p/data.py:116-121);
  * weights_out (optional) = the `--weighted_type adaptive` pixel weights (data.py:134-145): sklearn's

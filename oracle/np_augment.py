@@ -149,3 +149,37 @@ def gridmask_params(h, w, d, st_h, st_w, r, ratio=0.5):
         a2 = fix(a[2] + a[0] * 0.5 + a[1] * 0.5)
         a5 = fix(a[5] + a[3] * 0.5 + a[4] * 0.5)
     return [1, hh, d, l, st_h, st_w, kind, a0, a1, a2, a3, a4, a5, (hh - h) // 2, (hh - w) // 2]
+
+
+# ---- random_grayscale / random_blur (common/data_utils.py:152-172, 105-124).  PARITY UNPINNED: the arithmetic lives in OpenCV
+# (requirements.txt `opencv-python`), which is not in this image and whose wheels cannot be fetched; the functions below restate
+# its published 8-bit algorithms and nothing checks them against OpenCV itself:
+#   cvtColor BGR2GRAY, uint8 (imgproc/src/color_yuv / color_rgb: RGB2Gray<uchar>): fixed point with yuv_shift = 14,
+#     B2Y = 1868, G2Y = 9617, R2Y = 4899: gray = CV_DESCALE(c0 * B2Y + c1 * G2Y + c2 * R2Y, 14) = (... + (1 << 13)) >> 14
+#     -- c0 is the array's FIRST channel: the reference hands an RGB array (PIL) to a BGR conversion, kept as it is;
+#   GaussianBlur((5, 5), sigmaX = 0) on uint8 (imgproc/src/smooth: getGaussianKernel's small_gaussian_tab for ksize <= 7 and
+#     sigma <= 0 -> [1, 4, 6, 4, 1] / 16; the bit-exact 8-bit path (fixedSmoothInvoker, ufixedpoint16 with 8 fractional bits) keeps
+#     the horizontal pass exact and rounds once after the vertical pass: (sum_ij w_i w_j p + 128) >> 8; BORDER_DEFAULT =
+#     BORDER_REFLECT_101.
+def cv_gray(img):
+    c = img.astype(np.int64)
+    g = ((c[..., 0] * 1868 + c[..., 1] * 9617 + c[..., 2] * 4899 + (1 << 13)) >> 14).astype(np.uint8)
+    return np.stack([g, g, g], axis=-1)
+
+
+def cv_gaussian5(img):
+    w = np.array([1, 4, 6, 4, 1], np.int64)
+    p = np.pad(img.astype(np.int64), ((2, 2), (2, 2), (0, 0)), mode='reflect')       # numpy 'reflect' = BORDER_REFLECT_101
+    H, W, _ = img.shape
+    h = sum(w[j] * p[:, j:j + W] for j in range(5))
+    v = sum(w[i] * h[i:i + H] for i in range(5))
+    return ((v + 128) >> 8).astype(np.uint8)
+
+
+def gray_blur(img, flags):
+    out = img
+    if flags & 1:
+        out = cv_gray(out)
+    if flags & 2:
+        out = cv_gaussian5(out)
+    return out.copy()

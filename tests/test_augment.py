@@ -175,3 +175,54 @@ def test_device_gridmask_matches_pil():
             assert np.array_equal(gi[n], imgs[n] * mask[..., None]), case
             assert np.array_equal(gl[n], labs[n] * mask), case
         assert np.array_equal(gi[-1], imgs[-1]) and np.array_equal(gl[-1], labs[-1])
+
+
+# ---- random_grayscale / random_blur: UNPINNED restatements of OpenCV's 8-bit arithmetic (oracle/np_augment.py says why)
+def test_gray_and_blur_restatement_known_answers():
+    """what the published formulas give on inputs whose answer can be worked out by hand"""
+    flat = np.full((9, 11, 3), 77, np.uint8)
+    assert np.array_equal(A.cv_gaussian5(flat), flat)                     # the taps sum to 256: a constant image is a fixed point
+    assert np.array_equal(A.cv_gray(flat), flat)                          # 1868 + 9617 + 4899 = 16384 = 1 << 14
+    px = np.zeros((1, 1, 3), np.uint8); px[0, 0] = (255, 0, 0)
+    assert A.cv_gray(px)[0, 0, 0] == (255 * 1868 + 8192) >> 14 == 29      # the FIRST channel carries the blue weight (RGB array, BGR conversion)
+    px[0, 0] = (0, 0, 255)
+    assert A.cv_gray(px)[0, 0, 0] == 76
+    imp = np.zeros((9, 9, 3), np.uint8); imp[4, 4] = 255
+    b = A.cv_gaussian5(imp)[..., 0]
+    w = np.array([1, 4, 6, 4, 1])
+    assert np.array_equal(b[2:7, 2:7], (np.outer(w, w) * 255 + 128) >> 8) and b.sum() == b[2:7, 2:7].sum()
+    # BORDER_REFLECT_101 (gfedcb|abcdefgh|gfedcba): the mirror does NOT repeat the edge pixel, so an impulse one pixel inside the
+    # border is seen twice from the border pixel (taps -1 and +1) and the corner pixel itself only once
+    imp = np.zeros((9, 9, 3), np.uint8); imp[0, 1] = 255
+    b = A.cv_gaussian5(imp)[..., 0]
+    assert b[0, 0] == ((4 + 4) * 6 * 255 + 128) >> 8 and b[0, 1] == ((6 + 1) * 6 * 255 + 128) >> 8
+    imp = np.zeros((9, 9, 3), np.uint8); imp[0, 0] = 255
+    b = A.cv_gaussian5(imp)[..., 0]
+    assert b[0, 0] == (36 * 255 + 128) >> 8 and b[0, 1] == (4 * 6 * 255 + 128) >> 8 and b[1, 1] == (4 * 4 * 255 + 128) >> 8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(4, 37, 53), (2, 513, 513), (4, 3, 3), (4, 5, 64)])
+def test_device_gray_blur_matches_restatement(shape):
+    import torch
+    from conftest import load_pkg
+    aug = load_pkg('augment')
+    N, H, W = shape
+    rng = np.random.default_rng(H * W + N)
+    imgs = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)
+    t = torch.from_numpy(imgs).cuda()
+    flags = [0, 1, 2, 3][:N] + [3] * max(0, N - 4)
+    got = aug.gray_blur(t, flags).cpu().numpy()
+    for n in range(N):
+        assert np.array_equal(got[n], A.gray_blur(imgs[n], flags[n])), (shape, flags[n])
+    # the reference's names: the draws made on the host as the reference makes them
+    np.random.seed(3)
+    g = aug.random_grayscale(t, prob=0.5).cpu().numpy()
+    np.random.seed(3)
+    want = [A.gray_blur(imgs[n], 1 if np.random.rand() < 0.5 else 0) for n in range(N)]
+    assert all(np.array_equal(g[n], want[n]) for n in range(N))
+    np.random.seed(4)
+    b = aug.random_blur(t, prob=0.5).cpu().numpy()
+    np.random.seed(4)
+    want = [A.gray_blur(imgs[n], 2 if np.random.rand() < 0.5 else 0) for n in range(N)]
+    assert all(np.array_equal(b[n], want[n]) for n in range(N))

@@ -7,8 +7,11 @@ host exactly as the reference makes them (`rand() < prob` per image, `rand(jitte
 random_gridmask is here too: its rotation is PIL's (Image.rotate, NEAREST), restated from Pillow's 16.16 fixed-point affine
 map and pinned against PIL itself.
 
-Not here: random_zoom_rotate, random_grayscale, random_blur, random_histeq and the final cv2.resize -- OpenCV code whose
-fixed-point arithmetic cannot be pinned in an image without OpenCV; they stay on the host.
+random_grayscale and random_blur are here as UNPINNED restatements of OpenCV's published 8-bit arithmetic (cv2 is not in this image:
+the kernels are held to oracle/np_augment.py's restatement of the same formulas, not to OpenCV itself).
+
+Not here: random_zoom_rotate, random_histeq and the final cv2.resize -- OpenCV code (warpAffine's fixed-point interpolation tables,
+CLAHE) that cannot be pinned without OpenCV; they stay on the host.
 """
 import numpy as np
 import torch
@@ -77,6 +80,27 @@ def random_contrast(images, jitter=.5):
 
 def random_sharpness(images, jitter=.5):
     return enhance(images, SHARPNESS, [rand(jitter, 1 / jitter) for _ in range(images.shape[0])])
+
+
+def gray_blur(images, flags, out=None):
+    """flags[n] bit 0: cv2.cvtColor(BGR2GRAY) + GRAY2BGR; bit 1: cv2.GaussianBlur(image, (5, 5), 0) (grayscale first, as the generator
+    applies them)"""
+    N, H, W, C = images.shape
+    assert images.dtype == torch.uint8 and C == 3 and images.is_contiguous()
+    fl = torch.as_tensor(np.asarray(flags, np.int32).reshape(N)).to(images.device)
+    out = torch.empty_like(images) if out is None else out
+    lib().aug_gray_blur_u8(images.data_ptr(), out.data_ptr(), fl.data_ptr(), N, H, W, _stream())
+    return out
+
+
+def random_grayscale(images, prob=.2):
+    return gray_blur(images, [1 if rand() < prob else 0 for _ in range(images.shape[0])])
+
+
+def random_blur(images, prob=.5, size=5):
+    if size != 5:
+        raise ValueError('the device kernel restates the 5 x 5 table of cv2.GaussianBlur (the generator\'s default size)')
+    return gray_blur(images, [2 if rand() < prob else 0 for _ in range(images.shape[0])])
 
 
 def gridmask_params(h, w, d, st_h, st_w, r, ratio=0.5):

@@ -180,3 +180,58 @@ extern "C" int dl3p_aug_gridmask_u8(unsigned char* img, unsigned char* label, co
   DL3P_CHECK_LAUNCH("dl3p_aug_gridmask_u8");
   return DL3P_OK;
 }
+
+// random_grayscale + random_blur (common/data_utils.py:105-124, 152-172; applied in that order by deeplabv3p/data.py:95-99).  UNPINNED
+// restatements of OpenCV's published 8-bit arithmetic (cv2 is not in this image: oracle/np_augment.py restates the same formulas
+// and the tests hold the kernel to that restatement, not to OpenCV itself):
+//   cv2.cvtColor(BGR2GRAY) on uint8:  gray = (c0 * 1868 + c1 * 9617 + c2 * 4899 + (1 << 13)) >> 14   (the reference hands an RGB array
+//     to a BGR conversion: c0 is the array's first channel), then GRAY2BGR replicates it;
+//   cv2.GaussianBlur(img, (5, 5), 0) on uint8: sigma <= 0 with a 5-tap kernel takes the fixed table [1 4 6 4 1] / 16, separable,
+//     in 8.8 fixed point with ONE rounding at the end: out = (sum_ij w_i w_j p(reflect-101 border) + 128) >> 8.
+// flags[n]: bit 0 grayscale, bit 1 blur; 0 copies the image.
+__global__ __launch_bounds__(256) void aug_gray_blur_kernel(const unsigned char* img, unsigned char* out, const int* flags, int H, int W) {
+  const int n = blockIdx.y;
+  const int f = flags[n];
+  const long long P = (long long)H * W;
+  const unsigned char* src = img + (size_t)n * P * 3;
+  unsigned char* dst = out + (size_t)n * P * 3;
+  auto gray = [](int c0, int c1, int c2) { return (c0 * 1868 + c1 * 9617 + c2 * 4899 + (1 << 13)) >> 14; };
+  auto refl = [](int i, int n_) { return i < 0 ? -i : (i >= n_ ? 2 * n_ - 2 - i : i); };      // BORDER_REFLECT_101
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < P; i += (long long)gridDim.x * 256) {
+    const int y = (int)(i / W), x = (int)(i - (long long)y * W);
+    int o0, o1, o2;
+    if (!(f & 2)) {
+      o0 = src[3 * i]; o1 = src[3 * i + 1]; o2 = src[3 * i + 2];
+      if (f & 1) o0 = o1 = o2 = gray(o0, o1, o2);
+    } else {
+      const int wv[5] = {1, 4, 6, 4, 1};
+      int s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+      for (int dy = -2; dy <= 2; ++dy) {
+        const int yy = H > 1 ? refl(y + dy, H) : 0;
+#pragma unroll
+        for (int dx = -2; dx <= 2; ++dx) {
+          const int xx = W > 1 ? refl(x + dx, W) : 0;
+          const unsigned char* q = src + ((long long)yy * W + xx) * 3;
+          int c0 = q[0], c1 = q[1], c2 = q[2];
+          if (f & 1) c0 = c1 = c2 = gray(c0, c1, c2);
+          const int wgt = wv[dy + 2] * wv[dx + 2];
+          s0 += wgt * c0; s1 += wgt * c1; s2 += wgt * c2;
+        }
+      }
+      o0 = (s0 + 128) >> 8; o1 = (s1 + 128) >> 8; o2 = (s2 + 128) >> 8;
+    }
+    dst[3 * i] = (unsigned char)o0; dst[3 * i + 1] = (unsigned char)o1; dst[3 * i + 2] = (unsigned char)o2;
+  }
+}
+
+extern "C" int dl3p_aug_gray_blur_u8(const unsigned char* img, unsigned char* out, const int* flags, int N, int H, int W, void* stream) {
+  DL3P_CHECK_ARG(img && out && out != img && flags && N > 0 && H > 2 && W > 2, "dl3p_aug_gray_blur_u8: bad arguments (H, W >= 3, distinct output)");
+  const long long P = (long long)H * W;
+  long long gx = ceil_div_ll(P, 256 * 4);
+  if (gx > 2048) gx = 2048;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(aug_gray_blur_kernel, dim3((unsigned)gx, N), dim3(256), 0, (hipStream_t)stream, img, out, flags, H, W);
+  DL3P_CHECK_LAUNCH("dl3p_aug_gray_blur_u8");
+  return DL3P_OK;
+}
