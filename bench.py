@@ -99,14 +99,14 @@ def cpu_baseline(args):
     # images/s, 64 threads 2.8, 128 threads 1.2 and all 256 cores 0.011 -- three minutes per step -- so the probe stops at 64.)
     probe = {}
     for th in sorted({t for t in (8, 16, 32, 64) if t <= cores}):
-        probe[th] = rate(th, 1, 2, 6.0)[0]
+        probe[th] = rate(th, 1, 4, 8.0)[0]      # (>= 4 timed steps per candidate: with two the probe and the sample disagreed by 40 %)
     threads = max(probe, key=probe.get)
     all_rate, all_n = rate(threads, 3, args.cpu_steps, 30.0)
     one_rate, one_n = rate(1, 1, 3, 15.0)
     out = {'value': round(all_rate, 3), 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
            'sample': '%d train steps (3 warm-up) of mobilenetv2_lite %dx%d batch %d fp32: torch-CPU (oneDNN) restatement of the '
                      'same graph, NOT tf.keras (not installable here); host has %d cores' % (all_n, H, W, B, cores),
-           'thread_probe': {str(k): round(v, 3) for k, v in probe.items()},
+           'thread_probe': {str(k): round(v, 3) for k, v in probe.items()}, 'thread_probe_steps': 4,
            'one_core': {'value': round(one_rate, 3), 'steps': one_n}}
     try:
         from oracle.np_net import OracleModel
