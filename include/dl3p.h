@@ -559,6 +559,16 @@ int dl3p_pwconv_bwd_weight_slabs_bn(const float* x, int ldx, const float* in_sca
                                     const float* bn_shift, int bn_act, const float* save_mean, const float* save_invstd,
                                     const float* coef, float* dz, int lddz, float* workspace, size_t workspace_bytes,
                                     int* rows_out, int M, int K, int N, void* stream);
+/* Decoder_block (deeplabv3p/models/layers.py:207-215: x = img_resize(x) -> Concatenate([x, skip]) -> SepConv_BN) without the resized
+ * tensor in HBM.  dl3p_dw_upsampled_input describes the input of the NEXT dl3p_dwconv2d_fwd / dl3p_dwconv2d_bwd_weight_slabs /
+ * dl3p_dwconv2d_bwd_weight_slabs_bn call of the calling thread (one call consumes it): channels [0, up_C) of x are not read but
+ * formed on the fly as the bilinear upsampling of up_x (N, up_h, up_w, up_C; row pitch up_ld) to the conv's H x W, with
+ * dl3p_resize_bilinear_fwd's arithmetic expression for expression -- the output equals resize + conv bit for bit; channels from up_C
+ * on are read from x as ever.  Served: 3x3, stride 1, rate 1 launches of the window kernels behind a BatchNorm + activation
+ * prologue (dl3p_dw_upsampled_input_supported: role 0 forward, 1 weight gradient); anything else makes the consuming call fail. */
+int dl3p_dw_upsampled_input(const float* up_x, int up_ld, int up_h, int up_w, int up_C, void* stream);
+int dl3p_dw_upsampled_input_supported(int role, int N, int H, int W, int C, int up_C, int k, int stride, int rate, int pad_t, int pad_l,
+                                      int Ho, int Wo);
 /* the same for the depthwise 3x3 window kernels (stride 1 at any rate, stride 2): the weight gradient visits every output
  * pixel once, forms dz there and writes it (SepConv_BN: BN behind the depthwise conv, layers.py:100-105) */
 int dl3p_dwconv2d_bwd_weight_bn_supported(int N, int H, int W, int C, int k, int stride, int rate, int pad_t, int pad_l,

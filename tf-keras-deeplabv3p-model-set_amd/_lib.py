@@ -68,7 +68,7 @@ class Lib:
             setattr(self, name[len('dl3p_'):], self._wrap(name, fn, ret))
 
     def _wrap(self, name, fn, ret):
-        if ret != 'int' or name in ('dl3p_version', 'dl3p_device_cus', 'dl3p_head_train_supported', 'dl3p_head_train_rows_supported', 'dl3p_stem_conv_supported', 'dl3p_conv2d_gemm_supported', 'dl3p_reduce_rows_variant', 'dl3p_reduce_rows_block_elements', 'dl3p_pwconv_bwd_weight_bn_supported', 'dl3p_dwconv2d_bwd_weight_bn_supported', 'dl3p_pwconv_sb_supported', 'dl3p_pwconv_sb_pays', 'dl3p_pwconv_bwd_data_sb_apply_supported', 'dl3p_conv2d_gemm_sb_supported', 'dl3p_conv2d_gemm_sb_pays', 'dl3p_irb_supported', 'dl3p_pwconv_fwd_splitk_plan', 'dl3p_irb_bwd_supported', 'dl3p_get_option', 'dl3p_irb_get_plan', 'dl3p_irb_cov_rows_max'):
+        if ret != 'int' or name in ('dl3p_version', 'dl3p_device_cus', 'dl3p_head_train_supported', 'dl3p_head_train_rows_supported', 'dl3p_stem_conv_supported', 'dl3p_conv2d_gemm_supported', 'dl3p_reduce_rows_variant', 'dl3p_reduce_rows_block_elements', 'dl3p_pwconv_bwd_weight_bn_supported', 'dl3p_dwconv2d_bwd_weight_bn_supported', 'dl3p_pwconv_sb_supported', 'dl3p_pwconv_sb_pays', 'dl3p_pwconv_bwd_data_sb_apply_supported', 'dl3p_conv2d_gemm_sb_supported', 'dl3p_conv2d_gemm_sb_pays', 'dl3p_irb_supported', 'dl3p_pwconv_fwd_splitk_plan', 'dl3p_irb_bwd_supported', 'dl3p_get_option', 'dl3p_irb_get_plan', 'dl3p_irb_cov_rows_max', 'dl3p_dw_upsampled_input_supported'):
             return fn
         err = self.cdll.dl3p_last_error_string
         err.restype = ctypes.c_char_p

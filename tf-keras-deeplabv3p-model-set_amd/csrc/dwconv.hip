@@ -42,7 +42,37 @@ struct DwParams {
   const float* fa_z; int fa_ldz;
   const float* fa_scale; const float* fa_shift; const float* fa_mean; const float* fa_invstd; const float* fa_coef; int fa_act;
   float* fa_dz; int fa_lddz;
+  // UP instantiations (window kernels, stride 1, rate 1): channels [0, up_C) of the input are NOT read from x but formed on the fly as
+  // the bilinear upsampling of up_x (N, up_h, up_w, up_C) to H x W -- dl3p_resize_bilinear_fwd's arithmetic, expression for
+  // expression, so the result is the unfused pair's bit for bit; channels from up_C on come from x as ever (Decoder_block,
+  // deeplabv3p/models/layers.py:207-215: resize -> concat with the skip features -> depthwise conv, without the resized tensor in HBM)
+  const float* up_x; int up_ld, up_h, up_w, up_C;
 };
+
+// dl3p_resize_bilinear_fwd's source coordinates (csrc/resize_head.hip lerp_coeff: TF2 half-pixel centres), restated here
+struct DwLerp { int lo, hi; float t; };
+__device__ __forceinline__ DwLerp dw_lerp(int o, float scale, int in_size) {
+  const float src = ((float)o + 0.5f) * scale - 0.5f;
+  const float fl = floorf(src);
+  DwLerp r;
+  r.lo = max((int)fl, 0);
+  r.hi = min((int)ceilf(src), in_size - 1);
+  r.t = src - fl;
+  return r;
+}
+// one input vector of an UP launch: the four neighbours of (iy, ix) in the low-resolution map, TF's order of operations
+// (top = tl + (tr - tl) tx; bottom = bl + (br - bl) tx; out = top + (bottom - top) ty)
+__device__ __forceinline__ float4 dw_up_load(const float* img, int up_w, int up_ld, DwLerp ly, DwLerp lx) {
+  const float4 tl = ld4(img + ((size_t)ly.lo * up_w + lx.lo) * up_ld);
+  const float4 tr = ld4(img + ((size_t)ly.lo * up_w + lx.hi) * up_ld);
+  const float4 bl = ld4(img + ((size_t)ly.hi * up_w + lx.lo) * up_ld);
+  const float4 br = ld4(img + ((size_t)ly.hi * up_w + lx.hi) * up_ld);
+  float4 o;
+#define DW_LERP2(f) { const float top = tl.f + (tr.f - tl.f) * lx.t; const float bot = bl.f + (br.f - bl.f) * lx.t; o.f = top + (bot - top) * ly.t; }
+  DW_LERP2(x) DW_LERP2(y) DW_LERP2(z) DW_LERP2(w)
+#undef DW_LERP2
+  return o;
+}
 
 // g' = g * act'(z*scale+shift), xhat = (z - mean) * invstd  ->  s[0] += g', s[1] += g' * xhat
 __device__ __forceinline__ void bnb_accumulate(float4 (&s1)[2], float4 g, float4 zv, float4 bsc, float4 bsh, float4 bmu,
@@ -75,7 +105,7 @@ __device__ __forceinline__ float4 prologue4(float4 v, float4 sc, float4 sh, int 
 // zero padding are exec-masked loads that never leave the CU (at rate 18 on a 33x33 map a 2x2 output
 // block issues 4 loads instead of 36).  This replaces TF's SpaceToBatchND->conv->BatchToSpaceND
 // (two extra tensor passes) by index arithmetic.
-template <int KS, int TW, int S, int PRO, bool BNB = false>
+template <int KS, int TW, int S, int PRO, bool BNB = false, bool UP = false>
 __global__ __launch_bounds__(256) void dw_fwd_seg(DwParams p) {
   constexpr int SEG = (TW - 1) * S + KS;
   const int b = blockIdx.x;
@@ -134,6 +164,18 @@ __global__ __launch_bounds__(256) void dw_fwd_seg(DwParams p) {
         cok[i] = ix >= 0 && ix < p.W;
         coff[i] = ix * p.ldx;
       }
+      // UP: the column coefficients of the strip's input pixels in the low-resolution map (rows: per input row below)
+      DwLerp lxs[UP ? SEG : 1];
+      const bool upl = UP && c < p.up_C;
+      const float* uimg = nullptr;
+      float usy = 0.f;
+      if (UP) {
+        const float usx = (float)p.up_w / (float)p.W;
+        usy = (float)p.up_h / (float)p.H;
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) lxs[i] = dw_lerp(min(max(ix0 + i * rate, 0), p.W - 1), usx, p.up_w);
+        uimg = p.up_x + (size_t)n * p.up_h * p.up_w * p.up_ld + (upl ? c : 0);
+      }
       float4 win[KS][SEG];
       float4 raw[S][SEG];
       // prime the window with the KS rows of the first output row (exec-masked loads, math afterwards)
@@ -147,7 +189,7 @@ __global__ __launch_bounds__(256) void dw_fwd_seg(DwParams p) {
 #pragma unroll
           for (int i = 0; i < SEG; ++i) {
             win[ky][i] = zero4();
-            if (yok && cok[i]) win[ky][i] = ld4(xrow + coff[i]);
+            if (yok && cok[i]) win[ky][i] = (UP && upl) ? dw_up_load(uimg, p.up_w, p.up_ld, dw_lerp(iy, usy, p.up_h), lxs[UP ? i : 0]) : ld4(xrow + coff[i]);
           }
         }
 #pragma unroll
@@ -181,7 +223,7 @@ __global__ __launch_bounds__(256) void dw_fwd_seg(DwParams p) {
 #pragma unroll
           for (int i = 0; i < SEG; ++i) {
             raw[q][i] = zero4();
-            if (nyok[q] && cok[i]) raw[q][i] = ld4(xrow + coff[i]);
+            if (nyok[q] && cok[i]) raw[q][i] = (UP && upl) ? dw_up_load(uimg, p.up_w, p.up_ld, dw_lerp(iy, usy, p.up_h), lxs[UP ? i : 0]) : ld4(xrow + coff[i]);
           }
         }
         float4 acc[TW];
@@ -519,7 +561,7 @@ __global__ __launch_bounds__(256, 2) void dw5_wgrad_rows(DwParams p) {
 // Same window walk as the forward kernel (the activated input rows live in registers); every output
 // row adds win[ky][tw+kx] * dy[tw] into the k*k per-thread tap accumulators.  One partial row
 // [k*k][C] per workgroup, summed in a fixed order afterwards.
-template <int KS, int TW, int S, int PRO, bool BNA = false>
+template <int KS, int TW, int S, int PRO, bool BNA = false, bool UP = false>
 __global__ __launch_bounds__(256) void dw_bwd_weight_seg(DwParams p) {
   constexpr int SEG = (TW - 1) * S + KS;
   const int b = blockIdx.x;
@@ -571,6 +613,18 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_seg(DwParams p) {
         cok[i] = ix >= 0 && ix < p.W;
         coff[i] = ix * p.ldx;
       }
+      // UP: the column coefficients of the strip's input pixels in the low-resolution map (rows: per input row below)
+      DwLerp lxs[UP ? SEG : 1];
+      const bool upl = UP && c < p.up_C;
+      const float* uimg = nullptr;
+      float usy = 0.f;
+      if (UP) {
+        const float usx = (float)p.up_w / (float)p.W;
+        usy = (float)p.up_h / (float)p.H;
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) lxs[i] = dw_lerp(min(max(ix0 + i * rate, 0), p.W - 1), usx, p.up_w);
+        uimg = p.up_x + (size_t)n * p.up_h * p.up_w * p.up_ld + (upl ? c : 0);
+      }
       float4 win[KS][SEG];
       float4 raw[S][SEG];
       // prime the window with the KS rows of the first output row (exec-masked loads, math afterwards)
@@ -584,7 +638,7 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_seg(DwParams p) {
 #pragma unroll
           for (int i = 0; i < SEG; ++i) {
             win[ky][i] = zero4();
-            if (yok && cok[i]) win[ky][i] = ld4(xrow + coff[i]);
+            if (yok && cok[i]) win[ky][i] = (UP && upl) ? dw_up_load(uimg, p.up_w, p.up_ld, dw_lerp(iy, usy, p.up_h), lxs[UP ? i : 0]) : ld4(xrow + coff[i]);
           }
         }
 #pragma unroll
@@ -612,7 +666,7 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_seg(DwParams p) {
 #pragma unroll
           for (int i = 0; i < SEG; ++i) {
             raw[q][i] = zero4();
-            if (nyok[q] && cok[i]) raw[q][i] = ld4(xrow + coff[i]);
+            if (nyok[q] && cok[i]) raw[q][i] = (UP && upl) ? dw_up_load(uimg, p.up_w, p.up_ld, dw_lerp(iy, usy, p.up_h), lxs[UP ? i : 0]) : ld4(xrow + coff[i]);
           }
         }
         // gradient of the raw conv output for this row's strip
@@ -1286,6 +1340,13 @@ static void launch_fwd_pro(const DwParams& p, int kind, dim3 grid, hipStream_t s
     else dl3p_launch(dw_fwd_gather<5, PRO>, grid, block, 0, st, p);
     return;
   }
+  if (p.up_x) {          // (dl3p_dw_upsampled_input: checked by the caller -- 3x3, stride 1, rate 1, window kernel, BatchNorm + activation prologue)
+    if constexpr (PRO == 2) {
+      if (p.tw == 2) dl3p_launch(dw_fwd_seg<3, 2, 1, 2, false, true>, grid, block, 0, st, p);
+      else dl3p_launch(dw_fwd_seg<3, 4, 1, 2, false, true>, grid, block, 0, st, p);
+    }
+    return;
+  }
   if (kind == 1 && p.tw == 2) dl3p_launch(dw_fwd_seg<3, 2, 1, PRO>, grid, block, 0, st, p);
   else if (kind == 1) dl3p_launch(dw_fwd_seg<3, 4, 1, PRO>, grid, block, 0, st, p);
   else if (kind == 2) dl3p_launch(dw_fwd_seg<3, 2, 2, PRO>, grid, block, 0, st, p);
@@ -1295,7 +1356,7 @@ static void launch_fwd_pro(const DwParams& p, int kind, dim3 grid, hipStream_t s
 }
 
 // lanes + work decomposition of a forward-role launch (also what dl3p_dwconv2d_fwd reports as partial rows)
-static int plan_forward(DwParams& p, int KS, int tw5 = 0) {
+static int plan_forward(DwParams& p, int KS, int tw5) {
   p.ks = KS;
   p.ks5 = KS == 5;
   static const int dwf_per_cu = getenv("DL3P_DWF_PER_CU") ? atoi(getenv("DL3P_DWF_PER_CU")) : 8;
@@ -1312,7 +1373,7 @@ static int plan_forward(DwParams& p, int KS, int tw5 = 0) {
 template <int KS>
 static void launch_fwd(const DwParams& p0, hipStream_t st) {
   DwParams p = p0;
-  const int kind = plan_forward(p, KS);
+  const int kind = plan_forward(p, KS, 0);
   // streaming stores for forward outputs (bit 0 window kernels, bit 1 gather): -0.09 ms per step, and the rate-18
   // lattice kernel (always streaming) keeps its input in L2: 9.6 -> 8.8 us in-step
   static const int nt_mask = getenv("DL3P_DW_NT") ? atoi(getenv("DL3P_DW_NT")) : 3;
@@ -1322,6 +1383,45 @@ static void launch_fwd(const DwParams& p0, hipStream_t st) {
   if (pro == 2) launch_fwd_pro<KS, 2>(p, kind, grid, st);
   else if (pro == 1) launch_fwd_pro<KS, 1>(p, kind, grid, st);
   else launch_fwd_pro<KS, 0>(p, kind, grid, st);
+}
+
+// ---- an input whose first channels are a bilinear upsampling formed on the fly (DwParams::up_x)
+static thread_local DwParams t_dw_up = {};
+extern "C" int dl3p_dw_upsampled_input(const float* up_x, int up_ld, int up_h, int up_w, int up_C, void* stream) {
+  (void)stream;          // (every entry of a launch list ends in the stream)
+  DL3P_CHECK_ARG(up_x && aligned16(up_x) && up_ld % 4 == 0 && up_C > 0 && up_C % 4 == 0 && up_ld >= up_C && up_h > 0 && up_w > 0,
+                 "dl3p_dw_upsampled_input: bad arguments");
+  t_dw_up.up_x = up_x; t_dw_up.up_ld = up_ld; t_dw_up.up_h = up_h; t_dw_up.up_w = up_w; t_dw_up.up_C = up_C;
+  return DL3P_OK;
+}
+static int plan_forward(DwParams& p, int KS, int tw5);
+static int dwconv2d_bwd_weight_impl(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act, const float* dy,
+                                    int lddy, float* gw, float* workspace, size_t workspace_bytes, int N, int H, int W, int C, int k,
+                                    int stride, int rate, int pad_t, int pad_l, int Ho, int Wo, int* rows_out, void* stream,
+                                    const DwParams* fold, int* kind_out);
+// role 0: dl3p_dwconv2d_fwd, 1: dl3p_dwconv2d_bwd_weight_slabs[_bn] -- is the launch one of the 3x3 stride-1 window kernels that carry
+// the UP form (the caller's prologue must be a BatchNorm affine + activation)?
+extern "C" int dl3p_dw_upsampled_input_supported(int role, int N, int H, int W, int C, int up_C, int k, int stride, int rate, int pad_t,
+                                                 int pad_l, int Ho, int Wo) {
+  if (k != 3 || stride != 1 || rate != 1 || C <= 0 || C % 4 || up_C <= 0 || up_C % 4 || up_C > C || N <= 0 || H <= 0 || W <= 0) return 0;
+  DwParams p = {};
+  p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.rate = rate; p.pad_t = pad_t; p.pad_l = pad_l;
+  if (role == 0) {
+    pick_lanes(C, &p.c4s, &p.px, &p.nslab);
+    return plan_forward(p, 3, 0) == 1;
+  }
+  int kind = -1;
+  alignas(16) static float dummy[4];
+  const int rc = dwconv2d_bwd_weight_impl(dummy, C, nullptr, nullptr, DL3P_ACT_NONE, dummy, C, dummy, dummy, (size_t)-1, N, H, W, C, k,
+                                          stride, rate, pad_t, pad_l, Ho, Wo, nullptr, nullptr, nullptr, &kind);
+  return rc == DL3P_OK && kind == 1;
+}
+// (consumes the armed description: it applies to ONE call)
+static bool dw_take_up(DwParams& p) {
+  if (!t_dw_up.up_x) return false;
+  p.up_x = t_dw_up.up_x; p.up_ld = t_dw_up.up_ld; p.up_h = t_dw_up.up_h; p.up_w = t_dw_up.up_w; p.up_C = t_dw_up.up_C;
+  t_dw_up.up_x = nullptr;
+  return true;
 }
 
 extern "C" int dl3p_dwconv2d_fwd(const float* x, int ldx, const float* in_scale, const float* in_shift, int in_act,
@@ -1339,10 +1439,13 @@ extern "C" int dl3p_dwconv2d_fwd(const float* x, int ldx, const float* in_scale,
   p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.rate = rate;
   p.pad_t = pad_t; p.pad_l = pad_l;
   pick_lanes(C, &p.c4s, &p.px, &p.nslab);
+  const bool up = dw_take_up(p);
   {
     DwParams q = p;
-    plan_forward(q, k);
+    const int kind = plan_forward(q, k, 0);
     if (rows_out) *rows_out = q.nbx;
+    DL3P_CHECK_ARG(!up || (k == 3 && stride == 1 && rate == 1 && kind == 1 && in_scale && in_act != DL3P_ACT_NONE && p.up_C <= C),
+                   "dl3p_dwconv2d_fwd: the upsampled-input form serves 3x3 stride-1 window launches behind a BatchNorm + activation (dl3p_dw_upsampled_input_supported)");
   }
   hipStream_t st = (hipStream_t)stream;
   if (k == 3) launch_fwd<3>(p, st); else launch_fwd<5>(p, st);
@@ -1423,7 +1526,7 @@ extern "C" int dl3p_dwconv2d_bwd_data_bn(const float* dy, int lddy, const float*
     p.H = Ho; p.W = Wo; p.Ho = H; p.Wo = W; p.stride = 1; p.rate = rate;
     p.pad_t = rate * (k - 1) - pad_t; p.pad_l = rate * (k - 1) - pad_l;
     p.act = DL3P_ACT_NONE;
-    const int kind = plan_forward(p, k);
+    const int kind = plan_forward(p, k, 0);
     if (kind == 1) {
       if (p.tw == 2) dl3p_launch(dw_fwd_seg<3, 2, 1, 0, true>, dim3(p.nbx * p.nslab), dim3(256), 0, st, p);
       else dl3p_launch(dw_fwd_seg<3, 4, 1, 0, true>, dim3(p.nbx * p.nslab), dim3(256), 0, st, p);
@@ -1453,6 +1556,13 @@ extern "C" int dl3p_dwconv2d_bwd_data_bn(const float* dy, int lddy, const float*
 template <int PRO>
 static void launch_bwdw_bna(const DwParams& p, int kind, dim3 grid, hipStream_t st) {
   dim3 block(256);
+  if (p.up_x) {
+    if constexpr (PRO == 2) {
+      if (p.tw == 2) hipLaunchKernelGGL((dw_bwd_weight_seg<3, 2, 1, 2, true, true>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((dw_bwd_weight_seg<3, 4, 1, 2, true, true>), grid, block, 0, st, p);
+    }
+    return;
+  }
   if (kind == 1 && p.tw == 2) hipLaunchKernelGGL((dw_bwd_weight_seg<3, 2, 1, PRO, true>), grid, block, 0, st, p);
   else if (kind == 1) hipLaunchKernelGGL((dw_bwd_weight_seg<3, 4, 1, PRO, true>), grid, block, 0, st, p);
   else hipLaunchKernelGGL((dw_bwd_weight_seg<3, 2, 2, PRO, true>), grid, block, 0, st, p);
@@ -1463,6 +1573,13 @@ static void launch_bwdw(const DwParams& p, int kind, dim3 grid, hipStream_t st) 
   dim3 block(256);
   if (KS == 5) {     // 25 tap accumulators + a 5-row window do not fit the register file: per-pixel gather only
     hipLaunchKernelGGL((dw_bwd_weight<5, PRO>), grid, block, 0, st, p);
+    return;
+  }
+  if (p.up_x) {
+    if constexpr (PRO == 2) {
+      if (p.tw == 2) hipLaunchKernelGGL((dw_bwd_weight_seg<3, 2, 1, 2, false, true>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((dw_bwd_weight_seg<3, 4, 1, 2, false, true>), grid, block, 0, st, p);
+    }
     return;
   }
   if (kind == 1 && p.tw == 2) hipLaunchKernelGGL((dw_bwd_weight_seg<3, 2, 1, PRO>), grid, block, 0, st, p);
@@ -1482,7 +1599,7 @@ static int dwconv2d_bwd_weight_impl(const float* x, int ldx, const float* in_sca
                                     int in_act, const float* dy, int lddy, float* gw, float* workspace,
                                     size_t workspace_bytes, int N, int H, int W, int C, int k, int stride,
                                     int rate, int pad_t, int pad_l, int Ho, int Wo, int* rows_out, void* stream,
-                                    const DwParams* fold = nullptr, int* kind_out = nullptr) {
+                                    const DwParams* fold, int* kind_out) {
   int rc = check_dw_common("dl3p_dwconv2d_bwd_weight", x, ldx, C, k);
   if (rc) return rc;
   DL3P_CHECK_ARG(x && dy && (gw || rows_out) && workspace, "dl3p_dwconv2d_bwd_weight: null pointer");
@@ -1509,6 +1626,9 @@ static int dwconv2d_bwd_weight_impl(const float* x, int ldx, const float* in_sca
   if (kind_out) { *kind_out = kind; return DL3P_OK; }      // plan query (dl3p_dwconv2d_bwd_weight_bn_supported)
   dim3 grid(p.nbx * p.nslab);
   const int pro = (in_act != DL3P_ACT_NONE) ? 2 : (in_scale ? 1 : 0);
+  if (dw_take_up(p))
+    DL3P_CHECK_ARG(k == 3 && stride == 1 && rate == 1 && kind == 1 && pro == 2 && p.up_C <= C,
+                   "dl3p_dwconv2d_bwd_weight: the upsampled-input form serves 3x3 stride-1 window launches behind a BatchNorm + activation");
   if (fold) {
     DL3P_CHECK_ARG(k == 3 && (kind == 1 || kind == 2), "dl3p_dwconv2d_bwd_weight_slabs_bn: geometry not served by the window kernels");
     p.fa_z = fold->fa_z; p.fa_ldz = fold->fa_ldz; p.fa_scale = fold->fa_scale; p.fa_shift = fold->fa_shift;
@@ -1541,7 +1661,7 @@ extern "C" int dl3p_dwconv2d_bwd_weight(const float* x, int ldx, const float* in
                                         size_t workspace_bytes, int N, int H, int W, int C, int k, int stride,
                                         int rate, int pad_t, int pad_l, int Ho, int Wo, void* stream) {
   return dwconv2d_bwd_weight_impl(x, ldx, in_scale, in_shift, in_act, dy, lddy, gw, workspace, workspace_bytes, N, H, W, C, k,
-                                  stride, rate, pad_t, pad_l, Ho, Wo, nullptr, stream);
+                                  stride, rate, pad_t, pad_l, Ho, Wo, nullptr, stream, nullptr, nullptr);
 }
 
 // dl3p_dwconv2d_bwd_weight_slabs with the BatchNorm-backward apply of the conv's own output folded in (the depthwise
@@ -1571,7 +1691,7 @@ extern "C" int dl3p_dwconv2d_bwd_weight_slabs_bn(const float* x, int ldx, const 
   f.fa_z = z; f.fa_ldz = ldz; f.fa_scale = bn_scale; f.fa_shift = bn_shift; f.fa_mean = save_mean; f.fa_invstd = save_invstd;
   f.fa_coef = coef; f.fa_act = bn_act; f.fa_dz = dz; f.fa_lddz = lddz;
   return dwconv2d_bwd_weight_impl(x, ldx, in_scale, in_shift, in_act, g, ldg, nullptr, workspace, workspace_bytes, N, H, W, C, k,
-                                  stride, rate, pad_t, pad_l, Ho, Wo, rows_out, stream, &f);
+                                  stride, rate, pad_t, pad_l, Ho, Wo, rows_out, stream, &f, nullptr);
 }
 
 extern "C" int dl3p_dwconv2d_bwd_weight_slabs(const float* x, int ldx, const float* in_scale, const float* in_shift,
@@ -1580,7 +1700,7 @@ extern "C" int dl3p_dwconv2d_bwd_weight_slabs(const float* x, int ldx, const flo
                                               int stride, int rate, int pad_t, int pad_l, int Ho, int Wo, void* stream) {
   DL3P_CHECK_ARG(rows_out != nullptr, "dl3p_dwconv2d_bwd_weight_slabs: rows_out is required");
   return dwconv2d_bwd_weight_impl(x, ldx, in_scale, in_shift, in_act, dy, lddy, nullptr, workspace, workspace_bytes, N, H, W, C,
-                                  k, stride, rate, pad_t, pad_l, Ho, Wo, rows_out, stream);
+                                  k, stride, rate, pad_t, pad_l, Ho, Wo, rows_out, stream, nullptr, nullptr);
 }
 
 #include "dw_bf16_window.h"
@@ -1687,14 +1807,14 @@ extern "C" int dl3p_dw_plan_query(int role, int N, int H, int W, int C, int k, i
   if (role == 0) {
     p.x = dummy; p.ldx = C; p.y = dummy; p.ldy = C;
     p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.rate = rate; p.pad_t = pad_t; p.pad_l = pad_l;
-    kind = plan_forward(p, k);
+    kind = plan_forward(p, k, 0);
   } else if (role == 1 || role == 2) {
     if (role == 2) p.bb_z = dummy;
     if (stride == 1 && (role == 1 || k == 3)) {
       p.x = dummy; p.ldx = C; p.y = dummy; p.ldy = C; p.flip = 1;
       p.H = Ho; p.W = Wo; p.Ho = H; p.Wo = W; p.stride = 1; p.rate = rate;
       p.pad_t = rate * (k - 1) - pad_t; p.pad_l = rate * (k - 1) - pad_l;
-      kind = plan_forward(p, k);
+      kind = plan_forward(p, k, 0);
     } else {
       out6[0] = 4;          // stride-2 quads / strided gather of the data gradient: no row bands, no table
       return DL3P_OK;

@@ -424,6 +424,7 @@ class Executor:
         self._pinned = {k: self.L.get_option(k) for k in (b'conv_sb', b'sb_rs', b'sb_pipe', b'splitk', b'sb3')}
         self._pinned_irb = tuple(self.L.irb_get_plan(i) for i in range(4))
         self._find_irb()
+        self._find_up()
         self._alloc()
         # tracing runs every kernel once on zero inputs: keep the weights / optimiser state intact
         snap_p, snap_v, snap_step, snap_ostep = store.P.clone(), store.V.clone(), store.step.clone(), store.opt_step.clone()
@@ -622,6 +623,50 @@ class Executor:
             rec = (e, b, d)
             self._irb_expand[e], self._irb_bn[b], self._irb_dw[d] = rec, rec, rec
             self._irb_tensors.add(e.out.id)
+
+    def _find_up(self):
+        """Decoder_block (layers.py:207-215): img_resize -> Concatenate([x, skip]) -> 3x3 depthwise conv.  Where the resized tensor's
+        only reader is that conv, the resize launch goes and the conv's forward and weight gradient form those channels from the
+        low-resolution map while they load (dl3p_dw_upsampled_input: the resize kernel's arithmetic, bit for bit) -- 272 MB less
+        written and 2 x 272 MB less read per step at BASELINE configs[1].  self._up_conv: conv_dw op -> the resize op it absorbs"""
+        self._up_conv, self._up_resize = {}, set()
+        # OPT-IN (DL3P_FOLD_RESIZE=1): built, bit-identical, and measured SLOWER on MI355X -- 12.62 against 12.02 ms per headline step
+        # (profiles/r06_resize_fold.txt): the fused forward takes 468 us against 140 + 80 for the pair it replaces.  Four dependent
+        # 16-byte loads and three lerps per input vector turn an HBM-bound window kernel (2 waves per SIMD at 217-256 registers) into
+        # a latency-bound one: the compiler serialises the conditional gathers (57 s_waitcnt vmcnt(0) in the loop against 9)
+        if self.bf16 or os.environ.get('DL3P_FOLD_RESIZE', '0') != '1':
+            return
+        g, N, L = self.g, self.N, self.L
+        for r in g.ops:
+            if r.kind != 'resize' or r.out.base is None or r.out.c0 != 0:
+                continue
+            root = r.out.base
+            readers = [o for o in g.ops for slot in ('x', 'r', 's') if getattr(o, slot, None) is not None
+                       and getattr(o, slot).tensor.root is root and o is not r]
+            # (the other slices of the buffer are WRITTEN by their producers -- `out`, not a read -- and read through the root)
+            if len(readers) != 1 or readers[0].kind != 'conv_dw':
+                continue
+            d = readers[0]
+            if d.x.tensor is not root or d.x.group is None or d.x.act == ACT_NONE or d.k != 3 or d.stride != 1 or d.rate != 1:
+                continue
+            xl = r.x.tensor
+            if xl.base is not None or r.x.group is not None or xl.C != r.out.C or xl.ld % 4 or root.ld % 4:
+                continue
+            geo = (N, root.H, root.W, d.c, r.out.C, d.k, d.stride, d.rate, d.pad_t, d.pad_l, d.Ho, d.Wo)
+            if not L.dw_upsampled_input_supported(0, *geo):
+                continue
+            if self.training and d.layer.trainable and not L.dw_upsampled_input_supported(1, *geo):
+                continue
+            self._up_conv[d] = r
+            self._up_resize.add(r)
+
+    def _up_args(self, d):
+        """the arguments of dl3p_dw_upsampled_input for a conv that absorbed its resize (None otherwise)"""
+        r = self._up_conv.get(d)
+        if r is None:
+            return None
+        xl = r.x.tensor
+        return (self.tptr(xl), xl.ld, xl.H, xl.W, xl.C)
 
     def _irb_geo(self, rec):
         e, b, d = rec
@@ -829,6 +874,8 @@ class Executor:
                         self.tptr(op.out), op.out.ld, part, ctypes.byref(rows), N * op.Ho * op.Wo, op.cin, op.cout,
                         tag='pw:' + op.name)
                 elif k == 'conv_dw':
+                    if self._up_args(op) is not None:
+                        P.k(L.dw_upsampled_input, *self._up_args(op))
                     P.k(L.dwconv2d_fwd, xp, ldx, sp, hp, act, st.ptr(op.w), self.tptr(op.out), op.out.ld, part,
                         ctypes.byref(rows), N, xt.H, xt.W, op.c, op.k, op.stride, op.rate, op.pad_t, op.pad_l,
                         op.Ho, op.Wo, tag=op.name)
@@ -885,6 +932,8 @@ class Executor:
                 P.k(L.scale_bcast_fwd_bf16 if self.bf16 else L.scale_bcast_fwd, xp, ldx, sp, hp, act, s_ptr, lds, sact,
                     self.tptr(t), t.ld, N, t.H * t.W, t.C)
             elif k in ('resize', 'broadcast'):
+                if op in self._up_resize:
+                    continue                # (formed inside the depthwise conv that reads it: _find_up)
                 xt, t = op.x.tensor, op.out
                 P.k(L.resize_bilinear_fwd_bf16 if self.bf16 else L.resize_bilinear_fwd, self.tptr(xt), xt.ld, self.tptr(t),
                     t.ld, N, xt.H, xt.W, xt.C, t.H, t.W)
@@ -1127,14 +1176,17 @@ class Executor:
                     slab_need += (self._slab_bytes(op) + 255) // 256 * 256
             self.slab_ws = torch.zeros(slab_need // 4 + 64, **self.f32) if slab_need else None
 
-        def wgrad_slabs(fn, n, dst, nbytes, *args):
-            """fn(*args[:split], region, bytes, &rows, *args[split:]) with args given as (before, after)"""
+        def wgrad_slabs(fn, n, dst, nbytes, *args, up=None):
+            """fn(*args[:split], region, bytes, &rows, *args[split:]) with args given as (before, after); up: the arguments of the
+            dl3p_dw_upsampled_input call that describes this launch's input (a conv that absorbed its resize)"""
             before, after = args
             region = self.slab_ws.data_ptr() + 4 * slab_off[0]
             slab_off[0] += ((nbytes + 255) // 256 * 256) // 4
 
             def issue(P2):
                 rows = ctypes.c_int(0)
+                if up is not None:
+                    P2.k(L.dw_upsampled_input, *up)
                 P2.k(fn, *before, region, nbytes, ctypes.byref(rows), *after)
                 self._jobs.append((region, dst, rows.value, n))
             if defer:
@@ -1232,10 +1284,12 @@ class Executor:
                         dz, lddz = (self.dz_scratch.data_ptr(), op.c) if need_gx else (None, 0)
                         wgrad_slabs(L.dwconv2d_bwd_weight_slabs_bn, op.k * op.k * op.c, gw, nb,
                                     (xp, ldx, sp, hp, act, fg, fldg, fz, fldz, fsp, fhp, fact, fmean, finv, fcoef, dz, lddz),
-                                    (N, xt.H, xt.W, op.c, op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo))
+                                    (N, xt.H, xt.W, op.c, op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo),
+                                    up=self._up_args(op))
                     elif k == 'conv_dw':
                         wgrad_slabs(L.dwconv2d_bwd_weight_slabs, op.k * op.k * op.c, gw, nb, (xp, ldx, sp, hp, act, dz, lddz),
-                                    (N, xt.H, xt.W, op.c, op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo))
+                                    (N, xt.H, xt.W, op.c, op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo),
+                                    up=self._up_args(op))
                     elif self._stem_direct(op) and out.id in self._folded:
                         # the stem has no data gradient: dz = BatchNorm-backward apply of (g, z) is formed in the weight gradient's
                         # staging pass and never written
@@ -1256,6 +1310,8 @@ class Executor:
                         wgrad(L.pwconv_bwd_weight, xp, ldx, sp, hp, act, dz, lddz, gw, st.ptr(op.b, G) if op.b else None,
                               ws, wsb, N * op.Ho * op.Wo, op.cin, op.cout)
                     elif k == 'conv_dw':
+                        if self._up_args(op) is not None:
+                            wgrad(L.dw_upsampled_input, *self._up_args(op))
                         wgrad(L.dwconv2d_bwd_weight, xp, ldx, sp, hp, act, dz, lddz, gw, ws, wsb, N, xt.H, xt.W, op.c,
                               op.k, op.stride, op.rate, op.pad_t, op.pad_l, op.Ho, op.Wo)
                     elif self._stem_direct(op):

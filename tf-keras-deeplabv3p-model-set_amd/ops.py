@@ -64,9 +64,17 @@ def new_partials(C, device, rows=MAX_STAT_ROWS):
 
 
 # ------------------------------------------------------------------------------------- depthwise
+def _arm_upsampled(up):
+    """up (N,h,w,C1): the NEXT depthwise launch forms channels [0, C1) of its input from it (dl3p_dw_upsampled_input)"""
+    if up is not None:
+        upp, upld = _pl(up)
+        lib().dw_upsampled_input(upp, upld, up.shape[1], up.shape[2], up.shape[3], _stream())
+
+
 def dwconv2d_fwd(x, w, stride=1, rate=1, padding='same', in_scale=None, in_shift=None, in_act=ACT_NONE,
-                 out=None, partials=None):
+                 out=None, partials=None, upsampled=None):
     """x (N,H,W,C); w (k,k,C) or (k,k,C,1) -> y (N,Ho,Wo,C) [, rows]"""
+    _arm_upsampled(upsampled)
     N, H, W, C = x.shape
     k = w.shape[0]
     Ho, Wo, pt, pl = conv_geometry(H, W, k, stride, rate, padding)
@@ -109,7 +117,8 @@ def dwconv2d_bwd_data_bn(dy, w, x_shape, z, scale, shift, act, mean, invstd, par
 
 
 def dwconv2d_bwd_weight(x, dy, k, stride=1, rate=1, padding='same', in_scale=None, in_shift=None, in_act=ACT_NONE,
-                        workspace=None):
+                        workspace=None, upsampled=None):
+    _arm_upsampled(upsampled)
     N, H, W, C = x.shape
     Ho, Wo, pt, pl = conv_geometry(H, W, k, stride, rate, padding)
     need = lib().dwconv2d_bwd_weight_workspace(N, Ho, Wo, C, k)
@@ -123,9 +132,10 @@ def dwconv2d_bwd_weight(x, dy, k, stride=1, rate=1, padding='same', in_scale=Non
 
 
 def dwconv2d_bwd_weight_bn(x, g, z, bn, act, k, stride=1, rate=1, padding='same', in_scale=None, in_shift=None,
-                           in_act=ACT_NONE, want_dz=True):
+                           in_act=ACT_NONE, want_dz=True, upsampled=None):
     """depthwise weight gradient with the BatchNorm-backward apply of the conv's output folded in
     (dl3p_dwconv2d_bwd_weight_slabs_bn + the slab reduction) -> (gw, dz)"""
+    _arm_upsampled(upsampled)
     N, H, W, C = x.shape
     Ho, Wo, pt, pl = conv_geometry(H, W, k, stride, rate, padding)
     need = lib().dwconv2d_bwd_weight_workspace(N, Ho, Wo, C, k)
