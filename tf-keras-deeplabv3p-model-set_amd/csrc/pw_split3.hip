@@ -349,9 +349,15 @@ int dl3p_sb3_grid(int M) {
 bool dl3p_launch_gemm_sb3(GemmParams p, bool stats, int grid, hipStream_t st) {
   p.num_m_tiles = ceil_div(p.M, S3_BM);
   const bool pro = p.scale != nullptr;
+#ifdef S3_ONLY_ONE
+  // (tests/test_isa_gaps.py compiles ONE instantiation to assembly and counts what sits between its MFMAs)
+  if (p.act == DL3P_ACT_RELU && pro) { launch_sb3_act<DL3P_ACT_RELU, true>(p, stats, grid, st); return true; }
+  return false;
+#else
 #define S3_CASE(A) \
   if (p.act == A) { if (pro) launch_sb3_act<A, true>(p, stats, grid, st); else launch_sb3_act<A, false>(p, stats, grid, st); return true; }
   S3_CASE(DL3P_ACT_NONE) S3_CASE(DL3P_ACT_RELU) S3_CASE(DL3P_ACT_RELU6)
 #undef S3_CASE
   return false;
+#endif
 }
