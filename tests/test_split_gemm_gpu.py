@@ -610,3 +610,65 @@ def test_pinned_schedule_forward_is_the_default_on_the_long_decoder_layers_only(
         assert float((y.double() - y64).abs().max()) < 2e-5 * float(y64.abs().max())
     finally:
         L.set_option(b'pw_small_min_rows', 64)
+
+
+@pytest.mark.parametrize('act_name,front_act', [('relu', 'relu'), ('relu6', 'relu6'), ('none', 'relu')])
+@pytest.mark.parametrize('M', [16 * 129 * 129, 70001, 300])
+def test_pinned_schedule_data_gradient_with_the_folded_apply(ops, M, act_name, front_act):
+    """dl3p_pwconv_bwd_data_sb_apply on pw_gemm_sb3d_kernel (256 output columns over a reduction of 256, no accumulation): dz, gx and the
+    fused BatchNorm-backward sums of the layer in front against float64 at the row-stationary kernel's tolerances, dz in place of g
+    and in its own buffer bit for bit, operands inside wider buffers, rows past M untouched -- and dz equal to the row-stationary
+    kernel's bit for bit (the same arithmetic)"""
+    K = N = 256
+    A = {'relu6': ops.ACT_RELU6, 'relu': ops.ACT_RELU, 'none': ops.ACT_NONE}
+    act, fact = A[act_name], A[front_act]
+    L = ops.lib()
+    L.set_option(b'sb3', 1)
+    try:
+        g_ = torch.Generator(device=DEV); g_.manual_seed(M + 11)
+        rnd = lambda *s: torch.randn(*s, device=DEV, generator=g_)
+        gbuf = rnd(M, N + 16); g = gbuf[:, :N]                  # operands with their own pitches
+        zbuf = rnd(M, N + 32) * 1.5 + 0.3; z_out = zbuf[:, 8:8 + N]
+        bsc, bsh = torch.rand(N, device=DEV, generator=g_) + 0.5, rnd(N) * 0.5 + (1.0 if act == ops.ACT_RELU6 else 0.0)
+        mu, istd = rnd(N) * 0.2, torch.rand(N, device=DEV, generator=g_) + 0.5
+        coef = torch.stack([torch.rand(N, device=DEV, generator=g_) + 0.5, rnd(N) * 0.1, rnd(N) * 0.1]).contiguous()
+        w = (rnd(K, N) / N ** 0.5).contiguous()
+        w_sp = ops.split_bf16x3(w)
+        u = z_out.double() * bsc.double() + bsh.double()
+        m = {'relu6': ((u > 0) & (u < 6)).double(), 'relu': (u > 0).double(), 'none': torch.ones_like(u)}[act_name]
+        dz64 = coef[0].double() * (g.double() * m - coef[1].double() - (z_out.double() - mu.double()) * istd.double() * coef[2].double())
+        gx64 = dz64 @ w.double().t()
+        z = rnd(M, K)
+        sc, sh = torch.rand(K, device=DEV, generator=g_) + 0.5, rnd(K) * 0.3 + (1.0 if fact == ops.ACT_RELU6 else 0.0)
+        mean, invstd = z.mean(0), 1.0 / torch.sqrt(z.var(0, unbiased=False) + 1e-3)
+        # separate dz buffer, with the sums
+        dzb = torch.full((M + 3, N + 8), 5.0, device=DEV)
+        gxb = torch.full((M + 3, K + 4), 7.0, device=DEV)
+        part = ops.new_partials(K, DEV)
+        dz, gx, rows = ops.pwconv_bwd_data_sb_apply(g, z_out, bsc, bsh, act, mu, istd, coef, w_sp, N, dz=dzb[:M, :N], out=gxb[:M, :K],
+                                                    z=z, scale=sc, shift=sh, act=fact, mean=mean, invstd=invstd, partials=part)
+        assert rows == min(256, -(-M // 128)), rows            # (one partial row per workgroup: the pinned form took the launch)
+        assert float((dz.double() - dz64).abs().max()) < 4e-6 * float(dz64.abs().max()), 'dz'
+        assert float((gx.double() - gx64).abs().max()) < 2e-5 * float(gx64.abs().max()), 'gx'
+        assert float((dzb[M:] - 5.0).abs().max()) == 0 and float((dzb[:, N:] - 5.0).abs().max()) == 0, 'dz wrote outside its rows / columns'
+        assert float((gxb[M:] - 7.0).abs().max()) == 0 and float((gxb[:, K:] - 7.0).abs().max()) == 0, 'gx wrote outside its rows / columns'
+        uu = z.double() * sc.double() + sh.double()
+        fm = {'relu6': ((uu > 0) & (uu < 6)).double(), 'relu': (uu > 0).double(), 'none': torch.ones_like(uu)}[front_act]
+        d = gx64 * fm
+        xh = (z.double() - mean.double()) * invstd.double()
+        p = part[:rows * 2 * K].reshape(rows, 2, K).double().sum(0)
+        assert float((p[0] - d.sum(0)).abs().max()) < 2e-4 * float(d.abs().sum(0).max()), 'BN backward sum'
+        assert float((p[1] - (d * xh).sum(0)).abs().max()) < 2e-4 * float((d * xh).abs().sum(0).max()), 'BN backward sum * xhat'
+        # in place of g, no sums: the same bits
+        g2 = gbuf.clone()
+        dz2, gx2 = ops.pwconv_bwd_data_sb_apply(g2[:, :N], z_out, bsc, bsh, act, mu, istd, coef, w_sp, N)
+        assert dz2.data_ptr() == g2.data_ptr() and torch.equal(dz2, dz) and torch.equal(gx2, gx)
+        assert torch.equal(g2[:, N:], gbuf[:, N:])
+        # the row-stationary kernel on the same launch (where it serves it): dz bit for bit, gx to rounding
+        if L.pwconv_bwd_data_sb_apply_supported(M, K, N, act, 0):
+            L.set_option(b'sb3', 0)
+            dz3, gx3 = ops.pwconv_bwd_data_sb_apply(g, z_out, bsc, bsh, act, mu, istd, coef, w_sp, N, dz=torch.empty(M, N, device=DEV))
+            assert torch.equal(dz3, dz)
+            assert float((gx3.double() - gx.double()).abs().max()) < 2e-5 * float(gx64.abs().max())
+    finally:
+        L.set_option(b'sb3', -1)

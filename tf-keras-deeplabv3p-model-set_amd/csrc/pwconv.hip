@@ -1230,6 +1230,7 @@ void dl3p_launch_gemm_sbp(const GemmParams& p, bool stats, bool bnb, int nt, int
 bool dl3p_sb3_supported(int role, int M, int K, int N, int pitch, int act, bool has_scale, bool accumulate, bool bias);
 int dl3p_sb3_grid(int M);
 bool dl3p_launch_gemm_sb3(GemmParams p, bool stats, int grid, hipStream_t st);
+bool dl3p_launch_gemm_sb3d(GemmParams p, bool bnb, int grid, hipStream_t st);
 static thread_local int t_sb3_veto = 0;        // set while a launch whose prologue / epilogue the form does not serve is planned again
 static bool sb3_route(int role, int M, int K, int N) {
   if (g_sb3 < 0) { static const int env = getenv("DL3P_SB3") ? atoi(getenv("DL3P_SB3")) : -1; if (env >= 0) g_sb3 = env; }
@@ -1423,10 +1424,24 @@ extern "C" int dl3p_pwconv_bwd_data_sb(const float* dy, int lddy, const void* ws
 }
 
 bool dl3p_sb_rs_fold_supported(int M, int K, int N, int act);
+bool dl3p_sb3d_supported(int M, int kout, int nred, int pitch, int f_act, int bb_act, bool bnb, bool accumulate);
+static bool sb3d_takes(int M, int K, int N, int pitch, int bn_act, int front_act, bool bnb, bool accumulate) {
+  if (g_sb3 < 0) { static const int env = getenv("DL3P_SB3") ? atoi(getenv("DL3P_SB3")) : -1; if (env >= 0) g_sb3 = env; }
+  // OPT-IN by rule (DL3P_SB3_DGRAD=1; dl3p_set_option("sb3", 1) takes it wherever it is supported): measured on MI355X the pinned form
+  // is 7-12 % faster than the row-stationary kernel without the fused sums (263-300 against 281-340 us on 262144-266256 rows) and
+  // level with it with them (346-396 against 343-426), and the headline step does not move (11.87 ms either way): this launch moves
+  // 1.09-1.36 GB (g, z, dz, gx and the front layer's z) -- 240-300 us at the 4.5-5 TB/s such kernels reach -- so it is bound by HBM,
+  // not by the matrix pipe (scripts/micro/sb3d_bench.py)
+  static const int sb3d = getenv("DL3P_SB3_DGRAD") ? atoi(getenv("DL3P_SB3_DGRAD")) : 0;
+  if (g_sb3 == 0 || !dl3p_sb3d_supported(M, K, N, pitch, bn_act, front_act, bnb, accumulate)) return false;
+  return g_sb3 == 1 || (sb3d && M >= 65536);
+}
 extern "C" int dl3p_pwconv_bwd_data_sb_apply_supported(int M, int K, int N, int bn_act, int with_sums) {
-  // (M, K, N) as dl3p_pwconv_bwd_data_sb: K output columns, N the reduction = channels of the folded BatchNorm
+  // (M, K, N) as dl3p_pwconv_bwd_data_sb: K output columns, N the reduction = channels of the folded BatchNorm.  Two kernels serve
+  // it: the pinned-schedule form (256 x 256, no accumulation: the call falls back where the caller accumulates) and the
+  // row-stationary one
+  if (sb3d_takes(M, K, N, (N + 31) / 32 * 32, bn_act, DL3P_ACT_RELU, with_sums != 0, false) && M >= 131072) return 1;
   if (M < 131072 || !dl3p_sb_rs_fold_supported(M, N, K, bn_act)) return 0;
-  (void)with_sums;
   return 1;
 }
 
@@ -1454,7 +1469,8 @@ extern "C" int dl3p_pwconv_bwd_data_sb_apply(const float* g, int ldg, const floa
     if (rc) return rc;
     DL3P_CHECK_ARG(scale && shift && save_mean && save_invstd && partials && rows_out, "%s: bad BatchNorm arguments", fn);
   }
-  DL3P_CHECK_ARG(dl3p_pwconv_bwd_data_sb_apply_supported(M, K, N, bn_act, bnb), "%s: shape M=%d K=%d N=%d act %d is not served", fn, M, K, N, bn_act);
+  const bool take3 = sb3d_takes(M, K, N, pitch, bn_act, act, bnb, accumulate != 0);
+  DL3P_CHECK_ARG(take3 || dl3p_pwconv_bwd_data_sb_apply_supported(M, K, N, bn_act, bnb), "%s: shape M=%d K=%d N=%d act %d is not served", fn, M, K, N, bn_act);
   int ldm = ldg > ldgx ? ldg : ldgx;
   if (ldz > ldm) ldm = ldz;
   if (ldz_out > ldm) ldm = ldz_out;
@@ -1470,6 +1486,15 @@ extern "C" int dl3p_pwconv_bwd_data_sb_apply(const float* g, int ldg, const floa
   if (bnb) {
     p.partials = partials;
     p.bb_z = z; p.bb_ldz = ldz; p.bb_scale = scale; p.bb_shift = shift; p.bb_mean = save_mean; p.bb_invstd = save_invstd; p.bb_act = act;
+  }
+  // the pinned-schedule form (pw_split3.hip) where it serves the launch: 256 output columns over a reduction of 256,
+  // no accumulation; dl3p_set_option("sb3", 0) / DL3P_SB3_DGRAD=0 keep the row-stationary kernel
+  if (take3) {
+    const int g3 = dl3p_sb3_grid(M);
+    if (rows_out) *rows_out = g3;
+    DL3P_CHECK_ARG(dl3p_launch_gemm_sb3d(p, bnb, g3, (hipStream_t)stream), "%s: no pinned-schedule instantiation for activation %d", fn, bn_act);
+    DL3P_CHECK_LAUNCH(fn);
+    return DL3P_OK;
   }
   p.num_m_tiles = ceil_div(M, 64);
   const int gxn = dl3p_sb_rs_grid(M);
