@@ -84,3 +84,24 @@ def test_batched_wgrad_off_at_a_fused_shape_keeps_the_unfused_blocks(monkeypatch
     assert 'dl3p_irb_fwd' in on[3] and 'dl3p_irb_bwd_data' in on[3]
     assert not any(c.startswith('dl3p_irb_') for c in off[3])
     _same_step(on, off, 3e-2, 0.35)
+
+
+@pytest.mark.parametrize('model_type,N', [('mobilenetv2', 5), ('xception', 5)])
+def test_pinned_schedule_forward_is_taken_at_its_row_threshold_and_the_step_stays(model_type, N, monkeypatch):
+    """round 6 (csrc/pw_split3.hip): at 513 x 513 from batch 4 up the decoder's 129 x 129 maps cross 65536 rows and the 256-column
+    forwards that the measured table does not know run on the pinned-schedule kernel -- the step is the tiled kernels' step to the
+    bound of two summation orders (the kernels agree to 2e-5 per element: tests/test_split_gemm_gpu.py)"""
+    import ctypes
+    pkg = load_pkg()
+    L = load_pkg('ops').lib()
+    q = (ctypes.c_int * 6)()
+    L.set_option(b'pw_small_min_rows', -1)
+    try:
+        L.gemm_plan_query(6, N * 129 * 129, 304, 256, q)
+        assert q[0] == 3 and q[3] == 4, list(q)
+        on = _step(model_type, 513, 513, 21, N, monkeypatch, {}, options={b'pw_small_min_rows': -1})
+        off = _step(model_type, 513, 513, 21, N, monkeypatch, {}, options={b'pw_small_min_rows': -1, b'sb3': 0})
+    finally:
+        L.set_option(b'pw_small_min_rows', 64)
+        L.set_option(b'sb3', -1)
+    _same_step(on, off, 3e-2, 0.35)
