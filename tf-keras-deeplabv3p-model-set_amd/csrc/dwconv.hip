@@ -29,6 +29,7 @@ struct DwParams {
   long long total;
   int flip, accumulate;
   int nt;              // streaming stores for the output (forward role only)
+  int fast_rows;       // dw_fwd_seg: interior strips on the counted-wait rows (DL3P_DW_FAST_ROWS, default 1)
   int tw;              // strip width the plan was made for (3x3 window kernels)
   int lat;             // residue-lattice kernels (kind 3): pixels per class and dimension, 2 or 3
   int bf16_io;         // x / w / y / dy are bf16 (the mixed-precision entry at the end of this file; window kernels only)
@@ -203,10 +204,22 @@ __global__ __launch_bounds__(256) void dw_fwd_seg(DwParams p) {
           }
         }
       }
-      for (int v = v0; v < v1; ++v) {
+      // rows of the band that exist on this sub-lattice
+      const int vmax = (p.Ho - py + rate - 1) / rate;
+      const int vend = v1 < vmax ? v1 : vmax;
+      // FAST rows (interior strips of a plain launch: every output column of the strip exists, nothing is accumulated): the loads
+      // of the entering rows are UNCONDITIONAL (row / column clamped into the image; what is outside is zeroed after the prologue,
+      // as always) and so are the stores, and the band's last row (which loads nothing) is a separate copy of the body -- the
+      // compiler can then count: the wait for the entering rows becomes vmcnt(TW), the row's stores stay in flight.  With any
+      // of them under an `if` it waits vmcnt(0) at the top of every row: vmcnt retires in order, so each row also waited for the
+      // round trip of the stores of the row before (csrc/resize_head.hip, resize_fwd_seg_kernel, has the measurement).
+      int coffc[SEG];
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) coffc[i] = min(max(ix0 + i * rate, 0), p.W - 1) * p.ldx;
+      auto row = [&](int v, auto fast_c, auto load_c) __attribute__((always_inline)) {
+        constexpr bool FAST = decltype(fast_c)::value, LOAD = decltype(load_c)::value;
         const int oy = py + v * rate;
-        if (oy >= p.Ho) break;
-        const bool more = v + 1 < v1 && oy + rate < p.Ho;
+        const bool more = LOAD;
         float4 zv[TW];
         if (BNB) {      // z at this row's output pixels: in flight during the FMAs below
           const float* zrow = p.bb_z + (((size_t)n * p.Ho + oy) * p.Wo + ox0) * p.bb_ldz + c;
@@ -219,13 +232,24 @@ __global__ __launch_bounds__(256) void dw_fwd_seg(DwParams p) {
         for (int q = 0; q < S; ++q) {
           const int iy = (oy + rate) * S - p.pad_t + (KS - S + q) * rate;
           nyok[q] = more && iy >= 0 && iy < p.H;
-          const float* xrow = ximg + (size_t)iy * p.W * p.ldx;
+          if (FAST) {
+            if (LOAD) {
+              const float* xrow = ximg + (size_t)min(max(iy, 0), p.H - 1) * p.W * p.ldx;
 #pragma unroll
-          for (int i = 0; i < SEG; ++i) {
-            raw[q][i] = zero4();
-            if (nyok[q] && cok[i]) raw[q][i] = (UP && upl) ? dw_up_load(uimg, p.up_w, p.up_ld, dw_lerp(iy, usy, p.up_h), lxs[UP ? i : 0]) : ld4(xrow + coff[i]);
+              for (int i = 0; i < SEG; ++i) raw[q][i] = ld4(xrow + coffc[i]);
+            }
+          } else {
+            const float* xrow = ximg + (size_t)iy * p.W * p.ldx;
+#pragma unroll
+            for (int i = 0; i < SEG; ++i) {
+              raw[q][i] = zero4();
+              if (nyok[q] && cok[i]) raw[q][i] = (UP && upl) ? dw_up_load(uimg, p.up_w, p.up_ld, dw_lerp(iy, usy, p.up_h), lxs[UP ? i : 0]) : ld4(xrow + coff[i]);
+            }
           }
         }
+        // FAST: the loads stay in front of the row's FMAs (without the branches of the general path around them the scheduler sinks
+        // them next to their use, behind the FMAs)
+        if (FAST) __builtin_amdgcn_sched_barrier(0);
         float4 acc[TW];
 #pragma unroll
         for (int i = 0; i < TW; ++i) acc[i] = zero4();
@@ -242,11 +266,14 @@ __global__ __launch_bounds__(256) void dw_fwd_seg(DwParams p) {
         float* yrow = p.y + (((size_t)n * p.Ho + oy) * p.Wo + ox0) * p.ldy + c;
 #pragma unroll
         for (int tw = 0; tw < TW; ++tw) {
-          if (ox0 + tw * rate < p.Wo) {
+          if (FAST || ox0 + tw * rate < p.Wo) {
             float4 vv = acc[tw];
             float* yp = yrow + (size_t)tw * rate * p.ldy;
-            if (p.accumulate) vv = add4(vv, ld4(yp));
-            if (p.nt) st4_nt(yp, vv); else st4(yp, vv);
+            if (!FAST && p.accumulate) vv = add4(vv, ld4(yp));
+            // (FAST: the kind of store is known at compile time -- forward launches stream, data gradients do not -- so that the
+            // stores of a row can be counted)
+            if (FAST) { if (PRO != 0) st4_nt(yp, vv); else st4(yp, vv); }
+            else if (p.nt) st4_nt(yp, vv); else st4(yp, vv);
             if (BNB) {
               bnb_accumulate(s1, vv, zv[tw], bsc, bsh, bmu, bis, p.bb_act);
             } else {
@@ -255,6 +282,8 @@ __global__ __launch_bounds__(256) void dw_fwd_seg(DwParams p) {
             }
           }
         }
+        if (!LOAD) return;
+        if (FAST) __builtin_amdgcn_sched_barrier(0);       // ... and their consumption behind the row's stores
         // slide the window down by S rows
 #pragma unroll
         for (int ky = 0; ky + S < KS; ++ky)
@@ -264,9 +293,22 @@ __global__ __launch_bounds__(256) void dw_fwd_seg(DwParams p) {
         for (int q = 0; q < S; ++q)
 #pragma unroll
           for (int i = 0; i < SEG; ++i) {
-            const float4 a = prologue4<PRO>(raw[q][i], sc, sh, act);
+            float4 a = prologue4<PRO>(raw[q][i], sc, sh, act);
+            // FAST: the prologue runs whether or not the pixel is inside the image (left to itself the compiler branches around
+            // it, the wait for raw[q][i] lands inside the branch, and the top of the next row waits vmcnt(0) again)
+            if (FAST) asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));
             win[KS - S + q][i] = (nyok[q] && cok[i]) ? a : zero4();
           }
+      };
+      // (compiled into the forward instantiations only: the rule never sends a data gradient here)
+      constexpr bool HAS_FAST = PRO != 0 && !BNB && !UP;
+      const bool fast = HAS_FAST && !p.accumulate && p.fast_rows && p.nt && ox0 + (TW - 1) * rate < p.Wo;
+      if (HAS_FAST && fast) {
+        for (int v = v0; v + 1 < vend; ++v) row(v, std::true_type{}, std::true_type{});
+        if (vend > v0) row(vend - 1, std::true_type{}, std::false_type{});
+      } else {
+        for (int v = v0; v + 1 < vend; ++v) row(v, std::false_type{}, std::true_type{});
+        if (vend > v0) row(vend - 1, std::false_type{}, std::false_type{});
       }
     }
   }
@@ -1378,6 +1420,13 @@ static void launch_fwd(const DwParams& p0, hipStream_t st) {
   // lattice kernel (always streaming) keeps its input in L2: 9.6 -> 8.8 us in-step
   static const int nt_mask = getenv("DL3P_DW_NT") ? atoi(getenv("DL3P_DW_NT")) : 3;
   p.nt = (p.flip == 0 && !p.accumulate) ? ((kind == 0 ? (nt_mask >> 1) : nt_mask) & 1) : 0;
+  // counted-wait rows (dw_fwd_seg FAST): measured on MI355X they pay where the row's stores are slow to retire -- the STREAMING stores
+  // of forward launches on tensors far beyond the caches (decoder_conv0 / conv1_depthwise at batch 16: 142.9 -> 137.5, 127.4 -> 108.0 us)
+  // -- and lose 10-15 % on cache-sized tensors and on every data gradient (plain stores retire at L2 anyway).  DL3P_DW_FAST_ROWS:
+  // 0 never, 1 that rule (default), 2 every launch that can
+  static const int fast_rows = getenv("DL3P_DW_FAST_ROWS") ? atoi(getenv("DL3P_DW_FAST_ROWS")) : 1;
+  const long long out_bytes = (long long)p.N * p.Ho * p.Wo * p.C * 4;
+  p.fast_rows = fast_rows >= 2 || (fast_rows == 1 && p.nt && out_bytes >= (200ll << 20));
   dim3 grid(p.nbx * p.nslab);
   const int pro = (p.act != DL3P_ACT_NONE) ? 2 : (p.scale ? 1 : 0);
   if (pro == 2) launch_fwd_pro<KS, 2>(p, kind, grid, st);

@@ -63,51 +63,67 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(ResizeParams p) {
   }
 }
 
-// Upsampling (W >= 2 w): a pixel lane walks a STRIP of consecutive output columns of one row and keeps the two input columns it is
-// between in registers -- at 33 -> 129 the pair changes every ~3.9 outputs and the new low column is the old high one, so a strip of
-// 8 outputs issues ~6 loads where the pixel-at-a-time kernel issues 32 (its 4x gather amplification is 1.1 GB of L2 reads for the
-// 272 MB decoder_resize writes: 90.8 us = 3 TB/s of stores).  Same arithmetic per output, same bits.
-#define RS_STRIP 8
-__global__ __launch_bounds__(256) void resize_fwd_strip_kernel(ResizeParams p) {
-  const int b = blockIdx.x;
-  const int slab = b / p.nbx;
-  const int bx = b - slab * p.nbx;
-  const int pl = threadIdx.x / p.c4s;
-  const int cl = threadIdx.x - pl * p.c4s;
-  if (pl >= p.px) return;
-  const int c = (slab * p.c4s + cl) * 4;
+// Upsampling with 256-channel slabs (decoder_resize: 33 x 33 -> 129 x 129 x 256, layers.py:207): one WAVE per (output row, segment of SEG
+// output columns, 256-channel slab), a lane per float4 of the slab.  What bounds the pixel-at-a-time kernel above is not its ~150 vector
+// instructions per stored float4 and not its four gathers per output (1.1 GB of L2 reads for 272 MB of stores) but that every store
+// is followed by loads the next output waits for: vmcnt retires in order, so each wave has ONE 1 KB store in flight per memory round
+// trip -- 3.5 TB/s at batch 16 (82.7 us) where a fill kernel writes 7 TB/s.  Three rewrites that kept a load between stores (a strip
+// walker, the same with the next strip's loads hoisted, a wave-per-row kernel with the column pair cached) all landed on 3.5-3.6 TB/s.
+// Here a segment's loads all come first: the at most six input columns (SEG = 16 above 3.9x, 8 from 2x up) of both input rows go
+// through a wave-private LDS tile, and the SEG outputs are then formed from LDS reads only -- SEG stores in flight per wave.
+// Column coefficients: lane j computes lerp_coeff of column ox0 + j, the unrolled loop reads them back with v_readlane.
+// Same arithmetic per output, same bits.
+#define RS_NCOL 6
+template <int SEG>
+__global__ __launch_bounds__(256) void resize_fwd_seg_kernel(ResizeParams p) {
+  extern __shared__ __attribute__((aligned(16))) float rs_lds[];          // [4 waves][2 rows][RS_NCOL][256 floats]
   const float sy = (float)p.h / (float)p.H, sx = (float)p.w / (float)p.W;
-  const int spr = (p.W + RS_STRIP - 1) / RS_STRIP;          // strips per output row
-  XcdRange r = xcd_range(p.total, bx, p.nbx, p.px, pl);     // p.total = N * H * spr strips
-  for (int s = r.begin; s < r.end; s += r.step) {
-    const int st = s % spr;
-    const int row = s / spr;
-    const int oy = row % p.H;
-    const int n = row / p.H;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wave = blockIdx.x * 4 + wv;
+  const int nwaves = gridDim.x * 4;
+  float* tile = rs_lds + (size_t)wv * 2 * RS_NCOL * 256 + lane * 4;
+  const int nseg = (p.W + SEG - 1) / SEG, nslab = p.C / 256;
+  const int items = p.N * p.H * nslab * nseg;          // (the host rejects >= 2^31)
+  for (int item = wave; item < items; item += nwaves) {
+    const int seg = item % nseg;
+    int rr = item / nseg;
+    const int slab = rr % nslab; rr /= nslab;
+    const int oy = rr % p.H, n = rr / p.H;
     const Lerp ly = lerp_coeff(oy, sy, p.h);
-    const float* top = p.x + ((size_t)n * p.h + ly.lo) * p.w * p.ldx + c;
-    const float* bot = p.x + ((size_t)n * p.h + ly.hi) * p.w * p.ldx + c;
+    const int c = slab * 256 + lane * 4;
+    const int ox0 = seg * SEG;
+    const Lerp mine = lerp_coeff(min(ox0 + (lane & (SEG - 1)), p.W - 1), sx, p.w);      // lane j < SEG: column ox0 + j
+    const int base = __builtin_amdgcn_readlane(mine.lo, 0);
+    const float* top = p.x + (((size_t)n * p.h + ly.lo) * p.w) * p.ldx + c;
+    const float* bot = p.x + (((size_t)n * p.h + ly.hi) * p.w) * p.ldx + c;
+    float4 vt[RS_NCOL], vb[RS_NCOL];
+#pragma unroll
+    for (int k = 0; k < RS_NCOL; ++k) {
+      const size_t col = (size_t)min(base + k, p.w - 1) * p.ldx;
+      vt[k] = ld4(top + col);
+      vb[k] = ld4(bot + col);
+    }
+    __builtin_amdgcn_sched_barrier(0);          // all twelve loads in flight together (left alone the compiler pairs each with its LDS store)
+#pragma unroll
+    for (int k = 0; k < RS_NCOL; ++k) {
+      st4(tile + k * 256, vt[k]);
+      st4(tile + (RS_NCOL + k) * 256, vb[k]);
+    }
+    // (wave-private tile: the LDS writes above and the reads below are ordered by lgkmcnt within the wave; no barrier)
     float* yrow = p.y + (((size_t)n * p.H + oy) * p.W) * p.ldy + c;
-    const int ox0 = st * RS_STRIP, ox1 = min(ox0 + RS_STRIP, p.W);
-    int cur_lo = -1, cur_hi = -1;
-    float4 tl = zero4(), tr = zero4(), bl = zero4(), br = zero4();
-    for (int ox = ox0; ox < ox1; ++ox) {
-      const Lerp lx = lerp_coeff(ox, sx, p.w);
-      if (lx.lo != cur_lo) {
-        if (lx.lo == cur_hi) { tl = tr; bl = br; }
-        else { tl = ld4(top + (size_t)lx.lo * p.ldx); bl = ld4(bot + (size_t)lx.lo * p.ldx); }
-        cur_lo = lx.lo;
-      }
-      if (lx.hi != cur_hi) {
-        if (lx.hi == cur_lo) { tr = tl; br = bl; }
-        else { tr = ld4(top + (size_t)lx.hi * p.ldx); br = ld4(bot + (size_t)lx.hi * p.ldx); }
-        cur_hi = lx.hi;
-      }
+#pragma unroll
+    for (int j = 0; j < SEG; ++j) {
+      const int lo = __builtin_amdgcn_readlane(mine.lo, j) - base, hi = __builtin_amdgcn_readlane(mine.hi, j) - base;
+      const float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.t), j));
+      const float4 tl = ld4(tile + lo * 256), tr = ld4(tile + hi * 256);
+      const float4 bl = ld4(tile + (RS_NCOL + lo) * 256), br = ld4(tile + (RS_NCOL + hi) * 256);
       float4 o;
-#define LERP2(f) { float tp = tl.f + (tr.f - tl.f) * lx.t; float bt = bl.f + (br.f - bl.f) * lx.t; o.f = tp + (bt - tp) * ly.t; }
+#define LERP2(f) { float tp = tl.f + (tr.f - tl.f) * t; float bt = bl.f + (br.f - bl.f) * t; o.f = tp + (bt - tp) * ly.t; }
       LERP2(x) LERP2(y) LERP2(z) LERP2(w)
 #undef LERP2
-      st4(yrow + (size_t)ox * p.ldy, o);
+      // a column past the row's end repeats the last pixel (same value, same address): the stores stay unconditional
+      st4(yrow + (size_t)min(ox0 + j, p.W - 1) * p.ldy, o);
     }
   }
 }
@@ -212,12 +228,19 @@ extern "C" int dl3p_resize_bilinear_fwd(const float* x, int ldx, float* y, int l
   p.x = x; p.ldx = ldx; p.y = y; p.ldy = ldy; p.N = N; p.h = h; p.w = w; p.C = C; p.H = H; p.W = W;
   pick_lanes(C, &p.c4s, &p.px, &p.nslab);
   static const int strip_ok = getenv("DL3P_RESIZE_STRIP") ? atoi(getenv("DL3P_RESIZE_STRIP")) : 1;      // (A/B switch)
-  if (strip_ok && W >= 2 * w && W >= 2 * RS_STRIP) {
-    p.total = (long long)N * H * ((W + RS_STRIP - 1) / RS_STRIP);
-    p.nbx = pick_nbx(p.total, p.px, p.nslab);
-    hipLaunchKernelGGL(resize_fwd_strip_kernel, dim3(p.nbx * p.nslab), dim3(256), 0, (hipStream_t)stream, p);
-    DL3P_CHECK_LAUNCH("dl3p_resize_bilinear_fwd");
-    return DL3P_OK;
+  if (strip_ok && W >= 2 * w && C % 256 == 0) {
+    // SEG outputs lie between at most RS_NCOL = 6 input columns: floor((SEG - 1) w / W) + 3 <= 6
+    const int seg = (15ll * w) / W <= 3 ? 16 : 8;
+    const long long items = (long long)N * H * (C / 256) * ((W + seg - 1) / seg);
+    if (items < (1ll << 31)) {
+      long long wgs = (items + 3) / 4;
+      if (wgs > DL3P_NUM_CUS * 3) wgs = DL3P_NUM_CUS * 3;          // 48 KB of LDS per workgroup: three per CU
+      const size_t lds = (size_t)4 * 2 * RS_NCOL * 256 * sizeof(float);
+      if (seg == 16) hipLaunchKernelGGL(resize_fwd_seg_kernel<16>, dim3((unsigned)wgs), dim3(256), lds, (hipStream_t)stream, p);
+      else hipLaunchKernelGGL(resize_fwd_seg_kernel<8>, dim3((unsigned)wgs), dim3(256), lds, (hipStream_t)stream, p);
+      DL3P_CHECK_LAUNCH("dl3p_resize_bilinear_fwd");
+      return DL3P_OK;
+    }
   }
   p.total = (long long)N * H * W;
   p.nbx = pick_nbx(p.total, p.px, p.nslab);
