@@ -28,3 +28,10 @@ for (N, h, w, C, H, W, ld) in [(16, 33, 33, 256, 129, 129, 304), (4, 33, 33, 256
     t = timeit(lambda: ops.resize_bilinear_fwd(x, H, W, out=y))
     mb = N * H * W * C * 4 / 1e6
     print('%d x %dx%d -> %dx%d x %d (ld %d): %6.1f us  %.2f TB/s of stores' % (N, h, w, H, W, C, ld, t, mb / t), flush=True)
+
+for (N, h, w, C, H, W, ld) in [(16, 33, 33, 256, 129, 129, 304), (4, 33, 33, 256, 129, 129, 304), (2, 97, 97, 256, 193, 193, 304)]:
+    buf = torch.randn(N, H, W, ld, device='cuda')
+    g = buf[..., :C]
+    gx = torch.empty(N, h, w, C, device='cuda')
+    t = timeit(lambda: ops.resize_bilinear_bwd(g, h, w, out=gx))
+    print('bwd %d x %dx%d <- %dx%d x %d (ld %d): %6.1f us' % (N, h, w, H, W, C, ld, t), flush=True)

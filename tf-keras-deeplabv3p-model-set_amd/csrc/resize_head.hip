@@ -138,6 +138,7 @@ __host__ __device__ __forceinline__ void touch_range(int i, float inv_scale, int
 }
 
 #define RB_MAXW 12
+#define RB_TIGHT 8
 __global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeParams p) {
   const int b = blockIdx.x;
   const int slab = b / p.nbx;
@@ -164,7 +165,45 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeParams p) {
     if (ix == p.w - 1) x1 = p.W - 1;
     float4 acc = zero4();
     const float* gimg = p.x + (size_t)n * p.H * p.W * p.ldx + c;
-    if (x1 - x0 < RB_MAXW) {
+    // the output columns that read input column ix lie in an open interval 2 / sx wide: at most RB_TIGHT of them when 2 / sx < RB_TIGHT
+    // (33 -> 129: 7.8).  touch_range() is widened for rounding, so the first column with a non-zero weight is found by looking at up
+    // to four candidates; every row then costs RB_TIGHT loads instead of RB_MAXW (the skipped terms were exact zeros)
+    bool tight = 2.f * isx < (float)RB_TIGHT && x1 - x0 < RB_MAXW;
+    int xs = x0;
+    if (tight) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const Lerp lx = lerp_coeff(min(xs, p.W - 1), sx, p.w);
+        if (xs < x1 && lx.lo != ix && lx.hi != ix) ++xs;
+      }
+      const Lerp lend = lerp_coeff(min(xs + RB_TIGHT, p.W - 1), sx, p.w);
+      if (xs + RB_TIGHT <= x1 && (lend.lo == ix || lend.hi == ix)) tight = false;      // (never at these scales: the general path is right anyway)
+    }
+    if (tight) {
+      float wxs[RB_TIGHT];
+#pragma unroll
+      for (int j = 0; j < RB_TIGHT; ++j) {
+        const int ox = min(xs + j, p.W - 1);
+        const Lerp lx = lerp_coeff(ox, sx, p.w);
+        const float wx = (lx.lo == ix ? 1.f - lx.t : 0.f) + (lx.hi == ix ? lx.t : 0.f);
+        wxs[j] = (xs + j <= x1) ? wx : 0.f;
+      }
+      for (int oy = y0; oy <= y1; ++oy) {
+        const Lerp ly = lerp_coeff(oy, sy, p.h);
+        const float wy = (ly.lo == iy ? 1.f - ly.t : 0.f) + (ly.hi == iy ? ly.t : 0.f);
+        if (wy == 0.f) continue;
+        const float* grow = gimg + (size_t)oy * p.W * p.ldx;
+        float4 g[RB_TIGHT];
+#pragma unroll
+        for (int j = 0; j < RB_TIGHT; ++j) g[j] = ld4(grow + (size_t)min(xs + j, x1) * p.ldx);
+#pragma unroll
+        for (int j = 0; j < RB_TIGHT; ++j) {
+          const float wgt = wy * wxs[j];
+          acc.x = fmaf(g[j].x, wgt, acc.x); acc.y = fmaf(g[j].y, wgt, acc.y);
+          acc.z = fmaf(g[j].z, wgt, acc.z); acc.w = fmaf(g[j].w, wgt, acc.w);
+        }
+      }
+    } else if (x1 - x0 < RB_MAXW) {
       // column weights once per pixel (not once per row): the window is at most RB_MAXW wide for scales <= ~4
       float wxs[RB_MAXW];
 #pragma unroll
