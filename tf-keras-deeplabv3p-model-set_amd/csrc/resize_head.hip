@@ -31,6 +31,7 @@ struct ResizeParams {
   int c4s, px, nslab, nbx;
   long long total;
   int accumulate;
+  int tight;           // resize_bwd_kernel: the eight-column window where it applies (DL3P_RESIZE_TIGHT, default 1)
 };
 
 __global__ __launch_bounds__(256) void resize_fwd_kernel(ResizeParams p) {
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(ResizeParams p) {
     // the output columns that read input column ix lie in an open interval 2 / sx wide: at most RB_TIGHT of them when 2 / sx < RB_TIGHT
     // (33 -> 129: 7.8).  touch_range() is widened for rounding, so the first column with a non-zero weight is found by looking at up
     // to four candidates; every row then costs RB_TIGHT loads instead of RB_MAXW (the skipped terms were exact zeros)
-    bool tight = 2.f * isx < (float)RB_TIGHT && x1 - x0 < RB_MAXW;
+    bool tight = p.tight && 2.f * isx < (float)RB_TIGHT && x1 - x0 < RB_MAXW;
     int xs = x0;
     if (tight) {
 #pragma unroll
@@ -295,6 +296,8 @@ extern "C" int dl3p_resize_bilinear_bwd(const float* gy, int ldgy, float* gx, in
   ResizeParams p = {};
   p.x = gy; p.ldx = ldgy; p.y = gx; p.ldy = ldgx; p.N = N; p.h = h; p.w = w; p.C = C; p.H = H; p.W = W;
   p.accumulate = accumulate;
+  static const int tight = getenv("DL3P_RESIZE_TIGHT") ? atoi(getenv("DL3P_RESIZE_TIGHT")) : 1;      // (A/B switch)
+  p.tight = tight;
   pick_lanes(C, &p.c4s, &p.px, &p.nslab);
   p.total = (long long)N * h * w;
   p.nbx = pick_nbx(p.total, p.px, p.nslab);
