@@ -556,6 +556,9 @@ __global__ __launch_bounds__(256, 2) void pw_small_kernel(GemmParams p) {
         if (p.bias) o = add4(o, ld4(p.bias + (yl[i] - yrow[i] * TP)));
         float* yp = reinterpret_cast<float*>(Yb + (ybase + yg[i]));
         if (p.accumulate) o = add4(o, ld4(yp));
+#ifdef DL3P_ABLATE_STORES
+        if (o.x == 1234.5678f)
+#endif
         st4(yp, o);
         if (STATS && BNB) {
           // (sum g', sum g' * xhat) of the BatchNorm behind this gradient, as dl3p_bn_bwd_reduce forms them

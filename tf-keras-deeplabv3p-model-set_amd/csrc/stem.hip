@@ -171,6 +171,9 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemParams p) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           const float4 o = make_float4(acc[g][ni][0], acc[g][ni][1], acc[g][ni][2], acc[g][ni][3]);
+#ifdef DL3P_ABLATE_STORES
+          if (o.x == 1234.5678f)
+#endif
           st4(p.y + (m0 + ox) * p.ldy + ni * 16 + 4 * kq, o);
           s1[ni] = add4(s1[ni], o);
           s2[ni] = fma4(o, o, s2[ni]);
