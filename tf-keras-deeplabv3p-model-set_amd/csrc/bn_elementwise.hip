@@ -876,8 +876,9 @@ static bool pool_ws_ok(const float* ws, size_t bytes, int N, int HW, int C) {
 
 // All 256 threads call.  Block-reduces the pixel lanes' partial sums into row `chunk` of the workspace, takes a
 // ticket, and lets the workgroup with the last ticket add the rows up.  The partial rows are written and read with
-// agent-scope atomic accesses (write-through / L2-bypassing on the 8-XCD part), so no __threadfence() is needed: a
-// full fence writes back the whole L2, which is ruinous next to a kernel that is streaming its output through it.
+// agent-scope atomic accesses (write-through / L2-bypassing on the 8-XCD part); ONE wave per workgroup issues the agent-scope
+// release / acquire pair around the ticket (a __threadfence() in every wave writes back the whole L2 four times over, which is
+// ruinous next to a kernel that is streaming its output through it).
 __device__ __forceinline__ void pool_finish(const float4& val, bool active, int pl, int cl, int px, float* ws,
                                             size_t ticket_floats, int n, int chunk, int slab, int nslab, int nchunk,
                                             int c4s, int cbase4, int C, float* out_row, float scale) {
@@ -895,11 +896,18 @@ __device__ __forceinline__ void pool_finish(const float4& val, bool active, int 
     __hip_atomic_store(r + 2, a.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(r + 3, a.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the stores above have completed ...
-  __syncthreads();                                            // ... for every lane before the ticket is drawn
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the stores above have left every lane ...
+  __syncthreads();                                            // ... before the ticket is drawn
   int* tickets = reinterpret_cast<int*>(ws);
-  if (threadIdx.x == 0)
+  if (threadIdx.x == 0) {
+    // AGENT-scope release in front of the ticket and acquire behind it (one wave of the workgroup: the barrier above makes it
+    // cumulative).  Round 6: with the workgroup-scope fence alone the ticket -- another address, another memory channel -- could
+    // overtake the write-through rows on their way out of this XCD, and the workgroup with the last ticket (on another XCD) summed a
+    // stale row: test_chunked_per_image_reductions failed once in ~15 suite runs with sums differing from call to call.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     last = __hip_atomic_fetch_add(&tickets[n * nslab + slab], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nchunk - 1;
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
   __syncthreads();
   if (!last) return;
   if ((int)threadIdx.x < c4s) {
