@@ -15,6 +15,17 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.fixture(autouse=True)
+def _release_cached_device_memory():
+    """most tests here start other processes on the SAME GPU (RCCL + a second copy of the model): hand the memory this process's
+    caching allocator is only holding on to back first -- late in the full suite that is most of the device"""
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    yield
+
+
 def test_forced_single_rank_dist_is_bit_identical():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'dist_check.py')], capture_output=True, text=True,
                        cwd=ROOT, timeout=900)

@@ -49,6 +49,9 @@ print('DIGESTS ' + json.dumps(out))
 
 
 def _run(env):
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()          # (the children run on the same GPU)
     e = dict(os.environ)
     e.update(env)
     r = subprocess.run([sys.executable, '-c', CHILD % {'root': ROOT}], env=e, capture_output=True, text=True, timeout=600)
