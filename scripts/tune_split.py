@@ -195,7 +195,9 @@ def measure_wgrad(M, K, N):
     res = {}
     L.set_option(b'split_wgrad_tile', -1); L.set_option(b'split_wgrad_per_cu', 0)
     # (a pinned tile / workgroups-per-CU bypasses the verdict tables: wgrad_sb_route in pwconv.hip)
-    for tile in range(4):
+    for tile in range(5):            # (4: the 128 x 256 tile, round 6 -- only wide layers: N >= 256)
+        if tile == 4 and N < 256:
+            continue
         for pc in (1, 2, 3, 4, 6):      # (1: half the slabs of the default -- the few-row layers with large K x N, Xception's middle flow)
             L.set_option(b'split_wgrad_tile', tile); L.set_option(b'split_wgrad_per_cu', pc)
             res[(tile, pc, 0)] = cost()

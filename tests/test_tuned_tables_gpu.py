@@ -310,9 +310,10 @@ def test_every_wgrad_tile_choice_is_correct(ops, tile, per_cu):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('per_cu', [1, 2, 3, 4, 6])
-@pytest.mark.parametrize('tile', [0, 1, 2, 3])
+@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4])
 def test_every_split_wgrad_tile_choice_is_correct(ops, tile, per_cu):
-    """pw_wgrad_sb_kernel: 128 x 128 (waves 2 x 2), 64 x 128, 128 x 64, 64 x 64 tiles x workgroups per CU, ragged M / K / N"""
+    """pw_wgrad_sb_kernel: 128 x 128 (waves 2 x 2), 64 x 128, 128 x 64, 64 x 64, 128 x 256 (round 6, dynamic LDS) tiles x workgroups
+    per CU, ragged M / K / N"""
     L = _lib()
     L.set_option(b'split_wgrad', 1)
     L.set_option(b'split_wgrad_tile', tile)

@@ -924,8 +924,10 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_sb_kernel(WgradSB p) {
   constexpr int XCPR = TK / 8, DCPR = TN / 8;         // 8-element chunks per tile row
   constexpr int XROWS = 256 / XCPR, DROWS = 256 / DCPR;   // rows staged per pass
   constexpr int NXP = MS / XROWS, NDP = MS / DROWS;
-  __shared__ __attribute__((aligned(16))) unsigned short Xs[3 * X_PLANE];
-  __shared__ __attribute__((aligned(16))) unsigned short Ds[3 * D_PLANE];
+  // (dynamic: the 128 x 256 tile's operand planes are 76.8 KB)
+  extern __shared__ __attribute__((aligned(16))) unsigned short wg_lds[];
+  unsigned short* Xs = wg_lds;
+  unsigned short* Ds = wg_lds + 3 * X_PLANE;
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int wk = w / WN, wn = w - wk * WN;
   const int tile = blockIdx.x, kt = tile / p.ntiles, nt = tile - kt * p.ntiles;
@@ -1084,9 +1086,9 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_sb_kernel(WgradSB p) {
 // served).  max_slabs: what the caller's workspace holds; tile < 0 / per_cu <= 0: the heuristics (measured: scripts/micro/sb_wgrad.py)
 int dl3p_wgrad_sb_plan(int M, int K, int N, int max_slabs, int tile, int per_cu, int* kf, int* nw, int* ktiles, int* ntiles, int* mrows) {
   if (M < 1024 || K < 32 || N < 32 || K % 4 || N % 4 || max_slabs < 1) return 0;
-  static const int cand[4][2] = {{2, 8}, {1, 8}, {2, 4}, {1, 4}};
+  static const int cand[5][2] = {{2, 8}, {1, 8}, {2, 4}, {1, 4}, {2, 16}};      // (128 x 256: by tile index 4 only, never by the cost rule)
   float best = 1e30f;
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < (tile == 4 ? 5 : 4); ++i) {
     const int tk = 64 * cand[i][0], tn = 16 * cand[i][1];
     const float area = (float)((K + tk - 1) / tk * tk) * (float)((N + tn - 1) / tn * tn);
     const float cost = area * (1.f + 0.5f * (64.f / tk + 64.f / tn));
@@ -1106,6 +1108,18 @@ int dl3p_wgrad_sb_plan(int M, int K, int N, int max_slabs, int tile, int per_cu,
   return (M + chunk - 1) / chunk;
 }
 
+template <int KF, int NW, int WN, bool GX>
+static void launch_wgrad_tile(const WgradSB& p, dim3 grid, hipStream_t st) {
+  constexpr size_t lds = (size_t)3 * 32 * ((64 * KF + 8) + (16 * NW + 8)) * sizeof(unsigned short);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)pw_wgrad_sb_kernel<KF, NW, WN, GX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dl3p_launch(pw_wgrad_sb_kernel<KF, NW, WN, GX>, grid, dim3(256), lds, st, p);
+}
+
 void dl3p_launch_wgrad_sb(const float* x, int ldx, const float* scale, const float* shift, int act, const float* dy, int lddy,
                           float* slabs, int M, int K, int N, int kf, int nw, int ktiles, int ntiles, int mrows, int splits, hipStream_t st) {
   WgradSB p = {x, ldx, scale, shift, act, dy, lddy, slabs, M, K, N, ktiles, ntiles, mrows, 0};
@@ -1121,16 +1135,17 @@ void dl3p_launch_wgrad_sb(const float* x, int ldx, const float* scale, const flo
     static const int mixed = getenv("DL3P_WGRAD_SB_MIXED") ? atoi(getenv("DL3P_WGRAD_SB_MIXED")) : 0;
     if (mixed && rem > 0 && rem <= 64 && ktiles > 1) {
       p.ktiles = ktiles - 1;
-      dl3p_launch(pw_wgrad_sb_kernel<2, 8, 2>, dim3(p.ktiles * ntiles, splits), block, 0, st, p);
+      launch_wgrad_tile<2, 8, 2, false>(p, dim3(p.ktiles * ntiles, splits), st);
       p.k_base = 128 * (ktiles - 1);
       p.ktiles = 1;
-      dl3p_launch(pw_wgrad_sb_kernel<1, 8, 1>, dim3(ntiles, splits), block, 0, st, p);
+      launch_wgrad_tile<1, 8, 1, false>(p, dim3(ntiles, splits), st);
       return;
     }
-    dl3p_launch(pw_wgrad_sb_kernel<2, 8, 2>, dim3(ktiles * ntiles, splits), block, 0, st, p);
-  } else if (kf == 1 && nw == 8) dl3p_launch(pw_wgrad_sb_kernel<1, 8, 1>, dim3(ktiles * ntiles, splits), block, 0, st, p);
-  else if (kf == 2 && nw == 4) dl3p_launch(pw_wgrad_sb_kernel<2, 4, 1>, dim3(ktiles * ntiles, splits), block, 0, st, p);
-  else dl3p_launch(pw_wgrad_sb_kernel<1, 4, 1>, dim3(ktiles * ntiles, splits), block, 0, st, p);
+    launch_wgrad_tile<2, 8, 2, false>(p, dim3(ktiles * ntiles, splits), st);
+  } else if (kf == 2 && nw == 16) launch_wgrad_tile<2, 16, 2, false>(p, dim3(ktiles * ntiles, splits), st);
+  else if (kf == 1 && nw == 8) launch_wgrad_tile<1, 8, 1, false>(p, dim3(ktiles * ntiles, splits), st);
+  else if (kf == 2 && nw == 4) launch_wgrad_tile<2, 4, 1, false>(p, dim3(ktiles * ntiles, splits), st);
+  else launch_wgrad_tile<1, 4, 1, false>(p, dim3(ktiles * ntiles, splits), st);
 }
 
 // the same tiles with the X operand gathered from a convolution's input tensor (dl3p_conv2d_gemm_bwd_weight*); geo = {RH, RW, SH, SW,
@@ -1142,9 +1157,9 @@ void dl3p_launch_wgrad_sb_gx(const float* x, int ldx, const float* scale, const 
   p.g_RH = geo[0]; p.g_RW = geo[1]; p.g_SH = geo[2]; p.g_SW = geo[3]; p.g_C = geo[4]; p.g_kw = geo[5]; p.g_mul = geo[6];
   p.g_ay = geo[7]; p.g_ax = geo[8]; p.g_d = geo[9];
   p.g_invRW = 1.f / (float)p.g_RW; p.g_invRH = 1.f / (float)p.g_RH;
-  const dim3 block(256), grid(ktiles * ntiles, splits);
-  if (kf == 2 && nw == 8) dl3p_launch(pw_wgrad_sb_kernel<2, 8, 2, true>, grid, block, 0, st, p);
-  else if (kf == 1 && nw == 8) dl3p_launch(pw_wgrad_sb_kernel<1, 8, 1, true>, grid, block, 0, st, p);
-  else if (kf == 2 && nw == 4) dl3p_launch(pw_wgrad_sb_kernel<2, 4, 1, true>, grid, block, 0, st, p);
-  else dl3p_launch(pw_wgrad_sb_kernel<1, 4, 1, true>, grid, block, 0, st, p);
+  const dim3 grid(ktiles * ntiles, splits);
+  if (kf == 2 && nw == 8) launch_wgrad_tile<2, 8, 2, true>(p, grid, st);
+  else if (kf == 1 && nw == 8) launch_wgrad_tile<1, 8, 1, true>(p, grid, st);
+  else if (kf == 2 && nw == 4) launch_wgrad_tile<2, 4, 1, true>(p, grid, st);
+  else launch_wgrad_tile<1, 4, 1, true>(p, grid, st);
 }

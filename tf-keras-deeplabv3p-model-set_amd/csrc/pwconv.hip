@@ -665,7 +665,7 @@ extern "C" int dl3p_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm_tuned")) { g_gemm_use_table = value ? 1 : 0; return DL3P_OK; }
   if (!strcmp(name, "sb_pipe")) { g_sb_pipe = value ? 1 : 0; return DL3P_OK; }
   if (!strcmp(name, "split_wgrad")) { g_split_wgrad = value ? 1 : 0; return DL3P_OK; }
-  if (!strcmp(name, "split_wgrad_tile")) { g_sbw_force_tile = (value >= 0 && value <= 3) ? value : -1; return DL3P_OK; }
+  if (!strcmp(name, "split_wgrad_tile")) { g_sbw_force_tile = (value >= 0 && value <= 4) ? value : -1; return DL3P_OK; }
   if (!strcmp(name, "split_wgrad_per_cu")) { g_sbw_force_pc = value > 0 ? value : 0; return DL3P_OK; }
   if (!strcmp(name, "splitk")) { g_splitk_force = value; return DL3P_OK; }
   if (!strcmp(name, "sb_wm")) { g_sb_force_wm = (value >= -1 && value <= 2) ? value : 0; return DL3P_OK; }    // -1: never wide
@@ -2413,7 +2413,8 @@ extern "C" int dl3p_conv2d_gemm_bwd_data_sb(const float* dy, int lddy, const voi
 static int conv_wgrad_sb_route(int M, int K, int N, size_t max_slabs, int* kf, int* nw, int* kt, int* nt, int* mrows) {
   if (!dl3p_conv2d_gemm_sb_pays(4, M, K, N)) return 0;
   if (max_slabs > (size_t)DL3P_MAX_STAT_ROWS) max_slabs = DL3P_MAX_STAT_ROWS;
-  return dl3p_wgrad_sb_plan(M, K, N, (int)max_slabs, g_sbw_force_tile, g_sbw_force_pc, kf, nw, kt, nt, mrows);
+  // (the gathered-operand instantiations stop at 128 x 128: a pinned 128 x 256 tile means 128 x 128 here)
+  return dl3p_wgrad_sb_plan(M, K, N, (int)max_slabs, g_sbw_force_tile == 4 ? 0 : g_sbw_force_tile, g_sbw_force_pc, kf, nw, kt, nt, mrows);
 }
 
 extern "C" size_t dl3p_conv2d_gemm_bwd_weight_workspace(int N, int Ho, int Wo, int Cin, int Cout, int k) {
@@ -2509,7 +2510,7 @@ extern "C" int dl3p_gemm_plan_query(int role, int M, int K, int N, int* out6) {
     int kf, nw, kt, nt, mrows;
     const int s = (dl3p_pw_tiny_applies(M) || (M >= 16 && wgrad_small_pick(K, N, &sh))) ? 0 : wgrad_sb_route(M, K, N, DL3P_MAX_STAT_ROWS, &kf, &nw, &kt, &nt, &mrows);
     if (s <= 0) { out6[0] = -1; return DL3P_OK; }
-    out6[0] = 4; out6[1] = (kf == 2 ? 0 : 1) + (nw == 8 ? 0 : 2); out6[2] = kf; out6[3] = s; out6[4] = kt * nt; out6[5] = gemm_tuned_lookup(9, M, K, N) != nullptr;
+    out6[0] = 4; out6[1] = nw == 16 ? 4 : (kf == 2 ? 0 : 1) + (nw == 8 ? 0 : 2); out6[2] = kf; out6[3] = s; out6[4] = kt * nt; out6[5] = gemm_tuned_lookup(9, M, K, N) != nullptr;
     return DL3P_OK;
   }
   if (role >= 5) {      // the split-bf16 twin of role - 5: {3, nt, mi, wm (0 = producer / consumer form), workgroups, from table}
