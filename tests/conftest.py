@@ -62,6 +62,12 @@ def pytest_sessionfinish(session, exitstatus):
     if not _durations or not any('_gpu.py' in n for _, n in _durations):
         return
     try:
+        import torch
+        if not torch.cuda.is_available():      # (a CPU run of a *_gpu.py file's unmarked tests is not the GPU suite)
+            return
+    except Exception:
+        return
+    try:
         d = os.path.join(ROOT, 'gpurun_out')
         os.makedirs(d, exist_ok=True)
         with open(os.path.join(d, 'gpu_suite_durations.txt'), 'w') as f:
